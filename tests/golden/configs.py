@@ -1,0 +1,35 @@
+"""Fixture configurations shared by make_golden.py (reference side) and the parity tests."""
+from types import SimpleNamespace
+
+CONFIGS = {
+    # small, fast: every test tier can afford it
+    "tiny_sep": dict(B=8, T=6, N=40, seed=1, critic="separate", cube="6-3-128=4-3-128", traj=3),
+    "tiny_cat": dict(B=8, T=6, N=40, seed=2, critic="concat", cube="6-3-128=4-3-128", traj=2),
+    # ragged a/v lengths (zero rows) -> packed-sequence semantics of Model.py:425-447
+    "tiny_ragged": dict(B=8, T=6, N=40, seed=3, critic="separate", cube="6-3-128=4-3-128", traj=1, ragged=True),
+    # ln_first CubeMLP variant + hardtanh CMI head + nwj bound (flag-reachable alternatives)
+    "tiny_alt": dict(B=8, T=6, N=40, seed=4, critic="concat", cube="6-3-128=4-3-128", traj=1,
+                     ln_first=True, cmi_last="hardtanh", bound="nwj"),
+    # BASELINE cfg1: B=32, T=50, canonical README flags, N=1000 as in the reference smoke test (Model.py:607)
+    "cfg1_sep": dict(B=32, T=50, N=1000, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=6),
+    "cfg1_cat": dict(B=32, T=50, N=1000, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
+}
+
+
+def parse_cube(s):
+    return [list(map(int, blk.split("-"))) for blk in s.split("=")]
+
+
+def make_opt(c):
+    """The subset of Parameters.py flags the hot path reads, README values."""
+    cube = parse_cube(c["cube"])
+    return SimpleNamespace(
+        batch_size=c["B"], d_common=128, encoders="gru", features_compose_t="mean", features_compose_k="mean",
+        num_class=1, activate="gelu", time_len=c["T"], d_hiddens=cube, d_outs=cube,
+        dropout_mlp=[0.0, 0.0, 0.0], dropout=[0.0, 0.0, 0.0, 0.0], bias=True, ln_first=c.get("ln_first", False),
+        res_project=[True] * len(cube), critic_type=c["critic"], baseline_type="constant",
+        bound_type=c.get("bound", "infonce"), loss_mi_coefficient1=[1.0] * 11, loss_mi_coefficient2=[0.01] * 8,
+        mi_lr_rate=1.0, cmi_lr_rate=1.0, k_neighbor=2, radius=1.0, cmi_last_acticate=c.get("cmi_last", "sigmoid"),
+        stage1_n=1, loss="MAE", gradient_clip=1.5, optm="Adam", learning_rate=4e-3, weight_decay=0.0,
+        dataset="mosi_Dec", parallel=True, text="none",
+    )
