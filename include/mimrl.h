@@ -1,0 +1,137 @@
+/* libmimrl_hip -- C ABI of the MI355X-native MIMRL two-stage training step.
+ *
+ * The reference (kiva12138/MIMRL) has no FFI: its boundary is the Python class surface
+ *   Solver.train loop bodies      Solver.py:204-216 (stage 1), :220-238 (stage 2)
+ *   Model.forward                 Model.py:388-519
+ *   Model.compute_vmi_loss_stage1 Model.py:305-341,  ..._stage2  Model.py:343-386
+ *   clip_grad_value_ + Adam.step  Solver.py:144-146,211-213,233-235
+ * This header is what a ctypes / pybind / cgo binding of that path binds to.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * MIMRL_ERR_* code (message via mimrl_last_error(), thread-local); nothing throws or aborts.  All device
+ * memory except the private workspace is owned by the caller (PyTorch-ROCm tensors on the Python side) and
+ * borrowed for the lifetime of the handle.  All work is enqueued on the stream given at create time;
+ * no call synchronises the host.  One handle per (process, GPU); calls on a handle are not re-entrant.
+ */
+#ifndef MIMRL_H_
+#define MIMRL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIMRL_ABI_VERSION 1
+#define MIMRL_MAX_BLOCKS 4
+
+enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -3, MIMRL_ERR_NODEVICE = -4 };
+enum { MIMRL_GROUP_MAIN = 0, MIMRL_GROUP_CRITIC = 1 };
+enum { MIMRL_CRITIC_SEPARATE = 0, MIMRL_CRITIC_CONCAT = 1 };                       /* VMI.py:35-45 */
+enum { MIMRL_BOUND_INFONCE = 0, MIMRL_BOUND_NWJ, MIMRL_BOUND_TUBA, MIMRL_BOUND_DV, MIMRL_BOUND_JS_FGAN,
+       MIMRL_BOUND_JS, MIMRL_BOUND_SMILE };                                        /* Model.py:121-146 */
+enum { MIMRL_ACT_NONE = 0, MIMRL_ACT_RELU = 1, MIMRL_ACT_GELU = 2, MIMRL_ACT_TANH = 3 };
+enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16 = 1 };  /* MFMA operand type; accumulation/state/optimizer are fp32 */
+
+/* Hot-path subset of Parameters.py:8-70 (same meaning as the flags of the same name). */
+typedef struct mimrl_cfg {
+  int32_t batch;                 /* --batch_size (rows per rank) */
+  int32_t seq_len;               /* T of the input triples, <= time_len */
+  int32_t time_len;              /* --time_len (L axis of CubeMLP) */
+  int32_t d_t, d_a, d_v;         /* 768 / 74 / 35 for MOSI-shaped data (Config.py:59-76) */
+  int32_t d_common;              /* --d_common; must be 128 (Model.py:285 hard-codes embed_dim) */
+  int32_t n_blocks;              /* len(--d_hiddens) */
+  int32_t d_hiddens[MIMRL_MAX_BLOCKS][3];
+  int32_t d_outs[MIMRL_MAX_BLOCKS][3];
+  int32_t res_project[MIMRL_MAX_BLOCKS];
+  int32_t bias, ln_first;
+  int32_t activation;            /* --activate */
+  int32_t compose_t_sum, compose_k_sum; /* --features_compose_t/k: 0 mean, 1 sum */
+  int32_t critic_type, bound_type;
+  int32_t cmi_hardtanh;          /* --cmi_last_acticate hardtanh */
+  int32_t k_neighbor;
+  int32_t bank_capacity;         /* max rows of the feature banks (dataset size) */
+  float dropout[4];              /* --dropout (t,a,v,classifier) */
+  float dropout_mlp[3];          /* --dropout_mlp (l,k,d) */
+  float coef1[11];               /* --loss_mi_coefficient1 */
+  float coef2[8];                /* --loss_mi_coefficient2 */
+  float weight_decay, grad_clip; /* --weight_decay, --gradient_clip */
+  float beta1, beta2, adam_eps;  /* torch.optim.Adam defaults 0.9 / 0.999 / 1e-8 */
+  int32_t precision;             /* MIMRL_PREC_* */
+  int32_t use_graph;             /* capture each stage into a hipGraph on first use */
+  uint64_t seed;                 /* dropout stream seed */
+} mimrl_cfg;
+
+/* Device pointers (fp32 unless noted).  Flat buckets follow the layout reported by mimrl_layout_entry. */
+typedef struct mimrl_buffers {
+  float *main_p, *main_g, *main_m, *main_v;       /* [mimrl_bucket_floats(MAIN)]   */
+  float *crit_p, *crit_g, *crit_m, *crit_v;       /* [mimrl_bucket_floats(CRITIC)] */
+  const float *text, *audio, *video, *labels;     /* [B,T,d_t] [B,T,d_a] [B,T,d_v] [B] */
+  const float *bank_c, *bank_f, *bank_t, *bank_a, *bank_v; /* [cap,1] [cap,128] x4 : previous epoch's stage-2 features */
+  const int32_t* anchors;                         /* [2][6][B/k] kNN anchor rows for stage 1 / stage 2 (Model.py:81) */
+  float *lr_main, *lr_critic;                     /* device scalars (schedulers rewrite them) */
+  float *pred;                                    /* [B] */
+  float *feats;                                   /* [4][B,128] = F_F, T_F, A_F, V_F */
+  float *scalars;                                 /* [MIMRL_NSCALARS] see MIMRL_S_* */
+} mimrl_buffers;
+
+/* indices into mimrl_buffers.scalars */
+enum {
+  MIMRL_S1_LOSS = 0,      /* stage-1 total loss                                   */
+  MIMRL_S1_MIS = 1,       /* 11 values: mi_f_t..mi_t_v, cmi_ac_t..cmi_tc_v         */
+  MIMRL_S1_LOSSES = 12,   /* 11 values: -mi x5, BCE x6                             */
+  MIMRL_S2_LOSS = 32,     /* stage-2 total loss                                   */
+  MIMRL_S2_TASK = 33,     /* MAE task loss                                        */
+  MIMRL_S2_MIS = 34,      /* 8 values: f_t f_a f_v inv spec_t spec_a spec_v comp   */
+  MIMRL_S2_LOSSES = 42,   /* 8 values                                             */
+  MIMRL_NSCALARS = 64
+};
+
+const char* mimrl_last_error(void);
+int mimrl_abi_version(void);
+int mimrl_device_check(void);   /* 0 iff a gfx950 device is usable by this process */
+
+/* ---- parameter layout (host only; callable without a GPU) ---- */
+int mimrl_layout_count(const mimrl_cfg* cfg);
+int mimrl_layout_entry(const mimrl_cfg* cfg, int idx, char* name, int name_cap, int* group, int64_t* offset, int* ndim,
+                       int* dim0, int* dim1);
+int64_t mimrl_bucket_floats(const mimrl_cfg* cfg, int group);
+
+/* ---- engine ---- */
+typedef struct mimrl_handle mimrl_handle;
+int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out);
+int mimrl_bind(mimrl_handle* h, const mimrl_buffers* bufs);
+int mimrl_set_bank_rows(mimrl_handle* h, int rows);    /* 0 => epoch-0 rule (Customization.py:97-98,105-106) */
+int mimrl_stage1_step(mimrl_handle* h);                /* Solver.py:205-214 : critics update               */
+int mimrl_stage2_step(mimrl_handle* h);                /* Solver.py:221-236 : main-model update            */
+int mimrl_stage_grads(mimrl_handle* h, int stage);     /* forward+backward only (data-parallel: all-reduce follows) */
+int mimrl_stage_apply(mimrl_handle* h, int stage);     /* value-clip + Adam on that stage's bucket         */
+int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses);  /* Solver.evaluate body (Solver.py:255-258) */
+int64_t mimrl_workspace_bytes(const mimrl_handle* h);
+void mimrl_destroy(mimrl_handle* h);
+
+/* ---- operator-level entry points (used by the parity tests; all asynchronous on `stream`) ---- */
+int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch,
+                  const int64_t strides[9] /* sa_m sa_k sa_b sb_k sb_n sb_b sc_m sc_n sc_b */, const float* bias_n,
+                  const float* bias_m, float alpha, float beta, int act, int precision);
+int64_t mimrl_op_gru_saved_floats(int B, int T);
+/* one bidirectional GRU layer (both directions): gx/w_hh/b_hh/saved per direction; out [B,T,256] */
+int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                         const float* bhh_f, const float* bhh_r, const int32_t* lens, float* out, float* saved_f,
+                         float* saved_r, int B, int T, int precision);
+int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, const float* saved_f,
+                          const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dgx_f,
+                          float* dgx_r, float* dgh_f, float* dgh_r, float* hprev_f, float* hprev_r, int B, int T,
+                          int precision);
+int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
+                      int bound);
+int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
+int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
+                      const float* g_cmi, int E, int n, int hardtanh);
+int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,
+                  float beta1, float beta2, float eps, float weight_decay, float clip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMRL_H_ */

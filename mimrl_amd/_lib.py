@@ -1,0 +1,181 @@
+"""ctypes binding of libmimrl_hip.so (include/mimrl.h).  There is NO fallback: if the HIP library is missing or
+no gfx950 device is visible, every compute entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmimrl_hip.so")
+MAX_BLOCKS = 4
+NSCALARS = 64
+S1_LOSS, S1_MIS, S1_LOSSES, S2_LOSS, S2_TASK, S2_MIS, S2_LOSSES = 0, 1, 12, 32, 33, 34, 42
+
+BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6}
+ACTS = {"none": 0, "relu": 1, "gelu": 2, "tanh": 3}
+PREC = {"fp32": 0, "bf16": 1}
+
+
+class MimrlError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("seq_len", C.c_int32), ("time_len", C.c_int32),
+        ("d_t", C.c_int32), ("d_a", C.c_int32), ("d_v", C.c_int32), ("d_common", C.c_int32),
+        ("n_blocks", C.c_int32),
+        ("d_hiddens", (C.c_int32 * 3) * MAX_BLOCKS), ("d_outs", (C.c_int32 * 3) * MAX_BLOCKS),
+        ("res_project", C.c_int32 * MAX_BLOCKS),
+        ("bias", C.c_int32), ("ln_first", C.c_int32), ("activation", C.c_int32),
+        ("compose_t_sum", C.c_int32), ("compose_k_sum", C.c_int32),
+        ("critic_type", C.c_int32), ("bound_type", C.c_int32), ("cmi_hardtanh", C.c_int32),
+        ("k_neighbor", C.c_int32), ("bank_capacity", C.c_int32),
+        ("dropout", C.c_float * 4), ("dropout_mlp", C.c_float * 3),
+        ("coef1", C.c_float * 11), ("coef2", C.c_float * 8),
+        ("weight_decay", C.c_float), ("grad_clip", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("precision", C.c_int32), ("use_graph", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+_FP = C.c_void_p
+
+
+class Buffers(C.Structure):
+    _fields_ = [(n, _FP) for n in (
+        "main_p", "main_g", "main_m", "main_v", "crit_p", "crit_g", "crit_m", "crit_v",
+        "text", "audio", "video", "labels", "bank_c", "bank_f", "bank_t", "bank_a", "bank_v",
+        "anchors", "lr_main", "lr_critic", "pred", "feats", "scalars")]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (works on a GPU-less host too: only the layout functions are callable there)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MimrlError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"or `make -C mimrl_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mimrl_last_error.restype = C.c_char_p
+    lib.mimrl_bucket_floats.restype = C.c_int64
+    lib.mimrl_workspace_bytes.restype = C.c_int64
+    lib.mimrl_op_gru_saved_floats.restype = C.c_int64
+    lib.mimrl_destroy.restype = None
+    lib.mimrl_op_gemm.argtypes = [_FP, _FP, _FP, _FP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _FP, _FP,
+                                  C.c_float, C.c_float, C.c_int, C.c_int]
+    lib.mimrl_op_adam.argtypes = [_FP, _FP, _FP, _FP, _FP, C.c_int64, _FP, _FP, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_float]
+    lib.mimrl_op_gru_forward.argtypes = [_FP] * 11 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_gru_backward.argtypes = [_FP] * 14 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_mi_bound.argtypes = [_FP] * 5 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_knn.argtypes = [_FP, _FP, C.c_int, C.c_int, _FP, C.c_int, C.c_int, _FP]
+    lib.mimrl_op_cmi_loss.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_create.argtypes = [C.POINTER(Cfg), _FP, C.POINTER(_FP)]
+    lib.mimrl_bind.argtypes = [_FP, C.POINTER(Buffers)]
+    for fn in ("mimrl_set_bank_rows", "mimrl_stage_grads", "mimrl_stage_apply"):
+        getattr(lib, fn).argtypes = [_FP, C.c_int]
+    for fn in ("mimrl_stage1_step", "mimrl_stage2_step", "mimrl_destroy", "mimrl_workspace_bytes"):
+        getattr(lib, fn).argtypes = [_FP]
+    lib.mimrl_forward.argtypes = [_FP, C.c_int, C.c_int]
+    lib.mimrl_layout_count.argtypes = [C.POINTER(Cfg)]
+    lib.mimrl_bucket_floats.argtypes = [C.POINTER(Cfg), C.c_int]
+    lib.mimrl_layout_entry.argtypes = [C.POINTER(Cfg), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    _lib = lib
+    return lib
+
+
+EXPORTS = [
+    "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry",
+    "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_stage1_step", "mimrl_stage2_step",
+    "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_workspace_bytes", "mimrl_destroy", "mimrl_op_gemm",
+    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_knn",
+    "mimrl_op_cmi_loss", "mimrl_op_adam",
+]
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise MimrlError(f"libmimrl_hip error {rc}: {load().mimrl_last_error().decode()}")
+    return rc
+
+
+def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capacity: int = 0, precision: str = "fp32",
+             use_graph: bool = False, seed: int = 0) -> Cfg:
+    """Translate the reference's ``opt`` Namespace (Parameters.py) into the C config."""
+    c = Cfg()
+    c.batch = int(opt.batch_size)
+    c.time_len = int(opt.time_len)
+    c.seq_len = int(seq_len if seq_len is not None else opt.time_len)
+    c.d_t, c.d_a, c.d_v, c.d_common = int(d_t), int(d_a), int(d_v), int(opt.d_common)
+    if getattr(opt, "encoders", "gru") != "gru":
+        raise MimrlError(f"--encoders {opt.encoders}: only 'gru' is on the MI355X hot path (lstm/conv: SURVEY.md 8f N3)")
+    nb = len(opt.d_hiddens)
+    if nb > MAX_BLOCKS or len(opt.d_outs) != nb or len(opt.res_project) != nb:
+        raise MimrlError("d_hiddens / d_outs / res_project must have the same length (<= 4)")   # MLPProcess.py:129
+    c.n_blocks = nb
+    for i in range(nb):
+        for ax in range(3):
+            c.d_hiddens[i][ax] = int(opt.d_hiddens[i][ax])
+            c.d_outs[i][ax] = int(opt.d_outs[i][ax])
+        c.res_project[i] = int(bool(opt.res_project[i]))
+    c.bias, c.ln_first = int(bool(opt.bias)), int(bool(opt.ln_first))
+    if opt.activate not in ACTS:
+        raise MimrlError(f"--activate {opt.activate} not supported on the HIP path (gelu/relu/tanh)")
+    c.activation = ACTS[opt.activate]
+    for name, attr in (("features_compose_t", "compose_t_sum"), ("features_compose_k", "compose_k_sum")):
+        v = getattr(opt, name, "mean")
+        if v not in ("mean", "sum"):
+            raise MimrlError(f"--{name} {v}: only mean/sum supported")
+        setattr(c, attr, int(v == "sum"))
+    if opt.critic_type not in ("separate", "concat"):
+        raise NotImplementedError(opt.critic_type)             # VMI.py:44-45
+    c.critic_type = 0 if opt.critic_type == "separate" else 1
+    if getattr(opt, "baseline_type", "constant") != "constant":
+        raise MimrlError("only --baseline_type constant is supported")
+    if opt.bound_type not in BOUNDS:
+        raise NotImplementedError(opt.bound_type)              # Model.py:144-145
+    c.bound_type = BOUNDS[opt.bound_type]
+    if opt.cmi_last_acticate not in ("sigmoid", "hardtanh"):
+        raise NotImplementedError(opt.cmi_last_acticate)       # Model.py:62-63
+    c.cmi_hardtanh = int(opt.cmi_last_acticate == "hardtanh")
+    c.k_neighbor = int(opt.k_neighbor)
+    c.bank_capacity = int(bank_capacity)
+    for i in range(4):
+        c.dropout[i] = float(opt.dropout[i])
+    for i in range(3):
+        c.dropout_mlp[i] = float(opt.dropout_mlp[i])
+    if len(opt.loss_mi_coefficient1) != 11 or len(opt.loss_mi_coefficient2) != 8:
+        raise MimrlError("loss_mi_coefficient1/2 need 11 / 8 entries")
+    for i in range(11):
+        c.coef1[i] = float(opt.loss_mi_coefficient1[i])
+    for i in range(8):
+        c.coef2[i] = float(opt.loss_mi_coefficient2[i])
+    c.weight_decay, c.grad_clip = float(opt.weight_decay), float(opt.gradient_clip)
+    c.beta1, c.beta2, c.adam_eps = 0.9, 0.999, 1e-8
+    c.precision = PREC[precision]
+    c.use_graph = int(bool(use_graph))
+    c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return c
+
+
+def layout_entries(cfg: Cfg) -> Tuple[List[Tuple[str, int, int, Tuple[int, ...]]], Tuple[int, int]]:
+    """-> ([(name, group, offset, shape)], (main_floats, critic_floats)) as the native library lays them out."""
+    lib = load()
+    n = check(lib.mimrl_layout_count(C.byref(cfg)))
+    out = []
+    name = C.create_string_buffer(256)
+    g, nd, d0, d1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    off = C.c_int64()
+    for i in range(n):
+        check(lib.mimrl_layout_entry(C.byref(cfg), i, name, 256, C.byref(g), C.byref(off), C.byref(nd), C.byref(d0), C.byref(d1)))
+        shape = (d0.value, d1.value) if nd.value == 2 else (d0.value,)
+        out.append((name.value.decode(), g.value, off.value, shape))
+    sizes = (check(lib.mimrl_bucket_floats(C.byref(cfg), 0)), check(lib.mimrl_bucket_floats(C.byref(cfg), 1)))
+    return out, sizes

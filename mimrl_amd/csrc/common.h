@@ -1,0 +1,119 @@
+// Shared device/host helpers for libmimrl_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/mimrl.h"
+
+namespace mimrl {
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing: nothing throws across the C ABI; every launcher returns 0 or a negative code and
+// leaves a message in a thread-local string that mimrl_last_error() hands out.
+// ----------------------------------------------------------------------------------------------
+std::string& last_error_slot();
+int set_error(int code, const char* fmt, ...);
+
+#define HIPX(expr)                                                                                  \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return ::mimrl::set_error(MIMRL_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                                hipGetErrorString(_e));                                             \
+  } while (0)
+
+#define MX(expr)            \
+  do {                      \
+    int _r = (expr);        \
+    if (_r != 0) return _r; \
+  } while (0)
+
+#define LAUNCH_CHECK() HIPX(hipGetLastError())
+
+// ----------------------------------------------------------------------------------------------
+// device math
+// ----------------------------------------------------------------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3 };
+
+__device__ __forceinline__ float gelu_f(float x) {  // F.gelu default = exact erf form (MLPProcess.py:14, Utils.py:86)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_GELU: return gelu_f(x);
+    case ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+// derivative w.r.t. the PRE-activation value u
+__device__ __forceinline__ float act_grad(int act, float u) {
+  switch (act) {
+    case ACT_RELU: return u > 0.f ? 1.f : 0.f;
+    case ACT_GELU: return gelu_grad_f(u);
+    case ACT_TANH: { float t = tanhf(u); return 1.f - t * t; }
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` = >=16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = (l < nw) ? red[l] : 0.f;
+  r = wave_sum(r);
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = (l < nw) ? red[l] : -INFINITY;
+  r = wave_max(r);
+  return r;
+}
+
+// counter-based RNG for dropout: one 32-bit hash per element, keyed by (seed, stream id, step, index).
+// (The reference's torch Philox stream cannot be reproduced; parity runs use p=0 or explicit masks.)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float uniform01(uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint32_t step,
+                                           uint32_t idx) {
+  uint32_t h = mix32(idx ^ mix32(step * 0x9E3779B9U + stream) ^ seed_lo);
+  h = mix32(h + seed_hi * 0x85ebca6bU + 0x632be5abU);
+  return (h >> 8) * (1.0f / 16777216.0f);
+}
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+__device__ __forceinline__ __bf16 to_bf16(float x) { return (__bf16)x; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+
+}  // namespace mimrl

@@ -1,0 +1,1201 @@
+// Engine: the two-stage training step of MIMRL orchestrated on one HIP stream (optionally replayed as hipGraphs).
+//
+//   stage 1  (Solver.py:205-214): model forward -> 5 MI + 6 CMI estimators -> backward into the CRITIC weights
+//            -> value-clip + Adam on the critic bucket.
+//   stage 2  (Solver.py:221-236): model forward (activations kept) -> estimators (data gradients only) -> MAE ->
+//            backward through head / CubeMLP / LN / bi-GRU BPTT / W_t -> value-clip + Adam on the main bucket.
+// The reference back-propagates stage 1 through the main model and stage 2 into the critic weights as well, but
+// those gradients are never applied: they are skipped here with no effect on any parameter.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "estimator_ops.h"
+#include "gemm.h"
+#include "gru.h"
+#include "layout.h"
+#include "model_ops.h"
+
+namespace mimrl {
+
+namespace {
+
+constexpr int H = 128, G = 384, HID = 256, EMB = 128;
+constexpr int NE_MI = 5, NE_CMI = 6;
+
+// feature slots: F,T,A,V ; 4 = labels (C)
+enum { FT_F = 0, FT_T = 1, FT_A = 2, FT_V = 3, FT_C = 4 };
+const int kMiWire[NE_MI][2] = {{FT_F, FT_T}, {FT_F, FT_A}, {FT_F, FT_V}, {FT_T, FT_A}, {FT_T, FT_V}};   // Model.py:313-319
+const int kCmiWire[NE_CMI][3] = {{FT_A, FT_C, FT_T}, {FT_T, FT_A, FT_C}, {FT_V, FT_C, FT_T},           // Model.py:323-339
+                                 {FT_T, FT_V, FT_C}, {FT_T, FT_C, FT_A}, {FT_T, FT_C, FT_V}};
+const char* kVmi[NE_MI] = {"f_t", "f_a", "f_v", "t_a", "t_v"};
+const char* kVcmi[NE_CMI] = {"ac_t", "ta_c", "vc_t", "tv_c", "tc_a", "tc_v"};
+
+__global__ void begin_stage_kernel(int* rng_step, int* adam_step, float* scalars, int scal_off, int scal_n) {
+  if (threadIdx.x == 0) {
+    *rng_step += 1;
+    if (adam_step) *adam_step += 1;
+  }
+  for (int i = threadIdx.x; i < scal_n; i += blockDim.x) scalars[scal_off + i] = 0.f;
+}
+
+// MAE (nn.L1Loss, Solver.py:181-182) + its gradient
+__global__ void mae_kernel(const float* __restrict__ pred, const float* __restrict__ y, float* __restrict__ dpred,
+                           float* __restrict__ task, int B) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float d = pred[b] - y[b];
+    s += fabsf(d);
+    if (dpred) dpred[b] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / B;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *task = s / B;
+}
+
+// Model.py:341 + Customization.py:100-102
+__global__ void finalize_stage1_kernel(float* scal, const float* mi, const float* cmi, const float* bce, const float* coef1) {
+  if (threadIdx.x != 0) return;
+  float loss = 0.f;
+  for (int e = 0; e < NE_MI; ++e) {
+    scal[MIMRL_S1_MIS + e] = mi[e];
+    scal[MIMRL_S1_LOSSES + e] = -mi[e];
+    loss += coef1[e] * -mi[e];
+  }
+  for (int e = 0; e < NE_CMI; ++e) {
+    scal[MIMRL_S1_MIS + NE_MI + e] = cmi[e];
+    scal[MIMRL_S1_LOSSES + NE_MI + e] = bce[e];
+    loss += coef1[NE_MI + e] * bce[e];
+  }
+  scal[MIMRL_S1_LOSS] = loss;
+}
+// Model.py:357,381-386 + Customization.py:109-111
+__global__ void finalize_stage2_kernel(float* scal, const float* mi, const float* cmi, const float* coef2, int have_mi) {
+  if (threadIdx.x != 0) return;
+  const float task = scal[MIMRL_S2_TASK];
+  if (!have_mi) {
+    for (int i = 0; i < 8; ++i) { scal[MIMRL_S2_MIS + i] = 0.f; scal[MIMRL_S2_LOSSES + i] = 0.f; }
+    scal[MIMRL_S2_LOSS] = task;
+    return;
+  }
+  const float ac_t = cmi[0], ta_c = cmi[1], vc_t = cmi[2], tv_c = cmi[3], tc_a = cmi[4], tc_v = cmi[5];
+  float v[8];
+  v[0] = mi[0]; v[1] = mi[1]; v[2] = mi[2];
+  v[3] = mi[3] + mi[4];
+  v[4] = tc_a + tc_v - ta_c - tv_c;
+  v[5] = ac_t - ta_c;
+  v[6] = vc_t - tv_c;
+  v[7] = ta_c + tv_c;
+  float loss = task;
+  for (int i = 0; i < 8; ++i) {
+    scal[MIMRL_S2_MIS + i] = v[i];
+    scal[MIMRL_S2_LOSSES + i] = -v[i];
+    loss += coef2[i] * -v[i];
+  }
+  scal[MIMRL_S2_LOSS] = loss;
+}
+
+struct Lin { long w = -1, b = -1; int out = 0, in = 0; };
+struct GruDirW { long w_ih, w_hh, b_ih, b_hh; int din; };
+struct AxisW { Lin fc1, fc2; long res = -1, ln_g = -1, ln_b = -1; int in = 0, hid = 0, out = 0; };
+struct BlockW { AxisW ax[3]; };
+struct MixBuf { float *xn = nullptr, *xn_mean = nullptr, *xn_rstd = nullptr, *u = nullptr, *h = nullptr, *y = nullptr,
+                      *z = nullptr, *mean = nullptr, *rstd = nullptr; };
+struct BlockBuf { MixBuf l, k, d; };
+
+}  // namespace
+
+}  // namespace mimrl
+
+using namespace mimrl;
+
+struct mimrl_handle {
+  mimrl_cfg cfg;
+  hipStream_t stream = nullptr;
+  Layout layout;
+  mimrl_buffers bufs;
+  bool bound = false;
+  int bank_rows = 0;
+  bool bf16 = false;
+
+  // parameter handles
+  GruDirW gru[2][2][2];          // [mod a=0,v=1][layer][dir]
+  long ln_g[2], ln_b[2], w_t;
+  BlockW blk[MIMRL_MAX_BLOCKS];
+  long cls_w, cls_b;
+  long tower0 = 0, tower_stride = 0;   // critic bucket: first tower, distance between consecutive towers
+  long tower_l[4][2];                  // per-layer (w,b) offsets relative to tower0
+  long cmi0 = 0, cmi_stride = 0, cmi_l[4][2];
+
+  // workspace
+  char* ws = nullptr;
+  size_t ws_bytes = 0, ws_used = 0;
+  int* d_ints = nullptr;               // [0] rng step, [1] adam main step, [2] adam critic step
+  float* d_consts = nullptr;           // coef1[11] coef2[8] gs_mi[2][5] g_bce[2][6] g_cmi[2][6]
+  int *lens[2] = {nullptr, nullptr};
+  float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
+  float* cube0 = nullptr;
+  BlockBuf bb[MIMRL_MAX_BLOCKS];
+  float *ff = nullptr, *dpred = nullptr;
+  // estimators
+  float *tin = nullptr, *ta[3], *tout = nullptr, *scores = nullptr, *dscores = nullptr;
+  float *cP = nullptr, *cQ = nullptr, *ca[3];
+  int* knn_idx = nullptr;
+  float *cmi_in = nullptr, *cc[3], *logits = nullptr, *dlogits = nullptr;
+  float *mi_raw = nullptr, *cmi_raw = nullptr, *bce_raw = nullptr;
+  // backward temporaries
+  float *dfeat = nullptr, *dtout = nullptr, *dta[2], *dtin = nullptr, *dca[2], *dP = nullptr, *dQ = nullptr;
+  float *dcc[2], *dcin = nullptr;
+  float* gbuf[4];
+  size_t gbuf_floats = 0;
+  float *dtx = nullptr, *ds[2], *dgx[2][2], *dgh[2][2], *hprev[2][2], *dh0[2];
+
+  // graphs: [stage 1|2][kind: 0 = step (grads+apply), 1 = grads only]
+  hipGraphExec_t graph[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  int graph_rows[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+
+  // ------------------------------------------------------------------------------------------
+  float* P(long off) const { return bufs.main_p + off; }
+  float* Gm(long off) const { return bufs.main_g + off; }
+  float* CP(long off) const { return bufs.crit_p + off; }
+  float* CG(long off) const { return bufs.crit_g + off; }
+  RngKey key() const { return RngKey{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints}; }
+  const float* coef1() const { return d_consts; }
+  const float* coef2() const { return d_consts + 11; }
+  const float* gs_mi(int stage) const { return d_consts + 19 + (stage - 1) * 5; }
+  const float* g_bce(int stage) const { return d_consts + 29 + (stage - 1) * 6; }
+  const float* g_cmi(int stage) const { return d_consts + 41 + (stage - 1) * 6; }
+  int nprod() const { return (cfg.batch / cfg.k_neighbor) * cfg.k_neighbor; }   // rows of the product batch (Model.py:79)
+  int m_anchor() const { return cfg.batch / cfg.k_neighbor; }
+
+  int resolve();
+  int alloc_workspace();
+  template <typename T>
+  int take(T** p, size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
+    if (ws) {
+      if (ws_used + bytes > ws_bytes) return set_error(MIMRL_ERR_STATE, "workspace overflow");
+      *p = reinterpret_cast<T*>(ws + ws_used);
+    }
+    ws_used += bytes;
+    return MIMRL_OK;
+  }
+  int carve();
+
+  int G_(const GemmDesc& d) { return gemm(stream, d, bf16); }
+  int model_forward(bool train, bool save);
+  int cube_forward(bool train);
+  int cube_backward(int cur_in, int* cur_out);
+  int model_backward();
+  int estimators_forward(int stage, bool want_grad);
+  int estimators_backward(int stage);
+  // grouped MLP stacks living in the critic bucket (nb groups, uniform parameter stride `pstride`)
+  int mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2], const int* dims,
+                        const float* in, float* const* act, float* out);
+  int mlp_stack_backward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
+                         const int* dims, const float* in, float* const* act, float* dout, float* const* dtmp, float* din,
+                         bool wgrad);
+  int enqueue_grads(int stage);
+  int enqueue_apply(int stage);
+  int run(int stage, int kind);
+};
+
+// =================================================================================================
+int mimrl_handle::resolve() {
+  auto off = [&](const std::string& n, long* o) -> int {
+    const LayoutEntry* e = layout.find(n);
+    if (!e) return set_error(MIMRL_ERR_STATE, "layout: missing tensor %s", n.c_str());
+    *o = e->offset;
+    return MIMRL_OK;
+  };
+  auto opt = [&](const std::string& n) -> long {
+    const LayoutEntry* e = layout.find(n);
+    return e ? e->offset : -1;
+  };
+  const char* modn[2] = {"rnn_a", "rnn_v"};
+  const int dmod[2] = {cfg.d_a, cfg.d_v};
+  for (int m = 0; m < 2; ++m)
+    for (int l = 0; l < 2; ++l)
+      for (int d = 0; d < 2; ++d) {
+        const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
+        GruDirW& g = gru[m][l][d];
+        MX(off(std::string(modn[m]) + ".weight_ih" + sfx, &g.w_ih));
+        MX(off(std::string(modn[m]) + ".weight_hh" + sfx, &g.w_hh));
+        MX(off(std::string(modn[m]) + ".bias_ih" + sfx, &g.b_ih));
+        MX(off(std::string(modn[m]) + ".bias_hh" + sfx, &g.b_hh));
+        g.din = l == 0 ? dmod[m] : 2 * H;
+      }
+  MX(off("ln_a.weight", &ln_g[0])); MX(off("ln_a.bias", &ln_b[0]));
+  MX(off("ln_v.weight", &ln_g[1])); MX(off("ln_v.bias", &ln_b[1]));
+  MX(off("W_t.weight", &w_t));
+  int din[3] = {cfg.time_len, 3, cfg.d_common};
+  const char axn[3] = {'l', 'k', 'd'};
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const std::string pre = "mlp_encoder.layers_stack." + std::to_string(i);
+    for (int ax = 0; ax < 3; ++ax) {
+      AxisW& a = blk[i].ax[ax];
+      a.in = din[ax]; a.hid = cfg.d_hiddens[i][ax]; a.out = cfg.d_outs[i][ax];
+      const std::string m = pre + ".mlp_" + axn[ax];
+      MX(off(m + ".fc1.weight", &a.fc1.w)); a.fc1.b = opt(m + ".fc1.bias"); a.fc1.out = a.hid; a.fc1.in = a.in;
+      MX(off(m + ".fc2.weight", &a.fc2.w)); a.fc2.b = opt(m + ".fc2.bias"); a.fc2.out = a.out; a.fc2.in = a.hid;
+      MX(off(pre + ".ln_" + axn[ax] + ".weight", &a.ln_g));
+      MX(off(pre + ".ln_" + axn[ax] + ".bias", &a.ln_b));
+      a.res = opt(pre + ".res_projection_" + axn[ax] + ".weight");
+    }
+    for (int ax = 0; ax < 3; ++ax) din[ax] = cfg.d_outs[i][ax];
+  }
+  MX(off("classifier.0.weight", &cls_w)); MX(off("classifier.0.bias", &cls_b));
+  const int idx4[4] = {0, 2, 4, 6};
+  // critic towers: uniform stride between consecutive towers (layout order is [estimator][tower][layer])
+  {
+    const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
+    const std::string t0 = std::string("vmi_estimator_f_t.critic_model.") + (sep ? "MLP_g" : "MLP_f");
+    const std::string t1 = sep ? "vmi_estimator_f_t.critic_model.MLP_h" : "vmi_estimator_f_a.critic_model.MLP_f";
+    long a, b;
+    MX(off(t0 + ".0.weight", &a)); MX(off(t1 + ".0.weight", &b));
+    tower0 = a; tower_stride = b - a;
+    for (int l = 0; l < 4; ++l) {
+      long w, bb_;
+      MX(off(t0 + "." + std::to_string(idx4[l]) + ".weight", &w));
+      MX(off(t0 + "." + std::to_string(idx4[l]) + ".bias", &bb_));
+      tower_l[l][0] = w - tower0; tower_l[l][1] = bb_ - tower0;
+    }
+    // verify uniformity
+    const int ntw = sep ? 10 : 5;
+    for (int t = 0; t < ntw; ++t) {
+      const int e = sep ? t / 2 : t;
+      const std::string nm = std::string("vmi_estimator_") + kVmi[e] + ".critic_model." +
+                             (sep ? (t % 2 ? "MLP_h" : "MLP_g") : "MLP_f") + ".0.weight";
+      long o; MX(off(nm, &o));
+      if (o != tower0 + t * tower_stride) return set_error(MIMRL_ERR_STATE, "critic towers are not uniformly strided");
+    }
+  }
+  {
+    long a, b;
+    MX(off("vcmi_estimator_ac_t.classifier.mlp.0.weight", &a));
+    MX(off("vcmi_estimator_ta_c.classifier.mlp.0.weight", &b));
+    cmi0 = a; cmi_stride = b - a;
+    for (int l = 0; l < 4; ++l) {
+      long w, bb_;
+      MX(off("vcmi_estimator_ac_t.classifier.mlp." + std::to_string(idx4[l]) + ".weight", &w));
+      MX(off("vcmi_estimator_ac_t.classifier.mlp." + std::to_string(idx4[l]) + ".bias", &bb_));
+      cmi_l[l][0] = w - cmi0; cmi_l[l][1] = bb_ - cmi0;
+    }
+    for (int e = 0; e < NE_CMI; ++e) {
+      long o; MX(off(std::string("vcmi_estimator_") + kVcmi[e] + ".classifier.mlp.0.weight", &o));
+      if (o != cmi0 + e * cmi_stride) return set_error(MIMRL_ERR_STATE, "CMI classifiers are not uniformly strided");
+    }
+  }
+  return MIMRL_OK;
+}
+
+int mimrl_handle::carve() {
+  const size_t B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+  const size_t BT_ = B * T;
+  MX(take(&d_ints, 16));
+  MX(take(&d_consts, 64));
+  for (int m = 0; m < 2; ++m) MX(take(&lens[m], B));
+  MX(take(&tx_raw, BT_ * D));
+  for (int m = 0; m < 2; ++m) {
+    for (int d = 0; d < 2; ++d) MX(take(&gx[m][d], BT_ * G));
+    MX(take(&h0[m], BT_ * 2 * H));
+    MX(take(&h1[m], BT_ * 2 * H));
+    for (int l = 0; l < 2; ++l)
+      for (int d = 0; d < 2; ++d) MX(take(&sv[l][m][d], (size_t)gru_saved_floats(cfg.batch, cfg.seq_len)));
+    MX(take(&ln_mean[m], BT_));
+    MX(take(&ln_rstd[m], BT_));
+  }
+  MX(take(&cube0, B * L * 3 * D));
+  size_t gmax = B * L * 3 * D;
+  int il = cfg.time_len, ik = 3, id = cfg.d_common;
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const int hl = cfg.d_hiddens[i][0], hk = cfg.d_hiddens[i][1], hd = cfg.d_hiddens[i][2];
+    const int ol = cfg.d_outs[i][0], ok = cfg.d_outs[i][1], od = cfg.d_outs[i][2];
+    (void)hk;
+    BlockBuf& b = bb[i];
+    const size_t C = (size_t)ik * id;
+    if (cfg.ln_first) { MX(take(&b.l.xn, B * il * C)); MX(take(&b.l.xn_mean, B * C)); MX(take(&b.l.xn_rstd, B * C)); }
+    MX(take(&b.l.u, B * hl * C)); MX(take(&b.l.h, B * hl * C));
+    MX(take(&b.l.y, B * ol * C));
+    if (!cfg.ln_first) { MX(take(&b.l.z, B * ol * C)); MX(take(&b.l.mean, B * C)); MX(take(&b.l.rstd, B * C)); }
+    else b.l.z = b.l.y;
+    MX(take(&b.k.z, B * ol * ok * id));
+    const size_t R2 = B * ol * ok;
+    if (cfg.ln_first) { MX(take(&b.d.xn, R2 * id)); MX(take(&b.d.xn_mean, R2)); MX(take(&b.d.xn_rstd, R2)); }
+    MX(take(&b.d.u, R2 * hd)); MX(take(&b.d.h, R2 * hd));
+    MX(take(&b.d.y, R2 * od));
+    if (!cfg.ln_first) { MX(take(&b.d.z, R2 * od)); MX(take(&b.d.mean, R2)); MX(take(&b.d.rstd, R2)); }
+    else b.d.z = b.d.y;
+    const size_t cand[] = {B * il * C, B * hl * C, B * ol * C, B * ol * ok * id, R2 * hd, R2 * od};
+    for (size_t c : cand) gmax = c > gmax ? c : gmax;
+    il = ol; ik = ok; id = od;
+  }
+  MX(take(&ff, B * D));
+  MX(take(&dpred, B));
+  // estimators
+  const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
+  MX(take(&tin, 10 * B * EMB));
+  MX(take(&scores, NE_MI * B * B));
+  MX(take(&dscores, NE_MI * B * B));
+  if (sep) {
+    for (int l = 0; l < 3; ++l) MX(take(&ta[l], 10 * B * HID));
+    MX(take(&tout, 10 * B * EMB));
+    MX(take(&dtout, 10 * B * EMB));
+    for (int l = 0; l < 2; ++l) MX(take(&dta[l], 10 * B * HID));
+  } else {
+    MX(take(&cP, NE_MI * B * HID)); MX(take(&cQ, NE_MI * B * HID));
+    MX(take(&dP, NE_MI * B * HID)); MX(take(&dQ, NE_MI * B * HID));
+    for (int l = 0; l < 3; ++l) MX(take(&ca[l], NE_MI * B * B * HID));
+    for (int l = 0; l < 2; ++l) MX(take(&dca[l], NE_MI * B * B * HID));
+  }
+  MX(take(&dtin, 10 * B * EMB));
+  const size_t n = nprod();
+  MX(take(&knn_idx, NE_CMI * n));
+  MX(take(&cmi_in, NE_CMI * 2 * n * 384));
+  for (int l = 0; l < 3; ++l) MX(take(&cc[l], NE_CMI * 2 * n * HID));
+  MX(take(&logits, NE_CMI * 2 * n * 2));
+  MX(take(&dlogits, NE_CMI * 2 * n * 2));
+  for (int l = 0; l < 2; ++l) MX(take(&dcc[l], NE_CMI * 2 * n * HID));
+  MX(take(&dcin, NE_CMI * 2 * n * 384));
+  MX(take(&mi_raw, 8)); MX(take(&cmi_raw, 8)); MX(take(&bce_raw, 8));
+  MX(take(&dfeat, 4 * B * D));
+  gbuf_floats = gmax;
+  for (int i = 0; i < 4; ++i) MX(take(&gbuf[i], gmax));
+  MX(take(&dtx, BT_ * D));
+  for (int m = 0; m < 2; ++m) {
+    MX(take(&ds[m], BT_ * H));
+    MX(take(&dh0[m], BT_ * 2 * H));
+    for (int d = 0; d < 2; ++d) {
+      MX(take(&dgx[m][d], BT_ * G));
+      MX(take(&dgh[m][d], BT_ * G));
+      MX(take(&hprev[m][d], BT_ * H));
+    }
+  }
+  return MIMRL_OK;
+}
+
+int mimrl_handle::alloc_workspace() {
+  ws = nullptr; ws_used = 0;
+  MX(carve());                       // dry run: size
+  ws_bytes = ws_used + 4096;
+  HIPX(hipMalloc(reinterpret_cast<void**>(&ws), ws_bytes));
+  HIPX(hipMemsetAsync(ws, 0, ws_bytes, stream));
+  ws_used = 0;
+  MX(carve());
+  // constants
+  float c[64];
+  std::memset(c, 0, sizeof c);
+  for (int i = 0; i < 11; ++i) c[i] = cfg.coef1[i];
+  for (int i = 0; i < 8; ++i) c[11 + i] = cfg.coef2[i];
+  const float* k1 = cfg.coef1; const float* k2 = cfg.coef2;
+  for (int e = 0; e < NE_MI; ++e) c[19 + e] = -k1[e];                              // stage 1: d(loss)/d(mi_e)
+  const float s2mi[NE_MI] = {-k2[0], -k2[1], -k2[2], -k2[3], -k2[3]};
+  for (int e = 0; e < NE_MI; ++e) c[24 + e] = s2mi[e];
+  for (int e = 0; e < NE_CMI; ++e) c[29 + e] = k1[NE_MI + e];                      // stage 1: coefficient of BCE_e
+  // stage 2: d(loss)/d(cmi_e), Model.py:381-386 (order ac_t, ta_c, vc_t, tv_c, tc_a, tc_v)
+  const float s2c[NE_CMI] = {-k2[5], k2[4] + k2[5] - k2[7], -k2[6], k2[4] + k2[6] - k2[7], -k2[4], -k2[4]};
+  for (int e = 0; e < NE_CMI; ++e) c[47 + e] = s2c[e];                             // g_cmi(stage 2) = d_consts+41+6
+  HIPX(hipMemcpyAsync(d_consts, c, sizeof c, hipMemcpyHostToDevice, stream));
+  HIPX(hipStreamSynchronize(stream));
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+// model forward
+// =================================================================================================
+int mimrl_handle::model_forward(bool train, bool save) {
+  const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+  const long BT_ = (long)B * T;
+  const float* xin[2] = {bufs.audio, bufs.video};
+  const int dmod[2] = {cfg.d_a, cfg.d_v};
+  const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
+  if (T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
+  // text: W_t projection (Model.py:395) + dropout -> cube slot 0
+  MX(G_(gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t)));
+  MX(text_post_fwd(stream, tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+  // lengths (Model.py:425-432)
+  for (int m = 0; m < 2; ++m) MX(seq_lengths(stream, xin[m], B, T, dmod[m], lens[m]));
+  // bi-GRU, 2 layers (Model.py:441-447)
+  for (int l = 0; l < 2; ++l) {
+    GruFwdArgs a;
+    a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
+    for (int m = 0; m < 2; ++m) {
+      a.lens[m] = lens[m];
+      const float* in = l == 0 ? xin[m] : h0[m];
+      for (int d = 0; d < 2; ++d) {
+        const GruDirW& g = gru[m][l][d];
+        GemmDesc gd = gemm_nt(in, g.din, P(g.w_ih), g.din, gx[m][d], G, (int)BT_, G, g.din);
+        gd.bias_n = P(g.b_ih);
+        MX(G_(gd));
+        a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
+      }
+    }
+    MX(gru_forward(stream, a, bf16));
+  }
+  // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
+  for (int m = 0; m < 2; ++m)
+    MX(ln_relu_drop_fwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), cube0, ln_mean[m], ln_rstd[m], B, T, L, 3, D, 1 + m,
+                        pdrop[1 + m], key(), 1 + m));
+  // T_F, A_F, V_F (Model.py:466)
+  MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
+  MX(cube_forward(train));
+  // head (Model.py:489-515)
+  const BlockBuf& last = bb[cfg.n_blocks - 1];
+  const int ol = cfg.d_outs[cfg.n_blocks - 1][0], ok = cfg.d_outs[cfg.n_blocks - 1][1], od = cfg.d_outs[cfg.n_blocks - 1][2];
+  if (od != D) return set_error(MIMRL_ERR_ARG, "last block d_out must equal d_common (features feed 128-wide estimators)");
+  MX(head_fwd(stream, last.d.z, P(cls_w), P(cls_b), bufs.feats, bufs.pred, B, ol, ok, od, cfg.compose_t_sum,
+              cfg.compose_k_sum));
+  (void)ff;
+  return MIMRL_OK;
+}
+
+int mimrl_handle::cube_forward(bool train) {
+  const int B = cfg.batch;
+  const float* x = cube0;
+  int il = cfg.time_len, ik = 3, id = cfg.d_common;
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const BlockW& w = blk[i];
+    BlockBuf& b = bb[i];
+    const int hl = w.ax[0].hid, ol = w.ax[0].out, hk = w.ax[1].hid, ok = w.ax[1].out, hd = w.ax[2].hid, od = w.ax[2].out;
+    const float pl = train ? cfg.dropout_mlp[0] : 0.f, pk = train ? cfg.dropout_mlp[1] : 0.f,
+                pd = train ? cfg.dropout_mlp[2] : 0.f;
+    // ------------------------------------------------ L axis (MLPProcess.py:95-104 / 65-74)
+    {
+      const AxisW& a = w.ax[0];
+      const long C = (long)ik * id;
+      const float* xi = x;
+      if (cfg.ln_first) { MX(colln_fwd(stream, x, P(a.ln_g), P(a.ln_b), b.l.xn, b.l.xn_mean, b.l.xn_rstd, B, il, (int)C)); xi = b.l.xn; }
+      GemmDesc g1;   // H = act(W1 . X_b + b1)
+      g1.A = P(a.fc1.w); g1.sa_m = il; g1.sa_k = 1; g1.sa_b = 0;
+      g1.B = xi; g1.sb_k = C; g1.sb_n = 1; g1.sb_b = (long)il * C;
+      g1.C = b.l.h; g1.sc_m = C; g1.sc_n = 1; g1.sc_b = (long)hl * C;
+      g1.M = hl; g1.N = (int)C; g1.K = il; g1.batch = B;
+      g1.bias_m = a.fc1.b >= 0 ? P(a.fc1.b) : nullptr; g1.act = cfg.activation; g1.pre = b.l.u;
+      MX(G_(g1));
+      GemmDesc g2;   // Y = W2 . H_b + b2
+      g2.A = P(a.fc2.w); g2.sa_m = hl; g2.sa_k = 1;
+      g2.B = b.l.h; g2.sb_k = C; g2.sb_n = 1; g2.sb_b = (long)hl * C;
+      g2.C = b.l.y; g2.sc_m = C; g2.sc_n = 1; g2.sc_b = (long)ol * C;
+      g2.M = ol; g2.N = (int)C; g2.K = hl; g2.batch = B;
+      g2.bias_m = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+      MX(G_(g2));
+      MX(dropout_inplace(stream, b.l.y, (long)B * ol * C, pl, key(), 10 + 3 * i));
+      if (a.res >= 0) {   // Y += Wr . X_b
+        GemmDesc g3 = g2;
+        g3.A = P(a.res); g3.sa_m = il; g3.B = x; g3.sb_b = (long)il * C; g3.K = il; g3.bias_m = nullptr; g3.beta = 1.f;
+        MX(G_(g3));
+      } else {
+        MX(add_inplace(stream, b.l.y, x, (long)B * ol * C));
+      }
+      if (!cfg.ln_first) MX(colln_fwd(stream, b.l.y, P(a.ln_g), P(a.ln_b), b.l.z, b.l.mean, b.l.rstd, B, ol, (int)C));
+    }
+    // ------------------------------------------------ K axis (MLPProcess.py:106-112 / 76-82)
+    {
+      const AxisW& a = w.ax[1];
+      KMixW kw;
+      std::memset(&kw, 0, sizeof kw);
+      kw.w1 = P(a.fc1.w); kw.b1 = a.fc1.b >= 0 ? P(a.fc1.b) : nullptr;
+      kw.w2 = P(a.fc2.w); kw.b2 = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+      kw.wr = a.res >= 0 ? P(a.res) : nullptr; kw.g = P(a.ln_g); kw.be = P(a.ln_b);
+      kw.ik = ik; kw.hk = hk; kw.ok = ok; kw.act = cfg.activation; kw.ln_first = cfg.ln_first;
+      kw.drop_p = pk; kw.key = key(); kw.stream_id = 11 + 3 * i;
+      MX(kmix_fwd(stream, b.l.z, b.k.z, kw, (long)B * ol, id));
+    }
+    // ------------------------------------------------ D axis (MLPProcess.py:114-120 / 84-90)
+    {
+      const AxisW& a = w.ax[2];
+      const long R2 = (long)B * ol * ok;
+      const float* xi = b.k.z;
+      if (cfg.ln_first) { MX(rowln_fwd(stream, b.k.z, P(a.ln_g), P(a.ln_b), b.d.xn, b.d.xn_mean, b.d.xn_rstd, R2, id)); xi = b.d.xn; }
+      GemmDesc g1 = gemm_nt(xi, id, P(a.fc1.w), id, b.d.h, hd, (int)R2, hd, id);
+      g1.bias_n = a.fc1.b >= 0 ? P(a.fc1.b) : nullptr; g1.act = cfg.activation; g1.pre = b.d.u;
+      MX(G_(g1));
+      GemmDesc g2 = gemm_nt(b.d.h, hd, P(a.fc2.w), hd, b.d.y, od, (int)R2, od, hd);
+      g2.bias_n = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+      MX(G_(g2));
+      MX(dropout_inplace(stream, b.d.y, R2 * od, pd, key(), 12 + 3 * i));
+      if (a.res >= 0) {
+        GemmDesc g3 = gemm_nt(b.k.z, id, P(a.res), id, b.d.y, od, (int)R2, od, id);
+        g3.beta = 1.f;
+        MX(G_(g3));
+      } else {
+        MX(add_inplace(stream, b.d.y, b.k.z, R2 * od));
+      }
+      if (!cfg.ln_first) MX(rowln_fwd(stream, b.d.y, P(a.ln_g), P(a.ln_b), b.d.z, b.d.mean, b.d.rstd, R2, od));
+    }
+    x = b.d.z;
+    il = ol; ik = ok; id = od;
+  }
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+// CubeMLP backward.  The incoming gradient (w.r.t. the last block's output) lives in gbuf[cur_in]; on return
+// gbuf[*cur_out] holds d(cube0).  Four rotating gradient buffers are enough: at any time at most
+// {dY, dY through dropout, dU, dX} are live.
+// =================================================================================================
+int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
+  const int B = cfg.batch;
+  int dims[MIMRL_MAX_BLOCKS + 1][3];
+  dims[0][0] = cfg.time_len; dims[0][1] = 3; dims[0][2] = cfg.d_common;
+  for (int i = 0; i < cfg.n_blocks; ++i)
+    for (int ax = 0; ax < 3; ++ax) dims[i + 1][ax] = cfg.d_outs[i][ax];
+  int used[4] = {0, 0, 0, 0};
+  used[cur_in] = 1;
+  int cur = cur_in;
+  auto grab = [&]() { for (int q = 0; q < 4; ++q) if (!used[q]) { used[q] = 1; return q; } return -1; };
+  auto release = [&](int q) { used[q] = 0; };
+#define GRAB(var)                                                                                   \
+  const int var = grab();                                                                           \
+  if (var < 0) return set_error(MIMRL_ERR_STATE, "cube_backward: out of gradient buffers (line %d)", __LINE__)
+
+  for (int i = cfg.n_blocks - 1; i >= 0; --i) {
+    const BlockW& w = blk[i];
+    BlockBuf& b = bb[i];
+    const int il = dims[i][0], ik = dims[i][1], id = dims[i][2];
+    const int hl = w.ax[0].hid, ol = w.ax[0].out, hk = w.ax[1].hid, ok = w.ax[1].out, hd = w.ax[2].hid, od = w.ax[2].out;
+    const float* xblk = i == 0 ? cube0 : bb[i - 1].d.z;
+    const float pl = cfg.dropout_mlp[0], pk = cfg.dropout_mlp[1], pd = cfg.dropout_mlp[2];
+    // ------------------------------------------------ D axis backward
+    {
+      const AxisW& a = w.ax[2];
+      const long R2 = (long)B * ol * ok;
+      const float* xin = b.k.z;                              // residual / un-normalised input
+      const float* xmlp = cfg.ln_first ? b.d.xn : b.k.z;     // what fc1 saw
+      int i_dy = cur;
+      if (!cfg.ln_first) {
+        GRAB(q);
+        MX(rowln_bwd(stream, b.d.y, P(a.ln_g), b.d.mean, b.d.rstd, gbuf[cur], gbuf[q], Gm(a.ln_g), Gm(a.ln_b), R2, od));
+        release(cur);
+        i_dy = q;
+      }
+      const float* dy = gbuf[i_dy];
+      int i_dym = i_dy;
+      if (pd > 0.f) {                                        // gradient entering the dropped-out MLP branch
+        GRAB(q);
+        HIPX(hipMemcpyAsync(gbuf[q], dy, sizeof(float) * R2 * od, hipMemcpyDeviceToDevice, stream));
+        MX(dropout_inplace(stream, gbuf[q], R2 * od, pd, key(), 12 + 3 * i));
+        i_dym = q;
+      }
+      const float* dym = gbuf[i_dym];
+      { GemmDesc g = gemm_tn(dym, od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(G_(g)); }
+      if (a.fc2.b >= 0) MX(colsum(stream, dym, R2, od, od, Gm(a.fc2.b)));
+      if (a.res >= 0) { GemmDesc g = gemm_tn(dy, od, xin, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(G_(g)); }
+      GRAB(i_du);                                            // dU = (dYm . W2) * act'(U)
+      { GemmDesc g = gemm_nn(dym, od, P(a.fc2.w), hd, gbuf[i_du], hd, (int)R2, hd, od); g.act = cfg.activation; g.gradact_u = b.d.u; MX(G_(g)); }
+      if (i_dym != i_dy) release(i_dym);
+      { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(G_(g)); }
+      if (a.fc1.b >= 0) MX(colsum(stream, gbuf[i_du], R2, hd, hd, Gm(a.fc1.b)));
+      GRAB(i_dx0);
+      int i_dx = i_dx0;
+      { GemmDesc g = gemm_nn(gbuf[i_du], hd, P(a.fc1.w), id, gbuf[i_dx], id, (int)R2, id, hd); MX(G_(g)); }
+      if (cfg.ln_first) {                                    // that was dXn: LayerNorm backward into the (now free) dU buffer
+        MX(rowln_bwd(stream, b.k.z, P(a.ln_g), b.d.xn_mean, b.d.xn_rstd, gbuf[i_dx], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b), R2, id));
+        release(i_dx);
+        i_dx = i_du;
+      } else {
+        release(i_du);
+      }
+      if (a.res >= 0) { GemmDesc g = gemm_nn(dy, od, P(a.res), id, gbuf[i_dx], id, (int)R2, id, od); g.beta = 1.f; MX(G_(g)); }
+      else MX(add_inplace(stream, gbuf[i_dx], dy, R2 * id));
+      release(i_dy);
+      cur = i_dx;
+    }
+    // ------------------------------------------------ K axis backward
+    {
+      const AxisW& a = w.ax[1];
+      KMixW kw;
+      std::memset(&kw, 0, sizeof kw);
+      kw.w1 = P(a.fc1.w); kw.b1 = a.fc1.b >= 0 ? P(a.fc1.b) : nullptr;
+      kw.w2 = P(a.fc2.w); kw.b2 = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+      kw.wr = a.res >= 0 ? P(a.res) : nullptr; kw.g = P(a.ln_g); kw.be = P(a.ln_b);
+      kw.dw1 = Gm(a.fc1.w); kw.db1 = a.fc1.b >= 0 ? Gm(a.fc1.b) : nullptr;
+      kw.dw2 = Gm(a.fc2.w); kw.db2 = a.fc2.b >= 0 ? Gm(a.fc2.b) : nullptr;
+      kw.dwr = a.res >= 0 ? Gm(a.res) : nullptr; kw.dg = Gm(a.ln_g); kw.dbe = Gm(a.ln_b);
+      kw.ik = ik; kw.hk = hk; kw.ok = ok; kw.act = cfg.activation; kw.ln_first = cfg.ln_first;
+      kw.drop_p = pk; kw.key = key(); kw.stream_id = 11 + 3 * i;
+      GRAB(q);
+      MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
+      release(cur);
+      cur = q;
+    }
+    // ------------------------------------------------ L axis backward (per-sample [.,C] tiles, C = ik*id)
+    {
+      const AxisW& a = w.ax[0];
+      const long C = (long)ik * id;
+      const float* xmlp = cfg.ln_first ? b.l.xn : xblk;
+      int i_dy = cur;
+      if (!cfg.ln_first) {
+        GRAB(q);
+        MX(colln_bwd(stream, b.l.y, P(a.ln_g), b.l.mean, b.l.rstd, gbuf[cur], gbuf[q], Gm(a.ln_g), Gm(a.ln_b), B, ol, (int)C));
+        release(cur);
+        i_dy = q;
+      }
+      const float* dy = gbuf[i_dy];
+      int i_dym = i_dy;
+      if (pl > 0.f) {
+        GRAB(q);
+        HIPX(hipMemcpyAsync(gbuf[q], dy, sizeof(float) * B * ol * C, hipMemcpyDeviceToDevice, stream));
+        MX(dropout_inplace(stream, gbuf[q], (long)B * ol * C, pl, key(), 10 + 3 * i));
+        i_dym = q;
+      }
+      const float* dym = gbuf[i_dym];
+      // dW2[ol,hl] += sum_b dYm_b[ol,C] . H_b[hl,C]^T
+      { GemmDesc g; g.A = dym; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;
+        g.B = b.l.h; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)hl * C;
+        g.C = Gm(a.fc2.w); g.sc_m = hl; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = hl; g.K = (int)C; g.batch = B; g.atomic = 1;
+        MX(G_(g)); }
+      if (a.fc2.b >= 0) MX(rowsum_batched(stream, dym, B, ol, (int)C, Gm(a.fc2.b)));
+      if (a.res >= 0) {
+        GemmDesc g; g.A = dy; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;
+        g.B = xblk; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
+        g.C = Gm(a.res); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
+        MX(G_(g));
+      }
+      GRAB(i_du);                                            // dU_b[hl,C] = (W2^T . dYm_b) * act'(U)
+      { GemmDesc g; g.A = P(a.fc2.w); g.sa_m = 1; g.sa_k = hl; g.sa_b = 0;
+        g.B = dym; g.sb_k = C; g.sb_n = 1; g.sb_b = (long)ol * C;
+        g.C = gbuf[i_du]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)hl * C; g.M = hl; g.N = (int)C; g.K = ol; g.batch = B;
+        g.act = cfg.activation; g.gradact_u = b.l.u;
+        MX(G_(g)); }
+      if (i_dym != i_dy) release(i_dym);
+      { GemmDesc g; g.A = gbuf[i_du]; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)hl * C;
+        g.B = xmlp; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
+        g.C = Gm(a.fc1.w); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = hl; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
+        MX(G_(g)); }
+      if (a.fc1.b >= 0) MX(rowsum_batched(stream, gbuf[i_du], B, hl, (int)C, Gm(a.fc1.b)));
+      GRAB(i_dx0);                                           // dX_b[il,C] = W1^T . dU_b (+LN-first bwd) + Wr^T . dY_b
+      int i_dx = i_dx0;
+      { GemmDesc g; g.A = P(a.fc1.w); g.sa_m = 1; g.sa_k = il; g.sa_b = 0;
+        g.B = gbuf[i_du]; g.sb_k = C; g.sb_n = 1; g.sb_b = (long)hl * C;
+        g.C = gbuf[i_dx]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)il * C; g.M = il; g.N = (int)C; g.K = hl; g.batch = B;
+        MX(G_(g)); }
+      if (cfg.ln_first) {
+        MX(colln_bwd(stream, xblk, P(a.ln_g), b.l.xn_mean, b.l.xn_rstd, gbuf[i_dx], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b), B, il, (int)C));
+        release(i_dx);
+        i_dx = i_du;
+      } else {
+        release(i_du);
+      }
+      if (a.res >= 0) {
+        GemmDesc g; g.A = P(a.res); g.sa_m = 1; g.sa_k = il; g.sa_b = 0;
+        g.B = dy; g.sb_k = C; g.sb_n = 1; g.sb_b = (long)ol * C;
+        g.C = gbuf[i_dx]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)il * C; g.M = il; g.N = (int)C; g.K = ol; g.batch = B; g.beta = 1.f;
+        MX(G_(g));
+      } else {
+        MX(add_inplace(stream, gbuf[i_dx], dy, (long)B * il * C));
+      }
+      release(i_dy);
+      cur = i_dx;
+    }
+  }
+#undef GRAB
+  *cur_out = cur;
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+// model backward (stage 2): needs dfeat (F,T,A,V contributions of the estimators) and dpred
+// =================================================================================================
+int mimrl_handle::model_backward() {
+  const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+  const long BT_ = (long)B * T;
+  const int nb = cfg.n_blocks;
+  const int ol = cfg.d_outs[nb - 1][0], ok = cfg.d_outs[nb - 1][1], od = cfg.d_outs[nb - 1][2];
+  // head backward -> gradient of the last cube output (in gbuf[0])
+  MX(head_bwd(stream, dfeat, dpred, P(cls_w), bufs.feats, gbuf[0], Gm(cls_w), Gm(cls_b), B, ol, ok, od,
+              cfg.compose_t_sum, cfg.compose_k_sum));
+  int ci = 0;
+  MX(cube_backward(0, &ci));
+  float* dcube = gbuf[ci];
+  // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T
+  MX(feat_mean_bwd(stream, dfeat + (size_t)B * D, dcube, B, T, L, 3, D));
+  // text branch: dW_t = dtx^T . text
+  MX(text_post_bwd(stream, dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0));
+  { GemmDesc g = gemm_tn(dtx, D, bufs.text, cfg.d_t, Gm(w_t), cfg.d_t, D, cfg.d_t, (int)BT_); g.atomic = 1; MX(G_(g)); }
+  // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
+  for (int m = 0; m < 2; ++m)
+    MX(ln_relu_drop_bwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dcube, ds[m], Gm(ln_g[m]),
+                        Gm(ln_b[m]), B, T, L, 3, D, 1 + m, cfg.dropout[1 + m], key(), 1 + m));
+  const float* xin[2] = {bufs.audio, bufs.video};
+  for (int l = 1; l >= 0; --l) {
+    GruBwdArgs a;
+    a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
+    a.dout_ld = l == 1 ? H : 2 * H; a.dout_off = l == 1 ? 0 : H;
+    for (int m = 0; m < 2; ++m) {
+      a.lens[m] = lens[m];
+      for (int d = 0; d < 2; ++d) {
+        const GruDirW& g = gru[m][l][d];
+        a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dgx[m][d],
+                                dgh[m][d], hprev[m][d]};
+      }
+    }
+    MX(gru_backward(stream, a, bf16));
+    for (int m = 0; m < 2; ++m) {
+      const float* in = l == 0 ? xin[m] : h0[m];
+      for (int d = 0; d < 2; ++d) {
+        const GruDirW& g = gru[m][l][d];
+        { GemmDesc q = gemm_tn(dgx[m][d], G, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_(q)); }
+        { GemmDesc q = gemm_tn(dgh[m][d], G, hprev[m][d], H, Gm(g.w_hh), H, G, H, (int)BT_); q.atomic = 1; MX(G_(q)); }
+        MX(colsum(stream, dgx[m][d], BT_, G, G, Gm(g.b_ih)));
+        MX(colsum(stream, dgh[m][d], BT_, G, G, Gm(g.b_hh)));
+        if (l == 1) {   // gradient to the layer-0 outputs: dh0 = sum_dir dgx_dir . W_ih_l1_dir
+          GemmDesc q = gemm_nn(dgx[m][d], G, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
+          q.beta = d == 0 ? 0.f : 1.f;
+          MX(G_(q));
+        }
+      }
+    }
+  }
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+// grouped MLP stacks (critic towers, concat-critic tail, CMI classifiers).  Activations are ReLU (Model.py:285).
+//   layer l:  A_{l+1} = relu?( A_l W_l^T + b_l ),  A_0 = in, last layer linear.
+// `brows` = rows between consecutive groups in the activation buffers (>= rows).
+// =================================================================================================
+int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
+                                    const int* dims, const float* in, float* const* act, float* out) {
+  for (int l = 0; l < nl; ++l) {
+    const int din_ = dims[l], dout_ = dims[l + 1];
+    GemmDesc g;
+    g.A = l == 0 ? in : act[l - 1]; g.sa_m = din_; g.sa_k = 1; g.sa_b = (long)brows * din_;
+    g.B = CP(p0 + l_off[l][0]); g.sb_k = 1; g.sb_n = din_; g.sb_b = pstride;
+    g.C = l == nl - 1 ? out : act[l]; g.sc_m = dout_; g.sc_n = 1; g.sc_b = (long)brows * dout_;
+    g.M = rows; g.N = dout_; g.K = din_; g.batch = nb;
+    g.bias_n = CP(p0 + l_off[l][1]); g.bias_n_b = pstride;
+    g.act = l == nl - 1 ? ACT_NONE : ACT_RELU;
+    MX(G_(g));
+  }
+  return MIMRL_OK;
+}
+
+int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
+                                     const int* dims, const float* in, float* const* act, float* dout, float* const* dtmp,
+                                     float* din, bool wgrad) {
+  float* dz = dout;
+  int pp = 0;
+  for (int l = nl - 1; l >= 0; --l) {
+    const int din_ = dims[l], dout_ = dims[l + 1];
+    const float* a_in = l == 0 ? in : act[l - 1];
+    if (wgrad) {   // dW_l = dZ^T A_l ; db_l = colsum(dZ)     (one writer per tensor: plain stores into the zeroed bucket)
+      GemmDesc g;
+      g.A = dz; g.sa_m = 1; g.sa_k = dout_; g.sa_b = (long)brows * dout_;
+      g.B = a_in; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
+      g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
+      g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
+      MX(G_(g));
+      MX(colsum(stream, dz, rows, dout_, dout_, CG(p0 + l_off[l][1]), nb, (long)brows * dout_, pstride));
+    }
+    float* target = l > 0 ? dtmp[pp] : din;
+    if (!target) break;
+    GemmDesc g;   // dA_l = dZ W_l
+    g.A = dz; g.sa_m = dout_; g.sa_k = 1; g.sa_b = (long)brows * dout_;
+    g.B = CP(p0 + l_off[l][0]); g.sb_k = din_; g.sb_n = 1; g.sb_b = pstride;
+    g.C = target; g.sc_m = din_; g.sc_n = 1; g.sc_b = (long)brows * din_;
+    g.M = rows; g.N = din_; g.K = dout_; g.batch = nb;
+    MX(G_(g));
+    if (l > 0) {
+      // relu backward against the saved post-activation; rows beyond `rows` inside a group are never read
+      MX(relu_bwd_inplace(stream, act[l - 1], target, (long)nb * brows * din_));
+      dz = target;
+      pp ^= 1;
+    }
+  }
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+int mimrl_handle::estimators_forward(int stage, bool want_grad) {
+  const int B = cfg.batch, n = nprod(), m = m_anchor(), k = cfg.k_neighbor;
+  const size_t BD = (size_t)B * EMB;
+  const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
+  {   // tower inputs: x operand -> slot 2e, y operand -> slot 2e+1
+    CopyTable t;
+    t.n = 10;
+    for (int e = 0; e < NE_MI; ++e)
+      for (int sd = 0; sd < 2; ++sd) {
+        t.src[e * 2 + sd] = bufs.feats + kMiWire[e][sd] * BD;
+        t.dst[e * 2 + sd] = tin + (e * 2 + sd) * BD;
+      }
+    MX(copy_rows(stream, t, (long)BD));
+  }
+  if (sep) {
+    const int dims[5] = {EMB, HID, HID, HID, EMB};
+    MX(mlp_stack_forward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, tout));
+    GemmDesc g;   // scores_e = h(y) g(x)^T   (VMI.py:55-57)
+    g.A = tout + BD; g.sa_m = EMB; g.sa_k = 1; g.sa_b = 2 * (long)BD;
+    g.B = tout; g.sb_k = 1; g.sb_n = EMB; g.sb_b = 2 * (long)BD;
+    g.C = scores; g.sc_m = B; g.sc_n = 1; g.sc_b = (long)B * B;
+    g.M = B; g.N = B; g.K = EMB; g.batch = NE_MI;
+    MX(G_(g));
+  } else {
+    // layer 0 in separable form: W0 [x|y] = W0x x + W0y y   (VMI.py:59-65: scores[i,j] = f(x_i, y_j))
+    GemmDesc gp;
+    gp.A = tin; gp.sa_m = EMB; gp.sa_k = 1; gp.sa_b = 2 * (long)BD;
+    gp.B = CP(tower0 + tower_l[0][0]); gp.sb_k = 1; gp.sb_n = 2 * EMB; gp.sb_b = tower_stride;
+    gp.C = cP; gp.sc_m = HID; gp.sc_n = 1; gp.sc_b = (long)B * HID;
+    gp.M = B; gp.N = HID; gp.K = EMB; gp.batch = NE_MI;
+    MX(G_(gp));
+    GemmDesc gq = gp;
+    gq.A = tin + BD; gq.B = CP(tower0 + tower_l[0][0]) + EMB; gq.C = cQ;
+    gq.bias_n = CP(tower0 + tower_l[0][1]); gq.bias_n_b = tower_stride;
+    MX(G_(gq));
+    MX(pair_expand_fwd(stream, cP, cQ, ca[0], NE_MI, B, HID));
+    const int dims[4] = {HID, HID, HID, 1};
+    MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
+  }
+  MX(mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, gs_mi(stage), NE_MI, B, cfg.bound_type));
+
+  // ---- CMI: kNN product sampling + classifier
+  const float* cur[5] = {bufs.feats, bufs.feats + BD, bufs.feats + 2 * BD, bufs.feats + 3 * BD, bufs.labels};
+  const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
+  const int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
+  KnnArgs ka;
+  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = knn_idx;
+  CmiAssembleArgs ca_;
+  ca_.anchors = anc; ca_.idx_x = knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
+  for (int e = 0; e < NE_CMI; ++e) {
+    const int z = kCmiWire[e][2];
+    ka.call[e].Z = bank[z]; ka.call[e].dz = z == FT_C ? 1 : EMB;
+    for (int o = 0; o < 3; ++o) {
+      const int f = kCmiWire[e][o];
+      ca_.op[e][o] = CmiOperand{cur[f], bank[f], f == FT_C ? 1 : 0};
+    }
+  }
+  MX(knn_sample(stream, ka));
+  MX(cmi_assemble(stream, ca_));
+  const int cdims[5] = {3 * EMB, HID, HID, HID, 2};
+  MX(mlp_stack_forward(NE_CMI, 2 * n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, logits));
+  MX(cmi_loss_fwd_bwd(stream, logits, want_grad ? dlogits : nullptr, bce_raw, cmi_raw, g_bce(stage), g_cmi(stage), NE_CMI,
+                      n, cfg.cmi_hardtanh));
+  return MIMRL_OK;
+}
+
+int mimrl_handle::estimators_backward(int stage) {
+  const int B = cfg.batch, n = nprod();
+  const size_t BD = (size_t)B * EMB;
+  const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
+  const bool wgrad = stage == 1;
+  float* din_mi = stage == 2 ? dtin : nullptr;
+  if (sep) {
+    GemmDesc gh;   // d h = dS g
+    gh.A = dscores; gh.sa_m = B; gh.sa_k = 1; gh.sa_b = (long)B * B;
+    gh.B = tout; gh.sb_k = EMB; gh.sb_n = 1; gh.sb_b = 2 * (long)BD;
+    gh.C = dtout + BD; gh.sc_m = EMB; gh.sc_n = 1; gh.sc_b = 2 * (long)BD;
+    gh.M = B; gh.N = EMB; gh.K = B; gh.batch = NE_MI;
+    MX(G_(gh));
+    GemmDesc gg = gh;   // d g = dS^T h
+    gg.sa_m = 1; gg.sa_k = B; gg.B = tout + BD; gg.C = dtout;
+    MX(G_(gg));
+    const int dims[5] = {EMB, HID, HID, HID, EMB};
+    MX(mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad));
+  } else {
+    const int dims[4] = {HID, HID, HID, 1};
+    MX(mlp_stack_backward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], dscores, dca,
+                          dca[0], wgrad));
+    MX(pair_expand_bwd(stream, ca[0], dca[0], dP, dQ, NE_MI, B, HID));
+    if (wgrad) {
+      GemmDesc g;   // dW0[:, :128] = dP^T x ; dW0[:, 128:] = dQ^T y ; db0 = colsum(dQ)
+      g.A = dP; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * HID;
+      g.B = tin; g.sb_k = EMB; g.sb_n = 1; g.sb_b = 2 * (long)BD;
+      g.C = CG(tower0 + tower_l[0][0]); g.sc_m = 2 * EMB; g.sc_n = 1; g.sc_b = tower_stride;
+      g.M = HID; g.N = EMB; g.K = B; g.batch = NE_MI;
+      MX(G_(g));
+      GemmDesc g2 = g;
+      g2.A = dQ; g2.B = tin + BD; g2.C = CG(tower0 + tower_l[0][0]) + EMB;
+      MX(G_(g2));
+      MX(colsum(stream, dQ, B, HID, HID, CG(tower0 + tower_l[0][1]), NE_MI, (long)B * HID, tower_stride));
+    } else {
+      GemmDesc g;   // dx = dP W0x ; dy = dQ W0y
+      g.A = dP; g.sa_m = HID; g.sa_k = 1; g.sa_b = (long)B * HID;
+      g.B = CP(tower0 + tower_l[0][0]); g.sb_k = 2 * EMB; g.sb_n = 1; g.sb_b = tower_stride;
+      g.C = dtin; g.sc_m = EMB; g.sc_n = 1; g.sc_b = 2 * (long)BD;
+      g.M = B; g.N = EMB; g.K = HID; g.batch = NE_MI;
+      MX(G_(g));
+      GemmDesc g2 = g;
+      g2.A = dQ; g2.B = CP(tower0 + tower_l[0][0]) + EMB; g2.C = dtin + BD;
+      MX(G_(g2));
+    }
+  }
+  const int cdims[5] = {3 * EMB, HID, HID, HID, 2};
+  if (wgrad) {
+    MX(mlp_stack_backward(NE_CMI, 2 * n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, dlogits, dcc, nullptr, true));
+  } else {
+    // only the n joint rows carry gradient to the model (the product rows come from the detached banks)
+    MX(mlp_stack_backward(NE_CMI, n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, dlogits, dcc, dcin, false));
+    // route input gradients back to F_F, T_F, A_F, V_F (deterministic gather-sum)
+    for (int f = 0; f < 4; ++f) {
+      GatherSum gs;
+      gs.n = 0;
+      for (int e = 0; e < NE_MI; ++e)
+        for (int sd = 0; sd < 2; ++sd)
+          if (kMiWire[e][sd] == f) {
+            gs.src[gs.n] = dtin + (e * 2 + sd) * BD; gs.ld[gs.n] = EMB; gs.off[gs.n] = 0; gs.rows[gs.n] = B; ++gs.n;
+          }
+      for (int e = 0; e < NE_CMI; ++e)
+        for (int o = 0; o < 3; ++o)
+          if (kCmiWire[e][o] == f) {
+            gs.src[gs.n] = dcin + (size_t)e * 2 * n * 384; gs.ld[gs.n] = 384; gs.off[gs.n] = o * EMB; gs.rows[gs.n] = n; ++gs.n;
+          }
+      MX(gather_sum(stream, dfeat + f * BD, gs, B, EMB, 0));
+    }
+  }
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+// stage drivers
+// =================================================================================================
+int mimrl_handle::enqueue_grads(int stage) {
+  const int B = cfg.batch;
+  const bool have_banks = bank_rows > 0;
+  if (stage == 1) {
+    hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, have_banks ? d_ints + 2 : nullptr,
+                       bufs.scalars, 0, 32);
+    LAUNCH_CHECK();
+    HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));
+    if (!have_banks) return MIMRL_OK;   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
+    MX(model_forward(true, false));
+    MX(estimators_forward(1, true));
+    MX(estimators_backward(1));
+    hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
+  hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
+  LAUNCH_CHECK();
+  HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
+  MX(model_forward(true, true));
+  hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
+  LAUNCH_CHECK();
+  if (have_banks) {
+    MX(estimators_forward(2, true));
+    MX(estimators_backward(2));
+  } else {
+    HIPX(hipMemsetAsync(dfeat, 0, sizeof(float) * 4 * B * EMB, stream));
+  }
+  hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, coef2(),
+                     have_banks ? 1 : 0);
+  LAUNCH_CHECK();
+  MX(model_backward());
+  return MIMRL_OK;
+}
+
+int mimrl_handle::enqueue_apply(int stage) {
+  if (stage == 1 && bank_rows <= 0) return MIMRL_OK;
+  AdamArgs a;
+  if (stage == 1) {
+    a.p = bufs.crit_p; a.g = bufs.crit_g; a.m = bufs.crit_m; a.v = bufs.crit_v; a.n = layout.floats[MIMRL_GROUP_CRITIC];
+    a.lr = bufs.lr_critic; a.step = d_ints + 2;
+  } else {
+    a.p = bufs.main_p; a.g = bufs.main_g; a.m = bufs.main_m; a.v = bufs.main_v; a.n = layout.floats[MIMRL_GROUP_MAIN];
+    a.lr = bufs.lr_main; a.step = d_ints + 1;
+  }
+  a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
+  return adam_step(stream, a);
+}
+
+// kind 0: grads + apply (single-GPU step); kind 1: grads only; kind 2: apply only (never captured: one kernel)
+int mimrl_handle::run(int stage, int kind) {
+  if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
+  if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
+  if (kind == 2) return enqueue_apply(stage);
+  auto body = [&]() -> int {
+    MX(enqueue_grads(stage));
+    if (kind == 0) MX(enqueue_apply(stage));
+    return MIMRL_OK;
+  };
+  if (!cfg.use_graph) return body();
+  hipGraphExec_t& ex = graph[stage][kind];
+  if (ex && graph_rows[stage][kind] != bank_rows) {   // bank size is baked into the kernel arguments
+    HIPX(hipGraphExecDestroy(ex));
+    ex = nullptr;
+  }
+  if (!ex) {
+    hipGraph_t g = nullptr;
+    HIPX(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const int r = body();
+    const hipError_t ce = hipStreamEndCapture(stream, &g);
+    if (r != 0) { if (g) hipGraphDestroy(g); return r; }
+    if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    graph_rows[stage][kind] = bank_rows;
+  }
+  HIPX(hipGraphLaunch(ex, stream));
+  return MIMRL_OK;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* mimrl_last_error(void) { return mimrl::last_error_slot().c_str(); }
+int mimrl_abi_version(void) { return MIMRL_ABI_VERSION; }
+
+int mimrl_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_error(MIMRL_ERR_NODEVICE, "no HIP device visible");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return set_error(MIMRL_ERR_NODEVICE, "hipGetDevice failed");
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return set_error(MIMRL_ERR_NODEVICE, "hipGetDeviceProperties failed");
+  if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
+    return set_error(MIMRL_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, p.gcnArchName);
+  return MIMRL_OK;
+}
+
+int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
+  if (!cfg || !out) return set_error(MIMRL_ERR_ARG, "null argument");
+  *out = nullptr;
+  MX(validate_cfg(*cfg));
+  if (cfg->batch > 1024) return set_error(MIMRL_ERR_ARG, "batch per rank must be <= 1024");
+  MX(mimrl_device_check());
+  mimrl_handle* h = new (std::nothrow) mimrl_handle();
+  if (!h) return set_error(MIMRL_ERR_STATE, "out of host memory");
+  h->cfg = *cfg;
+  if (h->cfg.beta1 == 0.f) h->cfg.beta1 = 0.9f;
+  if (h->cfg.beta2 == 0.f) h->cfg.beta2 = 0.999f;
+  if (h->cfg.adam_eps == 0.f) h->cfg.adam_eps = 1e-8f;
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  h->bf16 = cfg->precision == MIMRL_PREC_BF16;
+  std::memset(&h->bufs, 0, sizeof h->bufs);
+  int r = build_layout(h->cfg, &h->layout);
+  if (r == 0) r = h->resolve();
+  if (r == 0) r = h->alloc_workspace();
+  if (r != 0) { mimrl_destroy(h); return r; }
+  *out = h;
+  return MIMRL_OK;
+}
+
+int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
+  if (!h || !b) return set_error(MIMRL_ERR_ARG, "null argument");
+  const void* need[] = {b->main_p, b->main_g, b->main_m, b->main_v, b->crit_p, b->crit_g, b->crit_m, b->crit_v,
+                        b->text, b->audio, b->video, b->labels, b->lr_main, b->lr_critic, b->pred, b->feats, b->scalars};
+  for (const void* p : need)
+    if (!p) return set_error(MIMRL_ERR_ARG, "mimrl_bind: a required buffer is null");
+  h->bufs = *b;
+  h->bound = true;
+  for (int s = 1; s <= 2; ++s)
+    for (int k = 0; k < 2; ++k)
+      if (h->graph[s][k]) { hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  return MIMRL_OK;
+}
+
+int mimrl_set_bank_rows(mimrl_handle* h, int rows) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if (rows < 0 || rows > h->cfg.bank_capacity) return set_error(MIMRL_ERR_ARG, "bank rows %d outside [0,%d]", rows, h->cfg.bank_capacity);
+  if (rows > 0) {
+    if (!h->bufs.bank_c || !h->bufs.bank_f || !h->bufs.bank_t || !h->bufs.bank_a || !h->bufs.bank_v || !h->bufs.anchors)
+      return set_error(MIMRL_ERR_STATE, "banks/anchors must be bound before enabling them");
+    if (rows - h->m_anchor() < h->cfg.k_neighbor)
+      return set_error(MIMRL_ERR_ARG, "bank of %d rows is too small for %d anchors and k=%d", rows, h->m_anchor(), h->cfg.k_neighbor);
+  }
+  h->bank_rows = rows;
+  return MIMRL_OK;
+}
+
+int mimrl_stage1_step(mimrl_handle* h) { return h ? h->run(1, 0) : set_error(MIMRL_ERR_ARG, "null handle"); }
+int mimrl_stage2_step(mimrl_handle* h) { return h ? h->run(2, 0) : set_error(MIMRL_ERR_ARG, "null handle"); }
+int mimrl_stage_grads(mimrl_handle* h, int stage) { return h ? h->run(stage, 1) : set_error(MIMRL_ERR_ARG, "null handle"); }
+int mimrl_stage_apply(mimrl_handle* h, int stage) { return h ? h->run(stage, 2) : set_error(MIMRL_ERR_ARG, "null handle"); }
+
+int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ints, (int*)nullptr, h->bufs.scalars, 32, 32);
+  LAUNCH_CHECK();
+  MX(h->model_forward(train_mode != 0, false));
+  if (!with_losses) return MIMRL_OK;
+  hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, h->stream, h->bufs.pred, h->bufs.labels, (float*)nullptr,
+                     h->bufs.scalars + MIMRL_S2_TASK, h->cfg.batch);
+  LAUNCH_CHECK();
+  if (h->bank_rows > 0) MX(h->estimators_forward(2, false));
+  hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, h->stream, h->bufs.scalars, h->mi_raw, h->cmi_raw,
+                     h->coef2(), h->bank_rows > 0 ? 1 : 0);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int64_t mimrl_workspace_bytes(const mimrl_handle* h) { return h ? (int64_t)h->ws_bytes : 0; }
+
+void mimrl_destroy(mimrl_handle* h) {
+  if (!h) return;
+  for (int s = 1; s <= 2; ++s)
+    for (int k = 0; k < 2; ++k)
+      if (h->graph[s][k]) hipGraphExecDestroy(h->graph[s][k]);
+  if (h->ws) hipFree(h->ws);
+  delete h;
+}
+
+// ---- operator-level entry points ------------------------------------------------------------
+int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch,
+                  const int64_t st[9], const float* bias_n, const float* bias_m, float alpha, float beta, int act,
+                  int precision) {
+  if (!st) return set_error(MIMRL_ERR_ARG, "null strides");
+  GemmDesc d;
+  d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.batch = batch;
+  d.sa_m = st[0]; d.sa_k = st[1]; d.sa_b = st[2]; d.sb_k = st[3]; d.sb_n = st[4]; d.sb_b = st[5];
+  d.sc_m = st[6]; d.sc_n = st[7]; d.sc_b = st[8];
+  d.bias_n = bias_n; d.bias_m = bias_m; d.alpha = alpha; d.beta = beta; d.act = act;
+  return gemm(reinterpret_cast<hipStream_t>(stream), d, precision == MIMRL_PREC_BF16);
+}
+
+int64_t mimrl_op_gru_saved_floats(int B, int T) { return gru_saved_floats(B, T); }
+
+int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
+                         const float* bhh_f, const float* bhh_r, const int32_t* lens, float* out, float* saved_f,
+                         float* saved_r, int B, int T, int precision) {
+  GruFwdArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 1;
+  a.lens[0] = lens; a.lens[1] = lens;
+  a.seq[0][0] = GruSeq{gx_f, whh_f, bhh_f, out, saved_f};
+  a.seq[0][1] = GruSeq{gx_r, whh_r, bhh_r, out, saved_r};
+  return gru_forward(reinterpret_cast<hipStream_t>(stream), a, precision == MIMRL_PREC_BF16);
+}
+
+int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, const float* saved_f,
+                          const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dgx_f,
+                          float* dgx_r, float* dgh_f, float* dgh_r, float* hprev_f, float* hprev_r, int B, int T,
+                          int precision) {
+  GruBwdArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.B = B; a.T = T; a.out_ld = 2 * H; a.dout_ld = 2 * H; a.dout_off = H; a.nmod = 1;
+  a.lens[0] = lens; a.lens[1] = lens;
+  a.seq[0][0] = GruSeqBwd{whh_f, saved_f, out, dout, dgx_f, dgh_f, hprev_f};
+  a.seq[0][1] = GruSeqBwd{whh_r, saved_r, out, dout, dgx_r, dgh_r, hprev_r};
+  return gru_backward(reinterpret_cast<hipStream_t>(stream), a, precision == MIMRL_PREC_BF16);
+}
+
+int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
+                      int bound) {
+  return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, gscale, E, B, bound);
+}
+
+int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out) {
+  KnnArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.call[0] = KnnCall{Z, dz};
+  a.anchors = anchors; a.idx_x = idx_out; a.N = N; a.m = m; a.k = k; a.ncall = 1;
+  return knn_sample(reinterpret_cast<hipStream_t>(stream), a);
+}
+
+int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
+                      const float* g_cmi, int E, int n, int hardtanh) {
+  return cmi_loss_fwd_bwd(reinterpret_cast<hipStream_t>(stream), logits, dlogits, bce, cmi, g_bce, g_cmi, E, n, hardtanh);
+}
+
+int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,
+                  float beta1, float beta2, float eps, float weight_decay, float clip) {
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.step = step;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.clip = clip;
+  return adam_step(reinterpret_cast<hipStream_t>(stream), a);
+}
+
+}  // extern "C"

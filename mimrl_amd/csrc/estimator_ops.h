@@ -1,0 +1,66 @@
+// Kernels of the 5 variational-MI and 6 classifier-CMI estimators (VMI.py:53-69,162-166; Model.py:75-225,305-386).
+#pragma once
+#include "common.h"
+
+namespace mimrl {
+
+enum Bound : int { BOUND_INFONCE = 0, BOUND_NWJ = 1, BOUND_TUBA = 2, BOUND_DV = 3, BOUND_JS_FGAN = 4, BOUND_JS = 5,
+                   BOUND_SMILE = 6 };
+
+// copy rows:  dst[i][b,:] = src[i][b,:]   for i < n (table of pointers; used to gather tower inputs)
+struct CopyTable { const float* src[16]; float* dst[16]; int n; };
+int copy_rows(hipStream_t s, const CopyTable& t, long floats_each);
+
+// scores [E][B][B] -> mi[e] (bound value) and dscores = gscale[e] * d(mi)/d(scores)   (one workgroup / estimator)
+// gscale lives in device memory (loss coefficient with sign); dscores may be null (evaluation only).
+int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
+                     int bound);
+
+// concat critic layer 1:  a1[(i*B+j), c] = relu(P[i,c] + Q[j,c])     P = x Wx^T, Q = y Wy^T + b   (VMI.py:59-65)
+int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, int E, int B, int Hd);
+// da1 (in place -> du1 = da1 * (a1>0)), then dP[i,c] = sum_j du1, dQ[j,c] = sum_i du1
+int pair_expand_bwd(hipStream_t s, const float* a1, float* da1, float* dP, float* dQ, int E, int B, int Hd);
+// relu backward in place: g *= (a > 0)
+int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n);
+
+// exact kNN product sampler (Model.py:75-106): for call c and anchor a: the k nearest non-anchor rows of Z.
+struct KnnCall { const float* Z; int dz; };
+struct KnnArgs {
+  KnnCall call[6];
+  const int* anchors;   // [6][m]
+  int* idx_x;           // [6][m*k]   nearest first, anchor-major
+  int N, m, k, ncall;
+};
+int knn_sample(hipStream_t s, const KnnArgs& a);
+
+// classifier input batch (Model.py:160-174):
+//   rows [0,n): joint = [x | y | z] of the current batch (operand = feature block [B,128] or the label column)
+//   rows [n,2n): prod  = [X[idx_x[j]] | Y[anchor[j/k]] | Z[anchor[j/k]]] from the banks (label bank tiled x128)
+struct CmiOperand { const float* cur; const float* bank; int is_label; };   // cur: [B,128] or labels [B]; bank: [N,128] or [N,1]
+struct CmiAssembleArgs {
+  CmiOperand op[6][3];
+  const int* anchors;   // [6][m]
+  const int* idx_x;     // [6][n]
+  float* out;           // [6][2n][384]
+  int n, m, k, ncall;
+};
+int cmi_assemble(hipStream_t s, const CmiAssembleArgs& a);
+
+// logits [E][2n][2] -> bce[e], cmi[e]; dlogits = g_bce[e]*dBCE/dlogit + g_cmi[e]*dCMI/dlogit   (Model.py:65-72,198-219)
+int cmi_loss_fwd_bwd(hipStream_t s, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
+                     const float* g_cmi, int E, int n, int hardtanh);
+
+// dst[b,:] (+)= sum_i src_i[b*ld_i + off_i + :]  for rows b < rows_i   (deterministic gather-sum of input gradients)
+struct GatherSum { const float* src[12]; int ld[12]; int off[12]; int rows[12]; int n; };
+int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int accumulate);
+
+// fused gradient value-clip + Adam over one flat bucket (Solver.py:144-146,211-213; torch.optim.Adam semantics)
+struct AdamArgs {
+  float* p; float* g; float* m; float* v; long n;
+  const float* lr;        // device scalar (schedulers rewrite it between epochs)
+  const int* step;        // device counter, already incremented for this update
+  float beta1, beta2, eps, weight_decay, clip;
+};
+int adam_step(hipStream_t s, const AdamArgs& a);
+
+}  // namespace mimrl

@@ -1,0 +1,400 @@
+// Estimator-side kernels (see estimator_ops.h for reference citations).
+#include "estimator_ops.h"
+
+namespace mimrl {
+
+namespace {
+
+inline int grid_for(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__global__ void copy_rows_kernel(CopyTable t, long n) {
+  const int i = blockIdx.y;
+  const float* __restrict__ s = t.src[i];
+  float* __restrict__ d = t.dst[i];
+  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) d[j] = s[j];
+}
+
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+
+// ------------------------------------------------------------------------------------------------
+// MI bounds on a [B,B] score matrix; one 1024-thread workgroup per estimator, deterministic reductions.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict__ scores, float* __restrict__ dscores,
+                                                        float* __restrict__ mi, const float* __restrict__ gscale, int B,
+                                                        int bound) {
+  __shared__ float red[16];
+  __shared__ float rowstat[1024];   // per-row lse (InfoNCE); B <= 1024
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+  const float* __restrict__ S = scores + (long)e * B * B;
+  float* __restrict__ dS = dscores ? dscores + (long)e * B * B : nullptr;
+  const float gs = gscale ? gscale[e] : 0.f;
+  const float invB = 1.f / B;
+
+  if (bound == BOUND_INFONCE) {
+    // mi = log B + mean_i( s_ii - logsumexp_j s_ij )                       (VMI.py:162-166)
+    float part = 0.f;
+    for (int i = w; i < B; i += nw) {
+      float mx = -INFINITY;
+      for (int j = lane; j < B; j += 64) mx = fmaxf(mx, S[(long)i * B + j]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int j = lane; j < B; j += 64) se += __expf(S[(long)i * B + j] - mx);
+      se = wave_sum(se);
+      const float lse = mx + __logf(se);
+      if (lane == 0) { rowstat[i] = lse; part += S[(long)i * B + i] - lse; }
+    }
+    const float tot = block_sum(part, red);
+    if (tid == 0) mi[e] = __logf((float)B) + tot * invB;
+    if (dS) {
+      __syncthreads();
+      for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+        const int i = idx / B, j = idx % B;
+        const float pij = __expf(S[idx] - rowstat[i]);
+        dS[idx] = gs * invB * ((i == j ? 1.f : 0.f) - pij);
+      }
+    }
+    return;
+  }
+
+  // ---- bounds built from diag mean / off-diagonal log-mean-exp / softplus sums      (VMI.py:121-198)
+  const float shift = (bound == BOUND_NWJ || bound == BOUND_JS) ? 1.f : 0.f;
+  const bool clipped = bound == BOUND_SMILE;
+  auto tr = [&](float v) { v -= shift; return clipped ? fminf(fmaxf(v, -1.f), 1.f) : v; };
+  float mx = -INFINITY;
+  for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+    const int i = idx / B, j = idx % B;
+    if (i != j) mx = fmaxf(mx, tr(S[idx]));
+  }
+  mx = block_max(mx, red);
+  float se = 0.f, dsum = 0.f, sp_all = 0.f, sp_diag = 0.f, nsp_diag = 0.f;
+  for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+    const int i = idx / B, j = idx % B;
+    const float v = S[idx];
+    sp_all += softplus_f(v);
+    if (i == j) { dsum += v; sp_diag += softplus_f(v); nsp_diag += -softplus_f(-v); }
+    else se += __expf(tr(v) - mx);
+  }
+  se = block_sum(se, red);
+  dsum = block_sum(dsum, red);
+  sp_all = block_sum(sp_all, red);
+  sp_diag = block_sum(sp_diag, red);
+  nsp_diag = block_sum(nsp_diag, red);
+  const float M = (float)B * (B - 1.f);
+  const float lme = mx + __logf(se) - __logf(M);             // logmeanexp_nodiag
+  const float dmean = dsum * invB;
+  const float js = nsp_diag * invB - (sp_all - sp_diag) / M;  // js_fgan_lower_bound
+  float val;
+  switch (bound) {
+    case BOUND_TUBA: val = 1.f + dmean - __expf(lme); break;
+    case BOUND_NWJ: val = 1.f + (dmean - 1.f) - __expf(lme); break;
+    case BOUND_DV: val = dmean - lme; break;
+    case BOUND_JS_FGAN: val = js; break;
+    case BOUND_JS: val = 1.f + (dmean - 1.f) - __expf(lme); break;        // value of nwj, gradient of js
+    default: val = dmean - lme; break;                                    // SMILE: value dv(clamped lme), gradient js
+  }
+  if (tid == 0) mi[e] = val;
+  if (!dS) return;
+  for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+    const int i = idx / B, j = idx % B;
+    const float v = S[idx];
+    float g;
+    if (bound == BOUND_TUBA || bound == BOUND_NWJ) g = (i == j) ? invB : -__expf(v - shift) / M;
+    else if (bound == BOUND_DV) g = (i == j) ? invB : -__expf(v - mx) / se;
+    else g = (i == j) ? sigmoid_f(-v) * invB : -sigmoid_f(v) / M;          // js_fgan / js / smile
+    dS[idx] = gs * g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// concat critic, first layer in its separable form
+// ------------------------------------------------------------------------------------------------
+__global__ void pair_expand_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q, float* __restrict__ a1,
+                                       int B, int Hd) {
+  const int i = blockIdx.x, e = blockIdx.y;
+  const float* p = P + ((long)e * B + i) * Hd;
+  const float* q = Q + (long)e * B * Hd;
+  float* out = a1 + ((long)e * B + i) * B * Hd;
+  for (long idx = threadIdx.x; idx < (long)B * Hd; idx += blockDim.x) {
+    const float v = p[idx % Hd] + q[idx];
+    out[idx] = v > 0.f ? v : 0.f;
+  }
+}
+// du1 = da1 * (a1 > 0) in place;  dP[i,c] = sum_j du1[i,j,c]
+__global__ void pair_reduce_p_kernel(const float* __restrict__ a1, float* __restrict__ da1, float* __restrict__ dP, int B,
+                                     int Hd) {
+  const int i = blockIdx.x, e = blockIdx.y;
+  const float* a = a1 + ((long)e * B + i) * B * Hd;
+  float* g = da1 + ((long)e * B + i) * B * Hd;
+  for (int c = threadIdx.x; c < Hd; c += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < B; ++j) {
+      const long o = (long)j * Hd + c;
+      const float v = a[o] > 0.f ? g[o] : 0.f;
+      g[o] = v;
+      s += v;
+    }
+    dP[((long)e * B + i) * Hd + c] = s;
+  }
+}
+__global__ void pair_reduce_q_kernel(const float* __restrict__ du1, float* __restrict__ dQ, int B, int Hd) {
+  const int j = blockIdx.x, e = blockIdx.y;
+  const float* g = du1 + (long)e * B * B * Hd + (long)j * Hd;
+  for (int c = threadIdx.x; c < Hd; c += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) s += g[(long)i * B * Hd + c];
+    dQ[((long)e * B + j) * Hd + c] = s;
+  }
+}
+__global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__ g, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    if (!(a[i] > 0.f)) g[i] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact kNN among non-anchor rows; one workgroup per (anchor, call)
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_KMAX = 8;
+
+struct TopK {
+  float d[KNN_KMAX];
+  int i[KNN_KMAX];
+  __device__ void init() {
+#pragma unroll
+    for (int q = 0; q < KNN_KMAX; ++q) { d[q] = INFINITY; i[q] = 0x7fffffff; }
+  }
+  __device__ void push(float dist, int idx, int k) {
+    // keep ascending (dist, idx); insertion with static indexing
+    float cd = dist; int ci = idx;
+#pragma unroll
+    for (int q = 0; q < KNN_KMAX; ++q) {
+      if (q < k) {
+        const bool lt = cd < d[q] || (cd == d[q] && ci < i[q]);
+        if (lt) { const float td = d[q]; const int ti = i[q]; d[q] = cd; i[q] = ci; cd = td; ci = ti; }
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void knn_kernel(KnnArgs a) {
+  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask, then candidate lists
+  const int ai = blockIdx.x, c = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nwords = (a.N + 31) / 32;
+  unsigned* mask = smem;
+  float* cd = reinterpret_cast<float*>(smem + nwords);
+  int* ci = reinterpret_cast<int*>(cd + 256 * KNN_KMAX);
+  for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
+  __syncthreads();
+  const int* anc = a.anchors + (long)c * a.m;
+  for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
+  __syncthreads();
+  const float* Z = a.call[c].Z;
+  const int dz = a.call[c].dz;
+  const int me = anc[ai];
+  TopK tk; tk.init();
+  int nlists;
+  if (dz == 1) {
+    const float z0 = Z[me];
+    for (int r = tid; r < a.N; r += 256) {
+      if (mask[r >> 5] >> (r & 31) & 1u) continue;
+      const float df = Z[r] - z0;
+      tk.push(df * df, r, a.k);
+    }
+    nlists = 256;
+#pragma unroll
+    for (int q = 0; q < KNN_KMAX; ++q) { cd[tid * KNN_KMAX + q] = tk.d[q]; ci[tid * KNN_KMAX + q] = tk.i[q]; }
+  } else {
+    // wave per row, lanes over dims (coalesced row reads)
+    float zr[4];
+    const int per = (dz + 63) / 64;           // dz <= 256
+    for (int q = 0; q < per; ++q) { const int j = lane + 64 * q; zr[q] = j < dz ? Z[(long)me * dz + j] : 0.f; }
+    for (int r = w; r < a.N; r += 4) {
+      if (mask[r >> 5] >> (r & 31) & 1u) continue;
+      float s = 0.f;
+      for (int q = 0; q < per; ++q) {
+        const int j = lane + 64 * q;
+        const float df = (j < dz ? Z[(long)r * dz + j] : 0.f) - zr[q];
+        s += df * df;
+      }
+      s = wave_sum(s);
+      tk.push(s, r, a.k);
+    }
+    nlists = 4;
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < KNN_KMAX; ++q) { cd[w * KNN_KMAX + q] = tk.d[q]; ci[w * KNN_KMAX + q] = tk.i[q]; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    TopK fin; fin.init();
+    for (int l = 0; l < nlists; ++l)
+      for (int q = 0; q < a.k; ++q) fin.push(cd[l * KNN_KMAX + q], ci[l * KNN_KMAX + q], a.k);
+    for (int q = 0; q < a.k; ++q) a.idx_x[((long)c * a.m + ai) * a.k + q] = fin.i[q];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void cmi_assemble_kernel(CmiAssembleArgs a) {
+  const int row = blockIdx.x, c = blockIdx.y;
+  float* out = a.out + ((long)c * 2 * a.n + row) * 384;
+  for (int col = threadIdx.x; col < 384; col += blockDim.x) {
+    const int part = col >> 7, j = col & 127;
+    const CmiOperand& op = a.op[c][part];
+    float v;
+    if (row < a.n) {
+      v = op.is_label ? op.cur[row] : op.cur[(long)row * 128 + j];
+    } else {
+      const int jj = row - a.n;
+      const int src = part == 0 ? a.idx_x[(long)c * a.n + jj] : a.anchors[(long)c * a.m + jj / a.k];
+      v = op.is_label ? op.bank[src] : op.bank[(long)src * 128 + j];
+    }
+    out[col] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cmi_loss_kernel(const float* __restrict__ logits, float* __restrict__ dlogits,
+                                                       float* __restrict__ bce, float* __restrict__ cmi,
+                                                       const float* __restrict__ g_bce, const float* __restrict__ g_cmi,
+                                                       int n, int hardtanh) {
+  __shared__ float red[16];
+  const int e = blockIdx.x;
+  const float* L = logits + (long)e * 2 * n * 2;
+  float* dL = dlogits ? dlogits + (long)e * 2 * n * 2 : nullptr;
+  const float gb = g_bce ? g_bce[e] : 0.f, gc = g_cmi ? g_cmi[e] : 0.f;
+  float sb = 0.f, s1 = 0.f, s2 = 0.f;
+  const float inv4n = 1.f / (4.f * n), inv2n = 1.f / (2.f * n);
+  for (int r = threadIdx.x; r < 2 * n; r += blockDim.x) {
+    const bool joint = r < n;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float raw = L[r * 2 + c];
+      const float o = fminf(fmaxf(raw, -10.f), 10.f);                  // Model.py:69
+      const bool pass = raw >= -10.f && raw <= 10.f;
+      float gam, dgo;
+      if (hardtanh) { gam = fminf(fmaxf(o, 1e-4f), 1.f - 1e-4f); dgo = (o > 1e-4f && o < 1.f - 1e-4f) ? 1.f : 0.f; }
+      else { gam = sigmoid_f(o); dgo = gam * (1.f - gam); }
+      const float t = (joint ? (c == 0) : (c == 1)) ? 1.f : 0.f;       // Model.py:176-178
+      const float lg = fmaxf(__logf(gam), -100.f), l1g = fmaxf(__logf(1.f - gam), -100.f);
+      sb += -(t * lg + (1.f - t) * l1g);
+      float dgam = gb * (-(t / gam - (1.f - t) / (1.f - gam)) * inv4n);
+      if (c == 0) {
+        const float lr = __logf(gam / (1.f - gam + 1e-6f));            // Model.py:215-216
+        if (joint) s1 += lr; else s2 += lr;
+        dgam += gc * (joint ? inv2n : -inv2n) * (1.f / gam + 1.f / (1.f - gam + 1e-6f));
+      }
+      if (dL) dL[r * 2 + c] = pass ? dgam * dgo : 0.f;
+    }
+  }
+  sb = block_sum(sb, red);
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    bce[e] = sb * inv4n;
+    cmi[e] = 1.f + s1 * inv2n - s2 * inv2n;                            // Model.py:219 (divisor = stacked batch 2n)
+  }
+}
+
+__global__ void gather_sum_kernel(float* __restrict__ dst, GatherSum g, int B, int D, int accumulate) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * D; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / D, d = i % D;
+    float s = accumulate ? dst[i] : 0.f;
+    for (int q = 0; q < g.n; ++q)
+      if (b < g.rows[q]) s += g.src[q][(long)b * g.ld[q] + g.off[q] + d];
+    dst[i] = s;
+  }
+}
+
+__global__ void adam_kernel(AdamArgs a) {
+  const int t = *a.step;
+  const float lr = *a.lr;
+  const float bc1 = 1.f - powf(a.beta1, (float)t), bc2 = 1.f - powf(a.beta2, (float)t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    float g = a.g[i];
+    if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);             // clip_grad_value_ (Solver.py:211-212)
+    const float p = a.p[i];
+    if (a.weight_decay != 0.f) g += a.weight_decay * p;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m; a.v[i] = v;
+    a.p[i] = p - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+  }
+}
+
+}  // namespace
+
+int copy_rows(hipStream_t s, const CopyTable& t, long n) {
+  if (t.n <= 0) return MIMRL_OK;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(n, 256, 64), t.n), dim3(256), 0, s, t, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
+                     int bound) {
+  if (B > 1024) return set_error(MIMRL_ERR_ARG, "mi_bound: batch %d > 1024 per rank", B);
+  hipLaunchKernelGGL(mi_bound_kernel, dim3(E), dim3(1024), 0, s, scores, dscores, mi, gscale, B, bound);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, int E, int B, int Hd) {
+  hipLaunchKernelGGL(pair_expand_fwd_kernel, dim3(B, E), dim3(256), 0, s, P, Q, a1, B, Hd);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int pair_expand_bwd(hipStream_t s, const float* a1, float* da1, float* dP, float* dQ, int E, int B, int Hd) {
+  hipLaunchKernelGGL(pair_reduce_p_kernel, dim3(B, E), dim3(256), 0, s, a1, da1, dP, B, Hd);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(pair_reduce_q_kernel, dim3(B, E), dim3(256), 0, s, da1, dQ, B, Hd);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n) {
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, g, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int knn_sample(hipStream_t s, const KnnArgs& a) {
+  if (a.k > KNN_KMAX || a.k < 1) return set_error(MIMRL_ERR_ARG, "knn: k_neighbor must be in [1,%d]", KNN_KMAX);
+  if (a.N - a.m < a.k) return set_error(MIMRL_ERR_ARG, "knn: bank too small (N=%d, m=%d, k=%d)", a.N, a.m, a.k);
+  for (int c = 0; c < a.ncall; ++c)
+    if (a.call[c].dz != 1 && a.call[c].dz > 256) return set_error(MIMRL_ERR_ARG, "knn: feature width > 256");
+  const size_t sh = ((a.N + 31) / 32) * sizeof(unsigned) + 256 * KNN_KMAX * (sizeof(float) + sizeof(int));
+  hipLaunchKernelGGL(knn_kernel, dim3(a.m, a.ncall), dim3(256), sh, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int cmi_assemble(hipStream_t s, const CmiAssembleArgs& a) {
+  hipLaunchKernelGGL(cmi_assemble_kernel, dim3(2 * a.n, a.ncall), dim3(128), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int cmi_loss_fwd_bwd(hipStream_t s, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
+                     const float* g_cmi, int E, int n, int hardtanh) {
+  hipLaunchKernelGGL(cmi_loss_kernel, dim3(E), dim3(256), 0, s, logits, dlogits, bce, cmi, g_bce, g_cmi, n, hardtanh);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int accumulate) {
+  hipLaunchKernelGGL(gather_sum_kernel, dim3(grid_for((long)B * D)), dim3(256), 0, s, dst, g, B, D, accumulate);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int adam_step(hipStream_t s, const AdamArgs& a) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a.n, 256, 2048)), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+}  // namespace mimrl

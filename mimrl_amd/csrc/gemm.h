@@ -1,0 +1,51 @@
+// Generic strided / batched GEMM on the gfx950 matrix cores.
+//   C[b][m,n] = epilogue( alpha * sum_k A[b][m,k] * B[b][k,n] )
+// fp32 mode: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); bf16 mode: operands rounded to bf16 while they are
+// staged into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate.  All matrices are fp32 in HBM with arbitrary
+// element strides, so transposes, the L-axis mixes of CubeMLP (left-multiplication of a [L, K*D] sample tile)
+// and the grouped critic towers are all expressed as strides -- no data is ever physically permuted.
+#pragma once
+#include "common.h"
+
+namespace mimrl {
+
+struct GemmDesc {
+  const float* A = nullptr;
+  const float* B = nullptr;
+  float* C = nullptr;
+  int M = 0, N = 0, K = 0, batch = 1;
+  long sa_m = 0, sa_k = 0, sa_b = 0;
+  long sb_k = 0, sb_n = 0, sb_b = 0;
+  long sc_m = 0, sc_n = 0, sc_b = 0;
+  const float* bias_n = nullptr; long bias_n_b = 0;   // + bias_n[b*bias_n_b + n]
+  const float* bias_m = nullptr; long bias_m_b = 0;   // + bias_m[b*bias_m_b + m]
+  float alpha = 1.f;
+  float beta = 0.f;                  // + beta * C_old
+  int act = ACT_NONE;                // applied after bias/beta
+  float* pre = nullptr;              // optional: pre-activation copy (same strides as C)
+  const float* gradact_u = nullptr;  // optional: multiply by act'(u[m,n]) (same strides as C) -- backward of act
+  int atomic = 0;                    // C += result with float atomics (batch acts as an extra reduction when sc_b==0)
+};
+
+// A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T
+inline GemmDesc gemm_nt(const float* A, long lda, const float* W, long ldw, float* C, long ldc, int M, int N, int K) {
+  GemmDesc d; d.A = A; d.B = W; d.C = C; d.M = M; d.N = N; d.K = K;
+  d.sa_m = lda; d.sa_k = 1; d.sb_k = 1; d.sb_n = ldw; d.sc_m = ldc; d.sc_n = 1;
+  return d;
+}
+// C = A * B, A [M,K] (lda), B [K,N] (ldb)
+inline GemmDesc gemm_nn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K) {
+  GemmDesc d; d.A = A; d.B = Bm; d.C = C; d.M = M; d.N = N; d.K = K;
+  d.sa_m = lda; d.sa_k = 1; d.sb_k = ldb; d.sb_n = 1; d.sc_m = ldc; d.sc_n = 1;
+  return d;
+}
+// C = A^T * B, A stored [K,M] (lda), B [K,N] (ldb)   (weight gradients: dW = dY^T X)
+inline GemmDesc gemm_tn(const float* A, long lda, const float* Bm, long ldb, float* C, long ldc, int M, int N, int K) {
+  GemmDesc d; d.A = A; d.B = Bm; d.C = C; d.M = M; d.N = N; d.K = K;
+  d.sa_m = 1; d.sa_k = lda; d.sb_k = ldb; d.sb_n = 1; d.sc_m = ldc; d.sc_n = 1;
+  return d;
+}
+
+int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
+
+}  // namespace mimrl

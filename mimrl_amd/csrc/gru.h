@@ -1,0 +1,41 @@
+// Launch descriptors of the persistent bi-GRU recurrence kernels (gru.hip).
+#pragma once
+#include "common.h"
+
+namespace mimrl {
+
+struct GruSeq {
+  const float* gx;     // [B,T,3H]  x W_ih^T + b_ih  (hoisted input projection)
+  const float* w_hh;   // [3H,H]
+  const float* b_hh;   // [3H]
+  float* out;          // [B,T,out_ld]; this direction writes columns [dir*H, dir*H+H)
+  float* saved;        // gate slab for BPTT (gru_saved_floats(B,T) floats) or nullptr
+};
+
+struct GruFwdArgs {
+  GruSeq seq[2][2];        // [modality][direction]
+  const int* lens[2];      // [modality][B] valid lengths (packed-sequence semantics)
+  int B, T, out_ld, nmod;
+};
+
+struct GruSeqBwd {
+  const float* w_hh;   // [3H,H]
+  const float* saved;  // gate slab written by the forward kernel
+  const float* out;    // forward outputs [B,T,out_ld] (source of h_prev)
+  const float* dout;   // gradient w.r.t. this direction's outputs, [B,T,dout_ld] (+ dir*dout_off)
+  float* dgx;          // [B,T,3H]
+  float* dgh;          // [B,T,3H]
+  float* hprev;        // [B,T,H]  h_{prev} of every step (0 at sequence starts / padded steps): operand of dW_hh
+};
+
+struct GruBwdArgs {
+  GruSeqBwd seq[2][2];
+  const int* lens[2];
+  int B, T, out_ld, dout_ld, dout_off, nmod;
+};
+
+int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);
+int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16);
+long gru_saved_floats(int B, int T);
+
+}  // namespace mimrl

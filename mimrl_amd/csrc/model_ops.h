@@ -1,0 +1,74 @@
+// Non-GEMM kernels of Model.forward / backward (Model.py:388-519, MLPProcess.py:64-122): length inference,
+// LayerNorm(+ReLU+dropout) epilogues, temporal means, CubeMLP axis LayerNorms, the K-axis mix and the head.
+#pragma once
+#include "common.h"
+
+namespace mimrl {
+
+struct RngKey {            // dropout keying; `step` is read from device memory so that hipGraph replays advance it
+  uint32_t seed_lo, seed_hi;
+  const int* step;         // device counter (bumped by begin_stage)
+};
+
+// lens[b] = max(1, #rows t with sum_d |x[b,t,d]| != 0)                    (Model.py:425-432)
+int seq_lengths(hipStream_t s, const float* x, int B, int T, int d, int* lens);
+
+// cube[b,t,slot,:] = dropout(src[b,t,:])  (text branch, Model.py:461,475)
+int text_post_fwd(hipStream_t s, const float* src, float* cube, int B, int T, int L, int K, int D, int slot, float p,
+                  RngKey key, uint32_t stream_id);
+// dsrc[b,t,:] = dropout_mask * dcube[b,t,slot,:]
+int text_post_bwd(hipStream_t s, const float* dcube, float* dsrc, int B, int T, int L, int K, int D, int slot, float p,
+                  RngKey key, uint32_t stream_id);
+
+// cube[b,t,slot,:] = dropout(relu(LN(h[b,t,:H] + h[b,t,H:])))            (Model.py:452-461)
+int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, float* cube, float* mean,
+                     float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id);
+// ds[b,t,:] (gradient of the fwd+bwd sum) from dcube; accumulates dgamma/dbeta
+int ln_relu_drop_bwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, const float* dcube, float* ds, float* dgamma, float* dbeta, int B, int T, int L,
+                     int K, int D, int slot, float p, RngKey key, uint32_t stream_id);
+
+// feats[k][b,:] = mean_{t<T} cube[b,t,k,:]   (Model.py:466)   feats laid out [K][B][D]
+int feat_mean_fwd(hipStream_t s, const float* cube, float* feats, int B, int T, int L, int K, int D);
+// dcube[b,t,k,:] += dfeats[k][b,:]/T  for t<T
+int feat_mean_bwd(hipStream_t s, const float* dfeats, float* dcube, int B, int T, int L, int K, int D);
+
+// head: F_F[b,:] = compose_{l,k} x[b,l,k,:]; pred[b] = F_F.w + bias        (Model.py:489-515)
+int head_fwd(hipStream_t s, const float* x, const float* w, const float* bias, float* ff, float* pred, int B, int L,
+             int K, int D, int sum_l, int sum_k);
+// dx[b,l,k,:] = scale*(dff_ext[b,:] + dpred[b]*w);  dw += sum_b dpred[b]*ff[b,:];  dbias += sum_b dpred[b]
+int head_bwd(hipStream_t s, const float* dff_ext, const float* dpred, const float* w, const float* ff, float* dx,
+             float* dw, float* dbias, int B, int L, int K, int D, int sum_l, int sum_k);
+
+// ---- LayerNorm along the LAST axis of [R, n] rows (D-axis mix)
+int rowln_fwd(hipStream_t s, const float* y, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
+              long R, int n);
+int rowln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
+              float* dy, float* dgamma, float* dbeta, long R, int n);
+// ---- LayerNorm along the FIRST axis of per-sample [n, C] tiles (L-axis mix): stats per (b, c)
+int colln_fwd(hipStream_t s, const float* y, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
+              int B, int n, int C);
+int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
+              float* dy, float* dgamma, float* dbeta, int B, int n, int C);
+
+// ---- K-axis mix (tiny 3x3-class MLP + residual + LN over K), fully fused; x:[R,ik,D] -> z:[R,ok,D]
+struct KMixW {
+  const float *w1, *b1, *w2, *b2, *wr, *g, *be;   // b1/b2/wr may be null (no bias / identity residual)
+  float *dw1, *db1, *dw2, *db2, *dwr, *dg, *dbe;  // gradient slots (backward only)
+  int ik, hk, ok, act, ln_first;
+  float drop_p; RngKey key; uint32_t stream_id;   // dropout_k on the MLP branch (MLPProcess.py:81,110)
+};
+int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D);
+int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D);
+
+// ---- reductions / misc
+// out[z*os + n] += sum_m X[z*xs + m*ld + n]   for z < batch
+int colsum(hipStream_t s, const float* X, long M, int N, long ld, float* out, int batch = 1, long xs = 0, long os = 0);
+// out[r] += sum_b sum_c X[(b*R + r)*C + c]
+int rowsum_batched(hipStream_t s, const float* X, int B, int R, int C, float* out);
+// y += x (n elements)
+int add_inplace(hipStream_t s, float* y, const float* x, long n);
+// y = dropout(y) in place / dy *= mask
+int dropout_inplace(hipStream_t s, float* y, long n, float p, RngKey key, uint32_t stream_id);
+
+}  // namespace mimrl

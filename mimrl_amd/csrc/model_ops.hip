@@ -1,0 +1,622 @@
+// Non-GEMM kernels of the model forward/backward (see model_ops.h for the reference citations).
+#include "model_ops.h"
+
+namespace mimrl {
+
+namespace {
+
+constexpr float LN_EPS = 1e-6f;   // every LayerNorm of the model uses eps=1e-6 (Model.py:260, MLPProcess.py:35-41)
+
+__device__ __forceinline__ float drop_scale(float p, const RngKey& key, uint32_t stream, uint32_t idx) {
+  if (p <= 0.f) return 1.f;
+  const float u = uniform01(key.seed_lo, key.seed_hi, stream, (uint32_t)*key.step, idx);
+  return u >= p ? 1.f / (1.f - p) : 0.f;
+}
+
+// ------------------------------------------------------------------ lengths
+__global__ void seq_lengths_kernel(const float* __restrict__ x, int T, int d, int* __restrict__ lens) {
+  __shared__ int cnt;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  for (int t = w; t < T; t += nw) {
+    const float* row = x + ((long)b * T + t) * d;
+    float s = 0.f;
+    for (int j = lane; j < d; j += 64) s += fabsf(row[j]);
+    s = wave_sum(s);
+    if (lane == 0 && s != 0.f) atomicAdd(&cnt, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) lens[b] = cnt > 0 ? cnt : 1;
+}
+
+// ------------------------------------------------------------------ text branch
+__global__ void text_post_kernel(const float* __restrict__ src, float* __restrict__ cube, long n, int T, int L, int K,
+                                 int D, int slot, float p, RngKey key, uint32_t stream, int backward) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int dd = i % D;
+    const long bt = i / D;
+    const int t = bt % T;
+    const long b = bt / T;
+    const long ci = ((b * L + t) * K + slot) * D + dd;
+    const float sc = drop_scale(p, key, stream, (uint32_t)i);
+    if (backward) cube[i] = sc * src[ci];     // here: src = dcube, cube = dsrc (contiguous [B,T,D])
+    else cube[ci] = sc * src[i];
+  }
+}
+
+// ------------------------------------------------------------------ LN + ReLU + dropout on the bi-GRU output
+template <int PER>   // D = 64*PER
+__global__ void ln_relu_drop_fwd_kernel(const float* __restrict__ h2, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ cube,
+                                        float* __restrict__ mean, float* __restrict__ rstd, long rows, int T, int L,
+                                        int K, int slot, float p, RngKey key, uint32_t stream) {
+  constexpr int D = 64 * PER;
+  const int lane = threadIdx.x & 63;
+  const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long r = wid; r < rows; r += nwv) {
+    const float* hr = h2 + r * 2 * D;
+    float v[PER], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { v[i] = hr[lane + 64 * i] + hr[D + lane + 64 * i]; s += v[i]; }
+    const float mu = wave_sum(s) * (1.f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float c = v[i] - mu; q += c * c; }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / D) + LN_EPS);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    const long b = r / T, t = r % T;
+    float* out = cube + ((b * L + t) * K + slot) * D;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = lane + 64 * i;
+      float y = (v[i] - mu) * rs * gamma[j] + beta[j];
+      y = y > 0.f ? y : 0.f;
+      out[j] = y * drop_scale(p, key, stream, (uint32_t)(r * D + j));
+    }
+  }
+}
+
+template <int PER>
+__global__ void ln_relu_drop_bwd_kernel(const float* __restrict__ h2, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, const float* __restrict__ dcube,
+                                        float* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                        long rows, int T, int L, int K, int slot, float p, RngKey key, uint32_t stream) {
+  constexpr int D = 64 * PER;
+  __shared__ float sg[D], sb[D];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) { sg[i] = 0.f; sb[i] = 0.f; }
+  __syncthreads();
+  const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
+  float ag[PER], ab[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (long r = wid; r < rows; r += nwv) {
+    const float* hr = h2 + r * 2 * D;
+    const float mu = mean[r], rs = rstd[r];
+    const long b = r / T, t = r % T;
+    const float* dc = dcube + ((b * L + t) * K + slot) * D;
+    float xh[PER], dxh[PER], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = lane + 64 * i;
+      xh[i] = (hr[j] + hr[D + j] - mu) * rs;
+      const float y = xh[i] * gamma[j] + beta[j];
+      float dy = dc[j] * drop_scale(p, key, stream, (uint32_t)(r * D + j));
+      dy = y > 0.f ? dy : 0.f;
+      ag[i] += dy * xh[i];
+      ab[i] += dy;
+      dxh[i] = dy * gamma[j];
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
+    }
+    s1 = wave_sum(s1) * (1.f / D);
+    s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) ds[r * D + lane + 64 * i] = rs * (dxh[i] - s1 - xh[i] * s2);
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { atomicAdd(&sg[lane + 64 * i], ag[i]); atomicAdd(&sb[lane + 64 * i], ab[i]); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(&dgamma[i], sg[i]); atomicAdd(&dbeta[i], sb[i]); }
+}
+
+// ------------------------------------------------------------------ temporal means
+__global__ void feat_mean_fwd_kernel(const float* __restrict__ cube, float* __restrict__ feats, int B, int T, int L,
+                                     int K, int D) {
+  const int b = blockIdx.x, k = blockIdx.y;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += cube[(((long)b * L + t) * K + k) * D + d];
+    feats[((long)k * B + b) * D + d] = s / T;
+  }
+}
+__global__ void feat_mean_bwd_kernel(const float* __restrict__ dfeats, float* __restrict__ dcube, long n, int B, int T,
+                                     int L, int K, int D) {
+  const float inv = 1.f / T;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int d = i % D;
+    long r = i / D;
+    const int k = r % K; r /= K;
+    const int t = r % T;
+    const long b = r / T;
+    dcube[((b * L + t) * K + k) * D + d] += dfeats[((long)k * B + b) * D + d] * inv;
+  }
+}
+
+// ------------------------------------------------------------------ head
+__global__ void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ ff, float* __restrict__ pred, int L, int K, int D, float scale) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  float part = 0.f;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    const float* xb = x + (long)b * L * K * D + d;
+    for (int i = 0; i < L * K; ++i) s += xb[(long)i * D];
+    s *= scale;
+    ff[(long)b * D + d] = s;
+    part += s * w[d];
+  }
+  part = block_sum(part, red);
+  if (threadIdx.x == 0) pred[b] = part + bias[0];
+}
+__global__ void head_bwd_kernel(const float* __restrict__ dff_ext, const float* __restrict__ dpred,
+                                const float* __restrict__ w, const float* __restrict__ ff, float* __restrict__ dx,
+                                float* __restrict__ dw, float* __restrict__ dbias, int L, int K, int D, float scale) {
+  const int b = blockIdx.x;
+  const float dp = dpred[b];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float g = scale * ((dff_ext ? dff_ext[(long)b * D + d] : 0.f) + dp * w[d]);
+    float* xb = dx + (long)b * L * K * D + d;
+    for (int i = 0; i < L * K; ++i) xb[(long)i * D] = g;
+    atomicAdd(&dw[d], dp * ff[(long)b * D + d]);
+  }
+  if (threadIdx.x == 0) atomicAdd(dbias, dp);
+}
+
+// ------------------------------------------------------------------ row LayerNorm (one wave per row)
+__global__ void rowln_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ z, float* __restrict__ mean,
+                                 float* __restrict__ rstd, long R, int n) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long r = wid; r < R; r += nwv) {
+    const float* yr = y + r * n;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += yr[j];
+    const float mu = wave_sum(s) / n;
+    float q = 0.f;
+    for (int j = lane; j < n; j += 64) { const float c = yr[j] - mu; q += c * c; }
+    const float rs = rsqrtf(wave_sum(q) / n + LN_EPS);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    for (int j = lane; j < n; j += 64) z[r * n + j] = (yr[j] - mu) * rs * gamma[j] + beta[j];
+  }
+}
+__global__ void rowln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ dz, float* __restrict__ dy, float* __restrict__ dgamma,
+                                 float* __restrict__ dbeta, long R, int n) {
+  extern __shared__ float sh[];   // [2n]
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long r = wid; r < R; r += nwv) {
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < n; j += 64) {
+      const float xh = (y[r * n + j] - mu) * rs, g = dz[r * n + j];
+      const float dxh = g * gamma[j];
+      s1 += dxh; s2 += dxh * xh;
+      atomicAdd(&sh[j], g * xh);
+      atomicAdd(&sh[n + j], g);
+    }
+    s1 = wave_sum(s1) / n; s2 = wave_sum(s2) / n;
+    for (int j = lane; j < n; j += 64) {
+      const float xh = (y[r * n + j] - mu) * rs;
+      dy[r * n + j] = rs * (dz[r * n + j] * gamma[j] - s1 - xh * s2);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { atomicAdd(&dgamma[i], sh[i]); atomicAdd(&dbeta[i], sh[n + i]); }
+}
+
+// ------------------------------------------------------------------ column LayerNorm (thread per (b,c))
+__global__ void colln_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ z, float* __restrict__ mean,
+                                 float* __restrict__ rstd, int B, int n, int C) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const long b = i / C;
+  const int c = i % C;
+  const float* yb = y + b * n * C + c;
+  float s = 0.f;
+  for (int l = 0; l < n; ++l) s += yb[(long)l * C];
+  const float mu = s / n;
+  float q = 0.f;
+  for (int l = 0; l < n; ++l) { const float d = yb[(long)l * C] - mu; q += d * d; }
+  const float rs = rsqrtf(q / n + LN_EPS);
+  mean[i] = mu; rstd[i] = rs;
+  float* zb = z + b * n * C + c;
+  for (int l = 0; l < n; ++l) zb[(long)l * C] = (yb[(long)l * C] - mu) * rs * gamma[l] + beta[l];
+}
+__global__ void colln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ dz, float* __restrict__ dy, float* __restrict__ dgamma,
+                                 float* __restrict__ dbeta, int B, int n, int C) {
+  extern __shared__ float sh[];   // [2n]
+  for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const bool ok = i < (long)B * C;
+  const long b = ok ? i / C : 0;
+  const int c = ok ? i % C : 0;
+  const float* yb = y + b * n * C + c;
+  const float* dzb = dz + b * n * C + c;
+  const float mu = ok ? mean[i] : 0.f, rs = ok ? rstd[i] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  const int lane = threadIdx.x & 63;
+  for (int l = 0; l < n; ++l) {
+    float g = 0.f, xh = 0.f;
+    if (ok) { g = dzb[(long)l * C]; xh = (yb[(long)l * C] - mu) * rs; }
+    const float dxh = g * gamma[l];
+    s1 += dxh; s2 += dxh * xh;
+    const float a = wave_sum(g * xh), bb = wave_sum(g);
+    if (lane == 0) { atomicAdd(&sh[l], a); atomicAdd(&sh[n + l], bb); }
+  }
+  if (ok) {
+    s1 /= n; s2 /= n;
+    float* dyb = dy + b * n * C + c;
+    for (int l = 0; l < n; ++l) {
+      const float xh = (yb[(long)l * C] - mu) * rs;
+      dyb[(long)l * C] = rs * (dzb[(long)l * C] * gamma[l] - s1 - xh * s2);
+    }
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < n; l += blockDim.x) { atomicAdd(&dgamma[l], sh[l]); atomicAdd(&dbeta[l], sh[n + l]); }
+}
+
+// ------------------------------------------------------------------ K-axis mix, fused (thread per (row, d))
+constexpr int KM = 8;   // max size of any K-axis dimension
+
+struct KMixVals {
+  float x[KM], xn[KM], u[KM], h[KM], y[KM], xh[KM], sc[KM];   // sc: dropout scale of the MLP branch per output
+  float mu, rs;
+};
+
+__device__ __forceinline__ void ln_small(const float* v, int n, const float* g, const float* be, float* out, float* xh,
+                                         float& mu, float& rs) {
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += v[i];
+  mu = s / n;
+  float q = 0.f;
+  for (int i = 0; i < n; ++i) { const float c = v[i] - mu; q += c * c; }
+  rs = rsqrtf(q / n + LN_EPS);
+  for (int i = 0; i < n; ++i) { xh[i] = (v[i] - mu) * rs; out[i] = xh[i] * g[i] + be[i]; }
+}
+
+__device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* sw, KMixVals& v) {
+  // sw: LDS copy of [w1 | b1 | w2 | b2 | wr | g | be] (missing pieces zero / identity)
+  const float* w1 = sw; const float* b1 = w1 + KM * KM; const float* w2 = b1 + KM; const float* b2 = w2 + KM * KM;
+  const float* wr = b2 + KM; const float* g = wr + KM * KM; const float* be = g + KM;
+  const float* in = v.x;
+  if (w.ln_first) { ln_small(v.x, w.ik, g, be, v.xn, v.xh, v.mu, v.rs); in = v.xn; }
+  for (int j = 0; j < w.hk; ++j) {
+    float s = b1[j];
+    for (int k = 0; k < w.ik; ++k) s += w1[j * KM + k] * in[k];
+    v.u[j] = s; v.h[j] = act_apply(w.act, s);
+  }
+  for (int o = 0; o < w.ok; ++o) {
+    float s = b2[o], rr = 0.f;
+    for (int j = 0; j < w.hk; ++j) s += w2[o * KM + j] * v.h[j];
+    for (int k = 0; k < w.ik; ++k) rr += wr[o * KM + k] * v.x[k];
+    v.y[o] = v.sc[o] * s + rr;
+  }
+}
+
+__device__ __forceinline__ void kmix_stage_weights(const KMixW& w, float* sw) {
+  for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sw[i] = 0.f;
+  __syncthreads();
+  float* w1 = sw; float* b1 = w1 + KM * KM; float* w2 = b1 + KM; float* b2 = w2 + KM * KM;
+  float* wr = b2 + KM; float* g = wr + KM * KM; float* be = g + KM;
+  const int t = threadIdx.x;
+  if (t < w.hk * w.ik) w1[(t / w.ik) * KM + t % w.ik] = w.w1[t];
+  if (t < w.hk && w.b1) b1[t] = w.b1[t];
+  if (t < w.ok * w.hk) w2[(t / w.hk) * KM + t % w.hk] = w.w2[t];
+  if (t < w.ok && w.b2) b2[t] = w.b2[t];
+  if (t < w.ok * w.ik) wr[(t / w.ik) * KM + t % w.ik] = w.wr ? w.wr[t] : ((t / w.ik) == (t % w.ik) ? 1.f : 0.f);
+  const int nln = w.ln_first ? w.ik : w.ok;
+  if (t < nln) { g[t] = w.g[t]; be[t] = w.be[t]; }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__ x, float* __restrict__ z, KMixW w,
+                                                       long R, int D) {
+  __shared__ float sw[3 * KM * KM + 4 * KM];
+  kmix_stage_weights(w, sw);
+  const float* g = sw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < R * D; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D; const int d = i % D;
+    KMixVals v;
+    for (int k = 0; k < w.ik; ++k) v.x[k] = x[(r * w.ik + k) * D + d];
+    for (int o = 0; o < w.ok; ++o) v.sc[o] = drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d));
+    kmix_forward_vals(w, sw, v);
+    if (w.ln_first) {
+      for (int o = 0; o < w.ok; ++o) z[(r * w.ok + o) * D + d] = v.y[o];
+    } else {
+      float out[KM];
+      ln_small(v.y, w.ok, g, be, out, v.xh, v.mu, v.rs);
+      for (int o = 0; o < w.ok; ++o) z[(r * w.ok + o) * D + d] = out[o];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                       float* __restrict__ dx, KMixW w, long R, int D) {
+  __shared__ float sw[3 * KM * KM + 4 * KM];
+  __shared__ float sg[3 * KM * KM + 4 * KM];   // gradient accumulators, same packing
+  kmix_stage_weights(w, sw);
+  for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sg[i] = 0.f;
+  __syncthreads();
+  const float* w1 = sw; const float* w2 = w1 + KM * KM + KM; const float* wr = w2 + KM * KM + KM;
+  const float* g = wr + KM * KM;
+  float* gw1 = sg; float* gb1 = gw1 + KM * KM; float* gw2 = gb1 + KM; float* gb2 = gw2 + KM * KM;
+  float* gwr = gb2 + KM; float* gg = gwr + KM * KM; float* gbe = gg + KM;
+  const int lane = threadIdx.x & 63;
+  const long total = R * D;
+  const long span = (long)gridDim.x * blockDim.x;
+  for (long base = blockIdx.x * (long)blockDim.x; base < total; base += span) {   // wave-uniform trip count
+    const long i = base + threadIdx.x;
+    const bool ok = i < total;
+    const long r = ok ? i / D : 0; const int d = ok ? i % D : 0;
+    KMixVals v;
+    float dzv[KM], dyv[KM], dh[KM], du[KM], dxn[KM], dxv[KM];
+    for (int k = 0; k < w.ik; ++k) v.x[k] = ok ? x[(r * w.ik + k) * D + d] : 0.f;
+    for (int o = 0; o < w.ok; ++o) dzv[o] = ok ? dz[(r * w.ok + o) * D + d] : 0.f;
+    for (int o = 0; o < w.ok; ++o) v.sc[o] = drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d));
+    kmix_forward_vals(w, sw, v);
+    if (w.ln_first) {
+      for (int o = 0; o < w.ok; ++o) dyv[o] = dzv[o];
+    } else {
+      float out[KM];
+      ln_small(v.y, w.ok, g, g + KM, out, v.xh, v.mu, v.rs);
+      float s1 = 0.f, s2 = 0.f;
+      for (int o = 0; o < w.ok; ++o) { const float t = dzv[o] * g[o]; s1 += t; s2 += t * v.xh[o]; }
+      s1 /= w.ok; s2 /= w.ok;
+      for (int o = 0; o < w.ok; ++o) {
+        dyv[o] = v.rs * (dzv[o] * g[o] - s1 - v.xh[o] * s2);
+        const float a = wave_sum(dzv[o] * v.xh[o]), b = wave_sum(dzv[o]);
+        if (lane == 0) { atomicAdd(&gg[o], a); atomicAdd(&gbe[o], b); }
+      }
+    }
+    const float* in = w.ln_first ? v.xn : v.x;
+    float dym[KM];   // gradient entering the (dropped-out) MLP branch
+    for (int o = 0; o < w.ok; ++o) dym[o] = dyv[o] * v.sc[o];
+    for (int j = 0; j < w.hk; ++j) {
+      float s = 0.f;
+      for (int o = 0; o < w.ok; ++o) s += w2[o * KM + j] * dym[o];
+      dh[j] = s; du[j] = s * act_grad(w.act, v.u[j]);
+    }
+    for (int k = 0; k < w.ik; ++k) {
+      float s = 0.f, rr = 0.f;
+      for (int j = 0; j < w.hk; ++j) s += w1[j * KM + k] * du[j];
+      for (int o = 0; o < w.ok; ++o) rr += wr[o * KM + k] * dyv[o];
+      dxn[k] = s; dxv[k] = rr;
+    }
+    if (w.ln_first) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < w.ik; ++k) { const float t = dxn[k] * g[k]; s1 += t; s2 += t * v.xh[k]; }
+      s1 /= w.ik; s2 /= w.ik;
+      for (int k = 0; k < w.ik; ++k) {
+        dxv[k] += v.rs * (dxn[k] * g[k] - s1 - v.xh[k] * s2);
+        const float a = wave_sum(dxn[k] * v.xh[k]), b = wave_sum(dxn[k]);
+        if (lane == 0) { atomicAdd(&gg[k], a); atomicAdd(&gbe[k], b); }
+      }
+    } else {
+      for (int k = 0; k < w.ik; ++k) dxv[k] += dxn[k];
+    }
+    if (ok) for (int k = 0; k < w.ik; ++k) dx[(r * w.ik + k) * D + d] = dxv[k];
+    // weight gradients (wave reduce -> LDS)
+    for (int o = 0; o < w.ok; ++o) {
+      for (int j = 0; j < w.hk; ++j) { const float a = wave_sum(dym[o] * v.h[j]); if (lane == 0) atomicAdd(&gw2[o * KM + j], a); }
+      for (int k = 0; k < w.ik; ++k) { const float a = wave_sum(dyv[o] * v.x[k]); if (lane == 0) atomicAdd(&gwr[o * KM + k], a); }
+      const float a = wave_sum(dym[o]); if (lane == 0) atomicAdd(&gb2[o], a);
+    }
+    for (int j = 0; j < w.hk; ++j) {
+      for (int k = 0; k < w.ik; ++k) { const float a = wave_sum(du[j] * in[k]); if (lane == 0) atomicAdd(&gw1[j * KM + k], a); }
+      const float a = wave_sum(du[j]); if (lane == 0) atomicAdd(&gb1[j], a);
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < w.hk * w.ik) atomicAdd(&w.dw1[t], gw1[(t / w.ik) * KM + t % w.ik]);
+  if (t < w.hk && w.db1) atomicAdd(&w.db1[t], gb1[t]);
+  if (t < w.ok * w.hk) atomicAdd(&w.dw2[t], gw2[(t / w.hk) * KM + t % w.hk]);
+  if (t < w.ok && w.db2) atomicAdd(&w.db2[t], gb2[t]);
+  if (t < w.ok * w.ik && w.dwr) atomicAdd(&w.dwr[t], gwr[(t / w.ik) * KM + t % w.ik]);
+  const int nln = w.ln_first ? w.ik : w.ok;
+  if (t < nln) { atomicAdd(&w.dg[t], gg[t]); atomicAdd(&w.dbe[t], gbe[t]); }
+}
+
+// ------------------------------------------------------------------ reductions / misc
+__global__ void colsum_kernel(const float* __restrict__ X, long M, int N, long ld, float* __restrict__ out, long xs,
+                              long os) {
+  __shared__ float red[4][64];
+  X += blockIdx.z * xs;
+  out += blockIdx.z * os;
+  const int c = threadIdx.x & 63, rr = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const long m0 = (long)blockIdx.y * 256;
+  const long m1 = m0 + 256 < M ? m0 + 256 : M;
+  float s = 0.f;
+  if (n < N) for (long m = m0 + rr; m < m1; m += 4) s += X[m * ld + n];
+  red[rr][c] = s;
+  __syncthreads();
+  if (rr == 0 && n < N) atomicAdd(&out[n], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+__global__ void rowsum_batched_kernel(const float* __restrict__ X, int B, int R, int C, float* __restrict__ out) {
+  __shared__ float red[16];
+  const int r = blockIdx.x;
+  const int b0 = blockIdx.y * 8, b1 = b0 + 8 < B ? b0 + 8 : B;
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float* p = X + ((long)b * R + r) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s += p[c];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(&out[r], s);
+}
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += x[i];
+}
+__global__ void dropout_inplace_kernel(float* __restrict__ y, long n, float p, RngKey key, uint32_t stream) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] *= drop_scale(p, key, stream, (uint32_t)i);
+}
+
+inline int grid_for(long n, int block = 256, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+int seq_lengths(hipStream_t s, const float* x, int B, int T, int d, int* lens) {
+  hipLaunchKernelGGL(seq_lengths_kernel, dim3(B), dim3(256), 0, s, x, T, d, lens);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int text_post_fwd(hipStream_t s, const float* src, float* cube, int B, int T, int L, int K, int D, int slot, float p,
+                  RngKey key, uint32_t stream_id) {
+  const long n = (long)B * T * D;
+  hipLaunchKernelGGL(text_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, cube, n, T, L, K, D, slot, p, key,
+                     stream_id, 0);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int text_post_bwd(hipStream_t s, const float* dcube, float* dsrc, int B, int T, int L, int K, int D, int slot, float p,
+                  RngKey key, uint32_t stream_id) {
+  const long n = (long)B * T * D;
+  hipLaunchKernelGGL(text_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, dcube, dsrc, n, T, L, K, D, slot, p, key,
+                     stream_id, 1);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, float* cube, float* mean,
+                     float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id) {
+  if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
+  const long rows = (long)B * T;
+  hipLaunchKernelGGL(ln_relu_drop_fwd_kernel<2>, dim3(grid_for(rows * 64)), dim3(256), 0, s, h2, gamma, beta, cube,
+                     mean, rstd, rows, T, L, K, slot, p, key, stream_id);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int ln_relu_drop_bwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, const float* mean,
+                     const float* rstd, const float* dcube, float* ds, float* dgamma, float* dbeta, int B, int T, int L,
+                     int K, int D, int slot, float p, RngKey key, uint32_t stream_id) {
+  if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
+  const long rows = (long)B * T;
+  hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256)), dim3(256), 0, s, h2, gamma, beta,
+                     mean, rstd, dcube, ds, dgamma, dbeta, rows, T, L, K, slot, p, key, stream_id);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int feat_mean_fwd(hipStream_t s, const float* cube, float* feats, int B, int T, int L, int K, int D) {
+  hipLaunchKernelGGL(feat_mean_fwd_kernel, dim3(B, K), dim3(128), 0, s, cube, feats, B, T, L, K, D);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int feat_mean_bwd(hipStream_t s, const float* dfeats, float* dcube, int B, int T, int L, int K, int D) {
+  const long n = (long)B * T * K * D;
+  hipLaunchKernelGGL(feat_mean_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dfeats, dcube, n, B, T, L, K, D);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int head_fwd(hipStream_t s, const float* x, const float* w, const float* bias, float* ff, float* pred, int B, int L,
+             int K, int D, int sum_l, int sum_k) {
+  const float scale = (sum_l ? 1.f : 1.f / L) * (sum_k ? 1.f : 1.f / K);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(128), 0, s, x, w, bias, ff, pred, L, K, D, scale);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int head_bwd(hipStream_t s, const float* dff_ext, const float* dpred, const float* w, const float* ff, float* dx,
+             float* dw, float* dbias, int B, int L, int K, int D, int sum_l, int sum_k) {
+  const float scale = (sum_l ? 1.f : 1.f / L) * (sum_k ? 1.f : 1.f / K);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(128), 0, s, dff_ext, dpred, w, ff, dx, dw, dbias, L, K, D, scale);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int rowln_fwd(hipStream_t s, const float* y, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
+              long R, int n) {
+  hipLaunchKernelGGL(rowln_fwd_kernel, dim3(grid_for(R * 64)), dim3(256), 0, s, y, gamma, beta, z, mean, rstd, R, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int rowln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
+              float* dy, float* dgamma, float* dbeta, long R, int n) {
+  hipLaunchKernelGGL(rowln_bwd_kernel, dim3(grid_for(R * 64, 256, 256)), dim3(256), 2 * n * sizeof(float), s, y, gamma,
+                     mean, rstd, dz, dy, dgamma, dbeta, R, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int colln_fwd(hipStream_t s, const float* y, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
+              int B, int n, int C) {
+  const long tot = (long)B * C;
+  hipLaunchKernelGGL(colln_fwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, y, gamma, beta, z, mean, rstd, B, n, C);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
+              float* dy, float* dgamma, float* dbeta, int B, int n, int C) {
+  const long tot = (long)B * C;
+  hipLaunchKernelGGL(colln_bwd_kernel, dim3((tot + 255) / 256), dim3(256), 2 * n * sizeof(float), s, y, gamma, mean,
+                     rstd, dz, dy, dgamma, dbeta, B, n, C);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
+  if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
+  if (!w.wr && w.ik != w.ok) return set_error(MIMRL_ERR_ARG, "kmix: identity residual needs ik == ok");
+  hipLaunchKernelGGL(kmix_fwd_kernel, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D) {
+  if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
+  hipLaunchKernelGGL(kmix_bwd_kernel, dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int colsum(hipStream_t s, const float* X, long M, int N, long ld, float* out, int batch, long xs, long os) {
+  dim3 grid((N + 63) / 64, (unsigned)((M + 255) / 256), batch);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, X, M, N, ld, out, xs, os);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int rowsum_batched(hipStream_t s, const float* X, int B, int R, int C, float* out) {
+  hipLaunchKernelGGL(rowsum_batched_kernel, dim3(R, (B + 7) / 8), dim3(256), 0, s, X, B, R, C, out);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int add_inplace(hipStream_t s, float* y, const float* x, long n) {
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int dropout_inplace(hipStream_t s, float* y, long n, float p, RngKey key, uint32_t stream_id) {
+  if (p <= 0.f) return MIMRL_OK;
+  hipLaunchKernelGGL(dropout_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, n, p, key, stream_id);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+}  // namespace mimrl

@@ -1,0 +1,154 @@
+"""HipEngine: owns the torch tensors (the "tensor-holding boundary") and drives libmimrl_hip through its C ABI.
+
+PyTorch-ROCm is used only for device memory, the stream and (in dist.py) RCCL; every FLOP of the two-stage step
+runs in the hand-written HIP library.  There is no eager/CPU fallback anywhere in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Buffers, MimrlError, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipEngine:
+    """One engine = one (process, GPU).  Mirrors the state the reference keeps in Model + two Adam optimizers."""
+
+    def __init__(self, opt, d_t: int, d_a: int, d_v: int, seq_len: Optional[int] = None, bank_capacity: int = 0,
+                 precision: str = "fp32", use_graph: bool = False, seed: int = 0, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise MimrlError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        torch.cuda.set_device(self.device)
+        self.opt = opt
+        self.cfg = _lib.make_cfg(opt, d_t, d_a, d_v, seq_len, bank_capacity, precision, use_graph, seed)
+        check(self.lib.mimrl_device_check())
+        self.entries, (n_main, n_crit) = _lib.layout_entries(self.cfg)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        B, T = self.cfg.batch, self.cfg.seq_len
+        self.m_anchor = B // self.cfg.k_neighbor
+        z = lambda *s: torch.zeros(*s, **f32)
+        self.main = {k: z(max(n_main, 1)) for k in "pgmv"}
+        self.crit = {k: z(max(n_crit, 1)) for k in "pgmv"}
+        self.text, self.audio, self.video = z(B, T, d_t), z(B, T, d_a), z(B, T, d_v)
+        self.labels = z(B)
+        cap = max(int(bank_capacity), 1)
+        self.bank = {"C": z(cap, 1), "F": z(cap, 128), "T": z(cap, 128), "A": z(cap, 128), "V": z(cap, 128)}
+        self.anchors = torch.zeros(2, 6, max(self.m_anchor, 1), dtype=torch.int32, device=self.device)
+        self.lr_main = torch.full((1,), float(opt.learning_rate), **f32)
+        self.lr_critic = torch.full((1,), float(opt.learning_rate) * float(opt.mi_lr_rate), **f32)   # Solver.py:140-142
+        self.pred = z(B)
+        self.feats = z(4, B, 128)
+        self.scalars = z(_lib.NSCALARS)
+        self.bank_rows = 0
+        # named views into the flat buckets (state_dict compatibility)
+        self.params: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        for name, group, off, shape in self.entries:
+            bucket = self.crit if group == 1 else self.main
+            n = int(np.prod(shape))
+            self.params[name] = bucket["p"][off:off + n].view(*shape)
+            self.grads[name] = bucket["g"][off:off + n].view(*shape)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        check(self.lib.mimrl_create(C.byref(self.cfg), C.c_void_p(self.stream.cuda_stream), C.byref(h)))
+        self.handle = h
+        self._bind()
+
+    def _bind(self):
+        b = Buffers()
+        b.main_p, b.main_g, b.main_m, b.main_v = (_ptr(self.main[k]) for k in "pgmv")
+        b.crit_p, b.crit_g, b.crit_m, b.crit_v = (_ptr(self.crit[k]) for k in "pgmv")
+        b.text, b.audio, b.video, b.labels = _ptr(self.text), _ptr(self.audio), _ptr(self.video), _ptr(self.labels)
+        b.bank_c, b.bank_f, b.bank_t, b.bank_a, b.bank_v = (_ptr(self.bank[k]) for k in "CFTAV")
+        b.anchors = _ptr(self.anchors)
+        b.lr_main, b.lr_critic = _ptr(self.lr_main), _ptr(self.lr_critic)
+        b.pred, b.feats, b.scalars = _ptr(self.pred), _ptr(self.feats), _ptr(self.scalars)
+        self._buffers = b
+        check(self.lib.mimrl_bind(self.handle, C.byref(b)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.mimrl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state
+    def load_params(self, state: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        for name, view in self.params.items():
+            if name not in state:
+                if strict:
+                    raise KeyError(name)
+                continue
+            src = state[name]
+            src = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src
+            view.copy_(src.to(torch.float32).reshape(view.shape))
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: v.detach().clone() for k, v in self.params.items()}
+
+    def set_batch(self, text, audio, video, labels):
+        """text: [B,T,d_t] post-BERT features; audio/video: [B,T,d]; labels: [B] or [B,1] (host or device tensors)."""
+        for dst, src in ((self.text, text), (self.audio, audio), (self.video, video)):
+            src = torch.as_tensor(src)
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        self.labels.copy_(torch.as_tensor(labels).reshape(-1), non_blocking=True)
+
+    def set_banks(self, C_all, F_all, T_all, A_all, V_all):
+        """Previous epoch's stage-2 labels/features (Solver.py:223-227,244).  Empty => epoch-0 rule."""
+        n = 0 if C_all is None else len(C_all)
+        if n:
+            if n > self.cfg.bank_capacity:
+                raise MimrlError(f"bank of {n} rows exceeds capacity {self.cfg.bank_capacity}")
+            for k, src in zip("CFTAV", (C_all, F_all, T_all, A_all, V_all)):
+                src = torch.as_tensor(src)
+                self.bank[k][:n].copy_(src.reshape(n, -1), non_blocking=True)
+        self.bank_rows = n
+        check(self.lib.mimrl_set_bank_rows(self.handle, n))
+
+    def set_anchors(self, stage: int, anchors):
+        """anchors: int array [6, B//k] -- the six ``np.random.choice`` draws of one stage (Model.py:81)."""
+        a = torch.as_tensor(np.asarray(anchors, dtype=np.int32)).reshape(6, self.m_anchor)
+        self.anchors[stage - 1].copy_(a, non_blocking=True)
+
+    def set_lr(self, lr_main: float, lr_critic: float):
+        self.lr_main.fill_(float(lr_main))
+        self.lr_critic.fill_(float(lr_critic))
+
+    # ------------------------------------------------------------------ compute (all asynchronous)
+    def stage1_step(self):
+        check(self.lib.mimrl_stage1_step(self.handle))
+
+    def stage2_step(self):
+        check(self.lib.mimrl_stage2_step(self.handle))
+
+    def stage_grads(self, stage: int):
+        check(self.lib.mimrl_stage_grads(self.handle, stage))
+
+    def stage_apply(self, stage: int):
+        check(self.lib.mimrl_stage_apply(self.handle, stage))
+
+    def forward(self, train: bool = False, with_losses: bool = False):
+        check(self.lib.mimrl_forward(self.handle, int(train), int(with_losses)))
+
+    def read_scalars(self) -> np.ndarray:
+        """One device->host read-back (the reference does >= 10 ``.item()`` syncs per iteration)."""
+        return self.scalars.detach().cpu().numpy()
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mimrl_workspace_bytes(self.handle))

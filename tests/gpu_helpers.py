@@ -1,0 +1,50 @@
+"""Helpers for the -m gpu parity tests (HIP path through the C ABI vs oracle / goldens)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from mimrl_amd import _lib
+from oracle import mimrl_ref as R
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x)).to(dtype).cuda()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def oracle_raw_grads(params, opt, stage, batch, banks, anchors, names):
+    """Un-clipped gradients of the stage loss (autograd = ground truth for the hand-written backward)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    loss, mis, pred, feats, task = R.stage_loss(leaves, opt, stage, batch, banks, anchors)
+    gs = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    return loss.detach(), [m.detach() for m in mis], pred.detach(), feats, task.detach(), \
+        {n: (g if g is not None else torch.zeros_like(leaves[n])) for n, g in zip(names, gs)}
+
+
+def assert_close(got, want, rtol, atol, msg=""):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    if not np.all(err <= tol):
+        i = np.unravel_index(np.argmax(err - tol), err.shape) if err.shape else ()
+        raise AssertionError(f"{msg}: max violation at {i}: got {got[i] if err.shape else got} want "
+                             f"{want[i] if err.shape else want} (|err|={err.max():.3e}, rtol={rtol}, atol={atol}); "
+                             f"rel-to-max={err.max() / (np.abs(want).max() + 1e-30):.3e}")
+
+
+def grad_close(got, want, rel=2e-3, msg=""):
+    """Gradient tensors: compare against the tensor's own scale (elementwise rtol is meaningless near zero)."""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = np.abs(want).max() + 1e-12
+    err = np.abs(got - want).max()
+    assert err <= rel * scale + 1e-9, f"{msg}: max|err|={err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"

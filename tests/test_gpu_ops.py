@@ -1,0 +1,202 @@
+"""-m gpu: operator-level parity of the HIP kernels (through the C ABI) against the CPU oracle."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from mimrl_amd import _lib
+from oracle import mimrl_ref as R
+from tests.gpu_helpers import P, assert_close, dev, grad_close, stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = _lib.load()
+    _lib.check(lib.mimrl_device_check())
+    return lib
+
+
+def _gemm(lib, A, B, Cm, M, N, K, batch, st, bias_n=None, bias_m=None, alpha=1.0, beta=0.0, act=0, prec=0):
+    arr = (C.c_int64 * 9)(*st)
+    _lib.check(lib.mimrl_op_gemm(stream(), P(A), P(B), P(Cm), M, N, K, batch, arr, P(bias_n), P(bias_m), alpha, beta, act, prec))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 70, 45), (1, 2, 384), (50, 384, 50), (333, 128, 768)])
+def test_gemm_nt_bias_act(lib, M, N, K):
+    g = np.random.default_rng(0)
+    a, w, b = g.standard_normal((M, K)), g.standard_normal((N, K)), g.standard_normal(N)
+    A, W, Bv = dev(a), dev(w), dev(b)
+    out = torch.zeros(M, N, device="cuda")
+    _gemm(lib, A, W, out, M, N, K, 1, (K, 1, 0, 1, K, 0, N, 1, 0), bias_n=Bv, act=1)
+    ref = np.maximum(a @ w.T + b, 0)
+    assert_close(out.cpu().numpy(), ref, 1e-5, 1e-4, "fp32 gemm")
+    _gemm(lib, A, W, out, M, N, K, 1, (K, 1, 0, 1, K, 0, N, 1, 0), bias_n=Bv, act=1, prec=1)
+    assert_close(out.cpu().numpy(), ref, 2e-2, 2e-2 * math.sqrt(K), "bf16 gemm")
+
+
+def test_gemm_batched_left_multiply_and_tn(lib):
+    """The CubeMLP L-axis mix: Y_b[m,C] = W[m,l] X_b[l,C] + bias_m, and a batch-reduced weight gradient."""
+    g = np.random.default_rng(1)
+    Bn, l, m, Cc = 5, 50, 10, 384
+    w, x, bm = g.standard_normal((m, l)), g.standard_normal((Bn, l, Cc)), g.standard_normal(m)
+    Wd, Xd, bd = dev(w), dev(x), dev(bm)
+    Y = torch.zeros(Bn, m, Cc, device="cuda")
+    _gemm(lib, Wd, Xd, Y, m, Cc, l, Bn, (l, 1, 0, Cc, 1, l * Cc, Cc, 1, m * Cc), bias_m=bd)
+    ref = np.einsum("ml,blc->bmc", w, x) + bm[None, :, None]
+    assert_close(Y.cpu().numpy(), ref, 1e-5, 1e-4, "left-multiply")
+    # dW[m,l] = sum_b dY_b X_b^T via atomic accumulation over the batch (sc_b = 0)
+    dW = torch.zeros(m, l, device="cuda")
+    arr = (C.c_int64 * 9)(Cc, 1, m * Cc, 1, Cc, l * Cc, l, 1, 0)
+    lib.mimrl_op_gemm(stream(), P(Y), P(Xd), P(dW), m, l, Cc, Bn, arr, None, None, C.c_float(1.0), C.c_float(1.0), 0, 0)
+    # beta=1 with plain stores would race across the batch; the engine uses the atomic mode: emulate per batch
+    dW.zero_()
+    for b in range(Bn):
+        arr = (C.c_int64 * 9)(Cc, 1, 0, 1, Cc, 0, l, 1, 0)
+        _lib.check(lib.mimrl_op_gemm(stream(), P(Y[b]), P(Xd[b]), P(dW), m, l, Cc, 1, arr, None, None, 1.0, 1.0, 0, 0))
+    torch.cuda.synchronize()
+    ref = np.einsum("bmc,blc->ml", Y.cpu().numpy().astype(np.float64), x)
+    assert_close(dW.cpu().numpy(), ref, 1e-4, 1e-2, "batch-reduced TN")
+
+
+def _gru_case(B, T, d, seed, ragged):
+    g = np.random.default_rng(seed)
+    H = 128
+    x = g.standard_normal((B, T, d)).astype(np.float32)
+    lens = np.full(B, T, np.int32)
+    if ragged:
+        lens = g.integers(1, T + 1, size=B).astype(np.int32)
+        lens[0] = T
+        for b in range(B):
+            x[b, lens[b]:] = 0
+    k = 1 / math.sqrt(H)
+    W = {n: g.uniform(-k, k, size=s).astype(np.float32) for n, s in
+         [("wih_f", (384, d)), ("whh_f", (384, H)), ("bih_f", (384,)), ("bhh_f", (384,)),
+          ("wih_r", (384, d)), ("whh_r", (384, H)), ("bih_r", (384,)), ("bhh_r", (384,))]}
+    return x, lens, W
+
+
+@pytest.mark.parametrize("B,T,ragged,prec", [(5, 7, False, 0), (16, 12, True, 0), (37, 9, True, 0), (16, 12, True, 1)])
+def test_gru_layer_forward_backward(lib, B, T, ragged, prec):
+    """One bidirectional layer: forward outputs and BPTT (dgx, dgh, h_prev) vs the oracle cell + autograd."""
+    H, G = 128, 384
+    x, lens, W = _gru_case(B, T, 20, 3, ragged)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    Wt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.items()}
+    lt = torch.from_numpy(lens.astype(np.int64))
+    of = R.gru_direction(xt, lt, Wt["wih_f"], Wt["whh_f"], Wt["bih_f"], Wt["bhh_f"], False)
+    orr = R.gru_direction(xt, lt, Wt["wih_r"], Wt["whh_r"], Wt["bih_r"], Wt["bhh_r"], True)
+    out_ref = torch.cat([of, orr], -1)
+    gsel = torch.from_numpy(np.random.default_rng(9).standard_normal((B, T, 2 * H)).astype(np.float32))
+    (out_ref * gsel).sum().backward()
+    # device: hoisted input projections on the host (exact), recurrence on the GPU
+    gx_f = dev(x.reshape(B * T, -1) @ W["wih_f"].T + W["bih_f"]).reshape(B, T, G).contiguous()
+    gx_r = dev(x.reshape(B * T, -1) @ W["wih_r"].T + W["bih_r"]).reshape(B, T, G).contiguous()
+    nsv = lib.mimrl_op_gru_saved_floats(B, T)
+    sv_f, sv_r = torch.zeros(nsv, device="cuda"), torch.zeros(nsv, device="cuda")
+    out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+    lens_d = torch.from_numpy(lens).cuda()
+    Wd = {k: dev(v) for k, v in W.items()}
+    _lib.check(lib.mimrl_op_gru_forward(stream(), P(gx_f), P(gx_r), P(Wd["whh_f"]), P(Wd["whh_r"]), P(Wd["bhh_f"]),
+                                        P(Wd["bhh_r"]), P(lens_d), P(out), P(sv_f), P(sv_r), B, T, prec))
+    torch.cuda.synchronize()
+    tol = 1e-5 if prec == 0 else 2e-2
+    assert_close(out.cpu().numpy(), out_ref.detach().numpy(), tol, tol, "gru forward")
+    dout = gsel.cuda()
+    dgx_f, dgx_r, dgh_f, dgh_r = (torch.full((B, T, G), float("nan"), device="cuda") for _ in range(4))
+    hp_f, hp_r = (torch.full((B, T, H), float("nan"), device="cuda") for _ in range(2))
+    _lib.check(lib.mimrl_op_gru_backward(stream(), P(Wd["whh_f"]), P(Wd["whh_r"]), P(sv_f), P(sv_r), P(lens_d), P(out),
+                                         P(dout), P(dgx_f), P(dgx_r), P(dgh_f), P(dgh_r), P(hp_f), P(hp_r), B, T, prec))
+    torch.cuda.synchronize()
+    rel = 2e-4 if prec == 0 else 4e-2
+    for tag, dgx, dgh, hp in (("f", dgx_f, dgh_f, hp_f), ("r", dgx_r, dgh_r, hp_r)):
+        dgx_n, dgh_n, hp_n = dgx.cpu().numpy().astype(np.float64), dgh.cpu().numpy().astype(np.float64), hp.cpu().numpy().astype(np.float64)
+        assert np.isfinite(dgx_n).all() and np.isfinite(dgh_n).all() and np.isfinite(hp_n).all()
+        x64 = x.reshape(B * T, -1).astype(np.float64)
+        grad_close(dgx_n.reshape(B * T, G).T @ x64, Wt["wih_" + tag].grad.numpy(), rel, "dW_ih " + tag)
+        grad_close(dgx_n.reshape(B * T, G).sum(0), Wt["bih_" + tag].grad.numpy(), rel, "db_ih " + tag)
+        grad_close(dgh_n.reshape(B * T, G).T @ hp_n.reshape(B * T, H), Wt["whh_" + tag].grad.numpy(), rel, "dW_hh " + tag)
+        grad_close(dgh_n.reshape(B * T, G).sum(0), Wt["bhh_" + tag].grad.numpy(), rel, "db_hh " + tag)
+    dx = dgx_f.cpu().numpy().astype(np.float64).reshape(B * T, G) @ W["wih_f"] + \
+        dgx_r.cpu().numpy().astype(np.float64).reshape(B * T, G) @ W["wih_r"]
+    grad_close(dx.reshape(B, T, -1), xt.grad.numpy(), rel, "dx")
+
+
+@pytest.mark.parametrize("bound", list(_lib.BOUNDS))
+@pytest.mark.parametrize("B", [8, 32, 128])
+def test_mi_bounds_value_and_gradient(lib, bound, B):
+    g = np.random.default_rng(4)
+    E = 3
+    s = (g.standard_normal((E, B, B)) * 1.5).astype(np.float32)
+    gs = np.array([-1.0, 0.5, -0.01], np.float32)
+    S, dS, mi, GS = dev(s), torch.zeros(E, B, B, device="cuda"), torch.zeros(E, device="cuda"), dev(gs)
+    _lib.check(lib.mimrl_op_mi_bound(stream(), P(S), P(dS), P(mi), P(GS), E, B, _lib.BOUNDS[bound]))
+    torch.cuda.synchronize()
+    for e in range(E):
+        st = torch.from_numpy(s[e]).double().requires_grad_(True)
+        val = R.BOUNDS[bound](st)
+        (val * float(gs[e])).backward()
+        assert_close(mi[e].item(), val.item(), 1e-4, 2e-5, f"{bound} value")
+        grad_close(dS[e].cpu().numpy(), st.grad.numpy(), 1e-3, f"{bound} gradient")
+
+
+@pytest.mark.parametrize("dz,N,m,k", [(128, 300, 16, 2), (1, 300, 16, 2), (128, 1284, 64, 2), (1, 1284, 64, 3), (128, 70, 33, 4)])
+def test_knn_matches_exact_bruteforce(lib, dz, N, m, k):
+    g = np.random.default_rng(5)
+    Z = g.standard_normal((N, dz)).astype(np.float32) if dz > 1 else g.uniform(-3, 3, size=(N, 1)).astype(np.float32)
+    anchors = g.choice(N, size=m, replace=False).astype(np.int32)
+    out = torch.full((m, k), -1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.mimrl_op_knn(stream(), P(dev(Z)), dz, N, P(torch.from_numpy(anchors).cuda()), m, k, P(out)))
+    torch.cuda.synchronize()
+    ref = R.knn_indices(Z, anchors.astype(np.int64), k)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("hardtanh", [0, 1])
+def test_cmi_loss_and_gradient(lib, hardtanh):
+    g = np.random.default_rng(6)
+    E, n = 2, 12
+    logits = (g.standard_normal((E, 2 * n, 2)) * (0.4 if hardtanh else 4.0)).astype(np.float32)
+    if hardtanh:
+        logits += 0.5
+    logits[0, 0, 0] = 11.0      # exercises the +-10 clamp (Model.py:69)
+    gb, gc = np.array([1.0, 0.3], np.float32), np.array([-0.01, 0.7], np.float32)
+    Ld, dL = dev(logits), torch.zeros(E, 2 * n, 2, device="cuda")
+    bce, cmi = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    _lib.check(lib.mimrl_op_cmi_loss(stream(), P(Ld), P(dL), P(bce), P(cmi), P(dev(gb)), P(dev(gc)), E, n, hardtanh))
+    torch.cuda.synchronize()
+    for e in range(E):
+        lt = torch.from_numpy(logits[e]).double().requires_grad_(True)
+        o = torch.clamp(lt, -10, 10)
+        gam = torch.nn.functional.hardtanh(o, 1e-4, 1 - 1e-4) if hardtanh else torch.sigmoid(o)
+        tgt = torch.zeros(2 * n, 2, dtype=torch.float64)
+        tgt[:n, 0] = 1
+        tgt[n:, 1] = 1
+        b = torch.nn.functional.binary_cross_entropy(gam, tgt)
+        lr = torch.log(gam[:, 0] / (1 - gam[:, 0] + 1e-6))
+        cm = 1 + lr[:n].sum() / (2 * n) - lr[n:].sum() / (2 * n)
+        (float(gb[e]) * b + float(gc[e]) * cm).backward()
+        assert_close(bce[e].item(), b.item(), 1e-4, 1e-6, "bce")
+        assert_close(cmi[e].item(), cm.item(), 1e-4, 1e-5, "cmi")
+        grad_close(dL[e].cpu().numpy(), lt.grad.numpy(), 1e-3, "dlogits")
+
+
+def test_fused_clip_adam_matches_torch_semantics(lib):
+    g = np.random.default_rng(7)
+    n = 5000
+    p0 = g.standard_normal(n).astype(np.float32)
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lr, step = dev(np.array([4e-3], np.float32)), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ref = {"w": torch.from_numpy(p0.copy())}
+    adam = R.AdamState(ref, ["w"])
+    for it in range(5):
+        gr = (g.standard_normal(n) * 2).astype(np.float32)
+        step += 1
+        _lib.check(lib.mimrl_op_adam(stream(), P(p), P(dev(gr)), P(m), P(v), n, P(lr), P(step), 0.9, 0.999, 1e-8, 0.01, 1.5))
+        adam.step(ref, {"w": torch.from_numpy(gr).clamp(-1.5, 1.5)}, 4e-3, 0.01)
+    torch.cuda.synchronize()
+    assert_close(p.cpu().numpy(), ref["w"].numpy(), 1e-5, 1e-6, "adam params")

@@ -1,0 +1,146 @@
+"""-m gpu: the full two-stage step through the C ABI vs (a) reference-generated goldens, (b) the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from mimrl_amd import _lib, synth
+from mimrl_amd.engine import HipEngine
+from oracle import mimrl_ref as R
+from tests.gpu_helpers import assert_close, grad_close, oracle_raw_grads
+from tests.helpers import case, load_golden, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt"]
+ALL = TINY + ["cfg1_sep", "cfg1_cat"]
+
+
+def make_engine(name, precision="fp32", use_graph=False):
+    c, opt, batch, banks = case(name)
+    eng = HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision=precision, use_graph=use_graph)
+    p = oracle_params(opt, c["seed"])
+    eng.load_params(p)
+    eng.set_batch(*batch)
+    return c, opt, batch, banks, p, eng
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_forward_matches_golden(name):
+    c, opt, batch, banks, p, eng = make_engine(name)
+    g = load_golden(name)
+    eng.forward(train=False)
+    torch.cuda.synchronize()
+    feats = eng.feats.cpu().numpy()
+    assert_close(eng.pred.cpu().numpy(), g["fwd_pred"].reshape(-1), 1e-3, 1e-5, "pred")
+    for i, k in enumerate(["F_F", "T_F", "A_F", "V_F"]):
+        assert_close(feats[i], g["fwd_" + k], 1e-3, 2e-5, k)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_sep", "cfg1_sep"])
+def test_epoch0_rule(name):
+    c, opt, batch, banks, p, eng = make_engine(name)
+    g = load_golden(name)
+    before = eng.crit["p"].clone()
+    eng.set_banks(None, None, None, None, None)
+    eng.stage1_step()
+    eng.forward(train=True, with_losses=True)
+    s = eng.read_scalars()
+    assert s[_lib.S1_LOSS] == 0.0 and torch.equal(before, eng.crit["p"])      # Solver.py:201-203
+    assert_close(s[_lib.S2_LOSS], g["e0_stage2_loss"], 1e-3, 1e-6, "epoch-0 stage-2 loss = task loss")
+    assert np.all(s[_lib.S2_MIS:_lib.S2_MIS + 8] == 0)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_stage_losses_and_all_gradients_vs_oracle(name):
+    """Every MI/CMI value, both losses and EVERY parameter gradient of both stages against the oracle's autograd."""
+    c, opt, batch, banks, p, eng = make_engine(name)
+    g = load_golden(name)
+    anchors = g["anchors"][0]
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    crit = [n for n in p if R.is_critic_param(n)]
+    main = [n for n in p if not R.is_critic_param(n)]
+    for stage, names in ((1, crit), (2, main)):
+        eng.set_anchors(stage, anchors[stage - 1])
+        eng.stage_grads(stage)
+        torch.cuda.synchronize()
+        s = eng.read_scalars()
+        loss, mis, pred, feats, task, grads = oracle_raw_grads(p, opt, stage, batch, banks, anchors[stage - 1], names)
+        if stage == 1:
+            assert_close(s[_lib.S1_LOSS], loss.item(), 1e-3, 1e-5, "stage-1 loss")
+            assert_close(s[_lib.S1_MIS:_lib.S1_MIS + 11], [m.item() for m in mis], 1e-3, 2e-5, "stage-1 MI/CMI")
+            assert_close(s[_lib.S1_LOSS], g["traj_s1_loss"][0], 1e-3, 1e-5, "stage-1 loss vs reference")
+            assert_close(s[_lib.S1_MIS:_lib.S1_MIS + 11], g["traj_s1_mis"][0], 1e-3, 2e-5, "stage-1 MI/CMI vs reference")
+        else:
+            assert_close(s[_lib.S2_LOSS], loss.item(), 1e-3, 1e-5, "stage-2 loss")
+            assert_close(s[_lib.S2_TASK], task.item(), 1e-3, 1e-6, "task loss")
+            assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], [m.item() for m in mis], 1e-3, 5e-5, "stage-2 MI terms")
+            assert_close(s[_lib.S2_LOSS], g["traj_s2_loss"][0], 1e-3, 1e-5, "stage-2 loss vs reference")
+            assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 1e-3, 5e-5, "stage-2 MI vs reference")
+        bad = []
+        for n in names:
+            try:
+                grad_close(eng.grads[n].cpu().numpy(), grads[n].numpy(), 3e-3, n)
+            except AssertionError as e:
+                bad.append(str(e))
+        assert not bad, f"stage {stage}: {len(bad)}/{len(names)} gradient tensors off:\n" + "\n".join(bad[:12])
+        # reference-captured small gradient tensors (pre-clip)
+        for key in g.files:
+            if key.startswith(f"s{stage}_grad:"):
+                n = key.split(":", 1)[1]
+                grad_close(eng.grads[n].cpu().numpy(), g[key], 3e-3, "vs reference " + n)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "cfg1_sep"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_stage_trajectory(name, use_graph):
+    """Alternating stage-1/stage-2 updates (Solver.step) vs the reference trajectory and the oracle."""
+    c, opt, batch, banks, p, eng = make_engine(name, use_graph=use_graph)
+    g = load_golden(name)
+    anchors = g["anchors"]
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    crit = [n for n in p if R.is_critic_param(n)]
+    main = [n for n in p if not R.is_critic_param(n)]
+    adam_v, adam_m = R.AdamState(p, crit), R.AdamState(p, main)
+    steps = min(anchors.shape[0], 3)
+    for it in range(steps):
+        eng.set_anchors(1, anchors[it, 0])
+        eng.set_anchors(2, anchors[it, 1])
+        eng.stage1_step()
+        eng.stage2_step()
+        s = eng.read_scalars()
+        r1, r2 = R.two_stage_step(p, opt, adam_v, adam_m, batch, banks, anchors[it, 0], anchors[it, 1])
+        rt, at = (1e-3, 2e-5) if it == 0 else ((3e-2, 5e-3) if it < 3 else (0.25, 0.05))
+        assert_close(s[_lib.S1_LOSS], g["traj_s1_loss"][it], rt, at, f"it{it} s1 loss vs reference")
+        assert_close(s[_lib.S2_LOSS], g["traj_s2_loss"][it], rt, at, f"it{it} s2 loss vs reference")
+        assert_close(s[_lib.S2_TASK], g["traj_s2_task"][it], rt, at, f"it{it} task vs reference")
+        assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][it], rt, 5e-5 if it == 0 else 5e-3, f"it{it} MI vs reference")
+        assert_close(s[_lib.S1_LOSS], r1["loss"].item(), rt, at, f"it{it} s1 loss vs oracle")
+        assert_close(s[_lib.S2_LOSS], r2["loss"].item(), rt, at, f"it{it} s2 loss vs oracle")
+        if it == 0:   # parameters after one clip+Adam update of each bucket (tolerance = a few sign flips of ~0 grads)
+            names1 = [str(x) for x in g["s1_gnorm_names"]]
+            ps = np.array([eng.params[n].double().sum().item() for n in names1])
+            np.testing.assert_allclose(ps, g["s1_psum_after"], rtol=1e-4, atol=0.05)
+            names2 = [str(x) for x in g["s2_gnorm_names"]]
+            ps = np.array([eng.params[n].double().sum().item() for n in names2])
+            np.testing.assert_allclose(ps, g["s2_psum_after"], rtol=1e-4, atol=0.05)
+    eng.close()
+
+
+def test_bf16_mode_tracks_fp32_oracle():
+    """bf16 MFMA operands, fp32 accumulation/state: losses within 2e-2 relative of the fp32 oracle."""
+    c, opt, batch, banks, p, eng = make_engine("cfg1_sep", precision="bf16")
+    g = load_golden("cfg1_sep")
+    anchors = g["anchors"][0]
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    eng.set_anchors(1, anchors[0])
+    eng.set_anchors(2, anchors[1])
+    eng.stage_grads(1)
+    eng.stage_grads(2)
+    s = eng.read_scalars()
+    assert_close(s[_lib.S1_LOSS], g["traj_s1_loss"][0], 2e-2, 1e-3, "bf16 stage-1 loss")
+    assert_close(s[_lib.S2_LOSS], g["traj_s2_loss"][0], 2e-2, 1e-3, "bf16 stage-2 loss")
+    assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 5e-2, 5e-3, "bf16 MI terms")
+    eng.close()

@@ -1,0 +1,71 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/mimrl.h declares, and its parameter layout
+agrees with the Python mirror (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mimrl_amd import _lib, layout
+from tests.golden.configs import CONFIGS, make_opt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mimrl.h")).read()
+    declared = sorted(set(re.findall(r"\b(mimrl_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/mimrl.h but not exported"
+    assert set(_lib.EXPORTS) == set(declared)
+    assert lib.mimrl_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_native_layout_matches_python(name):
+    opt = make_opt(CONFIGS[name])
+    cfg = _lib.make_cfg(opt, 768, 74, 35, bank_capacity=CONFIGS[name]["N"])
+    entries, sizes = _lib.layout_entries(cfg)
+    py_entries, py_sizes = layout.build_layout(opt, 768, 74, 35)
+    assert len(entries) == len(py_entries)
+    for (n, g, off, shape), e in zip(entries, py_entries):
+        assert (n, off, tuple(shape)) == (e.name, e.offset, e.shape)
+        assert g == (1 if e.group == "critic" else 0)
+    assert sizes == (py_sizes["main"], py_sizes["critic"])
+
+
+def test_parameter_counts_match_survey():
+    """SURVEY.md Appendix B [probe of the reference]: main 1,083,479 / vmi 1,975,040 (concat 988,165) / vcmi 1,383,948."""
+    opt = make_opt(CONFIGS["cfg1_sep"])
+    ents, _ = layout.build_layout(opt, 768, 74, 35)
+    main = sum(e.numel for e in ents if e.group == "main")
+    vmi = sum(e.numel for e in ents if e.name.startswith("vmi"))
+    vcmi = sum(e.numel for e in ents if e.name.startswith("vcmi"))
+    assert (main, vmi, vcmi) == (1083479, 1975040, 1383948)
+    opt = make_opt(CONFIGS["cfg1_cat"])
+    ents, _ = layout.build_layout(opt, 768, 74, 35)
+    assert sum(e.numel for e in ents if e.name.startswith("vmi")) == 988165
+
+
+def test_bad_config_is_rejected_loudly():
+    opt = make_opt(CONFIGS["tiny_sep"])
+    opt.d_common = 256            # the reference itself cannot run this
+    cfg = _lib.make_cfg(opt, 768, 74, 35)
+    with pytest.raises(_lib.MimrlError):
+        _lib.layout_entries(cfg)
+    opt = make_opt(CONFIGS["tiny_sep"])
+    opt.critic_type = "joint"     # VMI.py:44-45 raises NotImplementedError
+    with pytest.raises(NotImplementedError):
+        _lib.make_cfg(opt, 768, 74, 35)
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mimrl_amd.engine import HipEngine
+    with pytest.raises(_lib.MimrlError):
+        HipEngine(make_opt(CONFIGS["tiny_sep"]), 768, 74, 35)
+    assert _lib.load().mimrl_device_check() < 0
