@@ -31,7 +31,9 @@ enum { MIMRL_CRITIC_SEPARATE = 0, MIMRL_CRITIC_CONCAT = 1 };                    
 enum { MIMRL_BOUND_INFONCE = 0, MIMRL_BOUND_NWJ, MIMRL_BOUND_TUBA, MIMRL_BOUND_DV, MIMRL_BOUND_JS_FGAN,
        MIMRL_BOUND_JS, MIMRL_BOUND_SMILE };                                        /* Model.py:121-146 */
 enum { MIMRL_ACT_NONE = 0, MIMRL_ACT_RELU = 1, MIMRL_ACT_GELU = 2, MIMRL_ACT_TANH = 3 };
-enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16 = 1 };  /* MFMA operand type; accumulation/state/optimizer are fp32 */
+/* MFMA operand type per section (bit mask); accumulation, recurrent state, statistics and optimizer are always fp32 */
+enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16_GEMM_FWD = 1, MIMRL_PREC_BF16_GEMM_BWD = 2, MIMRL_PREC_BF16_GRU_FWD = 4,
+       MIMRL_PREC_BF16_GRU_BWD = 8, MIMRL_PREC_BF16 = 15 };
 
 /* Hot-path subset of Parameters.py:8-70 (same meaning as the flags of the same name). */
 typedef struct mimrl_cfg {

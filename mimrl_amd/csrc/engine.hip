@@ -111,12 +111,15 @@ using namespace mimrl;
 
 struct mimrl_handle {
   mimrl_cfg cfg;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // stream every launch goes to (the caller's, or cap_stream while capturing)
+  hipStream_t user_stream = nullptr;   // the caller's stream (graphs are launched here)
+  hipStream_t cap_stream = nullptr;    // private non-default stream: capture is illegal on the legacy default stream
   Layout layout;
   mimrl_buffers bufs;
   bool bound = false;
   int bank_rows = 0;
-  bool bf16 = false;
+  bool bf16 = false;                   // current GEMM operand mode (switched between forward / backward sections)
+  int prec = 0;                        // MIMRL_PREC_* bit mask
 
   // parameter handles
   GruDirW gru[2][2][2];          // [mod a=0,v=1][layer][dir]
@@ -430,7 +433,7 @@ int mimrl_handle::model_forward(bool train, bool save) {
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
       }
     }
-    MX(gru_forward(stream, a, bf16));
+    MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0));
   }
   // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
   for (int m = 0; m < 2; ++m)
@@ -730,7 +733,7 @@ int mimrl_handle::model_backward() {
                                 dgh[m][d], hprev[m][d]};
       }
     }
-    MX(gru_backward(stream, a, bf16));
+    MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0));
     for (int m = 0; m < 2; ++m) {
       const float* in = l == 0 ? xin[m] : h0[m];
       for (int d = 0; d < 2; ++d) {
@@ -957,9 +960,12 @@ int mimrl_handle::enqueue_grads(int stage) {
     LAUNCH_CHECK();
     HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));
     if (!have_banks) return MIMRL_OK;   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
+    bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     MX(model_forward(true, false));
     MX(estimators_forward(1, true));
+    bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
     MX(estimators_backward(1));
+    bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
     return MIMRL_OK;
@@ -967,11 +973,13 @@ int mimrl_handle::enqueue_grads(int stage) {
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
   LAUNCH_CHECK();
   HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
+  bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   MX(model_forward(true, true));
   hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
   LAUNCH_CHECK();
   if (have_banks) {
     MX(estimators_forward(2, true));
+    bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
     MX(estimators_backward(2));
   } else {
     HIPX(hipMemsetAsync(dfeat, 0, sizeof(float) * 4 * B * EMB, stream));
@@ -979,7 +987,9 @@ int mimrl_handle::enqueue_grads(int stage) {
   hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, coef2(),
                      have_banks ? 1 : 0);
   LAUNCH_CHECK();
+  bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   MX(model_backward());
+  bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   return MIMRL_OK;
 }
 
@@ -1015,13 +1025,16 @@ int mimrl_handle::run(int stage, int kind) {
   }
   if (!ex) {
     hipGraph_t g = nullptr;
-    HIPX(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+    stream = cap_stream;
     const int r = body();
-    const hipError_t ce = hipStreamEndCapture(stream, &g);
-    if (r != 0) { if (g) hipGraphDestroy(g); return r; }
+    stream = user_stream;
+    const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
+    if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
     if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
     const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
     graph_rows[stage][kind] = bank_rows;
   }
@@ -1061,8 +1074,9 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   if (h->cfg.beta1 == 0.f) h->cfg.beta1 = 0.9f;
   if (h->cfg.beta2 == 0.f) h->cfg.beta2 = 0.999f;
   if (h->cfg.adam_eps == 0.f) h->cfg.adam_eps = 1e-8f;
-  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
-  h->bf16 = cfg->precision == MIMRL_PREC_BF16;
+  h->stream = h->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
+  h->prec = cfg->precision;
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   std::memset(&h->bufs, 0, sizeof h->bufs);
   int r = build_layout(h->cfg, &h->layout);
   if (r == 0) r = h->resolve();
@@ -1082,7 +1096,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
   h->bound = true;
   for (int s = 1; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) { hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
   return MIMRL_OK;
 }
 
@@ -1127,8 +1141,9 @@ void mimrl_destroy(mimrl_handle* h) {
   if (!h) return;
   for (int s = 1; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) hipGraphExecDestroy(h->graph[s][k]);
-  if (h->ws) hipFree(h->ws);
+      if (h->graph[s][k]) (void)hipGraphExecDestroy(h->graph[s][k]);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->ws) (void)hipFree(h->ws);
   delete h;
 }
 
@@ -1142,7 +1157,7 @@ int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M,
   d.sa_m = st[0]; d.sa_k = st[1]; d.sa_b = st[2]; d.sb_k = st[3]; d.sb_n = st[4]; d.sb_b = st[5];
   d.sc_m = st[6]; d.sc_n = st[7]; d.sc_b = st[8];
   d.bias_n = bias_n; d.bias_m = bias_m; d.alpha = alpha; d.beta = beta; d.act = act;
-  return gemm(reinterpret_cast<hipStream_t>(stream), d, precision == MIMRL_PREC_BF16);
+  return gemm(reinterpret_cast<hipStream_t>(stream), d, (precision & 1) != 0);
 }
 
 int64_t mimrl_op_gru_saved_floats(int B, int T) { return gru_saved_floats(B, T); }
@@ -1156,7 +1171,7 @@ int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, con
   a.lens[0] = lens; a.lens[1] = lens;
   a.seq[0][0] = GruSeq{gx_f, whh_f, bhh_f, out, saved_f};
   a.seq[0][1] = GruSeq{gx_r, whh_r, bhh_r, out, saved_r};
-  return gru_forward(reinterpret_cast<hipStream_t>(stream), a, precision == MIMRL_PREC_BF16);
+  return gru_forward(reinterpret_cast<hipStream_t>(stream), a, (precision & 1) != 0);
 }
 
 int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, const float* saved_f,
@@ -1169,7 +1184,7 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
   a.lens[0] = lens; a.lens[1] = lens;
   a.seq[0][0] = GruSeqBwd{whh_f, saved_f, out, dout, dgx_f, dgh_f, hprev_f};
   a.seq[0][1] = GruSeqBwd{whh_r, saved_r, out, dout, dgx_r, dgh_r, hprev_r};
-  return gru_backward(reinterpret_cast<hipStream_t>(stream), a, precision == MIMRL_PREC_BF16);
+  return gru_backward(reinterpret_cast<hipStream_t>(stream), a, (precision & 1) != 0);
 }
 
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,

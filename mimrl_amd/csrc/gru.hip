@@ -26,7 +26,7 @@ namespace {
 constexpr int H = 128;       // hidden size (= d_common; the reference only runs with 128)
 constexpr int G = 3 * H;
 constexpr int BT = 16;       // batch rows per workgroup (MFMA N)
-constexpr int NW = 4;        // waves per workgroup; wave w owns units [32w, 32w+32)
+// 4 waves per workgroup; wave w owns units [32w, 32w+32)
 
 template <bool BF16>
 struct Cfg;

@@ -41,10 +41,12 @@ def assert_close(got, want, rtol, atol, msg=""):
                              f"rel-to-max={err.max() / (np.abs(want).max() + 1e-30):.3e}")
 
 
-def grad_close(got, want, rel=2e-3, msg=""):
-    """Gradient tensors: compare against the tensor's own scale (elementwise rtol is meaningless near zero)."""
+def grad_close(got, want, rel=2e-3, msg="", atol=3e-7):
+    """Gradient tensors: compare against the tensor's own scale (elementwise rtol is meaningless near zero).
+    ``atol`` covers tensors whose true gradient is identically zero (e.g. the last-layer bias of an InfoNCE critic:
+    the bound is invariant to a constant shift of the scores, so fp32 noise ~1e-8 is all there is)."""
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     scale = np.abs(want).max() + 1e-12
     err = np.abs(got - want).max()
-    assert err <= rel * scale + 1e-9, f"{msg}: max|err|={err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
+    assert err <= rel * scale + atol, f"{msg}: max|err|={err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
