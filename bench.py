@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the MIMRL two-stage training step on MI355X (BASELINE.json metric: two-stage train iters/sec).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N=1 default
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one stage-1 (critic) update + one stage-2 (model) update on one batch of MOSI-shaped synthetic triples
+(B=128 per rank, T=50, d=768/74/35, GRU encoders, d_common=128, CubeMLP 50-3-128=10-3-128, separable InfoNCE critics,
+k-NN CMI with k=2 against N=1284-row banks, Adam lr 4e-3, clip 1.5, dropout 0.1) -- BASELINE.json configs[1].
+Inputs are resident in HBM before the timed region; every step runs the full forward, all 11 estimators, the
+backward and the fused clip+Adam of both stages, kNN anchor sampling included (on the device).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mimrl_amd import _lib, dist as mdist, synth  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+H = 128
+
+
+def workload(name):
+    base = dict(d_common=128, encoders="gru", features_compose_t="mean", features_compose_k="mean", num_class=1,
+                activate="gelu", dropout_mlp=[0.0, 0.0, 0.0], dropout=[0.1, 0.1, 0.1, 0.1], bias=True, ln_first=False,
+                res_project=[True, True], baseline_type="constant", bound_type="infonce",
+                loss_mi_coefficient1=[1.0] * 11, loss_mi_coefficient2=[0.01] * 8, mi_lr_rate=1.0, cmi_lr_rate=1.0,
+                k_neighbor=2, radius=1.0, cmi_last_acticate="sigmoid", stage1_n=1, loss="MAE", gradient_clip=1.5,
+                optm="Adam", learning_rate=4e-3, weight_decay=0.0, d_hiddens=[[50, 3, 128], [10, 3, 128]],
+                d_outs=[[50, 3, 128], [10, 3, 128]])
+    cfgs = {
+        "cfg1": dict(batch_size=32, time_len=50, critic_type="separate", bank=1284),
+        "cfg2": dict(batch_size=128, time_len=50, critic_type="separate", bank=1284),
+        "cfg2-concat": dict(batch_size=128, time_len=50, critic_type="concat", bank=1284),
+    }
+    c = cfgs[name]
+    base.update(batch_size=c["batch_size"], time_len=c["time_len"], critic_type=c["critic_type"])
+    return SimpleNamespace(**base), c["bank"]
+
+
+def algorithmic_flops(opt, N):
+    """2 * (4 F_m + 5 F_c + 2 F_k) MACs per two-stage iteration."""
+    B, T, D = opt.batch_size, opt.time_len, 128
+    gru = lambda d: T * 2 * (3 * H * (d + H) + 3 * H * 3 * H)
+    cube, d_in = 0, [T, 3, D]
+    for hid, out in zip(opt.d_hiddens, opt.d_outs):
+        l, k, d = d_in
+        cube += k * d * (l * hid[0] + hid[0] * out[0] + l * out[0])
+        cube += out[0] * d * (k * hid[1] + hid[1] * out[1] + k * out[1])
+        cube += out[0] * out[1] * (d * hid[2] + hid[2] * out[2] + d * out[2])
+        d_in = out
+    F_m = B * (T * 768 * H + gru(74) + gru(35) + cube + H)
+    mi = 5 * (2 * B * 196608 + B * B * 128) if opt.critic_type == "separate" else 5 * (2 * B * 32768 + B * B * 131328)
+    F_c = mi + 6 * 2 * B * 229888
+    m = B // opt.k_neighbor
+    F_k = m * (N - m) * (4 * 128 + 2 * 1)
+    return 2.0 * (4 * F_m + 5 * F_c + 2 * F_k)
+
+
+def cpu_baseline(opt, N, budget_s=25.0):
+    """The CPU oracle (our PyTorch-CPU restatement, pinned to the reference by tests/golden) timed on this host's
+    cores on the SAME workload: a bounded sample of whole two-stage iterations."""
+    from oracle import mimrl_ref as R
+    from mimrl_amd import layout
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = {n: torch.from_numpy(synth.portable_tensor(n, s, 0)) for n, s in layout.named_shapes(opt, 768, 74, 35)}
+    batch = tuple(torch.from_numpy(x) for x in synth.synthetic_batch(opt.batch_size, opt.time_len, seed=0))
+    banks = {k: torch.from_numpy(v) for k, v in synth.synthetic_banks(N, seed=0).items()}
+    crit = [n for n in p if R.is_critic_param(n)]
+    main = [n for n in p if not R.is_critic_param(n)]
+    av, am = R.AdamState(p, crit), R.AdamState(p, main)
+    m = opt.batch_size // opt.k_neighbor
+    cpu_opt = SimpleNamespace(**vars(opt))
+    cpu_opt.dropout = [0.0] * 4          # dropout masks are explicit in the oracle; their cost is negligible
+
+    def one():
+        R.two_stage_step(p, cpu_opt, av, am, batch, banks, synth.draw_anchors(N, m, 6), synth.draw_anchors(N, m, 6))
+
+    one()                                 # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 12:
+            break
+    return {"value": n / dt, "unit": "two-stage iters/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 warm-up + {n} two-stage iterations of the same workload (B={opt.batch_size}, T={opt.time_len}, "
+                      f"N={N}), fp32 PyTorch-CPU oracle incl. host kNN", "ms_per_step": 1e3 * dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--precision", default="bf16", choices=sorted(_lib.PREC))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    world, rank, local = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    from mimrl_amd.engine import HipEngine
+
+    opt, N = workload(args.workload)
+    B, T = opt.batch_size, opt.time_len
+    eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision=args.precision, use_graph=not args.no_graph,
+                    seed=1234 + rank, device_anchors=True)
+    shapes = [(n, tuple(v.shape)) for n, v in eng.params.items()]
+    eng.load_params({n: synth.default_tensor(n, s, 0) for n, s in shapes})        # random init, identical on all ranks
+    eng.set_batch(*synth.synthetic_batch(B, T, seed=rank))                       # rank-local batch, resident in HBM
+    banks = synth.synthetic_banks(N, seed=0)
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+
+    def step():
+        if world > 1:
+            mdist.ddp_stage_step(eng, 1, world)
+            mdist.ddp_stage_step(eng, 2, world)
+        else:
+            eng.stage1_step()
+            eng.stage2_step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    el = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    wall = float(el.item())
+    scal = eng.read_scalars()
+    finite = bool(np.isfinite(scal).all())
+
+    # ---- live per-phase / dominant-kernel timing with HIP events on the engine's stream (eager launches)
+    phases, roof = {}, None
+    if rank == 0 and args.profile_steps > 0:
+        eng.profile(True)
+        for _ in range(3):
+            eng.stage1_step(); eng.stage2_step()
+        eng.profile_read()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(args.profile_steps):
+            eng.stage1_step(); eng.stage2_step()
+        ev1.record()
+        pr = eng.profile_read()
+        eager_ms = ev0.elapsed_time(ev1) / args.profile_steps
+        eng.profile(False)
+        phases = {k: {"ms_per_step": v[0] / args.profile_steps, "launch_groups_per_step": v[1] / args.profile_steps}
+                  for k, v in pr.items() if v[1]}
+        phases["eager_total_ms_per_step"] = eager_ms
+        # dominant kernel: the persistent bi-GRU recurrence (forward: 4 launches/step, BPTT: 2 launches/step)
+        fl = 2 * 2 * B * T * (H * 3 * H) * 2.0          # 2 modalities x 2 directions, [B,T] x (128 x 384) MACs
+        kname = "gru_fwd" if pr["gru_fwd"][0] >= pr["gru_bwd"][0] else "gru_bwd"
+        avg_ms = pr[kname][0] / max(pr[kname][1], 1)
+        peak = PEAK_TFLOPS["bf16" if _lib.PREC[args.precision] & (4 if kname == "gru_fwd" else 8) else "fp32"]
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": f"{kname}_kernel (persistent bi-GRU recurrence, one launch per layer)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "avg_launch_ms": avg_ms, "flops_per_launch": fl,
+                "share_of_step": pr[kname][0] / args.profile_steps / eager_ms}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(opt, N)
+
+    if rank == 0:
+        ms = 1e3 * wall / args.steps
+        out = {
+            "metric": "two-stage train iters/sec", "value": world * args.steps / wall if False else args.steps / wall,
+            "unit": "two-stage iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if _lib.PREC[args.precision] else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: MOSI-shaped synthetic triples B={B}/rank T={T} d=768/74/35, gru, "
+                                   f"d_common=128, CubeMLP 50-3-128=10-3-128, {opt.critic_type} InfoNCE critics, kNN-CMI k=2, "
+                                   f"banks N={N}, Adam lr 4e-3, dropout 0.1",
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "precision": args.precision, "hipgraph": not args.no_graph, "samples_per_sec": B * world * args.steps / wall},
+            "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,
+            "achieved_tflops_whole_step": world * algorithmic_flops(opt, N) / (wall / args.steps) / 1e12,
+            "roofline": roof, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,
+            "stage1_loss": float(scal[_lib.S1_LOSS]), "stage2_loss": float(scal[_lib.S2_LOSS]),
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

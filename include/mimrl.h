@@ -61,6 +61,7 @@ typedef struct mimrl_cfg {
   float beta1, beta2, adam_eps;  /* torch.optim.Adam defaults 0.9 / 0.999 / 1e-8 */
   int32_t precision;             /* MIMRL_PREC_* */
   int32_t use_graph;             /* capture each stage into a hipGraph on first use */
+  int32_t device_anchors;        /* 1: draw the kNN anchors on the device each step (overwrites buffers.anchors); 0: host-provided */
   uint64_t seed;                 /* dropout stream seed */
 } mimrl_cfg;
 
@@ -70,7 +71,7 @@ typedef struct mimrl_buffers {
   float *crit_p, *crit_g, *crit_m, *crit_v;       /* [mimrl_bucket_floats(CRITIC)] */
   const float *text, *audio, *video, *labels;     /* [B,T,d_t] [B,T,d_a] [B,T,d_v] [B] */
   const float *bank_c, *bank_f, *bank_t, *bank_a, *bank_v; /* [cap,1] [cap,128] x4 : previous epoch's stage-2 features */
-  const int32_t* anchors;                         /* [2][6][B/k] kNN anchor rows for stage 1 / stage 2 (Model.py:81) */
+  int32_t* anchors;                               /* [2][6][B/k] kNN anchor rows for stage 1 / stage 2 (Model.py:81) */
   float *lr_main, *lr_critic;                     /* device scalars (schedulers rewrite them) */
   float *pred;                                    /* [B] */
   float *feats;                                   /* [4][B,128] = F_F, T_F, A_F, V_F */
@@ -109,7 +110,13 @@ int mimrl_stage2_step(mimrl_handle* h);                /* Solver.py:221-236 : ma
 int mimrl_stage_grads(mimrl_handle* h, int stage);     /* forward+backward only (data-parallel: all-reduce follows) */
 int mimrl_stage_apply(mimrl_handle* h, int stage);     /* value-clip + Adam on that stage's bucket         */
 int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses);  /* Solver.evaluate body (Solver.py:255-258) */
+int mimrl_estimate(mimrl_handle* h, int stage);        /* estimators only, on the features of the last forward (Model.py:305/343) */
 int64_t mimrl_workspace_bytes(const mimrl_handle* h);
+/* phase profiler: HIP events on the engine's stream around each phase of the eager (non-graph) path */
+enum { MIMRL_PH_GEMM_MISC = 0, MIMRL_PH_GRU_FWD, MIMRL_PH_GRU_BWD, MIMRL_PH_CUBE_FWD, MIMRL_PH_CUBE_BWD, MIMRL_PH_EST_FWD,
+       MIMRL_PH_EST_BWD, MIMRL_PH_OPT, MIMRL_PH_MODEL_MISC, MIMRL_NPHASES };
+int mimrl_profile_enable(mimrl_handle* h, int on);     /* forces eager launches while on */
+int mimrl_profile_read(mimrl_handle* h, float* ms_sum /*[MIMRL_NPHASES]*/, int32_t* launches /*[MIMRL_NPHASES]*/);  /* syncs; resets */
 void mimrl_destroy(mimrl_handle* h);
 
 /* ---- operator-level entry points (used by the parity tests; all asynchronous on `stream`) ---- */

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmimrl_hip.so")
 MAX_BLOCKS = 4
 NSCALARS = 64
+PHASES = ["gemm_misc", "gru_fwd", "gru_bwd", "cube_fwd", "cube_bwd", "est_fwd", "est_bwd", "opt", "model_misc"]
 S1_LOSS, S1_MIS, S1_LOSSES, S2_LOSS, S2_TASK, S2_MIS, S2_LOSSES = 0, 1, 12, 32, 33, 34, 42
 
 BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6}
@@ -37,7 +38,7 @@ class Cfg(C.Structure):
         ("coef1", C.c_float * 11), ("coef2", C.c_float * 8),
         ("weight_decay", C.c_float), ("grad_clip", C.c_float),
         ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("precision", C.c_int32), ("use_graph", C.c_int32), ("seed", C.c_uint64),
+        ("precision", C.c_int32), ("use_graph", C.c_int32), ("device_anchors", C.c_int32), ("seed", C.c_uint64),
     ]
 
 
@@ -79,7 +80,8 @@ def load() -> C.CDLL:
     lib.mimrl_op_cmi_loss.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_create.argtypes = [C.POINTER(Cfg), _FP, C.POINTER(_FP)]
     lib.mimrl_bind.argtypes = [_FP, C.POINTER(Buffers)]
-    for fn in ("mimrl_set_bank_rows", "mimrl_stage_grads", "mimrl_stage_apply"):
+    lib.mimrl_profile_read.argtypes = [_FP, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    for fn in ("mimrl_set_bank_rows", "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_estimate", "mimrl_profile_enable"):
         getattr(lib, fn).argtypes = [_FP, C.c_int]
     for fn in ("mimrl_stage1_step", "mimrl_stage2_step", "mimrl_destroy", "mimrl_workspace_bytes"):
         getattr(lib, fn).argtypes = [_FP]
@@ -95,7 +97,8 @@ def load() -> C.CDLL:
 EXPORTS = [
     "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry",
     "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_stage1_step", "mimrl_stage2_step",
-    "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_workspace_bytes", "mimrl_destroy", "mimrl_op_gemm",
+    "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read",
+    "mimrl_workspace_bytes", "mimrl_destroy", "mimrl_op_gemm",
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_adam",
 ]
@@ -108,7 +111,7 @@ def check(rc: int) -> int:
 
 
 def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capacity: int = 0, precision: str = "fp32",
-             use_graph: bool = False, seed: int = 0) -> Cfg:
+             use_graph: bool = False, seed: int = 0, device_anchors: bool = False) -> Cfg:
     """Translate the reference's ``opt`` Namespace (Parameters.py) into the C config."""
     c = Cfg()
     c.batch = int(opt.batch_size)
@@ -162,6 +165,7 @@ def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capaci
     c.beta1, c.beta2, c.adam_eps = 0.9, 0.999, 1e-8
     c.precision = PREC[precision]
     c.use_graph = int(bool(use_graph))
+    c.device_anchors = int(bool(device_anchors))
     c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     return c
 

@@ -153,6 +153,25 @@ struct mimrl_handle {
   size_t gbuf_floats = 0;
   float *dtx = nullptr, *ds[2], *dgx[2][2], *dgh[2][2], *hprev[2][2], *dh0[2];
 
+  // phase profiler
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[MIMRL_NPHASES];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  struct Scope {
+    mimrl_handle* h; int ph; hipEvent_t a = nullptr, b = nullptr;
+    Scope(mimrl_handle* h_, int ph_) : h(h_), ph(ph_) {
+      if (!h->prof_on) return;
+      if (!h->prof_pool.empty()) { a = h->prof_pool.back().first; b = h->prof_pool.back().second; h->prof_pool.pop_back(); }
+      else { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+      (void)hipEventRecord(a, h->stream);
+    }
+    ~Scope() {
+      if (!a) return;
+      (void)hipEventRecord(b, h->stream);
+      h->prof_ev[ph].push_back({a, b});
+    }
+  };
+
   // graphs: [stage 1|2][kind: 0 = step (grads+apply), 1 = grads only]
   hipGraphExec_t graph[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   int graph_rows[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
@@ -433,7 +452,7 @@ int mimrl_handle::model_forward(bool train, bool save) {
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
       }
     }
-    MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0));
+    { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
   }
   // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
   for (int m = 0; m < 2; ++m)
@@ -441,7 +460,7 @@ int mimrl_handle::model_forward(bool train, bool save) {
                         pdrop[1 + m], key(), 1 + m));
   // T_F, A_F, V_F (Model.py:466)
   MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
-  MX(cube_forward(train));
+  { Scope sc(this, MIMRL_PH_CUBE_FWD); MX(cube_forward(train)); }
   // head (Model.py:489-515)
   const BlockBuf& last = bb[cfg.n_blocks - 1];
   const int ol = cfg.d_outs[cfg.n_blocks - 1][0], ok = cfg.d_outs[cfg.n_blocks - 1][1], od = cfg.d_outs[cfg.n_blocks - 1][2];
@@ -709,7 +728,7 @@ int mimrl_handle::model_backward() {
   MX(head_bwd(stream, dfeat, dpred, P(cls_w), bufs.feats, gbuf[0], Gm(cls_w), Gm(cls_b), B, ol, ok, od,
               cfg.compose_t_sum, cfg.compose_k_sum));
   int ci = 0;
-  MX(cube_backward(0, &ci));
+  { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
   float* dcube = gbuf[ci];
   // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T
   MX(feat_mean_bwd(stream, dfeat + (size_t)B * D, dcube, B, T, L, 3, D));
@@ -733,7 +752,7 @@ int mimrl_handle::model_backward() {
                                 dgh[m][d], hprev[m][d]};
       }
     }
-    MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0));
+    { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
     for (int m = 0; m < 2; ++m) {
       const float* in = l == 0 ? xin[m] : h0[m];
       for (int d = 0; d < 2; ++d) {
@@ -854,7 +873,9 @@ int mimrl_handle::estimators_forward(int stage, bool want_grad) {
   // ---- CMI: kNN product sampling + classifier
   const float* cur[5] = {bufs.feats, bufs.feats + BD, bufs.feats + 2 * BD, bufs.feats + 3 * BD, bufs.labels};
   const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
-  const int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
+  int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
+  if (cfg.device_anchors)
+    MX(sample_anchors(stream, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage));
   KnnArgs ka;
   ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = knn_idx;
   CmiAssembleArgs ca_;
@@ -962,9 +983,9 @@ int mimrl_handle::enqueue_grads(int stage) {
     if (!have_banks) return MIMRL_OK;   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     MX(model_forward(true, false));
-    MX(estimators_forward(1, true));
+    { Scope sc(this, MIMRL_PH_EST_FWD); MX(estimators_forward(1, true)); }
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
-    MX(estimators_backward(1));
+    { Scope sc(this, MIMRL_PH_EST_BWD); MX(estimators_backward(1)); }
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
@@ -978,9 +999,9 @@ int mimrl_handle::enqueue_grads(int stage) {
   hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
   LAUNCH_CHECK();
   if (have_banks) {
-    MX(estimators_forward(2, true));
+    { Scope sc(this, MIMRL_PH_EST_FWD); MX(estimators_forward(2, true)); }
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
-    MX(estimators_backward(2));
+    { Scope sc(this, MIMRL_PH_EST_BWD); MX(estimators_backward(2)); }
   } else {
     HIPX(hipMemsetAsync(dfeat, 0, sizeof(float) * 4 * B * EMB, stream));
   }
@@ -1004,6 +1025,7 @@ int mimrl_handle::enqueue_apply(int stage) {
     a.lr = bufs.lr_main; a.step = d_ints + 1;
   }
   a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
+  Scope sc(this, MIMRL_PH_OPT);
   return adam_step(stream, a);
 }
 
@@ -1017,7 +1039,7 @@ int mimrl_handle::run(int stage, int kind) {
     if (kind == 0) MX(enqueue_apply(stage));
     return MIMRL_OK;
   };
-  if (!cfg.use_graph) return body();
+  if (!cfg.use_graph || prof_on) return body();
   hipGraphExec_t& ex = graph[stage][kind];
   if (ex && graph_rows[stage][kind] != bank_rows) {   // bank size is baked into the kernel arguments
     HIPX(hipGraphExecDestroy(ex));
@@ -1104,6 +1126,8 @@ int mimrl_set_bank_rows(mimrl_handle* h, int rows) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (rows < 0 || rows > h->cfg.bank_capacity) return set_error(MIMRL_ERR_ARG, "bank rows %d outside [0,%d]", rows, h->cfg.bank_capacity);
   if (rows > 0) {
+    if (h->cfg.device_anchors && rows > 16384)
+      return set_error(MIMRL_ERR_ARG, "device anchor sampling supports banks up to 16384 rows (got %d)", rows);
     if (!h->bufs.bank_c || !h->bufs.bank_f || !h->bufs.bank_t || !h->bufs.bank_a || !h->bufs.bank_v || !h->bufs.anchors)
       return set_error(MIMRL_ERR_STATE, "banks/anchors must be bound before enabling them");
     if (rows - h->m_anchor() < h->cfg.k_neighbor)
@@ -1135,6 +1159,49 @@ int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses) {
   return MIMRL_OK;
 }
 
+int mimrl_estimate(mimrl_handle* h, int stage) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
+  if (h->bank_rows <= 0) return set_error(MIMRL_ERR_STATE, "mimrl_estimate needs non-empty banks");
+  MX(h->estimators_forward(stage, false));
+  if (stage == 1) {
+    hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, h->stream, h->bufs.scalars, h->mi_raw, h->cmi_raw,
+                       h->bce_raw, h->coef1());
+  } else {
+    hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, h->stream, h->bufs.pred, h->bufs.labels, (float*)nullptr,
+                       h->bufs.scalars + MIMRL_S2_TASK, h->cfg.batch);
+    hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, h->stream, h->bufs.scalars, h->mi_raw, h->cmi_raw,
+                       h->coef2(), 1);
+  }
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int mimrl_profile_enable(mimrl_handle* h, int on) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  h->prof_on = on != 0;
+  return MIMRL_OK;
+}
+
+int mimrl_profile_read(mimrl_handle* h, float* ms_sum, int32_t* launches) {
+  if (!h || !ms_sum || !launches) return set_error(MIMRL_ERR_ARG, "null argument");
+  HIPX(hipStreamSynchronize(h->stream));
+  for (int p = 0; p < MIMRL_NPHASES; ++p) {
+    double acc = 0.0;
+    for (auto& ev : h->prof_ev[p]) {
+      float ms = 0.f;
+      HIPX(hipEventElapsedTime(&ms, ev.first, ev.second));
+      acc += ms;
+      h->prof_pool.push_back(ev);
+    }
+    ms_sum[p] = (float)acc;
+    launches[p] = (int32_t)h->prof_ev[p].size();
+    h->prof_ev[p].clear();
+  }
+  return MIMRL_OK;
+}
+
 int64_t mimrl_workspace_bytes(const mimrl_handle* h) { return h ? (int64_t)h->ws_bytes : 0; }
 
 void mimrl_destroy(mimrl_handle* h) {
@@ -1142,6 +1209,9 @@ void mimrl_destroy(mimrl_handle* h) {
   for (int s = 1; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) (void)hipGraphExecDestroy(h->graph[s][k]);
+  for (int p = 0; p < MIMRL_NPHASES; ++p)
+    for (auto& ev : h->prof_ev[p]) h->prof_pool.push_back(ev);
+  for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->ws) (void)hipFree(h->ws);
   delete h;

@@ -33,6 +33,12 @@ struct KnnArgs {
 };
 int knn_sample(hipStream_t s, const KnnArgs& a);
 
+// device-side replacement of `np.random.choice(range(N), m, replace=False)` (Model.py:81): every row gets a random
+// 32-bit key (counter hash of seed/step/call/row); the m rows with the smallest keys, in key order, are the
+// anchors -- a uniformly random m-subset in uniformly random order.  One workgroup per call, bitonic sort in LDS.
+int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
+                   const int* step, uint32_t stream_id);
+
 // classifier input batch (Model.py:160-174):
 //   rows [0,n): joint = [x | y | z] of the current batch (operand = feature block [B,128] or the label column)
 //   rows [n,2n): prod  = [X[idx_x[j]] | Y[anchor[j/k]] | Z[anchor[j/k]]] from the banks (label bank tiled x128)

@@ -299,6 +299,37 @@ __global__ __launch_bounds__(256) void cmi_loss_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sample_anchors_kernel(int* __restrict__ anchors, int m, int N, int npow2,
+                                                              uint32_t seed_lo, uint32_t seed_hi,
+                                                              const int* __restrict__ step, uint32_t stream_id) {
+  extern __shared__ unsigned long long keys[];   // (hash << 32) | row ; padding = ~0
+  const int c = blockIdx.x;
+  const uint32_t st = (uint32_t)*step;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    unsigned long long k = ~0ull;
+    if (i < N) {
+      uint32_t h = mix32((uint32_t)i ^ mix32(st * 0x9E3779B9U + stream_id + 977u * c) ^ seed_lo);
+      h = mix32(h + seed_hi * 0x85ebca6bU + 0x632be5abU);
+      k = ((unsigned long long)h << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
+        const int lo = 2 * i - (i & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < m; i += blockDim.x) anchors[(long)c * m + i] = (int)(keys[i] & 0xffffffffu);
+}
+
 __global__ void gather_sum_kernel(float* __restrict__ dst, GatherSum g, int B, int D, int accumulate) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * D; i += (long)gridDim.x * blockDim.x) {
     const int b = i / D, d = i % D;
@@ -368,6 +399,22 @@ int knn_sample(hipStream_t s, const KnnArgs& a) {
     if (a.call[c].dz != 1 && a.call[c].dz > 256) return set_error(MIMRL_ERR_ARG, "knn: feature width > 256");
   const size_t sh = ((a.N + 31) / 32) * sizeof(unsigned) + 256 * KNN_KMAX * (sizeof(float) + sizeof(int));
   hipLaunchKernelGGL(knn_kernel, dim3(a.m, a.ncall), dim3(256), sh, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
+                   const int* step, uint32_t stream_id) {
+  int npow2 = 1;
+  while (npow2 < N) npow2 <<= 1;
+  if (npow2 < 2) npow2 = 2;
+  if (npow2 > 16384) return set_error(MIMRL_ERR_ARG, "device anchor sampling supports banks up to 16384 rows (got %d)", N);
+  if (m > N) return set_error(MIMRL_ERR_ARG, "more anchors than bank rows");
+  const size_t sh = (size_t)npow2 * sizeof(unsigned long long);
+  if (sh > 64 * 1024)
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_anchors_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+  hipLaunchKernelGGL(sample_anchors_kernel, dim3(ncall), dim3(1024), sh, s, anchors, m, N, npow2, seed_lo, seed_hi, step,
+                     stream_id);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

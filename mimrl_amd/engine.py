@@ -23,14 +23,15 @@ class HipEngine:
     """One engine = one (process, GPU).  Mirrors the state the reference keeps in Model + two Adam optimizers."""
 
     def __init__(self, opt, d_t: int, d_a: int, d_v: int, seq_len: Optional[int] = None, bank_capacity: int = 0,
-                 precision: str = "fp32", use_graph: bool = False, seed: int = 0, device: Optional[torch.device] = None):
+                 precision: str = "fp32", use_graph: bool = False, seed: int = 0, device: Optional[torch.device] = None,
+                 device_anchors: bool = False):
         if not torch.cuda.is_available():
             raise MimrlError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         torch.cuda.set_device(self.device)
         self.opt = opt
-        self.cfg = _lib.make_cfg(opt, d_t, d_a, d_v, seq_len, bank_capacity, precision, use_graph, seed)
+        self.cfg = _lib.make_cfg(opt, d_t, d_a, d_v, seq_len, bank_capacity, precision, use_graph, seed, device_anchors)
         check(self.lib.mimrl_device_check())
         self.entries, (n_main, n_crit) = _lib.layout_entries(self.cfg)
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -143,8 +144,29 @@ class HipEngine:
     def stage_apply(self, stage: int):
         check(self.lib.mimrl_stage_apply(self.handle, stage))
 
+    def bucket_grad(self, stage: int) -> torch.Tensor:
+        """Flat gradient bucket updated by ``stage`` (1: critics, 2: main model) -- the all-reduce payload."""
+        return self.crit["g"] if stage == 1 else self.main["g"]
+
+    def has_update(self, stage: int) -> bool:
+        return stage == 2 or self.bank_rows > 0          # epoch-0 rule: stage 1 does nothing without banks
+
     def forward(self, train: bool = False, with_losses: bool = False):
         check(self.lib.mimrl_forward(self.handle, int(train), int(with_losses)))
+
+    def estimate(self, stage: int):
+        """Estimators only, on the features left by the last forward (Model.compute_vmi_loss_stage1/2)."""
+        check(self.lib.mimrl_estimate(self.handle, stage))
+
+    def profile(self, on: bool):
+        check(self.lib.mimrl_profile_enable(self.handle, int(on)))
+
+    def profile_read(self):
+        """-> {phase: (total_ms, launches)} since the last read (synchronises)."""
+        n = len(_lib.PHASES)
+        ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
+        check(self.lib.mimrl_profile_read(self.handle, ms, cnt))
+        return {p: (float(ms[i]), int(cnt[i])) for i, p in enumerate(_lib.PHASES)}
 
     def read_scalars(self) -> np.ndarray:
         """One device->host read-back (the reference does >= 10 ``.item()`` syncs per iteration)."""

@@ -240,11 +240,30 @@ def gen_units():
     print(f"units: wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
 
 
+def gen_flags():
+    """Defaults and a README-style invocation parsed by the REFERENCE's Parameters.parse_args (Parameters.py:4-74)."""
+    import json
+    import Parameters as RP  # reference
+    out = {}
+    for tag, argv in (("defaults", []), ("readme", ["--d_hiddens", "50-3-128=10-3-128", "--d_outs", "50-3-128=10-3-128",
+                                                   "--dropout_mlp", "0.0-0.0-0.0", "--dropout", "0.1-0.1-0.1-0.1", "--bias",
+                                                   "--res_project", "1-1", "--critic_type", "separate", "--bound_type",
+                                                   "infonce", "--k_neighbor", "2", "--stage1_n", "2", "--gradient_clip", "1.5",
+                                                   "--learning_rate", "4e-3", "--loss", "MAE", "--optm", "Adam"])):
+        sys.argv = ["Main.py"] + argv
+        out[tag] = {"argv": argv, "parsed": vars(RP.parse_args())}
+    path = os.path.join(HERE, "ref_flags.json")
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print("flags: wrote", path)
+
+
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = sys.argv[1:] or list(CONFIGS) + ["units"]
+    which = sys.argv[1:] or list(CONFIGS) + ["units", "flags"]
     for name in which:
         if name == "units":
             gen_units()
+        elif name == "flags":
+            gen_flags()
         else:
             gen(name, CONFIGS[name])

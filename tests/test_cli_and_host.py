@@ -1,0 +1,57 @@
+"""CPU tier: CLI parity with the reference's Parameters.py (fixture captured from the reference), host-side logic
+(lr schedules, anchors draw), and the gloo world_size-2 data-parallel path driven by an oracle-backed engine."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mimrl_amd import Parameters, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_flags_match_reference_defaults_and_readme():
+    ref = json.load(open(os.path.join(HERE, "golden", "ref_flags.json")))
+    for tag in ("defaults", "readme"):
+        ours = vars(Parameters.parse_args(ref[tag]["argv"]))
+        for k, v in ref[tag]["parsed"].items():
+            assert k in ours, f"missing reference flag --{k}"
+            assert ours[k] == v, f"--{k}: {ours[k]!r} != reference {v!r} ({tag})"
+    with pytest.raises(SystemExit):
+        Parameters.parse_args(["--cmi_last_acticate", "tanh"])       # reference: choices=['hardtanh','sigmoid']
+
+
+def test_anchor_draw_consumes_numpy_rng_like_reference():
+    """Model.py:81 draws np.random.choice(range(N), size=m, replace=False) once per prod_knn_sample call."""
+    np.random.seed(123)
+    ours = synth.draw_anchors(1000, 16, 6)
+    np.random.seed(123)
+    ref = np.stack([np.random.choice(range(1000), size=16, replace=False) for _ in range(6)])
+    np.testing.assert_array_equal(ours, ref)
+    assert all(len(set(r)) == 16 for r in ours)
+
+
+def test_lr_schedules():
+    from mimrl_amd.Solver import Solver
+    s = Solver.__new__(Solver)
+    s.opt = Parameters.parse_args(["--lr_decrease", "multi_step", "--lr_decrease_iter", "2-4", "--lr_decrease_rate", "0.1"])
+    assert [round(s.lr_factor(e), 6) for e in range(6)] == [1, 1, 0.1, 0.1, 0.01, 0.01]      # MultiStepLR
+    s.opt = Parameters.parse_args(["--lr_decrease", "step", "--lr_decrease_iter", "3", "--lr_decrease_rate", "0.5"])
+    assert [s.lr_factor(e) for e in range(7)] == [1, 1, 1, 0.5, 0.5, 0.5, 0.25]              # StepLR
+    s.opt = Parameters.parse_args(["--lr_decrease", "exp", "--lr_decrease_rate", "0.5"])
+    assert [s.lr_factor(e) for e in range(3)] == [1, 0.5, 0.25]                              # ExponentialLR
+
+
+def test_ddp_two_ranks_gloo():
+    """world_size 2 on CPU (gloo): grads -> all-reduce(mean) -> clip+Adam equals single-process Adam on the mean."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(HERE, "ddp_gloo_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DDP_OK" in r.stdout
