@@ -27,6 +27,20 @@ sys.path.insert(0, ROOT)
 from mimrl_amd import _lib, dist as mdist, synth  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Cores this process may actually use (cgroup/affinity aware), capped: the oracle's small ops stop scaling ~16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
 H = 128
 
 
@@ -72,7 +86,7 @@ def cpu_baseline(opt, N, budget_s=25.0):
     cores on the SAME workload: a bounded sample of whole two-stage iterations."""
     from oracle import mimrl_ref as R
     from mimrl_amd import layout
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     p = {n: torch.from_numpy(synth.portable_tensor(n, s, 0)) for n, s in layout.named_shapes(opt, 768, 74, 35)}
     batch = tuple(torch.from_numpy(x) for x in synth.synthetic_batch(opt.batch_size, opt.time_len, seed=0))
     banks = {k: torch.from_numpy(v) for k, v in synth.synthetic_banks(N, seed=0).items()}
@@ -86,13 +100,16 @@ def cpu_baseline(opt, N, budget_s=25.0):
     def one():
         R.two_stage_step(p, cpu_opt, av, am, batch, banks, synth.draw_anchors(N, m, 6), synth.draw_anchors(N, m, 6))
 
+    tw = time.perf_counter()
     one()                                 # warm-up
+    tw = time.perf_counter() - tw
+    log(f"cpu baseline warm-up iteration took {tw:.1f}s on {torch.get_num_threads()} threads")
     t0, n = time.perf_counter(), 0
     while True:
         one()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 12:
+        if dt + tw > budget_s or n >= 12:   # bounded sample: stop once ~budget_s of CPU work is spent
             break
     return {"value": n / dt, "unit": "two-stage iters/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 warm-up + {n} two-stage iterations of the same workload (B={opt.batch_size}, T={opt.time_len}, "
@@ -121,6 +138,7 @@ def main():
 
     opt, N = workload(args.workload)
     B, T = opt.batch_size, opt.time_len
+    log(f"creating engine ({args.workload}, {args.precision}, graph={not args.no_graph})")
     eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision=args.precision, use_graph=not args.no_graph,
                     seed=1234 + rank, device_anchors=True)
     shapes = [(n, tuple(v.shape)) for n, v in eng.params.items()]
@@ -137,9 +155,14 @@ def main():
             eng.stage1_step()
             eng.stage2_step()
 
-    for _ in range(args.warmup):
+    log("engine ready; warm-up")
+    for i in range(args.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     torch.cuda.synchronize()
+    log("warm-up done; timing")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -158,6 +181,7 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     wall = float(el.item())
+    log(f"timed region: {1e3 * wall / args.steps:.3f} ms/step")
     scal = eng.read_scalars()
     finite = bool(np.isfinite(scal).all())
 
@@ -176,6 +200,7 @@ def main():
         pr = eng.profile_read()
         eager_ms = ev0.elapsed_time(ev1) / args.profile_steps
         eng.profile(False)
+        log(f"phase profile done (eager {eager_ms:.3f} ms/step)")
         phases = {k: {"ms_per_step": v[0] / args.profile_steps, "launch_groups_per_step": v[1] / args.profile_steps}
                   for k, v in pr.items() if v[1]}
         phases["eager_total_ms_per_step"] = eager_ms

@@ -62,6 +62,13 @@ __device__ __forceinline__ float act_grad(int act, float u) {
   }
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// hardware-rate versions for the recurrent gate math: v_exp_f32 + v_rcp_f32 (~1 ulp each), no IEEE division, no libm
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2/(exp(2x)+1); saturates cleanly to +-1
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

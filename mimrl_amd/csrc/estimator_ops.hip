@@ -154,86 +154,89 @@ __global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact kNN among non-anchor rows; one workgroup per (anchor, call)
+// exact kNN among non-anchor rows; one workgroup per (anchor, call).  Thread-per-row distance evaluation with the
+// anchor vector in LDS and 16-byte row loads; per-thread sorted top-K (K compile-time), merged through LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_KMAX = 8;
 
+template <int K>
 struct TopK {
-  float d[KNN_KMAX];
-  int i[KNN_KMAX];
-  __device__ void init() {
+  float d[K];
+  int i[K];
+  __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int q = 0; q < KNN_KMAX; ++q) { d[q] = INFINITY; i[q] = 0x7fffffff; }
+    for (int q = 0; q < K; ++q) { d[q] = INFINITY; i[q] = 0x7fffffff; }
   }
-  __device__ void push(float dist, int idx, int k) {
-    // keep ascending (dist, idx); insertion with static indexing
+  __device__ __forceinline__ void push(float dist, int idx) {   // keep ascending (dist, idx)
     float cd = dist; int ci = idx;
 #pragma unroll
-    for (int q = 0; q < KNN_KMAX; ++q) {
-      if (q < k) {
-        const bool lt = cd < d[q] || (cd == d[q] && ci < i[q]);
-        if (lt) { const float td = d[q]; const int ti = i[q]; d[q] = cd; i[q] = ci; cd = td; ci = ti; }
-      }
+    for (int q = 0; q < K; ++q) {
+      const bool lt = cd < d[q] || (cd == d[q] && ci < i[q]);
+      const float td = d[q]; const int tix = i[q];
+      d[q] = lt ? cd : td; i[q] = lt ? ci : tix;
+      cd = lt ? td : cd; ci = lt ? tix : ci;
     }
   }
 };
 
+template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(KnnArgs a) {
-  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask, then candidate lists
+  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask | [256] anchor vector | candidate lists
   const int ai = blockIdx.x, c = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
   const int nwords = (a.N + 31) / 32;
   unsigned* mask = smem;
-  float* cd = reinterpret_cast<float*>(smem + nwords);
-  int* ci = reinterpret_cast<int*>(cd + 256 * KNN_KMAX);
+  float* av = reinterpret_cast<float*>(smem + ((nwords + 3) & ~3));
+  float* cd = av + 256;
+  int* ci = reinterpret_cast<int*>(cd + 256 * K);
   for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
   __syncthreads();
   const int* anc = a.anchors + (long)c * a.m;
   for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
-  __syncthreads();
-  const float* Z = a.call[c].Z;
+  const float* __restrict__ Z = a.call[c].Z;
   const int dz = a.call[c].dz;
   const int me = anc[ai];
-  TopK tk; tk.init();
-  int nlists;
+  if (tid < dz) av[tid] = Z[(long)me * dz + tid];
+  __syncthreads();
+  TopK<K> tk; tk.init();
   if (dz == 1) {
-    const float z0 = Z[me];
+    const float z0 = av[0];
     for (int r = tid; r < a.N; r += 256) {
-      if (mask[r >> 5] >> (r & 31) & 1u) continue;
+      if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
       const float df = Z[r] - z0;
-      tk.push(df * df, r, a.k);
+      tk.push(df * df, r);
     }
-    nlists = 256;
-#pragma unroll
-    for (int q = 0; q < KNN_KMAX; ++q) { cd[tid * KNN_KMAX + q] = tk.d[q]; ci[tid * KNN_KMAX + q] = tk.i[q]; }
   } else {
-    // wave per row, lanes over dims (coalesced row reads)
-    float zr[4];
-    const int per = (dz + 63) / 64;           // dz <= 256
-    for (int q = 0; q < per; ++q) { const int j = lane + 64 * q; zr[q] = j < dz ? Z[(long)me * dz + j] : 0.f; }
-    for (int r = w; r < a.N; r += 4) {
-      if (mask[r >> 5] >> (r & 31) & 1u) continue;
-      float s = 0.f;
-      for (int q = 0; q < per; ++q) {
-        const int j = lane + 64 * q;
-        const float df = (j < dz ? Z[(long)r * dz + j] : 0.f) - zr[q];
-        s += df * df;
+    for (int r = tid; r < a.N; r += 256) {
+      if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
+      const float4* row = reinterpret_cast<const float4*>(Z + (long)r * dz);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int j = 0; j < dz / 4; ++j) {
+        const float4 q = row[j];
+        const float4 w = *reinterpret_cast<const float4*>(av + 4 * j);
+        const float d0 = q.x - w.x, d1 = q.y - w.y, d2 = q.z - w.z, d3 = q.w - w.w;
+        s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
       }
-      s = wave_sum(s);
-      tk.push(s, r, a.k);
-    }
-    nlists = 4;
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < KNN_KMAX; ++q) { cd[w * KNN_KMAX + q] = tk.d[q]; ci[w * KNN_KMAX + q] = tk.i[q]; }
+      tk.push((s0 + s1) + (s2 + s3), r);
     }
   }
+#pragma unroll
+  for (int q = 0; q < K; ++q) { cd[tid * K + q] = tk.d[q]; ci[tid * K + q] = tk.i[q]; }
   __syncthreads();
+  // tree merge of the 256 sorted lists: 8 rounds, list t absorbs list t+stride
+  for (int stride = 128; stride > 0; stride >>= 1) {
+    if (tid < stride) {
+#pragma unroll
+      for (int q = 0; q < K; ++q) tk.push(cd[(tid + stride) * K + q], ci[(tid + stride) * K + q]);
+#pragma unroll
+      for (int q = 0; q < K; ++q) { cd[tid * K + q] = tk.d[q]; ci[tid * K + q] = tk.i[q]; }
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
-    TopK fin; fin.init();
-    for (int l = 0; l < nlists; ++l)
-      for (int q = 0; q < a.k; ++q) fin.push(cd[l * KNN_KMAX + q], ci[l * KNN_KMAX + q], a.k);
-    for (int q = 0; q < a.k; ++q) a.idx_x[((long)c * a.m + ai) * a.k + q] = fin.i[q];
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      if (q < a.k) a.idx_x[((long)c * a.m + ai) * a.k + q] = tk.i[q];
   }
 }
 
@@ -396,9 +399,14 @@ int knn_sample(hipStream_t s, const KnnArgs& a) {
   if (a.k > KNN_KMAX || a.k < 1) return set_error(MIMRL_ERR_ARG, "knn: k_neighbor must be in [1,%d]", KNN_KMAX);
   if (a.N - a.m < a.k) return set_error(MIMRL_ERR_ARG, "knn: bank too small (N=%d, m=%d, k=%d)", a.N, a.m, a.k);
   for (int c = 0; c < a.ncall; ++c)
-    if (a.call[c].dz != 1 && a.call[c].dz > 256) return set_error(MIMRL_ERR_ARG, "knn: feature width > 256");
-  const size_t sh = ((a.N + 31) / 32) * sizeof(unsigned) + 256 * KNN_KMAX * (sizeof(float) + sizeof(int));
-  hipLaunchKernelGGL(knn_kernel, dim3(a.m, a.ncall), dim3(256), sh, s, a);
+    if (a.call[c].dz != 1 && (a.call[c].dz > 256 || a.call[c].dz % 4 != 0))
+      return set_error(MIMRL_ERR_ARG, "knn: feature width must be 1 or a multiple of 4 up to 256");
+  const int K = a.k <= 2 ? 2 : (a.k <= 4 ? 4 : 8);
+  const size_t sh = (((a.N + 31) / 32 + 3) & ~3) * sizeof(unsigned) + 256 * sizeof(float) +
+                    256 * (size_t)K * (sizeof(float) + sizeof(int));
+  if (K == 2) hipLaunchKernelGGL(knn_kernel<2>, dim3(a.m, a.ncall), dim3(256), sh, s, a);
+  else if (K == 4) hipLaunchKernelGGL(knn_kernel<4>, dim3(a.m, a.ncall), dim3(256), sh, s, a);
+  else hipLaunchKernelGGL(knn_kernel<8>, dim3(a.m, a.ncall), dim3(256), sh, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

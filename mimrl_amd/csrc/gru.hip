@@ -84,6 +84,14 @@ __device__ __forceinline__ void put4(Tile<false, K>& t, int b, int k0, float x0,
   t.v[k0][b] = x0; t.v[k0 + 1][b] = x1; t.v[k0 + 2][b] = x2; t.v[k0 + 3][b] = x3;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it would wait every step
+// for the saved-gate / output stores and for the prefetched gx loads -- the whole point of the prefetch is to keep
+// them in flight across the step boundary.  LDS operations of a wave complete in order, so lgkmcnt(0) before
+// s_barrier makes this wave's state-tile writes visible to the other waves after the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -198,10 +206,10 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
       const float gn[4] = {gxc[2][s].x, gxc[2][s].y, gxc[2][s].z, gxc[2][s].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        rr[r] = sigmoid_f(gr[r] + acc[0][s][r] + bh[0][s][r]);
-        zz[r] = sigmoid_f(gz[r] + acc[1][s][r] + bh[1][s][r]);
+        rr[r] = fast_sigmoid(gr[r] + acc[0][s][r] + bh[0][s][r]);
+        zz[r] = fast_sigmoid(gz[r] + acc[1][s][r] + bh[1][s][r]);
         hn[r] = acc[2][s][r] + bh[2][s][r];
-        nn[r] = tanhf(gn[r] + rr[r] * hn[r]);
+        nn[r] = fast_tanh(gn[r] + rr[r] * hn[r]);
         const float hnew = nn[r] + zz[r] * (hreg[s][r] - nn[r]);
         ho[r] = valid ? hnew : 0.f;
         hreg[s][r] = valid ? hnew : hreg[s][r];
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
         st4(q.saved + sv_index(t, ntile, tile, 3, w, s, lane), hn[0], hn[1], hn[2], hn[3]);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -276,28 +284,47 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   float* dgh_b = q.dgh + bb * rs_g;
   float* hp_b = q.hprev + bb * (long)T * H;
 
+  // software pipeline: the six operand vectors of step+1 are requested before step's math (global latency ~1-2 us
+  // would otherwise sit on the critical path of every step)
+  struct Ops { float4 R, Z, N, HN, DO, HP; };
+  Ops nx[2];
+  auto fetch = [&](int step, Ops* o) {
+    const int t = dir ? step : T - 1 - step;
+    const int tprev = dir ? t + 1 : t - 1;
+    const bool valid = t < len;
+    const bool hp_ok = valid && tprev >= 0 && tprev < len;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int unit = 32 * w + 16 * s + 4 * kq;
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      // h_prev is the previous VALID output of this direction; with packed semantics that is simply out[tprev]
+      // when tprev is inside [0,len) and the zero initial state otherwise.
+      o[s].R = valid ? ld4(q.saved + sv_index(t, ntile, tile, 0, w, s, lane)) : zero;
+      o[s].Z = valid ? ld4(q.saved + sv_index(t, ntile, tile, 1, w, s, lane)) : zero;
+      o[s].N = valid ? ld4(q.saved + sv_index(t, ntile, tile, 2, w, s, lane)) : zero;
+      o[s].HN = valid ? ld4(q.saved + sv_index(t, ntile, tile, 3, w, s, lane)) : zero;
+      o[s].DO = valid ? ld4(dout_b + (long)t * a.dout_ld + unit) : zero;
+      o[s].HP = hp_ok ? ld4(out_b + (long)tprev * a.out_ld + unit) : zero;
+    }
+  };
+  fetch(0, nx);
+
   for (int step = 0; step < T; ++step) {
     // forward visited t in order (dir ? T-1..0 : 0..T-1); backward walks it the other way round
     const int t = dir ? step : T - 1 - step;
-    const int tprev = dir ? t + 1 : t - 1;                  // time index of h_prev in the forward recurrence
     const int cur = step & 1;
     const bool valid = t < len;
+    Ops op[2] = {nx[0], nx[1]};
+    if (step + 1 < T) fetch(step + 1, nx);
     float dhz[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int unit = 32 * w + 16 * s + 4 * kq;
       float drp[4] = {0.f, 0.f, 0.f, 0.f}, dzp[4] = {0.f, 0.f, 0.f, 0.f}, dnp[4] = {0.f, 0.f, 0.f, 0.f},
             dnr[4] = {0.f, 0.f, 0.f, 0.f};
-      float4 HP = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 HP = op[s].HP;
       if (valid) {
-        const float4 R = ld4(q.saved + sv_index(t, ntile, tile, 0, w, s, lane));
-        const float4 Z = ld4(q.saved + sv_index(t, ntile, tile, 1, w, s, lane));
-        const float4 N = ld4(q.saved + sv_index(t, ntile, tile, 2, w, s, lane));
-        const float4 HN = ld4(q.saved + sv_index(t, ntile, tile, 3, w, s, lane));
-        const float4 DO = ld4(dout_b + (long)t * a.dout_ld + unit);
-        // h_prev is the previous VALID output of this direction; with packed semantics that is simply
-        // out[tprev] when tprev is inside [0,len) and the zero initial state otherwise.
-        if (tprev >= 0 && tprev < len) HP = ld4(out_b + (long)tprev * a.out_ld + unit);
+        const float4 R = op[s].R, Z = op[s].Z, N = op[s].N, HN = op[s].HN, DO = op[s].DO;
         const float rr[4] = {R.x, R.y, R.z, R.w}, zz[4] = {Z.x, Z.y, Z.z, Z.w}, nn[4] = {N.x, N.y, N.z, N.w},
                     hn[4] = {HN.x, HN.y, HN.z, HN.w}, dd[4] = {DO.x, DO.y, DO.z, DO.w},
                     hp[4] = {HP.x, HP.y, HP.z, HP.w};
@@ -329,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
         st4(dgh_b + (long)t * G + 2 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 acc[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
