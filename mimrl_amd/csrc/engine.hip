@@ -604,10 +604,11 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       if (a.fc2.b >= 0) MX(colsum(stream, dym, R2, od, od, Gm(a.fc2.b)));
       if (a.res >= 0) { GemmDesc g = gemm_tn(dy, od, xin, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(G_(g)); }
       GRAB(i_du);                                            // dU = (dYm . W2) * act'(U)
-      { GemmDesc g = gemm_nn(dym, od, P(a.fc2.w), hd, gbuf[i_du], hd, (int)R2, hd, od); g.act = cfg.activation; g.gradact_u = b.d.u; MX(G_(g)); }
+      { GemmDesc g = gemm_nn(dym, od, P(a.fc2.w), hd, gbuf[i_du], hd, (int)R2, hd, od); g.act = cfg.activation; g.gradact_u = b.d.u;
+        if (a.fc1.b >= 0) g.colsum = Gm(a.fc1.b);     // db1 = column sums of dU, fused into the epilogue
+        MX(G_(g)); }
       if (i_dym != i_dy) release(i_dym);
       { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(G_(g)); }
-      if (a.fc1.b >= 0) MX(colsum(stream, gbuf[i_du], R2, hd, hd, Gm(a.fc1.b)));
       GRAB(i_dx0);
       int i_dx = i_dx0;
       { GemmDesc g = gemm_nn(gbuf[i_du], hd, P(a.fc1.w), id, gbuf[i_dx], id, (int)R2, id, hd); MX(G_(g)); }
@@ -749,7 +750,7 @@ int mimrl_handle::model_backward() {
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dgx[m][d],
-                                dgh[m][d], hprev[m][d]};
+                                dgh[m][d], hprev[m][d], Gm(g.b_ih), Gm(g.b_hh)};
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
@@ -759,8 +760,6 @@ int mimrl_handle::model_backward() {
         const GruDirW& g = gru[m][l][d];
         { GemmDesc q = gemm_tn(dgx[m][d], G, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_(q)); }
         { GemmDesc q = gemm_tn(dgh[m][d], G, hprev[m][d], H, Gm(g.w_hh), H, G, H, (int)BT_); q.atomic = 1; MX(G_(q)); }
-        MX(colsum(stream, dgx[m][d], BT_, G, G, Gm(g.b_ih)));
-        MX(colsum(stream, dgh[m][d], BT_, G, G, Gm(g.b_hh)));
         if (l == 1) {   // gradient to the layer-0 outputs: dh0 = sum_dir dgx_dir . W_ih_l1_dir
           GemmDesc q = gemm_nn(dgx[m][d], G, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
           q.beta = d == 0 ? 0.f : 1.f;
@@ -798,32 +797,32 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
                                      float* din, bool wgrad) {
   float* dz = dout;
   int pp = 0;
+  if (wgrad)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
+    MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
   for (int l = nl - 1; l >= 0; --l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
     const float* a_in = l == 0 ? in : act[l - 1];
-    if (wgrad) {   // dW_l = dZ^T A_l ; db_l = colsum(dZ)     (one writer per tensor: plain stores into the zeroed bucket)
+    if (wgrad) {   // dW_l = dZ^T A_l     (one writer per tensor: plain stores into the zeroed bucket)
       GemmDesc g;
       g.A = dz; g.sa_m = 1; g.sa_k = dout_; g.sa_b = (long)brows * dout_;
       g.B = a_in; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
       g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
       g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
       MX(G_(g));
-      MX(colsum(stream, dz, rows, dout_, dout_, CG(p0 + l_off[l][1]), nb, (long)brows * dout_, pstride));
     }
     float* target = l > 0 ? dtmp[pp] : din;
     if (!target) break;
-    GemmDesc g;   // dA_l = dZ W_l
+    GemmDesc g;   // dZ_{l-1} = (dZ_l W_l) * relu'(A_l)  [+ column sums -> db_{l-1}]; for l == 0: plain input gradient
     g.A = dz; g.sa_m = dout_; g.sa_k = 1; g.sa_b = (long)brows * dout_;
     g.B = CP(p0 + l_off[l][0]); g.sb_k = din_; g.sb_n = 1; g.sb_b = pstride;
     g.C = target; g.sc_m = din_; g.sc_n = 1; g.sc_b = (long)brows * din_;
     g.M = rows; g.N = din_; g.K = dout_; g.batch = nb;
-    MX(G_(g));
     if (l > 0) {
-      // relu backward against the saved post-activation; rows beyond `rows` inside a group are never read
-      MX(relu_bwd_inplace(stream, act[l - 1], target, (long)nb * brows * din_));
-      dz = target;
-      pp ^= 1;
+      g.act = ACT_RELU; g.gradact_u = act[l - 1];     // post-activation > 0  <=>  pre-activation > 0
+      if (wgrad) { g.colsum = CG(p0 + l_off[l - 1][1]); g.colsum_b = pstride; }
     }
+    MX(G_(g));
+    if (l > 0) { dz = target; pp ^= 1; }
   }
   return MIMRL_OK;
 }
@@ -1226,7 +1225,8 @@ int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M,
   d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.batch = batch;
   d.sa_m = st[0]; d.sa_k = st[1]; d.sa_b = st[2]; d.sb_k = st[3]; d.sb_n = st[4]; d.sb_b = st[5];
   d.sc_m = st[6]; d.sc_n = st[7]; d.sc_b = st[8];
-  d.bias_n = bias_n; d.bias_m = bias_m; d.alpha = alpha; d.beta = beta; d.act = act;
+  d.bias_n = bias_n; d.bias_m = bias_m; d.alpha = alpha; d.beta = beta; d.act = act & 0xff;
+  d.atomic = (act >> 8) & 1;   // bit 8: accumulate with atomics (enables split-K / batch-group reduction)
   return gemm(reinterpret_cast<hipStream_t>(stream), d, (precision & 1) != 0);
 }
 
@@ -1252,8 +1252,8 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
   std::memset(&a, 0, sizeof a);
   a.B = B; a.T = T; a.out_ld = 2 * H; a.dout_ld = 2 * H; a.dout_off = H; a.nmod = 1;
   a.lens[0] = lens; a.lens[1] = lens;
-  a.seq[0][0] = GruSeqBwd{whh_f, saved_f, out, dout, dgx_f, dgh_f, hprev_f};
-  a.seq[0][1] = GruSeqBwd{whh_r, saved_r, out, dout, dgx_r, dgh_r, hprev_r};
+  a.seq[0][0] = GruSeqBwd{whh_f, saved_f, out, dout, dgx_f, dgh_f, hprev_f, nullptr, nullptr};
+  a.seq[0][1] = GruSeqBwd{whh_r, saved_r, out, dout, dgx_r, dgh_r, hprev_r, nullptr, nullptr};
   return gru_backward(reinterpret_cast<hipStream_t>(stream), a, (precision & 1) != 0);
 }
 

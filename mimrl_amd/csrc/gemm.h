@@ -25,6 +25,7 @@ struct GemmDesc {
   float* pre = nullptr;              // optional: pre-activation copy (same strides as C)
   const float* gradact_u = nullptr;  // optional: multiply by act'(u[m,n]) (same strides as C) -- backward of act
   int atomic = 0;                    // C += result with float atomics (batch acts as an extra reduction when sc_b==0)
+  float* colsum = nullptr; long colsum_b = 0;   // optional: colsum[b*colsum_b + n] += sum_m (stored value)  (bias gradients)
 };
 
 // A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   float* __restrict__ C = d.C + (long)bz * d.sc_b;
   const bool atomic = d.atomic || ka.ksplit > 1;
   const float bn = d.bias_n ? d.bias_n[(long)bz * d.bias_n_b + n] : 0.f;
+  float csum = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -182,6 +183,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     else v = act_apply(d.act, v);
     if (atomic) atomicAdd(&C[off], v);
     else C[off] = v;
+    csum += v;
+  }
+  if (d.colsum) {   // fused bias gradient: lanes l and l^32 hold the same column
+    csum += __shfl_xor(csum, 32, 64);
+    if (lane < 32) atomicAdd(&d.colsum[(long)bz * d.colsum_b + n], csum);
   }
 }
 
@@ -202,7 +208,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   const int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
   const int ktiles = (d.K + BK - 1) / BK;
   int ksplit = 1;
-  if (d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && d.act == ACT_NONE && ktiles >= 8) {
+  if (d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum && d.act == ACT_NONE && ktiles >= 8) {
     // accumulate-into-zeroed-output GEMMs (weight gradients): split K until the grid has ~2 waves of workgroups
     ksplit = (512 + tiles - 1) / tiles;
     if (ksplit > ktiles / 4) ksplit = ktiles / 4;

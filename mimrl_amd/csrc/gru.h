@@ -26,6 +26,8 @@ struct GruSeqBwd {
   float* dgx;          // [B,T,3H]
   float* dgh;          // [B,T,3H]
   float* hprev;        // [B,T,H]  h_{prev} of every step (0 at sequence starts / padded steps): operand of dW_hh
+  float* db_ih;        // [3H] += sum_{b,t} dgx   (nullable)
+  float* db_hh;        // [3H] += sum_{b,t} dgh   (nullable)
 };
 
 struct GruBwdArgs {

@@ -269,10 +269,14 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   }
 
   float carry[2][4];
+  float sb[4][2][4];     // running bias-gradient sums of this lane's (unit, batch) slots: [dr', dz', dn', dn'*r]
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) carry[s][r] = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      carry[s][r] = 0.f;
+      sb[0][s][r] = sb[1][s][r] = sb[2][s][r] = sb[3][s][r] = 0.f;
+    }
 
   const long rs_g = (long)T * G;
   const long rs_o = (long)T * a.out_ld;
@@ -346,6 +350,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       put4(ds[cur], bcol, 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
       put4(ds[cur], bcol, 1 * H + unit, dzp[0], dzp[1], dzp[2], dzp[3]);
       put4(ds[cur], bcol, 2 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sb[0][s][r] += drp[r]; sb[1][s][r] += dzp[r]; sb[2][s][r] += dnp[r]; sb[3][s][r] += dnr[r]; }
       if (brow_ok) {
         st4(hp_b + (long)t * H + unit, HP.x, HP.y, HP.z, HP.w);
         st4(dgx_b + (long)t * G + 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
@@ -371,6 +377,35 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) carry[s][r] = dhz[s][r] + acc[s][r];
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
+  }
+  // bias gradients: reduce over the 16 batch lanes of each lane group (lanes differing in bits 0..3), one atomic per unit
+  if (q.db_ih || q.db_hh) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = sb[g][s][r];
+          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+          sb[g][s][r] = v;
+        }
+    if (bcol == 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = 32 * w + 16 * s + 4 * kq + r;
+          if (q.db_ih) {
+            atomicAdd(&q.db_ih[0 * H + unit], sb[0][s][r]); atomicAdd(&q.db_ih[1 * H + unit], sb[1][s][r]);
+            atomicAdd(&q.db_ih[2 * H + unit], sb[2][s][r]);
+          }
+          if (q.db_hh) {
+            atomicAdd(&q.db_hh[0 * H + unit], sb[0][s][r]); atomicAdd(&q.db_hh[1 * H + unit], sb[1][s][r]);
+            atomicAdd(&q.db_hh[2 * H + unit], sb[3][s][r]);
+          }
+        }
+    }
   }
 }
 

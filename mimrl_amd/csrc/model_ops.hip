@@ -279,39 +279,51 @@ __global__ void colln_bwd_kernel(const float* __restrict__ y, const float* __res
 }
 
 // ------------------------------------------------------------------ K-axis mix, fused (thread per (row, d))
+// Sizes are template parameters (NK = max(ik,hk,ok) rounded to {4,8}) so that every per-thread array lives in
+// registers and every loop unrolls; runtime sizes only mask the tails.
 constexpr int KM = 8;   // max size of any K-axis dimension
 
+template <int NK>
 struct KMixVals {
-  float x[KM], xn[KM], u[KM], h[KM], y[KM], xh[KM], sc[KM];   // sc: dropout scale of the MLP branch per output
+  float x[NK], xn[NK], u[NK], h[NK], y[NK], xh[NK], sc[NK];   // sc: dropout scale of the MLP branch per output
   float mu, rs;
 };
 
+template <int NK>
 __device__ __forceinline__ void ln_small(const float* v, int n, const float* g, const float* be, float* out, float* xh,
                                          float& mu, float& rs) {
   float s = 0.f;
-  for (int i = 0; i < n; ++i) s += v[i];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) s += i < n ? v[i] : 0.f;
   mu = s / n;
   float q = 0.f;
-  for (int i = 0; i < n; ++i) { const float c = v[i] - mu; q += c * c; }
+#pragma unroll
+  for (int i = 0; i < NK; ++i) { const float c = i < n ? v[i] - mu : 0.f; q += c * c; }
   rs = rsqrtf(q / n + LN_EPS);
-  for (int i = 0; i < n; ++i) { xh[i] = (v[i] - mu) * rs; out[i] = xh[i] * g[i] + be[i]; }
+#pragma unroll
+  for (int i = 0; i < NK; ++i) { xh[i] = i < n ? (v[i] - mu) * rs : 0.f; out[i] = xh[i] * g[i] + be[i]; }
 }
 
-__device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* sw, KMixVals& v) {
-  // sw: LDS copy of [w1 | b1 | w2 | b2 | wr | g | be] (missing pieces zero / identity)
+// sw: LDS copy of [w1 | b1 | w2 | b2 | wr | g | be] with row stride KM (missing pieces zero / identity)
+template <int NK>
+__device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* sw, KMixVals<NK>& v) {
   const float* w1 = sw; const float* b1 = w1 + KM * KM; const float* w2 = b1 + KM; const float* b2 = w2 + KM * KM;
   const float* wr = b2 + KM; const float* g = wr + KM * KM; const float* be = g + KM;
-  const float* in = v.x;
-  if (w.ln_first) { ln_small(v.x, w.ik, g, be, v.xn, v.xh, v.mu, v.rs); in = v.xn; }
-  for (int j = 0; j < w.hk; ++j) {
+  if (w.ln_first) ln_small<NK>(v.x, w.ik, g, be, v.xn, v.xh, v.mu, v.rs);
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
     float s = b1[j];
-    for (int k = 0; k < w.ik; ++k) s += w1[j * KM + k] * in[k];
-    v.u[j] = s; v.h[j] = act_apply(w.act, s);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) s += w1[j * KM + k] * (w.ln_first ? v.xn[k] : v.x[k]);   // padded weights are zero
+    v.u[j] = s; v.h[j] = j < w.hk ? act_apply(w.act, s) : 0.f;
   }
-  for (int o = 0; o < w.ok; ++o) {
+#pragma unroll
+  for (int o = 0; o < NK; ++o) {
     float s = b2[o], rr = 0.f;
-    for (int j = 0; j < w.hk; ++j) s += w2[o * KM + j] * v.h[j];
-    for (int k = 0; k < w.ik; ++k) rr += wr[o * KM + k] * v.x[k];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) s += w2[o * KM + j] * v.h[j];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) rr += wr[o * KM + k] * v.x[k];
     v.y[o] = v.sc[o] * s + rr;
   }
 }
@@ -332,6 +344,7 @@ __device__ __forceinline__ void kmix_stage_weights(const KMixW& w, float* sw) {
   __syncthreads();
 }
 
+template <int NK>
 __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__ x, float* __restrict__ z, KMixW w,
                                                        long R, int D) {
   __shared__ float sw[3 * KM * KM + 4 * KM];
@@ -339,20 +352,29 @@ __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__
   const float* g = sw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < R * D; i += (long)gridDim.x * blockDim.x) {
     const long r = i / D; const int d = i % D;
-    KMixVals v;
-    for (int k = 0; k < w.ik; ++k) v.x[k] = x[(r * w.ik + k) * D + d];
-    for (int o = 0; o < w.ok; ++o) v.sc[o] = drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d));
-    kmix_forward_vals(w, sw, v);
+    KMixVals<NK> v;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v.x[k] = k < w.ik ? x[(r * w.ik + k) * D + d] : 0.f;
+#pragma unroll
+    for (int o = 0; o < NK; ++o)
+      v.sc[o] = o < w.ok ? drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d)) : 0.f;
+    kmix_forward_vals<NK>(w, sw, v);
     if (w.ln_first) {
-      for (int o = 0; o < w.ok; ++o) z[(r * w.ok + o) * D + d] = v.y[o];
+#pragma unroll
+      for (int o = 0; o < NK; ++o) if (o < w.ok) z[(r * w.ok + o) * D + d] = v.y[o];
     } else {
-      float out[KM];
-      ln_small(v.y, w.ok, g, be, out, v.xh, v.mu, v.rs);
-      for (int o = 0; o < w.ok; ++o) z[(r * w.ok + o) * D + d] = out[o];
+      float out[NK];
+      ln_small<NK>(v.y, w.ok, g, be, out, v.xh, v.mu, v.rs);
+#pragma unroll
+      for (int o = 0; o < NK; ++o) if (o < w.ok) z[(r * w.ok + o) * D + d] = out[o];
     }
   }
 }
 
+// backward: per-thread gradients are reduced over the wave with DPP-free shuffles only ONCE per workgroup iteration:
+// each thread accumulates its weight-gradient contributions in registers across its grid-stride iterations, and the
+// wave/LDS/global reduction runs once at the end of the kernel.
+template <int NK>
 __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                        float* __restrict__ dx, KMixW w, long R, int D) {
   __shared__ float sw[3 * KM * KM + 4 * KM];
@@ -362,72 +384,107 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
   __syncthreads();
   const float* w1 = sw; const float* w2 = w1 + KM * KM + KM; const float* wr = w2 + KM * KM + KM;
   const float* g = wr + KM * KM;
-  float* gw1 = sg; float* gb1 = gw1 + KM * KM; float* gw2 = gb1 + KM; float* gb2 = gw2 + KM * KM;
-  float* gwr = gb2 + KM; float* gg = gwr + KM * KM; float* gbe = gg + KM;
-  const int lane = threadIdx.x & 63;
+  float aw1[NK][NK], aw2[NK][NK], awr[NK][NK], ab1[NK], ab2[NK], ag[NK], abe[NK];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    ab1[i] = ab2[i] = ag[i] = abe[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) aw1[i][j] = aw2[i][j] = awr[i][j] = 0.f;
+  }
   const long total = R * D;
-  const long span = (long)gridDim.x * blockDim.x;
-  for (long base = blockIdx.x * (long)blockDim.x; base < total; base += span) {   // wave-uniform trip count
-    const long i = base + threadIdx.x;
-    const bool ok = i < total;
-    const long r = ok ? i / D : 0; const int d = ok ? i % D : 0;
-    KMixVals v;
-    float dzv[KM], dyv[KM], dh[KM], du[KM], dxn[KM], dxv[KM];
-    for (int k = 0; k < w.ik; ++k) v.x[k] = ok ? x[(r * w.ik + k) * D + d] : 0.f;
-    for (int o = 0; o < w.ok; ++o) dzv[o] = ok ? dz[(r * w.ok + o) * D + d] : 0.f;
-    for (int o = 0; o < w.ok; ++o) v.sc[o] = drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d));
-    kmix_forward_vals(w, sw, v);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D; const int d = i % D;
+    KMixVals<NK> v;
+    float dzv[NK], dyv[NK], dym[NK], du[NK], dxn[NK], dxv[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v.x[k] = k < w.ik ? x[(r * w.ik + k) * D + d] : 0.f;
+#pragma unroll
+    for (int o = 0; o < NK; ++o) {
+      dzv[o] = o < w.ok ? dz[(r * w.ok + o) * D + d] : 0.f;
+      v.sc[o] = o < w.ok ? drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d)) : 0.f;
+    }
+    kmix_forward_vals<NK>(w, sw, v);
     if (w.ln_first) {
-      for (int o = 0; o < w.ok; ++o) dyv[o] = dzv[o];
+#pragma unroll
+      for (int o = 0; o < NK; ++o) dyv[o] = dzv[o];
     } else {
-      float out[KM];
-      ln_small(v.y, w.ok, g, g + KM, out, v.xh, v.mu, v.rs);
+      float out[NK];
+      ln_small<NK>(v.y, w.ok, g, g + KM, out, v.xh, v.mu, v.rs);
       float s1 = 0.f, s2 = 0.f;
-      for (int o = 0; o < w.ok; ++o) { const float t = dzv[o] * g[o]; s1 += t; s2 += t * v.xh[o]; }
+#pragma unroll
+      for (int o = 0; o < NK; ++o) { const float t = dzv[o] * g[o]; s1 += t; s2 += t * v.xh[o]; }
       s1 /= w.ok; s2 /= w.ok;
-      for (int o = 0; o < w.ok; ++o) {
-        dyv[o] = v.rs * (dzv[o] * g[o] - s1 - v.xh[o] * s2);
-        const float a = wave_sum(dzv[o] * v.xh[o]), b = wave_sum(dzv[o]);
-        if (lane == 0) { atomicAdd(&gg[o], a); atomicAdd(&gbe[o], b); }
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        dyv[o] = o < w.ok ? v.rs * (dzv[o] * g[o] - s1 - v.xh[o] * s2) : 0.f;
+        ag[o] += dzv[o] * v.xh[o]; abe[o] += dzv[o];
       }
     }
-    const float* in = w.ln_first ? v.xn : v.x;
-    float dym[KM];   // gradient entering the (dropped-out) MLP branch
-    for (int o = 0; o < w.ok; ++o) dym[o] = dyv[o] * v.sc[o];
-    for (int j = 0; j < w.hk; ++j) {
+#pragma unroll
+    for (int o = 0; o < NK; ++o) dym[o] = dyv[o] * v.sc[o];   // gradient entering the (dropped-out) MLP branch
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
       float s = 0.f;
-      for (int o = 0; o < w.ok; ++o) s += w2[o * KM + j] * dym[o];
-      dh[j] = s; du[j] = s * act_grad(w.act, v.u[j]);
+#pragma unroll
+      for (int o = 0; o < NK; ++o) s += w2[o * KM + j] * dym[o];
+      du[j] = j < w.hk ? s * act_grad(w.act, v.u[j]) : 0.f;
     }
-    for (int k = 0; k < w.ik; ++k) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
       float s = 0.f, rr = 0.f;
-      for (int j = 0; j < w.hk; ++j) s += w1[j * KM + k] * du[j];
-      for (int o = 0; o < w.ok; ++o) rr += wr[o * KM + k] * dyv[o];
+#pragma unroll
+      for (int j = 0; j < NK; ++j) s += w1[j * KM + k] * du[j];
+#pragma unroll
+      for (int o = 0; o < NK; ++o) rr += wr[o * KM + k] * dyv[o];
       dxn[k] = s; dxv[k] = rr;
     }
     if (w.ln_first) {
       float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < w.ik; ++k) { const float t = dxn[k] * g[k]; s1 += t; s2 += t * v.xh[k]; }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { const float t = dxn[k] * g[k]; s1 += t; s2 += t * v.xh[k]; }
       s1 /= w.ik; s2 /= w.ik;
-      for (int k = 0; k < w.ik; ++k) {
-        dxv[k] += v.rs * (dxn[k] * g[k] - s1 - v.xh[k] * s2);
-        const float a = wave_sum(dxn[k] * v.xh[k]), b = wave_sum(dxn[k]);
-        if (lane == 0) { atomicAdd(&gg[k], a); atomicAdd(&gbe[k], b); }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        dxv[k] += k < w.ik ? v.rs * (dxn[k] * g[k] - s1 - v.xh[k] * s2) : 0.f;
+        ag[k] += dxn[k] * v.xh[k]; abe[k] += dxn[k];
       }
     } else {
-      for (int k = 0; k < w.ik; ++k) dxv[k] += dxn[k];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) dxv[k] += dxn[k];
     }
-    if (ok) for (int k = 0; k < w.ik; ++k) dx[(r * w.ik + k) * D + d] = dxv[k];
-    // weight gradients (wave reduce -> LDS)
-    for (int o = 0; o < w.ok; ++o) {
-      for (int j = 0; j < w.hk; ++j) { const float a = wave_sum(dym[o] * v.h[j]); if (lane == 0) atomicAdd(&gw2[o * KM + j], a); }
-      for (int k = 0; k < w.ik; ++k) { const float a = wave_sum(dyv[o] * v.x[k]); if (lane == 0) atomicAdd(&gwr[o * KM + k], a); }
-      const float a = wave_sum(dym[o]); if (lane == 0) atomicAdd(&gb2[o], a);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) if (k < w.ik) dx[(r * w.ik + k) * D + d] = dxv[k];
+#pragma unroll
+    for (int o = 0; o < NK; ++o) {
+      ab2[o] += dym[o];
+#pragma unroll
+      for (int j = 0; j < NK; ++j) aw2[o][j] += dym[o] * v.h[j];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) awr[o][k] += dyv[o] * v.x[k];
     }
-    for (int j = 0; j < w.hk; ++j) {
-      for (int k = 0; k < w.ik; ++k) { const float a = wave_sum(du[j] * in[k]); if (lane == 0) atomicAdd(&gw1[j * KM + k], a); }
-      const float a = wave_sum(du[j]); if (lane == 0) atomicAdd(&gb1[j], a);
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      ab1[j] += du[j];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) aw1[j][k] += du[j] * (w.ln_first ? v.xn[k] : v.x[k]);
     }
+  }
+  // one wave reduction + LDS + global atomic per scalar, once per kernel
+  float* gw1 = sg; float* gb1 = gw1 + KM * KM; float* gw2 = gb1 + KM; float* gb2 = gw2 + KM * KM;
+  float* gwr = gb2 + KM; float* gg = gwr + KM * KM; float* gbe = gg + KM;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      float a = wave_sum(aw1[i][j]); if (lane == 0) atomicAdd(&gw1[i * KM + j], a);
+      a = wave_sum(aw2[i][j]); if (lane == 0) atomicAdd(&gw2[i * KM + j], a);
+      a = wave_sum(awr[i][j]); if (lane == 0) atomicAdd(&gwr[i * KM + j], a);
+    }
+    float a = wave_sum(ab1[i]); if (lane == 0) atomicAdd(&gb1[i], a);
+    a = wave_sum(ab2[i]); if (lane == 0) atomicAdd(&gb2[i], a);
+    a = wave_sum(ag[i]); if (lane == 0) atomicAdd(&gg[i], a);
+    a = wave_sum(abe[i]); if (lane == 0) atomicAdd(&gbe[i], a);
   }
   __syncthreads();
   const int t = threadIdx.x;
@@ -585,13 +642,17 @@ int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* me
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   if (!w.wr && w.ik != w.ok) return set_error(MIMRL_ERR_ARG, "kmix: identity residual needs ik == ok");
-  hipLaunchKernelGGL(kmix_fwd_kernel, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
+  const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
+  if (mx <= 4) hipLaunchKernelGGL(kmix_fwd_kernel<4>, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
+  else hipLaunchKernelGGL(kmix_fwd_kernel<8>, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
-  hipLaunchKernelGGL(kmix_bwd_kernel, dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
+  if (mx <= 4) hipLaunchKernelGGL(kmix_bwd_kernel<4>, dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  else hipLaunchKernelGGL(kmix_bwd_kernel<8>, dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -1,0 +1,29 @@
+"""GPU microbenchmark of libmimrl_hip's strided GEMM on the shapes of the cfg2 step (run on the GPU box)."""
+import ctypes as C, sys, torch
+from mimrl_amd import _lib
+lib = _lib.load(); _lib.check(lib.mimrl_device_check())
+S = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def P(t): return C.c_void_p(t.data_ptr())
+def run(name, M, N, K, batch, st, a_shape, b_shape, c_shape, prec=1, iters=50, act=0, **kw):
+    A = torch.randn(*a_shape, device="cuda"); B = torch.randn(*b_shape, device="cuda"); Cm = torch.zeros(*c_shape, device="cuda")
+    arr = (C.c_int64 * 9)(*st)
+    f = lambda: lib.mimrl_op_gemm(S, P(A), P(B), P(Cm), M, N, K, batch, arr, None, None, 1.0, 0.0, act, prec)
+    for _ in range(5): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    print(f"{name:34s} {us:8.1f} us  {2.0*M*N*K*batch/us/1e6:8.1f} TF/s")
+BT = 6400
+run("gx l1: NT 6400x384x256", BT, 384, 256, 1, (256,1,0, 1,256,0, 384,1,0), (BT,256), (384,256), (BT,384))
+run("gx l0a: NT 6400x384x74", BT, 384, 74, 1, (74,1,0, 1,74,0, 384,1,0), (BT,74), (384,74), (BT,384))
+run("W_t: NT 6400x128x768", BT, 128, 768, 1, (768,1,0, 1,768,0, 128,1,0), (BT,768), (128,768), (BT,128))
+run("D-mix: NT 19200x128x128", 19200, 128, 128, 1, (128,1,0, 1,128,0, 128,1,0), (19200,128), (128,128), (19200,128))
+run("dh0: NN 6400x256x384", BT, 256, 384, 1, (384,1,0, 256,1,0, 256,1,0), (BT,384), (384,256), (BT,256))
+run("L-mix: W[50,50].X_b[50,384] x128", 50, 384, 50, 128, (50,1,0, 384,1,50*384, 384,1,50*384), (50,50), (128,50,384), (128,50,384))
+run("tower: NT 128x256x256 x10", 128, 256, 256, 10, (256,1,128*256, 1,256,256*256, 256,1,128*256), (10,128,256), (10,256,256), (10,128,256))
+run("cmi l0: NT 128x256x384 x6", 128, 256, 384, 6, (384,1,128*384, 1,384,256*384, 256,1,128*256), (6,128,384), (6,256,384), (6,128,256))
+run("wgrad TN 384x256x6400", 384, 256, BT, 1, (1,384,0, 256,1,0, 256,1,0), (BT,384), (BT,256), (384,256), act=256)
+run("wgrad TN 128x128x19200", 128, 128, 19200, 1, (1,128,0, 128,1,0, 128,1,0), (19200,128), (19200,128), (128,128), act=256)
+run("L-mix wgrad: dY_b.H_b^T x128 ->50x50", 50, 50, 384, 128, (384,1,50*384, 1,384,50*384, 50,1,0), (128,50,384), (128,50,384), (50,50), act=256)
