@@ -7,6 +7,7 @@
 // The reference back-propagates stage 1 through the main model and stage 2 into the critic weights as well, but
 // those gradients are never applied: they are skipped here with no effect on any parameter.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -151,7 +152,54 @@ struct mimrl_handle {
   float *dcc[2], *dcin = nullptr;
   float* gbuf[4];
   size_t gbuf_floats = 0;
-  float *dtx = nullptr, *ds[2], *dgx[2][2], *dgh[2][2], *hprev[2][2], *dh0[2];
+  float *dtx = nullptr, *ds[2], *dgx[2][2][2], *dgh[2][2][2], *hprev[2][2][2], *dh0[2];   // [layer][mod][dir]
+
+  // side streams: independent branches of a stage run concurrently (and are captured as parallel graph branches)
+  static constexpr int NSIDE = 6;      // 0: text branch, 1-3: per-(modality,direction) helpers / weight gradients, 4: kNN, 5: CMI
+  hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+  bool multi_stream = true;
+  int next_event(hipEvent_t* e) {
+    if (ev_next == ev_pool.size()) {
+      hipEvent_t n;
+      HIPX(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+      ev_pool.push_back(n);
+    }
+    *e = ev_pool[ev_next++];
+    return MIMRL_OK;
+  }
+  hipStream_t S(int i) const { return multi_stream ? side[i] : stream; }
+  // side[lo..hi] wait for everything enqueued on `stream` so far
+  int fork(int lo, int hi) {
+    if (!multi_stream) return MIMRL_OK;
+    hipEvent_t e;
+    MX(next_event(&e));
+    HIPX(hipEventRecord(e, stream));
+    for (int i = lo; i <= hi; ++i) HIPX(hipStreamWaitEvent(side[i], e, 0));
+    return MIMRL_OK;
+  }
+  // `stream` waits for side[lo..hi]
+  int join(int lo, int hi) {
+    if (!multi_stream) return MIMRL_OK;
+    for (int i = lo; i <= hi; ++i) {
+      hipEvent_t e;
+      MX(next_event(&e));
+      HIPX(hipEventRecord(e, side[i]));
+      HIPX(hipStreamWaitEvent(stream, e, 0));
+    }
+    return MIMRL_OK;
+  }
+  // side[i] waits for side[j]
+  int chain(int i, int j) {
+    if (!multi_stream) return MIMRL_OK;
+    hipEvent_t e;
+    MX(next_event(&e));
+    HIPX(hipEventRecord(e, side[j]));
+    HIPX(hipStreamWaitEvent(side[i], e, 0));
+    return MIMRL_OK;
+  }
+  int G_on(hipStream_t st, const GemmDesc& d) { return gemm(st, d, bf16); }
 
   // phase profiler
   bool prof_on = false;
@@ -209,8 +257,18 @@ struct mimrl_handle {
   int cube_forward(bool train);
   int cube_backward(int cur_in, int* cur_out);
   int model_backward();
-  int estimators_forward(int stage, bool want_grad);
-  int estimators_backward(int stage);
+  struct StreamGuard {   // route every launch of a scope to another stream
+    mimrl_handle* h; hipStream_t saved;
+    StreamGuard(mimrl_handle* h_, hipStream_t st) : h(h_), saved(h_->stream) { h->stream = st; }
+    ~StreamGuard() { h->stream = saved; }
+  };
+  int knn_launch(int stage, hipStream_t st);
+  int mi_forward(int stage, bool want_grad);
+  int cmi_forward(int stage, bool want_grad);
+  int mi_backward(int stage);
+  int cmi_backward(int stage);
+  int route_feature_grads();
+  int estimators_all(int stage, bool want_grad, bool backward);
   // grouped MLP stacks living in the critic bucket (nb groups, uniform parameter stride `pstride`)
   int mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2], const int* dims,
                         const float* in, float* const* act, float* out);
@@ -387,11 +445,12 @@ int mimrl_handle::carve() {
   for (int m = 0; m < 2; ++m) {
     MX(take(&ds[m], BT_ * H));
     MX(take(&dh0[m], BT_ * 2 * H));
-    for (int d = 0; d < 2; ++d) {
-      MX(take(&dgx[m][d], BT_ * G));
-      MX(take(&dgh[m][d], BT_ * G));
-      MX(take(&hprev[m][d], BT_ * H));
-    }
+    for (int l = 0; l < 2; ++l)
+      for (int d = 0; d < 2; ++d) {   // per layer: layer-1 weight-gradient GEMMs overlap the layer-0 BPTT
+        MX(take(&dgx[l][m][d], BT_ * G));
+        MX(take(&dgh[l][m][d], BT_ * G));
+        MX(take(&hprev[l][m][d], BT_ * H));
+      }
   }
   return MIMRL_OK;
 }
@@ -432,15 +491,17 @@ int mimrl_handle::model_forward(bool train, bool save) {
   const int dmod[2] = {cfg.d_a, cfg.d_v};
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
   if (T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
-  // text: W_t projection (Model.py:395) + dropout -> cube slot 0
-  MX(G_(gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t)));
-  MX(text_post_fwd(stream, tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+  MX(fork(0, 3));
+  // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
+  { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
+  MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
   // lengths (Model.py:425-432)
   for (int m = 0; m < 2; ++m) MX(seq_lengths(stream, xin[m], B, T, dmod[m], lens[m]));
-  // bi-GRU, 2 layers (Model.py:441-447)
+  // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
+    if (l == 1) MX(fork(1, 3));
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       const float* in = l == 0 ? xin[m] : h0[m];
@@ -448,12 +509,15 @@ int mimrl_handle::model_forward(bool train, bool save) {
         const GruDirW& g = gru[m][l][d];
         GemmDesc gd = gemm_nt(in, g.din, P(g.w_ih), g.din, gx[m][d], G, (int)BT_, G, g.din);
         gd.bias_n = P(g.b_ih);
-        MX(G_(gd));
+        const int q = m * 2 + d;
+        MX(G_on(q == 0 ? stream : S(q), gd));
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
       }
     }
+    MX(join(1, 3));
     { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
   }
+  MX(join(0, 0));
   // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
   for (int m = 0; m < 2; ++m)
     MX(ln_relu_drop_fwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), cube0, ln_mean[m], ln_rstd[m], B, T, L, 3, D, 1 + m,
@@ -500,14 +564,21 @@ int mimrl_handle::cube_forward(bool train) {
       g2.C = b.l.y; g2.sc_m = C; g2.sc_n = 1; g2.sc_b = (long)ol * C;
       g2.M = ol; g2.N = (int)C; g2.K = hl; g2.batch = B;
       g2.bias_m = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+      const bool fuse_res = a.res >= 0 && pl <= 0.f;     // Y = W2.H + b2 + Wr.X in ONE launch (no dropout in between)
+      if (fuse_res) {
+        g2.A2 = P(a.res); g2.sa2_m = il; g2.sa2_k = 1; g2.sa2_b = 0;
+        g2.B2 = x; g2.sb2_k = C; g2.sb2_n = 1; g2.sb2_b = (long)il * C; g2.K2 = il;
+      }
       MX(G_(g2));
-      MX(dropout_inplace(stream, b.l.y, (long)B * ol * C, pl, key(), 10 + 3 * i));
-      if (a.res >= 0) {   // Y += Wr . X_b
-        GemmDesc g3 = g2;
-        g3.A = P(a.res); g3.sa_m = il; g3.B = x; g3.sb_b = (long)il * C; g3.K = il; g3.bias_m = nullptr; g3.beta = 1.f;
-        MX(G_(g3));
-      } else {
-        MX(add_inplace(stream, b.l.y, x, (long)B * ol * C));
+      if (!fuse_res) {
+        MX(dropout_inplace(stream, b.l.y, (long)B * ol * C, pl, key(), 10 + 3 * i));
+        if (a.res >= 0) {   // Y += Wr . X_b
+          GemmDesc g3 = g2;
+          g3.A = P(a.res); g3.sa_m = il; g3.B = x; g3.sb_b = (long)il * C; g3.K = il; g3.bias_m = nullptr; g3.beta = 1.f;
+          MX(G_(g3));
+        } else {
+          MX(add_inplace(stream, b.l.y, x, (long)B * ol * C));
+        }
       }
       if (!cfg.ln_first) MX(colln_fwd(stream, b.l.y, P(a.ln_g), P(a.ln_b), b.l.z, b.l.mean, b.l.rstd, B, ol, (int)C));
     }
@@ -534,14 +605,20 @@ int mimrl_handle::cube_forward(bool train) {
       MX(G_(g1));
       GemmDesc g2 = gemm_nt(b.d.h, hd, P(a.fc2.w), hd, b.d.y, od, (int)R2, od, hd);
       g2.bias_n = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+      const bool fuse_res = a.res >= 0 && pd <= 0.f;
+      if (fuse_res) {
+        g2.A2 = b.k.z; g2.sa2_m = id; g2.sa2_k = 1; g2.B2 = P(a.res); g2.sb2_k = 1; g2.sb2_n = id; g2.K2 = id;
+      }
       MX(G_(g2));
-      MX(dropout_inplace(stream, b.d.y, R2 * od, pd, key(), 12 + 3 * i));
-      if (a.res >= 0) {
-        GemmDesc g3 = gemm_nt(b.k.z, id, P(a.res), id, b.d.y, od, (int)R2, od, id);
-        g3.beta = 1.f;
-        MX(G_(g3));
-      } else {
-        MX(add_inplace(stream, b.d.y, b.k.z, R2 * od));
+      if (!fuse_res) {
+        MX(dropout_inplace(stream, b.d.y, R2 * od, pd, key(), 12 + 3 * i));
+        if (a.res >= 0) {
+          GemmDesc g3 = gemm_nt(b.k.z, id, P(a.res), id, b.d.y, od, (int)R2, od, id);
+          g3.beta = 1.f;
+          MX(G_(g3));
+        } else {
+          MX(add_inplace(stream, b.d.y, b.k.z, R2 * od));
+        }
       }
       if (!cfg.ln_first) MX(rowln_fwd(stream, b.d.y, P(a.ln_g), P(a.ln_b), b.d.z, b.d.mean, b.d.rstd, R2, od));
     }
@@ -611,7 +688,10 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(G_(g)); }
       GRAB(i_dx0);
       int i_dx = i_dx0;
-      { GemmDesc g = gemm_nn(gbuf[i_du], hd, P(a.fc1.w), id, gbuf[i_dx], id, (int)R2, id, hd); MX(G_(g)); }
+      const bool fuse_dx = a.res >= 0 && !cfg.ln_first;        // dX = dU.W1 + dY.Wr in ONE launch
+      { GemmDesc g = gemm_nn(gbuf[i_du], hd, P(a.fc1.w), id, gbuf[i_dx], id, (int)R2, id, hd);
+        if (fuse_dx) { g.A2 = dy; g.sa2_m = od; g.sa2_k = 1; g.B2 = P(a.res); g.sb2_k = id; g.sb2_n = 1; g.K2 = od; }
+        MX(G_(g)); }
       if (cfg.ln_first) {                                    // that was dXn: LayerNorm backward into the (now free) dU buffer
         MX(rowln_bwd(stream, b.k.z, P(a.ln_g), b.d.xn_mean, b.d.xn_rstd, gbuf[i_dx], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b), R2, id));
         release(i_dx);
@@ -619,8 +699,10 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       } else {
         release(i_du);
       }
-      if (a.res >= 0) { GemmDesc g = gemm_nn(dy, od, P(a.res), id, gbuf[i_dx], id, (int)R2, id, od); g.beta = 1.f; MX(G_(g)); }
-      else MX(add_inplace(stream, gbuf[i_dx], dy, R2 * id));
+      if (!fuse_dx) {
+        if (a.res >= 0) { GemmDesc g = gemm_nn(dy, od, P(a.res), id, gbuf[i_dx], id, (int)R2, id, od); g.beta = 1.f; MX(G_(g)); }
+        else MX(add_inplace(stream, gbuf[i_dx], dy, R2 * id));
+      }
       release(i_dy);
       cur = i_dx;
     }
@@ -692,6 +774,10 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       { GemmDesc g; g.A = P(a.fc1.w); g.sa_m = 1; g.sa_k = il; g.sa_b = 0;
         g.B = gbuf[i_du]; g.sb_k = C; g.sb_n = 1; g.sb_b = (long)hl * C;
         g.C = gbuf[i_dx]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)il * C; g.M = il; g.N = (int)C; g.K = hl; g.batch = B;
+        if (a.res >= 0 && !cfg.ln_first) {                   // + Wr^T . dY_b in the same launch
+          g.A2 = P(a.res); g.sa2_m = 1; g.sa2_k = il; g.sa2_b = 0;
+          g.B2 = dy; g.sb2_k = C; g.sb2_n = 1; g.sb2_b = (long)ol * C; g.K2 = ol;
+        }
         MX(G_(g)); }
       if (cfg.ln_first) {
         MX(colln_bwd(stream, xblk, P(a.ln_g), b.l.xn_mean, b.l.xn_rstd, gbuf[i_dx], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b), B, il, (int)C));
@@ -700,7 +786,9 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       } else {
         release(i_du);
       }
-      if (a.res >= 0) {
+      if (a.res >= 0 && !cfg.ln_first) {
+        // fused above
+      } else if (a.res >= 0) {
         GemmDesc g; g.A = P(a.res); g.sa_m = 1; g.sa_k = il; g.sa_b = 0;
         g.B = dy; g.sb_k = C; g.sb_n = 1; g.sb_b = (long)ol * C;
         g.C = gbuf[i_dx]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)il * C; g.M = il; g.N = (int)C; g.K = ol; g.batch = B; g.beta = 1.f;
@@ -733,9 +821,10 @@ int mimrl_handle::model_backward() {
   float* dcube = gbuf[ci];
   // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T
   MX(feat_mean_bwd(stream, dfeat + (size_t)B * D, dcube, B, T, L, 3, D));
-  // text branch: dW_t = dtx^T . text
-  MX(text_post_bwd(stream, dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0));
-  { GemmDesc g = gemm_tn(dtx, D, bufs.text, cfg.d_t, Gm(w_t), cfg.d_t, D, cfg.d_t, (int)BT_); g.atomic = 1; MX(G_(g)); }
+  // text branch (side 0): dW_t = dtx^T . text
+  MX(fork(0, 0));
+  MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0));
+  { GemmDesc g = gemm_tn(dtx, D, bufs.text, cfg.d_t, Gm(w_t), cfg.d_t, D, cfg.d_t, (int)BT_); g.atomic = 1; MX(G_on(S(0), g)); }
   // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
   for (int m = 0; m < 2; ++m)
     MX(ln_relu_drop_bwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dcube, ds[m], Gm(ln_g[m]),
@@ -749,25 +838,33 @@ int mimrl_handle::model_backward() {
       a.lens[m] = lens[m];
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
-        a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dgx[m][d],
-                                dgh[m][d], hprev[m][d], Gm(g.b_ih), Gm(g.b_hh)};
+        a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dgx[l][m][d],
+                                dgh[l][m][d], hprev[l][m][d], Gm(g.b_ih), Gm(g.b_hh)};
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
+    // weight gradients of this layer: off the critical path, spread over side 1..3 (joined at the very end)
+    MX(fork(1, 3));
     for (int m = 0; m < 2; ++m) {
       const float* in = l == 0 ? xin[m] : h0[m];
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
-        { GemmDesc q = gemm_tn(dgx[m][d], G, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_(q)); }
-        { GemmDesc q = gemm_tn(dgh[m][d], G, hprev[m][d], H, Gm(g.w_hh), H, G, H, (int)BT_); q.atomic = 1; MX(G_(q)); }
-        if (l == 1) {   // gradient to the layer-0 outputs: dh0 = sum_dir dgx_dir . W_ih_l1_dir
-          GemmDesc q = gemm_nn(dgx[m][d], G, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
+        hipStream_t st = S(1 + (m * 2 + d) % 3);
+        { GemmDesc q = gemm_tn(dgx[l][m][d], G, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+        { GemmDesc q = gemm_tn(dgh[l][m][d], G, hprev[l][m][d], H, Gm(g.w_hh), H, G, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+      }
+    }
+    if (l == 1) {   // critical path: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
+      for (int m = 0; m < 2; ++m)
+        for (int d = 0; d < 2; ++d) {
+          const GruDirW& g = gru[m][l][d];
+          GemmDesc q = gemm_nn(dgx[l][m][d], G, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
           q.beta = d == 0 ? 0.f : 1.f;
           MX(G_(q));
         }
-      }
     }
   }
+  MX(join(0, 3));
   return MIMRL_OK;
 }
 
@@ -828,8 +925,26 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
 }
 
 // =================================================================================================
-int mimrl_handle::estimators_forward(int stage, bool want_grad) {
-  const int B = cfg.batch, n = nprod(), m = m_anchor(), k = cfg.k_neighbor;
+// estimators.  Three independent branches: kNN sampling (needs only banks + anchors -> launched before the model
+// forward on side 4), the CMI classifiers (side 5) and the MI critics (main stream).
+// =================================================================================================
+int mimrl_handle::knn_launch(int stage, hipStream_t st) {
+  const int m = m_anchor(), k = cfg.k_neighbor;
+  const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
+  int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
+  if (cfg.device_anchors)
+    MX(sample_anchors(st, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage));
+  KnnArgs ka;
+  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = knn_idx;
+  for (int e = 0; e < NE_CMI; ++e) {
+    const int z = kCmiWire[e][2];
+    ka.call[e].Z = bank[z]; ka.call[e].dz = z == FT_C ? 1 : EMB;
+  }
+  return knn_sample(st, ka);
+}
+
+int mimrl_handle::mi_forward(int stage, bool want_grad) {
+  const int B = cfg.batch;
   const size_t BD = (size_t)B * EMB;
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
   {   // tower inputs: x operand -> slot 2e, y operand -> slot 2e+1
@@ -867,37 +982,31 @@ int mimrl_handle::estimators_forward(int stage, bool want_grad) {
     const int dims[4] = {HID, HID, HID, 1};
     MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
   }
-  MX(mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, gs_mi(stage), NE_MI, B, cfg.bound_type));
+  return mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, gs_mi(stage), NE_MI, B, cfg.bound_type);
+}
 
-  // ---- CMI: kNN product sampling + classifier
+int mimrl_handle::cmi_forward(int stage, bool want_grad) {
+  const int B = cfg.batch, n = nprod(), m = m_anchor(), k = cfg.k_neighbor;
+  const size_t BD = (size_t)B * EMB;
   const float* cur[5] = {bufs.feats, bufs.feats + BD, bufs.feats + 2 * BD, bufs.feats + 3 * BD, bufs.labels};
   const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
-  int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
-  if (cfg.device_anchors)
-    MX(sample_anchors(stream, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage));
-  KnnArgs ka;
-  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = knn_idx;
   CmiAssembleArgs ca_;
-  ca_.anchors = anc; ca_.idx_x = knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
-  for (int e = 0; e < NE_CMI; ++e) {
-    const int z = kCmiWire[e][2];
-    ka.call[e].Z = bank[z]; ka.call[e].dz = z == FT_C ? 1 : EMB;
+  ca_.anchors = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
+  ca_.idx_x = knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
+  for (int e = 0; e < NE_CMI; ++e)
     for (int o = 0; o < 3; ++o) {
       const int f = kCmiWire[e][o];
       ca_.op[e][o] = CmiOperand{cur[f], bank[f], f == FT_C ? 1 : 0};
     }
-  }
-  MX(knn_sample(stream, ka));
   MX(cmi_assemble(stream, ca_));
   const int cdims[5] = {3 * EMB, HID, HID, HID, 2};
   MX(mlp_stack_forward(NE_CMI, 2 * n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, logits));
-  MX(cmi_loss_fwd_bwd(stream, logits, want_grad ? dlogits : nullptr, bce_raw, cmi_raw, g_bce(stage), g_cmi(stage), NE_CMI,
-                      n, cfg.cmi_hardtanh));
-  return MIMRL_OK;
+  return cmi_loss_fwd_bwd(stream, logits, want_grad ? dlogits : nullptr, bce_raw, cmi_raw, g_bce(stage), g_cmi(stage),
+                          NE_CMI, n, cfg.cmi_hardtanh);
 }
 
-int mimrl_handle::estimators_backward(int stage) {
-  const int B = cfg.batch, n = nprod();
+int mimrl_handle::mi_backward(int stage) {
+  const int B = cfg.batch;
   const size_t BD = (size_t)B * EMB;
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
   const bool wgrad = stage == 1;
@@ -913,59 +1022,83 @@ int mimrl_handle::estimators_backward(int stage) {
     gg.sa_m = 1; gg.sa_k = B; gg.B = tout + BD; gg.C = dtout;
     MX(G_(gg));
     const int dims[5] = {EMB, HID, HID, HID, EMB};
-    MX(mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad));
-  } else {
-    const int dims[4] = {HID, HID, HID, 1};
-    MX(mlp_stack_backward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], dscores, dca,
-                          dca[0], wgrad));
-    MX(pair_expand_bwd(stream, ca[0], dca[0], dP, dQ, NE_MI, B, HID));
-    if (wgrad) {
-      GemmDesc g;   // dW0[:, :128] = dP^T x ; dW0[:, 128:] = dQ^T y ; db0 = colsum(dQ)
-      g.A = dP; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * HID;
-      g.B = tin; g.sb_k = EMB; g.sb_n = 1; g.sb_b = 2 * (long)BD;
-      g.C = CG(tower0 + tower_l[0][0]); g.sc_m = 2 * EMB; g.sc_n = 1; g.sc_b = tower_stride;
-      g.M = HID; g.N = EMB; g.K = B; g.batch = NE_MI;
-      MX(G_(g));
-      GemmDesc g2 = g;
-      g2.A = dQ; g2.B = tin + BD; g2.C = CG(tower0 + tower_l[0][0]) + EMB;
-      MX(G_(g2));
-      MX(colsum(stream, dQ, B, HID, HID, CG(tower0 + tower_l[0][1]), NE_MI, (long)B * HID, tower_stride));
-    } else {
-      GemmDesc g;   // dx = dP W0x ; dy = dQ W0y
-      g.A = dP; g.sa_m = HID; g.sa_k = 1; g.sa_b = (long)B * HID;
-      g.B = CP(tower0 + tower_l[0][0]); g.sb_k = 2 * EMB; g.sb_n = 1; g.sb_b = tower_stride;
-      g.C = dtin; g.sc_m = EMB; g.sc_n = 1; g.sc_b = 2 * (long)BD;
-      g.M = B; g.N = EMB; g.K = HID; g.batch = NE_MI;
-      MX(G_(g));
-      GemmDesc g2 = g;
-      g2.A = dQ; g2.B = CP(tower0 + tower_l[0][0]) + EMB; g2.C = dtin + BD;
-      MX(G_(g2));
-    }
+    return mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad);
   }
-  const int cdims[5] = {3 * EMB, HID, HID, HID, 2};
+  const int dims[4] = {HID, HID, HID, 1};
+  MX(mlp_stack_backward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], dscores, dca,
+                        dca[0], wgrad));
+  MX(pair_expand_bwd(stream, ca[0], dca[0], dP, dQ, NE_MI, B, HID));
   if (wgrad) {
-    MX(mlp_stack_backward(NE_CMI, 2 * n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, dlogits, dcc, nullptr, true));
-  } else {
-    // only the n joint rows carry gradient to the model (the product rows come from the detached banks)
-    MX(mlp_stack_backward(NE_CMI, n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, dlogits, dcc, dcin, false));
-    // route input gradients back to F_F, T_F, A_F, V_F (deterministic gather-sum)
-    for (int f = 0; f < 4; ++f) {
-      GatherSum gs;
-      gs.n = 0;
-      for (int e = 0; e < NE_MI; ++e)
-        for (int sd = 0; sd < 2; ++sd)
-          if (kMiWire[e][sd] == f) {
-            gs.src[gs.n] = dtin + (e * 2 + sd) * BD; gs.ld[gs.n] = EMB; gs.off[gs.n] = 0; gs.rows[gs.n] = B; ++gs.n;
-          }
-      for (int e = 0; e < NE_CMI; ++e)
-        for (int o = 0; o < 3; ++o)
-          if (kCmiWire[e][o] == f) {
-            gs.src[gs.n] = dcin + (size_t)e * 2 * n * 384; gs.ld[gs.n] = 384; gs.off[gs.n] = o * EMB; gs.rows[gs.n] = n; ++gs.n;
-          }
-      MX(gather_sum(stream, dfeat + f * BD, gs, B, EMB, 0));
-    }
+    GemmDesc g;   // dW0[:, :128] = dP^T x ; dW0[:, 128:] = dQ^T y ; db0 = colsum(dQ)
+    g.A = dP; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * HID;
+    g.B = tin; g.sb_k = EMB; g.sb_n = 1; g.sb_b = 2 * (long)BD;
+    g.C = CG(tower0 + tower_l[0][0]); g.sc_m = 2 * EMB; g.sc_n = 1; g.sc_b = tower_stride;
+    g.M = HID; g.N = EMB; g.K = B; g.batch = NE_MI;
+    MX(G_(g));
+    GemmDesc g2 = g;
+    g2.A = dQ; g2.B = tin + BD; g2.C = CG(tower0 + tower_l[0][0]) + EMB;
+    MX(G_(g2));
+    return colsum(stream, dQ, B, HID, HID, CG(tower0 + tower_l[0][1]), NE_MI, (long)B * HID, tower_stride);
+  }
+  GemmDesc g;   // dx = dP W0x ; dy = dQ W0y
+  g.A = dP; g.sa_m = HID; g.sa_k = 1; g.sa_b = (long)B * HID;
+  g.B = CP(tower0 + tower_l[0][0]); g.sb_k = 2 * EMB; g.sb_n = 1; g.sb_b = tower_stride;
+  g.C = dtin; g.sc_m = EMB; g.sc_n = 1; g.sc_b = 2 * (long)BD;
+  g.M = B; g.N = EMB; g.K = HID; g.batch = NE_MI;
+  MX(G_(g));
+  GemmDesc g2 = g;
+  g2.A = dQ; g2.B = CP(tower0 + tower_l[0][0]) + EMB; g2.C = dtin + BD;
+  return G_(g2);
+}
+
+int mimrl_handle::cmi_backward(int stage) {
+  const int n = nprod();
+  const int cdims[5] = {3 * EMB, HID, HID, HID, 2};
+  if (stage == 1)
+    return mlp_stack_backward(NE_CMI, 2 * n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, dlogits, dcc, nullptr, true);
+  // stage 2: only the n joint rows carry gradient to the model (the product rows come from the detached banks)
+  return mlp_stack_backward(NE_CMI, n, 2 * n, cmi0, cmi_stride, 4, cmi_l, cdims, cmi_in, cc, dlogits, dcc, dcin, false);
+}
+
+// stage 2: route input gradients back to F_F, T_F, A_F, V_F (deterministic gather-sum)
+int mimrl_handle::route_feature_grads() {
+  const int B = cfg.batch, n = nprod();
+  const size_t BD = (size_t)B * EMB;
+  for (int f = 0; f < 4; ++f) {
+    GatherSum gs;
+    gs.n = 0;
+    for (int e = 0; e < NE_MI; ++e)
+      for (int sd = 0; sd < 2; ++sd)
+        if (kMiWire[e][sd] == f) {
+          gs.src[gs.n] = dtin + (e * 2 + sd) * BD; gs.ld[gs.n] = EMB; gs.off[gs.n] = 0; gs.rows[gs.n] = B; ++gs.n;
+        }
+    for (int e = 0; e < NE_CMI; ++e)
+      for (int o = 0; o < 3; ++o)
+        if (kCmiWire[e][o] == f) {
+          gs.src[gs.n] = dcin + (size_t)e * 2 * n * 384; gs.ld[gs.n] = 384; gs.off[gs.n] = o * EMB; gs.rows[gs.n] = n; ++gs.n;
+        }
+    MX(gather_sum(stream, dfeat + f * BD, gs, B, EMB, 0));
   }
   return MIMRL_OK;
+}
+
+// all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
+int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
+  const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  MX(fork(5, 5));
+  MX(chain(5, 4));                       // the CMI branch needs the kNN indices
+  {
+    StreamGuard g(this, S(5));
+    bf16 = bf_fwd;
+    MX(cmi_forward(stage, want_grad));
+    if (backward) { bf16 = bf_bwd; MX(cmi_backward(stage)); }
+  }
+  bf16 = bf_fwd;
+  { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
+  if (backward) { bf16 = bf_bwd; Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); }
+  bf16 = bf_fwd;
+  if (!multi_stream) return MIMRL_OK;
+  return join(5, 5);
 }
 
 // =================================================================================================
@@ -974,18 +1107,18 @@ int mimrl_handle::estimators_backward(int stage) {
 int mimrl_handle::enqueue_grads(int stage) {
   const int B = cfg.batch;
   const bool have_banks = bank_rows > 0;
+  ev_next = 0;
   if (stage == 1) {
     hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, have_banks ? d_ints + 2 : nullptr,
                        bufs.scalars, 0, 32);
     LAUNCH_CHECK();
     HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));
     if (!have_banks) return MIMRL_OK;   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
+    MX(fork(4, 4));
+    MX(knn_launch(1, S(4)));
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     MX(model_forward(true, false));
-    { Scope sc(this, MIMRL_PH_EST_FWD); MX(estimators_forward(1, true)); }
-    bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
-    { Scope sc(this, MIMRL_PH_EST_BWD); MX(estimators_backward(1)); }
-    bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+    MX(estimators_all(1, true, true));
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
     return MIMRL_OK;
@@ -993,14 +1126,17 @@ int mimrl_handle::enqueue_grads(int stage) {
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
   LAUNCH_CHECK();
   HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
+  if (have_banks) {
+    MX(fork(4, 4));
+    MX(knn_launch(2, S(4)));
+  }
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   MX(model_forward(true, true));
   hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
   LAUNCH_CHECK();
   if (have_banks) {
-    { Scope sc(this, MIMRL_PH_EST_FWD); MX(estimators_forward(2, true)); }
-    bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
-    { Scope sc(this, MIMRL_PH_EST_BWD); MX(estimators_backward(2)); }
+    MX(estimators_all(2, true, true));
+    MX(route_feature_grads());
   } else {
     HIPX(hipMemsetAsync(dfeat, 0, sizeof(float) * 4 * B * EMB, stream));
   }
@@ -1096,6 +1232,9 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   if (h->cfg.beta2 == 0.f) h->cfg.beta2 = 0.999f;
   if (h->cfg.adam_eps == 0.f) h->cfg.adam_eps = 1e-8f;
   h->stream = h->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
+  h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
+  for (int i = 0; i < mimrl_handle::NSIDE; ++i)
+    if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
   h->prec = cfg->precision;
   h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   std::memset(&h->bufs, 0, sizeof h->bufs);
@@ -1146,12 +1285,14 @@ int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses) {
   if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ints, (int*)nullptr, h->bufs.scalars, 32, 32);
   LAUNCH_CHECK();
+  h->ev_next = 0;
   MX(h->model_forward(train_mode != 0, false));
   if (!with_losses) return MIMRL_OK;
   hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, h->stream, h->bufs.pred, h->bufs.labels, (float*)nullptr,
                      h->bufs.scalars + MIMRL_S2_TASK, h->cfg.batch);
   LAUNCH_CHECK();
-  if (h->bank_rows > 0) MX(h->estimators_forward(2, false));
+  h->ev_next = 0;
+  if (h->bank_rows > 0) { MX(h->fork(4, 4)); MX(h->knn_launch(2, h->S(4))); MX(h->estimators_all(2, false, false)); }
   hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, h->stream, h->bufs.scalars, h->mi_raw, h->cmi_raw,
                      h->coef2(), h->bank_rows > 0 ? 1 : 0);
   LAUNCH_CHECK();
@@ -1163,7 +1304,10 @@ int mimrl_estimate(mimrl_handle* h, int stage) {
   if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
   if (h->bank_rows <= 0) return set_error(MIMRL_ERR_STATE, "mimrl_estimate needs non-empty banks");
-  MX(h->estimators_forward(stage, false));
+  h->ev_next = 0;
+  MX(h->fork(4, 4));
+  MX(h->knn_launch(stage, h->S(4)));
+  MX(h->estimators_all(stage, false, false));
   if (stage == 1) {
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, h->stream, h->bufs.scalars, h->mi_raw, h->cmi_raw,
                        h->bce_raw, h->coef1());
@@ -1211,6 +1355,9 @@ void mimrl_destroy(mimrl_handle* h) {
   for (int p = 0; p < MIMRL_NPHASES; ++p)
     for (auto& ev : h->prof_ev[p]) h->prof_pool.push_back(ev);
   for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (int i = 0; i < mimrl_handle::NSIDE; ++i)
+    if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->ws) (void)hipFree(h->ws);
   delete h;

@@ -26,6 +26,9 @@ struct GemmDesc {
   const float* gradact_u = nullptr;  // optional: multiply by act'(u[m,n]) (same strides as C) -- backward of act
   int atomic = 0;                    // C += result with float atomics (batch acts as an extra reduction when sc_b==0)
   float* colsum = nullptr; long colsum_b = 0;   // optional: colsum[b*colsum_b + n] += sum_m (stored value)  (bias gradients)
+  // optional SECOND product accumulated into the same output tile:  C = epi( A.B + A2.B2 )   (e.g. W2.H + Wr.X)
+  const float* A2 = nullptr; const float* B2 = nullptr; int K2 = 0;
+  long sa2_m = 0, sa2_k = 0, sa2_b = 0, sb2_k = 0, sb2_n = 0, sb2_b = 0;
 };
 
 // A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T

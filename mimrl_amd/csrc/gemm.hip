@@ -1,171 +1,215 @@
 // Generic strided batched GEMM kernel (see gemm.h).  64x64 block tile, 4 waves (2x2), one 32x32 MFMA accumulator
-// tile per wave, BK = 32, register-prefetched global->LDS staging.
-//   * interior tiles stage with 16-byte loads along whichever axis of the operand is contiguous; edge tiles and
-//     misaligned operands fall back to guarded scalar loads (wave-uniform choice per tile);
-//   * split-K: weight-gradient GEMMs (K = B*T ... B*L*K rows, tiny M x N) are spread over grid.z and accumulated with
-//     float atomics into the zeroed gradient bucket, so they fill the chip instead of running on a handful of CUs.
+// tile per wave, register-prefetched global->LDS staging, small register/LDS footprint (4 workgroups per CU): at the
+// sizes of this workload the k-loop is a chain of dependent memory round trips and inter-workgroup overlap is what
+// hides it (a deeper register ring / double-buffered LDS measured slower in situ: it costs occupancy).
+//   * two instantiations per precision: GENERIC (BK=32; guarded scalar loads on edge tiles / misaligned operands,
+//     16-byte loads elsewhere) and LEAN (BK=64, 16-byte loads only; chosen by the host when M,N are multiples of 64
+//     and both operands qualify) -- half the dependent round trips without the register cost of the scalar path;
+//   * optional second product accumulated into the same tile (C = A.B + A2.B2): residual projections ride along;
+//   * epilogue: bias (per row/column), beta*C, activation / activation-gradient, pre-activation copy, fused column
+//     sums (bias gradients), plain or atomic store;
+//   * split-K for accumulate-into-zeroed-output GEMMs (weight gradients with K = B*T ... B*L*K rows, tiny M x N).
 #include "gemm.h"
+
+#include <cstdlib>
 
 namespace mimrl {
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BM = 64, BN = 64;
 
-template <bool BF16>
+template <bool BF16, int BK>
 struct Smem;
-template <>
-struct Smem<false> {
+template <int BK>
+struct Smem<false, BK> {
   float a[BK][BM + 4];   // k-major: lanes 0..31 read 32 consecutive m; +4 keeps 16-B row alignment
   float b[BK][BN + 4];
 };
-template <>
-struct Smem<true> {
-  __bf16 a[BM][BK + 8];  // m-major, 80-B rows: 16-B fragment reads, conflict-free for ds_read_b128
+template <int BK>
+struct Smem<true, BK> {
+  __bf16 a[BM][BK + 8];  // m-major, 80-B / 144-B rows: 16-B fragment reads, conflict-free for ds_read_b128
   __bf16 b[BN][BK + 8];
 };
 
 struct KernelArgs {
   GemmDesc d;
   int ksplit;       // grid.z = batch * ksplit
-  int kt_per;       // k-tiles per split
-  int vec_a, vec_b; // operand may use the 16-byte path (alignment / stride conditions hold)
+  int kt_per;       // k-tiles per split (single-segment GEMMs only)
+  int vec_a, vec_b, vec_a2, vec_b2;   // operand may use the 16-byte path (alignment / stride conditions hold)
 };
 
-// stage one 64(rows) x 32(k) operand tile into registers.  `rfast`: rows (m or n) are the contiguous axis.
-// layout of the 8 per-thread values:
-//   vector path, k contiguous : v[0..3] = row r0, k k4..k4+3 ; v[4..7] = row r0+32
-//   vector path, row contig.  : v[0..3] = k k0, rows r4..r4+3 ; v[4..7] = k k0+16
-//   scalar path               : element e = i*256+tid ; (kfast) k = e&31,row = e>>5  | (rfast) row = e&63, k = e>>6
-struct TileIdx {
-  int tid;
-  __device__ __forceinline__ void vec_k(int h, int& row, int& k) const { row = (tid >> 3) + 32 * h; k = (tid & 7) * 4; }
-  __device__ __forceinline__ void vec_r(int h, int& row, int& k) const { k = (tid >> 4) + 16 * h; row = (tid & 15) * 4; }
-  __device__ __forceinline__ void sc(int i, bool kfast, int& row, int& k) const {
+// one operand of one product segment (workgroup-uniform)
+struct Operand {
+  const float* P;
+  long s_r, s_k;     // strides of the row (m or n) axis and of k
+  int r0, R;         // first row of this tile / number of rows
+  bool kfast;        // thread mapping: k runs fastest (else rows)
+  bool vec;          // 16-byte path for this tile
+};
+
+template <int BK>
+struct Map {
+  static constexpr int NV = BK / 16;   // float4 per thread per operand (64 x BK tile, 256 threads)
+  static constexpr int NE = 4 * NV;
+  // k contiguous: 4 consecutive k of one row;  rows contiguous: 4 consecutive rows at NV consecutive k
+  static __device__ __forceinline__ void vec(bool kfast, int tid, int h, int& row, int& k) {
+    if (kfast) { row = tid / (BK / 4) + (1024 / BK) * h; k = (tid % (BK / 4)) * 4; }
+    else { k = (tid >> 4) * NV + h; row = (tid & 15) * 4; }
+  }
+  static __device__ __forceinline__ void sc(bool kfast, int tid, int i, int& row, int& k) {
     const int e = i * 256 + tid;
-    if (kfast) { k = e & (BK - 1); row = e >> 5; } else { row = e & 63; k = e >> 6; }
+    if (kfast) { k = e % BK; row = e / BK; } else { row = e & 63; k = e >> 6; }
   }
 };
 
-template <bool BF16>
+template <int BK, bool LEAN>
+__device__ __forceinline__ void load_tile(const Operand& o, int K, int k0, int tid, float* v) {
+  using M = Map<BK>;
+  if (LEAN || o.vec) {
+#pragma unroll
+    for (int h = 0; h < M::NV; ++h) {
+      int row, k;
+      M::vec(o.kfast, tid, h, row, k);
+      const int gk = k0 + k;
+      const float* src = o.P + (long)(o.r0 + row) * o.s_r + (long)gk * o.s_k;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o.kfast) {
+        if (gk + 3 < K) q = *reinterpret_cast<const float4*>(src);
+        else {
+          if (gk < K) q.x = src[0];
+          if (gk + 1 < K) q.y = src[1];
+          if (gk + 2 < K) q.z = src[2];
+        }
+      } else if (gk < K) {
+        q = *reinterpret_cast<const float4*>(src);
+      }
+      v[4 * h + 0] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < M::NE; ++i) {
+      int row, k;
+      M::sc(o.kfast, tid, i, row, k);
+      const int gr = o.r0 + row, gk = k0 + k;
+      v[i] = (gr < o.R && gk < K) ? o.P[(long)gr * o.s_r + (long)gk * o.s_k] : 0.f;
+    }
+  }
+}
+
+// t: bf16 image [row][k]  /  fp32 image [k][row]
+template <bool BF16, int BK, bool LEAN, typename T>
+__device__ __forceinline__ void store_tile(const Operand& o, int tid, const float* v, T& t) {
+  using M = Map<BK>;
+  if (LEAN || o.vec) {
+    if (o.kfast) {
+#pragma unroll
+      for (int h = 0; h < M::NV; ++h) {
+        int row, k;
+        M::vec(true, tid, h, row, k);
+        if constexpr (BF16) {
+          bf16x4 p; p[0] = to_bf16(v[4 * h]); p[1] = to_bf16(v[4 * h + 1]); p[2] = to_bf16(v[4 * h + 2]); p[3] = to_bf16(v[4 * h + 3]);
+          *reinterpret_cast<bf16x4*>(&t[row][k]) = p;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t[k + j][row] = v[4 * h + j];
+        }
+      }
+    } else {
+      int row, k;
+      M::vec(false, tid, 0, row, k);
+      if constexpr (BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // the NV consecutive k of a row leave as one (2*NV)-byte store
+          typedef __attribute__((ext_vector_type(M::NV))) __bf16 bfv;
+          bfv p;
+#pragma unroll
+          for (int h = 0; h < M::NV; ++h) p[h] = to_bf16(v[4 * h + j]);
+          *reinterpret_cast<bfv*>(&t[row + j][k]) = p;
+        }
+      } else {
+#pragma unroll
+        for (int h = 0; h < M::NV; ++h)
+          *reinterpret_cast<float4*>(&t[k + h][row]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < M::NE; ++i) {
+      int row, k;
+      M::sc(o.kfast, tid, i, row, k);
+      if constexpr (BF16) t[row][k] = to_bf16(v[i]);
+      else t[k][row] = v[i];
+    }
+  }
+}
+
+template <bool BF16, int BK, bool LEAN>
 __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   const GemmDesc& d = ka.d;
-  __shared__ __attribute__((aligned(16))) Smem<BF16> sm;
+  using M = Map<BK>;
+  __shared__ __attribute__((aligned(16))) Smem<BF16, BK> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int bz = blockIdx.z / ka.ksplit, ks = blockIdx.z - bz * ka.ksplit;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const float* __restrict__ A = d.A + (long)bz * d.sa_b;
-  const float* __restrict__ B = d.B + (long)bz * d.sb_b;
-  const bool a_kfast = d.sa_k == 1;       // else rows (m) fastest
-  const bool b_kfast = d.sb_k == 1 && d.sb_n != 1;
-  const bool a_rfast = d.sa_m == 1 && !a_kfast;
-  const bool b_rfast = d.sb_n == 1;
   const bool full_m = m0 + BM <= d.M, full_n = n0 + BN <= d.N;
-  const bool va = ka.vec_a && full_m && (a_kfast || a_rfast);
-  const bool vb = ka.vec_b && full_n && (b_kfast || b_rfast);
-  const TileIdx ti{tid};
-
-  const int ktiles = (d.K + BK - 1) / BK;
-  const int kt0 = ks * ka.kt_per;
-  const int kt1 = kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles;
-
-  float ra[8], rb[8];
-  bool ra_vec = false, rb_vec = false;   // how the registers currently held were loaded
-  auto load_operand = [&](const float* __restrict__ P, long s_r, long s_k, int r0, int R, bool kfast, bool vec_ok, int k0,
-                          float* v, bool& used_vec) {
-    const bool kfull = k0 + BK <= d.K;
-    used_vec = vec_ok && kfull;
-    if (used_vec) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int row, k;
-        if (kfast) ti.vec_k(h, row, k); else ti.vec_r(h, row, k);
-        const float4 q = *reinterpret_cast<const float4*>(P + (long)(r0 + row) * s_r + (long)(k0 + k) * s_k);
-        v[4 * h + 0] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int row, k;
-        ti.sc(i, kfast, row, k);
-        const int gr = r0 + row, gk = k0 + k;
-        v[i] = (gr < R && gk < d.K) ? P[(long)gr * s_r + (long)gk * s_k] : 0.f;
-      }
-    }
-  };
-  auto store_operand = [&](const float* v, bool kfast, bool used_vec, auto& tile_bf16, auto& tile_f32) {
-    if (used_vec) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int row, k;
-        if (kfast) {
-          ti.vec_k(h, row, k);
-          if constexpr (BF16) {
-            bf16x4 p; p[0] = to_bf16(v[4 * h]); p[1] = to_bf16(v[4 * h + 1]); p[2] = to_bf16(v[4 * h + 2]); p[3] = to_bf16(v[4 * h + 3]);
-            *reinterpret_cast<bf16x4*>(&tile_bf16[row][k]) = p;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tile_f32[k + j][row] = v[4 * h + j];
-          }
-        } else {
-          ti.vec_r(h, row, k);
-          if constexpr (BF16) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) tile_bf16[row + j][k] = to_bf16(v[4 * h + j]);
-          } else {
-            *reinterpret_cast<float4*>(&tile_f32[k][row]) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int row, k;
-        ti.sc(i, kfast, row, k);
-        if constexpr (BF16) tile_bf16[row][k] = to_bf16(v[i]);
-        else tile_f32[k][row] = v[i];
-      }
-    }
-  };
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  if (kt0 < kt1) {
-    load_operand(A, d.sa_m, d.sa_k, m0, d.M, a_kfast || !a_rfast, va, kt0 * BK, ra, ra_vec);
-    load_operand(B, d.sb_n, d.sb_k, n0, d.N, b_kfast, vb, kt0 * BK, rb, rb_vec);
-  }
-  for (int kt = kt0; kt < kt1; ++kt) {
-    store_operand(ra, a_kfast || !a_rfast, ra_vec, sm.a, sm.a);
-    store_operand(rb, b_kfast, rb_vec, sm.b, sm.b);
-    __syncthreads();
-    if (kt + 1 < kt1) {
-      load_operand(A, d.sa_m, d.sa_k, m0, d.M, a_kfast || !a_rfast, va, (kt + 1) * BK, ra, ra_vec);
-      load_operand(B, d.sb_n, d.sb_k, n0, d.N, b_kfast, vb, (kt + 1) * BK, rb, rb_vec);
+  // one product segment: acc += A[m0:m0+64, :K] . B[:K, n0:n0+64]   (called once, or twice for C = A.B + A2.B2)
+  auto segment = [&](const float* __restrict__ Ap, long sa_m, long sa_k, const float* __restrict__ Bp, long sb_k, long sb_n,
+                     int K, bool veca, bool vecb, int kt0, int kt1) {
+    const bool a_k = sa_k == 1, a_r = sa_m == 1 && !a_k;
+    const bool b_k = sb_k == 1 && sb_n != 1, b_r = sb_n == 1;
+    const Operand oa{Ap, sa_m, sa_k, m0, d.M, a_k || !a_r, veca && full_m && (a_k || a_r)};
+    const Operand ob{Bp, sb_n, sb_k, n0, d.N, b_k, vecb && full_n && (b_k || b_r)};
+    float ra[M::NE], rb[M::NE];
+    if (kt0 < kt1) {
+      load_tile<BK, LEAN>(oa, K, kt0 * BK, tid, ra);
+      load_tile<BK, LEAN>(ob, K, kt0 * BK, tid, rb);
     }
-    if constexpr (BF16) {
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sm.a[wm * 32 + (lane & 31)][s * 16 + 8 * (lane >> 5)]);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(&sm.b[wn * 32 + (lane & 31)][s * 16 + 8 * (lane >> 5)]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      store_tile<BF16, BK, LEAN>(oa, tid, ra, sm.a);
+      store_tile<BF16, BK, LEAN>(ob, tid, rb, sm.b);
+      __syncthreads();
+      if (kt + 1 < kt1) {
+        load_tile<BK, LEAN>(oa, K, (kt + 1) * BK, tid, ra);
+        load_tile<BK, LEAN>(ob, K, (kt + 1) * BK, tid, rb);
       }
-    } else {
+      if constexpr (BF16) {
 #pragma unroll
-      for (int s = 0; s < BK / 2; ++s) {
-        const float a = sm.a[s * 2 + (lane >> 5)][wm * 32 + (lane & 31)];
-        const float b = sm.b[s * 2 + (lane >> 5)][wn * 32 + (lane & 31)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int s = 0; s < BK / 16; ++s) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sm.a[wm * 32 + (lane & 31)][s * 16 + 8 * (lane >> 5)]);
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(&sm.b[wn * 32 + (lane & 31)][s * 16 + 8 * (lane >> 5)]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+          const float a = sm.a[s * 2 + (lane >> 5)][wm * 32 + (lane & 31)];
+          const float b = sm.b[s * 2 + (lane >> 5)][wn * 32 + (lane & 31)];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
+  };
+  {
+    const int ktiles = (d.K + BK - 1) / BK;
+    const int kt0 = ks * ka.kt_per;                       // split-K only ever applies to single-product GEMMs
+    const int kt1 = kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles;
+    segment(d.A + (long)bz * d.sa_b, d.sa_m, d.sa_k, d.B + (long)bz * d.sb_b, d.sb_k, d.sb_n, d.K, ka.vec_a, ka.vec_b, kt0, kt1);
   }
+  if (d.A2)
+    segment(d.A2 + (long)bz * d.sa2_b, d.sa2_m, d.sa2_k, d.B2 + (long)bz * d.sb2_b, d.sb2_k, d.sb2_n, d.K2, ka.vec_a2, ka.vec_b2,
+            0, (d.K2 + BK - 1) / BK);
 
   // epilogue: lane holds column n, 16 rows
   const int n = n0 + wn * 32 + (lane & 31);
-  if (n >= d.N) return;
+  if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
   float* __restrict__ C = d.C + (long)bz * d.sc_b;
   const bool atomic = d.atomic || ka.ksplit > 1;
   const float bn = d.bias_n ? d.bias_n[(long)bz * d.bias_n_b + n] : 0.f;
@@ -192,23 +236,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// 16-byte path: unit stride along one axis, the other stride and the batch stride multiples of 4 floats, base aligned
+inline bool vec_ok_a(const float* P, long s_m, long s_k, long s_b) {
+  return aligned16(P) && s_b % 4 == 0 && ((s_k == 1 && s_m % 4 == 0) || (s_m == 1 && s_k != 1 && s_k % 4 == 0));
+}
+inline bool vec_ok_b(const float* P, long s_k, long s_n, long s_b) {
+  return aligned16(P) && s_b % 4 == 0 && ((s_k == 1 && s_n != 1 && s_n % 4 == 0) || (s_n == 1 && s_k % 4 == 0));
+}
 
 }  // namespace
 
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return MIMRL_OK;
   if (!d.A || !d.B || !d.C) return set_error(MIMRL_ERR_ARG, "gemm: null operand");
+  if ((d.A2 != nullptr) != (d.B2 != nullptr)) return set_error(MIMRL_ERR_ARG, "gemm: second product needs both operands");
   KernelArgs ka;
   ka.d = d;
-  // 16-byte path: unit stride along one axis, the other stride and the batch stride multiples of 4 floats, base aligned
-  ka.vec_a = aligned16(d.A) && d.sa_b % 4 == 0 &&
-             ((d.sa_k == 1 && d.sa_m % 4 == 0) || (d.sa_m == 1 && d.sa_k != 1 && d.sa_k % 4 == 0));
-  ka.vec_b = aligned16(d.B) && d.sb_b % 4 == 0 &&
-             ((d.sb_k == 1 && d.sb_n != 1 && d.sb_n % 4 == 0) || (d.sb_n == 1 && d.sb_k % 4 == 0));
+  ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b);
+  ka.vec_b = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b);
+  ka.vec_a2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : 1;
+  ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
+  static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knob
+  const bool lean = bf16 && !no_lean && d.M % BM == 0 && d.N % BN == 0 && ka.vec_a && ka.vec_b && ka.vec_a2 && ka.vec_b2 &&
+                    d.K >= 64;
+  const int BKh = lean ? 64 : 32;
   const int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
-  const int ktiles = (d.K + BK - 1) / BK;
+  const int ktiles = (d.K + BKh - 1) / BKh;
   int ksplit = 1;
-  if (d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum && d.act == ACT_NONE && ktiles >= 8) {
+  if (!d.A2 && d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum &&
+      d.act == ACT_NONE && ktiles >= 8) {
     // accumulate-into-zeroed-output GEMMs (weight gradients): split K until the grid has ~2 waves of workgroups
     ksplit = (512 + tiles - 1) / tiles;
     if (ksplit > ktiles / 4) ksplit = ktiles / 4;
@@ -218,8 +274,9 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   ka.kt_per = (ktiles + ksplit - 1) / ksplit;
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * ksplit);
   if (grid.y > 65535 || grid.z > 65535) return set_error(MIMRL_ERR_ARG, "gemm: grid too large (M=%d batch=%d)", d.M, d.batch);
-  if (bf16) hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, ka);
-  else hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, ka);
+  if (!bf16) hipLaunchKernelGGL((gemm_kernel<false, 32, false>), grid, dim3(256), 0, s, ka);
+  else if (lean) hipLaunchKernelGGL((gemm_kernel<true, 64, true>), grid, dim3(256), 0, s, ka);
+  else hipLaunchKernelGGL((gemm_kernel<true, 32, false>), grid, dim3(256), 0, s, ka);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
