@@ -118,6 +118,7 @@ struct mimrl_handle {
   Layout layout;
   mimrl_buffers bufs;
   bool bound = false;
+  bool grads_clean[3] = {true, true, true};   // bucket known to be all-zero (fresh buffers / zeroed by the fused Adam)
   int bank_rows = 0;
   bool bf16 = false;                   // current GEMM operand mode (switched between forward / backward sections)
   int prec = 0;                        // MIMRL_PREC_* bit mask
@@ -253,7 +254,7 @@ struct mimrl_handle {
   int carve();
 
   int G_(const GemmDesc& d) { return gemm(stream, d, bf16); }
-  int model_forward(bool train, bool save);
+  int model_forward(bool train, bool save, int knn_stage = 0);
   int cube_forward(bool train);
   int cube_backward(int cur_in, int* cur_out);
   int model_backward();
@@ -275,7 +276,7 @@ struct mimrl_handle {
   int mlp_stack_backward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
                          const int* dims, const float* in, float* const* act, float* dout, float* const* dtmp, float* din,
                          bool wgrad);
-  int enqueue_grads(int stage);
+  int enqueue_grads(int stage, bool skip_zero = false);
   int enqueue_apply(int stage);
   int run(int stage, int kind);
 };
@@ -484,7 +485,7 @@ int mimrl_handle::alloc_workspace() {
 // =================================================================================================
 // model forward
 // =================================================================================================
-int mimrl_handle::model_forward(bool train, bool save) {
+int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
   const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const long BT_ = (long)B * T;
   const float* xin[2] = {bufs.audio, bufs.video};
@@ -515,6 +516,10 @@ int mimrl_handle::model_forward(bool train, bool save) {
       }
     }
     MX(join(1, 3));
+    if (l == 0 && knn_stage) {   // the kNN sampler needs only banks + anchors: overlap it with the recurrence (32 of 256 CUs busy)
+      MX(fork(4, 4));
+      MX(knn_launch(knn_stage, S(4)));
+    }
     { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
   }
   MX(join(0, 0));
@@ -677,22 +682,24 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         i_dym = q;
       }
       const float* dym = gbuf[i_dym];
-      { GemmDesc g = gemm_tn(dym, od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(G_(g)); }
-      if (a.fc2.b >= 0) MX(colsum(stream, dym, R2, od, od, Gm(a.fc2.b)));
-      if (a.res >= 0) { GemmDesc g = gemm_tn(dy, od, xin, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(G_(g)); }
+      MX(fork(1, 2));                                        // weight gradients leave the critical path
+      { GemmDesc g = gemm_tn(dym, od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(G_on(S(1), g)); }
+      if (a.fc2.b >= 0) MX(colsum(S(1), dym, R2, od, od, Gm(a.fc2.b)));
+      if (a.res >= 0) { GemmDesc g = gemm_tn(dy, od, xin, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(G_on(S(2), g)); }
       GRAB(i_du);                                            // dU = (dYm . W2) * act'(U)
       { GemmDesc g = gemm_nn(dym, od, P(a.fc2.w), hd, gbuf[i_du], hd, (int)R2, hd, od); g.act = cfg.activation; g.gradact_u = b.d.u;
         if (a.fc1.b >= 0) g.colsum = Gm(a.fc1.b);     // db1 = column sums of dU, fused into the epilogue
         MX(G_(g)); }
-      if (i_dym != i_dy) release(i_dym);
-      { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(G_(g)); }
+      MX(fork(3, 3));
+      { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(G_on(S(3), g)); }
       GRAB(i_dx0);
       int i_dx = i_dx0;
       const bool fuse_dx = a.res >= 0 && !cfg.ln_first;        // dX = dU.W1 + dY.Wr in ONE launch
       { GemmDesc g = gemm_nn(gbuf[i_du], hd, P(a.fc1.w), id, gbuf[i_dx], id, (int)R2, id, hd);
         if (fuse_dx) { g.A2 = dy; g.sa2_m = od; g.sa2_k = 1; g.B2 = P(a.res); g.sb2_k = id; g.sb2_n = 1; g.K2 = od; }
         MX(G_(g)); }
-      if (cfg.ln_first) {                                    // that was dXn: LayerNorm backward into the (now free) dU buffer
+      if (cfg.ln_first) {                                    // that was dXn: LayerNorm backward into the dU buffer,
+        MX(join(3, 3));                                      // once the dW1 GEMM on side 3 has finished reading it
         MX(rowln_bwd(stream, b.k.z, P(a.ln_g), b.d.xn_mean, b.d.xn_rstd, gbuf[i_dx], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b), R2, id));
         release(i_dx);
         i_dx = i_du;
@@ -703,6 +710,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         if (a.res >= 0) { GemmDesc g = gemm_nn(dy, od, P(a.res), id, gbuf[i_dx], id, (int)R2, id, od); g.beta = 1.f; MX(G_(g)); }
         else MX(add_inplace(stream, gbuf[i_dx], dy, R2 * id));
       }
+      MX(join(1, 3));                                        // side streams are done with dy / dym / dU before they are recycled
+      if (i_dym != i_dy) release(i_dym);
       release(i_dy);
       cur = i_dx;
     }
@@ -746,16 +755,17 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       }
       const float* dym = gbuf[i_dym];
       // dW2[ol,hl] += sum_b dYm_b[ol,C] . H_b[hl,C]^T
+      MX(fork(1, 2));
       { GemmDesc g; g.A = dym; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;
         g.B = b.l.h; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)hl * C;
         g.C = Gm(a.fc2.w); g.sc_m = hl; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = hl; g.K = (int)C; g.batch = B; g.atomic = 1;
-        MX(G_(g)); }
-      if (a.fc2.b >= 0) MX(rowsum_batched(stream, dym, B, ol, (int)C, Gm(a.fc2.b)));
+        MX(G_on(S(1), g)); }
+      if (a.fc2.b >= 0) MX(rowsum_batched(S(1), dym, B, ol, (int)C, Gm(a.fc2.b)));
       if (a.res >= 0) {
         GemmDesc g; g.A = dy; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;
         g.B = xblk; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
         g.C = Gm(a.res); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
-        MX(G_(g));
+        MX(G_on(S(2), g));
       }
       GRAB(i_du);                                            // dU_b[hl,C] = (W2^T . dYm_b) * act'(U)
       { GemmDesc g; g.A = P(a.fc2.w); g.sa_m = 1; g.sa_k = hl; g.sa_b = 0;
@@ -763,12 +773,12 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         g.C = gbuf[i_du]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)hl * C; g.M = hl; g.N = (int)C; g.K = ol; g.batch = B;
         g.act = cfg.activation; g.gradact_u = b.l.u;
         MX(G_(g)); }
-      if (i_dym != i_dy) release(i_dym);
+      MX(fork(3, 3));
       { GemmDesc g; g.A = gbuf[i_du]; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)hl * C;
         g.B = xmlp; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
         g.C = Gm(a.fc1.w); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = hl; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
-        MX(G_(g)); }
-      if (a.fc1.b >= 0) MX(rowsum_batched(stream, gbuf[i_du], B, hl, (int)C, Gm(a.fc1.b)));
+        MX(G_on(S(3), g)); }
+      if (a.fc1.b >= 0) MX(rowsum_batched(S(3), gbuf[i_du], B, hl, (int)C, Gm(a.fc1.b)));
       GRAB(i_dx0);                                           // dX_b[il,C] = W1^T . dU_b (+LN-first bwd) + Wr^T . dY_b
       int i_dx = i_dx0;
       { GemmDesc g; g.A = P(a.fc1.w); g.sa_m = 1; g.sa_k = il; g.sa_b = 0;
@@ -780,6 +790,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         }
         MX(G_(g)); }
       if (cfg.ln_first) {
+        MX(join(3, 3));                                      // dW1 / db1 on side 3 still read the dU buffer
         MX(colln_bwd(stream, xblk, P(a.ln_g), b.l.xn_mean, b.l.xn_rstd, gbuf[i_dx], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b), B, il, (int)C));
         release(i_dx);
         i_dx = i_du;
@@ -796,6 +807,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       } else {
         MX(add_inplace(stream, gbuf[i_dx], dy, (long)B * il * C));
       }
+      MX(join(1, 3));
+      if (i_dym != i_dy) release(i_dym);
       release(i_dy);
       cur = i_dx;
     }
@@ -1104,7 +1117,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
 // =================================================================================================
 // stage drivers
 // =================================================================================================
-int mimrl_handle::enqueue_grads(int stage) {
+int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   const int B = cfg.batch;
   const bool have_banks = bank_rows > 0;
   ev_next = 0;
@@ -1112,12 +1125,10 @@ int mimrl_handle::enqueue_grads(int stage) {
     hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, have_banks ? d_ints + 2 : nullptr,
                        bufs.scalars, 0, 32);
     LAUNCH_CHECK();
-    HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));
-    if (!have_banks) return MIMRL_OK;   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
-    MX(fork(4, 4));
-    MX(knn_launch(1, S(4)));
+    if (!have_banks) return MIMRL_OK;
+    if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-    MX(model_forward(true, false));
+    MX(model_forward(true, false, 1));
     MX(estimators_all(1, true, true));
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
@@ -1125,13 +1136,9 @@ int mimrl_handle::enqueue_grads(int stage) {
   }
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
   LAUNCH_CHECK();
-  HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
-  if (have_banks) {
-    MX(fork(4, 4));
-    MX(knn_launch(2, S(4)));
-  }
+  if (!skip_zero) HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-  MX(model_forward(true, true));
+  MX(model_forward(true, true, have_banks ? 2 : 0));
   hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
   LAUNCH_CHECK();
   if (have_banks) {
@@ -1168,12 +1175,20 @@ int mimrl_handle::enqueue_apply(int stage) {
 int mimrl_handle::run(int stage, int kind) {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
-  if (kind == 2) return enqueue_apply(stage);
+  if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
+  // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
+  // an all-reduce): always zero first -- the caller may call it repeatedly
+  const bool skip_zero = kind == 0 && grads_clean[stage];
   auto body = [&]() -> int {
-    MX(enqueue_grads(stage));
+    MX(enqueue_grads(stage, skip_zero));
     if (kind == 0) MX(enqueue_apply(stage));
     return MIMRL_OK;
   };
+  if (kind == 0 && !skip_zero) {   // a graph captured now would bake the memset in; run this one eagerly instead
+    grads_clean[stage] = true;
+    return body();
+  }
+  if (kind == 1) grads_clean[stage] = false;
   if (!cfg.use_graph || prof_on) return body();
   hipGraphExec_t& ex = graph[stage][kind];
   if (ex && graph_rows[stage][kind] != bank_rows) {   // bank size is baked into the kernel arguments
