@@ -128,10 +128,10 @@ int64_t mimrl_op_gru_saved_floats(int B, int T);
 int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,
                          const float* bhh_f, const float* bhh_r, const int32_t* lens, float* out, float* saved_f,
                          float* saved_r, int B, int T, int precision);
+/* BPTT of that layer: dg_* [B,T,512] rows = [dr'|dz'|dn'|dn'*r] (dgx = cols 0..383, dgh = cols 0..255 + 384..511) */
 int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, const float* saved_f,
-                          const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dgx_f,
-                          float* dgx_r, float* dgh_f, float* dgh_r, float* hprev_f, float* hprev_r, int B, int T,
-                          int precision);
+                          const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dg_f,
+                          float* dg_r, float* hprev_f, float* hprev_r, int B, int T, int precision);
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
                       int bound);
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);

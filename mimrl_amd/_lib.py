@@ -74,7 +74,7 @@ def load() -> C.CDLL:
     lib.mimrl_op_adam.argtypes = [_FP, _FP, _FP, _FP, _FP, C.c_int64, _FP, _FP, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_float]
     lib.mimrl_op_gru_forward.argtypes = [_FP] * 11 + [C.c_int, C.c_int, C.c_int]
-    lib.mimrl_op_gru_backward.argtypes = [_FP] * 14 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_gru_backward.argtypes = [_FP] * 12 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_mi_bound.argtypes = [_FP] * 5 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_knn.argtypes = [_FP, _FP, C.c_int, C.c_int, _FP, C.c_int, C.c_int, _FP]
     lib.mimrl_op_cmi_loss.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]

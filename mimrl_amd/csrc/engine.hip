@@ -153,7 +153,7 @@ struct mimrl_handle {
   float *dcc[2], *dcin = nullptr;
   float* gbuf[4];
   size_t gbuf_floats = 0;
-  float *dtx = nullptr, *ds[2], *dgx[2][2][2], *dgh[2][2][2], *hprev[2][2][2], *dh0[2];   // [layer][mod][dir]
+  float *dtx = nullptr, *ds[2], *dg[2][2][2], *hprev[2][2][2], *dh0[2];   // [layer][mod][dir]; dg = [dr'|dz'|dn'|dn'r] rows of 4H
 
   // side streams: independent branches of a stage run concurrently (and are captured as parallel graph branches)
   static constexpr int NSIDE = 6;      // 0: text branch, 1-3: per-(modality,direction) helpers / weight gradients, 4: kNN, 5: CMI
@@ -448,8 +448,7 @@ int mimrl_handle::carve() {
     MX(take(&dh0[m], BT_ * 2 * H));
     for (int l = 0; l < 2; ++l)
       for (int d = 0; d < 2; ++d) {   // per layer: layer-1 weight-gradient GEMMs overlap the layer-0 BPTT
-        MX(take(&dgx[l][m][d], BT_ * G));
-        MX(take(&dgh[l][m][d], BT_ * G));
+        MX(take(&dg[l][m][d], BT_ * 4 * H));
         MX(take(&hprev[l][m][d], BT_ * H));
       }
   }
@@ -502,6 +501,8 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
+    a.dbg = getenv("MIMRL_GRU_DBG") ? atoi(getenv("MIMRL_GRU_DBG")) : 0;
+    a.btv = gru_pick_btv(B, 2);
     if (l == 1) MX(fork(1, 3));
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
@@ -847,12 +848,14 @@ int mimrl_handle::model_backward() {
     GruBwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.dout_ld = l == 1 ? H : 2 * H; a.dout_off = l == 1 ? 0 : H;
+    a.dbg = getenv("MIMRL_GRU_DBG") ? atoi(getenv("MIMRL_GRU_DBG")) : 0;
+    a.btv = gru_pick_btv(B, 2);
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
-        a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dgx[l][m][d],
-                                dgh[l][m][d], hprev[l][m][d], Gm(g.b_ih), Gm(g.b_hh)};
+        a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dg[l][m][d],
+                                hprev[l][m][d], Gm(g.b_ih), Gm(g.b_hh)};
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
@@ -863,15 +866,17 @@ int mimrl_handle::model_backward() {
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         hipStream_t st = S(1 + (m * 2 + d) % 3);
-        { GemmDesc q = gemm_tn(dgx[l][m][d], G, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
-        { GemmDesc q = gemm_tn(dgh[l][m][d], G, hprev[l][m][d], H, Gm(g.w_hh), H, G, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+        // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H)
+        { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+        { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, hprev[l][m][d], H, Gm(g.w_hh), H, 2 * H, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+        { GemmDesc q = gemm_tn(dg[l][m][d] + 3 * H, 4 * H, hprev[l][m][d], H, Gm(g.w_hh) + 2 * H * H, H, H, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
       }
     }
     if (l == 1) {   // critical path: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
       for (int m = 0; m < 2; ++m)
         for (int d = 0; d < 2; ++d) {
           const GruDirW& g = gru[m][l][d];
-          GemmDesc q = gemm_nn(dgx[l][m][d], G, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
+          GemmDesc q = gemm_nn(dg[l][m][d], 4 * H, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
           q.beta = d == 0 ? 0.f : 1.f;
           MX(G_(q));
         }
@@ -1399,7 +1404,7 @@ int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, con
                          float* saved_r, int B, int T, int precision) {
   GruFwdArgs a;
   std::memset(&a, 0, sizeof a);
-  a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 1;
+  a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 1; a.btv = gru_pick_btv(B, 1);
   a.lens[0] = lens; a.lens[1] = lens;
   a.seq[0][0] = GruSeq{gx_f, whh_f, bhh_f, out, saved_f};
   a.seq[0][1] = GruSeq{gx_r, whh_r, bhh_r, out, saved_r};
@@ -1407,15 +1412,14 @@ int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, con
 }
 
 int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, const float* saved_f,
-                          const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dgx_f,
-                          float* dgx_r, float* dgh_f, float* dgh_r, float* hprev_f, float* hprev_r, int B, int T,
-                          int precision) {
+                          const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dg_f,
+                          float* dg_r, float* hprev_f, float* hprev_r, int B, int T, int precision) {
   GruBwdArgs a;
   std::memset(&a, 0, sizeof a);
-  a.B = B; a.T = T; a.out_ld = 2 * H; a.dout_ld = 2 * H; a.dout_off = H; a.nmod = 1;
+  a.B = B; a.T = T; a.out_ld = 2 * H; a.dout_ld = 2 * H; a.dout_off = H; a.nmod = 1; a.btv = gru_pick_btv(B, 1);
   a.lens[0] = lens; a.lens[1] = lens;
-  a.seq[0][0] = GruSeqBwd{whh_f, saved_f, out, dout, dgx_f, dgh_f, hprev_f, nullptr, nullptr};
-  a.seq[0][1] = GruSeqBwd{whh_r, saved_r, out, dout, dgx_r, dgh_r, hprev_r, nullptr, nullptr};
+  a.seq[0][0] = GruSeqBwd{whh_f, saved_f, out, dout, dg_f, hprev_f, nullptr, nullptr};
+  a.seq[0][1] = GruSeqBwd{whh_r, saved_r, out, dout, dg_r, hprev_r, nullptr, nullptr};
   return gru_backward(reinterpret_cast<hipStream_t>(stream), a, (precision & 1) != 0);
 }
 

@@ -259,7 +259,11 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knob
   const bool lean = bf16 && !no_lean && d.M % BM == 0 && d.N % BN == 0 && ka.vec_a && ka.vec_b && ka.vec_a2 && ka.vec_b2 &&
                     d.K >= 64;
-  const int BKh = lean ? 64 : 32;
+  // small grids gain nothing from occupancy: stage 128 k-values per round trip (one-shot for K <= 128)
+  const int tiles_all = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
+  static const int no_big = getenv("MIMRL_GEMM_NO_BK128") != nullptr;   // tuning knob
+  const bool lean128 = lean && !no_big && tiles_all <= 256 && d.K >= 128 && (!d.A2 || d.K2 >= 64);
+  const int BKh = lean128 ? 128 : (lean ? 64 : 32);
   const int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
   const int ktiles = (d.K + BKh - 1) / BKh;
   int ksplit = 1;
@@ -275,6 +279,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * ksplit);
   if (grid.y > 65535 || grid.z > 65535) return set_error(MIMRL_ERR_ARG, "gemm: grid too large (M=%d batch=%d)", d.M, d.batch);
   if (!bf16) hipLaunchKernelGGL((gemm_kernel<false, 32, false>), grid, dim3(256), 0, s, ka);
+  else if (lean128) hipLaunchKernelGGL((gemm_kernel<true, 128, true>), grid, dim3(256), 0, s, ka);
   else if (lean) hipLaunchKernelGGL((gemm_kernel<true, 64, true>), grid, dim3(256), 0, s, ka);
   else hipLaunchKernelGGL((gemm_kernel<true, 32, false>), grid, dim3(256), 0, s, ka);
   LAUNCH_CHECK();

@@ -16,6 +16,8 @@ struct GruFwdArgs {
   GruSeq seq[2][2];        // [modality][direction]
   const int* lens[2];      // [modality][B] valid lengths (packed-sequence semantics)
   int B, T, out_ld, nmod;
+  int dbg;             // tuning only (see GruBwdArgs)
+  int btv;             // valid batch rows per workgroup (1..16); the MFMA tile stays 16 wide, the rest is padding
 };
 
 struct GruSeqBwd {
@@ -23,8 +25,7 @@ struct GruSeqBwd {
   const float* saved;  // gate slab written by the forward kernel
   const float* out;    // forward outputs [B,T,out_ld] (source of h_prev)
   const float* dout;   // gradient w.r.t. this direction's outputs, [B,T,dout_ld] (+ dir*dout_off)
-  float* dgx;          // [B,T,3H]
-  float* dgh;          // [B,T,3H]
+  float* dg;           // [B,T,4H] = [dr' | dz' | dn' | dn'*r]:  dgx = columns [0,3H), dgh = columns [0,2H) + [3H,4H)
   float* hprev;        // [B,T,H]  h_{prev} of every step (0 at sequence starts / padded steps): operand of dW_hh
   float* db_ih;        // [3H] += sum_{b,t} dgx   (nullable)
   float* db_hh;        // [3H] += sum_{b,t} dgh   (nullable)
@@ -34,10 +35,15 @@ struct GruBwdArgs {
   GruSeqBwd seq[2][2];
   const int* lens[2];
   int B, T, out_ld, dout_ld, dout_off, nmod;
+  int dbg;             // tuning only: bit0 skip global stores, bit1 skip MFMA, bit2 skip operand loads
+  int btv;             // must equal the forward launch's value (addresses the saved-gate slab)
 };
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);
 int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16);
 long gru_saved_floats(int B, int T);
+// batch rows per workgroup: both kernels are bound by per-CU load/store bandwidth, not MFMA, so the batch is spread
+// over as many CUs as possible (MFMA columns beyond btv are padding)
+int gru_pick_btv(int B, int nmod);
 
 }  // namespace mimrl

@@ -19,6 +19,8 @@
 //            fp32 accumulate, fp32 gate math.
 #include "gru.h"
 
+#include <cstdlib>
+
 namespace mimrl {
 
 namespace {
@@ -97,10 +99,53 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 
+// saved-gate slab: fp32 mode stores r,z,n,hn as four float4 per (lane, s); bf16 mode packs them into two 16-byte
+// vectors [r|z] and [n|hn] of bf16 (half the store / load instructions of the two recurrence kernels).
+template <bool BF16>
+__device__ __forceinline__ void save_gates(float* base, int t, int ntile, int tile, int w, int s, int lane, const float* rr,
+                                           const float* zz, const float* nn, const float* hn);
+template <bool BF16>
+__device__ __forceinline__ void load_gates(const float* base, int t, int ntile, int tile, int w, int s, int lane, float* rr,
+                                           float* zz, float* nn, float* hn);
+
 // saved-gate slab addressing ("lane-native": every wave-instruction stores 1 KiB contiguous)
 //   index = ((((t*ntile + tile)*4 + q)*8 + (w*2+s))*64 + lane)*4      q: 0=r 1=z 2=n 3=hn
 __device__ __forceinline__ long sv_index(int t, int ntile, int tile, int q, int w, int s, int lane) {
-  return ((((long)t * ntile + tile) * 4 + q) * 8 + (w * 2 + s)) * 256 + lane * 4;
+  return ((((long)t * ntile + tile) * 4 + q) * 8 + (w * 2 + s)) * 256 + lane * 4;   // 16 batch columns per tile slot
+}
+
+template <>
+__device__ __forceinline__ void save_gates<false>(float* base, int t, int ntile, int tile, int w, int s, int lane,
+                                                  const float* rr, const float* zz, const float* nn, const float* hn) {
+  st4(base + sv_index(t, ntile, tile, 0, w, s, lane), rr[0], rr[1], rr[2], rr[3]);
+  st4(base + sv_index(t, ntile, tile, 1, w, s, lane), zz[0], zz[1], zz[2], zz[3]);
+  st4(base + sv_index(t, ntile, tile, 2, w, s, lane), nn[0], nn[1], nn[2], nn[3]);
+  st4(base + sv_index(t, ntile, tile, 3, w, s, lane), hn[0], hn[1], hn[2], hn[3]);
+}
+template <>
+__device__ __forceinline__ void save_gates<true>(float* base, int t, int ntile, int tile, int w, int s, int lane,
+                                                 const float* rr, const float* zz, const float* nn, const float* hn) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[r] = to_bf16(rr[r]); a[4 + r] = to_bf16(zz[r]); b[r] = to_bf16(nn[r]); b[4 + r] = to_bf16(hn[r]); }
+  *reinterpret_cast<bf16x8*>(base + sv_index(t, ntile, tile, 0, w, s, lane)) = a;
+  *reinterpret_cast<bf16x8*>(base + sv_index(t, ntile, tile, 1, w, s, lane)) = b;
+}
+template <>
+__device__ __forceinline__ void load_gates<false>(const float* base, int t, int ntile, int tile, int w, int s, int lane,
+                                                  float* rr, float* zz, float* nn, float* hn) {
+  const float4 R = ld4(base + sv_index(t, ntile, tile, 0, w, s, lane)), Z = ld4(base + sv_index(t, ntile, tile, 1, w, s, lane));
+  const float4 N = ld4(base + sv_index(t, ntile, tile, 2, w, s, lane)), Hn = ld4(base + sv_index(t, ntile, tile, 3, w, s, lane));
+  rr[0] = R.x; rr[1] = R.y; rr[2] = R.z; rr[3] = R.w; zz[0] = Z.x; zz[1] = Z.y; zz[2] = Z.z; zz[3] = Z.w;
+  nn[0] = N.x; nn[1] = N.y; nn[2] = N.z; nn[3] = N.w; hn[0] = Hn.x; hn[1] = Hn.y; hn[2] = Hn.z; hn[3] = Hn.w;
+}
+template <>
+__device__ __forceinline__ void load_gates<true>(const float* base, int t, int ntile, int tile, int w, int s, int lane,
+                                                 float* rr, float* zz, float* nn, float* hn) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + sv_index(t, ntile, tile, 0, w, s, lane));
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(base + sv_index(t, ntile, tile, 1, w, s, lane));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { rr[r] = (float)a[r]; zz[r] = (float)a[4 + r]; nn[r] = (float)b[r]; hn[r] = (float)b[4 + r]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -115,8 +160,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
   const GruSeq& q = a.seq[mod][dir];
   const int B = a.B, T = a.T, ntile = gridDim.x;
   const int bcol = lane & 15, kq = lane >> 4;
-  const int b = tile * BT + bcol;
-  const bool brow_ok = b < B;
+  const int b = tile * a.btv + bcol;
+  const bool brow_ok = bcol < a.btv && b < B;
   const int len = brow_ok ? a.lens[mod][b] : 0;
 
   // ---- W_hh slice -> registers as MFMA A fragments: rows (gate g, unit 32w+16s+i), i = lane&15
@@ -169,7 +214,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) gxn[g][s] = ld4(gx_b + (long)t * G + g * H + 32 * w + 16 * s + 4 * kq);
+      for (int s = 0; s < 2; ++s)
+        gxn[g][s] = brow_ok ? ld4(gx_b + (long)t * G + g * H + 32 * w + 16 * s + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   load_gx(dir ? T - 1 : 0);
 
@@ -181,13 +227,14 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int s = 0; s < 2; ++s) gxc[g][s] = gxn[g][s];
-    if (step + 1 < T) load_gx(dir ? T - 2 - step : step + 1);
+    if (step + 1 < T && !(a.dbg & 4)) load_gx(dir ? T - 2 - step : step + 1);
 
     f32x4 acc[3][2];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int s = 0; s < 2; ++s) acc[g][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < C::KS_F; ++ks) {
       const auto bf = bfrag(hs[cur], ks, lane);
@@ -216,13 +263,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
       }
       const int unit = 32 * w + 16 * s + 4 * kq;
       put4(hs[cur ^ 1], bcol, unit, hreg[s][0], hreg[s][1], hreg[s][2], hreg[s][3]);
-      if (brow_ok) st4(out_b + (long)t * a.out_ld + dir * H + unit, ho[0], ho[1], ho[2], ho[3]);
-      if (q.saved) {
-        st4(q.saved + sv_index(t, ntile, tile, 0, w, s, lane), rr[0], rr[1], rr[2], rr[3]);
-        st4(q.saved + sv_index(t, ntile, tile, 1, w, s, lane), zz[0], zz[1], zz[2], zz[3]);
-        st4(q.saved + sv_index(t, ntile, tile, 2, w, s, lane), nn[0], nn[1], nn[2], nn[3]);
-        st4(q.saved + sv_index(t, ntile, tile, 3, w, s, lane), hn[0], hn[1], hn[2], hn[3]);
-      }
+      if (brow_ok && !(a.dbg & 1)) st4(out_b + (long)t * a.out_ld + dir * H + unit, ho[0], ho[1], ho[2], ho[3]);
+      if (q.saved && brow_ok && !(a.dbg & 1)) save_gates<BF16>(q.saved, t, ntile, tile, w, s, lane, rr, zz, nn, hn);
     }
     lds_barrier();
   }
@@ -246,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const GruSeqBwd& q = a.seq[mod][dir];
   const int B = a.B, T = a.T, ntile = gridDim.x;
   const int bcol = lane & 15, kq = lane >> 4;
-  const int b = tile * BT + bcol;
-  const bool brow_ok = b < B;
+  const int b = tile * a.btv + bcol;
+  const bool brow_ok = bcol < a.btv && b < B;
   const int len = brow_ok ? a.lens[mod][b] : 0;
 
   // A fragments of W_hh^T: rows = this wave's units (32w+16s+i), k = gate row index (0..383)
@@ -278,19 +320,17 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       sb[0][s][r] = sb[1][s][r] = sb[2][s][r] = sb[3][s][r] = 0.f;
     }
 
-  const long rs_g = (long)T * G;
   const long rs_o = (long)T * a.out_ld;
   const long rs_d = (long)T * a.dout_ld;
   const long bb = brow_ok ? b : 0;
   const float* out_b = q.out + bb * rs_o + dir * H;        // forward outputs of THIS direction (h_prev source)
   const float* dout_b = q.dout + bb * rs_d + a.dout_off * dir;
-  float* dgx_b = q.dgx + bb * rs_g;
-  float* dgh_b = q.dgh + bb * rs_g;
+  float* dg_b = q.dg + bb * (long)T * 4 * H;
   float* hp_b = q.hprev + bb * (long)T * H;
 
   // software pipeline: the six operand vectors of step+1 are requested before step's math (global latency ~1-2 us
   // would otherwise sit on the critical path of every step)
-  struct Ops { float4 R, Z, N, HN, DO, HP; };
+  struct Ops { float rr[4], zz[4], nn[4], hn[4]; float4 DO, HP; };
   Ops nx[2];
   auto fetch = [&](int step, Ops* o) {
     const int t = dir ? step : T - 1 - step;
@@ -303,10 +343,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
       // h_prev is the previous VALID output of this direction; with packed semantics that is simply out[tprev]
       // when tprev is inside [0,len) and the zero initial state otherwise.
-      o[s].R = valid ? ld4(q.saved + sv_index(t, ntile, tile, 0, w, s, lane)) : zero;
-      o[s].Z = valid ? ld4(q.saved + sv_index(t, ntile, tile, 1, w, s, lane)) : zero;
-      o[s].N = valid ? ld4(q.saved + sv_index(t, ntile, tile, 2, w, s, lane)) : zero;
-      o[s].HN = valid ? ld4(q.saved + sv_index(t, ntile, tile, 3, w, s, lane)) : zero;
+      if (valid) load_gates<BF16>(q.saved, t, ntile, tile, w, s, lane, o[s].rr, o[s].zz, o[s].nn, o[s].hn);
       o[s].DO = valid ? ld4(dout_b + (long)t * a.dout_ld + unit) : zero;
       o[s].HP = hp_ok ? ld4(out_b + (long)tprev * a.out_ld + unit) : zero;
     }
@@ -319,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     const int cur = step & 1;
     const bool valid = t < len;
     Ops op[2] = {nx[0], nx[1]};
-    if (step + 1 < T) fetch(step + 1, nx);
+    if (step + 1 < T && !(a.dbg & 4)) fetch(step + 1, nx);
     float dhz[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -328,10 +365,9 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
             dnr[4] = {0.f, 0.f, 0.f, 0.f};
       const float4 HP = op[s].HP;
       if (valid) {
-        const float4 R = op[s].R, Z = op[s].Z, N = op[s].N, HN = op[s].HN, DO = op[s].DO;
-        const float rr[4] = {R.x, R.y, R.z, R.w}, zz[4] = {Z.x, Z.y, Z.z, Z.w}, nn[4] = {N.x, N.y, N.z, N.w},
-                    hn[4] = {HN.x, HN.y, HN.z, HN.w}, dd[4] = {DO.x, DO.y, DO.z, DO.w},
-                    hp[4] = {HP.x, HP.y, HP.z, HP.w};
+        const float4 DO = op[s].DO;
+        const float* rr = op[s].rr; const float* zz = op[s].zz; const float* nn = op[s].nn; const float* hn = op[s].hn;
+        const float dd[4] = {DO.x, DO.y, DO.z, DO.w}, hp[4] = {HP.x, HP.y, HP.z, HP.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float dh = dd[r] + carry[s][r];
@@ -352,20 +388,19 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
       put4(ds[cur], bcol, 2 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) { sb[0][s][r] += drp[r]; sb[1][s][r] += dzp[r]; sb[2][s][r] += dnp[r]; sb[3][s][r] += dnr[r]; }
-      if (brow_ok) {
+      if (brow_ok && !(a.dbg & 1)) {
         st4(hp_b + (long)t * H + unit, HP.x, HP.y, HP.z, HP.w);
-        st4(dgx_b + (long)t * G + 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
-        st4(dgx_b + (long)t * G + 1 * H + unit, dzp[0], dzp[1], dzp[2], dzp[3]);
-        st4(dgx_b + (long)t * G + 2 * H + unit, dnp[0], dnp[1], dnp[2], dnp[3]);
-        st4(dgh_b + (long)t * G + 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
-        st4(dgh_b + (long)t * G + 1 * H + unit, dzp[0], dzp[1], dzp[2], dzp[3]);
-        st4(dgh_b + (long)t * G + 2 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
+        st4(dg_b + (long)t * 4 * H + 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
+        st4(dg_b + (long)t * 4 * H + 1 * H + unit, dzp[0], dzp[1], dzp[2], dzp[3]);
+        st4(dg_b + (long)t * 4 * H + 2 * H + unit, dnp[0], dnp[1], dnp[2], dnp[3]);
+        st4(dg_b + (long)t * 4 * H + 3 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
       }
     }
     lds_barrier();
     f32x4 acc[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int ks = 0; ks < C::KS_B; ++ks) {
       const auto bf = bfrag(ds[cur], ks, lane);
@@ -413,7 +448,8 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_forward: empty batch");
-  dim3 grid((a.B + BT - 1) / BT, 2, a.nmod);
+  if (a.btv < 1 || a.btv > BT) return set_error(MIMRL_ERR_ARG, "gru_forward: btv must be in [1,16]");
+  dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
   if (bf16) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, s, a);
   LAUNCH_CHECK();
@@ -422,7 +458,8 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
 
 int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_backward: empty batch");
-  dim3 grid((a.B + BT - 1) / BT, 2, a.nmod);
+  if (a.btv < 1 || a.btv > BT) return set_error(MIMRL_ERR_ARG, "gru_backward: btv must be in [1,16]");
+  dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
   if (bf16) hipLaunchKernelGGL(gru_bwd_kernel<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gru_bwd_kernel<false>, grid, dim3(256), 0, s, a);
   LAUNCH_CHECK();
@@ -430,8 +467,16 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
 }
 
 long gru_saved_floats(int B, int T) {
-  const long ntile = (B + BT - 1) / BT;
-  return (long)T * ntile * 4 * 8 * 256;
+  return (long)T * B * 4 * 8 * 256;   // worst case: one batch row per workgroup (btv = 1)
+}
+
+int gru_pick_btv(int B, int nmod) {
+  static const int force = getenv("MIMRL_GRU_BTV") ? atoi(getenv("MIMRL_GRU_BTV")) : 0;   // tuning knob
+  if (force >= 1 && force <= BT) return force;
+  int btv = (B * nmod * 2 + 127) / 128;      // ~128 workgroups (measured best at B=128: 4 rows per workgroup)
+  if (btv < 1) btv = 1;
+  if (btv > BT) btv = BT;
+  return btv;
 }
 
 }  // namespace mimrl

@@ -107,22 +107,25 @@ def test_gru_layer_forward_backward(lib, B, T, ragged, prec):
     tol = 1e-5 if prec == 0 else 2e-2
     assert_close(out.cpu().numpy(), out_ref.detach().numpy(), tol, tol, "gru forward")
     dout = gsel.cuda()
-    dgx_f, dgx_r, dgh_f, dgh_r = (torch.full((B, T, G), float("nan"), device="cuda") for _ in range(4))
+    dg_f, dg_r = (torch.full((B, T, 4 * H), float("nan"), device="cuda") for _ in range(2))
     hp_f, hp_r = (torch.full((B, T, H), float("nan"), device="cuda") for _ in range(2))
     _lib.check(lib.mimrl_op_gru_backward(stream(), P(Wd["whh_f"]), P(Wd["whh_r"]), P(sv_f), P(sv_r), P(lens_d), P(out),
-                                         P(dout), P(dgx_f), P(dgx_r), P(dgh_f), P(dgh_r), P(hp_f), P(hp_r), B, T, prec))
+                                         P(dout), P(dg_f), P(dg_r), P(hp_f), P(hp_r), B, T, prec))
     torch.cuda.synchronize()
     rel = 2e-4 if prec == 0 else 4e-2
-    for tag, dgx, dgh, hp in (("f", dgx_f, dgh_f, hp_f), ("r", dgx_r, dgh_r, hp_r)):
-        dgx_n, dgh_n, hp_n = dgx.cpu().numpy().astype(np.float64), dgh.cpu().numpy().astype(np.float64), hp.cpu().numpy().astype(np.float64)
-        assert np.isfinite(dgx_n).all() and np.isfinite(dgh_n).all() and np.isfinite(hp_n).all()
+    dgx = {}
+    for tag, dg, hp in (("f", dg_f, hp_f), ("r", dg_r, hp_r)):
+        dg_n, hp_n = dg.cpu().numpy().astype(np.float64), hp.cpu().numpy().astype(np.float64)
+        assert np.isfinite(dg_n).all() and np.isfinite(hp_n).all()
+        dgx_n = dg_n[..., :G]                                           # [dr'|dz'|dn']
+        dgh_n = np.concatenate([dg_n[..., :2 * H], dg_n[..., 3 * H:]], -1)   # [dr'|dz'|dn'*r]
+        dgx[tag] = dgx_n
         x64 = x.reshape(B * T, -1).astype(np.float64)
         grad_close(dgx_n.reshape(B * T, G).T @ x64, Wt["wih_" + tag].grad.numpy(), rel, "dW_ih " + tag)
         grad_close(dgx_n.reshape(B * T, G).sum(0), Wt["bih_" + tag].grad.numpy(), rel, "db_ih " + tag)
         grad_close(dgh_n.reshape(B * T, G).T @ hp_n.reshape(B * T, H), Wt["whh_" + tag].grad.numpy(), rel, "dW_hh " + tag)
         grad_close(dgh_n.reshape(B * T, G).sum(0), Wt["bhh_" + tag].grad.numpy(), rel, "db_hh " + tag)
-    dx = dgx_f.cpu().numpy().astype(np.float64).reshape(B * T, G) @ W["wih_f"] + \
-        dgx_r.cpu().numpy().astype(np.float64).reshape(B * T, G) @ W["wih_r"]
+    dx = dgx["f"].reshape(B * T, G) @ W["wih_f"] + dgx["r"].reshape(B * T, G) @ W["wih_r"]
     grad_close(dx.reshape(B, T, -1), xt.grad.numpy(), rel, "dx")
 
 
