@@ -859,13 +859,22 @@ int mimrl_handle::model_backward() {
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
-    // weight gradients of this layer: off the critical path, spread over side 1..3 (joined at the very end)
-    MX(fork(1, 3));
+    // weight gradients of this layer: off the critical path.  Layer 1: side 1..3 (they overlap the layer-0 BPTT);
+    // layer 0 is the tail of the stage: all twelve GEMMs go out on six streams at once.
+    MX(fork(1, l == 0 ? 5 : 3));
+    int rr = 0;
     for (int m = 0; m < 2; ++m) {
       const float* in = l == 0 ? xin[m] : h0[m];
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
-        hipStream_t st = S(1 + (m * 2 + d) % 3);
+        hipStream_t st = l == 0 ? nullptr : S(1 + (m * 2 + d) % 3);
+        auto pick = [&]() { const int q = rr++ % 6; return q == 0 ? stream : S(q); };
+        if (l == 0) {
+          { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(pick(), q)); }
+          { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, hprev[l][m][d], H, Gm(g.w_hh), H, 2 * H, H, (int)BT_); q.atomic = 1; MX(G_on(pick(), q)); }
+          { GemmDesc q = gemm_tn(dg[l][m][d] + 3 * H, 4 * H, hprev[l][m][d], H, Gm(g.w_hh) + 2 * H * H, H, H, H, (int)BT_); q.atomic = 1; MX(G_on(pick(), q)); }
+          continue;
+        }
         // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H)
         { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
         { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, hprev[l][m][d], H, Gm(g.w_hh), H, 2 * H, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
@@ -882,7 +891,7 @@ int mimrl_handle::model_backward() {
         }
     }
   }
-  MX(join(0, 3));
+  MX(join(0, 5));
   return MIMRL_OK;
 }
 
