@@ -1,0 +1,384 @@
+// Fused CubeMLP block forward for gfx950 (see cube_fused.h).  bf16 MFMA operands, fp32 accumulation / LayerNorm.
+//
+// One workgroup (4 waves) per sample.  The sample tile x[L, K, 128] (<= 64 x 512) is loaded once into LDS as bf16 and
+// never leaves the CU until the block output is written:
+//   phase L : per 64-column slab of the tile (columns are independent under the L-axis contraction)
+//               U = W1.X + b1 ; H = act(U) ; Y = W2.H + Wr.X + b2 ; Z = LayerNorm over L  -> written back in place
+//             W1/W2/Wr live in LDS as MFMA A-images for the whole phase; X^T and H^T slabs are the B-images (the
+//             epilogue of the first product writes H directly in the layout the second product reads).
+//   phase K : the 3x3-class K-axis MLP + LayerNorm over K, elementwise per (l, d), in place.
+//   phase D : rows (l,k) x 128: H = act(Z W1^T + b1) ; Y = H W2^T + Z Wr^T + b2 ; LayerNorm over D.
+//             All row tiles (<= 3 x 64 rows) stay resident as A-images, so each 64x64 weight image is staged from
+//             L2 exactly once per workgroup (12 stagings per block).
+// Everything the (unfused) backward pass needs is written out in fp32 with the unfused path's layouts.
+#include "cube_fused.h"
+
+#include "kmix_device.h"
+
+namespace mimrl {
+
+namespace {
+
+constexpr int D = 128;
+constexpr int ILD = 72;                  // image row length (bf16): 64 + 8 -> 144-B rows, conflict-free ds_read_b128
+constexpr int IMG = 64 * ILD;            // elements per 64x64 image
+constexpr int CTL = 68, CTD = 132;       // fp32 staging tile row lengths
+
+typedef __bf16 bf;
+
+__device__ __forceinline__ void mma64(f32x16& acc, const bf* A, const bf* B, int wm, int wn, int lane) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (wm * 32 + (lane & 31)) * ILD + s * 16 + 8 * (lane >> 5));
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + (wn * 32 + (lane & 31)) * ILD + s * 16 + 8 * (lane >> 5));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ int acc_row(int r, int wm, int lane) { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// stage a 64(n) x 64(k) weight image  Bw[n][k] = W[(n0+n)*ld + k0 + k]  (fp32 global -> bf16 LDS), zero beyond (N, K)
+__device__ __forceinline__ void stage_weight(bf* img, const float* __restrict__ W, int ld, int n0, int k0, int N, int K, int tid) {
+  const int n = tid >> 2, kc = (tid & 3) * 16;
+  bf16x8 lo, hi;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int gn = n0 + n, gk = k0 + kc + j;
+    const float v = (gn < N && gk < K) ? W[(long)gn * ld + gk] : 0.f;
+    if (j < 8) lo[j] = to_bf16(v); else hi[j - 8] = to_bf16(v);
+  }
+  *reinterpret_cast<bf16x8*>(img + n * ILD + kc) = lo;
+  *reinterpret_cast<bf16x8*>(img + n * ILD + kc + 8) = hi;
+}
+// 128-wide row-major weights (D axis): a 64x64 image = 4 float4 per thread.  Split into issue (global -> registers)
+// and commit (registers -> bf16 LDS image) so that the next image's loads are in flight during the current MFMAs.
+struct WImg { float4 q0, q1, q2, q3; };
+__device__ __forceinline__ WImg load_weight128(const float* __restrict__ W, int n0, int k0, int tid) {
+  const int n = tid >> 2, kc = (tid & 3) * 16;
+  const float4* src = reinterpret_cast<const float4*>(W + (long)(n0 + n) * D + k0 + kc);
+  return WImg{src[0], src[1], src[2], src[3]};
+}
+__device__ __forceinline__ void commit_weight128(bf* img, const WImg& w, int tid) {
+  const int n = tid >> 2, kc = (tid & 3) * 16;
+  bf16x8 lo, hi;
+  lo[0] = to_bf16(w.q0.x); lo[1] = to_bf16(w.q0.y); lo[2] = to_bf16(w.q0.z); lo[3] = to_bf16(w.q0.w);
+  lo[4] = to_bf16(w.q1.x); lo[5] = to_bf16(w.q1.y); lo[6] = to_bf16(w.q1.z); lo[7] = to_bf16(w.q1.w);
+  hi[0] = to_bf16(w.q2.x); hi[1] = to_bf16(w.q2.y); hi[2] = to_bf16(w.q2.z); hi[3] = to_bf16(w.q2.w);
+  hi[4] = to_bf16(w.q3.x); hi[5] = to_bf16(w.q3.y); hi[6] = to_bf16(w.q3.z); hi[7] = to_bf16(w.q3.w);
+  *reinterpret_cast<bf16x8*>(img + n * ILD + kc) = lo;
+  *reinterpret_cast<bf16x8*>(img + n * ILD + kc + 8) = hi;
+}
+
+struct Carve {          // byte offsets into dynamic LDS (all multiples of 16)
+  int xm, aw, bx, bh, ctl, red, ksw;      // phases L / K
+  int bw, bw2, ctd, az, ah;               // phase D (aliases the L-phase regions; Xm is dead once Az is built)
+  int total;
+};
+__host__ __device__ inline Carve carve(int K, int nmt) {
+  Carve c;
+  const int C = K * D, XP = C + 8;
+  const int xm_bytes = 64 * XP * 2;
+  c.xm = 0;
+  c.aw = xm_bytes;
+  c.bx = c.aw + 3 * IMG * 2;
+  c.bh = c.bx + IMG * 2;
+  c.ctl = c.bh + IMG * 2;
+  c.red = c.ctl + 64 * CTL * 4;
+  c.ksw = c.red + 2 * 4 * 64 * 4;
+  const int l_end = c.ksw + 256 * 4;
+  c.bw = 0;
+  c.bw2 = c.bw + IMG * 2;
+  c.ctd = c.bw2 + IMG * 2;
+  int after = c.ctd + 64 * CTD * 4;
+  if (after < xm_bytes) after = xm_bytes;     // Az must not overlap Xm (it is built from it)
+  c.az = (after + 15) & ~15;
+  c.ah = c.az + nmt * 2 * IMG * 2;
+  const int d_end = c.ah + nmt * 2 * IMG * 2;
+  c.total = l_end > d_end ? l_end : d_end;
+  return c;
+}
+
+template <bool SAVE, int NMT>
+__global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x;
+  const int K = a.K, C = K * D, XP = C + 8, il = a.il, hl = a.hl, ol = a.ol;
+  const Carve cv = carve(K, NMT);
+  bf* Xm = reinterpret_cast<bf*>(smem + cv.xm);
+  bf* Aw = reinterpret_cast<bf*>(smem + cv.aw);
+  bf* Bx = reinterpret_cast<bf*>(smem + cv.bx);
+  bf* Bh = reinterpret_cast<bf*>(smem + cv.bh);
+  float* CtL = reinterpret_cast<float*>(smem + cv.ctl);
+  float* red = reinterpret_cast<float*>(smem + cv.red);
+  float* ksw = reinterpret_cast<float*>(smem + cv.ksw);
+
+  // ------------------------------------------------------------------ load the sample tile (bf16), zero-pad rows >= il
+  {
+    const float* xb = a.x + (long)b * il * C;
+    const int nq = C / 4;
+    for (int i = tid; i < 64 * nq; i += 256) {
+      const int l = i / nq, c4 = (i - l * nq) * 4;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l < il) q = *reinterpret_cast<const float4*>(xb + (long)l * C + c4);
+      bf16x4 p; p[0] = to_bf16(q.x); p[1] = to_bf16(q.y); p[2] = to_bf16(q.z); p[3] = to_bf16(q.w);
+      *reinterpret_cast<bf16x4*>(Xm + l * XP + c4) = p;
+    }
+    // L-axis weights as A-images [m][k], zero padded to 64x64
+    stage_weight(Aw + 0 * IMG, a.l_w1, il, 0, 0, hl, il, tid);
+    stage_weight(Aw + 1 * IMG, a.l_w2, hl, 0, 0, ol, hl, tid);
+    stage_weight(Aw + 2 * IMG, a.l_wr, il, 0, 0, ol, il, tid);
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ phase L: 64-column slabs
+  for (int n0 = 0; n0 < C; n0 += 64) {
+    {   // Bx[n][k] = X[k][n0+n]   (transpose within LDS; 16 consecutive k per thread -> two 16-byte stores)
+      const int n = tid & 63, kg = (tid >> 6) * 16;
+      bf16x8 lo, hi;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { lo[j] = Xm[(kg + j) * XP + n0 + n]; hi[j] = Xm[(kg + 8 + j) * XP + n0 + n]; }
+      *reinterpret_cast<bf16x8*>(Bx + n * ILD + kg) = lo;
+      *reinterpret_cast<bf16x8*>(Bx + n * ILD + kg + 8) = hi;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma64(acc, Aw + 0 * IMG, Bx, wm, wn, lane);
+    {   // U = acc + b1 ; H = act(U) -> Bh[n][m] (B-image of the second product), saved tensors to HBM
+      const int n = wn * 32 + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = acc_row(4 * g + q, wm, lane);
+          float h = 0.f;
+          if (m < hl) {
+            const float u = acc[4 * g + q] + (a.l_b1 ? a.l_b1[m] : 0.f);
+            h = act_apply(a.act, u);
+            if (SAVE) {
+              a.l_u[((long)b * hl + m) * C + n0 + n] = u;
+              a.l_h[((long)b * hl + m) * C + n0 + n] = h;
+            }
+          }
+          p[q] = to_bf16(h);
+        }
+        *reinterpret_cast<bf16x4*>(Bh + n * ILD + wm * 32 + 8 * g + 4 * (lane >> 5)) = p;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    mma64(acc, Aw + 1 * IMG, Bh, wm, wn, lane);     // W2 . H
+    mma64(acc, Aw + 2 * IMG, Bx, wm, wn, lane);     // + Wr . X
+    {
+      const int n = wn * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = acc_row(r, wm, lane);
+        CtL[m * CTL + n] = acc[r] + ((m < ol && a.l_b2) ? a.l_b2[m] : 0.f);
+      }
+    }
+    __syncthreads();
+    {   // LayerNorm over the L axis (rows m < ol) for each of the 64 columns; 4 threads per column, rows in registers
+      const int n = tid & 63, q = tid >> 6;
+      float yv[16];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {                         // 16 independent LDS reads (one round trip, not 16)
+        const int m = q + 4 * j;
+        yv[j] = m < ol ? CtL[m * CTL + n] : 0.f;
+        s += yv[j];
+      }
+      red[q * 64 + n] = s;
+      __syncthreads();
+      const float mu = (red[n] + red[64 + n] + red[128 + n] + red[192 + n]) / ol;
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { const float c = (q + 4 * j < ol) ? yv[j] - mu : 0.f; v += c * c; }
+      red[256 + q * 64 + n] = v;
+      __syncthreads();
+      const float rs = rsqrtf((red[256 + n] + red[320 + n] + red[384 + n] + red[448 + n]) / ol + LN_EPS);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int m = q + 4 * j;
+        if (m < ol) {
+          const float z = (yv[j] - mu) * rs * a.l_g[m] + a.l_be[m];
+          Xm[m * XP + n0 + n] = to_bf16(z);                     // in place: this slab's X columns are dead
+          if (SAVE) {
+            a.l_y[((long)b * ol + m) * C + n0 + n] = yv[j];
+            a.l_z[((long)b * ol + m) * C + n0 + n] = z;
+          }
+        }
+      }
+      if (SAVE && q == 0) { a.l_mean[(long)b * C + n0 + n] = mu; a.l_rstd[(long)b * C + n0 + n] = rs; }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ phase K: K-axis mix in place on rows l < ol
+  kmix_stage_weights(a.kw, ksw);
+  {
+    const float* g = ksw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
+    for (int i = tid; i < ol * D; i += 256) {
+      const int l = i >> 7, d = i & 127;
+      KMixVals<4> v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v.x[k] = k < K ? (float)Xm[l * XP + k * D + d] : 0.f; v.sc[k] = 1.f; }
+      kmix_forward_vals<4>(a.kw, ksw, v);
+      float out[4];
+      ln_small<4>(v.y, K, g, be, out, v.xh, v.mu, v.rs);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < K) {
+          Xm[l * XP + o * D + d] = to_bf16(out[o]);
+          if (SAVE) a.k_z[(((long)b * ol + l) * K + o) * D + d] = out[o];
+        }
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ phase D
+  const int R = ol * K;
+  bf* Bw = reinterpret_cast<bf*>(smem + cv.bw);
+  float* CtD = reinterpret_cast<float*>(smem + cv.ctd);
+  bf* Az = reinterpret_cast<bf*>(smem + cv.az);     // [NMT][2][64][ILD]   A-images of Z_k (k halves of d)
+  bf* Ah = reinterpret_cast<bf*>(smem + cv.ah);     // [NMT][2][64][ILD]   A-images of H
+  for (int c = tid; c < NMT * 64 * 16; c += 256) {   // 16-byte chunks: row r, chunk ch (8 d-values)
+    const int r = c >> 4, ch = c & 15;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = to_bf16(0.f);
+    if (r < R) {
+      const int l = r / K, kk = r - l * K;
+      v = *reinterpret_cast<const bf16x8*>(Xm + l * XP + kk * D + ch * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Az + ((r >> 6) * 2 + (ch >> 3)) * IMG + (r & 63) * ILD + (ch & 7) * 8) = v;
+  }
+  __syncthreads();   // Xm is dead from here on (Bw / CtD alias it)
+
+  f32x16 acc[NMT][2];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+  // The 12 weight images of this phase, in consumption order: W1 (nt,kh) x4, then W2 (nt,kh) x4, then Wr (nt,kh) x4.
+  // Image i+1 is requested from L2 before the MFMAs of image i (register prefetch), two LDS image buffers alternate.
+  auto wsrc = [&](int i) -> const float* { return i < 4 ? a.d_w1 : (i < 8 ? a.d_w2 : a.d_wr); };
+  bf* Bw2[2] = {Bw, reinterpret_cast<bf*>(smem + cv.bw2)};
+  WImg wnext = load_weight128(wsrc(0), 0, 0, tid);
+  // H = act(Z W1^T + b1): 4 weight images (nt, kh), each used by all row tiles
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nt = i >> 1, kh = i & 1;
+    commit_weight128(Bw2[i & 1], wnext, tid);
+    { const int j = i + 1; wnext = load_weight128(wsrc(j), ((j >> 1) & 1) * 64, (j & 1) * 64, tid); }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][nt], Az + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
+  }
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = wn * 32 + (lane & 31), col = nt * 64 + n;
+      const float b1 = a.d_b1 ? a.d_b1[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = acc_row(r, wm, lane), row = mt * 64 + m;
+        float h = 0.f;
+        if (row < R) {
+          const float u = acc[mt][nt][r] + b1;
+          h = act_apply(a.act, u);
+          if (SAVE) {
+            a.d_u[((long)b * R + row) * D + col] = u;
+            a.d_h[((long)b * R + row) * D + col] = h;
+          }
+        }
+        Ah[(mt * 2 + nt) * IMG + m * ILD + n] = to_bf16(h);     // A-image of the next product: k = this column
+        acc[mt][nt][r] = 0.f;
+      }
+    }
+  __syncthreads();
+  // Y = H W2^T + Z Wr^T + b2: 8 weight images
+#pragma unroll
+  for (int i = 4; i < 12; ++i) {
+    const int which = i >= 8, nt = (i >> 1) & 1, kh = i & 1;
+    commit_weight128(Bw2[i & 1], wnext, tid);
+    if (i + 1 < 12) { const int j = i + 1; wnext = load_weight128(wsrc(j), ((j >> 1) & 1) * 64, (j & 1) * 64, tid); }
+    __syncthreads();
+    const bf* Asrc = which == 0 ? Ah : Az;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][nt], Asrc + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
+  }
+  __syncthreads();
+  // LayerNorm over D per row, through an fp32 LDS tile
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int n = wn * 32 + (lane & 31), col = nt * 64 + n;
+      const float b2 = a.d_b2 ? a.d_b2[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) CtD[acc_row(r, wm, lane) * CTD + col] = acc[mt][nt][r] + b2;
+    }
+    __syncthreads();
+    for (int m = wave; m < 64; m += 4) {
+      const int row = mt * 64 + m;
+      if (row >= R) break;
+      const float y0 = CtD[m * CTD + lane], y1 = CtD[m * CTD + 64 + lane];
+      const float mu = wave_sum(y0 + y1) * (1.f / D);
+      const float c0 = y0 - mu, c1 = y1 - mu;
+      const float rs = rsqrtf(wave_sum(c0 * c0 + c1 * c1) * (1.f / D) + LN_EPS);
+      const long o = ((long)b * R + row) * D;
+      a.d_z[o + lane] = c0 * rs * a.d_g[lane] + a.d_be[lane];
+      a.d_z[o + 64 + lane] = c1 * rs * a.d_g[64 + lane] + a.d_be[64 + lane];
+      if (SAVE) {
+        a.d_y[o + lane] = y0; a.d_y[o + 64 + lane] = y1;
+        if (lane == 0) { a.d_mean[(long)b * R + row] = mu; a.d_rstd[(long)b * R + row] = rs; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool cube_fused_supported(int il, int hl, int ol, int ik, int hk, int ok, int id, int hd, int od, bool ln_first,
+                          bool res_project, bool bias, const float* dropout_mlp) {
+  (void)bias;
+  if (ln_first || !res_project) return false;
+  if (dropout_mlp[0] > 0.f || dropout_mlp[1] > 0.f || dropout_mlp[2] > 0.f) return false;
+  if (id != D || hd != D || od != D) return false;
+  if (il > 64 || hl > 64 || ol > 64 || il < 1 || hl < 1 || ol < 1) return false;
+  if (ik != hk || ik != ok || ik < 1 || ik > 4) return false;
+  if (ol * ok > 192) return false;
+  return true;
+}
+
+int cube_block_fwd_fused(hipStream_t s, const CubeFusedArgs& a) {
+  const int R = a.ol * a.K;
+  const int nmt = (R + 63) / 64;
+  if (nmt < 1 || nmt > 3) return set_error(MIMRL_ERR_ARG, "cube_fused: unsupported row count %d", R);
+  const Carve cv = carve(a.K, nmt);
+  if (cv.total > 160 * 1024) return set_error(MIMRL_ERR_ARG, "cube_fused: LDS budget exceeded (%d B)", cv.total);
+#define LAUNCH_FUSED(SAVE, NMT)                                                                                    \
+  do {                                                                                                             \
+    auto kern = cube_fwd_fused_kernel<SAVE, NMT>;                                                                  \
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, cv.total)); \
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), cv.total, s, a);                                                \
+  } while (0)
+  if (a.save) {
+    if (nmt == 1) LAUNCH_FUSED(true, 1); else if (nmt == 2) LAUNCH_FUSED(true, 2); else LAUNCH_FUSED(true, 3);
+  } else {
+    if (nmt == 1) LAUNCH_FUSED(false, 1); else if (nmt == 2) LAUNCH_FUSED(false, 2); else LAUNCH_FUSED(false, 3);
+  }
+#undef LAUNCH_FUSED
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+}  // namespace mimrl

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 
+#include "cube_fused.h"
 #include "estimator_ops.h"
 #include "gemm.h"
 #include "gru.h"
@@ -161,6 +162,7 @@ struct mimrl_handle {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   bool multi_stream = true;
+  bool fused_cube = true;              // bf16 mode: CubeMLP blocks as one LDS-resident kernel (MIMRL_NO_FUSED_CUBE=1 disables)
   int next_event(hipEvent_t* e) {
     if (ev_next == ev_pool.size()) {
       hipEvent_t n;
@@ -255,7 +257,7 @@ struct mimrl_handle {
 
   int G_(const GemmDesc& d) { return gemm(stream, d, bf16); }
   int model_forward(bool train, bool save, int knn_stage = 0);
-  int cube_forward(bool train);
+  int cube_forward(bool train, bool save);
   int cube_backward(int cur_in, int* cur_out);
   int model_backward();
   struct StreamGuard {   // route every launch of a scope to another stream
@@ -530,7 +532,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
                         pdrop[1 + m], key(), 1 + m));
   // T_F, A_F, V_F (Model.py:466)
   MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
-  { Scope sc(this, MIMRL_PH_CUBE_FWD); MX(cube_forward(train)); }
+  { Scope sc(this, MIMRL_PH_CUBE_FWD); MX(cube_forward(train, save)); }
   // head (Model.py:489-515)
   const BlockBuf& last = bb[cfg.n_blocks - 1];
   const int ol = cfg.d_outs[cfg.n_blocks - 1][0], ok = cfg.d_outs[cfg.n_blocks - 1][1], od = cfg.d_outs[cfg.n_blocks - 1][2];
@@ -541,16 +543,45 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
   return MIMRL_OK;
 }
 
-int mimrl_handle::cube_forward(bool train) {
+int mimrl_handle::cube_forward(bool train, bool save) {
   const int B = cfg.batch;
   const float* x = cube0;
   int il = cfg.time_len, ik = 3, id = cfg.d_common;
+  const bool no_fused = !fused_cube;
   for (int i = 0; i < cfg.n_blocks; ++i) {
     const BlockW& w = blk[i];
     BlockBuf& b = bb[i];
     const int hl = w.ax[0].hid, ol = w.ax[0].out, hk = w.ax[1].hid, ok = w.ax[1].out, hd = w.ax[2].hid, od = w.ax[2].out;
     const float pl = train ? cfg.dropout_mlp[0] : 0.f, pk = train ? cfg.dropout_mlp[1] : 0.f,
                 pd = train ? cfg.dropout_mlp[2] : 0.f;
+    const float pmlp[3] = {pl, pk, pd};
+    // bf16 mode: the whole block as ONE kernel with the sample tile resident in LDS (cube_fused.hip)
+    if (bf16 && !no_fused &&
+        cube_fused_supported(il, hl, ol, ik, hk, ok, id, hd, od, cfg.ln_first != 0, cfg.res_project[i] != 0, cfg.bias != 0, pmlp)) {
+      CubeFusedArgs fa;
+      std::memset(&fa, 0, sizeof fa);
+      auto PB = [&](long off) -> const float* { return off >= 0 ? P(off) : nullptr; };
+      fa.x = x;
+      fa.l_w1 = P(w.ax[0].fc1.w); fa.l_b1 = PB(w.ax[0].fc1.b); fa.l_w2 = P(w.ax[0].fc2.w); fa.l_b2 = PB(w.ax[0].fc2.b);
+      fa.l_wr = P(w.ax[0].res); fa.l_g = P(w.ax[0].ln_g); fa.l_be = P(w.ax[0].ln_b);
+      fa.kw.w1 = P(w.ax[1].fc1.w); fa.kw.b1 = PB(w.ax[1].fc1.b); fa.kw.w2 = P(w.ax[1].fc2.w); fa.kw.b2 = PB(w.ax[1].fc2.b);
+      fa.kw.wr = P(w.ax[1].res); fa.kw.g = P(w.ax[1].ln_g); fa.kw.be = P(w.ax[1].ln_b);
+      fa.kw.ik = ik; fa.kw.hk = hk; fa.kw.ok = ok; fa.kw.act = cfg.activation; fa.kw.ln_first = 0; fa.kw.drop_p = 0.f;
+      fa.kw.key = key(); fa.kw.stream_id = 0;
+      fa.d_w1 = P(w.ax[2].fc1.w); fa.d_b1 = PB(w.ax[2].fc1.b); fa.d_w2 = P(w.ax[2].fc2.w); fa.d_b2 = PB(w.ax[2].fc2.b);
+      fa.d_wr = P(w.ax[2].res); fa.d_g = P(w.ax[2].ln_g); fa.d_be = P(w.ax[2].ln_b);
+      if (save) {
+        fa.l_u = b.l.u; fa.l_h = b.l.h; fa.l_y = b.l.y; fa.l_z = b.l.z; fa.l_mean = b.l.mean; fa.l_rstd = b.l.rstd;
+        fa.k_z = b.k.z;
+        fa.d_u = b.d.u; fa.d_h = b.d.h; fa.d_y = b.d.y; fa.d_mean = b.d.mean; fa.d_rstd = b.d.rstd;
+      }
+      fa.d_z = b.d.z;
+      fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.K = ik; fa.act = cfg.activation; fa.save = save ? 1 : 0;
+      MX(cube_block_fwd_fused(stream, fa));
+      x = b.d.z;
+      il = ol; ik = ok; id = od;
+      continue;
+    }
     // ------------------------------------------------ L axis (MLPProcess.py:95-104 / 65-74)
     {
       const AxisW& a = w.ax[0];
@@ -1262,6 +1293,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   if (h->cfg.adam_eps == 0.f) h->cfg.adam_eps = 1e-8f;
   h->stream = h->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
   h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
+  h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
   h->prec = cfg->precision;

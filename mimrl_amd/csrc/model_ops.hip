@@ -1,17 +1,11 @@
 // Non-GEMM kernels of the model forward/backward (see model_ops.h for the reference citations).
 #include "model_ops.h"
 
+#include "kmix_device.h"
+
 namespace mimrl {
 
 namespace {
-
-constexpr float LN_EPS = 1e-6f;   // every LayerNorm of the model uses eps=1e-6 (Model.py:260, MLPProcess.py:35-41)
-
-__device__ __forceinline__ float drop_scale(float p, const RngKey& key, uint32_t stream, uint32_t idx) {
-  if (p <= 0.f) return 1.f;
-  const float u = uniform01(key.seed_lo, key.seed_hi, stream, (uint32_t)*key.step, idx);
-  return u >= p ? 1.f / (1.f - p) : 0.f;
-}
 
 // ------------------------------------------------------------------ lengths
 __global__ void seq_lengths_kernel(const float* __restrict__ x, int T, int d, int* __restrict__ lens) {
@@ -281,69 +275,6 @@ __global__ void colln_bwd_kernel(const float* __restrict__ y, const float* __res
 // ------------------------------------------------------------------ K-axis mix, fused (thread per (row, d))
 // Sizes are template parameters (NK = max(ik,hk,ok) rounded to {4,8}) so that every per-thread array lives in
 // registers and every loop unrolls; runtime sizes only mask the tails.
-constexpr int KM = 8;   // max size of any K-axis dimension
-
-template <int NK>
-struct KMixVals {
-  float x[NK], xn[NK], u[NK], h[NK], y[NK], xh[NK], sc[NK];   // sc: dropout scale of the MLP branch per output
-  float mu, rs;
-};
-
-template <int NK>
-__device__ __forceinline__ void ln_small(const float* v, int n, const float* g, const float* be, float* out, float* xh,
-                                         float& mu, float& rs) {
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NK; ++i) s += i < n ? v[i] : 0.f;
-  mu = s / n;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NK; ++i) { const float c = i < n ? v[i] - mu : 0.f; q += c * c; }
-  rs = rsqrtf(q / n + LN_EPS);
-#pragma unroll
-  for (int i = 0; i < NK; ++i) { xh[i] = i < n ? (v[i] - mu) * rs : 0.f; out[i] = xh[i] * g[i] + be[i]; }
-}
-
-// sw: LDS copy of [w1 | b1 | w2 | b2 | wr | g | be] with row stride KM (missing pieces zero / identity)
-template <int NK>
-__device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* sw, KMixVals<NK>& v) {
-  const float* w1 = sw; const float* b1 = w1 + KM * KM; const float* w2 = b1 + KM; const float* b2 = w2 + KM * KM;
-  const float* wr = b2 + KM; const float* g = wr + KM * KM; const float* be = g + KM;
-  if (w.ln_first) ln_small<NK>(v.x, w.ik, g, be, v.xn, v.xh, v.mu, v.rs);
-#pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    float s = b1[j];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) s += w1[j * KM + k] * (w.ln_first ? v.xn[k] : v.x[k]);   // padded weights are zero
-    v.u[j] = s; v.h[j] = j < w.hk ? act_apply(w.act, s) : 0.f;
-  }
-#pragma unroll
-  for (int o = 0; o < NK; ++o) {
-    float s = b2[o], rr = 0.f;
-#pragma unroll
-    for (int j = 0; j < NK; ++j) s += w2[o * KM + j] * v.h[j];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) rr += wr[o * KM + k] * v.x[k];
-    v.y[o] = v.sc[o] * s + rr;
-  }
-}
-
-__device__ __forceinline__ void kmix_stage_weights(const KMixW& w, float* sw) {
-  for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sw[i] = 0.f;
-  __syncthreads();
-  float* w1 = sw; float* b1 = w1 + KM * KM; float* w2 = b1 + KM; float* b2 = w2 + KM * KM;
-  float* wr = b2 + KM; float* g = wr + KM * KM; float* be = g + KM;
-  const int t = threadIdx.x;
-  if (t < w.hk * w.ik) w1[(t / w.ik) * KM + t % w.ik] = w.w1[t];
-  if (t < w.hk && w.b1) b1[t] = w.b1[t];
-  if (t < w.ok * w.hk) w2[(t / w.hk) * KM + t % w.hk] = w.w2[t];
-  if (t < w.ok && w.b2) b2[t] = w.b2[t];
-  if (t < w.ok * w.ik) wr[(t / w.ik) * KM + t % w.ik] = w.wr ? w.wr[t] : ((t / w.ik) == (t % w.ik) ? 1.f : 0.f);
-  const int nln = w.ln_first ? w.ik : w.ok;
-  if (t < nln) { g[t] = w.g[t]; be[t] = w.be[t]; }
-  __syncthreads();
-}
-
 template <int NK>
 __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__ x, float* __restrict__ z, KMixW w,
                                                        long R, int D) {

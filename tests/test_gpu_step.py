@@ -172,3 +172,37 @@ def test_bf16_mode_tracks_fp32():
         va, vb = res["fp32"][i], res["bf16"][i]
         cos = float(va @ vb / (np.linalg.norm(va) * np.linalg.norm(vb)))
         assert cos > 0.9, f"bf16 {nm} gradient direction: cosine {cos}"
+
+
+@pytest.mark.parametrize("name", ["tiny_sep", "cfg1_sep"])
+def test_fused_cube_forward_matches_unfused(name, monkeypatch):
+    """bf16 mode: the LDS-resident fused CubeMLP block kernel (cube_fused.hip) against the unfused GEMM/LN/K-mix chain
+    in the same precision mode: forward outputs, every loss / MI term and the whole main-bucket gradient (the fused
+    kernel also produces the saved activations the backward consumes)."""
+    res = {}
+    for tag, env in (("fused", None), ("unfused", "1")):
+        if env:
+            monkeypatch.setenv("MIMRL_NO_FUSED_CUBE", env)
+        else:
+            monkeypatch.delenv("MIMRL_NO_FUSED_CUBE", raising=False)
+        c, opt, batch, banks, p, eng = make_engine(name, precision="bf16")
+        g = load_golden(name)
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(1, g["anchors"][0, 0])
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.stage_grads(1)
+        eng.stage_grads(2)
+        torch.cuda.synchronize()
+        res[tag] = (eng.read_scalars().copy(), eng.feats.cpu().numpy().copy(), eng.pred.cpu().numpy().copy(),
+                    eng.main["g"].double().cpu().numpy().copy())
+        eng.close()
+    (sa, fa, pa, ga), (sb, fb, pb, gb) = res["fused"], res["unfused"]
+    # the fused kernel keeps the inter-mix activations as bf16 in LDS: ~1 % of the activation scale
+    assert_close(pa, pb, 3e-2, 1e-2, "pred")
+    assert_close(fa[0], fb[0], 3e-2, 1e-2, "F_F")
+    assert_close(fa[1:], fb[1:], 1e-6, 1e-7, "T_F/A_F/V_F do not pass through CubeMLP")
+    assert_close(sa[_lib.S1_LOSS], sb[_lib.S1_LOSS], 1e-2, 1e-3, "stage-1 loss")
+    assert_close(sa[_lib.S2_LOSS], sb[_lib.S2_LOSS], 1e-2, 1e-3, "stage-2 loss")
+    assert_close(sa[_lib.S2_MIS:_lib.S2_MIS + 8], sb[_lib.S2_MIS:_lib.S2_MIS + 8], 2e-2, 2e-2, "MI terms")
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    assert cos > 0.98, f"main gradient direction fused vs unfused: cosine {cos}"
