@@ -17,6 +17,7 @@ struct CubeFusedArgs {
   float *d_u, *d_h, *d_y, *d_mean, *d_rstd;                    // [B*ol*K, 128] x3, [B*ol*K] x2
   float* d_z;                                                  // block output [B, ol, K, 128]
   int B, il, hl, ol, K, act, save;
+  int dbg_phase;                                               // tuning only: stop after phase n (0 = run everything)
 };
 
 // true if this block's configuration is covered by the fused kernel (else the engine uses the unfused path)

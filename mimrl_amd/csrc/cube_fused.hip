@@ -69,8 +69,8 @@ __device__ __forceinline__ void commit_weight128(bf* img, const WImg& w, int tid
 }
 
 struct Carve {          // byte offsets into dynamic LDS (all multiples of 16)
-  int xm, aw, bx, bh, ctl, red, ksw;      // phases L / K
-  int bw, bw2, ctd, az, ah;               // phase D (aliases the L-phase regions; Xm is dead once Az is built)
+  int xm, aw, bx, bh, ctl, red, ksw, prm; // phases L / K
+  int bw, bw2, ctd, dprm, az, ah;         // phase D (aliases the L-phase regions; Xm is dead once Az is built)
   int total;
 };
 __host__ __device__ inline Carve carve(int K, int nmt) {
@@ -84,11 +84,13 @@ __host__ __device__ inline Carve carve(int K, int nmt) {
   c.ctl = c.bh + IMG * 2;
   c.red = c.ctl + 64 * CTL * 4;
   c.ksw = c.red + 2 * 4 * 64 * 4;
-  const int l_end = c.ksw + 256 * 4;
+  c.prm = c.ksw + 256 * 4;
+  const int l_end = c.prm + 4 * 64 * 4;
   c.bw = 0;
   c.bw2 = c.bw + IMG * 2;
   c.ctd = c.bw2 + IMG * 2;
-  int after = c.ctd + 64 * CTD * 4;
+  c.dprm = c.ctd + 64 * CTD * 4;
+  int after = c.dprm + 2 * D * 4;
   if (after < xm_bytes) after = xm_bytes;     // Az must not overlap Xm (it is built from it)
   c.az = (after + 15) & ~15;
   c.ah = c.az + nmt * 2 * IMG * 2;
@@ -111,17 +113,36 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   float* CtL = reinterpret_cast<float*>(smem + cv.ctl);
   float* red = reinterpret_cast<float*>(smem + cv.red);
   float* ksw = reinterpret_cast<float*>(smem + cv.ksw);
+  float* prm = reinterpret_cast<float*>(smem + cv.prm);   // [4][64] L-axis b1, b2, gamma, beta
 
   // ------------------------------------------------------------------ load the sample tile (bf16), zero-pad rows >= il
   {
     const float* xb = a.x + (long)b * il * C;
-    const int nq = C / 4;
-    for (int i = tid; i < 64 * nq; i += 256) {
-      const int l = i / nq, c4 = (i - l * nq) * 4;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (l < il) q = *reinterpret_cast<const float4*>(xb + (long)l * C + c4);
-      bf16x4 p; p[0] = to_bf16(q.x); p[1] = to_bf16(q.y); p[2] = to_bf16(q.z); p[3] = to_bf16(q.w);
-      *reinterpret_cast<bf16x4*>(Xm + l * XP + c4) = p;
+    const int nq = C / 4, total = 64 * nq;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {          // 8 independent 16-byte loads in flight per thread
+      float4 q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 256 * j;
+        const int l = i / nq, c4 = (i - l * nq) * 4;
+        q[j] = (i < total && l < il) ? *reinterpret_cast<const float4*>(xb + (long)l * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 256 * j;
+        if (i < total) {
+          const int l = i / nq, c4 = (i - l * nq) * 4;
+          bf16x4 p; p[0] = to_bf16(q[j].x); p[1] = to_bf16(q[j].y); p[2] = to_bf16(q[j].z); p[3] = to_bf16(q[j].w);
+          *reinterpret_cast<bf16x4*>(Xm + l * XP + c4) = p;
+        }
+      }
+    }
+    // small per-row / per-column parameters -> LDS once (they sit on the critical path of every epilogue otherwise)
+    if (tid < 64) {
+      prm[0 * 64 + tid] = (tid < hl && a.l_b1) ? a.l_b1[tid] : 0.f;
+      prm[1 * 64 + tid] = (tid < ol && a.l_b2) ? a.l_b2[tid] : 0.f;
+      prm[2 * 64 + tid] = tid < ol ? a.l_g[tid] : 0.f;
+      prm[3 * 64 + tid] = tid < ol ? a.l_be[tid] : 0.f;
     }
     // L-axis weights as A-images [m][k], zero padded to 64x64
     stage_weight(Aw + 0 * IMG, a.l_w1, il, 0, 0, hl, il, tid);
@@ -129,6 +150,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     stage_weight(Aw + 2 * IMG, a.l_wr, il, 0, 0, ol, il, tid);
   }
   __syncthreads();
+  if (a.dbg_phase == 1) return;
 
   // ------------------------------------------------------------------ phase L: 64-column slabs
   for (int n0 = 0; n0 < C; n0 += 64) {
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
           const int m = acc_row(4 * g + q, wm, lane);
           float h = 0.f;
           if (m < hl) {
-            const float u = acc[4 * g + q] + (a.l_b1 ? a.l_b1[m] : 0.f);
+            const float u = acc[4 * g + q] + prm[m];
             h = act_apply(a.act, u);
             if (SAVE) {
               a.l_u[((long)b * hl + m) * C + n0 + n] = u;
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = acc_row(r, wm, lane);
-        CtL[m * CTL + n] = acc[r] + ((m < ol && a.l_b2) ? a.l_b2[m] : 0.f);
+        CtL[m * CTL + n] = acc[r] + prm[64 + m];
       }
     }
     __syncthreads();
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
       for (int j = 0; j < 16; ++j) {
         const int m = q + 4 * j;
         if (m < ol) {
-          const float z = (yv[j] - mu) * rs * a.l_g[m] + a.l_be[m];
+          const float z = (yv[j] - mu) * rs * prm[128 + m] + prm[192 + m];
           Xm[m * XP + n0 + n] = to_bf16(z);                     // in place: this slab's X columns are dead
           if (SAVE) {
             a.l_y[((long)b * ol + m) * C + n0 + n] = yv[j];
@@ -217,6 +239,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     __syncthreads();
   }
 
+  if (a.dbg_phase == 2) return;
   // ------------------------------------------------------------------ phase K: K-axis mix in place on rows l < ol
   kmix_stage_weights(a.kw, ksw);
   {
@@ -239,10 +262,13 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   }
   __syncthreads();
 
+  if (a.dbg_phase == 3) return;
   // ------------------------------------------------------------------ phase D
   const int R = ol * K;
   bf* Bw = reinterpret_cast<bf*>(smem + cv.bw);
   float* CtD = reinterpret_cast<float*>(smem + cv.ctd);
+  float* dgam = reinterpret_cast<float*>(smem + cv.dprm);   // D-axis LayerNorm gain / bias (staged after Xm died)
+  float* dbet = dgam + D;
   bf* Az = reinterpret_cast<bf*>(smem + cv.az);     // [NMT][2][64][ILD]   A-images of Z_k (k halves of d)
   bf* Ah = reinterpret_cast<bf*>(smem + cv.ah);     // [NMT][2][64][ILD]   A-images of H
   for (int c = tid; c < NMT * 64 * 16; c += 256) {   // 16-byte chunks: row r, chunk ch (8 d-values)
@@ -257,6 +283,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     *reinterpret_cast<bf16x8*>(Az + ((r >> 6) * 2 + (ch >> 3)) * IMG + (r & 63) * ILD + (ch & 7) * 8) = v;
   }
   __syncthreads();   // Xm is dead from here on (Bw / CtD alias it)
+  if (tid < D) { dgam[tid] = a.d_g[tid]; dbet[tid] = a.d_be[tid]; }   // visible after the barriers of the GEMM loops
 
   f32x16 acc[NMT][2];
 #pragma unroll
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
       }
     }
   __syncthreads();
+  if (a.dbg_phase == 4) return;
   // Y = H W2^T + Z Wr^T + b2: 8 weight images
 #pragma unroll
   for (int i = 4; i < 12; ++i) {
@@ -315,6 +343,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][nt], Asrc + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
   }
   __syncthreads();
+  if (a.dbg_phase == 5) return;
   // LayerNorm over D per row, through an fp32 LDS tile
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
@@ -326,19 +355,37 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
       for (int r = 0; r < 16; ++r) CtD[acc_row(r, wm, lane) * CTD + col] = acc[mt][nt][r] + b2;
     }
     __syncthreads();
-    for (int m = wave; m < 64; m += 4) {
-      const int row = mt * 64 + m;
-      if (row >= R) break;
-      const float y0 = CtD[m * CTD + lane], y1 = CtD[m * CTD + 64 + lane];
-      const float mu = wave_sum(y0 + y1) * (1.f / D);
-      const float c0 = y0 - mu, c1 = y1 - mu;
-      const float rs = rsqrtf(wave_sum(c0 * c0 + c1 * c1) * (1.f / D) + LN_EPS);
-      const long o = ((long)b * R + row) * D;
-      a.d_z[o + lane] = c0 * rs * a.d_g[lane] + a.d_be[lane];
-      a.d_z[o + 64 + lane] = c1 * rs * a.d_g[64 + lane] + a.d_be[64 + lane];
-      if (SAVE) {
-        a.d_y[o + lane] = y0; a.d_y[o + 64 + lane] = y1;
-        if (lane == 0) { a.d_mean[(long)b * R + row] = mu; a.d_rstd[(long)b * R + row] = rs; }
+    {   // 4 threads per row, 32 columns each (two 2-step reductions instead of two 6-step wave reductions per row)
+      const int m = tid >> 2, part = tid & 3, row = mt * 64 + m;
+      float yv[32];
+      float s0 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(&CtD[m * CTD + part * 32 + 4 * j]);
+        yv[4 * j] = q.x; yv[4 * j + 1] = q.y; yv[4 * j + 2] = q.z; yv[4 * j + 3] = q.w;
+        s0 += (q.x + q.y) + (q.z + q.w);
+      }
+      s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+      const float mu = s0 * (1.f / D);
+      float v0 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) { const float c = yv[j] - mu; v0 += c * c; }
+      v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64);
+      const float rs = rsqrtf(v0 * (1.f / D) + LN_EPS);
+      if (row < R) {
+        const long o = ((long)b * R + row) * D + part * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = part * 32 + 4 * j;
+          float4 z;
+          z.x = (yv[4 * j] - mu) * rs * dgam[c] + dbet[c];
+          z.y = (yv[4 * j + 1] - mu) * rs * dgam[c + 1] + dbet[c + 1];
+          z.z = (yv[4 * j + 2] - mu) * rs * dgam[c + 2] + dbet[c + 2];
+          z.w = (yv[4 * j + 3] - mu) * rs * dgam[c + 3] + dbet[c + 3];
+          *reinterpret_cast<float4*>(a.d_z + o + 4 * j) = z;
+          if (SAVE) *reinterpret_cast<float4*>(a.d_y + o + 4 * j) = make_float4(yv[4 * j], yv[4 * j + 1], yv[4 * j + 2], yv[4 * j + 3]);
+        }
+        if (SAVE && part == 0) { a.d_mean[(long)b * R + row] = mu; a.d_rstd[(long)b * R + row] = rs; }
       }
     }
     __syncthreads();

@@ -576,7 +576,9 @@ int mimrl_handle::cube_forward(bool train, bool save) {
         fa.d_u = b.d.u; fa.d_h = b.d.h; fa.d_y = b.d.y; fa.d_mean = b.d.mean; fa.d_rstd = b.d.rstd;
       }
       fa.d_z = b.d.z;
+      fa.dbg_phase = getenv("MIMRL_CUBE_PHASE") ? atoi(getenv("MIMRL_CUBE_PHASE")) : 0;
       fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.K = ik; fa.act = cfg.activation; fa.save = save ? 1 : 0;
+      if (fa.dbg_phase == 100) { fa.save = 0; fa.dbg_phase = 0; }   // timing-only: skip the saved-activation stores
       MX(cube_block_fwd_fused(stream, fa));
       x = b.d.z;
       il = ol; ik = ok; id = od;

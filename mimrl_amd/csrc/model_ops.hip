@@ -188,33 +188,43 @@ __global__ void rowln_fwd_kernel(const float* __restrict__ y, const float* __res
     for (int j = lane; j < n; j += 64) z[r * n + j] = (yr[j] - mu) * rs * gamma[j] + beta[j];
   }
 }
+template <int PER>   // n <= 64*PER; lane owns columns lane + 64*i for the whole kernel -> dgamma/dbeta accumulate in registers
 __global__ void rowln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                  const float* __restrict__ dz, float* __restrict__ dy, float* __restrict__ dgamma,
                                  float* __restrict__ dbeta, long R, int n) {
-  extern __shared__ float sh[];   // [2n]
+  __shared__ float sh[2 * 64 * PER];
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * 64 * PER; i += blockDim.x) sh[i] = 0.f;
   __syncthreads();
+  float gam[PER], ag[PER], ab[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const int j = lane + 64 * i; gam[i] = j < n ? gamma[j] : 0.f; ag[i] = 0.f; ab[i] = 0.f; }
   const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
   for (long r = wid; r < R; r += nwv) {
     const float mu = mean[r], rs = rstd[r];
-    float s1 = 0.f, s2 = 0.f;
-    for (int j = lane; j < n; j += 64) {
-      const float xh = (y[r * n + j] - mu) * rs, g = dz[r * n + j];
-      const float dxh = g * gamma[j];
-      s1 += dxh; s2 += dxh * xh;
-      atomicAdd(&sh[j], g * xh);
-      atomicAdd(&sh[n + j], g);
+    float xh[PER], g[PER], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = lane + 64 * i;
+      const bool ok = j < n;
+      xh[i] = ok ? (y[r * n + j] - mu) * rs : 0.f;
+      g[i] = ok ? dz[r * n + j] : 0.f;
+      const float dxh = g[i] * gam[i];
+      s1 += dxh; s2 += dxh * xh[i];
+      ag[i] += g[i] * xh[i]; ab[i] += g[i];
     }
     s1 = wave_sum(s1) / n; s2 = wave_sum(s2) / n;
-    for (int j = lane; j < n; j += 64) {
-      const float xh = (y[r * n + j] - mu) * rs;
-      dy[r * n + j] = rs * (dz[r * n + j] * gamma[j] - s1 - xh * s2);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = lane + 64 * i;
+      if (j < n) dy[r * n + j] = rs * (g[i] * gam[i] - s1 - xh[i] * s2);
     }
   }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { atomicAdd(&sh[lane + 64 * i], ag[i]); atomicAdd(&sh[64 * PER + lane + 64 * i], ab[i]); }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) { atomicAdd(&dgamma[i], sh[i]); atomicAdd(&dbeta[i], sh[n + i]); }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) { atomicAdd(&dgamma[j], sh[j]); atomicAdd(&dbeta[j], sh[64 * PER + j]); }
 }
 
 // ------------------------------------------------------------------ column LayerNorm (thread per (b,c))
@@ -240,36 +250,39 @@ __global__ void colln_bwd_kernel(const float* __restrict__ y, const float* __res
                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                  const float* __restrict__ dz, float* __restrict__ dy, float* __restrict__ dgamma,
                                  float* __restrict__ dbeta, int B, int n, int C) {
-  extern __shared__ float sh[];   // [2n]
-  for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) sh[i] = 0.f;
+  extern __shared__ float sh[];   // [2][n][64] per-lane partial sums of dgamma / dbeta (ds_add_f32, conflict-free)
+  for (int i = threadIdx.x; i < 2 * n * 64; i += blockDim.x) sh[i] = 0.f;
   __syncthreads();
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const bool ok = i < (long)B * C;
-  const long b = ok ? i / C : 0;
-  const int c = ok ? i % C : 0;
-  const float* yb = y + b * n * C + c;
-  const float* dzb = dz + b * n * C + c;
-  const float mu = ok ? mean[i] : 0.f, rs = ok ? rstd[i] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
   const int lane = threadIdx.x & 63;
-  for (int l = 0; l < n; ++l) {
-    float g = 0.f, xh = 0.f;
-    if (ok) { g = dzb[(long)l * C]; xh = (yb[(long)l * C] - mu) * rs; }
-    const float dxh = g * gamma[l];
-    s1 += dxh; s2 += dxh * xh;
-    const float a = wave_sum(g * xh), bb = wave_sum(g);
-    if (lane == 0) { atomicAdd(&sh[l], a); atomicAdd(&sh[n + l], bb); }
-  }
   if (ok) {
-    s1 /= n; s2 /= n;
+    const long b = i / C;
+    const int c = i % C;
+    const float* yb = y + b * n * C + c;
+    const float* dzb = dz + b * n * C + c;
     float* dyb = dy + b * n * C + c;
+    const float mu = mean[i], rs = rstd[i];
+    float s1 = 0.f, s2 = 0.f;
+    for (int l = 0; l < n; ++l) {
+      const float g = dzb[(long)l * C], xh = (yb[(long)l * C] - mu) * rs;
+      const float dxh = g * gamma[l];
+      s1 += dxh; s2 += dxh * xh;
+      atomicAdd(&sh[l * 64 + lane], g * xh);
+      atomicAdd(&sh[(n + l) * 64 + lane], g);
+    }
+    s1 /= n; s2 /= n;
     for (int l = 0; l < n; ++l) {
       const float xh = (yb[(long)l * C] - mu) * rs;
       dyb[(long)l * C] = rs * (dzb[(long)l * C] * gamma[l] - s1 - xh * s2);
     }
   }
   __syncthreads();
-  for (int l = threadIdx.x; l < n; l += blockDim.x) { atomicAdd(&dgamma[l], sh[l]); atomicAdd(&dbeta[l], sh[n + l]); }
+  for (int q = threadIdx.x; q < 2 * n; q += blockDim.x) {
+    float t = 0.f;
+    for (int j = 0; j < 64; ++j) t += sh[q * 64 + ((j + q) & 63)];
+    atomicAdd(q < n ? &dgamma[q] : &dbeta[q - n], t);
+  }
 }
 
 // ------------------------------------------------------------------ K-axis mix, fused (thread per (row, d))
@@ -549,8 +562,13 @@ int rowln_fwd(hipStream_t s, const float* y, const float* gamma, const float* be
 }
 int rowln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
               float* dy, float* dgamma, float* dbeta, long R, int n) {
-  hipLaunchKernelGGL(rowln_bwd_kernel, dim3(grid_for(R * 64, 256, 256)), dim3(256), 2 * n * sizeof(float), s, y, gamma,
-                     mean, rstd, dz, dy, dgamma, dbeta, R, n);
+  if (n > 512) return set_error(MIMRL_ERR_ARG, "rowln_bwd: row length %d > 512", n);
+  if (n <= 128)
+    hipLaunchKernelGGL(rowln_bwd_kernel<2>, dim3(grid_for(R * 64, 256, 512)), dim3(256), 0, s, y, gamma, mean, rstd, dz, dy,
+                       dgamma, dbeta, R, n);
+  else
+    hipLaunchKernelGGL(rowln_bwd_kernel<8>, dim3(grid_for(R * 64, 256, 512)), dim3(256), 0, s, y, gamma, mean, rstd, dz, dy,
+                       dgamma, dbeta, R, n);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -564,7 +582,8 @@ int colln_fwd(hipStream_t s, const float* y, const float* gamma, const float* be
 int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
               float* dy, float* dgamma, float* dbeta, int B, int n, int C) {
   const long tot = (long)B * C;
-  hipLaunchKernelGGL(colln_bwd_kernel, dim3((tot + 255) / 256), dim3(256), 2 * n * sizeof(float), s, y, gamma, mean,
+  if (n > 64) return set_error(MIMRL_ERR_ARG, "colln_bwd: axis length %d > 64", n);
+  hipLaunchKernelGGL(colln_bwd_kernel, dim3((tot + 255) / 256), dim3(256), 2 * n * 64 * sizeof(float), s, y, gamma, mean,
                      rstd, dz, dy, dgamma, dbeta, B, n, C);
   LAUNCH_CHECK();
   return MIMRL_OK;
