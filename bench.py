@@ -222,13 +222,15 @@ def main():
     if rank == 0:
         ms = 1e3 * wall / args.steps
         out = {
-            "metric": "two-stage train iters/sec", "value": world * args.steps / wall if False else args.steps / wall,
+            "metric": "two-stage train iters/sec", "value": world * args.steps / wall,
             "unit": "two-stage iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if _lib.PREC[args.precision] else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: MOSI-shaped synthetic triples B={B}/rank T={T} d=768/74/35, gru, "
                                    f"d_common=128, CubeMLP 50-3-128=10-3-128, {opt.critic_type} InfoNCE critics, kNN-CMI k=2, "
                                    f"banks N={N}, Adam lr 4e-3, dropout 0.1",
+                       "unit_definition": "one iter = stage-1 + stage-2 update over one B=128 batch; under weak-scaling DP every "
+                                          "global step processes n_gpus such batches (gradients all-reduced), so value = n_gpus*steps/time",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
                        "precision": args.precision, "hipgraph": not args.no_graph, "samples_per_sec": B * world * args.steps / wall},
             "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,

@@ -493,12 +493,12 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
   const int dmod[2] = {cfg.d_a, cfg.d_v};
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
   if (T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
-  MX(fork(0, 3));
+  MX(fork(0, 5));
   // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
   { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
   MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
-  // lengths (Model.py:425-432)
-  for (int m = 0; m < 2; ++m) MX(seq_lengths(stream, xin[m], B, T, dmod[m], lens[m]));
+  // lengths (Model.py:425-432): only the recurrence needs them -> sides 4/5, next to the input projections
+  for (int m = 0; m < 2; ++m) MX(seq_lengths(S(4 + m), xin[m], B, T, dmod[m], lens[m]));
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
@@ -518,7 +518,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
       }
     }
-    MX(join(1, 3));
+    MX(join(1, l == 0 ? 5 : 3));
     if (l == 0 && knn_stage) {   // the kNN sampler needs only banks + anchors: overlap it with the recurrence (32 of 256 CUs busy)
       MX(fork(4, 4));
       MX(knn_launch(knn_stage, S(4)));
@@ -915,13 +915,15 @@ int mimrl_handle::model_backward() {
       }
     }
     if (l == 1) {   // critical path: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
-      for (int m = 0; m < 2; ++m)
-        for (int d = 0; d < 2; ++d) {
-          const GruDirW& g = gru[m][l][d];
-          GemmDesc q = gemm_nn(dg[l][m][d], 4 * H, P(g.w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
-          q.beta = d == 0 ? 0.f : 1.f;
-          MX(G_(q));
-        }
+      // one dual-product GEMM per modality (both directions accumulate in the same output tile); video on side 4
+      MX(fork(4, 4));
+      for (int m = 0; m < 2; ++m) {
+        GemmDesc q = gemm_nn(dg[l][m][0], 4 * H, P(gru[m][l][0].w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
+        q.A2 = dg[l][m][1]; q.sa2_m = 4 * H; q.sa2_k = 1;
+        q.B2 = P(gru[m][l][1].w_ih); q.sb2_k = 2 * H; q.sb2_n = 1; q.K2 = G;
+        MX(G_on(m == 0 ? stream : S(4), q));
+      }
+      MX(join(4, 4));
     }
   }
   MX(join(0, 5));
