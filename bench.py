@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 from mimrl_amd import _lib, dist as mdist, synth  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                               # HBM3E peak, MI355X_MICROARCH.md
 _T0 = time.time()
 
 
@@ -204,16 +205,33 @@ def main():
         phases = {k: {"ms_per_step": v[0] / args.profile_steps, "launch_groups_per_step": v[1] / args.profile_steps}
                   for k, v in pr.items() if v[1]}
         phases["eager_total_ms_per_step"] = eager_ms
-        # dominant kernel: the persistent bi-GRU recurrence (forward: 4 launches/step, BPTT: 2 launches/step)
+        # dominant single kernel: the persistent bi-GRU recurrence (one launch per layer; 4 forward launches per step, 2 of
+        # them also save the gates for BPTT).  Which roofline binds it?  Per launch it moves 66 MB (>= 8 us at 8 TB/s) and
+        # does 2.5 GFLOP (1 us at the bf16 MFMA peak): HBM is the nearer ceiling, so that is the one reported; the MFMA
+        # figures ride along as extra keys.  What actually limits it is the serial dependence of T cell steps.
+        gru_bf16 = bool(_lib.PREC[args.precision] & 4)
         fl = 2 * 2 * B * T * (H * 3 * H) * 2.0          # 2 modalities x 2 directions, [B,T] x (128 x 384) MACs
-        kname = "gru_fwd" if pr["gru_fwd"][0] >= pr["gru_bwd"][0] else "gru_bwd"
-        avg_ms = pr[kname][0] / max(pr[kname][1], 1)
-        peak = PEAK_TFLOPS["bf16" if _lib.PREC[args.precision] & (4 if kname == "gru_fwd" else 8) else "fp32"]
-        ach = fl / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"{kname}_kernel (persistent bi-GRU recurrence, one launch per layer)",
-                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "avg_launch_ms": avg_ms, "flops_per_launch": fl,
-                "share_of_step": pr[kname][0] / args.profile_steps / eager_ms}
+        gate_bytes = 2 if gru_bf16 else 4
+        alg_bytes = (4 * B * T * 3 * H * 4             # gx[B,T,384] fp32 per (modality, direction): read
+                     + 4 * (3 * H * H + 3 * H) * 4     # W_hh, b_hh
+                     + 2 * B * T * 2 * H * 4           # h[B,T,256] per modality: written
+                     + 0.5 * 4 * B * T * 4 * H * gate_bytes)   # saved gates (r,z,n,hn), on the 2 of 4 launches that train
+        avg_ms = pr["gru_fwd"][0] / max(pr["gru_fwd"][1], 1)
+        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes (separate runs), committed
+        if os.path.exists(pmc) and args.workload == "cfg2" and args.precision == "bf16":
+            k = json.load(open(pmc))["kernels"].get("gru_fwd_kernel<true>")
+            traffic = k and k["traffic_bytes_per_launch"]
+        roof = {"bound": "hbm", "kernel": "gru_fwd_kernel (persistent bi-GRU recurrence, one launch per layer)",
+                "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), bytes per launch",
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                "mfma": {"flops_per_launch": fl, "achieved_tflops": fl / (avg_ms * 1e-3) / 1e12,
+                         "peak_tflops": PEAK_TFLOPS["bf16" if gru_bf16 else "fp32"],
+                         "frac": fl / (avg_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16" if gru_bf16 else "fp32"]},
+                "serial_cell_steps_per_launch": T, "us_per_cell_step": 1e3 * avg_ms / T,
+                "share_of_step": pr["gru_fwd"][0] / args.profile_steps / eager_ms}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -152,7 +152,8 @@ struct mimrl_handle {
   // backward temporaries
   float *dfeat = nullptr, *dtout = nullptr, *dta[2], *dtin = nullptr, *dca[2], *dP = nullptr, *dQ = nullptr;
   float *dcc[2], *dcin = nullptr;
-  float* gbuf[4];
+  static constexpr int NGBUF = 16;   // cube backward: rotating (4 in use) or one-shot (deferred weight gradients)
+  float* gbuf[NGBUF];
   size_t gbuf_floats = 0;
   float *dtx = nullptr, *ds[2], *dg[2][2][2], *hprev[2][2][2], *dh0[2];   // [layer][mod][dir]; dg = [dr'|dz'|dn'|dn'r] rows of 4H
 
@@ -255,7 +256,12 @@ struct mimrl_handle {
   }
   int carve();
 
-  int G_(const GemmDesc& d) { return gemm(stream, d, bf16); }
+  int G_(const GemmDesc& d) { return G_on(stream, d); }
+  // weight-gradient work parked by cube_backward and issued on the side streams once the data-gradient chain is through
+  // (it then overlaps the latency-bound GRU BPTT instead of competing with the chain for CUs and L2)
+  struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst; };
+  std::vector<Deferred> deferred;
+  int flush_deferred();
   int model_forward(bool train, bool save, int knn_stage = 0);
   int cube_forward(bool train, bool save);
   int cube_backward(int cur_in, int* cur_out);
@@ -443,7 +449,7 @@ int mimrl_handle::carve() {
   MX(take(&mi_raw, 8)); MX(take(&cmi_raw, 8)); MX(take(&bce_raw, 8));
   MX(take(&dfeat, 4 * B * D));
   gbuf_floats = gmax;
-  for (int i = 0; i < 4; ++i) MX(take(&gbuf[i], gmax));
+  for (int i = 0; i < NGBUF; ++i) MX(take(&gbuf[i], gmax));
   MX(take(&dtx, BT_ * D));
   for (int m = 0; m < 2; ++m) {
     MX(take(&ds[m], BT_ * H));
@@ -678,11 +684,29 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   dims[0][0] = cfg.time_len; dims[0][1] = 3; dims[0][2] = cfg.d_common;
   for (int i = 0; i < cfg.n_blocks; ++i)
     for (int ax = 0; ax < 3; ++ax) dims[i + 1][ax] = cfg.d_outs[i][ax];
-  int used[4] = {0, 0, 0, 0};
+  // deferred mode: every gradient buffer is used once (weight-gradient GEMMs read dY / dU after the chain has moved on)
+  static const bool no_defer = getenv("MIMRL_NO_DEFER_WGRAD") != nullptr;   // tuning knob
+  const bool defer = multi_stream && !cfg.ln_first && !no_defer && 7 * cfg.n_blocks + 1 <= NGBUF;
+  const int npool = defer ? NGBUF : 4;
+  int used[NGBUF] = {0};
   used[cur_in] = 1;
   int cur = cur_in;
-  auto grab = [&]() { for (int q = 0; q < 4; ++q) if (!used[q]) { used[q] = 1; return q; } return -1; };
-  auto release = [&](int q) { used[q] = 0; };
+  auto grab = [&]() { for (int q = 0; q < npool; ++q) if (!used[q]) { used[q] = 1; return q; } return -1; };
+  auto release = [&](int q) { if (!defer) used[q] = 0; };
+  auto W_gemm = [&](int sd, const GemmDesc& g) -> int {
+    if (defer) { deferred.push_back(Deferred{0, sd, g, nullptr, 0, 0, 0, 0, nullptr}); return MIMRL_OK; }
+    return G_on(S(sd), g);
+  };
+  auto W_colsum = [&](int sd, const float* src, long rows, int cols, int ld, float* dst) -> int {
+    if (defer) { deferred.push_back(Deferred{1, sd, GemmDesc(), src, rows, cols, ld, 0, dst}); return MIMRL_OK; }
+    return colsum(S(sd), src, rows, cols, ld, dst);
+  };
+  auto W_rowsum = [&](int sd, const float* src, int nb, int rows, int cols, float* dst) -> int {
+    if (defer) { deferred.push_back(Deferred{2, sd, GemmDesc(), src, nb, rows, cols, 0, dst}); return MIMRL_OK; }
+    return rowsum_batched(S(sd), src, nb, rows, cols, dst);
+  };
+  auto W_fork = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : fork(lo, hi); };
+  auto W_join = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : join(lo, hi); };
 #define GRAB(var)                                                                                   \
   const int var = grab();                                                                           \
   if (var < 0) return set_error(MIMRL_ERR_STATE, "cube_backward: out of gradient buffers (line %d)", __LINE__)
@@ -716,16 +740,16 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         i_dym = q;
       }
       const float* dym = gbuf[i_dym];
-      MX(fork(1, 2));                                        // weight gradients leave the critical path
-      { GemmDesc g = gemm_tn(dym, od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(G_on(S(1), g)); }
-      if (a.fc2.b >= 0) MX(colsum(S(1), dym, R2, od, od, Gm(a.fc2.b)));
-      if (a.res >= 0) { GemmDesc g = gemm_tn(dy, od, xin, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(G_on(S(2), g)); }
+      MX(W_fork(1, 2));                                      // weight gradients leave the critical path
+      { GemmDesc g = gemm_tn(dym, od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(W_gemm(1, g)); }
+      if (a.fc2.b >= 0) MX(W_colsum(1, dym, R2, od, od, Gm(a.fc2.b)));
+      if (a.res >= 0) { GemmDesc g = gemm_tn(dy, od, xin, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(W_gemm(2, g)); }
       GRAB(i_du);                                            // dU = (dYm . W2) * act'(U)
       { GemmDesc g = gemm_nn(dym, od, P(a.fc2.w), hd, gbuf[i_du], hd, (int)R2, hd, od); g.act = cfg.activation; g.gradact_u = b.d.u;
         if (a.fc1.b >= 0) g.colsum = Gm(a.fc1.b);     // db1 = column sums of dU, fused into the epilogue
         MX(G_(g)); }
-      MX(fork(3, 3));
-      { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(G_on(S(3), g)); }
+      MX(W_fork(3, 3));
+      { GemmDesc g = gemm_tn(gbuf[i_du], hd, xmlp, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(W_gemm(3, g)); }
       GRAB(i_dx0);
       int i_dx = i_dx0;
       const bool fuse_dx = a.res >= 0 && !cfg.ln_first;        // dX = dU.W1 + dY.Wr in ONE launch
@@ -744,7 +768,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         if (a.res >= 0) { GemmDesc g = gemm_nn(dy, od, P(a.res), id, gbuf[i_dx], id, (int)R2, id, od); g.beta = 1.f; MX(G_(g)); }
         else MX(add_inplace(stream, gbuf[i_dx], dy, R2 * id));
       }
-      MX(join(1, 3));                                        // side streams are done with dy / dym / dU before they are recycled
+      MX(W_join(1, 3));                                      // side streams are done with dy / dym / dU before they are recycled
       if (i_dym != i_dy) release(i_dym);
       release(i_dy);
       cur = i_dx;
@@ -789,17 +813,17 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       }
       const float* dym = gbuf[i_dym];
       // dW2[ol,hl] += sum_b dYm_b[ol,C] . H_b[hl,C]^T
-      MX(fork(1, 2));
+      MX(W_fork(1, 2));
       { GemmDesc g; g.A = dym; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;
         g.B = b.l.h; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)hl * C;
         g.C = Gm(a.fc2.w); g.sc_m = hl; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = hl; g.K = (int)C; g.batch = B; g.atomic = 1;
-        MX(G_on(S(1), g)); }
-      if (a.fc2.b >= 0) MX(rowsum_batched(S(1), dym, B, ol, (int)C, Gm(a.fc2.b)));
+        MX(W_gemm(1, g)); }
+      if (a.fc2.b >= 0) MX(W_rowsum(1, dym, B, ol, (int)C, Gm(a.fc2.b)));
       if (a.res >= 0) {
         GemmDesc g; g.A = dy; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;
         g.B = xblk; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
         g.C = Gm(a.res); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
-        MX(G_on(S(2), g));
+        MX(W_gemm(2, g));
       }
       GRAB(i_du);                                            // dU_b[hl,C] = (W2^T . dYm_b) * act'(U)
       { GemmDesc g; g.A = P(a.fc2.w); g.sa_m = 1; g.sa_k = hl; g.sa_b = 0;
@@ -807,12 +831,12 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         g.C = gbuf[i_du]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)hl * C; g.M = hl; g.N = (int)C; g.K = ol; g.batch = B;
         g.act = cfg.activation; g.gradact_u = b.l.u;
         MX(G_(g)); }
-      MX(fork(3, 3));
+      MX(W_fork(3, 3));
       { GemmDesc g; g.A = gbuf[i_du]; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)hl * C;
         g.B = xmlp; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
         g.C = Gm(a.fc1.w); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = hl; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
-        MX(G_on(S(3), g)); }
-      if (a.fc1.b >= 0) MX(rowsum_batched(S(3), gbuf[i_du], B, hl, (int)C, Gm(a.fc1.b)));
+        MX(W_gemm(3, g)); }
+      if (a.fc1.b >= 0) MX(W_rowsum(3, gbuf[i_du], B, hl, (int)C, Gm(a.fc1.b)));
       GRAB(i_dx0);                                           // dX_b[il,C] = W1^T . dU_b (+LN-first bwd) + Wr^T . dY_b
       int i_dx = i_dx0;
       { GemmDesc g; g.A = P(a.fc1.w); g.sa_m = 1; g.sa_k = il; g.sa_b = 0;
@@ -841,7 +865,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       } else {
         MX(add_inplace(stream, gbuf[i_dx], dy, (long)B * il * C));
       }
-      MX(join(1, 3));
+      MX(W_join(1, 3));
       if (i_dym != i_dy) release(i_dym);
       release(i_dy);
       cur = i_dx;
@@ -849,6 +873,19 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   }
 #undef GRAB
   *cur_out = cur;
+  return MIMRL_OK;
+}
+
+int mimrl_handle::flush_deferred() {
+  if (deferred.empty()) return MIMRL_OK;
+  MX(fork(1, 3));
+  for (const Deferred& d : deferred) {
+    hipStream_t st = S(d.side);
+    if (d.kind == 0) MX(G_on(st, d.g));
+    else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
+    else MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
+  }
+  deferred.clear();
   return MIMRL_OK;
 }
 
@@ -864,6 +901,7 @@ int mimrl_handle::model_backward() {
   MX(head_bwd(stream, dfeat, dpred, P(cls_w), bufs.feats, gbuf[0], Gm(cls_w), Gm(cls_b), B, ol, ok, od,
               cfg.compose_t_sum, cfg.compose_k_sum));
   int ci = 0;
+  deferred.clear();
   { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
   float* dcube = gbuf[ci];
   // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T
@@ -876,6 +914,7 @@ int mimrl_handle::model_backward() {
   for (int m = 0; m < 2; ++m)
     MX(ln_relu_drop_bwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dcube, ds[m], Gm(ln_g[m]),
                         Gm(ln_b[m]), B, T, L, 3, D, 1 + m, cfg.dropout[1 + m], key(), 1 + m));
+  MX(flush_deferred());   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT
   const float* xin[2] = {bufs.audio, bufs.video};
   for (int l = 1; l >= 0; --l) {
     GruBwdArgs a;

@@ -50,6 +50,13 @@ inline GemmDesc gemm_tn(const float* A, long lda, const float* Bm, long ldb, flo
   return d;
 }
 
+struct GemmPlan {
+  int variant;        // 0 fp32 generic, 1 bf16 generic (BK 32), 2 bf16 lean BK 64, 3 bf16 lean BK 128
+  int nsplit;         // split-K factor (partials are combined with float atomics)
+  int kt_per;         // k-tiles per split
+  long tiles;         // output tiles (64x64) incl. batch
+};
+void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p);
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
 
 }  // namespace mimrl

@@ -37,6 +37,7 @@ struct KernelArgs {
   int ksplit;       // grid.z = batch * ksplit
   int kt_per;       // k-tiles per split (single-segment GEMMs only)
   int vec_a, vec_b, vec_a2, vec_b2;   // operand may use the 16-byte path (alignment / stride conditions hold)
+  int xcd_remap;
 };
 
 // one operand of one product segment (workgroup-uniform)
@@ -72,7 +73,10 @@ __device__ __forceinline__ void load_tile(const Operand& o, int K, int k0, int t
       int row, k;
       M::vec(o.kfast, tid, h, row, k);
       const int gk = k0 + k;
-      const float* src = o.P + (long)(o.r0 + row) * o.s_r + (long)gk * o.s_k;
+      // k-contiguous operands may have a ragged last tile: rows beyond R are clamped (their products land in output
+      // rows/columns the epilogue never stores)
+      const int gr = (LEAN && o.kfast) ? (o.r0 + row < o.R ? o.r0 + row : o.R - 1) : o.r0 + row;
+      const float* src = o.P + (long)gr * o.s_r + (long)gk * o.s_k;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
       if (o.kfast) {
         if (gk + 3 < K) q = *reinterpret_cast<const float4*>(src);
@@ -144,6 +148,33 @@ __device__ __forceinline__ void store_tile(const Operand& o, int tid, const floa
   }
 }
 
+// epilogue of one 32x32 accumulator tile: lane holds column n, 16 rows (mbase + MFMA row pattern)
+__device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, const f32x16& acc, int mbase, int n, int lane) {
+  if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
+  float* __restrict__ C = d.C + (long)bz * d.sc_b;
+  const float bn = d.bias_n ? d.bias_n[(long)bz * d.bias_n_b + n] : 0.f;
+  float csum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m >= d.M) continue;
+    const long off = (long)m * d.sc_m + (long)n * d.sc_n;
+    float v = d.alpha * acc[r] + bn;
+    if (d.bias_m) v += d.bias_m[(long)bz * d.bias_m_b + m];
+    if (d.beta != 0.f) v += d.beta * C[off];
+    if (d.pre) d.pre[(long)bz * d.sc_b + off] = v;
+    if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[(long)bz * d.sc_b + off]);
+    else v = act_apply(d.act, v);
+    if (atomic) atomicAdd(&C[off], v);
+    else C[off] = v;
+    csum += v;
+  }
+  if (d.colsum) {   // fused bias gradient: lanes l and l^32 hold the same column
+    csum += __shfl_xor(csum, 32, 64);
+    if (lane < 32) atomicAdd(&d.colsum[(long)bz * d.colsum_b + n], csum);
+  }
+}
+
 template <bool BF16, int BK, bool LEAN>
 __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   const GemmDesc& d = ka.d;
@@ -151,8 +182,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   __shared__ __attribute__((aligned(16))) Smem<BF16, BK> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bz = blockIdx.z / ka.ksplit, ks = blockIdx.z - bz * ka.ksplit;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so linear ids that
+  // are equal mod 8 share an L2.  Re-deal the ids so that one XCD owns whole slices of the slowest grid axis: all
+  // column tiles of a row block (they re-read the same activation rows), all tiles of one split-K chunk / batch entry.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bzr = blockIdx.z;
+  if (ka.xcd_remap) {
+    const unsigned nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    const unsigned lin = (bzr * ny + by) * nx + bx, xcd = lin & 7u, idx = lin >> 3;
+    if (nz > 1) {
+      const unsigned per = nx * ny;
+      if (lin < per * (nz & ~7u)) { bzr = (idx / per) * 8 + xcd; const unsigned r = idx % per; by = r / nx; bx = r % nx; }
+    } else if (lin < nx * (ny & ~7u)) {
+      by = (idx / nx) * 8 + xcd; bx = idx % nx;
+    }
+  }
+  const int bz = bzr / ka.ksplit, ks = bzr - bz * ka.ksplit;
+  const int m0 = by * BM, n0 = bx * BN;
   const bool full_m = m0 + BM <= d.M, full_n = n0 + BN <= d.N;
 
   f32x16 acc;
@@ -207,32 +252,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     segment(d.A2 + (long)bz * d.sa2_b, d.sa2_m, d.sa2_k, d.B2 + (long)bz * d.sb2_b, d.sb2_k, d.sb2_n, d.K2, ka.vec_a2, ka.vec_b2,
             0, (d.K2 + BK - 1) / BK);
 
-  // epilogue: lane holds column n, 16 rows
-  const int n = n0 + wn * 32 + (lane & 31);
-  if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
-  float* __restrict__ C = d.C + (long)bz * d.sc_b;
-  const bool atomic = d.atomic || ka.ksplit > 1;
-  const float bn = d.bias_n ? d.bias_n[(long)bz * d.bias_n_b + n] : 0.f;
-  float csum = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m >= d.M) continue;
-    const long off = (long)m * d.sc_m + (long)n * d.sc_n;
-    float v = d.alpha * acc[r] + bn;
-    if (d.bias_m) v += d.bias_m[(long)bz * d.bias_m_b + m];
-    if (d.beta != 0.f) v += d.beta * C[off];
-    if (d.pre) d.pre[(long)bz * d.sc_b + off] = v;
-    if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[(long)bz * d.sc_b + off]);
-    else v = act_apply(d.act, v);
-    if (atomic) atomicAdd(&C[off], v);
-    else C[off] = v;
-    csum += v;
-  }
-  if (d.colsum) {   // fused bias gradient: lanes l and l^32 hold the same column
-    csum += __shfl_xor(csum, 32, 64);
-    if (lane < 32) atomicAdd(&d.colsum[(long)bz * d.colsum_b + n], csum);
-  }
+  epilogue(d, d.atomic || ka.ksplit > 1, bz, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -246,42 +266,61 @@ inline bool vec_ok_b(const float* P, long s_k, long s_n, long s_b) {
 
 }  // namespace
 
+void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
+  static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knobs
+  static const int no_big = getenv("MIMRL_GEMM_NO_BK128") != nullptr;
+  const bool va = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b), vb = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b);
+  const bool va2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : true, vb2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : true;
+  // lean = 16-byte loads only.  Ragged M / N are fine for k-contiguous operands (rows are clamped in the loader).
+  const bool a_kfast = d.sa_k == 1 && (!d.A2 || d.sa2_k == 1), b_kfast = d.sb_k == 1 && d.sb_n != 1 && (!d.B2 || (d.sb2_k == 1 && d.sb2_n != 1));
+  static const int no_ragged = getenv("MIMRL_GEMM_NO_RAGGED") != nullptr;
+  const bool lean = bf16 && !no_lean && (d.M % BM == 0 || (a_kfast && !no_ragged)) && (d.N % BN == 0 || (b_kfast && !no_ragged)) &&
+                    va && vb && va2 && vb2 && d.K >= 64;
+  const long tiles = (long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
+  // small grids gain nothing from occupancy: stage 128 k-values per round trip (one-shot for K <= 128)
+  const bool lean128 = lean && !no_big && tiles <= 256 && d.K >= 128 && (!d.A2 || d.K2 >= 64);
+  p->variant = !bf16 ? 0 : lean128 ? 3 : lean ? 2 : 1;
+  const int BKh = lean128 ? 128 : (lean ? 64 : 32);
+  const int ktiles = (d.K + BKh - 1) / BKh;
+  const bool plain_acc = !d.A2 && d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum &&
+                         d.act == ACT_NONE;
+  p->nsplit = 1; p->kt_per = ktiles; p->tiles = tiles;
+  if (plain_acc && ktiles >= 8) {
+    // accumulate-into-zeroed-output GEMMs (weight gradients): split K until the grid has ~2 waves of workgroups
+    int ksplit = (int)((512 + tiles - 1) / tiles);
+    if (ksplit > ktiles / 4) ksplit = ktiles / 4;
+    if (ksplit < 1) ksplit = 1;
+    p->nsplit = ksplit;
+    p->kt_per = (ktiles + ksplit - 1) / ksplit;
+  }
+}
+
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return MIMRL_OK;
+  static const int dbg_skip = getenv("MIMRL_DBG_SKIP_WGRAD") ? atoi(getenv("MIMRL_DBG_SKIP_WGRAD")) : 0;   // timing experiments only
+  if (dbg_skip && d.atomic && (dbg_skip == 1 || (dbg_skip == 2 && d.batch > 1 && d.sc_b == 0))) return MIMRL_OK;
   if (!d.A || !d.B || !d.C) return set_error(MIMRL_ERR_ARG, "gemm: null operand");
   if ((d.A2 != nullptr) != (d.B2 != nullptr)) return set_error(MIMRL_ERR_ARG, "gemm: second product needs both operands");
+  GemmPlan pl;
+  gemm_plan(d, bf16, &pl);
   KernelArgs ka;
   ka.d = d;
   ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b);
   ka.vec_b = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b);
   ka.vec_a2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : 1;
   ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
-  static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knob
-  const bool lean = bf16 && !no_lean && d.M % BM == 0 && d.N % BN == 0 && ka.vec_a && ka.vec_b && ka.vec_a2 && ka.vec_b2 &&
-                    d.K >= 64;
-  // small grids gain nothing from occupancy: stage 128 k-values per round trip (one-shot for K <= 128)
-  const int tiles_all = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
-  static const int no_big = getenv("MIMRL_GEMM_NO_BK128") != nullptr;   // tuning knob
-  const bool lean128 = lean && !no_big && tiles_all <= 256 && d.K >= 128 && (!d.A2 || d.K2 >= 64);
-  const int BKh = lean128 ? 128 : (lean ? 64 : 32);
-  const int tiles = ((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
-  const int ktiles = (d.K + BKh - 1) / BKh;
-  int ksplit = 1;
-  if (!d.A2 && d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum &&
-      d.act == ACT_NONE && ktiles >= 8) {
-    // accumulate-into-zeroed-output GEMMs (weight gradients): split K until the grid has ~2 waves of workgroups
-    ksplit = (512 + tiles - 1) / tiles;
-    if (ksplit > ktiles / 4) ksplit = ktiles / 4;
-    if (ksplit < 1) ksplit = 1;
-  }
-  ka.ksplit = ksplit;
-  ka.kt_per = (ktiles + ksplit - 1) / ksplit;
-  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * ksplit);
+  static const int no_xcd = getenv("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
+  ka.xcd_remap = !no_xcd;
+  ka.ksplit = pl.nsplit;
+  ka.kt_per = pl.kt_per;
+  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * pl.nsplit);
   if (grid.y > 65535 || grid.z > 65535) return set_error(MIMRL_ERR_ARG, "gemm: grid too large (M=%d batch=%d)", d.M, d.batch);
-  if (!bf16) hipLaunchKernelGGL((gemm_kernel<false, 32, false>), grid, dim3(256), 0, s, ka);
-  else if (lean128) hipLaunchKernelGGL((gemm_kernel<true, 128, true>), grid, dim3(256), 0, s, ka);
-  else if (lean) hipLaunchKernelGGL((gemm_kernel<true, 64, true>), grid, dim3(256), 0, s, ka);
-  else hipLaunchKernelGGL((gemm_kernel<true, 32, false>), grid, dim3(256), 0, s, ka);
+  switch (pl.variant) {
+    case 0: hipLaunchKernelGGL((gemm_kernel<false, 32, false>), grid, dim3(256), 0, s, ka); break;
+    case 3: hipLaunchKernelGGL((gemm_kernel<true, 128, true>), grid, dim3(256), 0, s, ka); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<true, 64, true>), grid, dim3(256), 0, s, ka); break;
+    default: hipLaunchKernelGGL((gemm_kernel<true, 32, false>), grid, dim3(256), 0, s, ka); break;
+  }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
