@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=sorted(_lib.PREC))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="run the two stages strictly one after the other")
     ap.add_argument("--profile-steps", type=int, default=20)
     args = ap.parse_args()
 
@@ -147,6 +148,10 @@ def main():
     eng.set_batch(*synth.synthetic_batch(B, T, seed=rank))                       # rank-local batch, resident in HBM
     banks = synth.synthetic_banks(N, seed=0)
     eng.set_banks(*(banks[k] for k in "CFTAV"))
+
+    # Solver.step() mode: both stages work on the same batch, so the stage-2 forward pass is issued beside stage 1
+    # (same arithmetic and results as the sequential order; tests/test_gpu_step.py::test_stage2_prefetch_matches_sequential)
+    eng.set_stage2_prefetch(not args.no_prefetch)
 
     def step():
         if world > 1:
@@ -250,7 +255,7 @@ def main():
                        "unit_definition": "one iter = stage-1 + stage-2 update over one B=128 batch; under weak-scaling DP every "
                                           "global step processes n_gpus such batches (gradients all-reduced), so value = n_gpus*steps/time",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "precision": args.precision, "hipgraph": not args.no_graph, "samples_per_sec": B * world * args.steps / wall},
+                       "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch, "samples_per_sec": B * world * args.steps / wall},
             "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,
             "achieved_tflops_whole_step": world * algorithmic_flops(opt, N) / (wall / args.steps) / 1e12,
             "roofline": roof, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,

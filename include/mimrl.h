@@ -111,6 +111,14 @@ int mimrl_stage_grads(mimrl_handle* h, int stage);     /* forward+backward only 
 int mimrl_stage_apply(mimrl_handle* h, int stage);     /* value-clip + Adam on that stage's bucket         */
 int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses);  /* Solver.evaluate body (Solver.py:255-258) */
 int mimrl_estimate(mimrl_handle* h, int stage);        /* estimators only, on the features of the last forward (Model.py:305/343) */
+/* Overlap mode for Solver.step() (one stage-1 + one stage-2 update on ONE batch).  When on,
+ * mimrl_stage1_step / mimrl_stage_grads(1) also run the stage-2 Model.forward (Model.py:388-519) of the bound batch on
+ * a second stream -- legal because stage 1 (Solver.py:205-214) only updates critic parameters -- and the next
+ * mimrl_stage2_step / mimrl_stage_grads(2) consumes it instead of running its own (Solver.py:221).  Results are the
+ * same as in sequential mode (same parameters, inputs and dropout key).  Contract: between the two calls the caller
+ * must not modify the bound inputs or main parameters; a stage-2 call without a preceding stage-1 call fails with
+ * MIMRL_ERR_STATE.  Ignored while the banks are empty (epoch-0 rule). */
+int mimrl_set_stage2_prefetch(mimrl_handle* h, int on);
 int64_t mimrl_workspace_bytes(const mimrl_handle* h);
 /* phase profiler: HIP events on the engine's stream around each phase of the eager (non-graph) path */
 enum { MIMRL_PH_GEMM_MISC = 0, MIMRL_PH_GRU_FWD, MIMRL_PH_GRU_BWD, MIMRL_PH_CUBE_FWD, MIMRL_PH_CUBE_BWD, MIMRL_PH_EST_FWD,

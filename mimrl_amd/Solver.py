@@ -95,8 +95,16 @@ class Solver:
         s = self.engine.scalars
         return s[_lib.S2_LOSS], s[_lib.S2_MIS:_lib.S2_MIS + 8], self.engine.pred.reshape(-1, 1)
 
+    def _prefetch(self, on):
+        if getattr(self, "_prefetch_on", False) != on:
+            self.engine.set_stage2_prefetch(on)
+            self._prefetch_on = on
+
     def step(self, datas):
-        """One two-stage iteration on one batch: the unit BASELINE.json's metric counts."""
+        """One two-stage iteration on one batch: the unit BASELINE.json's metric counts.  Both stages see the same
+        batch and stage 1 leaves the main model untouched, so the engine runs the stage-2 forward pass beside stage 1
+        (`mimrl_set_stage2_prefetch`); the numbers are those of the sequential order."""
+        self._prefetch(True)
         l1 = self.stage1_step(datas)
         l2, mis, pred = self.stage2_step()
         return l1, l2, mis, pred
@@ -105,6 +113,7 @@ class Solver:
     def train(self, epoch, train_loader, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
         self.model.train()
         e = self.engine
+        self._prefetch(False)                                                  # epoch-ordered passes: stages see different batches
         self._apply_lr(epoch)
         e.set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
         dev = e.device

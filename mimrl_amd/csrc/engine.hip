@@ -142,6 +142,29 @@ struct mimrl_handle {
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
   float* cube0 = nullptr;
   BlockBuf bb[MIMRL_MAX_BLOCKS];
+  // Second set of forward buffers.  In prefetch mode (mimrl_set_stage2_prefetch) stage 1 runs its forward pass and its
+  // estimators on this set while the stage-2 forward pass of the SAME batch (same main parameters: stage 1 only
+  // touches the critics) runs beside it on `pre_stream` into the primary set, which the stage-2 backward then reads.
+  struct FwdSet {
+    int* lens[2] = {nullptr, nullptr};
+    float *tx_raw = nullptr, *gx[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *h0[2] = {nullptr, nullptr}, *h1[2] = {nullptr, nullptr};
+    float *ln_mean[2] = {nullptr, nullptr}, *ln_rstd[2] = {nullptr, nullptr}, *cube0 = nullptr, *feats = nullptr, *pred = nullptr;
+    BlockBuf bb[MIMRL_MAX_BLOCKS];
+  } alt;
+  void swap_fwd_set() {
+    for (int m = 0; m < 2; ++m) {
+      std::swap(lens[m], alt.lens[m]); std::swap(h0[m], alt.h0[m]); std::swap(h1[m], alt.h1[m]);
+      std::swap(ln_mean[m], alt.ln_mean[m]); std::swap(ln_rstd[m], alt.ln_rstd[m]);
+      for (int d = 0; d < 2; ++d) std::swap(gx[m][d], alt.gx[m][d]);
+    }
+    std::swap(tx_raw, alt.tx_raw); std::swap(cube0, alt.cube0);
+    std::swap(bufs.feats, alt.feats); std::swap(bufs.pred, alt.pred);
+    for (int i = 0; i < MIMRL_MAX_BLOCKS; ++i) std::swap(bb[i], alt.bb[i]);
+  }
+  bool prefetch = false;               // mode switch (mimrl_set_stage2_prefetch)
+  bool fwd2_pending = false;           // a prefetched stage-2 forward is waiting to be consumed
+  hipStream_t pre_stream = nullptr;
+  int carve_fwd(size_t* gmax_out);
   float *ff = nullptr, *dpred = nullptr;
   // estimators
   float *tin = nullptr, *ta[3], *tout = nullptr, *scores = nullptr, *dscores = nullptr;
@@ -233,7 +256,8 @@ struct mimrl_handle {
   float* Gm(long off) const { return bufs.main_g + off; }
   float* CP(long off) const { return bufs.crit_p + off; }
   float* CG(long off) const { return bufs.crit_g + off; }
-  RngKey key() const { return RngKey{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints}; }
+  int rng_add = 0;
+  RngKey key() const { return RngKey{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, rng_add}; }
   const float* coef1() const { return d_consts; }
   const float* coef2() const { return d_consts + 11; }
   const float* gs_mi(int stage) const { return d_consts + 19 + (stage - 1) * 5; }
@@ -378,19 +402,16 @@ int mimrl_handle::resolve() {
   return MIMRL_OK;
 }
 
-int mimrl_handle::carve() {
+// forward-pass activations that exist twice (primary set / `alt` set, see FwdSet)
+int mimrl_handle::carve_fwd(size_t* gmax_out) {
   const size_t B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const size_t BT_ = B * T;
-  MX(take(&d_ints, 16));
-  MX(take(&d_consts, 64));
   for (int m = 0; m < 2; ++m) MX(take(&lens[m], B));
   MX(take(&tx_raw, BT_ * D));
   for (int m = 0; m < 2; ++m) {
     for (int d = 0; d < 2; ++d) MX(take(&gx[m][d], BT_ * G));
     MX(take(&h0[m], BT_ * 2 * H));
     MX(take(&h1[m], BT_ * 2 * H));
-    for (int l = 0; l < 2; ++l)
-      for (int d = 0; d < 2; ++d) MX(take(&sv[l][m][d], (size_t)gru_saved_floats(cfg.batch, cfg.seq_len)));
     MX(take(&ln_mean[m], BT_));
     MX(take(&ln_rstd[m], BT_));
   }
@@ -418,6 +439,31 @@ int mimrl_handle::carve() {
     const size_t cand[] = {B * il * C, B * hl * C, B * ol * C, B * ol * ok * id, R2 * hd, R2 * od};
     for (size_t c : cand) gmax = c > gmax ? c : gmax;
     il = ol; ik = ok; id = od;
+  }
+  *gmax_out = gmax;
+  return MIMRL_OK;
+}
+
+int mimrl_handle::carve() {
+  const size_t B = cfg.batch, T = cfg.seq_len, D = cfg.d_common;
+  const size_t BT_ = B * T;
+  MX(take(&d_ints, 16));
+  MX(take(&d_consts, 64));
+  size_t gmax = 0;
+  MX(carve_fwd(&gmax));
+  for (int l = 0; l < 2; ++l)
+    for (int m = 0; m < 2; ++m)
+      for (int d = 0; d < 2; ++d) MX(take(&sv[l][m][d], (size_t)gru_saved_floats(cfg.batch, cfg.seq_len)));
+  {   // the stage-1 side of prefetch mode (its features / prediction never reach the caller's buffers)
+    float *f0 = bufs.feats, *p0 = bufs.pred;
+    swap_fwd_set();
+    size_t g2 = 0;
+    int r = carve_fwd(&g2);
+    if (r == 0) r = take(&bufs.feats, 4 * B * D);
+    if (r == 0) r = take(&bufs.pred, B);
+    swap_fwd_set();
+    bufs.feats = f0; bufs.pred = p0;
+    MX(r);
   }
   MX(take(&ff, B * D));
   MX(take(&dpred, B));
@@ -1216,17 +1262,60 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (!have_banks) return MIMRL_OK;
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-    MX(model_forward(true, false, 1));
-    MX(estimators_all(1, true, true));
+    if (prefetch) {
+      // the stage-2 forward pass of this batch depends on nothing stage 1 changes: issue it now, as one sequential
+      // branch on its own stream, into the primary buffers; stage 1 itself works on the alternate set
+      hipEvent_t e;
+      MX(next_event(&e));
+      HIPX(hipEventRecord(e, stream));
+      HIPX(hipStreamWaitEvent(pre_stream, e, 0));
+      const bool ms = multi_stream;
+      int r;
+      {
+        StreamGuard g(this, pre_stream);
+        multi_stream = false; rng_add = 1;     // begin_stage(2) has not run yet: use the dropout key it will produce
+        r = model_forward(true, true, 0);
+        multi_stream = ms; rng_add = 0;
+      }
+      MX(r);
+      swap_fwd_set();
+    }
+    int r1;
+    if (prefetch) {
+      // two forward passes now run side by side; with only 4 hardware queues, more branches would just be serialised
+      // behind one another, so stage 1's own forward pass is one sequential branch too (its kNN sampler keeps side 4)
+      MX(fork(4, 4));
+      MX(knn_launch(1, S(4)));
+      const bool ms = multi_stream;
+      multi_stream = false;
+      r1 = model_forward(true, false, 0);
+      multi_stream = ms;
+    } else {
+      r1 = model_forward(true, false, 1);
+    }
+    if (r1 == 0) r1 = estimators_all(1, true, true);
+    if (prefetch) swap_fwd_set();
+    MX(r1);
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
+    if (prefetch) {   // rejoin before the stage ends (a captured graph must not leave a dangling branch)
+      hipEvent_t e;
+      MX(next_event(&e));
+      HIPX(hipEventRecord(e, pre_stream));
+      HIPX(hipStreamWaitEvent(stream, e, 0));
+    }
     return MIMRL_OK;
   }
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
   LAUNCH_CHECK();
   if (!skip_zero) HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-  MX(model_forward(true, true, have_banks ? 2 : 0));
+  if (prefetch && have_banks) {   // forward pass already done beside stage 1; only the kNN sampler is left to start
+    MX(fork(4, 4));
+    MX(knn_launch(2, S(4)));
+  } else {
+    MX(model_forward(true, true, have_banks ? 2 : 0));
+  }
   hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
   LAUNCH_CHECK();
   if (have_banks) {
@@ -1266,6 +1355,12 @@ int mimrl_handle::run(int stage, int kind) {
   if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
   // an all-reduce): always zero first -- the caller may call it repeatedly
+  if (prefetch && bank_rows > 0) {
+    if (stage == 1) fwd2_pending = true;
+    else if (!fwd2_pending)
+      return set_error(MIMRL_ERR_STATE, "stage-2 prefetch mode: stage 2 must follow a stage-1 call on the same batch");
+    else fwd2_pending = false;
+  }
   const bool skip_zero = kind == 0 && grads_clean[stage];
   auto body = [&]() -> int {
     MX(enqueue_grads(stage, skip_zero));
@@ -1449,6 +1544,19 @@ int mimrl_profile_read(mimrl_handle* h, float* ms_sum, int32_t* launches) {
   return MIMRL_OK;
 }
 
+int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if ((on != 0) == h->prefetch) return MIMRL_OK;
+  if (on && !h->pre_stream) HIPX(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
+  HIPX(hipStreamSynchronize(h->user_stream));
+  for (int s = 1; s <= 2; ++s)
+    for (int k = 0; k < 2; ++k)
+      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  h->prefetch = on != 0;
+  h->fwd2_pending = false;
+  return MIMRL_OK;
+}
+
 int64_t mimrl_workspace_bytes(const mimrl_handle* h) { return h ? (int64_t)h->ws_bytes : 0; }
 
 void mimrl_destroy(mimrl_handle* h) {
@@ -1463,6 +1571,7 @@ void mimrl_destroy(mimrl_handle* h) {
     if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
   if (h->ws) (void)hipFree(h->ws);
   delete h;
 }

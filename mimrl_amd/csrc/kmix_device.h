@@ -10,7 +10,7 @@ constexpr float LN_EPS = 1e-6f;   // every LayerNorm of the model uses eps=1e-6 
 
 __device__ __forceinline__ float drop_scale(float p, const RngKey& key, uint32_t stream, uint32_t idx) {
   if (p <= 0.f) return 1.f;
-  const float u = uniform01(key.seed_lo, key.seed_hi, stream, (uint32_t)*key.step, idx);
+  const float u = uniform01(key.seed_lo, key.seed_hi, stream, (uint32_t)(*key.step + key.add), idx);
   return u >= p ? 1.f / (1.f - p) : 0.f;
 }
 

@@ -8,6 +8,7 @@ namespace mimrl {
 struct RngKey {            // dropout keying; `step` is read from device memory so that hipGraph replays advance it
   uint32_t seed_lo, seed_hi;
   const int* step;         // device counter (bumped by begin_stage)
+  int add = 0;             // added to *step: a forward pass issued ahead of its stage's begin_stage uses +1
 };
 
 // lens[b] = max(1, #rows t with sum_d |x[b,t,d]| != 0)                    (Model.py:425-432)

@@ -138,6 +138,15 @@ class HipEngine:
     def stage2_step(self):
         check(self.lib.mimrl_stage2_step(self.handle))
 
+    def set_stage2_prefetch(self, on: bool):
+        """Overlap mode of Solver.step(): the stage-2 forward pass runs beside stage 1 (see include/mimrl.h)."""
+        check(self.lib.mimrl_set_stage2_prefetch(self.handle, int(on)))
+
+    def step(self):
+        """One stage-1 (critics) + one stage-2 (model) update on the bound batch."""
+        check(self.lib.mimrl_stage1_step(self.handle))
+        check(self.lib.mimrl_stage2_step(self.handle))
+
     def stage_grads(self, stage: int):
         check(self.lib.mimrl_stage_grads(self.handle, stage))
 

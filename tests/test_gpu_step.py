@@ -206,3 +206,46 @@ def test_fused_cube_forward_matches_unfused(name, monkeypatch):
     assert_close(sa[_lib.S2_MIS:_lib.S2_MIS + 8], sb[_lib.S2_MIS:_lib.S2_MIS + 8], 2e-2, 2e-2, "MI terms")
     cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
     assert cos > 0.98, f"main gradient direction fused vs unfused: cosine {cos}"
+
+
+@pytest.mark.parametrize("precision,use_graph", [("fp32", False), ("fp32", True), ("bf16", True)])
+def test_stage2_prefetch_matches_sequential(precision, use_graph):
+    """Solver.step() overlap mode (mimrl_set_stage2_prefetch): the stage-2 forward pass runs beside stage 1.
+    Same parameters, inputs and dropout keys => same losses / predictions / parameters as the sequential order
+    (dropout is ON here so that a wrong mask key between forward and backward would show)."""
+    import copy
+    name = "cfg1_sep"
+    out = []
+    for pre in (False, True):
+        c, opt, batch, banks = case(name)
+        opt = copy.copy(opt)
+        opt.dropout = [0.1, 0.1, 0.1, 0.1]
+        eng = HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision=precision, use_graph=use_graph)
+        eng.load_params(oracle_params(opt, c["seed"]))
+        eng.set_batch(*batch)
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        g = load_golden(name)
+        eng.set_anchors(1, g["anchors"][0, 0])
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.set_stage2_prefetch(pre)
+        rec = []
+        for _ in range(3):
+            eng.step()
+            rec.append((eng.read_scalars().copy(), eng.pred.cpu().numpy().copy(), eng.feats.cpu().numpy().copy()))
+        rec.append(torch.cat([eng.params[n].flatten() for n in sorted(eng.params)]).cpu().numpy())
+        if pre:   # stage 2 without its stage 1 must fail loudly in this mode
+            eng.stage1_step(); eng.stage2_step()
+            with pytest.raises(Exception):
+                eng.stage2_step()
+        eng.close()
+        out.append(rec)
+    seq, pre = out
+    for it in range(3):
+        # the forward is bit-stable; later steps inherit the atomics-order noise of the preceding updates
+        # (bf16: a flipped operand rounding after the first update is a 2^-9 relative kick, amplified by the LayerNorms)
+        rt, at = (1e-6, 1e-7) if it == 0 else ((2e-3, 1e-4) if precision == "fp32" else (5e-2, 5e-3))
+        assert_close(pre[it][1], seq[it][1], rt, at, f"it{it} pred")
+        assert_close(pre[it][2], seq[it][2], rt, at, f"it{it} feats")
+        assert_close(pre[it][0][:64], seq[it][0][:64], max(rt, 1e-5), max(at, 1e-5), f"it{it} scalars")
+    cos = float(np.dot(pre[3], seq[3]) / (np.linalg.norm(pre[3]) * np.linalg.norm(seq[3])))
+    assert cos > 1 - (1e-6 if precision == "fp32" else 1e-4), cos
