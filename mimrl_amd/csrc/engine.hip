@@ -196,20 +196,25 @@ struct mimrl_handle {
     *e = ev_pool[ev_next++];
     return MIMRL_OK;
   }
-  hipStream_t S(int i) const { return multi_stream ? side[i] : stream; }
+  unsigned side_mask = ~0u;            // sides that may be used right now; work for a masked-out side goes to `stream`
+  bool side_on(int i) const { return multi_stream && ((side_mask >> i) & 1u); }
+  hipStream_t S(int i) const { return side_on(i) ? side[i] : stream; }
   // side[lo..hi] wait for everything enqueued on `stream` so far
   int fork(int lo, int hi) {
     if (!multi_stream) return MIMRL_OK;
-    hipEvent_t e;
-    MX(next_event(&e));
-    HIPX(hipEventRecord(e, stream));
-    for (int i = lo; i <= hi; ++i) HIPX(hipStreamWaitEvent(side[i], e, 0));
+    hipEvent_t e = nullptr;
+    for (int i = lo; i <= hi; ++i) {
+      if (!side_on(i)) continue;
+      if (!e) { MX(next_event(&e)); HIPX(hipEventRecord(e, stream)); }
+      HIPX(hipStreamWaitEvent(side[i], e, 0));
+    }
     return MIMRL_OK;
   }
   // `stream` waits for side[lo..hi]
   int join(int lo, int hi) {
     if (!multi_stream) return MIMRL_OK;
     for (int i = lo; i <= hi; ++i) {
+      if (!side_on(i)) continue;
       hipEvent_t e;
       MX(next_event(&e));
       HIPX(hipEventRecord(e, side[i]));
@@ -219,11 +224,11 @@ struct mimrl_handle {
   }
   // side[i] waits for side[j]
   int chain(int i, int j) {
-    if (!multi_stream) return MIMRL_OK;
+    if (!multi_stream || S(i) == S(j)) return MIMRL_OK;
     hipEvent_t e;
     MX(next_event(&e));
-    HIPX(hipEventRecord(e, side[j]));
-    HIPX(hipStreamWaitEvent(side[i], e, 0));
+    HIPX(hipEventRecord(e, S(j)));
+    HIPX(hipStreamWaitEvent(S(i), e, 0));
     return MIMRL_OK;
   }
   int G_on(hipStream_t st, const GemmDesc& d) { return gemm(st, d, bf16); }
@@ -1262,40 +1267,45 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (!have_banks) return MIMRL_OK;
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-    if (prefetch) {
-      // the stage-2 forward pass of this batch depends on nothing stage 1 changes: issue it now, as one sequential
-      // branch on its own stream, into the primary buffers; stage 1 itself works on the alternate set
-      hipEvent_t e;
-      MX(next_event(&e));
-      HIPX(hipEventRecord(e, stream));
+    static const bool pre_first = getenv("MIMRL_PREFETCH_FIRST") != nullptr;   // tuning knob: capture order of the two chains
+    auto issue_prefetch = [&](hipEvent_t e) -> int {
+      // the stage-2 forward pass of this batch depends on nothing stage 1 changes: one sequential branch on its own
+      // stream, into the primary buffers (stage 1 itself works on the alternate set)
       HIPX(hipStreamWaitEvent(pre_stream, e, 0));
       const bool ms = multi_stream;
+      const unsigned sm = side_mask;
       int r;
       {
         StreamGuard g(this, pre_stream);
         multi_stream = false; rng_add = 1;     // begin_stage(2) has not run yet: use the dropout key it will produce
         r = model_forward(true, true, 0);
-        multi_stream = ms; rng_add = 0;
+        multi_stream = ms; rng_add = 0; side_mask = sm;
       }
-      MX(r);
+      return r;
+    };
+    hipEvent_t e_begin = nullptr;
+    if (prefetch) {
+      MX(next_event(&e_begin));
+      HIPX(hipEventRecord(e_begin, stream));
+      if (pre_first) MX(issue_prefetch(e_begin));
       swap_fwd_set();
     }
     int r1;
     if (prefetch) {
       // two forward passes now run side by side; with only 4 hardware queues, more branches would just be serialised
-      // behind one another, so stage 1's own forward pass is one sequential branch too (its kNN sampler keeps side 4)
-      MX(fork(4, 4));
-      MX(knn_launch(1, S(4)));
-      const bool ms = multi_stream;
-      multi_stream = false;
-      r1 = model_forward(true, false, 0);
-      multi_stream = ms;
+      // behind one another (measured: with 5+ concurrent branches the step falls back to the sequential time, and the
+      // prefetch chain as a separate graph on its own HIP stream is slower too), so stage 1's own forward pass keeps
+      // two sides only
+      side_mask = 0x11u;                 // text branch (side 0) + kNN sampler (side 4)
+      r1 = model_forward(true, false, 1);
+      side_mask = ~0u;
     } else {
       r1 = model_forward(true, false, 1);
     }
     if (r1 == 0) r1 = estimators_all(1, true, true);
     if (prefetch) swap_fwd_set();
     MX(r1);
+    if (prefetch && !pre_first) MX(issue_prefetch(e_begin));
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
     if (prefetch) {   // rejoin before the stage ends (a captured graph must not leave a dangling branch)
