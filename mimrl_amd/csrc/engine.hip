@@ -566,12 +566,22 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       const float* in = l == 0 ? xin[m] : h0[m];
+      // both directions read the same input: one GEMM, batch = direction (weights / outputs are a constant stride apart);
+      // layer 1 has the same shape for audio and video: one launch, batch = (modality, direction)
+      const GruDirW &gf = gru[m][l][0], &gr = gru[m][l][1];
+      GemmDesc gd = gemm_nt(in, gf.din, P(gf.w_ih), gf.din, gx[m][0], G, (int)BT_, G, gf.din);
+      gd.batch = 2; gd.sa_b = 0; gd.sb_b = gr.w_ih - gf.w_ih; gd.sc_b = gx[m][1] - gx[m][0];
+      gd.bias_n = P(gf.b_ih); gd.bias_n_b = gr.b_ih - gf.b_ih;
+      if (l == 1) {
+        if (m == 1) goto seqs;
+        gd.batch = 4; gd.batch_in = 2;
+        gd.sa_bo = h0[1] - h0[0]; gd.sb_bo = gru[1][l][0].w_ih - gf.w_ih; gd.sc_bo = gx[1][0] - gx[0][0];
+        gd.bias_n_bo = gru[1][l][0].b_ih - gf.b_ih;
+      }
+      MX(G_on(m == 0 ? stream : S(2), gd));
+    seqs:
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
-        GemmDesc gd = gemm_nt(in, g.din, P(g.w_ih), g.din, gx[m][d], G, (int)BT_, G, g.din);
-        gd.bias_n = P(g.b_ih);
-        const int q = m * 2 + d;
-        MX(G_on(q == 0 ? stream : S(q), gd));
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
       }
     }
@@ -987,33 +997,36 @@ int mimrl_handle::model_backward() {
     MX(fork(1, l == 0 ? 5 : 3));
     int rr = 0;
     for (int m = 0; m < 2; ++m) {
+      // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H).  Both directions in one
+      // launch each (batch = direction): dW_ih, dW_hh rows [0,2H), dW_hh rows [2H,3H).
       const float* in = l == 0 ? xin[m] : h0[m];
-      for (int d = 0; d < 2; ++d) {
-        const GruDirW& g = gru[m][l][d];
-        hipStream_t st = l == 0 ? nullptr : S(1 + (m * 2 + d) % 3);
-        auto pick = [&]() { const int q = rr++ % 6; return q == 0 ? stream : S(q); };
-        if (l == 0) {
-          { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(pick(), q)); }
-          { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, hprev[l][m][d], H, Gm(g.w_hh), H, 2 * H, H, (int)BT_); q.atomic = 1; MX(G_on(pick(), q)); }
-          { GemmDesc q = gemm_tn(dg[l][m][d] + 3 * H, 4 * H, hprev[l][m][d], H, Gm(g.w_hh) + 2 * H * H, H, H, H, (int)BT_); q.atomic = 1; MX(G_on(pick(), q)); }
-          continue;
-        }
-        // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H)
-        { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, in, g.din, Gm(g.w_ih), g.din, G, g.din, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
-        { GemmDesc q = gemm_tn(dg[l][m][d], 4 * H, hprev[l][m][d], H, Gm(g.w_hh), H, 2 * H, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
-        { GemmDesc q = gemm_tn(dg[l][m][d] + 3 * H, 4 * H, hprev[l][m][d], H, Gm(g.w_hh) + 2 * H * H, H, H, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
-      }
+      const GruDirW &gf = gru[m][l][0], &gr = gru[m][l][1];
+      const long s_dg = dg[l][m][1] - dg[l][m][0], s_hp = hprev[l][m][1] - hprev[l][m][0];
+      const bool both = l == 1;            // layer 1: same shapes for audio and video -> batch = (modality, direction)
+      if (both && m == 1) break;
+      auto two = [&](GemmDesc& q, long a_o, long b_o, long c_o) { if (both) { q.batch = 4; q.batch_in = 2; q.sa_bo = a_o; q.sb_bo = b_o; q.sc_bo = c_o; } };
+      const long o_dg = dg[l][1][0] - dg[l][0][0], o_hp = hprev[l][1][0] - hprev[l][0][0], o_in = both ? h0[1] - h0[0] : 0;
+      const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
+      auto pick = [&]() { if (l == 0) { const int q = rr++ % 6; return q == 0 ? stream : S(q); } return S(1 + rr++ % 3); };
+      { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
+        q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih); MX(G_on(pick(), q)); }
+      { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, hprev[l][m][0], H, Gm(gf.w_hh), H, 2 * H, H, (int)BT_);
+        q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
+      { GemmDesc q = gemm_tn(dg[l][m][0] + 3 * H, 4 * H, hprev[l][m][0], H, Gm(gf.w_hh) + 2 * H * H, H, H, H, (int)BT_);
+        q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
     }
     if (l == 1) {   // critical path: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
-      // one dual-product GEMM per modality (both directions accumulate in the same output tile); video on side 4
-      MX(fork(4, 4));
-      for (int m = 0; m < 2; ++m) {
-        GemmDesc q = gemm_nn(dg[l][m][0], 4 * H, P(gru[m][l][0].w_ih), 2 * H, dh0[m], 2 * H, (int)BT_, 2 * H, G);
-        q.A2 = dg[l][m][1]; q.sa2_m = 4 * H; q.sa2_k = 1;
-        q.B2 = P(gru[m][l][1].w_ih); q.sb2_k = 2 * H; q.sb2_n = 1; q.K2 = G;
-        MX(G_on(m == 0 ? stream : S(4), q));
+      // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
+      {
+        GemmDesc q = gemm_nn(dg[l][0][0], 4 * H, P(gru[0][l][0].w_ih), 2 * H, dh0[0], 2 * H, (int)BT_, 2 * H, G);
+        q.A2 = dg[l][0][1]; q.sa2_m = 4 * H; q.sa2_k = 1;
+        q.B2 = P(gru[0][l][1].w_ih); q.sb2_k = 2 * H; q.sb2_n = 1; q.K2 = G;
+        q.batch = 2;
+        q.sa_b = dg[l][1][0] - dg[l][0][0]; q.sa2_b = dg[l][1][1] - dg[l][0][1];
+        q.sb_b = gru[1][l][0].w_ih - gru[0][l][0].w_ih; q.sb2_b = gru[1][l][1].w_ih - gru[0][l][1].w_ih;
+        q.sc_b = dh0[1] - dh0[0];
+        MX(G_(q));
       }
-      MX(join(4, 4));
     }
   }
   MX(join(0, 5));

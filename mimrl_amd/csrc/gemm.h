@@ -17,6 +17,9 @@ struct GemmDesc {
   long sa_m = 0, sa_k = 0, sa_b = 0;
   long sb_k = 0, sb_n = 0, sb_b = 0;
   long sc_m = 0, sc_n = 0, sc_b = 0;
+  // optional two-level batch: entry b = (outer, inner) = (b / batch_in, b % batch_in) with its own outer strides for
+  // A, B, C (and pre / gradact_u, which share C's layout) and bias_n -- e.g. (modality, direction) of the GRU weights
+  int batch_in = 0; long sa_bo = 0, sb_bo = 0, sc_bo = 0, bias_n_bo = 0;
   const float* bias_n = nullptr; long bias_n_b = 0;   // + bias_n[b*bias_n_b + n]
   const float* bias_m = nullptr; long bias_m_b = 0;   // + bias_m[b*bias_m_b + m]
   float alpha = 1.f;

@@ -149,10 +149,11 @@ __device__ __forceinline__ void store_tile(const Operand& o, int tid, const floa
 }
 
 // epilogue of one 32x32 accumulator tile: lane holds column n, 16 rows (mbase + MFMA row pattern)
-__device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, const f32x16& acc, int mbase, int n, int lane) {
+__device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, long oc, long obn, const f32x16& acc, int mbase,
+                                         int n, int lane) {
   if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
-  float* __restrict__ C = d.C + (long)bz * d.sc_b;
-  const float bn = d.bias_n ? d.bias_n[(long)bz * d.bias_n_b + n] : 0.f;
+  float* __restrict__ C = d.C + oc;
+  const float bn = d.bias_n ? d.bias_n[obn + n] : 0.f;
   float csum = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -162,8 +163,8 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
     float v = d.alpha * acc[r] + bn;
     if (d.bias_m) v += d.bias_m[(long)bz * d.bias_m_b + m];
     if (d.beta != 0.f) v += d.beta * C[off];
-    if (d.pre) d.pre[(long)bz * d.sc_b + off] = v;
-    if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[(long)bz * d.sc_b + off]);
+    if (d.pre) d.pre[oc + off] = v;
+    if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[oc + off]);
     else v = act_apply(d.act, v);
     if (atomic) atomicAdd(&C[off], v);
     else C[off] = v;
@@ -197,6 +198,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     }
   }
   const int bz = bzr / ka.ksplit, ks = bzr - bz * ka.ksplit;
+  long oa = (long)bz * d.sa_b, ob = (long)bz * d.sb_b, oc = (long)bz * d.sc_b, obn = (long)bz * d.bias_n_b;
+  if (d.batch_in > 0) {
+    const int bo = bz / d.batch_in, bi = bz - bo * d.batch_in;
+    oa = (long)bo * d.sa_bo + (long)bi * d.sa_b; ob = (long)bo * d.sb_bo + (long)bi * d.sb_b;
+    oc = (long)bo * d.sc_bo + (long)bi * d.sc_b; obn = (long)bo * d.bias_n_bo + (long)bi * d.bias_n_b;
+  }
   const int m0 = by * BM, n0 = bx * BN;
   const bool full_m = m0 + BM <= d.M, full_n = n0 + BN <= d.N;
 
@@ -246,13 +253,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     const int ktiles = (d.K + BK - 1) / BK;
     const int kt0 = ks * ka.kt_per;                       // split-K only ever applies to single-product GEMMs
     const int kt1 = kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles;
-    segment(d.A + (long)bz * d.sa_b, d.sa_m, d.sa_k, d.B + (long)bz * d.sb_b, d.sb_k, d.sb_n, d.K, ka.vec_a, ka.vec_b, kt0, kt1);
+    segment(d.A + oa, d.sa_m, d.sa_k, d.B + ob, d.sb_k, d.sb_n, d.K, ka.vec_a, ka.vec_b, kt0, kt1);
   }
   if (d.A2)
     segment(d.A2 + (long)bz * d.sa2_b, d.sa2_m, d.sa2_k, d.B2 + (long)bz * d.sb2_b, d.sb2_k, d.sb2_n, d.K2, ka.vec_a2, ka.vec_b2,
             0, (d.K2 + BK - 1) / BK);
 
-  epilogue(d, d.atomic || ka.ksplit > 1, bz, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
+  epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, obn, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -269,7 +276,7 @@ inline bool vec_ok_b(const float* P, long s_k, long s_n, long s_b) {
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knobs
   static const int no_big = getenv("MIMRL_GEMM_NO_BK128") != nullptr;
-  const bool va = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b), vb = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b);
+  const bool va = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0, vb = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
   const bool va2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : true, vb2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : true;
   // lean = 16-byte loads only.  Ragged M / N are fine for k-contiguous operands (rows are clamped in the loader).
   const bool a_kfast = d.sa_k == 1 && (!d.A2 || d.sa2_k == 1), b_kfast = d.sb_k == 1 && d.sb_n != 1 && (!d.B2 || (d.sb2_k == 1 && d.sb2_n != 1));
@@ -301,12 +308,14 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (dbg_skip && d.atomic && (dbg_skip == 1 || (dbg_skip == 2 && d.batch > 1 && d.sc_b == 0))) return MIMRL_OK;
   if (!d.A || !d.B || !d.C) return set_error(MIMRL_ERR_ARG, "gemm: null operand");
   if ((d.A2 != nullptr) != (d.B2 != nullptr)) return set_error(MIMRL_ERR_ARG, "gemm: second product needs both operands");
+  if (d.batch_in > 0 && (d.A2 || d.bias_m || d.colsum || d.batch % d.batch_in != 0))
+    return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
   KernelArgs ka;
   ka.d = d;
-  ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b);
-  ka.vec_b = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b);
+  ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0;
+  ka.vec_b = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
   ka.vec_a2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : 1;
   ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
   static const int no_xcd = getenv("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
