@@ -145,6 +145,16 @@ int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* 
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
                       const float* g_cmi, int E, int n, int hardtanh);
+/* fused ReLU-MLP stack (critic towers VMI.py:13-22, CMI classifier Model.py:47-72), bf16 MFMA, fp32 in/out.
+ * W[l] is [dims[l+1], dims[l]] row-major, group g at + g*pstride (same for b[l], db[l]); activations are
+ * [nb, brows, width].  forward: act[l] (l < nl-1) = post-ReLU outputs, out = linear top layer.
+ * backward: data-gradient chain only: dz[l] (1 <= l < nl) = d/d(pre-activation of layer l-1's output), din (optional),
+ * db[l] (optional, l < nl-1) += column sums of dz[l+1]. */
+int mimrl_op_mlp_stack_forward(void* stream, int nb, int rows, int brows, int nl, const int32_t* dims, const float* const* W,
+                               const float* const* b, int64_t pstride, const float* in, float* const* act, float* out);
+int mimrl_op_mlp_stack_backward(void* stream, int nb, int rows, int brows, int nl, const int32_t* dims, const float* const* W,
+                                int64_t pstride, const float* const* act, const float* dout, float* const* dz, float* din,
+                                float* const* db);
 int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,
                   float beta1, float beta2, float eps, float weight_decay, float clip);
 

@@ -100,7 +100,7 @@ EXPORTS = [
     "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read",
     "mimrl_workspace_bytes", "mimrl_set_stage2_prefetch", "mimrl_destroy", "mimrl_op_gemm",
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_knn",
-    "mimrl_op_cmi_loss", "mimrl_op_adam",
+    "mimrl_op_cmi_loss", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
 ]
 
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "cube_fused.h"
+#include "mlp_fused.h"
 #include "estimator_ops.h"
 #include "gemm.h"
 #include "gru.h"
@@ -173,8 +174,8 @@ struct mimrl_handle {
   float *cmi_in = nullptr, *cc[3], *logits = nullptr, *dlogits = nullptr;
   float *mi_raw = nullptr, *cmi_raw = nullptr, *bce_raw = nullptr;
   // backward temporaries
-  float *dfeat = nullptr, *dtout = nullptr, *dta[2], *dtin = nullptr, *dca[2], *dP = nullptr, *dQ = nullptr;
-  float *dcc[2], *dcin = nullptr;
+  float *dfeat = nullptr, *dtout = nullptr, *dta[3], *dtin = nullptr, *dca[2], *dP = nullptr, *dQ = nullptr;
+  float *dcc[3], *dcin = nullptr;
   static constexpr int NGBUF = 16;   // cube backward: rotating (4 in use) or one-shot (deferred weight gradients)
   float* gbuf[NGBUF];
   size_t gbuf_floats = 0;
@@ -186,6 +187,7 @@ struct mimrl_handle {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   bool multi_stream = true;
+  bool fused_mlp = true;               // bf16 mode: estimator MLP stacks as one kernel per direction (MIMRL_NO_FUSED_MLP=1 disables)
   bool fused_cube = true;              // bf16 mode: CubeMLP blocks as one LDS-resident kernel (MIMRL_NO_FUSED_CUBE=1 disables)
   int next_event(hipEvent_t* e) {
     if (ev_next == ev_pool.size()) {
@@ -481,7 +483,7 @@ int mimrl_handle::carve() {
     for (int l = 0; l < 3; ++l) MX(take(&ta[l], 10 * B * HID));
     MX(take(&tout, 10 * B * EMB));
     MX(take(&dtout, 10 * B * EMB));
-    for (int l = 0; l < 2; ++l) MX(take(&dta[l], 10 * B * HID));
+    for (int l = 0; l < 3; ++l) MX(take(&dta[l], 10 * B * HID));
   } else {
     MX(take(&cP, NE_MI * B * HID)); MX(take(&cQ, NE_MI * B * HID));
     MX(take(&dP, NE_MI * B * HID)); MX(take(&dQ, NE_MI * B * HID));
@@ -495,7 +497,7 @@ int mimrl_handle::carve() {
   for (int l = 0; l < 3; ++l) MX(take(&cc[l], NE_CMI * 2 * n * HID));
   MX(take(&logits, NE_CMI * 2 * n * 2));
   MX(take(&dlogits, NE_CMI * 2 * n * 2));
-  for (int l = 0; l < 2; ++l) MX(take(&dcc[l], NE_CMI * 2 * n * HID));
+  for (int l = 0; l < 3; ++l) MX(take(&dcc[l], NE_CMI * 2 * n * HID));
   MX(take(&dcin, NE_CMI * 2 * n * 384));
   MX(take(&mi_raw, 8)); MX(take(&cmi_raw, 8)); MX(take(&bce_raw, 8));
   MX(take(&dfeat, 4 * B * D));
@@ -940,8 +942,9 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
 int mimrl_handle::flush_deferred() {
   if (deferred.empty()) return MIMRL_OK;
   MX(fork(1, 3));
+  static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
   for (const Deferred& d : deferred) {
-    hipStream_t st = S(d.side);
+    hipStream_t st = S(1 + (d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
     else MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
@@ -1007,7 +1010,9 @@ int mimrl_handle::model_backward() {
       auto two = [&](GemmDesc& q, long a_o, long b_o, long c_o) { if (both) { q.batch = 4; q.batch_in = 2; q.sa_bo = a_o; q.sb_bo = b_o; q.sc_bo = c_o; } };
       const long o_dg = dg[l][1][0] - dg[l][0][0], o_hp = hprev[l][1][0] - hprev[l][0][0], o_in = both ? h0[1] - h0[0] : 0;
       const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
-      auto pick = [&]() { if (l == 0) { const int q = rr++ % 6; return q == 0 ? stream : S(q); } return S(1 + rr++ % 3); };
+      static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 6;   // tuning knobs
+      static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
+      auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih); MX(G_on(pick(), q)); }
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, hprev[l][m][0], H, Gm(gf.w_hh), H, 2 * H, H, (int)BT_);
@@ -1040,6 +1045,14 @@ int mimrl_handle::model_backward() {
 // =================================================================================================
 int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
                                     const int* dims, const float* in, float* const* act, float* out) {
+  if (bf16 && fused_mlp && rows <= 512 && mlp_fused_supported(nb, rows, nl, dims)) {   // small stacks: one launch (mlp_fused.hip)
+    MlpFusedArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.nb = nb; fa.rows = rows; fa.brows = brows; fa.nl = nl; fa.pstride = pstride; fa.in = in; fa.out = out;
+    for (int l = 0; l <= nl; ++l) fa.dims[l] = dims[l];
+    for (int l = 0; l < nl; ++l) { fa.W[l] = CP(p0 + l_off[l][0]); fa.b[l] = CP(p0 + l_off[l][1]); if (l < nl - 1) fa.act[l] = act[l]; }
+    return mlp_stack_fwd_fused(stream, fa);
+  }
   for (int l = 0; l < nl; ++l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
     GemmDesc g;
@@ -1061,6 +1074,31 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
   int pp = 0;
   if (wgrad)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
     MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
+  // opt-in: the fused data-gradient kernel (transposed weight reads) only ties the four grouped GEMMs it replaces
+  static const bool fused_bwd = getenv("MIMRL_FUSED_MLP_BWD") != nullptr;
+  if (bf16 && fused_mlp && fused_bwd && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims)) {
+    // the whole data-gradient chain in one launch (dtmp must hold nl-1 buffers here); weight gradients follow as GEMMs
+    MlpFusedArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.nb = nb; fa.rows = rows; fa.brows = brows; fa.nl = nl; fa.pstride = pstride; fa.in = in; fa.dout = dout; fa.din = din;
+    for (int l = 0; l <= nl; ++l) fa.dims[l] = dims[l];
+    for (int l = 0; l < nl; ++l) {
+      fa.W[l] = CP(p0 + l_off[l][0]);
+      if (l < nl - 1) { fa.act[l] = act[l]; fa.dz[l + 1] = dtmp[l]; if (wgrad) fa.db[l] = CG(p0 + l_off[l][1]); }
+    }
+    MX(mlp_stack_bwd_fused(stream, fa));
+    if (!wgrad) return MIMRL_OK;
+    for (int l = nl - 1; l >= 0; --l) {   // dW_l = dZ_l^T A_l
+      const int din_ = dims[l], dout_ = dims[l + 1];
+      GemmDesc g;
+      g.A = l == nl - 1 ? dout : fa.dz[l + 1]; g.sa_m = 1; g.sa_k = dout_; g.sa_b = (long)brows * dout_;
+      g.B = l == 0 ? in : act[l - 1]; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
+      g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
+      g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
+      MX(G_(g));
+    }
+    return MIMRL_OK;
+  }
   for (int l = nl - 1; l >= 0; --l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
     const float* a_in = l == 0 ? in : act[l - 1];
@@ -1455,6 +1493,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->stream = h->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
   h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
   h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
+  h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
   h->prec = cfg->precision;
@@ -1655,6 +1694,37 @@ int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anc
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
                       const float* g_cmi, int E, int n, int hardtanh) {
   return cmi_loss_fwd_bwd(reinterpret_cast<hipStream_t>(stream), logits, dlogits, bce, cmi, g_bce, g_cmi, E, n, hardtanh);
+}
+
+static int fill_mlp_args(MlpFusedArgs* fa, int nb, int rows, int brows, int nl, const int32_t* dims, const float* const* W,
+                         int64_t pstride) {
+  if (!dims || !W || nl < 1 || nl > MLPF_MAX_LAYERS) return set_error(MIMRL_ERR_ARG, "mlp_stack: bad arguments");
+  std::memset(fa, 0, sizeof *fa);
+  fa->nb = nb; fa->rows = rows; fa->brows = brows; fa->nl = nl; fa->pstride = pstride;
+  for (int l = 0; l <= nl; ++l) fa->dims[l] = dims[l];
+  for (int l = 0; l < nl; ++l) fa->W[l] = W[l];
+  return MIMRL_OK;
+}
+
+int mimrl_op_mlp_stack_forward(void* stream, int nb, int rows, int brows, int nl, const int32_t* dims, const float* const* W,
+                               const float* const* b, int64_t pstride, const float* in, float* const* act, float* out) {
+  MlpFusedArgs fa;
+  MX(fill_mlp_args(&fa, nb, rows, brows, nl, dims, W, pstride));
+  if (!b || !in || !out || (nl > 1 && !act)) return set_error(MIMRL_ERR_ARG, "mlp_stack_forward: null argument");
+  for (int l = 0; l < nl; ++l) { fa.b[l] = b[l]; if (l < nl - 1) fa.act[l] = act[l]; }
+  fa.in = in; fa.out = out;
+  return mlp_stack_fwd_fused(reinterpret_cast<hipStream_t>(stream), fa);
+}
+
+int mimrl_op_mlp_stack_backward(void* stream, int nb, int rows, int brows, int nl, const int32_t* dims, const float* const* W,
+                                int64_t pstride, const float* const* act, const float* dout, float* const* dz, float* din,
+                                float* const* db) {
+  MlpFusedArgs fa;
+  MX(fill_mlp_args(&fa, nb, rows, brows, nl, dims, W, pstride));
+  if (!dout || (nl > 1 && (!act || !dz))) return set_error(MIMRL_ERR_ARG, "mlp_stack_backward: null argument");
+  for (int l = 0; l < nl - 1; ++l) { fa.act[l] = const_cast<float*>(act[l]); fa.dz[l + 1] = dz[l + 1]; fa.db[l] = db ? db[l] : nullptr; }
+  fa.dout = dout; fa.din = din;
+  return mlp_stack_bwd_fused(reinterpret_cast<hipStream_t>(stream), fa);
 }
 
 int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,

@@ -1,0 +1,36 @@
+// Fused ReLU-MLP stacks for the estimators (critic towers VMI.py:13-22,53-57; CMI classifiers Model.py:47-72), bf16 MFMA.
+// A stack is tiny (<= 256 rows per group, <= 4 layers, widths <= 384): as separate GEMMs every layer is a 10-20 us
+// kernel boundary on the critical path.  Here one workgroup owns 32 rows of one group for the WHOLE stack: the
+// activations stay in LDS (bf16), the weights stream from L2 straight into MFMA B-fragments (fp32 -> bf16 in registers;
+// with a single 32-row M-tile no other wave would reuse them, so LDS staging buys nothing).
+#pragma once
+#include "common.h"
+
+namespace mimrl {
+
+constexpr int MLPF_MAX_LAYERS = 4;
+constexpr int MLPF_MAX_WIDTH = 384;
+
+struct MlpFusedArgs {
+  int nb, rows, brows;            // groups, valid rows per group, row pitch between groups in every activation buffer
+  int nl;                         // layers
+  int dims[MLPF_MAX_LAYERS + 1];  // widths: dims[0] input ... dims[nl] output
+  const float* W[MLPF_MAX_LAYERS];   // [dims[l+1], dims[l]] row-major, group g at + g*pstride
+  const float* b[MLPF_MAX_LAYERS];   // [dims[l+1]]
+  long pstride;
+  const float* in;                // [nb, brows, dims[0]]
+  float* act[MLPF_MAX_LAYERS];    // post-ReLU outputs of layers 0..nl-2: [nb, brows, dims[l+1]]  (kept for the backward pass)
+  float* out;                     // [nb, brows, dims[nl]]  (linear)
+  // backward only
+  const float* dout;              // [nb, brows, dims[nl]]
+  float* dz[MLPF_MAX_LAYERS];     // dz[l] = gradient w.r.t. the pre-activation of layer l-1's output, l = 1..nl-1: [nb, brows, dims[l]]
+  float* din;                     // [nb, brows, dims[0]] or null
+  float* db[MLPF_MAX_LAYERS];     // optional bias gradients of layers 0..nl-2 (column sums of dz[l+1]), group g at + g*pstride
+};
+
+bool mlp_fused_supported(int nb, int rows, int nl, const int* dims);
+int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a);
+// data-gradient chain only: fills dz[1..nl-1] (+ din, + db[]); weight gradients stay GEMMs over (dz, act)
+int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a);
+
+}  // namespace mimrl

@@ -1,0 +1,288 @@
+// Fused ReLU-MLP stacks (see mlp_fused.h).  One workgroup = 32 rows of one group through every layer.
+//   MFMA v_mfma_f32_32x32x16_bf16: M = the 32 rows (A-fragments from the LDS activation tile), N = 32 output columns
+//   per tile (tiles dealt to the 4 waves), K = the layer's input width.  B-fragments come straight from global memory:
+//   forward  W[n, k..k+8)   two 16-byte loads per lane and k-step (row n of the weight matrix is k-contiguous);
+//   backward W[n..n+8, k]   eight 4-byte loads per lane (a half-wave reads 128 contiguous bytes of each row),
+//   double-buffered in registers so that the next chunk of weights is in flight while the current one is multiplied.
+#include "mlp_fused.h"
+
+#include <type_traits>
+
+namespace mimrl {
+
+namespace {
+
+typedef std::integral_constant<int, 0> I0;
+typedef std::integral_constant<int, 1> I1;
+constexpr int RT = 32;                        // rows per workgroup
+constexpr int LDA = MLPF_MAX_WIDTH + 8;       // bf16 pitch: 784 B = odd multiple of 16 B -> conflict-free ds_read_b128
+
+__device__ __forceinline__ bf16x8 pack8(const float4& x, const float4& y) {
+  bf16x8 p;
+  p[0] = to_bf16(x.x); p[1] = to_bf16(x.y); p[2] = to_bf16(x.z); p[3] = to_bf16(x.w);
+  p[4] = to_bf16(y.x); p[5] = to_bf16(y.y); p[6] = to_bf16(y.z); p[7] = to_bf16(y.w);
+  return p;
+}
+
+// rows [r0, r0+32) x [0, width) of a [.., width] fp32 matrix -> bf16 tile; rows >= rows_valid and columns up to the
+// next multiple of 16 are zero
+__device__ __forceinline__ void load_tile_bf16(const float* __restrict__ src, long rowbase, int r0, int rows_valid, int width,
+                                               __bf16 (*t)[LDA], int tid) {
+  const int w16 = (width + 15) & ~15;
+  if ((width & 3) == 0) {
+    const int q = w16 / 4;
+    for (int i = tid; i < RT * q; i += 256) {
+      const int r = i / q, c = (i - r * q) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + r < rows_valid && c < width) v = *reinterpret_cast<const float4*>(src + (rowbase + r) * width + c);
+      bf16x4 p; p[0] = to_bf16(v.x); p[1] = to_bf16(v.y); p[2] = to_bf16(v.z); p[3] = to_bf16(v.w);
+      *reinterpret_cast<bf16x4*>(&t[r][c]) = p;
+    }
+  } else {
+    for (int i = tid; i < RT * w16; i += 256) {
+      const int r = i / w16, c = i - r * w16;
+      t[r][c] = to_bf16((r0 + r < rows_valid && c < width) ? src[(rowbase + r) * width + c] : 0.f);
+    }
+  }
+}
+
+// Forward.  Weight rows are k-contiguous, the MFMA B-fragment wants (row n = lane&31, 8 k-values): loading fragments
+// directly makes every wave-instruction touch 32 different cache lines.  Instead each wave pulls its OWN two 32-row
+// tiles in fully coalesced 1 KiB instructions (16 lanes x 16 B per row, 4 rows per instruction), rounds them to bf16
+// into a wave-private LDS slab and reads the fragments back from there; no other wave needs those rows (single 32-row
+// M tile), so the hand-off needs no workgroup barrier.  Two chunks of 64 k-values are kept in flight in registers.
+constexpr int WCH = 64;                       // k-values per staged chunk
+constexpr int WLD = WCH + 8;                  // bf16 pitch of a staged weight tile (144 B)
+
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFusedArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
+  __shared__ __attribute__((aligned(16))) __bf16 wl[4][2][2][32][WLD];   // [wave][buffer][tile][row][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroups are dealt round-robin to the 8 XCDs: give every group (one weight set) to ONE XCD so that its row tiles
+  // share the weight lines in that XCD's L2 (grid.x = 8 * tiles * ceil(nb / 8), surplus ids exit)
+  const int tiles = (a.rows + RT - 1) / RT;
+  const int xslot = blockIdx.x >> 3;
+  const int g = (blockIdx.x & 7) + 8 * (xslot / tiles), r0 = (xslot % tiles) * RT;
+  if (g >= a.nb) return;
+  const long rowbase = (long)g * a.brows + r0;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int srow = lane >> 4, sk = (lane & 15) * 4;          // staging map: 4 rows x 64 k per instruction
+  load_tile_bf16(a.in, rowbase, r0, a.rows, a.dims[0], sa[0], tid);
+  __syncthreads();
+  int cur = 0;
+  for (int l = 0; l < a.nl; ++l) {
+    const int K = a.dims[l], N = a.dims[l + 1];
+    const float* __restrict__ W = a.W[l] + (long)g * a.pstride;
+    const float* __restrict__ bias = a.b[l] + (long)g * a.pstride;
+    const bool last = l == a.nl - 1;
+    float* __restrict__ dst = last ? a.out : a.act[l];
+    const int ntiles = (N + 31) / 32;
+    const int nchunk = K / WCH;                  // K is a multiple of 64
+    for (int nt0 = wave; nt0 < ntiles; nt0 += 8) {
+      const int nt1 = nt0 + 4;
+      const bool two = nt1 < ntiles;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      float4 rg[2][2][8];                        // [register buffer][tile][instruction]
+      auto fetch = [&](int c, auto S) {
+        constexpr int s = decltype(S)::value;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = i * 4 + srow;
+          rg[s][0][i] = *reinterpret_cast<const float4*>(W + (long)min(nt0 * 32 + row, N - 1) * K + c * WCH + sk);
+          if (two) rg[s][1][i] = *reinterpret_cast<const float4*>(W + (long)min(nt1 * 32 + row, N - 1) * K + c * WCH + sk);
+        }
+      };
+      auto stage = [&](int lb, auto S) {           // registers -> this wave's LDS slab `lb`
+        constexpr int s = decltype(S)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t == 1 && !two) break;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float4 v = rg[s][t][i];
+            bf16x4 p; p[0] = to_bf16(v.x); p[1] = to_bf16(v.y); p[2] = to_bf16(v.z); p[3] = to_bf16(v.w);
+            *reinterpret_cast<bf16x4*>(&wl[wave][lb][t][i * 4 + srow][sk]) = p;
+          }
+        }
+      };
+      auto mult = [&](int c, int lb) {
+#pragma unroll
+        for (int u = 0; u < WCH / 16; ++u) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sa[cur][lr][c * WCH + u * 16 + 8 * lh]);
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&wl[wave][lb][0][lr][u * 16 + 8 * lh]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc0, 0, 0, 0);
+          if (two) {
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&wl[wave][lb][1][lr][u * 16 + 8 * lh]);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc1, 0, 0, 0);
+          }
+        }
+      };
+      // chunk c lives in register buffer c&1 until staged into LDS slab c&1; chunks c+1 (and c+2) are in flight meanwhile
+      fetch(0, I0{});
+      if (nchunk > 1) fetch(1, I1{});
+      for (int c = 0; c < nchunk; c += 2) {
+        stage(0, I0{});
+        if (c + 2 < nchunk) fetch(c + 2, I0{});
+        mult(c, 0);
+        if (c + 1 < nchunk) {
+          stage(1, I1{});
+          if (c + 3 < nchunk) fetch(c + 3, I1{});
+          mult(c + 1, 1);
+        }
+      }
+      auto finish = [&](const f32x16& acc, int nt) {
+        const int n = nt * 32 + lr;
+        if (n >= N) return;
+        const float bn = bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[r] + bn;
+          if (!last) v = fmaxf(v, 0.f);
+          if (r0 + m < a.rows) dst[(rowbase + m) * N + n] = v;
+          if (!last) sa[cur ^ 1][m][n] = to_bf16(v);
+        }
+      };
+      finish(acc0, nt0);
+      if (two) finish(acc1, nt1);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpFusedArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroups are dealt round-robin to the 8 XCDs: give every group (one weight set) to ONE XCD so that its row tiles
+  // share the weight lines in that XCD's L2 (grid.x = 8 * tiles * ceil(nb / 8), surplus ids exit)
+  const int tiles = (a.rows + RT - 1) / RT;
+  const int xslot = blockIdx.x >> 3;
+  const int g = (blockIdx.x & 7) + 8 * (xslot / tiles), r0 = (xslot % tiles) * RT;
+  if (g >= a.nb) return;
+  const long rowbase = (long)g * a.brows + r0;
+  const int lr = lane & 31, lh = lane >> 5;
+  load_tile_bf16(a.dout, rowbase, r0, a.rows, a.dims[a.nl], sa[0], tid);
+  __syncthreads();
+  int cur = 0;
+  for (int l = a.nl - 1; l >= 0; --l) {
+    float* __restrict__ target = l > 0 ? a.dz[l] : a.din;
+    if (!target) break;
+    const int NR = a.dims[l + 1], KO = a.dims[l];          // reduction width, output width
+    const int nsteps = (NR + 15) / 16;
+    const float* __restrict__ W = a.W[l] + (long)g * a.pstride;
+    const float* __restrict__ mask = l > 0 ? a.act[l - 1] : nullptr;
+    float* __restrict__ db = (l > 0 && a.db[l - 1]) ? a.db[l - 1] + (long)g * a.pstride : nullptr;
+    const int ktiles = KO / 32;                             // KO is a multiple of 32
+    constexpr int TW = 3;                                   // output tiles per wave (KO <= 384)
+    f32x16 acc[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    constexpr int NS = 4;                                   // reduction steps (of 16) per register chunk
+    const int nchunk = (nsteps + NS - 1) / NS;
+    float wb[2][NS][TW][8];
+    auto fetch = [&](int c, auto S) {
+      constexpr int s = decltype(S)::value;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int ns = c * NS + q;
+        if (ns >= nsteps) break;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          const int kt = wave + 4 * t;
+          if (kt < ktiles) {
+            const int kc = kt * 32 + lr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int n = min(ns * 16 + 8 * lh + j, NR - 1);   // rows beyond NR meet zero A-columns
+              wb[s][q][t][j] = W[(long)n * KO + kc];
+            }
+          }
+        }
+      }
+    };
+    auto mult = [&](int c, auto S) {
+      constexpr int s = decltype(S)::value;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const int ns = c * NS + q;
+        if (ns >= nsteps) break;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sa[cur][lr][ns * 16 + 8 * lh]);
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          if (wave + 4 * t < ktiles) {
+            bf16x8 bfr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bfr[j] = to_bf16(wb[s][q][t][j]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    };
+    fetch(0, I0{});
+    for (int c = 0; c < nchunk; c += 2) {
+      if (c + 1 < nchunk) fetch(c + 1, I1{});
+      mult(c, I0{});
+      if (c + 2 < nchunk) fetch(c + 2, I0{});
+      if (c + 1 < nchunk) mult(c + 1, I1{});
+    }
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      const int kt = wave + 4 * t;
+      if (kt >= ktiles) continue;
+      const int kc = kt * 32 + lr;
+      float csum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = r0 + m < a.rows;
+        float v = acc[t][r];
+        if (mask) v = (ok && mask[(rowbase + m) * KO + kc] > 0.f) ? v : 0.f;   // post-activation > 0 <=> pre-activation > 0
+        if (ok) target[(rowbase + m) * KO + kc] = v;
+        if (l > 0) sa[cur ^ 1][m][kc] = to_bf16(v);
+        csum += v;
+      }
+      if (db) {
+        csum += __shfl_xor(csum, 32, 64);
+        if (lh == 0) atomicAdd(&db[kc], csum);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+}  // namespace
+
+bool mlp_fused_supported(int nb, int rows, int nl, const int* dims) {
+  if (nl < 1 || nl > MLPF_MAX_LAYERS || nb < 1 || rows < 1 || rows > 1024) return false;
+  for (int l = 0; l < nl; ++l)
+    if (dims[l] % 64 != 0 || dims[l] > MLPF_MAX_WIDTH) return false;   // every layer input: k-chunks of 64, <= 12 output tiles
+  return dims[nl] >= 1 && dims[nl] <= 256;
+}
+
+static int check(const MlpFusedArgs& a) {
+  if (!mlp_fused_supported(a.nb, a.rows, a.nl, a.dims)) return set_error(MIMRL_ERR_ARG, "mlp_fused: unsupported stack shape");
+  if (a.pstride % 4 != 0) return set_error(MIMRL_ERR_ARG, "mlp_fused: group stride must be a multiple of 4 floats");
+  return MIMRL_OK;
+}
+
+int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
+  MX(check(a));
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a) {
+  MX(check(a));
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+}  // namespace mimrl

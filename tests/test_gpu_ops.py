@@ -214,3 +214,71 @@ def test_fused_clip_adam_matches_torch_semantics(lib):
         adam.step(ref, {"w": torch.from_numpy(gr).clamp(-1.5, 1.5)}, 4e-3, 0.01)
     torch.cuda.synchronize()
     assert_close(p.cpu().numpy(), ref["w"].numpy(), 1e-5, 1e-6, "adam params")
+
+
+@pytest.mark.parametrize("nb,rows,brows,dims", [(10, 128, 128, [128, 256, 256, 256, 128]), (6, 200, 256, [384, 256, 256, 256, 2]),
+                                                 (3, 37, 64, [128, 256, 2]), (2, 32, 32, [64, 128])])
+def test_fused_mlp_stack_forward_backward(lib, nb, rows, brows, dims):
+    """mlp_fused.hip (critic towers VMI.py:13-22 / CMI classifier Model.py:47-72 as ONE kernel per direction) against a
+    torch fp32 reference that rounds the MFMA operands to bf16 the same way (so the comparison is tight)."""
+    torch.manual_seed(0)
+    nl = len(dims) - 1
+    pstride = sum(dims[l + 1] * dims[l] + dims[l + 1] for l in range(nl)) + 64
+    pstride += (-pstride) % 64
+    flat = torch.zeros(nb * pstride, device="cuda")
+    gflat = torch.zeros_like(flat)
+    offs, o = [], 0
+    for l in range(nl):
+        offs.append((o, o + dims[l + 1] * dims[l]))
+        o += dims[l + 1] * dims[l] + dims[l + 1]
+        o += (-o) % 4
+    Ws, bs = [], []
+    for g in range(nb):
+        for l in range(nl):
+            w = torch.randn(dims[l + 1], dims[l], device="cuda") / math.sqrt(dims[l])
+            b = torch.randn(dims[l + 1], device="cuda") * 0.1
+            flat[g * pstride + offs[l][0]: g * pstride + offs[l][0] + w.numel()] = w.flatten()
+            flat[g * pstride + offs[l][1]: g * pstride + offs[l][1] + b.numel()] = b
+            Ws.append(w); bs.append(b)
+    x = torch.randn(nb, brows, dims[0], device="cuda")
+    acts = [torch.zeros(nb, brows, dims[l + 1], device="cuda") for l in range(nl - 1)]
+    out = torch.zeros(nb, brows, dims[nl], device="cuda")
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
+    cdims = (C.c_int32 * (nl + 1))(*dims)
+    Wp = [flat[offs[l][0]:] for l in range(nl)]
+    bp = [flat[offs[l][1]:] for l in range(nl)]
+    _lib.check(lib.mimrl_op_mlp_stack_forward(stream(), nb, rows, brows, nl, cdims, arr(Wp), arr(bp), C.c_int64(pstride), P(x),
+                                              arr(acts + [None]), P(out)))
+    torch.cuda.synchronize()
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    # reference (per group), bf16-rounded operands, fp32 accumulate
+    dout = torch.randn(nb, brows, dims[nl], device="cuda")
+    dzs = [None] + [torch.zeros(nb, brows, dims[l], device="cuda") for l in range(1, nl)]
+    din = torch.zeros(nb, brows, dims[0], device="cuda")
+    dbp = [gflat[offs[l][1]:] for l in range(nl - 1)]
+    _lib.check(lib.mimrl_op_mlp_stack_backward(stream(), nb, rows, brows, nl, cdims, arr(Wp), C.c_int64(pstride), arr(acts + [None]),
+                                               P(dout), arr(dzs + [None]), P(din), arr(dbp + [None])))
+    torch.cuda.synchronize()
+    for g in range(nb):
+        a = x[g, :rows]
+        ref_acts = []
+        for l in range(nl):
+            z = r16(a) @ r16(Ws[g * nl + l]).T + bs[g * nl + l]
+            a = torch.relu(z) if l < nl - 1 else z
+            ref_acts.append(a)
+        for l in range(nl - 1):
+            assert_close(acts[l][g, :rows].cpu().numpy(), ref_acts[l].cpu().numpy(), 1e-2, 5e-3, f"g{g} act{l}")
+        assert_close(out[g, :rows].cpu().numpy(), ref_acts[-1].cpu().numpy(), 1e-2, 5e-3, f"g{g} out")
+        dz = dout[g, :rows]
+        for l in range(nl - 1, -1, -1):
+            d = r16(dz) @ r16(Ws[g * nl + l])
+            if l > 0:
+                d = d * (acts[l - 1][g, :rows] > 0)
+                assert_close(dzs[l][g, :rows].cpu().numpy(), d.cpu().numpy(), 1e-2, 1e-2, f"g{g} dz{l}")
+                got_db = gflat[g * pstride + offs[l - 1][1]: g * pstride + offs[l - 1][1] + dims[l]]
+                assert_close(got_db.cpu().numpy(), dzs[l][g, :rows].sum(0).cpu().numpy(), 1e-3, 1e-3, f"g{g} db{l - 1}")
+                dz = dzs[l][g, :rows]
+            else:
+                assert_close(din[g, :rows].cpu().numpy(), d.cpu().numpy(), 1e-2, 1e-2, f"g{g} din")
+        if rows < brows:
+            assert float(out[g, rows:].abs().max()) == 0.0 and float(din[g, rows:].abs().max()) == 0.0

@@ -251,3 +251,30 @@ def test_stage2_prefetch_matches_sequential(precision, use_graph):
         assert_close(pre[it][0][:64], seq[it][0][:64], max(rt, 1e-5), max(at, 1e-5), f"it{it} scalars")
     cos = float(np.dot(pre[3], seq[3]) / (np.linalg.norm(pre[3]) * np.linalg.norm(seq[3])))
     assert cos > 1 - (1e-6 if precision == "fp32" else 1e-4), cos
+
+
+def test_fused_mlp_stacks_match_unfused(monkeypatch):
+    """bf16 mode: estimator MLP stacks as fused kernels (mlp_fused.hip) vs the grouped-GEMM chain in the same precision:
+    every MI/CMI term, both losses, and the critic / main gradient buckets."""
+    res = {}
+    for tag, env in (("fused", None), ("unfused", "1")):
+        if env:
+            monkeypatch.setenv("MIMRL_NO_FUSED_MLP", env)
+        else:
+            monkeypatch.delenv("MIMRL_NO_FUSED_MLP", raising=False)
+        c, opt, batch, banks, p, eng = make_engine("cfg1_sep", precision="bf16")
+        g = load_golden("cfg1_sep")
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(1, g["anchors"][0, 0])
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.stage_grads(1)
+        gc = eng.crit["g"].double().cpu().numpy().copy()
+        eng.stage_grads(2)
+        torch.cuda.synchronize()
+        res[tag] = (eng.read_scalars().copy(), gc, eng.main["g"].double().cpu().numpy().copy())
+        eng.close()
+    (sa, ca, ma), (sb, cb, mb) = res["fused"], res["unfused"]
+    assert_close(sa[:64], sb[:64], 2e-3, 2e-4, "scalars (losses, MI / CMI terms)")
+    for name, x, y, lim in (("critic", ca, cb, 0.9995), ("main", ma, mb, 0.999)):
+        cos = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
+        assert cos > lim, f"{name} gradient direction fused vs unfused: cosine {cos}"
