@@ -38,7 +38,8 @@ class Cfg(C.Structure):
         ("coef1", C.c_float * 11), ("coef2", C.c_float * 8),
         ("weight_decay", C.c_float), ("grad_clip", C.c_float),
         ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("precision", C.c_int32), ("use_graph", C.c_int32), ("device_anchors", C.c_int32), ("seed", C.c_uint64),
+        ("precision", C.c_int32), ("use_graph", C.c_int32), ("device_anchors", C.c_int32), ("encoder", C.c_int32),
+        ("seed", C.c_uint64),
     ]
 
 
@@ -87,6 +88,7 @@ def load() -> C.CDLL:
         getattr(lib, fn).argtypes = [_FP]
     lib.mimrl_forward.argtypes = [_FP, C.c_int, C.c_int]
     lib.mimrl_layout_count.argtypes = [C.POINTER(Cfg)]
+    lib.mimrl_layout_entry_dim2.argtypes = [C.POINTER(Cfg), C.c_int]
     lib.mimrl_bucket_floats.argtypes = [C.POINTER(Cfg), C.c_int]
     lib.mimrl_layout_entry.argtypes = [C.POINTER(Cfg), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -94,8 +96,10 @@ def load() -> C.CDLL:
     return lib
 
 
+ENCODERS = {"gru": 0, "conv": 1}                                             # MIMRL_ENCODER_*
+
 EXPORTS = [
-    "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry",
+    "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry", "mimrl_layout_entry_dim2",
     "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_stage1_step", "mimrl_stage2_step",
     "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read",
     "mimrl_workspace_bytes", "mimrl_set_stage2_prefetch", "mimrl_destroy", "mimrl_op_gemm",
@@ -118,8 +122,10 @@ def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capaci
     c.time_len = int(opt.time_len)
     c.seq_len = int(seq_len if seq_len is not None else opt.time_len)
     c.d_t, c.d_a, c.d_v, c.d_common = int(d_t), int(d_a), int(d_v), int(opt.d_common)
-    if getattr(opt, "encoders", "gru") != "gru":
-        raise MimrlError(f"--encoders {opt.encoders}: only 'gru' is on the MI355X hot path (lstm/conv: SURVEY.md 8f N3)")
+    enc = getattr(opt, "encoders", "gru")
+    if enc not in ENCODERS:
+        raise MimrlError(f"--encoders {enc}: gru and conv are built for the MI355X hot path (lstm: SURVEY.md 8f N3)")
+    c.encoder = ENCODERS[enc]
     nb = len(opt.d_hiddens)
     if nb > MAX_BLOCKS or len(opt.d_outs) != nb or len(opt.res_project) != nb:
         raise MimrlError("d_hiddens / d_outs / res_project must have the same length (<= 4)")   # MLPProcess.py:129
@@ -181,6 +187,8 @@ def layout_entries(cfg: Cfg) -> Tuple[List[Tuple[str, int, int, Tuple[int, ...]]
     for i in range(n):
         check(lib.mimrl_layout_entry(C.byref(cfg), i, name, 256, C.byref(g), C.byref(off), C.byref(nd), C.byref(d0), C.byref(d1)))
         shape = (d0.value, d1.value) if nd.value == 2 else (d0.value,)
+        if nd.value == 3:
+            shape = (d0.value, d1.value, check(lib.mimrl_layout_entry_dim2(C.byref(cfg), i)))
         out.append((name.value.decode(), g.value, off.value, shape))
     sizes = (check(lib.mimrl_bucket_floats(C.byref(cfg), 0)), check(lib.mimrl_bucket_floats(C.byref(cfg), 1)))
     return out, sizes

@@ -99,7 +99,7 @@ __global__ void finalize_stage2_kernel(float* scal, const float* mi, const float
 }
 
 struct Lin { long w = -1, b = -1; int out = 0, in = 0; };
-struct GruDirW { long w_ih, w_hh, b_ih, b_hh; int din; };
+struct GruDirW { long w_ih = 0, w_hh = 0, b_ih = 0, b_hh = 0; int din = 0; };
 struct AxisW { Lin fc1, fc2; long res = -1, ln_g = -1, ln_b = -1; int in = 0, hid = 0, out = 0; };
 struct BlockW { AxisW ax[3]; };
 struct MixBuf { float *xn = nullptr, *xn_mean = nullptr, *xn_rstd = nullptr, *u = nullptr, *h = nullptr, *y = nullptr,
@@ -176,7 +176,7 @@ struct mimrl_handle {
   // backward temporaries
   float *dfeat = nullptr, *dtout = nullptr, *dta[3], *dtin = nullptr, *dca[2], *dP = nullptr, *dQ = nullptr;
   float *dcc[3], *dcin = nullptr;
-  static constexpr int NGBUF = 16;   // cube backward: rotating (4 in use) or one-shot (deferred weight gradients)
+  static constexpr int NGBUF = 24;   // cube backward: rotating (4 in use) or one-shot (deferred weight gradients)
   float* gbuf[NGBUF];
   size_t gbuf_floats = 0;
   float *dtx = nullptr, *ds[2], *dg[2][2][2], *hprev[2][2][2], *dh0[2];   // [layer][mod][dir]; dg = [dr'|dz'|dn'|dn'r] rows of 4H
@@ -263,6 +263,10 @@ struct mimrl_handle {
   float* Gm(long off) const { return bufs.main_g + off; }
   float* CP(long off) const { return bufs.crit_p + off; }
   float* CG(long off) const { return bufs.crit_g + off; }
+  long conv_w[2] = {0, 0}, conv_b[2] = {0, 0};   // --encoders conv: Conv1d weight [D, d, 3] / bias offsets (audio, video)
+  int encoders_forward(bool save, int knn_stage);
+  int conv_forward(int knn_stage);
+  int conv_backward();
   int rng_add = 0;
   RngKey key() const { return RngKey{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, rng_add}; }
   const float* coef1() const { return d_consts; }
@@ -334,7 +338,11 @@ int mimrl_handle::resolve() {
   };
   const char* modn[2] = {"rnn_a", "rnn_v"};
   const int dmod[2] = {cfg.d_a, cfg.d_v};
-  for (int m = 0; m < 2; ++m)
+  if (cfg.encoder == MIMRL_ENCODER_CONV) {
+    MX(off("conv_a.weight", &conv_w[0])); MX(off("conv_a.bias", &conv_b[0]));
+    MX(off("conv_v.weight", &conv_w[1])); MX(off("conv_v.bias", &conv_b[1]));
+  }
+  for (int m = 0; m < 2 && cfg.encoder == MIMRL_ENCODER_GRU; ++m)
     for (int l = 0; l < 2; ++l)
       for (int d = 0; d < 2; ++d) {
         const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
@@ -545,17 +553,14 @@ int mimrl_handle::alloc_workspace() {
 // =================================================================================================
 // model forward
 // =================================================================================================
-int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
-  const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+// audio / video encoders: h1[m][B,T,2H] whose two halves the LN+ReLU+dropout epilogue adds (forward + reverse direction
+// of the bi-GRU; the conv encoder writes the first half only, the second stays zero)
+int mimrl_handle::encoders_forward(bool save, int knn_stage) {
+  if (cfg.encoder == MIMRL_ENCODER_CONV) return conv_forward(knn_stage);
+  const int B = cfg.batch, T = cfg.seq_len;
   const long BT_ = (long)B * T;
   const float* xin[2] = {bufs.audio, bufs.video};
   const int dmod[2] = {cfg.d_a, cfg.d_v};
-  const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
-  if (T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
-  MX(fork(0, 5));
-  // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
-  { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
-  MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
   // lengths (Model.py:425-432): only the recurrence needs them -> sides 4/5, next to the input projections
   for (int m = 0; m < 2; ++m) MX(seq_lengths(S(4 + m), xin[m], B, T, dmod[m], lens[m]));
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
@@ -594,6 +599,48 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
     }
     { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
   }
+  return MIMRL_OK;
+}
+
+// Conv1d(d, 128, kernel 3, padding 1) over time (Model.py:247-249,437-439) as three shifted GEMMs per modality:
+// y[b,t] = b + W[:,:,0] x[b,t-1] + W[:,:,1] x[b,t] + W[:,:,2] x[b,t+1]; the zero padding is the row range of each tap.
+int mimrl_handle::conv_forward(int knn_stage) {
+  const int B = cfg.batch, T = cfg.seq_len;
+  const float* xin[2] = {bufs.audio, bufs.video};
+  const int dmod[2] = {cfg.d_a, cfg.d_v};
+  if (knn_stage) { MX(fork(4, 4)); MX(knn_launch(knn_stage, S(4))); }
+  MX(fork(2, 2));
+  for (int m = 0; m < 2; ++m) {
+    const int d = dmod[m];
+    hipStream_t st = m == 0 ? stream : S(2);
+    const int order[3] = {1, 0, 2};                     // the centre tap covers every row: it initialises the output
+    for (int q = 0; q < 3; ++q) {
+      const int tap = order[q];
+      const int rows = tap == 1 ? T : T - 1;
+      if (rows <= 0) continue;
+      GemmDesc g;
+      g.A = xin[m] + (tap == 2 ? d : 0); g.sa_m = d; g.sa_k = 1; g.sa_b = (long)T * d;
+      g.B = P(conv_w[m]) + tap; g.sb_k = 3; g.sb_n = 3L * d; g.sb_b = 0;
+      g.C = h1[m] + (tap == 0 ? 2 * H : 0); g.sc_m = 2 * H; g.sc_n = 1; g.sc_b = (long)T * 2 * H;
+      g.M = rows; g.N = H; g.K = d; g.batch = B;
+      if (tap == 1) g.bias_n = P(conv_b[m]); else g.beta = 1.f;
+      MX(G_on(st, g));
+    }
+  }
+  MX(join(2, 2));
+  return MIMRL_OK;
+}
+
+int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
+  const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+  const long BT_ = (long)B * T;
+  const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
+  if (T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
+  MX(fork(0, 5));
+  // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
+  { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
+  MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+  MX(encoders_forward(save, knn_stage));
   MX(join(0, 0));
   // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
   for (int m = 0; m < 2; ++m)
@@ -749,7 +796,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     for (int ax = 0; ax < 3; ++ax) dims[i + 1][ax] = cfg.d_outs[i][ax];
   // deferred mode: every gradient buffer is used once (weight-gradient GEMMs read dY / dU after the chain has moved on)
   static const bool no_defer = getenv("MIMRL_NO_DEFER_WGRAD") != nullptr;   // tuning knob
-  const bool defer = multi_stream && !cfg.ln_first && !no_defer && 7 * cfg.n_blocks + 1 <= NGBUF;
+  const int per_block = 7 + (cfg.dropout_mlp[0] > 0.f) + (cfg.dropout_mlp[2] > 0.f);   // buffers one block consumes
+  const bool defer = multi_stream && !cfg.ln_first && !no_defer && per_block * cfg.n_blocks + 1 <= NGBUF;
   const int npool = defer ? NGBUF : 4;
   int used[NGBUF] = {0};
   used[cur_in] = 1;
@@ -979,6 +1027,11 @@ int mimrl_handle::model_backward() {
     MX(ln_relu_drop_bwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dcube, ds[m], Gm(ln_g[m]),
                         Gm(ln_b[m]), B, T, L, 3, D, 1 + m, cfg.dropout[1 + m], key(), 1 + m));
   MX(flush_deferred());   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT
+  if (cfg.encoder == MIMRL_ENCODER_CONV) {
+    MX(conv_backward());
+    MX(join(0, 5));
+    return MIMRL_OK;
+  }
   const float* xin[2] = {bufs.audio, bufs.video};
   for (int l = 1; l >= 0; --l) {
     GruBwdArgs a;
@@ -1035,6 +1088,32 @@ int mimrl_handle::model_backward() {
     }
   }
   MX(join(0, 5));
+  return MIMRL_OK;
+}
+
+// Conv1d encoder backward: the inputs are data, so only dW[:, :, tap] = sum_b dy_b[rows]^T x_b[shifted rows] and the bias
+// gradient are needed (three batch-reduced GEMMs per modality, off the critical path by construction: nothing follows)
+int mimrl_handle::conv_backward() {
+  const int B = cfg.batch, T = cfg.seq_len;
+  const float* xin[2] = {bufs.audio, bufs.video};
+  const int dmod[2] = {cfg.d_a, cfg.d_v};
+  MX(fork(1, 3));
+  int rr = 0;
+  for (int m = 0; m < 2; ++m) {
+    const int d = dmod[m];
+    for (int tap = 0; tap < 3; ++tap) {
+      const int rows = tap == 1 ? T : T - 1;
+      if (rows <= 0) continue;
+      GemmDesc g;
+      g.A = ds[m] + (tap == 0 ? H : 0); g.sa_m = 1; g.sa_k = H; g.sa_b = (long)T * H;
+      g.B = xin[m] + (tap == 2 ? d : 0); g.sb_k = d; g.sb_n = 1; g.sb_b = (long)T * d;
+      g.C = Gm(conv_w[m]) + tap; g.sc_m = 3L * d; g.sc_n = 3; g.sc_b = 0;
+      g.M = H; g.N = d; g.K = rows; g.batch = B; g.atomic = 1;
+      const int q = rr++ % 4;
+      MX(G_on(q == 0 ? stream : S(q), g));
+    }
+    MX(colsum(stream, ds[m], (long)B * T, H, H, Gm(conv_b[m])));
+  }
   return MIMRL_OK;
 }
 

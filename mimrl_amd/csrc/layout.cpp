@@ -23,6 +23,8 @@ int validate_cfg(const mimrl_cfg& c) {
   if (c.k_neighbor < 1 || c.k_neighbor > 8) return set_error(MIMRL_ERR_ARG, "k_neighbor must be in [1,8]");
   if (c.batch / c.k_neighbor < 1) return set_error(MIMRL_ERR_ARG, "batch smaller than k_neighbor");
   if (c.d_t < 1 || c.d_a < 1 || c.d_v < 1) return set_error(MIMRL_ERR_ARG, "feature dims must be positive");
+  if (c.encoder != MIMRL_ENCODER_GRU && c.encoder != MIMRL_ENCODER_CONV)
+    return set_error(MIMRL_ERR_ARG, "encoder must be gru|conv (lstm is not built, SURVEY.md 8f N3)");
   int din[3] = {c.time_len, 3, c.d_common};
   for (int i = 0; i < c.n_blocks; ++i) {
     for (int ax = 0; ax < 3; ++ax) {
@@ -45,12 +47,13 @@ int build_layout(const mimrl_cfg& c, Layout* out) {
   out->entries.clear();
   out->index.clear();
   out->floats[0] = out->floats[1] = 0;
-  auto add = [&](const std::string& name, int d0, int d1) {
+  auto add = [&](const std::string& name, int d0, int d1, int d2 = 0) {
     LayoutEntry e;
     e.name = name;
-    e.ndim = d1 > 0 ? 2 : 1;
+    e.ndim = d2 > 0 ? 3 : d1 > 0 ? 2 : 1;
     e.d0 = d0;
     e.d1 = d1 > 0 ? d1 : 0;
+    e.d2 = d2 > 0 ? d2 : 0;
     e.group = (name.find("vmi") != std::string::npos || name.find("vcmi") != std::string::npos) ? MIMRL_GROUP_CRITIC
                                                                                                 : MIMRL_GROUP_MAIN;
     e.offset = out->floats[e.group];
@@ -59,9 +62,13 @@ int build_layout(const mimrl_cfg& c, Layout* out) {
     out->entries.push_back(e);
   };
   const int D = c.d_common, H = D;
+  if (c.encoder == MIMRL_ENCODER_CONV) {   // Model.py:247-249: Conv1d(d, d_common, kernel 3, padding 1), weight [out, in, 3]
+    add("conv_a.weight", D, c.d_a, 3); add("conv_a.bias", D, 0);
+    add("conv_v.weight", D, c.d_v, 3); add("conv_v.bias", D, 0);
+  }
   const struct { const char* nm; int d; } mods[2] = {{"rnn_v", c.d_v}, {"rnn_a", c.d_a}};
   for (auto& m : mods)
-    for (int layer = 0; layer < 2; ++layer) {
+    for (int layer = 0; layer < (c.encoder == MIMRL_ENCODER_GRU ? 2 : 0); ++layer) {
       const int din = layer == 0 ? m.d : 2 * H;
       for (const char* sfx : {"", "_reverse"}) {
         const std::string l = "_l" + std::to_string(layer) + sfx;
@@ -156,6 +163,15 @@ int mimrl_layout_entry(const mimrl_cfg* cfg, int idx, char* name, int name_cap, 
   if (dim0) *dim0 = e.d0;
   if (dim1) *dim1 = e.d1;
   return MIMRL_OK;
+}
+
+int mimrl_layout_entry_dim2(const mimrl_cfg* cfg, int idx) {
+  if (!cfg) return mimrl::set_error(MIMRL_ERR_ARG, "bad arguments");
+  mimrl::Layout L;
+  const int r = mimrl::build_layout(*cfg, &L);
+  if (r != 0) return r;
+  if (idx < 0 || idx >= (int)L.entries.size()) return mimrl::set_error(MIMRL_ERR_ARG, "layout index out of range");
+  return L.entries[idx].d2;
 }
 
 int64_t mimrl_bucket_floats(const mimrl_cfg* cfg, int group) {

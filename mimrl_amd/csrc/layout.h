@@ -11,10 +11,10 @@ namespace mimrl {
 struct LayoutEntry {
   std::string name;
   int ndim = 1;
-  int d0 = 0, d1 = 0;     // [d0] or [d0,d1]
+  int d0 = 0, d1 = 0, d2 = 0;   // [d0], [d0,d1] or [d0,d1,d2]
   int group = MIMRL_GROUP_MAIN;
   long offset = 0;        // floats, 64-aligned
-  long numel() const { return ndim == 2 ? (long)d0 * d1 : d0; }
+  long numel() const { return ndim == 3 ? (long)d0 * d1 * d2 : ndim == 2 ? (long)d0 * d1 : d0; }
 };
 
 struct Layout {

@@ -40,9 +40,14 @@ def named_shapes(opt, d_t: int, d_a: int, d_v: int) -> List[Tuple[str, Tuple[int
     D = int(opt.d_common)
     H = D
     out: List[Tuple[str, Tuple[int, ...]]] = []
+    enc = getattr(opt, "encoders", "gru")
+    if enc == "conv":                                                     # Model.py:247-249 (conv_a before conv_v)
+        out += [("conv_a.weight", (D, d_a, 3)), ("conv_a.bias", (D,)), ("conv_v.weight", (D, d_v, 3)), ("conv_v.bias", (D,))]
+    elif enc != "gru":
+        raise NotImplementedError(f"--encoders {enc} (lstm is not built: SURVEY.md 8f N3)")
     # rnn_v is registered before rnn_a in the reference (Model.py:254-255)
     for mod, d in (("rnn_v", d_v), ("rnn_a", d_a)):
-        for layer in range(2):
+        for layer in range(2 if enc == "gru" else 0):
             din = d if layer == 0 else 2 * H
             for sfx in ("", "_reverse"):
                 out += [(f"{mod}.weight_ih_l{layer}{sfx}", (3 * H, din)), (f"{mod}.weight_hh_l{layer}{sfx}", (3 * H, H)),

@@ -28,7 +28,7 @@ def portable_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndar
     if is_ln:
         u = g.uniform(-0.1, 0.1, size=shape)
         return (1.0 + u if name.endswith("weight") else u).astype(np.float32)
-    fan_in = shape[1] if len(shape) == 2 else shape[0]
+    fan_in = int(np.prod(shape[1:])) if len(shape) >= 2 else shape[0]      # Linear [out,in] / Conv1d [out,in,k]
     del base
     bound = 1.0 / np.sqrt(max(fan_in, 1))
     return g.uniform(-bound, bound, size=shape).astype(np.float32)
@@ -57,7 +57,7 @@ def default_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarr
     if parts[0].startswith("rnn_"):
         bound = 1.0 / np.sqrt(128.0)
     else:
-        fan_in = shape[1] if len(shape) == 2 else None
+        fan_in = int(np.prod(shape[1:])) if len(shape) >= 2 else None
         if fan_in is None:                       # bias: fan_in of its weight is unknown here -> use own length
             fan_in = shape[0]
         bound = 1.0 / np.sqrt(max(fan_in, 1))

@@ -154,10 +154,15 @@ def model_forward(p: Params, opt, t_feat: Tensor, a: Tensor, v: Tensor,
     't','a','v' ([B,T,128]) so that a device run with the same masks is comparable."""
     masks = masks or {}
     t = t_feat @ p["W_t.weight"].t()                            # Model.py:395
-    la, lv = infer_lengths(a), infer_lengths(v)                 # Model.py:425-432
-    ah = bigru2(p, "rnn_a", a, la)                              # Model.py:441-453
-    vh = bigru2(p, "rnn_v", v, lv)
     D = opt.d_common
+    if getattr(opt, "encoders", "gru") == "conv":               # Model.py:247-249,437-438: Conv1d(k=3, padding=1) over time
+        conv = lambda x, m: F.conv1d(x.transpose(1, 2), p[f"conv_{m}.weight"].reshape(D, x.shape[-1], 3), p[f"conv_{m}.bias"],
+                                     padding=1).transpose(1, 2)
+        ah, vh = conv(a, "a"), conv(v, "v")
+    else:
+        la, lv = infer_lengths(a), infer_lengths(v)             # Model.py:425-432
+        ah = bigru2(p, "rnn_a", a, la)                          # Model.py:441-453
+        vh = bigru2(p, "rnn_v", v, lv)
     ah = F.relu(F.layer_norm(ah, (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))   # Model.py:457
     vh = F.relu(F.layer_norm(vh, (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
     t = _dropout(t, opt.dropout[0], masks.get("t"))             # Model.py:461

@@ -10,6 +10,8 @@ CONFIGS = {
     # ln_first CubeMLP variant + hardtanh CMI head + nwj bound (flag-reachable alternatives)
     "tiny_alt": dict(B=8, T=6, N=40, seed=4, critic="concat", cube="6-3-128=4-3-128", traj=1,
                      ln_first=True, cmi_last="hardtanh", bound="nwj"),
+    # --encoders conv (Conv1d k=3 over time instead of the bi-GRUs, Model.py:247-249,437-439), ragged inputs
+    "tiny_conv": dict(B=8, T=6, N=40, seed=5, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="conv"),
     # BASELINE cfg1: B=32, T=50, canonical README flags, N=1000 as in the reference smoke test (Model.py:607)
     "cfg1_sep": dict(B=32, T=50, N=1000, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=6),
     "cfg1_cat": dict(B=32, T=50, N=1000, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
@@ -24,7 +26,7 @@ def make_opt(c):
     """The subset of Parameters.py flags the hot path reads, README values."""
     cube = parse_cube(c["cube"])
     return SimpleNamespace(
-        batch_size=c["B"], d_common=128, encoders="gru", features_compose_t="mean", features_compose_k="mean",
+        batch_size=c["B"], d_common=128, encoders=c.get("encoders", "gru"), features_compose_t="mean", features_compose_k="mean",
         num_class=1, activate="gelu", time_len=c["T"], d_hiddens=cube, d_outs=cube,
         dropout_mlp=[0.0, 0.0, 0.0], dropout=[0.0, 0.0, 0.0, 0.0], bias=True, ln_first=c.get("ln_first", False),
         res_project=[True] * len(cube), critic_type=c["critic"], baseline_type="constant",

@@ -11,7 +11,7 @@ from tests.helpers import case, load_golden, oracle_params
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt"]
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv"]
 ALL = TINY + ["cfg1_sep", "cfg1_cat"]
 
 
@@ -105,7 +105,7 @@ def test_stage_losses_and_all_gradients_vs_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "cfg1_sep"])
+@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "cfg1_sep"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_two_stage_trajectory(name, use_graph):
     """Alternating stage-1/stage-2 updates (Solver.step) vs the reference trajectory and the oracle."""
@@ -220,6 +220,7 @@ def test_stage2_prefetch_matches_sequential(precision, use_graph):
         c, opt, batch, banks = case(name)
         opt = copy.copy(opt)
         opt.dropout = [0.1, 0.1, 0.1, 0.1]
+        opt.dropout_mlp = [0.1, 0.1, 0.1]         # also exercises the unfused CubeMLP path with its dropped-out gradient buffers
         eng = HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision=precision, use_graph=use_graph)
         eng.load_params(oracle_params(opt, c["seed"]))
         eng.set_batch(*batch)
@@ -250,7 +251,7 @@ def test_stage2_prefetch_matches_sequential(precision, use_graph):
         assert_close(pre[it][2], seq[it][2], rt, at, f"it{it} feats")
         assert_close(pre[it][0][:64], seq[it][0][:64], max(rt, 1e-5), max(at, 1e-5), f"it{it} scalars")
     cos = float(np.dot(pre[3], seq[3]) / (np.linalg.norm(pre[3]) * np.linalg.norm(seq[3])))
-    assert cos > 1 - (1e-6 if precision == "fp32" else 1e-4), cos
+    assert cos > 1 - (1e-6 if precision == "fp32" else 1e-3), cos
 
 
 def test_fused_mlp_stacks_match_unfused(monkeypatch):
