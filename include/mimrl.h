@@ -29,7 +29,7 @@ enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -
 enum { MIMRL_GROUP_MAIN = 0, MIMRL_GROUP_CRITIC = 1 };
 enum { MIMRL_CRITIC_SEPARATE = 0, MIMRL_CRITIC_CONCAT = 1 };                       /* VMI.py:35-45 */
 enum { MIMRL_BOUND_INFONCE = 0, MIMRL_BOUND_NWJ, MIMRL_BOUND_TUBA, MIMRL_BOUND_DV, MIMRL_BOUND_JS_FGAN,
-       MIMRL_BOUND_JS, MIMRL_BOUND_SMILE };                                        /* Model.py:121-146 */
+       MIMRL_BOUND_JS, MIMRL_BOUND_SMILE, MIMRL_BOUND_MINE };                                        /* Model.py:121-146 */
 enum { MIMRL_ACT_NONE = 0, MIMRL_ACT_RELU = 1, MIMRL_ACT_GELU = 2, MIMRL_ACT_TANH = 3 };
 /* MFMA operand type per section (bit mask); accumulation, recurrent state, statistics and optimizer are always fp32 */
 enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16_GEMM_FWD = 1, MIMRL_PREC_BF16_GEMM_BWD = 2, MIMRL_PREC_BF16_GRU_FWD = 4,
@@ -146,6 +146,10 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
                           float* dg_r, float* hprev_f, float* hprev_r, int B, int T, int precision);
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
                       int bound);
+/* same + the estimators' loss terms (mi_loss of Model.py:115-148; differs from -mi only for `mine`); bit e of lossform:
+ * estimator e enters the objective through its loss term (all in stage 1; f_t,f_a,f_v in stage 2, Model.py:386) */
+int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, float* mi, float* mi_loss, const float* gscale,
+                         int E, int B, int bound, uint32_t lossform);
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
                       const float* g_cmi, int E, int n, int hardtanh);

@@ -13,7 +13,7 @@ NSCALARS = 64
 PHASES = ["gemm_misc", "gru_fwd", "gru_bwd", "cube_fwd", "cube_bwd", "est_fwd", "est_bwd", "opt", "model_misc"]
 S1_LOSS, S1_MIS, S1_LOSSES, S2_LOSS, S2_TASK, S2_MIS, S2_LOSSES = 0, 1, 12, 32, 33, 34, 42
 
-BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6}
+BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6, "mine": 7}
 ACTS = {"none": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"fp32": 0, "bf16": 15, "bf16_fwd": 5, "bf16_gemm_fwd": 1, "bf16_gemm_bwd": 2, "bf16_gru": 12, "bf16_gru_fwd": 4,
         "bf16_gru_bwd": 8, "bf16_nogemmbwd": 13}
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.mimrl_op_gru_forward.argtypes = [_FP] * 11 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_gru_backward.argtypes = [_FP] * 12 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_mi_bound.argtypes = [_FP] * 5 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_mi_bound_ex.argtypes = [_FP] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint32]
     lib.mimrl_op_knn.argtypes = [_FP, _FP, C.c_int, C.c_int, _FP, C.c_int, C.c_int, _FP]
     lib.mimrl_op_cmi_loss.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_create.argtypes = [C.POINTER(Cfg), _FP, C.POINTER(_FP)]
@@ -103,7 +104,7 @@ EXPORTS = [
     "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_stage1_step", "mimrl_stage2_step",
     "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read",
     "mimrl_workspace_bytes", "mimrl_set_stage2_prefetch", "mimrl_destroy", "mimrl_op_gemm",
-    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_knn",
+    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
 ]
 

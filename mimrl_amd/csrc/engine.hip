@@ -62,8 +62,8 @@ __global__ void finalize_stage1_kernel(float* scal, const float* mi, const float
   float loss = 0.f;
   for (int e = 0; e < NE_MI; ++e) {
     scal[MIMRL_S1_MIS + e] = mi[e];
-    scal[MIMRL_S1_LOSSES + e] = -mi[e];
-    loss += coef1[e] * -mi[e];
+    scal[MIMRL_S1_LOSSES + e] = mi[NE_MI + e];        // mi_loss (= -mi except for the `mine` bound)
+    loss += coef1[e] * mi[NE_MI + e];
   }
   for (int e = 0; e < NE_CMI; ++e) {
     scal[MIMRL_S1_MIS + NE_MI + e] = cmi[e];
@@ -91,9 +91,10 @@ __global__ void finalize_stage2_kernel(float* scal, const float* mi, const float
   v[7] = ta_c + tv_c;
   float loss = task;
   for (int i = 0; i < 8; ++i) {
+    const float li = i < 3 ? mi[NE_MI + i] : -v[i];   // Model.py:386: f_t, f_a, f_v through their mi_loss, the rest through -value
     scal[MIMRL_S2_MIS + i] = v[i];
-    scal[MIMRL_S2_LOSSES + i] = -v[i];
-    loss += coef2[i] * -v[i];
+    scal[MIMRL_S2_LOSSES + i] = li;
+    loss += coef2[i] * li;
   }
   scal[MIMRL_S2_LOSS] = loss;
 }
@@ -507,7 +508,7 @@ int mimrl_handle::carve() {
   MX(take(&dlogits, NE_CMI * 2 * n * 2));
   for (int l = 0; l < 3; ++l) MX(take(&dcc[l], NE_CMI * 2 * n * HID));
   MX(take(&dcin, NE_CMI * 2 * n * 384));
-  MX(take(&mi_raw, 8)); MX(take(&cmi_raw, 8)); MX(take(&bce_raw, 8));
+  MX(take(&mi_raw, 16)); MX(take(&cmi_raw, 8)); MX(take(&bce_raw, 8));   // mi_raw: 5 values + 5 loss terms
   MX(take(&dfeat, 4 * B * D));
   gbuf_floats = gmax;
   for (int i = 0; i < NGBUF; ++i) MX(take(&gbuf[i], gmax));
@@ -1264,7 +1265,8 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
     const int dims[4] = {HID, HID, HID, 1};
     MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
   }
-  return mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, gs_mi(stage), NE_MI, B, cfg.bound_type);
+  return mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B,
+                          cfg.bound_type, stage == 1 ? 0x1fu : 0x07u);
 }
 
 int mimrl_handle::cmi_forward(int stage, bool want_grad) {
@@ -1759,7 +1761,11 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
 
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
                       int bound) {
-  return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, gscale, E, B, bound);
+  return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, nullptr, gscale, E, B, bound, 0u);
+}
+int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, float* mi, float* mi_loss, const float* gscale,
+                         int E, int B, int bound, uint32_t lossform) {
+  return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, mi_loss, gscale, E, B, bound, lossform);
 }
 
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out) {

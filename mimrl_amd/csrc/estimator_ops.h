@@ -5,7 +5,7 @@
 namespace mimrl {
 
 enum Bound : int { BOUND_INFONCE = 0, BOUND_NWJ = 1, BOUND_TUBA = 2, BOUND_DV = 3, BOUND_JS_FGAN = 4, BOUND_JS = 5,
-                   BOUND_SMILE = 6 };
+                   BOUND_SMILE = 6, BOUND_MINE = 7 };
 
 // copy rows:  dst[i][b,:] = src[i][b,:]   for i < n (table of pointers; used to gather tower inputs)
 struct CopyTable { const float* src[16]; float* dst[16]; int n; };
@@ -13,8 +13,8 @@ int copy_rows(hipStream_t s, const CopyTable& t, long floats_each);
 
 // scores [E][B][B] -> mi[e] (bound value) and dscores = gscale[e] * d(mi)/d(scores)   (one workgroup / estimator)
 // gscale lives in device memory (loss coefficient with sign); dscores may be null (evaluation only).
-int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
-                     int bound);
+int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
+                     int B, int bound, unsigned lossform);
 
 // concat critic layer 1:  a1[(i*B+j), c] = relu(P[i,c] + Q[j,c])     P = x Wx^T, Q = y Wy^T + b   (VMI.py:59-65)
 int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, int E, int B, int Hd);

@@ -22,9 +22,13 @@ __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + lo
 // ------------------------------------------------------------------------------------------------
 // MI bounds on a [B,B] score matrix; one 1024-thread workgroup per estimator, deterministic reductions.
 // ------------------------------------------------------------------------------------------------
+// mi[e] = bound value; mil[e] (optional) = the estimator's loss term: -mi for every bound except `mine`, whose loss is
+// mean(diag) - mean(exp_nodiag) / ma_et with ma_et = 0.99 + 0.01 mean(exp_nodiag) detached and NOT negated
+// (Model.py:121-125).  Bit e of `lossform` says whether estimator e contributes through that loss (stage 1: all five,
+// stage 2: f_t, f_a, f_v -- t_a and t_v enter through -mi, Model.py:386) -- it selects the gradient written to dscores.
 __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict__ scores, float* __restrict__ dscores,
-                                                        float* __restrict__ mi, const float* __restrict__ gscale, int B,
-                                                        int bound) {
+                                                        float* __restrict__ mi, float* __restrict__ mil,
+                                                        const float* __restrict__ gscale, int B, int bound, unsigned lossform) {
   __shared__ float red[16];
   __shared__ float rowstat[1024];   // per-row lse (InfoNCE); B <= 1024
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict_
       if (lane == 0) { rowstat[i] = lse; part += S[(long)i * B + i] - lse; }
     }
     const float tot = block_sum(part, red);
-    if (tid == 0) mi[e] = __logf((float)B) + tot * invB;
+    if (tid == 0) { mi[e] = __logf((float)B) + tot * invB; if (mil) mil[e] = -mi[e]; }
     if (dS) {
       __syncthreads();
       for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
@@ -93,16 +97,27 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict_
     case BOUND_DV: val = dmean - lme; break;
     case BOUND_JS_FGAN: val = js; break;
     case BOUND_JS: val = 1.f + (dmean - 1.f) - __expf(lme); break;        // value of nwj, gradient of js
-    default: val = dmean - lme; break;                                    // SMILE: value dv(clamped lme), gradient js
+    default: val = dmean - lme; break;                                    // SMILE: value dv(clamped lme), gradient js; MINE: dv value
   }
-  if (tid == 0) mi[e] = val;
+  const bool mine_loss = bound == BOUND_MINE && ((lossform >> e) & 1u);
+  const float mean_et = __expf(mx) * se / ((float)B * B);                 // mean over all B^2 entries, diagonal = 0 (VMI.py:128-133)
+  const float ma_et = 0.99f + 0.01f * mean_et;
+  if (tid == 0) { mi[e] = val; if (mil) mil[e] = mine_loss ? dmean - mean_et / ma_et : -val; }
   if (!dS) return;
+  if (mine_loss) {   // gs = -coefficient (d total / d mi for a "-mi" loss); here the loss enters with +coefficient
+    const float c = -gs;
+    for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+      const int i = idx / B, j = idx % B;
+      dS[idx] = c * ((i == j) ? invB : -__expf(S[idx]) / (ma_et * (float)B * B));
+    }
+    return;
+  }
   for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
     const int i = idx / B, j = idx % B;
     const float v = S[idx];
     float g;
     if (bound == BOUND_TUBA || bound == BOUND_NWJ) g = (i == j) ? invB : -__expf(v - shift) / M;
-    else if (bound == BOUND_DV) g = (i == j) ? invB : -__expf(v - mx) / se;
+    else if (bound == BOUND_DV || bound == BOUND_MINE) g = (i == j) ? invB : -__expf(v - mx) / se;
     else g = (i == j) ? sigmoid_f(-v) * invB : -sigmoid_f(v) / M;          // js_fgan / js / smile
     dS[idx] = gs * g;
   }
@@ -370,10 +385,10 @@ int copy_rows(hipStream_t s, const CopyTable& t, long n) {
   return MIMRL_OK;
 }
 
-int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
-                     int bound) {
+int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
+                     int B, int bound, unsigned lossform) {
   if (B > 1024) return set_error(MIMRL_ERR_ARG, "mi_bound: batch %d > 1024 per rank", B);
-  hipLaunchKernelGGL(mi_bound_kernel, dim3(E), dim3(1024), 0, s, scores, dscores, mi, gscale, B, bound);
+  hipLaunchKernelGGL(mi_bound_kernel, dim3(E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B, bound, lossform);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -266,6 +266,13 @@ BOUNDS = {"infonce": infonce_lower_bound, "nwj": nwj_lower_bound, "tuba": tuba_l
 def vmi_estimate(p: Params, name: str, opt, x: Tensor, y: Tensor) -> Tuple[Tensor, Tensor]:
     """VMIEstimator.forward (Model.py:115-148), constant baseline.  -> (mi, mi_loss)"""
     s = critic_scores(p, name, opt.critic_type, x, y)
+    if opt.bound_type == "mine":                                # Model.py:121-125 + VMI.py:128-133,142-145
+        B = s.shape[0]
+        t = s.diag()
+        et = torch.exp(s) * (1.0 - torch.eye(B, dtype=s.dtype))    # exp_nodiag: exp(-inf) = 0 on the diagonal
+        mi = t.mean() - _logmeanexp_nodiag(s)
+        ma_et = (1 - 0.01) * 1 + 0.01 * et.mean()
+        return mi, t.mean() - (1 / ma_et.mean()).detach() * et.mean()   # NB: not negated in the reference
     mi = BOUNDS[opt.bound_type](s)
     return mi, -mi
 

@@ -12,6 +12,8 @@ CONFIGS = {
                      ln_first=True, cmi_last="hardtanh", bound="nwj"),
     # --encoders conv (Conv1d k=3 over time instead of the bi-GRUs, Model.py:247-249,437-439), ragged inputs
     "tiny_conv": dict(B=8, T=6, N=40, seed=5, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="conv"),
+    # mine bound: its loss term is not -mi (Model.py:121-125), and stage 2 mixes both forms (Model.py:386)
+    "tiny_mine": dict(B=8, T=6, N=40, seed=6, critic="separate", cube="6-3-128=4-3-128", traj=2, bound="mine"),
     # BASELINE cfg1: B=32, T=50, canonical README flags, N=1000 as in the reference smoke test (Model.py:607)
     "cfg1_sep": dict(B=32, T=50, N=1000, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=6),
     "cfg1_cat": dict(B=32, T=50, N=1000, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),

@@ -129,7 +129,7 @@ def test_gru_layer_forward_backward(lib, B, T, ragged, prec):
     grad_close(dx.reshape(B, T, -1), xt.grad.numpy(), rel, "dx")
 
 
-@pytest.mark.parametrize("bound", list(_lib.BOUNDS))
+@pytest.mark.parametrize("bound", [b for b in _lib.BOUNDS if b != "mine"])
 @pytest.mark.parametrize("B", [8, 32, 128])
 def test_mi_bounds_value_and_gradient(lib, bound, B):
     g = np.random.default_rng(4)
@@ -145,6 +145,31 @@ def test_mi_bounds_value_and_gradient(lib, bound, B):
         (val * float(gs[e])).backward()
         assert_close(mi[e].item(), val.item(), 1e-4, 2e-5, f"{bound} value")
         grad_close(dS[e].cpu().numpy(), st.grad.numpy(), 1e-3, f"{bound} gradient")
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_mine_bound_loss_term_and_both_gradient_forms(lib, B):
+    """`mine` (Model.py:121-125): value = dv form; loss term = mean(t) - mean(et)/ma_et (not negated).  Estimators flagged in
+    `lossform` get the gradient of coefficient * loss term, the others that of -coefficient * value (Model.py:386)."""
+    g = np.random.default_rng(5)
+    E = 3
+    s = (g.standard_normal((E, B, B)) * 1.2).astype(np.float32)
+    coef = np.array([1.0, 0.5, 0.01], np.float32)
+    S, dS, GS = dev(s), torch.zeros(E, B, B, device="cuda"), dev(-coef)
+    mi, ml = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    _lib.check(lib.mimrl_op_mi_bound_ex(stream(), P(S), P(dS), P(mi), P(ml), P(GS), E, B, _lib.BOUNDS["mine"], 0b101))
+    torch.cuda.synchronize()
+    for e in range(E):
+        st = torch.from_numpy(s[e]).double().requires_grad_(True)
+        t = st.diag()
+        et = torch.exp(st) * (1.0 - torch.eye(B, dtype=st.dtype))
+        val = t.mean() - R._logmeanexp_nodiag(st)
+        loss = t.mean() - (1 / (0.99 + 0.01 * et.mean())).detach() * et.mean()
+        lossform = bool((0b101 >> e) & 1)
+        (float(coef[e]) * (loss if lossform else -val)).backward()
+        assert_close(mi[e].item(), val.item(), 1e-4, 2e-5, "mine value")
+        assert_close(ml[e].item(), (loss if lossform else -val).item(), 1e-4, 2e-5, "mine loss term")
+        grad_close(dS[e].cpu().numpy(), st.grad.numpy(), 1e-3, f"mine gradient (lossform={lossform})")
 
 
 @pytest.mark.parametrize("dz,N,m,k", [(128, 300, 16, 2), (1, 300, 16, 2), (128, 1284, 64, 2), (1, 1284, 64, 3), (128, 70, 33, 4)])
