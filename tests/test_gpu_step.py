@@ -208,8 +208,9 @@ def test_fused_cube_forward_matches_unfused(name, monkeypatch):
     assert cos > 0.98, f"main gradient direction fused vs unfused: cosine {cos}"
 
 
-@pytest.mark.parametrize("precision,use_graph", [("fp32", False), ("fp32", True), ("bf16", True)])
-def test_stage2_prefetch_matches_sequential(precision, use_graph):
+@pytest.mark.parametrize("precision,use_graph,split", [("fp32", False, False), ("fp32", True, False), ("bf16", True, False),
+                                                       ("fp32", True, True)])
+def test_stage2_prefetch_matches_sequential(precision, use_graph, split):
     """Solver.step() overlap mode (mimrl_set_stage2_prefetch): the stage-2 forward pass runs beside stage 1.
     Same parameters, inputs and dropout keys => same losses / predictions / parameters as the sequential order
     (dropout is ON here so that a wrong mask key between forward and backward would show)."""
@@ -231,7 +232,12 @@ def test_stage2_prefetch_matches_sequential(precision, use_graph):
         eng.set_stage2_prefetch(pre)
         rec = []
         for _ in range(3):
-            eng.step()
+            if split and pre:    # the data-parallel call sequence (dist.ddp_stage_step): grads | all-reduce | apply, per stage
+                for st in (1, 2):
+                    eng.stage_grads(st)
+                    eng.stage_apply(st)
+            else:
+                eng.step()
             rec.append((eng.read_scalars().copy(), eng.pred.cpu().numpy().copy(), eng.feats.cpu().numpy().copy()))
         rec.append(torch.cat([eng.params[n].flatten() for n in sorted(eng.params)]).cpu().numpy())
         if pre:   # stage 2 without its stage 1 must fail loudly in this mode
