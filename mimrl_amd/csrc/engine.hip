@@ -1049,9 +1049,22 @@ int mimrl_handle::model_backward() {
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
+    MX(fork(1, l == 0 ? 5 : 3));   // the weight gradients below depend on the BPTT only
+    if (l == 1) {   // critical path, so first in capture order: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
+      // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
+      {
+        GemmDesc q = gemm_nn(dg[l][0][0], 4 * H, P(gru[0][l][0].w_ih), 2 * H, dh0[0], 2 * H, (int)BT_, 2 * H, G);
+        q.A2 = dg[l][0][1]; q.sa2_m = 4 * H; q.sa2_k = 1;
+        q.B2 = P(gru[0][l][1].w_ih); q.sb2_k = 2 * H; q.sb2_n = 1; q.K2 = G;
+        q.batch = 2;
+        q.sa_b = dg[l][1][0] - dg[l][0][0]; q.sa2_b = dg[l][1][1] - dg[l][0][1];
+        q.sb_b = gru[1][l][0].w_ih - gru[0][l][0].w_ih; q.sb2_b = gru[1][l][1].w_ih - gru[0][l][1].w_ih;
+        q.sc_b = dh0[1] - dh0[0];
+        MX(G_(q));
+      }
+    }
     // weight gradients of this layer: off the critical path.  Layer 1: side 1..3 (they overlap the layer-0 BPTT);
-    // layer 0 is the tail of the stage: all twelve GEMMs go out on six streams at once.
-    MX(fork(1, l == 0 ? 5 : 3));
+    // layer 0 is the tail of the stage.
     int rr = 0;
     for (int m = 0; m < 2; ++m) {
       // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H).  Both directions in one
@@ -1064,7 +1077,7 @@ int mimrl_handle::model_backward() {
       auto two = [&](GemmDesc& q, long a_o, long b_o, long c_o) { if (both) { q.batch = 4; q.batch_in = 2; q.sa_bo = a_o; q.sb_bo = b_o; q.sc_bo = c_o; } };
       const long o_dg = dg[l][1][0] - dg[l][0][0], o_hp = hprev[l][1][0] - hprev[l][0][0], o_in = both ? h0[1] - h0[0] : 0;
       const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
-      static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 6;   // tuning knobs
+      static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 4;   // tuning knobs
       static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
       auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
@@ -1073,19 +1086,6 @@ int mimrl_handle::model_backward() {
         q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
       { GemmDesc q = gemm_tn(dg[l][m][0] + 3 * H, 4 * H, hprev[l][m][0], H, Gm(gf.w_hh) + 2 * H * H, H, H, H, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
-    }
-    if (l == 1) {   // critical path: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
-      // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
-      {
-        GemmDesc q = gemm_nn(dg[l][0][0], 4 * H, P(gru[0][l][0].w_ih), 2 * H, dh0[0], 2 * H, (int)BT_, 2 * H, G);
-        q.A2 = dg[l][0][1]; q.sa2_m = 4 * H; q.sa2_k = 1;
-        q.B2 = P(gru[0][l][1].w_ih); q.sb2_k = 2 * H; q.sb2_n = 1; q.K2 = G;
-        q.batch = 2;
-        q.sa_b = dg[l][1][0] - dg[l][0][0]; q.sa2_b = dg[l][1][1] - dg[l][0][1];
-        q.sb_b = gru[1][l][0].w_ih - gru[0][l][0].w_ih; q.sb2_b = gru[1][l][1].w_ih - gru[0][l][1].w_ih;
-        q.sc_b = dh0[1] - dh0[0];
-        MX(G_(q));
-      }
     }
   }
   MX(join(0, 5));

@@ -246,38 +246,47 @@ __global__ void colln_fwd_kernel(const float* __restrict__ y, const float* __res
   float* zb = z + b * n * C + c;
   for (int l = 0; l < n; ++l) zb[(long)l * C] = (yb[(long)l * C] - mu) * rs * gamma[l] + beta[l];
 }
-__global__ void colln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
-                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                 const float* __restrict__ dz, float* __restrict__ dy, float* __restrict__ dgamma,
-                                 float* __restrict__ dbeta, int B, int n, int C) {
-  extern __shared__ float sh[];   // [2][n][64] per-lane partial sums of dgamma / dbeta (ds_add_f32, conflict-free)
-  for (int i = threadIdx.x; i < 2 * n * 64; i += blockDim.x) sh[i] = 0.f;
-  __syncthreads();
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const bool ok = i < (long)B * C;
-  const int lane = threadIdx.x & 63;
-  if (ok) {
-    const long b = i / C;
-    const int c = i % C;
-    const float* yb = y + b * n * C + c;
-    const float* dzb = dz + b * n * C + c;
-    float* dyb = dy + b * n * C + c;
-    const float mu = mean[i], rs = rstd[i];
-    float s1 = 0.f, s2 = 0.f;
-    for (int l = 0; l < n; ++l) {
-      const float g = dzb[(long)l * C], xh = (yb[(long)l * C] - mu) * rs;
-      const float dxh = g * gamma[l];
-      s1 += dxh; s2 += dxh * xh;
-      atomicAdd(&sh[l * 64 + lane], g * xh);
-      atomicAdd(&sh[(n + l) * 64 + lane], g);
-    }
-    s1 /= n; s2 /= n;
-    for (int l = 0; l < n; ++l) {
-      const float xh = (yb[(long)l * C] - mu) * rs;
-      dyb[(long)l * C] = rs * (dzb[(long)l * C] * gamma[l] - s1 - xh * s2);
+// Workgroup = 64 consecutive columns (one per lane); its 4 waves split the L axis (l = wave, wave+4, ...), keep their
+// (dz, xhat) pairs in registers -- one pass over memory -- and meet in LDS for the two column sums.
+__global__ __launch_bounds__(256) void colln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ dz, float* __restrict__ dy,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int n, int C) {
+  extern __shared__ float sh[];   // [2][n][64] per-column terms of dgamma / dbeta, then [2][4][64] partial column sums
+  float* red = sh + 2 * n * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + lane;          // column id = b * C + c   (C is a multiple of 64)
+  const long b = i / C;
+  const int c = i % C;
+  const float* yb = y + b * n * C + c;
+  const float* dzb = dz + b * n * C + c;
+  float* dyb = dy + b * n * C + c;
+  const float mu = mean[i], rs = rstd[i];
+  constexpr int PER = 16;                          // n <= 64
+  float g[PER], xh[PER];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int l = wave + 4 * q;
+    if (l < n) {
+      g[q] = dzb[(long)l * C];
+      xh[q] = (yb[(long)l * C] - mu) * rs;
+      const float dxh = g[q] * gamma[l];
+      s1 += dxh; s2 += dxh * xh[q];
+      sh[l * 64 + lane] = g[q] * xh[q];
+      sh[(n + l) * 64 + lane] = g[q];
     }
   }
+  red[wave * 64 + lane] = s1;
+  red[(4 + wave) * 64 + lane] = s2;
   __syncthreads();
+  s1 = (red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]) / n;
+  s2 = (red[256 + lane] + red[320 + lane] + red[384 + lane] + red[448 + lane]) / n;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int l = wave + 4 * q;
+    if (l < n) dyb[(long)l * C] = rs * (g[q] * gamma[l] - s1 - xh[q] * s2);
+  }
   for (int q = threadIdx.x; q < 2 * n; q += blockDim.x) {
     float t = 0.f;
     for (int j = 0; j < 64; ++j) t += sh[q * 64 + ((j + q) & 63)];
@@ -583,7 +592,8 @@ int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* me
               float* dy, float* dgamma, float* dbeta, int B, int n, int C) {
   const long tot = (long)B * C;
   if (n > 64) return set_error(MIMRL_ERR_ARG, "colln_bwd: axis length %d > 64", n);
-  hipLaunchKernelGGL(colln_bwd_kernel, dim3((tot + 255) / 256), dim3(256), 2 * n * 64 * sizeof(float), s, y, gamma, mean,
+  if (C % 64 != 0) return set_error(MIMRL_ERR_ARG, "colln_bwd: %d columns per sample is not a multiple of 64", C);
+  hipLaunchKernelGGL(colln_bwd_kernel, dim3(tot / 64), dim3(256), (2 * n + 8) * 64 * sizeof(float), s, y, gamma, mean,
                      rstd, dz, dy, dgamma, dbeta, B, n, C);
   LAUNCH_CHECK();
   return MIMRL_OK;
