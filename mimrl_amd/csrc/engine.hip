@@ -13,6 +13,7 @@
 
 #include "cube_fused.h"
 #include "mlp_fused.h"
+#include "cube_bwd_fused.h"
 #include "estimator_ops.h"
 #include "gemm.h"
 #include "gru.h"
@@ -188,6 +189,7 @@ struct mimrl_handle {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   bool multi_stream = true;
+  bool fused_cube_bwd = true;          // bf16 mode: per-axis fused data-gradient chains of CubeMLP (MIMRL_NO_FUSED_CUBE_BWD=1 disables)
   bool fused_mlp = true;               // bf16 mode: estimator MLP stacks as one kernel per direction (MIMRL_NO_FUSED_MLP=1 disables)
   bool fused_cube = true;              // bf16 mode: CubeMLP blocks as one LDS-resident kernel (MIMRL_NO_FUSED_CUBE=1 disables)
   int next_event(hipEvent_t* e) {
@@ -295,7 +297,8 @@ struct mimrl_handle {
   int G_(const GemmDesc& d) { return G_on(stream, d); }
   // weight-gradient work parked by cube_backward and issued on the side streams once the data-gradient chain is through
   // (it then overlaps the latency-bound GRU BPTT instead of competing with the chain for CUs and L2)
-  struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst; };
+  struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst;
+                    const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; };
   std::vector<Deferred> deferred;
   int flush_deferred();
   int model_forward(bool train, bool save, int knn_stage = 0);
@@ -817,6 +820,16 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     if (defer) { deferred.push_back(Deferred{2, sd, GemmDesc(), src, nb, rows, cols, 0, dst}); return MIMRL_OK; }
     return rowsum_batched(S(sd), src, nb, rows, cols, dst);
   };
+  auto W_lnpar = [&](int sd, const float* y, const float* mean, const float* rstd, const float* dz, float* dgam, float* dbet,
+                     int nb, int n, int cols) -> int {
+    if (defer) {
+      Deferred d{3, sd, GemmDesc(), y, nb, n, cols, 0, dgam};
+      d.p1 = mean; d.p2 = rstd; d.p3 = dz; d.dst2 = dbet;
+      deferred.push_back(d);
+      return MIMRL_OK;
+    }
+    return colln_param_grads(S(sd), y, mean, rstd, dz, dgam, dbet, nb, n, cols);
+  };
   auto W_fork = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : fork(lo, hi); };
   auto W_join = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : join(lo, hi); };
 #define GRAB(var)                                                                                   \
@@ -904,7 +917,37 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       cur = q;
     }
     // ------------------------------------------------ L axis backward (per-sample [.,C] tiles, C = ik*id)
-    {
+    if (bf16 && fused_cube_bwd && !cfg.ln_first && pl <= 0.f && w.ax[0].res >= 0 && laxis_bwd_supported(il, hl, ol, ik * id)) {
+      // one launch: LayerNorm(L) backward -> dY -> dU -> dX (+ LayerNorm and bias gradients); weight gradients stay GEMMs
+      const AxisW& a = w.ax[0];
+      const long C = (long)ik * id;
+      GRAB(i_dy); GRAB(i_du); GRAB(i_dx);
+      LAxisBwdArgs fa;
+      fa.dz = gbuf[cur]; fa.y = b.l.y; fa.mean = b.l.mean; fa.rstd = b.l.rstd; fa.gamma = P(a.ln_g); fa.u = b.l.u;
+      fa.w2 = P(a.fc2.w); fa.w1 = P(a.fc1.w); fa.wr = P(a.res);
+      fa.dy = gbuf[i_dy]; fa.du = gbuf[i_du]; fa.dx = gbuf[i_dx];
+      fa.db2 = a.fc2.b >= 0 ? Gm(a.fc2.b) : nullptr; fa.db1 = a.fc1.b >= 0 ? Gm(a.fc1.b) : nullptr;
+      fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.C = (int)C; fa.act = cfg.activation;
+      MX(laxis_bwd_fused(stream, fa));
+      MX(W_fork(1, 3));
+      MX(W_lnpar(1, b.l.y, b.l.mean, b.l.rstd, gbuf[cur], Gm(a.ln_g), Gm(a.ln_b), B, ol, (int)C));
+      release(cur);
+      { GemmDesc g; g.A = gbuf[i_dy]; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;        // dW2 += dY_b . H_b^T
+        g.B = b.l.h; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)hl * C;
+        g.C = Gm(a.fc2.w); g.sc_m = hl; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = hl; g.K = (int)C; g.batch = B; g.atomic = 1;
+        MX(W_gemm(1, g)); }
+      { GemmDesc g; g.A = gbuf[i_dy]; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)ol * C;        // dWr += dY_b . X_b^T
+        g.B = xblk; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
+        g.C = Gm(a.res); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = ol; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
+        MX(W_gemm(2, g)); }
+      { GemmDesc g; g.A = gbuf[i_du]; g.sa_m = C; g.sa_k = 1; g.sa_b = (long)hl * C;        // dW1 += dU_b . X_b^T
+        g.B = xblk; g.sb_k = 1; g.sb_n = C; g.sb_b = (long)il * C;
+        g.C = Gm(a.fc1.w); g.sc_m = il; g.sc_n = 1; g.sc_b = 0; g.M = hl; g.N = il; g.K = (int)C; g.batch = B; g.atomic = 1;
+        MX(W_gemm(3, g)); }
+      MX(W_join(1, 3));
+      release(i_dy); release(i_du);
+      cur = i_dx;
+    } else {
       const AxisW& a = w.ax[0];
       const long C = (long)ik * id;
       const float* xmlp = cfg.ln_first ? b.l.xn : xblk;
@@ -996,7 +1039,8 @@ int mimrl_handle::flush_deferred() {
     hipStream_t st = S(1 + (d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
-    else MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
+    else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
+    else MX(colln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, (int)d.n0, (int)d.n1, (int)d.n2));
   }
   deferred.clear();
   return MIMRL_OK;
@@ -1575,6 +1619,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
   h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
+  h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
   h->prec = cfg->precision;

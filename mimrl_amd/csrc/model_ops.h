@@ -49,6 +49,8 @@ int rowln_bwd(hipStream_t s, const float* y, const float* gamma, const float* me
 // ---- LayerNorm along the FIRST axis of per-sample [n, C] tiles (L-axis mix): stats per (b, c)
 int colln_fwd(hipStream_t s, const float* y, const float* gamma, const float* beta, float* z, float* mean, float* rstd,
               int B, int n, int C);
+int colln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,
+                      float* dbeta, int B, int n, int C);   // dgamma/dbeta only (the fused L-axis backward does the rest)
 int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
               float* dy, float* dgamma, float* dbeta, int B, int n, int C);
 

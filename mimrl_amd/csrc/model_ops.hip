@@ -588,6 +588,33 @@ int colln_fwd(hipStream_t s, const float* y, const float* gamma, const float* be
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
+// LayerNorm(L) parameter gradients as plain row sums over (sample, column): dgamma[l] = sum dz * xhat, dbeta[l] = sum dz.
+__global__ void colln_param_grads_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ dz,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int n, int C) {
+  __shared__ float red[16];
+  const int l = blockIdx.x;
+  float sg = 0.f, sb = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const float* yb = y + ((long)b * n + l) * C;
+    const float* dzb = dz + ((long)b * n + l) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float g = dzb[c];
+      sg += g * (yb[c] - mean[(long)b * C + c]) * rstd[(long)b * C + c];
+      sb += g;
+    }
+  }
+  sg = block_sum(sg, red);
+  sb = block_sum(sb, red);
+  if (threadIdx.x == 0) { atomicAdd(&dgamma[l], sg); atomicAdd(&dbeta[l], sb); }
+}
+int colln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,
+                      float* dbeta, int B, int n, int C) {
+  hipLaunchKernelGGL(colln_param_grads_kernel, dim3(n, (B + 7) / 8), dim3(128), 0, s, y, mean, rstd, dz, dgamma, dbeta, B, n, C);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
 int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* mean, const float* rstd, const float* dz,
               float* dy, float* dgamma, float* dbeta, int B, int n, int C) {
   const long tot = (long)B * C;

@@ -285,3 +285,35 @@ def test_fused_mlp_stacks_match_unfused(monkeypatch):
     for name, x, y, lim in (("critic", ca, cb, 0.9995), ("main", ma, mb, 0.999)):
         cos = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y)))
         assert cos > lim, f"{name} gradient direction fused vs unfused: cosine {cos}"
+
+
+@pytest.mark.parametrize("name", ["tiny_sep", "cfg1_sep"])
+def test_fused_cube_backward_matches_unfused(name, monkeypatch):
+    """bf16 mode: the per-axis fused data-gradient kernels of CubeMLP (cube_bwd_fused.hip) against the unfused
+    LayerNorm-backward + GEMM chain in the same precision: the whole main-bucket gradient, tensor by tensor."""
+    res = {}
+    for tag, env in (("fused", None), ("unfused", "1")):
+        if env:
+            monkeypatch.setenv("MIMRL_NO_FUSED_CUBE_BWD", env)
+        else:
+            monkeypatch.delenv("MIMRL_NO_FUSED_CUBE_BWD", raising=False)
+        c, opt, batch, banks, p, eng = make_engine(name, precision="bf16")
+        g = load_golden(name)
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(1, g["anchors"][0, 0])
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.stage_grads(2)
+        torch.cuda.synchronize()
+        res[tag] = {n: eng.grads[n].double().cpu().numpy().copy() for n in eng.grads if not R.is_critic_param(n)}
+        eng.close()
+    worst = 1.0
+    for n, ga in res["fused"].items():
+        gb = res["unfused"][n]
+        na, nb = np.linalg.norm(ga), np.linalg.norm(gb)
+        if nb < 1e-12:
+            assert na < 1e-9, n
+            continue
+        cos = float((ga * gb).sum() / (na * nb))
+        worst = min(worst, cos)
+        assert cos > 0.995 and abs(na / nb - 1) < 0.05, f"{n}: cosine {cos}, norm ratio {na / nb}"
+    assert worst > 0.995
