@@ -22,15 +22,22 @@ bool laxis_bwd_supported(int il, int hl, int ol, int C);
 int laxis_bwd_fused(hipStream_t s, const LAxisBwdArgs& a);
 
 struct DAxisBwdArgs {
-  const float *dz, *y, *mean, *rstd, *gamma;   // [R,od] [R,od] [R] [R] [od]
-  const float* u;                              // pre-activation [R,hd]
-  const float *w2, *w1, *wr;                   // [od,hd] [hd,id] [od,id]
-  float *dy, *du, *dx;                         // [R,od] [R,hd] [R,id]
-  float *dgamma, *dbeta, *db2, *db1;           // [od] [od] [od] or null, [hd] or null     (accumulated)
+  const float *dz, *y, *mean, *rstd, *gamma;   // [R,128] [R,128] [R] [R] [128]
+  const float* u;                              // pre-activation [R,128]
+  const __bf16 *w2t, *w1t, *wrt;               // TRANSPOSED bf16 images [n][k] of W2[o,h], W1[h,i], Wr[o,i] (wt_transpose_bf16)
+  float *dy, *du, *dx;                         // [R,128] x3
   long R;
-  int act;                                     // id == hd == od == 128
+  int act;                                     // id == hd == od == 128; LayerNorm / bias gradients: column-sum side kernels
 };
 bool daxis_bwd_supported(int id, int hd, int od);
 int daxis_bwd_fused(hipStream_t s, const DAxisBwdArgs& a);
+
+// dst[m][n][k] = bf16(src[m][k][n]) for up to 12 square 128x128 matrices (one launch per stage, off the critical path)
+struct WtTransposeArgs { const float* src[12]; __bf16* dst[12]; int n; };
+int wt_transpose_bf16(hipStream_t s, const WtTransposeArgs& a);
+
+// LayerNorm(D) parameter gradients as column sums over rows: dgamma[j] = sum_r dz * xhat, dbeta[j] = sum_r dz
+int rowln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,
+                      float* dbeta, long R, int n);
 
 }  // namespace mimrl

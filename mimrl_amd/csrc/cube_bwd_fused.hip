@@ -159,7 +159,165 @@ int laxis_bwd_fused(hipStream_t s, const LAxisBwdArgs& a) {
   return MIMRL_OK;
 }
 
-bool daxis_bwd_supported(int, int, int) { return false; }
-int daxis_bwd_fused(hipStream_t, const DAxisBwdArgs&) { return set_error(MIMRL_ERR_ARG, "daxis_bwd_fused: not built"); }
+// ---------------------------------------------------------------------------------------------------------------
+// D axis.  Rows are independent: workgroup = 32 rows, 8 threads per row for the LayerNorm, then MFMA with M = the 32 rows
+// (A-fragments from the LDS images of dY / dU), N = 32 output columns per wave, K = 128.  B-fragments are 16-byte loads
+// from the pre-transposed bf16 weight images (24 per wave in total: no LDS staging of weights at all).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int DR = 32;         // rows per workgroup
+constexpr int DP = 128 + 8;    // bf16 pitch (272 B)
+
+__global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sdy[DR][DP];
+  __shared__ __attribute__((aligned(16))) __bf16 sdu[DR][DP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const long r0 = (long)blockIdx.x * DR;
+  // B-fragments of this wave's 32 output columns, all three products, issued before anything else
+  const int n = wave * 32 + lr;
+  bf16x8 bw2[8], bw1[8], bwr[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    bw2[ks] = *reinterpret_cast<const bf16x8*>(a.w2t + n * 128 + ks * 16 + 8 * lh);
+    bw1[ks] = *reinterpret_cast<const bf16x8*>(a.w1t + n * 128 + ks * 16 + 8 * lh);
+    bwr[ks] = *reinterpret_cast<const bf16x8*>(a.wrt + n * 128 + ks * 16 + 8 * lh);
+  }
+  // ---- phase 1: LayerNorm over D, backward: 8 threads per row, 16 consecutive columns each
+  {
+    const int row = tid >> 3, part = tid & 7;
+    const long r = r0 + row;
+    const bool ok = r < a.R;
+    float g[16], xh[16];
+    float s1 = 0.f, s2 = 0.f;
+    const float mu = ok ? a.mean[r] : 0.f, rs = ok ? a.rstd[r] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 gz = make_float4(0.f, 0.f, 0.f, 0.f), yv = gz;
+      if (ok) {
+        gz = *reinterpret_cast<const float4*>(a.dz + r * 128 + part * 16 + q * 4);
+        yv = *reinterpret_cast<const float4*>(a.y + r * 128 + part * 16 + q * 4);
+      }
+      const float gg[4] = {gz.x, gz.y, gz.z, gz.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g[q * 4 + j] = gg[j];
+        xh[q * 4 + j] = (yy[j] - mu) * rs;
+        const float dxh = gg[j] * a.gamma[part * 16 + q * 4 + j];
+        s1 += dxh; s2 += dxh * xh[q * 4 + j];
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= (1.f / 128.f); s2 *= (1.f / 128.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = part * 16 + q * 4 + j;
+        v[j] = rs * (g[q * 4 + j] * a.gamma[c] - s1 - xh[q * 4 + j] * s2);
+      }
+      if (ok) *reinterpret_cast<float4*>(a.dy + r * 128 + part * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      bf16x4 p; p[0] = to_bf16(v[0]); p[1] = to_bf16(v[1]); p[2] = to_bf16(v[2]); p[3] = to_bf16(v[3]);
+      *reinterpret_cast<bf16x4*>(&sdy[row][part * 16 + q * 4]) = p;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: dU = (dY W2) * act'(U)
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sdy[lr][ks * 16 + 8 * lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw2[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const long row = r0 + m;
+      float v = 0.f;
+      if (row < a.R) {
+        v = acc[r] * act_grad(a.act, a.u[row * 128 + n]);
+        a.du[row * 128 + n] = v;
+      }
+      sdu[m][n] = to_bf16(v);
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: dX = dU W1 + dY Wr
+  {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&sdu[lr][ks * 16 + 8 * lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw1[ks], acc, 0, 0, 0);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&sdy[lr][ks * 16 + 8 * lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bwr[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long row = r0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < a.R) a.dx[row * 128 + n] = acc[r];
+    }
+  }
+}
+
+__global__ void wt_transpose_kernel(WtTransposeArgs a) {
+  __shared__ float t[32][33];
+  const float* __restrict__ src = a.src[blockIdx.z];
+  __bf16* __restrict__ dst = a.dst[blockIdx.z];
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) t[j][tx] = src[(k0 + j) * 128 + n0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) dst[(n0 + j) * 128 + k0 + tx] = to_bf16(t[tx][j]);
+}
+
+__global__ void rowln_param_grads_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ dz,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, long R, int n) {
+  // thread = column j (n <= 256), rows strided over the grid
+  const int j = threadIdx.x;
+  if (j >= n) return;
+  float sg = 0.f, sb = 0.f;
+  for (long r = blockIdx.x; r < R; r += gridDim.x) {
+    const float g = dz[r * n + j];
+    sg += g * (y[r * n + j] - mean[r]) * rstd[r];
+    sb += g;
+  }
+  atomicAdd(&dgamma[j], sg);
+  atomicAdd(&dbeta[j], sb);
+}
+
+}  // namespace
+
+bool daxis_bwd_supported(int id, int hd, int od) { return id == 128 && hd == 128 && od == 128; }
+
+int daxis_bwd_fused(hipStream_t s, const DAxisBwdArgs& a) {
+  if (!a.w2t || !a.w1t || !a.wrt) return set_error(MIMRL_ERR_ARG, "daxis_bwd_fused: needs the transposed weight images");
+  hipLaunchKernelGGL(daxis_bwd_kernel, dim3((unsigned)((a.R + DR - 1) / DR)), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int wt_transpose_bf16(hipStream_t s, const WtTransposeArgs& a) {
+  if (a.n < 1 || a.n > 12) return set_error(MIMRL_ERR_ARG, "wt_transpose_bf16: 1..12 matrices");
+  hipLaunchKernelGGL(wt_transpose_kernel, dim3(4, 4, a.n), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int rowln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,
+                      float* dbeta, long R, int n) {
+  if (n > 256) return set_error(MIMRL_ERR_ARG, "rowln_param_grads: row length %d > 256", n);
+  const int grid = (int)(R < 512 ? R : 512);
+  hipLaunchKernelGGL(rowln_param_grads_kernel, dim3(grid), dim3(256), 0, s, y, mean, rstd, dz, dgamma, dbeta, R, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
 
 }  // namespace mimrl

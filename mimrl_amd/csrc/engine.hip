@@ -145,6 +145,7 @@ struct mimrl_handle {
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
   float* cube0 = nullptr;
   BlockBuf bb[MIMRL_MAX_BLOCKS];
+  __bf16* wtT[MIMRL_MAX_BLOCKS][3] = {};   // transposed bf16 images of the D-axis weights (fc2, fc1, res) for the fused backward
   // Second set of forward buffers.  In prefetch mode (mimrl_set_stage2_prefetch) stage 1 runs its forward pass and its
   // estimators on this set while the stage-2 forward pass of the SAME batch (same main parameters: stage 1 only
   // touches the critics) runs beside it on `pre_stream` into the primary set, which the stage-2 backward then reads.
@@ -484,6 +485,8 @@ int mimrl_handle::carve() {
     bufs.feats = f0; bufs.pred = p0;
     MX(r);
   }
+  for (int i = 0; i < cfg.n_blocks; ++i)
+    for (int q = 0; q < 3; ++q) { float* t = nullptr; MX(take(&t, 128 * 128 / 2)); wtT[i][q] = reinterpret_cast<__bf16*>(t); }
   MX(take(&ff, B * D));
   MX(take(&dpred, B));
   // estimators
@@ -830,7 +833,32 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     }
     return colln_param_grads(S(sd), y, mean, rstd, dz, dgam, dbet, nb, n, cols);
   };
+  auto W_lnrow = [&](int sd, const float* y, const float* mean, const float* rstd, const float* dz, float* dgam, float* dbet,
+                     long rows, int n) -> int {
+    if (defer) {
+      Deferred d{4, sd, GemmDesc(), y, rows, n, 0, 0, dgam};
+      d.p1 = mean; d.p2 = rstd; d.p3 = dz; d.dst2 = dbet;
+      deferred.push_back(d);
+      return MIMRL_OK;
+    }
+    return rowln_param_grads(S(sd), y, mean, rstd, dz, dgam, dbet, rows, n);
+  };
   auto W_fork = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : fork(lo, hi); };
+  // transposed bf16 images of the D-axis weights for the fused data-gradient kernels (one small launch)
+  bool d_fused[MIMRL_MAX_BLOCKS] = {};
+  {
+    WtTransposeArgs ta;
+    ta.n = 0;
+    for (int i = 0; i < cfg.n_blocks; ++i) {
+      const AxisW& a = blk[i].ax[2];
+      d_fused[i] = bf16 && fused_cube_bwd && !cfg.ln_first && cfg.dropout_mlp[2] <= 0.f && a.res >= 0 &&
+                   daxis_bwd_supported(dims[i][2], a.hid, a.out) && ta.n + 3 <= 12;
+      if (!d_fused[i]) continue;
+      const long srcs[3] = {a.fc2.w, a.fc1.w, a.res};
+      for (int q = 0; q < 3; ++q) { ta.src[ta.n] = P(srcs[q]); ta.dst[ta.n] = wtT[i][q]; ++ta.n; }
+    }
+    if (ta.n > 0) MX(wt_transpose_bf16(stream, ta));
+  }
   auto W_join = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : join(lo, hi); };
 #define GRAB(var)                                                                                   \
   const int var = grab();                                                                           \
@@ -844,7 +872,28 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     const float* xblk = i == 0 ? cube0 : bb[i - 1].d.z;
     const float pl = cfg.dropout_mlp[0], pk = cfg.dropout_mlp[1], pd = cfg.dropout_mlp[2];
     // ------------------------------------------------ D axis backward
-    {
+    if (d_fused[i]) {
+      // one launch: LayerNorm(D) backward -> dY -> dU -> dX (row tiles); weight / bias / LayerNorm gradients stay side work
+      const AxisW& a = w.ax[2];
+      const long R2 = (long)B * ol * ok;
+      GRAB(i_dy); GRAB(i_du); GRAB(i_dx);
+      DAxisBwdArgs fa;
+      fa.dz = gbuf[cur]; fa.y = b.d.y; fa.mean = b.d.mean; fa.rstd = b.d.rstd; fa.gamma = P(a.ln_g); fa.u = b.d.u;
+      fa.w2t = wtT[i][0]; fa.w1t = wtT[i][1]; fa.wrt = wtT[i][2];
+      fa.dy = gbuf[i_dy]; fa.du = gbuf[i_du]; fa.dx = gbuf[i_dx];
+      fa.R = R2; fa.act = cfg.activation;
+      MX(daxis_bwd_fused(stream, fa));
+      MX(W_fork(1, 3));
+      MX(W_lnrow(2, b.d.y, b.d.mean, b.d.rstd, gbuf[cur], Gm(a.ln_g), Gm(a.ln_b), R2, od));
+      { GemmDesc g = gemm_tn(gbuf[i_dy], od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(W_gemm(1, g)); }
+      if (a.fc2.b >= 0) MX(W_colsum(1, gbuf[i_dy], R2, od, od, Gm(a.fc2.b)));
+      { GemmDesc g = gemm_tn(gbuf[i_dy], od, b.k.z, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(W_gemm(2, g)); }
+      { GemmDesc g = gemm_tn(gbuf[i_du], hd, b.k.z, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(W_gemm(3, g)); }
+      if (a.fc1.b >= 0) MX(W_colsum(3, gbuf[i_du], R2, hd, hd, Gm(a.fc1.b)));
+      MX(W_join(1, 3));
+      release(cur); release(i_dy); release(i_du);
+      cur = i_dx;
+    } else {
       const AxisW& a = w.ax[2];
       const long R2 = (long)B * ol * ok;
       const float* xin = b.k.z;                              // residual / un-normalised input
@@ -1040,7 +1089,8 @@ int mimrl_handle::flush_deferred() {
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
-    else MX(colln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, (int)d.n0, (int)d.n1, (int)d.n2));
+    else if (d.kind == 3) MX(colln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, (int)d.n0, (int)d.n1, (int)d.n2));
+    else MX(rowln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, d.n0, (int)d.n1));
   }
   deferred.clear();
   return MIMRL_OK;
