@@ -1162,7 +1162,7 @@ int mimrl_handle::model_backward() {
     int rr = 0;
     for (int m = 0; m < 2; ++m) {
       // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H).  Both directions in one
-      // launch each (batch = direction): dW_ih, dW_hh rows [0,2H), dW_hh rows [2H,3H).
+      // launch each (batch = direction): dW_ih and dW_hh (the latter reads dg through a row gap).
       const float* in = l == 0 ? xin[m] : h0[m];
       const GruDirW &gf = gru[m][l][0], &gr = gru[m][l][1];
       const long s_dg = dg[l][m][1] - dg[l][m][0], s_hp = hprev[l][m][1] - hprev[l][m][0];
@@ -1176,9 +1176,8 @@ int mimrl_handle::model_backward() {
       auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih); MX(G_on(pick(), q)); }
-      { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, hprev[l][m][0], H, Gm(gf.w_hh), H, 2 * H, H, (int)BT_);
-        q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
-      { GemmDesc q = gemm_tn(dg[l][m][0] + 3 * H, 4 * H, hprev[l][m][0], H, Gm(gf.w_hh) + 2 * H * H, H, H, H, (int)BT_);
+      { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, hprev[l][m][0], H, Gm(gf.w_hh), H, G, H, (int)BT_);   // dgh = dg columns [0,2H) u [3H,4H)
+        q.a_gap_at = 2 * H; q.a_gap_rows = H;
         q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
     }
   }

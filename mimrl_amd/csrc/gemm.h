@@ -20,6 +20,8 @@ struct GemmDesc {
   // optional two-level batch: entry b = (outer, inner) = (b / batch_in, b % batch_in) with its own outer strides for
   // A, B, C (and pre / gradact_u, which share C's layout) and bias_n -- e.g. (modality, direction) of the GRU weights
   int batch_in = 0; long sa_bo = 0, sb_bo = 0, sc_bo = 0, bias_n_bo = 0;
+  // optional gap in A's row (m) axis: rows m >= a_gap_at live a_gap_rows further on (dgh = columns [0,2H) u [3H,4H) of dg)
+  int a_gap_at = 0, a_gap_rows = 0;
   const float* bias_n = nullptr; long bias_n_b = 0;   // + bias_n[b*bias_n_b + n]
   const float* bias_m = nullptr; long bias_m_b = 0;   // + bias_m[b*bias_m_b + m]
   float alpha = 1.f;

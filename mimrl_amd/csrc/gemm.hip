@@ -45,6 +45,7 @@ struct Operand {
   const float* P;
   long s_r, s_k;     // strides of the row (m or n) axis and of k
   int r0, R;         // first row of this tile / number of rows
+  int gap_at, gap;   // rows >= gap_at are stored `gap` rows further on (0 = none; multiples of 4)
   bool kfast;        // thread mapping: k runs fastest (else rows)
   bool vec;          // 16-byte path for this tile
 };
@@ -75,7 +76,8 @@ __device__ __forceinline__ void load_tile(const Operand& o, int K, int k0, int t
       const int gk = k0 + k;
       // k-contiguous operands may have a ragged last tile: rows beyond R are clamped (their products land in output
       // rows/columns the epilogue never stores)
-      const int gr = (LEAN && o.kfast) ? (o.r0 + row < o.R ? o.r0 + row : o.R - 1) : o.r0 + row;
+      int gr = (LEAN && o.kfast) ? (o.r0 + row < o.R ? o.r0 + row : o.R - 1) : o.r0 + row;
+      if (gr >= o.gap_at) gr += o.gap;
       const float* src = o.P + (long)gr * o.s_r + (long)gk * o.s_k;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
       if (o.kfast) {
@@ -96,7 +98,7 @@ __device__ __forceinline__ void load_tile(const Operand& o, int K, int k0, int t
       int row, k;
       M::sc(o.kfast, tid, i, row, k);
       const int gr = o.r0 + row, gk = k0 + k;
-      v[i] = (gr < o.R && gk < K) ? o.P[(long)gr * o.s_r + (long)gk * o.s_k] : 0.f;
+      v[i] = (gr < o.R && gk < K) ? o.P[(long)(gr >= o.gap_at ? gr + o.gap : gr) * o.s_r + (long)gk * o.s_k] : 0.f;
     }
   }
 }
@@ -213,11 +215,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
 
   // one product segment: acc += A[m0:m0+64, :K] . B[:K, n0:n0+64]   (called once, or twice for C = A.B + A2.B2)
   auto segment = [&](const float* __restrict__ Ap, long sa_m, long sa_k, const float* __restrict__ Bp, long sb_k, long sb_n,
-                     int K, bool veca, bool vecb, int kt0, int kt1) {
+                     int K, bool veca, bool vecb, int kt0, int kt1, int ga_at, int ga) {
     const bool a_k = sa_k == 1, a_r = sa_m == 1 && !a_k;
     const bool b_k = sb_k == 1 && sb_n != 1, b_r = sb_n == 1;
-    const Operand oa{Ap, sa_m, sa_k, m0, d.M, a_k || !a_r, veca && full_m && (a_k || a_r)};
-    const Operand ob{Bp, sb_n, sb_k, n0, d.N, b_k, vecb && full_n && (b_k || b_r)};
+    const Operand oa{Ap, sa_m, sa_k, m0, d.M, ga_at, ga, a_k || !a_r, veca && full_m && (a_k || a_r)};
+    const Operand ob{Bp, sb_n, sb_k, n0, d.N, 0, 0, b_k, vecb && full_n && (b_k || b_r)};
     float ra[M::NE], rb[M::NE];
     if (kt0 < kt1) {
       load_tile<BK, LEAN>(oa, K, kt0 * BK, tid, ra);
@@ -253,11 +255,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     const int ktiles = (d.K + BK - 1) / BK;
     const int kt0 = ks * ka.kt_per;                       // split-K only ever applies to single-product GEMMs
     const int kt1 = kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles;
-    segment(d.A + oa, d.sa_m, d.sa_k, d.B + ob, d.sb_k, d.sb_n, d.K, ka.vec_a, ka.vec_b, kt0, kt1);
+    segment(d.A + oa, d.sa_m, d.sa_k, d.B + ob, d.sb_k, d.sb_n, d.K, ka.vec_a, ka.vec_b, kt0, kt1, d.a_gap_rows ? d.a_gap_at : 0x7fffffff, d.a_gap_rows);
   }
   if (d.A2)
     segment(d.A2 + (long)bz * d.sa2_b, d.sa2_m, d.sa2_k, d.B2 + (long)bz * d.sb2_b, d.sb2_k, d.sb2_n, d.K2, ka.vec_a2, ka.vec_b2,
-            0, (d.K2 + BK - 1) / BK);
+            0, (d.K2 + BK - 1) / BK, 0x7fffffff, 0);
 
   epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, obn, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
 }
@@ -308,6 +310,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (dbg_skip && d.atomic && (dbg_skip == 1 || (dbg_skip == 2 && d.batch > 1 && d.sc_b == 0))) return MIMRL_OK;
   if (!d.A || !d.B || !d.C) return set_error(MIMRL_ERR_ARG, "gemm: null operand");
   if ((d.A2 != nullptr) != (d.B2 != nullptr)) return set_error(MIMRL_ERR_ARG, "gemm: second product needs both operands");
+  if (d.a_gap_rows && (d.a_gap_at % 4 != 0 || d.a_gap_rows % 4 != 0 || d.A2))
+    return set_error(MIMRL_ERR_ARG, "gemm: the A-row gap must be a multiple of 4 rows (single product only)");
   if (d.batch_in > 0 && (d.A2 || d.bias_m || d.colsum || d.batch % d.batch_in != 0))
     return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   GemmPlan pl;
