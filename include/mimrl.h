@@ -123,6 +123,9 @@ int mimrl_estimate(mimrl_handle* h, int stage);        /* estimators only, on th
  * must not modify the bound inputs or main parameters; a stage-2 call without a preceding stage-1 call fails with
  * MIMRL_ERR_STATE.  Ignored while the banks are empty (epoch-0 rule). */
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on);
+/* Tell the engine that parameter buckets were written from outside (checkpoint load, broadcast): cached bf16 images of
+ * the critic parameters are rebuilt at the next call.  mimrl_bind implies it; the engine's own Adam keeps them fresh. */
+int mimrl_params_changed(mimrl_handle* h);
 int64_t mimrl_workspace_bytes(const mimrl_handle* h);
 /* phase profiler: HIP events on the engine's stream around each phase of the eager (non-graph) path */
 enum { MIMRL_PH_GEMM_MISC = 0, MIMRL_PH_GRU_FWD, MIMRL_PH_GRU_BWD, MIMRL_PH_CUBE_FWD, MIMRL_PH_CUBE_BWD, MIMRL_PH_EST_FWD,

@@ -40,6 +40,7 @@ class Solver:
         if self.world > 1:      # identical replicas: rank 0's initial parameters everywhere
             mdist.broadcast_(self.engine.main["p"])
             mdist.broadcast_(self.engine.crit["p"])
+            self.engine.params_changed()
         self.base_lr = float(opt.learning_rate)
         self.epoch = 0
 

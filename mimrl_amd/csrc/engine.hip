@@ -132,6 +132,18 @@ struct mimrl_handle {
   long ln_g[2], ln_b[2], w_t;
   BlockW blk[MIMRL_MAX_BLOCKS];
   long cls_w, cls_b;
+  // bf16 images of the critic bucket for the fused estimator stacks: straight (kept fresh by the critic Adam launch, rebuilt
+  // after mimrl_bind / mimrl_params_changed) and per-matrix transposed (rebuilt beside every estimator forward pass)
+  __bf16 *crit_img = nullptr, *crit_imgT = nullptr;
+  bool img_valid = false;
+  bool imgT_ready = false;             // a transposed-image refresh has been issued for the estimator pass being enqueued
+  TransposeTable ttab;
+  int ensure_images() {
+    if (img_valid || !crit_img) return MIMRL_OK;
+    MX(bf16_image(user_stream, bufs.crit_p, crit_img, layout.floats[MIMRL_GROUP_CRITIC]));
+    img_valid = true;
+    return MIMRL_OK;
+  }
   long tower0 = 0, tower_stride = 0;   // critic bucket: first tower, distance between consecutive towers
   long tower_l[4][2];                  // per-layer (w,b) offsets relative to tower0
   long cmi0 = 0, cmi_stride = 0, cmi_l[4][2];
@@ -419,6 +431,19 @@ int mimrl_handle::resolve() {
       if (o != cmi0 + e * cmi_stride) return set_error(MIMRL_ERR_STATE, "CMI classifiers are not uniformly strided");
     }
   }
+  {   // matrices whose transposed bf16 images the fused data-gradient chains read
+    ttab.n = 0;
+    auto add = [&](long o, int N, int K, int nb, long gs) {
+      const int e = ttab.n++;
+      ttab.off[e] = o; ttab.N[e] = N; ttab.K[e] = K; ttab.nb[e] = nb; ttab.gstride[e] = gs;
+    };
+    if (cfg.critic_type == MIMRL_CRITIC_SEPARATE) {
+      const int d[5] = {EMB, HID, HID, HID, EMB};
+      for (int l = 0; l < 4; ++l) add(tower0 + tower_l[l][0], d[l + 1], d[l], 10, tower_stride);
+    }
+    const int c[5] = {3 * EMB, HID, HID, HID, 2};
+    for (int l = 0; l < 4; ++l) add(cmi0 + cmi_l[l][0], c[l + 1], c[l], NE_CMI, cmi_stride);
+  }
   return MIMRL_OK;
 }
 
@@ -487,6 +512,11 @@ int mimrl_handle::carve() {
   }
   for (int i = 0; i < cfg.n_blocks; ++i)
     for (int q = 0; q < 3; ++q) { float* t = nullptr; MX(take(&t, 128 * 128 / 2)); wtT[i][q] = reinterpret_cast<__bf16*>(t); }
+  {
+    float *t1 = nullptr, *t2 = nullptr;
+    MX(take(&t1, layout.floats[MIMRL_GROUP_CRITIC] / 2 + 64)); MX(take(&t2, layout.floats[MIMRL_GROUP_CRITIC] / 2 + 64));
+    crit_img = reinterpret_cast<__bf16*>(t1); crit_imgT = reinterpret_cast<__bf16*>(t2);
+  }
   MX(take(&ff, B * D));
   MX(take(&dpred, B));
   // estimators
@@ -1223,7 +1253,11 @@ int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long p
     std::memset(&fa, 0, sizeof fa);
     fa.nb = nb; fa.rows = rows; fa.brows = brows; fa.nl = nl; fa.pstride = pstride; fa.in = in; fa.out = out;
     for (int l = 0; l <= nl; ++l) fa.dims[l] = dims[l];
-    for (int l = 0; l < nl; ++l) { fa.W[l] = CP(p0 + l_off[l][0]); fa.b[l] = CP(p0 + l_off[l][1]); if (l < nl - 1) fa.act[l] = act[l]; }
+    for (int l = 0; l < nl; ++l) {
+      fa.W[l] = CP(p0 + l_off[l][0]); fa.b[l] = CP(p0 + l_off[l][1]);
+      if (l < nl - 1) fa.act[l] = act[l];
+      if (img_valid && crit_img) fa.Wb[l] = crit_img + p0 + l_off[l][0];
+    }
     return mlp_stack_fwd_fused(stream, fa);
   }
   for (int l = 0; l < nl; ++l) {
@@ -1247,9 +1281,9 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
   int pp = 0;
   if (wgrad)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
     MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
-  // opt-in: the fused data-gradient kernel (transposed weight reads) only ties the four grouped GEMMs it replaces
-  static const bool fused_bwd = getenv("MIMRL_FUSED_MLP_BWD") != nullptr;
-  if (bf16 && fused_mlp && fused_bwd && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims)) {
+  // the fused data-gradient chain runs on the transposed bf16 images (the same coalesced loop as the forward pass)
+  static const bool fused_bwd = getenv("MIMRL_NO_FUSED_MLP_BWD") == nullptr;
+  if (bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims)) {
     // the whole data-gradient chain in one launch (dtmp must hold nl-1 buffers here); weight gradients follow as GEMMs
     MlpFusedArgs fa;
     std::memset(&fa, 0, sizeof fa);
@@ -1257,6 +1291,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     for (int l = 0; l <= nl; ++l) fa.dims[l] = dims[l];
     for (int l = 0; l < nl; ++l) {
       fa.W[l] = CP(p0 + l_off[l][0]);
+      fa.WbT[l] = crit_imgT + p0 + l_off[l][0];
       if (l < nl - 1) { fa.act[l] = act[l]; fa.dz[l + 1] = dtmp[l]; if (wgrad) fa.db[l] = CG(p0 + l_off[l][1]); }
     }
     MX(mlp_stack_bwd_fused(stream, fa));
@@ -1462,17 +1497,23 @@ int mimrl_handle::route_feature_grads() {
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  imgT_ready = false;
+  if (backward && bf_bwd && fused_mlp && crit_imgT && ttab.n > 0) {   // transposed weight images for the fused data-gradient chains,
+    MX(fork(3, 3));                                                   // built beside the forward stacks
+    MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
+    imgT_ready = true;
+  }
   MX(fork(5, 5));
   MX(chain(5, 4));                       // the CMI branch needs the kNN indices
   {
     StreamGuard g(this, S(5));
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
-    if (backward) { bf16 = bf_bwd; MX(cmi_backward(stage)); }
+    if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(chain(5, 3)); MX(cmi_backward(stage)); }
   }
   bf16 = bf_fwd;
   { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
-  if (backward) { bf16 = bf_bwd; Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); }
+  if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(join(3, 3)); Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); }
   bf16 = bf_fwd;
   if (!multi_stream) return MIMRL_OK;
   return join(5, 5);
@@ -1574,6 +1615,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   if (stage == 1) {
     a.p = bufs.crit_p; a.g = bufs.crit_g; a.m = bufs.crit_m; a.v = bufs.crit_v; a.n = layout.floats[MIMRL_GROUP_CRITIC];
     a.lr = bufs.lr_critic; a.step = d_ints + 2;
+    if (img_valid) a.pimg = crit_img;   // keep the straight bf16 image in step with the parameters
   } else {
     a.p = bufs.main_p; a.g = bufs.main_g; a.m = bufs.main_m; a.v = bufs.main_v; a.n = layout.floats[MIMRL_GROUP_MAIN];
     a.lr = bufs.lr_main; a.step = d_ints + 1;
@@ -1587,6 +1629,7 @@ int mimrl_handle::enqueue_apply(int stage) {
 int mimrl_handle::run(int stage, int kind) {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
+  MX(ensure_images());
   if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
   // an all-reduce): always zero first -- the caller may call it repeatedly
@@ -1690,6 +1733,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
     if (!p) return set_error(MIMRL_ERR_ARG, "mimrl_bind: a required buffer is null");
   h->bufs = *b;
   h->bound = true;
+  h->img_valid = false;
   for (int s = 1; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
@@ -1719,6 +1763,7 @@ int mimrl_stage_apply(mimrl_handle* h, int stage) { return h ? h->run(stage, 2) 
 int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  MX(h->ensure_images());
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, h->stream, h->d_ints, (int*)nullptr, h->bufs.scalars, 32, 32);
   LAUNCH_CHECK();
   h->ev_next = 0;
@@ -1740,6 +1785,7 @@ int mimrl_estimate(mimrl_handle* h, int stage) {
   if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
   if (h->bank_rows <= 0) return set_error(MIMRL_ERR_STATE, "mimrl_estimate needs non-empty banks");
+  MX(h->ensure_images());
   h->ev_next = 0;
   MX(h->fork(4, 4));
   MX(h->knn_launch(stage, h->S(4)));
@@ -1778,6 +1824,12 @@ int mimrl_profile_read(mimrl_handle* h, float* ms_sum, int32_t* launches) {
     launches[p] = (int32_t)h->prof_ev[p].size();
     h->prof_ev[p].clear();
   }
+  return MIMRL_OK;
+}
+
+int mimrl_params_changed(mimrl_handle* h) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  h->img_valid = false;
   return MIMRL_OK;
 }
 

@@ -66,6 +66,7 @@ struct AdamArgs {
   const float* lr;        // device scalar (schedulers rewrite it between epochs)
   const int* step;        // device counter, already incremented for this update
   float beta1, beta2, eps, weight_decay, clip;
+  __bf16* pimg = nullptr; // optional: bf16 image of the updated parameters (the fused estimator kernels read weights from it)
 };
 int adam_step(hipStream_t s, const AdamArgs& a);
 

@@ -371,7 +371,9 @@ __global__ void adam_kernel(AdamArgs a) {
     const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
     const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
     a.m[i] = m; a.v[i] = v;
-    a.p[i] = p - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+    const float pn = p - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+    a.p[i] = pn;
+    if (a.pimg) a.pimg[i] = to_bf16(pn);
     a.g[i] = 0.f;   // leave the bucket zeroed for the next accumulation pass (saves a memset per stage)
   }
 }

@@ -18,6 +18,10 @@ struct MlpFusedArgs {
   const float* W[MLPF_MAX_LAYERS];   // [dims[l+1], dims[l]] row-major, group g at + g*pstride
   const float* b[MLPF_MAX_LAYERS];   // [dims[l+1]]
   long pstride;
+  // optional bf16 images of the weights at the same group stride: Wb[l] = W[l] as is (forward), WbT[l] = W[l] transposed
+  // to [dims[l], dims[l+1]] (data-gradient chain).  With images the kernels never touch the fp32 weights.
+  const __bf16* Wb[MLPF_MAX_LAYERS];
+  const __bf16* WbT[MLPF_MAX_LAYERS];
   const float* in;                // [nb, brows, dims[0]]
   float* act[MLPF_MAX_LAYERS];    // post-ReLU outputs of layers 0..nl-2: [nb, brows, dims[l+1]]  (kept for the backward pass)
   float* out;                     // [nb, brows, dims[nl]]  (linear)
@@ -32,5 +36,11 @@ bool mlp_fused_supported(int nb, int rows, int nl, const int* dims);
 int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a);
 // data-gradient chain only: fills dz[1..nl-1] (+ din, + db[]); weight gradients stay GEMMs over (dz, act)
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a);
+
+// bf16 images of a parameter bucket: dst[i] = bf16(src[i]); and, for a table of strided groups of [N,K] matrices,
+// dstT[off + g*gstride + k*N + n] = bf16(src[off + g*gstride + n*K + k])
+int bf16_image(hipStream_t s, const float* src, __bf16* dst, long n);
+struct TransposeTable { long off[8]; int N[8], K[8], nb[8]; long gstride[8]; int n; };
+int bf16_transposed_images(hipStream_t s, const float* src, __bf16* dstT, const TransposeTable& t);
 
 }  // namespace mimrl

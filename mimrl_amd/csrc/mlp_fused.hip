@@ -153,6 +153,168 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpFusedArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Image variants: weights come from bf16 images (half the bytes, no conversion).  The data-gradient chain is the SAME
+// loop as the forward pass run on the transposed images: out[r, k] = sum_n dz[r, n] WT[k, n], i.e. "rows" of the staged
+// operand are output columns and are contiguous along the reduction axis -- coalesced 16-byte loads in both directions.
+// ---------------------------------------------------------------------------------------------------------------
+// one pair (or single) of 32-column output tiles of one layer: acc += A[32 x K] . W[tile rows, K]^T, W = bf16 image rows
+__device__ __forceinline__ void img_tiles(f32x16& accA, f32x16& accB, int nt0, bool two, const __bf16* __restrict__ W, int N, int K,
+                                          const __bf16 (*sa_cur)[LDA], __bf16 (*wlw)[2][32][WLD], int lr, int lh, int srow, int sk) {
+        const int nt1 = nt0 + 4;
+        const int nchunk = (K + WCH - 1) / WCH;
+        uint4 rgA[2][4], rgB[2][4];
+        auto fetch = [&](int c, auto S) {
+          constexpr int s = decltype(S)::value;
+          const int kk = c * WCH + sk;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + srow;
+            rgA[s][i] = make_uint4(0u, 0u, 0u, 0u);
+            rgB[s][i] = make_uint4(0u, 0u, 0u, 0u);
+            if (kk < K) {      // (a ternary between the load and a local zero would go through scratch and a flat load)
+              rgA[s][i] = *reinterpret_cast<const uint4*>(W + (long)min(nt0 * 32 + row, N - 1) * K + kk);
+              if (two) rgB[s][i] = *reinterpret_cast<const uint4*>(W + (long)min(nt1 * 32 + row, N - 1) * K + kk);
+            }
+          }
+        };
+        auto stage = [&](int lb, auto S) {
+          constexpr int s = decltype(S)::value;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&wlw[lb][0][i * 8 + srow][sk]) = rgA[s][i];
+          if (two) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(&wlw[lb][1][i * 8 + srow][sk]) = rgB[s][i];
+          }
+        };
+        auto mult = [&](int c, int lb) {
+#pragma unroll
+          for (int u = 0; u < WCH / 16; ++u) {
+            if (c * WCH + u * 16 >= K) break;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sa_cur[lr][c * WCH + u * 16 + 8 * lh]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&wlw[lb][0][lr][u * 16 + 8 * lh]);
+            accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, accA, 0, 0, 0);
+            if (two) {
+              const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&wlw[lb][1][lr][u * 16 + 8 * lh]);
+              accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, accB, 0, 0, 0);
+            }
+          }
+        };
+        fetch(0, I0{});
+        if (nchunk > 1) fetch(1, I1{});
+        for (int c = 0; c < nchunk; c += 2) {
+          stage(0, I0{});
+          if (c + 2 < nchunk) fetch(c + 2, I0{});
+          mult(c, 0);
+          if (c + 1 < nchunk) {
+            stage(1, I1{});
+            if (c + 3 < nchunk) fetch(c + 3, I1{});
+            mult(c + 1, 1);
+          }
+        }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
+  __shared__ __attribute__((aligned(16))) __bf16 wl[4][2][2][32][WLD];   // [wave][buffer][tile][row][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = (a.rows + RT - 1) / RT;
+  const int xslot = blockIdx.x >> 3;
+  const int g = (blockIdx.x & 7) + 8 * (xslot / tiles), r0 = (xslot % tiles) * RT;
+  if (g >= a.nb) return;
+  const long rowbase = (long)g * a.brows + r0;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int srow = lane >> 3, sk = (lane & 7) * 8;            // staging map: 8 rows x 64 k (bf16) per 16-byte instruction
+  load_tile_bf16(BWD ? a.dout : a.in, rowbase, r0, a.rows, BWD ? a.dims[a.nl] : a.dims[0], sa[0], tid);
+  __syncthreads();
+  int cur = 0;
+  for (int step = 0; step < a.nl; ++step) {
+    const int l = BWD ? a.nl - 1 - step : step;
+    const int K = BWD ? a.dims[l + 1] : a.dims[l];            // reduction width
+    const int N = BWD ? a.dims[l] : a.dims[l + 1];            // output width
+    float* __restrict__ dst = BWD ? (l > 0 ? a.dz[l] : a.din) : (l == a.nl - 1 ? a.out : a.act[l]);
+    if (BWD && !dst) break;
+    const __bf16* __restrict__ W = (BWD ? a.WbT[l] : a.Wb[l]) + (long)g * a.pstride;   // [N][K], K contiguous
+    const bool last = BWD ? l == 0 : l == a.nl - 1;
+    const int ntiles = (N + 31) / 32;
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    if (K < 16) {
+      // degenerate reduction (the 2-logit top layer of the CMI classifier, backward): plain FMAs
+      auto small = [&](f32x16& acc, int nt) {
+        const int n = nt * 32 + lr;
+        if (nt >= ntiles || n >= N) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = 0.f;
+          for (int kk = 0; kk < K; ++kk) v += (float)sa[cur][m][kk] * (float)W[(long)n * K + kk];
+          acc[r] = v;
+        }
+      };
+      small(acc0, wave); small(acc1, wave + 4); small(acc2, wave + 8);
+    } else {
+      // up to 3 output tiles per wave (N <= 384): a pair, then a single -- same staging as mlp_fwd_kernel
+      f32x16 dummy = acc2;
+      if (wave < ntiles) img_tiles(acc0, acc1, wave, wave + 4 < ntiles, W, N, K, sa[cur], wl[wave], lr, lh, srow, sk);
+      if (wave + 8 < ntiles) img_tiles(acc2, dummy, wave + 8, false, W, N, K, sa[cur], wl[wave], lr, lh, srow, sk);
+    }
+    // epilogue
+    const float* __restrict__ bias = BWD ? nullptr : a.b[l] + (long)g * a.pstride;
+    const float* __restrict__ mask = (BWD && l > 0) ? a.act[l - 1] : nullptr;
+    float* __restrict__ db = (BWD && l > 0 && a.db[l - 1]) ? a.db[l - 1] + (long)g * a.pstride : nullptr;
+    auto finish = [&](const f32x16& acc, int nt) {
+      const int n = nt * 32 + lr;
+      if (nt >= ntiles || n >= N) return;
+      const float bn = bias ? bias[n] : 0.f;
+      float csum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = r0 + m < a.rows;
+        float v = acc[r] + bn;
+        if (BWD) { if (mask) v = (ok && mask[(rowbase + m) * N + n] > 0.f) ? v : 0.f; }
+        else if (!last) v = fmaxf(v, 0.f);
+        if (ok) dst[(rowbase + m) * N + n] = v;
+        if (!last) sa[cur ^ 1][m][n] = to_bf16(v);
+        csum += v;
+      }
+      if (db) {
+        csum += __shfl_xor(csum, 32, 64);
+        if (lh == 0) atomicAdd(&db[n], csum);
+      }
+    };
+    finish(acc0, wave); finish(acc1, wave + 4); finish(acc2, wave + 8);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__global__ void bf16_image_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    bf16x4 p; p[0] = to_bf16(v.x); p[1] = to_bf16(v.y); p[2] = to_bf16(v.z); p[3] = to_bf16(v.w);
+    reinterpret_cast<bf16x4*>(dst)[i] = p;
+  }
+}
+
+__global__ void transpose_images_kernel(const float* __restrict__ src, __bf16* __restrict__ dstT, TransposeTable t) {
+  __shared__ float tile[32][33];
+  int z = blockIdx.z, e = 0;
+  while (e < t.n - 1 && z >= t.nb[e]) { z -= t.nb[e]; ++e; }
+  const int N = t.N[e], K = t.K[e];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  if (k0 >= K || n0 >= N) return;
+  const long base = t.off[e] + (long)z * t.gstride[e];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) tile[j][tx] = (n0 + j < N && k0 + tx < K) ? src[base + (long)(n0 + j) * K + k0 + tx] : 0.f;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (k0 + j < K && n0 + tx < N) dstT[base + (long)(k0 + j) * N + n0 + tx] = to_bf16(tile[tx][j]);
+}
+
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpFusedArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,6 +435,11 @@ static int check(const MlpFusedArgs& a) {
 
 int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   MX(check(a));
+  if (a.Wb[0]) {
+    hipLaunchKernelGGL(mlp_img_kernel<false>, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
@@ -280,7 +447,28 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
 
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   MX(check(a));
+  if (a.WbT[0]) {
+    hipLaunchKernelGGL(mlp_img_kernel<true>, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int bf16_image(hipStream_t s, const float* src, __bf16* dst, long n) {
+  if (n % 4 != 0) return set_error(MIMRL_ERR_ARG, "bf16_image: length must be a multiple of 4");
+  hipLaunchKernelGGL(bf16_image_kernel, dim3(1024), dim3(256), 0, s, src, dst, n / 4);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int bf16_transposed_images(hipStream_t s, const float* src, __bf16* dstT, const TransposeTable& t) {
+  if (t.n < 1 || t.n > 8) return set_error(MIMRL_ERR_ARG, "bf16_transposed_images: 1..8 table entries");
+  int z = 0, kmax = 0, nmax = 0;
+  for (int e = 0; e < t.n; ++e) { z += t.nb[e]; kmax = t.K[e] > kmax ? t.K[e] : kmax; nmax = t.N[e] > nmax ? t.N[e] : nmax; }
+  hipLaunchKernelGGL(transpose_images_kernel, dim3((kmax + 31) / 32, (nmax + 31) / 32, z), dim3(256), 0, s, src, dstT, t);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -99,6 +99,11 @@ class HipEngine:
             src = state[name]
             src = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src
             view.copy_(src.to(torch.float32).reshape(view.shape))
+        self.params_changed()
+
+    def params_changed(self):
+        """Call after writing parameter tensors from outside the engine (the bf16 weight images are rebuilt lazily)."""
+        check(self.lib.mimrl_params_changed(self.handle))
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.params.items()}
