@@ -73,22 +73,24 @@ class Solver:
         if e.bank_rows > 0 and not e.cfg.device_anchors:
             e.set_anchors(stage, synth.draw_anchors(e.bank_rows, e.m_anchor, 6))
 
-    def stage1_step(self, datas=None):
+    def stage1_step(self, datas=None, draw_anchors=True):
         """Critic update (Solver.py:205-214).  Returns the stage-1 loss as a device scalar."""
         if datas is not None:
             self._load(datas)
-        self._anchors(1)
+        if draw_anchors:
+            self._anchors(1)
         if self.world > 1:
             mdist.ddp_stage_step(self.engine, 1, self.world)
         else:
             self.engine.stage1_step()
         return self.engine.scalars[_lib.S1_LOSS]
 
-    def stage2_step(self, datas=None):
+    def stage2_step(self, datas=None, draw_anchors=True):
         """Model update (Solver.py:221-236).  Returns (loss, mis[8], pred[B,1]) as device tensors."""
         if datas is not None:
             self._load(datas)
-        self._anchors(2)
+        if draw_anchors:
+            self._anchors(2)
         if self.world > 1:
             mdist.ddp_stage_step(self.engine, 2, self.world)
         else:
@@ -106,8 +108,11 @@ class Solver:
         batch and stage 1 leaves the main model untouched, so the engine runs the stage-2 forward pass beside stage 1
         (`mimrl_set_stage2_prefetch`); the numbers are those of the sequential order."""
         self._prefetch(True)
-        l1 = self.stage1_step(datas)
-        l2, mis, pred = self.stage2_step()
+        self._load(datas)
+        self._anchors(1)          # host-drawn anchors (if any) for BOTH stages go up before stage 1: in overlap mode the
+        self._anchors(2)          # stage-2 kNN sampler already runs beside stage 1 (same draw order as the reference)
+        l1 = self.stage1_step(draw_anchors=False)
+        l2, mis, pred = self.stage2_step(draw_anchors=False)
         return l1, l2, mis, pred
 
     # ------------------------------------------------------------------ Solver.train (Solver.py:194-248)

@@ -136,6 +136,8 @@ struct mimrl_handle {
   // after mimrl_bind / mimrl_params_changed) and per-matrix transposed (rebuilt beside every estimator forward pass)
   __bf16 *crit_img = nullptr, *crit_imgT = nullptr;
   bool img_valid = false;
+  bool knn_pre = false;                // prefetch mode: also run stage 2's kNN sampling inside stage 1 (opt-in MIMRL_KNN_PREFETCH=1: measured 1 % slower)
+  bool mi_fused_bwd_done = false;      // mi_forward already produced the tower-output gradients (mi_sep_fused)
   bool imgT_ready = false;             // a transposed-image refresh has been issued for the estimator pass being enqueued
   TransposeTable ttab;
   int ensure_images() {
@@ -185,7 +187,7 @@ struct mimrl_handle {
   // estimators
   float *tin = nullptr, *ta[3], *tout = nullptr, *scores = nullptr, *dscores = nullptr;
   float *cP = nullptr, *cQ = nullptr, *ca[3];
-  int* knn_idx = nullptr;
+  int *knn_idx = nullptr, *knn_idx2 = nullptr;   // neighbour indices; stage 2 has its own set (prefetch mode samples it early)
   float *cmi_in = nullptr, *cc[3], *logits = nullptr, *dlogits = nullptr;
   float *mi_raw = nullptr, *cmi_raw = nullptr, *bce_raw = nullptr;
   // backward temporaries
@@ -537,7 +539,7 @@ int mimrl_handle::carve() {
   }
   MX(take(&dtin, 10 * B * EMB));
   const size_t n = nprod();
-  MX(take(&knn_idx, NE_CMI * n));
+  MX(take(&knn_idx, NE_CMI * n)); MX(take(&knn_idx2, NE_CMI * n));
   MX(take(&cmi_in, NE_CMI * 2 * n * 384));
   for (int l = 0; l < 3; ++l) MX(take(&cc[l], NE_CMI * 2 * n * HID));
   MX(take(&logits, NE_CMI * 2 * n * 2));
@@ -1344,9 +1346,9 @@ int mimrl_handle::knn_launch(int stage, hipStream_t st) {
   const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
   int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
   if (cfg.device_anchors)
-    MX(sample_anchors(st, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage));
+    MX(sample_anchors(st, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage, rng_add));
   KnnArgs ka;
-  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = knn_idx;
+  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = stage == 2 ? knn_idx2 : knn_idx;
   for (int e = 0; e < NE_CMI; ++e) {
     const int z = kCmiWire[e][2];
     ka.call[e].Z = bank[z]; ka.call[e].dz = z == FT_C ? 1 : EMB;
@@ -1371,6 +1373,14 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
   if (sep) {
     const int dims[5] = {EMB, HID, HID, HID, EMB};
     MX(mlp_stack_forward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, tout));
+    static const bool no_fused_mi = getenv("MIMRL_NO_FUSED_MI") != nullptr;   // tuning knob
+    mi_fused_bwd_done = false;
+    if (!no_fused_mi && (prec & MIMRL_PREC_BF16_GEMM_FWD) && (prec & MIMRL_PREC_BF16_GEMM_BWD) && mi_sep_fused_supported(B)) {
+      // scores, bound, d/dscores and the gradients of both tower outputs in one launch per stage (estimator_ops.hip)
+      mi_fused_bwd_done = want_grad;
+      return mi_sep_fused(stream, tout, dtout, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B, cfg.bound_type,
+                          stage == 1 ? 0x1fu : 0x07u, want_grad ? 1 : 0);
+    }
     GemmDesc g;   // scores_e = h(y) g(x)^T   (VMI.py:55-57)
     g.A = tout + BD; g.sa_m = EMB; g.sa_k = 1; g.sa_b = 2 * (long)BD;
     g.B = tout; g.sb_k = 1; g.sb_n = EMB; g.sb_b = 2 * (long)BD;
@@ -1404,7 +1414,7 @@ int mimrl_handle::cmi_forward(int stage, bool want_grad) {
   const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
   CmiAssembleArgs ca_;
   ca_.anchors = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
-  ca_.idx_x = knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
+  ca_.idx_x = stage == 2 ? knn_idx2 : knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
   for (int e = 0; e < NE_CMI; ++e)
     for (int o = 0; o < 3; ++o) {
       const int f = kCmiWire[e][o];
@@ -1423,6 +1433,10 @@ int mimrl_handle::mi_backward(int stage) {
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
   const bool wgrad = stage == 1;
   float* din_mi = stage == 2 ? dtin : nullptr;
+  if (sep && mi_fused_bwd_done) {   // dtout already written by mi_sep_fused
+    const int dims[5] = {EMB, HID, HID, HID, EMB};
+    return mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad);
+  }
   if (sep) {
     GemmDesc gh;   // d h = dS g
     gh.A = dscores; gh.sa_m = B; gh.sa_k = 1; gh.sa_b = (long)B * B;
@@ -1476,8 +1490,9 @@ int mimrl_handle::cmi_backward(int stage) {
 int mimrl_handle::route_feature_grads() {
   const int B = cfg.batch, n = nprod();
   const size_t BD = (size_t)B * EMB;
+  GatherSum4 g4;
   for (int f = 0; f < 4; ++f) {
-    GatherSum gs;
+    GatherSum& gs = g4.g[f];
     gs.n = 0;
     for (int e = 0; e < NE_MI; ++e)
       for (int sd = 0; sd < 2; ++sd)
@@ -1489,9 +1504,9 @@ int mimrl_handle::route_feature_grads() {
         if (kCmiWire[e][o] == f) {
           gs.src[gs.n] = dcin + (size_t)e * 2 * n * 384; gs.ld[gs.n] = 384; gs.off[gs.n] = o * EMB; gs.rows[gs.n] = n; ++gs.n;
         }
-    MX(gather_sum(stream, dfeat + f * BD, gs, B, EMB, 0));
+    g4.dst[f] = dfeat + f * BD;
   }
-  return MIMRL_OK;
+  return gather_sum4(stream, g4, B, EMB);
 }
 
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
@@ -1503,17 +1518,20 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
     imgT_ready = true;
   }
+  static const int dbg_skip = getenv("MIMRL_DBG_SKIP_EST") ? atoi(getenv("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
   MX(fork(5, 5));
   MX(chain(5, 4));                       // the CMI branch needs the kNN indices
-  {
+  if (!(dbg_skip & 1)) {
     StreamGuard g(this, S(5));
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
     if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(chain(5, 3)); MX(cmi_backward(stage)); }
   }
   bf16 = bf_fwd;
+  if (!(dbg_skip & 2)) {
   { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
   if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(join(3, 3)); Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); }
+  }
   bf16 = bf_fwd;
   if (!multi_stream) return MIMRL_OK;
   return join(5, 5);
@@ -1565,6 +1583,11 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       side_mask = 0x11u;                 // text branch (side 0) + kNN sampler (side 4)
       r1 = model_forward(true, false, 1);
       side_mask = ~0u;
+      if (r1 == 0 && knn_pre) {          // stage 2's kNN sampler rides on side 4 behind stage 1's: stage 2 then starts
+        rng_add = 1;                     // straight at its estimators (anchor key = the step counter begin_stage(2) will set)
+        r1 = knn_launch(2, S(4));
+        rng_add = 0;
+      }
     } else {
       r1 = model_forward(true, false, 1);
     }
@@ -1586,9 +1609,8 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   LAUNCH_CHECK();
   if (!skip_zero) HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-  if (prefetch && have_banks) {   // forward pass already done beside stage 1; only the kNN sampler is left to start
-    MX(fork(4, 4));
-    MX(knn_launch(2, S(4)));
+  if (prefetch && have_banks) {   // forward pass (and kNN sampling) already done beside stage 1
+    if (!knn_pre) { MX(fork(4, 4)); MX(knn_launch(2, S(4))); }
   } else {
     MX(model_forward(true, true, have_banks ? 2 : 0));
   }
@@ -1711,6 +1733,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
   h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
+  h->knn_pre = getenv("MIMRL_KNN_PREFETCH") != nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }

@@ -13,6 +13,10 @@ int copy_rows(hipStream_t s, const CopyTable& t, long floats_each);
 
 // scores [E][B][B] -> mi[e] (bound value) and dscores = gscale[e] * d(mi)/d(scores)   (one workgroup / estimator)
 // gscale lives in device memory (loss coefficient with sign); dscores may be null (evaluation only).
+// separable critic: scores, bound and the gradients w.r.t. both tower outputs in one launch (tout/dtout: [E][2][B][128])
+bool mi_sep_fused_supported(int B);
+int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B,
+                 int bound, unsigned lossform, int do_bwd);
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
                      int B, int bound, unsigned lossform);
 
@@ -37,7 +41,7 @@ int knn_sample(hipStream_t s, const KnnArgs& a);
 // 32-bit key (counter hash of seed/step/call/row); the m rows with the smallest keys, in key order, are the
 // anchors -- a uniformly random m-subset in uniformly random order.  One workgroup per call, bitonic sort in LDS.
 int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
-                   const int* step, uint32_t stream_id);
+                   const int* step, uint32_t stream_id, int step_add = 0);
 
 // classifier input batch (Model.py:160-174):
 //   rows [0,n): joint = [x | y | z] of the current batch (operand = feature block [B,128] or the label column)
@@ -59,6 +63,8 @@ int cmi_loss_fwd_bwd(hipStream_t s, const float* logits, float* dlogits, float* 
 // dst[b,:] (+)= sum_i src_i[b*ld_i + off_i + :]  for rows b < rows_i   (deterministic gather-sum of input gradients)
 struct GatherSum { const float* src[12]; int ld[12]; int off[12]; int rows[12]; int n; };
 int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int accumulate);
+struct GatherSum4 { GatherSum g[4]; float* dst[4]; };   // four destinations in one launch (F, T, A, V feature gradients)
+int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D);
 
 // fused gradient value-clip + Adam over one flat bucket (Solver.py:144-146,211-213; torch.optim.Adam semantics)
 struct AdamArgs {

@@ -26,15 +26,11 @@ __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + lo
 // mean(diag) - mean(exp_nodiag) / ma_et with ma_et = 0.99 + 0.01 mean(exp_nodiag) detached and NOT negated
 // (Model.py:121-125).  Bit e of `lossform` says whether estimator e contributes through that loss (stage 1: all five,
 // stage 2: f_t, f_a, f_v -- t_a and t_v enter through -mi, Model.py:386) -- it selects the gradient written to dscores.
-__global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict__ scores, float* __restrict__ dscores,
-                                                        float* __restrict__ mi, float* __restrict__ mil,
-                                                        const float* __restrict__ gscale, int B, int bound, unsigned lossform) {
-  __shared__ float red[16];
-  __shared__ float rowstat[1024];   // per-row lse (InfoNCE); B <= 1024
-  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-  const float* __restrict__ S = scores + (long)e * B * B;
-  float* __restrict__ dS = dscores ? dscores + (long)e * B * B : nullptr;
-  const float gs = gscale ? gscale[e] : 0.f;
+// S / dS may alias (every gradient entry depends on its own score and on reductions finished before it is written) and
+// may live in LDS (generic pointers): the fused separable-critic kernel below runs this body on its on-chip score tile.
+__device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi, float* __restrict__ mil, float gs, int e, int B,
+                              int bound, unsigned lossform, float* red, float* rowstat) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const float invB = 1.f / B;
 
   if (bound == BOUND_INFONCE) {
@@ -120,6 +116,83 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict_
     else if (bound == BOUND_DV || bound == BOUND_MINE) g = (i == j) ? invB : -__expf(v - mx) / se;
     else g = (i == j) ? sigmoid_f(-v) * invB : -sigmoid_f(v) / M;          // js_fgan / js / smile
     dS[idx] = gs * g;
+  }
+}
+
+__global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict__ scores, float* __restrict__ dscores,
+                                                        float* __restrict__ mi, float* __restrict__ mil,
+                                                        const float* __restrict__ gscale, int B, int bound, unsigned lossform) {
+  __shared__ float red[16];
+  __shared__ float rowstat[1024];   // per-row lse (InfoNCE); B <= 1024
+  const int e = blockIdx.x;
+  mi_bound_body(scores + (long)e * B * B, dscores ? dscores + (long)e * B * B : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B,
+                bound, lossform, red, rowstat);
+}
+
+// Separable critic, one estimator per workgroup, everything between the tower outputs and their gradients on chip:
+//   scores = h(y) g(x)^T (VMI.py:55-57) -> bound (+ d/dscores, in place in LDS) -> d h = dS g,  d g = dS^T h.
+// 16 waves: one 32x32 MFMA tile each (B <= 128, B % 32 == 0); bf16 operands, fp32 accumulate.
+__global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restrict__ tout, float* __restrict__ dtout,
+                                                            float* __restrict__ mi, float* __restrict__ mil,
+                                                            const float* __restrict__ gscale, int B, int bound,
+                                                            unsigned lossform, int do_bwd) {
+  extern __shared__ float S[];      // [B][B]
+  __shared__ float red[16];
+  __shared__ float rowstat[1024];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int nt = B / 32;
+  const float* __restrict__ X = tout + (long)(2 * e) * B * 128;       // g(x)
+  const float* __restrict__ Y = tout + (long)(2 * e + 1) * B * 128;   // h(y)
+  auto frag_rows = [&](const float* __restrict__ M, int row, int ks) {   // 8 consecutive k of one row -> bf16x8
+    const float4 a = *reinterpret_cast<const float4*>(M + (long)row * 128 + ks * 16 + 8 * lh);
+    const float4 b = *reinterpret_cast<const float4*>(M + (long)row * 128 + ks * 16 + 8 * lh + 4);
+    bf16x8 p;
+    p[0] = to_bf16(a.x); p[1] = to_bf16(a.y); p[2] = to_bf16(a.z); p[3] = to_bf16(a.w);
+    p[4] = to_bf16(b.x); p[5] = to_bf16(b.y); p[6] = to_bf16(b.z); p[7] = to_bf16(b.w);
+    return p;
+  };
+  if (wave < nt * nt) {
+    const int ti = wave / nt, tj = wave % nt;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Y, ti * 32 + lr, ks), frag_rows(X, tj * 32 + lr, ks), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * B + tj * 32 + lr] = acc[r];
+  }
+  __syncthreads();
+  mi_bound_body(S, do_bwd ? S : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B, bound, lossform, red, rowstat);
+  if (!do_bwd) return;
+  __syncthreads();
+  // d h[i][n] = sum_j dS[i][j] g[j][n]   and   d g[j][n] = sum_i dS[i][j] h[i][n]:  nt x 4 tiles each, wave -> (row tile, n tile)
+  if (wave < nt * 4) {
+    const int tr = wave >> 2, tn = wave & 3;
+    f32x16 ah, ag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ah[r] = 0.f; ag[r] = 0.f; }
+    for (int ks = 0; ks < B / 16; ++ks) {
+      const int k0 = ks * 16 + 8 * lh;
+      bf16x8 a1, a2, b1, b2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        a1[q] = to_bf16(S[(tr * 32 + lr) * B + k0 + q]);          // dS[i][j..]
+        a2[q] = to_bf16(S[(k0 + q) * B + tr * 32 + lr]);          // dS[i..][j]
+        b1[q] = to_bf16(X[(long)(k0 + q) * 128 + tn * 32 + lr]);
+        b2[q] = to_bf16(Y[(long)(k0 + q) * 128 + tn * 32 + lr]);
+      }
+      ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, ah, 0, 0, 0);
+      ag = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, ag, 0, 0, 0);
+    }
+    float* __restrict__ dX = dtout + (long)(2 * e) * B * 128;
+    float* __restrict__ dY = dtout + (long)(2 * e + 1) * B * 128;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      dY[(long)row * 128 + tn * 32 + lr] = ah[r];
+      dX[(long)row * 128 + tn * 32 + lr] = ag[r];
+    }
   }
 }
 
@@ -320,10 +393,10 @@ __global__ __launch_bounds__(256) void cmi_loss_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sample_anchors_kernel(int* __restrict__ anchors, int m, int N, int npow2,
                                                               uint32_t seed_lo, uint32_t seed_hi,
-                                                              const int* __restrict__ step, uint32_t stream_id) {
+                                                              const int* __restrict__ step, uint32_t stream_id, int step_add) {
   extern __shared__ unsigned long long keys[];   // (hash << 32) | row ; padding = ~0
   const int c = blockIdx.x;
-  const uint32_t st = (uint32_t)*step;
+  const uint32_t st = (uint32_t)(*step + step_add);
   for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
     unsigned long long k = ~0ull;
     if (i < N) {
@@ -358,6 +431,18 @@ __global__ void gather_sum_kernel(float* __restrict__ dst, GatherSum g, int B, i
   }
 }
 
+__global__ void gather_sum4_kernel(GatherSum4 a, int B, int D) {
+  const GatherSum& g = a.g[blockIdx.y];
+  float* __restrict__ dst = a.dst[blockIdx.y];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * D; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / D, d = i % D;
+    float s = 0.f;
+    for (int q = 0; q < g.n; ++q)
+      if (b < g.rows[q]) s += g.src[q][(long)b * g.ld[q] + g.off[q] + d];
+    dst[i] = s;
+  }
+}
+
 __global__ void adam_kernel(AdamArgs a) {
   const int t = *a.step;
   const float lr = *a.lr;
@@ -383,6 +468,21 @@ __global__ void adam_kernel(AdamArgs a) {
 int copy_rows(hipStream_t s, const CopyTable& t, long n) {
   if (t.n <= 0) return MIMRL_OK;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(n, 256, 64), t.n), dim3(256), 0, s, t, n);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+bool mi_sep_fused_supported(int B) { return B >= 32 && B <= 128 && B % 32 == 0; }
+int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B,
+                 int bound, unsigned lossform, int do_bwd) {
+  if (!mi_sep_fused_supported(B)) return set_error(MIMRL_ERR_ARG, "mi_sep_fused: batch %d unsupported", B);
+  static bool attr = false;
+  if (!attr) {
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(mi_sep_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr = true;
+  }
+  hipLaunchKernelGGL(mi_sep_fused_kernel, dim3(E), dim3(1024), (size_t)B * B * sizeof(float), s, tout, dtout, mi, mil, gscale, B,
+                     bound, lossform, do_bwd);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -430,7 +530,7 @@ int knn_sample(hipStream_t s, const KnnArgs& a) {
 }
 
 int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
-                   const int* step, uint32_t stream_id) {
+                   const int* step, uint32_t stream_id, int step_add) {
   int npow2 = 1;
   while (npow2 < N) npow2 <<= 1;
   if (npow2 < 2) npow2 = 2;
@@ -440,7 +540,7 @@ int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_
   if (sh > 64 * 1024)
     HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_anchors_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
   hipLaunchKernelGGL(sample_anchors_kernel, dim3(ncall), dim3(1024), sh, s, anchors, m, N, npow2, seed_lo, seed_hi, step,
-                     stream_id);
+                     stream_id, step_add);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -460,6 +560,12 @@ int cmi_loss_fwd_bwd(hipStream_t s, const float* logits, float* dlogits, float* 
 
 int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int accumulate) {
   hipLaunchKernelGGL(gather_sum_kernel, dim3(grid_for((long)B * D)), dim3(256), 0, s, dst, g, B, D, accumulate);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D) {
+  hipLaunchKernelGGL(gather_sum4_kernel, dim3(grid_for((long)B * D), 4), dim3(256), 0, s, g, B, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
