@@ -191,7 +191,7 @@ struct mimrl_handle {
   float *cmi_in = nullptr, *cc[3], *logits = nullptr, *dlogits = nullptr;
   float *mi_raw = nullptr, *cmi_raw = nullptr, *bce_raw = nullptr;
   // backward temporaries
-  float *dfeat = nullptr, *dtout = nullptr, *dta[3], *dtin = nullptr, *dca[2], *dP = nullptr, *dQ = nullptr;
+  float *dfeat = nullptr, *dtout = nullptr, *dta[3], *dtin = nullptr, *dca[3], *dP = nullptr, *dQ = nullptr;
   float *dcc[3], *dcin = nullptr;
   static constexpr int NGBUF = 24;   // cube backward: rotating (4 in use) or one-shot (deferred weight gradients)
   float* gbuf[NGBUF];
@@ -442,6 +442,9 @@ int mimrl_handle::resolve() {
     if (cfg.critic_type == MIMRL_CRITIC_SEPARATE) {
       const int d[5] = {EMB, HID, HID, HID, EMB};
       for (int l = 0; l < 4; ++l) add(tower0 + tower_l[l][0], d[l + 1], d[l], 10, tower_stride);
+    } else {   // concat critic: the tail 256 -> 256 -> 256 -> 1 behind the pair-expanded first layer
+      const int d[4] = {HID, HID, HID, 1};
+      for (int l = 0; l < 3; ++l) add(tower0 + tower_l[l + 1][0], d[l + 1], d[l], NE_MI, tower_stride);
     }
     const int c[5] = {3 * EMB, HID, HID, HID, 2};
     for (int l = 0; l < 4; ++l) add(cmi0 + cmi_l[l][0], c[l + 1], c[l], NE_CMI, cmi_stride);
@@ -535,7 +538,7 @@ int mimrl_handle::carve() {
     MX(take(&cP, NE_MI * B * HID)); MX(take(&cQ, NE_MI * B * HID));
     MX(take(&dP, NE_MI * B * HID)); MX(take(&dQ, NE_MI * B * HID));
     for (int l = 0; l < 3; ++l) MX(take(&ca[l], NE_MI * B * B * HID));
-    for (int l = 0; l < 2; ++l) MX(take(&dca[l], NE_MI * B * B * HID));
+    for (int l = 0; l < 3; ++l) MX(take(&dca[l], NE_MI * B * B * HID));
   }
   MX(take(&dtin, 10 * B * EMB));
   const size_t n = nprod();
@@ -1250,7 +1253,8 @@ int mimrl_handle::conv_backward() {
 // =================================================================================================
 int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
                                     const int* dims, const float* in, float* const* act, float* out) {
-  if (bf16 && fused_mlp && rows <= 512 && mlp_fused_supported(nb, rows, nl, dims)) {   // small stacks: one launch (mlp_fused.hip)
+  const bool big_ok = img_valid && crit_img && rows >= 2048 && dims[0] <= 256;   // concat-critic tail: direct-from-L2 variant
+  if (bf16 && fused_mlp && (rows <= 512 || big_ok) && mlp_fused_supported(nb, rows, nl, dims)) {   // one launch (mlp_fused.hip)
     MlpFusedArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.nb = nb; fa.rows = rows; fa.brows = brows; fa.nl = nl; fa.pstride = pstride; fa.in = in; fa.out = out;
@@ -1285,6 +1289,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
   // the fused data-gradient chain runs on the transposed bf16 images (the same coalesced loop as the forward pass)
   static const bool fused_bwd = getenv("MIMRL_NO_FUSED_MLP_BWD") == nullptr;
+  // (stacks with thousands of row tiles -- the concat critic -- keep the GEMM chain here: measured faster than the fused one)
   if (bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims)) {
     // the whole data-gradient chain in one launch (dtmp must hold nl-1 buffers here); weight gradients follow as GEMMs
     MlpFusedArgs fa;
@@ -1451,9 +1456,11 @@ int mimrl_handle::mi_backward(int stage) {
     return mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad);
   }
   const int dims[4] = {HID, HID, HID, 1};
+  // (the gradient of the pair-expanded first layer gets its own buffer: the fused chain keeps every dZ alive for the
+  // weight-gradient GEMMs)
   MX(mlp_stack_backward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], dscores, dca,
-                        dca[0], wgrad));
-  MX(pair_expand_bwd(stream, ca[0], dca[0], dP, dQ, NE_MI, B, HID));
+                        dca[2], wgrad));
+  MX(pair_expand_bwd(stream, ca[0], dca[2], dP, dQ, NE_MI, B, HID));
   if (wgrad) {
     GemmDesc g;   // dW0[:, :128] = dP^T x ; dW0[:, 128:] = dQ^T y ; db0 = colsum(dQ)
     g.A = dP; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * HID;

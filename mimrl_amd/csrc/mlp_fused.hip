@@ -214,14 +214,42 @@ __device__ __forceinline__ void img_tiles(f32x16& accA, f32x16& accB, int nt0, b
         }
 }
 
-template <bool BWD>
+// the same pair of output tiles with B-fragments loaded straight from the (L2-resident) image: for stacks with
+// thousands of row tiles (the concat critic: B^2 rows per estimator) every workgroup re-reads the same small weights,
+// so nothing is staged and nothing has to be hidden -- all loads of a layer are issued up front (K <= 256)
+__device__ __forceinline__ void img_tiles_direct(f32x16& accA, f32x16& accB, int nt0, bool two, const __bf16* __restrict__ W,
+                                                 int N, int K, const __bf16 (*sa_cur)[LDA], int lr, int lh) {
+  const __bf16* __restrict__ w0 = W + (long)min(nt0 * 32 + lr, N - 1) * K + 8 * lh;
+  const __bf16* __restrict__ w1 = W + (long)min((nt0 + 4) * 32 + lr, N - 1) * K + 8 * lh;
+  bf16x8 b0[16], b1[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    if (ks * 16 < K) {
+      b0[ks] = *reinterpret_cast<const bf16x8*>(w0 + ks * 16);
+      if (two) b1[ks] = *reinterpret_cast<const bf16x8*>(w1 + ks * 16);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    if (ks * 16 < K) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sa_cur[lr][ks * 16 + 8 * lh]);
+      accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0[ks], accA, 0, 0, 0);
+      if (two) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1[ks], accB, 0, 0, 0);
+    }
+  }
+}
+
+template <bool BWD, bool DIRECT>
 __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
-  __shared__ __attribute__((aligned(16))) __bf16 wl[4][2][2][32][WLD];   // [wave][buffer][tile][row][k]
+  __shared__ __attribute__((aligned(16))) __bf16 wl[DIRECT ? 1 : 4][2][2][32][WLD];   // [wave][buffer][tile][row][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = (a.rows + RT - 1) / RT;
   const int xslot = blockIdx.x >> 3;
-  const int g = (blockIdx.x & 7) + 8 * (xslot / tiles), r0 = (xslot % tiles) * RT;
+  // staged variant: a group (one weight set) is pinned to one XCD; direct variant (thousands of tiles per group, weights
+  // hot in every L2): plain (tile, group) grid over the whole chip
+  const int g = DIRECT ? blockIdx.y : (blockIdx.x & 7) + 8 * (xslot / tiles);
+  const int r0 = (DIRECT ? blockIdx.x : xslot % tiles) * RT;
   if (g >= a.nb) return;
   const long rowbase = (long)g * a.brows + r0;
   const int lr = lane & 31, lh = lane >> 5;
@@ -258,8 +286,13 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
     } else {
       // up to 3 output tiles per wave (N <= 384): a pair, then a single -- same staging as mlp_fwd_kernel
       f32x16 dummy = acc2;
-      if (wave < ntiles) img_tiles(acc0, acc1, wave, wave + 4 < ntiles, W, N, K, sa[cur], wl[wave], lr, lh, srow, sk);
-      if (wave + 8 < ntiles) img_tiles(acc2, dummy, wave + 8, false, W, N, K, sa[cur], wl[wave], lr, lh, srow, sk);
+      if constexpr (DIRECT) {
+        if (wave < ntiles) img_tiles_direct(acc0, acc1, wave, wave + 4 < ntiles, W, N, K, sa[cur], lr, lh);
+        if (wave + 8 < ntiles) img_tiles_direct(acc2, dummy, wave + 8, false, W, N, K, sa[cur], lr, lh);
+      } else {
+        if (wave < ntiles) img_tiles(acc0, acc1, wave, wave + 4 < ntiles, W, N, K, sa[cur], wl[wave], lr, lh, srow, sk);
+        if (wave + 8 < ntiles) img_tiles(acc2, dummy, wave + 8, false, W, N, K, sa[cur], wl[wave], lr, lh, srow, sk);
+      }
     }
     // epilogue
     const float* __restrict__ bias = BWD ? nullptr : a.b[l] + (long)g * a.pstride;
@@ -421,10 +454,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpFusedArgs a) {
 }  // namespace
 
 bool mlp_fused_supported(int nb, int rows, int nl, const int* dims) {
-  if (nl < 1 || nl > MLPF_MAX_LAYERS || nb < 1 || rows < 1 || rows > 1024) return false;
+  if (nl < 1 || nl > MLPF_MAX_LAYERS || nb < 1 || rows < 1) return false;
   for (int l = 0; l < nl; ++l)
     if (dims[l] % 64 != 0 || dims[l] > MLPF_MAX_WIDTH) return false;   // every layer input: k-chunks of 64, <= 12 output tiles
   return dims[nl] >= 1 && dims[nl] <= 256;
+}
+
+// many row tiles per group and every layer width <= 256: weights are hot in L2, read the fragments directly
+static bool mlp_direct(const MlpFusedArgs& a) {
+  if (a.rows < 2048) return false;
+  for (int l = 0; l <= a.nl; ++l)
+    if (a.dims[l] > 256) return false;
+  return true;
 }
 
 static int check(const MlpFusedArgs& a) {
@@ -436,7 +477,8 @@ static int check(const MlpFusedArgs& a) {
 int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   MX(check(a));
   if (a.Wb[0]) {
-    hipLaunchKernelGGL(mlp_img_kernel<false>, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+    if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<false, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp_img_kernel<false, false>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return MIMRL_OK;
   }
@@ -448,7 +490,8 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   MX(check(a));
   if (a.WbT[0]) {
-    hipLaunchKernelGGL(mlp_img_kernel<true>, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
+    if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<true, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mlp_img_kernel<true, false>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return MIMRL_OK;
   }
