@@ -14,6 +14,9 @@ CONFIGS = {
     "tiny_conv": dict(B=8, T=6, N=40, seed=5, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="conv"),
     # mine bound: its loss term is not -mi (Model.py:121-125), and stage 2 mixes both forms (Model.py:386)
     "tiny_mine": dict(B=8, T=6, N=40, seed=6, critic="separate", cube="6-3-128=4-3-128", traj=2, bound="mine"),
+    # awkward sizes: batch not a multiple of the tile sizes, inputs shorter than --time_len (zero padding of the cube,
+    # Model.py:468-470), k_neighbor=3, ragged lengths
+    "tiny_odd": dict(B=12, T=5, L=8, N=50, seed=7, critic="separate", cube="8-3-128=3-3-128", traj=2, ragged=True, k=3),
     # BASELINE cfg1: B=32, T=50, canonical README flags, N=1000 as in the reference smoke test (Model.py:607)
     "cfg1_sep": dict(B=32, T=50, N=1000, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=6),
     "cfg1_cat": dict(B=32, T=50, N=1000, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
@@ -29,11 +32,11 @@ def make_opt(c):
     cube = parse_cube(c["cube"])
     return SimpleNamespace(
         batch_size=c["B"], d_common=128, encoders=c.get("encoders", "gru"), features_compose_t="mean", features_compose_k="mean",
-        num_class=1, activate="gelu", time_len=c["T"], d_hiddens=cube, d_outs=cube,
+        num_class=1, activate="gelu", time_len=c.get("L", c["T"]), d_hiddens=cube, d_outs=cube,
         dropout_mlp=[0.0, 0.0, 0.0], dropout=[0.0, 0.0, 0.0, 0.0], bias=True, ln_first=c.get("ln_first", False),
         res_project=[True] * len(cube), critic_type=c["critic"], baseline_type="constant",
         bound_type=c.get("bound", "infonce"), loss_mi_coefficient1=[1.0] * 11, loss_mi_coefficient2=[0.01] * 8,
-        mi_lr_rate=1.0, cmi_lr_rate=1.0, k_neighbor=2, radius=1.0, cmi_last_acticate=c.get("cmi_last", "sigmoid"),
+        mi_lr_rate=1.0, cmi_lr_rate=1.0, k_neighbor=c.get("k", 2), radius=1.0, cmi_last_acticate=c.get("cmi_last", "sigmoid"),
         stage1_n=1, loss="MAE", gradient_clip=1.5, optm="Adam", learning_rate=4e-3, weight_decay=0.0,
         dataset="mosi_Dec", parallel=True, text="none",
     )
