@@ -317,3 +317,33 @@ def test_fused_cube_backward_matches_unfused(name, monkeypatch):
         worst = min(worst, cos)
         assert cos > 0.995 and abs(na / nb - 1) < 0.05, f"{n}: cosine {cos}, norm ratio {na / nb}"
     assert worst > 0.995
+
+
+@pytest.mark.parametrize("name", TINY + ["cfg1_cat"])
+def test_bf16_fused_paths_on_every_fixture(name):
+    """Every fixture (odd sizes, ragged, conv encoder, concat critic, ln_first, mine ...) through the bf16 product path with
+    all fused kernels, hipGraph and Solver.step() overlap mode on: losses and MI terms of the first step stay within bf16
+    distance of the fp32 run, and two more steps stay finite."""
+    res = {}
+    for precision in ("fp32", "bf16"):
+        c, opt, batch, banks, p, eng = make_engine(name, precision=precision, use_graph=precision == "bf16")
+        g = load_golden(name)
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(1, g["anchors"][0, 0])
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.set_stage2_prefetch(precision == "bf16")
+        eng.step()
+        res[precision] = eng.read_scalars().copy()
+        if precision == "bf16":
+            eng.step(); eng.step()
+            assert np.isfinite(eng.read_scalars()).all()
+            assert torch.isfinite(eng.main["p"]).all() and torch.isfinite(eng.crit["p"]).all()
+        eng.close()
+    a, b = res["bf16"], res["fp32"]
+    assert_close(a[_lib.S1_LOSS], b[_lib.S1_LOSS], 2e-2, 2e-2, "stage-1 loss")
+    if opt.cmi_last_acticate != "hardtanh":
+        assert_close(a[_lib.S2_LOSS], b[_lib.S2_LOSS], 2e-2, 2e-2, "stage-2 loss")
+    # the hardtanh CMI head clamps probabilities to [1e-4, 1-1e-4]: with 8 samples one logit crossing the clamp moves a
+    # CMI term by ~1 in any reduced precision (same numbers with every fused kernel switched off), so only MI terms there
+    nmi = 4 if opt.cmi_last_acticate == "hardtanh" else 8
+    assert_close(a[_lib.S2_MIS:_lib.S2_MIS + nmi], b[_lib.S2_MIS:_lib.S2_MIS + nmi], 5e-2, 3e-2, "stage-2 MI terms")
