@@ -29,7 +29,7 @@ enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -
 enum { MIMRL_GROUP_MAIN = 0, MIMRL_GROUP_CRITIC = 1 };
 enum { MIMRL_CRITIC_SEPARATE = 0, MIMRL_CRITIC_CONCAT = 1 };                       /* VMI.py:35-45 */
 enum { MIMRL_BOUND_INFONCE = 0, MIMRL_BOUND_NWJ, MIMRL_BOUND_TUBA, MIMRL_BOUND_DV, MIMRL_BOUND_JS_FGAN,
-       MIMRL_BOUND_JS, MIMRL_BOUND_SMILE, MIMRL_BOUND_MINE };                                        /* Model.py:121-146 */
+       MIMRL_BOUND_JS, MIMRL_BOUND_SMILE, MIMRL_BOUND_MINE, MIMRL_BOUND_INTERPOLATE };                                        /* Model.py:121-146 */
 enum { MIMRL_ACT_NONE = 0, MIMRL_ACT_RELU = 1, MIMRL_ACT_GELU = 2, MIMRL_ACT_TANH = 3 };
 /* MFMA operand type per section (bit mask); accumulation, recurrent state, statistics and optimizer are always fp32 */
 enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16_GEMM_FWD = 1, MIMRL_PREC_BF16_GEMM_BWD = 2, MIMRL_PREC_BF16_GRU_FWD = 4,

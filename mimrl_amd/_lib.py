@@ -13,7 +13,7 @@ NSCALARS = 64
 PHASES = ["gemm_misc", "gru_fwd", "gru_bwd", "cube_fwd", "cube_bwd", "est_fwd", "est_bwd", "opt", "model_misc"]
 S1_LOSS, S1_MIS, S1_LOSSES, S2_LOSS, S2_TASK, S2_MIS, S2_LOSSES = 0, 1, 12, 32, 33, 34, 42
 
-BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6, "mine": 7}
+BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6, "mine": 7, "interpolate": 8}
 ACTS = {"none": 0, "relu": 1, "gelu": 2, "tanh": 3}
 PREC = {"fp32": 0, "bf16": 15, "bf16_fwd": 5, "bf16_gemm_fwd": 1, "bf16_gemm_bwd": 2, "bf16_gru": 12, "bf16_gru_fwd": 4,
         "bf16_gru_bwd": 8, "bf16_nogemmbwd": 13}

@@ -5,7 +5,7 @@
 namespace mimrl {
 
 enum Bound : int { BOUND_INFONCE = 0, BOUND_NWJ = 1, BOUND_TUBA = 2, BOUND_DV = 3, BOUND_JS_FGAN = 4, BOUND_JS = 5,
-                   BOUND_SMILE = 6, BOUND_MINE = 7 };
+                   BOUND_SMILE = 6, BOUND_MINE = 7, BOUND_INTERP = 8 };
 
 // copy rows:  dst[i][b,:] = src[i][b,:]   for i < n (table of pointers; used to gather tower inputs)
 struct CopyTable { const float* src[16]; float* dst[16]; int n; };

@@ -59,6 +59,79 @@ __device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi,
     return;
   }
 
+  if (bound == BOUND_INTERP) {
+    // interpolated bound (VMI.py:201-250) with the constant baseline and alpha_logit = 0.01 (Model.py:118):
+    //   I_ij = logaddexp(log a + L_ij - log(B-1), log(1-a)),  L_ij = log sum_{k != j} e^{s_ik}   (leave-one-out, per row)
+    //   value = 1 + mean_{i != j}(s_jj - I_ij) - mean_{i != j} e^{s_ij - I_jj}
+    float* lse = rowstat; float* vj = rowstat + B; float* Rr = rowstat + 2 * B; float* Cj = rowstat + 3 * B;
+    const float la = -softplus_f(-0.01f), lb = -softplus_f(0.01f), lbm1 = __logf((float)B - 1.f);
+    const float M2 = (float)B * (B - 1.f);
+    auto interp = [&](float sv, float lsev, float& p, float& I, float& sig) {
+      p = __expf(sv - lsev);
+      const float d = lsev - sv;
+      const float L = d == 0.f ? sv + 1.f + __logf(1.f - __expf(-1.f)) : lsev + log1pf(-p);   // safe_d of compute_log_loomean
+      const float u = la + L - lbm1;
+      const float hi = fmaxf(u, lb);
+      I = hi + __logf(__expf(u - hi) + __expf(lb - hi));
+      sig = __expf(u - I);
+    };
+    float part_i = 0.f, part_d = 0.f;
+    for (int i = w; i < B; i += nw) {
+      float mx = -INFINITY;
+      for (int j = lane; j < B; j += 64) mx = fmaxf(mx, S[(long)i * B + j]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int j = lane; j < B; j += 64) se += __expf(S[(long)i * B + j] - mx);
+      se = wave_sum(se);
+      const float lsev = mx + __logf(se);
+      float r = 0.f, isum = 0.f;
+      for (int j = lane; j < B; j += 64) {
+        float p, I, sig;
+        interp(S[(long)i * B + j], lsev, p, I, sig);
+        if (j == i) { vj[i] = I; part_d += S[(long)i * B + j]; }
+        else { r += sig / (1.f - p); isum += I; }
+      }
+      r = wave_sum(r); isum = wave_sum(isum);
+      if (lane == 0) { lse[i] = lsev; Rr[i] = r; part_i += isum; }
+    }
+    const float sum_i = block_sum(part_i, red);
+    const float dsum = block_sum(part_d, red);
+    __syncthreads();
+    float mxc = -INFINITY;
+    for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+      const int i = idx / B, j = idx % B;
+      if (i != j) mxc = fmaxf(mxc, S[idx] - vj[j]);
+    }
+    mxc = block_max(mxc, red);
+    float csum = 0.f;
+    for (int j = tid; j < B; j += blockDim.x) {
+      float c = 0.f;
+      for (int i = 0; i < B; ++i)
+        if (i != j) c += __expf(S[(long)i * B + j] - vj[j] - mxc);
+      csum += c;
+      float p, I, sig;
+      interp(S[(long)j * B + j], lse[j], p, I, sig);
+      Cj[j] = c * __expf(mxc) * sig / (1.f - p);        // Q_j = C_j sigma_jj / (1 - p_jj)
+    }
+    csum = block_sum(csum, red);
+    const float emx = __expf(mxc);
+    const float marg = emx * csum / M2;
+    const float val = 1.f + ((B - 1.f) * dsum - sum_i) / M2 - marg;
+    if (tid == 0) { mi[e] = val; if (mil) mil[e] = -val; }
+    if (!dS) return;
+    __syncthreads();
+    for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
+      const int a = idx / B, b = idx % B;
+      float p, I, sig;
+      interp(S[idx], lse[a], p, I, sig);
+      float g;
+      if (a == b) g = invB - p * Rr[a] / M2;
+      else g = -p * (Rr[a] - sig / (1.f - p)) / M2 - (emx * __expf(S[idx] - vj[b] - mxc) - Cj[a] * p) / M2;
+      dS[idx] = gs * g;
+    }
+    return;
+  }
+
   // ---- bounds built from diag mean / off-diagonal log-mean-exp / softplus sums      (VMI.py:121-198)
   const float shift = (bound == BOUND_NWJ || bound == BOUND_JS) ? 1.f : 0.f;
   const bool clipped = bound == BOUND_SMILE;
@@ -123,7 +196,7 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict_
                                                         float* __restrict__ mi, float* __restrict__ mil,
                                                         const float* __restrict__ gscale, int B, int bound, unsigned lossform) {
   __shared__ float red[16];
-  __shared__ float rowstat[1024];   // per-row lse (InfoNCE); B <= 1024
+  __shared__ float rowstat[4 * 1024];   // per-row / per-column statistics (InfoNCE: lse; interpolate: 4 vectors); B <= 1024
   const int e = blockIdx.x;
   mi_bound_body(scores + (long)e * B * B, dscores ? dscores + (long)e * B * B : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B,
                 bound, lossform, red, rowstat);
@@ -138,7 +211,7 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
                                                             unsigned lossform, int do_bwd) {
   extern __shared__ float S[];      // [B][B]
   __shared__ float red[16];
-  __shared__ float rowstat[1024];
+  __shared__ float rowstat[4 * 128];
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int nt = B / 32;
   const float* __restrict__ X = tout + (long)(2 * e) * B * 128;       // g(x)

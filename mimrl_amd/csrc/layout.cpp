@@ -19,7 +19,7 @@ int validate_cfg(const mimrl_cfg& c) {
   if (c.n_blocks < 1 || c.n_blocks > MIMRL_MAX_BLOCKS) return set_error(MIMRL_ERR_ARG, "1..%d CubeMLP blocks", MIMRL_MAX_BLOCKS);
   if (c.critic_type != MIMRL_CRITIC_SEPARATE && c.critic_type != MIMRL_CRITIC_CONCAT)
     return set_error(MIMRL_ERR_ARG, "critic_type must be separate|concat (VMI.py:44-45)");
-  if (c.bound_type < MIMRL_BOUND_INFONCE || c.bound_type > MIMRL_BOUND_MINE) return set_error(MIMRL_ERR_ARG, "bound_type unsupported");
+  if (c.bound_type < MIMRL_BOUND_INFONCE || c.bound_type > MIMRL_BOUND_INTERPOLATE) return set_error(MIMRL_ERR_ARG, "bound_type unsupported");
   if (c.k_neighbor < 1 || c.k_neighbor > 8) return set_error(MIMRL_ERR_ARG, "k_neighbor must be in [1,8]");
   if (c.batch / c.k_neighbor < 1) return set_error(MIMRL_ERR_ARG, "batch smaller than k_neighbor");
   if (c.d_t < 1 || c.d_a < 1 || c.d_v < 1) return set_error(MIMRL_ERR_ARG, "feature dims must be positive");

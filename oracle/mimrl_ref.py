@@ -258,9 +258,27 @@ def smile_lower_bound(scores: Tensor, clip: float = 1.0) -> Tensor:
     return js + (dv - js).detach()
 
 
+def interp_lower_bound(scores: Tensor, alpha_logit: float = 0.01) -> Tensor:
+    """VMI.py:201-250 with the constant baseline (log a(y) = 0) and the alpha_logit VMIEstimator hard-codes (Model.py:118).
+    nce baseline = leave-one-out log-mean-exp of each row; interpolated with the constant baseline in log space."""
+    B = scores.shape[0]
+    lse = torch.logsumexp(scores, dim=1, keepdim=True)
+    d = lse - scores                                                   # >= 0; log(sum_k e^s_ik) - s_ij
+    safe_d = torch.where(d == 0, torch.ones_like(d), d)
+    loo_lme = scores + (safe_d + torch.log(-torch.expm1(-safe_d))) - math.log(B - 1.0)    # compute_log_loomean
+    log_alpha = -F.softplus(torch.tensor(-float(alpha_logit), dtype=scores.dtype))
+    log_1m = -F.softplus(torch.tensor(float(alpha_logit), dtype=scores.dtype))
+    interp = torch.logsumexp(torch.stack((log_alpha + loo_lme, log_1m + torch.zeros_like(loo_lme))), dim=0)
+    critic_marg = scores - torch.diag(interp)                          # broadcasts over rows: s_ij - interp_jj
+    marg = torch.exp(_logmeanexp_nodiag(critic_marg))
+    critic_joint = torch.diag(scores) - interp                         # s_jj - interp_ij
+    joint = (critic_joint.sum() - torch.diag(critic_joint).sum()) / (B * (B - 1.0))
+    return 1 + joint - marg
+
+
 BOUNDS = {"infonce": infonce_lower_bound, "nwj": nwj_lower_bound, "tuba": tuba_lower_bound,
           "dv": dv_lower_bound, "js_fgan": js_fgan_lower_bound, "js": js_lower_bound,
-          "smile": smile_lower_bound}
+          "smile": smile_lower_bound, "interpolate": interp_lower_bound}
 
 
 def vmi_estimate(p: Params, name: str, opt, x: Tensor, y: Tensor) -> Tuple[Tensor, Tensor]:

@@ -193,7 +193,7 @@ def gen_units():
     y = (0.5 * x + g.standard_normal((B, 128))).astype(np.float32)
     out["x"], out["y"] = x, y
     for critic in ("separate", "concat"):
-        for bound in ("infonce", "nwj", "tuba", "dv", "js", "js_fgan", "smile"):
+        for bound in ("infonce", "nwj", "tuba", "dv", "js", "js_fgan", "smile", "interpolate"):
             est = RM.VMIEstimator(critic, "constant", bound, 128, 256, 128, 2, "relu", 0, 1)
             sd = est.state_dict()
             pre = "vmi_estimator_f_t."

@@ -11,7 +11,7 @@ from tests.helpers import case, load_golden, oracle_params
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd"]
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp"]
 ALL = TINY + ["cfg1_sep", "cfg1_cat"]
 
 

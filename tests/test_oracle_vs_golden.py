@@ -7,7 +7,7 @@ import torch
 from oracle import mimrl_ref as R
 from tests.helpers import case, load_golden, oracle_params, rel_close
 
-TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd"]
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp"]
 ALL = TINY + ["cfg1_sep", "cfg1_cat"]
 
 
@@ -98,7 +98,7 @@ def test_unit_estimators_match_reference():
         p = {n: torch.from_numpy(synth.portable_tensor(n, s, 3)) for n, s in shapes}
         s = R.critic_scores(p, "f_t", critic, x, y)
         np.testing.assert_allclose(s.numpy(), g[f"{critic}_scores"], rtol=1e-4, atol=1e-5)
-        for bound in ("infonce", "nwj", "tuba", "dv", "js", "js_fgan", "smile"):
+        for bound in ("infonce", "nwj", "tuba", "dv", "js", "js_fgan", "smile", "interpolate"):
             xt, yt = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
             mi = R.BOUNDS[bound](R.critic_scores(p, "f_t", critic, xt, yt))
             (-mi).backward()
