@@ -313,7 +313,7 @@ struct mimrl_handle {
   // weight-gradient work parked by cube_backward and issued on the side streams once the data-gradient chain is through
   // (it then overlaps the latency-bound GRU BPTT instead of competing with the chain for CUs and L2)
   struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst;
-                    const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; };
+                    const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW(); };
   std::vector<Deferred> deferred;
   int flush_deferred();
   int model_forward(bool train, bool save, int knn_stage = 0);
@@ -996,7 +996,14 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       kw.ik = ik; kw.hk = hk; kw.ok = ok; kw.act = cfg.activation; kw.ln_first = cfg.ln_first;
       kw.drop_p = pk; kw.key = key(); kw.stream_id = 11 + 3 * i;
       GRAB(q);
-      MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
+      if (defer) {   // data gradient now, parameter gradients later (beside the BPTT); gbuf[cur] stays alive in deferred mode
+        MX(kmix_bwd_part(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id, 1));
+        Deferred d{5, 2, GemmDesc(), b.l.z, (long)B * ol, id, 0, 0, nullptr};
+        d.p3 = gbuf[cur]; d.kw = kw;
+        deferred.push_back(d);
+      } else {
+        MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
+      }
       release(cur);
       cur = q;
     }
@@ -1125,7 +1132,8 @@ int mimrl_handle::flush_deferred() {
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 3) MX(colln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, (int)d.n0, (int)d.n1, (int)d.n2));
-    else MX(rowln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, d.n0, (int)d.n1));
+    else if (d.kind == 4) MX(rowln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, d.n0, (int)d.n1));
+    else MX(kmix_bwd_part(st, d.src, d.p3, nullptr, d.kw, d.n0, (int)d.n1, 2));
   }
   deferred.clear();
   return MIMRL_OK;

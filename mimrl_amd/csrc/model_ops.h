@@ -63,6 +63,7 @@ struct KMixW {
 };
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D);
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D);
+int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D, int part);   // 1: dx only, 2: parameter gradients only
 
 // ---- reductions / misc
 // out[z*os + n] += sum_m X[z*xs + m*ld + n]   for z < batch

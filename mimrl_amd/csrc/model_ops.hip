@@ -327,9 +327,13 @@ __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__
 // backward: per-thread gradients are reduced over the wave with DPP-free shuffles only ONCE per workgroup iteration:
 // each thread accumulates its weight-gradient contributions in registers across its grid-stride iterations, and the
 // wave/LDS/global reduction runs once at the end of the kernel.
-template <int NK>
+// MODE 0: data gradient and parameter gradients together; MODE 1: data gradient only (the critical path of the CubeMLP
+// backward: no accumulators, no reductions, no atomics); MODE 2: parameter gradients only (same arithmetic recomputed on
+// a side stream)
+template <int NK, int MODE>
 __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                        float* __restrict__ dx, KMixW w, long R, int D) {
+  constexpr bool GRADS = MODE != 1, DX = MODE != 2;
   __shared__ float sw[3 * KM * KM + 4 * KM];
   __shared__ float sg[3 * KM * KM + 4 * KM];   // gradient accumulators, same packing
   kmix_stage_weights(w, sw);
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int o = 0; o < NK; ++o) {
         dyv[o] = o < w.ok ? v.rs * (dzv[o] * g[o] - s1 - v.xh[o] * s2) : 0.f;
-        ag[o] += dzv[o] * v.xh[o]; abe[o] += dzv[o];
+        if (GRADS) { ag[o] += dzv[o] * v.xh[o]; abe[o] += dzv[o]; }
       }
     }
 #pragma unroll
@@ -399,14 +403,15 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         dxv[k] += k < w.ik ? v.rs * (dxn[k] * g[k] - s1 - v.xh[k] * s2) : 0.f;
-        ag[k] += dxn[k] * v.xh[k]; abe[k] += dxn[k];
+        if (GRADS) { ag[k] += dxn[k] * v.xh[k]; abe[k] += dxn[k]; }
       }
     } else {
 #pragma unroll
       for (int k = 0; k < NK; ++k) dxv[k] += dxn[k];
     }
 #pragma unroll
-    for (int k = 0; k < NK; ++k) if (k < w.ik) dx[(r * w.ik + k) * D + d] = dxv[k];
+    for (int k = 0; k < NK; ++k) if (DX && k < w.ik) dx[(r * w.ik + k) * D + d] = dxv[k];
+    if (!GRADS) continue;
 #pragma unroll
     for (int o = 0; o < NK; ++o) {
       ab2[o] += dym[o];
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
       for (int k = 0; k < NK; ++k) aw1[j][k] += du[j] * (w.ln_first ? v.xn[k] : v.x[k]);
     }
   }
+  if (!GRADS) return;
   // one wave reduction + LDS + global atomic per scalar, once per kernel
   float* gw1 = sg; float* gb1 = gw1 + KM * KM; float* gw2 = gb1 + KM; float* gb2 = gw2 + KM * KM;
   float* gwr = gb2 + KM; float* gg = gwr + KM * KM; float* gbe = gg + KM;
@@ -638,8 +644,25 @@ int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
-  if (mx <= 4) hipLaunchKernelGGL(kmix_bwd_kernel<4>, dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
-  else hipLaunchKernelGGL(kmix_bwd_kernel<8>, dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 0>), dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  else hipLaunchKernelGGL((kmix_bwd_kernel<8, 0>), dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+// the two halves of kmix_bwd as separate launches: `part` 1 = dx only (many workgroups, nothing shared), 2 = parameter
+// gradients only (few workgroups: its cost is the 64 reductions + atomics per workgroup)
+int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D, int part) {
+  if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
+  const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
+  if (part == 1) {
+    const dim3 grid(grid_for(R * D, 256, 4096));
+    if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+    else hipLaunchKernelGGL((kmix_bwd_kernel<8, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+  } else {
+    const dim3 grid(grid_for(R * D, 256, 128));
+    if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+    else hipLaunchKernelGGL((kmix_bwd_kernel<8, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+  }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
