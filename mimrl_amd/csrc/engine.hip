@@ -622,13 +622,11 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       gd.batch = 2; gd.sa_b = 0; gd.sb_b = gr.w_ih - gf.w_ih; gd.sc_b = gx[m][1] - gx[m][0];
       gd.bias_n = P(gf.b_ih); gd.bias_n_b = gr.b_ih - gf.b_ih;
       if (l == 1) {
-        if (m == 1) goto seqs;
         gd.batch = 4; gd.batch_in = 2;
         gd.sa_bo = h0[1] - h0[0]; gd.sb_bo = gru[1][l][0].w_ih - gf.w_ih; gd.sc_bo = gx[1][0] - gx[0][0];
         gd.bias_n_bo = gru[1][l][0].b_ih - gf.b_ih;
       }
-      MX(G_on(m == 0 ? stream : S(2), gd));
-    seqs:
+      if (l == 0 || m == 0) MX(G_on(m == 0 ? stream : S(2), gd));   // layer 1: the m == 0 launch covers both modalities
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
