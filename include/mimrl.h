@@ -35,7 +35,7 @@ enum { MIMRL_ACT_NONE = 0, MIMRL_ACT_RELU = 1, MIMRL_ACT_GELU = 2, MIMRL_ACT_TAN
 enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16_GEMM_FWD = 1, MIMRL_PREC_BF16_GEMM_BWD = 2, MIMRL_PREC_BF16_GRU_FWD = 4,
        MIMRL_PREC_BF16_GRU_BWD = 8, MIMRL_PREC_BF16 = 15 };
 
-enum { MIMRL_ENCODER_GRU = 0, MIMRL_ENCODER_CONV = 1 };                            /* Model.py:247-257 (lstm: not built) */
+enum { MIMRL_ENCODER_GRU = 0, MIMRL_ENCODER_CONV = 1, MIMRL_ENCODER_LSTM = 2 };    /* Model.py:247-257 */
 
 /* Hot-path subset of Parameters.py:8-70 (same meaning as the flags of the same name). */
 typedef struct mimrl_cfg {
@@ -64,7 +64,7 @@ typedef struct mimrl_cfg {
   int32_t precision;             /* MIMRL_PREC_* */
   int32_t use_graph;             /* capture each stage into a hipGraph on first use */
   int32_t device_anchors;        /* 1: draw the kNN anchors on the device each step (overwrites buffers.anchors); 0: host-provided */
-  int32_t encoder;               /* --encoders: MIMRL_ENCODER_GRU (Model.py:253-255) or MIMRL_ENCODER_CONV (Model.py:247-249,437-439) */
+  int32_t encoder;               /* --encoders: MIMRL_ENCODER_GRU (Model.py:253-255), _CONV (:247-249,437-439) or _LSTM (:250-252) */
   uint64_t seed;                 /* dropout stream seed */
 } mimrl_cfg;
 

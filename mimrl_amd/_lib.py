@@ -97,7 +97,7 @@ def load() -> C.CDLL:
     return lib
 
 
-ENCODERS = {"gru": 0, "conv": 1}                                             # MIMRL_ENCODER_*
+ENCODERS = {"gru": 0, "conv": 1, "lstm": 2}                                             # MIMRL_ENCODER_*
 
 EXPORTS = [
     "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry", "mimrl_layout_entry_dim2",
@@ -125,7 +125,7 @@ def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capaci
     c.d_t, c.d_a, c.d_v, c.d_common = int(d_t), int(d_a), int(d_v), int(opt.d_common)
     enc = getattr(opt, "encoders", "gru")
     if enc not in ENCODERS:
-        raise MimrlError(f"--encoders {enc}: gru and conv are built for the MI355X hot path (lstm: SURVEY.md 8f N3)")
+        raise MimrlError(f"--encoders {enc}: choose gru, conv or lstm (Model.py:237)")
     c.encoder = ENCODERS[enc]
     nb = len(opt.d_hiddens)
     if nb > MAX_BLOCKS or len(opt.d_outs) != nb or len(opt.res_project) != nb:

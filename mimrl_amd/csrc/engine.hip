@@ -17,6 +17,7 @@
 #include "estimator_ops.h"
 #include "gemm.h"
 #include "gru.h"
+#include "lstm.h"
 #include "layout.h"
 #include "model_ops.h"
 
@@ -285,6 +286,8 @@ struct mimrl_handle {
   int encoders_forward(bool save, int knn_stage);
   int conv_forward(int knn_stage);
   int conv_backward();
+  int lstm_encoders_forward(bool save, int knn_stage);
+  int lstm_encoders_backward();
   int rng_add = 0;
   RngKey key() const { return RngKey{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, rng_add}; }
   const float* coef1() const { return d_consts; }
@@ -361,8 +364,9 @@ int mimrl_handle::resolve() {
     MX(off("conv_a.weight", &conv_w[0])); MX(off("conv_a.bias", &conv_b[0]));
     MX(off("conv_v.weight", &conv_w[1])); MX(off("conv_v.bias", &conv_b[1]));
   }
-  for (int m = 0; m < 2 && cfg.encoder == MIMRL_ENCODER_GRU; ++m)
-    for (int l = 0; l < 2; ++l)
+  const int rnn_layers = cfg.encoder == MIMRL_ENCODER_GRU ? 2 : cfg.encoder == MIMRL_ENCODER_LSTM ? 1 : 0;
+  for (int m = 0; m < 2; ++m)
+    for (int l = 0; l < rnn_layers; ++l)
       for (int d = 0; d < 2; ++d) {
         const std::string sfx = "_l" + std::to_string(l) + (d ? "_reverse" : "");
         GruDirW& g = gru[m][l][d];
@@ -459,7 +463,7 @@ int mimrl_handle::carve_fwd(size_t* gmax_out) {
   for (int m = 0; m < 2; ++m) MX(take(&lens[m], B));
   MX(take(&tx_raw, BT_ * D));
   for (int m = 0; m < 2; ++m) {
-    for (int d = 0; d < 2; ++d) MX(take(&gx[m][d], BT_ * G));
+    for (int d = 0; d < 2; ++d) MX(take(&gx[m][d], BT_ * (cfg.encoder == MIMRL_ENCODER_LSTM ? 4 * H : G)));
     MX(take(&h0[m], BT_ * 2 * H));
     MX(take(&h1[m], BT_ * 2 * H));
     MX(take(&ln_mean[m], BT_));
@@ -599,6 +603,7 @@ int mimrl_handle::alloc_workspace() {
 // of the bi-GRU; the conv encoder writes the first half only, the second stays zero)
 int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   if (cfg.encoder == MIMRL_ENCODER_CONV) return conv_forward(knn_stage);
+  if (cfg.encoder == MIMRL_ENCODER_LSTM) return lstm_encoders_forward(save, knn_stage);
   const int B = cfg.batch, T = cfg.seq_len;
   const long BT_ = (long)B * T;
   const float* xin[2] = {bufs.audio, bufs.video};
@@ -639,6 +644,63 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
     }
     { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
   }
+  return MIMRL_OK;
+}
+
+// 1-layer bi-LSTM encoders (Model.py:250-252): hoisted input projection (one GEMM per modality, batch = direction), then
+// the recurrence (lstm.hip).  Outputs land in h1[m][B,T,2H] like the GRU's, so everything downstream is shared.
+int mimrl_handle::lstm_encoders_forward(bool save, int knn_stage) {
+  const int B = cfg.batch, T = cfg.seq_len;
+  const long BT_ = (long)B * T;
+  const float* xin[2] = {bufs.audio, bufs.video};
+  const int dmod[2] = {cfg.d_a, cfg.d_v};
+  MX(seq_lengths2(S(4), xin[0], dmod[0], lens[0], xin[1], dmod[1], lens[1], B, T));
+  MX(fork(2, 2));
+  LstmFwdArgs a;
+  a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
+  for (int m = 0; m < 2; ++m) {
+    a.lens[m] = lens[m];
+    const GruDirW &gf = gru[m][0][0], &gr = gru[m][0][1];
+    GemmDesc gd = gemm_nt(xin[m], gf.din, P(gf.w_ih), gf.din, gx[m][0], 4 * H, (int)BT_, 4 * H, gf.din);
+    gd.batch = 2; gd.sa_b = 0; gd.sb_b = gr.w_ih - gf.w_ih; gd.sc_b = gx[m][1] - gx[m][0];
+    gd.bias_n = P(gf.b_ih); gd.bias_n_b = gr.b_ih - gf.b_ih;
+    MX(G_on(m == 0 ? stream : S(2), gd));
+    for (int d = 0; d < 2; ++d) {
+      const GruDirW& g = gru[m][0][d];
+      a.seq[m][d] = LstmSeq{gx[m][d], P(g.w_hh), P(g.b_hh), h1[m], save ? sv[0][m][d] : nullptr};
+    }
+  }
+  MX(join(2, 2));
+  MX(join(4, 4));
+  if (knn_stage) { MX(fork(4, 4)); MX(knn_launch(knn_stage, S(4))); }
+  { Scope sc(this, MIMRL_PH_GRU_FWD); MX(lstm_forward(stream, a)); }
+  return MIMRL_OK;
+}
+
+int mimrl_handle::lstm_encoders_backward() {
+  const int B = cfg.batch, T = cfg.seq_len;
+  const long BT_ = (long)B * T;
+  const float* xin[2] = {bufs.audio, bufs.video};
+  LstmBwdArgs a;
+  a.B = B; a.T = T; a.out_ld = 2 * H; a.dout_ld = H; a.nmod = 2;
+  for (int m = 0; m < 2; ++m) {
+    a.lens[m] = lens[m];
+    for (int d = 0; d < 2; ++d)
+      a.seq[m][d] = LstmSeqBwd{P(gru[m][0][d].w_hh), sv[0][m][d], h1[m], ds[m], dg[0][m][d], hprev[0][m][d]};
+  }
+  { Scope sc(this, MIMRL_PH_GRU_BWD); MX(lstm_backward(stream, a)); }
+  MX(fork(1, 3));
+  int rr = 0;
+  for (int m = 0; m < 2; ++m)
+    for (int d = 0; d < 2; ++d) {
+      const GruDirW& g = gru[m][0][d];
+      const int sq = rr++ % 4;
+      hipStream_t st = sq == 0 ? stream : S(sq);
+      { GemmDesc q = gemm_tn(dg[0][m][d], 4 * H, xin[m], g.din, Gm(g.w_ih), g.din, 4 * H, g.din, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+      { GemmDesc q = gemm_tn(dg[0][m][d], 4 * H, hprev[0][m][d], H, Gm(g.w_hh), H, 4 * H, H, (int)BT_); q.atomic = 1; MX(G_on(st, q)); }
+      MX(colsum(st, dg[0][m][d], BT_, 4 * H, 4 * H, Gm(g.b_ih)));
+      MX(colsum(st, dg[0][m][d], BT_, 4 * H, 4 * H, Gm(g.b_hh)));
+    }
   return MIMRL_OK;
 }
 
@@ -1173,6 +1235,11 @@ int mimrl_handle::model_backward() {
   MX(flush_deferred());   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT
   if (cfg.encoder == MIMRL_ENCODER_CONV) {
     MX(conv_backward());
+    MX(join(0, 5));
+    return MIMRL_OK;
+  }
+  if (cfg.encoder == MIMRL_ENCODER_LSTM) {
+    MX(lstm_encoders_backward());
     MX(join(0, 5));
     return MIMRL_OK;
   }

@@ -23,8 +23,8 @@ int validate_cfg(const mimrl_cfg& c) {
   if (c.k_neighbor < 1 || c.k_neighbor > 8) return set_error(MIMRL_ERR_ARG, "k_neighbor must be in [1,8]");
   if (c.batch / c.k_neighbor < 1) return set_error(MIMRL_ERR_ARG, "batch smaller than k_neighbor");
   if (c.d_t < 1 || c.d_a < 1 || c.d_v < 1) return set_error(MIMRL_ERR_ARG, "feature dims must be positive");
-  if (c.encoder != MIMRL_ENCODER_GRU && c.encoder != MIMRL_ENCODER_CONV)
-    return set_error(MIMRL_ERR_ARG, "encoder must be gru|conv (lstm is not built, SURVEY.md 8f N3)");
+  if (c.encoder != MIMRL_ENCODER_GRU && c.encoder != MIMRL_ENCODER_CONV && c.encoder != MIMRL_ENCODER_LSTM)
+    return set_error(MIMRL_ERR_ARG, "encoder must be gru|conv|lstm");
   int din[3] = {c.time_len, 3, c.d_common};
   for (int i = 0; i < c.n_blocks; ++i) {
     for (int ax = 0; ax < 3; ++ax) {
@@ -68,14 +68,15 @@ int build_layout(const mimrl_cfg& c, Layout* out) {
   }
   const struct { const char* nm; int d; } mods[2] = {{"rnn_v", c.d_v}, {"rnn_a", c.d_a}};
   for (auto& m : mods)
-    for (int layer = 0; layer < (c.encoder == MIMRL_ENCODER_GRU ? 2 : 0); ++layer) {
+    for (int layer = 0; layer < (c.encoder == MIMRL_ENCODER_GRU ? 2 : c.encoder == MIMRL_ENCODER_LSTM ? 1 : 0); ++layer) {
       const int din = layer == 0 ? m.d : 2 * H;
+      const int ng = c.encoder == MIMRL_ENCODER_LSTM ? 4 : 3;      // gates: LSTM i,f,g,o / GRU r,z,n
       for (const char* sfx : {"", "_reverse"}) {
         const std::string l = "_l" + std::to_string(layer) + sfx;
-        add(std::string(m.nm) + ".weight_ih" + l, 3 * H, din);
-        add(std::string(m.nm) + ".weight_hh" + l, 3 * H, H);
-        add(std::string(m.nm) + ".bias_ih" + l, 3 * H, 0);
-        add(std::string(m.nm) + ".bias_hh" + l, 3 * H, 0);
+        add(std::string(m.nm) + ".weight_ih" + l, ng * H, din);
+        add(std::string(m.nm) + ".weight_hh" + l, ng * H, H);
+        add(std::string(m.nm) + ".bias_ih" + l, ng * H, 0);
+        add(std::string(m.nm) + ".bias_hh" + l, ng * H, 0);
       }
     }
   add("ln_a.weight", D, 0); add("ln_a.bias", D, 0); add("ln_v.weight", D, 0); add("ln_v.bias", D, 0);

@@ -43,15 +43,16 @@ def named_shapes(opt, d_t: int, d_a: int, d_v: int) -> List[Tuple[str, Tuple[int
     enc = getattr(opt, "encoders", "gru")
     if enc == "conv":                                                     # Model.py:247-249 (conv_a before conv_v)
         out += [("conv_a.weight", (D, d_a, 3)), ("conv_a.bias", (D,)), ("conv_v.weight", (D, d_v, 3)), ("conv_v.bias", (D,))]
-    elif enc != "gru":
-        raise NotImplementedError(f"--encoders {enc} (lstm is not built: SURVEY.md 8f N3)")
-    # rnn_v is registered before rnn_a in the reference (Model.py:254-255)
+    elif enc not in ("gru", "lstm"):
+        raise NotImplementedError(f"--encoders {enc}")
+    # rnn_v is registered before rnn_a in the reference (Model.py:251-252 lstm: 1 layer, 4 gates; :254-255 gru: 2 layers, 3 gates)
+    ng, nlayers = (3, 2) if enc == "gru" else (4, 1) if enc == "lstm" else (0, 0)
     for mod, d in (("rnn_v", d_v), ("rnn_a", d_a)):
-        for layer in range(2 if enc == "gru" else 0):
+        for layer in range(nlayers):
             din = d if layer == 0 else 2 * H
             for sfx in ("", "_reverse"):
-                out += [(f"{mod}.weight_ih_l{layer}{sfx}", (3 * H, din)), (f"{mod}.weight_hh_l{layer}{sfx}", (3 * H, H)),
-                        (f"{mod}.bias_ih_l{layer}{sfx}", (3 * H,)), (f"{mod}.bias_hh_l{layer}{sfx}", (3 * H,))]
+                out += [(f"{mod}.weight_ih_l{layer}{sfx}", (ng * H, din)), (f"{mod}.weight_hh_l{layer}{sfx}", (ng * H, H)),
+                        (f"{mod}.bias_ih_l{layer}{sfx}", (ng * H,)), (f"{mod}.bias_hh_l{layer}{sfx}", (ng * H,))]
     out += [("ln_a.weight", (D,)), ("ln_a.bias", (D,)), ("ln_v.weight", (D,)), ("ln_v.bias", (D,))]
     out += [("W_t.weight", (D, d_t))]
     d_in = [int(opt.time_len), 3, D]

@@ -83,6 +83,37 @@ def bigru2(p: Params, prefix: str, x: Tensor, lengths: Tensor) -> Tensor:
     return inp[..., :H] + inp[..., H:]
 
 
+def lstm_direction(x: Tensor, lengths: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor,
+                   reverse: bool) -> Tensor:
+    """One direction of nn.LSTM(d, H, 1, bidirectional=True) with packed-sequence semantics (Model.py:250-252,441-447).
+    Gate order i,f,g,o;  c = f*c + i*g;  h = o*tanh(c).  x: [B,T,D] -> [B,T,H]"""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    gx = x @ w_ih.t() + b_ih                                   # [B,T,4H]
+    h = x.new_zeros(B, H)
+    c = x.new_zeros(B, H)
+    outs: List[Optional[Tensor]] = [None] * T
+    steps = range(T - 1, -1, -1) if reverse else range(T)
+    for t in steps:
+        g = gx[:, t] + h @ w_hh.t() + b_hh
+        i, f, gg, o = torch.sigmoid(g[:, :H]), torch.sigmoid(g[:, H:2 * H]), torch.tanh(g[:, 2 * H:3 * H]), torch.sigmoid(g[:, 3 * H:])
+        c_new = f * c + i * gg
+        h_new = o * torch.tanh(c_new)
+        valid = (lengths > t).to(x.dtype).unsqueeze(1)
+        h = valid * h_new + (1.0 - valid) * h
+        c = valid * c_new + (1.0 - valid) * c
+        outs[t] = valid * h_new
+    return torch.stack(outs, dim=1)
+
+
+def bilstm1(p: Params, prefix: str, x: Tensor, lengths: Tensor) -> Tensor:
+    """nn.LSTM(d, H, 1, bidirectional=True, batch_first=True) (Model.py:250-252) + the half sum of Model.py:452-453."""
+    outs = [lstm_direction(x, lengths, p[f"{prefix}.weight_ih_l0{sfx}"], p[f"{prefix}.weight_hh_l0{sfx}"],
+                           p[f"{prefix}.bias_ih_l0{sfx}"], p[f"{prefix}.bias_hh_l0{sfx}"], rev)
+            for rev, sfx in ((False, ""), (True, "_reverse"))]
+    return outs[0] + outs[1]
+
+
 def _dropout(x: Tensor, p_drop: float, mask: Optional[Tensor]) -> Tensor:
     """Inverted dropout with an *explicit* keep mask (0/1) so both sides can share it."""
     if mask is None or p_drop <= 0.0:
@@ -161,8 +192,9 @@ def model_forward(p: Params, opt, t_feat: Tensor, a: Tensor, v: Tensor,
         ah, vh = conv(a, "a"), conv(v, "v")
     else:
         la, lv = infer_lengths(a), infer_lengths(v)             # Model.py:425-432
-        ah = bigru2(p, "rnn_a", a, la)                          # Model.py:441-453
-        vh = bigru2(p, "rnn_v", v, lv)
+        rnn = bilstm1 if getattr(opt, "encoders", "gru") == "lstm" else bigru2
+        ah = rnn(p, "rnn_a", a, la)                             # Model.py:441-453
+        vh = rnn(p, "rnn_v", v, lv)
     ah = F.relu(F.layer_norm(ah, (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))   # Model.py:457
     vh = F.relu(F.layer_norm(vh, (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
     t = _dropout(t, opt.dropout[0], masks.get("t"))             # Model.py:461

@@ -14,6 +14,8 @@ CONFIGS = {
     "tiny_conv": dict(B=8, T=6, N=40, seed=5, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="conv"),
     # mine bound: its loss term is not -mi (Model.py:121-125), and stage 2 mixes both forms (Model.py:386)
     "tiny_mine": dict(B=8, T=6, N=40, seed=6, critic="separate", cube="6-3-128=4-3-128", traj=2, bound="mine"),
+    # --encoders lstm (1-layer bi-LSTM, Model.py:250-252), ragged inputs
+    "tiny_lstm": dict(B=8, T=6, N=40, seed=9, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="lstm"),
     # interpolated bound (VMI.py:201-250) with the constant baseline, concat critic
     "tiny_interp": dict(B=8, T=6, N=40, seed=8, critic="concat", cube="6-3-128=4-3-128", traj=2, bound="interpolate"),
     # awkward sizes: batch not a multiple of the tile sizes, inputs shorter than --time_len (zero padding of the cube,

@@ -11,7 +11,7 @@ from tests.helpers import case, load_golden, oracle_params
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp"]
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp", "tiny_lstm"]
 ALL = TINY + ["cfg1_sep", "cfg1_cat"]
 
 
@@ -105,7 +105,7 @@ def test_stage_losses_and_all_gradients_vs_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "cfg1_sep"])
+@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_lstm", "cfg1_sep"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_two_stage_trajectory(name, use_graph):
     """Alternating stage-1/stage-2 updates (Solver.step) vs the reference trajectory and the oracle."""

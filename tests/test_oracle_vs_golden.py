@@ -7,7 +7,7 @@ import torch
 from oracle import mimrl_ref as R
 from tests.helpers import case, load_golden, oracle_params, rel_close
 
-TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp"]
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp", "tiny_lstm"]
 ALL = TINY + ["cfg1_sep", "cfg1_cat"]
 
 
