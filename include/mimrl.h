@@ -35,6 +35,7 @@ enum { MIMRL_ACT_NONE = 0, MIMRL_ACT_RELU = 1, MIMRL_ACT_GELU = 2, MIMRL_ACT_TAN
 enum { MIMRL_PREC_FP32 = 0, MIMRL_PREC_BF16_GEMM_FWD = 1, MIMRL_PREC_BF16_GEMM_BWD = 2, MIMRL_PREC_BF16_GRU_FWD = 4,
        MIMRL_PREC_BF16_GRU_BWD = 8, MIMRL_PREC_BF16 = 15 };
 
+enum { MIMRL_BASELINE_CONSTANT = 0, MIMRL_BASELINE_GAUSSAIN = 1, MIMRL_BASELINE_UNNORMALIZED = 2 };   /* VMI.py:72-110 */
 enum { MIMRL_ENCODER_GRU = 0, MIMRL_ENCODER_CONV = 1, MIMRL_ENCODER_LSTM = 2 };    /* Model.py:247-257 */
 
 /* Hot-path subset of Parameters.py:8-70 (same meaning as the flags of the same name). */
@@ -64,6 +65,7 @@ typedef struct mimrl_cfg {
   int32_t precision;             /* MIMRL_PREC_* */
   int32_t use_graph;             /* capture each stage into a hipGraph on first use */
   int32_t device_anchors;        /* 1: draw the kNN anchors on the device each step (overwrites buffers.anchors); 0: host-provided */
+  int32_t baseline_type;         /* --baseline_type: MIMRL_BASELINE_CONSTANT | _GAUSSAIN | _UNNORMALIZED (VMI.py:72-110; read by tuba / interpolate) */
   int32_t encoder;               /* --encoders: MIMRL_ENCODER_GRU (Model.py:253-255), _CONV (:247-249,437-439) or _LSTM (:250-252) */
   uint64_t seed;                 /* dropout stream seed */
 } mimrl_cfg;
@@ -153,6 +155,9 @@ int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* 
  * estimator e enters the objective through its loss term (all in stage 1; f_t,f_a,f_v in stage 2, Model.py:386) */
 int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, float* mi, float* mi_loss, const float* gscale,
                          int E, int B, int bound, uint32_t lossform);
+/* tuba / interpolate with a log-baseline log a(y_i) per row (VMI.py:72-110): lb, dlb are [E,B]; scores are modified in place */
+int mimrl_op_mi_bound_baseline(void* stream, float* scores, float* dscores, float* mi, const float* gscale, const float* lb,
+                               float* dlb, int E, int B, int bound);
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
                       const float* g_cmi, int E, int n, int hardtanh);

@@ -38,7 +38,8 @@ class Cfg(C.Structure):
         ("coef1", C.c_float * 11), ("coef2", C.c_float * 8),
         ("weight_decay", C.c_float), ("grad_clip", C.c_float),
         ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-        ("precision", C.c_int32), ("use_graph", C.c_int32), ("device_anchors", C.c_int32), ("encoder", C.c_int32),
+        ("precision", C.c_int32), ("use_graph", C.c_int32), ("device_anchors", C.c_int32), ("baseline_type", C.c_int32),
+        ("encoder", C.c_int32),
         ("seed", C.c_uint64),
     ]
 
@@ -78,6 +79,7 @@ def load() -> C.CDLL:
     lib.mimrl_op_gru_backward.argtypes = [_FP] * 12 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_mi_bound.argtypes = [_FP] * 5 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_mi_bound_ex.argtypes = [_FP] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint32]
+    lib.mimrl_op_mi_bound_baseline.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_knn.argtypes = [_FP, _FP, C.c_int, C.c_int, _FP, C.c_int, C.c_int, _FP]
     lib.mimrl_op_cmi_loss.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_create.argtypes = [C.POINTER(Cfg), _FP, C.POINTER(_FP)]
@@ -97,14 +99,15 @@ def load() -> C.CDLL:
     return lib
 
 
-ENCODERS = {"gru": 0, "conv": 1, "lstm": 2}                                             # MIMRL_ENCODER_*
+ENCODERS = {"gru": 0, "conv": 1, "lstm": 2}
+BASELINES = {"constant": 0, "gaussain": 1, "unnormalized": 2}                 # MIMRL_BASELINE_* (the reference spells it "gaussain")                                             # MIMRL_ENCODER_*
 
 EXPORTS = [
     "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry", "mimrl_layout_entry_dim2",
     "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_stage1_step", "mimrl_stage2_step",
     "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read",
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_destroy", "mimrl_op_gemm",
-    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_knn",
+    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
 ]
 
@@ -148,8 +151,10 @@ def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capaci
     if opt.critic_type not in ("separate", "concat"):
         raise NotImplementedError(opt.critic_type)             # VMI.py:44-45
     c.critic_type = 0 if opt.critic_type == "separate" else 1
-    if getattr(opt, "baseline_type", "constant") != "constant":
-        raise MimrlError("only --baseline_type constant is supported")
+    bl = getattr(opt, "baseline_type", "constant")
+    if bl not in BASELINES:
+        raise NotImplementedError(f"--baseline_type {bl}")                           # VMI.py:89-90
+    c.baseline_type = BASELINES[bl]
     if opt.bound_type not in BOUNDS:
         raise NotImplementedError(opt.bound_type)              # Model.py:144-145
     c.bound_type = BOUNDS[opt.bound_type]

@@ -147,6 +147,15 @@ struct mimrl_handle {
     img_valid = true;
     return MIMRL_OK;
   }
+  // log-baseline of tuba / interpolate (VMI.py:72-110): per-estimator vector over the y rows, pitch 2B (the y operand of
+  // estimator e is slot 2e+1 of the tower-input buffer), its gradient, and for the trainable baseline an MLP 128-256-256-256-1
+  long bl0 = 0, bl_stride = 0, bl_l[4][2];
+  float *lbv = nullptr, *dlbv = nullptr, *bact[3] = {nullptr, nullptr, nullptr}, *bdz[3] = {nullptr, nullptr, nullptr}, *bdin = nullptr;
+  bool has_baseline() const {
+    return cfg.baseline_type != MIMRL_BASELINE_CONSTANT && (cfg.bound_type == MIMRL_BOUND_TUBA || cfg.bound_type == MIMRL_BOUND_INTERPOLATE);
+  }
+  int baseline_forward();
+  int baseline_backward(int stage);
   long tower0 = 0, tower_stride = 0;   // critic bucket: first tower, distance between consecutive towers
   long tower_l[4][2];                  // per-layer (w,b) offsets relative to tower0
   long cmi0 = 0, cmi_stride = 0, cmi_l[4][2];
@@ -437,6 +446,18 @@ int mimrl_handle::resolve() {
       if (o != cmi0 + e * cmi_stride) return set_error(MIMRL_ERR_STATE, "CMI classifiers are not uniformly strided");
     }
   }
+  if (cfg.baseline_type == MIMRL_BASELINE_UNNORMALIZED) {
+    long a, b;
+    MX(off("vmi_estimator_f_t.baseline_model.MLP.0.weight", &a));
+    MX(off("vmi_estimator_f_a.baseline_model.MLP.0.weight", &b));
+    bl0 = a; bl_stride = b - a;
+    for (int l = 0; l < 4; ++l) {
+      long w, bb_;
+      MX(off("vmi_estimator_f_t.baseline_model.MLP." + std::to_string(idx4[l]) + ".weight", &w));
+      MX(off("vmi_estimator_f_t.baseline_model.MLP." + std::to_string(idx4[l]) + ".bias", &bb_));
+      bl_l[l][0] = w - bl0; bl_l[l][1] = bb_ - bl0;
+    }
+  }
   {   // matrices whose transposed bf16 images the fused data-gradient chains read
     ttab.n = 0;
     auto add = [&](long o, int N, int K, int nb, long gs) {
@@ -452,6 +473,10 @@ int mimrl_handle::resolve() {
     }
     const int c[5] = {3 * EMB, HID, HID, HID, 2};
     for (int l = 0; l < 4; ++l) add(cmi0 + cmi_l[l][0], c[l + 1], c[l], NE_CMI, cmi_stride);
+    if (cfg.baseline_type == MIMRL_BASELINE_UNNORMALIZED) {
+      const int d[5] = {EMB, HID, HID, HID, 1};
+      for (int l = 0; l < 4; ++l) add(bl0 + bl_l[l][0], d[l + 1], d[l], NE_MI, bl_stride);
+    }
   }
   return MIMRL_OK;
 }
@@ -545,6 +570,11 @@ int mimrl_handle::carve() {
     for (int l = 0; l < 3; ++l) MX(take(&dca[l], NE_MI * B * B * HID));
   }
   MX(take(&dtin, 10 * B * EMB));
+  if (cfg.baseline_type != MIMRL_BASELINE_CONSTANT) {
+    MX(take(&lbv, NE_MI * 2 * B)); MX(take(&dlbv, NE_MI * 2 * B)); MX(take(&bdin, NE_MI * 2 * B * EMB));
+    if (cfg.baseline_type == MIMRL_BASELINE_UNNORMALIZED)
+      for (int l = 0; l < 3; ++l) { MX(take(&bact[l], NE_MI * 2 * B * HID)); MX(take(&bdz[l], NE_MI * 2 * B * HID)); }
+  }
   const size_t n = nprod();
   MX(take(&knn_idx, NE_CMI * n)); MX(take(&knn_idx2, NE_CMI * n));
   MX(take(&cmi_in, NE_CMI * 2 * n * 384));
@@ -1464,8 +1494,10 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
     if (!no_fused_mi && (prec & MIMRL_PREC_BF16_GEMM_FWD) && (prec & MIMRL_PREC_BF16_GEMM_BWD) && mi_sep_fused_supported(B)) {
       // scores, bound, d/dscores and the gradients of both tower outputs in one launch per stage (estimator_ops.hip)
       mi_fused_bwd_done = want_grad;
+      if (has_baseline()) MX(baseline_forward());
       return mi_sep_fused(stream, tout, dtout, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B, cfg.bound_type,
-                          stage == 1 ? 0x1fu : 0x07u, want_grad ? 1 : 0);
+                          stage == 1 ? 0x1fu : 0x07u, want_grad ? 1 : 0, has_baseline() ? lbv : nullptr,
+                          has_baseline() ? dlbv : nullptr, 2L * B);
     }
     GemmDesc g;   // scores_e = h(y) g(x)^T   (VMI.py:55-57)
     g.A = tout + BD; g.sa_m = EMB; g.sa_k = 1; g.sa_b = 2 * (long)BD;
@@ -1489,8 +1521,10 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
     const int dims[4] = {HID, HID, HID, 1};
     MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
   }
+  if (has_baseline()) MX(baseline_forward());
   return mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B,
-                          cfg.bound_type, stage == 1 ? 0x1fu : 0x07u);
+                          cfg.bound_type, stage == 1 ? 0x1fu : 0x07u, has_baseline() ? lbv : nullptr,
+                          has_baseline() && want_grad ? dlbv : nullptr, 2L * B);
 }
 
 int mimrl_handle::cmi_forward(int stage, bool want_grad) {
@@ -1513,7 +1547,51 @@ int mimrl_handle::cmi_forward(int stage, bool want_grad) {
                           NE_CMI, n, cfg.cmi_hardtanh);
 }
 
+// log a(y) for every estimator's y operand (VMI.py:101-108)
+__global__ void gauss_baseline_kernel(const float* __restrict__ y, float* __restrict__ lb, const float* __restrict__ dlb,
+                                      float* __restrict__ dy, int B, int D) {
+  // forward (dlb == null): lb[e][i] = sum_d log N(y_id; 0, 1);  backward: dy[e][i][:] = dlb[e][i] * (-y[e][i][:])
+  const int e = blockIdx.y, i = blockIdx.x;
+  const float* yr = y + ((long)(2 * e + 1) * B + i) * D;
+  if (!dlb) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) s += -0.5f * yr[d] * yr[d] - 0.91893853320467274178f;
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) lb[(long)e * 2 * B + i] = s;
+  } else {
+    const float g = dlb[(long)e * 2 * B + i];
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dy[((long)e * 2 * B + i) * D + d] = -g * yr[d];
+  }
+}
+
+int mimrl_handle::baseline_forward() {
+  const int B = cfg.batch;
+  if (cfg.baseline_type == MIMRL_BASELINE_GAUSSAIN) {
+    hipLaunchKernelGGL(gauss_baseline_kernel, dim3(B, NE_MI), dim3(128), 0, stream, tin, lbv, (const float*)nullptr,
+                       (float*)nullptr, B, EMB);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
+  const int dims[5] = {EMB, HID, HID, HID, 1};
+  return mlp_stack_forward(NE_MI, B, 2 * B, bl0, bl_stride, 4, bl_l, dims, tin + (size_t)B * EMB, bact, lbv);
+}
+
+int mimrl_handle::baseline_backward(int stage) {
+  const int B = cfg.batch;
+  if (cfg.baseline_type == MIMRL_BASELINE_GAUSSAIN) {
+    if (stage != 2) return MIMRL_OK;     // no parameters; in stage 1 the features are constants
+    hipLaunchKernelGGL(gauss_baseline_kernel, dim3(B, NE_MI), dim3(128), 0, stream, tin, (float*)nullptr, dlbv, bdin, B, EMB);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
+  const int dims[5] = {EMB, HID, HID, HID, 1};
+  return mlp_stack_backward(NE_MI, B, 2 * B, bl0, bl_stride, 4, bl_l, dims, tin + (size_t)B * EMB, bact, dlbv, bdz,
+                            stage == 2 ? bdin : nullptr, stage == 1);
+}
+
 int mimrl_handle::mi_backward(int stage) {
+  if (has_baseline()) MX(baseline_backward(stage));
   const int B = cfg.batch;
   const size_t BD = (size_t)B * EMB;
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
@@ -1586,6 +1664,11 @@ int mimrl_handle::route_feature_grads() {
       for (int sd = 0; sd < 2; ++sd)
         if (kMiWire[e][sd] == f) {
           gs.src[gs.n] = dtin + (e * 2 + sd) * BD; gs.ld[gs.n] = EMB; gs.off[gs.n] = 0; gs.rows[gs.n] = B; ++gs.n;
+        }
+    if (has_baseline())   // the baseline is a function of the y operand (VMI.py:101-108)
+      for (int e = 0; e < NE_MI; ++e)
+        if (kMiWire[e][1] == f) {
+          gs.src[gs.n] = bdin + (size_t)e * 2 * B * EMB; gs.ld[gs.n] = EMB; gs.off[gs.n] = 0; gs.rows[gs.n] = B; ++gs.n;
         }
     for (int e = 0; e < NE_CMI; ++e)
       for (int o = 0; o < 3; ++o)
@@ -2019,6 +2102,10 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
                       int bound) {
   return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, nullptr, gscale, E, B, bound, 0u);
+}
+int mimrl_op_mi_bound_baseline(void* stream, float* scores, float* dscores, float* mi, const float* gscale, const float* lb,
+                               float* dlb, int E, int B, int bound) {
+  return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, nullptr, gscale, E, B, bound, 0u, lb, dlb, B);
 }
 int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, float* mi, float* mi_loss, const float* gscale,
                          int E, int B, int bound, uint32_t lossform) {

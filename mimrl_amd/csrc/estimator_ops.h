@@ -16,9 +16,9 @@ int copy_rows(hipStream_t s, const CopyTable& t, long floats_each);
 // separable critic: scores, bound and the gradients w.r.t. both tower outputs in one launch (tout/dtout: [E][2][B][128])
 bool mi_sep_fused_supported(int B);
 int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B,
-                 int bound, unsigned lossform, int do_bwd);
+                 int bound, unsigned lossform, int do_bwd, const float* lb = nullptr, float* dlb = nullptr, long lb_stride = 0);
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
-                     int B, int bound, unsigned lossform);
+                     int B, int bound, unsigned lossform, const float* lb = nullptr, float* dlb = nullptr, long lb_stride = 0);
 
 // concat critic layer 1:  a1[(i*B+j), c] = relu(P[i,c] + Q[j,c])     P = x Wx^T, Q = y Wy^T + b   (VMI.py:59-65)
 int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, int E, int B, int Hd);

@@ -28,10 +28,17 @@ __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + lo
 // stage 2: f_t, f_a, f_v -- t_a and t_v enter through -mi, Model.py:386) -- it selects the gradient written to dscores.
 // S / dS may alias (every gradient entry depends on its own score and on reductions finished before it is written) and
 // may live in LDS (generic pointers): the fused separable-critic kernel below runs this body on its on-chip score tile.
-__device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi, float* __restrict__ mil, float gs, int e, int B,
-                              int bound, unsigned lossform, float* red, float* rowstat) {
+// lb / dlb (optional, tuba and interpolate only): log-baseline log a(y_i) per row (VMI.py:72-110) and the gradient of the
+// objective with respect to it.  With a baseline, S is modified in place for tuba (S_ij -= lb_i).
+__device__ void mi_bound_body(float* S, float* dS, float* __restrict__ mi, float* __restrict__ mil, float gs, int e, int B,
+                              int bound, unsigned lossform, float* red, float* rowstat, const float* __restrict__ lb,
+                              float* __restrict__ dlb) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
   const float invB = 1.f / B;
+  if (lb && bound == BOUND_TUBA) {
+    for (long idx = tid; idx < (long)B * B; idx += blockDim.x) S[idx] -= lb[idx / B];
+    __syncthreads();
+  }
 
   if (bound == BOUND_INFONCE) {
     // mi = log B + mean_i( s_ii - logsumexp_j s_ij )                       (VMI.py:162-166)
@@ -64,15 +71,20 @@ __device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi,
     //   I_ij = logaddexp(log a + L_ij - log(B-1), log(1-a)),  L_ij = log sum_{k != j} e^{s_ik}   (leave-one-out, per row)
     //   value = 1 + mean_{i != j}(s_jj - I_ij) - mean_{i != j} e^{s_ij - I_jj}
     float* lse = rowstat; float* vj = rowstat + B; float* Rr = rowstat + 2 * B; float* Cj = rowstat + 3 * B;
-    const float la = -softplus_f(-0.01f), lb = -softplus_f(0.01f), lbm1 = __logf((float)B - 1.f);
+    float* Ur = rowstat + 4 * B; float* Cm = rowstat + 5 * B;   // baseline gradient: sum_{j != i}(1 - sigma_ij), C_i (1 - sigma_ii)
+    const float la = -softplus_f(-0.01f), l1m = -softplus_f(0.01f), lbm1 = __logf((float)B - 1.f);
     const float M2 = (float)B * (B - 1.f);
-    auto interp = [&](float sv, float lsev, float& p, float& I, float& sig) {
-      p = __expf(sv - lsev);
+    // p = e^{s - lse}; its complement 1 - p = -expm1(-d) is what the gradient divides by: computed the reference's way
+    // (VMI.py:214-226), a plain 1 - p loses all digits when one score dominates its row
+    auto omp_of = [&](float sv, float lsev) { const float d = lsev - sv; return d == 0.f ? 1.f - __expf(-1.f) : -expm1f(-d); };
+    auto interp = [&](float sv, float lsev, float lbi, float& p, float& I, float& sig) {
       const float d = lsev - sv;
-      const float L = d == 0.f ? sv + 1.f + __logf(1.f - __expf(-1.f)) : lsev + log1pf(-p);   // safe_d of compute_log_loomean
-      const float u = la + L - lbm1;
-      const float hi = fmaxf(u, lb);
-      I = hi + __logf(__expf(u - hi) + __expf(lb - hi));
+      const float omp = d == 0.f ? 1.f - __expf(-1.f) : -expm1f(-d);
+      p = 1.f - omp;
+      const float L = d == 0.f ? sv + 1.f + __logf(omp) : sv + d + __logf(omp);               // safe_d of compute_log_loomean
+      const float u = la + L - lbm1, v = l1m + lbi;
+      const float hi = fmaxf(u, v);
+      I = hi + __logf(__expf(u - hi) + __expf(v - hi));
       sig = __expf(u - I);
     };
     float part_i = 0.f, part_d = 0.f;
@@ -84,15 +96,16 @@ __device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi,
       for (int j = lane; j < B; j += 64) se += __expf(S[(long)i * B + j] - mx);
       se = wave_sum(se);
       const float lsev = mx + __logf(se);
-      float r = 0.f, isum = 0.f;
+      float r = 0.f, isum = 0.f, ur = 0.f;
+      const float lbi = lb ? lb[i] : 0.f;
       for (int j = lane; j < B; j += 64) {
         float p, I, sig;
-        interp(S[(long)i * B + j], lsev, p, I, sig);
+        interp(S[(long)i * B + j], lsev, lbi, p, I, sig);
         if (j == i) { vj[i] = I; part_d += S[(long)i * B + j]; }
-        else { r += sig / (1.f - p); isum += I; }
+        else { r += sig / omp_of(S[(long)i * B + j], lsev); isum += I; ur += 1.f - sig; }
       }
-      r = wave_sum(r); isum = wave_sum(isum);
-      if (lane == 0) { lse[i] = lsev; Rr[i] = r; part_i += isum; }
+      r = wave_sum(r); isum = wave_sum(isum); ur = wave_sum(ur);
+      if (lane == 0) { lse[i] = lsev; Rr[i] = r; Ur[i] = ur; part_i += isum; }
     }
     const float sum_i = block_sum(part_i, red);
     const float dsum = block_sum(part_d, red);
@@ -110,8 +123,9 @@ __device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi,
         if (i != j) c += __expf(S[(long)i * B + j] - vj[j] - mxc);
       csum += c;
       float p, I, sig;
-      interp(S[(long)j * B + j], lse[j], p, I, sig);
-      Cj[j] = c * __expf(mxc) * sig / (1.f - p);        // Q_j = C_j sigma_jj / (1 - p_jj)
+      interp(S[(long)j * B + j], lse[j], lb ? lb[j] : 0.f, p, I, sig);
+      Cj[j] = c * __expf(mxc) * sig / omp_of(S[(long)j * B + j], lse[j]);        // Q_j = C_j sigma_jj / (1 - p_jj)
+      Cm[j] = c * __expf(mxc) * (1.f - sig);
     }
     csum = block_sum(csum, red);
     const float emx = __expf(mxc);
@@ -120,13 +134,15 @@ __device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi,
     if (tid == 0) { mi[e] = val; if (mil) mil[e] = -val; }
     if (!dS) return;
     __syncthreads();
+    if (dlb)
+      for (int i = tid; i < B; i += blockDim.x) dlb[i] = gs * (Cm[i] - Ur[i]) / M2;
     for (long idx = tid; idx < (long)B * B; idx += blockDim.x) {
       const int a = idx / B, b = idx % B;
       float p, I, sig;
-      interp(S[idx], lse[a], p, I, sig);
+      interp(S[idx], lse[a], lb ? lb[a] : 0.f, p, I, sig);
       float g;
       if (a == b) g = invB - p * Rr[a] / M2;
-      else g = -p * (Rr[a] - sig / (1.f - p)) / M2 - (emx * __expf(S[idx] - vj[b] - mxc) - Cj[a] * p) / M2;
+      else g = -p * (Rr[a] - sig / omp_of(S[idx], lse[a])) / M2 - (emx * __expf(S[idx] - vj[b] - mxc) - Cj[a] * p) / M2;
       dS[idx] = gs * g;
     }
     return;
@@ -190,16 +206,26 @@ __device__ void mi_bound_body(const float* S, float* dS, float* __restrict__ mi,
     else g = (i == j) ? sigmoid_f(-v) * invB : -sigmoid_f(v) / M;          // js_fgan / js / smile
     dS[idx] = gs * g;
   }
+  if (dlb && bound == BOUND_TUBA) {   // S_ij entered as s_ij - lb_i
+    __syncthreads();
+    for (int i = tid; i < B; i += blockDim.x) {
+      float t = 0.f;
+      for (int j = 0; j < B; ++j) t += dS[(long)i * B + j];
+      dlb[i] = -t;
+    }
+  }
 }
 
-__global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict__ scores, float* __restrict__ dscores,
+__global__ __launch_bounds__(1024) void mi_bound_kernel(const float* scores, float* dscores,
                                                         float* __restrict__ mi, float* __restrict__ mil,
-                                                        const float* __restrict__ gscale, int B, int bound, unsigned lossform) {
+                                                        const float* __restrict__ gscale, int B, int bound, unsigned lossform,
+                                                        const float* __restrict__ lb, float* __restrict__ dlb, long lb_stride) {
   __shared__ float red[16];
-  __shared__ float rowstat[4 * 1024];   // per-row / per-column statistics (InfoNCE: lse; interpolate: 4 vectors); B <= 1024
+  __shared__ float rowstat[6 * 1024];   // per-row / per-column statistics (InfoNCE: lse; interpolate: 6 vectors); B <= 1024
   const int e = blockIdx.x;
-  mi_bound_body(scores + (long)e * B * B, dscores ? dscores + (long)e * B * B : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B,
-                bound, lossform, red, rowstat);
+  mi_bound_body(const_cast<float*>(scores) + (long)e * B * B, dscores ? dscores + (long)e * B * B : nullptr, mi, mil,
+                gscale ? gscale[e] : 0.f, e, B, bound, lossform, red, rowstat, lb ? lb + e * lb_stride : nullptr,
+                dlb ? dlb + e * lb_stride : nullptr);
 }
 
 // Separable critic, one estimator per workgroup, everything between the tower outputs and their gradients on chip:
@@ -208,10 +234,11 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restrict__ tout, float* __restrict__ dtout,
                                                             float* __restrict__ mi, float* __restrict__ mil,
                                                             const float* __restrict__ gscale, int B, int bound,
-                                                            unsigned lossform, int do_bwd) {
+                                                            unsigned lossform, int do_bwd, const float* __restrict__ lb,
+                                                            float* __restrict__ dlb, long lb_stride) {
   extern __shared__ float S[];      // [B][B]
   __shared__ float red[16];
-  __shared__ float rowstat[4 * 128];
+  __shared__ float rowstat[6 * 128];
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int nt = B / 32;
   const float* __restrict__ X = tout + (long)(2 * e) * B * 128;       // g(x)
@@ -236,7 +263,8 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) S[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * B + tj * 32 + lr] = acc[r];
   }
   __syncthreads();
-  mi_bound_body(S, do_bwd ? S : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B, bound, lossform, red, rowstat);
+  mi_bound_body(S, do_bwd ? S : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B, bound, lossform, red, rowstat,
+                lb ? lb + e * lb_stride : nullptr, (do_bwd && dlb) ? dlb + e * lb_stride : nullptr);
   if (!do_bwd) return;
   __syncthreads();
   // d h[i][n] = sum_j dS[i][j] g[j][n]   and   d g[j][n] = sum_i dS[i][j] h[i][n]:  nt x 4 tiles each, wave -> (row tile, n tile)
@@ -547,7 +575,7 @@ int copy_rows(hipStream_t s, const CopyTable& t, long n) {
 
 bool mi_sep_fused_supported(int B) { return B >= 32 && B <= 128 && B % 32 == 0; }
 int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B,
-                 int bound, unsigned lossform, int do_bwd) {
+                 int bound, unsigned lossform, int do_bwd, const float* lb, float* dlb, long lb_stride) {
   if (!mi_sep_fused_supported(B)) return set_error(MIMRL_ERR_ARG, "mi_sep_fused: batch %d unsupported", B);
   static bool attr = false;
   if (!attr) {
@@ -555,15 +583,16 @@ int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, floa
     attr = true;
   }
   hipLaunchKernelGGL(mi_sep_fused_kernel, dim3(E), dim3(1024), (size_t)B * B * sizeof(float), s, tout, dtout, mi, mil, gscale, B,
-                     bound, lossform, do_bwd);
+                     bound, lossform, do_bwd, lb, dlb, lb_stride);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
 
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
-                     int B, int bound, unsigned lossform) {
+                     int B, int bound, unsigned lossform, const float* lb, float* dlb, long lb_stride) {
   if (B > 1024) return set_error(MIMRL_ERR_ARG, "mi_bound: batch %d > 1024 per rank", B);
-  hipLaunchKernelGGL(mi_bound_kernel, dim3(E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B, bound, lossform);
+  hipLaunchKernelGGL(mi_bound_kernel, dim3(E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B, bound, lossform, lb, dlb,
+                     lb_stride);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

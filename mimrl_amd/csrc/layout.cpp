@@ -23,6 +23,8 @@ int validate_cfg(const mimrl_cfg& c) {
   if (c.k_neighbor < 1 || c.k_neighbor > 8) return set_error(MIMRL_ERR_ARG, "k_neighbor must be in [1,8]");
   if (c.batch / c.k_neighbor < 1) return set_error(MIMRL_ERR_ARG, "batch smaller than k_neighbor");
   if (c.d_t < 1 || c.d_a < 1 || c.d_v < 1) return set_error(MIMRL_ERR_ARG, "feature dims must be positive");
+  if (c.baseline_type < MIMRL_BASELINE_CONSTANT || c.baseline_type > MIMRL_BASELINE_UNNORMALIZED)
+    return set_error(MIMRL_ERR_ARG, "baseline_type must be constant|gaussain|unnormalized (VMI.py:89-90)");
   if (c.encoder != MIMRL_ENCODER_GRU && c.encoder != MIMRL_ENCODER_CONV && c.encoder != MIMRL_ENCODER_LSTM)
     return set_error(MIMRL_ERR_ARG, "encoder must be gru|conv|lstm");
   int din[3] = {c.time_len, 3, c.d_common};
@@ -124,6 +126,16 @@ int build_layout(const mimrl_cfg& c, Layout* out) {
       }
     }
   }
+  if (c.baseline_type == MIMRL_BASELINE_UNNORMALIZED)   // VMI.py:82-84: mlps(128, 256, 1, 2); behind all critics (towers stay strided)
+    for (const char* n : kVmi) {
+      const std::string pre = std::string("vmi_estimator_") + n + ".baseline_model.MLP";
+      const int dims[4][2] = {{256, D}, {256, 256}, {256, 256}, {1, 256}};
+      const int idx[4] = {0, 2, 4, 6};
+      for (int l = 0; l < 4; ++l) {
+        add(pre + "." + std::to_string(idx[l]) + ".weight", dims[l][0], dims[l][1]);
+        add(pre + "." + std::to_string(idx[l]) + ".bias", dims[l][0], 0);
+      }
+    }
   for (const char* n : kVcmi) {
     const std::string pre = std::string("vcmi_estimator_") + n + ".classifier.mlp";
     const int dims[4][2] = {{hid, 3 * emb}, {hid, hid}, {hid, hid}, {2, hid}};

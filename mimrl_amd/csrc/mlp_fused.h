@@ -40,7 +40,7 @@ int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a);
 // bf16 images of a parameter bucket: dst[i] = bf16(src[i]); and, for a table of strided groups of [N,K] matrices,
 // dstT[off + g*gstride + k*N + n] = bf16(src[off + g*gstride + n*K + k])
 int bf16_image(hipStream_t s, const float* src, __bf16* dst, long n);
-struct TransposeTable { long off[8]; int N[8], K[8], nb[8]; long gstride[8]; int n; };
+struct TransposeTable { long off[12]; int N[12], K[12], nb[12]; long gstride[12]; int n; };
 int bf16_transposed_images(hipStream_t s, const float* src, __bf16* dstT, const TransposeTable& t);
 
 }  // namespace mimrl

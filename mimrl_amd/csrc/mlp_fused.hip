@@ -508,7 +508,7 @@ int bf16_image(hipStream_t s, const float* src, __bf16* dst, long n) {
 }
 
 int bf16_transposed_images(hipStream_t s, const float* src, __bf16* dstT, const TransposeTable& t) {
-  if (t.n < 1 || t.n > 8) return set_error(MIMRL_ERR_ARG, "bf16_transposed_images: 1..8 table entries");
+  if (t.n < 1 || t.n > 12) return set_error(MIMRL_ERR_ARG, "bf16_transposed_images: 1..12 table entries");
   int z = 0, kmax = 0, nmax = 0;
   for (int e = 0; e < t.n; ++e) { z += t.nb[e]; kmax = t.K[e] > kmax ? t.K[e] : kmax; nmax = t.N[e] > nmax ? t.N[e] : nmax; }
   hipLaunchKernelGGL(transpose_images_kernel, dim3((kmax + 31) / 32, (nmax + 31) / 32, z), dim3(256), 0, s, src, dstT, t);

@@ -88,6 +88,12 @@ def named_shapes(opt, d_t: int, d_a: int, d_v: int) -> List[Tuple[str, Tuple[int
                 out += [(f"{pre}.MLP_f.{idx}.weight", shp), (f"{pre}.MLP_f.{idx}.bias", (shp[0],))]
         else:
             raise NotImplementedError(opt.critic_type)                    # VMI.py:44-45
+    if getattr(opt, "baseline_type", "constant") == "unnormalized":      # VMI.py:82-84: mlps(128, 256, 1, 2); kept behind all
+        for n in VMI_NAMES:                                               # critics so that the towers stay uniformly strided
+            pre = f"vmi_estimator_{n}.baseline_model.MLP"
+            dims = [(hid, D), (hid, hid), (hid, hid), (1, hid)]
+            for idx, shp in zip((0, 2, 4, 6), dims):
+                out += [(f"{pre}.{idx}.weight", shp), (f"{pre}.{idx}.bias", (shp[0],))]
     for n in VCMI_NAMES:
         pre = f"vcmi_estimator_{n}.classifier.mlp"
         dims = [(hid, 3 * emb), (hid, hid), (hid, hid), (2, hid)]

@@ -255,9 +255,29 @@ def _logmeanexp_nodiag(x: Tensor) -> Tensor:
     return torch.logsumexp(x.reshape(-1), 0) - math.log(B * (B - 1.0))
 
 
-def tuba_lower_bound(scores: Tensor) -> Tensor:
-    """VMI.py:148-154 with constant (zero) log-baseline."""
+def tuba_lower_bound(scores: Tensor, log_baseline: Optional[Tensor] = None) -> Tensor:
+    """VMI.py:148-154; log_baseline [B,1] is subtracted row-wise (None = the constant zero baseline)."""
+    if log_baseline is not None:
+        scores = scores - log_baseline
     return 1.0 + scores.diag().mean() - torch.exp(_logmeanexp_nodiag(scores))
+
+
+def log_baseline(p: Params, name: str, opt, y: Tensor) -> Optional[Tensor]:
+    """BaselineModel.forward (VMI.py:72-110) -> [B,1] or None for the constant baseline.  `gaussain`: sum of
+    Normal(mu=0, rho=1) log-densities (Model.py:290-295 pass mu=0, rho=1); `unnormalized`: a trainable mlps(128,256,1,2)."""
+    kind = getattr(opt, "baseline_type", "constant")
+    if kind == "constant":
+        return None
+    if kind == "gaussain":
+        return (-0.5 * y * y - 0.5 * math.log(2 * math.pi)).sum(-1, keepdim=True)
+    if kind == "unnormalized":
+        h = y
+        for j, i in enumerate((0, 2, 4, 6)):
+            h = _linear(p, f"vmi_estimator_{name}.baseline_model.MLP.{i}", h)
+            if j < 3:
+                h = torch.relu(h)
+        return h.reshape(-1, 1)
+    raise NotImplementedError(kind)
 
 
 def nwj_lower_bound(scores: Tensor) -> Tensor:
@@ -290,7 +310,7 @@ def smile_lower_bound(scores: Tensor, clip: float = 1.0) -> Tensor:
     return js + (dv - js).detach()
 
 
-def interp_lower_bound(scores: Tensor, alpha_logit: float = 0.01) -> Tensor:
+def interp_lower_bound(scores: Tensor, log_baseline: Optional[Tensor] = None, alpha_logit: float = 0.01) -> Tensor:
     """VMI.py:201-250 with the constant baseline (log a(y) = 0) and the alpha_logit VMIEstimator hard-codes (Model.py:118).
     nce baseline = leave-one-out log-mean-exp of each row; interpolated with the constant baseline in log space."""
     B = scores.shape[0]
@@ -300,7 +320,8 @@ def interp_lower_bound(scores: Tensor, alpha_logit: float = 0.01) -> Tensor:
     loo_lme = scores + (safe_d + torch.log(-torch.expm1(-safe_d))) - math.log(B - 1.0)    # compute_log_loomean
     log_alpha = -F.softplus(torch.tensor(-float(alpha_logit), dtype=scores.dtype))
     log_1m = -F.softplus(torch.tensor(float(alpha_logit), dtype=scores.dtype))
-    interp = torch.logsumexp(torch.stack((log_alpha + loo_lme, log_1m + torch.zeros_like(loo_lme))), dim=0)
+    base = torch.zeros_like(loo_lme) if log_baseline is None else log_baseline.repeat(1, B)     # element (i,j) = log a(y_i)
+    interp = torch.logsumexp(torch.stack((log_alpha + loo_lme, log_1m + base)), dim=0)
     critic_marg = scores - torch.diag(interp)                          # broadcasts over rows: s_ij - interp_jj
     marg = torch.exp(_logmeanexp_nodiag(critic_marg))
     critic_joint = torch.diag(scores) - interp                         # s_jj - interp_ij
@@ -323,7 +344,10 @@ def vmi_estimate(p: Params, name: str, opt, x: Tensor, y: Tensor) -> Tuple[Tenso
         mi = t.mean() - _logmeanexp_nodiag(s)
         ma_et = (1 - 0.01) * 1 + 0.01 * et.mean()
         return mi, t.mean() - (1 / ma_et.mean()).detach() * et.mean()   # NB: not negated in the reference
-    mi = BOUNDS[opt.bound_type](s)
+    if opt.bound_type in ("tuba", "interpolate"):               # the only bounds that read the baseline (Model.py:127-142)
+        mi = BOUNDS[opt.bound_type](s, log_baseline(p, name, opt, y))
+    else:
+        mi = BOUNDS[opt.bound_type](s)
     return mi, -mi
 
 

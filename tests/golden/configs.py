@@ -14,6 +14,11 @@ CONFIGS = {
     "tiny_conv": dict(B=8, T=6, N=40, seed=5, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="conv"),
     # mine bound: its loss term is not -mi (Model.py:121-125), and stage 2 mixes both forms (Model.py:386)
     "tiny_mine": dict(B=8, T=6, N=40, seed=6, critic="separate", cube="6-3-128=4-3-128", traj=2, bound="mine"),
+    # baselines (VMI.py:72-110) of the two bounds that read them: trainable (unnormalized) and Gaussian
+    "tiny_tuba_un": dict(B=8, T=6, N=40, seed=10, critic="separate", cube="6-3-128=4-3-128", traj=2, bound="tuba",
+                         baseline="unnormalized"),
+    "tiny_interp_ga": dict(B=8, T=6, N=40, seed=11, critic="separate", cube="6-3-128=4-3-128", traj=2, bound="interpolate",
+                           baseline="gaussain"),
     # --encoders lstm (1-layer bi-LSTM, Model.py:250-252), ragged inputs
     "tiny_lstm": dict(B=8, T=6, N=40, seed=9, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="lstm"),
     # interpolated bound (VMI.py:201-250) with the constant baseline, concat critic
@@ -38,7 +43,7 @@ def make_opt(c):
         batch_size=c["B"], d_common=128, encoders=c.get("encoders", "gru"), features_compose_t="mean", features_compose_k="mean",
         num_class=1, activate="gelu", time_len=c.get("L", c["T"]), d_hiddens=cube, d_outs=cube,
         dropout_mlp=[0.0, 0.0, 0.0], dropout=[0.0, 0.0, 0.0, 0.0], bias=True, ln_first=c.get("ln_first", False),
-        res_project=[True] * len(cube), critic_type=c["critic"], baseline_type="constant",
+        res_project=[True] * len(cube), critic_type=c["critic"], baseline_type=c.get("baseline", "constant"),
         bound_type=c.get("bound", "infonce"), loss_mi_coefficient1=[1.0] * 11, loss_mi_coefficient2=[0.01] * 8,
         mi_lr_rate=1.0, cmi_lr_rate=1.0, k_neighbor=c.get("k", 2), radius=1.0, cmi_last_acticate=c.get("cmi_last", "sigmoid"),
         stage1_n=1, loss="MAE", gradient_clip=1.5, optm="Adam", learning_rate=4e-3, weight_decay=0.0,

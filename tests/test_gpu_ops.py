@@ -147,6 +147,29 @@ def test_mi_bounds_value_and_gradient(lib, bound, B):
         grad_close(dS[e].cpu().numpy(), st.grad.numpy(), 1e-3, f"{bound} gradient")
 
 
+@pytest.mark.parametrize("bound", ["tuba", "interpolate"])
+@pytest.mark.parametrize("B", [8, 32, 128])
+def test_bounds_with_log_baseline(lib, bound, B):
+    """tuba / interpolate with a per-row log-baseline (VMI.py:72-110): value, d/dscores and d/dbaseline vs autograd."""
+    g = np.random.default_rng(6)
+    E = 3
+    s = (g.standard_normal((E, B, B)) * 1.2).astype(np.float32)
+    lbv = (g.standard_normal((E, B)) * 0.7 - 0.3).astype(np.float32)
+    gs = np.array([-1.0, 0.5, -0.01], np.float32)
+    S, dS, GS = dev(s), torch.zeros(E, B, B, device="cuda"), dev(gs)
+    LB, dLB, mi = dev(lbv), torch.zeros(E, B, device="cuda"), torch.zeros(E, device="cuda")
+    _lib.check(lib.mimrl_op_mi_bound_baseline(stream(), P(S), P(dS), P(mi), P(GS), P(LB), P(dLB), E, B, _lib.BOUNDS[bound]))
+    torch.cuda.synchronize()
+    for e in range(E):
+        st = torch.from_numpy(s[e]).double().requires_grad_(True)
+        lt = torch.from_numpy(lbv[e]).double().reshape(B, 1).requires_grad_(True)
+        val = R.BOUNDS[bound](st, lt)
+        (val * float(gs[e])).backward()
+        assert_close(mi[e].item(), val.item(), 1e-4, 2e-5, f"{bound} value")
+        grad_close(dS[e].cpu().numpy(), st.grad.numpy(), 1e-3, f"{bound} d/dscores")
+        grad_close(dLB[e].cpu().numpy(), lt.grad.numpy().reshape(-1), 1e-3, f"{bound} d/dbaseline")
+
+
 @pytest.mark.parametrize("B", [8, 64])
 def test_mine_bound_loss_term_and_both_gradient_forms(lib, B):
     """`mine` (Model.py:121-125): value = dv form; loss term = mean(t) - mean(et)/ma_et (not negated).  Estimators flagged in
