@@ -644,7 +644,6 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
-    a.dbg = getenv("MIMRL_GRU_DBG") ? atoi(getenv("MIMRL_GRU_DBG")) : 0;
     a.btv = gru_pick_btv(B, 2);
     if (l == 1) MX(fork(1, 3));
     for (int m = 0; m < 2; ++m) {
@@ -1278,7 +1277,6 @@ int mimrl_handle::model_backward() {
     GruBwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.dout_ld = l == 1 ? H : 2 * H; a.dout_off = l == 1 ? 0 : H;
-    a.dbg = getenv("MIMRL_GRU_DBG") ? atoi(getenv("MIMRL_GRU_DBG")) : 0;
     a.btv = gru_pick_btv(B, 2);
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];

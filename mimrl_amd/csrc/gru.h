@@ -16,8 +16,7 @@ struct GruFwdArgs {
   GruSeq seq[2][2];        // [modality][direction]
   const int* lens[2];      // [modality][B] valid lengths (packed-sequence semantics)
   int B, T, out_ld, nmod;
-  int dbg;             // tuning only (see GruBwdArgs)
-  int btv;             // valid batch rows per workgroup (1..16); the MFMA tile stays 16 wide, the rest is padding
+  int btv;             // batch rows per workgroup (1..4)
 };
 
 struct GruSeqBwd {
@@ -35,15 +34,14 @@ struct GruBwdArgs {
   GruSeqBwd seq[2][2];
   const int* lens[2];
   int B, T, out_ld, dout_ld, dout_off, nmod;
-  int dbg;             // tuning only: bit0 skip global stores, bit1 skip MFMA, bit2 skip operand loads
   int btv;             // must equal the forward launch's value (addresses the saved-gate slab)
 };
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);
 int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16);
 long gru_saved_floats(int B, int T);
-// batch rows per workgroup: both kernels are bound by per-CU load/store bandwidth, not MFMA, so the batch is spread
-// over as many CUs as possible (MFMA columns beyond btv are padding)
+// batch rows per workgroup (<= 4): the kernels are bound by the per-step instruction latency of one wave, so the batch
+// is spread over as many CUs as possible
 int gru_pick_btv(int B, int nmod);
 
 }  // namespace mimrl

@@ -5,13 +5,18 @@
 // the state; the reverse direction therefore effectively starts at t = length-1.
 //
 // MI355X design.  The recurrence is the latency floor of the whole training step: 2 layers x T
-// dependent steps per pass.  It is independent across batch rows, so one workgroup owns a 16-row batch tile of one
-// (modality, direction) for all T steps -- no inter-workgroup traffic at all.  Inside the workgroup the four
-// waves (one per SIMD) split the 128 hidden units 32/32/32/32; each wave keeps its slice of W_hh (all three
-// gates) in REGISTERS as ready-made MFMA A-fragments for the whole sequence (bf16: 96 VGPRs, fp32: 192 VGPRs),
-// so the only per-step shared-memory traffic is the 16x128 state tile (double-buffered in LDS, ONE barrier per
-// step).  gates^T[unit, batch] = W_hh[unit, :] . h^T[:, batch] puts the batch on the MFMA lane axis and the
-// r/z/n values of one (unit, batch) pair in the same lane/register slot, so the gate math is register-only.
+// dependent steps per pass.  It is independent across batch rows, so one workgroup owns 4 batch rows of one
+// (modality, direction) for all T steps -- no inter-workgroup traffic at all, and B=128 spreads over 128 CUs.
+// Inside the workgroup the four waves (one per SIMD) split the 128 hidden units 32/32/32/32; each wave keeps its
+// slice of W_hh (all three gates) in REGISTERS as ready-made MFMA B-fragments for the whole sequence (bf16: 96
+// VGPRs, fp32: 192 VGPRs), so the only per-step shared-memory traffic is the 4x128 state tile (double-buffered in
+// LDS, ONE barrier per step).  The per-step cost is the wave's own instruction stream (MFMA issue + gate math on
+// the quarter-rate transcendental unit), so the mapping is chosen to leave NO idle lanes in the gate math:
+// gates[batch, unit] = h[batch, :] . W_hh[unit, :]^T with the state as the A operand, each batch row replicated
+// over 4 MFMA rows, so that accumulator register 0 of lane (n, kq) is exactly (batch kq, unit n) -- one useful
+// value per lane per MFMA, the r/z/n values of one (unit, batch) pair in the same lane, two adjacent units per
+// lane: all loads / stores are 8-byte, the gate math is register-only and 4x shorter than with the batch on the
+// MFMA column axis (where 12 of 16 columns were padding).
 // The input projections gx = x W_ih^T + b_ih are hoisted out of the loop into one GEMM per layer (gemm.hip).
 //
 // fp32 mode: v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chains) -- parity mode.
@@ -27,8 +32,9 @@ namespace {
 
 constexpr int H = 128;       // hidden size (= d_common; the reference only runs with 128)
 constexpr int G = 3 * H;
-constexpr int BT = 16;       // batch rows per workgroup (MFMA N)
-// 4 waves per workgroup; wave w owns units [32w, 32w+32)
+constexpr int BR = 4;        // batch rows per workgroup
+// 4 waves per workgroup; wave w owns units [32w, 32w+32); lane (n = lane&15, kq = lane>>4) owns the two adjacent
+// units u0 = 32w + 2n, u0+1 of batch row kq
 
 template <bool BF16>
 struct Cfg;
@@ -36,28 +42,32 @@ template <>
 struct Cfg<true> {
   static constexpr int KS_F = H / 32;   // k-steps over H (forward product)
   static constexpr int KS_B = G / 32;   // k-steps over 3H (backward product)
-  using AFrag = bf16x8;
+  using Frag = bf16x8;
 };
 template <>
 struct Cfg<false> {
   static constexpr int KS_F = H / 4;
   static constexpr int KS_B = G / 4;
-  using AFrag = float;
+  using Frag = float;
 };
 
-// LDS state tile.  bf16: [batch][k] rows of (K+16) bf16 (288-B / 800-B rows -> conflict-free ds_read_b128);
-//                  fp32: [k][batch] (k-major: a wave's 64 lanes read 64 consecutive words).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// LDS state tile (4 batch rows).  bf16: [batch][k] rows of (K+32) bf16 -- the row pitch is 16 words mod 64, so the 16
+//                  distinct 16-byte chunks a wave reads (4 rows x 4 k-quarters, each broadcast to 4 lanes) hit
+//                  16 different bank groups;  fp32: [k][batch] (16 consecutive words per wave read).
 template <bool BF16, int K>
 struct Tile;
 template <int K>
 struct Tile<true, K> {
-  __bf16 v[BT][K + 16];
+  __bf16 v[BR][K + 32];
 };
 template <int K>
 struct Tile<false, K> {
-  float v[K][BT];
+  float v[K][BR];
 };
 
+// D[m, n] += sum_k A[m, k] B[k, n];  A = state rows, B = weight columns
 __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -65,25 +75,27 @@ __device__ __forceinline__ f32x4 mfma16(const float& a, const float& b, f32x4 c)
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// B-fragment (state^T) of k-step ks for this lane
+// A-fragment of k-step ks: MFMA row m carries batch row m>>2 (every batch row replicated over 4 MFMA rows), so the
+// accumulator register 0 of lane (n, kq) -- MFMA row 4kq -- is the result for batch row kq: the 16x16 result tile lands
+// as ONE useful value per lane, 16 units x 4 batch rows, and the gate math runs on all 64 lanes without any shuffle.
 template <int K>
-__device__ __forceinline__ bf16x8 bfrag(const Tile<true, K>& t, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(&t.v[lane & 15][ks * 32 + 8 * (lane >> 4)]);
+__device__ __forceinline__ bf16x8 state_frag(const Tile<true, K>& t, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(&t.v[(lane & 15) >> 2][ks * 32 + 8 * (lane >> 4)]);
 }
 template <int K>
-__device__ __forceinline__ float bfrag(const Tile<false, K>& t, int ks, int lane) {
-  return t.v[ks * 4 + (lane >> 4)][lane & 15];
+__device__ __forceinline__ float state_frag(const Tile<false, K>& t, int ks, int lane) {
+  return t.v[ks * 4 + (lane >> 4)][(lane & 15) >> 2];
 }
-// write 4 consecutive "k" values (k0..k0+3) of batch column b
+// write "k" values k0, k0+1 of batch row b
 template <int K>
-__device__ __forceinline__ void put4(Tile<true, K>& t, int b, int k0, float x0, float x1, float x2, float x3) {
-  bf16x4 p;
-  p[0] = to_bf16(x0); p[1] = to_bf16(x1); p[2] = to_bf16(x2); p[3] = to_bf16(x3);
-  *reinterpret_cast<bf16x4*>(&t.v[b][k0]) = p;
+__device__ __forceinline__ void put2(Tile<true, K>& t, int b, int k0, float x0, float x1) {
+  bf16x2 p;
+  p[0] = to_bf16(x0); p[1] = to_bf16(x1);
+  *reinterpret_cast<bf16x2*>(&t.v[b][k0]) = p;
 }
 template <int K>
-__device__ __forceinline__ void put4(Tile<false, K>& t, int b, int k0, float x0, float x1, float x2, float x3) {
-  t.v[k0][b] = x0; t.v[k0 + 1][b] = x1; t.v[k0 + 2][b] = x2; t.v[k0 + 3][b] = x3;
+__device__ __forceinline__ void put2(Tile<false, K>& t, int b, int k0, float x0, float x1) {
+  t.v[k0][b] = x0; t.v[k0 + 1][b] = x1;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. it would wait every step
@@ -94,58 +106,41 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-}
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
 
-// saved-gate slab: fp32 mode stores r,z,n,hn as four float4 per (lane, s); bf16 mode packs them into two 16-byte
-// vectors [r|z] and [n|hn] of bf16 (half the store / load instructions of the two recurrence kernels).
+// saved-gate slab, "lane-native": one record {r0 r1 z0 z1 n0 n1 hn0 hn1} per (t, tile, wave, lane); bf16 mode packs it
+// into ONE 16-byte vector (a wave instruction stores 1 KiB contiguous), fp32 mode into two.
 template <bool BF16>
-__device__ __forceinline__ void save_gates(float* base, int t, int ntile, int tile, int w, int s, int lane, const float* rr,
-                                           const float* zz, const float* nn, const float* hn);
+struct SvRec { static constexpr int F = BF16 ? 4 : 8; };   // floats per record
 template <bool BF16>
-__device__ __forceinline__ void load_gates(const float* base, int t, int ntile, int tile, int w, int s, int lane, float* rr,
-                                           float* zz, float* nn, float* hn);
+__device__ __forceinline__ long sv_index(int t, int ntile, int tile, int w, int lane) {
+  return ((((long)t * ntile + tile) * 4 + w) * 64 + lane) * SvRec<BF16>::F;
+}
+struct Gates { float r[2], z[2], n[2], hn[2]; };
 
-// saved-gate slab addressing ("lane-native": every wave-instruction stores 1 KiB contiguous)
-//   index = ((((t*ntile + tile)*4 + q)*8 + (w*2+s))*64 + lane)*4      q: 0=r 1=z 2=n 3=hn
-__device__ __forceinline__ long sv_index(int t, int ntile, int tile, int q, int w, int s, int lane) {
-  return ((((long)t * ntile + tile) * 4 + q) * 8 + (w * 2 + s)) * 256 + lane * 4;   // 16 batch columns per tile slot
-}
-
-template <>
-__device__ __forceinline__ void save_gates<false>(float* base, int t, int ntile, int tile, int w, int s, int lane,
-                                                  const float* rr, const float* zz, const float* nn, const float* hn) {
-  st4(base + sv_index(t, ntile, tile, 0, w, s, lane), rr[0], rr[1], rr[2], rr[3]);
-  st4(base + sv_index(t, ntile, tile, 1, w, s, lane), zz[0], zz[1], zz[2], zz[3]);
-  st4(base + sv_index(t, ntile, tile, 2, w, s, lane), nn[0], nn[1], nn[2], nn[3]);
-  st4(base + sv_index(t, ntile, tile, 3, w, s, lane), hn[0], hn[1], hn[2], hn[3]);
-}
-template <>
-__device__ __forceinline__ void save_gates<true>(float* base, int t, int ntile, int tile, int w, int s, int lane,
-                                                 const float* rr, const float* zz, const float* nn, const float* hn) {
-  bf16x8 a, b;
+template <bool BF16>
+__device__ __forceinline__ void save_gates(float* p, const Gates& g) {
+  if constexpr (BF16) {
+    bf16x8 a;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { a[r] = to_bf16(rr[r]); a[4 + r] = to_bf16(zz[r]); b[r] = to_bf16(nn[r]); b[4 + r] = to_bf16(hn[r]); }
-  *reinterpret_cast<bf16x8*>(base + sv_index(t, ntile, tile, 0, w, s, lane)) = a;
-  *reinterpret_cast<bf16x8*>(base + sv_index(t, ntile, tile, 1, w, s, lane)) = b;
+    for (int e = 0; e < 2; ++e) { a[e] = to_bf16(g.r[e]); a[2 + e] = to_bf16(g.z[e]); a[4 + e] = to_bf16(g.n[e]); a[6 + e] = to_bf16(g.hn[e]); }
+    *reinterpret_cast<bf16x8*>(p) = a;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(g.r[0], g.r[1], g.z[0], g.z[1]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(g.n[0], g.n[1], g.hn[0], g.hn[1]);
+  }
 }
-template <>
-__device__ __forceinline__ void load_gates<false>(const float* base, int t, int ntile, int tile, int w, int s, int lane,
-                                                  float* rr, float* zz, float* nn, float* hn) {
-  const float4 R = ld4(base + sv_index(t, ntile, tile, 0, w, s, lane)), Z = ld4(base + sv_index(t, ntile, tile, 1, w, s, lane));
-  const float4 N = ld4(base + sv_index(t, ntile, tile, 2, w, s, lane)), Hn = ld4(base + sv_index(t, ntile, tile, 3, w, s, lane));
-  rr[0] = R.x; rr[1] = R.y; rr[2] = R.z; rr[3] = R.w; zz[0] = Z.x; zz[1] = Z.y; zz[2] = Z.z; zz[3] = Z.w;
-  nn[0] = N.x; nn[1] = N.y; nn[2] = N.z; nn[3] = N.w; hn[0] = Hn.x; hn[1] = Hn.y; hn[2] = Hn.z; hn[3] = Hn.w;
-}
-template <>
-__device__ __forceinline__ void load_gates<true>(const float* base, int t, int ntile, int tile, int w, int s, int lane,
-                                                 float* rr, float* zz, float* nn, float* hn) {
-  const bf16x8 a = *reinterpret_cast<const bf16x8*>(base + sv_index(t, ntile, tile, 0, w, s, lane));
-  const bf16x8 b = *reinterpret_cast<const bf16x8*>(base + sv_index(t, ntile, tile, 1, w, s, lane));
+template <bool BF16>
+__device__ __forceinline__ void load_gates(const float* p, Gates& g) {
+  if constexpr (BF16) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { rr[r] = (float)a[r]; zz[r] = (float)a[4 + r]; nn[r] = (float)b[r]; hn[r] = (float)b[4 + r]; }
+    for (int e = 0; e < 2; ++e) { g.r[e] = (float)a[e]; g.z[e] = (float)a[2 + e]; g.n[e] = (float)a[4 + e]; g.hn[e] = (float)a[6 + e]; }
+  } else {
+    const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+    g.r[0] = x.x; g.r[1] = x.y; g.z[0] = x.z; g.z[1] = x.w; g.n[0] = y.x; g.n[1] = y.y; g.hn[0] = y.z; g.hn[1] = y.w;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,22 +154,24 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
   const int tile = blockIdx.x, dir = blockIdx.y, mod = blockIdx.z;
   const GruSeq& q = a.seq[mod][dir];
   const int B = a.B, T = a.T, ntile = gridDim.x;
-  const int bcol = lane & 15, kq = lane >> 4;
-  const int b = tile * a.btv + bcol;
-  const bool brow_ok = bcol < a.btv && b < B;
+  const int n = lane & 15, kq = lane >> 4;
+  const int u0 = 32 * w + 2 * n;
+  const int b = tile * a.btv + kq;
+  const bool brow_ok = kq < a.btv && b < B;
   const int len = brow_ok ? a.lens[mod][b] : 0;
 
-  // ---- W_hh slice -> registers as MFMA A fragments: rows (gate g, unit 32w+16s+i), i = lane&15
-  typename C::AFrag wr[3][2][C::KS_F];
+  // ---- W_hh slice -> registers as MFMA B fragments: column n of N-tile (g, s) is gate row g*H + u0 + s
+  typename C::Frag wr[3][2][C::KS_F];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const float* row = q.w_hh + (long)(g * H + 32 * w + 16 * s + (lane & 15)) * H;
+      const float* row = q.w_hh + (long)(g * H + u0 + s) * H;
 #pragma unroll
       for (int ks = 0; ks < C::KS_F; ++ks) {
         if constexpr (BF16) {
-          const float4 lo = ld4(row + ks * 32 + 8 * kq), hi = ld4(row + ks * 32 + 8 * kq + 4);
+          const float4 lo = *reinterpret_cast<const float4*>(row + ks * 32 + 8 * kq);
+          const float4 hi = *reinterpret_cast<const float4*>(row + ks * 32 + 8 * kq + 4);
           bf16x8 f;
           f[0] = to_bf16(lo.x); f[1] = to_bf16(lo.y); f[2] = to_bf16(lo.z); f[3] = to_bf16(lo.w);
           f[4] = to_bf16(hi.x); f[5] = to_bf16(hi.y); f[6] = to_bf16(hi.z); f[7] = to_bf16(hi.w);
@@ -184,87 +181,71 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
         }
       }
     }
-  // b_hh for this lane's output rows: unit = 32w + 16s + 4kq + r
-  float bh[3][2][4];
+  float bh[3][2];
 #pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const float4 v = ld4(q.b_hh + g * H + 32 * w + 16 * s + 4 * kq);
-      bh[g][s][0] = v.x; bh[g][s][1] = v.y; bh[g][s][2] = v.z; bh[g][s][3] = v.w;
-    }
+  for (int g = 0; g < 3; ++g) {
+    const float2 v = ld2(q.b_hh + g * H + u0);
+    bh[g][0] = v.x; bh[g][1] = v.y;
+  }
 
   // ---- state
-  float hreg[2][4];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hreg[s][r] = 0.f;
-#pragma unroll
-  for (int s = 0; s < 2; ++s) put4(hs[0], bcol, 32 * w + 16 * s + 4 * kq, 0.f, 0.f, 0.f, 0.f);
+  float hreg[2] = {0.f, 0.f};
+  put2(hs[0], kq, u0, 0.f, 0.f);
   __syncthreads();
 
-  const long row_stride_gx = (long)T * G;          // gx [B,T,3H]
-  const long row_stride_out = (long)T * a.out_ld;  // out [B,T,out_ld]
-  const float* gx_b = q.gx + (long)(brow_ok ? b : 0) * row_stride_gx;
-  float* out_b = q.out + (long)(brow_ok ? b : 0) * row_stride_out;
+  const float* gx_b = q.gx + (long)(brow_ok ? b : 0) * T * G + u0;                       // gx [B,T,3H]
+  float* out_b = q.out + (long)(brow_ok ? b : 0) * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
+  float* sv_b = q.saved ? q.saved + sv_index<BF16>(0, ntile, tile, w, lane) : nullptr;
+  const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
 
-  float4 gxn[3][2];   // prefetched gx of the next step
+  float2 gxn[3];   // prefetched gx of the next step
   auto load_gx = [&](int t) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        gxn[g][s] = brow_ok ? ld4(gx_b + (long)t * G + g * H + 32 * w + 16 * s + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 3; ++g) gxn[g] = ld2(gx_b + (long)t * G + g * H);   // unconditional (padding lanes read row 0):
+                                                                            // a guarded load becomes a branch with an
+                                                                            // immediate vmcnt(0) -- the full memory
+                                                                            // latency on the critical path of every step
   };
   load_gx(dir ? T - 1 : 0);
 
   for (int step = 0; step < T; ++step) {
     const int t = dir ? T - 1 - step : step;
     const int cur = step & 1;
-    float4 gxc[3][2];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) gxc[g][s] = gxn[g][s];
-    if (step + 1 < T && !(a.dbg & 4)) load_gx(dir ? T - 2 - step : step + 1);
+    const float2 gxc[3] = {gxn[0], gxn[1], gxn[2]};
+    if (step + 1 < T) load_gx(dir ? T - 2 - step : step + 1);
 
     f32x4 acc[3][2];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acc[g][s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 2))
+      for (int s = 0; s < 2; ++s) acc[g][s] = f32x4{bh[g][s], 0.f, 0.f, 0.f};   // only register 0 is read
 #pragma unroll
     for (int ks = 0; ks < C::KS_F; ++ks) {
-      const auto bf = bfrag(hs[cur], ks, lane);
+      const auto sf = state_frag(hs[cur], ks, lane);
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(wr[g][s][ks], bf, acc[g][s]);
+        for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(sf, wr[g][s][ks], acc[g][s]);
     }
 
     const bool valid = t < len;
+    const float gr[2] = {gxc[0].x, gxc[0].y}, gz[2] = {gxc[1].x, gxc[1].y}, gn[2] = {gxc[2].x, gxc[2].y};
+    Gates gt;
+    float ho[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      float rr[4], zz[4], nn[4], hn[4], ho[4];
-      const float gr[4] = {gxc[0][s].x, gxc[0][s].y, gxc[0][s].z, gxc[0][s].w};
-      const float gz[4] = {gxc[1][s].x, gxc[1][s].y, gxc[1][s].z, gxc[1][s].w};
-      const float gn[4] = {gxc[2][s].x, gxc[2][s].y, gxc[2][s].z, gxc[2][s].w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        rr[r] = fast_sigmoid(gr[r] + acc[0][s][r] + bh[0][s][r]);
-        zz[r] = fast_sigmoid(gz[r] + acc[1][s][r] + bh[1][s][r]);
-        hn[r] = acc[2][s][r] + bh[2][s][r];
-        nn[r] = fast_tanh(gn[r] + rr[r] * hn[r]);
-        const float hnew = nn[r] + zz[r] * (hreg[s][r] - nn[r]);
-        ho[r] = valid ? hnew : 0.f;
-        hreg[s][r] = valid ? hnew : hreg[s][r];
-      }
-      const int unit = 32 * w + 16 * s + 4 * kq;
-      put4(hs[cur ^ 1], bcol, unit, hreg[s][0], hreg[s][1], hreg[s][2], hreg[s][3]);
-      if (brow_ok && !(a.dbg & 1)) st4(out_b + (long)t * a.out_ld + dir * H + unit, ho[0], ho[1], ho[2], ho[3]);
-      if (q.saved && brow_ok && !(a.dbg & 1)) save_gates<BF16>(q.saved, t, ntile, tile, w, s, lane, rr, zz, nn, hn);
+      gt.r[s] = fast_sigmoid(gr[s] + acc[0][s][0]);
+      gt.z[s] = fast_sigmoid(gz[s] + acc[1][s][0]);
+      gt.hn[s] = acc[2][s][0];
+      gt.n[s] = fast_tanh(gn[s] + gt.r[s] * gt.hn[s]);
+      const float hnew = gt.n[s] + gt.z[s] * (hreg[s] - gt.n[s]);
+      ho[s] = valid ? hnew : 0.f;
+      hreg[s] = valid ? hnew : hreg[s];
+    }
+    put2(hs[cur ^ 1], kq, u0, hreg[0], hreg[1]);
+    if (brow_ok) {
+      st2(out_b + (long)t * a.out_ld, ho[0], ho[1]);
+      if (sv_b) save_gates<BF16>(sv_b + t * sv_step, gt);
     }
     lds_barrier();
   }
@@ -276,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
 //   dn = dh(1-z); dz = dh(h_prev - n); dn' = dn(1-n^2); dz' = dz z(1-z); dr' = dn' hn r(1-r)
 //   dgx[t] = [dr', dz', dn']          (grad wrt x-side pre-activations, incl. b_ih)
 //   dgh[t] = [dr', dz', dn' r]        (grad wrt h-side pre-activations, incl. b_hh)
-//   carry  = dh z + dgh[t] . W_hh                            ([16,384].[384,128] on the matrix cores)
+//   carry  = dh z + dgh[t] . W_hh                            ([4,384].[384,128] on the matrix cores)
 // dW_ih, dW_hh, biases and the gradient to the layer input are plain GEMMs over the stored dgx/dgh (engine).
 // ------------------------------------------------------------------------------------------------
 template <bool BF16>
@@ -287,66 +268,57 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const int tile = blockIdx.x, dir = blockIdx.y, mod = blockIdx.z;
   const GruSeqBwd& q = a.seq[mod][dir];
   const int B = a.B, T = a.T, ntile = gridDim.x;
-  const int bcol = lane & 15, kq = lane >> 4;
-  const int b = tile * a.btv + bcol;
-  const bool brow_ok = bcol < a.btv && b < B;
+  const int n = lane & 15, kq = lane >> 4;
+  const int u0 = 32 * w + 2 * n;
+  const int b = tile * a.btv + kq;
+  const bool brow_ok = kq < a.btv && b < B;
   const int len = brow_ok ? a.lens[mod][b] : 0;
 
-  // A fragments of W_hh^T: rows = this wave's units (32w+16s+i), k = gate row index (0..383)
-  typename C::AFrag wr[2][C::KS_B];
+  // B fragments of W_hh (k = gate row 0..383, column = unit u0 + s)
+  typename C::Frag wr[2][C::KS_B];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int unit = 32 * w + 16 * s + (lane & 15);
 #pragma unroll
     for (int ks = 0; ks < C::KS_B; ++ks) {
       if constexpr (BF16) {
         bf16x8 f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = to_bf16(q.w_hh[(long)(ks * 32 + 8 * kq + j) * H + unit]);
+        for (int j = 0; j < 8; ++j) f[j] = to_bf16(q.w_hh[(long)(ks * 32 + 8 * kq + j) * H + u0 + s]);
         wr[s][ks] = f;
       } else {
-        wr[s][ks] = q.w_hh[(long)(ks * 4 + kq) * H + unit];
+        wr[s][ks] = q.w_hh[(long)(ks * 4 + kq) * H + u0 + s];
       }
     }
   }
 
-  float carry[2][4];
-  float sb[4][2][4];     // running bias-gradient sums of this lane's (unit, batch) slots: [dr', dz', dn', dn'*r]
+  float carry[2] = {0.f, 0.f};
+  float sb[4][2];     // running bias-gradient sums of this lane's (unit, batch) slots: [dr', dz', dn', dn'*r]
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      carry[s][r] = 0.f;
-      sb[0][s][r] = sb[1][s][r] = sb[2][s][r] = sb[3][s][r] = 0.f;
-    }
+  for (int g = 0; g < 4; ++g) sb[g][0] = sb[g][1] = 0.f;
 
-  const long rs_o = (long)T * a.out_ld;
-  const long rs_d = (long)T * a.dout_ld;
   const long bb = brow_ok ? b : 0;
-  const float* out_b = q.out + bb * rs_o + dir * H;        // forward outputs of THIS direction (h_prev source)
-  const float* dout_b = q.dout + bb * rs_d + a.dout_off * dir;
-  float* dg_b = q.dg + bb * (long)T * 4 * H;
-  float* hp_b = q.hprev + bb * (long)T * H;
+  const float* out_b = q.out + bb * T * a.out_ld + dir * H + u0;        // forward outputs of THIS direction (h_prev source)
+  const float* dout_b = q.dout + bb * T * a.dout_ld + a.dout_off * dir + u0;
+  float* dg_b = q.dg + bb * (long)T * 4 * H + u0;
+  float* hp_b = q.hprev + bb * (long)T * H + u0;
+  const float* sv_b = q.saved + sv_index<BF16>(0, ntile, tile, w, lane);
+  const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
 
-  // software pipeline: the six operand vectors of step+1 are requested before step's math (global latency ~1-2 us
+  // software pipeline: the operand vectors of step+1 are requested before step's math (global latency ~1-2 us
   // would otherwise sit on the critical path of every step)
-  struct Ops { float rr[4], zz[4], nn[4], hn[4]; float4 DO, HP; };
-  Ops nx[2];
-  auto fetch = [&](int step, Ops* o) {
+  struct Ops { Gates g; float2 DO, HP; };
+  Ops nx;
+  auto fetch = [&](int step, Ops& o) {
     const int t = dir ? step : T - 1 - step;
     const int tprev = dir ? t + 1 : t - 1;
-    const bool valid = t < len;
-    const bool hp_ok = valid && tprev >= 0 && tprev < len;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int unit = 32 * w + 16 * s + 4 * kq;
-      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-      // h_prev is the previous VALID output of this direction; with packed semantics that is simply out[tprev]
-      // when tprev is inside [0,len) and the zero initial state otherwise.
-      if (valid) load_gates<BF16>(q.saved, t, ntile, tile, w, s, lane, o[s].rr, o[s].zz, o[s].nn, o[s].hn);
-      o[s].DO = valid ? ld4(dout_b + (long)t * a.dout_ld + unit) : zero;
-      o[s].HP = hp_ok ? ld4(out_b + (long)tprev * a.out_ld + unit) : zero;
-    }
+    const int tc = tprev < 0 ? 0 : (tprev >= T ? T - 1 : tprev);
+    // every load is unconditional and in bounds (padding lanes / padded steps read row 0 / stale-but-initialised
+    // records and are masked in the math): a guarded load becomes a branch with an immediate vmcnt(0).
+    // h_prev is the previous VALID output of this direction; with packed semantics that is simply out[tprev]
+    // when tprev is inside [0,len) and the zero initial state otherwise (selected at use).
+    load_gates<BF16>(sv_b + t * sv_step, o.g);
+    o.DO = ld2(dout_b + (long)t * a.dout_ld);
+    o.HP = ld2(out_b + (long)tc * a.out_ld);
   };
   fetch(0, nx);
 
@@ -355,91 +327,79 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     const int t = dir ? step : T - 1 - step;
     const int cur = step & 1;
     const bool valid = t < len;
-    Ops op[2] = {nx[0], nx[1]};
-    if (step + 1 < T && !(a.dbg & 4)) fetch(step + 1, nx);
-    float dhz[2][4];
+    const Ops op = nx;
+    if (step + 1 < T) fetch(step + 1, nx);
+    float dhz[2];
+    float drp[2] = {0.f, 0.f}, dzp[2] = {0.f, 0.f}, dnp[2] = {0.f, 0.f}, dnr[2] = {0.f, 0.f};
+    const int tprev = dir ? t + 1 : t - 1;
+    const bool hp_ok = valid && tprev >= 0 && tprev < len;
+    const float hp[2] = {hp_ok ? op.HP.x : 0.f, hp_ok ? op.HP.y : 0.f};
+    if (valid) {
+      const float dd[2] = {op.DO.x, op.DO.y};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int unit = 32 * w + 16 * s + 4 * kq;
-      float drp[4] = {0.f, 0.f, 0.f, 0.f}, dzp[4] = {0.f, 0.f, 0.f, 0.f}, dnp[4] = {0.f, 0.f, 0.f, 0.f},
-            dnr[4] = {0.f, 0.f, 0.f, 0.f};
-      const float4 HP = op[s].HP;
-      if (valid) {
-        const float4 DO = op[s].DO;
-        const float* rr = op[s].rr; const float* zz = op[s].zz; const float* nn = op[s].nn; const float* hn = op[s].hn;
-        const float dd[4] = {DO.x, DO.y, DO.z, DO.w}, hp[4] = {HP.x, HP.y, HP.z, HP.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dh = dd[r] + carry[s][r];
-          const float dn = dh * (1.f - zz[r]);
-          const float dz = dh * (hp[r] - nn[r]);
-          dnp[r] = dn * (1.f - nn[r] * nn[r]);
-          dzp[r] = dz * zz[r] * (1.f - zz[r]);
-          drp[r] = dnp[r] * hn[r] * rr[r] * (1.f - rr[r]);
-          dnr[r] = dnp[r] * rr[r];
-          dhz[s][r] = dh * zz[r];
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dhz[s][r] = carry[s][r];
+      for (int e = 0; e < 2; ++e) {
+        const float rr = op.g.r[e], zz = op.g.z[e], nn = op.g.n[e], hn = op.g.hn[e];
+        const float dh = dd[e] + carry[e];
+        const float dn = dh * (1.f - zz);
+        const float dz = dh * (hp[e] - nn);
+        dnp[e] = dn * (1.f - nn * nn);
+        dzp[e] = dz * zz * (1.f - zz);
+        drp[e] = dnp[e] * hn * rr * (1.f - rr);
+        dnr[e] = dnp[e] * rr;
+        dhz[e] = dh * zz;
       }
-      put4(ds[cur], bcol, 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
-      put4(ds[cur], bcol, 1 * H + unit, dzp[0], dzp[1], dzp[2], dzp[3]);
-      put4(ds[cur], bcol, 2 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
+    } else {
+      dhz[0] = carry[0]; dhz[1] = carry[1];
+    }
+    put2(ds[cur], kq, 0 * H + u0, drp[0], drp[1]);
+    put2(ds[cur], kq, 1 * H + u0, dzp[0], dzp[1]);
+    put2(ds[cur], kq, 2 * H + u0, dnr[0], dnr[1]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { sb[0][s][r] += drp[r]; sb[1][s][r] += dzp[r]; sb[2][s][r] += dnp[r]; sb[3][s][r] += dnr[r]; }
-      if (brow_ok && !(a.dbg & 1)) {
-        st4(hp_b + (long)t * H + unit, HP.x, HP.y, HP.z, HP.w);
-        st4(dg_b + (long)t * 4 * H + 0 * H + unit, drp[0], drp[1], drp[2], drp[3]);
-        st4(dg_b + (long)t * 4 * H + 1 * H + unit, dzp[0], dzp[1], dzp[2], dzp[3]);
-        st4(dg_b + (long)t * 4 * H + 2 * H + unit, dnp[0], dnp[1], dnp[2], dnp[3]);
-        st4(dg_b + (long)t * 4 * H + 3 * H + unit, dnr[0], dnr[1], dnr[2], dnr[3]);
-      }
+    for (int e = 0; e < 2; ++e) { sb[0][e] += drp[e]; sb[1][e] += dzp[e]; sb[2][e] += dnp[e]; sb[3][e] += dnr[e]; }
+    if (brow_ok) {
+      st2(hp_b + (long)t * H, hp[0], hp[1]);
+      float* dgt = dg_b + (long)t * 4 * H;
+      st2(dgt + 0 * H, drp[0], drp[1]);
+      st2(dgt + 1 * H, dzp[0], dzp[1]);
+      st2(dgt + 2 * H, dnp[0], dnp[1]);
+      st2(dgt + 3 * H, dnr[0], dnr[1]);
     }
     lds_barrier();
     f32x4 acc[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 2))
+    for (int s = 0; s < 2; ++s) acc[s] = f32x4{dhz[s], 0.f, 0.f, 0.f};   // only register 0 is read
 #pragma unroll
     for (int ks = 0; ks < C::KS_B; ++ks) {
-      const auto bf = bfrag(ds[cur], ks, lane);
+      const auto sf = state_frag(ds[cur], ks, lane);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acc[s] = mfma16(wr[s][ks], bf, acc[s]);
+      for (int s = 0; s < 2; ++s) acc[s] = mfma16(sf, wr[s][ks], acc[s]);
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) carry[s][r] = dhz[s][r] + acc[s][r];
+    carry[0] = acc[0][0]; carry[1] = acc[1][0];
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
   }
-  // bias gradients: reduce over the 16 batch lanes of each lane group (lanes differing in bits 0..3), one atomic per unit
+  // bias gradients: reduce over the 4 batch rows (lanes differing in bits 4..5), one atomic per unit
   if (q.db_ih || q.db_hh) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int e = 0; e < 2; ++e) {
+        float v = sb[g][e];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        sb[g][e] = v;
+      }
+    if (kq == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = sb[g][s][r];
-          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-          sb[g][s][r] = v;
+      for (int e = 0; e < 2; ++e) {
+        const int unit = u0 + e;
+        if (q.db_ih) {
+          atomicAdd(&q.db_ih[0 * H + unit], sb[0][e]); atomicAdd(&q.db_ih[1 * H + unit], sb[1][e]);
+          atomicAdd(&q.db_ih[2 * H + unit], sb[2][e]);
         }
-    if (bcol == 0) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int unit = 32 * w + 16 * s + 4 * kq + r;
-          if (q.db_ih) {
-            atomicAdd(&q.db_ih[0 * H + unit], sb[0][s][r]); atomicAdd(&q.db_ih[1 * H + unit], sb[1][s][r]);
-            atomicAdd(&q.db_ih[2 * H + unit], sb[2][s][r]);
-          }
-          if (q.db_hh) {
-            atomicAdd(&q.db_hh[0 * H + unit], sb[0][s][r]); atomicAdd(&q.db_hh[1 * H + unit], sb[1][s][r]);
-            atomicAdd(&q.db_hh[2 * H + unit], sb[3][s][r]);
-          }
+        if (q.db_hh) {
+          atomicAdd(&q.db_hh[0 * H + unit], sb[0][e]); atomicAdd(&q.db_hh[1 * H + unit], sb[1][e]);
+          atomicAdd(&q.db_hh[2 * H + unit], sb[3][e]);
         }
+      }
     }
   }
 }
@@ -448,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_forward: empty batch");
-  if (a.btv < 1 || a.btv > BT) return set_error(MIMRL_ERR_ARG, "gru_forward: btv must be in [1,16]");
+  if (a.btv < 1 || a.btv > BR) return set_error(MIMRL_ERR_ARG, "gru_forward: btv must be in [1,4]");
   dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
   if (bf16) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, s, a);
@@ -458,7 +418,7 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
 
 int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_backward: empty batch");
-  if (a.btv < 1 || a.btv > BT) return set_error(MIMRL_ERR_ARG, "gru_backward: btv must be in [1,16]");
+  if (a.btv < 1 || a.btv > BR) return set_error(MIMRL_ERR_ARG, "gru_backward: btv must be in [1,4]");
   dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
   if (bf16) hipLaunchKernelGGL(gru_bwd_kernel<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gru_bwd_kernel<false>, grid, dim3(256), 0, s, a);
@@ -467,15 +427,15 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
 }
 
 long gru_saved_floats(int B, int T) {
-  return (long)T * B * 4 * 8 * 256;   // worst case: one batch row per workgroup (btv = 1)
+  return (long)T * B * 4 * 64 * 8;   // worst case: one batch row per workgroup (btv = 1)
 }
 
 int gru_pick_btv(int B, int nmod) {
   static const int force = getenv("MIMRL_GRU_BTV") ? atoi(getenv("MIMRL_GRU_BTV")) : 0;   // tuning knob
-  if (force >= 1 && force <= BT) return force;
+  if (force >= 1 && force <= BR) return force;
   int btv = (B * nmod * 2 + 127) / 128;      // ~128 workgroups (measured best at B=128: 4 rows per workgroup)
   if (btv < 1) btv = 1;
-  if (btv > BT) btv = BT;
+  if (btv > BR) btv = BR;
   return btv;
 }
 
