@@ -146,7 +146,7 @@ __device__ __forceinline__ void load_gates(const float* p, Gates& g) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+template <bool BF16, bool SAVE>
 __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   __shared__ __attribute__((aligned(16))) Tile<BF16, H> hs[2];
@@ -156,9 +156,11 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
   const int B = a.B, T = a.T, ntile = gridDim.x;
   const int n = lane & 15, kq = lane >> 4;
   const int u0 = 32 * w + 2 * n;
-  const int b = tile * a.btv + kq;
-  const bool brow_ok = kq < a.btv && b < B;
-  const int len = brow_ok ? a.lens[mod][b] : 0;
+  // padding lanes (kq >= btv, or rows past B) MIRROR the last real row of the tile instead of idling: they compute
+  // and store exactly the same values, so no load or store in the loop is guarded and the waitcnt bookkeeping of the
+  // software pipeline stays exact (a guarded access is a branch, and the wait after a branch merge is vmcnt(0))
+  const int b = min(tile * a.btv + min(kq, a.btv - 1), B - 1);
+  const int len = a.lens[mod][b];
 
   // ---- W_hh slice -> registers as MFMA B fragments: column n of N-tile (g, s) is gate row g*H + u0 + s
   typename C::Frag wr[3][2][C::KS_F];
@@ -193,26 +195,25 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
   put2(hs[0], kq, u0, 0.f, 0.f);
   __syncthreads();
 
-  const float* gx_b = q.gx + (long)(brow_ok ? b : 0) * T * G + u0;                       // gx [B,T,3H]
-  float* out_b = q.out + (long)(brow_ok ? b : 0) * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
-  float* sv_b = q.saved ? q.saved + sv_index<BF16>(0, ntile, tile, w, lane) : nullptr;
+  const float* gx_b = q.gx + (long)b * T * G + u0;                       // gx [B,T,3H]
+  float* out_b = q.out + (long)b * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
+  float* sv_b = SAVE ? q.saved + sv_index<BF16>(0, ntile, tile, w, lane) : nullptr;
   const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
 
-  float2 gxn[3];   // prefetched gx of the next step
-  auto load_gx = [&](int t) {
+  // software pipeline, distance 2: gx of step+2 is requested at the end of step (two named buffers, loop unrolled by
+  // two, so that no register copy has to wait for the youngest load); the tail re-reads the last step
+  auto load_gx = [&](float2 (&dst)[3], int step) {
+    const int sc = step < T ? step : T - 1;
+    const int t = dir ? T - 1 - sc : sc;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) gxn[g] = ld2(gx_b + (long)t * G + g * H);   // unconditional (padding lanes read row 0):
-                                                                            // a guarded load becomes a branch with an
-                                                                            // immediate vmcnt(0) -- the full memory
-                                                                            // latency on the critical path of every step
+    for (int g = 0; g < 3; ++g) dst[g] = ld2(gx_b + (long)t * G + g * H);
   };
-  load_gx(dir ? T - 1 : 0);
+  float2 gxA[3], gxB[3];
+  load_gx(gxA, 0);
+  load_gx(gxB, 1);
 
-  for (int step = 0; step < T; ++step) {
+  auto do_step = [&](const int step, const int cur, float2 (&gx)[3]) {
     const int t = dir ? T - 1 - step : step;
-    const int cur = step & 1;
-    const float2 gxc[3] = {gxn[0], gxn[1], gxn[2]};
-    if (step + 1 < T) load_gx(dir ? T - 2 - step : step + 1);
 
     f32x4 acc[3][2];
 #pragma unroll
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
     }
 
     const bool valid = t < len;
-    const float gr[2] = {gxc[0].x, gxc[0].y}, gz[2] = {gxc[1].x, gxc[1].y}, gn[2] = {gxc[2].x, gxc[2].y};
+    const float gr[2] = {gx[0].x, gx[0].y}, gz[2] = {gx[1].x, gx[1].y}, gn[2] = {gx[2].x, gx[2].y};
     Gates gt;
     float ho[2];
 #pragma unroll
@@ -243,12 +244,29 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
       hreg[s] = valid ? hnew : hreg[s];
     }
     put2(hs[cur ^ 1], kq, u0, hreg[0], hreg[1]);
-    if (brow_ok) {
-      st2(out_b + (long)t * a.out_ld, ho[0], ho[1]);
-      if (sv_b) save_gates<BF16>(sv_b + t * sv_step, gt);
-    }
+    st2(out_b + (long)t * a.out_ld, ho[0], ho[1]);
+    if constexpr (SAVE) save_gates<BF16>(sv_b + t * sv_step, gt);
     lds_barrier();
+    // refill this buffer only now, behind the barrier (a compiler fence): its old contents are dead, so the loop-carried
+    // value stays in the same registers.  Issued earlier, old and new values would be live together and the copy at the
+    // loop back-edge would wait for the youngest load -- the whole latency back on the critical path.
+    load_gx(gx, step + 2);
+    asm volatile("" ::: "memory");   // ... and do not let the scheduler sink the loads towards their use either
+  };
+  // the first pair is peeled: the waitcnt bookkeeping at the loop header merges the counts of all incoming edges
+  // conservatively, and the pre-loop path (two bare prefetches) would otherwise force near-zero counts -- i.e. waiting
+  // for the youngest prefetch -- on every iteration
+  int step = 0;
+  if (T >= 2) {
+    do_step(0, 0, gxA);
+    do_step(1, 1, gxB);
+    step = 2;
   }
+  for (; step + 1 < T; step += 2) {
+    do_step(step, 0, gxA);
+    do_step(step + 1, 1, gxB);
+  }
+  if (step < T) do_step(step, 0, gxA);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,9 +288,10 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const int B = a.B, T = a.T, ntile = gridDim.x;
   const int n = lane & 15, kq = lane >> 4;
   const int u0 = 32 * w + 2 * n;
-  const int b = tile * a.btv + kq;
-  const bool brow_ok = kq < a.btv && b < B;
-  const int len = brow_ok ? a.lens[mod][b] : 0;
+  // padding lanes mirror the last real row of the tile (see gru_fwd_kernel); only the bias sums must not count them
+  const bool own = kq < a.btv && tile * a.btv + kq < B;
+  const int b = min(tile * a.btv + min(kq, a.btv - 1), B - 1);
+  const int len = a.lens[mod][b];
 
   // B fragments of W_hh (k = gate row 0..383, column = unit u0 + s)
   typename C::Frag wr[2][C::KS_B];
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) sb[g][0] = sb[g][1] = 0.f;
 
-  const long bb = brow_ok ? b : 0;
+  const long bb = b;
   const float* out_b = q.out + bb * T * a.out_ld + dir * H + u0;        // forward outputs of THIS direction (h_prev source)
   const float* dout_b = q.dout + bb * T * a.dout_ld + a.dout_off * dir + u0;
   float* dg_b = q.dg + bb * (long)T * 4 * H + u0;
@@ -304,31 +323,29 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const float* sv_b = q.saved + sv_index<BF16>(0, ntile, tile, w, lane);
   const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
 
-  // software pipeline: the operand vectors of step+1 are requested before step's math (global latency ~1-2 us
-  // would otherwise sit on the critical path of every step)
+  // software pipeline, distance 2 (see gru_fwd_kernel): every load is unconditional and in bounds (padded steps read
+  // stale-but-initialised records and are masked in the math).  h_prev is the previous VALID output of this direction;
+  // with packed semantics that is simply out[tprev] when tprev is inside [0,len) and the zero initial state otherwise
+  // (selected at use).
   struct Ops { Gates g; float2 DO, HP; };
-  Ops nx;
-  auto fetch = [&](int step, Ops& o) {
-    const int t = dir ? step : T - 1 - step;
+  auto fetch = [&](Ops& o, int step) {
+    const int sc = step < T ? step : T - 1;
+    const int t = dir ? sc : T - 1 - sc;
     const int tprev = dir ? t + 1 : t - 1;
     const int tc = tprev < 0 ? 0 : (tprev >= T ? T - 1 : tprev);
-    // every load is unconditional and in bounds (padding lanes / padded steps read row 0 / stale-but-initialised
-    // records and are masked in the math): a guarded load becomes a branch with an immediate vmcnt(0).
-    // h_prev is the previous VALID output of this direction; with packed semantics that is simply out[tprev]
-    // when tprev is inside [0,len) and the zero initial state otherwise (selected at use).
     load_gates<BF16>(sv_b + t * sv_step, o.g);
     o.DO = ld2(dout_b + (long)t * a.dout_ld);
     o.HP = ld2(out_b + (long)tc * a.out_ld);
   };
-  fetch(0, nx);
+  Ops opA, opB;
+  fetch(opA, 0);
+  fetch(opB, 1);
 
-  for (int step = 0; step < T; ++step) {
+  auto do_step = [&](const int step, const int cur, Ops& nx) {
     // forward visited t in order (dir ? T-1..0 : 0..T-1); backward walks it the other way round
     const int t = dir ? step : T - 1 - step;
-    const int cur = step & 1;
     const bool valid = t < len;
-    const Ops op = nx;
-    if (step + 1 < T) fetch(step + 1, nx);
+    const Ops& op = nx;
     float dhz[2];
     float drp[2] = {0.f, 0.f}, dzp[2] = {0.f, 0.f}, dnp[2] = {0.f, 0.f}, dnr[2] = {0.f, 0.f};
     const int tprev = dir ? t + 1 : t - 1;
@@ -356,15 +373,15 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     put2(ds[cur], kq, 2 * H + u0, dnr[0], dnr[1]);
 #pragma unroll
     for (int e = 0; e < 2; ++e) { sb[0][e] += drp[e]; sb[1][e] += dzp[e]; sb[2][e] += dnp[e]; sb[3][e] += dnr[e]; }
-    if (brow_ok) {
-      st2(hp_b + (long)t * H, hp[0], hp[1]);
-      float* dgt = dg_b + (long)t * 4 * H;
-      st2(dgt + 0 * H, drp[0], drp[1]);
-      st2(dgt + 1 * H, dzp[0], dzp[1]);
-      st2(dgt + 2 * H, dnp[0], dnp[1]);
-      st2(dgt + 3 * H, dnr[0], dnr[1]);
-    }
+    st2(hp_b + (long)t * H, hp[0], hp[1]);
+    float* dgt = dg_b + (long)t * 4 * H;
+    st2(dgt + 0 * H, drp[0], drp[1]);
+    st2(dgt + 1 * H, dzp[0], dzp[1]);
+    st2(dgt + 2 * H, dnp[0], dnp[1]);
+    st2(dgt + 3 * H, dnr[0], dnr[1]);
     lds_barrier();
+    fetch(nx, step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
+    asm volatile("" ::: "memory");
     f32x4 acc[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) acc[s] = f32x4{dhz[s], 0.f, 0.f, 0.f};   // only register 0 is read
@@ -376,14 +393,25 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     }
     carry[0] = acc[0][0]; carry[1] = acc[1][0];
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
+  };
+  int step = 0;
+  if (T >= 2) {   // peeled first pair (see gru_fwd_kernel)
+    do_step(0, 0, opA);
+    do_step(1, 1, opB);
+    step = 2;
   }
+  for (; step + 1 < T; step += 2) {
+    do_step(step, 0, opA);
+    do_step(step + 1, 1, opB);
+  }
+  if (step < T) do_step(step, 0, opA);
   // bias gradients: reduce over the 4 batch rows (lanes differing in bits 4..5), one atomic per unit
   if (q.db_ih || q.db_hh) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        float v = sb[g][e];
+        float v = own ? sb[g][e] : 0.f;
         v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
         sb[g][e] = v;
       }
@@ -410,8 +438,17 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_forward: empty batch");
   if (a.btv < 1 || a.btv > BR) return set_error(MIMRL_ERR_ARG, "gru_forward: btv must be in [1,4]");
   dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
-  if (bf16) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, s, a);
+  bool save = a.seq[0][0].saved != nullptr;
+  for (int m = 0; m < a.nmod; ++m)
+    for (int d = 0; d < 2; ++d)
+      if ((a.seq[m][d].saved != nullptr) != save) return set_error(MIMRL_ERR_ARG, "gru_forward: saved slabs must be all set or all null");
+  if (bf16) {
+    if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gru_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (save) hipLaunchKernelGGL((gru_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gru_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+  }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
