@@ -327,8 +327,8 @@ struct mimrl_handle {
   struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst;
                     const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW(); };
   std::vector<Deferred> deferred;
-  int flush_deferred();
-  int model_forward(bool train, bool save, int knn_stage = 0);
+  int flush_deferred(int only_side = 0);
+  int model_forward(bool train, bool save, int knn_stage = 0, int part = 0);   // part: 0 all, 1 prefix, 2 tail
   int cube_forward(bool train, bool save);
   int cube_backward(int cur_in, int* cur_out);
   int model_backward();
@@ -762,17 +762,26 @@ int mimrl_handle::conv_forward(int knn_stage) {
   return MIMRL_OK;
 }
 
-int mimrl_handle::model_forward(bool train, bool save, int knn_stage) {
+// part 1 = the deterministic PREFIX (W_t projection, encoders: nothing random before their outputs tx_raw / h1), part 2 =
+// the TAIL from the first dropout on; 0 = both.  In prefetch mode the two forward passes of one two-stage step see the
+// same batch and the same main parameters, so their prefixes are the same function of the same inputs: it is evaluated
+// once (into the primary set) and both tails read it.
+int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) {
   const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const long BT_ = (long)B * T;
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
-  if (T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
-  MX(fork(0, 5));
-  // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
-  { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
-  MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
-  MX(encoders_forward(save, knn_stage));
-  MX(join(0, 0));
+  if (part != 1 && T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
+  if (part != 2) {
+    MX(fork(0, 5));
+    // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
+    { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
+    if (part == 0) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+    MX(encoders_forward(save, knn_stage));
+    MX(join(0, 0));
+    if (part == 1) return MIMRL_OK;
+  } else {
+    MX(text_post_fwd(stream, tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+  }
   // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
   {
     LnSide2 sd[2];
@@ -1209,18 +1218,22 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       release(i_dy);
       cur = i_dx;
     }
+    // tuning knob: hand this block's parameter-gradient work to ONE side stream right away (it then overlaps the rest of
+    // the data-gradient chain instead of queueing up beside the BPTT); 1 = last block only, 2 = every block
+    static const int early = getenv("MIMRL_EARLY_FLUSH") ? atoi(getenv("MIMRL_EARLY_FLUSH")) : 0;
+    if (defer && (early == 2 || (early == 1 && i == cfg.n_blocks - 1))) MX(flush_deferred(1));
   }
 #undef GRAB
   *cur_out = cur;
   return MIMRL_OK;
 }
 
-int mimrl_handle::flush_deferred() {
+int mimrl_handle::flush_deferred(int only_side) {
   if (deferred.empty()) return MIMRL_OK;
-  MX(fork(1, 3));
+  if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
   static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
   for (const Deferred& d : deferred) {
-    hipStream_t st = S(1 + (d.side - 1) % wg_sides);
+    hipStream_t st = only_side > 0 ? S(only_side) : S(1 + (d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
@@ -1737,14 +1750,48 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       return r;
     };
     hipEvent_t e_begin = nullptr;
+    static const bool no_share = getenv("MIMRL_NO_SHARED_PREFIX") != nullptr;   // tuning knob: evaluate the prefix twice
+    const bool share = prefetch && !no_share;
     if (prefetch) {
       MX(next_event(&e_begin));
       HIPX(hipEventRecord(e_begin, stream));
-      if (pre_first) MX(issue_prefetch(e_begin));
-      swap_fwd_set();
+      if (pre_first && !share) MX(issue_prefetch(e_begin));
+      if (!share) swap_fwd_set();
     }
     int r1;
-    if (prefetch) {
+    if (share) {
+      // (1) prefix, once, into the primary set, on the main stream (text projection on side 0, stage 1's kNN sampler on
+      //     side 4).  It has to be the capture's origin stream that forks the sides: a fork / join pair hanging off
+      //     another captured stream sends this HIP runtime's EndCapture into an endless recursion.
+      side_mask = 0x11u;
+      r1 = model_forward(true, true, 1, 1);
+      side_mask = ~0u;
+      MX(r1);
+      hipEvent_t e_prefix = nullptr;
+      MX(next_event(&e_prefix));
+      HIPX(hipEventRecord(e_prefix, stream));
+      // (2) stage 2's tail: one sequential branch behind the prefix on pre_stream, into the primary set
+      HIPX(hipStreamWaitEvent(pre_stream, e_prefix, 0));
+      {
+        StreamGuard g(this, pre_stream);
+        const bool ms = multi_stream;
+        multi_stream = false; rng_add = 1;     // begin_stage(2) has not run yet: use the dropout key it will produce
+        r1 = model_forward(true, true, 0, 2);
+        multi_stream = ms; rng_add = 0;
+      }
+      MX(r1);
+      // (3) stage 1's tail on the main stream, into the alternate set, reading the primary set's prefix
+      swap_fwd_set();
+      float* own_tx = tx_raw; float* own_h1[2] = {h1[0], h1[1]};
+      tx_raw = alt.tx_raw; h1[0] = alt.h1[0]; h1[1] = alt.h1[1];
+      {
+        const bool ms = multi_stream;
+        multi_stream = false;
+        r1 = model_forward(true, false, 0, 2);
+        multi_stream = ms;
+      }
+      tx_raw = own_tx; h1[0] = own_h1[0]; h1[1] = own_h1[1];
+    } else if (prefetch) {
       // two forward passes now run side by side; with only 4 hardware queues, more branches would just be serialised
       // behind one another (measured: with 5+ concurrent branches the step falls back to the sequential time, and the
       // prefetch chain as a separate graph on its own HIP stream is slower too), so stage 1's own forward pass keeps
@@ -1763,7 +1810,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (r1 == 0) r1 = estimators_all(1, true, true);
     if (prefetch) swap_fwd_set();
     MX(r1);
-    if (prefetch && !pre_first) MX(issue_prefetch(e_begin));
+    if (prefetch && !share && !pre_first) MX(issue_prefetch(e_begin));
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
     if (prefetch) {   // rejoin before the stage ends (a captured graph must not leave a dangling branch)
