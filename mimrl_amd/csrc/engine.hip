@@ -328,6 +328,7 @@ struct mimrl_handle {
                     const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW(); };
   std::vector<Deferred> deferred;
   int flush_deferred(int only_side = 0);
+  int dbg_delay(hipStream_t st, int tag);   // critical-path probe (MIMRL_DBG_DELAY_TAG / _US): a spin kernel behind one phase
   int model_forward(bool train, bool save, int knn_stage = 0, int part = 0);   // part: 0 all, 1 prefix, 2 tail
   int cube_forward(bool train, bool save);
   int cube_backward(int cur_in, int* cur_out);
@@ -670,8 +671,10 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
     if (l == 0 && knn_stage) {   // the kNN sampler needs only banks + anchors: overlap it with the recurrence (32 of 256 CUs busy)
       MX(fork(4, 4));
       MX(knn_launch(knn_stage, S(4)));
+      MX(dbg_delay(S(4), 11));
     }
     { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
+    MX(dbg_delay(stream, 1));
   }
   return MIMRL_OK;
 }
@@ -775,6 +778,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     MX(fork(0, 5));
     // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
     { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
+    MX(dbg_delay(S(0), 10));
     if (part == 0) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
     MX(encoders_forward(save, knn_stage));
     MX(join(0, 0));
@@ -793,6 +797,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   // T_F, A_F, V_F (Model.py:466)
   MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
   { Scope sc(this, MIMRL_PH_CUBE_FWD); MX(cube_forward(train, save)); }
+  MX(dbg_delay(stream, save ? 2 : 13));
   // head (Model.py:489-515)
   const BlockBuf& last = bb[cfg.n_blocks - 1];
   const int ol = cfg.d_outs[cfg.n_blocks - 1][0], ok = cfg.d_outs[cfg.n_blocks - 1][1], od = cfg.d_outs[cfg.n_blocks - 1][2];
@@ -1228,9 +1233,26 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   return MIMRL_OK;
 }
 
+// Critical-path probe: with MIMRL_DBG_DELAY_TAG=<n> a single-wave kernel that spins MIMRL_DBG_DELAY_US (default 50)
+// microseconds is enqueued behind phase <n> on that phase's stream.  Step-time increase / injected time = how much of
+// that phase sits on the critical path of the captured graph (tools/critical_path.sh); costs nothing when unset.
+__global__ void dbg_spin_kernel(long ticks) {
+  const long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+int mimrl_handle::dbg_delay(hipStream_t st, int tag) {
+  static const int want = getenv("MIMRL_DBG_DELAY_TAG") ? atoi(getenv("MIMRL_DBG_DELAY_TAG")) : -1;
+  static const int us = getenv("MIMRL_DBG_DELAY_US") ? atoi(getenv("MIMRL_DBG_DELAY_US")) : 50;
+  if (tag != want) return MIMRL_OK;
+  hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, st, (long)us * 100);   // wall_clock64 ticks at 100 MHz
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
 int mimrl_handle::flush_deferred(int only_side) {
   if (deferred.empty()) return MIMRL_OK;
   if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
+  for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
   static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
   for (const Deferred& d : deferred) {
     hipStream_t st = only_side > 0 ? S(only_side) : S(1 + (d.side - 1) % wg_sides);
@@ -1259,6 +1281,7 @@ int mimrl_handle::model_backward() {
   int ci = 0;
   deferred.clear();
   { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
+  MX(dbg_delay(stream, 7));
   float* dcube = gbuf[ci];
   // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T
   MX(feat_mean_bwd(stream, dfeat + (size_t)B * D, dcube, B, T, L, 3, D));
@@ -1300,6 +1323,7 @@ int mimrl_handle::model_backward() {
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
+    MX(dbg_delay(stream, 8));
     MX(fork(1, l == 0 ? 5 : 3));   // the weight gradients below depend on the BPTT only
     if (l == 1) {   // critical path, so first in capture order: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
       // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
@@ -1707,12 +1731,14 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     StreamGuard g(this, S(5));
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
-    if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(chain(5, 3)); MX(cmi_backward(stage)); }
+    MX(dbg_delay(stream, stage == 1 ? 4 : 14));
+    if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
   }
   bf16 = bf_fwd;
   if (!(dbg_skip & 2)) {
   { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
-  if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(join(3, 3)); Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); }
+  MX(dbg_delay(stream, stage == 1 ? 3 : 15));
+  if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(join(3, 3)); Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 5 : 17)); }
   }
   bf16 = bf_fwd;
   if (!multi_stream) return MIMRL_OK;
@@ -1777,6 +1803,9 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
         const bool ms = multi_stream;
         multi_stream = false; rng_add = 1;     // begin_stage(2) has not run yet: use the dropout key it will produce
         r1 = model_forward(true, true, 0, 2);
+        // stage 2's kNN sampler rides behind its forward tail (this branch has slack: stage 1 still runs its estimators),
+        // so stage 2 starts straight at its estimators (anchor key = the step counter begin_stage(2) will set)
+        if (r1 == 0 && knn_pre) r1 = knn_launch(2, stream);
         multi_stream = ms; rng_add = 0;
       }
       MX(r1);
@@ -1826,7 +1855,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   if (!skip_zero) HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   if (prefetch && have_banks) {   // forward pass (and kNN sampling) already done beside stage 1
-    if (!knn_pre) { MX(fork(4, 4)); MX(knn_launch(2, S(4))); }
+    if (!knn_pre) { MX(fork(4, 4)); MX(knn_launch(2, S(4))); MX(dbg_delay(S(4), 18)); }
   } else {
     MX(model_forward(true, true, have_banks ? 2 : 0));
   }
@@ -1860,7 +1889,8 @@ int mimrl_handle::enqueue_apply(int stage) {
   }
   a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
   Scope sc(this, MIMRL_PH_OPT);
-  return adam_step(stream, a);
+  MX(adam_step(stream, a));
+  return dbg_delay(stream, 12);
 }
 
 // kind 0: grads + apply (single-GPU step); kind 1: grads only; kind 2: apply only (never captured: one kernel)

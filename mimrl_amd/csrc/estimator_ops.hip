@@ -30,7 +30,7 @@ __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + lo
 // may live in LDS (generic pointers): the fused separable-critic kernel below runs this body on its on-chip score tile.
 // lb / dlb (optional, tuba and interpolate only): log-baseline log a(y_i) per row (VMI.py:72-110) and the gradient of the
 // objective with respect to it.  With a baseline, S is modified in place for tuba (S_ij -= lb_i).
-__device__ void mi_bound_body(float* S, float* dS, float* __restrict__ mi, float* __restrict__ mil, float gs, int e, int B,
+__device__ __forceinline__ void mi_bound_body(float* S, float* dS, float* __restrict__ mi, float* __restrict__ mil, float gs, int e, int B,
                               int bound, unsigned lossform, float* red, float* rowstat, const float* __restrict__ lb,
                               float* __restrict__ dlb) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
                                                             float* __restrict__ mi, float* __restrict__ mil,
                                                             const float* __restrict__ gscale, int B, int bound,
                                                             unsigned lossform, int do_bwd, const float* __restrict__ lb,
-                                                            float* __restrict__ dlb, long lb_stride) {
-  extern __shared__ float S[];      // [B][B], then the transposed bf16 images XT / YT [128][B + 8] for the gradient products
+                                                            float* __restrict__ dlb, long lb_stride, int dbg) {
+  extern __shared__ float S[];      // [B][B] scores / their gradient, then the bf16 transpose of the gradient
   __shared__ float red[16];
   __shared__ float rowstat[6 * 128];
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
@@ -251,20 +251,6 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
     p[4] = to_bf16(b.x); p[5] = to_bf16(b.y); p[6] = to_bf16(b.z); p[7] = to_bf16(b.w);
     return p;
   };
-  const int TP = B + 8;             // row pitch of the transposed images (bf16)
-  __bf16* XT = reinterpret_cast<__bf16*>(S + B * B);
-  __bf16* YT = XT + 128 * TP;
-  if (do_bwd) {   // XT[n][j] = g(x)[j][n], YT[n][i] = h(y)[i][n]: the B operands of d h = dS g and d g = dS^T h as 16-byte rows
-    for (int idx = tid; idx < B * 32; idx += 1024) {
-      const int j = idx >> 5, n4 = (idx & 31) * 4;
-      const float4 vx = *reinterpret_cast<const float4*>(X + (long)j * 128 + n4);
-      const float4 vy = *reinterpret_cast<const float4*>(Y + (long)j * 128 + n4);
-      XT[(n4 + 0) * TP + j] = to_bf16(vx.x); XT[(n4 + 1) * TP + j] = to_bf16(vx.y);
-      XT[(n4 + 2) * TP + j] = to_bf16(vx.z); XT[(n4 + 3) * TP + j] = to_bf16(vx.w);
-      YT[(n4 + 0) * TP + j] = to_bf16(vy.x); YT[(n4 + 1) * TP + j] = to_bf16(vy.y);
-      YT[(n4 + 2) * TP + j] = to_bf16(vy.z); YT[(n4 + 3) * TP + j] = to_bf16(vy.w);
-    }
-  }
   if (wave < nt * nt) {
     const int ti = wave / nt, tj = wave % nt;
     f32x16 acc;
@@ -277,9 +263,20 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) S[(ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * B + tj * 32 + lr] = acc[r];
   }
   __syncthreads();
+  if (dbg == 1) return;
   mi_bound_body(S, do_bwd ? S : nullptr, mi, mil, gscale ? gscale[e] : 0.f, e, B, bound, lossform, red, rowstat,
                 lb ? lb + e * lb_stride : nullptr, (do_bwd && dlb) ? dlb + e * lb_stride : nullptr);
-  if (!do_bwd) return;
+  if (!do_bwd || dbg == 2) return;
+  __syncthreads();
+  // The A fragment of d h = dS g wants, per lane, 8 consecutive j of ITS row i: with the rows 128 words apart all 32 lanes
+  // hit one LDS bank (32-way conflict on every read, and 16 waves share the LDS).  A transposed bf16 copy dST[j][i]
+  // (pitch B + 2: conflict-free to write and to read) turns them into the same lane-contiguous reads as d g = dS^T h.
+  __bf16* dST = reinterpret_cast<__bf16*>(S + B * B);
+  const int SP = B + 2;
+  for (int idx = tid; idx < B * B; idx += 1024) {
+    const int i = idx / B, j = idx - i * B;
+    dST[j * SP + i] = to_bf16(S[idx]);
+  }
   __syncthreads();
   // d h[i][n] = sum_j dS[i][j] g[j][n]   and   d g[j][n] = sum_i dS[i][j] h[i][n]:  nt x 4 tiles each, wave -> (row tile, n tile)
   if (wave < nt * 4) {
@@ -287,17 +284,18 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
     f32x16 ah, ag;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ah[r] = 0.f; ag[r] = 0.f; }
-    for (int ks = 0; ks < B / 16; ++ks) {
-      const int k0 = ks * 16 + 8 * lh;
-      bf16x8 a1, a2;
-      const float4 s0 = *reinterpret_cast<const float4*>(&S[(tr * 32 + lr) * B + k0]);        // dS[i][j..]
-      const float4 s1 = *reinterpret_cast<const float4*>(&S[(tr * 32 + lr) * B + k0 + 4]);
-      a1[0] = to_bf16(s0.x); a1[1] = to_bf16(s0.y); a1[2] = to_bf16(s0.z); a1[3] = to_bf16(s0.w);
-      a1[4] = to_bf16(s1.x); a1[5] = to_bf16(s1.y); a1[6] = to_bf16(s1.z); a1[7] = to_bf16(s1.w);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) a2[q] = to_bf16(S[(k0 + q) * B + tr * 32 + lr]);             // dS[i..][j]
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&XT[(tn * 32 + lr) * TP + k0]);
-      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&YT[(tn * 32 + lr) * TP + k0]);
+    for (int ks = 0; ks < 8; ++ks) {         // B <= 128; fully unrolled so that all operand loads are in flight together
+      if (ks * 16 >= B) break;
+      const int k0 = ks * 16 + 8 * lh;
+      bf16x8 a1, a2, b1, b2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        a1[q] = dST[(k0 + q) * SP + tr * 32 + lr];                // dS[i][j..]
+        a2[q] = to_bf16(S[(k0 + q) * B + tr * 32 + lr]);          // dS[i..][j]
+        b1[q] = to_bf16(X[(long)(k0 + q) * 128 + tn * 32 + lr]);
+        b2[q] = to_bf16(Y[(long)(k0 + q) * 128 + tn * 32 + lr]);
+      }
       ah = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, ah, 0, 0, 0);
       ag = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, ag, 0, 0, 0);
     }
@@ -595,11 +593,11 @@ int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, floa
   static bool attr = false;
   if (!attr) {
     HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(mi_sep_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             65536 + 2 * 128 * (128 + 8) * 2));
+                             65536 + 128 * 130 * 2));
     attr = true;
   }
-  hipLaunchKernelGGL(mi_sep_fused_kernel, dim3(E), dim3(1024), (size_t)B * B * sizeof(float) + (size_t)2 * 128 * (B + 8) * 2, s, tout, dtout, mi, mil, gscale, B,
-                     bound, lossform, do_bwd, lb, dlb, lb_stride);
+  hipLaunchKernelGGL(mi_sep_fused_kernel, dim3(E), dim3(1024), (size_t)B * B * sizeof(float) + (size_t)B * (B + 2) * 2, s, tout, dtout, mi, mil, gscale, B,
+                     bound, lossform, do_bwd, lb, dlb, lb_stride, getenv("MIMRL_DBG_MI") ? atoi(getenv("MIMRL_DBG_MI")) : 0);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -1,0 +1,15 @@
+#!/bin/bash
+# average duration of kernels matching $1 under the given env knobs: tools/kstat.sh <pattern> "ENV=.." ...
+pat=$1; shift
+for ks in "$@"; do
+  rm -rf /tmp/ks_prof
+  (cd /tmp && TMPDIR=/tmp env $ks rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_prof -- python3 /root/repo/bench.py --steps 30 --warmup 5 --profile-steps 0 --no-cpu-baseline > /tmp/ks.log 2>&1)
+  f=$(find /tmp/ks_prof -name "*kernel_stats.csv" | head -1)
+  echo "[$ks]"
+  python3 - "$f" "$pat" <<'PY'
+import csv, re, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if re.search(sys.argv[2], r["Name"]):
+        print("   %-50s calls %5s avg_us %7.1f" % (r["Name"].split("(")[0][-50:], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+done
