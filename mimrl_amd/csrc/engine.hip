@@ -328,6 +328,7 @@ struct mimrl_handle {
                     const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW(); };
   std::vector<Deferred> deferred;
   int flush_deferred(int only_side = 0);
+  int wg_helper = -1;                  // side stream that takes every second weight-gradient GEMM of an MLP stack (-1: none)
   int dbg_delay(hipStream_t st, int tag);   // critical-path probe (MIMRL_DBG_DELAY_TAG / _US): a spin kernel behind one phase
   int model_forward(bool train, bool save, int knn_stage = 0, int part = 0);   // part: 0 all, 1 prefix, 2 tail
   int cube_forward(bool train, bool save);
@@ -1431,12 +1432,13 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
                                      float* din, bool wgrad) {
   float* dz = dout;
   int pp = 0;
-  if (wgrad)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
-    MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
   // the fused data-gradient chain runs on the transposed bf16 images (the same coalesced loop as the forward pass)
   static const bool fused_bwd = getenv("MIMRL_NO_FUSED_MLP_BWD") == nullptr;
   // (stacks with thousands of row tiles -- the concat critic -- keep the GEMM chain here: measured faster than the fused one)
-  if (bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims)) {
+  const bool use_fused = bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims);
+  if (wgrad && !use_fused)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
+    MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
+  if (use_fused) {
     // the whole data-gradient chain in one launch (dtmp must hold nl-1 buffers here); weight gradients follow as GEMMs
     MlpFusedArgs fa;
     std::memset(&fa, 0, sizeof fa);
@@ -1449,6 +1451,13 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     }
     MX(mlp_stack_bwd_fused(stream, fa));
     if (!wgrad) return MIMRL_OK;
+    // the nl weight-gradient GEMMs are independent of each other: on the critical branch (wg_helper >= 0) every second
+    // one goes to a helper side stream
+    static const bool no_split = getenv("MIMRL_NO_WG_SPLIT") != nullptr;   // tuning knob
+    const int hs = (multi_stream && !no_split) ? wg_helper : -1;
+    if (hs >= 0) MX(fork(hs, hs));
+    // bias gradient of the top layer: behind the chain (it only reads dout), on the helper stream when there is one
+    MX(colsum(hs >= 0 ? S(hs) : stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
     for (int l = nl - 1; l >= 0; --l) {   // dW_l = dZ_l^T A_l
       const int din_ = dims[l], dout_ = dims[l + 1];
       GemmDesc g;
@@ -1456,8 +1465,9 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
       g.B = l == 0 ? in : act[l - 1]; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
       g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
       g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
-      MX(G_(g));
+      MX(G_on((hs >= 0 && ((nl - 1 - l) & 1)) ? S(hs) : stream, g));
     }
+    if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;
   }
   for (int l = nl - 1; l >= 0; --l) {
@@ -1738,7 +1748,16 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   if (!(dbg_skip & 2)) {
   { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
   MX(dbg_delay(stream, stage == 1 ? 3 : 15));
-  if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(join(3, 3)); Scope sc(this, MIMRL_PH_EST_BWD); MX(mi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 5 : 17)); }
+  if (backward) {
+    bf16 = bf_bwd;
+    if (imgT_ready) MX(join(3, 3));
+    Scope sc(this, MIMRL_PH_EST_BWD);
+    wg_helper = stage == 1 ? 1 : -1;     // the MI branch is the critical one of stage 1 (tools/critical_path.sh)
+    const int r = mi_backward(stage);
+    wg_helper = -1;
+    MX(r);
+    MX(dbg_delay(stream, stage == 1 ? 5 : 17));
+  }
   }
   bf16 = bf_fwd;
   if (!multi_stream) return MIMRL_OK;
@@ -1793,6 +1812,12 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       r1 = model_forward(true, true, 1, 1);
       side_mask = ~0u;
       MX(r1);
+      if (knn_pre) {                     // stage 2's kNN sampler rides on side 4 behind stage 1's, both beside the prefix (the
+        rng_add = 1;                     // recurrence leaves half the CUs idle); anchor key = the step counter begin_stage(2) will set
+        r1 = knn_launch(2, S(4));
+        rng_add = 0;
+        MX(r1);
+      }
       hipEvent_t e_prefix = nullptr;
       MX(next_event(&e_prefix));
       HIPX(hipEventRecord(e_prefix, stream));
@@ -1803,9 +1828,6 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
         const bool ms = multi_stream;
         multi_stream = false; rng_add = 1;     // begin_stage(2) has not run yet: use the dropout key it will produce
         r1 = model_forward(true, true, 0, 2);
-        // stage 2's kNN sampler rides behind its forward tail (this branch has slack: stage 1 still runs its estimators),
-        // so stage 2 starts straight at its estimators (anchor key = the step counter begin_stage(2) will set)
-        if (r1 == 0 && knn_pre) r1 = knn_launch(2, stream);
         multi_stream = ms; rng_add = 0;
       }
       MX(r1);
