@@ -210,23 +210,28 @@ def main():
         phases = {k: {"ms_per_step": v[0] / args.profile_steps, "launch_groups_per_step": v[1] / args.profile_steps}
                   for k, v in pr.items() if v[1]}
         phases["eager_total_ms_per_step"] = eager_ms
-        # dominant single kernel: the persistent bi-GRU recurrence (one launch per layer; 4 forward launches per step, 2 of
-        # them also save the gates for BPTT).  Which roofline binds it?  Per launch it moves 66 MB (>= 8 us at 8 TB/s) and
-        # does 2.5 GFLOP (1 us at the bf16 MFMA peak): HBM is the nearer ceiling, so that is the one reported; the MFMA
-        # figures ride along as extra keys.  What actually limits it is the serial dependence of T cell steps.
+        # dominant single kernel: the persistent bi-GRU recurrence (one launch per layer).  With the shared encoder prefix
+        # (default: both forward passes of a two-stage step read ONE evaluation of the encoders) that is 2 forward
+        # launches per step, both saving the gates for BPTT; without it 4, of which 2 save.  Which roofline binds it?
+        # Per launch it moves ~79 MB (>= 10 us at 8 TB/s) and does 2.5 GFLOP (1 us at the bf16 MFMA peak): HBM is the
+        # nearer ceiling, so that is the one reported; the MFMA figures ride along as extra keys.  What actually limits
+        # it is the serial dependence of T cell steps.
+        shared_prefix = (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX")
+        save_frac = 1.0 if shared_prefix else 0.5
         gru_bf16 = bool(_lib.PREC[args.precision] & 4)
         fl = 2 * 2 * B * T * (H * 3 * H) * 2.0          # 2 modalities x 2 directions, [B,T] x (128 x 384) MACs
         gate_bytes = 2 if gru_bf16 else 4
         alg_bytes = (4 * B * T * 3 * H * 4             # gx[B,T,384] fp32 per (modality, direction): read
                      + 4 * (3 * H * H + 3 * H) * 4     # W_hh, b_hh
                      + 2 * B * T * 2 * H * 4           # h[B,T,256] per modality: written
-                     + 0.5 * 4 * B * T * 4 * H * gate_bytes)   # saved gates (r,z,n,hn), on the 2 of 4 launches that train
+                     + save_frac * 4 * B * T * 4 * H * gate_bytes)   # saved gates (r,z,n,hn) on the launches that train
         avg_ms = pr["gru_fwd"][0] / max(pr["gru_fwd"][1], 1)
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes (separate runs), committed
         if os.path.exists(pmc) and args.workload == "cfg2" and args.precision == "bf16":
-            k = json.load(open(pmc))["kernels"].get("gru_fwd_kernel<true>")
+            ks = json.load(open(pmc))["kernels"]
+            k = ks.get("gru_fwd_kernel<true, true>") or ks.get("gru_fwd_kernel<true>")
             traffic = k and k["traffic_bytes_per_launch"]
         roof = {"bound": "hbm", "kernel": "gru_fwd_kernel (persistent bi-GRU recurrence, one launch per layer)",
                 "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
@@ -255,7 +260,8 @@ def main():
                        "unit_definition": "one iter = stage-1 + stage-2 update over one B=128 batch; under weak-scaling DP every "
                                           "global step processes n_gpus such batches (gradients all-reduced), so value = n_gpus*steps/time",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch, "samples_per_sec": B * world * args.steps / wall},
+                       "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch,
+                       "shared_encoder_prefix": (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX"), "samples_per_sec": B * world * args.steps / wall},
             "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,
             "achieved_tflops_whole_step": world * algorithmic_flops(opt, N) / (wall / args.steps) / 1e12,
             "roofline": roof, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,

@@ -356,8 +356,8 @@ __global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact kNN among non-anchor rows; one workgroup per (anchor, call).  Thread-per-row distance evaluation with the
-// anchor vector in LDS and 16-byte row loads; per-thread sorted top-K (K compile-time), merged through LDS.
+// exact kNN among non-anchor rows; one workgroup per (tile of anchors, call).  Thread-per-row distance evaluation with
+// the anchor vectors in LDS and 16-byte row loads; per-thread sorted top-K (K compile-time), merged through LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_KMAX = 8;
 
@@ -381,64 +381,88 @@ struct TopK {
   }
 };
 
-template <int K>
+// AT anchors of one call per workgroup: every bank row a thread loads is used for AT distances (the row loads, one
+// scattered 16-byte piece per lane, are what the kernel costs), each pair summed in exactly the order of the
+// single-anchor form -- the selected indices do not depend on AT.
+template <int K, int AT>
 __global__ __launch_bounds__(256) void knn_kernel(KnnArgs a) {
-  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask | [256] anchor vector | candidate lists
-  const int ai = blockIdx.x, c = blockIdx.y;
+  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask | [AT][256] anchor vectors | candidate lists
+  const int a0 = blockIdx.x * AT, c = blockIdx.y;
   const int tid = threadIdx.x;
   const int nwords = (a.N + 31) / 32;
   unsigned* mask = smem;
   float* av = reinterpret_cast<float*>(smem + ((nwords + 3) & ~3));
-  float* cd = av + 256;
-  int* ci = reinterpret_cast<int*>(cd + 256 * K);
+  float* cd = av + AT * 256;
+  int* ci = reinterpret_cast<int*>(cd + AT * 256 * K);
   for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
   __syncthreads();
   const int* anc = a.anchors + (long)c * a.m;
   for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
   const float* __restrict__ Z = a.call[c].Z;
   const int dz = a.call[c].dz;
-  const int me = anc[ai];
-  if (tid < dz) av[tid] = Z[(long)me * dz + tid];
+#pragma unroll
+  for (int t = 0; t < AT; ++t) {
+    const int me = anc[min(a0 + t, a.m - 1)];  // a ragged last tile repeats its last anchor (never stored)
+    if (tid < dz) av[t * 256 + tid] = Z[(long)me * dz + tid];
+  }
   __syncthreads();
-  TopK<K> tk; tk.init();
+  TopK<K> tk[AT];
+#pragma unroll
+  for (int t = 0; t < AT; ++t) tk[t].init();
   if (dz == 1) {
-    const float z0 = av[0];
     for (int r = tid; r < a.N; r += 256) {
       if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
-      const float df = Z[r] - z0;
-      tk.push(df * df, r);
+      const float zr = Z[r];
+#pragma unroll
+      for (int t = 0; t < AT; ++t) {
+        const float df = zr - av[t * 256];
+        tk[t].push(df * df, r);
+      }
     }
   } else {
     for (int r = tid; r < a.N; r += 256) {
       if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
       const float4* row = reinterpret_cast<const float4*>(Z + (long)r * dz);
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      float s[AT][4];
+#pragma unroll
+      for (int t = 0; t < AT; ++t) s[t][0] = s[t][1] = s[t][2] = s[t][3] = 0.f;
       for (int j = 0; j < dz / 4; ++j) {
         const float4 q = row[j];
-        const float4 w = *reinterpret_cast<const float4*>(av + 4 * j);
-        const float d0 = q.x - w.x, d1 = q.y - w.y, d2 = q.z - w.z, d3 = q.w - w.w;
-        s0 += d0 * d0; s1 += d1 * d1; s2 += d2 * d2; s3 += d3 * d3;
+#pragma unroll
+        for (int t = 0; t < AT; ++t) {
+          const float4 w = *reinterpret_cast<const float4*>(av + t * 256 + 4 * j);
+          const float d0 = q.x - w.x, d1 = q.y - w.y, d2 = q.z - w.z, d3 = q.w - w.w;
+          s[t][0] += d0 * d0; s[t][1] += d1 * d1; s[t][2] += d2 * d2; s[t][3] += d3 * d3;
+        }
       }
-      tk.push((s0 + s1) + (s2 + s3), r);
+#pragma unroll
+      for (int t = 0; t < AT; ++t) tk[t].push((s[t][0] + s[t][1]) + (s[t][2] + s[t][3]), r);
     }
   }
 #pragma unroll
-  for (int q = 0; q < K; ++q) { cd[tid * K + q] = tk.d[q]; ci[tid * K + q] = tk.i[q]; }
+  for (int t = 0; t < AT; ++t)
+#pragma unroll
+    for (int q = 0; q < K; ++q) { cd[(t * 256 + tid) * K + q] = tk[t].d[q]; ci[(t * 256 + tid) * K + q] = tk[t].i[q]; }
   __syncthreads();
-  // tree merge of the 256 sorted lists: 8 rounds, list t absorbs list t+stride
+  // tree merge of the 256 sorted lists of every anchor: 8 rounds, list t absorbs list t+stride
   for (int stride = 128; stride > 0; stride >>= 1) {
     if (tid < stride) {
 #pragma unroll
-      for (int q = 0; q < K; ++q) tk.push(cd[(tid + stride) * K + q], ci[(tid + stride) * K + q]);
+      for (int t = 0; t < AT; ++t) {
 #pragma unroll
-      for (int q = 0; q < K; ++q) { cd[tid * K + q] = tk.d[q]; ci[tid * K + q] = tk.i[q]; }
+        for (int q = 0; q < K; ++q) tk[t].push(cd[(t * 256 + tid + stride) * K + q], ci[(t * 256 + tid + stride) * K + q]);
+#pragma unroll
+        for (int q = 0; q < K; ++q) { cd[(t * 256 + tid) * K + q] = tk[t].d[q]; ci[(t * 256 + tid) * K + q] = tk[t].i[q]; }
+      }
     }
     __syncthreads();
   }
   if (tid == 0) {
 #pragma unroll
-    for (int q = 0; q < K; ++q)
-      if (q < a.k) a.idx_x[((long)c * a.m + ai) * a.k + q] = tk.i[q];
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+        if (q < a.k && a0 + t < a.m) a.idx_x[((long)c * a.m + a0 + t) * a.k + q] = tk[t].i[q];
   }
 }
 
@@ -636,11 +660,14 @@ int knn_sample(hipStream_t s, const KnnArgs& a) {
     if (a.call[c].dz != 1 && (a.call[c].dz > 256 || a.call[c].dz % 4 != 0))
       return set_error(MIMRL_ERR_ARG, "knn: feature width must be 1 or a multiple of 4 up to 256");
   const int K = a.k <= 2 ? 2 : (a.k <= 4 ? 4 : 8);
-  const size_t sh = (((a.N + 31) / 32 + 3) & ~3) * sizeof(unsigned) + 256 * sizeof(float) +
-                    256 * (size_t)K * (sizeof(float) + sizeof(int));
-  if (K == 2) hipLaunchKernelGGL(knn_kernel<2>, dim3(a.m, a.ncall), dim3(256), sh, s, a);
-  else if (K == 4) hipLaunchKernelGGL(knn_kernel<4>, dim3(a.m, a.ncall), dim3(256), sh, s, a);
-  else hipLaunchKernelGGL(knn_kernel<8>, dim3(a.m, a.ncall), dim3(256), sh, s, a);
+  constexpr int AT = 4;   // anchors per workgroup (m = 128, 6 calls: 192 workgroups)
+  const size_t sh = (((a.N + 31) / 32 + 3) & ~3) * sizeof(unsigned) + AT * 256 * sizeof(float) +
+                    AT * 256 * (size_t)K * (sizeof(float) + sizeof(int));
+  const dim3 grid((a.m + AT - 1) / AT, a.ncall);
+  if (sh > 64 * 1024) return set_error(MIMRL_ERR_ARG, "knn: bank too large for the LDS bitmask (N=%d)", a.N);
+  if (K == 2) hipLaunchKernelGGL((knn_kernel<2, AT>), grid, dim3(256), sh, s, a);
+  else if (K == 4) hipLaunchKernelGGL((knn_kernel<4, AT>), grid, dim3(256), sh, s, a);
+  else hipLaunchKernelGGL((knn_kernel<8, AT>), grid, dim3(256), sh, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
