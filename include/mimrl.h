@@ -121,9 +121,11 @@ int mimrl_estimate(mimrl_handle* h, int stage);        /* estimators only, on th
  * mimrl_stage1_step / mimrl_stage_grads(1) also run the stage-2 Model.forward (Model.py:388-519) of the bound batch on
  * a second stream -- legal because stage 1 (Solver.py:205-214) only updates critic parameters -- and the next
  * mimrl_stage2_step / mimrl_stage_grads(2) consumes it instead of running its own (Solver.py:221).  Results are the
- * same as in sequential mode (same parameters, inputs and dropout key).  Contract: between the two calls the caller
- * must not modify the bound inputs or main parameters; a stage-2 call without a preceding stage-1 call fails with
- * MIMRL_ERR_STATE.  Ignored while the banks are empty (epoch-0 rule). */
+ * same as in sequential mode (same parameters, inputs and dropout key).  The part of that forward pass in front of the
+ * first dropout (W_t projection, encoders) is the same function of the same inputs in both stages and is evaluated once;
+ * stage 2's kNN sampler (Model.py:74-105) runs beside it.  Contract: between the two calls the caller must not modify
+ * the bound inputs, the banks, host-supplied anchors of EITHER stage (mimrl_set_anchors) or main parameters; a stage-2
+ * call without a preceding stage-1 call fails with MIMRL_ERR_STATE.  Ignored while the banks are empty (epoch-0 rule). */
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on);
 /* Tell the engine that parameter buckets were written from outside (checkpoint load, broadcast): cached bf16 images of
  * the critic parameters are rebuilt at the next call.  mimrl_bind implies it; the engine's own Adam keeps them fresh. */

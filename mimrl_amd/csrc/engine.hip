@@ -137,7 +137,7 @@ struct mimrl_handle {
   // after mimrl_bind / mimrl_params_changed) and per-matrix transposed (rebuilt beside every estimator forward pass)
   __bf16 *crit_img = nullptr, *crit_imgT = nullptr;
   bool img_valid = false;
-  bool knn_pre = false;                // prefetch mode: also run stage 2's kNN sampling inside stage 1 (opt-in MIMRL_KNN_PREFETCH=1: measured 1 % slower)
+  bool knn_pre = true;                 // prefetch mode: stage 2's kNN sampling also runs inside stage 1, beside the encoder prefix (MIMRL_NO_KNN_PREFETCH=1: off)
   bool mi_fused_bwd_done = false;      // mi_forward already produced the tower-output gradients (mi_sep_fused)
   bool imgT_ready = false;             // a transposed-image refresh has been issued for the estimator pass being enqueued
   TransposeTable ttab;
@@ -2001,7 +2001,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
   h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
-  h->knn_pre = getenv("MIMRL_KNN_PREFETCH") != nullptr;
+  h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
