@@ -1326,7 +1326,8 @@ int mimrl_handle::model_backward() {
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
     MX(dbg_delay(stream, 8));
     MX(fork(1, l == 0 ? 5 : 3));   // the weight gradients below depend on the BPTT only
-    if (l == 1) {   // critical path, so first in capture order: gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
+    static const bool dh0_last = getenv("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
+    auto dh0_gemm = [&]() -> int {   // gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
       // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
       {
         GemmDesc q = gemm_nn(dg[l][0][0], 4 * H, P(gru[0][l][0].w_ih), 2 * H, dh0[0], 2 * H, (int)BT_, 2 * H, G);
@@ -1338,7 +1339,9 @@ int mimrl_handle::model_backward() {
         q.sc_b = dh0[1] - dh0[0];
         MX(G_(q));
       }
-    }
+      return MIMRL_OK;
+    };
+    if (l == 1 && !dh0_last) MX(dh0_gemm());
     // weight gradients of this layer: off the critical path.  Layer 1: side 1..3 (they overlap the layer-0 BPTT);
     // layer 0 is the tail of the stage.
     int rr = 0;
@@ -1362,6 +1365,7 @@ int mimrl_handle::model_backward() {
         q.a_gap_at = 2 * H; q.a_gap_rows = H;
         q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
     }
+    if (l == 1 && dh0_last) MX(dh0_gemm());
   }
   MX(join(0, 5));
   return MIMRL_OK;
@@ -1465,7 +1469,8 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
       g.B = l == 0 ? in : act[l - 1]; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
       g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
       g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
-      MX(G_on((hs >= 0 && ((nl - 1 - l) & 1)) ? S(hs) : stream, g));
+      static const int helper_par = getenv("MIMRL_WG_SPLIT_PARITY") ? atoi(getenv("MIMRL_WG_SPLIT_PARITY")) : 0;   // tuning knob
+      MX(G_on((hs >= 0 && ((nl - 1 - l) & 1) == helper_par) ? S(hs) : stream, g));
     }
     if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;
@@ -1737,28 +1742,36 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   static const int dbg_skip = getenv("MIMRL_DBG_SKIP_EST") ? atoi(getenv("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
   MX(fork(5, 5));
   MX(chain(5, 4));                       // the CMI branch needs the kNN indices
-  if (!(dbg_skip & 1)) {
+  auto cmi_branch = [&]() -> int {
+    if (dbg_skip & 1) return MIMRL_OK;
     StreamGuard g(this, S(5));
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
     MX(dbg_delay(stream, stage == 1 ? 4 : 14));
     if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
-  }
-  bf16 = bf_fwd;
-  if (!(dbg_skip & 2)) {
-  { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
-  MX(dbg_delay(stream, stage == 1 ? 3 : 15));
-  if (backward) {
-    bf16 = bf_bwd;
-    if (imgT_ready) MX(join(3, 3));
-    Scope sc(this, MIMRL_PH_EST_BWD);
-    wg_helper = stage == 1 ? 1 : -1;     // the MI branch is the critical one of stage 1 (tools/critical_path.sh)
-    const int r = mi_backward(stage);
-    wg_helper = -1;
-    MX(r);
-    MX(dbg_delay(stream, stage == 1 ? 5 : 17));
-  }
-  }
+    return MIMRL_OK;
+  };
+  auto mi_branch = [&]() -> int {
+    bf16 = bf_fwd;
+    if (dbg_skip & 2) return MIMRL_OK;
+    { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
+    MX(dbg_delay(stream, stage == 1 ? 3 : 15));
+    if (backward) {
+      bf16 = bf_bwd;
+      if (imgT_ready) MX(join(3, 3));
+      Scope sc(this, MIMRL_PH_EST_BWD);
+      wg_helper = stage == 1 ? 1 : -1;     // the MI branch is the critical one of stage 1 (tools/critical_path.sh)
+      const int r = mi_backward(stage);
+      wg_helper = -1;
+      MX(r);
+      MX(dbg_delay(stream, stage == 1 ? 5 : 17));
+    }
+    return MIMRL_OK;
+  };
+  // capture order of the two branches (graph nodes are dispatched in capture order; bit 0: stage 1, bit 1: stage 2 -> MI first)
+  static const int mi_first = getenv("MIMRL_EST_MI_FIRST") ? atoi(getenv("MIMRL_EST_MI_FIRST")) : 0;
+  if ((mi_first >> (stage - 1)) & 1) { MX(mi_branch()); MX(cmi_branch()); }
+  else { MX(cmi_branch()); MX(mi_branch()); }
   bf16 = bf_fwd;
   if (!multi_stream) return MIMRL_OK;
   return join(5, 5);
