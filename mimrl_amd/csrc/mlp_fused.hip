@@ -285,6 +285,13 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
       }
     };
     if (BWD && mask) { prefetch_mask(mk0, wave); prefetch_mask(mk1, wave + 4); prefetch_mask(mk2, wave + 8); }
+    // same for the bias of the forward pass: one value per lane and tile, but a dependent round trip each in the epilogue
+    const float* __restrict__ bias = BWD ? nullptr : a.b[l] + (long)g * a.pstride;
+    float bn3[3] = {0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bn3[q] = bias[min((wave + 4 * q) * 32 + lr, N - 1)];
+    }
     if (K < 16) {
       // degenerate reduction (the 2-logit top layer of the CMI classifier, backward): plain FMAs
       auto small = [&](f32x16& acc, int nt) {
@@ -311,12 +318,10 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
       }
     }
     // epilogue
-    const float* __restrict__ bias = BWD ? nullptr : a.b[l] + (long)g * a.pstride;
     float* __restrict__ db = (BWD && l > 0 && a.db[l - 1] && !(a.dbg & 2)) ? a.db[l - 1] + (long)g * a.pstride : nullptr;
-    auto finish = [&](const f32x16& acc, int nt, const float (&mk)[16]) {
+    auto finish = [&](const f32x16& acc, int nt, const float (&mk)[16], const float bn) {
       const int n = nt * 32 + lr;
       if (nt >= ntiles || n >= N) return;
-      const float bn = bias ? bias[n] : 0.f;
       float csum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
         if (lh == 0) atomicAdd(&db[n], csum);
       }
     };
-    finish(acc0, wave, mk0); finish(acc1, wave + 4, mk1); finish(acc2, wave + 8, mk2);
+    finish(acc0, wave, mk0, bn3[0]); finish(acc1, wave + 4, mk1, bn3[1]); finish(acc2, wave + 8, mk2, bn3[2]);
     __syncthreads();
     cur ^= 1;
   }
