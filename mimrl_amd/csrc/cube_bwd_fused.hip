@@ -31,6 +31,19 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   const int b = blockIdx.y, c0 = blockIdx.x * CT;
   const int il = a.il, hl = a.hl, ol = a.ol, C = a.C;
 
+  // pre-activations for act'(U) of phase 2 (this wave's 32 columns x up to 64 rows h): requested before anything else
+  // -- loaded in that phase's epilogue they were a dependent memory round trip in the middle of the kernel
+  float uu[2][16];
+  {
+    const int ccu = c0 + wave * 32 + lr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int h = min(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, hl - 1);
+        uu[mt][r] = a.u[((long)b * hl + h) * C + ccu];
+      }
+  }
   // weights, transposed and zero-padded to 64x64: zero fill with 16-byte stores, then scatter from coalesced reads
   {
     uint4* z = reinterpret_cast<uint4*>(&wts[0][0][0]);
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
         float v = 0.f;
         if (h < hl) {
           const long ui = ((long)b * hl + h) * C + cc;
-          v = (mt == 0 ? acc0[r] : acc1[r]) * act_grad(a.act, a.u[ui]);
+          v = (mt == 0 ? acc0[r] : acc1[r]) * act_grad(a.act, uu[mt][r]);
           a.du[ui] = v;
         }
         sdu[nt * 32 + lr][h] = to_bf16(v);
@@ -183,21 +196,28 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
     bw1[ks] = *reinterpret_cast<const bf16x8*>(a.w1t + n * 128 + ks * 16 + 8 * lh);
     bwr[ks] = *reinterpret_cast<const bf16x8*>(a.wrt + n * 128 + ks * 16 + 8 * lh);
   }
+  // pre-activations for act'(U) of phase 2: requested now -- loaded in that phase's epilogue they were a dependent memory
+  // round trip in the middle of the kernel (every load here is unconditional with a clamped row: a guarded load is a
+  // branch with an immediate vmcnt(0))
+  float uu[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long row = min(r0 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.R - 1);
+    uu[r] = a.u[row * 128 + n];
+  }
   // ---- phase 1: LayerNorm over D, backward: 8 threads per row, 16 consecutive columns each
   {
     const int row = tid >> 3, part = tid & 7;
     const long r = r0 + row;
     const bool ok = r < a.R;
+    const long rc = ok ? r : a.R - 1;
     float g[16], xh[16];
     float s1 = 0.f, s2 = 0.f;
-    const float mu = ok ? a.mean[r] : 0.f, rs = ok ? a.rstd[r] : 0.f;
+    const float mu = a.mean[rc], rs = a.rstd[rc];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 gz = make_float4(0.f, 0.f, 0.f, 0.f), yv = gz;
-      if (ok) {
-        gz = *reinterpret_cast<const float4*>(a.dz + r * 128 + part * 16 + q * 4);
-        yv = *reinterpret_cast<const float4*>(a.y + r * 128 + part * 16 + q * 4);
-      }
+      const float4 gz = *reinterpret_cast<const float4*>(a.dz + rc * 128 + part * 16 + q * 4);
+      const float4 yv = *reinterpret_cast<const float4*>(a.y + rc * 128 + part * 16 + q * 4);
       const float gg[4] = {gz.x, gz.y, gz.z, gz.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
       const long row = r0 + m;
       float v = 0.f;
       if (row < a.R) {
-        v = acc[r] * act_grad(a.act, a.u[row * 128 + n]);
+        v = acc[r] * act_grad(a.act, uu[r]);
         a.du[row * 128 + n] = v;
       }
       sdu[m][n] = to_bf16(v);
