@@ -284,6 +284,15 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   }
   __syncthreads();   // Xm is dead from here on (Bw / CtD alias it)
   if (tid < D) { dgam[tid] = a.d_g[tid]; dbet[tid] = a.d_be[tid]; }   // visible after the barriers of the GEMM loops
+  // biases of the two D-axis products for this lane's columns: requested here, not in the epilogues behind the GEMM loops
+  // (a dependent global round trip there, with one workgroup per CU and nothing to hide it)
+  float b1v[2], b2v[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = nt * 64 + wn * 32 + (lane & 31);
+    b1v[nt] = a.d_b1 ? a.d_b1[col] : 0.f;
+    b2v[nt] = a.d_b2 ? a.d_b2[col] : 0.f;
+  }
 
   f32x16 acc[NMT][2];
 #pragma unroll
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int n = wn * 32 + (lane & 31), col = nt * 64 + n;
-      const float b1 = a.d_b1 ? a.d_b1[col] : 0.f;
+      const float b1 = b1v[nt];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = acc_row(r, wm, lane), row = mt * 64 + m;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int n = wn * 32 + (lane & 31), col = nt * 64 + n;
-      const float b2 = a.d_b2 ? a.d_b2[col] : 0.f;
+      const float b2 = b2v[nt];
 #pragma unroll
       for (int r = 0; r < 16; ++r) CtD[acc_row(r, wm, lane) * CTD + col] = acc[mt][nt][r] + b2;
     }
