@@ -151,11 +151,10 @@ __device__ __forceinline__ void store_tile(const Operand& o, int tid, const floa
 }
 
 // epilogue of one 32x32 accumulator tile: lane holds column n, 16 rows (mbase + MFMA row pattern)
-__device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, long oc, long obn, const f32x16& acc, int mbase,
+__device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, long oc, const float bn, const f32x16& acc, int mbase,
                                          int n, int lane) {
   if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
   float* __restrict__ C = d.C + oc;
-  const float bn = d.bias_n ? d.bias_n[obn + n] : 0.f;
   float csum = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -212,6 +211,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // column bias of the epilogue: requested before the k-loop (behind it, it is a dependent round trip per workgroup)
+  const int n_lane = n0 + wn * 32 + (lane & 31);
+  const float bn_pre = d.bias_n ? d.bias_n[obn + (n_lane < d.N ? n_lane : d.N - 1)] : 0.f;
 
   // one product segment: acc += A[m0:m0+64, :K] . B[:K, n0:n0+64]   (called once, or twice for C = A.B + A2.B2)
   auto segment = [&](const float* __restrict__ Ap, long sa_m, long sa_k, const float* __restrict__ Bp, long sb_k, long sb_n,
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     segment(d.A2 + (long)bz * d.sa2_b, d.sa2_m, d.sa2_k, d.B2 + (long)bz * d.sb2_b, d.sb2_k, d.sb2_n, d.K2, ka.vec_a2, ka.vec_b2,
             0, (d.K2 + BK - 1) / BK, 0x7fffffff, 0);
 
-  epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, obn, acc, m0 + wm * 32, n0 + wn * 32 + (lane & 31), lane);
+  epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre, acc, m0 + wm * 32, n_lane, lane);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
