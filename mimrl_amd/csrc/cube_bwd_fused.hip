@@ -76,15 +76,13 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   s1 = (red[0][0][col] + red[0][1][col]) / ol;
   s2 = (red[1][0][col] + red[1][1][col]) / ol;
 #pragma unroll 8
-  for (int l = half; l < 64; l += 2) {
-    float v = 0.f;
-    if (l < ol) {                      // uniform per wave
-      const float gq = dzb[(long)l * C], xq = (yb[(long)l * C] - mu) * rs;
-      v = rs * (gq * a.gamma[l] - s1 - xq * s2);
-      dyb[(long)l * C] = v;
-    }
-    sdy[col][l] = to_bf16(v);          // rows l >= ol: zero padding of the K axis
+  for (int l = half; l < ol; l += 2) {   // no guard inside the loop: the loads of an unrolled batch go out together
+    const float gq = dzb[(long)l * C], xq = (yb[(long)l * C] - mu) * rs;
+    const float v = rs * (gq * a.gamma[l] - s1 - xq * s2);
+    dyb[(long)l * C] = v;
+    sdy[col][l] = to_bf16(v);
   }
+  for (int l = ol + ((half ^ ol) & 1); l < 64; l += 2) sdy[col][l] = to_bf16(0.f);   // rows l >= ol: zero padding of the K axis
   __syncthreads();
 
   if (a.db2 && tid >= 192 && tid - 192 < ol) {   // db2[o] = sum over this tile's columns of dY (bf16 image, as the weight-gradient GEMM sees it)
