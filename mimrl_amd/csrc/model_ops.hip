@@ -370,10 +370,14 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
     KMixVals<NK> v;
     float dzv[NK], dyv[NK], dym[NK], du[NK], dxn[NK], dxv[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) v.x[k] = k < w.ik ? x[(r * w.ik + k) * D + d] : 0.f;
+    for (int k = 0; k < NK; ++k) {   // unconditional, clamped: a guarded load is a branch with its own vmcnt(0) -- 2 NK dependent round trips
+      const float xv = x[(r * w.ik + (k < w.ik ? k : w.ik - 1)) * D + d];
+      v.x[k] = k < w.ik ? xv : 0.f;
+    }
 #pragma unroll
     for (int o = 0; o < NK; ++o) {
-      dzv[o] = o < w.ok ? dz[(r * w.ok + o) * D + d] : 0.f;
+      const float gv = dz[(r * w.ok + (o < w.ok ? o : w.ok - 1)) * D + d];
+      dzv[o] = o < w.ok ? gv : 0.f;
       v.sc[o] = o < w.ok ? drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d)) : 0.f;
     }
     kmix_forward_vals<NK>(w, sw, v);
