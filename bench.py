@@ -158,8 +158,7 @@ def main():
             mdist.ddp_stage_step(eng, 1, world)
             mdist.ddp_stage_step(eng, 2, world)
         else:
-            eng.stage1_step()
-            eng.stage2_step()
+            eng.step()            # mimrl_two_stage_step: in overlap mode with graphs both stages are ONE captured graph
 
     log("engine ready; warm-up")
     for i in range(args.warmup):

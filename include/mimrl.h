@@ -113,6 +113,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* bufs);
 int mimrl_set_bank_rows(mimrl_handle* h, int rows);    /* 0 => epoch-0 rule (Customization.py:97-98,105-106) */
 int mimrl_stage1_step(mimrl_handle* h);                /* Solver.py:205-214 : critics update               */
 int mimrl_stage2_step(mimrl_handle* h);                /* Solver.py:221-236 : main-model update            */
+int mimrl_two_stage_step(mimrl_handle* h);             /* the new Solver.step(datas): mimrl_stage1_step then mimrl_stage2_step on the bound batch; in overlap mode with graphs ONE captured graph, one launch */
 int mimrl_stage_grads(mimrl_handle* h, int stage);     /* forward+backward only (data-parallel: all-reduce follows) */
 int mimrl_stage_apply(mimrl_handle* h, int stage);     /* value-clip + Adam on that stage's bucket         */
 int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses);  /* Solver.evaluate body (Solver.py:255-258) */

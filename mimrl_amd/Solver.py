@@ -111,9 +111,13 @@ class Solver:
         self._load(datas)
         self._anchors(1)          # host-drawn anchors (if any) for BOTH stages go up before stage 1: in overlap mode the
         self._anchors(2)          # stage-2 kNN sampler already runs beside stage 1 (same draw order as the reference)
-        l1 = self.stage1_step(draw_anchors=False)
-        l2, mis, pred = self.stage2_step(draw_anchors=False)
-        return l1, l2, mis, pred
+        if self.world > 1:
+            l1 = self.stage1_step(draw_anchors=False)
+            l2, mis, pred = self.stage2_step(draw_anchors=False)
+            return l1, l2, mis, pred
+        self.engine.step()        # mimrl_two_stage_step: both stages as one captured graph
+        sc = self.engine.scalars
+        return sc[_lib.S1_LOSS], sc[_lib.S2_LOSS], sc[_lib.S2_MIS:_lib.S2_MIS + 8], self.engine.pred.reshape(-1, 1)
 
     # ------------------------------------------------------------------ Solver.train (Solver.py:194-248)
     def train(self, epoch, train_loader, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):

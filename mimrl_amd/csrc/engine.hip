@@ -355,6 +355,8 @@ struct mimrl_handle {
   int enqueue_grads(int stage, bool skip_zero = false);
   int enqueue_apply(int stage);
   int run(int stage, int kind);
+  int run_step();                      // both stages as ONE captured graph where possible (mimrl_two_stage_step)
+  bool keep_events = false;            // second stage of a combined capture: do not recycle the first stage's events
 };
 
 // =================================================================================================
@@ -1783,7 +1785,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
 int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   const int B = cfg.batch;
   const bool have_banks = bank_rows > 0;
-  ev_next = 0;
+  if (!keep_events) ev_next = 0;
   if (stage == 1) {
     hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, have_banks ? d_ints + 2 : nullptr,
                        bufs.scalars, 0, 32);
@@ -1978,6 +1980,44 @@ int mimrl_handle::run(int stage, int kind) {
   return MIMRL_OK;
 }
 
+// Solver.step(): stage 1 then stage 2 on the bound batch.  In overlap mode with graphs the two stages are ONE captured
+// graph (one launch, no idle device between the stage-1 Adam and the stage-2 estimators); otherwise two run() calls.
+int mimrl_handle::run_step() {
+  if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
+  static const bool no_step_graph = getenv("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
+  const bool combined = cfg.use_graph && !prof_on && prefetch && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
+  if (!combined) { MX(run(1, 0)); return run(2, 0); }
+  MX(ensure_images());
+  hipGraphExec_t& ex = graph[0][0];
+  if (ex && graph_rows[0][0] != bank_rows) {   // bank size is baked into the kernel arguments
+    HIPX(hipGraphExecDestroy(ex));
+    ex = nullptr;
+  }
+  if (!ex) {
+    hipGraph_t g = nullptr;
+    if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+    stream = cap_stream;
+    int r = enqueue_grads(1, true);
+    if (r == 0) r = enqueue_apply(1);
+    keep_events = true;
+    if (r == 0) r = enqueue_grads(2, true);
+    keep_events = false;
+    if (r == 0) r = enqueue_apply(2);
+    stream = user_stream;
+    const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
+    if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    graph_rows[0][0] = bank_rows;
+  }
+  HIPX(hipGraphLaunch(ex, stream));
+  fwd2_pending = false;
+  return MIMRL_OK;
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -2038,7 +2078,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
   h->bufs = *b;
   h->bound = true;
   h->img_valid = false;
-  for (int s = 1; s <= 2; ++s)
+  for (int s = 0; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
   return MIMRL_OK;
@@ -2061,6 +2101,7 @@ int mimrl_set_bank_rows(mimrl_handle* h, int rows) {
 
 int mimrl_stage1_step(mimrl_handle* h) { return h ? h->run(1, 0) : set_error(MIMRL_ERR_ARG, "null handle"); }
 int mimrl_stage2_step(mimrl_handle* h) { return h ? h->run(2, 0) : set_error(MIMRL_ERR_ARG, "null handle"); }
+int mimrl_two_stage_step(mimrl_handle* h) { return h ? h->run_step() : set_error(MIMRL_ERR_ARG, "null handle"); }
 int mimrl_stage_grads(mimrl_handle* h, int stage) { return h ? h->run(stage, 1) : set_error(MIMRL_ERR_ARG, "null handle"); }
 int mimrl_stage_apply(mimrl_handle* h, int stage) { return h ? h->run(stage, 2) : set_error(MIMRL_ERR_ARG, "null handle"); }
 
@@ -2142,7 +2183,7 @@ int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
   if ((on != 0) == h->prefetch) return MIMRL_OK;
   if (on && !h->pre_stream) HIPX(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
   HIPX(hipStreamSynchronize(h->user_stream));
-  for (int s = 1; s <= 2; ++s)
+  for (int s = 0; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
   h->prefetch = on != 0;
@@ -2154,7 +2195,7 @@ int64_t mimrl_workspace_bytes(const mimrl_handle* h) { return h ? (int64_t)h->ws
 
 void mimrl_destroy(mimrl_handle* h) {
   if (!h) return;
-  for (int s = 1; s <= 2; ++s)
+  for (int s = 0; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) (void)hipGraphExecDestroy(h->graph[s][k]);
   for (int p = 0; p < MIMRL_NPHASES; ++p)

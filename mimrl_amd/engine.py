@@ -149,8 +149,7 @@ class HipEngine:
 
     def step(self):
         """One stage-1 (critics) + one stage-2 (model) update on the bound batch."""
-        check(self.lib.mimrl_stage1_step(self.handle))
-        check(self.lib.mimrl_stage2_step(self.handle))
+        check(self.lib.mimrl_two_stage_step(self.handle))
 
     def stage_grads(self, stage: int):
         check(self.lib.mimrl_stage_grads(self.handle, stage))
