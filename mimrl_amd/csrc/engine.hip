@@ -1358,7 +1358,7 @@ int mimrl_handle::model_backward() {
       auto two = [&](GemmDesc& q, long a_o, long b_o, long c_o) { if (both) { q.batch = 4; q.batch_in = 2; q.sa_bo = a_o; q.sb_bo = b_o; q.sc_bo = c_o; } };
       const long o_dg = dg[l][1][0] - dg[l][0][0], o_hp = hprev[l][1][0] - hprev[l][0][0], o_in = both ? h0[1] - h0[0] : 0;
       const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
-      static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 4;   // tuning knobs
+      static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 1;   // tuning knobs
       static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
       auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
