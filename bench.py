@@ -57,6 +57,10 @@ def workload(name):
         "cfg1": dict(batch_size=32, time_len=50, critic_type="separate", bank=1284),
         "cfg2": dict(batch_size=128, time_len=50, critic_type="separate", bank=1284),
         "cfg2-concat": dict(batch_size=128, time_len=50, critic_type="concat", bank=1284),
+        # BASELINE configs[2]: MOSEI-shaped, T=500, concat critic, k=2, MOSEI-sized banks
+        "cfg3": dict(batch_size=256, time_len=500, critic_type="concat", bank=16326),
+        # BASELINE configs[4], reference-supported subset: AVEC-shaped long sequences, gru, d_common=128
+        "cfg5": dict(batch_size=32, time_len=1000, critic_type="separate", bank=163),
     }
     c = cfgs[name]
     base.update(batch_size=c["batch_size"], time_len=c["time_len"], critic_type=c["critic_type"])

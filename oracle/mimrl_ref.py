@@ -521,9 +521,10 @@ class AdamState:
             params[n] = (params[n] - (lr / bc1) * self.m[n] / denom).detach()
 
 
-def stage_step(params: Params, opt, stage: int, adam: AdamState, batch, banks, anchors, masks=None):
+def stage_step(params: Params, opt, stage: int, adam: AdamState, batch, banks, anchors, masks=None, lr_scale: float = 1.0):
     """One optimiser update of stage 1 (critics; Solver.py:205-214) or stage 2 (main; :221-236).
-    Mutates ``params`` in place (dict entries are replaced).  Returns dict of observables."""
+    Mutates ``params`` in place (dict entries are replaced).  Returns dict of observables.
+    ``lr_scale`` = the factor the epoch-level lr schedulers have applied so far (Solver.py:52-57,153-169)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
     loss, mis, pred, feats, task = stage_loss(leaves, opt, stage, batch, banks, anchors, masks)
     grads: Dict[str, Tensor] = {}
@@ -535,7 +536,7 @@ def stage_step(params: Params, opt, stage: int, adam: AdamState, batch, banks, a
             if g is None:
                 continue
             grads[n] = g.clamp(-clip, clip) if clip > 0 else g   # Solver.py:211-212 clip_grad_value_
-    lr = float(opt.learning_rate) * (float(opt.mi_lr_rate) if stage == 1 else 1.0)   # Solver.py:135-142
+    lr = float(opt.learning_rate) * (float(opt.mi_lr_rate) if stage == 1 else 1.0) * lr_scale   # Solver.py:135-142
     if grads or stage == 2:
         adam.step(params, grads, lr, float(opt.weight_decay))
     return {"loss": loss.detach(), "mis": [m.detach() for m in mis], "pred": pred.detach(),
@@ -548,3 +549,58 @@ def two_stage_step(params: Params, opt, adam_vmi: AdamState, adam_main: AdamStat
     r1 = stage_step(params, opt, 1, adam_vmi, batch, banks, anchors1, masks1)
     r2 = stage_step(params, opt, 2, adam_main, batch, banks, anchors2, masks2)
     return r1, r2
+
+
+# --------------------------------------------------------------------------------------
+# epoch level: Solver.train / Solver.evaluate (Solver.py:194-248, 250-270)
+# --------------------------------------------------------------------------------------
+def _bank_dict(banks):
+    if banks is None or len(banks["C"]) == 0:
+        return None
+    return banks
+
+
+def train_epoch(params: Params, opt, epoch: int, adam_vmi: AdamState, adam_main: AdamState, batches, banks, draw,
+                lr_scale: float = 1.0):
+    """Solver.train (Solver.py:194-248).  ``batches``: list of (t_feat, a, v, labels) -- the last one may be shorter
+    (Parameters.py:21 drop_last defaults to False); ``banks``: dict C,F,T,A,V of the previous epoch's stage-2 pass or
+    None/empty; ``draw(N, m)`` -> six anchor arrays, called once per estimator pass in the reference's order (Model.py:81).
+    Returns the reference's return tuple as a dict (losses averaged over len(batches), new banks = features of THIS pass)."""
+    banks = _bank_dict(banks)
+    nb = len(batches)
+    run_mi = 0.0
+    if epoch > 0:                                                          # Solver.py:200-203: epoch 0 skips stage 1
+        for _ in range(int(opt.stage1_n)):
+            for batch in batches:
+                anc = draw(len(banks["C"]), batch[3].shape[0] // opt.k_neighbor) if banks is not None else None
+                r = stage_step(params, opt, 1, adam_vmi, batch, banks, anc, lr_scale=lr_scale)
+                run_mi += float(r["loss"])
+    new = {k: [] for k in "CFTAV"}
+    run, mis, preds, targs = 0.0, [0.0] * 8, [], []
+    for batch in batches:
+        anc = draw(len(banks["C"]), batch[3].shape[0] // opt.k_neighbor) if banks is not None else None
+        r = stage_step(params, opt, 2, adam_main, batch, banks, anc, lr_scale=lr_scale)
+        new["C"].append(batch[3].reshape(-1, 1))                           # Solver.py:223-227
+        for k in "FTAV":
+            new[k].append(r["feats"][k])
+        run += float(r["loss"])
+        mis = [a + float(b) for a, b in zip(mis, r["mis"])]
+        preds.append(r["pred"].reshape(-1))
+        targs.append(batch[3].reshape(-1))
+    return {"loss": run / nb, "loss_mi": run_mi / nb, "mis": [m / nb for m in mis], "pred": torch.cat(preds), "target": torch.cat(targs),
+            "banks": {k: torch.cat(v, 0) for k, v in new.items()}}
+
+
+def evaluate_epoch(params: Params, opt, batches, banks, draw):
+    """Solver.evaluate (Solver.py:250-270): the stage-2 loss of every batch under no_grad, eval mode (dropout off)."""
+    banks = _bank_dict(banks)
+    run, mis, preds = 0.0, [0.0] * 8, []
+    with torch.no_grad():
+        for batch in batches:
+            anc = draw(len(banks["C"]), batch[3].shape[0] // opt.k_neighbor) if banks is not None else None
+            loss, m, pred, feats, task = stage_loss(params, opt, 2, batch, banks, anc)
+            run += float(loss)
+            mis = [a + float(b) for a, b in zip(mis, m)]
+            preds.append(pred.reshape(-1))
+    nb = len(batches)
+    return {"loss": run / nb, "mis": [m / nb for m in mis], "pred": torch.cat(preds)}

@@ -29,6 +29,24 @@ CONFIGS = {
     # BASELINE cfg1: B=32, T=50, canonical README flags, N=1000 as in the reference smoke test (Model.py:607)
     "cfg1_sep": dict(B=32, T=50, N=1000, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=6),
     "cfg1_cat": dict(B=32, T=50, N=1000, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
+    # BASELINE cfg2 at FULL size (the bench configuration: B=128, T=50, MOSI-sized banks)
+    "cfg2_sep": dict(B=128, T=50, N=1284, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=1),
+    # BASELINE cfg3 reduced in the batch only: T = time_len = 500 (L-axis MLP 500 -> 50), concat critic, k=2
+    "cfg3_small": dict(B=16, T=500, N=400, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
+    # BASELINE cfg5, reference-supported subset (gru, d_common=128, fp32), T = 1000: 2000 serial cell steps per pass
+    "cfg5_small": dict(B=8, T=1000, N=163, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=1),
+    # --features_compose_t/k sum (Model.py:473-485)
+    "tiny_sum": dict(B=8, T=6, N=40, seed=12, critic="separate", cube="6-3-128=4-3-128", traj=1, compose="sum"),
+}
+
+# Epoch-level fixtures: the reference's own Solver.train / Solver.evaluate (Solver.py:194-270) over several epochs.
+# n_*: dataset sizes (a size that is not a multiple of B exercises the partial last batch: drop_last defaults to False,
+# Parameters.py:21); stage1_n critic passes per epoch; multi-step lr schedule stepping at the given epochs.
+EPOCH_CONFIGS = {
+    "epoch_tiny": dict(B=8, T=6, seed=21, critic="separate", cube="6-3-128=4-3-128", n_train=32, n_valid=16, n_test=8,
+                       epochs=3, stage1_n=2, lr=1e-4, lr_iter="1-2", lr_rate=0.5),
+    "epoch_tail": dict(B=8, T=6, seed=22, critic="separate", cube="6-3-128=4-3-128", n_train=36, n_valid=12, n_test=8,
+                       epochs=2, stage1_n=1, lr=1e-4, lr_iter="1-2", lr_rate=0.5),
 }
 
 
@@ -40,12 +58,26 @@ def make_opt(c):
     """The subset of Parameters.py flags the hot path reads, README values."""
     cube = parse_cube(c["cube"])
     return SimpleNamespace(
-        batch_size=c["B"], d_common=128, encoders=c.get("encoders", "gru"), features_compose_t="mean", features_compose_k="mean",
+        batch_size=c["B"], d_common=128, encoders=c.get("encoders", "gru"), features_compose_t=c.get("compose", "mean"),
+        features_compose_k=c.get("compose", "mean"),
         num_class=1, activate="gelu", time_len=c.get("L", c["T"]), d_hiddens=cube, d_outs=cube,
         dropout_mlp=[0.0, 0.0, 0.0], dropout=[0.0, 0.0, 0.0, 0.0], bias=True, ln_first=c.get("ln_first", False),
         res_project=[True] * len(cube), critic_type=c["critic"], baseline_type=c.get("baseline", "constant"),
         bound_type=c.get("bound", "infonce"), loss_mi_coefficient1=[1.0] * 11, loss_mi_coefficient2=[0.01] * 8,
         mi_lr_rate=1.0, cmi_lr_rate=1.0, k_neighbor=c.get("k", 2), radius=1.0, cmi_last_acticate=c.get("cmi_last", "sigmoid"),
-        stage1_n=1, loss="MAE", gradient_clip=1.5, optm="Adam", learning_rate=4e-3, weight_decay=0.0,
+        stage1_n=c.get("stage1_n", 1), loss="MAE", gradient_clip=1.5, optm="Adam", learning_rate=c.get("lr", 4e-3), weight_decay=0.0,
+        lr_decrease="multi_step", lr_decrease_iter=c.get("lr_iter", "50-60"), lr_decrease_rate=c.get("lr_rate", 0.1),
         dataset="mosi_Dec", parallel=True, text="none",
     )
+
+
+def epoch_data(c):
+    """Synthetic train / valid / test sets of an epoch fixture -> dict of (t, a, v, y) numpy tuples."""
+    from mimrl_amd import synth
+    return {k: synth.synthetic_batch(c["n_" + k], c["T"], seed=c["seed"] + i) for i, k in enumerate(("train", "valid", "test"))}
+
+
+def split_batches(data, B):
+    """[(t, a, v, y)] in loader order, last batch partial (drop_last=False, Parameters.py:21)."""
+    n = data[3].shape[0]
+    return [tuple(x[i:i + B] for x in data) for i in range(0, n, B)]

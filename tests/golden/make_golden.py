@@ -30,7 +30,7 @@ import Model as RM  # noqa: E402  (reference)
 import Customization as RC  # noqa: E402  (reference)
 
 from mimrl_amd import synth  # noqa: E402
-from tests.golden.configs import CONFIGS, make_opt  # noqa: E402
+from tests.golden.configs import CONFIGS, EPOCH_CONFIGS, epoch_data, make_opt, split_batches  # noqa: E402
 
 
 class StubBert(torch.nn.Module):
@@ -184,6 +184,95 @@ def gen(name, c):
           f"s2_loss0={traj['s2_loss'][0]:.6f} s2_mis0={np.round(traj['s2_mis'][0], 5).tolist()}")
 
 
+def gen_epoch(name, c):
+    """Epoch fixture through the reference's OWN Solver (Solver.py:18-36 ctor, :194-248 train, :250-270 evaluate), stubs of
+    SURVEY.md Appendix A.  Records what Solver.solve would log per epoch, the feature banks handed from epoch to epoch,
+    and every anchor draw (np.random.choice, Model.py:81) in call order."""
+    import random
+    sys.modules.setdefault("torch.utils.tensorboard", types.SimpleNamespace(
+        SummaryWriter=lambda *a, **k: types.SimpleNamespace(add_scalar=lambda *a, **k: None, close=lambda: None)))
+    sys.modules.setdefault("DataLoaderLocal", types.SimpleNamespace(mosi_r2c_7=None, pom_r2c_7=None, r2c_2=None, r2c_7=None,
+                                                                    LocalDataset=None))
+    import transformers
+    transformers.BertTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: None)
+    import Parameters as RP  # reference
+    import Solver as RS      # reference
+
+    B, T = c["B"], c["T"]
+    data = epoch_data(c)
+    text = np.concatenate([data[k][0] for k in ("train", "valid", "test")])
+    base = {"train": 0, "valid": c["n_train"], "test": c["n_train"] + c["n_valid"]}
+
+    def loader(k):
+        out = []
+        for j, (t, a, v, y) in enumerate(split_batches(data[k], B)):
+            ids = (base[k] + j * B + np.arange(len(y))).reshape(-1, 1).repeat(T, 1)
+            out.append((None, torch.from_numpy(a), torch.from_numpy(v), None, None, torch.from_numpy(y).reshape(-1, 1), ids,
+                        np.zeros_like(ids), np.ones_like(ids), None, None))
+        return out
+
+    loaders = (loader("train"), loader("valid"), loader("test"), 768, 74, 35)
+    RS.get_data_loader = lambda opt: loaders
+    one = lambda n, v: "-".join([str(v)] * n)
+    sys.argv = ["Main.py", "--dataset", "mosi_Dec", "--parallel", "--text", "none", "--batch_size", str(B), "--time_len", str(T),
+                "--d_hiddens", c["cube"], "--d_outs", c["cube"], "--bias", "--res_project", "1-1", "--dropout", "0.0-0.0-0.0-0.0",
+                "--dropout_mlp", "0.0-0.0-0.0", "--loss_mi_coefficient1", one(11, 1.0), "--loss_mi_coefficient2", one(8, 0.01),
+                "--stage1_n", str(c["stage1_n"]), "--lr_decrease", "multi_step", "--lr_decrease_iter", c["lr_iter"],
+                "--lr_decrease_rate", str(c["lr_rate"]), "--learning_rate", str(c["lr"]), "--critic_type", c["critic"],
+                "--bound_type", "infonce", "--k_neighbor", "2", "--gradient_clip", "1.5", "--loss", "MAE", "--optm", "Adam",
+                "--encoders", "gru", "--d_common", "128", "--activate", "gelu", "--task_name", "golden_" + name,
+                "--epochs_num", str(c["epochs"])]
+    opt = RP.parse_args()
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    sol = RS.Solver(opt)                       # nn.DataParallel without GPUs calls the module directly (Solver.py:33-35)
+    model = sol.model.module
+    sd = model.state_dict()
+    model.load_state_dict({k: torch.from_numpy(synth.portable_tensor(k, tuple(v.shape), c["seed"])) for k, v in sd.items()})
+    model.bertmodel.feat = torch.from_numpy(text)
+
+    draws = []
+    real_choice = np.random.choice
+
+    def rec_choice(a, size=None, replace=True, p=None):
+        r = real_choice(a, size=size, replace=replace, p=p)
+        draws.append(np.asarray(r, np.int64).copy())
+        return r
+
+    np.random.choice = rec_choice
+    np.random.seed(c["seed"])
+    out = {}
+    try:
+        banks = ([], [], [], [], [])
+        for ep in range(c["epochs"]):
+            r = sol.train(ep, sol.train_loader, *banks)
+            banks = r[4:]
+            out[f"ep{ep}_train_loss"], out[f"ep{ep}_train_loss_mi"] = np.float64(r[0]), np.float64(r[1])
+            out[f"ep{ep}_train_mis"] = np.array(r[2], np.float64)
+            out[f"ep{ep}_train_mae"], out[f"ep{ep}_train_corr"] = np.float64(r[3]["mae"]), np.float64(r[3]["corr"])
+            for k, bk in zip("CFTAV", banks):
+                out[f"ep{ep}_bank_{k}"] = bk.detach().numpy().astype(np.float32).copy()
+            for tag, ld in (("valid", sol.valid_loader), ("test", sol.test_loader)):
+                e = sol.evaluate(ld, *banks)
+                out[f"ep{ep}_{tag}_loss"], out[f"ep{ep}_{tag}_mis"] = np.float64(e[0]), np.array(e[1], np.float64)
+                out[f"ep{ep}_{tag}_mae"] = np.float64(e[2]["mae"])
+                out[f"ep{ep}_{tag}_pred"] = np.asarray(e[3], np.float32).reshape(-1)
+            sol.lr_schedule_main.step(); sol.lr_schedule_vmi.step()          # Solver.py:52-57
+            out[f"ep{ep}_lr_next"] = np.array([sol.optimizer_main.param_groups[1]["lr"], sol.optimizer_vmi.param_groups[0]["lr"]])
+    finally:
+        np.random.choice = real_choice
+    names = [n for n, _ in model.named_parameters() if "bert" not in n]
+    out["final_names"] = np.array(names)
+    out["final_psum"] = np.array([p.detach().double().sum().item() for n, p in model.named_parameters() if "bert" not in n])
+    out["final_psq"] = np.array([(p.detach().double() ** 2).sum().item() for n, p in model.named_parameters() if "bert" not in n])
+    out["draw_len"] = np.array([len(d) for d in draws], np.int64)
+    out["draws"] = np.concatenate(draws) if draws else np.zeros(0, np.int64)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.1f} KiB); {len(draws)} anchor draws; " +
+          " | ".join(f"ep{e}: loss {out[f'ep{e}_train_loss']:.5f} mi {out[f'ep{e}_train_loss_mi']:.5f} val {out[f'ep{e}_valid_loss']:.5f}"
+                     for e in range(c["epochs"])))
+
+
 def gen_units():
     """F1/F2: estimator-level fixtures straight from the reference classes (all bounds, both critics)."""
     out = {}
@@ -259,9 +348,11 @@ def gen_flags():
 
 if __name__ == "__main__":
     os.chdir("/tmp")
-    which = sys.argv[1:] or list(CONFIGS) + ["units", "flags"]
+    which = sys.argv[1:] or list(CONFIGS) + ["units", "flags"] + list(EPOCH_CONFIGS)
     for name in which:
-        if name == "units":
+        if name in EPOCH_CONFIGS:
+            gen_epoch(name, EPOCH_CONFIGS[name])
+        elif name == "units":
             gen_units()
         elif name == "flags":
             gen_flags()
