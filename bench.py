@@ -148,7 +148,7 @@ def main():
     eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision=args.precision, use_graph=not args.no_graph,
                     seed=1234 + rank, device_anchors=True)
     shapes = [(n, tuple(v.shape)) for n, v in eng.params.items()]
-    eng.load_params({n: synth.default_tensor(n, s, 0) for n, s in shapes})        # random init, identical on all ranks
+    eng.load_params(synth.default_state(shapes, 0))                              # random init, identical on all ranks
     eng.set_batch(*synth.synthetic_batch(B, T, seed=rank))                       # rank-local batch, resident in HBM
     banks = synth.synthetic_banks(N, seed=0)
     eng.set_banks(*(banks[k] for k in "CFTAV"))

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIMRL_ABI_VERSION 1
+#define MIMRL_ABI_VERSION 2
 #define MIMRL_MAX_BLOCKS 4
 
 enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -3, MIMRL_ERR_NODEVICE = -4 };
@@ -81,6 +81,13 @@ typedef struct mimrl_buffers {
   float *pred;                                    /* [B] */
   float *feats;                                   /* [4][B,128] = F_F, T_F, A_F, V_F */
   float *scalars;                                 /* [MIMRL_NSCALARS] see MIMRL_S_* */
+  int32_t* counters;                              /* [4] device ints owned by the caller like m / v: [0] dropout/anchor RNG step,
+                                                     [1] Adam step of the main bucket, [2] Adam step of the critic bucket
+                                                     (torch.optim.Adam's state['step'], Solver.py:144-146), [3] reserved.
+                                                     Optional (NULL: private storage).  Handles bound to the same buckets AND
+                                                     counters form one optimizer (e.g. a second handle for the partial last
+                                                     batch, Parameters.py:21 drop_last=False); saving m, v and these three
+                                                     ints is a complete optimizer checkpoint (Solver.py:57-62). */
 } mimrl_buffers;
 
 /* indices into mimrl_buffers.scalars */

@@ -15,7 +15,7 @@ from .engine import HipEngine
 
 class Model:
     def __init__(self, opt, d_t: int, d_a: int, d_v: int, bank_capacity: int = 0, precision: str = None,
-                 use_graph: bool = None, device_anchors: bool = None, seq_len: int = None, init: str = "default"):
+                 use_graph: bool = None, device_anchors: bool = None, seq_len: int = None, init: str = "default", rank: int = 0):
         self.opt = opt
         self.d_t, self.d_a, self.d_v, self.d_common = d_t, d_a, d_v, opt.d_common
         assert opt.encoders in ["lstm", "gru", "conv"]                                   # Model.py:237
@@ -24,11 +24,13 @@ class Model:
         use_graph = (not getattr(opt, "no_graph", False)) if use_graph is None else use_graph
         device_anchors = (not getattr(opt, "host_anchors", False)) if device_anchors is None else device_anchors
         self.engine = HipEngine(opt, d_t, d_a, d_v, seq_len=seq_len, bank_capacity=bank_capacity, precision=precision,
-                                use_graph=use_graph, seed=int(getattr(opt, "seed", 0)), device_anchors=device_anchors)
+                                use_graph=use_graph, seed=int(getattr(opt, "seed", 0)) + 7919 * int(rank),   # dropout / anchor streams differ per rank
+                                device_anchors=device_anchors)
         self.training = True
         self.k_neighbor = opt.k_neighbor
-        gen = synth.default_tensor if init == "default" else synth.portable_tensor
-        self.engine.load_params({n: gen(n, tuple(v.shape), int(getattr(opt, "seed", 0))) for n, v in self.engine.params.items()})
+        shapes = [(n, tuple(v.shape)) for n, v in self.engine.params.items()]
+        gen = synth.default_state if init == "default" else synth.portable_state
+        self.engine.load_params(gen(shapes, int(getattr(opt, "seed", 0))))
 
     # ---- nn.Module-like surface -------------------------------------------------------------
     def train(self, mode: bool = True):

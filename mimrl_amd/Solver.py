@@ -5,6 +5,10 @@ New (named by BASELINE.json's north star, absent in the reference): ``Solver.ste
 epoch ordering -- ``stage1_n`` full critic passes (skipped in epoch 0), then one model pass that also builds the next
 epoch's feature banks -- but accumulates losses / MI terms / banks on the device and reads back once per epoch
 (the reference performs >= 10 ``.item()`` syncs and 18 bank D2H copies per iteration).
+
+Batches shorter than ``--batch_size`` (the last batch of a loader with the reference's default ``drop_last=False``,
+Parameters.py:21) run on a second engine handle of that batch size bound to the SAME parameter / Adam buckets, step
+counters and banks (`HipEngine(share=...)`), i.e. the same optimizer, as in the reference.
 """
 from __future__ import annotations
 
@@ -15,8 +19,17 @@ import torch
 
 from . import _lib, dist as mdist, synth
 from .Customization import compute_custumized_loss, compute_outputs_from_model, other_model_operations
+from .engine import HipEngine
 from .Model import Model
 from .Utils import log_message, set_logger
+
+
+def _loader_samples(loader, batch_size):
+    if hasattr(loader, "num_samples"):
+        return int(loader.num_samples())
+    if isinstance(loader, (list, tuple)):
+        return int(sum(len(d[5]) for d in loader))
+    return len(loader) * batch_size
 
 
 class Solver:
@@ -29,20 +42,27 @@ class Solver:
             raise NotImplementedError(f"--optm {opt.optm}: only Adam is fused on the MI355X hot path")
         if loaders is None:
             from .data import get_data_loader
-            loaders = get_data_loader(opt)
+            loaders = get_data_loader(opt, self.rank, self.world)          # training data sharded by rank
         self.train_loader, self.valid_loader, self.test_loader, self.d_t, self.d_a, self.d_v = loaders
         if torch.cuda.is_available():
             torch.cuda.set_device(self.local_rank)
-        cap = len(self.train_loader) * opt.batch_size * self.world
-        self.model = Model(opt, self.d_t, self.d_a, self.d_v, bank_capacity=cap)
+        # banks hold one row per training sample of EVERY rank (all-gathered once per epoch)
+        cap = _loader_samples(self.train_loader, opt.batch_size) * self.world
+        self.model = Model(opt, self.d_t, self.d_a, self.d_v, bank_capacity=cap, rank=self.rank)
         other_model_operations(self.model, opt)
         self.engine = self.model.engine
+        self._tails = {}                 # batch size -> engine sharing self.engine's buckets (partial last batch)
+        self._active = self.engine
+        self._want_prefetch = False
         if self.world > 1:      # identical replicas: rank 0's initial parameters everywhere
             mdist.broadcast_(self.engine.main["p"])
             mdist.broadcast_(self.engine.crit["p"])
             self.engine.params_changed()
         self.base_lr = float(opt.learning_rate)
         self.epoch = 0
+        self.task_path = os.path.join("./TaskRuning", str(opt.task_name))                  # Solver.py:107-112
+        self.best_valid_model_path = os.path.join(self.task_path, "best_valid_model.pth.tar")
+        self.best_test_model_path = os.path.join(self.task_path, "best_test_model.pth.tar")
 
     # ------------------------------------------------------------------ learning-rate schedules (Solver.py:153-169)
     def lr_factor(self, epoch: int) -> float:
@@ -60,116 +80,146 @@ class Solver:
         f = self.lr_factor(epoch)
         self.engine.set_lr(self.base_lr * f, self.base_lr * float(self.opt.mi_lr_rate) * f)
 
-    # ------------------------------------------------------------------ the hot path
+    # ------------------------------------------------------------------ engines
     def get_label_from_datas(self, datas):
         return datas[5]                                                       # Solver.py:273-275 ('Dec' layout)
 
-    def _load(self, datas):
-        _, a, v, _, _, labels, feats, _, _, _, _ = datas
-        self.engine.set_batch(feats, a, v, labels)
+    def _engine_for(self, B: int) -> HipEngine:
+        """The engine whose batch size is ``B``: the primary one, or a lazily created sibling sharing its optimizer."""
+        B = int(B)
+        e = self.engine if B == self.engine.cfg.batch else self._tails.get(B)
+        if e is None:
+            if B > self.engine.cfg.batch or B < int(self.opt.k_neighbor):
+                raise _lib.MimrlError(f"batch of {B} rows: need k_neighbor <= B <= --batch_size {self.engine.cfg.batch}")
+            if self.world > 1:
+                raise _lib.MimrlError("data-parallel ranks need full batches (sharded loaders drop the ragged tail)")
+            p = self.engine
+            e = HipEngine(self.opt, self.d_t, self.d_a, self.d_v, seq_len=p.cfg.seq_len, precision=p.precision,
+                          use_graph=bool(p.cfg.use_graph), seed=int(p.cfg.seed), device=p.device,
+                          device_anchors=bool(p.cfg.device_anchors), share=p, batch=B)
+            self._tails[B] = e
+        if e is not self._active:
+            e.params_changed()                      # its bf16 weight images went stale while another handle stepped
+            self._active = e
+        if e.bank_rows != self.engine.bank_rows:
+            e.set_bank_rows(self.engine.bank_rows)
+        if getattr(e, "_prefetch_on", False) != self._want_prefetch:
+            e.set_stage2_prefetch(self._want_prefetch)
+            e._prefetch_on = self._want_prefetch
+        return e
 
-    def _anchors(self, stage):
-        e = self.engine
+    def _load(self, datas) -> HipEngine:
+        _, a, v, _, _, labels, feats, _, _, _, _ = datas
+        e = self._engine_for(len(labels))
+        e.set_batch(feats, a, v, labels)
+        return e
+
+    def _anchors(self, e, stage):
         if e.bank_rows > 0 and not e.cfg.device_anchors:
             e.set_anchors(stage, synth.draw_anchors(e.bank_rows, e.m_anchor, 6))
 
+    def _set_banks(self, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
+        self.engine.set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
+
+    def _prefetch(self, on):
+        self._want_prefetch = bool(on)
+
+    # ------------------------------------------------------------------ the hot path
+    def _stage(self, e, stage):
+        if self.world > 1:
+            mdist.ddp_stage_step(e, stage, self.world)
+        elif stage == 1:
+            e.stage1_step()
+        else:
+            e.stage2_step()
+
     def stage1_step(self, datas=None, draw_anchors=True):
         """Critic update (Solver.py:205-214).  Returns the stage-1 loss as a device scalar."""
-        if datas is not None:
-            self._load(datas)
+        self._prefetch(False)                       # a lone stage call is the sequential schedule
+        e = self._load(datas) if datas is not None else self._engine_for(self._active.cfg.batch)
         if draw_anchors:
-            self._anchors(1)
-        if self.world > 1:
-            mdist.ddp_stage_step(self.engine, 1, self.world)
-        else:
-            self.engine.stage1_step()
-        return self.engine.scalars[_lib.S1_LOSS]
+            self._anchors(e, 1)
+        self._stage(e, 1)
+        return e.scalars[_lib.S1_LOSS]
 
     def stage2_step(self, datas=None, draw_anchors=True):
         """Model update (Solver.py:221-236).  Returns (loss, mis[8], pred[B,1]) as device tensors."""
-        if datas is not None:
-            self._load(datas)
+        self._prefetch(False)
+        e = self._load(datas) if datas is not None else self._engine_for(self._active.cfg.batch)
         if draw_anchors:
-            self._anchors(2)
-        if self.world > 1:
-            mdist.ddp_stage_step(self.engine, 2, self.world)
-        else:
-            self.engine.stage2_step()
-        s = self.engine.scalars
-        return s[_lib.S2_LOSS], s[_lib.S2_MIS:_lib.S2_MIS + 8], self.engine.pred.reshape(-1, 1)
-
-    def _prefetch(self, on):
-        if getattr(self, "_prefetch_on", False) != on:
-            self.engine.set_stage2_prefetch(on)
-            self._prefetch_on = on
+            self._anchors(e, 2)
+        self._stage(e, 2)
+        s = e.scalars
+        return s[_lib.S2_LOSS], s[_lib.S2_MIS:_lib.S2_MIS + 8], e.pred.reshape(-1, 1)
 
     def step(self, datas):
         """One two-stage iteration on one batch: the unit BASELINE.json's metric counts.  Both stages see the same
         batch and stage 1 leaves the main model untouched, so the engine runs the stage-2 forward pass beside stage 1
         (`mimrl_set_stage2_prefetch`); the numbers are those of the sequential order."""
         self._prefetch(True)
-        self._load(datas)
-        self._anchors(1)          # host-drawn anchors (if any) for BOTH stages go up before stage 1: in overlap mode the
-        self._anchors(2)          # stage-2 kNN sampler already runs beside stage 1 (same draw order as the reference)
+        e = self._load(datas)
+        self._anchors(e, 1)       # host-drawn anchors (if any) for BOTH stages go up before stage 1: in overlap mode the
+        self._anchors(e, 2)       # stage-2 kNN sampler already runs beside stage 1 (same draw order as the reference)
         if self.world > 1:
-            l1 = self.stage1_step(draw_anchors=False)
-            l2, mis, pred = self.stage2_step(draw_anchors=False)
-            return l1, l2, mis, pred
-        self.engine.step()        # mimrl_two_stage_step: both stages as one captured graph
-        sc = self.engine.scalars
-        return sc[_lib.S1_LOSS], sc[_lib.S2_LOSS], sc[_lib.S2_MIS:_lib.S2_MIS + 8], self.engine.pred.reshape(-1, 1)
+            mdist.ddp_two_stage_step(e, self.world)
+        else:
+            e.step()              # mimrl_two_stage_step: both stages as one captured graph
+        sc = e.scalars
+        return sc[_lib.S1_LOSS], sc[_lib.S2_LOSS], sc[_lib.S2_MIS:_lib.S2_MIS + 8], e.pred.reshape(-1, 1)
 
     # ------------------------------------------------------------------ Solver.train (Solver.py:194-248)
     def train(self, epoch, train_loader, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
         self.model.train()
-        e = self.engine
         self._prefetch(False)                                                  # epoch-ordered passes: stages see different batches
         self._apply_lr(epoch)
-        e.set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
-        dev = e.device
+        self._set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
+        dev = self.engine.device
         acc = torch.zeros(_lib.NSCALARS, device=dev)
         nb = len(train_loader)
         if epoch > 0 and len(C_F_all) > 0:                                     # Solver.py:200-203: epoch 0 skips stage 1
             for _ in range(self.opt.stage1_n):
                 for datas in self.train_loader:
-                    self.stage1_step(datas)
+                    e = self._load(datas)
+                    self._anchors(e, 1)
+                    self._stage(e, 1)
                     acc[_lib.S1_LOSS] += e.scalars[_lib.S1_LOSS]
-        B = self.opt.batch_size
-        newC = torch.empty(nb * B, 1, device=dev)
-        newF, newT, newA, newV = (torch.empty(nb * B, 128, device=dev) for _ in range(4))
-        preds = torch.empty(nb * B, device=dev)
-        targs = torch.empty(nb * B, device=dev)
-        for i, datas in enumerate(train_loader):
-            self.stage2_step(datas)
-            sl = slice(i * B, (i + 1) * B)
-            newC[sl, 0] = e.labels                                            # Solver.py:223-227 (features of THIS pass)
-            newF[sl], newT[sl], newA[sl], newV[sl] = e.feats[0], e.feats[1], e.feats[2], e.feats[3]
-            preds[sl], targs[sl] = e.pred, e.labels
+        new = {k: [] for k in "CFTAV"}
+        preds, targs = [], []
+        for datas in train_loader:
+            e = self._load(datas)
+            self._anchors(e, 2)
+            self._stage(e, 2)
+            new["C"].append(e.labels.reshape(-1, 1).clone())                   # Solver.py:223-227 (features of THIS pass)
+            for i, k in enumerate("FTAV"):
+                new[k].append(e.feats[i].clone())
+            preds.append(e.pred.clone())
+            targs.append(e.labels.clone())
             acc[32:] += e.scalars[32:]
+        banks = [torch.cat(new[k], 0) for k in "CFTAV"]
         if self.world > 1:                                                    # banks are replicated (SURVEY.md 8e)
-            newC, newF, newT, newA, newV = (mdist.allgather_rows(x, self.world) for x in (newC, newF, newT, newA, newV))
+            banks = [mdist.allgather_rows(x, self.world) for x in banks]
         a = acc.cpu().numpy()                                                 # the ONE read-back of the epoch
-        predictions, targets = preds.cpu().numpy().reshape(-1, 1), targs.cpu().numpy().reshape(-1, 1)
+        predictions, targets = torch.cat(preds).cpu().numpy().reshape(-1, 1), torch.cat(targs).cpu().numpy().reshape(-1, 1)
         train_score = self.get_score_from_result(predictions, targets)
         mis = [float(x) / nb for x in a[_lib.S2_MIS:_lib.S2_MIS + 8]]
-        return (float(a[_lib.S2_LOSS]) / nb, float(a[_lib.S1_LOSS]) / nb, mis, train_score, newC, newF, newT, newA, newV)
+        return (float(a[_lib.S2_LOSS]) / nb, float(a[_lib.S1_LOSS]) / nb, mis, train_score, *banks)
 
     # ------------------------------------------------------------------ Solver.evaluate (Solver.py:250-270)
     def evaluate(self, valid_loader, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
         self.model.eval()
-        e = self.engine
-        e.set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
-        acc = torch.zeros(_lib.NSCALARS, device=e.device)
+        self._prefetch(False)
+        self._set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
+        acc = torch.zeros(_lib.NSCALARS, device=self.engine.device)
         preds, targs, feats = [], [], []
         for datas in valid_loader:
-            self._load(datas)
-            self._anchors(2)
+            e = self._load(datas)
+            self._anchors(e, 2)
             e.forward(train=False, with_losses=True)
             acc += e.scalars
             preds.append(e.pred.clone())
             targs.append(e.labels.clone())
             if self.opt.save_best_features:
-                feats.append(e.feats.clone())
+                feats.append([f.cpu() for f in e.feats.clone()])
         a = acc.cpu().numpy()
         nb = len(valid_loader)
         predictions = torch.cat(preds).cpu().numpy().reshape(-1, 1)
@@ -187,35 +237,89 @@ class Solver:
 
     # ------------------------------------------------------------------ cold path
     def get_score_from_result(self, predictions, targets):
+        """mae / corr of Utils.calc_metrics (Utils.py:135-136); the class-accuracy metrics are outside the hot path."""
         p, t = predictions.reshape(-1).astype(np.float64), targets.reshape(-1).astype(np.float64)
         mae = float(np.abs(p - t).mean())
         corr = float(np.corrcoef(p, t)[0, 1]) if p.std() > 0 and t.std() > 0 else 0.0
         return {"mae": mae, "corr": corr}
 
     def current_result_better(self, best, current):
-        return best is None or current["mae"] < best["mae"]
+        return best is None or current["mae"] < best["mae"]                                      # Solver.py:425-433
+
+    # checkpoints: the reference's keys (Solver.py:57-62); 'model' = state_dict with the reference's parameter names,
+    # the optimizers as flat Adam-moment buckets + device step counters (a complete, resumable optimizer state)
+    def checkpoint(self, epoch):
+        st = self.engine.optimizer_state()
+        cpu = lambda d: {k: v.detach().cpu() for k, v in d.items()}
+        return {"epoch": epoch, "model": cpu(self.model.state_dict()),
+                "optim_main": cpu({"m": st["main_m"], "v": st["main_v"], "step": st["counters"][1:2], "lr": st["lr_main"]}),
+                "optim_vmi": cpu({"m": st["crit_m"], "v": st["crit_v"], "step": st["counters"][2:3], "lr": st["lr_critic"]}),
+                "rng_step": st["counters"][0:1].cpu()}
+
+    def load_checkpoint(self, ck):
+        ck = torch.load(ck, map_location="cpu") if isinstance(ck, (str, os.PathLike)) else ck
+        self.model.load_state_dict(ck["model"])
+        cnt = torch.cat([ck["rng_step"].reshape(1), ck["optim_main"]["step"].reshape(1), ck["optim_vmi"]["step"].reshape(1),
+                         torch.zeros(1, dtype=torch.int32)]).to(torch.int32)
+        self.engine.load_optimizer_state({"main_m": ck["optim_main"]["m"], "main_v": ck["optim_main"]["v"],
+                                          "crit_m": ck["optim_vmi"]["m"], "crit_v": ck["optim_vmi"]["v"], "counters": cnt,
+                                          "lr_main": ck["optim_main"]["lr"], "lr_critic": ck["optim_vmi"]["lr"]})
+        return int(ck["epoch"])
+
+    def save_results(self, best_predictions, best_targets, best_features, best_valid_state, best_test_state):
+        """Solver.py:513-531."""
+        os.makedirs(self.task_path, exist_ok=True)
+        for name, arr in (("predictions_val", best_predictions[0]), ("predictions_test", best_predictions[1]),
+                          ("predictions_test_for_valid", best_predictions[2]), ("targets_val", best_targets[0]),
+                          ("targets_test", best_targets[1])):
+            np.save(os.path.join(self.task_path, name + ".npy"), arr)
+        if self.opt.save_best_features:
+            import pickle
+            for name, f in (("features_val", best_features[0]), ("features_test", best_features[1]),
+                            ("features_test_for_valid", best_features[2])):
+                with open(os.path.join(self.task_path, name + ".pkl"), "wb") as fh:
+                    pickle.dump(f, fh)
+        torch.save(best_valid_state, self.best_valid_model_path)
+        torch.save(best_test_state, self.best_test_model_path)
 
     def solve(self):
-        """Solver.py:38-105 (epoch loop; logging/saving reduced to the essentials)."""
+        """Solver.py:38-105: epoch loop, best-valid / best-test tracking, checkpoints and prediction files (rank 0).
+        TensorBoard and the class-accuracy metric tables are outside the hot path."""
         if self.rank == 0:
-            task_path = os.path.join("./TaskRuning", self.opt.task_name)
-            os.makedirs(task_path, exist_ok=True)
-            set_logger(os.path.join(task_path, "Running.log"))
+            os.makedirs(self.task_path, exist_ok=True)
+            set_logger(os.path.join(self.task_path, "Running.log"))
             log_message(str(self.opt))
         banks = ([], [], [], [], [])
-        best = [None, None]
+        best_score, best_predictions, best_features = [None, None, None], [None, None, None], [None, None, None]
+        best_targets = [None, None]
+        best_valid_state = best_test_state = None
         for epoch in range(self.opt.epochs_num):
+            self.epoch = epoch
             r = self.train(epoch, self.train_loader, *banks)
             train_loss, train_loss_mi, train_mis, train_score = r[:4]
             banks = r[4:]
-            val_loss, val_mis, val_score, *_ = self.evaluate(self.valid_loader, *banks)
-            test_loss, test_mis, test_score, *_ = self.evaluate(self.test_loader, *banks)
-            if self.current_result_better(best[0], val_score):
-                best[0], best[1] = val_score, test_score
+            val_loss, val_mis, val_score, val_pred, val_targ, val_feat = self.evaluate(self.valid_loader, *banks)
+            test_loss, test_mis, test_score, test_pred, test_targ, test_feat = self.evaluate(self.test_loader, *banks)
+            if self.current_result_better(best_score[0], val_score):
+                if self.rank == 0:
+                    best_valid_state = self.checkpoint(epoch)
+                best_score[0], best_predictions[0], best_features[0] = val_score, val_pred, val_feat
+                best_score[2], best_predictions[2], best_features[2] = test_score, test_pred, test_feat
+                best_targets[0] = val_targ
+            if self.current_result_better(best_score[1], test_score):
+                if self.rank == 0:
+                    best_test_state = self.checkpoint(epoch)
+                best_score[1], best_predictions[1], best_features[1] = test_score, test_pred, test_feat
+                best_targets[1] = test_targ
             if self.rank == 0:
-                log_message(f"Epoch {epoch:3d} | train loss {train_loss:.4f} mi-loss {train_loss_mi:.4f} mae {train_score['mae']:.4f} "
-                            f"| valid loss {val_loss:.4f} mae {val_score['mae']:.4f} | test loss {test_loss:.4f} mae {test_score['mae']:.4f} "
-                            f"| mi ft/fa/fv/in/st/sa/sv/cp " + "/".join(f"{m:.4f}" for m in train_mis))
+                log_message(f"Epoch:[{epoch + 1:3d}] || TrainLoss:[{train_loss:.3f}] TrainMILoss:[{train_loss_mi:.3f}] "
+                            f"TrainMI_ft/fa/fv/in/st/sa/sv/cp:[" + "/".join(f"{m:.3f}" for m in train_mis) + "] "
+                            f"Train_mae:[{train_score['mae']:6.3f}] || ValLoss:[{val_loss:.3f}] Val_mae:[{val_score['mae']:6.3f}] "
+                            f"Val_corr:[{val_score['corr']:6.3f}] || TestLoss:[{test_loss:.3f}] Test_mae:[{test_score['mae']:6.3f}] "
+                            f"Test_corr:[{test_score['corr']:6.3f}]")
         if self.rank == 0:
-            log_message(f"Training complete. best valid {best[0]} / test at best valid {best[1]}")
-        return best
+            log_message("Training complete.")
+            for tag, sc in (("Best Valid Score", best_score[0]), ("Test Score at Best Valid", best_score[2]), ("Best Test Score", best_score[1])):
+                log_message(tag + " " + " ".join(f"{k}:[{v:6.3f}]" for k, v in (sc or {}).items()))
+            self.save_results(best_predictions, best_targets, best_features, best_valid_state, best_test_state)
+        return best_score

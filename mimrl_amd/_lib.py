@@ -51,7 +51,7 @@ class Buffers(C.Structure):
     _fields_ = [(n, _FP) for n in (
         "main_p", "main_g", "main_m", "main_v", "crit_p", "crit_g", "crit_m", "crit_v",
         "text", "audio", "video", "labels", "bank_c", "bank_f", "bank_t", "bank_a", "bank_v",
-        "anchors", "lr_main", "lr_critic", "pred", "feats", "scalars")]
+        "anchors", "lr_main", "lr_critic", "pred", "feats", "scalars", "counters")]
 
 
 _lib = None
@@ -119,10 +119,10 @@ def check(rc: int) -> int:
 
 
 def make_cfg(opt, d_t: int, d_a: int, d_v: int, seq_len: int = None, bank_capacity: int = 0, precision: str = "fp32",
-             use_graph: bool = False, seed: int = 0, device_anchors: bool = False) -> Cfg:
+             use_graph: bool = False, seed: int = 0, device_anchors: bool = False, batch: int = None) -> Cfg:
     """Translate the reference's ``opt`` Namespace (Parameters.py) into the C config."""
     c = Cfg()
-    c.batch = int(opt.batch_size)
+    c.batch = int(batch if batch is not None else opt.batch_size)
     c.time_len = int(opt.time_len)
     c.seq_len = int(seq_len if seq_len is not None else opt.time_len)
     c.d_t, c.d_a, c.d_v, c.d_common = int(d_t), int(d_a), int(d_v), int(opt.d_common)

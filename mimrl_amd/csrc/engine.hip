@@ -163,7 +163,8 @@ struct mimrl_handle {
   // workspace
   char* ws = nullptr;
   size_t ws_bytes = 0, ws_used = 0;
-  int* d_ints = nullptr;               // [0] rng step, [1] adam main step, [2] adam critic step
+  int* d_ints = nullptr;               // [0] rng step, [1] adam main step, [2] adam critic step (= bufs.counters when the caller owns them)
+  int* d_ints_own = nullptr;           // private fallback storage
   float* d_consts = nullptr;           // coef1[11] coef2[8] gs_mi[2][5] g_bce[2][6] g_cmi[2][6]
   int *lens[2] = {nullptr, nullptr};
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
@@ -530,7 +531,8 @@ int mimrl_handle::carve_fwd(size_t* gmax_out) {
 int mimrl_handle::carve() {
   const size_t B = cfg.batch, T = cfg.seq_len, D = cfg.d_common;
   const size_t BT_ = B * T;
-  MX(take(&d_ints, 16));
+  MX(take(&d_ints_own, 16));
+  d_ints = d_ints_own;
   MX(take(&d_consts, 64));
   size_t gmax = 0;
   MX(carve_fwd(&gmax));
@@ -2078,6 +2080,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
   h->bufs = *b;
   h->bound = true;
   h->img_valid = false;
+  h->d_ints = b->counters ? b->counters : h->d_ints_own;   // graphs are rebuilt below, so the new address is baked in
   for (int s = 0; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }

@@ -2,23 +2,35 @@
 section 0 item 8).  Batches use the reference's ``mosi_Dec`` 11-tuple layout (Customization.py:46, Solver.py:273-275)
 with one substitution: slot 6 (``bert_sentences``) carries the precomputed BERT last-hidden-state features
 [B,T,d_t] instead of token ids -- BERT itself is outside the hot path."""
-import numpy as np
+import logging
+
 import torch
 
 from . import synth
 
 
 class SyntheticLoader:
-    def __init__(self, n, batch_size, T, d_t=768, d_a=74, d_v=35, seed=0, drop_last=True, device=None, ragged=False):
+    """In-memory loader.  ``rank``/``world`` shard the samples by stride (rank, rank+world, ...) the way a
+    DistributedSampler would, so that data-parallel replicas see disjoint data; a sharded loader always drops the ragged
+    tail so that every rank runs the same number of (full) batches and collectives stay matched.  ``drop_last=False`` (the
+    reference's default, Parameters.py:21) yields a shorter last batch."""
+
+    def __init__(self, n, batch_size, T, d_t=768, d_a=74, d_v=35, seed=0, drop_last=False, device=None, ragged=False,
+                 rank=0, world=1, pin=False):
         t, a, v, y = synth.synthetic_batch(n, T, d_t, d_a, d_v, seed=seed, ragged=ragged)
-        dev = device
-        self.t, self.a, self.v = (torch.from_numpy(x).to(dev) if dev else torch.from_numpy(x) for x in (t, a, v))
-        self.y = torch.from_numpy(y).to(dev) if dev else torch.from_numpy(y)
-        self.n, self.bs, self.drop_last = n, batch_size, drop_last
-        self.T = T
+        if world > 1:
+            per = n // world
+            t, a, v, y = (x[rank::world][:per] for x in (t, a, v, y))
+            drop_last = True
+        mk = lambda x: torch.from_numpy(x.copy()).to(device) if device else (torch.from_numpy(x.copy()).pin_memory() if pin else torch.from_numpy(x.copy()))
+        self.t, self.a, self.v, self.y = mk(t), mk(a), mk(v), mk(y)
+        self.n, self.bs, self.drop_last, self.T = int(self.y.shape[0]), batch_size, drop_last, T
 
     def __len__(self):
         return self.n // self.bs if self.drop_last else (self.n + self.bs - 1) // self.bs
+
+    def num_samples(self):
+        return len(self) * self.bs if self.drop_last else self.n
 
     def __iter__(self):
         for i in range(len(self)):
@@ -29,13 +41,28 @@ class SyntheticLoader:
                    None, None)
 
 
-def get_data_loader(opt):
-    """-> (train, valid, test, d_t, d_a, d_v) like DataLoaderUniversal.get_data_loader (DataLoaderUniversal.py:10-95);
-    only ``--dataset synthetic`` exists here."""
+def get_data_loader(opt, rank=0, world=1):
+    """-> (train, valid, test, d_t, d_a, d_v) like DataLoaderUniversal.get_data_loader (DataLoaderUniversal.py:10-95).
+    Only synthetic data exists here: ``--dataset synthetic`` is the honest name; the reference's ``mosi_Dec`` / ``mosei_Dec``
+    names are accepted (they select the 'Dec' batch layout) but produce SYNTHETIC data too, and say so loudly.
+    The training set is sharded over data-parallel ranks; valid / test are replicated (every rank evaluates all of it)."""
     if opt.dataset not in ("synthetic", "mosi_Dec", "mosei_Dec"):
         raise NotImplementedError(f"--dataset {opt.dataset}: only synthetic MOSI/MOSEI-shaped data is available "
                                   f"(the reference's pickles and DataLoaderLocal are not shipped)")
+    if opt.dataset != "synthetic":
+        logging.warning("--dataset %s: the %s pickles are not shipped; training on SYNTHETIC %s-shaped random triples "
+                        "(scores are NOT dataset results). Use --dataset synthetic to silence this.", opt.dataset,
+                        opt.dataset, opt.dataset.split("_")[0])
     n = int(getattr(opt, "synthetic_n", 1284))
     d_t, d_a, d_v = int(getattr(opt, "d_t", 768)), int(getattr(opt, "d_a", 74)), int(getattr(opt, "d_v", 35))
-    mk = lambda m, seed: SyntheticLoader(m, opt.batch_size, opt.time_len, d_t, d_a, d_v, seed=seed, drop_last=True)
-    return mk(n, opt.seed), mk(max(n // 6, opt.batch_size), opt.seed + 1), mk(max(n // 3, opt.batch_size), opt.seed + 2), d_t, d_a, d_v
+    drop = bool(getattr(opt, "drop_last", False))
+    pin = torch.cuda.is_available()
+    k = int(getattr(opt, "k_neighbor", 2))
+
+    def mk(m, seed, r, w):
+        if 0 < m % opt.batch_size < k:      # a last batch with fewer than k_neighbor rows has no kNN product sample (the
+            m -= m % opt.batch_size          # reference's sklearn call raises on it, Model.py:85-86): do not generate one
+        return SyntheticLoader(m, opt.batch_size, opt.time_len, d_t, d_a, d_v, seed=seed, drop_last=drop, rank=r, world=w, pin=pin)
+
+    return (mk(n, opt.seed, rank, world), mk(max(n // 6, opt.batch_size), opt.seed + 1, 0, 1),
+            mk(max(n // 3, opt.batch_size), opt.seed + 2, 0, 1), d_t, d_a, d_v)

@@ -56,6 +56,12 @@ def ddp_stage_step(engine, stage: int, world: int):
     engine.stage_apply(stage)
 
 
+def ddp_two_stage_step(engine, world: int):
+    """Solver.step() under data parallelism: stage 1 then stage 2, each grads -> all-reduce(mean) -> clip+Adam."""
+    ddp_stage_step(engine, 1, world)
+    ddp_stage_step(engine, 2, world)
+
+
 def allgather_rows(x: torch.Tensor, world: int) -> torch.Tensor:
     """Concatenate per-rank bank rows (once per epoch, off the hot path)."""
     if world <= 1:

@@ -24,29 +24,40 @@ class HipEngine:
 
     def __init__(self, opt, d_t: int, d_a: int, d_v: int, seq_len: Optional[int] = None, bank_capacity: int = 0,
                  precision: str = "fp32", use_graph: bool = False, seed: int = 0, device: Optional[torch.device] = None,
-                 device_anchors: bool = False):
+                 device_anchors: bool = False, share: Optional["HipEngine"] = None, batch: Optional[int] = None):
+        """``share``: another engine whose parameter / gradient / Adam buckets, step counters, learning rates and feature
+        banks this one binds too (same optimizer, different batch size: the partial last batch of a loader with
+        drop_last=False, Parameters.py:21).  ``batch`` overrides ``opt.batch_size``."""
         if not torch.cuda.is_available():
             raise MimrlError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         torch.cuda.set_device(self.device)
         self.opt = opt
-        self.cfg = _lib.make_cfg(opt, d_t, d_a, d_v, seq_len, bank_capacity, precision, use_graph, seed, device_anchors)
+        if share is not None:
+            bank_capacity = share.cfg.bank_capacity
+        self.cfg = _lib.make_cfg(opt, d_t, d_a, d_v, seq_len, bank_capacity, precision, use_graph, seed, device_anchors, batch=batch)
+        self.precision = precision
         check(self.lib.mimrl_device_check())
         self.entries, (n_main, n_crit) = _lib.layout_entries(self.cfg)
         f32 = dict(dtype=torch.float32, device=self.device)
         B, T = self.cfg.batch, self.cfg.seq_len
         self.m_anchor = B // self.cfg.k_neighbor
         z = lambda *s: torch.zeros(*s, **f32)
-        self.main = {k: z(max(n_main, 1)) for k in "pgmv"}
-        self.crit = {k: z(max(n_crit, 1)) for k in "pgmv"}
+        self.shared = share is not None
+        self.main = share.main if share else {k: z(max(n_main, 1)) for k in "pgmv"}
+        self.crit = share.crit if share else {k: z(max(n_crit, 1)) for k in "pgmv"}
+        if share and (share.main["p"].numel() != max(n_main, 1) or share.crit["p"].numel() != max(n_crit, 1)):
+            raise MimrlError("engines that share buckets must have the same parameter layout")
         self.text, self.audio, self.video = z(B, T, d_t), z(B, T, d_a), z(B, T, d_v)
         self.labels = z(B)
         cap = max(int(bank_capacity), 1)
-        self.bank = {"C": z(cap, 1), "F": z(cap, 128), "T": z(cap, 128), "A": z(cap, 128), "V": z(cap, 128)}
+        self.bank = share.bank if share else {"C": z(cap, 1), "F": z(cap, 128), "T": z(cap, 128), "A": z(cap, 128), "V": z(cap, 128)}
         self.anchors = torch.zeros(2, 6, max(self.m_anchor, 1), dtype=torch.int32, device=self.device)
-        self.lr_main = torch.full((1,), float(opt.learning_rate), **f32)
-        self.lr_critic = torch.full((1,), float(opt.learning_rate) * float(opt.mi_lr_rate), **f32)   # Solver.py:140-142
+        self.lr_main = share.lr_main if share else torch.full((1,), float(opt.learning_rate), **f32)
+        self.lr_critic = share.lr_critic if share else torch.full((1,), float(opt.learning_rate) * float(opt.mi_lr_rate), **f32)   # Solver.py:140-142
+        # [rng step, Adam step (main), Adam step (critics), -]: optimizer / RNG state owned here like m and v
+        self.counters = share.counters if share else torch.zeros(4, dtype=torch.int32, device=self.device)
         self.pred = z(B)
         self.feats = z(4, B, 128)
         self.scalars = z(_lib.NSCALARS)
@@ -74,6 +85,7 @@ class HipEngine:
         b.anchors = _ptr(self.anchors)
         b.lr_main, b.lr_critic = _ptr(self.lr_main), _ptr(self.lr_critic)
         b.pred, b.feats, b.scalars = _ptr(self.pred), _ptr(self.feats), _ptr(self.scalars)
+        b.counters = _ptr(self.counters)
         self._buffers = b
         check(self.lib.mimrl_bind(self.handle, C.byref(b)))
 
@@ -126,6 +138,22 @@ class HipEngine:
                 self.bank[k][:n].copy_(src.reshape(n, -1), non_blocking=True)
         self.bank_rows = n
         check(self.lib.mimrl_set_bank_rows(self.handle, n))
+
+    def set_bank_rows(self, n: int):
+        """Number of valid rows in the (possibly shared) bank tensors."""
+        self.bank_rows = int(n)
+        check(self.lib.mimrl_set_bank_rows(self.handle, int(n)))
+
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        """Both Adam optimizers (Solver.py:57-62 'optim_main' / 'optim_vmi'): moments as flat buckets + the step counters."""
+        return {"main_m": self.main["m"].clone(), "main_v": self.main["v"].clone(), "crit_m": self.crit["m"].clone(),
+                "crit_v": self.crit["v"].clone(), "counters": self.counters.clone(), "lr_main": self.lr_main.clone(),
+                "lr_critic": self.lr_critic.clone()}
+
+    def load_optimizer_state(self, st: Dict[str, torch.Tensor]):
+        for k, dst in (("main_m", self.main["m"]), ("main_v", self.main["v"]), ("crit_m", self.crit["m"]), ("crit_v", self.crit["v"]),
+                       ("counters", self.counters), ("lr_main", self.lr_main), ("lr_critic", self.lr_critic)):
+            dst.copy_(torch.as_tensor(st[k]).to(dst.dtype).reshape(dst.shape))
 
     def set_anchors(self, stage: int, anchors):
         """anchors: int array [6, B//k] -- the six ``np.random.choice`` draws of one stage (Model.py:81)."""

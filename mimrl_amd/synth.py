@@ -38,10 +38,11 @@ def portable_state(named_shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: in
     return {n: portable_tensor(n, s, seed) for n, s in named_shapes}
 
 
-def default_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
+def default_tensor(name: str, shape: Tuple[int, ...], seed: int = 0, fan_in: int = None) -> np.ndarray:
     """Distribution-faithful default init of the reference modules:
     nn.Linear / nn.GRU uniform(+-1/sqrt(fan_in | H)); LayerNorm 1/0; critic-tower biases 0
-    (VMI.py:47-51); every ``weight_hh`` orthogonal (Customization.py:18-21)."""
+    (VMI.py:47-51); every ``weight_hh`` orthogonal (Customization.py:18-21).  ``fan_in``: for a bias, the input width
+    of its layer's weight (nn.Linear draws the bias from +-1/sqrt(in_features)); see ``default_state``."""
     g = _rng("default:" + name, seed)
     shape = tuple(int(s) for s in shape)
     parts = name.split(".")
@@ -57,11 +58,26 @@ def default_tensor(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarr
     if parts[0].startswith("rnn_"):
         bound = 1.0 / np.sqrt(128.0)
     else:
-        fan_in = int(np.prod(shape[1:])) if len(shape) >= 2 else None
-        if fan_in is None:                       # bias: fan_in of its weight is unknown here -> use own length
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+        elif fan_in is None:                     # bias without its weight's shape: fall back to its own length
             fan_in = shape[0]
         bound = 1.0 / np.sqrt(max(fan_in, 1))
     return g.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def default_state(named_shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0) -> Dict[str, np.ndarray]:
+    """``default_tensor`` for a whole model: every ``X.bias`` gets the fan-in of ``X.weight``."""
+    named_shapes = [(n, tuple(int(d) for d in s)) for n, s in named_shapes]
+    shapes = dict(named_shapes)
+    out = {}
+    for n, s in named_shapes:
+        fi = None
+        if n.endswith(".bias") and n[:-5] + ".weight" in shapes:
+            w = shapes[n[:-5] + ".weight"]
+            fi = int(np.prod(w[1:])) if len(w) >= 2 else None
+        out[n] = default_tensor(n, s, seed, fan_in=fi)
+    return out
 
 
 def synthetic_batch(B: int, T: int, d_t: int = 768, d_a: int = 74, d_v: int = 35, seed: int = 0,

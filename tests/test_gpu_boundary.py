@@ -1,0 +1,219 @@
+"""-m gpu: the reference-shaped Python surface (Solver / Model / Customization / Main) on the device -- the boundary a
+user of the reference actually calls -- against fixtures produced by the REAL reference's own
+Solver.train / Solver.evaluate (tests/golden/epoch_*.npz) and against the oracle."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mimrl_amd import _lib, synth
+from mimrl_amd.Customization import compute_custumized_loss, compute_outputs_from_model, other_model_operations
+from mimrl_amd.Model import Model
+from mimrl_amd.Solver import Solver
+from oracle import mimrl_ref as R
+from tests.epoch_helpers import DrawReplay, bands, epoch_case
+from tests.gpu_helpers import assert_close
+from tests.helpers import case, load_golden, oracle_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def as_datas(batch):
+    """(t, a, v, y) -> the reference's 'Dec' 11-tuple (Customization.py:46) with BERT features in slot 6."""
+    t, a, v, y = batch
+    ones = torch.ones(a.shape[0], a.shape[1], dtype=torch.long)
+    return (None, a, v, None, None, y.reshape(-1, 1), t, torch.zeros_like(ones), ones, None, None)
+
+
+def solver_opt(opt, **kw):
+    o = copy.copy(opt)
+    o.task_name, o.seed, o.epochs_num, o.save_best_features = kw.pop("task_name", "pytest"), 0, 1, False
+    o.precision, o.no_graph, o.host_anchors = kw.pop("precision", "fp32"), kw.pop("no_graph", True), kw.pop("host_anchors", True)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+@pytest.mark.parametrize("name", ["epoch_tiny", "epoch_tail"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_solver_train_evaluate_match_reference_solver(name, use_graph, monkeypatch):
+    """mimrl_amd.Solver.train / evaluate over several epochs == the reference's Solver.train / evaluate
+    (Solver.py:194-270): stage1_n critic passes, epoch-0 skip, bank hand-over, eval-mode stage-2 loss with banks,
+    multi-step lr schedule, and (epoch_tail) a partial last batch under drop_last=False (Parameters.py:21)."""
+    c, opt, sets, g = epoch_case(name)
+    loaders = tuple([as_datas(b) for b in sets[k]] for k in ("train", "valid", "test")) + (768, 74, 35)
+    sol = Solver(solver_opt(opt, no_graph=not use_graph), loaders)
+    sol.model.load_state_dict(oracle_params(opt, c["seed"]))
+    draw = DrawReplay(g)
+    monkeypatch.setattr(synth, "draw_anchors", lambda N, m, calls=6: draw(N, m))   # the reference's recorded np.random.choice draws
+    banks = ([], [], [], [], [])
+    for ep in range(c["epochs"]):
+        rt, at, aat = bands(ep)
+        r = sol.train(ep, sol.train_loader, *banks)
+        banks = r[4:]
+        assert_close(r[0], g[f"ep{ep}_train_loss"], rt, at, f"ep{ep} train loss")
+        assert_close(r[1], g[f"ep{ep}_train_loss_mi"], rt, at, f"ep{ep} stage-1 loss")
+        assert_close(r[2], g[f"ep{ep}_train_mis"], rt, at, f"ep{ep} MI means")
+        assert_close(r[3]["mae"], g[f"ep{ep}_train_mae"], rt, at, f"ep{ep} train mae")
+        for k, bk in zip("CFTAV", banks):
+            assert tuple(bk.shape) == g[f"ep{ep}_bank_{k}"].shape, (k, bk.shape)
+            assert_close(bk.cpu().numpy(), g[f"ep{ep}_bank_{k}"], rt, aat, f"ep{ep} bank {k}")
+        for tag, ld in (("valid", sol.valid_loader), ("test", sol.test_loader)):
+            e = sol.evaluate(ld, *banks)
+            assert_close(e[0], g[f"ep{ep}_{tag}_loss"], rt, at, f"ep{ep} {tag} loss")
+            assert_close(e[1], g[f"ep{ep}_{tag}_mis"], rt, at, f"ep{ep} {tag} MI means")
+            assert_close(e[3].reshape(-1), g[f"ep{ep}_{tag}_pred"], rt, aat, f"ep{ep} {tag} predictions")
+            assert_close(e[2]["mae"], g[f"ep{ep}_{tag}_mae"], rt, at, f"ep{ep} {tag} mae")
+    assert draw.done(), "the reference drew more anchors than Solver.train/evaluate consumed"
+    names = [str(n) for n in g["final_names"]]
+    ps = np.array([sol.model.state_dict()[n].double().sum().item() for n in names])
+    np.testing.assert_allclose(ps, g["final_psum"], rtol=1e-3, atol=0.05)
+    if name == "epoch_tail":
+        assert list(sol._tails) == [4], "the partial last batch (36 = 4*8 + 4) runs on a second handle of batch 4"
+
+
+@pytest.mark.parametrize("precision,use_graph", [("fp32", False), ("bf16", True)])
+def test_solver_step_equals_engine_step_and_oracle(precision, use_graph, monkeypatch):
+    """Solver(opt, loaders).step(datas) x3 == HipEngine.step() x3 (bitwise: same library calls) == the oracle."""
+    from mimrl_amd.engine import HipEngine
+    c, opt, batch, banks = case("tiny_sep")
+    g = load_golden("tiny_sep")
+    anchors = g["anchors"]
+    datas = as_datas(batch)
+    sol = Solver(solver_opt(opt, precision=precision, no_graph=not use_graph), ([datas] * 5, [datas], [datas], 768, 74, 35))
+    p = oracle_params(opt, c["seed"])
+    sol.model.load_state_dict(p)
+    sol.engine.set_banks(*(banks[k] for k in "CFTAV"))
+    eng = HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision=precision, use_graph=use_graph)
+    eng.load_params(p)
+    eng.set_batch(*batch)
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    eng.set_stage2_prefetch(True)
+    import itertools
+    seq = itertools.chain([anchors[it, st] for it in range(3) for st in (0, 1)], itertools.repeat(anchors[0, 0]))
+    monkeypatch.setattr(synth, "draw_anchors", lambda N, m, calls=6: next(seq))
+    crit = [n for n in p if R.is_critic_param(n)]
+    main = [n for n in p if not R.is_critic_param(n)]
+    adam_v, adam_m = R.AdamState(p, crit), R.AdamState(p, main)
+    for it in range(3):
+        l1, l2, mis, pred = sol.step(datas)
+        eng.set_anchors(1, anchors[it, 0]); eng.set_anchors(2, anchors[it, 1])
+        eng.step()
+        s = eng.read_scalars()
+        if precision == "fp32" and it == 0:   # same library calls; reductions / weight gradients use float atomics (last-ulp order noise,
+            assert_close(float(l1), s[_lib.S1_LOSS], 2e-6, 1e-7, "Solver.step vs HipEngine.step, stage-1 loss")     # amplified by later updates)
+            assert_close(float(l2), s[_lib.S2_LOSS], 2e-6, 1e-7, "Solver.step vs HipEngine.step, stage-2 loss")
+            assert_close(pred.reshape(-1).cpu().numpy(), eng.pred.cpu().numpy(), 2e-6, 1e-7, "predictions")
+        r1, r2 = R.two_stage_step(p, opt, adam_v, adam_m, batch, banks, anchors[it, 0], anchors[it, 1])
+        rt, at = ((1e-3, 2e-5) if it == 0 else (3e-2, 5e-3)) if precision == "fp32" else (3e-2, 2e-2)
+        assert_close(float(l1), r1["loss"].item(), rt, at, f"it{it} stage-1 loss vs oracle")
+        assert_close(float(l2), r2["loss"].item(), rt, at, f"it{it} stage-2 loss vs oracle")
+        # (bf16 after an update: a CMI term is a difference of two log-ratio sums over 8 samples, one logit moving by 2^-8 shows)
+        mi_at = 5e-5 if (it == 0 and precision == "fp32") else (3e-2 if precision == "fp32" or it == 0 else 0.15)
+        assert_close(mis.cpu().numpy(), [m.item() for m in r2["mis"]], rt, mi_at, f"it{it} MI terms")
+    # usability: a lone stage call after step() must not trip over the overlap mode (it switches back to sequential)
+    sol.stage1_step(datas)
+    sol.stage2_step(datas)
+    sol.stage2_step(datas)
+    assert np.isfinite(sol.engine.read_scalars()).all()
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_sum"])
+def test_model_and_customization_surface(name):
+    """Model.forward(return_features=True), compute_vmi_loss_stage1/2, compute_outputs_from_model and
+    compute_custumized_loss (incl. the empty-bank rule, Customization.py:97-98,105-106) against the reference goldens."""
+    c, opt, batch, banks = case(name)
+    g = load_golden(name)
+    o = solver_opt(opt)
+    np.random.seed(0)
+    model = Model(o, 768, 74, 35, bank_capacity=c["N"], init="portable")
+    assert other_model_operations(model, o) is None
+    model.load_state_dict(oracle_params(opt, c["seed"]))
+    assert set(n for n, _ in model.named_parameters()) == set(oracle_params(opt, c["seed"]))
+    model.eval()
+    out = model(batch[0], None, None, batch[1], batch[2], return_features=True)
+    assert len(out) == 5 and tuple(out[0].shape) == (c["B"], 1)
+    for val, k in zip(out, ["pred", "F_F", "T_F", "A_F", "V_F"]):
+        assert_close(val.cpu().numpy().reshape(g["fwd_" + k].shape), g["fwd_" + k], 1e-3, 2e-5, k)
+    assert len(model(batch[0], None, None, batch[1], batch[2])) == 1
+    # the glue functions, reference signatures
+    model.train()
+    datas = as_datas(batch)
+    outputs = compute_outputs_from_model(model, datas, o)
+    labels = datas[5]
+    task = (outputs[0].reshape(-1) - labels.reshape(-1).cuda()).abs().mean()
+    empty = ([], [], [], [], [])
+    l1, mis1 = compute_custumized_loss(model, task, outputs, labels, None, o, 1, *empty)
+    l2, mis2 = compute_custumized_loss(model, task, outputs, labels, None, o, 2, *empty)
+    assert float(l1) == 0.0 and float(l2) == float(task) and all(float(m) == 0 for m in mis2) and len(mis2) == 8
+    assert_close(float(l2), g["e0_stage2_loss"], 1e-3, 1e-6, "epoch-0 stage-2 loss")
+    bank_t = tuple(banks[k] for k in "CFTAV")
+    anchors = g["anchors"][0]
+    seq = iter([anchors[0], anchors[1]])
+    real = synth.draw_anchors
+    synth.draw_anchors = lambda N, m, calls=6: next(seq)
+    try:
+        l1, mis1 = compute_custumized_loss(model, task, outputs, labels, None, o, 1, *bank_t)
+        s1 = model.engine.read_scalars().copy()
+        mis_a, losses_a = model.compute_vmi_loss_stage2(outputs[0], labels, *outputs[1:], *bank_t)
+    finally:
+        synth.draw_anchors = real
+    assert_close(float(l1), g["traj_s1_loss"][0], 1e-3, 1e-5, "stage-1 loss through compute_custumized_loss")
+    assert_close(s1[_lib.S1_MIS:_lib.S1_MIS + 11], g["traj_s1_mis"][0], 1e-3, 2e-5, "11 stage-1 MI / CMI values")
+    assert len(mis1) == 11 and len(mis_a) == 8 and len(losses_a) == 8
+    # stage 2 here is evaluated BEFORE any critic update (the golden trajectory applies stage 1 first): compare with the oracle
+    p = oracle_params(opt, c["seed"])
+    with torch.no_grad():
+        _, mis_o, *_ = R.stage_loss(p, opt, 2, batch, banks, anchors[1])
+    assert_close([float(m) for m in mis_a], [float(m) for m in mis_o], 1e-3, 5e-5, "8 stage-2 MI terms")
+    model.engine.close()
+
+
+def test_checkpoint_round_trip(tmp_path, monkeypatch):
+    """Solver.checkpoint / load_checkpoint: parameters, both Adam moment buckets and the device step counters
+    (Solver.py:57-62: 'model', 'optim_main', 'optim_vmi') -- save, continue; reload, continue: identical results."""
+    c, opt, batch, banks = case("tiny_sep")
+    datas = as_datas(batch)
+    loaders = ([datas] * 5, [datas], [datas], 768, 74, 35)
+    o = solver_opt(opt, host_anchors=False)
+    sol = Solver(o, loaders)
+    sol.model.load_state_dict(oracle_params(opt, c["seed"]))
+    sol.engine.set_banks(*(banks[k] for k in "CFTAV"))
+    for _ in range(3):
+        sol.step(datas)
+    ck = sol.checkpoint(0)
+    path = tmp_path / "ck.pth.tar"
+    torch.save(ck, path)
+    assert set(ck) >= {"epoch", "model", "optim_main", "optim_vmi"} and int(ck["optim_main"]["step"]) == 3 and int(ck["optim_vmi"]["step"]) == 3
+    ref = [tuple(float(x) for x in sol.step(datas)[:2]) for _ in range(2)]
+    sol2 = Solver(o, loaders)
+    assert sol2.load_checkpoint(str(path)) == 0
+    sol2.engine.set_banks(*(banks[k] for k in "CFTAV"))
+    got = [tuple(float(x) for x in sol2.step(datas)[:2]) for _ in range(2)]
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_main_cli_subprocess_smoke(tmp_path):
+    """`python Main.py --dataset synthetic ... --epochs_num 2`: the runner end to end (two epochs incl. stage 1, evaluation,
+    checkpoints and prediction files written like Solver.py:513-531), partial last batches included (n=100, B=16)."""
+    cmd = [sys.executable, os.path.join(ROOT, "Main.py"), "--dataset", "synthetic", "--synthetic_n", "100", "--batch_size", "16",
+           "--time_len", "12", "--d_hiddens", "12-3-128=4-3-128", "--d_outs", "12-3-128=4-3-128", "--bias", "--res_project", "1-1",
+           "--dropout", "0.1-0.1-0.1-0.1", "--dropout_mlp", "0.0-0.0-0.0", "--epochs_num", "2", "--stage1_n", "1", "--precision", "bf16",
+           "--loss_mi_coefficient1", "-".join(["1.0"] * 11), "--loss_mi_coefficient2", "-".join(["0.01"] * 8), "--task_name", "cli_smoke",
+           "--gradient_clip", "1.5", "--learning_rate", "1e-3"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    task = tmp_path / "TaskRuning" / "cli_smoke"
+    for f in ("Running.log", "best_valid_model.pth.tar", "best_test_model.pth.tar", "predictions_val.npy", "predictions_test.npy",
+              "targets_val.npy"):
+        assert (task / f).exists(), f
+    log = (task / "Running.log").read_text()
+    assert "Epoch:[  2]" in log and "Training complete." in log and "nan" not in log.lower()
+    ck = torch.load(task / "best_valid_model.pth.tar", map_location="cpu")
+    assert "W_t.weight" in ck["model"] and "vmi_estimator_f_t.critic_model.MLP_g.0.weight" in ck["model"]

@@ -11,8 +11,11 @@ from tests.helpers import case, load_golden, oracle_params
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp", "tiny_lstm", "tiny_tuba_un", "tiny_interp_ga"]
-ALL = TINY + ["cfg1_sep", "cfg1_cat"]
+TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp", "tiny_lstm", "tiny_tuba_un", "tiny_interp_ga",
+        "tiny_sum"]
+# cfg2_sep = BASELINE configs[1] at FULL size (the bench configuration); cfg3_small / cfg5_small = configs[2] / [4] with only the
+# batch reduced (T = time_len = 500 / 1000, concat critic for cfg3)
+ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg2_sep", "cfg3_small", "cfg5_small"]
 
 
 def make_engine(name, precision="fp32", use_graph=False):
@@ -109,7 +112,8 @@ def test_stage_losses_and_all_gradients_vs_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_lstm", "cfg1_sep"])
+@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_lstm", "tiny_sum", "cfg1_sep",
+                                  "cfg2_sep", "cfg3_small", "cfg5_small"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_two_stage_trajectory(name, use_graph):
     """Alternating stage-1/stage-2 updates (Solver.step) vs the reference trajectory and the oracle."""
@@ -351,3 +355,141 @@ def test_bf16_fused_paths_on_every_fixture(name):
     # CMI term by ~1 in any reduced precision (same numbers with every fused kernel switched off), so only MI terms there
     nmi = 4 if opt.cmi_last_acticate == "hardtanh" else 8
     assert_close(a[_lib.S2_MIS:_lib.S2_MIS + nmi], b[_lib.S2_MIS:_lib.S2_MIS + nmi], 5e-2, 3e-2, "stage-2 MI terms")
+
+
+def test_cfg2_full_size_in_bench_mode():
+    """BASELINE configs[1] at full size (B=128, T=50, N=1284) in EXACTLY the mode bench.py times -- bf16 MFMA operands, every
+    fused kernel, one hipGraph per two-stage step, Solver.step() overlap mode with the shared encoder prefix -- against the
+    reference's golden values and the fp32 engine.  (Anchors are host-supplied here so that both modes and the reference
+    see the same kNN samples; bench.py draws them on the device.)"""
+    name = "cfg2_sep"
+    g = load_golden(name)
+    res = {}
+    for precision in ("fp32", "bf16"):
+        c, opt, batch, banks, p, eng = make_engine(name, precision=precision, use_graph=precision == "bf16")
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(1, g["anchors"][0, 0])
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.set_stage2_prefetch(precision == "bf16")
+        eng.step()
+        torch.cuda.synchronize()
+        res[precision] = (eng.read_scalars().copy(), eng.pred.cpu().numpy().copy(), eng.feats.cpu().numpy().copy())
+        if precision == "bf16":
+            for _ in range(3):
+                eng.step()
+            assert np.isfinite(eng.read_scalars()).all() and torch.isfinite(eng.main["p"]).all() and torch.isfinite(eng.crit["p"]).all()
+        eng.close()
+    (sa, pa, fa), (sb, pb, fb) = res["fp32"], res["bf16"]
+    # fp32 mode vs the real reference: the 1e-3 bar
+    assert_close(sa[_lib.S1_LOSS], g["traj_s1_loss"][0], 1e-3, 1e-5, "fp32 stage-1 loss vs reference")
+    assert_close(sa[_lib.S2_LOSS], g["traj_s2_loss"][0], 1e-3, 1e-5, "fp32 stage-2 loss vs reference")
+    assert_close(sa[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 1e-3, 5e-5, "fp32 MI terms vs reference")
+    # bench mode vs the reference: bf16 band (operands rounded to 8 bits of mantissa; CMI terms are differences of log-ratio sums)
+    assert_close(sb[_lib.S1_LOSS], g["traj_s1_loss"][0], 5e-3, 1e-3, "bench-mode stage-1 loss vs reference")
+    assert_close(sb[_lib.S2_LOSS], g["traj_s2_loss"][0], 5e-3, 1e-3, "bench-mode stage-2 loss vs reference")
+    assert_close(sb[_lib.S2_TASK], g["traj_s2_task"][0], 5e-3, 1e-3, "bench-mode task loss vs reference")
+    assert_close(sb[_lib.S1_MIS:_lib.S1_MIS + 11], g["traj_s1_mis"][0], 2e-2, 1e-2, "bench-mode stage-1 MI/CMI vs reference")
+    assert_close(sb[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 2e-2, 2e-2, "bench-mode MI terms vs reference")
+    assert_close(pb, pa, 2e-2, 2e-2, "bench-mode predictions vs fp32")
+    assert_close(fb, fa, 2e-2, 2e-2, "bench-mode features vs fp32")
+
+
+def _bench_engine(workload, precision, use_graph, device_anchors=True, **env):
+    import bench
+    opt, N = bench.workload(workload)
+    opt.dropout = [0.0] * 4                                   # deterministic comparisons
+    B, T = opt.batch_size, opt.time_len
+    eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision=precision, use_graph=use_graph, seed=1,
+                    device_anchors=device_anchors)
+    eng.load_params(synth.default_state([(n, tuple(v.shape)) for n, v in eng.params.items()], 0))
+    batch = synth.synthetic_batch(B, T, seed=0)
+    eng.set_batch(*batch)
+    banks = synth.synthetic_banks(N, seed=0)
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    return opt, N, batch, banks, eng
+
+
+def test_cfg3_full_size_properties(monkeypatch):
+    """BASELINE configs[2] at FULL size (MOSEI-shaped B=256, T=500, concat critic, k=2, N=16326 banks): no reference run is
+    affordable at this size, so size-independent properties: (a) the epoch-0 rule, (b) the task loss and the features against
+    the oracle's forward pass on the same inputs (fp32: 1e-3), (c) bf16 + fused + graph + overlap == bf16 unfused eager
+    sequential within the bf16 band, (d) three updates stay finite, (e) workspace fits and anchors are under the 16384 cap."""
+    opt, N, batch, banks, eng = _bench_engine("cfg3", "fp32", False, device_anchors=False)
+    assert N < 16384 and eng.workspace_bytes() < 64 * 2 ** 30
+    # (a) epoch-0 rule
+    eng.set_banks(None, None, None, None, None)
+    before = eng.crit["p"].clone()
+    eng.stage1_step()
+    eng.forward(train=True, with_losses=True)
+    s0 = eng.read_scalars()
+    assert s0[_lib.S1_LOSS] == 0.0 and torch.equal(before, eng.crit["p"]) and np.all(s0[_lib.S2_MIS:_lib.S2_MIS + 8] == 0)
+    # (b) forward vs the oracle (one CPU forward pass of B=256, T=500: seconds)
+    p = {n: v.detach().cpu() for n, v in eng.params.items()}
+    tb = tuple(torch.from_numpy(x) for x in batch)
+    with torch.no_grad():
+        pred, F_F, T_F, A_F, V_F = R.model_forward(p, opt, *tb[:3])
+        task = R.task_loss_mae(pred, tb[3])
+    assert_close(s0[_lib.S2_TASK], task.item(), 1e-3, 1e-6, "task loss vs oracle")
+    assert_close(s0[_lib.S2_LOSS], task.item(), 1e-3, 1e-6, "epoch-0 stage-2 loss = task loss")
+    feats = eng.feats.cpu().numpy()
+    for i, (k, want) in enumerate((("F_F", F_F), ("T_F", T_F), ("A_F", A_F), ("V_F", V_F))):
+        assert_close(feats[i], want.numpy(), 1e-3, 5e-5, k)
+    eng.close()
+    # (c) + (d): the benchmarked mode vs the plain mode, same anchors
+    rng = np.random.default_rng(3)
+    m = opt.batch_size // opt.k_neighbor
+    anchors = [np.stack([rng.choice(N, size=m, replace=False) for _ in range(6)]) for _ in range(2)]
+    res = {}
+    for tag, graph, pre, envs in (("plain", False, False, ("MIMRL_NO_FUSED_CUBE", "MIMRL_NO_FUSED_CUBE_BWD", "MIMRL_NO_FUSED_MLP", "MIMRL_NO_FUSED_MI")),
+                                  ("bench", True, True, ())):
+        for e in ("MIMRL_NO_FUSED_CUBE", "MIMRL_NO_FUSED_CUBE_BWD", "MIMRL_NO_FUSED_MLP", "MIMRL_NO_FUSED_MI"):
+            monkeypatch.delenv(e, raising=False)
+        for e in envs:
+            monkeypatch.setenv(e, "1")
+        opt, N, batch, banks, eng = _bench_engine("cfg3", "bf16", graph, device_anchors=False)
+        eng.set_anchors(1, anchors[0]); eng.set_anchors(2, anchors[1])
+        eng.set_stage2_prefetch(pre)
+        eng.step()
+        torch.cuda.synchronize()
+        res[tag] = (eng.read_scalars().copy(), eng.pred.cpu().numpy().copy())
+        if tag == "bench":
+            eng.step(); eng.step()
+            assert np.isfinite(eng.read_scalars()).all() and torch.isfinite(eng.main["p"]).all() and torch.isfinite(eng.crit["p"]).all()
+        eng.close()
+    (sa, pa), (sb, pb) = res["plain"], res["bench"]
+    assert_close(sb[_lib.S1_LOSS], sa[_lib.S1_LOSS], 1e-2, 1e-3, "stage-1 loss")
+    assert_close(sb[_lib.S2_LOSS], sa[_lib.S2_LOSS], 1e-2, 1e-3, "stage-2 loss")
+    assert_close(sb[_lib.S2_MIS:_lib.S2_MIS + 8], sa[_lib.S2_MIS:_lib.S2_MIS + 8], 3e-2, 3e-2, "MI terms")
+    assert_close(pb, pa, 3e-2, 2e-2, "predictions")
+
+
+def test_cfg5_full_size_vs_oracle():
+    """BASELINE configs[4], reference-supported subset at FULL size (B=32, T=1000, gru, d_common=128, fp32: 2000 serial cell
+    steps per pass): both stage losses, all 11 + 8 MI/CMI terms and the predictions against the oracle's forward passes
+    (no_grad: the oracle's autograd through 4000 Python-level cell steps takes minutes; gradients at T=1000 are pinned by
+    the cfg5_small fixture), then three updates stay finite."""
+    opt, N, batch, banks, eng = _bench_engine("cfg5", "fp32", False, device_anchors=False)
+    rng = np.random.default_rng(4)
+    m = opt.batch_size // opt.k_neighbor
+    anchors = [np.stack([rng.choice(N, size=m, replace=False) for _ in range(6)]) for _ in range(2)]
+    eng.set_anchors(1, anchors[0]); eng.set_anchors(2, anchors[1])
+    p = {n: v.detach().cpu().clone() for n, v in eng.params.items()}
+    eng.stage_grads(1)
+    eng.stage_grads(2)
+    torch.cuda.synchronize()
+    s = eng.read_scalars()
+    tb = tuple(torch.from_numpy(x) for x in batch)
+    bk = {k: torch.from_numpy(v) for k, v in banks.items()}
+    with torch.no_grad():
+        l1, mis1, *_ = R.stage_loss(p, opt, 1, tb, bk, anchors[0])
+        l2, mis2, pred, feats, task = R.stage_loss(p, opt, 2, tb, bk, anchors[1])
+    assert_close(s[_lib.S1_LOSS], l1.item(), 1e-3, 1e-5, "stage-1 loss")
+    assert_close(s[_lib.S1_MIS:_lib.S1_MIS + 11], [x.item() for x in mis1], 1e-3, 2e-5, "stage-1 MI/CMI")
+    assert_close(s[_lib.S2_TASK], task.item(), 1e-3, 1e-6, "task loss")
+    assert_close(s[_lib.S2_LOSS], l2.item(), 1e-3, 1e-5, "stage-2 loss")
+    assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], [x.item() for x in mis2], 1e-3, 5e-5, "stage-2 MI terms")
+    assert_close(eng.pred.cpu().numpy(), pred.numpy().reshape(-1), 1e-3, 1e-5, "predictions")
+    for _ in range(3):
+        eng.step()
+    assert np.isfinite(eng.read_scalars()).all() and torch.isfinite(eng.main["p"]).all() and torch.isfinite(eng.crit["p"]).all()
+    eng.close()

@@ -16,7 +16,7 @@ B, T = opt.batch_size, opt.time_len
 t0 = time.time()
 eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision=prec, use_graph=graph, seed=1, device_anchors=True)
 print(f"{name} {prec} graph={graph} prefetch={pre}: workspace {eng.workspace_bytes() / 2**30:.2f} GiB, create {time.time() - t0:.1f}s", flush=True)
-eng.load_params({n: synth.default_tensor(n, tuple(v.shape), 0) for n, v in eng.params.items()})
+eng.load_params(synth.default_state([(n, tuple(v.shape)) for n, v in eng.params.items()], 0))
 eng.set_batch(*synth.synthetic_batch(B, T, seed=0))
 banks = synth.synthetic_banks(N, seed=0)
 eng.set_banks(*(banks[k] for k in "CFTAV"))

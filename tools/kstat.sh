@@ -3,7 +3,7 @@
 pat=$1; shift
 for ks in "$@"; do
   rm -rf /tmp/ks_prof
-  (cd /tmp && TMPDIR=/tmp env $ks rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_prof -- python3 /root/repo/bench.py --steps 30 --warmup 5 --profile-steps 0 --no-cpu-baseline > /tmp/ks.log 2>&1)
+  (cd /tmp && TMPDIR=/tmp env $ks rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_prof -- python3 $(cd "$(dirname "$0")/.." && pwd)/bench.py --steps 30 --warmup 5 --profile-steps 0 --no-cpu-baseline > /tmp/ks.log 2>&1)
   f=$(find /tmp/ks_prof -name "*kernel_stats.csv" | head -1)
   echo "[$ks]"
   python3 - "$f" "$pat" <<'PY'
