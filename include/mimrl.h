@@ -150,6 +150,11 @@ void mimrl_destroy(mimrl_handle* h);
 int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch,
                   const int64_t strides[9] /* sa_m sa_k sa_b sb_k sb_n sb_b sc_m sc_n sc_b */, const float* bias_n,
                   const float* bias_m, float alpha, float beta, int act, int precision);
+/* same + the optional parts the engine uses: second product C = epi(A.B + A2.B2) (strides2 = sa2_m sa2_k sa2_b sb2_k sb2_n sb2_b),
+ * a gap in A's row axis (rows >= a_gap_at live a_gap_rows further on), act'(u) factor, fused column sums; act bit 8 = atomic */
+int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch, const int64_t strides[9],
+                     const float* A2, const float* B2, int K2, const int64_t strides2[6], int a_gap_at, int a_gap_rows,
+                     const float* bias_n, const float* gradact_u, float* colsum, int act, int precision);
 int64_t mimrl_op_gru_saved_floats(int B, int T);
 /* one bidirectional GRU layer (both directions): gx/w_hh/b_hh/saved per direction; out [B,T,256] */
 int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,

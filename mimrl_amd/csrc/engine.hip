@@ -2227,6 +2227,23 @@ int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M,
   return gemm(reinterpret_cast<hipStream_t>(stream), d, (precision & 1) != 0);
 }
 
+int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch, const int64_t st[9],
+                     const float* A2, const float* B2, int K2, const int64_t st2[6], int a_gap_at, int a_gap_rows, const float* bias_n,
+                     const float* gradact_u, float* colsum, int act, int precision) {
+  if (!st || (A2 && !st2)) return set_error(MIMRL_ERR_ARG, "null strides");
+  GemmDesc d;
+  d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.batch = batch;
+  d.sa_m = st[0]; d.sa_k = st[1]; d.sa_b = st[2]; d.sb_k = st[3]; d.sb_n = st[4]; d.sb_b = st[5];
+  d.sc_m = st[6]; d.sc_n = st[7]; d.sc_b = st[8];
+  if (A2) {
+    d.A2 = A2; d.B2 = B2; d.K2 = K2;
+    d.sa2_m = st2[0]; d.sa2_k = st2[1]; d.sa2_b = st2[2]; d.sb2_k = st2[3]; d.sb2_n = st2[4]; d.sb2_b = st2[5];
+  }
+  d.a_gap_at = a_gap_at; d.a_gap_rows = a_gap_rows;
+  d.bias_n = bias_n; d.gradact_u = gradact_u; d.colsum = colsum; d.act = act & 0xff; d.atomic = (act >> 8) & 1;
+  return gemm(reinterpret_cast<hipStream_t>(stream), d, (precision & 1) != 0);
+}
+
 int64_t mimrl_op_gru_saved_floats(int B, int T) { return gru_saved_floats(B, T); }
 
 int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,

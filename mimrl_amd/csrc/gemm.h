@@ -56,7 +56,9 @@ inline GemmDesc gemm_tn(const float* A, long lda, const float* Bm, long ldb, flo
 }
 
 struct GemmPlan {
-  int variant;        // 0 fp32 generic, 1 bf16 generic (BK 32), 2 bf16 lean BK 64, 3 bf16 lean BK 128
+  int variant;        // 0 fp32 generic, 1 bf16 generic (BK 32), 2 bf16 lean BK 64, 3 bf16 lean BK 128, >= 10 fast path
+  int fast, tm, tn;   // fast path: block tile (64*tm) x (64*tn)
+  int ca, cb;         // fast path: operand layout classes (1 k-contiguous, 2 row-contiguous)
   int nsplit;         // split-K factor (partials are combined with float atomics)
   int kt_per;         // k-tiles per split
   long tiles;         // output tiles (64x64) incl. batch

@@ -19,6 +19,8 @@ namespace {
 
 constexpr int BM = 64, BN = 64;
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <bool BF16, int BK>
 struct Smem;
 template <int BK>
@@ -177,6 +179,23 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
   }
 }
 
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so linear ids that
+// are equal mod 8 share an L2.  Re-deal the ids so that one XCD owns whole slices of the slowest grid axis: all
+// column tiles of a row block (they re-read the same activation rows), all tiles of one split-K chunk / batch entry.
+__device__ __forceinline__ void tile_ids(int remap, unsigned& bx, unsigned& by, unsigned& bzr) {
+  bx = blockIdx.x; by = blockIdx.y; bzr = blockIdx.z;
+  if (!remap) return;
+  const unsigned nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+  const unsigned lin = (bzr * ny + by) * nx + bx, xcd = lin & 7u, idx = lin >> 3;
+  if (nz > 1) {
+    const unsigned per = nx * ny;
+    if (lin < per * (nz & ~7u)) { bzr = (idx / per) * 8 + xcd; const unsigned r = idx % per; by = r / nx; bx = r % nx; }
+  } else if (lin < nx * (ny & ~7u)) {
+    by = (idx / nx) * 8 + xcd; bx = idx % nx;
+  }
+}
+
 template <bool BF16, int BK, bool LEAN>
 __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   const GemmDesc& d = ka.d;
@@ -184,20 +203,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   __shared__ __attribute__((aligned(16))) Smem<BF16, BK> sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so linear ids that
-  // are equal mod 8 share an L2.  Re-deal the ids so that one XCD owns whole slices of the slowest grid axis: all
-  // column tiles of a row block (they re-read the same activation rows), all tiles of one split-K chunk / batch entry.
-  unsigned bx = blockIdx.x, by = blockIdx.y, bzr = blockIdx.z;
-  if (ka.xcd_remap) {
-    const unsigned nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
-    const unsigned lin = (bzr * ny + by) * nx + bx, xcd = lin & 7u, idx = lin >> 3;
-    if (nz > 1) {
-      const unsigned per = nx * ny;
-      if (lin < per * (nz & ~7u)) { bzr = (idx / per) * 8 + xcd; const unsigned r = idx % per; by = r / nx; bx = r % nx; }
-    } else if (lin < nx * (ny & ~7u)) {
-      by = (idx / nx) * 8 + xcd; bx = idx % nx;
-    }
-  }
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
   const int bz = bzr / ka.ksplit, ks = bzr - bz * ka.ksplit;
   long oa = (long)bz * d.sa_b, ob = (long)bz * d.sb_b, oc = (long)bz * d.sc_b, obn = (long)bz * d.bias_n_b;
   if (d.batch_in > 0) {
@@ -266,7 +273,195 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre, acc, m0 + wm * 32, n_lane, lane);
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// =================================================================================================
+// FAST bf16 path (the layouts this workload actually uses, fixed at compile time).
+//   block tile (64*TM) x (64*TN), 4 waves as 2x2, each wave TM x TN accumulator tiles of v_mfma_f32_32x32x16_bf16;
+//   BK = 32; operands are fp32 in HBM and are rounded to bf16 on their way into LDS (16-byte global loads, 8-byte LDS
+//   stores, nothing else: no runtime strides, no per-element address math);
+//   LDS double-buffered: the global loads of k-tile t+1 are in flight under the MFMAs of tile t, their LDS stores go to
+//   the other buffer behind the MFMAs, ONE barrier per k-tile.
+// An operand is either
+//   KC  k-contiguous   (row stride s, k stride 1): LDS image [row][k] (80-byte rows), fragments by ds_read_b128;
+//   RC  row-contiguous (row stride 1, k stride s): LDS image [k][row], stored exactly as loaded (4 rows of one k per
+//       lane, lanes along the rows: coalesced and conflict-free) and transposed for free by the fragment reads,
+//       2 x ds_read_b64_tr_b16 (each 16-lane group fetches a 4(k) x 16(row) block column-major).
+// The three combinations (A,B) = (KC,KC) forward products, (KC,RC) data gradients / left-multiplications,
+// (RC,RC) weight gradients cover every large GEMM of the step; anything else falls back to gemm_kernel.
+// =================================================================================================
+constexpr int FBK = 32;
+template <int T>
+struct FT {
+  static constexpr int R = 64 * T;
+  static constexpr int KCP = FBK + 8;   // [row][k]: 80-byte rows, 16-byte fragment reads conflict-free
+  static constexpr int RCP = R + 32;    // [k][row]: pitch = 64 B mod 256 B -> the 4 k-rows of a transposed read hit distinct bank quarters
+  static constexpr int ELEMS = (R * KCP > FBK * RCP) ? R * KCP : FBK * RCP;
+  static constexpr int NV = 2 * T;      // float4 per thread per k-tile
+  static constexpr int KB = 2 * T;      // RC: consecutive k per thread (T=2: 32 row-quads x 8 k-quads; T=1: 16 x 16 k-pairs)
+};
+
+__device__ __forceinline__ bf16x4 cvt4(const float4& q) {
+  bf16x4 p; p[0] = to_bf16(q.x); p[1] = to_bf16(q.y); p[2] = to_bf16(q.z); p[3] = to_bf16(q.w);
+  return p;
+}
+
+// every load is unconditional from a clamped (valid) address and zeroed afterwards: a guarded load is a branch whose
+// join waits for ALL outstanding loads
+template <int T, bool KC>
+__device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, int r0, int R, int gap_at, int gap, int K, int k0,
+                                          int tid, float4* v) {
+  if constexpr (KC) {
+#pragma unroll
+    for (int h = 0; h < FT<T>::NV; ++h) {
+      const int idx = h * 256 + tid, row = idx >> 3, gk = k0 + (idx & 7) * 4;
+      int gr = r0 + row < R ? r0 + row : R - 1;          // ragged tiles: clamped rows land in outputs nobody stores
+      if (gr >= gap_at) gr += gap;
+      const int gkc = gk < K ? gk : K - 4;               // K % 4 == 0
+      float4 q = *reinterpret_cast<const float4*>(P + (long)gr * s + gkc);
+      if (gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[h] = q;
+    }
+  } else {
+    constexpr int KB = FT<T>::KB;
+    const int rq = tid & (16 * T - 1), kq = tid / (16 * T);
+    int gr = r0 + rq * 4;
+    const bool rin = gr < R;                              // R % 4 == 0: a row quad is inside or outside as a whole
+    if (!rin) gr = R - 4;
+    if (gr >= gap_at) gr += gap;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int gk = k0 + kq * KB + j;
+      const int gkc = gk < K ? gk : K - 1;
+      float4 q = *reinterpret_cast<const float4*>(P + gr + (long)gkc * s);
+      if (!rin || gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[j] = q;
+    }
+  }
+}
+
+template <int T, bool KC>
+__device__ __forceinline__ void fast_store(const float4* v, __bf16* __restrict__ img, int tid) {
+  if constexpr (KC) {
+#pragma unroll
+    for (int h = 0; h < FT<T>::NV; ++h) {
+      const int idx = h * 256 + tid;
+      *reinterpret_cast<bf16x4*>(img + (idx >> 3) * FT<T>::KCP + (idx & 7) * 4) = cvt4(v[h]);
+    }
+  } else {
+    constexpr int KB = FT<T>::KB;
+    const int rq = tid & (16 * T - 1), kq = tid / (16 * T);
+#pragma unroll
+    for (int j = 0; j < KB; ++j) *reinterpret_cast<bf16x4*>(img + (kq * KB + j) * FT<T>::RCP + rq * 4) = cvt4(v[j]);
+  }
+}
+
+// MFMA operand fragment of the 32 rows starting at `rb`, k-step s (16 k): lane holds row rb + (lane & 31), k = 8*(lane>>5) .. +7
+template <int T, bool KC>
+__device__ __forceinline__ bf16x8 fast_frag(const __bf16* __restrict__ img, int rb, int s, int lane) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const bf16x8*>(img + (rb + (lane & 31)) * FT<T>::KCP + s * 16 + 8 * (lane >> 5));
+  } else {
+    typedef __attribute__((address_space(3))) bf16x4 lds4;
+    const int j = lane & 15, q = j >> 2, p = j & 3;      // lane 4q+p of a 16-lane group addresses block row q, columns 4p..4p+3
+    const __bf16* a = img + (s * 16 + 8 * (lane >> 5) + q) * FT<T>::RCP + rb + 16 * ((lane >> 4) & 1) + 4 * p;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4*)(a));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4*)(a + 4 * FT<T>::RCP));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
+  const GemmDesc& d = ka.d;
+  constexpr int BMf = 64 * TM, BNf = 64 * TN;
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2][FT<TM>::ELEMS];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[2][FT<TN>::ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
+  const int bz = bzr / ka.ksplit, ks = bzr - bz * ka.ksplit;
+  long oa = (long)bz * d.sa_b, ob = (long)bz * d.sb_b, oc = (long)bz * d.sc_b, obn = (long)bz * d.bias_n_b;
+  if (d.batch_in > 0) {
+    const int bo = bz / d.batch_in, bi = bz - bo * d.batch_in;
+    oa = (long)bo * d.sa_bo + (long)bi * d.sa_b; ob = (long)bo * d.sb_bo + (long)bi * d.sb_b;
+    oc = (long)bo * d.sc_bo + (long)bi * d.sc_b; obn = (long)bo * d.bias_n_bo + (long)bi * d.bias_n_b;
+  }
+  const int m0 = by * BMf, n0 = bx * BNf;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bn_pre[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * 32 * TN + j * 32 + (lane & 31);
+    bn_pre[j] = d.bias_n ? d.bias_n[obn + (n < d.N ? n : d.N - 1)] : 0.f;
+  }
+
+  auto segment = [&](const float* __restrict__ Ap, long sa, const float* __restrict__ Bp, long sb, int K, int kt0, int kt1, int ga_at, int ga) {
+    float4 ra[FT<TM>::NV], rb[FT<TN>::NV];
+    if (kt0 >= kt1) return;
+    fast_load<TM, AKC>(Ap, sa, m0, d.M, ga_at, ga, K, kt0 * FBK, tid, ra);
+    fast_load<TN, BKC>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, kt0 * FBK, tid, rb);
+    fast_store<TM, AKC>(ra, sA[0], tid);
+    fast_store<TN, BKC>(rb, sB[0], tid);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      if (more) {
+        fast_load<TM, AKC>(Ap, sa, m0, d.M, ga_at, ga, K, (kt + 1) * FBK, tid, ra);
+        fast_load<TN, BKC>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, (kt + 1) * FBK, tid, rb);
+      }
+#pragma unroll
+      for (int s = 0; s < FBK / 16; ++s) {
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = fast_frag<TM, AKC>(sA[cur], wm * 32 * TM + i * 32, s, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = fast_frag<TN, BKC>(sB[cur], wn * 32 * TN + j * 32, s, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        fast_store<TM, AKC>(ra, sA[cur ^ 1], tid);
+        fast_store<TN, BKC>(rb, sB[cur ^ 1], tid);
+      }
+      __syncthreads();
+    }
+  };
+  {
+    const int ktiles = (d.K + FBK - 1) / FBK;
+    const int kt0 = ks * ka.kt_per;
+    const int kt1 = kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles;
+    segment(d.A + oa, AKC ? d.sa_m : d.sa_k, d.B + ob, BKC ? d.sb_n : d.sb_k, d.K, kt0, kt1, d.a_gap_rows ? d.a_gap_at : 0x7fffffff, d.a_gap_rows);
+  }
+  if (d.A2)
+    segment(d.A2 + (long)bz * d.sa2_b, AKC ? d.sa2_m : d.sa2_k, d.B2 + (long)bz * d.sb2_b, BKC ? d.sb2_n : d.sb2_k, d.K2, 0,
+            (d.K2 + FBK - 1) / FBK, 0x7fffffff, 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre[j], acc[i][j], m0 + wm * 32 * TM + i * 32, n0 + wn * 32 * TN + j * 32 + (lane & 31), lane);
+}
+
+// layout class of one operand for the fast path: 1 = KC, 2 = RC, 0 = not eligible.  (row axis = m for A, n for B)
+inline int fast_class(const float* P, long s_r, long s_k, long s_b, long s_bo, int R, int K) {
+  if (!aligned16(P) || s_b % 4 != 0 || s_bo % 4 != 0) return 0;
+  if (s_k == 1 && s_r % 4 == 0 && K % 4 == 0 && K >= 4 && s_r != 1) return 1;
+  if (s_r == 1 && s_k % 4 == 0 && R % 4 == 0 && R >= 4) return 2;
+  return 0;
+}
+
 // 16-byte path: unit stride along one axis, the other stride and the batch stride multiples of 4 floats, base aligned
 inline bool vec_ok_a(const float* P, long s_m, long s_k, long s_b) {
   return aligned16(P) && s_b % 4 == 0 && ((s_k == 1 && s_m % 4 == 0) || (s_m == 1 && s_k != 1 && s_k % 4 == 0));
@@ -277,7 +472,46 @@ inline bool vec_ok_b(const float* P, long s_k, long s_n, long s_b) {
 
 }  // namespace
 
+static bool plain_accumulate(const GemmDesc& d) {
+  return !d.A2 && d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum && d.act == ACT_NONE;
+}
+
+// fast-path eligibility and tile shape; returns false when the generic kernel has to take the GEMM
+static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
+  static const int no_fast = getenv("MIMRL_GEMM_NO_FAST") != nullptr;   // tuning knob
+  if (!bf16 || no_fast) return false;
+  const int ca = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K), cb = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K);
+  if (!ca || !cb || (ca == 2 && cb == 1)) return false;
+  if (d.A2 && (fast_class(d.A2, d.sa2_m, d.sa2_k, d.sa2_b, 0, d.M, d.K2) != ca || fast_class(d.B2, d.sb2_n, d.sb2_k, d.sb2_b, 0, d.N, d.K2) != cb))
+    return false;
+  const int ktiles = (d.K + FBK - 1) / FBK;
+  const bool acc = plain_accumulate(d) && ktiles >= 32;
+  auto tiles = [&](int tm, int tn) { return (long)((d.M + 64 * tm - 1) / (64 * tm)) * ((d.N + 64 * tn - 1) / (64 * tn)) * d.batch; };
+  auto split = [&](long t) {   // split-K factor for accumulate-into-zeroed-output GEMMs: ~2 workgroups per CU, >= 16 k-tiles each
+    if (!acc) return 1;
+    long ks = (512 + t - 1) / t;
+    if (ks > ktiles / 16) ks = ktiles / 16;
+    return (int)(ks < 1 ? 1 : ks);
+  };
+  const int cand[3][2] = {{2, 2}, {2, 1}, {1, 1}};
+  int pick = 2;
+  for (int c = 0; c < 3; ++c) {
+    const int tm = cand[c][0], tn = cand[c][1];
+    if (d.M < 64 * tm || d.N < 64 * tn) continue;
+    const long t = tiles(tm, tn);
+    if (t * split(t) >= 224 || c == 2) { pick = c; break; }   // the largest tile that still gives (almost) every CU a workgroup
+  }
+  p->fast = 1; p->tm = cand[pick][0]; p->tn = cand[pick][1]; p->ca = ca; p->cb = cb;
+  p->tiles = tiles(p->tm, p->tn);
+  p->nsplit = split(p->tiles);
+  p->kt_per = (ktiles + p->nsplit - 1) / p->nsplit;
+  p->variant = 10 + 4 * pick + (ca == 1 ? (cb == 1 ? 0 : 1) : 2);
+  return true;
+}
+
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
+  p->fast = 0; p->tm = p->tn = 1; p->ca = p->cb = 0;
+  if (fast_plan(d, bf16, p)) return;
   static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knobs
   static const int no_big = getenv("MIMRL_GEMM_NO_BK128") != nullptr;
   const bool va = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0, vb = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
@@ -293,10 +527,8 @@ void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   p->variant = !bf16 ? 0 : lean128 ? 3 : lean ? 2 : 1;
   const int BKh = lean128 ? 128 : (lean ? 64 : 32);
   const int ktiles = (d.K + BKh - 1) / BKh;
-  const bool plain_acc = !d.A2 && d.atomic && d.beta == 0.f && !d.bias_n && !d.bias_m && !d.pre && !d.gradact_u && !d.colsum &&
-                         d.act == ACT_NONE;
   p->nsplit = 1; p->kt_per = ktiles; p->tiles = tiles;
-  if (plain_acc && ktiles >= 8) {
+  if (plain_accumulate(d) && ktiles >= 8) {
     // accumulate-into-zeroed-output GEMMs (weight gradients): split K until the grid has ~2 waves of workgroups
     int ksplit = (int)((512 + tiles - 1) / tiles);
     if (ksplit > ktiles / 4) ksplit = ktiles / 4;
@@ -328,14 +560,26 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   ka.xcd_remap = !no_xcd;
   ka.ksplit = pl.nsplit;
   ka.kt_per = pl.kt_per;
-  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM, d.batch * pl.nsplit);
+  const int bm = 64 * pl.tm, bn = 64 * pl.tn;   // (64 x 64 unless the fast path picked a larger tile)
+  dim3 grid((d.N + bn - 1) / bn, (d.M + bm - 1) / bm, d.batch * pl.nsplit);
   if (grid.y > 65535 || grid.z > 65535) return set_error(MIMRL_ERR_ARG, "gemm: grid too large (M=%d batch=%d)", d.M, d.batch);
+#define FASTK(TM_, TN_, A_, B_) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_>), grid, dim3(256), 0, s, ka); break
   switch (pl.variant) {
+    case 10: FASTK(2, 2, true, true);
+    case 11: FASTK(2, 2, true, false);
+    case 12: FASTK(2, 2, false, false);
+    case 14: FASTK(2, 1, true, true);
+    case 15: FASTK(2, 1, true, false);
+    case 16: FASTK(2, 1, false, false);
+    case 18: FASTK(1, 1, true, true);
+    case 19: FASTK(1, 1, true, false);
+    case 20: FASTK(1, 1, false, false);
     case 0: hipLaunchKernelGGL((gemm_kernel<false, 32, false>), grid, dim3(256), 0, s, ka); break;
     case 3: hipLaunchKernelGGL((gemm_kernel<true, 128, true>), grid, dim3(256), 0, s, ka); break;
     case 2: hipLaunchKernelGGL((gemm_kernel<true, 64, true>), grid, dim3(256), 0, s, ka); break;
     default: hipLaunchKernelGGL((gemm_kernel<true, 32, false>), grid, dim3(256), 0, s, ka); break;
   }
+#undef FASTK
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

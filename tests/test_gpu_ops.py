@@ -63,6 +63,75 @@ def test_gemm_batched_left_multiply_and_tn(lib):
     assert_close(dW.cpu().numpy(), ref, 1e-4, 1e-2, "batch-reduced TN")
 
 
+def _bf16_round(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+_LAYOUTS = {   # (A stored as, B stored as): which axis is contiguous
+    "nt": ("mk", "nk"),      # forward products            (KC, KC)
+    "nn": ("mk", "kn"),      # data gradients / left mixes (KC, RC)
+    "tn": ("km", "kn"),      # weight gradients            (RC, RC)
+}
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K,batch,atomic", [(256, 256, 96, 1, 0), (200, 72, 100, 3, 0), (128, 128, 4096, 1, 1), (1000, 384, 256, 2, 0),
+                                                (64, 64, 32, 1, 0), (132, 260, 36, 1, 0), (50, 52, 384, 8, 1)])
+def test_gemm_fast_path_layouts(lib, layout, M, N, K, batch, atomic):
+    """The bf16 fast path (gemm_fast_kernel: 128x128 / 128x64 / 64x64 tiles, double-buffered LDS, transposing LDS reads for
+    row-contiguous operands) on every operand-layout combination it serves, ragged M / N / K tiles, batch, split-K with
+    atomics -- against a float64 product of the bf16-ROUNDED operands (what is left is fp32 accumulation order)."""
+    g = np.random.default_rng(M * 7 + N * 3 + K)
+    a = g.standard_normal((batch, M, K)).astype(np.float32)
+    b = g.standard_normal((batch, K, N)).astype(np.float32)
+    la, lb = _LAYOUTS[layout]
+    A = dev(a if la == "mk" else a.transpose(0, 2, 1).copy())
+    Bm = dev(b if lb == "kn" else b.transpose(0, 2, 1).copy())
+    sa = (K, 1, M * K) if la == "mk" else (1, M, M * K)
+    sb = (N, 1, K * N) if lb == "kn" else (1, K, K * N)
+    red = atomic and batch > 1                                  # batch as an extra reduction axis (sc_b = 0)
+    out = torch.zeros((1 if red else batch), M, N, device="cuda")
+    st = (*sa, *sb, N, 1, 0 if red else M * N)
+    arr = (C.c_int64 * 9)(*st)
+    _lib.check(lib.mimrl_op_gemm(stream(), P(A), P(Bm), P(out), M, N, K, batch, arr, None, None, 1.0, 0.0, 256 * atomic, 1))
+    torch.cuda.synchronize()
+    ref = np.einsum("bmk,bkn->bmn", _bf16_round(a), _bf16_round(b))
+    if red:
+        ref = ref.sum(0, keepdims=True)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err <= 3e-6 * K * (batch if red else 1) + 1e-5, f"{layout} {M}x{N}x{K}: max |err| {err}"
+
+
+def test_gemm_fast_path_dual_gap_epilogues(lib):
+    """Second product (C = A.B + A2.B2: both directions of a bi-GRU data gradient), the row gap in A (dgh = columns
+    [0,2H) u [3H,4H) of dg), act'(u) epilogue and fused column sums -- the parts of GemmDesc the engine drives."""
+    g = np.random.default_rng(5)
+    M, N, K = 640, 256, 384
+    a1, a2 = g.standard_normal((M, 512)).astype(np.float32), g.standard_normal((M, 512)).astype(np.float32)
+    w1, w2 = g.standard_normal((K, N)).astype(np.float32), g.standard_normal((K, N)).astype(np.float32)
+    u = g.standard_normal((M, N)).astype(np.float32)
+    out = torch.zeros(M, N, device="cuda")
+    cs = torch.zeros(N, device="cuda")
+    st = (C.c_int64 * 9)(512, 1, 0, N, 1, 0, N, 1, 0)
+    st2 = (C.c_int64 * 6)(512, 1, 0, N, 1, 0)
+    A1, A2, W1, W2, U = dev(a1), dev(a2), dev(w1), dev(w2), dev(u)
+    _lib.check(lib.mimrl_op_gemm_ex(stream(), P(A1), P(W1), P(out), M, N, K, 1, st, P(A2), P(W2), K, st2, 0, 0, None, P(U), P(cs), 1, 1))
+    torch.cuda.synchronize()
+    ref = (_bf16_round(a1[:, :K]) @ _bf16_round(w1) + _bf16_round(a2[:, :K]) @ _bf16_round(w2)) * (u > 0)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 3e-6 * 2 * K + 1e-5
+    assert_close(cs.cpu().numpy(), ref.sum(0), 1e-4, 2e-3, "fused column sums")
+    # TN with a gap in A's row axis: rows m >= 256 of A^T live 128 further on (columns [0,256) u [384,512) of a1)
+    hp = g.standard_normal((M, 128)).astype(np.float32)
+    Hp = dev(hp)
+    dw = torch.zeros(384, 128, device="cuda")
+    st = (C.c_int64 * 9)(1, 512, 0, 128, 1, 0, 128, 1, 0)
+    _lib.check(lib.mimrl_op_gemm_ex(stream(), P(A1), P(Hp), P(dw), 384, 128, M, 1, st, None, None, 0, None, 256, 128, None, None, None, 256, 1))
+    torch.cuda.synchronize()
+    sel = np.concatenate([a1[:, :256], a1[:, 384:512]], axis=1)
+    ref = _bf16_round(sel).T @ _bf16_round(hp)
+    assert np.abs(dw.cpu().numpy() - ref).max() <= 3e-6 * M + 1e-5
+
+
 def _gru_case(B, T, d, seed, ragged):
     g = np.random.default_rng(seed)
     H = 128

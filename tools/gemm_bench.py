@@ -27,3 +27,14 @@ run("cmi l0: NT 128x256x384 x6", 128, 256, 384, 6, (384,1,128*384, 1,384,256*384
 run("wgrad TN 384x256x6400", 384, 256, BT, 1, (1,384,0, 256,1,0, 256,1,0), (BT,384), (BT,256), (384,256), act=256)
 run("wgrad TN 128x128x19200", 128, 128, 19200, 1, (1,128,0, 128,1,0, 128,1,0), (19200,128), (19200,128), (128,128), act=256)
 run("L-mix wgrad: dY_b.H_b^T x128 ->50x50", 50, 50, 384, 128, (384,1,50*384, 1,384,50*384, 50,1,0), (128,50,384), (128,50,384), (50,50), act=256)
+
+# ---- cfg3-sized (B=256, T=500) and concat-critic shapes
+BT3 = 128000
+run("cfg3 gx l1: NT 128000x384x256 x4", BT3, 384, 256, 4, (256,1,0, 1,256,384*256, 384,1,BT3*384), (BT3,256), (4,384,256), (4,BT3,384), iters=10)
+run("cfg3 W_t: NT 128000x128x768", BT3, 128, 768, 1, (768,1,0, 1,768,0, 128,1,0), (BT3,768), (128,768), (BT3,128), iters=10)
+run("cfg3 dh0: NN 128000x256x384 x2", BT3, 256, 384, 2, (384,1,BT3*384, 256,1,384*256, 256,1,BT3*256), (2,BT3,384), (2,384,256), (2,BT3,256), iters=10)
+run("cfg3 wgrad TN 384x256x128000", 384, 256, BT3, 1, (1,384,0, 256,1,0, 256,1,0), (BT3,384), (BT3,256), (384,256), act=256, iters=10)
+run("concat tail: NT 65536x256x256 x5", 65536, 256, 256, 5, (256,1,65536*256, 1,256,256*256, 256,1,65536*256), (5,65536,256), (5,256,256), (5,65536,256), iters=10)
+run("concat dgrad: NN 65536x256x256 x5", 65536, 256, 256, 5, (256,1,65536*256, 256,1,256*256, 256,1,65536*256), (5,65536,256), (5,256,256), (5,65536,256), iters=10)
+run("concat wgrad: TN 256x256x65536 x5", 256, 256, 65536, 5, (1,256,65536*256, 256,1,65536*256, 256,1,256*256), (5,65536,256), (5,65536,256), (5,256,256), act=256, iters=10)
+run("cfg3 L-mix: W[50,500].X_b[500,384] x256", 50, 384, 500, 256, (500,1,0, 384,1,500*384, 384,1,50*384), (50,500), (256,500,384), (256,50,384), iters=10)
