@@ -67,8 +67,9 @@ def workload(name):
     return SimpleNamespace(**base), c["bank"]
 
 
-def algorithmic_flops(opt, N):
-    """2 * (4 F_m + 5 F_c + 2 F_k) MACs per two-stage iteration."""
+def flop_terms(opt, N):
+    """SURVEY.md 8(d) MAC counts per pass: F_pre (W_t projection + both bi-GRU stacks: the part of Model.forward in front of the
+    first dropout), F_tail (CubeMLP + head), F_c (all 11 estimators, concat layer 0 in its separable form), F_k (kNN)."""
     B, T, D = opt.batch_size, opt.time_len, 128
     gru = lambda d: T * 2 * (3 * H * (d + H) + 3 * H * 3 * H)
     cube, d_in = 0, [T, 3, D]
@@ -78,12 +79,26 @@ def algorithmic_flops(opt, N):
         cube += out[0] * d * (k * hid[1] + hid[1] * out[1] + k * out[1])
         cube += out[0] * out[1] * (d * hid[2] + hid[2] * out[2] + d * out[2])
         d_in = out
-    F_m = B * (T * 768 * H + gru(74) + gru(35) + cube + H)
+    F_pre = B * (T * 768 * H + gru(74) + gru(35))
+    F_tail = B * (cube + H)
     mi = 5 * (2 * B * 196608 + B * B * 128) if opt.critic_type == "separate" else 5 * (2 * B * 32768 + B * B * 131328)
     F_c = mi + 6 * 2 * B * 229888
     m = B // opt.k_neighbor
     F_k = m * (N - m) * (4 * 128 + 2 * 1)
-    return 2.0 * (4 * F_m + 5 * F_c + 2 * F_k)
+    return F_pre, F_tail, F_c, F_k
+
+
+def algorithmic_flops(opt, N):
+    """2 * (4 F_m + 5 F_c + 2 F_k) FLOPs per two-stage iteration (F_m = F_pre + F_tail)."""
+    F_pre, F_tail, F_c, F_k = flop_terms(opt, N)
+    return 2.0 * (4 * (F_pre + F_tail) + 5 * F_c + 2 * F_k)
+
+
+def executed_flops(opt, N, shared_prefix):
+    """What the engine actually executes: with the shared encoder prefix (Solver.step overlap mode) the two forward passes
+    of a step evaluate W_t + the GRUs ONCE, so the prefix is charged 3x (1 forward + 2x backward) instead of 4x."""
+    F_pre, F_tail, F_c, F_k = flop_terms(opt, N)
+    return 2.0 * ((3 if shared_prefix else 4) * F_pre + 4 * F_tail + 5 * F_c + 2 * F_k)
 
 
 def cpu_baseline(opt, N, budget_s=25.0):
@@ -132,6 +147,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="run the two stages strictly one after the other")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--no-extra", action="store_true", help="skip the sequential / fresh-batch schedules")
     args = ap.parse_args()
 
     world, rank, local = mdist.init_from_env()
@@ -155,12 +171,14 @@ def main():
 
     # Solver.step() mode: both stages work on the same batch, so the stage-2 forward pass is issued beside stage 1
     # (same arithmetic and results as the sequential order; tests/test_gpu_step.py::test_stage2_prefetch_matches_sequential)
-    eng.set_stage2_prefetch(not args.no_prefetch)
+    eng.set_stage2_prefetch(0 if args.no_prefetch else (2 if world > 1 else 1))   # world > 1: deferred-tail variant (dist.py)
 
     def step():
-        if world > 1:
+        if world > 1 and args.no_prefetch:
             mdist.ddp_stage_step(eng, 1, world)
             mdist.ddp_stage_step(eng, 2, world)
+        elif world > 1:
+            mdist.ddp_two_stage_step(eng, world)    # critic-bucket all-reduce under the stage-2 forward tail
         else:
             eng.step()            # mimrl_two_stage_step: in overlap mode with graphs both stages are ONE captured graph
 
@@ -194,57 +212,123 @@ def main():
     scal = eng.read_scalars()
     finite = bool(np.isfinite(scal).all())
 
-    # ---- live per-phase / dominant-kernel timing with HIP events on the engine's stream (eager launches)
-    phases, roof = {}, None
+    # ---- the other schedules of the same step (same engine, same batch): strictly sequential stages (what Solver.train's
+    #      epoch-ordered passes get per stage pair) and fresh host batches through the overlapped upload path (PCIe-inclusive)
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t) / n
+
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_extra:
+        n_x = max(10, min(args.steps, 100))
+        if not args.no_prefetch:
+            eng.set_stage2_prefetch(False)
+            extra["ms_per_step_sequential"] = timed(eng.step, n_x)
+            eng.set_stage2_prefetch(True)
+        host = [tuple(torch.from_numpy(x).pin_memory() for x in synth.synthetic_batch(B, T, seed=100 + i)) for i in range(4)]
+        state = {"i": 0}
+        eng.stage_batch(*host[0])
+
+        def fresh():
+            eng.commit_batch()
+            state["i"] += 1
+            eng.stage_batch(*host[state["i"] % len(host)])
+            eng.step()
+
+        extra["ms_per_step_fresh_batch"] = timed(fresh, n_x)
+        extra["fresh_batch_note"] = (f"every step binds a NEW host batch ({sum(x.numel() * 4 for x in host[0]) / 1e6:.1f} MB, pinned): H2D on a copy "
+                                     "stream under the previous step, then 4 device-to-device copies into the bound buffers")
+        eng.set_batch(*synth.synthetic_batch(B, T, seed=rank))
+        log(f"extra schedules: {extra.get('ms_per_step_sequential')} ms sequential, {extra['ms_per_step_fresh_batch']:.3f} ms fresh-batch")
+
+    # ---- live per-phase and GEMM-family timing with HIP events on the launch streams (eager launches)
+    phases, roof, kernels = {}, None, []
     if rank == 0 and args.profile_steps > 0:
         eng.profile(True)
         for _ in range(3):
             eng.stage1_step(); eng.stage2_step()
-        eng.profile_read()
+        eng.profile_read(); eng.profile_read_gemm()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(args.profile_steps):
             eng.stage1_step(); eng.stage2_step()
         ev1.record()
         pr = eng.profile_read()
+        gm = eng.profile_read_gemm()
         eager_ms = ev0.elapsed_time(ev1) / args.profile_steps
         eng.profile(False)
         log(f"phase profile done (eager {eager_ms:.3f} ms/step)")
-        phases = {k: {"ms_per_step": v[0] / args.profile_steps, "launch_groups_per_step": v[1] / args.profile_steps}
-                  for k, v in pr.items() if v[1]}
+        n = args.profile_steps
+        phases = {k: {"ms_per_step": v[0] / n, "launch_groups_per_step": v[1] / n} for k, v in pr.items() if v[1]}
         phases["eager_total_ms_per_step"] = eager_ms
-        # dominant single kernel: the persistent bi-GRU recurrence (one launch per layer).  With the shared encoder prefix
-        # (default: both forward passes of a two-stage step read ONE evaluation of the encoders) that is 2 forward
-        # launches per step, both saving the gates for BPTT; without it 4, of which 2 save.  Which roofline binds it?
-        # Per launch it moves ~79 MB (>= 10 us at 8 TB/s) and does 2.5 GFLOP (1 us at the bf16 MFMA peak): HBM is the
-        # nearer ceiling, so that is the one reported; the MFMA figures ride along as extra keys.  What actually limits
-        # it is the serial dependence of T cell steps.
         shared_prefix = (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX")
+        bf = bool(_lib.PREC[args.precision] & 1)
+        peak_mfma = PEAK_TFLOPS["bf16" if bf else "fp32"]
+        # --- kernel families, by time per step (summed launch durations; branches of a step overlap, so they do not add up
+        #     to the step time).  GEMM: every gemm() launch bracketed by events on its own stream, algorithmic FLOPs/bytes
+        #     from its descriptor.  GRU / CubeMLP / estimator stacks / Adam: the phase events.
         save_frac = 1.0 if shared_prefix else 0.5
         gru_bf16 = bool(_lib.PREC[args.precision] & 4)
-        fl = 2 * 2 * B * T * (H * 3 * H) * 2.0          # 2 modalities x 2 directions, [B,T] x (128 x 384) MACs
-        gate_bytes = 2 if gru_bf16 else 4
-        alg_bytes = (4 * B * T * 3 * H * 4             # gx[B,T,384] fp32 per (modality, direction): read
-                     + 4 * (3 * H * H + 3 * H) * 4     # W_hh, b_hh
-                     + 2 * B * T * 2 * H * 4           # h[B,T,256] per modality: written
-                     + save_frac * 4 * B * T * 4 * H * gate_bytes)   # saved gates (r,z,n,hn) on the launches that train
-        avg_ms = pr["gru_fwd"][0] / max(pr["gru_fwd"][1], 1)
-        ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes (separate runs), committed
-        if os.path.exists(pmc) and args.workload == "cfg2" and args.precision == "bf16":
+        gru_fl = 2 * 2 * B * T * (H * 3 * H) * 2.0          # per launch: 2 modalities x 2 directions, [B,T] x (128 x 384) MACs
+        gru_by = (4 * B * T * 3 * H * 4 + 4 * (3 * H * H + 3 * H) * 4 + 2 * B * T * 2 * H * 4
+                  + save_frac * 4 * B * T * 4 * H * (2 if gru_bf16 else 4))
+        F_pre, F_tail, F_c, F_k = flop_terms(opt, N)
+
+        def row(name, ms_total, launches, flops_total, bytes_total, note=""):
+            if not launches:
+                return None
+            us = 1e3 * ms_total / launches
+            return {"kernel": name, "ms_per_step": ms_total / n, "launches_per_step": launches / n, "avg_launch_us": us,
+                    "gflop_per_launch": flops_total / launches / 1e9, "mbytes_per_launch": bytes_total / launches / 1e6,
+                    "achieved_tflops": flops_total / (ms_total * 1e-3) / 1e12 if ms_total else 0.0,
+                    "achieved_gbs": bytes_total / (ms_total * 1e-3) / 1e9 if ms_total else 0.0, "note": note}
+
+        kernels = [r for r in (
+            row("gemm family (gemm_fast_kernel<*> / gemm_kernel<*>: projections, data and weight gradients)", gm["ms"], gm["launches"],
+                gm["flops"], gm["bytes"], "per-launch events on each launch's own stream; operands + output counted once"),
+            row("gru_fwd_kernel (persistent bi-GRU recurrence, one launch per layer)", pr["gru_fwd"][0], pr["gru_fwd"][1],
+                gru_fl * pr["gru_fwd"][1], gru_by * pr["gru_fwd"][1], f"{T} serial cell steps per launch"),
+            row("gru_bwd_kernel (BPTT, one launch per layer)", pr["gru_bwd"][0], pr["gru_bwd"][1], 2 * gru_fl * pr["gru_bwd"][1],
+                (4 * B * T * 4 * H * 4 + 4 * B * T * H * 4 + gru_by) * pr["gru_bwd"][1]),
+            row("cube_fwd (fused CubeMLP block kernels, or the unfused chain)", pr["cube_fwd"][0], pr["cube_fwd"][1],
+                2.0 * F_tail * pr["cube_fwd"][1], 0.0, "phase = one whole CubeMLP forward"),
+            row("cube_bwd (CubeMLP data-gradient chain)", pr["cube_bwd"][0], pr["cube_bwd"][1], 2.0 * F_tail * pr["cube_bwd"][1], 0.0,
+                "phase = one whole CubeMLP backward chain (weight gradients are in the gemm family)"),
+            row("estimators forward (critic towers / classifiers + bounds; MI branch)", pr["est_fwd"][0], pr["est_fwd"][1],
+                2.0 * F_c * pr["est_fwd"][1], 0.0),
+            row("estimators backward (MI branch)", pr["est_bwd"][0], pr["est_bwd"][1], 2.0 * F_c * pr["est_bwd"][1], 0.0),
+            row("adam_kernel (fused clip + Adam, flat bucket)", pr["opt"][0], pr["opt"][1], 0.0,
+                7 * 4.0 * (eng.main["p"].numel() + eng.crit["p"].numel()) / 2 * pr["opt"][1], "HBM-bound: 7 words per parameter"),
+        ) if r]
+        kernels.sort(key=lambda r: -r["ms_per_step"])
+        top = kernels[0]
+        traffic, tsrc = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes of THIS round (separate runs), committed
+        if os.path.exists(pmc) and args.workload == "cfg2" and args.precision == "bf16" and top["kernel"].startswith("gemm"):
             ks = json.load(open(pmc))["kernels"]
-            k = ks.get("gru_fwd_kernel<true, true>") or ks.get("gru_fwd_kernel<true>")
-            traffic = k and k["traffic_bytes_per_launch"]
-        roof = {"bound": "hbm", "kernel": "gru_fwd_kernel (persistent bi-GRU recurrence, one launch per layer)",
-                "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), bytes per launch",
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-                "mfma": {"flops_per_launch": fl, "achieved_tflops": fl / (avg_ms * 1e-3) / 1e12,
-                         "peak_tflops": PEAK_TFLOPS["bf16" if gru_bf16 else "fp32"],
-                         "frac": fl / (avg_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16" if gru_bf16 else "fp32"]},
-                "serial_cell_steps_per_launch": T, "us_per_cell_step": 1e3 * avg_ms / T,
-                "share_of_step": pr["gru_fwd"][0] / args.profile_steps / eager_ms}
+            tot = [(v["traffic_bytes_per_launch"], v["launches_per_step"]) for k, v in ks.items() if "gemm" in k]
+            if tot:
+                traffic = sum(a * b for a, b in tot) / sum(b for _, b in tot)
+                tsrc = "profiles/r02_pmc_hbm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), mean bytes per gemm launch"
+        mf = top["achieved_tflops"] / peak_mfma
+        hb = top["achieved_gbs"] / PEAK_HBM_GBS
+        bound = "mfma" if (top["kernel"].startswith("gemm") or mf >= hb) else "hbm"
+        roof = {"bound": bound, "kernel": top["kernel"],
+                "selection": "largest summed launch time per step among the kernel families measured live (see `kernels`)",
+                "achieved": top["achieved_tflops"] if bound == "mfma" else top["achieved_gbs"],
+                "peak": peak_mfma if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": mf if bound == "mfma" else hb, "traffic": traffic, "traffic_source": tsrc,
+                "algorithmic_flops_per_launch": top["gflop_per_launch"] * 1e9, "algorithmic_bytes_per_launch": top["mbytes_per_launch"] * 1e6,
+                "avg_launch_ms": top["avg_launch_us"] / 1e3, "launches_per_step": top["launches_per_step"],
+                "share_of_eager_step": top["ms_per_step"] / eager_ms,
+                "hbm_view": {"achieved_gbs": top["achieved_gbs"], "peak": PEAK_HBM_GBS, "frac": hb},
+                "mfma_view": {"achieved_tflops": top["achieved_tflops"], "peak": peak_mfma, "frac": mf}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -257,17 +341,24 @@ def main():
             "unit": "two-stage iters/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if _lib.PREC[args.precision] else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: MOSI-shaped synthetic triples B={B}/rank T={T} d=768/74/35, gru, "
+            "config": {"workload": f"{args.workload}: {'MOSEI' if T >= 500 else 'MOSI'}-shaped synthetic triples B={B}/rank T={T} d=768/74/35, gru, "
                                    f"d_common=128, CubeMLP 50-3-128=10-3-128, {opt.critic_type} InfoNCE critics, kNN-CMI k=2, "
                                    f"banks N={N}, Adam lr 4e-3, dropout 0.1",
-                       "unit_definition": "one iter = stage-1 + stage-2 update over one B=128 batch; under weak-scaling DP every "
+                       "unit_definition": f"one iter = stage-1 + stage-2 update over one B={B} batch; under weak-scaling DP every "
                                           "global step processes n_gpus such batches (gradients all-reduced), so value = n_gpus*steps/time",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
                        "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch,
                        "shared_encoder_prefix": (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX"), "samples_per_sec": B * world * args.steps / wall},
             "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,
             "achieved_tflops_whole_step": world * algorithmic_flops(opt, N) / (wall / args.steps) / 1e12,
-            "roofline": roof, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,
+            "whole_step": {"algorithmic_gflop": algorithmic_flops(opt, N) / 1e9,
+                           "executed_gflop": executed_flops(opt, N, (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX")) / 1e9,
+                           "achieved_tflops_algorithmic": world * algorithmic_flops(opt, N) / (wall / args.steps) / 1e12,
+                           "achieved_tflops_executed": world * executed_flops(opt, N, (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX")) / (wall / args.steps) / 1e12,
+                           "peak_tflops": PEAK_TFLOPS["bf16" if _lib.PREC[args.precision] else "fp32"],
+                           "frac_of_mfma_peak_executed": world * executed_flops(opt, N, (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX")) / (wall / args.steps) / 1e12 / (world * PEAK_TFLOPS["bf16" if _lib.PREC[args.precision] else "fp32"])},
+            **extra,
+            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,
             "stage1_loss": float(scal[_lib.S1_LOSS]), "stage2_loss": float(scal[_lib.S2_LOSS]),
         }
         print(json.dumps(out))

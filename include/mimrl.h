@@ -135,6 +135,16 @@ int mimrl_estimate(mimrl_handle* h, int stage);        /* estimators only, on th
  * the bound inputs, the banks, host-supplied anchors of EITHER stage (mimrl_set_anchors) or main parameters; a stage-2
  * call without a preceding stage-1 call fails with MIMRL_ERR_STATE.  Ignored while the banks are empty (epoch-0 rule). */
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on);
+/* Data-parallel variant (on = 2, "deferred tail"): as above, except that the stage-2 forward TAIL (everything behind the
+ * first dropout: LN+ReLU+dropout, CubeMLP, head; Model.py:452-515) is not issued beside stage 1 but by this call, which
+ * the caller places between the START of the stage-1 gradient all-reduce and mimrl_stage_apply(1): the collective of the
+ * critic bucket (the larger one) then runs under it.  Order per step: mimrl_stage_grads(1) -> all-reduce(crit_g) [async]
+ * -> mimrl_stage2_forward_tail -> wait -> mimrl_stage_apply(1) -> mimrl_stage_grads(2) -> all-reduce(main_g) ->
+ * mimrl_stage_apply(2).  A no-op in the other modes and while the banks are empty. */
+int mimrl_stage2_forward_tail(mimrl_handle* h);
+/* The gradient buckets are multiplied by `scale` inside the fused clip+Adam (before clipping): 1/world_size after a SUM
+ * all-reduce, so that no separate scaling pass runs over the bucket.  Default 1. */
+int mimrl_set_grad_scale(mimrl_handle* h, float scale);
 /* Tell the engine that parameter buckets were written from outside (checkpoint load, broadcast): cached bf16 images of
  * the critic parameters are rebuilt at the next call.  mimrl_bind implies it; the engine's own Adam keeps them fresh. */
 int mimrl_params_changed(mimrl_handle* h);
@@ -144,6 +154,9 @@ enum { MIMRL_PH_GEMM_MISC = 0, MIMRL_PH_GRU_FWD, MIMRL_PH_GRU_BWD, MIMRL_PH_CUBE
        MIMRL_PH_EST_BWD, MIMRL_PH_OPT, MIMRL_PH_MODEL_MISC, MIMRL_NPHASES };
 int mimrl_profile_enable(mimrl_handle* h, int on);     /* forces eager launches while on */
 int mimrl_profile_read(mimrl_handle* h, float* ms_sum /*[MIMRL_NPHASES]*/, int32_t* launches /*[MIMRL_NPHASES]*/);  /* syncs; resets */
+/* GEMM family of the eager steps since the last read: out = {algorithmic FLOPs, algorithmic bytes (operands and output once),
+ * summed launch durations in ms (HIP events on each launch's own stream), launches}; syncs; resets */
+int mimrl_profile_read_gemm(mimrl_handle* h, double out[4]);
 void mimrl_destroy(mimrl_handle* h);
 
 /* ---- operator-level entry points (used by the parity tests; all asynchronous on `stream`) ---- */

@@ -45,7 +45,7 @@ class Solver:
             loaders = get_data_loader(opt, self.rank, self.world)          # training data sharded by rank
         self.train_loader, self.valid_loader, self.test_loader, self.d_t, self.d_a, self.d_v = loaders
         if torch.cuda.is_available():
-            torch.cuda.set_device(self.local_rank)
+            torch.cuda.set_device(self.local_rank % torch.cuda.device_count())   # (more ranks than GPUs: ranks share devices)
         # banks hold one row per training sample of EVERY rank (all-gathered once per epoch)
         cap = _loader_samples(self.train_loader, opt.batch_size) * self.world
         self.model = Model(opt, self.d_t, self.d_a, self.d_v, bank_capacity=cap, rank=self.rank)
@@ -84,15 +84,15 @@ class Solver:
     def get_label_from_datas(self, datas):
         return datas[5]                                                       # Solver.py:273-275 ('Dec' layout)
 
-    def _engine_for(self, B: int) -> HipEngine:
+    def _engine_for(self, B: int, training: bool = True) -> HipEngine:
         """The engine whose batch size is ``B``: the primary one, or a lazily created sibling sharing its optimizer."""
         B = int(B)
         e = self.engine if B == self.engine.cfg.batch else self._tails.get(B)
         if e is None:
             if B > self.engine.cfg.batch or B < int(self.opt.k_neighbor):
                 raise _lib.MimrlError(f"batch of {B} rows: need k_neighbor <= B <= --batch_size {self.engine.cfg.batch}")
-            if self.world > 1:
-                raise _lib.MimrlError("data-parallel ranks need full batches (sharded loaders drop the ragged tail)")
+            if self.world > 1 and training:     # (evaluation has no collectives: a short last batch is fine there)
+                raise _lib.MimrlError("data-parallel ranks need full training batches (sharded loaders drop the ragged tail)")
             p = self.engine
             e = HipEngine(self.opt, self.d_t, self.d_a, self.d_v, seq_len=p.cfg.seq_len, precision=p.precision,
                           use_graph=bool(p.cfg.use_graph), seed=int(p.cfg.seed), device=p.device,
@@ -103,9 +103,10 @@ class Solver:
             self._active = e
         if e.bank_rows != self.engine.bank_rows:
             e.set_bank_rows(self.engine.bank_rows)
-        if getattr(e, "_prefetch_on", False) != self._want_prefetch:
-            e.set_stage2_prefetch(self._want_prefetch)
-            e._prefetch_on = self._want_prefetch
+        want = (2 if self.world > 1 else 1) if self._want_prefetch else 0     # data parallel: deferred-tail variant (dist.py)
+        if getattr(e, "_prefetch_on", 0) != want:
+            e.set_stage2_prefetch(want)
+            e._prefetch_on = want
         return e
 
     def _load(self, datas) -> HipEngine:
@@ -113,6 +114,27 @@ class Solver:
         e = self._engine_for(len(labels))
         e.set_batch(feats, a, v, labels)
         return e
+
+    def _iter_loaded(self, loader, training: bool = True):
+        """Iterate ``(engine, datas)`` over a loader with each batch bound to its engine, uploading batch i+1 on a copy
+        stream while the caller's step on batch i runs (HipEngine.stage_batch / commit_batch)."""
+        it = iter(loader)
+        cur = next(it, None)
+        staged = None
+        while cur is not None:
+            _, a, v, _, _, labels, feats, _, _, _, _ = cur
+            e = self._engine_for(len(labels), training)
+            if staged is e:
+                e.commit_batch()
+            else:
+                e.set_batch(feats, a, v, labels)
+            nxt = next(it, None)
+            staged = None
+            if nxt is not None and len(nxt[5]) == e.cfg.batch:
+                e.stage_batch(nxt[6], nxt[1], nxt[2], nxt[5])
+                staged = e
+            yield e, cur
+            cur = nxt
 
     def _anchors(self, e, stage):
         if e.bank_rows > 0 and not e.cfg.device_anchors:
@@ -178,15 +200,13 @@ class Solver:
         nb = len(train_loader)
         if epoch > 0 and len(C_F_all) > 0:                                     # Solver.py:200-203: epoch 0 skips stage 1
             for _ in range(self.opt.stage1_n):
-                for datas in self.train_loader:
-                    e = self._load(datas)
+                for e, datas in self._iter_loaded(self.train_loader):
                     self._anchors(e, 1)
                     self._stage(e, 1)
                     acc[_lib.S1_LOSS] += e.scalars[_lib.S1_LOSS]
         new = {k: [] for k in "CFTAV"}
         preds, targs = [], []
-        for datas in train_loader:
-            e = self._load(datas)
+        for e, datas in self._iter_loaded(train_loader):
             self._anchors(e, 2)
             self._stage(e, 2)
             new["C"].append(e.labels.reshape(-1, 1).clone())                   # Solver.py:223-227 (features of THIS pass)
@@ -211,8 +231,7 @@ class Solver:
         self._set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)
         acc = torch.zeros(_lib.NSCALARS, device=self.engine.device)
         preds, targs, feats = [], [], []
-        for datas in valid_loader:
-            e = self._load(datas)
+        for e, datas in self._iter_loaded(valid_loader, training=False):
             self._anchors(e, 2)
             e.forward(train=False, with_losses=True)
             acc += e.scalars

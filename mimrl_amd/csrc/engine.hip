@@ -191,7 +191,13 @@ struct mimrl_handle {
     for (int i = 0; i < MIMRL_MAX_BLOCKS; ++i) std::swap(bb[i], alt.bb[i]);
   }
   bool prefetch = false;               // mode switch (mimrl_set_stage2_prefetch)
+  bool defer_tail = false;             // prefetch mode 2: the stage-2 forward tail is NOT issued beside stage 1 but by
+                                       // mimrl_stage2_forward_tail (the caller runs it under the stage-1 gradient all-reduce)
+  bool tail2_needed = false;           // deferred tail still to be issued before stage 2 may run
   bool fwd2_pending = false;           // a prefetched stage-2 forward is waiting to be consumed
+  float grad_scale = 1.f;              // folded into the fused clip+Adam (mimrl_set_grad_scale)
+  hipGraphExec_t graph_tail = nullptr; int graph_tail_rows = -1;
+  int run_fwd2_tail();
   hipStream_t pre_stream = nullptr;
   int carve_fwd(size_t* gmax_out);
   float *ff = nullptr, *dpred = nullptr;
@@ -262,7 +268,29 @@ struct mimrl_handle {
     HIPX(hipStreamWaitEvent(S(i), e, 0));
     return MIMRL_OK;
   }
-  int G_on(hipStream_t st, const GemmDesc& d) { return gemm(st, d, bf16); }
+  // GEMM family accounting of the phase profiler: HIP events on the launch stream around every gemm() of an eager step,
+  // with the algorithmic FLOPs / bytes of the launch (operands and output counted once)
+  struct GemmProf { hipEvent_t a, b; double flops, bytes; };
+  std::vector<GemmProf> prof_gemm;
+  int G_on(hipStream_t st, const GemmDesc& d) {
+    if (!prof_on) return gemm(st, d, bf16);
+    GemmProf g;
+    if (!prof_pool.empty()) { g.a = prof_pool.back().first; g.b = prof_pool.back().second; prof_pool.pop_back(); }
+    else { HIPX(hipEventCreate(&g.a)); HIPX(hipEventCreate(&g.b)); }
+    auto distinct = [&](long s_b, long s_bo) -> double {
+      if (d.batch_in > 0) return (double)(s_bo != 0 ? d.batch / d.batch_in : 1) * (s_b != 0 ? d.batch_in : 1);
+      return s_b != 0 ? d.batch : 1;
+    };
+    g.flops = 2.0 * d.M * d.N * ((double)d.K + (d.A2 ? d.K2 : 0)) * d.batch;
+    g.bytes = 4.0 * ((double)d.M * d.K * distinct(d.sa_b, d.sa_bo) + (double)d.K * d.N * distinct(d.sb_b, d.sb_bo) +
+                     (double)d.M * d.N * distinct(d.sc_b, d.sc_bo) * ((d.beta != 0.f || d.atomic) ? 2 : 1));
+    if (d.A2) g.bytes += 4.0 * ((double)d.M * d.K2 * (d.sa2_b ? d.batch : 1) + (double)d.K2 * d.N * (d.sb2_b ? d.batch : 1));
+    HIPX(hipEventRecord(g.a, st));
+    const int r = gemm(st, d, bf16);
+    HIPX(hipEventRecord(g.b, st));
+    prof_gemm.push_back(g);
+    return r;
+  }
 
   // phase profiler
   bool prof_on = false;
@@ -328,7 +356,7 @@ struct mimrl_handle {
   struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst;
                     const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW(); };
   std::vector<Deferred> deferred;
-  int flush_deferred(int only_side = 0);
+  int flush_deferred(int only_side = 0, hipEvent_t after = nullptr);
   int wg_helper = -1;                  // side stream that takes every second weight-gradient GEMM of an MLP stack (-1: none)
   int dbg_delay(hipStream_t st, int tag);   // critical-path probe (MIMRL_DBG_DELAY_TAG / _US): a spin kernel behind one phase
   int model_forward(bool train, bool save, int knn_stage = 0, int part = 0);   // part: 0 all, 1 prefix, 2 tail
@@ -1254,9 +1282,14 @@ int mimrl_handle::dbg_delay(hipStream_t st, int tag) {
   return MIMRL_OK;
 }
 
-int mimrl_handle::flush_deferred(int only_side) {
+// `after`: an event recorded earlier on the main stream; the side streams then wait for THAT point instead of the main
+// stream's current position (lets the caller enqueue -- and, in a captured graph, order -- main-stream work in front of the
+// parked kernels without making them depend on it)
+int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   if (deferred.empty()) return MIMRL_OK;
-  if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
+  if (after && multi_stream) {
+    for (int i = 1; i <= 3; ++i) if (side_on(i)) HIPX(hipStreamWaitEvent(side[i], after, 0));
+  } else if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
   for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
   static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
   for (const Deferred& d : deferred) {
@@ -1302,7 +1335,18 @@ int mimrl_handle::model_backward() {
                       cfg.dropout[1 + m], (uint32_t)(1 + m)};
     MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key()));
   }
-  MX(flush_deferred());   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT
+  // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT.  Tuning knob MIMRL_BPTT_FIRST=1 captures the BPTT launch in
+  // front of the parked kernels (graph nodes are dispatched in capture order).  Measured on cfg2: 1.58 vs 1.36 ms -- the
+  // recurrence is latency-bound and loses more to the weight-gradient kernels sharing its CUs from the first cell step on
+  // than the ~100 us it waits behind their first wave; default off.
+  static const bool bptt_first = getenv("MIMRL_BPTT_FIRST") != nullptr;
+  hipEvent_t ev_pre = nullptr;
+  if (bptt_first && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU && !deferred.empty()) {
+    MX(next_event(&ev_pre));
+    HIPX(hipEventRecord(ev_pre, stream));
+  } else {
+    MX(flush_deferred());
+  }
   if (cfg.encoder == MIMRL_ENCODER_CONV) {
     MX(conv_backward());
     MX(join(0, 5));
@@ -1328,6 +1372,7 @@ int mimrl_handle::model_backward() {
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
+    if (l == 1 && ev_pre) MX(flush_deferred(0, ev_pre));
     MX(dbg_delay(stream, 8));
     MX(fork(1, l == 0 ? 5 : 3));   // the weight gradients below depend on the BPTT only
     static const bool dh0_last = getenv("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
@@ -1839,8 +1884,9 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       MX(next_event(&e_prefix));
       HIPX(hipEventRecord(e_prefix, stream));
       // (2) stage 2's tail: one sequential branch behind the prefix on pre_stream, into the primary set
-      HIPX(hipStreamWaitEvent(pre_stream, e_prefix, 0));
-      {
+      //     (deferred mode: issued later by mimrl_stage2_forward_tail, under the stage-1 gradient all-reduce)
+      if (!defer_tail) HIPX(hipStreamWaitEvent(pre_stream, e_prefix, 0));
+      if (!defer_tail) {
         StreamGuard g(this, pre_stream);
         const bool ms = multi_stream;
         multi_stream = false; rng_add = 1;     // begin_stage(2) has not run yet: use the dropout key it will produce
@@ -1881,7 +1927,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (prefetch && !share && !pre_first) MX(issue_prefetch(e_begin));
     hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
-    if (prefetch) {   // rejoin before the stage ends (a captured graph must not leave a dangling branch)
+    if (prefetch && !(share && defer_tail)) {   // rejoin before the stage ends (a captured graph must not leave a dangling branch)
       hipEvent_t e;
       MX(next_event(&e));
       HIPX(hipEventRecord(e, pre_stream));
@@ -1927,6 +1973,7 @@ int mimrl_handle::enqueue_apply(int stage) {
     a.lr = bufs.lr_main; a.step = d_ints + 1;
   }
   a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
+  a.gscale = grad_scale;
   Scope sc(this, MIMRL_PH_OPT);
   MX(adam_step(stream, a));
   return dbg_delay(stream, 12);
@@ -1941,9 +1988,11 @@ int mimrl_handle::run(int stage, int kind) {
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
   // an all-reduce): always zero first -- the caller may call it repeatedly
   if (prefetch && bank_rows > 0) {
-    if (stage == 1) fwd2_pending = true;
+    if (stage == 1) { fwd2_pending = true; tail2_needed = defer_tail; }
     else if (!fwd2_pending)
       return set_error(MIMRL_ERR_STATE, "stage-2 prefetch mode: stage 2 must follow a stage-1 call on the same batch");
+    else if (tail2_needed)
+      return set_error(MIMRL_ERR_STATE, "deferred-tail mode: call mimrl_stage2_forward_tail between stage 1 and stage 2");
     else fwd2_pending = false;
   }
   const bool skip_zero = kind == 0 && grads_clean[stage];
@@ -1982,13 +2031,51 @@ int mimrl_handle::run(int stage, int kind) {
   return MIMRL_OK;
 }
 
+// Deferred-tail mode (data parallel): the stage-2 forward tail of the bound batch -- LN+ReLU+dropout, CubeMLP, head, with the
+// activations saved for the backward pass -- as its own launch on the caller's stream.  The caller starts the all-reduce of the
+// stage-1 (critic) gradients first; this work needs neither those gradients nor the critic update, so the collective hides under it.
+int mimrl_handle::run_fwd2_tail() {
+  if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
+  if (!(prefetch && defer_tail && bank_rows > 0)) return MIMRL_OK;          // nothing deferred in the other modes
+  if (!tail2_needed) return set_error(MIMRL_ERR_STATE, "mimrl_stage2_forward_tail: no stage-1 call is pending");
+  tail2_needed = false;
+  auto body = [&]() -> int {
+    if (!keep_events) ev_next = 0;
+    const bool ms = multi_stream;
+    bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+    multi_stream = false; rng_add = 1;       // begin_stage(2) has not run yet: use the dropout key it will produce
+    const int r = model_forward(true, true, 0, 2);
+    multi_stream = ms; rng_add = 0;
+    return r;
+  };
+  if (!cfg.use_graph || prof_on) return body();
+  if (graph_tail && graph_tail_rows != bank_rows) { HIPX(hipGraphExecDestroy(graph_tail)); graph_tail = nullptr; }
+  if (!graph_tail) {
+    hipGraph_t g = nullptr;
+    if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+    stream = cap_stream;
+    const int r = body();
+    stream = user_stream;
+    const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
+    if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    const hipError_t ie = hipGraphInstantiate(&graph_tail, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) { graph_tail = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    graph_tail_rows = bank_rows;
+  }
+  HIPX(hipGraphLaunch(graph_tail, stream));
+  return MIMRL_OK;
+}
+
 // Solver.step(): stage 1 then stage 2 on the bound batch.  In overlap mode with graphs the two stages are ONE captured
 // graph (one launch, no idle device between the stage-1 Adam and the stage-2 estimators); otherwise two run() calls.
 int mimrl_handle::run_step() {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   static const bool no_step_graph = getenv("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
-  const bool combined = cfg.use_graph && !prof_on && prefetch && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
-  if (!combined) { MX(run(1, 0)); return run(2, 0); }
+  const bool combined = cfg.use_graph && !prof_on && prefetch && !defer_tail && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
+  if (!combined) { MX(run(1, 0)); if (defer_tail) MX(run_fwd2_tail()); return run(2, 0); }
   MX(ensure_images());
   hipGraphExec_t& ex = graph[0][0];
   if (ex && graph_rows[0][0] != bank_rows) {   // bank size is baked into the kernel arguments
@@ -2175,22 +2262,53 @@ int mimrl_profile_read(mimrl_handle* h, float* ms_sum, int32_t* launches) {
   return MIMRL_OK;
 }
 
+int mimrl_profile_read_gemm(mimrl_handle* h, double out[4]) {
+  if (!h || !out) return set_error(MIMRL_ERR_ARG, "null argument");
+  HIPX(hipStreamSynchronize(h->stream));
+  HIPX(hipDeviceSynchronize());
+  out[0] = out[1] = out[2] = 0.0; out[3] = (double)h->prof_gemm.size();
+  for (auto& g : h->prof_gemm) {
+    float ms = 0.f;
+    HIPX(hipEventElapsedTime(&ms, g.a, g.b));
+    out[0] += g.flops; out[1] += g.bytes; out[2] += ms;
+    h->prof_pool.push_back({g.a, g.b});
+  }
+  h->prof_gemm.clear();
+  return MIMRL_OK;
+}
+
 int mimrl_params_changed(mimrl_handle* h) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   h->img_valid = false;
   return MIMRL_OK;
 }
 
+int mimrl_stage2_forward_tail(mimrl_handle* h) { return h ? h->run_fwd2_tail() : set_error(MIMRL_ERR_ARG, "null handle"); }
+
+int mimrl_set_grad_scale(mimrl_handle* h, float scale) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if (scale == h->grad_scale) return MIMRL_OK;
+  HIPX(hipStreamSynchronize(h->user_stream));
+  for (int s = 0; s <= 2; ++s)            // the scale is a kernel argument of the captured Adam launches
+    for (int k = 0; k < 2; ++k)
+      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  h->grad_scale = scale;
+  return MIMRL_OK;
+}
+
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
-  if ((on != 0) == h->prefetch) return MIMRL_OK;
+  if ((on != 0) == h->prefetch && (on == 2) == h->defer_tail) return MIMRL_OK;
   if (on && !h->pre_stream) HIPX(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
   HIPX(hipStreamSynchronize(h->user_stream));
   for (int s = 0; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
       if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  if (h->graph_tail) { (void)hipGraphExecDestroy(h->graph_tail); h->graph_tail = nullptr; }
   h->prefetch = on != 0;
+  h->defer_tail = on == 2;
   h->fwd2_pending = false;
+  h->tail2_needed = false;
   return MIMRL_OK;
 }
 
@@ -2203,10 +2321,12 @@ void mimrl_destroy(mimrl_handle* h) {
       if (h->graph[s][k]) (void)hipGraphExecDestroy(h->graph[s][k]);
   for (int p = 0; p < MIMRL_NPHASES; ++p)
     for (auto& ev : h->prof_ev[p]) h->prof_pool.push_back(ev);
+  for (auto& g : h->prof_gemm) h->prof_pool.push_back({g.a, g.b});
   for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->graph_tail) (void)hipGraphExecDestroy(h->graph_tail);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
   if (h->ws) (void)hipFree(h->ws);

@@ -73,6 +73,7 @@ struct AdamArgs {
   const int* step;        // device counter, already incremented for this update
   float beta1, beta2, eps, weight_decay, clip;
   __bf16* pimg = nullptr; // optional: bf16 image of the updated parameters (the fused estimator kernels read weights from it)
+  float gscale = 1.f;     // the gradient is multiplied by this first (1 / world_size after a SUM all-reduce: no separate scaling pass)
 };
 int adam_step(hipStream_t s, const AdamArgs& a);
 

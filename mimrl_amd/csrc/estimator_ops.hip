@@ -587,7 +587,7 @@ __global__ void adam_kernel(AdamArgs a) {
   const float bc1 = 1.f - powf(a.beta1, (float)t), bc2 = 1.f - powf(a.beta2, (float)t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
-    float g = a.g[i];
+    float g = a.g[i] * a.gscale;
     if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);             // clip_grad_value_ (Solver.py:211-212)
     const float p = a.p[i];
     if (a.weight_decay != 0.f) g += a.weight_decay * p;

@@ -32,13 +32,12 @@ def init_from_env(backend: str = None):
     return world, rank, local
 
 
-def allreduce_mean_(flat: torch.Tensor, world: int):
-    """In-place mean over ranks of one flat bucket (a single collective; RCCL picks ring/tree/direct over xGMI)."""
+def allreduce_sum_(flat: torch.Tensor, world: int, async_op: bool = False):
+    """In-place SUM over ranks of one flat bucket (a single collective; RCCL picks ring/tree/direct over xGMI).  The 1/world
+    factor of the mean is folded into the engine's fused clip+Adam (``set_grad_scale``): no scaling pass over the bucket."""
     if world <= 1:
-        return flat
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.mul_(1.0 / world)
-    return flat
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
 def broadcast_(flat: torch.Tensor, src: int = 0):
@@ -47,19 +46,49 @@ def broadcast_(flat: torch.Tensor, src: int = 0):
     return flat
 
 
+def prepare_engine(engine, world: int):
+    """Once per engine: fold the mean's 1/world into Adam."""
+    if getattr(engine, "_ddp_world", None) != world:
+        engine.set_grad_scale(1.0 / world)
+        engine._ddp_world = world
+
+
 def ddp_stage_step(engine, stage: int, world: int):
-    """grads -> all-reduce(mean) of the stage's bucket -> clip+Adam.  ``engine`` needs stage_grads / stage_apply /
-    bucket_grad(stage).  The collective is enqueued on the same stream as the kernels: no host synchronisation."""
+    """grads -> all-reduce(sum) of the stage's bucket -> clip+Adam on bucket/world.  ``engine`` needs stage_grads /
+    stage_apply / bucket_grad(stage) / set_grad_scale.  The collective is enqueued behind the kernels in stream order: no host
+    synchronisation (RCCL); value-clipping happens after averaging, as in a single process."""
+    prepare_engine(engine, world)
     engine.stage_grads(stage)
     if world > 1 and engine.has_update(stage):
-        allreduce_mean_(engine.bucket_grad(stage), world)
+        allreduce_sum_(engine.bucket_grad(stage), world)
     engine.stage_apply(stage)
 
 
 def ddp_two_stage_step(engine, world: int):
-    """Solver.step() under data parallelism: stage 1 then stage 2, each grads -> all-reduce(mean) -> clip+Adam."""
-    ddp_stage_step(engine, 1, world)
-    ddp_stage_step(engine, 2, world)
+    """Solver.step() under data parallelism, with the critic-bucket collective hidden:
+
+        stage_grads(1)            shared encoder prefix, stage-1 tail, 11 estimators fwd+bwd  -> crit_g complete
+        all-reduce(crit_g) ASYNC  on RCCL's communication stream (13.4 MB, the larger bucket)
+        stage2_forward_tail()     LN+ReLU+dropout, CubeMLP, head of the stage-2 pass: needs neither crit_g nor the critic
+                                  update, so it runs UNDER the collective (engine in deferred-tail mode)
+        wait; stage_apply(1)      clip + Adam on crit_g / world  ->  stage 2's estimators see the updated critics
+        stage_grads(2); all-reduce(main_g); stage_apply(2)
+
+    The main bucket (4.3 MB) is reduced in one piece behind the backward pass: its last producers (GRU layer-0 and W_t
+    weight gradients) finish with the stage, and CubeMLP's weight gradients are deliberately issued late (beside the BPTT),
+    so there is no early-ready prefix of that bucket to reduce ahead of time.
+    Requires ``engine.set_stage2_prefetch(2)`` (Solver.step does it)."""
+    prepare_engine(engine, world)
+    engine.stage_grads(1)
+    work = allreduce_sum_(engine.bucket_grad(1), world, async_op=True) if (world > 1 and engine.has_update(1)) else None
+    engine.stage2_forward_tail()
+    if work is not None:
+        work.wait()
+    engine.stage_apply(1)
+    engine.stage_grads(2)
+    if world > 1:
+        allreduce_sum_(engine.bucket_grad(2), world)
+    engine.stage_apply(2)
 
 
 def allgather_rows(x: torch.Tensor, world: int) -> torch.Tensor:

@@ -171,9 +171,17 @@ class HipEngine:
     def stage2_step(self):
         check(self.lib.mimrl_stage2_step(self.handle))
 
-    def set_stage2_prefetch(self, on: bool):
-        """Overlap mode of Solver.step(): the stage-2 forward pass runs beside stage 1 (see include/mimrl.h)."""
+    def set_stage2_prefetch(self, on):
+        """Overlap mode of Solver.step(): the stage-2 forward pass runs beside stage 1 (see include/mimrl.h).
+        ``on`` = 2 ("deferred tail"): data-parallel variant, the stage-2 forward tail is issued by ``stage2_forward_tail``."""
         check(self.lib.mimrl_set_stage2_prefetch(self.handle, int(on)))
+
+    def stage2_forward_tail(self):
+        check(self.lib.mimrl_stage2_forward_tail(self.handle))
+
+    def set_grad_scale(self, scale: float):
+        """Multiply the gradient buckets by ``scale`` inside the fused clip+Adam (1 / world_size after a SUM all-reduce)."""
+        check(self.lib.mimrl_set_grad_scale(self.handle, float(scale)))
 
     def step(self):
         """One stage-1 (critics) + one stage-2 (model) update on the bound batch."""
@@ -208,6 +216,35 @@ class HipEngine:
         ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
         check(self.lib.mimrl_profile_read(self.handle, ms, cnt))
         return {p: (float(ms[i]), int(cnt[i])) for i, p in enumerate(_lib.PHASES)}
+
+    def profile_read_gemm(self):
+        """GEMM family of the eager steps since the last read -> dict(flops, bytes, ms, launches) (synchronises)."""
+        out = (C.c_double * 4)()
+        check(self.lib.mimrl_profile_read_gemm(self.handle, out))
+        return {"flops": out[0], "bytes": out[1], "ms": out[2], "launches": int(out[3])}
+
+    # ------------------------------------------------------------------ overlapped batch upload
+    def stage_batch(self, text, audio, video, labels):
+        """Start the host->device copy of the NEXT batch on a copy stream (it overlaps the step that is running on the
+        current batch).  Sources in pinned memory make the copy truly asynchronous."""
+        if not hasattr(self, "_stg"):
+            self._stg = [torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels)]
+            self._copy_stream = torch.cuda.Stream(self.device)
+            self._staged_ev, self._commit_ev = torch.cuda.Event(), torch.cuda.Event()
+            self._commit_ev.record(self.stream)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(self._commit_ev)          # the previous commit still reads the staging set
+            for dst, src in zip(self._stg, (text, audio, video, labels)):
+                dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+            self._staged_ev.record(self._copy_stream)
+
+    def commit_batch(self):
+        """Make the staged batch the bound one: four device-to-device copies on the engine's stream (the bound input
+        addresses are baked into the captured graphs, so the data moves, not the pointers)."""
+        self.stream.wait_event(self._staged_ev)
+        for dst, src in zip((self.text, self.audio, self.video, self.labels), self._stg):
+            dst.copy_(src, non_blocking=True)
+        self._commit_ev.record(self.stream)
 
     def read_scalars(self) -> np.ndarray:
         """One device->host read-back (the reference does >= 10 ``.item()`` syncs per iteration)."""

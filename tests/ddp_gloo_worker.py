@@ -26,6 +26,9 @@ class OracleEngine:
     def has_update(self, stage):
         return stage == 2 or self.bank_rows > 0
 
+    def set_grad_scale(self, scale):
+        self.gscale = float(scale)
+
     def bucket_grad(self, stage):
         return self.flat[stage]
 
@@ -42,7 +45,7 @@ class OracleEngine:
         grads, o = {}, 0
         for n in self.names[stage]:
             k = self.p[n].numel()
-            grads[n] = self.flat[stage][o:o + k].reshape(self.p[n].shape).clamp(-clip, clip)
+            grads[n] = (self.flat[stage][o:o + k] * getattr(self, "gscale", 1.0)).reshape(self.p[n].shape).clamp(-clip, clip)
             o += k
         lr = float(self.opt.learning_rate) * (float(self.opt.mi_lr_rate) if stage == 1 else 1.0)
         self.adam[stage].step(self.p, grads, lr, float(self.opt.weight_decay))
