@@ -81,6 +81,7 @@ typedef struct mimrl_buffers {
   float *pred;                                    /* [B] */
   float *feats;                                   /* [4][B,128] = F_F, T_F, A_F, V_F */
   float *scalars;                                 /* [MIMRL_NSCALARS] see MIMRL_S_* */
+  const int32_t* knn_override;                    /* optional [2][6][(B/k)*k]: neighbour rows for mimrl_set_knn_override_mask */
   int32_t* counters;                              /* [4] device ints owned by the caller like m / v: [0] dropout/anchor RNG step,
                                                      [1] Adam step of the main bucket, [2] Adam step of the critic bucket
                                                      (torch.optim.Adam's state['step'], Solver.py:144-146), [3] reserved.
@@ -187,6 +188,14 @@ int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, floa
 int mimrl_op_mi_bound_baseline(void* stream, float* scores, float* dscores, float* mi, const float* gscale, const float* lb,
                                float* dlb, int E, int B, int bound);
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
+/* HOST routine (no device work): the k nearest non-anchor rows of a 1-column bank Z (the labels) for every anchor, with
+ * scikit-learn's KDTree tie order (Model.py:82-86 with sklearn 1.7.2; see csrc/knn_r1.cpp).  idx_out [m*k]: ORIGINAL bank rows,
+ * nearest first, anchor-major.  Real labels are discrete, so ties decide the product sample of the ta_c / tv_c estimators. */
+int mimrl_knn_r1_host(const float* z, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
+/* Use caller-supplied neighbour rows instead of the device kNN for the calls whose bit is set in `call_mask` (bit e = e-th
+ * CMI estimator in the order ac_t ta_c vc_t tv_c tc_a tc_v) of `stage` (1 | 2): the rows are read from
+ * mimrl_buffers.knn_override [2][6][(B/k)*k] (device int32, stage-major) at every step. */
+int mimrl_set_knn_override_mask(mimrl_handle* h, int stage, unsigned call_mask);
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,
                       const float* g_cmi, int E, int n, int hardtanh);
 /* fused ReLU-MLP stack (critic towers VMI.py:13-22, CMI classifier Model.py:47-72), bf16 MFMA, fp32 in/out.

@@ -80,7 +80,7 @@ class Model:
         if banks is not None:
             e.set_banks(*banks)
         if not e.cfg.device_anchors:
-            e.set_anchors(stage, synth.draw_anchors(e.bank_rows, e.m_anchor, 6))   # consumes numpy's global RNG like Model.py:81
+            e.set_anchors(stage, synth.draw_anchors(e.bank_rows, e.m_anchor, 6), exact_ties=True)   # consumes numpy's global RNG like Model.py:81
         e.estimate(stage)
 
     def compute_vmi_loss_stage1(self, predictions, labels, F_F, T_F, A_F, V_F, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):

@@ -138,7 +138,7 @@ class Solver:
 
     def _anchors(self, e, stage):
         if e.bank_rows > 0 and not e.cfg.device_anchors:
-            e.set_anchors(stage, synth.draw_anchors(e.bank_rows, e.m_anchor, 6))
+            e.set_anchors(stage, synth.draw_anchors(e.bank_rows, e.m_anchor, 6), exact_ties=True, bank_c=self.engine.bank_c_host)
 
     def _set_banks(self, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
         self.engine.set_banks(C_F_all, F_F_all, T_F_all, A_F_all, V_F_all)

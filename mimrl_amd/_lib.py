@@ -51,7 +51,7 @@ class Buffers(C.Structure):
     _fields_ = [(n, _FP) for n in (
         "main_p", "main_g", "main_m", "main_v", "crit_p", "crit_g", "crit_m", "crit_v",
         "text", "audio", "video", "labels", "bank_c", "bank_f", "bank_t", "bank_a", "bank_v",
-        "anchors", "lr_main", "lr_critic", "pred", "feats", "scalars", "counters")]
+        "anchors", "lr_main", "lr_critic", "pred", "feats", "scalars", "knn_override", "counters")]
 
 
 _lib = None
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
     for fn in ("mimrl_set_bank_rows", "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_estimate", "mimrl_profile_enable", "mimrl_set_stage2_prefetch"):
         getattr(lib, fn).argtypes = [_FP, C.c_int]
     lib.mimrl_set_grad_scale.argtypes = [_FP, C.c_float]
+    lib.mimrl_knn_r1_host.argtypes = [_FP, C.c_int, _FP, C.c_int, C.c_int, _FP]
+    lib.mimrl_set_knn_override_mask.argtypes = [_FP, C.c_int, C.c_uint]
     for fn in ("mimrl_stage1_step", "mimrl_stage2_step", "mimrl_two_stage_step", "mimrl_destroy", "mimrl_workspace_bytes", "mimrl_params_changed",
                "mimrl_stage2_forward_tail"):
         getattr(lib, fn).argtypes = [_FP]
@@ -113,7 +115,7 @@ EXPORTS = [
     "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read", "mimrl_profile_read_gemm",
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_stage2_forward_tail", "mimrl_set_grad_scale", "mimrl_destroy", "mimrl_op_gemm", "mimrl_op_gemm_ex",
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_knn",
-    "mimrl_op_cmi_loss", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
+    "mimrl_op_cmi_loss", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
 ]
 
 
@@ -203,3 +205,17 @@ def layout_entries(cfg: Cfg) -> Tuple[List[Tuple[str, int, int, Tuple[int, ...]]
         out.append((name.value.decode(), g.value, off.value, shape))
     sizes = (check(lib.mimrl_bucket_floats(C.byref(cfg), 0)), check(lib.mimrl_bucket_floats(C.byref(cfg), 1)))
     return out, sizes
+
+
+def knn_r1_host(z, anchors, k: int):
+    """k nearest non-anchor rows of the 1-column bank ``z`` for every anchor, scikit-learn KDTree tie order (csrc/knn_r1.cpp).
+    Pure host code: callable without a GPU.  -> int32 [m, k] (original bank rows) or None in scikit-learn's brute-force regime."""
+    import numpy as np
+    z = np.ascontiguousarray(np.asarray(z, dtype=np.float32).reshape(-1))
+    a = np.ascontiguousarray(np.asarray(anchors, dtype=np.int32).reshape(-1))
+    if int(k) >= (len(z) - len(a)) // 2:
+        return None
+    out = np.empty((len(a), int(k)), dtype=np.int32)
+    check(load().mimrl_knn_r1_host(z.ctypes.data_as(C.c_void_p), len(z), a.ctypes.data_as(C.c_void_p), len(a), int(k),
+                                   out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -137,6 +137,7 @@ struct mimrl_handle {
   // after mimrl_bind / mimrl_params_changed) and per-matrix transposed (rebuilt beside every estimator forward pass)
   __bf16 *crit_img = nullptr, *crit_imgT = nullptr;
   bool img_valid = false;
+  unsigned knn_ovr_mask[2] = {0u, 0u};  // per stage: CMI calls whose neighbour rows come from bufs.knn_override
   bool knn_pre = true;                 // prefetch mode: stage 2's kNN sampling also runs inside stage 1, beside the encoder prefix (MIMRL_NO_KNN_PREFETCH=1: off)
   bool mi_fused_bwd_done = false;      // mi_forward already produced the tower-output gradients (mi_sep_fused)
   bool imgT_ready = false;             // a transposed-image refresh has been issued for the estimator pass being enqueued
@@ -1564,11 +1565,18 @@ int mimrl_handle::knn_launch(int stage, hipStream_t st) {
     MX(sample_anchors(st, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage, rng_add));
   KnnArgs ka;
   ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = stage == 2 ? knn_idx2 : knn_idx;
+  const unsigned ovr = bufs.knn_override ? knn_ovr_mask[stage - 1] : 0u;
   for (int e = 0; e < NE_CMI; ++e) {
     const int z = kCmiWire[e][2];
-    ka.call[e].Z = bank[z]; ka.call[e].dz = z == FT_C ? 1 : EMB;
+    ka.call[e].Z = ((ovr >> e) & 1u) ? nullptr : bank[z];     // null: the kernel leaves this call's rows alone
+    ka.call[e].dz = z == FT_C ? 1 : EMB;
   }
-  return knn_sample(st, ka);
+  MX(knn_sample(st, ka));
+  for (int e = 0; e < NE_CMI; ++e)   // caller-supplied neighbour rows (mimrl_set_knn_override_mask): copied in at every step
+    if ((ovr >> e) & 1u)
+      HIPX(hipMemcpyAsync(ka.idx_x + (size_t)e * nprod(), bufs.knn_override + ((size_t)(stage - 1) * NE_CMI + e) * nprod(),
+                          sizeof(int32_t) * nprod(), hipMemcpyDeviceToDevice, st));
+  return MIMRL_OK;
 }
 
 int mimrl_handle::mi_forward(int stage, bool want_grad) {
@@ -2280,6 +2288,18 @@ int mimrl_profile_read_gemm(mimrl_handle* h, double out[4]) {
 int mimrl_params_changed(mimrl_handle* h) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   h->img_valid = false;
+  return MIMRL_OK;
+}
+
+int mimrl_set_knn_override_mask(mimrl_handle* h, int stage, unsigned call_mask) {
+  if (!h || (stage != 1 && stage != 2)) return set_error(MIMRL_ERR_ARG, "bad handle / stage");
+  if (call_mask && !h->bufs.knn_override) return set_error(MIMRL_ERR_STATE, "mimrl_buffers.knn_override is not bound");
+  if (h->knn_ovr_mask[stage - 1] == (call_mask & 63u)) return MIMRL_OK;
+  HIPX(hipStreamSynchronize(h->user_stream));
+  for (int s = 0; s <= 2; ++s)            // which calls the kNN kernel skips is baked into the captured launches
+    for (int k = 0; k < 2; ++k)
+      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  h->knn_ovr_mask[stage - 1] = call_mask & 63u;
   return MIMRL_OK;
 }
 

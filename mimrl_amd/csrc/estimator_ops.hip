@@ -396,9 +396,10 @@ __global__ __launch_bounds__(256) void knn_kernel(KnnArgs a) {
   int* ci = reinterpret_cast<int*>(cd + AT * 256 * K);
   for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
   __syncthreads();
+  const float* __restrict__ Z = a.call[c].Z;
+  if (!Z) return;                                // this call's neighbour rows are supplied by the caller (whole workgroup leaves)
   const int* anc = a.anchors + (long)c * a.m;
   for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
-  const float* __restrict__ Z = a.call[c].Z;
   const int dz = a.call[c].dz;
 #pragma unroll
   for (int t = 0; t < AT; ++t) {

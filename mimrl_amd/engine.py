@@ -54,6 +54,9 @@ class HipEngine:
         cap = max(int(bank_capacity), 1)
         self.bank = share.bank if share else {"C": z(cap, 1), "F": z(cap, 128), "T": z(cap, 128), "A": z(cap, 128), "V": z(cap, 128)}
         self.anchors = torch.zeros(2, 6, max(self.m_anchor, 1), dtype=torch.int32, device=self.device)
+        self.knn_override = torch.zeros(2, 6, max(self.m_anchor * self.cfg.k_neighbor, 1), dtype=torch.int32, device=self.device)
+        self._ovr_mask = [0, 0]
+        self.bank_c_host = share.bank_c_host if share else None     # host copy of the label bank (exact R^1 kNN tie order)
         self.lr_main = share.lr_main if share else torch.full((1,), float(opt.learning_rate), **f32)
         self.lr_critic = share.lr_critic if share else torch.full((1,), float(opt.learning_rate) * float(opt.mi_lr_rate), **f32)   # Solver.py:140-142
         # [rng step, Adam step (main), Adam step (critics), -]: optimizer / RNG state owned here like m and v
@@ -86,6 +89,7 @@ class HipEngine:
         b.lr_main, b.lr_critic = _ptr(self.lr_main), _ptr(self.lr_critic)
         b.pred, b.feats, b.scalars = _ptr(self.pred), _ptr(self.feats), _ptr(self.scalars)
         b.counters = _ptr(self.counters)
+        b.knn_override = _ptr(self.knn_override)
         self._buffers = b
         check(self.lib.mimrl_bind(self.handle, C.byref(b)))
 
@@ -137,6 +141,7 @@ class HipEngine:
                 src = torch.as_tensor(src)
                 self.bank[k][:n].copy_(src.reshape(n, -1), non_blocking=True)
         self.bank_rows = n
+        self.bank_c_host = None if not n else np.ascontiguousarray(torch.as_tensor(C_all).detach().cpu().numpy().reshape(-1), dtype=np.float32)
         check(self.lib.mimrl_set_bank_rows(self.handle, n))
 
     def set_bank_rows(self, n: int):
@@ -155,10 +160,27 @@ class HipEngine:
                        ("counters", self.counters), ("lr_main", self.lr_main), ("lr_critic", self.lr_critic)):
             dst.copy_(torch.as_tensor(st[k]).to(dst.dtype).reshape(dst.shape))
 
-    def set_anchors(self, stage: int, anchors):
-        """anchors: int array [6, B//k] -- the six ``np.random.choice`` draws of one stage (Model.py:81)."""
-        a = torch.as_tensor(np.asarray(anchors, dtype=np.int32)).reshape(6, self.m_anchor)
-        self.anchors[stage - 1].copy_(a, non_blocking=True)
+    def set_anchors(self, stage: int, anchors, exact_ties: bool = False, bank_c=None):
+        """anchors: int array [6, B//k] -- the six ``np.random.choice`` draws of one stage (Model.py:81).
+        ``exact_ties``: the two label-conditioned estimators (ta_c, tv_c: kNN in the 1-column label bank, Model.py:327,335)
+        get their neighbour rows from the host-side restatement of scikit-learn's KDTree (csrc/knn_r1.cpp) instead of the
+        device kernel, so that ties between equal labels -- real MOSI / MOSEI labels are discrete -- resolve exactly as in
+        the reference.  (The other four calls search 128-column banks of continuous features: no ties.)"""
+        an = np.asarray(anchors, dtype=np.int32).reshape(6, self.m_anchor)
+        self.anchors[stage - 1].copy_(torch.from_numpy(an), non_blocking=True)
+        mask = 0
+        if exact_ties:
+            zc = self.bank_c_host if bank_c is None else np.asarray(bank_c, np.float32).reshape(-1)
+            if zc is None:
+                raise MimrlError("exact_ties needs the label bank on the host (set_banks first)")
+            for e in (1, 3):                                     # ta_c, tv_c
+                idx = _lib.knn_r1_host(zc[:self.bank_rows], an[e], self.cfg.k_neighbor)
+                if idx is not None:
+                    self.knn_override[stage - 1, e].copy_(torch.from_numpy(idx.reshape(-1)), non_blocking=True)
+                    mask |= 1 << e
+        if mask != self._ovr_mask[stage - 1]:
+            check(self.lib.mimrl_set_knn_override_mask(self.handle, stage, mask))
+            self._ovr_mask[stage - 1] = mask
 
     def set_lr(self, lr_main: float, lr_critic: float):
         self.lr_main.fill_(float(lr_main))

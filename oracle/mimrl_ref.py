@@ -356,15 +356,29 @@ def vmi_estimate(p: Params, name: str, opt, x: Tensor, y: Tensor) -> Tuple[Tenso
 # --------------------------------------------------------------------------------------
 def knn_indices(Z: np.ndarray, anchors: np.ndarray, k: int) -> np.ndarray:
     """Exact Euclidean kNN of Z[anchors] among the non-anchor rows of Z (Model.py:81-86).
-    Returns indices into the ORIGINAL bank, [m,k], nearest first (ties -> lower index)."""
-    Z = np.asarray(Z, dtype=np.float64)
+    Returns indices into the ORIGINAL bank, [m,k], nearest first.
+
+    Ties.  For the 128-column feature banks (continuous values) there are none and a brute-force argsort is the restatement.
+    For a 1-column Z -- the label bank of the ta_c / tv_c estimators; real MOSI / MOSEI labels are discrete, so every anchor
+    has many rows at distance 0 -- the result IS scikit-learn's tie order: the reference calls
+    ``sklearn.neighbors.NearestNeighbors(n_neighbors=k, radius=radius, metric='euclidean')`` (Model.py:82), whose
+    algorithm='auto' builds a KDTree for <= 15 features.  That third-party dependency is not part of /root/reference
+    (pinned here: scikit-learn 1.7.2, the version of this image); the oracle calls it exactly as the reference does, the product
+    restates it in csrc/knn_r1.cpp, and tests/test_knn_ties.py pins the one against the other."""
+    Z = np.asarray(Z)
     N = Z.shape[0]
     keep = np.ones(N, dtype=bool)
     keep[anchors] = False
     cand = np.nonzero(keep)[0]
+    if Z.ndim == 2 and Z.shape[1] == 1 and k < len(cand) // 2:
+        from sklearn.neighbors import NearestNeighbors
+        neigh = NearestNeighbors(n_neighbors=k, radius=1.0, metric="euclidean")
+        neigh.fit(Z[cand])                                                     # Model.py:83-85 (rows that are not anchors)
+        return cand[neigh.kneighbors(Z[np.asarray(anchors)], return_distance=False)].astype(np.int64)
+    Zd = np.asarray(Z, dtype=np.float64)
     out = np.empty((len(anchors), k), dtype=np.int64)
     for i, a in enumerate(anchors):
-        d = ((Z[cand] - Z[a]) ** 2).sum(1)
+        d = ((Zd[cand] - Zd[a]) ** 2).sum(1)
         order = np.argsort(d, kind="stable")[:k]
         out[i] = cand[order]
     return out

@@ -37,6 +37,10 @@ CONFIGS = {
     "cfg5_small": dict(B=8, T=1000, N=163, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=1),
     # --features_compose_t/k sum (Model.py:473-485)
     "tiny_sum": dict(B=8, T=6, N=40, seed=12, critic="separate", cube="6-3-128=4-3-128", traj=1, compose="sum"),
+    # DISCRETE labels (steps of 0.2 like MOSI's annotator averages) in the batch and in the label bank: the R^1 kNN of the
+    # ta_c / tv_c estimators is then decided by scikit-learn's KDTree tie order (Model.py:82-86)
+    "tiny_disc": dict(B=8, T=6, N=120, seed=13, critic="separate", cube="6-3-128=4-3-128", traj=2, discrete=True),
+    "cfg1_disc": dict(B=32, T=50, N=1000, seed=14, critic="separate", cube="50-3-128=10-3-128", traj=1, discrete=True),
 }
 
 # Epoch-level fixtures: the reference's own Solver.train / Solver.evaluate (Solver.py:194-270) over several epochs.
@@ -81,3 +85,15 @@ def split_batches(data, B):
     """[(t, a, v, y)] in loader order, last batch partial (drop_last=False, Parameters.py:21)."""
     n = data[3].shape[0]
     return [tuple(x[i:i + B] for x in data) for i in range(0, n, B)]
+
+
+def quantize_labels(c, batch, banks):
+    """``discrete`` fixtures: labels and the label bank rounded to multiples of 0.2 (in place on copies)."""
+    import numpy as np
+    if not c.get("discrete"):
+        return batch, banks
+    q = lambda x: (np.round(np.asarray(x, np.float32) * 5) / 5).astype(np.float32)
+    t, a, v, y = batch
+    banks = dict(banks)
+    banks["C"] = q(banks["C"])
+    return (t, a, v, q(y)), banks

@@ -30,7 +30,7 @@ import Model as RM  # noqa: E402  (reference)
 import Customization as RC  # noqa: E402  (reference)
 
 from mimrl_amd import synth  # noqa: E402
-from tests.golden.configs import CONFIGS, EPOCH_CONFIGS, epoch_data, make_opt, split_batches  # noqa: E402
+from tests.golden.configs import CONFIGS, EPOCH_CONFIGS, epoch_data, make_opt, quantize_labels, split_batches  # noqa: E402
 
 
 class StubBert(torch.nn.Module):
@@ -106,6 +106,7 @@ def gen(name, c):
     out = {}
     batch = synth.synthetic_batch(B, T, seed=seed, ragged=c.get("ragged", False))
     banks = synth.synthetic_banks(N, seed=seed)
+    batch, banks = quantize_labels(c, batch, banks)
     banks_t = [torch.from_numpy(banks[k]) for k in "CFTAV"]
     model = build_reference_model(opt, seed)
     vmi, main = split_params(model)

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from mimrl_amd import layout, synth
-from tests.golden.configs import CONFIGS, make_opt
+from tests.golden.configs import CONFIGS, make_opt, quantize_labels
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -24,6 +24,7 @@ def case(name, dtype=torch.float32):
     opt = make_opt(c)
     t, a, v, y = synth.synthetic_batch(c["B"], c["T"], seed=c["seed"], ragged=c.get("ragged", False))
     banks = synth.synthetic_banks(c["N"], seed=c["seed"])
+    (t, a, v, y), banks = quantize_labels(c, (t, a, v, y), banks)
     batch = tuple(torch.from_numpy(x).to(dtype) for x in (t, a, v, y))
     banks_t = {k: torch.from_numpy(val).to(dtype) for k, val in banks.items()}
     return c, opt, batch, banks_t

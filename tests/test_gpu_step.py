@@ -12,10 +12,10 @@ from tests.helpers import case, load_golden, oracle_params
 pytestmark = pytest.mark.gpu
 
 TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp", "tiny_lstm", "tiny_tuba_un", "tiny_interp_ga",
-        "tiny_sum"]
+        "tiny_sum", "tiny_disc"]
 # cfg2_sep = BASELINE configs[1] at FULL size (the bench configuration); cfg3_small / cfg5_small = configs[2] / [4] with only the
 # batch reduced (T = time_len = 500 / 1000, concat critic for cfg3)
-ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg2_sep", "cfg3_small", "cfg5_small"]
+ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg1_disc", "cfg2_sep", "cfg3_small", "cfg5_small"]
 
 
 def make_engine(name, precision="fp32", use_graph=False):
@@ -66,7 +66,7 @@ def test_stage_losses_and_all_gradients_vs_oracle(name):
     main = [n for n in p if not R.is_critic_param(n)]
     adam_v = R.AdamState(p, crit)
     for stage, names in ((1, crit), (2, main)):
-        eng.set_anchors(stage, anchors[stage - 1])
+        eng.set_anchors(stage, anchors[stage - 1], exact_ties=bool(c.get("discrete")))
         eng.stage_grads(stage)
         torch.cuda.synchronize()
         s = eng.read_scalars()
@@ -112,7 +112,7 @@ def test_stage_losses_and_all_gradients_vs_oracle(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_lstm", "tiny_sum", "cfg1_sep",
+@pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_lstm", "tiny_sum", "tiny_disc", "cfg1_sep", "cfg1_disc",
                                   "cfg2_sep", "cfg3_small", "cfg5_small"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_two_stage_trajectory(name, use_graph):
@@ -126,8 +126,8 @@ def test_two_stage_trajectory(name, use_graph):
     adam_v, adam_m = R.AdamState(p, crit), R.AdamState(p, main)
     steps = min(anchors.shape[0], 3)
     for it in range(steps):
-        eng.set_anchors(1, anchors[it, 0])
-        eng.set_anchors(2, anchors[it, 1])
+        eng.set_anchors(1, anchors[it, 0], exact_ties=bool(c.get("discrete")))
+        eng.set_anchors(2, anchors[it, 1], exact_ties=bool(c.get("discrete")))
         eng.stage1_step()
         eng.stage2_step()
         s = eng.read_scalars()
@@ -176,10 +176,10 @@ def test_bf16_mode_tracks_fp32():
     assert_close(b[_lib.S1_MIS:_lib.S1_MIS + 11], a[_lib.S1_MIS:_lib.S1_MIS + 11], 2e-2, 2e-2, "bf16 MI/CMI")
     assert_close(b[_lib.S2_LOSS], a[_lib.S2_LOSS], 2e-2, 1e-3, "bf16 stage-2 loss")
     assert_close(b[_lib.S2_MIS:_lib.S2_MIS + 8], a[_lib.S2_MIS:_lib.S2_MIS + 8], 2e-2, 4e-2, "bf16 MI terms")
-    for i, nm in ((1, "critic"), (2, "main")):
+    for i, nm, lim in ((1, "critic", 0.998), (2, "main", 0.95)):      # measured 0.9994 / 0.964
         va, vb = res["fp32"][i], res["bf16"][i]
         cos = float(va @ vb / (np.linalg.norm(va) * np.linalg.norm(vb)))
-        assert cos > 0.9, f"bf16 {nm} gradient direction: cosine {cos}"
+        assert cos > lim, f"bf16 {nm} gradient direction: cosine {cos}"
 
 
 @pytest.mark.parametrize("name", ["tiny_sep", "cfg1_sep"])
@@ -337,8 +337,8 @@ def test_bf16_fused_paths_on_every_fixture(name):
         c, opt, batch, banks, p, eng = make_engine(name, precision=precision, use_graph=precision == "bf16")
         g = load_golden(name)
         eng.set_banks(*(banks[k] for k in "CFTAV"))
-        eng.set_anchors(1, g["anchors"][0, 0])
-        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.set_anchors(1, g["anchors"][0, 0], exact_ties=bool(c.get("discrete")))
+        eng.set_anchors(2, g["anchors"][0, 1], exact_ties=bool(c.get("discrete")))
         eng.set_stage2_prefetch(precision == "bf16")
         eng.step()
         res[precision] = eng.read_scalars().copy()
@@ -493,3 +493,29 @@ def test_cfg5_full_size_vs_oracle():
         eng.step()
     assert np.isfinite(eng.read_scalars()).all() and torch.isfinite(eng.main["p"]).all() and torch.isfinite(eng.crit["p"]).all()
     eng.close()
+
+
+def test_bench_mode_trains_like_fp32():
+    """Does the benchmarked mode (bf16 MFMA operands, every fused kernel, hipGraph, Solver.step overlap) TRAIN like fp32?
+    100 two-stage iterations over 4 cycling cfg1-shaped batches (lr 4e-3, dropout off, shared host anchors) from one
+    initialisation in three runs: fp32 eager sequential, fp32 graph+overlap (same arithmetic, different summation order: the
+    chaos floor of this adversarial objective -- Adam's ~lr*sign(g) steps amplify last-ulp differences), and the bench mode.
+    The bench mode must (a) train: task MAE falls below half its initial window, and (b) stay as close to fp32 as fp32 stays
+    to itself: window-mean gaps (task MAE, stage-1 loss, 8 MI/CMI series) within 3x the floor + a small band.
+    Measured (tools/bf16_convergence.py): final-window task MAE 0.30 / 0.26 / 0.36; see DESIGN.md section 2."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bf16_convergence", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                   "tools", "bf16_convergence.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a, b, c = mod.run("fp32", False, False), mod.run("fp32", True, True), mod.run("bf16", True, True)
+    assert np.isfinite(c).all()
+    win = lambda r: r.reshape(5, 20, -1).mean(1)
+    wa, wb, wc = win(a), win(b), win(c)
+    for tag, w in (("fp32 eager", wa), ("fp32 graph+overlap", wb), ("bench mode", wc)):
+        assert w[-1, 0] < 0.5 * w[0, 0], f"{tag}: task MAE {w[0, 0]:.3f} -> {w[-1, 0]:.3f} did not halve in 100 steps"
+    floor = np.abs(wa - wb).max(0)
+    gap = np.minimum(np.abs(wc - wa), np.abs(wc - wb)).max(0)
+    band = np.array([0.1, 0.3, 0.15, 0.1, 0.1, 0.3, 1.0, 1.0, 1.0, 1.0])      # task, s1 loss, f_t f_a f_v inv | spec_t spec_a spec_v comp
+    assert np.all(gap <= 3 * floor + band), f"bench-vs-fp32 gaps {np.round(gap, 3).tolist()} vs fp32-vs-fp32 floor {np.round(floor, 3).tolist()}"
