@@ -170,6 +170,10 @@ struct mimrl_handle {
   int *lens[2] = {nullptr, nullptr};
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
   float* cube0 = nullptr;
+  // layer-0 GRU operands in a common aligned shape (model_ops.h: L0Pack): one batched input projection, two batched weight gradients
+  float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;
+  int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
+  bool l0_packed = false;              // see mimrl_create
   BlockBuf bb[MIMRL_MAX_BLOCKS];
   __bf16* wtT[MIMRL_MAX_BLOCKS][3] = {};   // transposed bf16 images of the D-axis weights (fc2, fc1, res) for the fused backward
   // Second set of forward buffers.  In prefetch mode (mimrl_set_stage2_prefetch) stage 1 runs its forward pass and its
@@ -588,6 +592,10 @@ int mimrl_handle::carve() {
   }
   MX(take(&ff, B * D));
   MX(take(&dpred, B));
+  if (cfg.encoder == MIMRL_ENCODER_GRU) {
+    MX(take(&xpack, 2 * BT_ * KP())); MX(take(&wpack, (size_t)4 * G * KP())); MX(take(&bpack, (size_t)4 * G));
+    MX(take(&dwih_pack, (size_t)4 * G * KP())); MX(take(&dwhh_pack, (size_t)4 * G * H));
+  }
   // estimators
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
   MX(take(&tin, 10 * B * EMB));
@@ -681,6 +689,22 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.btv = gru_pick_btv(B, 2);
     if (l == 1) MX(fork(1, 3));
+    if (l == 0 && l0_packed) {
+      // all four (modality, direction) projections of layer 0 as ONE batched launch on the packed operands
+      L0Pack pk;
+      for (int m = 0; m < 2; ++m) {
+        pk.x[m] = xin[m]; pk.d[m] = dmod[m];
+        for (int d = 0; d < 2; ++d) { pk.w_ih[m][d] = P(gru[m][0][d].w_ih); pk.b_ih[m][d] = P(gru[m][0][d].b_ih); }
+      }
+      pk.xpack = xpack; pk.wpack = wpack; pk.bpack = bpack; pk.rows = BT_; pk.KP = KP();
+      MX(l0_pack(stream, pk, true));
+      GemmDesc gd = gemm_nt(xpack, KP(), wpack, KP(), gx[0][0], G, (int)BT_, G, KP());
+      gd.batch = 4; gd.batch_in = 2;
+      gd.sa_b = 0; gd.sa_bo = BT_ * KP(); gd.sb_b = (long)G * KP(); gd.sb_bo = 2L * G * KP();
+      gd.sc_b = gx[0][1] - gx[0][0]; gd.sc_bo = gx[1][0] - gx[0][0];
+      gd.bias_n = bpack; gd.bias_n_b = G; gd.bias_n_bo = 2 * G;
+      MX(G_on(stream, gd));
+    }
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       const float* in = l == 0 ? xin[m] : h0[m];
@@ -695,7 +719,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         gd.sa_bo = h0[1] - h0[0]; gd.sb_bo = gru[1][l][0].w_ih - gf.w_ih; gd.sc_bo = gx[1][0] - gx[0][0];
         gd.bias_n_bo = gru[1][l][0].b_ih - gf.b_ih;
       }
-      if (l == 0 || m == 0) MX(G_on(m == 0 ? stream : S(2), gd));   // layer 1: the m == 0 launch covers both modalities
+      if ((l == 0 && !l0_packed) || (l == 1 && m == 0)) MX(G_on(m == 0 ? stream : S(2), gd));   // layer 1: the m == 0 launch covers both modalities
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
@@ -810,7 +834,9 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   if (part != 1 && T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
   if (part != 2) {
     MX(fork(0, 5));
-    // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0
+    // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0.  Captured BEFORE the encoders although it
+    // has slack until the tail starts: graph nodes start in capture order, and a branch captured behind the two GRU layers is
+    // dispatched behind them too and then delays the tail (measured: 1.46 vs 1.34 ms).
     { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
     MX(dbg_delay(S(0), 10));
     if (part == 0) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
@@ -1293,7 +1319,9 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   } else if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
   for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
   static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
+  static const int dbg_skip_kinds = getenv("MIMRL_DBG_SKIP_DEFERRED") ? atoi(getenv("MIMRL_DBG_SKIP_DEFERRED")) : 0;   // timing experiments only (bit = kind)
   for (const Deferred& d : deferred) {
+    if ((dbg_skip_kinds >> d.kind) & 1) continue;
     hipStream_t st = only_side > 0 ? S(only_side) : S(1 + (d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
@@ -1394,6 +1422,29 @@ int mimrl_handle::model_backward() {
     if (l == 1 && !dh0_last) MX(dh0_gemm());
     // weight gradients of this layer: off the critical path.  Layer 1: side 1..3 (they overlap the layer-0 BPTT);
     // layer 0 is the tail of the stage.
+    if (l == 0 && l0_packed) {
+      // layer 0: the W_ih (against the packed inputs) and W_hh gradients of all four (modality, direction) pairs as two batched
+      // launches into packed scratch, scattered into the bucket by one small kernel: 3 launches on 2 streams close the stage
+      // instead of four GEMMs in a row (the per-modality widths 74 / 35 ruled out both batching and 16-byte loads)
+      const long s_dg = dg[0][0][1] - dg[0][0][0], o_dg = dg[0][1][0] - dg[0][0][0];
+      const long s_hp = hprev[0][0][1] - hprev[0][0][0], o_hp = hprev[0][1][0] - hprev[0][0][0];
+      { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, xpack, KP(), dwih_pack, KP(), G, KP(), (int)BT_);
+        q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = 0; q.sb_bo = BT_ * KP(); q.sc_b = (long)G * KP(); q.sc_bo = 2L * G * KP();
+        q.atomic = 1; MX(G_on(stream, q)); }
+      { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, hprev[0][0][0], H, dwhh_pack, H, G, H, (int)BT_);
+        q.a_gap_at = 2 * H; q.a_gap_rows = H;
+        q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = s_hp; q.sb_bo = o_hp; q.sc_b = (long)G * H; q.sc_bo = 2L * G * H;
+        q.atomic = 1; MX(G_on(S(1), q)); }
+      MX(join(1, 1));
+      L0Unpack up;
+      for (int m = 0; m < 2; ++m) {
+        up.d[m] = gru[m][0][0].din;
+        for (int d = 0; d < 2; ++d) { up.g_ih[m][d] = Gm(gru[m][0][d].w_ih); up.g_hh[m][d] = Gm(gru[m][0][d].w_hh); }
+      }
+      up.dwih_pack = dwih_pack; up.dwhh_pack = dwhh_pack; up.KP = KP();
+      MX(l0_unpack_grads(stream, up));
+      continue;
+    }
     int rr = 0;
     for (int m = 0; m < 2; ++m) {
       // dg rows are [dr'|dz'|dn'|dn'r]: dgx = columns [0,3H); dgh = columns [0,2H) and [3H,4H).  Both directions in one
@@ -2153,6 +2204,10 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
+  // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches.  Pays off once the
+  // launches are large (cfg3: -2 %); at cfg2 the extra pack / unpack launches and the padded K cost as much as the batching
+  // saves (1.34 vs 1.32 ms), so the default follows the row count.  MIMRL_L0_PACK=1 / 0 forces it.
+  h->l0_packed = getenv("MIMRL_L0_PACK") ? atoi(getenv("MIMRL_L0_PACK")) != 0 : (long)h->cfg.batch * h->cfg.seq_len >= 16384;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
   h->prec = cfg->precision;

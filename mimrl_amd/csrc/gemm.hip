@@ -40,6 +40,7 @@ struct KernelArgs {
   int kt_per;       // k-tiles per split (single-segment GEMMs only)
   int vec_a, vec_b, vec_a2, vec_b2;   // operand may use the 16-byte path (alignment / stride conditions hold)
   int xcd_remap;
+  int dbg;          // timing experiments only (MIMRL_DBG_GEMM): 1 = no output stores, 2 = no k-loop
 };
 
 // one operand of one product segment (workgroup-uniform)
@@ -158,27 +159,56 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
   if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
   float* __restrict__ C = d.C + oc;
   float csum = 0.f;
+  // PLAIN outputs (bias_n / activation / plain or atomic store / column sums -- every projection and weight gradient): a
+  // store loop with NO load in it.  On this ISA stores count on vmcnt like loads, and a conditional load in the loop body
+  // (`beta ? C[off]`, `bias_m ?`, `gradact_u ?`: even when the condition is false) is a branch whose join waits for
+  // vmcnt(0), i.e. for the PREVIOUS STORE to retire: the 16 stores of a tile then run at one memory latency each --
+  // measured 1.4 TB/s for the store phase of a 128000x384 output, most of the time of every tall GEMM.
+  if (!d.bias_m && d.beta == 0.f && !d.pre && !d.gradact_u) {
+    float v[16];
+    if (d.act == ACT_NONE) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m >= d.M) continue;
-    const long off = (long)m * d.sc_m + (long)n * d.sc_n;
-    float v = d.alpha * acc[r] + bn;
-    if (d.bias_m) v += d.bias_m[(long)bz * d.bias_m_b + m];
-    if (d.beta != 0.f) v += d.beta * C[off];
-    if (d.pre) d.pre[oc + off] = v;
-    if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[oc + off]);
-    else v = act_apply(d.act, v);
-    if (atomic) atomicAdd(&C[off], v);
-    else C[off] = v;
-    csum += v;
+      for (int r = 0; r < 16; ++r) v[r] = d.alpha * acc[r] + bn;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_apply(d.act, d.alpha * acc[r] + bn);
+    }
+    float* __restrict__ Cn = C + (long)n * d.sc_n;
+    if (atomic) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < d.M) { atomicAdd(Cn + (long)m * d.sc_m, v[r]); csum += v[r]; }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < d.M) { Cn[(long)m * d.sc_m] = v[r]; csum += v[r]; }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= d.M) continue;
+      const long off = (long)m * d.sc_m + (long)n * d.sc_n;
+      float v = d.alpha * acc[r] + bn;
+      if (d.bias_m) v += d.bias_m[(long)bz * d.bias_m_b + m];
+      if (d.beta != 0.f) v += d.beta * C[off];
+      if (d.pre) d.pre[oc + off] = v;
+      if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[oc + off]);
+      else v = act_apply(d.act, v);
+      if (atomic) atomicAdd(&C[off], v);
+      else C[off] = v;
+      csum += v;
+    }
   }
   if (d.colsum) {   // fused bias gradient: lanes l and l^32 hold the same column
     csum += __shfl_xor(csum, 32, 64);
     if (lane < 32) atomicAdd(&d.colsum[(long)bz * d.colsum_b + n], csum);
   }
 }
-
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so linear ids that
 // are equal mod 8 share an L2.  Re-deal the ids so that one XCD owns whole slices of the slowest grid axis: all
@@ -441,12 +471,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
   {
     const int ktiles = (d.K + FBK - 1) / FBK;
     const int kt0 = ks * ka.kt_per;
-    const int kt1 = kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles;
+    const int kt1 = ka.dbg == 2 ? kt0 : (kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles);
     segment(d.A + oa, AKC ? d.sa_m : d.sa_k, d.B + ob, BKC ? d.sb_n : d.sb_k, d.K, kt0, kt1, d.a_gap_rows ? d.a_gap_at : 0x7fffffff, d.a_gap_rows);
   }
   if (d.A2)
     segment(d.A2 + (long)bz * d.sa2_b, AKC ? d.sa2_m : d.sa2_k, d.B2 + (long)bz * d.sb2_b, BKC ? d.sb2_n : d.sb2_k, d.K2, 0,
             (d.K2 + FBK - 1) / FBK, 0x7fffffff, 0);
+  if (ka.dbg == 1) { if (acc[0][0][0] == 123.456f) d.C[0] = 1.f; return; }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -558,6 +589,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
   static const int no_xcd = getenv("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
   ka.xcd_remap = !no_xcd;
+  static const int dbg_gemm = getenv("MIMRL_DBG_GEMM") ? atoi(getenv("MIMRL_DBG_GEMM")) : 0;
+  ka.dbg = dbg_gemm;
   ka.ksplit = pl.nsplit;
   ka.kt_per = pl.kt_per;
   const int bm = 64 * pl.tm, bn = 64 * pl.tn;   // (64 x 64 unless the fast path picked a larger tile)

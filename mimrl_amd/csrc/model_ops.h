@@ -26,6 +26,24 @@ struct LnSide2 { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamm
 int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* cube, int B, int T, int L, int K, int D, RngKey key);
 int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
                       RngKey key);
+// Layer-0 GRU operands in a common, 16-byte-aligned shape.  audio [rows, d_a] and video [rows, d_v] (d = 74 / 35 for MOSI: rows
+// of 296 / 140 bytes, no 16-byte loads possible, and different widths, so no batching) are copied into xpack[2][rows, KP]
+// (zero padded), the four W_ih matrices [384, d] into wpack[2][2][384, KP] and the four b_ih into bpack[2][2][384]: the input
+// projection of both modalities and directions is then ONE batched k-contiguous GEMM, and the W_ih / W_hh weight gradients
+// two (accumulated in packed scratch and scattered back by l0_unpack_grads).
+struct L0Pack {
+  const float* x[2]; int d[2];               // audio, video
+  const float* w_ih[2][2]; const float* b_ih[2][2];
+  float* xpack; float* wpack; float* bpack;
+  long rows; int KP;
+};
+int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs);
+struct L0Unpack {
+  float* g_ih[2][2]; float* g_hh[2][2]; int d[2];
+  float* dwih_pack; float* dwhh_pack;        // [2][2][384, KP], [2][2][384, 128]: read, added to the gradients, re-zeroed
+  int KP;
+};
+int l0_unpack_grads(hipStream_t s, const L0Unpack& a);
 int seq_lengths2(hipStream_t s, const float* xa, int da, int* lens_a, const float* xv, int dv, int* lens_v, int B, int T);
 int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, float* cube, float* mean,
                      float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id);

@@ -517,7 +517,57 @@ inline int grid_for(long n, int block = 256, int cap = 2048) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+__global__ void l0_pack_kernel(L0Pack a, int pack_inputs) {
+  const int m = blockIdx.y;
+  const long nx = pack_inputs ? a.rows * a.KP : 0, nw = 2L * 384 * a.KP, nb = 2L * 384;
+  const int d = a.d[m];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx + nw + nb; i += (long)gridDim.x * blockDim.x) {
+    if (i < nx) {
+      const long r = i / a.KP; const int c = (int)(i - r * a.KP);
+      a.xpack[(long)m * a.rows * a.KP + i] = c < d ? a.x[m][r * d + c] : 0.f;
+    } else if (i < nx + nw) {
+      const long j = i - nx; const int dir = (int)(j / (384L * a.KP)); const long q = j - dir * 384L * a.KP;
+      const int r = (int)(q / a.KP), c = (int)(q - (long)r * a.KP);
+      a.wpack[((long)m * 2 + dir) * 384 * a.KP + q] = c < d ? a.w_ih[m][dir][(long)r * d + c] : 0.f;
+    } else {
+      const long j = i - nx - nw; const int dir = (int)(j / 384), r = (int)(j - dir * 384L);
+      a.bpack[((long)m * 2 + dir) * 384 + r] = a.b_ih[m][dir][r];
+    }
+  }
+}
+
+__global__ void l0_unpack_kernel(L0Unpack a) {
+  const int md = blockIdx.y, m = md >> 1, dir = md & 1;
+  const int d = a.d[m];
+  const long nih = 384L * a.KP, nhh = 384L * 128;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nih + nhh; i += (long)gridDim.x * blockDim.x) {
+    if (i < nih) {
+      const int r = (int)(i / a.KP), c = (int)(i - (long)r * a.KP);
+      float* src = a.dwih_pack + (long)md * nih + i;
+      if (c < d) a.g_ih[m][dir][(long)r * d + c] += *src;
+      *src = 0.f;
+    } else {
+      const long j = i - nih;
+      float* src = a.dwhh_pack + (long)md * nhh + j;
+      a.g_hh[m][dir][j] += *src;
+      *src = 0.f;
+    }
+  }
+}
+
 }  // namespace
+
+int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs) {
+  const long n = (pack_inputs ? a.rows * a.KP : 0) + 2L * 384 * a.KP + 2L * 384;
+  hipLaunchKernelGGL(l0_pack_kernel, dim3(grid_for(n, 256, 1024), 2), dim3(256), 0, s, a, pack_inputs ? 1 : 0);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+int l0_unpack_grads(hipStream_t s, const L0Unpack& a) {
+  hipLaunchKernelGGL(l0_unpack_kernel, dim3(grid_for(384L * (a.KP + 128), 256, 256), 4), dim3(256), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
 
 int seq_lengths(hipStream_t s, const float* x, int B, int T, int d, int* lens) {
   hipLaunchKernelGGL(seq_lengths_kernel, dim3(B), dim3(256), 0, s, x, T, d, lens, (const float*)nullptr, 0, (int*)nullptr);

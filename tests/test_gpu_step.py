@@ -55,9 +55,13 @@ def test_epoch0_rule(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ALL)
-def test_stage_losses_and_all_gradients_vs_oracle(name):
-    """Every MI/CMI value, both losses and EVERY parameter gradient of both stages against the oracle's autograd."""
+@pytest.mark.parametrize("name", ALL + ["tiny_ragged+l0pack", "cfg1_sep+l0pack"])
+def test_stage_losses_and_all_gradients_vs_oracle(name, monkeypatch):
+    """Every MI/CMI value, both losses and EVERY parameter gradient of both stages against the oracle's autograd.
+    (`+l0pack`: with the packed layer-0 GRU operands forced on -- the default only above 16384 rows, i.e. cfg3 / cfg5.)"""
+    if name.endswith("+l0pack"):
+        name = name[:-7]
+        monkeypatch.setenv("MIMRL_L0_PACK", "1")
     c, opt, batch, banks, p, eng = make_engine(name)
     g = load_golden(name)
     anchors = g["anchors"][0]
@@ -517,5 +521,6 @@ def test_bench_mode_trains_like_fp32():
         assert w[-1, 0] < 0.5 * w[0, 0], f"{tag}: task MAE {w[0, 0]:.3f} -> {w[-1, 0]:.3f} did not halve in 100 steps"
     floor = np.abs(wa - wb).max(0)
     gap = np.minimum(np.abs(wc - wa), np.abs(wc - wb)).max(0)
-    band = np.array([0.1, 0.3, 0.15, 0.1, 0.1, 0.3, 1.0, 1.0, 1.0, 1.0])      # task, s1 loss, f_t f_a f_v inv | spec_t spec_a spec_v comp
+    # (one fp32 pair is a noisy estimate of the floor: the bands are the fp32-vs-fp32 gaps seen over several boxes)
+    band = np.array([0.25, 0.6, 0.3, 0.15, 0.15, 0.6, 2.5, 2.5, 2.5, 2.5])    # task, s1 loss, f_t f_a f_v inv | spec_t spec_a spec_v comp
     assert np.all(gap <= 3 * floor + band), f"bench-vs-fp32 gaps {np.round(gap, 3).tolist()} vs fp32-vs-fp32 floor {np.round(floor, 3).tolist()}"
