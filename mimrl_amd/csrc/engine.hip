@@ -1541,7 +1541,12 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
   static const bool fused_bwd = getenv("MIMRL_NO_FUSED_MLP_BWD") == nullptr;
   // (stacks with thousands of row tiles -- the concat critic -- keep the GEMM chain here: measured faster than the fused one)
   const bool use_fused = bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims);
-  if (wgrad && !use_fused)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
+  // single-output top layer (the concat critic's score head) over many rows: one streaming kernel instead of three GEMMs with
+  // one real column in 64 (dz, dW, both bias gradients)
+  static const bool no_top1 = getenv("MIMRL_NO_TOP1") != nullptr;   // tuning knob
+  const bool top1 = !use_fused && !no_top1 && dims[nl] == 1 && nl >= 2 && dims[nl - 1] % 4 == 0 && dims[nl - 1] <= 1024 && 1024 % dims[nl - 1] == 0 &&
+                    dtmp[0] != nullptr;
+  if (wgrad && !use_fused && !top1)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
     MX(colsum(stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
   if (use_fused) {
     // the whole data-gradient chain in one launch (dtmp must hold nl-1 buffers here); weight gradients follow as GEMMs
@@ -1579,6 +1584,12 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
   for (int l = nl - 1; l >= 0; --l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
     const float* a_in = l == 0 ? in : act[l - 1];
+    if (top1 && l == nl - 1) {
+      MX(top1_bwd(stream, dz, CP(p0 + l_off[l][0]), act[l - 1], dtmp[pp], wgrad ? CG(p0 + l_off[l][0]) : nullptr,
+                  wgrad ? CG(p0 + l_off[l][1]) : nullptr, wgrad ? CG(p0 + l_off[l - 1][1]) : nullptr, nb, rows, brows, din_, pstride));
+      dz = dtmp[pp]; pp ^= 1;
+      continue;
+    }
     if (wgrad) {   // dW_l = dZ^T A_l     (one writer per tensor: plain stores into the zeroed bucket)
       GemmDesc g;
       g.A = dz; g.sa_m = 1; g.sa_k = dout_; g.sa_b = (long)brows * dout_;

@@ -26,6 +26,13 @@ int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, in
 int pair_expand_bwd(hipStream_t s, const float* a1, float* da1, float* dP, float* dQ, int E, int B, int Hd);
 // relu backward in place: g *= (a > 0)
 int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n);
+// Backward of an MLP top layer with ONE output (the concat critic's score head, VMI.py:33: Linear(256, 1)), as a streaming
+// pass instead of three 64-column GEMM tiles of which one column is real:
+//   dz[g][r,c] = dout[g][r] * W[g][c] * (act[g][r,c] > 0)          gradient into the ReLU layer below
+//   dW[g][c]  += sum_r dout[g][r] * act[g][r,c] ;  db_top[g] += sum_r dout[g][r] ;  db_below[g][c] += sum_r dz[g][r,c]
+// act / dz are [nb][brows, din] (rows valid: `rows`), W / dW / db_* live in a parameter bucket with group stride pstride.
+int top1_bwd(hipStream_t s, const float* dout, const float* W, const float* act, float* dz, float* dW, float* db_top, float* db_below,
+             int nb, int rows, int brows, int din, long pstride);
 
 // exact kNN product sampler (Model.py:75-106): for call c and anchor a: the k nearest non-anchor rows of Z.
 struct KnnCall { const float* Z; int dz; };

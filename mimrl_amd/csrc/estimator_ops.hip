@@ -582,6 +582,51 @@ __global__ void gather_sum4_kernel(GatherSum4 a, int B, int D) {
   }
 }
 
+// one workgroup = 256 rows of one group; a thread owns 4 consecutive columns (float4) of every 4th..(256/ (din/4))-th row
+__global__ __launch_bounds__(256) void top1_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ W, const float* __restrict__ act,
+                                                       float* __restrict__ dz, float* __restrict__ dW, float* __restrict__ db_top,
+                                                       float* __restrict__ db_below, int rows, int brows, int din, long pstride) {
+  __shared__ float red[3][256 * 4];
+  const int g = blockIdx.y, r0 = blockIdx.x * 256;
+  const int tpr = din >> 2;                    // threads per row
+  const int rpp = 256 / tpr;                   // rows per pass
+  const int c4 = (threadIdx.x % tpr) * 4, rr = threadIdx.x / tpr;
+  const float4 w = *reinterpret_cast<const float4*>(W + (long)g * pstride + c4);
+  float4 sw = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
+  float st = 0.f;
+  const int rend = min(r0 + 256, rows);
+  for (int r = r0 + rr; r < rend; r += rpp) {
+    const long o = ((long)g * brows + r) * din + c4;
+    const float d = dout[(long)g * brows + r];
+    const float4 a = *reinterpret_cast<const float4*>(act + o);
+    float4 z;
+    z.x = a.x > 0.f ? d * w.x : 0.f; z.y = a.y > 0.f ? d * w.y : 0.f; z.z = a.z > 0.f ? d * w.z : 0.f; z.w = a.w > 0.f ? d * w.w : 0.f;
+    *reinterpret_cast<float4*>(dz + o) = z;
+    sw.x += d * a.x; sw.y += d * a.y; sw.z += d * a.z; sw.w += d * a.w;
+    sb.x += z.x; sb.y += z.y; sb.z += z.z; sb.w += z.w;
+    if (c4 == 0) st += d;
+  }
+  if (!dW && !db_below && !db_top) return;
+  float* mine = &red[0][threadIdx.x * 4];
+  mine[0] = sw.x; mine[1] = sw.y; mine[2] = sw.z; mine[3] = sw.w;
+  mine = &red[1][threadIdx.x * 4];
+  mine[0] = sb.x; mine[1] = sb.y; mine[2] = sb.z; mine[3] = sb.w;
+  red[2][threadIdx.x] = st;
+  __syncthreads();
+  if (threadIdx.x < din) {                      // column c: sum over the rpp row slots
+    const int c = threadIdx.x, slot = c >> 2, sub = c & 3;
+    float a1 = 0.f, a2 = 0.f;
+    for (int q = 0; q < rpp; ++q) { a1 += red[0][(q * tpr + slot) * 4 + sub]; a2 += red[1][(q * tpr + slot) * 4 + sub]; }
+    if (dW) atomicAdd(dW + (long)g * pstride + c, a1);
+    if (db_below) atomicAdd(db_below + (long)g * pstride + c, a2);
+  }
+  if (threadIdx.x == 0 && db_top) {
+    float t = 0.f;
+    for (int q = 0; q < rpp; ++q) t += red[2][q * tpr];
+    atomicAdd(db_top + (long)g * pstride, t);
+  }
+}
+
 __global__ void adam_kernel(AdamArgs a) {
   const int t = *a.step;
   const float lr = *a.lr;
@@ -710,6 +755,15 @@ int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int 
 
 int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D) {
   hipLaunchKernelGGL(gather_sum4_kernel, dim3(grid_for((long)B * D), 4), dim3(256), 0, s, g, B, D);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int top1_bwd(hipStream_t s, const float* dout, const float* W, const float* act, float* dz, float* dW, float* db_top, float* db_below,
+             int nb, int rows, int brows, int din, long pstride) {
+  if (din % 4 != 0 || din > 1024 || 1024 % din != 0) return set_error(MIMRL_ERR_ARG, "top1_bwd: width %d unsupported", din);
+  hipLaunchKernelGGL(top1_bwd_kernel, dim3((rows + 255) / 256, nb), dim3(256), 0, s, dout, W, act, dz, dW, db_top, db_below, rows, brows, din,
+                     pstride);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -154,6 +154,9 @@ __device__ __forceinline__ void store_tile(const Operand& o, int tid, const floa
 }
 
 // epilogue of one 32x32 accumulator tile: lane holds column n, 16 rows (mbase + MFMA row pattern)
+// GEN: the kernel instantiation that also serves bias_m / beta / pre / gradact_u outputs (it needs ~80 more VGPRs for the
+// loads-first schedule below; plain GEMMs run the GEN = false instantiation at twice the occupancy)
+template <bool GEN>
 __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, long oc, const float bn, const f32x16& acc, int mbase,
                                          int n, int lane) {
   if (n >= d.N) return;   // lanes l and l^32 share n, so the pair exits together (shuffle below stays well-defined)
@@ -164,7 +167,7 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
   // (`beta ? C[off]`, `bias_m ?`, `gradact_u ?`: even when the condition is false) is a branch whose join waits for
   // vmcnt(0), i.e. for the PREVIOUS STORE to retire: the 16 stores of a tile then run at one memory latency each --
   // measured 1.4 TB/s for the store phase of a 128000x384 output, most of the time of every tall GEMM.
-  if (!d.bias_m && d.beta == 0.f && !d.pre && !d.gradact_u) {
+  if (!GEN || (!d.bias_m && d.beta == 0.f && !d.pre && !d.gradact_u)) {
     float v[16];
     if (d.act == ACT_NONE) {
 #pragma unroll
@@ -187,21 +190,53 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
         if (m < d.M) { Cn[(long)m * d.sc_m] = v[r]; csum += v[r]; }
       }
     }
-  } else {
+  } else if constexpr (GEN) {
+    // general outputs: every optional operand is fetched FIRST -- 8 unconditional loads back to back from clamped rows (one
+    // memory latency per operand kind and half tile, not per element) -- then a compute / store pass without loads
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= d.M) continue;
-      const long off = (long)m * d.sc_m + (long)n * d.sc_n;
-      float v = d.alpha * acc[r] + bn;
-      if (d.bias_m) v += d.bias_m[(long)bz * d.bias_m_b + m];
-      if (d.beta != 0.f) v += d.beta * C[off];
-      if (d.pre) d.pre[oc + off] = v;
-      if (d.gradact_u) v *= act_grad(d.act, d.gradact_u[oc + off]);
-      else v = act_apply(d.act, v);
-      if (atomic) atomicAdd(&C[off], v);
-      else C[off] = v;
-      csum += v;
+    for (int h = 0; h < 2; ++h) {
+      float v[8], t[8];
+      auto row = [&](int q) { const int r = 8 * h + q; return mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); };
+      auto offs = [&](int q) { const int m = row(q); return (long)(m < d.M ? m : d.M - 1) * d.sc_m + (long)n * d.sc_n; };
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = d.alpha * acc[8 * h + q] + bn;
+      if (d.bias_m) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int m = row(q); t[q] = d.bias_m[(long)bz * d.bias_m_b + (m < d.M ? m : d.M - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += t[q];
+      }
+      if (d.beta != 0.f) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = C[offs(q)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += d.beta * t[q];
+      }
+      if (d.gradact_u) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = d.gradact_u[oc + offs(q)];
+      }
+      if (d.pre) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (row(q) < d.M) d.pre[oc + offs(q)] = v[q];
+      }
+      if (d.gradact_u) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= act_grad(d.act, t[q]);
+      } else if (d.act != ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = act_apply(d.act, v[q]);
+      }
+      if (atomic) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (row(q) < d.M) { atomicAdd(&C[offs(q)], v[q]); csum += v[q]; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (row(q) < d.M) { C[offs(q)] = v[q]; csum += v[q]; }
+      }
     }
   }
   if (d.colsum) {   // fused bias gradient: lanes l and l^32 hold the same column
@@ -226,7 +261,7 @@ __device__ __forceinline__ void tile_ids(int remap, unsigned& bx, unsigned& by, 
   }
 }
 
-template <bool BF16, int BK, bool LEAN>
+template <bool BF16, int BK, bool LEAN, bool GEN>
 __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
   const GemmDesc& d = ka.d;
   using M = Map<BK>;
@@ -300,7 +335,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
     segment(d.A2 + (long)bz * d.sa2_b, d.sa2_m, d.sa2_k, d.B2 + (long)bz * d.sb2_b, d.sb2_k, d.sb2_n, d.K2, ka.vec_a2, ka.vec_b2,
             0, (d.K2 + BK - 1) / BK, 0x7fffffff, 0);
 
-  epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre, acc, m0 + wm * 32, n_lane, lane);
+  epilogue<GEN>(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre, acc, m0 + wm * 32, n_lane, lane);
 }
 
 
@@ -402,7 +437,7 @@ __device__ __forceinline__ bf16x8 fast_frag(const __bf16* __restrict__ img, int 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC>
+template <int TM, int TN, bool AKC, bool BKC, bool GEN>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
   const GemmDesc& d = ka.d;
   constexpr int BMf = 64 * TM, BNf = 64 * TN;
@@ -482,7 +517,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epilogue(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre[j], acc[i][j], m0 + wm * 32 * TM + i * 32, n0 + wn * 32 * TN + j * 32 + (lane & 31), lane);
+      epilogue<GEN>(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre[j], acc[i][j], m0 + wm * 32 * TM + i * 32, n0 + wn * 32 * TN + j * 32 + (lane & 31), lane);
 }
 
 // layout class of one operand for the fast path: 1 = KC, 2 = RC, 0 = not eligible.  (row axis = m for A, n for B)
@@ -596,7 +631,15 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   const int bm = 64 * pl.tm, bn = 64 * pl.tn;   // (64 x 64 unless the fast path picked a larger tile)
   dim3 grid((d.N + bn - 1) / bn, (d.M + bm - 1) / bm, d.batch * pl.nsplit);
   if (grid.y > 65535 || grid.z > 65535) return set_error(MIMRL_ERR_ARG, "gemm: grid too large (M=%d batch=%d)", d.M, d.batch);
-#define FASTK(TM_, TN_, A_, B_) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_>), grid, dim3(256), 0, s, ka); break
+  const bool gen = d.bias_m || d.beta != 0.f || d.pre || d.gradact_u;
+#define FASTK(TM_, TN_, A_, B_)                                                                               \
+  if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);         \
+  else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \
+  break
+#define GENK(BF_, BK_, LEAN_)                                                                                 \
+  if (gen) hipLaunchKernelGGL((gemm_kernel<BF_, BK_, LEAN_, true>), grid, dim3(256), 0, s, ka);               \
+  else hipLaunchKernelGGL((gemm_kernel<BF_, BK_, LEAN_, false>), grid, dim3(256), 0, s, ka);                  \
+  break
   switch (pl.variant) {
     case 10: FASTK(2, 2, true, true);
     case 11: FASTK(2, 2, true, false);
@@ -607,11 +650,12 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
     case 18: FASTK(1, 1, true, true);
     case 19: FASTK(1, 1, true, false);
     case 20: FASTK(1, 1, false, false);
-    case 0: hipLaunchKernelGGL((gemm_kernel<false, 32, false>), grid, dim3(256), 0, s, ka); break;
-    case 3: hipLaunchKernelGGL((gemm_kernel<true, 128, true>), grid, dim3(256), 0, s, ka); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<true, 64, true>), grid, dim3(256), 0, s, ka); break;
-    default: hipLaunchKernelGGL((gemm_kernel<true, 32, false>), grid, dim3(256), 0, s, ka); break;
+    case 0: GENK(false, 32, false);
+    case 3: GENK(true, 128, true);
+    case 2: GENK(true, 64, true);
+    default: GENK(true, 32, false);
   }
+#undef GENK
 #undef FASTK
   LAUNCH_CHECK();
   return MIMRL_OK;

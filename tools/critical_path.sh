@@ -3,7 +3,7 @@
 # (MIMRL_DBG_DELAY_TAG, engine.hip: dbg_delay) and report the step-time increase per injected microsecond.
 # usage: tools/critical_path.sh [US]      (run on the GPU box from the repo root)
 US=${1:-100}
-run() { env "$@" timeout 200 python bench.py --profile-steps 0 --no-cpu-baseline --steps 150 2>/dev/null | tail -1 | python -c "import sys,json; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])"; }
+run() { env "$@" timeout 200 python bench.py --profile-steps 0 --no-cpu-baseline --no-extra --steps 150 2>/dev/null | tail -1 | python -c "import sys,json; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])"; }
 b1=$(run X=0); 
 names=(x "gru_fwd(x2)" "cube_fwd tail s2" "MI fwd s1" "CMI fwd s1" "MI bwd s1" "CMI bwd s1" "cube_bwd" "gru_bwd(x2)" "wgrad sides(3 streams)" "text GEMM" "kNN s1" "adam(x2)" "cube_fwd tail s1" "CMI fwd s2" "MI fwd s2" "CMI bwd s2" "MI bwd s2" "kNN s2")
 mult=(0 2 1 1 1 1 1 1 2 1 1 1 2 1 1 1 1 1 1)
