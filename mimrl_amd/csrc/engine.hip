@@ -238,6 +238,11 @@ struct mimrl_handle {
     *e = ev_pool[ev_next++];
     return MIMRL_OK;
   }
+  int G_group(hipStream_t st, const GemmDesc* ds, int n) {
+    if (!prof_on) return gemm_group(st, ds, n, bf16);
+    for (int i = 0; i < n; ++i) MX(G_on(st, ds[i]));      // profiling: one event pair per product
+    return MIMRL_OK;
+  }
   unsigned side_mask = ~0u;            // sides that may be used right now; work for a masked-out side goes to `stream`
   bool side_on(int i) const { return multi_stream && ((side_mask >> i) & 1u); }
   hipStream_t S(int i) const { return side_on(i) ? side[i] : stream; }
@@ -1568,15 +1573,26 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     if (hs >= 0) MX(fork(hs, hs));
     // bias gradient of the top layer: behind the chain (it only reads dout), on the helper stream when there is one
     MX(colsum(hs >= 0 ? S(hs) : stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
+    GemmDesc gs[MLPF_MAX_LAYERS];
     for (int l = nl - 1; l >= 0; --l) {   // dW_l = dZ_l^T A_l
       const int din_ = dims[l], dout_ = dims[l + 1];
-      GemmDesc g;
+      GemmDesc& g = gs[nl - 1 - l];
+      g = GemmDesc();
       g.A = l == nl - 1 ? dout : fa.dz[l + 1]; g.sa_m = 1; g.sa_k = dout_; g.sa_b = (long)brows * dout_;
       g.B = l == 0 ? in : act[l - 1]; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
       g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
       g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
+    }
+    // the nl weight-gradient products are independent of each other: ONE grouped launch (gemm_group; it falls back to nl launches
+    // when a product is not eligible, e.g. the 2-row top layer of the CMI classifiers, which then goes alone)
+    static const bool no_group = getenv("MIMRL_NO_WG_GROUP") != nullptr;   // tuning knob: the round-1 schedule (helper stream, alternating)
+    if (!no_group) {
+      int lo = 0;
+      if (dims[nl] % 4 != 0) { MX(G_on(hs >= 0 ? S(hs) : stream, gs[0])); lo = 1; }   // not row-contiguous-eligible: beside the group
+      MX(G_group(stream, gs + lo, nl - lo));
+    } else {
       static const int helper_par = getenv("MIMRL_WG_SPLIT_PARITY") ? atoi(getenv("MIMRL_WG_SPLIT_PARITY")) : 0;   // tuning knob
-      MX(G_on((hs >= 0 && ((nl - 1 - l) & 1) == helper_par) ? S(hs) : stream, g));
+      for (int q = 0; q < nl; ++q) MX(G_on((hs >= 0 && (q & 1) == helper_par) ? S(hs) : stream, gs[q]));
     }
     if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;

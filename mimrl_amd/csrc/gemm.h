@@ -65,5 +65,8 @@ struct GemmPlan {
 };
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p);
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
+// up to 6 independent GEMMs as ONE launch when they are plain (no second product / operand-reading epilogue), bf16 and of one
+// operand-layout class of the fast path; otherwise n ordinary launches.  No split-K: meant for many small products.
+int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16);
 
 }  // namespace mimrl

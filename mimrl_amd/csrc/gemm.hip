@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
 // (RC,RC) weight gradients cover every large GEMM of the step; anything else falls back to gemm_kernel.
 // =================================================================================================
 constexpr int FBK = 32;
+constexpr int GEMM_GROUP_MAX = 6;
 template <int T>
 struct FT {
   static constexpr int R = 64 * T;
@@ -438,16 +439,13 @@ __device__ __forceinline__ bf16x8 fast_frag(const __bf16* __restrict__ img, int 
 }
 
 template <int TM, int TN, bool AKC, bool BKC, bool GEN>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
-  const GemmDesc& d = ka.d;
+__device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_per, int dbg, unsigned bx, unsigned by, unsigned bzr) {
   constexpr int BMf = 64 * TM, BNf = 64 * TN;
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][FT<TM>::ELEMS];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2][FT<TN>::ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  unsigned bx, by, bzr;
-  tile_ids(ka.xcd_remap, bx, by, bzr);
-  const int bz = bzr / ka.ksplit, ks = bzr - bz * ka.ksplit;
+  const int bz = bzr / ksplit, ks = bzr - bz * ksplit;
   long oa = (long)bz * d.sa_b, ob = (long)bz * d.sb_b, oc = (long)bz * d.sc_b, obn = (long)bz * d.bias_n_b;
   if (d.batch_in > 0) {
     const int bo = bz / d.batch_in, bi = bz - bo * d.batch_in;
@@ -505,19 +503,46 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
   };
   {
     const int ktiles = (d.K + FBK - 1) / FBK;
-    const int kt0 = ks * ka.kt_per;
-    const int kt1 = ka.dbg == 2 ? kt0 : (kt0 + ka.kt_per < ktiles ? kt0 + ka.kt_per : ktiles);
+    const int kt0 = ks * kt_per;
+    const int kt1 = dbg == 2 ? kt0 : (kt0 + kt_per < ktiles ? kt0 + kt_per : ktiles);
     segment(d.A + oa, AKC ? d.sa_m : d.sa_k, d.B + ob, BKC ? d.sb_n : d.sb_k, d.K, kt0, kt1, d.a_gap_rows ? d.a_gap_at : 0x7fffffff, d.a_gap_rows);
   }
   if (d.A2)
     segment(d.A2 + (long)bz * d.sa2_b, AKC ? d.sa2_m : d.sa2_k, d.B2 + (long)bz * d.sb2_b, BKC ? d.sb2_n : d.sb2_k, d.K2, 0,
             (d.K2 + FBK - 1) / FBK, 0x7fffffff, 0);
-  if (ka.dbg == 1) { if (acc[0][0][0] == 123.456f) d.C[0] = 1.f; return; }
+  if (dbg == 1) { if (acc[0][0][0] == 123.456f) d.C[0] = 1.f; return; }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      epilogue<GEN>(d, d.atomic || ka.ksplit > 1, bz, oc, bn_pre[j], acc[i][j], m0 + wm * 32 * TM + i * 32, n0 + wn * 32 * TN + j * 32 + (lane & 31), lane);
+      epilogue<GEN>(d, d.atomic || ksplit > 1, bz, oc, bn_pre[j], acc[i][j], m0 + wm * 32 * TM + i * 32, n0 + wn * 32 * TN + j * 32 + (lane & 31), lane);
+}
+
+template <int TM, int TN, bool AKC, bool BKC, bool GEN>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
+  fast_body<TM, TN, AKC, BKC, GEN>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
+}
+
+// GROUPED launch: up to GEMM_GROUP_MAX independent plain GEMMs of one layout class (64x64 tiles, no split-K) in ONE launch --
+// the weight gradients of an estimator MLP stack (4 layers x 10 towers / 6 classifiers) are 4-5 launches of ~10 us of work
+// each on the critical branch of stage 1; as one launch they fill the chip once.
+struct GroupArgs {
+  GemmDesc d[GEMM_GROUP_MAX];
+  int start[GEMM_GROUP_MAX + 1];   // first linear workgroup id of each problem
+  int n;
+};
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < GEMM_GROUP_MAX; ++q)
+    if (q < ga.n && (int)blockIdx.x >= ga.start[q]) p = q;
+  const GemmDesc& d = ga.d[p];
+  const unsigned t = blockIdx.x - ga.start[p];
+  const unsigned nx = (d.N + 63) / 64, ny = (d.M + 63) / 64;
+  fast_body<1, 1, AKC, BKC, false>(d, 1, (d.K + FBK - 1) / FBK, 0, t % nx, (t / nx) % ny, t / (nx * ny));
 }
 
 // layout class of one operand for the fast path: 1 = KC, 2 = RC, 0 = not eligible.  (row axis = m for A, n for B)
@@ -602,6 +627,39 @@ void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
     p->nsplit = ksplit;
     p->kt_per = (ktiles + ksplit - 1) / ksplit;
   }
+}
+
+int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
+  static const int no_group = getenv("MIMRL_GEMM_NO_GROUP") != nullptr;   // tuning knob
+  bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUP_MAX;
+  int ca = 0, cb = 0;
+  long total = 0;
+  for (int i = 0; ok && i < n; ++i) {
+    const GemmDesc& d = ds[i];
+    if (d.M <= 0 || d.N <= 0 || d.batch <= 0 || !d.A || !d.B || !d.C) { ok = false; break; }
+    const int a = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K), b = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K);
+    if (!a || !b || (a == 2 && b == 1) || (i > 0 && (a != ca || b != cb))) { ok = false; break; }
+    ca = a; cb = b;
+    if (d.A2 || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.a_gap_rows) { ok = false; break; }   // plain epilogue, single product
+    total += (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+  }
+  if (!ok || total > 65535L * 16) {
+    for (int i = 0; i < n; ++i) MX(gemm(s, ds[i], bf16));
+    return MIMRL_OK;
+  }
+  GroupArgs ga;
+  ga.n = n;
+  int acc = 0;
+  for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
+    if (i < n) { ga.d[i] = ds[i]; ga.start[i] = acc; acc += ((ds[i].M + 63) / 64) * ((ds[i].N + 63) / 64) * ds[i].batch; }
+    else { ga.d[i] = GemmDesc(); ga.start[i] = 0x7fffffff; }
+  }
+  ga.start[GEMM_GROUP_MAX] = acc;
+  if (ca == 1 && cb == 1) hipLaunchKernelGGL((gemm_group_kernel<true, true>), dim3(acc), dim3(256), 0, s, ga);
+  else if (ca == 1) hipLaunchKernelGGL((gemm_group_kernel<true, false>), dim3(acc), dim3(256), 0, s, ga);
+  else hipLaunchKernelGGL((gemm_group_kernel<false, false>), dim3(acc), dim3(256), 0, s, ga);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
 }
 
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
