@@ -101,6 +101,40 @@ __global__ void finalize_stage2_kernel(float* scal, const float* mi, const float
   scal[MIMRL_S2_LOSS] = loss;
 }
 
+// Stage boundary of a combined two-stage step as ONE launch: finalize_stage1 (Model.py:341) + begin_stage(2) + MAE (Solver.py:181-182).
+// Behind the critic Adam; the stage-1 raw terms are still intact (stage 2's estimators overwrite them later).
+__global__ void stage_boundary_kernel(float* scal, const float* mi, const float* cmi, const float* bce, const float* coef1, int* rng_step,
+                                      int* adam_step, const float* __restrict__ pred, const float* __restrict__ y,
+                                      float* __restrict__ dpred, int B) {
+  __shared__ float red[16];
+  if (threadIdx.x == 0) {
+    float loss = 0.f;
+    for (int e = 0; e < NE_MI; ++e) {
+      scal[MIMRL_S1_MIS + e] = mi[e];
+      scal[MIMRL_S1_LOSSES + e] = mi[NE_MI + e];
+      loss += coef1[e] * mi[NE_MI + e];
+    }
+    for (int e = 0; e < NE_CMI; ++e) {
+      scal[MIMRL_S1_MIS + NE_MI + e] = cmi[e];
+      scal[MIMRL_S1_LOSSES + NE_MI + e] = bce[e];
+      loss += coef1[NE_MI + e] * bce[e];
+    }
+    scal[MIMRL_S1_LOSS] = loss;
+    *rng_step += 1;
+    *adam_step += 1;
+  }
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) scal[32 + i] = 0.f;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float d = pred[b] - y[b];
+    s += fabsf(d);
+    dpred[b] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / B;
+  }
+  s = block_sum(s, red);
+  __syncthreads();                       // the zeroing of scal[32..63] above is complete before the task loss lands in it
+  if (threadIdx.x == 0) scal[MIMRL_S2_TASK] = s / B;
+}
+
 struct Lin { long w = -1, b = -1; int out = 0, in = 0; };
 struct GruDirW { long w_ih = 0, w_hh = 0, b_ih = 0, b_hh = 0; int din = 0; };
 struct AxisW { Lin fc1, fc2; long res = -1, ln_g = -1, ln_b = -1; int in = 0, hid = 0, out = 0; };
@@ -372,6 +406,7 @@ struct mimrl_handle {
   int model_forward(bool train, bool save, int knn_stage = 0, int part = 0);   // part: 0 all, 1 prefix, 2 tail
   int cube_forward(bool train, bool save);
   int cube_backward(int cur_in, int* cur_out);
+  int wt_images(hipStream_t st, bool bwd_bf16, bool launch, bool* d_fused);
   int model_backward();
   struct StreamGuard {   // route every launch of a scope to another stream
     mimrl_handle* h; hipStream_t saved;
@@ -396,6 +431,11 @@ struct mimrl_handle {
   int run(int stage, int kind);
   int run_step();                      // both stages as ONE captured graph where possible (mimrl_two_stage_step)
   bool keep_events = false;            // second stage of a combined capture: do not recycle the first stage's events
+  // combined two-stage capture (run_step) only -- the state is provably periodic there:
+  bool fuse_boundary = false;          // finalize_stage1 + begin_stage(2) + mae as ONE launch behind the critic Adam
+  bool imgT_valid = false;             // transposed critic images match the critic parameters (refreshed once per step, behind Adam_vmi)
+  bool skip_imgT_refresh = false;      // stage 1 of a combined step: the images built in the previous step's stage 2 are current
+  bool wtT_prebuilt = false;           // D-axis weight images for the CubeMLP backward built at step start (off the chain)
 };
 
 // =================================================================================================
@@ -1002,6 +1042,24 @@ int mimrl_handle::cube_forward(bool train, bool save) {
 // gbuf[*cur_out] holds d(cube0).  Four rotating gradient buffers are enough: at any time at most
 // {dY, dY through dropout, dU, dX} are live.
 // =================================================================================================
+// which blocks run the fused D-axis backward (needs bf16 operands in the backward section) + their transposed weight images
+int mimrl_handle::wt_images(hipStream_t st, bool bwd_bf16, bool launch, bool* d_fused) {
+  int din2 = cfg.d_common;
+  WtTransposeArgs ta;
+  ta.n = 0;
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const AxisW& a = blk[i].ax[2];
+    d_fused[i] = bwd_bf16 && fused_cube_bwd && !cfg.ln_first && cfg.dropout_mlp[2] <= 0.f && a.res >= 0 &&
+                 daxis_bwd_supported(din2, a.hid, a.out) && ta.n + 3 <= 12;
+    din2 = cfg.d_outs[i][2];
+    if (!d_fused[i]) continue;
+    const long srcs[3] = {a.fc2.w, a.fc1.w, a.res};
+    for (int q = 0; q < 3; ++q) { ta.src[ta.n] = P(srcs[q]); ta.dst[ta.n] = wtT[i][q]; ++ta.n; }
+  }
+  if (launch && ta.n > 0) MX(wt_transpose_bf16(st, ta));
+  return MIMRL_OK;
+}
+
 int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   const int B = cfg.batch;
   int dims[MIMRL_MAX_BLOCKS + 1][3];
@@ -1051,21 +1109,10 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     return rowln_param_grads(S(sd), y, mean, rstd, dz, dgam, dbet, rows, n);
   };
   auto W_fork = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : fork(lo, hi); };
-  // transposed bf16 images of the D-axis weights for the fused data-gradient kernels (one small launch)
+  // transposed bf16 images of the D-axis weights for the fused data-gradient kernels (one small launch; in a combined step
+  // it already ran at step start on side 0, off this chain)
   bool d_fused[MIMRL_MAX_BLOCKS] = {};
-  {
-    WtTransposeArgs ta;
-    ta.n = 0;
-    for (int i = 0; i < cfg.n_blocks; ++i) {
-      const AxisW& a = blk[i].ax[2];
-      d_fused[i] = bf16 && fused_cube_bwd && !cfg.ln_first && cfg.dropout_mlp[2] <= 0.f && a.res >= 0 &&
-                   daxis_bwd_supported(dims[i][2], a.hid, a.out) && ta.n + 3 <= 12;
-      if (!d_fused[i]) continue;
-      const long srcs[3] = {a.fc2.w, a.fc1.w, a.res};
-      for (int q = 0; q < 3; ++q) { ta.src[ta.n] = P(srcs[q]); ta.dst[ta.n] = wtT[i][q]; ++ta.n; }
-    }
-    if (ta.n > 0) MX(wt_transpose_bf16(stream, ta));
-  }
+  MX(wt_images(stream, bf16, !wtT_prebuilt, d_fused));
   auto W_join = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : join(lo, hi); };
 #define GRAB(var)                                                                                   \
   const int var = grab();                                                                           \
@@ -1870,8 +1917,10 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   imgT_ready = false;
   if (backward && bf_bwd && fused_mlp && crit_imgT && ttab.n > 0) {   // transposed weight images for the fused data-gradient chains,
-    MX(fork(3, 3));                                                   // built beside the forward stacks
-    MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
+    if (!(skip_imgT_refresh && stage == 1)) {                         // built beside the forward stacks (combined step: once per step,
+      MX(fork(3, 3));                                                 // in stage 2 -- stage 1 of the NEXT step sees the same critics)
+      MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
+    }
     imgT_ready = true;
   }
   static const int dbg_skip = getenv("MIMRL_DBG_SKIP_EST") ? atoi(getenv("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
@@ -1883,7 +1932,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
     MX(dbg_delay(stream, stage == 1 ? 4 : 14));
-    if (backward) { bf16 = bf_bwd; if (imgT_ready) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
+    if (backward) { bf16 = bf_bwd; if (imgT_ready && !(skip_imgT_refresh && stage == 1)) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
     return MIMRL_OK;
   };
   auto mi_branch = [&]() -> int {
@@ -1893,7 +1942,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     MX(dbg_delay(stream, stage == 1 ? 3 : 15));
     if (backward) {
       bf16 = bf_bwd;
-      if (imgT_ready) MX(join(3, 3));
+      if (imgT_ready && !(skip_imgT_refresh && stage == 1)) MX(join(3, 3));
       Scope sc(this, MIMRL_PH_EST_BWD);
       wg_helper = stage == 1 ? 1 : -1;     // the MI branch is the critical one of stage 1 (tools/critical_path.sh)
       const int r = mi_backward(stage);
@@ -1924,6 +1973,11 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
                        bufs.scalars, 0, 32);
     LAUNCH_CHECK();
     if (!have_banks) return MIMRL_OK;
+    if (wtT_prebuilt) {   // combined step: the CubeMLP backward's weight images now, beside the encoders (main parameters only)
+      bool df[MIMRL_MAX_BLOCKS];
+      MX(fork(0, 0));
+      MX(wt_images(S(0), (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0, true, df));
+    }
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     static const bool pre_first = getenv("MIMRL_PREFETCH_FIRST") != nullptr;   // tuning knob: capture order of the two chains
@@ -2011,8 +2065,10 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (prefetch) swap_fwd_set();
     MX(r1);
     if (prefetch && !share && !pre_first) MX(issue_prefetch(e_begin));
-    hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
-    LAUNCH_CHECK();
+    if (!fuse_boundary) {
+      hipLaunchKernelGGL(finalize_stage1_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
+      LAUNCH_CHECK();
+    }
     if (prefetch && !(share && defer_tail)) {   // rejoin before the stage ends (a captured graph must not leave a dangling branch)
       hipEvent_t e;
       MX(next_event(&e));
@@ -2021,7 +2077,12 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     }
     return MIMRL_OK;
   }
-  hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
+  if (fuse_boundary) {
+    hipLaunchKernelGGL(stage_boundary_kernel, dim3(1), dim3(256), 0, stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1(), d_ints, d_ints + 1,
+                       bufs.pred, bufs.labels, dpred, B);
+  } else {
+    hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
+  }
   LAUNCH_CHECK();
   if (!skip_zero) HIPX(hipMemsetAsync(bufs.main_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_MAIN], stream));
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
@@ -2030,15 +2091,19 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   } else {
     MX(model_forward(true, true, have_banks ? 2 : 0));
   }
-  hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
-  LAUNCH_CHECK();
+  if (!fuse_boundary) {
+    hipLaunchKernelGGL(mae_kernel, dim3(1), dim3(256), 0, stream, bufs.pred, bufs.labels, dpred, bufs.scalars + MIMRL_S2_TASK, B);
+    LAUNCH_CHECK();
+  }
   if (have_banks) {
     MX(estimators_all(2, true, true));
     MX(route_feature_grads());
   } else {
     HIPX(hipMemsetAsync(dfeat, 0, sizeof(float) * 4 * B * EMB, stream));
   }
-  hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, stream, bufs.scalars, mi_raw, cmi_raw, coef2(),
+  // (writes scalars only: beside the backward chain on side 0; model_backward joins every side before the stage ends)
+  MX(fork(0, 0));
+  hipLaunchKernelGGL(finalize_stage2_kernel, dim3(1), dim3(64), 0, S(0), bufs.scalars, mi_raw, cmi_raw, coef2(),
                      have_banks ? 1 : 0);
   LAUNCH_CHECK();
   bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
@@ -2070,6 +2135,7 @@ int mimrl_handle::run(int stage, int kind) {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
   MX(ensure_images());
+  if (stage == 1 && kind != 1) imgT_valid = false;     // a critic update outside the combined step: its periodic image state is gone
   if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
   // an all-reduce): always zero first -- the caller may call it repeatedly
@@ -2163,22 +2229,31 @@ int mimrl_handle::run_step() {
   const bool combined = cfg.use_graph && !prof_on && prefetch && !defer_tail && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
   if (!combined) { MX(run(1, 0)); if (defer_tail) MX(run_fwd2_tail()); return run(2, 0); }
   MX(ensure_images());
+  const bool bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  const bool use_imgT = bf_bwd && fused_mlp && crit_imgT && ttab.n > 0;
+  if (use_imgT && !imgT_valid) {   // the captured stage 1 relies on the images left by the previous step's stage 2
+    MX(bf16_transposed_images(user_stream, bufs.crit_p, crit_imgT, ttab));
+    imgT_valid = true;
+  }
   hipGraphExec_t& ex = graph[0][0];
   if (ex && graph_rows[0][0] != bank_rows) {   // bank size is baked into the kernel arguments
     HIPX(hipGraphExecDestroy(ex));
     ex = nullptr;
   }
   if (!ex) {
+    static const bool no_boundary = getenv("MIMRL_NO_FUSED_BOUNDARY") != nullptr;   // tuning knob: the round-1 stage boundary
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
     stream = cap_stream;
+    fuse_boundary = !no_boundary; skip_imgT_refresh = use_imgT && !no_boundary; wtT_prebuilt = bf_bwd && fused_cube_bwd && !no_boundary;
     int r = enqueue_grads(1, true);
     if (r == 0) r = enqueue_apply(1);
     keep_events = true;
     if (r == 0) r = enqueue_grads(2, true);
     keep_events = false;
     if (r == 0) r = enqueue_apply(2);
+    fuse_boundary = false; skip_imgT_refresh = false; wtT_prebuilt = false;
     stream = user_stream;
     const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
     if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
@@ -2257,6 +2332,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
   h->bufs = *b;
   h->bound = true;
   h->img_valid = false;
+  h->imgT_valid = false;
   h->d_ints = b->counters ? b->counters : h->d_ints_own;   // graphs are rebuilt below, so the new address is baked in
   for (int s = 0; s <= 2; ++s)
     for (int k = 0; k < 2; ++k)
@@ -2370,6 +2446,7 @@ int mimrl_profile_read_gemm(mimrl_handle* h, double out[4]) {
 int mimrl_params_changed(mimrl_handle* h) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   h->img_valid = false;
+  h->imgT_valid = false;
   return MIMRL_OK;
 }
 
