@@ -764,7 +764,9 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         gd.sa_bo = h0[1] - h0[0]; gd.sb_bo = gru[1][l][0].w_ih - gf.w_ih; gd.sc_bo = gx[1][0] - gx[0][0];
         gd.bias_n_bo = gru[1][l][0].b_ih - gf.b_ih;
       }
-      if ((l == 0 && !l0_packed) || (l == 1 && m == 0)) MX(G_on(m == 0 ? stream : S(2), gd));   // layer 1: the m == 0 launch covers both modalities
+      // layer 1: the m == 0 launch covers both modalities; layer 0: video beside audio (side 2, or behind the length scan on side 4
+      // when the overlap mode has masked side 2 off -- both are joined in front of the recurrence)
+      if ((l == 0 && !l0_packed) || (l == 1 && m == 0)) MX(G_on(m == 0 ? stream : (side_on(2) ? S(2) : S(4)), gd));
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
@@ -1611,6 +1613,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
       fa.WbT[l] = crit_imgT + p0 + l_off[l][0];
       if (l < nl - 1) { fa.act[l] = act[l]; fa.dz[l + 1] = dtmp[l]; if (wgrad) fa.db[l] = CG(p0 + l_off[l][1]); }
     }
+    if (wgrad) fa.db_top = CG(p0 + l_off[nl - 1][1]);   // the top layer's bias gradient rides along (was a separate column-sum launch)
     MX(mlp_stack_bwd_fused(stream, fa));
     if (!wgrad) return MIMRL_OK;
     // the nl weight-gradient GEMMs are independent of each other: on the critical branch (wg_helper >= 0) every second
@@ -1618,8 +1621,6 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     static const bool no_split = getenv("MIMRL_NO_WG_SPLIT") != nullptr;   // tuning knob
     const int hs = (multi_stream && !no_split) ? wg_helper : -1;
     if (hs >= 0) MX(fork(hs, hs));
-    // bias gradient of the top layer: behind the chain (it only reads dout), on the helper stream when there is one
-    MX(colsum(hs >= 0 ? S(hs) : stream, dout, rows, dims[nl], dims[nl], CG(p0 + l_off[nl - 1][1]), nb, (long)brows * dims[nl], pstride));
     GemmDesc gs[MLPF_MAX_LAYERS];
     for (int l = nl - 1; l >= 0; --l) {   // dW_l = dZ_l^T A_l
       const int din_ = dims[l], dout_ = dims[l + 1];

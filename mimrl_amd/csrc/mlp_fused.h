@@ -30,6 +30,7 @@ struct MlpFusedArgs {
   float* dz[MLPF_MAX_LAYERS];     // dz[l] = gradient w.r.t. the pre-activation of layer l-1's output, l = 1..nl-1: [nb, brows, dims[l]]
   float* din;                     // [nb, brows, dims[0]] or null
   float* db[MLPF_MAX_LAYERS];     // optional bias gradients of layers 0..nl-2 (column sums of dz[l+1]), group g at + g*pstride
+  float* db_top;                  // optional bias gradient of the TOP layer (column sums of dout), group g at + g*pstride
   int dbg;                        // timing experiments only (MIMRL_DBG_MLPB): 1 no ReLU mask, 2 no bias atomics, 4 no dz stores
 };
 

@@ -257,6 +257,13 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
   const int lr = lane & 31, lh = lane >> 5;
   const int srow = lane >> 3, sk = (lane & 7) * 8;            // staging map: 8 rows x 64 k (bf16) per 16-byte instruction
   load_tile_bf16(BWD ? a.dout : a.in, rowbase, r0, a.rows, BWD ? a.dims[a.nl] : a.dims[0], sa[0], tid);
+  if (BWD && a.db_top && tid < a.dims[a.nl]) {   // top-layer bias gradient: column sums of this tile's dout rows (fp32 source, L2-hot)
+    const int w = a.dims[a.nl];
+    const int nr = min(RT, a.rows - r0);
+    float s = 0.f;
+    for (int r = 0; r < nr; ++r) s += a.dout[(rowbase + r) * w + tid];
+    atomicAdd(a.db_top + (long)g * a.pstride + tid, s);
+  }
   __syncthreads();
   int cur = 0;
   for (int step = 0; step < a.nl; ++step) {
@@ -517,6 +524,7 @@ int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
     LAUNCH_CHECK();
     return MIMRL_OK;
   }
+  if (a.db_top) return set_error(MIMRL_ERR_ARG, "mlp_stack_bwd_fused: db_top needs the transposed bf16 weight images");
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
