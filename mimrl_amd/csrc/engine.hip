@@ -435,7 +435,8 @@ struct mimrl_handle {
   bool fuse_boundary = false;          // finalize_stage1 + begin_stage(2) + mae as ONE launch behind the critic Adam
   bool imgT_valid = false;             // transposed critic images match the critic parameters (refreshed once per step, behind Adam_vmi)
   bool skip_imgT_refresh = false;      // stage 1 of a combined step: the images built in the previous step's stage 2 are current
-  bool wtT_prebuilt = false;           // D-axis weight images for the CubeMLP backward built at step start (off the chain)
+  bool wtT_prebuilt = false;           // D-axis weight images for the CubeMLP backward are built beside the encoders (off the chain) ...
+  bool wtT_built = false;              // ... and that launch has been captured (only the shared-prefix path issues it)
 };
 
 // =================================================================================================
@@ -1114,7 +1115,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   // transposed bf16 images of the D-axis weights for the fused data-gradient kernels (one small launch; in a combined step
   // it already ran at step start on side 0, off this chain)
   bool d_fused[MIMRL_MAX_BLOCKS] = {};
-  MX(wt_images(stream, bf16, !wtT_prebuilt, d_fused));
+  MX(wt_images(stream, bf16, !(wtT_prebuilt && wtT_built), d_fused));
   auto W_join = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : join(lo, hi); };
 #define GRAB(var)                                                                                   \
   const int var = grab();                                                                           \
@@ -1974,11 +1975,6 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
                        bufs.scalars, 0, 32);
     LAUNCH_CHECK();
     if (!have_banks) return MIMRL_OK;
-    if (wtT_prebuilt) {   // combined step: the CubeMLP backward's weight images now, beside the encoders (main parameters only)
-      bool df[MIMRL_MAX_BLOCKS];
-      MX(fork(0, 0));
-      MX(wt_images(S(0), (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0, true, df));
-    }
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
     static const bool pre_first = getenv("MIMRL_PREFETCH_FIRST") != nullptr;   // tuning knob: capture order of the two chains
@@ -2015,6 +2011,12 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       r1 = model_forward(true, true, 1, 1);
       side_mask = ~0u;
       MX(r1);
+      if (wtT_prebuilt) {   // combined step: the CubeMLP backward's weight images (main parameters only) on side 0 -- captured BEHIND the
+        bool df[MIMRL_MAX_BLOCKS];   // encoders (nodes start in capture order: in front of them it delayed the input projections by 12 us);
+        MX(fork(0, 0));              // side 0 is joined at the end of stage 2, which is part of the same capture
+        MX(wt_images(S(0), (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0, true, df));
+        wtT_built = true;
+      }
       if (knn_pre) {                     // stage 2's kNN sampler rides on side 4 behind stage 1's, both beside the prefix (the
         rng_add = 1;                     // recurrence leaves half the CUs idle); anchor key = the step counter begin_stage(2) will set
         r1 = knn_launch(2, S(4));
@@ -2248,6 +2250,7 @@ int mimrl_handle::run_step() {
     HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
     stream = cap_stream;
     fuse_boundary = !no_boundary; skip_imgT_refresh = use_imgT && !no_boundary; wtT_prebuilt = bf_bwd && fused_cube_bwd && !no_boundary;
+    wtT_built = false;
     int r = enqueue_grads(1, true);
     if (r == 0) r = enqueue_apply(1);
     keep_events = true;

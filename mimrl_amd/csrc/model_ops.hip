@@ -15,12 +15,20 @@ __global__ void seq_lengths_kernel(const float* __restrict__ x, int T, int d, in
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  for (int t = w; t < T; t += nw) {
-    const float* row = x + ((long)b * T + t) * d;
-    float s = 0.f;
-    for (int j = lane; j < d; j += 64) s += fabsf(row[j]);
-    s = wave_sum(s);
-    if (lane == 0 && s != 0.f) atomicAdd(&cnt, 1);
+  // four rows per wave and pass, all loads issued before the first reduction: the scan is a chain of memory round trips
+  for (int t0 = 4 * w; t0 < T; t0 += 4 * nw) {
+    float s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = t0 + q < T ? t0 + q : T - 1;
+      const float* row = x + ((long)b * T + t) * d;
+      s[q] = 0.f;
+      for (int j = lane; j < d; j += 64) s[q] += fabsf(row[j]);
+    }
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c += (t0 + q < T && wave_sum(s[q]) != 0.f) ? 1 : 0;
+    if (lane == 0 && c) atomicAdd(&cnt, c);
   }
   __syncthreads();
   if (threadIdx.x == 0) lens[b] = cnt > 0 ? cnt : 1;
@@ -575,7 +583,7 @@ int seq_lengths(hipStream_t s, const float* x, int B, int T, int d, int* lens) {
   return MIMRL_OK;
 }
 int seq_lengths2(hipStream_t s, const float* xa, int da, int* lens_a, const float* xv, int dv, int* lens_v, int B, int T) {
-  hipLaunchKernelGGL(seq_lengths_kernel, dim3(B, 2), dim3(256), 0, s, xa, T, da, lens_a, xv, dv, lens_v);
+  hipLaunchKernelGGL(seq_lengths_kernel, dim3(B, 2), dim3(1024), 0, s, xa, T, da, lens_a, xv, dv, lens_v);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
