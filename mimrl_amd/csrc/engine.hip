@@ -1405,20 +1405,29 @@ int mimrl_handle::model_backward() {
   { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
   MX(dbg_delay(stream, 7));
   float* dcube = gbuf[ci];
-  // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T
-  MX(feat_mean_bwd(stream, dfeat + (size_t)B * D, dcube, B, T, L, 3, D));
-  // text branch (side 0): dW_t = dtx^T . text
-  MX(fork(0, 0));
-  MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0));
-  { GemmDesc g = gemm_tn(dtx, D, bufs.text, cfg.d_t, Gm(w_t), cfg.d_t, D, cfg.d_t, (int)BT_); g.atomic = 1; MX(G_on(S(0), g)); }
+  // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T -- folded into the two consumers of dcube below
+  // (no feat_mean_bwd launch on the chain).  The critical consumer goes first in capture order; the text branch has slack.
+  const float* dmean = dfeat + (size_t)B * D;      // [3][B, D]: gradients of T_F, A_F, V_F
+  // capture order of the two consumers: text branch FIRST although the LayerNorm backward is the critical one -- captured
+  // second, the text branch (35 us of W_t weight gradient) starts late and holds up the join at the end of the stage
+  // (measured 1.229 vs 1.259 ms; MIMRL_TEXT_BWD_LAST=1 for the other order)
+  static const bool text_bwd_first = getenv("MIMRL_TEXT_BWD_LAST") == nullptr;
+  auto text_bwd = [&]() -> int {   // text branch (side 0): dW_t = dtx^T . text
+    MX(fork(0, 0));
+    MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0, dmean));
+    { GemmDesc g = gemm_tn(dtx, D, bufs.text, cfg.d_t, Gm(w_t), cfg.d_t, D, cfg.d_t, (int)BT_); g.atomic = 1; MX(G_on(S(0), g)); }
+    return MIMRL_OK;
+  };
+  if (text_bwd_first) MX(text_bwd());
   // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
   {
     LnSide2 sd[2];
     for (int m = 0; m < 2; ++m)
       sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], ds[m], Gm(ln_g[m]), Gm(ln_b[m]), 1 + m,
                       cfg.dropout[1 + m], (uint32_t)(1 + m)};
-    MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key()));
+    MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key(), dmean + (size_t)B * D, dmean + 2 * (size_t)B * D));
   }
+  if (!text_bwd_first) MX(text_bwd());
   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT.  Tuning knob MIMRL_BPTT_FIRST=1 captures the BPTT launch in
   // front of the parked kernels (graph nodes are dispatched in capture order).  Measured on cfg2: 1.58 vs 1.36 ms -- the
   // recurrence is latency-bound and loses more to the weight-gradient kernels sharing its CUs from the first cell step on

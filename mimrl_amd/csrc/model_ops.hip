@@ -35,8 +35,11 @@ __global__ void seq_lengths_kernel(const float* __restrict__ x, int T, int d, in
 }
 
 // ------------------------------------------------------------------ text branch
+// backward: `dmean` (optional) = gradient of this slot's temporal mean [B, D] (Model.py:466), added as dmean / T -- the
+// feat_mean backward folded into its consumer
 __global__ void text_post_kernel(const float* __restrict__ src, float* __restrict__ cube, long n, int T, int L, int K,
-                                 int D, int slot, float p, RngKey key, uint32_t stream, int backward) {
+                                 int D, int slot, float p, RngKey key, uint32_t stream, int backward, const float* __restrict__ dmean) {
+  const float invT = 1.f / T;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int dd = i % D;
     const long bt = i / D;
@@ -44,13 +47,13 @@ __global__ void text_post_kernel(const float* __restrict__ src, float* __restric
     const long b = bt / T;
     const long ci = ((b * L + t) * K + slot) * D + dd;
     const float sc = drop_scale(p, key, stream, (uint32_t)i);
-    if (backward) cube[i] = sc * src[ci];     // here: src = dcube, cube = dsrc (contiguous [B,T,D])
+    if (backward) cube[i] = sc * (src[ci] + (dmean ? dmean[b * D + dd] * invT : 0.f));     // here: src = dcube, cube = dsrc (contiguous [B,T,D])
     else cube[ci] = sc * src[i];
   }
 }
 
 // ------------------------------------------------------------------ LN + ReLU + dropout on the bi-GRU output
-struct LnSide { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamma, *dbeta; int slot; float p; uint32_t stream; };
+struct LnSide { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamma, *dbeta; int slot; float p; uint32_t stream; const float* dmean; };
 template <int PER>   // D = 64*PER; blockIdx.y selects the modality (audio / video) of a paired launch
 __global__ void ln_relu_drop_fwd_kernel(LnSide s0, LnSide s1, float* __restrict__ cube, long rows, int T, int L, int K,
                                         RngKey key) {
@@ -92,6 +95,8 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
   const float* __restrict__ mean = sd.mean; const float* __restrict__ rstd = sd.rstd;
   float* __restrict__ ds = sd.ds; float* __restrict__ dgamma = sd.dgamma; float* __restrict__ dbeta = sd.dbeta;
   const int slot = sd.slot; const float p = sd.p; const uint32_t stream = sd.stream;
+  const float* __restrict__ dmean = sd.dmean;       // optional: gradient of this slot's temporal mean [B, D] (feat_mean backward folded in)
+  const float invT = 1.f / T;
   constexpr int D = 64 * PER;
   __shared__ float sg[D], sb[D];
   const int lane = threadIdx.x & 63;
@@ -112,7 +117,7 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
       const int j = lane + 64 * i;
       xh[i] = (hr[j] + hr[D + j] - mu) * rs;
       const float y = xh[i] * gamma[j] + beta[j];
-      float dy = dc[j] * drop_scale(p, key, stream, (uint32_t)(r * D + j));
+      float dy = (dc[j] + (dmean ? dmean[b * D + j] * invT : 0.f)) * drop_scale(p, key, stream, (uint32_t)(r * D + j));
       dy = y > 0.f ? dy : 0.f;
       ag[i] += dy * xh[i];
       ab[i] += dy;
@@ -592,15 +597,15 @@ int text_post_fwd(hipStream_t s, const float* src, float* cube, int B, int T, in
                   RngKey key, uint32_t stream_id) {
   const long n = (long)B * T * D;
   hipLaunchKernelGGL(text_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, cube, n, T, L, K, D, slot, p, key,
-                     stream_id, 0);
+                     stream_id, 0, (const float*)nullptr);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
 int text_post_bwd(hipStream_t s, const float* dcube, float* dsrc, int B, int T, int L, int K, int D, int slot, float p,
-                  RngKey key, uint32_t stream_id) {
+                  RngKey key, uint32_t stream_id, const float* dmean) {
   const long n = (long)B * T * D;
   hipLaunchKernelGGL(text_post_kernel, dim3(grid_for(n)), dim3(256), 0, s, dcube, dsrc, n, T, L, K, D, slot, p, key,
-                     stream_id, 1);
+                     stream_id, 1, dmean);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -609,7 +614,7 @@ int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const f
                      float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  const LnSide a{h2, gamma, beta, mean, rstd, nullptr, nullptr, nullptr, slot, p, stream_id};
+  const LnSide a{h2, gamma, beta, mean, rstd, nullptr, nullptr, nullptr, slot, p, stream_id, nullptr};
   hipLaunchKernelGGL(ln_relu_drop_fwd_kernel<2>, dim3(grid_for(rows * 64)), dim3(256), 0, s, a, a, cube, rows, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
@@ -619,7 +624,7 @@ int ln_relu_drop_bwd(hipStream_t s, const float* h2, const float* gamma, const f
                      int K, int D, int slot, float p, RngKey key, uint32_t stream_id) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  const LnSide a{h2, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), ds, dgamma, dbeta, slot, p, stream_id};
+  const LnSide a{h2, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), ds, dgamma, dbeta, slot, p, stream_id, nullptr};
   hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256)), dim3(256), 0, s, a, a, dcube, rows, T, L,
                      K, key);
   LAUNCH_CHECK();
@@ -630,18 +635,18 @@ int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* 
                       RngKey key) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream};
-  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream};
+  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, nullptr};
+  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, nullptr};
   hipLaunchKernelGGL(ln_relu_drop_fwd_kernel<2>, dim3(grid_for(rows * 64), 2), dim3(256), 0, s, sa, sv, cube, rows, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
 int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
-                      RngKey key) {
+                      RngKey key, const float* dmean_a, const float* dmean_v) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream};
-  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream};
+  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, dmean_a};
+  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v};
   hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T,
                      L, K, key);
   LAUNCH_CHECK();
