@@ -208,6 +208,7 @@ struct mimrl_handle {
   float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool l0_packed = false;              // see mimrl_create
+  bool l0_bwd_pack = false;            // small batches: only the INPUTS are packed (off the chain) and only the weight gradients use them
   BlockBuf bb[MIMRL_MAX_BLOCKS];
   __bf16* wtT[MIMRL_MAX_BLOCKS][3] = {};   // transposed bf16 images of the D-axis weights (fc2, fc1, res) for the fused backward
   // Second set of forward buffers.  In prefetch mode (mimrl_set_stage2_prefetch) stage 1 runs its forward pass and its
@@ -735,6 +736,12 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.btv = gru_pick_btv(B, 2);
     if (l == 1) MX(fork(1, 3));
+    if (l == 0 && !l0_packed && l0_bwd_pack && save) {   // packed copy of the inputs for the layer-0 weight gradients: side 0 has slack
+      L0Pack pk;
+      for (int m = 0; m < 2; ++m) { pk.x[m] = xin[m]; pk.d[m] = dmod[m]; for (int d = 0; d < 2; ++d) { pk.w_ih[m][d] = nullptr; pk.b_ih[m][d] = nullptr; } }
+      pk.xpack = xpack; pk.wpack = wpack; pk.bpack = bpack; pk.rows = BT_; pk.KP = KP();
+      MX(l0_pack(S(0), pk, true, false));
+    }
     if (l == 0 && l0_packed) {
       // all four (modality, direction) projections of layer 0 as ONE batched launch on the packed operands
       L0Pack pk;
@@ -1486,7 +1493,7 @@ int mimrl_handle::model_backward() {
     if (l == 1 && !dh0_last) MX(dh0_gemm());
     // weight gradients of this layer: off the critical path.  Layer 1: side 1..3 (they overlap the layer-0 BPTT);
     // layer 0 is the tail of the stage.
-    if (l == 0 && l0_packed) {
+    if (l == 0 && (l0_packed || l0_bwd_pack)) {
       // layer 0: the W_ih (against the packed inputs) and W_hh gradients of all four (modality, direction) pairs as two batched
       // launches into packed scratch, scattered into the bucket by one small kernel: 3 launches on 2 streams close the stage
       // instead of four GEMMs in a row (the per-modality widths 74 / 35 ruled out both batching and 16-byte loads)
@@ -2323,6 +2330,9 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   // launches are large (cfg3: -2 %); at cfg2 the extra pack / unpack launches and the padded K cost as much as the batching
   // saves (1.34 vs 1.32 ms), so the default follows the row count.  MIMRL_L0_PACK=1 / 0 forces it.
   h->l0_packed = getenv("MIMRL_L0_PACK") ? atoi(getenv("MIMRL_L0_PACK")) != 0 : (long)h->cfg.batch * h->cfg.seq_len >= 16384;
+  // (inputs packed on side 0, only the layer-0 weight gradients batched: measured WORSE than four GEMMs in a row at cfg2 / cfg1,
+  //  1.245 vs 1.231 ms / 0.98 vs 0.94 ms -- the extra stream hop and the unpack launch cost more than the batching saves; off)
+  h->l0_bwd_pack = getenv("MIMRL_L0_BWD_PACK") ? atoi(getenv("MIMRL_L0_BWD_PACK")) != 0 : false;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
   h->prec = cfg->precision;

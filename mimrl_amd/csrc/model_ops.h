@@ -39,7 +39,7 @@ struct L0Pack {
   float* xpack; float* wpack; float* bpack;
   long rows; int KP;
 };
-int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs);
+int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights = true);
 struct L0Unpack {
   float* g_ih[2][2]; float* g_hh[2][2]; int d[2];
   float* dwih_pack; float* dwhh_pack;        // [2][2][384, KP], [2][2][384, 128]: read, added to the gradients, re-zeroed

@@ -530,9 +530,9 @@ inline int grid_for(long n, int block = 256, int cap = 2048) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-__global__ void l0_pack_kernel(L0Pack a, int pack_inputs) {
+__global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
   const int m = blockIdx.y;
-  const long nx = pack_inputs ? a.rows * a.KP : 0, nw = 2L * 384 * a.KP, nb = 2L * 384;
+  const long nx = pack_inputs ? a.rows * a.KP : 0, nw = pack_weights ? 2L * 384 * a.KP : 0, nb = pack_weights ? 2L * 384 : 0;
   const int d = a.d[m];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx + nw + nb; i += (long)gridDim.x * blockDim.x) {
     if (i < nx) {
@@ -570,9 +570,10 @@ __global__ void l0_unpack_kernel(L0Unpack a) {
 
 }  // namespace
 
-int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs) {
-  const long n = (pack_inputs ? a.rows * a.KP : 0) + 2L * 384 * a.KP + 2L * 384;
-  hipLaunchKernelGGL(l0_pack_kernel, dim3(grid_for(n, 256, 1024), 2), dim3(256), 0, s, a, pack_inputs ? 1 : 0);
+int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights) {
+  const long n = (pack_inputs ? a.rows * a.KP : 0) + (pack_weights ? 2L * 384 * a.KP + 2L * 384 : 0);
+  if (n <= 0) return MIMRL_OK;
+  hipLaunchKernelGGL(l0_pack_kernel, dim3(grid_for(n, 256, 1024), 2), dim3(256), 0, s, a, pack_inputs ? 1 : 0, pack_weights ? 1 : 0);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
