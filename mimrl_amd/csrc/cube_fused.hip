@@ -40,11 +40,20 @@ __device__ __forceinline__ int acc_row(int r, int wm, int lane) { return wm * 32
 __device__ __forceinline__ void stage_weight(bf* img, const float* __restrict__ W, int ld, int n0, int k0, int N, int K, int tid) {
   const int n = tid >> 2, kc = (tid & 3) * 16;
   bf16x8 lo, hi;
+  // 16 UNCONDITIONAL loads from clamped addresses, zeroed afterwards: a guarded load is a branch whose join waits for every
+  // outstanding load, i.e. 16 dependent round trips per image (this staging was 10 of the block's 18 us of set-up)
+  const int gn = n0 + n, gnc = gn < N ? gn : N - 1;
+  float v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int gn = n0 + n, gk = k0 + kc + j;
-    const float v = (gn < N && gk < K) ? W[(long)gn * ld + gk] : 0.f;
-    if (j < 8) lo[j] = to_bf16(v); else hi[j - 8] = to_bf16(v);
+    const int gk = k0 + kc + j;
+    v[j] = W[(long)gnc * ld + (gk < K ? gk : K - 1)];
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int gk = k0 + kc + j;
+    const float x = (gn < N && gk < K) ? v[j] : 0.f;
+    if (j < 8) lo[j] = to_bf16(x); else hi[j - 8] = to_bf16(x);
   }
   *reinterpret_cast<bf16x8*>(img + n * ILD + kc) = lo;
   *reinterpret_cast<bf16x8*>(img + n * ILD + kc + 8) = hi;
@@ -244,7 +253,8 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   kmix_stage_weights(a.kw, ksw);
   {
     const float* g = ksw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
-    for (int i = tid; i < ol * D; i += 256) {
+#pragma unroll 2
+    for (int i = tid; i < ol * D; i += 256) {   // (two (l, d) pairs interleaved: one wave per SIMD has nothing else to hide the VALU chains)
       const int l = i >> 7, d = i & 127;
       KMixVals<4> v;
 #pragma unroll
