@@ -138,7 +138,7 @@ def cpu_baseline(opt, N, budget_s=25.0):
 
 def extra_schedules(eng, args, B, T, rank):
     """ms/step of (a) strictly sequential stages and (b) a NEW pinned host batch every step through HipEngine.stage_batch /
-    commit_batch (H2D on a copy stream under the previous step, then four device-to-device copies into the bound buffers)."""
+    commit_batch (H2D into the idle one of two input sets on a copy stream under the previous step; the switch is host-only)."""
     def timed(fn, n):
         for _ in range(3):
             fn()
@@ -166,8 +166,10 @@ def extra_schedules(eng, args, B, T, rank):
         eng.step()
 
     extra["ms_per_step_fresh_batch"] = timed(fresh, n_x)
-    extra["fresh_batch_note"] = (f"every step binds a NEW host batch ({sum(x.numel() * 4 for x in host[0]) / 1e6:.1f} MB, pinned): H2D on a copy "
-                                 "stream under the previous step, then 4 device-to-device copies into the bound buffers")
+    extra["fresh_batch_note"] = (f"every step binds a NEW host batch ({sum(x.numel() * 4 for x in host[0]) / 1e6:.1f} MB, pinned): H2D into the idle "
+                                 "input set on a copy stream under the previous step, host-only switch (graphs cached per set); the "
+                                 "concurrent upload itself costs the step ~0.25 ms (tools/fresh_dbg.py: 1.24 -> 1.51 ms with the copy "
+                                 "running and no switch) -- it competes with the graph's branches for the 4 hardware queues")
     torch.cuda.synchronize()
     return extra
 

@@ -119,6 +119,11 @@ typedef struct mimrl_handle mimrl_handle;
 int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out);
 int mimrl_bind(mimrl_handle* h, const mimrl_buffers* bufs);
 int mimrl_set_bank_rows(mimrl_handle* h, int rows);    /* 0 => epoch-0 rule (Customization.py:97-98,105-106) */
+/* Double-buffered inputs (host-only call, no device work): make input set `set` (0 | 1) = the given (text, audio, video, labels)
+ * device buffers the bound batch.  Captured graphs bake the input addresses in, so they are cached per set: a caller that
+ * alternates between two fixed buffer sets uploads batch i+1 into the idle set while the step on batch i runs, and pays
+ * nothing to switch (the reference's loop does a synchronous .cuda() per batch, Customization.py:47-50).  mimrl_bind sets set 0. */
+int mimrl_set_inputs(mimrl_handle* h, int set, const float* text, const float* audio, const float* video, const float* labels);
 int mimrl_stage1_step(mimrl_handle* h);                /* Solver.py:205-214 : critics update               */
 int mimrl_stage2_step(mimrl_handle* h);                /* Solver.py:221-236 : main-model update            */
 int mimrl_two_stage_step(mimrl_handle* h);             /* the new Solver.step(datas): mimrl_stage1_step then mimrl_stage2_step on the bound batch; in overlap mode with graphs ONE captured graph, one launch */

@@ -236,7 +236,7 @@ struct mimrl_handle {
   bool tail2_needed = false;           // deferred tail still to be issued before stage 2 may run
   bool fwd2_pending = false;           // a prefetched stage-2 forward is waiting to be consumed
   float grad_scale = 1.f;              // folded into the fused clip+Adam (mimrl_set_grad_scale)
-  hipGraphExec_t graph_tail = nullptr; int graph_tail_rows = -1;
+
   int run_fwd2_tail();
   hipStream_t pre_stream = nullptr;
   int carve_fwd(size_t* gmax_out);
@@ -357,8 +357,26 @@ struct mimrl_handle {
   };
 
   // graphs: [stage 1|2][kind: 0 = step (grads+apply), 1 = grads only]
-  hipGraphExec_t graph[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  int graph_rows[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+  // The captured graphs bake the input addresses in, so they are cached PER INPUT SET: the caller may alternate between two
+  // sets of (text, audio, video, labels) buffers (mimrl_set_inputs) -- the next batch is uploaded into the idle set while the
+  // step runs on the active one, and switching costs no device work.
+  struct GraphSet {
+    hipGraphExec_t graph[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    int rows[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+    hipGraphExec_t tail = nullptr; int tail_rows = -1;
+    const void* in[4] = {nullptr, nullptr, nullptr, nullptr};
+  } gsets[2];
+  int cur_set = 0;
+  GraphSet& GS() { return gsets[cur_set]; }
+  void drop_graphs(int set = -1) {
+    for (int q = 0; q < 2; ++q) {
+      if (set >= 0 && q != set) continue;
+      for (int s = 0; s <= 2; ++s)
+        for (int k = 0; k < 2; ++k)
+          if (gsets[q].graph[s][k]) { (void)hipGraphExecDestroy(gsets[q].graph[s][k]); gsets[q].graph[s][k] = nullptr; }
+      if (gsets[q].tail) { (void)hipGraphExecDestroy(gsets[q].tail); gsets[q].tail = nullptr; }
+    }
+  }
 
   // ------------------------------------------------------------------------------------------
   float* P(long off) const { return bufs.main_p + off; }
@@ -2178,8 +2196,8 @@ int mimrl_handle::run(int stage, int kind) {
   }
   if (kind == 1) grads_clean[stage] = false;
   if (!cfg.use_graph || prof_on) return body();
-  hipGraphExec_t& ex = graph[stage][kind];
-  if (ex && graph_rows[stage][kind] != bank_rows) {   // bank size is baked into the kernel arguments
+  hipGraphExec_t& ex = GS().graph[stage][kind];
+  if (ex && GS().rows[stage][kind] != bank_rows) {   // bank size is baked into the kernel arguments
     HIPX(hipGraphExecDestroy(ex));
     ex = nullptr;
   }
@@ -2196,7 +2214,7 @@ int mimrl_handle::run(int stage, int kind) {
     const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
-    graph_rows[stage][kind] = bank_rows;
+    GS().rows[stage][kind] = bank_rows;
   }
   HIPX(hipGraphLaunch(ex, stream));
   return MIMRL_OK;
@@ -2220,8 +2238,8 @@ int mimrl_handle::run_fwd2_tail() {
     return r;
   };
   if (!cfg.use_graph || prof_on) return body();
-  if (graph_tail && graph_tail_rows != bank_rows) { HIPX(hipGraphExecDestroy(graph_tail)); graph_tail = nullptr; }
-  if (!graph_tail) {
+  if (GS().tail && GS().tail_rows != bank_rows) { HIPX(hipGraphExecDestroy(GS().tail)); GS().tail = nullptr; }
+  if (!GS().tail) {
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
@@ -2231,12 +2249,12 @@ int mimrl_handle::run_fwd2_tail() {
     const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
     if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
     if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-    const hipError_t ie = hipGraphInstantiate(&graph_tail, g, nullptr, nullptr, 0);
+    const hipError_t ie = hipGraphInstantiate(&GS().tail, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (ie != hipSuccess) { graph_tail = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
-    graph_tail_rows = bank_rows;
+    if (ie != hipSuccess) { GS().tail = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+    GS().tail_rows = bank_rows;
   }
-  HIPX(hipGraphLaunch(graph_tail, stream));
+  HIPX(hipGraphLaunch(GS().tail, stream));
   return MIMRL_OK;
 }
 
@@ -2254,8 +2272,8 @@ int mimrl_handle::run_step() {
     MX(bf16_transposed_images(user_stream, bufs.crit_p, crit_imgT, ttab));
     imgT_valid = true;
   }
-  hipGraphExec_t& ex = graph[0][0];
-  if (ex && graph_rows[0][0] != bank_rows) {   // bank size is baked into the kernel arguments
+  hipGraphExec_t& ex = GS().graph[0][0];
+  if (ex && GS().rows[0][0] != bank_rows) {   // bank size is baked into the kernel arguments
     HIPX(hipGraphExecDestroy(ex));
     ex = nullptr;
   }
@@ -2281,7 +2299,7 @@ int mimrl_handle::run_step() {
     const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
-    graph_rows[0][0] = bank_rows;
+    GS().rows[0][0] = bank_rows;
   }
   HIPX(hipGraphLaunch(ex, stream));
   fwd2_pending = false;
@@ -2354,12 +2372,28 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
     if (!p) return set_error(MIMRL_ERR_ARG, "mimrl_bind: a required buffer is null");
   h->bufs = *b;
   h->bound = true;
+  h->cur_set = 0;
+  for (int q = 0; q < 2; ++q) for (int i = 0; i < 4; ++i) h->gsets[q].in[i] = nullptr;
+  h->gsets[0].in[0] = b->text; h->gsets[0].in[1] = b->audio; h->gsets[0].in[2] = b->video; h->gsets[0].in[3] = b->labels;
   h->img_valid = false;
   h->imgT_valid = false;
   h->d_ints = b->counters ? b->counters : h->d_ints_own;   // graphs are rebuilt below, so the new address is baked in
-  for (int s = 0; s <= 2; ++s)
-    for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  h->drop_graphs();
+  return MIMRL_OK;
+}
+
+int mimrl_set_inputs(mimrl_handle* h, int set, const float* text, const float* audio, const float* video, const float* labels) {
+  if (!h || set < 0 || set > 1 || !text || !audio || !video || !labels) return set_error(MIMRL_ERR_ARG, "mimrl_set_inputs: bad argument");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  const void* p[4] = {text, audio, video, labels};
+  mimrl_handle::GraphSet& g = h->gsets[set];
+  if (g.in[0] && (g.in[0] != p[0] || g.in[1] != p[1] || g.in[2] != p[2] || g.in[3] != p[3])) {
+    HIPX(hipStreamSynchronize(h->user_stream));
+    h->drop_graphs(set);                      // this set's graphs were captured with other addresses
+  }
+  for (int i = 0; i < 4; ++i) g.in[i] = p[i];
+  h->cur_set = set;
+  h->bufs.text = text; h->bufs.audio = audio; h->bufs.video = video; h->bufs.labels = labels;
   return MIMRL_OK;
 }
 
@@ -2478,9 +2512,7 @@ int mimrl_set_knn_override_mask(mimrl_handle* h, int stage, unsigned call_mask) 
   if (call_mask && !h->bufs.knn_override) return set_error(MIMRL_ERR_STATE, "mimrl_buffers.knn_override is not bound");
   if (h->knn_ovr_mask[stage - 1] == (call_mask & 63u)) return MIMRL_OK;
   HIPX(hipStreamSynchronize(h->user_stream));
-  for (int s = 0; s <= 2; ++s)            // which calls the kNN kernel skips is baked into the captured launches
-    for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  h->drop_graphs();
   h->knn_ovr_mask[stage - 1] = call_mask & 63u;
   return MIMRL_OK;
 }
@@ -2491,9 +2523,7 @@ int mimrl_set_grad_scale(mimrl_handle* h, float scale) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (scale == h->grad_scale) return MIMRL_OK;
   HIPX(hipStreamSynchronize(h->user_stream));
-  for (int s = 0; s <= 2; ++s)            // the scale is a kernel argument of the captured Adam launches
-    for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
+  h->drop_graphs();
   h->grad_scale = scale;
   return MIMRL_OK;
 }
@@ -2503,10 +2533,7 @@ int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
   if ((on != 0) == h->prefetch && (on == 2) == h->defer_tail) return MIMRL_OK;
   if (on && !h->pre_stream) HIPX(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
   HIPX(hipStreamSynchronize(h->user_stream));
-  for (int s = 0; s <= 2; ++s)
-    for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) { (void)hipGraphExecDestroy(h->graph[s][k]); h->graph[s][k] = nullptr; }
-  if (h->graph_tail) { (void)hipGraphExecDestroy(h->graph_tail); h->graph_tail = nullptr; }
+  h->drop_graphs();
   h->prefetch = on != 0;
   h->defer_tail = on == 2;
   h->fwd2_pending = false;
@@ -2518,9 +2545,7 @@ int64_t mimrl_workspace_bytes(const mimrl_handle* h) { return h ? (int64_t)h->ws
 
 void mimrl_destroy(mimrl_handle* h) {
   if (!h) return;
-  for (int s = 0; s <= 2; ++s)
-    for (int k = 0; k < 2; ++k)
-      if (h->graph[s][k]) (void)hipGraphExecDestroy(h->graph[s][k]);
+  h->drop_graphs();
   for (int p = 0; p < MIMRL_NPHASES; ++p)
     for (auto& ev : h->prof_ev[p]) h->prof_pool.push_back(ev);
   for (auto& g : h->prof_gemm) h->prof_pool.push_back({g.a, g.b});
@@ -2528,7 +2553,6 @@ void mimrl_destroy(mimrl_handle* h) {
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-  if (h->graph_tail) (void)hipGraphExecDestroy(h->graph_tail);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
   if (h->ws) (void)hipFree(h->ws);

@@ -245,28 +245,37 @@ class HipEngine:
         check(self.lib.mimrl_profile_read_gemm(self.handle, out))
         return {"flops": out[0], "bytes": out[1], "ms": out[2], "launches": int(out[3])}
 
-    # ------------------------------------------------------------------ overlapped batch upload
+    # ------------------------------------------------------------------ overlapped batch upload (double-buffered inputs)
     def stage_batch(self, text, audio, video, labels):
-        """Start the host->device copy of the NEXT batch on a copy stream (it overlaps the step that is running on the
-        current batch).  Sources in pinned memory make the copy truly asynchronous."""
-        if not hasattr(self, "_stg"):
-            self._stg = [torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels)]
+        """Start the host->device copy of the NEXT batch into the IDLE input set on a copy stream (it overlaps the step that
+        is running on the active set).  Sources in pinned memory make the copy truly asynchronous."""
+        if not hasattr(self, "_sets"):
+            self._sets = [(self.text, self.audio, self.video, self.labels),
+                          tuple(torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels))]
+            self._active = 0
             self._copy_stream = torch.cuda.Stream(self.device)
-            self._staged_ev, self._commit_ev = torch.cuda.Event(), torch.cuda.Event()
-            self._commit_ev.record(self.stream)
+            self._staged_ev = torch.cuda.Event()
+            self._free_ev = [torch.cuda.Event(), torch.cuda.Event()]   # set q is no longer read by the device after this point
+            for ev in self._free_ev:
+                ev.record(self.stream)
+        idle = 1 - self._active
         with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(self._commit_ev)          # the previous commit still reads the staging set
-            for dst, src in zip(self._stg, (text, audio, video, labels)):
+            self._copy_stream.wait_event(self._free_ev[idle])          # steps that read the idle set have finished
+            for dst, src in zip(self._sets[idle], (text, audio, video, labels)):
                 dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
             self._staged_ev.record(self._copy_stream)
 
     def commit_batch(self):
-        """Make the staged batch the bound one: four device-to-device copies on the engine's stream (the bound input
-        addresses are baked into the captured graphs, so the data moves, not the pointers)."""
+        """Make the staged batch the bound one: switch the engine to the other input set (mimrl_set_inputs: host-only, the
+        graphs are cached per set) -- no device copy."""
+        old = self._active
+        new = 1 - old
+        self._free_ev[old].record(self.stream)                         # everything enqueued so far may still read the old set
         self.stream.wait_event(self._staged_ev)
-        for dst, src in zip((self.text, self.audio, self.video, self.labels), self._stg):
-            dst.copy_(src, non_blocking=True)
-        self._commit_ev.record(self.stream)
+        t, a, v, y = self._sets[new]
+        check(self.lib.mimrl_set_inputs(self.handle, new, _ptr(t), _ptr(a), _ptr(v), _ptr(y)))
+        self.text, self.audio, self.video, self.labels = t, a, v, y
+        self._active = new
 
     def read_scalars(self) -> np.ndarray:
         """One device->host read-back (the reference does >= 10 ``.item()`` syncs per iteration)."""
