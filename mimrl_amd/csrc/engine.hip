@@ -207,6 +207,7 @@ struct mimrl_handle {
   // layer-0 GRU operands in a common aligned shape (model_ops.h: L0Pack): one batched input projection, two batched weight gradients
   float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
+  bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
   bool l0_packed = false;              // see mimrl_create
   bool l0_bwd_pack = false;            // small batches: only the INPUTS are packed (off the chain) and only the weight gradients use them
   BlockBuf bb[MIMRL_MAX_BLOCKS];
@@ -327,9 +328,10 @@ struct mimrl_handle {
       return s_b != 0 ? d.batch : 1;
     };
     g.flops = 2.0 * d.M * d.N * ((double)d.K + (d.A2 ? d.K2 : 0)) * d.batch;
-    g.bytes = 4.0 * ((double)d.M * d.K * distinct(d.sa_b, d.sa_bo) + (double)d.K * d.N * distinct(d.sb_b, d.sb_bo) +
-                     (double)d.M * d.N * distinct(d.sc_b, d.sc_bo) * ((d.beta != 0.f || d.atomic) ? 2 : 1));
-    if (d.A2) g.bytes += 4.0 * ((double)d.M * d.K2 * (d.sa2_b ? d.batch : 1) + (double)d.K2 * d.N * (d.sb2_b ? d.batch : 1));
+    const double ea = d.a_bf16 ? 2.0 : 4.0, eb = d.b_bf16 ? 2.0 : 4.0;
+    g.bytes = ea * d.M * d.K * distinct(d.sa_b, d.sa_bo) + eb * d.K * d.N * distinct(d.sb_b, d.sb_bo) +
+              4.0 * d.M * d.N * distinct(d.sc_b, d.sc_bo) * ((d.beta != 0.f || d.atomic) ? 2 : 1);
+    if (d.A2) g.bytes += ea * d.M * d.K2 * (d.sa2_b ? d.batch : 1) + eb * d.K2 * d.N * (d.sb2_b ? d.batch : 1);
     HIPX(hipEventRecord(g.a, st));
     const int r = gemm(st, d, bf16);
     HIPX(hipEventRecord(g.b, st));
@@ -1481,6 +1483,10 @@ int mimrl_handle::model_backward() {
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.dout_ld = l == 1 ? H : 2 * H; a.dout_off = l == 1 ? 0 : H;
     a.btv = gru_pick_btv(B, 2);
+    // layer 0 without packed inputs keeps fp32 dg: its dW_ih product reads the caller's unaligned [rows, 74 / 35] inputs through
+    // the generic kernel, which has no bf16-operand variant
+    const bool lbf = dg_bf16 && (l == 1 || l0_packed || l0_bwd_pack);
+    a.dg_bf16 = lbf ? 1 : 0;
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       for (int d = 0; d < 2; ++d) {
@@ -1504,6 +1510,7 @@ int mimrl_handle::model_backward() {
         q.sa_b = dg[l][1][0] - dg[l][0][0]; q.sa2_b = dg[l][1][1] - dg[l][0][1];
         q.sb_b = gru[1][l][0].w_ih - gru[0][l][0].w_ih; q.sb2_b = gru[1][l][1].w_ih - gru[0][l][1].w_ih;
         q.sc_b = dh0[1] - dh0[0];
+        if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa2_b *= 2; }   // buffer distances are fp32-element counts; bf16 elements: x2
         MX(G_(q));
       }
       return MIMRL_OK;
@@ -1519,10 +1526,12 @@ int mimrl_handle::model_backward() {
       const long s_hp = hprev[0][0][1] - hprev[0][0][0], o_hp = hprev[0][1][0] - hprev[0][0][0];
       { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, xpack, KP(), dwih_pack, KP(), G, KP(), (int)BT_);
         q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = 0; q.sb_bo = BT_ * KP(); q.sc_b = (long)G * KP(); q.sc_bo = 2L * G * KP();
+        if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; }
         q.atomic = 1; MX(G_on(stream, q)); }
       { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, hprev[0][0][0], H, dwhh_pack, H, G, H, (int)BT_);
         q.a_gap_at = 2 * H; q.a_gap_rows = H;
         q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = s_hp; q.sb_bo = o_hp; q.sc_b = (long)G * H; q.sc_bo = 2L * G * H;
+        if (lbf) { q.a_bf16 = q.b_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; q.sb_b *= 2; q.sb_bo *= 2; }
         q.atomic = 1; MX(G_on(S(1), q)); }
       MX(join(1, 1));
       L0Unpack up;
@@ -1550,10 +1559,14 @@ int mimrl_handle::model_backward() {
       static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
       auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
-        q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih); MX(G_on(pick(), q)); }
+        q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih);
+        if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; }
+        MX(G_on(pick(), q)); }
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, hprev[l][m][0], H, Gm(gf.w_hh), H, G, H, (int)BT_);   // dgh = dg columns [0,2H) u [3H,4H)
         q.a_gap_at = 2 * H; q.a_gap_rows = H;
-        q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh); MX(G_on(pick(), q)); }
+        q.batch = 2; q.sa_b = s_dg; q.sb_b = s_hp; q.sc_b = gr.w_hh - gf.w_hh; q.atomic = 1; two(q, o_dg, o_hp, o_whh);
+        if (lbf) { q.a_bf16 = q.b_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; q.sb_b *= 2; q.sb_bo *= 2; }
+        MX(G_on(pick(), q)); }
     }
     if (l == 1 && dh0_last) MX(dh0_gemm());
   }
@@ -2350,6 +2363,10 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->l0_packed = getenv("MIMRL_L0_PACK") ? atoi(getenv("MIMRL_L0_PACK")) != 0 : (long)h->cfg.batch * h->cfg.seq_len >= 16384;
   // (inputs packed on side 0, only the layer-0 weight gradients batched: measured WORSE than four GEMMs in a row at cfg2 / cfg1,
   //  1.245 vs 1.231 ms / 0.98 vs 0.94 ms -- the extra stream hop and the unpack launch cost more than the batching saves; off)
+  // dg[B,T,4H] / h_prev are consumed only by GEMMs that round their operands to bf16 anyway: storing them as bf16 changes no
+  // number in this mode and halves what the BPTT writes and the weight-gradient / dh0 products read
+  h->dg_bf16 = cfg->encoder == MIMRL_ENCODER_GRU && (cfg->precision & MIMRL_PREC_BF16_GRU_BWD) && (cfg->precision & MIMRL_PREC_BF16_GEMM_BWD) &&
+               getenv("MIMRL_DG_FP32") == nullptr;
   h->l0_bwd_pack = getenv("MIMRL_L0_BWD_PACK") ? atoi(getenv("MIMRL_L0_BWD_PACK")) != 0 : false;
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }

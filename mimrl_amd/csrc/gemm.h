@@ -34,6 +34,9 @@ struct GemmDesc {
   // optional SECOND product accumulated into the same output tile:  C = epi( A.B + A2.B2 )   (e.g. W2.H + Wr.X)
   const float* A2 = nullptr; const float* B2 = nullptr; int K2 = 0;
   long sa2_m = 0, sa2_k = 0, sa2_b = 0, sb2_k = 0, sb2_n = 0, sb2_b = 0;
+  // operand storage: A (and A2) / B (and B2) are bf16 arrays behind the float-typed pointers (strides in bf16 elements).  Fast
+  // path only (16-byte pieces go straight to LDS, no conversion): everything must be 8-element aligned, else gemm() fails.
+  int a_bf16 = 0, b_bf16 = 0;
 };
 
 // A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T

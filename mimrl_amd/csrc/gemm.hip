@@ -373,10 +373,39 @@ __device__ __forceinline__ bf16x4 cvt4(const float4& q) {
 
 // every load is unconditional from a clamped (valid) address and zeroed afterwards: a guarded load is a branch whose
 // join waits for ALL outstanding loads
-template <int T, bool KC>
+// bf16-stored operand (BF): 16 bytes = 8 elements, half as many pieces per thread, no conversion
+template <int T, bool KC, bool BF>
 __device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, int r0, int R, int gap_at, int gap, int K, int k0,
                                           int tid, float4* v) {
-  if constexpr (KC) {
+  if constexpr (BF) {
+    const __bf16* __restrict__ Pb = reinterpret_cast<const __bf16*>(P);
+    if constexpr (KC) {
+#pragma unroll
+      for (int h = 0; h < T; ++h) {
+        const int idx = h * 256 + tid, row = idx >> 2, gk = k0 + (idx & 3) * 8;
+        int gr = r0 + row < R ? r0 + row : R - 1;
+        if (gr >= gap_at) gr += gap;
+        const int gkc = gk < K ? gk : K - 8;               // K % 8 == 0
+        float4 q = *reinterpret_cast<const float4*>(Pb + (long)gr * s + gkc);
+        if (gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[h] = q;
+      }
+    } else {
+      const int rq = tid & (8 * T - 1), kq = tid / (8 * T);   // T=2: 16 row-octets x 16 k-pairs; T=1: 8 x 32 k
+      int gr = r0 + rq * 8;
+      const bool rin = gr < R;                              // R % 8 == 0
+      if (!rin) gr = R - 8;
+      if (gr >= gap_at) gr += gap;
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const int gk = k0 + kq * T + j;
+        const int gkc = gk < K ? gk : K - 1;
+        float4 q = *reinterpret_cast<const float4*>(Pb + gr + (long)gkc * s);
+        if (!rin || gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = q;
+      }
+    }
+  } else if constexpr (KC) {
 #pragma unroll
     for (int h = 0; h < FT<T>::NV; ++h) {
       const int idx = h * 256 + tid, row = idx >> 3, gk = k0 + (idx & 7) * 4;
@@ -405,9 +434,21 @@ __device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, i
   }
 }
 
-template <int T, bool KC>
+template <int T, bool KC, bool BF>
 __device__ __forceinline__ void fast_store(const float4* v, __bf16* __restrict__ img, int tid) {
-  if constexpr (KC) {
+  if constexpr (BF) {
+    if constexpr (KC) {
+#pragma unroll
+      for (int h = 0; h < T; ++h) {
+        const int idx = h * 256 + tid;
+        *reinterpret_cast<float4*>(img + (idx >> 2) * FT<T>::KCP + (idx & 3) * 8) = v[h];
+      }
+    } else {
+      const int rq = tid & (8 * T - 1), kq = tid / (8 * T);
+#pragma unroll
+      for (int j = 0; j < T; ++j) *reinterpret_cast<float4*>(img + (kq * T + j) * FT<T>::RCP + rq * 8) = v[j];
+    }
+  } else if constexpr (KC) {
 #pragma unroll
     for (int h = 0; h < FT<T>::NV; ++h) {
       const int idx = h * 256 + tid;
@@ -438,7 +479,7 @@ __device__ __forceinline__ bf16x8 fast_frag(const __bf16* __restrict__ img, int 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool GEN>
+template <int TM, int TN, bool AKC, bool BKC, bool GEN, bool ABF = false, bool BBF = false>
 __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_per, int dbg, unsigned bx, unsigned by, unsigned bzr) {
   constexpr int BMf = 64 * TM, BNf = 64 * TN;
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][FT<TM>::ELEMS];
@@ -470,17 +511,17 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
   auto segment = [&](const float* __restrict__ Ap, long sa, const float* __restrict__ Bp, long sb, int K, int kt0, int kt1, int ga_at, int ga) {
     float4 ra[FT<TM>::NV], rb[FT<TN>::NV];
     if (kt0 >= kt1) return;
-    fast_load<TM, AKC>(Ap, sa, m0, d.M, ga_at, ga, K, kt0 * FBK, tid, ra);
-    fast_load<TN, BKC>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, kt0 * FBK, tid, rb);
-    fast_store<TM, AKC>(ra, sA[0], tid);
-    fast_store<TN, BKC>(rb, sB[0], tid);
+    fast_load<TM, AKC, ABF>(Ap, sa, m0, d.M, ga_at, ga, K, kt0 * FBK, tid, ra);
+    fast_load<TN, BKC, BBF>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, kt0 * FBK, tid, rb);
+    fast_store<TM, AKC, ABF>(ra, sA[0], tid);
+    fast_store<TN, BKC, BBF>(rb, sB[0], tid);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
       const bool more = kt + 1 < kt1;
       if (more) {
-        fast_load<TM, AKC>(Ap, sa, m0, d.M, ga_at, ga, K, (kt + 1) * FBK, tid, ra);
-        fast_load<TN, BKC>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, (kt + 1) * FBK, tid, rb);
+        fast_load<TM, AKC, ABF>(Ap, sa, m0, d.M, ga_at, ga, K, (kt + 1) * FBK, tid, ra);
+        fast_load<TN, BKC, BBF>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, (kt + 1) * FBK, tid, rb);
       }
 #pragma unroll
       for (int s = 0; s < FBK / 16; ++s) {
@@ -495,8 +536,8 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
       }
       if (more) {
-        fast_store<TM, AKC>(ra, sA[cur ^ 1], tid);
-        fast_store<TN, BKC>(rb, sB[cur ^ 1], tid);
+        fast_store<TM, AKC, ABF>(ra, sA[cur ^ 1], tid);
+        fast_store<TN, BKC, BBF>(rb, sB[cur ^ 1], tid);
       }
       __syncthreads();
     }
@@ -505,11 +546,17 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
     const int ktiles = (d.K + FBK - 1) / FBK;
     const int kt0 = ks * kt_per;
     const int kt1 = dbg == 2 ? kt0 : (kt0 + kt_per < ktiles ? kt0 + kt_per : ktiles);
-    segment(d.A + oa, AKC ? d.sa_m : d.sa_k, d.B + ob, BKC ? d.sb_n : d.sb_k, d.K, kt0, kt1, d.a_gap_rows ? d.a_gap_at : 0x7fffffff, d.a_gap_rows);
+    // (element offsets: a bf16 operand's base is advanced in bf16 elements)
+    const float* Ab = ABF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(d.A) + oa) : d.A + oa;
+    const float* Bb = BBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(d.B) + ob) : d.B + ob;
+    segment(Ab, AKC ? d.sa_m : d.sa_k, Bb, BKC ? d.sb_n : d.sb_k, d.K, kt0, kt1, d.a_gap_rows ? d.a_gap_at : 0x7fffffff, d.a_gap_rows);
   }
-  if (d.A2)
-    segment(d.A2 + (long)bz * d.sa2_b, AKC ? d.sa2_m : d.sa2_k, d.B2 + (long)bz * d.sb2_b, BKC ? d.sb2_n : d.sb2_k, d.K2, 0,
-            (d.K2 + FBK - 1) / FBK, 0x7fffffff, 0);
+  if (d.A2) {
+    const long oa2 = (long)bz * d.sa2_b, ob2 = (long)bz * d.sb2_b;
+    const float* Ab = ABF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(d.A2) + oa2) : d.A2 + oa2;
+    const float* Bb = BBF ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(d.B2) + ob2) : d.B2 + ob2;
+    segment(Ab, AKC ? d.sa2_m : d.sa2_k, Bb, BKC ? d.sb2_n : d.sb2_k, d.K2, 0, (d.K2 + FBK - 1) / FBK, 0x7fffffff, 0);
+  }
   if (dbg == 1) { if (acc[0][0][0] == 123.456f) d.C[0] = 1.f; return; }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -523,6 +570,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
   unsigned bx, by, bzr;
   tile_ids(ka.xcd_remap, bx, by, bzr);
   fast_body<TM, TN, AKC, BKC, GEN>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
+}
+// bf16-stored operands (plain epilogue): A bf16 with B fp32 (data gradient dh0, dW_ih against fp32 inputs) or both bf16 (dW_hh)
+template <int TM, int TN, bool AKC, bool BKC, bool BBF>
+__global__ __launch_bounds__(256) void gemm_fast_bf_kernel(KernelArgs ka) {
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
+  fast_body<TM, TN, AKC, BKC, false, true, BBF>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
 }
 
 // GROUPED launch: up to GEMM_GROUP_MAX independent plain GEMMs of one layout class (64x64 tiles, no split-K) in ONE launch --
@@ -546,10 +600,11 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
 }
 
 // layout class of one operand for the fast path: 1 = KC, 2 = RC, 0 = not eligible.  (row axis = m for A, n for B)
-inline int fast_class(const float* P, long s_r, long s_k, long s_b, long s_bo, int R, int K) {
-  if (!aligned16(P) || s_b % 4 != 0 || s_bo % 4 != 0) return 0;
-  if (s_k == 1 && s_r % 4 == 0 && K % 4 == 0 && K >= 4 && s_r != 1) return 1;
-  if (s_r == 1 && s_k % 4 == 0 && R % 4 == 0 && R >= 4) return 2;
+inline int fast_class(const float* P, long s_r, long s_k, long s_b, long s_bo, int R, int K, int bf = 0) {
+  const int q = bf ? 8 : 4;   // elements per 16-byte piece
+  if (!aligned16(P) || s_b % q != 0 || s_bo % q != 0) return 0;
+  if (s_k == 1 && s_r % q == 0 && K % q == 0 && K >= q && s_r != 1) return 1;
+  if (s_r == 1 && s_k % q == 0 && R % q == 0 && R >= q) return 2;
   return 0;
 }
 
@@ -571,10 +626,14 @@ static bool plain_accumulate(const GemmDesc& d) {
 static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   static const int no_fast = getenv("MIMRL_GEMM_NO_FAST") != nullptr;   // tuning knob
   if (!bf16 || no_fast) return false;
-  const int ca = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K), cb = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K);
+  const int ca = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16), cb = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K, d.b_bf16);
   if (!ca || !cb || (ca == 2 && cb == 1)) return false;
-  if (d.A2 && (fast_class(d.A2, d.sa2_m, d.sa2_k, d.sa2_b, 0, d.M, d.K2) != ca || fast_class(d.B2, d.sb2_n, d.sb2_k, d.sb2_b, 0, d.N, d.K2) != cb))
+  if (d.A2 && (fast_class(d.A2, d.sa2_m, d.sa2_k, d.sa2_b, 0, d.M, d.K2, d.a_bf16) != ca || fast_class(d.B2, d.sb2_n, d.sb2_k, d.sb2_b, 0, d.N, d.K2, d.b_bf16) != cb))
     return false;
+  if (d.a_bf16 || d.b_bf16) {   // instantiated: A bf16 (+ B bf16), plain epilogue, layouts (KC,RC) and (RC,RC); gaps in 8-row units
+    if (!d.a_bf16 || (ca == 1 && cb == 1) || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u) return false;
+    if (d.a_gap_rows && (d.a_gap_at % 8 != 0 || d.a_gap_rows % 8 != 0)) return false;
+  }
   const int ktiles = (d.K + FBK - 1) / FBK;
   const bool acc = plain_accumulate(d) && ktiles >= 32;
   auto tiles = [&](int tm, int tn) { return (long)((d.M + 64 * tm - 1) / (64 * tm)) * ((d.N + 64 * tn - 1) / (64 * tn)) * d.batch; };
@@ -640,7 +699,7 @@ int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
     const int a = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K), b = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K);
     if (!a || !b || (a == 2 && b == 1) || (i > 0 && (a != ca || b != cb))) { ok = false; break; }
     ca = a; cb = b;
-    if (d.A2 || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.a_gap_rows) { ok = false; break; }   // plain epilogue, single product
+    if (d.A2 || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.a_gap_rows || d.a_bf16 || d.b_bf16) { ok = false; break; }   // plain epilogue, single product, fp32 storage
     total += (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
   }
   if (!ok || total > 65535L * 16) {
@@ -690,8 +749,16 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   dim3 grid((d.N + bn - 1) / bn, (d.M + bm - 1) / bm, d.batch * pl.nsplit);
   if (grid.y > 65535 || grid.z > 65535) return set_error(MIMRL_ERR_ARG, "gemm: grid too large (M=%d batch=%d)", d.M, d.batch);
   const bool gen = d.bias_m || d.beta != 0.f || d.pre || d.gradact_u;
+  if ((d.a_bf16 || d.b_bf16) && !pl.fast)
+    return set_error(MIMRL_ERR_ARG, "gemm: bf16-stored operands need the fast path (bf16 mode, 8-element alignment, A bf16, layouts KC/RC or RC/RC, plain epilogue)");
 #define FASTK(TM_, TN_, A_, B_)                                                                               \
   if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);         \
+  else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \
+  break
+#define FASTB(TM_, TN_, A_, B_)                                                                               \
+  if (d.a_bf16 && d.b_bf16) hipLaunchKernelGGL((gemm_fast_bf_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);   \
+  else if (d.a_bf16) hipLaunchKernelGGL((gemm_fast_bf_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);         \
+  else if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);    \
   else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \
   break
 #define GENK(BF_, BK_, LEAN_)                                                                                 \
@@ -700,19 +767,20 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   break
   switch (pl.variant) {
     case 10: FASTK(2, 2, true, true);
-    case 11: FASTK(2, 2, true, false);
-    case 12: FASTK(2, 2, false, false);
+    case 11: FASTB(2, 2, true, false);
+    case 12: FASTB(2, 2, false, false);
     case 14: FASTK(2, 1, true, true);
-    case 15: FASTK(2, 1, true, false);
-    case 16: FASTK(2, 1, false, false);
+    case 15: FASTB(2, 1, true, false);
+    case 16: FASTB(2, 1, false, false);
     case 18: FASTK(1, 1, true, true);
-    case 19: FASTK(1, 1, true, false);
-    case 20: FASTK(1, 1, false, false);
+    case 19: FASTB(1, 1, true, false);
+    case 20: FASTB(1, 1, false, false);
     case 0: GENK(false, 32, false);
     case 3: GENK(true, 128, true);
     case 2: GENK(true, 64, true);
     default: GENK(true, 32, false);
   }
+#undef FASTB
 #undef GENK
 #undef FASTK
   LAUNCH_CHECK();

@@ -35,6 +35,7 @@ struct GruBwdArgs {
   const int* lens[2];
   int B, T, out_ld, dout_ld, dout_off, nmod;
   int btv;             // must equal the forward launch's value (addresses the saved-gate slab)
+  int dg_bf16 = 0;     // dg / hprev are written as bf16 (same element indices): their only consumers are bf16-operand GEMMs
 };
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);

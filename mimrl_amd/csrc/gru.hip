@@ -108,6 +108,13 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 __device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+// BPTT outputs as packed bf16 pairs (DGBF): `p` is the fp32-typed base of a bf16 array, `i` the element index
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+template <bool DGBF>
+__device__ __forceinline__ void st2o(float* p, long i, float a, float b) {
+  if constexpr (DGBF) { bf16x2 v; v[0] = to_bf16(a); v[1] = to_bf16(b); *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(p) + i) = v; }
+  else *reinterpret_cast<float2*>(p + i) = make_float2(a, b);
+}
 
 // saved-gate slab, "lane-native": one record {r0 r1 z0 z1 n0 n1 hn0 hn1} per (t, tile, wave, lane); bf16 mode packs it
 // into ONE 16-byte vector (a wave instruction stores 1 KiB contiguous), fp32 mode into two.
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
 //   carry  = dh z + dgh[t] . W_hh                            ([4,384].[384,128] on the matrix cores)
 // dW_ih, dW_hh, biases and the gradient to the layer input are plain GEMMs over the stored dgx/dgh (engine).
 // ------------------------------------------------------------------------------------------------
-template <bool BF16>
+template <bool BF16, bool DGBF>
 __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   using C = Cfg<BF16>;
   __shared__ __attribute__((aligned(16))) Tile<BF16, G> ds[2];
@@ -318,8 +325,7 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
   const long bb = b;
   const float* out_b = q.out + bb * T * a.out_ld + dir * H + u0;        // forward outputs of THIS direction (h_prev source)
   const float* dout_b = q.dout + bb * T * a.dout_ld + a.dout_off * dir + u0;
-  float* dg_b = q.dg + bb * (long)T * 4 * H + u0;
-  float* hp_b = q.hprev + bb * (long)T * H + u0;
+  const long dg_o = bb * (long)T * 4 * H + u0, hp_o = bb * (long)T * H + u0;   // element offsets (fp32 or bf16 elements: DGBF)
   const float* sv_b = q.saved + sv_index<BF16>(0, ntile, tile, w, lane);
   const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
 
@@ -373,12 +379,12 @@ __global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
     put2(ds[cur], kq, 2 * H + u0, dnr[0], dnr[1]);
 #pragma unroll
     for (int e = 0; e < 2; ++e) { sb[0][e] += drp[e]; sb[1][e] += dzp[e]; sb[2][e] += dnp[e]; sb[3][e] += dnr[e]; }
-    st2(hp_b + (long)t * H, hp[0], hp[1]);
-    float* dgt = dg_b + (long)t * 4 * H;
-    st2(dgt + 0 * H, drp[0], drp[1]);
-    st2(dgt + 1 * H, dzp[0], dzp[1]);
-    st2(dgt + 2 * H, dnp[0], dnp[1]);
-    st2(dgt + 3 * H, dnr[0], dnr[1]);
+    st2o<DGBF>(q.hprev, hp_o + (long)t * H, hp[0], hp[1]);
+    const long dgt = dg_o + (long)t * 4 * H;
+    st2o<DGBF>(q.dg, dgt + 0 * H, drp[0], drp[1]);
+    st2o<DGBF>(q.dg, dgt + 1 * H, dzp[0], dzp[1]);
+    st2o<DGBF>(q.dg, dgt + 2 * H, dnp[0], dnp[1]);
+    st2o<DGBF>(q.dg, dgt + 3 * H, dnr[0], dnr[1]);
     lds_barrier();
     fetch(nx, step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
     asm volatile("" ::: "memory");
@@ -457,8 +463,10 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_backward: empty batch");
   if (a.btv < 1 || a.btv > BR) return set_error(MIMRL_ERR_ARG, "gru_backward: btv must be in [1,4]");
   dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
-  if (bf16) hipLaunchKernelGGL(gru_bwd_kernel<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gru_bwd_kernel<false>, grid, dim3(256), 0, s, a);
+  if (a.dg_bf16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_backward: bf16 dg / h_prev storage needs the bf16 recurrence mode");
+  if (bf16 && a.dg_bf16) hipLaunchKernelGGL((gru_bwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+  else if (bf16) hipLaunchKernelGGL((gru_bwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gru_bwd_kernel<false, false>), grid, dim3(256), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

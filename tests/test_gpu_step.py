@@ -524,3 +524,28 @@ def test_bench_mode_trains_like_fp32():
     # (one fp32 pair is a noisy estimate of the floor: the bands are the fp32-vs-fp32 gaps seen over several boxes)
     band = np.array([0.25, 0.6, 0.3, 0.15, 0.15, 0.6, 2.5, 2.5, 2.5, 2.5])    # task, s1 loss, f_t f_a f_v inv | spec_t spec_a spec_v comp
     assert np.all(gap <= 3 * floor + band), f"bench-vs-fp32 gaps {np.round(gap, 3).tolist()} vs fp32-vs-fp32 floor {np.round(floor, 3).tolist()}"
+
+
+def test_bf16_stored_bptt_outputs_change_nothing(monkeypatch):
+    """bf16 mode stores the BPTT outputs dg[B,T,4H] / h_prev of GRU layer 1 as bf16: their only consumers (dh0, dW_ih, dW_hh
+    products) round their operands to bf16 anyway, so the gradients must equal the fp32-stored run up to the summation-order
+    noise of the split-K atomics (MIMRL_DG_FP32=1 = the fp32-stored run)."""
+    res = {}
+    for tag, env in (("bf16", None), ("fp32", "1")):
+        if env:
+            monkeypatch.setenv("MIMRL_DG_FP32", env)
+        else:
+            monkeypatch.delenv("MIMRL_DG_FP32", raising=False)
+        c, opt, batch, banks, p, eng = make_engine("cfg1_sep", precision="bf16")
+        g = load_golden("cfg1_sep")
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.stage_grads(2)
+        torch.cuda.synchronize()
+        res[tag] = {n: eng.grads[n].double().cpu().numpy().copy() for n in eng.grads if n.startswith("rnn_")}
+        eng.close()
+    assert len(res["bf16"]) == 32
+    for n, ga in res["bf16"].items():
+        gb = res["fp32"][n]
+        scale = np.abs(gb).max() + 1e-30
+        assert np.abs(ga - gb).max() <= 2e-5 * scale, f"{n}: rel diff {np.abs(ga - gb).max() / scale:.2e}"
