@@ -1708,6 +1708,9 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
       g.B = a_in; g.sb_k = din_; g.sb_n = 1; g.sb_b = (long)brows * din_;
       g.C = CG(p0 + l_off[l][0]); g.sc_m = din_; g.sc_n = 1; g.sc_b = pstride;
       g.M = dout_; g.N = din_; g.K = rows; g.batch = nb;
+      // thousands of rows (concat critic: B*B per estimator): accumulate into the zeroed bucket with atomics so that the GEMM may
+      // split K -- as plain stores the 5 x 16 output tiles ran 2048 k-tiles each on 80 CUs (1.6 ms per layer at cfg3)
+      if (rows >= 2048) g.atomic = 1;
       MX(G_(g));
     }
     float* target = l > 0 ? dtmp[pp] : din;

@@ -38,3 +38,5 @@ run("concat tail: NT 65536x256x256 x5", 65536, 256, 256, 5, (256,1,65536*256, 1,
 run("concat dgrad: NN 65536x256x256 x5", 65536, 256, 256, 5, (256,1,65536*256, 256,1,256*256, 256,1,65536*256), (5,65536,256), (5,256,256), (5,65536,256), iters=10)
 run("concat wgrad: TN 256x256x65536 x5", 256, 256, 65536, 5, (1,256,65536*256, 256,1,65536*256, 256,1,256*256), (5,65536,256), (5,65536,256), (5,256,256), act=256, iters=10)
 run("cfg3 L-mix: W[50,500].X_b[500,384] x256", 50, 384, 500, 256, (500,1,0, 384,1,500*384, 384,1,50*384), (50,500), (256,500,384), (256,50,384), iters=10)
+run("cfg3 D-axis wgrad TN 128x128x38400", 128, 128, 38400, 1, (1,128,0, 128,1,0, 128,1,0), (38400,128), (38400,128), (128,128), act=256, iters=10)
+run("cfg3 concat dW0 TN 256x128x256 x5", 256, 128, 256, 5, (1,256,256*256, 128,1,2*256*128, 256,1,256*256), (5,256,256), (5,2,256,128), (5,256,256), act=0, iters=10)
