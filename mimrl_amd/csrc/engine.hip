@@ -1607,7 +1607,10 @@ int mimrl_handle::conv_backward() {
 // =================================================================================================
 int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
                                     const int* dims, const float* in, float* const* act, float* out) {
-  const bool big_ok = img_valid && crit_img && rows >= 2048 && dims[0] <= 256;   // concat-critic tail: direct-from-L2 variant
+  // concat-critic tail (thousands of row tiles): the direct-from-L2 fused variant was the faster one in round 1; with the round-2
+  // GEMM kernels the plain chain wins (cfg3 9.80 vs 10.15 ms), so it is opt-in now (MIMRL_FUSED_MLP_BIG=1)
+  static const bool use_big = getenv("MIMRL_FUSED_MLP_BIG") != nullptr;   // tuning knob
+  const bool big_ok = use_big && img_valid && crit_img && rows >= 2048 && dims[0] <= 256;
   if (bf16 && fused_mlp && (rows <= 512 || big_ok) && mlp_fused_supported(nb, rows, nl, dims)) {   // one launch (mlp_fused.hip)
     MlpFusedArgs fa;
     std::memset(&fa, 0, sizeof fa);
