@@ -1696,6 +1696,8 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;
   }
+  static const bool no_big_side = getenv("MIMRL_NO_WG_BIG_SIDE") != nullptr;   // tuning knob
+  const bool big_side = wgrad && multi_stream && !no_big_side && wg_helper >= 0 && rows >= 2048 && nl <= 3;
   for (int l = nl - 1; l >= 0; --l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
     const float* a_in = l == 0 ? in : act[l - 1];
@@ -1714,7 +1716,10 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
       // thousands of rows (concat critic: B*B per estimator): accumulate into the zeroed bucket with atomics so that the GEMM may
       // split K -- as plain stores the 5 x 16 output tiles ran 2048 k-tiles each on 80 CUs (1.6 ms per layer at cfg3)
       if (rows >= 2048) g.atomic = 1;
-      MX(G_(g));
+      // ... and they are 200+ us kernels that only READ dz_l / act_{l-1}: beside the data-gradient chain on the helper stream (no
+      // gradient buffer is reused within a stack of <= 3 layers, so nothing is overwritten under them)
+      if (big_side) { MX(fork(wg_helper, wg_helper)); MX(G_on(S(wg_helper), g)); }
+      else MX(G_(g));
     }
     float* target = l > 0 ? dtmp[pp] : din;
     if (!target) break;
@@ -1730,6 +1735,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     MX(G_(g));
     if (l > 0) { dz = target; pp ^= 1; }
   }
+  if (big_side) MX(join(wg_helper, wg_helper));
   return MIMRL_OK;
 }
 
