@@ -370,17 +370,21 @@ struct mimrl_handle {
   } gsets[2];
   int cur_set = 0;
   GraphSet& GS() { return gsets[cur_set]; }
+  // Invalidated graphs are RETIRED, not destroyed: hipGraphExecDestroy followed by instantiating and launching new graphs crashes
+  // this HIP runtime in ~7-14 % of fresh processes (SIGSEGV in hip::Graph::UpdateStreams under hipGraphLaunch of the NEW graph:
+  // rocgdb backtrace in DESIGN.md section 8; 3/40 and 7/50 runs of `bench.py --extras-only`, whose first action is a mode switch).
+  // A retired exec is a few hundred bytes of host state per node; invalidation happens on mode switches and when the bank size
+  // changes (once per training run), so the list stays short.  They are released with the handle.
+  std::vector<hipGraphExec_t> retired;
+  void retire(hipGraphExec_t& ex) { if (ex) { retired.push_back(ex); ex = nullptr; } }
   void drop_graphs(int set = -1) {
     for (int q = 0; q < 2; ++q) {
       if (set >= 0 && q != set) continue;
       for (int s = 0; s <= 2; ++s)
-        for (int k = 0; k < 2; ++k)
-          if (gsets[q].graph[s][k]) { (void)hipGraphExecDestroy(gsets[q].graph[s][k]); gsets[q].graph[s][k] = nullptr; }
-      if (gsets[q].tail) { (void)hipGraphExecDestroy(gsets[q].tail); gsets[q].tail = nullptr; }
+        for (int k = 0; k < 2; ++k) retire(gsets[q].graph[s][k]);
+      retire(gsets[q].tail);
     }
   }
-
-  // ------------------------------------------------------------------------------------------
   float* P(long off) const { return bufs.main_p + off; }
   float* Gm(long off) const { return bufs.main_g + off; }
   float* CP(long off) const { return bufs.crit_p + off; }
@@ -2222,10 +2226,7 @@ int mimrl_handle::run(int stage, int kind) {
   if (kind == 1) grads_clean[stage] = false;
   if (!cfg.use_graph || prof_on) return body();
   hipGraphExec_t& ex = GS().graph[stage][kind];
-  if (ex && GS().rows[stage][kind] != bank_rows) {   // bank size is baked into the kernel arguments
-    HIPX(hipGraphExecDestroy(ex));
-    ex = nullptr;
-  }
+  if (ex && GS().rows[stage][kind] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
   if (!ex) {
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
@@ -2263,7 +2264,7 @@ int mimrl_handle::run_fwd2_tail() {
     return r;
   };
   if (!cfg.use_graph || prof_on) return body();
-  if (GS().tail && GS().tail_rows != bank_rows) { HIPX(hipGraphExecDestroy(GS().tail)); GS().tail = nullptr; }
+  if (GS().tail && GS().tail_rows != bank_rows) retire(GS().tail);
   if (!GS().tail) {
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
@@ -2298,10 +2299,7 @@ int mimrl_handle::run_step() {
     imgT_valid = true;
   }
   hipGraphExec_t& ex = GS().graph[0][0];
-  if (ex && GS().rows[0][0] != bank_rows) {   // bank size is baked into the kernel arguments
-    HIPX(hipGraphExecDestroy(ex));
-    ex = nullptr;
-  }
+  if (ex && GS().rows[0][0] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
   if (!ex) {
     static const bool no_boundary = getenv("MIMRL_NO_FUSED_BOUNDARY") != nullptr;   // tuning knob: the round-1 stage boundary
     hipGraph_t g = nullptr;
@@ -2575,6 +2573,8 @@ int64_t mimrl_workspace_bytes(const mimrl_handle* h) { return h ? (int64_t)h->ws
 void mimrl_destroy(mimrl_handle* h) {
   if (!h) return;
   h->drop_graphs();
+  for (auto g : h->retired) (void)hipGraphExecDestroy(g);
+  h->retired.clear();
   for (int p = 0; p < MIMRL_NPHASES; ++p)
     for (auto& ev : h->prof_ev[p]) h->prof_pool.push_back(ev);
   for (auto& g : h->prof_gemm) h->prof_pool.push_back({g.a, g.b});
