@@ -911,6 +911,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   const long BT_ = (long)B * T;
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
   if (part != 1 && T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
+  static const bool fused_pre = getenv("MIMRL_NO_FUSED_TAIL_PRE") == nullptr;   // tuning knob: text_post + ln_relu_drop + feat_mean as one launch
   if (part != 2) {
     MX(fork(0, 5));
     // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0.  Captured BEFORE the encoders although it
@@ -918,23 +919,26 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     // dispatched behind them too and then delays the tail (measured: 1.46 vs 1.34 ms).
     { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
     MX(dbg_delay(S(0), 10));
-    if (part == 0) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+    if (part == 0 && !fused_pre) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
     MX(encoders_forward(save, knn_stage));
     MX(join(0, 0));
     if (part == 1) return MIMRL_OK;
-  } else {
+  } else if (!fused_pre) {
     MX(text_post_fwd(stream, tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
   }
-  // fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2
+  // text dropout -> cube slot 0; fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2; T_F, A_F, V_F (Model.py:466)
   {
     LnSide2 sd[2];
     for (int m = 0; m < 2; ++m)
       sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], nullptr, nullptr, nullptr, 1 + m, pdrop[1 + m],
                       (uint32_t)(1 + m)};
-    MX(ln_relu_drop_fwd2(stream, sd[0], sd[1], cube0, B, T, L, 3, D, key()));   // audio and video in one launch
+    if (fused_pre) {   // one launch instead of three on the chain of each tail
+      MX(tail_pre_fwd(stream, tx_raw, pdrop[0], sd[0], sd[1], cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D, key()));
+    } else {
+      MX(ln_relu_drop_fwd2(stream, sd[0], sd[1], cube0, B, T, L, 3, D, key()));   // audio and video in one launch
+      MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
+    }
   }
-  // T_F, A_F, V_F (Model.py:466)
-  MX(feat_mean_fwd(stream, cube0, bufs.feats + (size_t)B * D, B, T, L, 3, D));
   { Scope sc(this, MIMRL_PH_CUBE_FWD); MX(cube_forward(train, save)); }
   MX(dbg_delay(stream, save ? 2 : 13));
   // head (Model.py:489-515)

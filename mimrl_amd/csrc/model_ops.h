@@ -56,6 +56,10 @@ int ln_relu_drop_bwd(hipStream_t s, const float* h2, const float* gamma, const f
 
 // feats[k][b,:] = mean_{t<T} cube[b,t,k,:]   (Model.py:466)   feats laid out [K][B][D]
 int feat_mean_fwd(hipStream_t s, const float* cube, float* feats, int B, int T, int L, int K, int D);
+// text_post_fwd (slot 0) + ln_relu_drop_fwd2 (slots 1, 2) + feat_mean_fwd of one forward tail as ONE launch (same arithmetic and
+// dropout keys; feats = [3][B, D] = T_F, A_F, V_F)
+int tail_pre_fwd(hipStream_t s, const float* tx_raw, float p_text, const LnSide2& a, const LnSide2& v, float* cube, float* feats, int B, int T,
+                 int L, int K, int D, RngKey key);
 // dcube[b,t,k,:] += dfeats[k][b,:]/T  for t<T
 int feat_mean_bwd(hipStream_t s, const float* dfeats, float* dcube, int B, int T, int L, int K, int D);
 

@@ -136,6 +136,77 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
   for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(&dgamma[i], sg[i]); atomicAdd(&dbeta[i], sb[i]); }
 }
 
+// ------------------------------------------------------------------ the three pre-CubeMLP pieces of one forward tail in ONE launch
+// text_post (slot 0) | LN + ReLU + dropout of the audio / video GRU outputs (slots 1, 2) -> cube, and the temporal means T_F / A_F / V_F
+// of exactly those cube values (Model.py:452-466).  One workgroup per (sample, slot); a wave owns rows t = w, w+4, ...; two rows in
+// flight per pass.  Element indices of the dropout hash are those of the separate kernels (the backward regenerates the masks).
+struct TailPre { const float* tx_raw; LnSide a, v; float p_text; };
+__global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __restrict__ cube, float* __restrict__ feats, int B, int T, int L, int K,
+                                                       RngKey key) {
+  constexpr int D = 128;
+  __shared__ float part[4][D];
+  const int b = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float acc0 = 0.f, acc1 = 0.f;
+  if (slot == 0) {
+    for (int t0 = w; t0 < T; t0 += 8) {
+      float x[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = t0 + 4 * q < T ? t0 + 4 * q : T - 1;
+        const float* src = tp.tx_raw + ((long)b * T + t) * D;
+        x[q][0] = src[lane]; x[q][1] = src[lane + 64];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = t0 + 4 * q;
+        if (t < T) {
+          const long r = (long)b * T + t;
+          float* out = cube + (((long)b * L + t) * K + 0) * D;
+          const float y0 = x[q][0] * drop_scale(tp.p_text, key, 0u, (uint32_t)(r * D + lane));
+          const float y1 = x[q][1] * drop_scale(tp.p_text, key, 0u, (uint32_t)(r * D + lane + 64));
+          out[lane] = y0; out[lane + 64] = y1;
+          acc0 += y0; acc1 += y1;
+        }
+      }
+    }
+  } else {
+    const LnSide& sd = slot == 1 ? tp.a : tp.v;
+    const float g0 = sd.gamma[lane], g1 = sd.gamma[lane + 64], be0 = sd.beta[lane], be1 = sd.beta[lane + 64];
+    for (int t0 = w; t0 < T; t0 += 8) {
+      float v[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = t0 + 4 * q < T ? t0 + 4 * q : T - 1;
+        const float* hr = sd.h2 + ((long)b * T + t) * 2 * D;
+        v[q][0] = hr[lane] + hr[D + lane]; v[q][1] = hr[lane + 64] + hr[D + lane + 64];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = t0 + 4 * q;
+        if (t < T) {                                            // (wave-uniform)
+          const long r = (long)b * T + t;
+          const float mu = wave_sum(v[q][0] + v[q][1]) * (1.f / D);
+          const float c0 = v[q][0] - mu, c1 = v[q][1] - mu;
+          const float rs = rsqrtf(wave_sum(c0 * c0 + c1 * c1) * (1.f / D) + LN_EPS);
+          if (lane == 0) { sd.mean[r] = mu; sd.rstd[r] = rs; }
+          float* out = cube + (((long)b * L + t) * K + sd.slot) * D;
+          float y0 = c0 * rs * g0 + be0, y1 = c1 * rs * g1 + be1;
+          y0 = (y0 > 0.f ? y0 : 0.f) * drop_scale(sd.p, key, sd.stream, (uint32_t)(r * D + lane));
+          y1 = (y1 > 0.f ? y1 : 0.f) * drop_scale(sd.p, key, sd.stream, (uint32_t)(r * D + lane + 64));
+          out[lane] = y0; out[lane + 64] = y1;
+          acc0 += y0; acc1 += y1;
+        }
+      }
+    }
+  }
+  part[w][lane] = acc0; part[w][lane + 64] = acc1;
+  __syncthreads();
+  if (threadIdx.x < D) {
+    const int d = threadIdx.x;
+    feats[((long)slot * B + b) * D + d] = (part[0][d] + part[1][d] + part[2][d] + part[3][d]) / T;
+  }
+}
+
 // ------------------------------------------------------------------ temporal means
 __global__ void feat_mean_fwd_kernel(const float* __restrict__ cube, float* __restrict__ feats, int B, int T, int L,
                                      int K, int D) {
@@ -650,6 +721,18 @@ int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const f
   const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v};
   hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T,
                      L, K, key);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int tail_pre_fwd(hipStream_t s, const float* tx_raw, float p_text, const LnSide2& a, const LnSide2& v, float* cube, float* feats, int B, int T,
+                 int L, int K, int D, RngKey key) {
+  if (D != 128 || K != 3 || a.slot != 1 || v.slot != 2) return set_error(MIMRL_ERR_ARG, "tail_pre_fwd: d_common 128, 3 modality slots");
+  TailPre tp;
+  tp.tx_raw = tx_raw; tp.p_text = p_text;
+  tp.a = LnSide{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, nullptr};
+  tp.v = LnSide{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, nullptr};
+  hipLaunchKernelGGL(tail_pre_kernel, dim3(B, 3), dim3(256), 0, s, tp, cube, feats, B, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
