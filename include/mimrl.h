@@ -174,6 +174,11 @@ int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M,
 int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch, const int64_t strides[9],
                      const float* A2, const float* B2, int K2, const int64_t strides2[6], int a_gap_at, int a_gap_rows,
                      const float* bias_n, const float* gradact_u, float* colsum, int act, int precision);
+/* n <= 12 weight-gradient products C_i += A_i . B_i (float atomics into caller-zeroed outputs; a batch with sc_b = 0 is reduced too) as
+ * ONE grouped split-K launch when all share one operand-layout class, else n launches.  dims = n x {M, N, K, batch}, strides = n x 9 as
+ * in mimrl_op_gemm.  (The engine's parked CubeMLP weight gradients, Model.py:150-214 backward.) */
+int mimrl_op_gemm_wgrad_group(void* stream, int n, const float* const* A, const float* const* B, float* const* C, const int32_t* dims,
+                              const int64_t* strides, int precision);
 int64_t mimrl_op_gru_saved_floats(int B, int T);
 /* one bidirectional GRU layer (both directions): gx/w_hh/b_hh/saved per direction; out [B,T,256] */
 int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r,

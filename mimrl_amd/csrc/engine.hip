@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "cube_fused.h"
@@ -1410,9 +1411,23 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
   static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
   static const int dbg_skip_kinds = getenv("MIMRL_DBG_SKIP_DEFERRED") ? atoi(getenv("MIMRL_DBG_SKIP_DEFERRED")) : 0;   // timing experiments only (bit = kind)
+  // the weight-gradient GEMMs as (at most) two grouped split-K launches, one per operand-layout class: D-axis products are
+  // (RC,RC), the batch-reduced L-axis products (KC,KC).  Alone each is a ~20 us launch of 4..64 tiles.
+  static const bool no_wg_groupk = getenv("MIMRL_NO_WG_GROUPK") != nullptr;   // tuning knob
+  const bool groupk = !no_wg_groupk && !prof_on && bf16 && !((dbg_skip_kinds >> 0) & 1);
+  if (groupk) {
+    std::vector<GemmDesc> cls[2];
+    for (const Deferred& d : deferred) if (d.kind == 0) cls[d.g.sa_k == 1 ? 0 : 1].push_back(d.g);
+    for (int c = 0; c < 2; ++c) {
+      hipStream_t st = only_side > 0 ? S(only_side) : S(1 + c % wg_sides);
+      for (size_t i = 0; i < cls[c].size(); i += 12) MX(gemm_group_splitk(st, cls[c].data() + i, (int)std::min<size_t>(12, cls[c].size() - i), bf16));
+    }
+  }
+  int rr = 2;
   for (const Deferred& d : deferred) {
     if ((dbg_skip_kinds >> d.kind) & 1) continue;
-    hipStream_t st = only_side > 0 ? S(only_side) : S(1 + (d.side - 1) % wg_sides);
+    if (groupk && d.kind == 0) continue;
+    hipStream_t st = only_side > 0 ? S(only_side) : S(1 + (groupk ? rr++ : d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
@@ -2621,6 +2636,21 @@ int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int
   d.a_gap_at = a_gap_at; d.a_gap_rows = a_gap_rows;
   d.bias_n = bias_n; d.gradact_u = gradact_u; d.colsum = colsum; d.act = act & 0xff; d.atomic = (act >> 8) & 1;
   return gemm(reinterpret_cast<hipStream_t>(stream), d, (precision & 1) != 0);
+}
+
+int mimrl_op_gemm_wgrad_group(void* stream, int n, const float* const* A, const float* const* B, float* const* C, const int32_t* dims,
+                              const int64_t* st, int precision) {
+  if (n <= 0 || n > 12 || !A || !B || !C || !dims || !st) return set_error(MIMRL_ERR_ARG, "gemm_wgrad_group: 1..12 problems");
+  GemmDesc d[12];
+  for (int i = 0; i < n; ++i) {
+    d[i].A = A[i]; d[i].B = B[i]; d[i].C = C[i];
+    d[i].M = dims[4 * i]; d[i].N = dims[4 * i + 1]; d[i].K = dims[4 * i + 2]; d[i].batch = dims[4 * i + 3];
+    const int64_t* q = st + 9 * i;
+    d[i].sa_m = q[0]; d[i].sa_k = q[1]; d[i].sa_b = q[2]; d[i].sb_k = q[3]; d[i].sb_n = q[4]; d[i].sb_b = q[5];
+    d[i].sc_m = q[6]; d[i].sc_n = q[7]; d[i].sc_b = q[8];
+    d[i].atomic = 1;
+  }
+  return gemm_group_splitk(reinterpret_cast<hipStream_t>(stream), d, n, (precision & 1) != 0);
 }
 
 int64_t mimrl_op_gru_saved_floats(int B, int T) { return gru_saved_floats(B, T); }

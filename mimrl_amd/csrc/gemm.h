@@ -71,5 +71,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
 // up to 6 independent GEMMs as ONE launch when they are plain (no second product / operand-reading epilogue), bf16 and of one
 // operand-layout class of the fast path; otherwise n ordinary launches.  No split-K: meant for many small products.
 int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16);
+// up to 12 plain accumulate-into-zeroed-output GEMMs (C += A.B with float atomics; weight gradients) of one layout class -- both
+// operands k-contiguous or both row-contiguous -- as ONE launch, each problem with its own split-K factor; otherwise n launches.
+int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16);
 
 }  // namespace mimrl

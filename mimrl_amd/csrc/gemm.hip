@@ -599,6 +599,38 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(GroupArgs ga) {
   fast_body<1, 1, AKC, BKC, false>(d, 1, (d.K + FBK - 1) / FBK, 0, t % nx, (t / nx) % ny, t / (nx * ny));
 }
 
+// GROUPED SPLIT-K launch: up to GEMM_GROUPK_MAX plain accumulate-into-zeroed-output GEMMs (weight gradients: C += A.B with float
+// atomics, optional batch reduced into the same C) of one layout class in ONE launch, each with its own split-K factor.  The parked
+// CubeMLP weight gradients are 12 such products of 4..64 tiles each: alone every one is a ~20 us launch that cannot fill the chip.
+constexpr int GEMM_GROUPK_MAX = 12;
+struct GroupKProb {
+  const float* A; const float* B; float* C;
+  int M, N, K, batch;
+  long sa, sa_b, sb, sb_b, sc_m, sc_b;   // sa / sb: the non-unit stride of the operand (row stride for KC, k stride for RC)
+  int nsplit, kt_per;
+};
+struct GroupKArgs {
+  GroupKProb p[GEMM_GROUPK_MAX];
+  int start[GEMM_GROUPK_MAX];            // first linear workgroup id of each problem
+  int n;
+};
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_groupk_kernel(GroupKArgs ga) {
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < GEMM_GROUPK_MAX; ++q)
+    if (q < ga.n && (int)blockIdx.x >= ga.start[q]) p = q;
+  const GroupKProb& g = ga.p[p];
+  GemmDesc d;
+  d.A = g.A; d.B = g.B; d.C = g.C; d.M = g.M; d.N = g.N; d.K = g.K; d.batch = g.batch;
+  d.sa_m = AKC ? g.sa : 1; d.sa_k = AKC ? 1 : g.sa; d.sa_b = g.sa_b;
+  d.sb_n = BKC ? g.sb : 1; d.sb_k = BKC ? 1 : g.sb; d.sb_b = g.sb_b;
+  d.sc_m = g.sc_m; d.sc_n = 1; d.sc_b = g.sc_b; d.atomic = 1;
+  const unsigned t = blockIdx.x - ga.start[p];
+  const unsigned nx = (g.N + 63) / 64, ny = (g.M + 63) / 64;
+  fast_body<1, 1, AKC, BKC, false>(d, g.nsplit, g.kt_per, 0, t % nx, (t / nx) % ny, t / (nx * ny));
+}
+
 // layout class of one operand for the fast path: 1 = KC, 2 = RC, 0 = not eligible.  (row axis = m for A, n for B)
 inline int fast_class(const float* P, long s_r, long s_k, long s_b, long s_bo, int R, int K, int bf = 0) {
   const int q = bf ? 8 : 4;   // elements per 16-byte piece
@@ -717,6 +749,53 @@ int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
   if (ca == 1 && cb == 1) hipLaunchKernelGGL((gemm_group_kernel<true, true>), dim3(acc), dim3(256), 0, s, ga);
   else if (ca == 1) hipLaunchKernelGGL((gemm_group_kernel<true, false>), dim3(acc), dim3(256), 0, s, ga);
   else hipLaunchKernelGGL((gemm_group_kernel<false, false>), dim3(acc), dim3(256), 0, s, ga);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
+  static const int no_group = getenv("MIMRL_GEMM_NO_GROUPK") != nullptr;   // tuning knob
+  bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUPK_MAX;
+  int ca = 0, cb = 0;
+  long tiles = 0;
+  for (int i = 0; ok && i < n; ++i) {
+    const GemmDesc& d = ds[i];
+    if (d.M <= 0 || d.N <= 0 || d.batch <= 0 || !d.A || !d.B || !d.C) { ok = false; break; }
+    const int a = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K), b = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K);
+    if (!a || !b || a != b || (i > 0 && a != ca)) { ok = false; break; }
+    ca = a; cb = b;
+    if (!plain_accumulate(d) || d.alpha != 1.f || d.sc_n != 1 || d.batch_in > 0 || d.a_gap_rows || d.a_bf16 || d.b_bf16) { ok = false; break; }
+    tiles += (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) MX(gemm(s, ds[i], bf16));
+    return MIMRL_OK;
+  }
+  (void)cb;
+  GroupKArgs ga;
+  ga.n = n;
+  // ~3 workgroups per CU over the whole group, at least 8 k-tiles (256 k) per workgroup
+  const long want = (768 + tiles - 1) / tiles;
+  long acc = 0;
+  for (int i = 0; i < GEMM_GROUPK_MAX; ++i) {
+    if (i >= n) { ga.p[i] = GroupKProb(); ga.start[i] = 0x7fffffff; continue; }
+    const GemmDesc& d = ds[i];
+    GroupKProb& g = ga.p[i];
+    g.A = d.A; g.B = d.B; g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.batch = d.batch;
+    g.sa = ca == 1 ? d.sa_m : d.sa_k; g.sa_b = d.sa_b; g.sb = ca == 1 ? d.sb_n : d.sb_k; g.sb_b = d.sb_b;
+    g.sc_m = d.sc_m; g.sc_b = d.sc_b;
+    const int ktiles = (d.K + FBK - 1) / FBK;
+    long ks = want < 1 ? 1 : want;
+    if (ks > ktiles / 8) ks = ktiles / 8;
+    if (ks < 1) ks = 1;
+    g.kt_per = (int)((ktiles + ks - 1) / ks);
+    g.nsplit = (ktiles + g.kt_per - 1) / g.kt_per;
+    ga.start[i] = (int)acc;
+    acc += (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * g.nsplit;
+  }
+  if (acc > 0x7fffffffL) return set_error(MIMRL_ERR_ARG, "gemm_group_splitk: grid too large");
+  if (ca == 1) hipLaunchKernelGGL((gemm_groupk_kernel<true, true>), dim3((unsigned)acc), dim3(256), 0, s, ga);
+  else hipLaunchKernelGGL((gemm_groupk_kernel<false, false>), dim3((unsigned)acc), dim3(256), 0, s, ga);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -132,6 +132,37 @@ def test_gemm_fast_path_dual_gap_epilogues(lib):
     assert np.abs(dw.cpu().numpy() - ref).max() <= 3e-6 * M + 1e-5
 
 
+@pytest.mark.parametrize("kind", ["daxis", "laxis", "mixed"])
+def test_gemm_wgrad_group_splitk(lib, kind):
+    """The parked CubeMLP weight gradients as one grouped split-K launch: D-axis products dW = dY^T X (both operands
+    row-contiguous, K = B*L*K rows) and the batch-reduced L-axis products dW += dY_b X_b^T (both k-contiguous, all
+    samples into one output).  Ragged tiles, different K per problem; `mixed` = two layout classes -> the n-launch fallback."""
+    g = np.random.default_rng(11)
+    probs = []
+    if kind in ("daxis", "mixed"):
+        for (M, N, K) in [(128, 128, 9600), (128, 32, 9600), (32, 128, 9600), (20, 24, 1000), (64, 64, 96)]:
+            a, b = g.standard_normal((K, M)).astype(np.float32), g.standard_normal((K, N)).astype(np.float32)
+            probs.append((a, b, M, N, K, 1, (1, M, 0, N, 1, 0, N, 1, 0), _bf16_round(a).T @ _bf16_round(b)))
+    if kind in ("laxis", "mixed"):
+        for (M, N, K, nb) in [(50, 50, 384, 64), (50, 12, 384, 64), (12, 50, 384, 64), (8, 4, 128, 7)]:
+            a, b = g.standard_normal((nb, M, K)).astype(np.float32), g.standard_normal((nb, N, K)).astype(np.float32)
+            ref = np.einsum("bmk,bnk->mn", _bf16_round(a), _bf16_round(b))
+            probs.append((a, b, M, N, K, nb, (K, 1, M * K, 1, K, N * K, N, 1, 0), ref))
+    n = len(probs)
+    As, Bs = [dev(q[0]) for q in probs], [dev(q[1]) for q in probs]
+    Cs = [torch.zeros(q[2], q[3], device="cuda") for q in probs]
+    pa = (C.c_void_p * n)(*[P(t) for t in As])
+    pb = (C.c_void_p * n)(*[P(t) for t in Bs])
+    pc = (C.c_void_p * n)(*[P(t) for t in Cs])
+    dims = (C.c_int32 * (4 * n))(*[v for q in probs for v in (q[2], q[3], q[4], q[5])])
+    st = (C.c_int64 * (9 * n))(*[v for q in probs for v in q[6]])
+    _lib.check(lib.mimrl_op_gemm_wgrad_group(stream(), n, pa, pb, pc, dims, st, 1))
+    torch.cuda.synchronize()
+    for i, q in enumerate(probs):
+        err = np.abs(Cs[i].cpu().numpy() - q[7]).max()
+        assert err <= 3e-6 * q[4] * q[5] + 1e-5, f"{kind} problem {i} ({q[2]}x{q[3]}x{q[4]} batch {q[5]}): max |err| {err}"
+
+
 def _gru_case(B, T, d, seed, ragged):
     g = np.random.default_rng(seed)
     H = 128
