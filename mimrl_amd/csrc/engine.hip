@@ -203,6 +203,7 @@ struct mimrl_handle {
   int* d_ints_own = nullptr;           // private fallback storage
   float* d_consts = nullptr;           // coef1[11] coef2[8] gs_mi[2][5] g_bce[2][6] g_cmi[2][6]
   int *lens[2] = {nullptr, nullptr};
+  hipEvent_t ev_lens = nullptr;        // set while the length scan of this forward pass runs on side 0 (in front of the text projection)
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
   float* cube0 = nullptr;
   // layer-0 GRU operands in a common aligned shape (model_ops.h: L0Pack): one batched input projection, two batched weight gradients
@@ -754,7 +755,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   const float* xin[2] = {bufs.audio, bufs.video};
   const int dmod[2] = {cfg.d_a, cfg.d_v};
   // lengths (Model.py:425-432): only the recurrence needs them -> sides 4/5, next to the input projections
-  MX(seq_lengths2(S(4), xin[0], dmod[0], lens[0], xin[1], dmod[1], lens[1], B, T));
+  if (!ev_lens) MX(seq_lengths2(S(4), xin[0], dmod[0], lens[0], xin[1], dmod[1], lens[1], B, T));
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
@@ -806,6 +807,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       }
     }
     MX(join(1, l == 0 ? 4 : 3));
+    if (l == 0 && ev_lens) { HIPX(hipStreamWaitEvent(stream, ev_lens, 0)); ev_lens = nullptr; }
     if (l == 0 && knn_stage) {   // the kNN sampler needs only banks + anchors: overlap it with the recurrence (32 of 256 CUs busy)
       MX(fork(4, 4));
       MX(knn_launch(knn_stage, S(4)));
@@ -918,6 +920,14 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0.  Captured BEFORE the encoders although it
     // has slack until the tail starts: graph nodes start in capture order, and a branch captured behind the two GRU layers is
     // dispatched behind them too and then delays the tail (measured: 1.46 vs 1.34 ms).
+    static const bool prefix_split = getenv("MIMRL_LENS_SIDE0") != nullptr;   // tuning knob
+    if (prefix_split && cfg.encoder == MIMRL_ENCODER_GRU && side_on(0)) {
+      // lengths (Model.py:425-432): only the recurrence needs them.  Side 0 has slack (the text projection is needed at the tail);
+      // on side 4 the scan sat in front of the video input projection, the longest chain ahead of the layer-0 recurrence
+      MX(seq_lengths2(S(0), bufs.audio, cfg.d_a, lens[0], bufs.video, cfg.d_v, lens[1], B, T));
+      MX(next_event(&ev_lens));
+      HIPX(hipEventRecord(ev_lens, S(0)));
+    }
     { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
     MX(dbg_delay(S(0), 10));
     if (part == 0 && !fused_pre) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
@@ -2002,8 +2012,9 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   imgT_ready = false;
   if (backward && bf_bwd && fused_mlp && crit_imgT && ttab.n > 0) {   // transposed weight images for the fused data-gradient chains,
     if (!(skip_imgT_refresh && stage == 1)) {                         // built beside the forward stacks (combined step: once per step,
+      static const bool dbg_skip_imgt = getenv("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
       MX(fork(3, 3));                                                 // in stage 2 -- stage 1 of the NEXT step sees the same critics)
-      MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
+      if (!dbg_skip_imgt) MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
     }
     imgT_ready = true;
   }
@@ -2053,7 +2064,14 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   const bool have_banks = bank_rows > 0;
   if (!keep_events) ev_next = 0;
   if (stage == 1) {
-    hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, stream, d_ints, have_banks ? d_ints + 2 : nullptr,
+    static const bool no_share = getenv("MIMRL_NO_SHARED_PREFIX") != nullptr;   // tuning knob: evaluate the prefix twice
+    static const bool prefix_split = getenv("MIMRL_BEGIN_ON_SIDE") != nullptr;   // tuning knob
+    const bool share = prefetch && !no_share;
+    // counters + scalar reset: the first consumers are the kNN sampler and the recurrence, both behind the join of side 4 in
+    // encoders_forward -- in the shared-prefix step it runs on side 4 beside the input projections instead of in front of them
+    const bool begin_on_side = share && have_banks && skip_zero && prefix_split && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU;
+    if (begin_on_side) MX(fork(4, 4));
+    hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, begin_on_side ? side[4] : stream, d_ints, have_banks ? d_ints + 2 : nullptr,
                        bufs.scalars, 0, 32);
     LAUNCH_CHECK();
     if (!have_banks) return MIMRL_OK;
@@ -2076,8 +2094,6 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       return r;
     };
     hipEvent_t e_begin = nullptr;
-    static const bool no_share = getenv("MIMRL_NO_SHARED_PREFIX") != nullptr;   // tuning knob: evaluate the prefix twice
-    const bool share = prefetch && !no_share;
     if (prefetch) {
       MX(next_event(&e_begin));
       HIPX(hipEventRecord(e_begin, stream));
@@ -2386,12 +2402,12 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
-  // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches.  Pays off once the
-  // launches are large (cfg3: -2 %); at cfg2 the extra pack / unpack launches and the padded K cost as much as the batching
-  // saves (1.34 vs 1.32 ms), so the default follows the row count.  MIMRL_L0_PACK=1 / 0 forces it.
-  h->l0_packed = getenv("MIMRL_L0_PACK") ? atoi(getenv("MIMRL_L0_PACK")) != 0 : (long)h->cfg.batch * h->cfg.seq_len >= 16384;
-  // (inputs packed on side 0, only the layer-0 weight gradients batched: measured WORSE than four GEMMs in a row at cfg2 / cfg1,
-  //  1.245 vs 1.231 ms / 0.98 vs 0.94 ms -- the extra stream hop and the unpack launch cost more than the batching saves; off)
+  // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches: the four layer-0
+  // weight-gradient GEMMs in a row are what closes the stage behind the BPTT.  (History: before the parked CubeMLP weight gradients
+  // became two grouped launches the side streams were the bottleneck and packing lost at cfg2, 1.34 vs 1.32 ms; since then it
+  // wins, 1.14 vs 1.18 ms.)  MIMRL_L0_PACK=0 / 1 forces it.
+  h->l0_packed = getenv("MIMRL_L0_PACK") ? atoi(getenv("MIMRL_L0_PACK")) != 0 : true;
+  // (inputs packed on side 0, only the layer-0 weight gradients batched: MIMRL_L0_BWD_PACK=1 with MIMRL_L0_PACK=0; 1.15 ms at cfg2)
   // dg[B,T,4H] / h_prev are consumed only by GEMMs that round their operands to bf16 anyway: storing them as bf16 changes no
   // number in this mode and halves what the BPTT writes and the weight-gradient / dh0 products read
   h->dg_bf16 = cfg->encoder == MIMRL_ENCODER_GRU && (cfg->precision & MIMRL_PREC_BF16_GRU_BWD) && (cfg->precision & MIMRL_PREC_BF16_GEMM_BWD) &&
