@@ -78,49 +78,55 @@ __device__ __forceinline__ void commit_weight128(bf* img, const WImg& w, int tid
 }
 
 struct Carve {          // byte offsets into dynamic LDS (all multiples of 16)
-  int xm, aw, bx, bh, ctl, red, ksw, prm; // phases L / K
-  int bw, bw2, ctd, dprm, az, ah;         // phase D (aliases the L-phase regions; Xm is dead once Az is built)
+  int xm, aw, bx, bh, ctl, red, ksw, prm; // phases L / K   (bx, bh, ctl, red: one set per wave group)
+  int bw, ctd, dprm, az, ah;              // phase D (aliases the L-phase regions; Xm is dead once Az is built)
   int total;
 };
-__host__ __device__ inline Carve carve(int K, int nmt) {
+__host__ __device__ inline Carve carve(int K, int nmt, int G) {
   Carve c;
   const int C = K * D, XP = C + 8;
   const int xm_bytes = 64 * XP * 2;
   c.xm = 0;
   c.aw = xm_bytes;
   c.bx = c.aw + 3 * IMG * 2;
-  c.bh = c.bx + IMG * 2;
-  c.ctl = c.bh + IMG * 2;
-  c.red = c.ctl + 64 * CTL * 4;
-  c.ksw = c.red + 2 * 4 * 64 * 4;
+  c.bh = c.bx + G * IMG * 2;
+  c.ctl = c.bh + G * IMG * 2;
+  c.red = c.ctl + G * 64 * CTL * 4;
+  c.ksw = c.red + G * 2 * 4 * 64 * 4;
   c.prm = c.ksw + 256 * 4;
   const int l_end = c.prm + 4 * 64 * 4;
-  c.bw = 0;
-  c.bw2 = c.bw + IMG * 2;
-  c.ctd = c.bw2 + IMG * 2;
-  c.dprm = c.ctd + 64 * CTD * 4;
+  c.bw = 0;                                   // 2 weight-image buffers per wave group
+  c.dprm = c.bw + 2 * G * IMG * 2;
   int after = c.dprm + 2 * D * 4;
   if (after < xm_bytes) after = xm_bytes;     // Az must not overlap Xm (it is built from it)
   c.az = (after + 15) & ~15;
   c.ah = c.az + nmt * 2 * IMG * 2;
-  const int d_end = c.ah + nmt * 2 * IMG * 2;
+  // the fp32 LayerNorm tile aliases the H images (dead once the second product has been accumulated)
+  const int ah_bytes = nmt * 2 * IMG * 2, ctd_bytes = 64 * CTD * 4;
+  c.ctd = c.ah;
+  const int d_end = c.ah + (ah_bytes > ctd_bytes ? ah_bytes : ctd_bytes);
   c.total = l_end > d_end ? l_end : d_end;
   return c;
 }
 
-template <bool SAVE, int NMT>
-__global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
+// G wave groups of 4 waves each (256 * G threads).  With one workgroup per CU (the tile fills the LDS) G = 1 leaves ONE wave per SIMD:
+// every LDS / global round trip and every VALU dependency chain of the epilogues is exposed.  G = 2: the groups take alternate column
+// slabs in phase L (own B-images and staging tiles), interleave the (l, d) pairs of phase K, and each owns one 64-column half of the
+// D-axis outputs (own weight-image buffers: 6 stagings per group instead of 12 in a row).
+template <bool SAVE, int NMT, int G>
+__global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  constexpr int NT = 256 * G;
+  const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
   const int b = blockIdx.x;
   const int K = a.K, C = K * D, XP = C + 8, il = a.il, hl = a.hl, ol = a.ol;
-  const Carve cv = carve(K, NMT);
+  const Carve cv = carve(K, NMT, G);
   bf* Xm = reinterpret_cast<bf*>(smem + cv.xm);
   bf* Aw = reinterpret_cast<bf*>(smem + cv.aw);
-  bf* Bx = reinterpret_cast<bf*>(smem + cv.bx);
-  bf* Bh = reinterpret_cast<bf*>(smem + cv.bh);
-  float* CtL = reinterpret_cast<float*>(smem + cv.ctl);
-  float* red = reinterpret_cast<float*>(smem + cv.red);
+  bf* Bx = reinterpret_cast<bf*>(smem + cv.bx) + grp * IMG;
+  bf* Bh = reinterpret_cast<bf*>(smem + cv.bh) + grp * IMG;
+  float* CtL = reinterpret_cast<float*>(smem + cv.ctl) + grp * 64 * CTL;
+  float* red = reinterpret_cast<float*>(smem + cv.red) + grp * 2 * 4 * 64;
   float* ksw = reinterpret_cast<float*>(smem + cv.ksw);
   float* prm = reinterpret_cast<float*>(smem + cv.prm);   // [4][64] L-axis b1, b2, gamma, beta
 
@@ -128,17 +134,17 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   {
     const float* xb = a.x + (long)b * il * C;
     const int nq = C / 4, total = 64 * nq;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {          // 8 independent 16-byte loads in flight per thread
+    for (int i0 = tid; i0 < total; i0 += NT * 8) {           // 8 independent 16-byte loads in flight per thread
       float4 q[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int i = i0 + 256 * j;
+        const int i = i0 + NT * j;
         const int l = i / nq, c4 = (i - l * nq) * 4;
         q[j] = (i < total && l < il) ? *reinterpret_cast<const float4*>(xb + (long)l * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int i = i0 + 256 * j;
+        const int i = i0 + NT * j;
         if (i < total) {
           const int l = i / nq, c4 = (i - l * nq) * 4;
           bf16x4 p; p[0] = to_bf16(q[j].x); p[1] = to_bf16(q[j].y); p[2] = to_bf16(q[j].z); p[3] = to_bf16(q[j].w);
@@ -154,17 +160,19 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
       prm[3 * 64 + tid] = tid < ol ? a.l_be[tid] : 0.f;
     }
     // L-axis weights as A-images [m][k], zero padded to 64x64
-    stage_weight(Aw + 0 * IMG, a.l_w1, il, 0, 0, hl, il, tid);
-    stage_weight(Aw + 1 * IMG, a.l_w2, hl, 0, 0, ol, hl, tid);
-    stage_weight(Aw + 2 * IMG, a.l_wr, il, 0, 0, ol, il, tid);
+    if (G == 1 || grp == 0) stage_weight(Aw + 0 * IMG, a.l_w1, il, 0, 0, hl, il, t);
+    if (G == 1 || grp == 1) stage_weight(Aw + 1 * IMG, a.l_w2, hl, 0, 0, ol, hl, t);
+    if (G == 1 || grp == 0) stage_weight(Aw + 2 * IMG, a.l_wr, il, 0, 0, ol, il, t);
   }
   __syncthreads();
   if (a.dbg_phase == 1) return;
 
-  // ------------------------------------------------------------------ phase L: 64-column slabs
-  for (int n0 = 0; n0 < C; n0 += 64) {
-    {   // Bx[n][k] = X[k][n0+n]   (transpose within LDS; 16 consecutive k per thread -> two 16-byte stores)
-      const int n = tid & 63, kg = (tid >> 6) * 16;
+  // ------------------------------------------------------------------ phase L: 64-column slabs, one per wave group and round
+  for (int nb = 0; nb < C; nb += 64 * G) {
+    const int n0 = nb + 64 * grp;
+    const bool on = n0 < C;                                   // (barriers are workgroup-wide: an idle group keeps step)
+    if (on) {   // Bx[n][k] = X[k][n0+n]   (transpose within LDS; 16 consecutive k per thread -> two 16-byte stores)
+      const int n = t & 63, kg = (t >> 6) * 16;
       bf16x8 lo, hi;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { lo[j] = Xm[(kg + j) * XP + n0 + n]; hi[j] = Xm[(kg + 8 + j) * XP + n0 + n]; }
@@ -175,8 +183,9 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma64(acc, Aw + 0 * IMG, Bx, wm, wn, lane);
-    {   // U = acc + b1 ; H = act(U) -> Bh[n][m] (B-image of the second product), saved tensors to HBM
+    if (on) {
+      mma64(acc, Aw + 0 * IMG, Bx, wm, wn, lane);
+      // U = acc + b1 ; H = act(U) -> Bh[n][m] (B-image of the second product), saved tensors to HBM
       const int n = wn * 32 + (lane & 31);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -199,11 +208,11 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
       }
     }
     __syncthreads();
+    if (on) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    mma64(acc, Aw + 1 * IMG, Bh, wm, wn, lane);     // W2 . H
-    mma64(acc, Aw + 2 * IMG, Bx, wm, wn, lane);     // + Wr . X
-    {
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      mma64(acc, Aw + 1 * IMG, Bh, wm, wn, lane);     // W2 . H
+      mma64(acc, Aw + 2 * IMG, Bx, wm, wn, lane);     // + Wr . X
       const int n = wn * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -213,37 +222,44 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     }
     __syncthreads();
     {   // LayerNorm over the L axis (rows m < ol) for each of the 64 columns; 4 threads per column, rows in registers
-      const int n = tid & 63, q = tid >> 6;
+      const int n = t & 63, q = t >> 6;
       float yv[16];
       float s = 0.f;
+      if (on) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {                         // 16 independent LDS reads (one round trip, not 16)
-        const int m = q + 4 * j;
-        yv[j] = m < ol ? CtL[m * CTL + n] : 0.f;
-        s += yv[j];
+        for (int j = 0; j < 16; ++j) {                         // 16 independent LDS reads (one round trip, not 16)
+          const int m = q + 4 * j;
+          yv[j] = m < ol ? CtL[m * CTL + n] : 0.f;
+          s += yv[j];
+        }
+        red[q * 64 + n] = s;
       }
-      red[q * 64 + n] = s;
       __syncthreads();
-      const float mu = (red[n] + red[64 + n] + red[128 + n] + red[192 + n]) / ol;
-      float v = 0.f;
+      float mu = 0.f;
+      if (on) {
+        mu = (red[n] + red[64 + n] + red[128 + n] + red[192 + n]) / ol;
+        float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { const float c = (q + 4 * j < ol) ? yv[j] - mu : 0.f; v += c * c; }
-      red[256 + q * 64 + n] = v;
+        for (int j = 0; j < 16; ++j) { const float c = (q + 4 * j < ol) ? yv[j] - mu : 0.f; v += c * c; }
+        red[256 + q * 64 + n] = v;
+      }
       __syncthreads();
-      const float rs = rsqrtf((red[256 + n] + red[320 + n] + red[384 + n] + red[448 + n]) / ol + LN_EPS);
+      if (on) {
+        const float rs = rsqrtf((red[256 + n] + red[320 + n] + red[384 + n] + red[448 + n]) / ol + LN_EPS);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int m = q + 4 * j;
-        if (m < ol) {
-          const float z = (yv[j] - mu) * rs * prm[128 + m] + prm[192 + m];
-          Xm[m * XP + n0 + n] = to_bf16(z);                     // in place: this slab's X columns are dead
-          if (SAVE) {
-            a.l_y[((long)b * ol + m) * C + n0 + n] = yv[j];
-            a.l_z[((long)b * ol + m) * C + n0 + n] = z;
+        for (int j = 0; j < 16; ++j) {
+          const int m = q + 4 * j;
+          if (m < ol) {
+            const float z = (yv[j] - mu) * rs * prm[128 + m] + prm[192 + m];
+            Xm[m * XP + n0 + n] = to_bf16(z);                     // in place: this slab's X columns are dead
+            if (SAVE) {
+              a.l_y[((long)b * ol + m) * C + n0 + n] = yv[j];
+              a.l_z[((long)b * ol + m) * C + n0 + n] = z;
+            }
           }
         }
+        if (SAVE && q == 0) { a.l_mean[(long)b * C + n0 + n] = mu; a.l_rstd[(long)b * C + n0 + n] = rs; }
       }
-      if (SAVE && q == 0) { a.l_mean[(long)b * C + n0 + n] = mu; a.l_rstd[(long)b * C + n0 + n] = rs; }
     }
     __syncthreads();
   }
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   {
     const float* g = ksw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
 #pragma unroll 2
-    for (int i = tid; i < ol * D; i += 256) {   // (two (l, d) pairs interleaved: one wave per SIMD has nothing else to hide the VALU chains)
+    for (int i = tid; i < ol * D; i += NT) {   // (two (l, d) pairs interleaved: the VALU chains of one pair hide nothing)
       const int l = i >> 7, d = i & 127;
       KMixVals<4> v;
 #pragma unroll
@@ -275,13 +291,12 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
   if (a.dbg_phase == 3) return;
   // ------------------------------------------------------------------ phase D
   const int R = ol * K;
-  bf* Bw = reinterpret_cast<bf*>(smem + cv.bw);
   float* CtD = reinterpret_cast<float*>(smem + cv.ctd);
   float* dgam = reinterpret_cast<float*>(smem + cv.dprm);   // D-axis LayerNorm gain / bias (staged after Xm died)
   float* dbet = dgam + D;
   bf* Az = reinterpret_cast<bf*>(smem + cv.az);     // [NMT][2][64][ILD]   A-images of Z_k (k halves of d)
   bf* Ah = reinterpret_cast<bf*>(smem + cv.ah);     // [NMT][2][64][ILD]   A-images of H
-  for (int c = tid; c < NMT * 64 * 16; c += 256) {   // 16-byte chunks: row r, chunk ch (8 d-values)
+  for (int c = tid; c < NMT * 64 * 16; c += NT) {    // 16-byte chunks: row r, chunk ch (8 d-values)
     const int r = c >> 4, ch = c & 15;
     bf16x8 v;
 #pragma unroll
@@ -292,52 +307,59 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
     }
     *reinterpret_cast<bf16x8*>(Az + ((r >> 6) * 2 + (ch >> 3)) * IMG + (r & 63) * ILD + (ch & 7) * 8) = v;
   }
-  __syncthreads();   // Xm is dead from here on (Bw / CtD alias it)
+  __syncthreads();   // Xm is dead from here on (the weight-image buffers alias it)
   if (tid < D) { dgam[tid] = a.d_g[tid]; dbet[tid] = a.d_be[tid]; }   // visible after the barriers of the GEMM loops
+  // a wave owns NTW of the two 64-column halves of the outputs (both for G = 1, its group's one for G = 2)
+  constexpr int NTW = 2 / G, NI1 = 2 * NTW;        // weight images per product and group: (nt, kh)
+  const int nt0 = G == 1 ? 0 : grp;
   // biases of the two D-axis products for this lane's columns: requested here, not in the epilogues behind the GEMM loops
   // (a dependent global round trip there, with one workgroup per CU and nothing to hide it)
-  float b1v[2], b2v[2];
+  float b1v[NTW], b2v[NTW];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = nt * 64 + wn * 32 + (lane & 31);
-    b1v[nt] = a.d_b1 ? a.d_b1[col] : 0.f;
-    b2v[nt] = a.d_b2 ? a.d_b2[col] : 0.f;
+  for (int q = 0; q < NTW; ++q) {
+    const int col = (nt0 + q) * 64 + wn * 32 + (lane & 31);
+    b1v[q] = a.d_b1 ? a.d_b1[col] : 0.f;
+    b2v[q] = a.d_b2 ? a.d_b2[col] : 0.f;
   }
 
-  f32x16 acc[NMT][2];
+  f32x16 acc[NMT][NTW];
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int q = 0; q < NTW; ++q)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
-  // The 12 weight images of this phase, in consumption order: W1 (nt,kh) x4, then W2 (nt,kh) x4, then Wr (nt,kh) x4.
+      for (int i = 0; i < 16; ++i) acc[mt][q][i] = 0.f;
+  // The 3 * NI1 weight images of this group, in consumption order: W1 (nt,kh), then W2 (nt,kh), then Wr (nt,kh).
   // Image i+1 is requested from L2 before the MFMAs of image i (register prefetch), two LDS image buffers alternate.
-  auto wsrc = [&](int i) -> const float* { return i < 4 ? a.d_w1 : (i < 8 ? a.d_w2 : a.d_wr); };
-  bf* Bw2[2] = {Bw, reinterpret_cast<bf*>(smem + cv.bw2)};
-  WImg wnext = load_weight128(wsrc(0), 0, 0, tid);
-  // H = act(Z W1^T + b1): 4 weight images (nt, kh), each used by all row tiles
+  auto wload = [&](int i) -> WImg {
+    const float* W = i < NI1 ? a.d_w1 : (i < 2 * NI1 ? a.d_w2 : a.d_wr);
+    const int j = i % NI1;
+    return load_weight128(W, (nt0 + (j >> 1)) * 64, (j & 1) * 64, t);
+  };
+  bf* Bw2[2] = {reinterpret_cast<bf*>(smem + cv.bw) + (2 * grp) * IMG, reinterpret_cast<bf*>(smem + cv.bw) + (2 * grp + 1) * IMG};
+  WImg wnext = wload(0);
+  // H = act(Z W1^T + b1): NI1 weight images (nt, kh), each used by all row tiles
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int nt = i >> 1, kh = i & 1;
-    commit_weight128(Bw2[i & 1], wnext, tid);
-    { const int j = i + 1; wnext = load_weight128(wsrc(j), ((j >> 1) & 1) * 64, (j & 1) * 64, tid); }
+  for (int i = 0; i < NI1; ++i) {
+    const int q = i >> 1, kh = i & 1;
+    commit_weight128(Bw2[i & 1], wnext, t);
+    wnext = wload(i + 1);
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][nt], Az + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
+    for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][q], Az + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
   }
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = wn * 32 + (lane & 31), col = nt * 64 + n;
-      const float b1 = b1v[nt];
+    for (int q = 0; q < NTW; ++q) {
+      const int nt = nt0 + q, n = wn * 32 + (lane & 31), col = nt * 64 + n;
+      const float b1 = b1v[q];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = acc_row(r, wm, lane), row = mt * 64 + m;
         float h = 0.f;
         if (row < R) {
-          const float u = acc[mt][nt][r] + b1;
+          const float u = acc[mt][q][r] + b1;
           h = act_apply(a.act, u);
           if (SAVE) {
             a.d_u[((long)b * R + row) * D + col] = u;
@@ -345,57 +367,60 @@ __global__ __launch_bounds__(256) void cube_fwd_fused_kernel(CubeFusedArgs a) {
           }
         }
         Ah[(mt * 2 + nt) * IMG + m * ILD + n] = to_bf16(h);     // A-image of the next product: k = this column
-        acc[mt][nt][r] = 0.f;
+        acc[mt][q][r] = 0.f;
       }
     }
   __syncthreads();
   if (a.dbg_phase == 4) return;
-  // Y = H W2^T + Z Wr^T + b2: 8 weight images
+  // Y = H W2^T + Z Wr^T + b2: 2 * NI1 weight images
 #pragma unroll
-  for (int i = 4; i < 12; ++i) {
-    const int which = i >= 8, nt = (i >> 1) & 1, kh = i & 1;
-    commit_weight128(Bw2[i & 1], wnext, tid);
-    if (i + 1 < 12) { const int j = i + 1; wnext = load_weight128(wsrc(j), ((j >> 1) & 1) * 64, (j & 1) * 64, tid); }
+  for (int i = NI1; i < 3 * NI1; ++i) {
+    const int which = i >= 2 * NI1, q = (i % NI1) >> 1, kh = i & 1;
+    commit_weight128(Bw2[i & 1], wnext, t);
+    if (i + 1 < 3 * NI1) wnext = wload(i + 1);
     __syncthreads();
     const bf* Asrc = which == 0 ? Ah : Az;
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][nt], Asrc + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
+    for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][q], Asrc + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
   }
-  __syncthreads();
+  __syncthreads();   // (the H images are dead: the LayerNorm tile below aliases them)
   if (a.dbg_phase == 5) return;
   // LayerNorm over D per row, through an fp32 LDS tile
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int n = wn * 32 + (lane & 31), col = nt * 64 + n;
-      const float b2 = b2v[nt];
+    for (int q = 0; q < NTW; ++q) {
+      const int n = wn * 32 + (lane & 31), col = (nt0 + q) * 64 + n;
+      const float b2 = b2v[q];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) CtD[acc_row(r, wm, lane) * CTD + col] = acc[mt][nt][r] + b2;
+      for (int r = 0; r < 16; ++r) CtD[acc_row(r, wm, lane) * CTD + col] = acc[mt][q][r] + b2;
     }
     __syncthreads();
-    {   // 4 threads per row, 32 columns each (two 2-step reductions instead of two 6-step wave reductions per row)
-      const int m = tid >> 2, part = tid & 3, row = mt * 64 + m;
-      float yv[32];
+    {   // 4 * G threads per row, 32 / G columns each (short shuffle reductions instead of two 6-step wave reductions per row)
+      constexpr int TPR = 4 * G, CW = 32 / G;
+      const int m = tid / TPR, part = tid % TPR, row = mt * 64 + m;
+      float yv[CW];
       float s0 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 q = *reinterpret_cast<const float4*>(&CtD[m * CTD + part * 32 + 4 * j]);
+      for (int j = 0; j < CW / 4; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(&CtD[m * CTD + part * CW + 4 * j]);
         yv[4 * j] = q.x; yv[4 * j + 1] = q.y; yv[4 * j + 2] = q.z; yv[4 * j + 3] = q.w;
         s0 += (q.x + q.y) + (q.z + q.w);
       }
-      s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) s0 += __shfl_xor(s0, o, 64);
       const float mu = s0 * (1.f / D);
       float v0 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) { const float c = yv[j] - mu; v0 += c * c; }
-      v0 += __shfl_xor(v0, 1, 64); v0 += __shfl_xor(v0, 2, 64);
+      for (int j = 0; j < CW; ++j) { const float c = yv[j] - mu; v0 += c * c; }
+#pragma unroll
+      for (int o = 1; o < TPR; o <<= 1) v0 += __shfl_xor(v0, o, 64);
       const float rs = rsqrtf(v0 * (1.f / D) + LN_EPS);
       if (row < R) {
-        const long o = ((long)b * R + row) * D + part * 32;
+        const long o = ((long)b * R + row) * D + part * CW;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = part * 32 + 4 * j;
+        for (int j = 0; j < CW / 4; ++j) {
+          const int c = part * CW + 4 * j;
           float4 z;
           z.x = (yv[4 * j] - mu) * rs * dgam[c] + dbet[c];
           z.y = (yv[4 * j + 1] - mu) * rs * dgam[c + 1] + dbet[c + 1];
@@ -429,19 +454,23 @@ int cube_block_fwd_fused(hipStream_t s, const CubeFusedArgs& a) {
   const int R = a.ol * a.K;
   const int nmt = (R + 63) / 64;
   if (nmt < 1 || nmt > 3) return set_error(MIMRL_ERR_ARG, "cube_fused: unsupported row count %d", R);
-  const Carve cv = carve(a.K, nmt);
+  static const int groups = getenv("MIMRL_CUBE_FWD_GROUPS") ? atoi(getenv("MIMRL_CUBE_FWD_GROUPS")) : 2;   // tuning knob: wave groups per workgroup
+  const int G = groups == 1 ? 1 : 2;
+  const Carve cv = carve(a.K, nmt, G);
   if (cv.total > 160 * 1024) return set_error(MIMRL_ERR_ARG, "cube_fused: LDS budget exceeded (%d B)", cv.total);
-#define LAUNCH_FUSED(SAVE, NMT)                                                                                    \
+#define LAUNCH_FUSED(SAVE, NMT, GG)                                                                                \
   do {                                                                                                             \
-    auto kern = cube_fwd_fused_kernel<SAVE, NMT>;                                                                  \
+    auto kern = cube_fwd_fused_kernel<SAVE, NMT, GG>;                                                              \
     HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, cv.total)); \
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), cv.total, s, a);                                                \
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256 * GG), cv.total, s, a);                                           \
   } while (0)
-  if (a.save) {
-    if (nmt == 1) LAUNCH_FUSED(true, 1); else if (nmt == 2) LAUNCH_FUSED(true, 2); else LAUNCH_FUSED(true, 3);
-  } else {
-    if (nmt == 1) LAUNCH_FUSED(false, 1); else if (nmt == 2) LAUNCH_FUSED(false, 2); else LAUNCH_FUSED(false, 3);
-  }
+#define LAUNCH_NMT(SAVE, GG)                                                                                       \
+  do {                                                                                                             \
+    if (nmt == 1) LAUNCH_FUSED(SAVE, 1, GG); else if (nmt == 2) LAUNCH_FUSED(SAVE, 2, GG); else LAUNCH_FUSED(SAVE, 3, GG); \
+  } while (0)
+  if (a.save) { if (G == 1) LAUNCH_NMT(true, 1); else LAUNCH_NMT(true, 2); }
+  else { if (G == 1) LAUNCH_NMT(false, 1); else LAUNCH_NMT(false, 2); }
+#undef LAUNCH_NMT
 #undef LAUNCH_FUSED
   LAUNCH_CHECK();
   return MIMRL_OK;

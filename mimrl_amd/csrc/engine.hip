@@ -914,7 +914,10 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   const long BT_ = (long)B * T;
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
   if (part != 1 && T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
-  static const bool fused_pre = getenv("MIMRL_NO_FUSED_TAIL_PRE") == nullptr;   // tuning knob: text_post + ln_relu_drop + feat_mean as one launch
+  // text_post + ln_relu_drop + feat_mean as one launch, one workgroup per (sample, slot): for short sequences, where the three
+  // launches are latency (cfg2: -15 us per tail); a workgroup walking T = 1000 rows loses to the row-parallel kernels (cfg5: +60 us)
+  static const bool fused_pre_on = getenv("MIMRL_NO_FUSED_TAIL_PRE") == nullptr;   // tuning knob
+  const bool fused_pre = fused_pre_on && T <= 128;
   if (part != 2) {
     MX(fork(0, 5));
     // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0.  Captured BEFORE the encoders although it

@@ -758,6 +758,7 @@ int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
   bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUPK_MAX;
   int ca = 0, cb = 0;
   long tiles = 0;
+  double macs = 0;
   for (int i = 0; ok && i < n; ++i) {
     const GemmDesc& d = ds[i];
     if (d.M <= 0 || d.N <= 0 || d.batch <= 0 || !d.A || !d.B || !d.C) { ok = false; break; }
@@ -766,7 +767,11 @@ int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
     ca = a; cb = b;
     if (!plain_accumulate(d) || d.alpha != 1.f || d.sc_n != 1 || d.batch_in > 0 || d.a_gap_rows || d.a_bf16 || d.b_bf16) { ok = false; break; }
     tiles += (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+    macs += (double)d.M * d.N * d.K * d.batch;
   }
+  // large products fill the chip on their own and want the 128-wide tiles of the single launches (measured: grouping costs
+  // 90 us at cfg3 and 100 us at cfg5, saves 50 us at cfg2)
+  if (macs > 3e9) ok = false;
   if (!ok) {
     for (int i = 0; i < n; ++i) MX(gemm(s, ds[i], bf16));
     return MIMRL_OK;
