@@ -155,6 +155,12 @@ def extra_schedules(eng, args, B, T, rank):
         eng.set_stage2_prefetch(False)
         extra["ms_per_step_sequential"] = timed(eng.step, n_x)
         eng.set_stage2_prefetch(True)
+    if not args.no_prefetch:
+        # the launch structure every rank runs at N > 1 (dist.ddp_two_stage_step: per-stage gradient graphs, deferred stage-2
+        # forward tail, separate apply launches), here with world = 1, i.e. WITHOUT the two collectives: what the split costs
+        eng.set_stage2_prefetch(2)
+        extra["ms_per_step_ddp_schedule_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
+        eng.set_stage2_prefetch(True)
     host = [tuple(torch.from_numpy(x).pin_memory() for x in synth.synthetic_batch(B, T, seed=100 + i)) for i in range(4)]
     state = {"i": 0}
     eng.stage_batch(*host[0])

@@ -78,17 +78,49 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2/(exp(2x)+1); sa
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
 }
 
+// Wave-wide reductions on the VALU (DPP lane permutes), result in every lane.  __shfl_xor is ds_bpermute on gfx9 -- an LDS round trip
+// per step, six dependent ones per reduction; this is 6 DPP adds + one v_readlane.  All 64 lanes must be active (every caller reduces
+// under wave-uniform control flow).  Lanes combine as: quads, 8s, 16-lane rows, then row_bcast:15 / row_bcast:31 carry the row sums
+// into row 3, whose last lane holds the total.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef MIMRL_WAVE_SHFL
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#endif
+  v += dpp_take<0xB1>(0.f, v);          // quad_perm:[1,0,3,2]
+  v += dpp_take<0x4E>(0.f, v);          // quad_perm:[2,3,0,1]
+  v += dpp_take<0x141>(0.f, v);         // row_half_mirror
+  v += dpp_take<0x140>(0.f, v);         // row_mirror
+  v += dpp_take<0x142, 0xA>(0.f, v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xC>(0.f, v);    // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#ifdef MIMRL_WAVE_SHFL
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+#endif
+  v = fmaxf(v, dpp_take<0xB1>(v, v));
+  v = fmaxf(v, dpp_take<0x4E>(v, v));
+  v = fmaxf(v, dpp_take<0x141>(v, v));
+  v = fmaxf(v, dpp_take<0x140>(v, v));
+  v = fmaxf(v, dpp_take<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_take<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// (butterfly version through ds_bpermute: kept as the cross-check of tools/dpp_check.hip; -DMIMRL_WAVE_SHFL builds everything with it)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` = >=16 floats of LDS
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

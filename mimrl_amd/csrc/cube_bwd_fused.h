@@ -27,7 +27,11 @@ struct DAxisBwdArgs {
   const __bf16 *w2t, *w1t, *wrt;               // TRANSPOSED bf16 images [n][k] of W2[o,h], W1[h,i], Wr[o,i] (wt_transpose_bf16)
   float *dy, *du, *dx;                         // [R,128] x3
   long R;
-  int act;                                     // id == hd == od == 128; LayerNorm / bias gradients: column-sum side kernels
+  int act;                                     // id == hd == od == 128
+  // optional (all four or none): parameter gradients that are column sums over the rows of what this kernel holds anyway --
+  // dgamma = sum dz * xhat, dbeta = sum dz (LayerNorm), db2 = sum dY, db1 = sum dU; accumulated with atomics ([128] each).
+  // Null: the caller runs rowln_param_grads / colsum side kernels instead.
+  float *dgamma, *dbeta, *db2, *db1;
 };
 bool daxis_bwd_supported(int id, int hd, int od);
 int daxis_bwd_fused(hipStream_t s, const DAxisBwdArgs& a);
@@ -35,6 +39,11 @@ int daxis_bwd_fused(hipStream_t s, const DAxisBwdArgs& a);
 // dst[m][n][k] = bf16(src[m][k][n]) for up to 12 square 128x128 matrices (one launch per stage, off the critical path)
 struct WtTransposeArgs { const float* src[12]; __bf16* dst[12]; int n; };
 int wt_transpose_bf16(hipStream_t s, const WtTransposeArgs& a);
+
+// the four column-sum parameter gradients of the D axis (rows x 128) in one streaming pass: dgamma = sum dz * xhat, dbeta = sum dz,
+// db2 = sum dY, db1 = sum dU (db2 / db1 may be null); accumulated with atomics
+int daxis_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, const float* dy,
+                      const float* du, float* dgamma, float* dbeta, float* db2, float* db1, long R);
 
 // LayerNorm(D) parameter gradients as column sums over rows: dgamma[j] = sum_r dz * xhat, dbeta[j] = sum_r dz
 int rowln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,

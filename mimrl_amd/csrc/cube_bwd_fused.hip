@@ -183,8 +183,11 @@ constexpr int DP = 128 + 8;    // bf16 pitch (272 B)
 __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sdy[DR][DP];
   __shared__ __attribute__((aligned(16))) __bf16 sdu[DR][DP];
+  __shared__ float spg[3][128];     // this workgroup's column sums: dgamma, dbeta, db2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const long r0 = (long)blockIdx.x * DR;
+  const bool pg = a.dgamma != nullptr;
+  if (pg) for (int i = tid; i < 3 * 128; i += 256) (&spg[0][0])[i] = 0.f;   // (visible after the barrier behind phase 1... see below)
   // B-fragments of this wave's 32 output columns, all three products, issued before anything else
   const int n = wave * 32 + lr;
   bf16x8 bw2[8], bw1[8], bwr[8];
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
     const long r = r0 + row;
     const bool ok = r < a.R;
     const long rc = ok ? r : a.R - 1;
-    float g[16], xh[16];
+    float g[16], xh[16], dyk[16];
     float s1 = 0.f, s2 = 0.f;
     const float mu = a.mean[rc], rs = a.rstd[rc];
 #pragma unroll
@@ -239,6 +242,22 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
       if (ok) *reinterpret_cast<float4*>(a.dy + r * 128 + part * 16 + q * 4) = make_float4(v[0], v[1], v[2], v[3]);
       bf16x4 p; p[0] = to_bf16(v[0]); p[1] = to_bf16(v[1]); p[2] = to_bf16(v[2]); p[3] = to_bf16(v[3]);
       *reinterpret_cast<bf16x4*>(&sdy[row][part * 16 + q * 4]) = p;
+      if (pg) {   // keep dY in g[] for the column sums below (dz is no longer needed once dgamma / dbeta terms are formed)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float gz = ok ? g[q * 4 + j] : 0.f; xh[q * 4 + j] *= gz; g[q * 4 + j] = gz; v[j] = ok ? v[j] : 0.f; }
+        dyk[q * 4 + 0] = v[0]; dyk[q * 4 + 1] = v[1]; dyk[q * 4 + 2] = v[2]; dyk[q * 4 + 3] = v[3];
+      }
+    }
+    if (pg) {
+      // column sums over this wave's 8 rows (lanes row*8 + part: xor 8, 16, 32), then one LDS atomic per column and wave
+      __syncthreads();                 // spg zeroed
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float sa = xh[j], sb = g[j], sc = dyk[j];
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); sc += __shfl_xor(sc, o, 64); }
+        if (lane < 8) { atomicAdd(&spg[0][part * 16 + j], sa); atomicAdd(&spg[1][part * 16 + j], sb); atomicAdd(&spg[2][part * 16 + j], sc); }
+      }
     }
   }
   __syncthreads();
@@ -252,6 +271,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
       const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sdy[lr][ks * 16 + 8 * lh]);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw2[ks], acc, 0, 0, 0);
     }
+    float csum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -262,9 +282,19 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
         a.du[row * 128 + n] = v;
       }
       sdu[m][n] = to_bf16(v);
+      csum += v;
+    }
+    if (pg) {   // db1[n] = sum over this tile's rows of dU (rows beyond R contributed zeros)
+      csum += __shfl_xor(csum, 32, 64);
+      if (lh == 0) atomicAdd(&a.db1[n], csum);
     }
   }
   __syncthreads();
+  if (pg && tid < 128) {   // (spg complete: every wave's LDS atomics precede the barrier behind phase 1)
+    atomicAdd(&a.dgamma[tid], spg[0][tid]);
+    atomicAdd(&a.dbeta[tid], spg[1][tid]);
+    atomicAdd(&a.db2[tid], spg[2][tid]);
+  }
   // ---- phase 3: dX = dU W1 + dY Wr
   {
     f32x16 acc;
@@ -311,12 +341,66 @@ __global__ void rowln_param_grads_kernel(const float* __restrict__ y, const floa
   atomicAdd(&dbeta[j], sb);
 }
 
+// All four column-sum parameter gradients of the D axis in one streaming pass over dz, y, dY, dU ([R,128] each):
+//   dgamma = sum dz * xhat, dbeta = sum dz, db2 = sum dY, db1 = sum dU.
+// Workgroup = 64 rows: thread = (column quad, row lane), 8 rows each with 16-byte loads; LDS reduction over the 8 row lanes,
+// then 512 atomics.  (Replaces rowln_param_grads + 2 x colsum: 3 launches of 30-40 us each at R = 19,200.)
+__global__ __launch_bounds__(256) void daxis_param_grads_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ dz,
+                                                                const float* __restrict__ dy, const float* __restrict__ du,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ db2, float* __restrict__ db1, long R) {
+  __shared__ float4 red[4][8][32];
+  const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const long r0 = (long)blockIdx.x * 64;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long r = r0 + rl + 8 * i;
+    const long rc = r < R ? r : R - 1;             // unconditional loads from a clamped row, zeroed afterwards
+    const float m = r < R ? 1.f : 0.f;
+    const float mu = mean[rc], rs = rstd[rc] * m;
+    const float4 g = *reinterpret_cast<const float4*>(dz + rc * 128 + cq * 4);
+    const float4 yv = *reinterpret_cast<const float4*>(y + rc * 128 + cq * 4);
+    const float4 v = *reinterpret_cast<const float4*>(dy + rc * 128 + cq * 4);
+    const float4 u = *reinterpret_cast<const float4*>(du + rc * 128 + cq * 4);
+    a0.x += g.x * (yv.x - mu) * rs; a0.y += g.y * (yv.y - mu) * rs; a0.z += g.z * (yv.z - mu) * rs; a0.w += g.w * (yv.w - mu) * rs;
+    a1.x += g.x * m; a1.y += g.y * m; a1.z += g.z * m; a1.w += g.w * m;
+    a2.x += v.x * m; a2.y += v.y * m; a2.z += v.z * m; a2.w += v.w * m;
+    a3.x += u.x * m; a3.y += u.y * m; a3.z += u.z * m; a3.w += u.w * m;
+  }
+  red[0][rl][cq] = a0; red[1][rl][cq] = a1; red[2][rl][cq] = a2; red[3][rl][cq] = a3;
+  __syncthreads();
+  // 512 sums of 8: thread t -> quantity t >> 6 (and + 4 ... no: 256 threads, two sums each)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int idx = threadIdx.x + 256 * h, q = idx >> 7, c = idx & 127;
+    const float* base = reinterpret_cast<const float*>(&red[q][0][0]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += base[j * 128 + c];
+    float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : (q == 2 ? db2 : db1));
+    if (dst) atomicAdd(&dst[c], sum);
+  }
+}
+
 }  // namespace
+
+int daxis_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, const float* dy,
+                      const float* du, float* dgamma, float* dbeta, float* db2, float* db1, long R) {
+  if (R <= 0) return MIMRL_OK;
+  hipLaunchKernelGGL(daxis_param_grads_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, s, y, mean, rstd, dz, dy, du, dgamma, dbeta,
+                     db2, db1, R);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
 
 bool daxis_bwd_supported(int id, int hd, int od) { return id == 128 && hd == 128 && od == 128; }
 
 int daxis_bwd_fused(hipStream_t s, const DAxisBwdArgs& a) {
   if (!a.w2t || !a.w1t || !a.wrt) return set_error(MIMRL_ERR_ARG, "daxis_bwd_fused: needs the transposed weight images");
+  if ((a.dgamma || a.dbeta || a.db2 || a.db1) && !(a.dgamma && a.dbeta && a.db2 && a.db1))
+    return set_error(MIMRL_ERR_ARG, "daxis_bwd_fused: the four parameter-gradient outputs come together");
   hipLaunchKernelGGL(daxis_bwd_kernel, dim3((unsigned)((a.R + DR - 1) / DR)), dim3(256), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;

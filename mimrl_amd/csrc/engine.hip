@@ -425,7 +425,8 @@ struct mimrl_handle {
   // weight-gradient work parked by cube_backward and issued on the side streams once the data-gradient chain is through
   // (it then overlaps the latency-bound GRU BPTT instead of competing with the chain for CUs and L2)
   struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst;
-                    const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW(); };
+                    const float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; float* dst2 = nullptr; KMixW kw = KMixW();
+                    const float *p4 = nullptr, *p5 = nullptr; float *dst3 = nullptr, *dst4 = nullptr; };
   std::vector<Deferred> deferred;
   int flush_deferred(int only_side = 0, hipEvent_t after = nullptr);
   int wg_helper = -1;                  // side stream that takes every second weight-gradient GEMM of an MLP stack (-1: none)
@@ -1160,6 +1161,16 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     }
     return rowln_param_grads(S(sd), y, mean, rstd, dz, dgam, dbet, rows, n);
   };
+  auto W_dpg = [&](int sd, const float* y, const float* mean, const float* rstd, const float* dz, const float* dy, const float* du,
+                   float* dgam, float* dbet, float* db2, float* db1, long rows) -> int {
+    if (defer) {
+      Deferred d{6, sd, GemmDesc(), y, rows, 0, 0, 0, dgam};
+      d.p1 = mean; d.p2 = rstd; d.p3 = dz; d.p4 = dy; d.p5 = du; d.dst2 = dbet; d.dst3 = db2; d.dst4 = db1;
+      deferred.push_back(d);
+      return MIMRL_OK;
+    }
+    return daxis_param_grads(S(sd), y, mean, rstd, dz, dy, du, dgam, dbet, db2, db1, rows);
+  };
   auto W_fork = [&](int lo, int hi) -> int { return defer ? MIMRL_OK : fork(lo, hi); };
   // transposed bf16 images of the D-axis weights for the fused data-gradient kernels (one small launch; in a combined step
   // it already ran at step start on side 0, off this chain)
@@ -1188,14 +1199,25 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       fa.w2t = wtT[i][0]; fa.w1t = wtT[i][1]; fa.wrt = wtT[i][2];
       fa.dy = gbuf[i_dy]; fa.du = gbuf[i_du]; fa.dx = gbuf[i_dx];
       fa.R = R2; fa.act = cfg.activation;
+      // LayerNorm and bias gradients (column sums over the rows of dz, y, dY, dU).  Folded into the data-gradient kernel they cost
+      // the chain 13 us per block (MIMRL_DAXIS_PG_FUSE=1: 19 -> 32 us); as ONE streaming side kernel instead of rowln_param_grads +
+      // 2 x colsum (3 launches of 30-40 us each) they are ~10 us beside the BPTT (MIMRL_NO_DAXIS_PG_ONE=1: the three launches)
+      static const bool pg_fuse = getenv("MIMRL_DAXIS_PG_FUSE") != nullptr;        // tuning knobs
+      static const bool no_pg_one = getenv("MIMRL_NO_DAXIS_PG_ONE") != nullptr;
+      const bool pg_fused = pg_fuse && a.fc2.b >= 0 && a.fc1.b >= 0;
+      const bool pg_one = !pg_fused && !no_pg_one;
+      fa.dgamma = fa.dbeta = fa.db2 = fa.db1 = nullptr;
+      if (pg_fused) { fa.dgamma = Gm(a.ln_g); fa.dbeta = Gm(a.ln_b); fa.db2 = Gm(a.fc2.b); fa.db1 = Gm(a.fc1.b); }
       MX(daxis_bwd_fused(stream, fa));
       MX(W_fork(1, 3));
-      MX(W_lnrow(2, b.d.y, b.d.mean, b.d.rstd, gbuf[cur], Gm(a.ln_g), Gm(a.ln_b), R2, od));
+      if (pg_one) MX(W_dpg(2, b.d.y, b.d.mean, b.d.rstd, gbuf[cur], gbuf[i_dy], gbuf[i_du], Gm(a.ln_g), Gm(a.ln_b),
+                           a.fc2.b >= 0 ? Gm(a.fc2.b) : nullptr, a.fc1.b >= 0 ? Gm(a.fc1.b) : nullptr, R2));
+      if (!pg_fused && !pg_one) MX(W_lnrow(2, b.d.y, b.d.mean, b.d.rstd, gbuf[cur], Gm(a.ln_g), Gm(a.ln_b), R2, od));
       { GemmDesc g = gemm_tn(gbuf[i_dy], od, b.d.h, hd, Gm(a.fc2.w), hd, od, hd, (int)R2); g.atomic = 1; MX(W_gemm(1, g)); }
-      if (a.fc2.b >= 0) MX(W_colsum(1, gbuf[i_dy], R2, od, od, Gm(a.fc2.b)));
+      if (!pg_fused && !pg_one && a.fc2.b >= 0) MX(W_colsum(1, gbuf[i_dy], R2, od, od, Gm(a.fc2.b)));
       { GemmDesc g = gemm_tn(gbuf[i_dy], od, b.k.z, id, Gm(a.res), id, od, id, (int)R2); g.atomic = 1; MX(W_gemm(2, g)); }
       { GemmDesc g = gemm_tn(gbuf[i_du], hd, b.k.z, id, Gm(a.fc1.w), id, hd, id, (int)R2); g.atomic = 1; MX(W_gemm(3, g)); }
-      if (a.fc1.b >= 0) MX(W_colsum(3, gbuf[i_du], R2, hd, hd, Gm(a.fc1.b)));
+      if (!pg_fused && !pg_one && a.fc1.b >= 0) MX(W_colsum(3, gbuf[i_du], R2, hd, hd, Gm(a.fc1.b)));
       MX(W_join(1, 3));
       release(cur); release(i_dy); release(i_du);
       cur = i_dx;
@@ -1271,6 +1293,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
         MX(kmix_bwd_part(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id, 1));
         Deferred d{5, 2, GemmDesc(), b.l.z, (long)B * ol, id, 0, 0, nullptr};
         d.p3 = gbuf[cur]; d.kw = kw;
+        static const int kdbg = getenv("MIMRL_DBG_KMIX") ? atoi(getenv("MIMRL_DBG_KMIX")) : 0;
+        d.kw.dbg = kdbg;
         deferred.push_back(d);
       } else {
         MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
@@ -1427,7 +1451,9 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   // the weight-gradient GEMMs as (at most) two grouped split-K launches, one per operand-layout class: D-axis products are
   // (RC,RC), the batch-reduced L-axis products (KC,KC).  Alone each is a ~20 us launch of 4..64 tiles.
   static const bool no_wg_groupk = getenv("MIMRL_NO_WG_GROUPK") != nullptr;   // tuning knob
-  const bool groupk = !no_wg_groupk && !prof_on && bf16 && !((dbg_skip_kinds >> 0) & 1);
+  // (short sequences only: at T = 1000 the recurrence beside them runs for a millisecond, launch latencies are hidden and one
+  // chip-filling launch in front of the BPTT costs more than it saves -- cfg5: 3.85 vs 3.74 ms)
+  const bool groupk = !no_wg_groupk && !prof_on && bf16 && !((dbg_skip_kinds >> 0) & 1) && cfg.seq_len <= 128;
   if (groupk) {
     std::vector<GemmDesc> cls[2];
     for (const Deferred& d : deferred) if (d.kind == 0) cls[d.g.sa_k == 1 ? 0 : 1].push_back(d.g);
@@ -1446,6 +1472,7 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
     else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 3) MX(colln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, (int)d.n0, (int)d.n1, (int)d.n2));
     else if (d.kind == 4) MX(rowln_param_grads(st, d.src, d.p1, d.p2, d.p3, d.dst, d.dst2, d.n0, (int)d.n1));
+    else if (d.kind == 6) MX(daxis_param_grads(st, d.src, d.p1, d.p2, d.p3, d.p4, d.p5, d.dst, d.dst2, d.dst3, d.dst4, d.n0));
     else MX(kmix_bwd_part(st, d.src, d.p3, nullptr, d.kw, d.n0, (int)d.n1, 2));
   }
   deferred.clear();
@@ -1534,7 +1561,12 @@ int mimrl_handle::model_backward() {
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
     if (l == 1 && ev_pre) MX(flush_deferred(0, ev_pre));
     MX(dbg_delay(stream, 8));
-    MX(fork(1, l == 0 ? 5 : 3));   // the weight gradients below depend on the BPTT only
+    // side streams of the GRU weight gradients (tuning knobs).  Sides 1..3 still carry the parked CubeMLP parameter-gradient
+    // kernels at this point; sides 0 (text branch), 4 and 5 (kNN sampler, CMI branch) have been idle since the forward pass.
+    static const int l0_side = getenv("MIMRL_L0_WG_SIDE") ? atoi(getenv("MIMRL_L0_WG_SIDE")) : 1;
+    static const int l1_side0 = getenv("MIMRL_L1_WG_SIDE") ? atoi(getenv("MIMRL_L1_WG_SIDE")) : 1;
+    MX(fork(1, (l == 0 || l1_side0 == 4) ? 5 : 3));   // the weight gradients below depend on the BPTT only
+    if (l0_side == 0 && l == 0) MX(fork(0, 0));
     static const bool dh0_last = getenv("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
     auto dh0_gemm = [&]() -> int {   // gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
       // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
@@ -1568,8 +1600,8 @@ int mimrl_handle::model_backward() {
         q.a_gap_at = 2 * H; q.a_gap_rows = H;
         q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = s_hp; q.sb_bo = o_hp; q.sc_b = (long)G * H; q.sc_bo = 2L * G * H;
         if (lbf) { q.a_bf16 = q.b_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; q.sb_b *= 2; q.sb_bo *= 2; }
-        q.atomic = 1; MX(G_on(S(1), q)); }
-      MX(join(1, 1));
+        q.atomic = 1; MX(G_on(S(l0_side), q)); }
+      MX(join(l0_side, l0_side));
       L0Unpack up;
       for (int m = 0; m < 2; ++m) {
         up.d[m] = gru[m][0][0].din;
@@ -1593,7 +1625,7 @@ int mimrl_handle::model_backward() {
       const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
       static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 1;   // tuning knobs
       static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
-      auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return S(1 + rr++ % wg_sides); };
+      auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return l1_side0 == 4 ? S(4 + rr++ % 2) : S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih);
         if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; }

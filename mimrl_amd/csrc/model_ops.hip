@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < NK; ++j) aw1[i][j] = aw2[i][j] = awr[i][j] = 0.f;
   }
-  const long total = R * D;
+  const long total = (GRADS && (w.dbg & 1)) ? 0 : R * D;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / D; const int d = i % D;
     KMixVals<NK> v;
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
   }
   __syncthreads();
   const int t = threadIdx.x;
+  if (w.dbg & 2) return;
   if (t < w.hk * w.ik) atomicAdd(&w.dw1[t], gw1[(t / w.ik) * KM + t % w.ik]);
   if (t < w.hk && w.db1) atomicAdd(&w.db1[t], gb1[t]);
   if (t < w.ok * w.hk) atomicAdd(&w.dw2[t], gw2[(t / w.hk) * KM + t % w.hk]);
@@ -854,7 +855,13 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
     if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else hipLaunchKernelGGL((kmix_bwd_kernel<8, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
   } else {
-    const dim3 grid(grid_for(R * D, 256, 128));
+    // workgroup count (tuning knob).  The kernel is ~33 us of fixed cost (weight staging, 64 wave reductions, LDS and global
+    // atomics) + ~25 us of element work at cfg2; 256 workgroups is the measured optimum (128: 67 us, 256: 53 us, 512: 75 us).  A
+    // two-level reduction through scratch slots with a last-arriver finisher was tried and lost (the __threadfence it needs is an
+    // L2 write-back on this multi-XCD part: 157 us).
+    static const int pg_wgs = getenv("MIMRL_KMIX_PG_WGS") ? atoi(getenv("MIMRL_KMIX_PG_WGS")) : 256;
+    const int cap = pg_wgs > 0 ? pg_wgs : 256;
+    const dim3 grid(grid_for(R * D, 256, cap));
     if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else hipLaunchKernelGGL((kmix_bwd_kernel<8, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
   }

@@ -45,5 +45,8 @@ def lr_scale(c, epoch):
 # 4e-3 (and already at 1e-3) Adam's early ~lr*sign(g) updates amplify fp32 summation-order noise chaotically -- the
 # reference, the fp32 oracle and the fp64 oracle then disagree by O(0.1) in the features after ONE epoch (measured), so
 # nothing could be pinned.  At 1e-4 the oracle tracks the reference's own Solver to <= 3e-3 over three epochs.
+# Bank entries / predictions in epoch 0 (third value): one Adam sign flip on a gradient entry that is zero to fp32 noise moves that
+# parameter by 2 lr after its first update and a post-ReLU bank entry of the last batches by ~2e-3 (seen on hardware when only the
+# summation order of the wave reductions changed), hence 3e-3 there rather than 1e-3.
 def bands(epoch):
-    return (1e-3, 2e-5, 1e-3) if epoch == 0 else (3e-3, 3e-4, 1e-2)
+    return (1e-3, 2e-5, 3e-3) if epoch == 0 else (3e-3, 3e-4, 1e-2)

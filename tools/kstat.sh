@@ -11,6 +11,7 @@ for ks in "$@"; do
 import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if re.search(sys.argv[2], r["Name"]):
-        print("   %-50s calls %5s avg_us %7.1f" % (r["Name"].split("(")[0][-50:], r["Calls"], float(r["AverageNs"]) / 1e3))
+        nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("mimrl::", "")
+        print("   %-50s calls %5s avg_us %7.1f" % (nm.split("(")[0][:50], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
