@@ -100,6 +100,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_take<0x143, 0xC>(0.f, v);    // row_bcast:31 into rows 2 and 3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum over aligned groups of N = 2, 4, 8 or 16 lanes, result in every lane of the group
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(N == 2 || N == 4 || N == 8 || N == 16, "group_sum: 2, 4, 8 or 16 lanes");
+  v += dpp_take<0xB1>(0.f, v);
+  if (N >= 4) v += dpp_take<0x4E>(0.f, v);
+  if (N >= 8) v += dpp_take<0x141>(0.f, v);
+  if (N >= 16) v += dpp_take<0x140>(0.f, v);
+  return v;
+}
+// sum over each half of the wave (the 32 lanes that share lane >> 5); the result is valid in the UPPER 16 lanes of each half only
+// (lanes 16..31 and 48..63)
+__device__ __forceinline__ float half_sum_hi(float v) {
+  v = group_sum<16>(v);
+  v += dpp_take<0x142, 0xA>(0.f, v);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #ifdef MIMRL_WAVE_SHFL
 #pragma unroll

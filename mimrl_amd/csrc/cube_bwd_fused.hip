@@ -8,12 +8,6 @@ namespace {
 constexpr int CT = 128;       // L axis: columns per workgroup
 constexpr int KP = 64 + 8;    // bf16 pitch of a [.][<=64] operand image (144 B: conflict-free 16-byte fragment reads)
 
-__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes that share lane>>5
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // L axis.  Workgroup = (sample b, 128 columns).  MFMA 32x32x16: M = rows of the transposed weight (h or i), N = columns,
 // K = o or h.  dY / dU are kept TRANSPOSED in LDS ([column][k]) so that B-fragments are 16-byte reads; the weights
@@ -120,8 +114,8 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
         }
         sdu[nt * 32 + lr][h] = to_bf16(v);
         if (a.db1) {
-          const float t = half_sum32(v);
-          if (lr == 0 && h < hl) atomicAdd(&acc_h[h], t);
+          const float t = half_sum_hi(v);                        // (valid in lanes 16..31 / 48..63)
+          if (lr == 16 && h < hl) atomicAdd(&acc_h[h], t);
         }
       }
   }
@@ -228,8 +222,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
         s1 += dxh; s2 += dxh * xh[q * 4 + j];
       }
     }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 = group_sum<8>(s1); s2 = group_sum<8>(s2);
     s1 *= (1.f / 128.f); s2 *= (1.f / 128.f);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

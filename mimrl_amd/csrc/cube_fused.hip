@@ -407,14 +407,12 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
         yv[4 * j] = q.x; yv[4 * j + 1] = q.y; yv[4 * j + 2] = q.z; yv[4 * j + 3] = q.w;
         s0 += (q.x + q.y) + (q.z + q.w);
       }
-#pragma unroll
-      for (int o = 1; o < TPR; o <<= 1) s0 += __shfl_xor(s0, o, 64);
+      s0 = group_sum<TPR>(s0);
       const float mu = s0 * (1.f / D);
       float v0 = 0.f;
 #pragma unroll
       for (int j = 0; j < CW; ++j) { const float c = yv[j] - mu; v0 += c * c; }
-#pragma unroll
-      for (int o = 1; o < TPR; o <<= 1) v0 += __shfl_xor(v0, o, 64);
+      v0 = group_sum<TPR>(v0);
       const float rs = rsqrtf(v0 * (1.f / D) + LN_EPS);
       if (row < R) {
         const long o = ((long)b * R + row) * D + part * CW;
