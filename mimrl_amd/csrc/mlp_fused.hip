@@ -28,12 +28,13 @@ __device__ __forceinline__ bf16x8 pack8(const float4& x, const float4& y) {
 
 // rows [r0, r0+32) x [0, width) of a [.., width] fp32 matrix -> bf16 tile; rows >= rows_valid and columns up to the
 // next multiple of 16 are zero
+template <int NT = 256>
 __device__ __forceinline__ void load_tile_bf16(const float* __restrict__ src, long rowbase, int r0, int rows_valid, int width,
                                                __bf16 (*t)[LDA], int tid) {
   const int w16 = (width + 15) & ~15;
   if ((width & 3) == 0) {
     const int q = w16 / 4;
-    for (int i = tid; i < RT * q; i += 256) {
+    for (int i = tid; i < RT * q; i += NT) {
       const int r = i / q, c = (i - r * q) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r0 + r < rows_valid && c < width) v = *reinterpret_cast<const float4*>(src + (rowbase + r) * width + c);
@@ -41,7 +42,7 @@ __device__ __forceinline__ void load_tile_bf16(const float* __restrict__ src, lo
       *reinterpret_cast<bf16x4*>(&t[r][c]) = p;
     }
   } else {
-    for (int i = tid; i < RT * w16; i += 256) {
+    for (int i = tid; i < RT * w16; i += NT) {
       const int r = i / w16, c = i - r * w16;
       t[r][c] = to_bf16((r0 + r < rows_valid && c < width) ? src[(rowbase + r) * width + c] : 0.f);
     }
@@ -352,6 +353,184 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 8-wave variant of the image kernel for SMALL stacks (tens of workgroups: the separable critic towers and the CMI classifiers
+// at B <= 256), where the 4-wave kernel is a chain of memory round trips: per layer every wave streamed two 32-row weight tiles
+// through its LDS slab, two 64-k chunks in flight, i.e. two dependent L2 round trips per layer and four layers in a row.
+// Here a wave owns ONE 32-column output tile per layer (tile = wave; a second one, wave + 8, only where N = 384), holds the whole
+// [32 x K] weight tile of the CURRENT layer in registers (K <= 384: 24 x 16 B per lane) and re-fills those registers with the
+// NEXT layer's tile while the current one is staged and multiplied chunk by chunk -- weights do not depend on activations, so
+// the only exposed round trip is the first layer's.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W8_MAXCH = MLPF_MAX_WIDTH / WCH;   // 6 chunks of 64 k
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// compile-time loop: the register tile below must only ever be indexed with constants (a runtime index sends it to scratch)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <bool BWD, int NCH>   // NCH: 64-k chunks held in registers (4: every reduction width <= 256; 6: <= 384)
+__global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
+  __shared__ __attribute__((aligned(16))) __bf16 wl[8][2][32][WLD];      // [wave][buffer][row][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = (a.rows + RT - 1) / RT;
+  const int xslot = blockIdx.x >> 3;
+  const int g = (blockIdx.x & 7) + 8 * (xslot / tiles);      // a group (one weight set) is pinned to one XCD
+  const int r0 = (xslot % tiles) * RT;
+  if (g >= a.nb) return;
+  const long rowbase = (long)g * a.brows + r0;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int srow = lane >> 3, sk = (lane & 7) * 8;            // staging map: 8 rows x 64 k (bf16) per 16-byte instruction
+  // ragged last row tile: loads use a clamped row = min(uniform part, rclamp) + lhoff (<= rows_here - 1), stores are guarded
+  const int rows_here = min(RT, a.rows - r0);
+  const int lhoff = min(4 * lh, rows_here - 1), rclamp = max(rows_here - 5, 0);
+
+  // geometry of the layer processed at `step`
+  auto layer_of = [&](int step) { return BWD ? a.nl - 1 - step : step; };
+  auto K_of = [&](int l) { return BWD ? a.dims[l + 1] : a.dims[l]; };
+  auto N_of = [&](int l) { return BWD ? a.dims[l] : a.dims[l + 1]; };
+  auto W_of = [&](int l) { return (BWD ? a.WbT[l] : a.Wb[l]) + (long)g * a.pstride; };
+  auto has_target = [&](int l) { return !BWD || (l > 0 ? a.dz[l] != nullptr : a.din != nullptr); };
+
+  // this wave's weight tile of one layer: chunk c = k in [64c, 64c+64), rows i*8 + srow.  Six separate arrays picked at compile
+  // time, of a native vector type: HIP's uint4 is a struct whose assignment is a memcpy, and an array of them that lives across
+  // the layer loop is not promoted to registers (384 B of scratch per lane)
+  u32x4 rg0[4], rg1[4], rg2[4], rg3[4], rg4[4], rg5[4];
+  static_assert(W8_MAXCH == 6, "six register chunks");
+#define RG(c) (c == 0 ? rg0 : c == 1 ? rg1 : c == 2 ? rg2 : c == 3 ? rg3 : c == 4 ? rg4 : rg5)
+  // request the whole tile `nt` of layer l (zeros beyond the layer's K / tiles and for the FMA-path layers; clamped rows are
+  // never stored).  Every condition is wave-uniform.
+  auto fetch_layer = [&](int l, int nt) __attribute__((always_inline)) {
+    const int K = K_of(l), N = N_of(l);
+    const __bf16* __restrict__ W = W_of(l);
+    const bool any = K >= 16 && nt * 32 < N;
+    static_for<0, NCH>([&](auto C) __attribute__((always_inline)) {
+      constexpr int c = decltype(C)::value;
+      if (any && c * WCH < K) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RG(c)[i] = *reinterpret_cast<const u32x4*>(W + (long)min(nt * 32 + i * 8 + srow, N - 1) * K + c * WCH + sk);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) RG(c)[i] = u32x4{0u, 0u, 0u, 0u};
+      }
+    });
+  };
+  // first layer's weights: in flight under the activation tile load
+  fetch_layer(layer_of(0), wave);
+
+  load_tile_bf16<512>(BWD ? a.dout : a.in, rowbase, r0, a.rows, BWD ? a.dims[a.nl] : a.dims[0], sa[0], tid);
+  if (BWD && a.db_top && tid < a.dims[a.nl]) {   // top-layer bias gradient: column sums of this tile's dout rows (fp32 source, L2-hot)
+    const int w = a.dims[a.nl];
+    const int nr = min(RT, a.rows - r0);
+    float s = 0.f;
+    for (int r = 0; r < nr; ++r) s += a.dout[(rowbase + r) * w + tid];
+    atomicAdd(a.db_top + (long)g * a.pstride + tid, s);
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 1
+  for (int step = 0; step < a.nl; ++step) {
+    const int l = layer_of(step);
+    if (!has_target(l)) break;
+    const int K = K_of(l), N = N_of(l);
+    float* __restrict__ dst = BWD ? (l > 0 ? a.dz[l] : a.din) : (l == a.nl - 1 ? a.out : a.act[l]);
+    const __bf16* __restrict__ W = W_of(l);
+    const bool last = BWD ? l == 0 : l == a.nl - 1;
+    const int ntiles = (N + 31) / 32;
+    const bool more = step + 1 < a.nl && has_target(layer_of(step + 1));
+    const int ln = more ? layer_of(step + 1) : l;
+    const float* __restrict__ mask = (BWD && l > 0 && !(a.dbg & 1)) ? a.act[l - 1] : nullptr;
+    const float* __restrict__ bias = BWD ? nullptr : a.b[l] + (long)g * a.pstride;
+    float* __restrict__ db = (BWD && l > 0 && a.db[l - 1] && !(a.dbg & 2)) ? a.db[l - 1] + (long)g * a.pstride : nullptr;
+    const int npass = ntiles > 8 ? 2 : 1;      // a second tile per wave only where N = 384 (input gradient of the CMI classifiers)
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+      const int nt = wave + 8 * pass;
+      const bool mine = nt < ntiles;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // ReLU mask of the data-gradient chain (= forward activations of the layer below) and the forward bias: requested before
+      // the products, unconditional clamped addresses
+      // (addresses = wave-uniform row pointer + ONE 32-bit lane offset shared by the 16 accesses: as 16 per-lane 64-bit addresses
+      //  they cost 32 registers per access group and the backward instantiation spilled)
+      float mk[16];
+      if (BWD && mask) {
+        const unsigned loff = (unsigned)(lhoff * N + min(nt * 32 + lr, N - 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* __restrict__ mrow = mask + (rowbase + min((r & 3) + 8 * (r >> 2), rclamp)) * (long)N;
+          mk[r] = mrow[loff];
+        }
+      }
+      const float bn = bias ? bias[min(nt * 32 + lr, N - 1)] : 0.f;
+      if (K < 16) {
+        // degenerate reduction (the 2-logit top layer of the CMI classifier, backward): plain FMAs
+        const int n = nt * 32 + lr;
+        if (mine && n < N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = 0.f;
+            for (int kk = 0; kk < K; ++kk) v += (float)sa[cur][m][kk] * (float)W[(long)n * K + kk];
+            acc[r] = v;
+          }
+        }
+      } else {
+        const int nchunk = (K + WCH - 1) / WCH;
+        // the tile is in registers: stage chunk c into the wave's slab (two buffers alternate), multiply
+        static_for<0, NCH>([&](auto C) __attribute__((always_inline)) {
+          constexpr int c = decltype(C)::value;
+          if (c < nchunk && mine) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&wl[wave][c & 1][i * 8 + srow][sk]) = RG(c)[i];
+#pragma unroll
+            for (int u = 0; u < WCH / 16; ++u) {
+              if (c * WCH + u * 16 < K) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sa[cur][lr][c * WCH + u * 16 + 8 * lh]);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&wl[wave][c & 1][lr][u * 16 + 8 * lh]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc, 0, 0, 0);
+              }
+            }
+          }
+        });
+      }
+      // the registers are free again: the next tile (this layer's second one, else the next layer's) is requested now and arrives
+      // under the epilogue and the barrier
+      if (pass + 1 < npass) fetch_layer(l, wave + 8);
+      else if (more) fetch_layer(ln, wave);
+      // epilogue
+      const int n = nt * 32 + lr;
+      if (mine && n < N) {
+        float csum = 0.f;
+        const unsigned soff = (unsigned)(4 * lh * N + n);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mu = (r & 3) + 8 * (r >> 2), m = mu + 4 * lh;
+          const bool ok = m < rows_here;
+          float v = acc[r] + bn;
+          if (BWD) { if (mask) v = (ok && mk[r] > 0.f) ? v : 0.f; }
+          else if (!last) v = fmaxf(v, 0.f);
+          float* __restrict__ drow = dst + (rowbase + mu) * (long)N;
+          if (ok && !(a.dbg & 4)) drow[soff] = v;
+          if (!last) sa[cur ^ 1][m][n] = to_bf16(v);
+          csum += v;
+        }
+        if (db) {
+          csum += __shfl_xor(csum, 32, 64);
+          if (lh == 0) atomicAdd(&db[n], csum);
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+#undef RG
+
 __global__ void bf16_image_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(src)[i];
@@ -495,6 +674,23 @@ static bool mlp_direct(const MlpFusedArgs& a) {
   return true;
 }
 
+// few workgroups (latency-bound stack): the 8-wave kernel with the register-resident, prefetched weight tile.  Every reduction
+// width must be a whole number of 8-element pieces (16-byte loads) or < 16 (the FMA path).
+static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wave kernel), or the register chunks needed: 4 / 6
+  static const int waves = getenv("MIMRL_MLP_IMG_WAVES") ? atoi(getenv("MIMRL_MLP_IMG_WAVES")) : 0;   // tuning knob: 4 = never, 8 = both directions
+  if (waves == 4) return 0;
+  const long wgs = (long)((a.rows + RT - 1) / RT) * a.nb;
+  if (wgs > 512) return 0;
+  int kmax = 0;
+  for (int l = 0; l < a.nl; ++l) {
+    const int K = bwd ? a.dims[l + 1] : a.dims[l];
+    if (K >= 16 && K % 8 != 0) return 0;
+    kmax = K > kmax ? K : kmax;
+  }
+  if (bwd) return kmax <= 256 ? 4 : 0;      // (the 6-chunk backward instantiation spills)
+  return kmax <= 256 ? 4 : 6;
+}
+
 static int check(const MlpFusedArgs& a) {
   if (!mlp_fused_supported(a.nb, a.rows, a.nl, a.dims)) return set_error(MIMRL_ERR_ARG, "mlp_fused: unsupported stack shape");
   if (a.pstride % 4 != 0) return set_error(MIMRL_ERR_ARG, "mlp_fused: group stride must be a multiple of 4 floats");
@@ -505,6 +701,8 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   MX(check(a));
   if (a.Wb[0]) {
     if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<false, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
+    else if (mlp_small8(a, false) == 4) hipLaunchKernelGGL((mlp_img8_kernel<false, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
+    else if (mlp_small8(a, false) == 6) hipLaunchKernelGGL((mlp_img8_kernel<false, 6>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((mlp_img_kernel<false, false>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return MIMRL_OK;
@@ -520,6 +718,7 @@ int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
   MX(check(a));
   if (a.WbT[0]) {
     if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<true, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
+    else if (mlp_small8(a, true) == 4) hipLaunchKernelGGL((mlp_img8_kernel<true, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((mlp_img_kernel<true, false>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return MIMRL_OK;
