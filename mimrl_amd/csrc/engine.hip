@@ -1837,6 +1837,10 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
   const int B = cfg.batch;
   const size_t BD = (size_t)B * EMB;
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
+  static const bool no_fused_mi = getenv("MIMRL_NO_FUSED_MI") != nullptr;        // tuning knobs
+  static const bool no_nce_tiled = getenv("MIMRL_NO_MI_NCE_TILED") != nullptr;
+  const bool fused_mi = sep && !no_fused_mi && (prec & MIMRL_PREC_BF16_GEMM_FWD) && (prec & MIMRL_PREC_BF16_GEMM_BWD) && mi_sep_fused_supported(B);
+  const bool nce_tiled = fused_mi && !no_nce_tiled && cfg.bound_type == MIMRL_BOUND_INFONCE && !has_baseline();
   {   // tower inputs: x operand -> slot 2e, y operand -> slot 2e+1
     CopyTable t;
     t.n = 10;
@@ -1845,14 +1849,21 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
         t.src[e * 2 + sd] = bufs.feats + kMiWire[e][sd] * BD;
         t.dst[e * 2 + sd] = tin + (e * 2 + sd) * BD;
       }
+    if (nce_tiled) {   // the row-tiled InfoNCE kernel accumulates: its outputs are zeroed by this launch
+      t.z[0].p = mi_raw; t.z[0].chunk = 2 * NE_MI; t.z[0].stride = 0; t.z[0].rep = 1;
+      if (want_grad) { t.z[1].p = dtout; t.z[1].chunk = (long)BD; t.z[1].stride = 2 * (long)BD; t.z[1].rep = NE_MI; }
+    }
     MX(copy_rows(stream, t, (long)BD));
   }
   if (sep) {
     const int dims[5] = {EMB, HID, HID, HID, EMB};
     MX(mlp_stack_forward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, tout));
-    static const bool no_fused_mi = getenv("MIMRL_NO_FUSED_MI") != nullptr;   // tuning knob
     mi_fused_bwd_done = false;
-    if (!no_fused_mi && (prec & MIMRL_PREC_BF16_GEMM_FWD) && (prec & MIMRL_PREC_BF16_GEMM_BWD) && mi_sep_fused_supported(B)) {
+    if (nce_tiled) {   // InfoNCE: one workgroup per (estimator, 32 score rows) instead of one per estimator
+      mi_fused_bwd_done = want_grad;
+      return mi_sep_nce_tiled(stream, tout, dtout, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B, want_grad ? 1 : 0);
+    }
+    if (fused_mi) {
       // scores, bound, d/dscores and the gradients of both tower outputs in one launch per stage (estimator_ops.hip)
       mi_fused_bwd_done = want_grad;
       if (has_baseline()) MX(baseline_forward());

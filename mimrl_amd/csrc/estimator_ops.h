@@ -8,13 +8,18 @@ enum Bound : int { BOUND_INFONCE = 0, BOUND_NWJ = 1, BOUND_TUBA = 2, BOUND_DV = 
                    BOUND_SMILE = 6, BOUND_MINE = 7, BOUND_INTERP = 8 };
 
 // copy rows:  dst[i][b,:] = src[i][b,:]   for i < n (table of pointers; used to gather tower inputs)
-struct CopyTable { const float* src[16]; float* dst[16]; int n; };
+// (+ optional zero-fill jobs done by the same launch: `rep` chunks of `chunk` floats, `stride` apart)
+struct ZeroJob { float* p = nullptr; long chunk = 0, stride = 0; int rep = 0; };
+struct CopyTable { const float* src[16]; float* dst[16]; int n; ZeroJob z[2]; };
 int copy_rows(hipStream_t s, const CopyTable& t, long floats_each);
 
 // scores [E][B][B] -> mi[e] (bound value) and dscores = gscale[e] * d(mi)/d(scores)   (one workgroup / estimator)
 // gscale lives in device memory (loss coefficient with sign); dscores may be null (evaluation only).
 // separable critic: scores, bound and the gradients w.r.t. both tower outputs in one launch (tout/dtout: [E][2][B][128])
 bool mi_sep_fused_supported(int B);
+// InfoNCE only, row-tiled: one workgroup per (estimator, 32 rows of the score matrix) -- the bound is a sum of row terms.  mi / mil
+// and the g(x) halves of dtout are ACCUMULATED (float atomics): the caller zeroes them first (CopyTable::z in the same stage).
+int mi_sep_nce_tiled(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B, int do_bwd);
 int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B,
                  int bound, unsigned lossform, int do_bwd, const float* lb = nullptr, float* dlb = nullptr, long lb_stride = 0);
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,

@@ -15,6 +15,11 @@ __global__ void copy_rows_kernel(CopyTable t, long n) {
   const float* __restrict__ s = t.src[i];
   float* __restrict__ d = t.dst[i];
   for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) d[j] = s[j];
+  if (i < 2 && t.z[i].p) {               // zero-fill job i rides on the row-i workgroups
+    const ZeroJob z = t.z[i];
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < z.chunk * z.rep; j += (long)gridDim.x * blockDim.x)
+      z.p[(j / z.chunk) * z.stride + j % z.chunk] = 0.f;
+  }
 }
 
 __device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
@@ -307,6 +312,130 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
       dY[(long)row * 128 + tn * 32 + lr] = ah[r];
       dX[(long)row * 128 + tn * 32 + lr] = ag[r];
     }
+  }
+}
+
+// Separable critic + InfoNCE, row-tiled: workgroup = (32 rows i of the score matrix, estimator).  InfoNCE is a sum of per-row terms
+// (s_ii - logsumexp_j s_ij), so a row tile needs h(y) for its 32 rows and g(x) for all B columns and nothing from the other tiles:
+//   scores tile = h_tile g^T -> row log-sum-exps -> value (atomic partial) -> dS tile -> d h_tile = dS g (owned rows: plain stores),
+//   d g += dS^T h_tile (partial over this tile's rows: float atomics into the caller-zeroed gradient).
+// 4 waves; g(x) and the h(y) tile are staged once into LDS as bf16 (coalesced 16-byte loads), every fragment comes from there.
+// The one-workgroup-per-estimator kernel above is 5 workgroups of serial phases (37 us at B = 128); this one is 5 x B/32.
+constexpr int NXP = 128 + 8;       // bf16 pitch of a staged [.][128] operand (272 B: conflict-free 16-byte fragment reads)
+__global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict__ tout, float* __restrict__ dtout,
+                                                         float* __restrict__ mi, float* __restrict__ mil,
+                                                         const float* __restrict__ gscale, int B, int do_bwd) {
+  extern __shared__ __attribute__((aligned(16))) char nce_smem[];
+  __shared__ float red[4];
+  __shared__ float lse_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int ti = blockIdx.x, e = blockIdx.y, i0 = ti * 32, nt = B / 32, SP = B + 1;
+  __bf16* Xs = reinterpret_cast<__bf16*>(nce_smem);                       // [B][NXP]   g(x), all rows
+  __bf16* Ys = Xs + (size_t)B * NXP;                                  // [32][NXP]  h(y), this tile's rows
+  float* S = reinterpret_cast<float*>(Ys + 32 * NXP);                 // [32][SP]   scores, then their gradient
+  const float* __restrict__ X = tout + (long)(2 * e) * B * 128;
+  const float* __restrict__ Y = tout + (long)(2 * e + 1) * B * 128 + (long)i0 * 128;
+  // ---- stage (all loads of a batch in flight together)
+  {
+    float4 q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = reinterpret_cast<const float4*>(Y)[tid + 256 * j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+      bf16x4 p; p[0] = to_bf16(q[j].x); p[1] = to_bf16(q[j].y); p[2] = to_bf16(q[j].z); p[3] = to_bf16(q[j].w);
+      *reinterpret_cast<bf16x4*>(Ys + row * NXP + c4) = p;
+    }
+    for (int base = 0; base < B * 32; base += 256 * 8) {
+      float4 x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int idx = base + tid + 256 * j; x[j] = reinterpret_cast<const float4*>(X)[idx < B * 32 ? idx : 0]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = base + tid + 256 * j, row = idx >> 5, c4 = (idx & 31) * 4;
+        if (idx < B * 32) {
+          bf16x4 p; p[0] = to_bf16(x[j].x); p[1] = to_bf16(x[j].y); p[2] = to_bf16(x[j].z); p[3] = to_bf16(x[j].w);
+          *reinterpret_cast<bf16x4*>(Xs + row * NXP + c4) = p;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- scores tile [32 x B]: wave -> column tiles tj = wave, wave + 4, ...
+  for (int tj = wave; tj < nt; tj += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ys + lr * NXP + ks * 16 + 8 * lh);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Xs + (tj * 32 + lr) * NXP + ks * 16 + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP + tj * 32 + lr] = acc[r];
+  }
+  __syncthreads();
+  // ---- row log-sum-exps and this tile's share of  mi = log B + mean_i(s_ii - lse_i)      (VMI.py:162-166)
+  float part = 0.f;
+  for (int i = wave; i < 32; i += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < B; j += 64) mx = fmaxf(mx, S[i * SP + j]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < B; j += 64) se += __expf(S[i * SP + j] - mx);
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    if (lane == 0) { lse_s[i] = lse; part += S[i * SP + i0 + i] - lse; }
+  }
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    const float v = (red[0] + red[1] + red[2] + red[3]) / B + (ti == 0 ? __logf((float)B) : 0.f);
+    atomicAdd(&mi[e], v);
+    if (mil) atomicAdd(&mil[e], -v);
+  }
+  if (!do_bwd) return;
+  // ---- dS = gs / B * (I - softmax rows), in place
+  const float gsb = (gscale ? gscale[e] : 0.f) / B;
+  for (int idx = tid; idx < 32 * B; idx += 256) {
+    const int i = idx / B, j = idx - i * B;
+    const float pij = __expf(S[i * SP + j] - lse_s[i]);
+    S[i * SP + j] = gsb * ((j == i0 + i ? 1.f : 0.f) - pij);
+  }
+  __syncthreads();
+  float* __restrict__ dX = dtout + (long)(2 * e) * B * 128;
+  float* __restrict__ dY = dtout + (long)(2 * e + 1) * B * 128 + (long)i0 * 128;
+  const int tn = wave;                       // this wave's 32 feature columns in both products
+  {   // d h_tile [32 x 128] = dS [32 x B] . g [B x 128]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ks = 0; ks * 16 < B; ++ks) {
+      const int k0 = ks * 16 + 8 * lh;
+      bf16x8 a, b;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a[q] = to_bf16(S[lr * SP + k0 + q]); b[q] = Xs[(k0 + q) * NXP + tn * 32 + lr]; }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dY[(long)((r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + tn * 32 + lr] = acc[r];
+  }
+  // d g [B x 128] += dS^T [B x 32] . h_tile [32 x 128]   (reduction over this tile's 32 rows: two k-steps)
+  for (int tr = 0; tr < nt; ++tr) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int k0 = ks * 16 + 8 * lh;
+      bf16x8 a, b;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a[q] = to_bf16(S[(k0 + q) * SP + tr * 32 + lr]); b[q] = Ys[(k0 + q) * NXP + tn * 32 + lr]; }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(&dX[(long)(tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + tn * 32 + lr], acc[r]);
   }
 }
 
@@ -668,6 +797,14 @@ int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, floa
   }
   hipLaunchKernelGGL(mi_sep_fused_kernel, dim3(E), dim3(1024), (size_t)B * B * sizeof(float) + (size_t)B * (B + 2) * 2, s, tout, dtout, mi, mil, gscale, B,
                      bound, lossform, do_bwd, lb, dlb, lb_stride, getenv("MIMRL_DBG_MI") ? atoi(getenv("MIMRL_DBG_MI")) : 0);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int mi_sep_nce_tiled(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B, int do_bwd) {
+  if (!mi_sep_fused_supported(B)) return set_error(MIMRL_ERR_ARG, "mi_sep_nce_tiled: batch %d unsupported", B);
+  const size_t lds = (size_t)(B + 32) * NXP * 2 + (size_t)32 * (B + 1) * sizeof(float);
+  hipLaunchKernelGGL(mi_sep_nce_kernel, dim3(B / 32, E), dim3(256), lds, s, tout, dtout, mi, mil, gscale, B, do_bwd);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
