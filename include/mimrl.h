@@ -197,6 +197,12 @@ int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, floa
 /* tuba / interpolate with a log-baseline log a(y_i) per row (VMI.py:72-110): lb, dlb are [E,B]; scores are modified in place */
 int mimrl_op_mi_bound_baseline(void* stream, float* scores, float* dscores, float* mi, const float* gscale, const float* lb,
                                float* dlb, int E, int B, int bound);
+/* separable critic + InfoNCE in one launch (VMI.py:55-57, 162-166): tout = [E][2][B][128] tower outputs (g(x), h(y)), scores = h g^T,
+ * mi[e] = log B + mean_i(s_ii - logsumexp_j s_ij), mi_loss[e] = -mi[e], dtout (may be null) = gscale[e] * d mi / d tout.  bf16 MFMA.
+ * tiled = 0: one workgroup per estimator; 1: one per (estimator, 32 score rows) -- that one ACCUMULATES into mi, mi_loss and the g(x)
+ * halves of dtout, which the caller zeroes first.  B in {32, 64, 96, 128}. */
+int mimrl_op_mi_sep_infonce(void* stream, const float* tout, float* dtout, float* mi, float* mi_loss, const float* gscale, int E,
+                            int B, int tiled);
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
 /* HOST routine (no device work): the k nearest non-anchor rows of a 1-column bank Z (the labels) for every anchor, with
  * scikit-learn's KDTree tie order (Model.py:82-86 with sklearn 1.7.2; see csrc/knn_r1.cpp).  idx_out [m*k]: ORIGINAL bank rows,

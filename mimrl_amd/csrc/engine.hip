@@ -2073,6 +2073,8 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
     MX(dbg_delay(stream, stage == 1 ? 4 : 14));
+    // (no helper side stream for this branch's weight gradients: it runs on side 5, and a fork / join pair hanging off a captured stream
+    //  other than the capture's origin sends this HIP runtime's EndCapture into an endless recursion -- tried, core dump)
     if (backward) { bf16 = bf_bwd; if (imgT_ready && !(skip_imgT_refresh && stage == 1)) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
     return MIMRL_OK;
   };
@@ -2752,6 +2754,13 @@ int mimrl_op_mi_bound_baseline(void* stream, float* scores, float* dscores, floa
 int mimrl_op_mi_bound_ex(void* stream, const float* scores, float* dscores, float* mi, float* mi_loss, const float* gscale,
                          int E, int B, int bound, uint32_t lossform) {
   return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, mi_loss, gscale, E, B, bound, lossform);
+}
+
+int mimrl_op_mi_sep_infonce(void* stream, const float* tout, float* dtout, float* mi, float* mi_loss, const float* gscale, int E,
+                            int B, int tiled) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!tiled) return mi_sep_fused(st, tout, dtout, mi, mi_loss, gscale, E, B, BOUND_INFONCE, 0x1fu, dtout ? 1 : 0);
+  return mi_sep_nce_tiled(st, tout, dtout, mi, mi_loss, gscale, E, B, dtout ? 1 : 0);   // accumulates: caller zeroes mi / mi_loss / dtout
 }
 
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out) {

@@ -163,6 +163,37 @@ def test_gemm_wgrad_group_splitk(lib, kind):
         assert err <= 3e-6 * q[4] * q[5] + 1e-5, f"{kind} problem {i} ({q[2]}x{q[3]}x{q[4]} batch {q[5]}): max |err| {err}"
 
 
+@pytest.mark.parametrize("B", [32, 96, 128])
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_mi_sep_infonce_fused(lib, B, tiled):
+    """Separable critic + InfoNCE in one launch (scores = h g^T, bound, gradients of both tower outputs): the one-workgroup-per-
+    estimator kernel and the row-tiled one (accumulating outputs) against float64 on the bf16-rounded tower outputs."""
+    g = np.random.default_rng(B + tiled)
+    E = 5
+    tout = (0.5 * g.standard_normal((E, 2, B, 128))).astype(np.float32)
+    gs = g.uniform(0.5, 1.5, E).astype(np.float32) * np.array([1, -1, 1, -1, 1], np.float32)
+    T, GS = dev(tout), dev(gs)
+    dT = torch.zeros(E, 2, B, 128, device="cuda")
+    mi, ml = torch.zeros(E, device="cuda"), torch.zeros(E, device="cuda")
+    _lib.check(lib.mimrl_op_mi_sep_infonce(stream(), P(T), P(dT), P(mi), P(ml), P(GS), E, B, tiled))
+    torch.cuda.synchronize()
+    tb = _bf16_round(tout).astype(np.float64)
+    for e in range(E):
+        gx, hy = tb[e, 0], tb[e, 1]
+        S = hy @ gx.T
+        lse = np.log(np.exp(S - S.max(1, keepdims=True)).sum(1)) + S.max(1)
+        want = np.log(B) + np.mean(np.diag(S) - lse)
+        assert abs(mi[e].item() - want) <= 1e-4 + 1e-4 * abs(want), (e, mi[e].item(), want)
+        assert abs(ml[e].item() + want) <= 1e-4 + 1e-4 * abs(want)
+        dS = gs[e] / B * (np.eye(B) - np.exp(S - lse[:, None]))
+        # the kernels round dS (and the other operand) to bf16 for the two gradient products
+        dh, dg = dS @ gx, dS.T @ hy
+        got = dT[e].cpu().numpy()
+        for name, got_m, want_m in (("d g(x)", got[0], dg), ("d h(y)", got[1], dh)):
+            scale = np.abs(want_m).max() + 1e-12
+            assert np.abs(got_m - want_m).max() <= 1.5e-2 * scale, (e, name, np.abs(got_m - want_m).max() / scale)
+
+
 def _gru_case(B, T, d, seed, ragged):
     g = np.random.default_rng(seed)
     H = 128
