@@ -1733,6 +1733,11 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
       if (l < nl - 1) { fa.act[l] = act[l]; fa.dz[l + 1] = dtmp[l]; if (wgrad) fa.db[l] = CG(p0 + l_off[l][1]); }
     }
     if (wgrad) fa.db_top = CG(p0 + l_off[nl - 1][1]);   // the top layer's bias gradient rides along (was a separate column-sum launch)
+    // ... and so does the weight gradient of a narrow top layer (the 2-logit CMI head: not eligible for the grouped launch, it was a
+    // 17 us generic GEMM in front of it on the CMI branch of stage 1)
+    static const bool no_top_wg = getenv("MIMRL_NO_TOP_WGRAD_FUSE") != nullptr;   // tuning knob
+    const bool top_wg = wgrad && !no_top_wg && dims[nl] % 4 != 0 && mlp_bwd_takes_top_wgrad(fa);
+    if (top_wg) fa.dw_top = CG(p0 + l_off[nl - 1][0]);
     MX(mlp_stack_bwd_fused(stream, fa));
     if (!wgrad) return MIMRL_OK;
     // the nl weight-gradient GEMMs are independent of each other: on the critical branch (wg_helper >= 0) every second
@@ -1755,11 +1760,12 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     static const bool no_group = getenv("MIMRL_NO_WG_GROUP") != nullptr;   // tuning knob: the round-1 schedule (helper stream, alternating)
     if (!no_group) {
       int lo = 0;
-      if (dims[nl] % 4 != 0) { MX(G_on(hs >= 0 ? S(hs) : stream, gs[0])); lo = 1; }   // not row-contiguous-eligible: beside the group
+      if (top_wg) lo = 1;                                                             // done inside the data-gradient kernel
+      else if (dims[nl] % 4 != 0) { MX(G_on(hs >= 0 ? S(hs) : stream, gs[0])); lo = 1; }   // not row-contiguous-eligible: beside the group
       MX(G_group(stream, gs + lo, nl - lo));
     } else {
       static const int helper_par = getenv("MIMRL_WG_SPLIT_PARITY") ? atoi(getenv("MIMRL_WG_SPLIT_PARITY")) : 0;   // tuning knob
-      for (int q = 0; q < nl; ++q) MX(G_on((hs >= 0 && (q & 1) == helper_par) ? S(hs) : stream, gs[q]));
+      for (int q = top_wg ? 1 : 0; q < nl; ++q) MX(G_on((hs >= 0 && (q & 1) == helper_par) ? S(hs) : stream, gs[q]));
     }
     if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;

@@ -31,6 +31,8 @@ struct MlpFusedArgs {
   float* din;                     // [nb, brows, dims[0]] or null
   float* db[MLPF_MAX_LAYERS];     // optional bias gradients of layers 0..nl-2 (column sums of dz[l+1]), group g at + g*pstride
   float* db_top;                  // optional bias gradient of the TOP layer (column sums of dout), group g at + g*pstride
+  float* dw_top;                  // optional WEIGHT gradient of a narrow top layer (dims[nl] * dims[nl-1] <= 512, e.g. the 2-logit CMI
+                                  // head: dW = dout^T act[nl-2]), accumulated; only where mlp_bwd_takes_top_wgrad() says so
   int dbg;                        // timing experiments only (MIMRL_DBG_MLPB): 1 no ReLU mask, 2 no bias atomics, 4 no dz stores
 };
 
@@ -38,6 +40,8 @@ bool mlp_fused_supported(int nb, int rows, int nl, const int* dims);
 int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a);
 // data-gradient chain only: fills dz[1..nl-1] (+ din, + db[]); weight gradients stay GEMMs over (dz, act)
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a);
+// true if mlp_stack_bwd_fused will also produce dw_top for this stack (8-wave image kernel, narrow top layer)
+bool mlp_bwd_takes_top_wgrad(const MlpFusedArgs& a);
 
 // bf16 images of a parameter bucket: dst[i] = bf16(src[i]); and, for a table of strided groups of [N,K] matrices,
 // dstT[off + g*gstride + k*N + n] = bf16(src[off + g*gstride + n*K + k])

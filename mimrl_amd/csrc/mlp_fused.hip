@@ -428,6 +428,18 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
     for (int r = 0; r < nr; ++r) s += a.dout[(rowbase + r) * w + tid];
     atomicAdd(a.db_top + (long)g * a.pstride + tid, s);
   }
+  if (BWD && a.dw_top && a.nl >= 2) {   // narrow top layer: dW[c][k] = sum over this tile's rows of dout[r][c] * act[r][k]  (fp32, L2-hot)
+    const int w = a.dims[a.nl], K1 = a.dims[a.nl - 1];
+    if (tid < w * K1) {
+      const int c = tid / K1, kk = tid - c * K1;
+      const int nr = min(RT, a.rows - r0);
+      const float* __restrict__ ap = a.act[a.nl - 2] + rowbase * K1 + kk;
+      const float* __restrict__ dp = a.dout + rowbase * w + c;
+      float s = 0.f;
+      for (int r = 0; r < nr; ++r) s += dp[(long)r * w] * ap[(long)r * K1];
+      atomicAdd(a.dw_top + (long)g * a.pstride + tid, s);
+    }
+  }
   __syncthreads();
   int cur = 0;
 #pragma unroll 1
@@ -712,10 +724,15 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   return MIMRL_OK;
 }
 
+bool mlp_bwd_takes_top_wgrad(const MlpFusedArgs& a) {
+  return a.WbT[0] && !mlp_direct(a) && mlp_small8(a, true) == 4 && a.nl >= 2 && a.dims[a.nl] * a.dims[a.nl - 1] <= 512;
+}
+
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
   MlpFusedArgs a = a_;
   a.dbg = getenv("MIMRL_DBG_MLPB") ? atoi(getenv("MIMRL_DBG_MLPB")) : 0;
   MX(check(a));
+  if (a.dw_top && !mlp_bwd_takes_top_wgrad(a)) return set_error(MIMRL_ERR_ARG, "mlp_stack_bwd_fused: dw_top not supported for this stack");
   if (a.WbT[0]) {
     if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<true, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
     else if (mlp_small8(a, true) == 4) hipLaunchKernelGGL((mlp_img8_kernel<true, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
