@@ -160,6 +160,9 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return r;
 }
 
+// dst[b, :] = sum_q src[q][b * ld[q] + off[q] + :]  over the sources whose row count covers b  (feature-gradient routing)
+struct GatherSum { const float* src[12]; int ld[12]; int off[12]; int rows[12]; int n; };
+
 // counter-based RNG for dropout: one 32-bit hash per element, keyed by (seed, stream id, step, index).
 // (The reference's torch Philox stream cannot be reproduced; parity runs use p=0 or explicit masks.)
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -447,6 +447,9 @@ struct mimrl_handle {
   int mi_backward(int stage);
   int cmi_backward(int stage);
   int route_feature_grads();
+  GatherSum head_gather;               // sources of the F_F gradient (summed inside head_bwd) while head_gather_on
+  bool head_gather_on = false;
+  hipEvent_t ev_dmean = nullptr;       // T / A / V feature gradients ready (gathered on side 0)
   int estimators_all(int stage, bool want_grad, bool backward);
   // grouped MLP stacks living in the critic bucket (nb groups, uniform parameter stride `pstride`)
   int mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2], const int* dims,
@@ -1489,7 +1492,7 @@ int mimrl_handle::model_backward() {
   const int ol = cfg.d_outs[nb - 1][0], ok = cfg.d_outs[nb - 1][1], od = cfg.d_outs[nb - 1][2];
   // head backward -> gradient of the last cube output (in gbuf[0])
   MX(head_bwd(stream, dfeat, dpred, P(cls_w), bufs.feats, gbuf[0], Gm(cls_w), Gm(cls_b), B, ol, ok, od,
-              cfg.compose_t_sum, cfg.compose_k_sum));
+              cfg.compose_t_sum, cfg.compose_k_sum, head_gather_on ? &head_gather : nullptr));
   int ci = 0;
   deferred.clear();
   { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
@@ -1509,6 +1512,7 @@ int mimrl_handle::model_backward() {
     return MIMRL_OK;
   };
   if (text_bwd_first) MX(text_bwd());
+  if (head_gather_on && ev_dmean) { HIPX(hipStreamWaitEvent(stream, ev_dmean, 0)); ev_dmean = nullptr; }   // dmean gathered on side 0
   // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
   {
     LnSide2 sd[2];
@@ -2055,7 +2059,17 @@ int mimrl_handle::route_feature_grads() {
         }
     g4.dst[f] = dfeat + f * BD;
   }
-  return gather_sum4(stream, g4, B, EMB);
+  // The F slot's sum is folded into head_bwd (its only consumer); T / A / V are needed only behind the CubeMLP backward: side 0,
+  // off the chain (was one launch + a queue hop between the stage-2 estimators and the head: ~20 us)
+  static const bool no_head_gather = getenv("MIMRL_NO_HEAD_GATHER") != nullptr;   // tuning knob
+  head_gather_on = !no_head_gather && multi_stream && side_on(0);
+  if (!head_gather_on) return gather_sum4(stream, g4, B, EMB);
+  head_gather = g4.g[0];
+  MX(fork(0, 0));
+  MX(gather_sum4(S(0), g4, B, EMB, 1));
+  MX(next_event(&ev_dmean));
+  HIPX(hipEventRecord(ev_dmean, S(0)));
+  return MIMRL_OK;
 }
 
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
@@ -2254,6 +2268,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     MX(estimators_all(2, true, true));
     MX(route_feature_grads());
   } else {
+    head_gather_on = false;
     HIPX(hipMemsetAsync(dfeat, 0, sizeof(float) * 4 * B * EMB, stream));
   }
   // (writes scalars only: beside the backward chain on side 0; model_backward joins every side before the stage ends)

@@ -73,10 +73,9 @@ int cmi_loss_fwd_bwd(hipStream_t s, const float* logits, float* dlogits, float* 
                      const float* g_cmi, int E, int n, int hardtanh);
 
 // dst[b,:] (+)= sum_i src_i[b*ld_i + off_i + :]  for rows b < rows_i   (deterministic gather-sum of input gradients)
-struct GatherSum { const float* src[12]; int ld[12]; int off[12]; int rows[12]; int n; };
 int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int accumulate);
 struct GatherSum4 { GatherSum g[4]; float* dst[4]; };   // four destinations in one launch (F, T, A, V feature gradients)
-int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D);
+int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D, int first = 0);   // destinations first..3
 
 // fused gradient value-clip + Adam over one flat bucket (Solver.py:144-146,211-213; torch.optim.Adam semantics)
 struct AdamArgs {

@@ -699,9 +699,9 @@ __global__ void gather_sum_kernel(float* __restrict__ dst, GatherSum g, int B, i
   }
 }
 
-__global__ void gather_sum4_kernel(GatherSum4 a, int B, int D) {
-  const GatherSum& g = a.g[blockIdx.y];
-  float* __restrict__ dst = a.dst[blockIdx.y];
+__global__ void gather_sum4_kernel(GatherSum4 a, int B, int D, int first) {
+  const GatherSum& g = a.g[blockIdx.y + first];
+  float* __restrict__ dst = a.dst[blockIdx.y + first];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)B * D; i += (long)gridDim.x * blockDim.x) {
     const int b = i / D, d = i % D;
     float s = 0.f;
@@ -890,8 +890,8 @@ int gather_sum(hipStream_t s, float* dst, const GatherSum& g, int B, int D, int 
   return MIMRL_OK;
 }
 
-int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D) {
-  hipLaunchKernelGGL(gather_sum4_kernel, dim3(grid_for((long)B * D), 4), dim3(256), 0, s, g, B, D);
+int gather_sum4(hipStream_t s, const GatherSum4& g, int B, int D, int first) {
+  hipLaunchKernelGGL(gather_sum4_kernel, dim3(grid_for((long)B * D), 4 - first), dim3(256), 0, s, g, B, D, first);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -67,8 +67,10 @@ int feat_mean_bwd(hipStream_t s, const float* dfeats, float* dcube, int B, int T
 int head_fwd(hipStream_t s, const float* x, const float* w, const float* bias, float* ff, float* pred, int B, int L,
              int K, int D, int sum_l, int sum_k);
 // dx[b,l,k,:] = scale*(dff_ext[b,:] + dpred[b]*w);  dw += sum_b dpred[b]*ff[b,:];  dbias += sum_b dpred[b]
+// gather (optional): dff_ext is not read; the gradient of F_F is summed from its sources on the fly (the estimators' input gradients:
+// the feature-gradient routing of the F slot folded into this kernel, one launch less on the chain)
 int head_bwd(hipStream_t s, const float* dff_ext, const float* dpred, const float* w, const float* ff, float* dx,
-             float* dw, float* dbias, int B, int L, int K, int D, int sum_l, int sum_k);
+             float* dw, float* dbias, int B, int L, int K, int D, int sum_l, int sum_k, const GatherSum* gather = nullptr);
 
 // ---- LayerNorm along the LAST axis of [R, n] rows (D-axis mix)
 int rowln_fwd(hipStream_t s, const float* y, const float* gamma, const float* beta, float* z, float* mean, float* rstd,

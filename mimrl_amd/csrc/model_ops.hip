@@ -1,6 +1,8 @@
 // Non-GEMM kernels of the model forward/backward (see model_ops.h for the reference citations).
 #include "model_ops.h"
 
+#include <cstring>
+
 #include "kmix_device.h"
 
 namespace mimrl {
@@ -258,11 +260,17 @@ __global__ void head_fwd_kernel(const float* __restrict__ x, const float* __rest
 }
 __global__ void head_bwd_kernel(const float* __restrict__ dff_ext, const float* __restrict__ dpred,
                                 const float* __restrict__ w, const float* __restrict__ ff, float* __restrict__ dx,
-                                float* __restrict__ dw, float* __restrict__ dbias, int L, int K, int D, float scale) {
+                                float* __restrict__ dw, float* __restrict__ dbias, int L, int K, int D, float scale, GatherSum gs,
+                                int use_gs) {
   const int b = blockIdx.x;
   const float dp = dpred[b];
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    const float g = scale * ((dff_ext ? dff_ext[(long)b * D + d] : 0.f) + dp * w[d]);
+    float de = 0.f;
+    if (use_gs) {
+      for (int q = 0; q < gs.n; ++q)
+        if (b < gs.rows[q]) de += gs.src[q][(long)b * gs.ld[q] + gs.off[q] + d];
+    } else if (dff_ext) de = dff_ext[(long)b * D + d];
+    const float g = scale * (de + dp * w[d]);
     float* xb = dx + (long)b * L * K * D + d;
     for (int i = 0; i < L * K; ++i) xb[(long)i * D] = g;
     atomicAdd(&dw[d], dp * ff[(long)b * D + d]);
@@ -758,9 +766,12 @@ int head_fwd(hipStream_t s, const float* x, const float* w, const float* bias, f
   return MIMRL_OK;
 }
 int head_bwd(hipStream_t s, const float* dff_ext, const float* dpred, const float* w, const float* ff, float* dx,
-             float* dw, float* dbias, int B, int L, int K, int D, int sum_l, int sum_k) {
+             float* dw, float* dbias, int B, int L, int K, int D, int sum_l, int sum_k, const GatherSum* gather) {
   const float scale = (sum_l ? 1.f : 1.f / L) * (sum_k ? 1.f : 1.f / K);
-  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(128), 0, s, dff_ext, dpred, w, ff, dx, dw, dbias, L, K, D, scale);
+  GatherSum gs;
+  std::memset(&gs, 0, sizeof gs);
+  if (gather) gs = *gather;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(128), 0, s, dff_ext, dpred, w, ff, dx, dw, dbias, L, K, D, scale, gs, gather ? 1 : 0);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
