@@ -203,6 +203,7 @@ struct mimrl_handle {
   int* d_ints_own = nullptr;           // private fallback storage
   float* d_consts = nullptr;           // coef1[11] coef2[8] gs_mi[2][5] g_bce[2][6] g_cmi[2][6]
   int *lens[2] = {nullptr, nullptr};
+  bool begin_in_pack = false;          // the stage-1 begin-of-stage bookkeeping is owed by the next layer-0 pack launch
   hipEvent_t ev_lens = nullptr;        // set while the length scan of this forward pass runs on side 0 (in front of the text projection)
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
   float* cube0 = nullptr;
@@ -780,6 +781,10 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         for (int d = 0; d < 2; ++d) { pk.w_ih[m][d] = P(gru[m][0][d].w_ih); pk.b_ih[m][d] = P(gru[m][0][d].b_ih); }
       }
       pk.xpack = xpack; pk.wpack = wpack; pk.bpack = bpack; pk.rows = BT_; pk.KP = KP();
+      if (begin_in_pack) {   // begin_stage(1) of the shared-prefix step rides on this launch (enqueue_grads)
+        pk.bs_rng = d_ints; pk.bs_adam = d_ints + 2; pk.bs_scal = bufs.scalars; pk.bs_off = 0; pk.bs_n = 32;
+        begin_in_pack = false;
+      }
       MX(l0_pack(stream, pk, true));
       GemmDesc gd = gemm_nt(xpack, KP(), wpack, KP(), gx[0][0], G, (int)BT_, G, KP());
       gd.batch = 4; gd.batch_in = 2;
@@ -1501,10 +1506,11 @@ int mimrl_handle::model_backward() {
   // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T -- folded into the two consumers of dcube below
   // (no feat_mean_bwd launch on the chain).  The critical consumer goes first in capture order; the text branch has slack.
   const float* dmean = dfeat + (size_t)B * D;      // [3][B, D]: gradients of T_F, A_F, V_F
-  // capture order of the two consumers: text branch FIRST although the LayerNorm backward is the critical one -- captured
-  // second, the text branch (35 us of W_t weight gradient) starts late and holds up the join at the end of the stage
-  // (measured 1.229 vs 1.259 ms; MIMRL_TEXT_BWD_LAST=1 for the other order)
-  static const bool text_bwd_first = getenv("MIMRL_TEXT_BWD_LAST") == nullptr;
+  // capture order of the two consumers (graph nodes are dispatched in capture order): the LayerNorm backward, head of the critical
+  // BPTT chain, first; the text branch (35 us of W_t weight gradient with slack until the end of the stage) behind it.  History: while
+  // the side streams were congested by the parked CubeMLP weight gradients the opposite order was faster (1.229 vs 1.259 ms); with the
+  // grouped / fused parameter-gradient kernels it is this one (0.980 vs 0.988 ms).  MIMRL_TEXT_BWD_FIRST=1: the other order.
+  static const bool text_bwd_first = getenv("MIMRL_TEXT_BWD_FIRST") != nullptr;
   auto text_bwd = [&]() -> int {   // text branch (side 0): dW_t = dtx^T . text
     MX(fork(0, 0));
     MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0, dmean));
@@ -2075,12 +2081,17 @@ int mimrl_handle::route_feature_grads() {
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  static const bool dbg_skip_imgt = getenv("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
+  static const bool imgt_first = getenv("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
+  bool imgT_pending = false;
   imgT_ready = false;
   if (backward && bf_bwd && fused_mlp && crit_imgT && ttab.n > 0) {   // transposed weight images for the fused data-gradient chains,
     if (!(skip_imgT_refresh && stage == 1)) {                         // built beside the forward stacks (combined step: once per step,
-      static const bool dbg_skip_imgt = getenv("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
       MX(fork(3, 3));                                                 // in stage 2 -- stage 1 of the NEXT step sees the same critics)
-      if (!dbg_skip_imgt) MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
+      // capture order: the launch itself goes BEHIND the CMI branch's forward kernels (see cmi_branch) -- graph nodes are dispatched in
+      // capture order, and as the first child of the stage boundary it held up both forward branches by ~18 us (MIMRL_IMGT_FIRST=1)
+      imgT_pending = !imgt_first && multi_stream && side_on(3) && side_on(5);
+      if (!imgT_pending && !dbg_skip_imgt) MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
     }
     imgT_ready = true;
   }
@@ -2092,6 +2103,10 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     StreamGuard g(this, S(5));
     bf16 = bf_fwd;
     MX(cmi_forward(stage, want_grad));
+    if (imgT_pending) {   // side 3 already waits for the stage boundary (fork above); only the launch was held back
+      imgT_pending = false;
+      if (!dbg_skip_imgt) MX(bf16_transposed_images(side[3], bufs.crit_p, crit_imgT, ttab));
+    }
     MX(dbg_delay(stream, stage == 1 ? 4 : 14));
     // (no helper side stream for this branch's weight gradients: it runs on side 5, and a fork / join pair hanging off a captured stream
     //  other than the capture's origin sends this HIP runtime's EndCapture into an endless recursion -- tried, core dump)
@@ -2139,9 +2154,16 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     // encoders_forward -- in the shared-prefix step it runs on side 4 beside the input projections instead of in front of them
     const bool begin_on_side = share && have_banks && skip_zero && prefix_split && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU;
     if (begin_on_side) MX(fork(4, 4));
-    hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, begin_on_side ? side[4] : stream, d_ints, have_banks ? d_ints + 2 : nullptr,
-                       bufs.scalars, 0, 32);
-    LAUNCH_CHECK();
+    // shared-prefix step with packed layer-0 operands: the pack launch is the first kernel of the prefix on this stream and nothing in
+    // front of the recurrence reads the counters or the scalars -- the bookkeeping rides on it (one launch + one gap less on the chain)
+    // (measured neutral, 0.970 vs 0.966 ms: the single-thread kernel hides in the gap between two graph launches -- opt-in)
+    static const bool want_begin_in_pack = getenv("MIMRL_BEGIN_IN_PACK") != nullptr;   // tuning knob
+    begin_in_pack = want_begin_in_pack && share && have_banks && skip_zero && !begin_on_side && l0_packed && cfg.encoder == MIMRL_ENCODER_GRU;
+    if (!begin_in_pack) {
+      hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, begin_on_side ? side[4] : stream, d_ints, have_banks ? d_ints + 2 : nullptr,
+                         bufs.scalars, 0, 32);
+      LAUNCH_CHECK();
+    }
     if (!have_banks) return MIMRL_OK;
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;

@@ -38,6 +38,9 @@ struct L0Pack {
   const float* w_ih[2][2]; const float* b_ih[2][2];
   float* xpack; float* wpack; float* bpack;
   long rows; int KP;
+  // optional: the stage's begin-of-stage bookkeeping rides on workgroup (0,0) of this launch (step counters += 1, scalar block zeroed):
+  // the pack is the first launch of the captured step, and a separate single-thread kernel in front of it was a launch + a gap
+  int* bs_rng = nullptr; int* bs_adam = nullptr; float* bs_scal = nullptr; int bs_off = 0, bs_n = 0;
 };
 int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights = true);
 struct L0Unpack {

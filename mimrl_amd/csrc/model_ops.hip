@@ -614,6 +614,10 @@ __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
   const int m = blockIdx.y;
   const long nx = pack_inputs ? a.rows * a.KP : 0, nw = pack_weights ? 2L * 384 * a.KP : 0, nb = pack_weights ? 2L * 384 : 0;
   const int d = a.d[m];
+  if (a.bs_rng && blockIdx.x == 0 && m == 0) {
+    if (threadIdx.x == 0) { *a.bs_rng += 1; if (a.bs_adam) *a.bs_adam += 1; }
+    for (int i = threadIdx.x; i < a.bs_n; i += blockDim.x) a.bs_scal[a.bs_off + i] = 0.f;
+  }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx + nw + nb; i += (long)gridDim.x * blockDim.x) {
     if (i < nx) {
       const long r = i / a.KP; const int c = (int)(i - r * a.KP);
