@@ -411,8 +411,9 @@ __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__
   __shared__ float sw[3 * KM * KM + 4 * KM];
   kmix_stage_weights(w, sw);
   const float* g = sw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
+  const bool pow2 = (D & (D - 1)) == 0; const int dsh = __ffs(D) - 1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < R * D; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / D; const int d = i % D;
+    const long r = pow2 ? (i >> dsh) : i / D; const int d = pow2 ? (int)(i & (D - 1)) : (int)(i % D);   // (64-bit division: ~80 instructions)
     KMixVals<NK> v;
 #pragma unroll
     for (int k = 0; k < NK; ++k) v.x[k] = k < w.ik ? x[(r * w.ik + k) * D + d] : 0.f;
@@ -457,8 +458,9 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
     for (int j = 0; j < NK; ++j) aw1[i][j] = aw2[i][j] = awr[i][j] = 0.f;
   }
   const long total = (GRADS && (w.dbg & 1)) ? 0 : R * D;
+  const bool pow2 = (D & (D - 1)) == 0; const int dsh = __ffs(D) - 1;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / D; const int d = i % D;
+    const long r = pow2 ? (i >> dsh) : i / D; const int d = pow2 ? (int)(i & (D - 1)) : (int)(i % D);   // (64-bit division: ~80 instructions)
     KMixVals<NK> v;
     float dzv[NK], dyv[NK], dym[NK], du[NK], dxn[NK], dxv[NK];
 #pragma unroll
@@ -866,7 +868,8 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
   if (part == 1) {
-    const dim3 grid(grid_for(R * D, 256, 4096));
+    static const int dx_wgs = getenv("MIMRL_KMIX_DX_WGS") ? atoi(getenv("MIMRL_KMIX_DX_WGS")) : 4096;   // tuning knob
+    const dim3 grid(grid_for(R * D, 256, dx_wgs));
     if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else hipLaunchKernelGGL((kmix_bwd_kernel<8, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
   } else {
