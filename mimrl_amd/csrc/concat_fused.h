@@ -1,0 +1,26 @@
+// Fused forward pass of the concat critic (VMI.py:59-65: scores[i,j] = f([x_i | y_j]) through Linear/ReLU x3 + Linear, VMI.py:13-22),
+// bf16 MFMA operands, fp32 accumulate.  The B*B pair rows of an estimator are the real dense contraction of this workload
+// (cfg3: 5 x 65,536 rows x 256 x 256 x 2 layers = 86 GFLOP per pass); as a chain of GEMMs every layer's [B*B, 256] activation
+// goes out to HBM in fp32 and comes back (3 TB/s, HBM-bound at 107 TFLOP/s).  Here a workgroup owns 128 pair rows for the WHOLE
+// stack: layer 0 in its separable form (relu(P_i + Q_j)) is generated straight into LDS, both 256x256 hidden layers run with the
+// activation tile resident in LDS (bf16), weights streamed from the L2-resident bf16 image in double-buffered 32-k chunks, and the
+// 256 -> 1 score head is a dot product on the accumulators.  The post-ReLU activations are still written out once in fp32 (the
+// unfused backward pass reads them).
+#pragma once
+#include "common.h"
+
+namespace mimrl {
+
+struct ConcatFwdArgs {
+  const float* P; const float* Q;            // [E][B][256]: W0x x_i and W0y y_j + b0 (the separable first layer)
+  const __bf16* W1; const __bf16* W2;         // bf16 images of the two hidden layers, [256 out][256 in] row-major; estimator e at + e*pstride
+  const float *b1, *b2, *w3, *b3;             // fp32 biases, score-head weight [256] and bias [1]; estimator e at + e*pstride
+  long pstride;                               // parameter stride between estimators (elements, same for the image and the fp32 bucket)
+  float *a0, *a1, *a2;                        // [E][B*B][256] post-ReLU activations of layers 0, 1, 2 (written; may NOT be null)
+  float* scores;                              // [E][B*B]   row p = i*B + j
+  int E, B;
+};
+bool concat_fwd_fused_supported(int B, int hid);
+int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a);
+
+}  // namespace mimrl

@@ -1,0 +1,142 @@
+// Fused concat-critic forward (see concat_fused.h).
+#include "concat_fused.h"
+
+namespace mimrl {
+
+namespace {
+
+constexpr int CR = 128;            // pair rows per workgroup
+constexpr int CH = 256;            // hidden width (VMI.py:13-22 with hidden_dim 256)
+constexpr int AP = CH + 8;         // bf16 pitch of the activation tile (528 B rows)
+constexpr int WKC = 32;            // k-values per staged weight chunk
+constexpr int WP = WKC + 8;        // bf16 pitch of a staged weight row (80 B: conflict-free 16-byte fragment reads)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 waves: wave = (wm, wn): 32-row tile wm of the 128 rows, 128-column half wn (four 32-column MFMA tiles)
+__global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 act[CR][AP];
+  __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
+  __shared__ float sc[CR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int e = blockIdx.y, B = a.B;
+  const long row0 = (long)blockIdx.x * CR, ebase = (long)e * B * B;
+  const float* __restrict__ P = a.P + (long)e * B * CH;
+  const float* __restrict__ Q = a.Q + (long)e * B * CH;
+  // ---- layer 0 in its separable form: act[p][u] = relu(P[i][u] + Q[j][u]),  p = i*B + j   (16 float4 pairs per thread, 4 in flight)
+  {
+    float* __restrict__ o0 = a.a0 + (ebase + row0) * CH;
+#pragma unroll 1
+    for (int base = 0; base < CR * 64; base += 512 * 4) {
+      float4 x[4], y[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
+        const long p = row0 + row;
+        const int i = (int)(p / B), j = (int)(p - (long)i * B);
+        x[q] = *reinterpret_cast<const float4*>(P + (long)i * CH + c4);
+        y[q] = *reinterpret_cast<const float4*>(Q + (long)j * CH + c4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
+        float4 v;
+        v.x = fmaxf(x[q].x + y[q].x, 0.f); v.y = fmaxf(x[q].y + y[q].y, 0.f); v.z = fmaxf(x[q].z + y[q].z, 0.f); v.w = fmaxf(x[q].w + y[q].w, 0.f);
+        *reinterpret_cast<float4*>(o0 + (long)row * CH + c4) = v;
+        bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
+        *reinterpret_cast<bf16x4*>(&act[row][c4]) = b;
+      }
+    }
+  }
+  if (tid < CR) sc[tid] = 0.f;
+  float hp[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hp[r] = 0.f;
+  // ---- the two hidden layers, activation tile resident in LDS
+#pragma unroll 1
+  for (int layer = 1; layer <= 2; ++layer) {
+    const __bf16* __restrict__ W = (layer == 1 ? a.W1 : a.W2) + (long)e * a.pstride;
+    const float* __restrict__ bias = (layer == 1 ? a.b1 : a.b2) + (long)e * a.pstride;
+    float* __restrict__ dst = (layer == 1 ? a.a1 : a.a2) + (ebase + row0) * CH;
+    float bn[4], w3c[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int col = wn * 128 + ct * 32 + lr;
+      bn[ct] = bias[col];
+      w3c[ct] = layer == 2 ? a.w3[(long)e * a.pstride + col] : 0.f;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    // weight chunk kc = W[:, 32 kc .. 32 kc + 32): thread -> (row n = tid >> 1, 16-element half), two 16-byte pieces
+    const int wn_ = tid >> 1, wh = (tid & 1) * 16;
+    const __bf16* __restrict__ wsrc = W + (long)wn_ * CH + wh;
+    u32x4 w0 = *reinterpret_cast<const u32x4*>(wsrc), w1 = *reinterpret_cast<const u32x4*>(wsrc + 8);
+    *reinterpret_cast<u32x4*>(&wb[0][wn_][wh]) = w0;
+    *reinterpret_cast<u32x4*>(&wb[0][wn_][wh + 8]) = w1;
+    __syncthreads();          // (also: the activation tile of this layer is complete)
+    int cur = 0;
+#pragma unroll 1
+    for (int kc = 0; kc < CH / WKC; ++kc) {
+      const bool more = kc + 1 < CH / WKC;
+      if (more) {
+        w0 = *reinterpret_cast<const u32x4*>(wsrc + (kc + 1) * WKC);
+        w1 = *reinterpret_cast<const u32x4*>(wsrc + (kc + 1) * WKC + 8);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(&act[wm * 32 + lr][kc * WKC + ks * 16 + 8 * lh]);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&wb[cur][wn * 128 + ct * 32 + lr][ks * 16 + 8 * lh]);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[ct], 0, 0, 0);
+        }
+      }
+      if (more) {
+        *reinterpret_cast<u32x4*>(&wb[cur ^ 1][wn_][wh]) = w0;
+        *reinterpret_cast<u32x4*>(&wb[cur ^ 1][wn_][wh + 8]) = w1;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    // every wave is done reading the activation tile: bias + ReLU, fp32 copy to HBM, bf16 back into the tile (in place)
+    const unsigned soff = (unsigned)(4 * lh * CH + wn * 128 + lr);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = wm * 32 + (r & 3) + 8 * (r >> 2), m = mu + 4 * lh, col = wn * 128 + ct * 32 + lr;
+        const float v = fmaxf(acc[ct][r] + bn[ct], 0.f);
+        float* __restrict__ drow = dst + (long)mu * CH + ct * 32;
+        drow[soff] = v;
+        act[m][col] = to_bf16(v);
+        hp[r] += v * w3c[ct];
+      }
+    __syncthreads();
+  }
+  // ---- score head (256 -> 1): the per-lane partial dot products are summed over this wave's 32-lane halves (= its 128 columns), then
+  // over the two column halves through LDS
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float t = half_sum_hi(hp[r]);                       // valid in lanes 16..31 / 48..63
+    if (lr == 16) atomicAdd(&sc[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh], t);
+  }
+  __syncthreads();
+  if (tid < CR) a.scores[ebase + row0 + tid] = sc[tid] + a.b3[(long)e * a.pstride];
+}
+
+}  // namespace
+
+bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 && ((long)B * B) % CR == 0; }
+
+int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a) {
+  if (!concat_fwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: batch %d unsupported", a.B);
+  if (!a.a0 || !a.a1 || !a.a2 || !a.scores) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: null output");
+  hipLaunchKernelGGL(concat_fwd_kernel, dim3((unsigned)(((long)a.B * a.B) / CR), a.E), dim3(512), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+}  // namespace mimrl

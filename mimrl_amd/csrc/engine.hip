@@ -14,6 +14,7 @@
 
 #include "cube_fused.h"
 #include "mlp_fused.h"
+#include "concat_fused.h"
 #include "cube_bwd_fused.h"
 #include "estimator_ops.h"
 #include "gemm.h"
@@ -1905,9 +1906,22 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
     gq.A = tin + BD; gq.B = CP(tower0 + tower_l[0][0]) + EMB; gq.C = cQ;
     gq.bias_n = CP(tower0 + tower_l[0][1]); gq.bias_n_b = tower_stride;
     MX(G_(gq));
-    MX(pair_expand_fwd(stream, cP, cQ, ca[0], NE_MI, B, HID));
-    const int dims[4] = {HID, HID, HID, 1};
-    MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
+    // pair expansion + both hidden layers + score head in ONE launch with the activation tile in LDS (concat_fused.hip); the
+    // unfused chain (fp32 mode, no bf16 image yet, MIMRL_NO_FUSED_CONCAT=1) is pair_expand + three GEMMs
+    static const bool no_fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") != nullptr;   // tuning knob
+    if (!no_fused_concat && bf16 && img_valid && crit_img && concat_fwd_fused_supported(B, HID)) {
+      ConcatFwdArgs fa;
+      fa.P = cP; fa.Q = cQ;
+      fa.W1 = crit_img + tower0 + tower_l[1][0]; fa.W2 = crit_img + tower0 + tower_l[2][0];
+      fa.b1 = CP(tower0 + tower_l[1][1]); fa.b2 = CP(tower0 + tower_l[2][1]);
+      fa.w3 = CP(tower0 + tower_l[3][0]); fa.b3 = CP(tower0 + tower_l[3][1]);
+      fa.pstride = tower_stride; fa.a0 = ca[0]; fa.a1 = ca[1]; fa.a2 = ca[2]; fa.scores = scores; fa.E = NE_MI; fa.B = B;
+      MX(concat_fwd_fused(stream, fa));
+    } else {
+      MX(pair_expand_fwd(stream, cP, cQ, ca[0], NE_MI, B, HID));
+      const int dims[4] = {HID, HID, HID, 1};
+      MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
+    }
   }
   if (has_baseline()) MX(baseline_forward());
   return mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B,
