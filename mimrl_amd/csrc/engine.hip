@@ -212,6 +212,7 @@ struct mimrl_handle {
   float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
+  bool fused_concat = true;            // concat critic forward as one launch (concat_fused.hip); MIMRL_NO_FUSED_CONCAT=1 at create time
   bool l0_packed = false;              // see mimrl_create
   bool l0_bwd_pack = false;            // small batches: only the INPUTS are packed (off the chain) and only the weight gradients use them
   BlockBuf bb[MIMRL_MAX_BLOCKS];
@@ -1908,8 +1909,7 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
     MX(G_(gq));
     // pair expansion + both hidden layers + score head in ONE launch with the activation tile in LDS (concat_fused.hip); the
     // unfused chain (fp32 mode, no bf16 image yet, MIMRL_NO_FUSED_CONCAT=1) is pair_expand + three GEMMs
-    static const bool no_fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") != nullptr;   // tuning knob
-    if (!no_fused_concat && bf16 && img_valid && crit_img && concat_fwd_fused_supported(B, HID)) {
+    if (fused_concat && bf16 && img_valid && crit_img && concat_fwd_fused_supported(B, HID)) {
       ConcatFwdArgs fa;
       fa.P = cP; fa.Q = cQ;
       fa.W1 = crit_img + tower0 + tower_l[1][0]; fa.W2 = crit_img + tower0 + tower_l[2][0];
@@ -2507,6 +2507,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
+  h->fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") == nullptr;
   // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches: the four layer-0
   // weight-gradient GEMMs in a row are what closes the stage behind the BPTT.  (History: before the parked CubeMLP weight gradients
   // became two grouped launches the side streams were the bottleneck and packing lost at cfg2, 1.34 vs 1.32 ms; since then it

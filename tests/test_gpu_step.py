@@ -361,6 +361,33 @@ def test_bf16_fused_paths_on_every_fixture(name):
     assert_close(a[_lib.S2_MIS:_lib.S2_MIS + nmi], b[_lib.S2_MIS:_lib.S2_MIS + nmi], 5e-2, 3e-2, "stage-2 MI terms")
 
 
+@pytest.mark.parametrize("name", ["tiny_cat", "cfg1_cat"])
+def test_fused_concat_forward_matches_gemm_chain(name, monkeypatch):
+    """The fused concat-critic forward (pair expansion + two hidden layers + score head per 128-row tile, activations in LDS) against
+    the pair_expand + three-GEMM chain in the same bf16 mode: same bf16-rounded operands, fp32 accumulation, so the MI values agree to
+    fp32 summation-order noise and every critic gradient (the backward pass reads the activations the forward kernel saved) to 2e-3
+    of its scale.  (tiny_cat: B*B = 64 rows -- not a multiple of the 128-row tile, both runs take the chain: the dispatch rule.)"""
+    res = {}
+    for tag in ("fused", "chain"):
+        if tag == "chain":
+            monkeypatch.setenv("MIMRL_NO_FUSED_CONCAT", "1")
+        else:
+            monkeypatch.delenv("MIMRL_NO_FUSED_CONCAT", raising=False)
+        c, opt, batch, banks, p, eng = make_engine(name, precision="bf16")
+        g = load_golden(name)
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(1, g["anchors"][0, 0], exact_ties=bool(c.get("discrete")))
+        eng.stage_grads(1)
+        torch.cuda.synchronize()
+        res[tag] = (eng.read_scalars().copy(), {n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if "MLP_f" in n})
+        eng.close()
+    (sa, ga), (sb, gb) = res["fused"], res["chain"]
+    assert_close(sa[_lib.S1_MIS:_lib.S1_MIS + 5], sb[_lib.S1_MIS:_lib.S1_MIS + 5], 1e-4, 1e-5, "MI values fused vs chain")
+    assert len(ga) == 40
+    for n in ga:
+        grad_close(ga[n], gb[n], 2e-3, n)
+
+
 def test_cfg2_full_size_in_bench_mode():
     """BASELINE configs[1] at full size (B=128, T=50, N=1284) in EXACTLY the mode bench.py times -- bf16 MFMA operands, every
     fused kernel, one hipGraph per two-stage step, Solver.step() overlap mode with the shared encoder prefix -- against the
@@ -444,9 +471,10 @@ def test_cfg3_full_size_properties(monkeypatch):
     m = opt.batch_size // opt.k_neighbor
     anchors = [np.stack([rng.choice(N, size=m, replace=False) for _ in range(6)]) for _ in range(2)]
     res = {}
-    for tag, graph, pre, envs in (("plain", False, False, ("MIMRL_NO_FUSED_CUBE", "MIMRL_NO_FUSED_CUBE_BWD", "MIMRL_NO_FUSED_MLP", "MIMRL_NO_FUSED_MI")),
+    for tag, graph, pre, envs in (("plain", False, False, ("MIMRL_NO_FUSED_CUBE", "MIMRL_NO_FUSED_CUBE_BWD", "MIMRL_NO_FUSED_MLP", "MIMRL_NO_FUSED_MI",
+                                                           "MIMRL_NO_FUSED_CONCAT")),
                                   ("bench", True, True, ())):
-        for e in ("MIMRL_NO_FUSED_CUBE", "MIMRL_NO_FUSED_CUBE_BWD", "MIMRL_NO_FUSED_MLP", "MIMRL_NO_FUSED_MI"):
+        for e in ("MIMRL_NO_FUSED_CUBE", "MIMRL_NO_FUSED_CUBE_BWD", "MIMRL_NO_FUSED_MLP", "MIMRL_NO_FUSED_MI", "MIMRL_NO_FUSED_CONCAT"):
             monkeypatch.delenv(e, raising=False)
         for e in envs:
             monkeypatch.setenv(e, "1")
