@@ -21,6 +21,26 @@ struct ConcatFwdArgs {
   int E, B;
 };
 bool concat_fwd_fused_supported(int B, int hid);
+
+// The data-gradient chain of the same stack per 128-row tile (B a multiple of 128: a tile = one x row i, 128 consecutive y rows j):
+//   dZ2 = ds w3^T (.) [a2 > 0]  ->  dZ1 = (dZ2 W2) (.) [a1 > 0]  ->  dZ0 = (dZ1 W1) (.) [a0 > 0]
+// with the gradient tile resident in LDS (bf16) and the TRANSPOSED bf16 weight images streamed as in the forward pass.  Written out:
+// dz0 (fp32: pair_reduce_q sums it over i), dP[i] = sum_j dZ0 (this tile's column sums), and -- stage 1 only -- dZ2 / dZ1 as bf16 for
+// the weight-gradient GEMMs plus the column-sum gradients db1, db2, dw3, db3 (float atomics into the zeroed bucket).
+struct ConcatBwdArgs {
+  const float* ds;                            // [E][B*B]   d loss / d score
+  const float *a0, *a1, *a2;                  // saved post-ReLU activations (the forward kernel's outputs)
+  const float* w3;                            // score-head weight [256], estimator e at + e*pstride
+  const __bf16 *W2T, *W1T;                    // transposed bf16 images [256 in][256 out], estimator e at + e*pstride
+  long pstride;
+  float* dz0;                                 // [E][B*B][256] fp32
+  float* dP;                                  // [E][B][256]; B == 128: plain stores, else accumulated (caller zeroes it)
+  __bf16 *dz2, *dz1;                          // [E][B*B][256] bf16 or null (stage 2: no weight gradients)
+  float *db1, *db2, *dw3, *db3;               // gradient slots (estimator e at + e*pstride) or null
+  int E, B;
+};
+bool concat_bwd_fused_supported(int B, int hid);
+int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a);
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a);
 
 }  // namespace mimrl

@@ -127,7 +127,181 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
   if (tid < CR) a.scores[ebase + row0 + tid] = sc[tid] + a.b3[(long)e * a.pstride];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward data-gradient chain (see concat_fused.h); same wave mapping and weight streaming as the forward kernel
+// ---------------------------------------------------------------------------------------------------------------
+// one hidden layer of the chain: acc = G (LDS tile [128][256] bf16) . WT^T   with WT = [in v][out u] row-major (u contiguous)
+__device__ __forceinline__ void bwd_product(f32x16 (&acc)[4], const __bf16 (*g)[AP], __bf16 (*wb)[CH][WP], const __bf16* __restrict__ WT,
+                                            int tid, int lr, int lh, int wm, int wn) {
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  const int wn_ = tid >> 1, wh = (tid & 1) * 16;
+  const __bf16* __restrict__ wsrc = WT + (long)wn_ * CH + wh;
+  u32x4 w0 = *reinterpret_cast<const u32x4*>(wsrc), w1 = *reinterpret_cast<const u32x4*>(wsrc + 8);
+  *reinterpret_cast<u32x4*>(&wb[0][wn_][wh]) = w0;
+  *reinterpret_cast<u32x4*>(&wb[0][wn_][wh + 8]) = w1;
+  __syncthreads();          // (also: the gradient tile of this layer is complete)
+  int cur = 0;
+#pragma unroll 1
+  for (int kc = 0; kc < CH / WKC; ++kc) {
+    const bool more = kc + 1 < CH / WKC;
+    if (more) {
+      w0 = *reinterpret_cast<const u32x4*>(wsrc + (kc + 1) * WKC);
+      w1 = *reinterpret_cast<const u32x4*>(wsrc + (kc + 1) * WKC + 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(&g[wm * 32 + lr][kc * WKC + ks * 16 + 8 * lh]);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&wb[cur][wn * 128 + ct * 32 + lr][ks * 16 + 8 * lh]);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[ct], 0, 0, 0);
+      }
+    }
+    if (more) {
+      *reinterpret_cast<u32x4*>(&wb[cur ^ 1][wn_][wh]) = w0;
+      *reinterpret_cast<u32x4*>(&wb[cur ^ 1][wn_][wh + 8]) = w1;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 gt[CR][AP];
+  __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
+  __shared__ float cs[2][CH];            // column sums of the tile (two quantities at a time)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int e = blockIdx.y, B = a.B;
+  const long row0 = (long)blockIdx.x * CR, ebase = (long)e * B * B, tile = (ebase + row0) * CH;
+  const bool wg = a.dz2 != nullptr;      // stage 1: weight-gradient operands and the column-sum gradients are wanted
+  if (tid < CH) { cs[0][tid] = 0.f; cs[1][tid] = 0.f; }
+  __syncthreads();
+  // ---- dZ2 = ds w3^T (.) [a2 > 0]; this thread owns one column quad (c4) and 16 of the 128 rows
+  {
+    const int c4 = (tid & 63) * 4;
+    const float4 w3v = *reinterpret_cast<const float4*>(a.w3 + (long)e * a.pstride + c4);
+    float4 sdb = make_float4(0.f, 0.f, 0.f, 0.f), sdw = sdb;
+    float sds = 0.f;
+#pragma unroll 1
+    for (int base = 0; base < CR * 64; base += 512 * 4) {
+      float4 av[4]; float dsv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (base + tid + 512 * q) >> 6;
+        av[q] = *reinterpret_cast<const float4*>(a.a2 + tile + (long)row * CH + c4);
+        dsv[q] = a.ds[ebase + row0 + row];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (base + tid + 512 * q) >> 6;
+        const float d = dsv[q];
+        float4 v;
+        v.x = av[q].x > 0.f ? d * w3v.x : 0.f; v.y = av[q].y > 0.f ? d * w3v.y : 0.f;
+        v.z = av[q].z > 0.f ? d * w3v.z : 0.f; v.w = av[q].w > 0.f ? d * w3v.w : 0.f;
+        bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
+        *reinterpret_cast<bf16x4*>(&gt[row][c4]) = b;
+        if (wg) {
+          *reinterpret_cast<bf16x4*>(a.dz2 + tile + (long)row * CH + c4) = b;
+          sdb.x += v.x; sdb.y += v.y; sdb.z += v.z; sdb.w += v.w;
+          sdw.x += d * av[q].x; sdw.y += d * av[q].y; sdw.z += d * av[q].z; sdw.w += d * av[q].w;
+          if (c4 == 0) sds += d;
+        }
+      }
+    }
+    if (wg) {
+      atomicAdd(&cs[0][c4], sdb.x); atomicAdd(&cs[0][c4 + 1], sdb.y); atomicAdd(&cs[0][c4 + 2], sdb.z); atomicAdd(&cs[0][c4 + 3], sdb.w);
+      atomicAdd(&cs[1][c4], sdw.x); atomicAdd(&cs[1][c4 + 1], sdw.y); atomicAdd(&cs[1][c4 + 2], sdw.z); atomicAdd(&cs[1][c4 + 3], sdw.w);
+      sds = wave_sum(sds);                       // (only lane 0 of each wave, whose column quad is 0, carries a value)
+    }
+    __syncthreads();
+    if (wg) {
+      if (tid < CH) {
+        atomicAdd(a.db2 + (long)e * a.pstride + tid, cs[0][tid]);
+        atomicAdd(a.dw3 + (long)e * a.pstride + tid, cs[1][tid]);
+        cs[0][tid] = 0.f; cs[1][tid] = 0.f;
+      }
+      if (lane == 0) atomicAdd(a.db3 + (long)e * a.pstride, sds);
+    }
+  }
+  // ---- dZ1 = (dZ2 W2) (.) [a1 > 0]
+  f32x16 acc[4];
+  const unsigned soff = (unsigned)(4 * lh * CH + wn * 128 + lr);
+  bwd_product(acc, gt, wb, a.W2T + (long)e * a.pstride, tid, lr, lh, wm, wn);
+  {
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* __restrict__ mrow = a.a1 + tile + (long)(wm * 32 + (r & 3) + 8 * (r >> 2)) * CH + ct * 32;
+        mk[r] = mrow[soff];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = wm * 32 + (r & 3) + 8 * (r >> 2), m = mu + 4 * lh, col = wn * 128 + ct * 32 + lr;
+        const float v = mk[r] > 0.f ? acc[ct][r] : 0.f;
+        const __bf16 vb = to_bf16(v);
+        gt[m][col] = vb;                                   // (every wave left the product loop through its last barrier)
+        if (wg) { __bf16* __restrict__ drow = a.dz1 + tile + (long)mu * CH + ct * 32; drow[soff] = vb; csum[ct] += v; }
+      }
+    }
+    if (wg) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) atomicAdd(&cs[0][wn * 128 + ct * 32 + lr], csum[ct]);
+    }
+  }
+  __syncthreads();
+  if (wg && tid < CH) { atomicAdd(a.db1 + (long)e * a.pstride + tid, cs[0][tid]); cs[0][tid] = 0.f; }
+  // ---- dZ0 = (dZ1 W1) (.) [a0 > 0]  -> dz0 (fp32) and its column sums = dP[i]
+  bwd_product(acc, gt, wb, a.W1T + (long)e * a.pstride, tid, lr, lh, wm, wn);
+  {
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* __restrict__ mrow = a.a0 + tile + (long)(wm * 32 + (r & 3) + 8 * (r >> 2)) * CH + ct * 32;
+        mk[r] = mrow[soff];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mu = wm * 32 + (r & 3) + 8 * (r >> 2);
+        const float v = mk[r] > 0.f ? acc[ct][r] : 0.f;
+        float* __restrict__ drow = a.dz0 + tile + (long)mu * CH + ct * 32;
+        drow[soff] = v;
+        csum[ct] += v;
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) atomicAdd(&cs[0][wn * 128 + ct * 32 + lr], csum[ct]);
+  }
+  __syncthreads();
+  if (tid < CH) {
+    const long i = row0 / B;                               // B % 128 == 0: the whole tile belongs to one x row
+    float* dp = a.dP + ((long)e * B + i) * CH + tid;
+    if (B == CR) *dp = cs[0][tid]; else atomicAdd(dp, cs[0][tid]);
+  }
+}
+
 }  // namespace
+
+bool concat_bwd_fused_supported(int B, int hid) { return hid == CH && B >= CR && B % CR == 0; }
+
+int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a) {
+  if (!concat_bwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: batch %d unsupported", a.B);
+  if (!a.dz0 || !a.dP || !a.ds) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null argument");
+  if ((a.dz2 != nullptr) != (a.dz1 != nullptr) || (a.dz2 && !(a.db1 && a.db2 && a.dw3 && a.db3)))
+    return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the weight-gradient outputs come together");
+  hipLaunchKernelGGL(concat_bwd_kernel, dim3((unsigned)(((long)a.B * a.B) / CR), a.E), dim3(512), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
 
 bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 && ((long)B * B) % CR == 0; }
 

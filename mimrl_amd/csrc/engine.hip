@@ -2017,11 +2017,44 @@ int mimrl_handle::mi_backward(int stage) {
     return mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad);
   }
   const int dims[4] = {HID, HID, HID, 1};
-  // (the gradient of the pair-expanded first layer gets its own buffer: the fused chain keeps every dZ alive for the
-  // weight-gradient GEMMs)
-  MX(mlp_stack_backward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], dscores, dca,
-                        dca[2], wgrad));
-  MX(pair_expand_bwd(stream, ca[0], dca[2], dP, dQ, NE_MI, B, HID));
+  if (fused_concat && bf16 && imgT_ready && concat_bwd_fused_supported(B, HID)) {
+    // the data-gradient chain of the tail (score head -> both hidden layers -> masked gradient of the pair-expanded layer) as ONE launch
+    // with the gradient tile in LDS (concat_fused.hip); dZ2 / dZ1 leave it as bf16 for the two weight-gradient GEMMs of stage 1
+    ConcatBwdArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.ds = dscores; fa.a0 = ca[0]; fa.a1 = ca[1]; fa.a2 = ca[2];
+    fa.w3 = CP(tower0 + tower_l[3][0]);
+    fa.W2T = crit_imgT + tower0 + tower_l[2][0]; fa.W1T = crit_imgT + tower0 + tower_l[1][0];
+    fa.pstride = tower_stride; fa.dz0 = dca[2]; fa.dP = dP; fa.E = NE_MI; fa.B = B;
+    __bf16* dz2 = reinterpret_cast<__bf16*>(dca[0]); __bf16* dz1 = reinterpret_cast<__bf16*>(dca[1]);
+    if (wgrad) {
+      fa.dz2 = dz2; fa.dz1 = dz1;
+      fa.db1 = CG(tower0 + tower_l[1][1]); fa.db2 = CG(tower0 + tower_l[2][1]);
+      fa.dw3 = CG(tower0 + tower_l[3][0]); fa.db3 = CG(tower0 + tower_l[3][1]);
+    }
+    if (B > 128) HIPX(hipMemsetAsync(dP, 0, sizeof(float) * NE_MI * B * HID, stream));   // two or more tiles add into each dP row
+    MX(concat_bwd_fused(stream, fa));
+    const bool side_wg = wgrad && multi_stream && wg_helper >= 0;
+    if (wgrad) {   // dW2 = dZ2^T a1, dW1 = dZ1^T a0: K = B*B rows, split-K with atomics, beside pair_reduce_q on the helper stream
+      if (side_wg) MX(fork(wg_helper, wg_helper));
+      for (int l = 2; l >= 1; --l) {
+        GemmDesc g;
+        g.A = reinterpret_cast<const float*>(l == 2 ? dz2 : dz1); g.a_bf16 = 1; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * B * HID;
+        g.B = l == 2 ? ca[1] : ca[0]; g.sb_k = HID; g.sb_n = 1; g.sb_b = (long)B * B * HID;
+        g.C = CG(tower0 + tower_l[l][0]); g.sc_m = HID; g.sc_n = 1; g.sc_b = tower_stride;
+        g.M = HID; g.N = HID; g.K = B * B; g.batch = NE_MI; g.atomic = 1;
+        MX(G_on(side_wg ? S(wg_helper) : stream, g));
+      }
+    }
+    MX(pair_reduce_q(stream, dca[2], dQ, NE_MI, B, HID));
+    if (side_wg) MX(join(wg_helper, wg_helper));
+  } else {
+    // (the gradient of the pair-expanded first layer gets its own buffer: the fused chain keeps every dZ alive for the
+    // weight-gradient GEMMs)
+    MX(mlp_stack_backward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], dscores, dca,
+                          dca[2], wgrad));
+    MX(pair_expand_bwd(stream, ca[0], dca[2], dP, dQ, NE_MI, B, HID));
+  }
   if (wgrad) {
     GemmDesc g;   // dW0[:, :128] = dP^T x ; dW0[:, 128:] = dQ^T y ; db0 = colsum(dQ)
     g.A = dP; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * HID;

@@ -28,6 +28,8 @@ int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* 
 // concat critic layer 1:  a1[(i*B+j), c] = relu(P[i,c] + Q[j,c])     P = x Wx^T, Q = y Wy^T + b   (VMI.py:59-65)
 int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, int E, int B, int Hd);
 // da1 (in place -> du1 = da1 * (a1>0)), then dP[i,c] = sum_j du1, dQ[j,c] = sum_i du1
+// dQ only, from a du1 that already carries the ReLU mask (the fused concat backward writes it)
+int pair_reduce_q(hipStream_t s, const float* du1, float* dQ, int E, int B, int Hd);
 int pair_expand_bwd(hipStream_t s, const float* a1, float* da1, float* dP, float* dQ, int E, int B, int Hd);
 // relu backward in place: g *= (a > 0)
 int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n);

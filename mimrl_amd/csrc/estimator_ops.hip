@@ -830,6 +830,11 @@ int pair_expand_bwd(hipStream_t s, const float* a1, float* da1, float* dP, float
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
+int pair_reduce_q(hipStream_t s, const float* du1, float* dQ, int E, int B, int Hd) {
+  hipLaunchKernelGGL(pair_reduce_q_kernel, dim3(B, E), dim3(256), 0, s, du1, dQ, B, Hd);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
 int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n) {
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, g, n);
   LAUNCH_CHECK();

@@ -440,6 +440,43 @@ def _bench_engine(workload, precision, use_graph, device_anchors=True, **env):
     return opt, N, batch, banks, eng
 
 
+@pytest.mark.parametrize("stage", [1, 2])
+def test_fused_concat_backward_matches_gemm_chain(stage, monkeypatch):
+    """cfg2 with the concat critic (B = 128: 5 x 16,384 pair rows), bf16: the fused forward + fused data-gradient chain of the critic
+    tail against pair_expand + GEMM chain + top1_bwd + pair_reduce (MIMRL_NO_FUSED_CONCAT=1).  Stage 1: every critic gradient
+    (weights through the bf16-stored dZ operands, biases / score head through the in-kernel column sums); stage 2: every main-model
+    gradient (through dP / dQ -> the feature gradients).  Same bf16-rounded MFMA operands on both sides except dZ, which the fused
+    kernel rounds once when it stores it for the weight-gradient GEMMs (the chain keeps fp32 and the GEMM rounds it on load: the
+    same value).  What differs is the forward summation order, and with 4.2e7 hidden activations per pass ~1e3 of them sit within
+    fp32 noise of the ReLU kink: their masks differ between the two runs, a relative perturbation of ~4e-3 of the
+    gradient signal.  Critic gradients (stage 1) agree to 3e-3 of their scale; the main-model gradients (stage 2), which the bf16
+    model backward amplifies ~10x (LayerNorm cancellation), to 5e-2 -- a wrong dP / dQ would be O(1).
+    (Chain vs chain on the same inputs: 1e-6, tools/concat_ab.py.)"""
+    rng = np.random.default_rng(5)
+    res = {}
+    for tag in ("fused", "chain"):
+        if tag == "chain":
+            monkeypatch.setenv("MIMRL_NO_FUSED_CONCAT", "1")
+        else:
+            monkeypatch.delenv("MIMRL_NO_FUSED_CONCAT", raising=False)
+        opt, N, batch, banks, eng = _bench_engine("cfg2-concat", "bf16", False, device_anchors=False)
+        if tag == "fused":
+            m = opt.batch_size // opt.k_neighbor
+            anchors = np.stack([rng.choice(N, size=m, replace=False) for _ in range(6)])
+        eng.set_anchors(stage, anchors)
+        eng.stage_grads(stage)
+        torch.cuda.synchronize()
+        pick = (lambda n: "MLP_f" in n) if stage == 1 else (lambda n: not n.startswith("vmi") and not n.startswith("vcmi"))
+        res[tag] = (eng.read_scalars().copy(), {n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if pick(n)})
+        eng.close()
+    (sa, ga), (sb, gb) = res["fused"], res["chain"]
+    off = _lib.S1_MIS if stage == 1 else _lib.S2_MIS
+    assert_close(sa[off:off + 4], sb[off:off + 4], 1e-4, 1e-5, "MI values fused vs chain")
+    assert len(ga) >= 40
+    for n in ga:
+        grad_close(ga[n], gb[n], 3e-3 if stage == 1 else 5e-2, n)
+
+
 def test_cfg3_full_size_properties(monkeypatch):
     """BASELINE configs[2] at FULL size (MOSEI-shaped B=256, T=500, concat critic, k=2, N=16326 banks): no reference run is
     affordable at this size, so size-independent properties: (a) the epoch-0 rule, (b) the task loss and the features against
