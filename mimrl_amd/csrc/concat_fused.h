@@ -16,7 +16,15 @@ struct ConcatFwdArgs {
   const __bf16* W1; const __bf16* W2;         // bf16 images of the two hidden layers, [256 out][256 in] row-major; estimator e at + e*pstride
   const float *b1, *b2, *w3, *b3;             // fp32 biases, score-head weight [256] and bias [1]; estimator e at + e*pstride
   long pstride;                               // parameter stride between estimators (elements, same for the image and the fp32 bucket)
-  float *a0, *a1, *a2;                        // [E][B*B][256] post-ReLU activations of layers 0, 1, 2 (written; may NOT be null)
+  // what the backward pass gets (save): 0 nothing (evaluation), 1 fp32 activations a0, a1, a2 (the unfused GEMM-chain backward),
+  // 2 compact: bf16 values a0b, a1b (operands of the weight-gradient GEMMs, which round to bf16 anyway), fp32 a2 (the score head's
+  //   weight gradient sum ds * a2 cancels to ~1e-3 of its terms: bf16 values are not good enough) + ReLU bitmasks m1, m2 (one 32-bit
+  //   word per row and 32 columns; the fused backward, stage 1),
+  // 3 bitmasks only (the fused backward of stage 2: no weight gradients, only the signs are needed; layer 0's sign is recomputed from P, Q)
+  int save;
+  float *a0, *a1, *a2;                        // [E][B*B][256] fp32 (save == 1)
+  __bf16 *a0b, *a1b;                          // [E][B*B][256] bf16 (save == 2)
+  uint32_t *m1, *m2;                          // [E][B*B][8]        (save == 2, 3)
   float* scores;                              // [E][B*B]   row p = i*B + j
   int E, B;
 };
@@ -29,7 +37,9 @@ bool concat_fwd_fused_supported(int B, int hid);
 // the weight-gradient GEMMs plus the column-sum gradients db1, db2, dw3, db3 (float atomics into the zeroed bucket).
 struct ConcatBwdArgs {
   const float* ds;                            // [E][B*B]   d loss / d score
-  const float *a0, *a1, *a2;                  // saved post-ReLU activations (the forward kernel's outputs)
+  const float *a0, *a1, *a2;                  // saved post-ReLU activations, fp32 (the forward kernel's save == 1) -- or, compact:
+  int compact;                                // 1: masks m1, m2 (+ fp32 a2 for dw3 in stage 1) and P, Q (layer 0's sign) instead
+  const uint32_t *m1, *m2; const float *P, *Q;
   const float* w3;                            // score-head weight [256], estimator e at + e*pstride
   const __bf16 *W2T, *W1T;                    // transposed bf16 images [256 in][256 out], estimator e at + e*pstride
   long pstride;

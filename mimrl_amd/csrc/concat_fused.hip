@@ -13,6 +13,7 @@ constexpr int WP = WKC + 8;        // bf16 pitch of a staged weight row (80 B: c
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // 8 waves: wave = (wm, wn): 32-row tile wm of the 128 rows, 128-column half wn (four 32-column MFMA tiles)
+template <int SAVE>   // what the backward pass gets: see ConcatFwdArgs::save (compile time: no branch inside the unrolled epilogues)
 __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 act[CR][AP];
   __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
@@ -26,6 +27,7 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
   // ---- layer 0 in its separable form: act[p][u] = relu(P[i][u] + Q[j][u]),  p = i*B + j   (16 float4 pairs per thread, 4 in flight)
   {
     float* __restrict__ o0 = a.a0 + (ebase + row0) * CH;
+    __bf16* __restrict__ o0b = a.a0b + (ebase + row0) * CH;
 #pragma unroll 1
     for (int base = 0; base < CR * 64; base += 512 * 4) {
       float4 x[4], y[4];
@@ -42,8 +44,9 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
         const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
         float4 v;
         v.x = fmaxf(x[q].x + y[q].x, 0.f); v.y = fmaxf(x[q].y + y[q].y, 0.f); v.z = fmaxf(x[q].z + y[q].z, 0.f); v.w = fmaxf(x[q].w + y[q].w, 0.f);
-        *reinterpret_cast<float4*>(o0 + (long)row * CH + c4) = v;
         bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
+        if (SAVE == 1) *reinterpret_cast<float4*>(o0 + (long)row * CH + c4) = v;
+        else if (SAVE == 2) *reinterpret_cast<bf16x4*>(o0b + (long)row * CH + c4) = b;
         *reinterpret_cast<bf16x4*>(&act[row][c4]) = b;
       }
     }
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
     const __bf16* __restrict__ W = (layer == 1 ? a.W1 : a.W2) + (long)e * a.pstride;
     const float* __restrict__ bias = (layer == 1 ? a.b1 : a.b2) + (long)e * a.pstride;
     float* __restrict__ dst = (layer == 1 ? a.a1 : a.a2) + (ebase + row0) * CH;
+    __bf16* __restrict__ dstb = a.a1b + (ebase + row0) * CH;                       // (layer 1 only)
+    uint32_t* __restrict__ dstm = (layer == 1 ? a.m1 : a.m2) + (ebase + row0) * 8;
     float bn[4], w3c[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -109,12 +114,23 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int mu = wm * 32 + (r & 3) + 8 * (r >> 2), m = mu + 4 * lh, col = wn * 128 + ct * 32 + lr;
         const float v = fmaxf(acc[ct][r] + bn[ct], 0.f);
-        float* __restrict__ drow = dst + (long)mu * CH + ct * 32;
-        drow[soff] = v;
+        if (SAVE == 1 || (SAVE == 2 && layer == 2)) { float* __restrict__ drow = dst + (long)mu * CH + ct * 32; drow[soff] = v; }
+        if (SAVE == 3 || (SAVE == 2 && layer == 1)) {   // ReLU sign of (row, these 32 columns): the ballot's low word is row mu (lanes 0..31), its high word row mu + 4.
+          // Every lane of a half stores the same word to the same address (no divergent branch in the unrolled loop)
+          const unsigned long long bal = __ballot(v > 0.f);
+          dstm[(long)m * 8 + wn * 4 + ct] = lh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        }
         act[m][col] = to_bf16(v);
         hp[r] += v * w3c[ct];
       }
     __syncthreads();
+    if (SAVE == 2 && layer == 1) {   // the finished bf16 tile goes out with coalesced 16-byte stores (8 per thread)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int idx = tid + 512 * q, row = idx >> 5, c8 = (idx & 31) * 8;
+        *reinterpret_cast<u32x4*>(dstb + (long)row * CH + c8) = *reinterpret_cast<const u32x4*>(&act[row][c8]);
+      }
+    }
   }
   // ---- score head (256 -> 1): the per-lane partial dot products are summed over this wave's 32-lane halves (= its 128 columns), then
   // over the two column halves through LDS
@@ -169,6 +185,7 @@ __device__ __forceinline__ void bwd_product(f32x16 (&acc)[4], const __bf16 (*g)[
   }
 }
 
+template <bool COMPACT, bool WG>   // COMPACT: bitmask / bf16 inputs; WG: stage 1 (weight-gradient operands and column-sum gradients)
 __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 gt[CR][AP];
   __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   const int wm = wave & 3, wn = wave >> 2;
   const int e = blockIdx.y, B = a.B;
   const long row0 = (long)blockIdx.x * CR, ebase = (long)e * B * B, tile = (ebase + row0) * CH;
-  const bool wg = a.dz2 != nullptr;      // stage 1: weight-gradient operands and the column-sum gradients are wanted
+  constexpr bool wg = WG;
   if (tid < CH) { cs[0][tid] = 0.f; cs[1][tid] = 0.f; }
   __syncthreads();
   // ---- dZ2 = ds w3^T (.) [a2 > 0]; this thread owns one column quad (c4) and 16 of the 128 rows
@@ -188,17 +205,25 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
     float sds = 0.f;
 #pragma unroll 1
     for (int base = 0; base < CR * 64; base += 512 * 4) {
-      float4 av[4]; float dsv[4];
+      float4 av[4]; float dsv[4]; uint32_t mw[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = (base + tid + 512 * q) >> 6;
-        av[q] = *reinterpret_cast<const float4*>(a.a2 + tile + (long)row * CH + c4);
+        if (COMPACT && !wg) {
+          mw[q] = a.m2[(ebase + row0 + row) * 8 + (c4 >> 5)];
+        } else {
+          av[q] = *reinterpret_cast<const float4*>(a.a2 + tile + (long)row * CH + c4);
+        }
         dsv[q] = a.ds[ebase + row0 + row];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = (base + tid + 512 * q) >> 6;
         const float d = dsv[q];
+        if (COMPACT && !wg) {   // stage 2: only the signs are needed (bitmask)
+          const uint32_t bits = mw[q] >> (c4 & 31);
+          av[q].x = (bits & 1u) ? 1.f : 0.f; av[q].y = (bits & 2u) ? 1.f : 0.f; av[q].z = (bits & 4u) ? 1.f : 0.f; av[q].w = (bits & 8u) ? 1.f : 0.f;
+        }
         float4 v;
         v.x = av[q].x > 0.f ? d * w3v.x : 0.f; v.y = av[q].y > 0.f ? d * w3v.y : 0.f;
         v.z = av[q].z > 0.f ? d * w3v.z : 0.f; v.w = av[q].w > 0.f ? d * w3v.w : 0.f;
@@ -238,8 +263,14 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
       float mk[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float* __restrict__ mrow = a.a1 + tile + (long)(wm * 32 + (r & 3) + 8 * (r >> 2)) * CH + ct * 32;
-        mk[r] = mrow[soff];
+        const int mu = wm * 32 + (r & 3) + 8 * (r >> 2);
+        if (COMPACT) {
+          const uint32_t wrd = a.m1[(ebase + row0 + mu + 4 * lh) * 8 + wn * 4 + ct];
+          mk[r] = ((wrd >> lr) & 1u) ? 1.f : 0.f;
+        } else {
+          const float* __restrict__ mrow = a.a1 + tile + (long)mu * CH + ct * 32;
+          mk[r] = mrow[soff];
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -264,10 +295,18 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       float mk[16];
+      const int colg = wn * 128 + ct * 32 + lr;
+      const long irow = row0 / B, j0 = row0 - irow * B;                      // the tile's x row and its first y row
+      const float pv = COMPACT ? a.P[((long)e * B + irow) * CH + colg] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float* __restrict__ mrow = a.a0 + tile + (long)(wm * 32 + (r & 3) + 8 * (r >> 2)) * CH + ct * 32;
-        mk[r] = mrow[soff];
+        const int mu = wm * 32 + (r & 3) + 8 * (r >> 2);
+        if (COMPACT) {   // layer 0 is relu(P_i + Q_j): its sign is recomputed (the same fp32 sum the forward kernel formed)
+          mk[r] = pv + a.Q[((long)e * B + j0 + mu + 4 * lh) * CH + colg];
+        } else {
+          const float* __restrict__ mrow = a.a0 + tile + (long)mu * CH + ct * 32;
+          mk[r] = mrow[soff];
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -296,9 +335,14 @@ bool concat_bwd_fused_supported(int B, int hid) { return hid == CH && B >= CR &&
 int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a) {
   if (!concat_bwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: batch %d unsupported", a.B);
   if (!a.dz0 || !a.dP || !a.ds) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null argument");
+  if (a.compact ? !(a.m1 && a.m2 && a.P && a.Q && (a.a2 || !a.dz2)) : !(a.a0 && a.a1 && a.a2))
+    return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null activation input");
   if ((a.dz2 != nullptr) != (a.dz1 != nullptr) || (a.dz2 && !(a.db1 && a.db2 && a.dw3 && a.db3)))
     return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the weight-gradient outputs come together");
-  hipLaunchKernelGGL(concat_bwd_kernel, dim3((unsigned)(((long)a.B * a.B) / CR), a.E), dim3(512), 0, s, a);
+  const dim3 grid((unsigned)(((long)a.B * a.B) / CR), a.E);
+  const bool wg = a.dz2 != nullptr;
+  if (a.compact) { if (wg) hipLaunchKernelGGL((concat_bwd_kernel<true, true>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((concat_bwd_kernel<true, false>), grid, dim3(512), 0, s, a); }
+  else { if (wg) hipLaunchKernelGGL((concat_bwd_kernel<false, true>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((concat_bwd_kernel<false, false>), grid, dim3(512), 0, s, a); }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -307,8 +351,14 @@ bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 &&
 
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a) {
   if (!concat_fwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: batch %d unsupported", a.B);
-  if (!a.a0 || !a.a1 || !a.a2 || !a.scores) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: null output");
-  hipLaunchKernelGGL(concat_fwd_kernel, dim3((unsigned)(((long)a.B * a.B) / CR), a.E), dim3(512), 0, s, a);
+  if (!a.scores || a.save < 0 || a.save > 3) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: bad arguments");
+  if ((a.save == 1 && !(a.a0 && a.a1 && a.a2)) || (a.save == 2 && !(a.a0b && a.a1b && a.a2)) || (a.save >= 2 && !a.m1) || (a.save == 3 && !a.m2))
+    return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: null save buffer");
+  const dim3 grid((unsigned)(((long)a.B * a.B) / CR), a.E);
+  if (a.save == 0) hipLaunchKernelGGL(concat_fwd_kernel<0>, grid, dim3(512), 0, s, a);
+  else if (a.save == 1) hipLaunchKernelGGL(concat_fwd_kernel<1>, grid, dim3(512), 0, s, a);
+  else if (a.save == 2) hipLaunchKernelGGL(concat_fwd_kernel<2>, grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(concat_fwd_kernel<3>, grid, dim3(512), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

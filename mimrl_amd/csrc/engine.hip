@@ -212,6 +212,7 @@ struct mimrl_handle {
   float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
+  bool concat_compact = false;         // the last concat forward saved bitmasks (+ bf16 values) for the fused backward, not fp32 activations
   bool fused_concat = true;            // concat critic forward as one launch (concat_fused.hip); MIMRL_NO_FUSED_CONCAT=1 at create time
   bool l0_packed = false;              // see mimrl_create
   bool l0_bwd_pack = false;            // small batches: only the INPUTS are packed (off the chain) and only the weight gradients use them
@@ -1915,9 +1916,18 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
       fa.W1 = crit_img + tower0 + tower_l[1][0]; fa.W2 = crit_img + tower0 + tower_l[2][0];
       fa.b1 = CP(tower0 + tower_l[1][1]); fa.b2 = CP(tower0 + tower_l[2][1]);
       fa.w3 = CP(tower0 + tower_l[3][0]); fa.b3 = CP(tower0 + tower_l[3][1]);
-      fa.pstride = tower_stride; fa.a0 = ca[0]; fa.a1 = ca[1]; fa.a2 = ca[2]; fa.scores = scores; fa.E = NE_MI; fa.B = B;
+      fa.pstride = tower_stride; fa.scores = scores; fa.E = NE_MI; fa.B = B;
+      // what the backward pass will read: the fused one takes ReLU bitmasks (+ bf16 values for stage 1's weight gradients), 32x / 2x
+      // fewer bytes than the fp32 activations the GEMM-chain backward needs; an evaluation saves nothing
+      concat_compact = want_grad && (prec & MIMRL_PREC_BF16_GEMM_BWD) && imgT_ready && concat_bwd_fused_supported(B, HID);
+      const size_t half = (size_t)NE_MI * B * B * (HID / 2);      // floats: the bf16 copy fills the lower half of each fp32-sized buffer
+      fa.save = !want_grad ? 0 : !concat_compact ? 1 : stage == 1 ? 2 : 3;
+      fa.a0 = ca[0]; fa.a1 = ca[1]; fa.a2 = ca[2];
+      fa.a0b = reinterpret_cast<__bf16*>(ca[0]); fa.a1b = reinterpret_cast<__bf16*>(ca[1]);
+      fa.m1 = reinterpret_cast<uint32_t*>(ca[1] + half); fa.m2 = reinterpret_cast<uint32_t*>(ca[2] + half);   // (written in stage 2 only: in stage 1 a2 stays fp32 and fills its buffer)
       MX(concat_fwd_fused(stream, fa));
     } else {
+      concat_compact = false;
       MX(pair_expand_fwd(stream, cP, cQ, ca[0], NE_MI, B, HID));
       const int dims[4] = {HID, HID, HID, 1};
       MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
@@ -2017,12 +2027,15 @@ int mimrl_handle::mi_backward(int stage) {
     return mlp_stack_backward(10, B, B, tower0, tower_stride, 4, tower_l, dims, tin, ta, dtout, dta, din_mi, wgrad);
   }
   const int dims[4] = {HID, HID, HID, 1};
-  if (fused_concat && bf16 && imgT_ready && concat_bwd_fused_supported(B, HID)) {
+  if (concat_compact) {
     // the data-gradient chain of the tail (score head -> both hidden layers -> masked gradient of the pair-expanded layer) as ONE launch
     // with the gradient tile in LDS (concat_fused.hip); dZ2 / dZ1 leave it as bf16 for the two weight-gradient GEMMs of stage 1
     ConcatBwdArgs fa;
     std::memset(&fa, 0, sizeof fa);
-    fa.ds = dscores; fa.a0 = ca[0]; fa.a1 = ca[1]; fa.a2 = ca[2];
+    const size_t half = (size_t)NE_MI * B * B * (HID / 2);
+    fa.ds = dscores; fa.compact = 1;
+    fa.m1 = reinterpret_cast<const uint32_t*>(ca[1] + half); fa.m2 = reinterpret_cast<const uint32_t*>(ca[2] + half);
+    fa.a2 = ca[2]; fa.P = cP; fa.Q = cQ;
     fa.w3 = CP(tower0 + tower_l[3][0]);
     fa.W2T = crit_imgT + tower0 + tower_l[2][0]; fa.W1T = crit_imgT + tower0 + tower_l[1][0];
     fa.pstride = tower_stride; fa.dz0 = dca[2]; fa.dP = dP; fa.E = NE_MI; fa.B = B;
@@ -2040,7 +2053,7 @@ int mimrl_handle::mi_backward(int stage) {
       for (int l = 2; l >= 1; --l) {
         GemmDesc g;
         g.A = reinterpret_cast<const float*>(l == 2 ? dz2 : dz1); g.a_bf16 = 1; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * B * HID;
-        g.B = l == 2 ? ca[1] : ca[0]; g.sb_k = HID; g.sb_n = 1; g.sb_b = (long)B * B * HID;
+        g.B = l == 2 ? ca[1] : ca[0]; g.b_bf16 = 1; g.sb_k = HID; g.sb_n = 1; g.sb_b = (long)B * B * HID;   // (the bf16 copies)
         g.C = CG(tower0 + tower_l[l][0]); g.sc_m = HID; g.sc_n = 1; g.sc_b = tower_stride;
         g.M = HID; g.N = HID; g.K = B * B; g.batch = NE_MI; g.atomic = 1;
         MX(G_on(side_wg ? S(wg_helper) : stream, g));
