@@ -204,6 +204,7 @@ struct mimrl_handle {
   int* d_ints_own = nullptr;           // private fallback storage
   float* d_consts = nullptr;           // coef1[11] coef2[8] gs_mi[2][5] g_bce[2][6] g_cmi[2][6]
   int *lens[2] = {nullptr, nullptr};
+  bool kmix_pg_on_side3 = false;       // K-axis parameter-gradient kernels are in flight on side 3: the BPTT waits for them
   bool begin_in_pack = false;          // the stage-1 begin-of-stage bookkeeping is owed by the next layer-0 pack launch
   hipEvent_t ev_lens = nullptr;        // set while the length scan of this forward pass runs on side 0 (in front of the text projection)
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
@@ -1300,13 +1301,30 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       kw.ik = ik; kw.hk = hk; kw.ok = ok; kw.act = cfg.activation; kw.ln_first = cfg.ln_first;
       kw.drop_p = pk; kw.key = key(); kw.stream_id = 11 + 3 * i;
       GRAB(q);
-      if (defer) {   // data gradient now, parameter gradients later (beside the BPTT); gbuf[cur] stays alive in deferred mode
+      // K-axis parameter gradients: IN the chain kernel (MODE 0: data + parameter gradients; 0.99 ms at cfg2).  The split of round
+      // 2a -- data gradient on the chain, the parameter-gradient reductions as a parked kernel beside the BPTT, 0.97 ms -- was NOT
+      // reproducible (see MIMRL_EARLY_FLUSH below), and starting that kernel early on side 3 with the BPTT waiting for it costs more
+      // (1.02 ms: it fights the chain for CUs).  MIMRL_KMIX_PG_INCHAIN=0: the side-3 variant.
+      static const int kmix_inchain = getenv("MIMRL_KMIX_PG_INCHAIN") ? atoi(getenv("MIMRL_KMIX_PG_INCHAIN")) : 1;   // tuning knob
+      if (defer && kmix_inchain) {
+        MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
+      } else if (defer) {   // data gradient on the chain; gbuf[cur] stays alive in deferred mode
         MX(kmix_bwd_part(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id, 1));
-        Deferred d{5, 2, GemmDesc(), b.l.z, (long)B * ol, id, 0, 0, nullptr};
-        d.p3 = gbuf[cur]; d.kw = kw;
         static const int kdbg = getenv("MIMRL_DBG_KMIX") ? atoi(getenv("MIMRL_DBG_KMIX")) : 0;
-        d.kw.dbg = kdbg;
-        deferred.push_back(d);
+        static const bool kmix_park = getenv("MIMRL_KMIX_PG_PARKED") != nullptr;   // debugging: the round-2a placement (not reproducible!)
+        if (kmix_park) {
+          Deferred d{5, 2, GemmDesc(), b.l.z, (long)B * ol, id, 0, 0, nullptr};
+          d.p3 = gbuf[cur]; d.kw = kw; d.kw.dbg = kdbg;
+          deferred.push_back(d);
+        } else {
+          // The parameter gradients (same arithmetic recomputed) start RIGHT AWAY on side 3, beside the rest of the data-gradient chain,
+          // and model_backward makes the BPTT wait for side 3: this kernel must never be resident next to gru_bwd_kernel -- beside it
+          // the block-0 K-axis gradients came out 5-30 % off in most runs (see MIMRL_EARLY_FLUSH below and tools/kaxis_vals.py)
+          KMixW kp = kw; kp.dbg = kdbg;
+          MX(fork(3, 3));
+          MX(kmix_bwd_part(S(3), b.l.z, gbuf[cur], nullptr, kp, (long)B * ol, id, 2));
+          kmix_pg_on_side3 = true;
+        }
       } else {
         MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
       }
@@ -1422,9 +1440,16 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       release(i_dy);
       cur = i_dx;
     }
-    // tuning knob: hand this block's parameter-gradient work to ONE side stream right away (it then overlaps the rest of
-    // the data-gradient chain instead of queueing up beside the BPTT); 1 = last block only, 2 = every block
-    static const int early = getenv("MIMRL_EARLY_FLUSH") ? atoi(getenv("MIMRL_EARLY_FLUSH")) : 0;
+    // Hand this block's parked parameter-gradient work to ONE side stream right away: it then overlaps the rest of the data-gradient
+    // chain instead of queueing up beside the BPTT (1 = last block only, 2 = every block, 0 = everything behind the chain).
+    // DEFAULT 2 SINCE ROUND 2b, FOR CORRECTNESS: with 0 the K-axis parameter-gradient kernel (kmix_bwd<MODE 2>) ran beside the
+    // layer-1 BPTT and its results were NOT reproducible -- block-0 K-axis gradients off by 5-30 % in most runs, every other tensor
+    // exact (tools/determinism.py, tools/kaxis_vals.py).  Established by elimination: exact with the parked kernels on the main
+    // stream, with a join in front of the BPTT, or flushed early; wrong only while gru_bwd_kernel is resident next to it; device-scope
+    // loads of its inputs repair two of three components.  The mechanism is not understood (no out-of-bounds LDS / global write was
+    // found in either kernel); until it is, nothing register-heavy runs beside the recurrence.  tests/test_gpu_step.py::
+    // test_stage2_gradients_reproducible pins it.  Speed: neutral at cfg2 (0.984 vs 0.986 ms).
+    static const int early = getenv("MIMRL_EARLY_FLUSH") ? atoi(getenv("MIMRL_EARLY_FLUSH")) : 2;
     if (defer && (early == 2 || (early == 1 && i == cfg.n_blocks - 1))) MX(flush_deferred(1));
   }
 #undef GRAB
@@ -1477,7 +1502,8 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   for (const Deferred& d : deferred) {
     if ((dbg_skip_kinds >> d.kind) & 1) continue;
     if (groupk && d.kind == 0) continue;
-    hipStream_t st = only_side > 0 ? S(only_side) : S(1 + (groupk ? rr++ : d.side - 1) % wg_sides);
+    static const bool dbg_defer_main = getenv("MIMRL_DBG_DEFER_MAIN") != nullptr;   // debugging: parked non-GEMM kernels on the main stream
+    hipStream_t st = dbg_defer_main ? stream : only_side > 0 ? S(only_side) : S(1 + (groupk ? rr++ : d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
     else if (d.kind == 2) MX(rowsum_batched(st, d.src, (int)d.n0, (int)d.n1, (int)d.n2, d.dst));
@@ -1535,6 +1561,9 @@ int mimrl_handle::model_backward() {
   // front of the parked kernels (graph nodes are dispatched in capture order).  Measured on cfg2: 1.58 vs 1.36 ms -- the
   // recurrence is latency-bound and loses more to the weight-gradient kernels sharing its CUs from the first cell step on
   // than the ~100 us it waits behind their first wave; default off.
+  // debugging: make the main stream wait for sides 1..3 (the parked kernels) at point n: 1 before the BPTT, 2 behind the layer-1 BPTT,
+  // 3 behind the dh0 product, 4 behind the layer-0 BPTT
+  static const int dbg_join_at = getenv("MIMRL_DBG_JOIN_AT") ? atoi(getenv("MIMRL_DBG_JOIN_AT")) : 0;
   static const bool bptt_first = getenv("MIMRL_BPTT_FIRST") != nullptr;
   hipEvent_t ev_pre = nullptr;
   if (bptt_first && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU && !deferred.empty()) {
@@ -1542,7 +1571,9 @@ int mimrl_handle::model_backward() {
     HIPX(hipEventRecord(ev_pre, stream));
   } else {
     MX(flush_deferred());
+    if (dbg_join_at == 1) MX(join(1, 3));
   }
+  if (cfg.encoder != MIMRL_ENCODER_GRU) kmix_pg_on_side3 = false;   // (joined with every other side at the end of those paths)
   if (cfg.encoder == MIMRL_ENCODER_CONV) {
     MX(conv_backward());
     MX(join(0, 5));
@@ -1553,6 +1584,7 @@ int mimrl_handle::model_backward() {
     MX(join(0, 5));
     return MIMRL_OK;
   }
+  if (kmix_pg_on_side3) { MX(join(3, 3)); kmix_pg_on_side3 = false; }   // (long finished by now: they started beside the CubeMLP chain)
   const float* xin[2] = {bufs.audio, bufs.video};
   for (int l = 1; l >= 0; --l) {
     GruBwdArgs a;
@@ -1572,6 +1604,7 @@ int mimrl_handle::model_backward() {
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
+    if ((l == 1 && dbg_join_at == 2) || (l == 0 && dbg_join_at == 4)) MX(join(1, 3));
     if (l == 1 && ev_pre) MX(flush_deferred(0, ev_pre));
     MX(dbg_delay(stream, 8));
     // side streams of the GRU weight gradients (tuning knobs).  Sides 1..3 still carry the parked CubeMLP parameter-gradient
@@ -1597,6 +1630,7 @@ int mimrl_handle::model_backward() {
       return MIMRL_OK;
     };
     if (l == 1 && !dh0_last) MX(dh0_gemm());
+    if (l == 1 && dbg_join_at == 3) MX(join(1, 3));
     // weight gradients of this layer: off the critical path.  Layer 1: side 1..3 (they overlap the layer-0 BPTT);
     // layer 0 is the tail of the stage.
     if (l == 0 && (l0_packed || l0_bwd_pack)) {

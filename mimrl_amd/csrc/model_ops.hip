@@ -465,12 +465,14 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
     float dzv[NK], dyv[NK], dym[NK], du[NK], dxn[NK], dxv[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {   // unconditional, clamped: a guarded load is a branch with its own vmcnt(0) -- 2 NK dependent round trips
-      const float xv = x[(r * w.ik + (k < w.ik ? k : w.ik - 1)) * D + d];
+      const float* xp = &x[(r * w.ik + (k < w.ik ? k : w.ik - 1)) * D + d];
+      const float xv = (MODE == 2 && (w.dbg & 8)) ? __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *xp;
       v.x[k] = k < w.ik ? xv : 0.f;
     }
 #pragma unroll
     for (int o = 0; o < NK; ++o) {
-      const float gv = dz[(r * w.ok + (o < w.ok ? o : w.ok - 1)) * D + d];
+      const float* gp = &dz[(r * w.ok + (o < w.ok ? o : w.ok - 1)) * D + d];
+      const float gv = (MODE == 2 && (w.dbg & 16)) ? __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *gp;
       dzv[o] = o < w.ok ? gv : 0.f;
       v.sc[o] = o < w.ok ? drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d)) : 0.f;
     }
@@ -857,8 +859,9 @@ int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
-  if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 0>), dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
-  else hipLaunchKernelGGL((kmix_bwd_kernel<8, 0>), dim3(grid_for(R * D, 256, 512)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  static const int wgs = getenv("MIMRL_KMIX_BWD_WGS") ? atoi(getenv("MIMRL_KMIX_BWD_WGS")) : 512;   // tuning knob
+  if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  else hipLaunchKernelGGL((kmix_bwd_kernel<8, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

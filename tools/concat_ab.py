@@ -38,5 +38,7 @@ def worst(a, b, k=5):
     return rows[:k]
 
 
-print("chain vs chain:", worst(c1, c2))
-print("fused vs chain:", worst(f1, c1))
+_, s4, f2 = run(False, anc)
+print("chain vs chain:", worst(c1, c2, 3))
+print("fused vs chain:", worst(f1, c1, 3))
+print("fused vs fused:", worst(f1, f2, 3))

@@ -1,0 +1,28 @@
+"""Diagnostic: are the stage-2 main-model gradients of a bench workload reproducible run to run (fresh engine, same inputs)?
+usage: python tools/determinism.py [workload] [reps]   -- prints the worst tensors (relative to the tensor's scale)"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from tests.test_gpu_step import _bench_engine   # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+runs = []
+anchors = None
+for r in range(reps):
+    opt, N, batch, banks, eng = _bench_engine(wl, "bf16", False, device_anchors=False)
+    if anchors is None:
+        rng = np.random.default_rng(5)
+        m = opt.batch_size // opt.k_neighbor
+        anchors = np.stack([rng.choice(N, size=m, replace=False) for _ in range(6)])
+    eng.set_anchors(2, anchors)
+    eng.stage_grads(2)
+    torch.cuda.synchronize()
+    runs.append({n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if not n.startswith("v")})
+    eng.close()
+for r in range(1, reps):
+    rows = sorted(((np.abs(runs[r][n] - runs[0][n]).max() / (np.abs(runs[0][n]).max() + 1e-12), n) for n in runs[0]), reverse=True)
+    print("run %d vs 0:" % r, [(float("%.2e" % a), n) for a, n in rows[:3]])
