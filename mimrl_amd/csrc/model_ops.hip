@@ -439,8 +439,11 @@ __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__
 // MODE 0: data gradient and parameter gradients together; MODE 1: data gradient only (the critical path of the CubeMLP
 // backward: no accumulators, no reductions, no atomics); MODE 2: parameter gradients only (same arithmetic recomputed on
 // a side stream)
+#ifndef KMIX_MINB
+#define KMIX_MINB 1
+#endif
 template <int NK, int MODE>
-__global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+__global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                        float* __restrict__ dx, KMixW w, long R, int D) {
   constexpr bool GRADS = MODE != 1, DX = MODE != 2;
   __shared__ float sw[3 * KM * KM + 4 * KM];
@@ -544,6 +547,16 @@ __global__ __launch_bounds__(256) void kmix_bwd_kernel(const float* __restrict__
     }
   }
   if (!GRADS) return;
+  if (MODE == 2 && (w.dbg & 32)) {   // debugging: is the LDS copy of the weights still what was staged?  (+1000 on dbe[0] per mismatch)
+    __syncthreads();
+    const int t = threadIdx.x;
+    int bad = 0;
+    if (t < w.hk * w.ik && sw[(t / w.ik) * KM + t % w.ik] != w.w1[t]) ++bad;
+    if (t < w.ok * w.hk && sw[KM * KM + KM + (t / w.hk) * KM + t % w.hk] != w.w2[t]) ++bad;
+    if (w.wr && t < w.ok * w.ik && sw[2 * (KM * KM + KM) + (t / w.ik) * KM + t % w.ik] != w.wr[t]) ++bad;
+    if (t < w.ok && (sw[3 * KM * KM + 2 * KM + t] != w.g[t] || sw[3 * KM * KM + 3 * KM + t] != w.be[t])) ++bad;
+    if (bad) atomicAdd(&w.dbe[0], 1000.f * bad);
+  }
   // one wave reduction + LDS + global atomic per scalar, once per kernel
   float* gw1 = sg; float* gb1 = gw1 + KM * KM; float* gw2 = gb1 + KM; float* gb2 = gw2 + KM * KM;
   float* gwr = gb2 + KM; float* gg = gwr + KM * KM; float* gbe = gg + KM;
