@@ -154,7 +154,7 @@ __device__ __forceinline__ void load_gates(const float* p, Gates& g) {
 // forward
 // ------------------------------------------------------------------------------------------------
 template <bool BF16, bool SAVE>
-__global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
+__global__ __launch_bounds__(256, BF16 ? 2 : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   __shared__ __attribute__((aligned(16))) Tile<BF16, H> hs[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -285,8 +285,12 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs a) {
 //   carry  = dh z + dgh[t] . W_hh                            ([4,384].[384,128] on the matrix cores)
 // dW_ih, dW_hh, biases and the gradient to the layer input are plain GEMMs over the stored dgx/dgh (engine).
 // ------------------------------------------------------------------------------------------------
+// __launch_bounds__(256, 2) for the bf16 instantiations: with (256, 1) the compiler parks 12 (backward) / 48 (forward) values in AGPRs,
+// and next to THAT build a 223-VGPR kernel of another stream (kmix_bwd<MODE 2>) produced non-reproducible results (DESIGN.md section 5:
+// 30 of 30 fresh engines exact with the AGPR-free build, ~70 % of them wrong with the other; mechanism not understood).  190 VGPRs, no
+// AGPRs, no scratch, same speed.  The fp32 instantiations need more than 256 registers and keep (256, 1).
 template <bool BF16, bool DGBF>
-__global__ __launch_bounds__(256, 1) void gru_bwd_kernel(GruBwdArgs a) {
+__global__ __launch_bounds__(256, BF16 ? 2 : 1) void gru_bwd_kernel(GruBwdArgs a) {
   using C = Cfg<BF16>;
   __shared__ __attribute__((aligned(16))) Tile<BF16, G> ds[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
