@@ -477,15 +477,15 @@ def test_fused_concat_backward_matches_gemm_chain(stage, monkeypatch):
         grad_close(ga[n], gb[n], 3e-3 if stage == 1 else 5e-2, n)
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg1"])
-def test_stage2_gradients_reproducible(workload):
+@pytest.mark.parametrize("workload,graph", [("cfg2", False), ("cfg1", False), ("cfg2", True)])
+def test_stage2_gradients_reproducible(workload, graph):
     """Fresh engine, same inputs, the mode bench.py runs minus the graph: every main-model gradient of the stage-2 pass must come out
     the same three times (float atomics reorder additions: 1e-4 of the tensor scale is generous, observed <= 3e-6).  Round 2b found
     the block-0 K-axis parameter gradients off by 5-30 % from run to run while their kernel ran beside the layer-1 BPTT (engine.hip:
     MIMRL_EARLY_FLUSH) -- every parity test passed, because bf16-vs-fp32 bands are wider than that."""
     runs, anchors = [], None
     for r in range(3):
-        opt, N, batch, banks, eng = _bench_engine(workload, "bf16", False, device_anchors=False)
+        opt, N, batch, banks, eng = _bench_engine(workload, "bf16", graph, device_anchors=False)
         if anchors is None:
             rng = np.random.default_rng(5)
             anchors = np.stack([rng.choice(N, size=opt.batch_size // opt.k_neighbor, replace=False) for _ in range(6)])
