@@ -153,8 +153,11 @@ __device__ __forceinline__ void load_gates(const float* p, Gates& g) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+#ifndef GRU_BF16_MINB
+#define GRU_BF16_MINB 2   // -DGRU_BF16_MINB=1: the AGPR-using build of the reproducibility hunt, debugging only
+#endif
 template <bool BF16, bool SAVE>
-__global__ __launch_bounds__(256, BF16 ? 2 : 1) void gru_fwd_kernel(GruFwdArgs a) {
+__global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   __shared__ __attribute__((aligned(16))) Tile<BF16, H> hs[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 1) void gru_fwd_kernel(GruFwdArgs a
 // 30 of 30 fresh engines exact with the AGPR-free build, ~70 % of them wrong with the other; mechanism not understood).  190 VGPRs, no
 // AGPRs, no scratch, same speed.  The fp32 instantiations need more than 256 registers and keep (256, 1).
 template <bool BF16, bool DGBF>
-__global__ __launch_bounds__(256, BF16 ? 2 : 1) void gru_bwd_kernel(GruBwdArgs a) {
+__global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(GruBwdArgs a) {
   using C = Cfg<BF16>;
   __shared__ __attribute__((aligned(16))) Tile<BF16, G> ds[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

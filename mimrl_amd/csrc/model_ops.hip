@@ -493,7 +493,12 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
 #pragma unroll
       for (int o = 0; o < NK; ++o) {
         dyv[o] = o < w.ok ? v.rs * (dzv[o] * g[o] - s1 - v.xh[o] * s2) : 0.f;
-        if (GRADS) { ag[o] += dzv[o] * v.xh[o]; abe[o] += dzv[o]; }
+        if (GRADS) {
+          float term = dzv[o] * v.xh[o];
+          // debugging (parked MODE 2 only): accumulate an intermediate instead -- which quantity is the first one that differs run to run?
+          if (MODE == 2 && (w.dbg & (64 | 128 | 256))) term = (w.dbg & 64) ? v.x[o] : (w.dbg & 128) ? v.y[o] : v.u[o];
+          ag[o] += term; abe[o] += dzv[o];
+        }
       }
     }
 #pragma unroll
