@@ -94,7 +94,8 @@ struct KMixW {
   float *dw1, *db1, *dw2, *db2, *dwr, *dg, *dbe;  // gradient slots (backward only)
   int ik, hk, ok, act, ln_first;
   float drop_p; RngKey key; uint32_t stream_id;   // dropout_k on the MLP branch (MLPProcess.py:81,110)
-  int dbg;                                         // timing experiments only (bit 0: skip the element loop, bit 1: skip the final atomics)
+  int dbg;                                         // debugging only, MIMRL_DBG_KMIX (1: skip the element loop, 2: skip the final atomics; parked MODE 2: 8 / 16 device-scope loads of
+                                                   // x / dz, 32 check the LDS weights, 64 / 128 / 256 accumulate x / y / u in place of the LayerNorm-gain term)
 };
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D);
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D);
