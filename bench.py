@@ -173,9 +173,9 @@ def extra_schedules(eng, args, B, T, rank):
 
     extra["ms_per_step_fresh_batch"] = timed(fresh, n_x)
     extra["fresh_batch_note"] = (f"every step binds a NEW host batch ({sum(x.numel() * 4 for x in host[0]) / 1e6:.1f} MB, pinned): H2D into the idle "
-                                 "input set on a copy stream under the previous step, host-only switch (graphs cached per set); the "
-                                 "concurrent upload itself costs the step ~0.25 ms (tools/fresh_dbg.py: 1.24 -> 1.51 ms with the copy "
-                                 "running and no switch) -- it competes with the graph's branches for the 4 hardware queues")
+                                 "input set on a high-priority copy stream under the running step, host-only switch (graphs cached per set); "
+                                 "the host waits for the idle set (one step of run-ahead).  tools/fresh_variants.py: on a normal-priority "
+                                 "stream the step queued behind the upload (1.47-1.63 ms)")
     torch.cuda.synchronize()
     return extra
 
