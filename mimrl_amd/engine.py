@@ -6,6 +6,7 @@ runs in the hand-written HIP library.  There is no eager/CPU fallback anywhere i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -255,7 +256,8 @@ class HipEngine:
             self._active = 0
             # high priority = its own hardware queue: on a normal-priority stream the copy's barrier packet shares one of the 4
             # hardware queues with a branch of the step graph and the step starts BEHIND the upload (cfg2: 1.47 instead of 1.09 ms)
-            self._copy_stream = torch.cuda.Stream(self.device, priority=-1)
+            self._upload_legacy = os.environ.get("MIMRL_UPLOAD_LEGACY") is not None   # A/B knob: normal-priority stream + stream wait
+            self._copy_stream = torch.cuda.Stream(self.device, priority=0 if self._upload_legacy else -1)
             self._staged_ev = torch.cuda.Event()
             self._free_ev = [torch.cuda.Event(), torch.cuda.Event()]   # set q is no longer read by the device after this point
             for ev in self._free_ev:
@@ -264,8 +266,11 @@ class HipEngine:
         # steps that read the idle set have finished.  A HOST wait (the caller runs at most one step ahead of the device), not
         # hipStreamWaitEvent: a copy parked behind a not-yet-complete event of the compute stream cost the step 0.6 ms on this
         # runtime (tools/fresh_variants.py: 1.63 ms against 1.09 with the host wait)
-        self._free_ev[idle].synchronize()
+        if not self._upload_legacy:
+            self._free_ev[idle].synchronize()
         with torch.cuda.stream(self._copy_stream):
+            if self._upload_legacy:
+                self._copy_stream.wait_event(self._free_ev[idle])
             for dst, src in zip(self._sets[idle], (text, audio, video, labels)):
                 dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
             self._staged_ev.record(self._copy_stream)
