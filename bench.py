@@ -167,9 +167,9 @@ def extra_schedules(eng, args, B, T, rank):
 
     def fresh():
         eng.commit_batch()
-        state["i"] += 1
-        eng.stage_batch(*host[state["i"] % len(host)])
         eng.step()
+        state["i"] += 1
+        eng.stage_batch(*host[state["i"] % len(host)])   # (behind the step, like Solver._iter_loaded: the host wait inside never idles the device)
 
     extra["ms_per_step_fresh_batch"] = timed(fresh, n_x)
     extra["fresh_batch_note"] = (f"every step binds a NEW host batch ({sum(x.numel() * 4 for x in host[0]) / 1e6:.1f} MB, pinned): H2D into the idle "

@@ -33,6 +33,7 @@ _EXTRA_FLAGS = [
     ("precision", _STR, "fp32", ["fp32", "bf16"]),      # MFMA operand type (accumulation/state/optimizer always fp32)
     ("no_graph", _FLAG, None),                          # replay the two stages as hipGraphs unless set
     ("host_anchors", _FLAG, None),                      # draw kNN anchors with numpy's global RNG exactly like Model.py:81
+    ("host_data", _FLAG, None),                         # keep the dataset in (pinned) host memory; default: resident in HBM when it fits
     ("synthetic_n", _INT, 1284),                        # --dataset synthetic: number of training samples (MOSI-sized)
     ("d_t", _INT, 768), ("d_a", _INT, 74), ("d_v", _INT, 35),
 ]

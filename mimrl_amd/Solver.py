@@ -129,11 +129,14 @@ class Solver:
             else:
                 e.set_batch(feats, a, v, labels)
             nxt = next(it, None)
+            yield e, cur
+            # the upload of batch i+1 is enqueued AFTER the caller has enqueued its step on batch i: stage_batch waits (on the host)
+            # until the step before that one has released the idle input set, and with this order the device already has batch i's
+            # step queued while the host waits -- the copy then starts somewhere inside that step, not together with it
             staged = None
             if nxt is not None and len(nxt[5]) == e.cfg.batch:
                 e.stage_batch(nxt[6], nxt[1], nxt[2], nxt[5])
                 staged = e
-            yield e, cur
             cur = nxt
 
     def _anchors(self, e, stage):

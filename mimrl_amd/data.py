@@ -57,12 +57,20 @@ def get_data_loader(opt, rank=0, world=1):
     d_t, d_a, d_v = int(getattr(opt, "d_t", 768)), int(getattr(opt, "d_a", 74)), int(getattr(opt, "d_v", 35))
     drop = bool(getattr(opt, "drop_last", False))
     pin = torch.cuda.is_available()
+    # 288 GB of HBM: MOSI-sized features are 0.2 GB, MOSEI-sized 2.9 GB -- the whole dataset lives on the device and a batch is a
+    # device-to-device slice copy on the upload stream (no PCIe on the step path) unless --host_data or it would not fit
+    device = None
+    if pin and not getattr(opt, "host_data", False):
+        need = 1.5 * n * opt.time_len * (d_t + d_a + d_v) * 4
+        if need < 0.25 * torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory:
+            device = torch.device("cuda", torch.cuda.current_device())
     k = int(getattr(opt, "k_neighbor", 2))
 
     def mk(m, seed, r, w):
         if 0 < m % opt.batch_size < k:      # a last batch with fewer than k_neighbor rows has no kNN product sample (the
             m -= m % opt.batch_size          # reference's sklearn call raises on it, Model.py:85-86): do not generate one
-        return SyntheticLoader(m, opt.batch_size, opt.time_len, d_t, d_a, d_v, seed=seed, drop_last=drop, rank=r, world=w, pin=pin)
+        return SyntheticLoader(m, opt.batch_size, opt.time_len, d_t, d_a, d_v, seed=seed, drop_last=drop, rank=r, world=w, pin=pin,
+                               device=device)
 
     return (mk(n, opt.seed, rank, world), mk(max(n // 6, opt.batch_size), opt.seed + 1, 0, 1),
             mk(max(n // 3, opt.batch_size), opt.seed + 2, 0, 1), d_t, d_a, d_v)

@@ -217,3 +217,36 @@ def test_main_cli_subprocess_smoke(tmp_path):
     assert "Epoch:[  2]" in log and "Training complete." in log and "nan" not in log.lower()
     ck = torch.load(task / "best_valid_model.pth.tar", map_location="cpu")
     assert "W_t.weight" in ck["model"] and "vmi_estimator_f_t.critic_model.MLP_g.0.weight" in ck["model"]
+
+
+def test_resident_dataset_equals_host_dataset():
+    """data.get_data_loader: by default the (small) dataset lives in HBM and a batch is a device-to-device slice copy on the upload
+    stream; --host_data keeps it in pinned host memory (H2D per batch).  Same seeds -> the same epoch either way, including the
+    one-batch upload lookahead of Solver._iter_loaded and a partial last batch (n=100, B=16)."""
+    from mimrl_amd import Parameters
+    from mimrl_amd.data import get_data_loader
+    argv = ["--dataset", "synthetic", "--synthetic_n", "100", "--batch_size", "16", "--time_len", "12", "--d_hiddens", "12-3-128=4-3-128",
+            "--d_outs", "12-3-128=4-3-128", "--bias", "--res_project", "1-1", "--dropout", "0.0-0.0-0.0-0.0", "--dropout_mlp", "0.0-0.0-0.0",
+            "--loss_mi_coefficient1", "-".join(["1.0"] * 11), "--loss_mi_coefficient2", "-".join(["0.01"] * 8), "--learning_rate", "1e-4",
+            "--task_name", "pytest_resident"]
+    out = {}
+    for host in (False, True):
+        opt = Parameters.parse_args(argv + (["--host_data"] if host else []))
+        loaders = get_data_loader(opt)
+        assert loaders[0].t.is_cuda == (not host) and (host is False or loaders[0].t.is_pinned())
+        sol = Solver(solver_opt(opt, host_anchors=False, no_graph=False), loaders)
+        sol.model.load_state_dict(oracle_params(opt, 3))
+        banks = ([], [], [], [], [])
+        res = []
+        for ep in range(2):
+            r = sol.train(ep, sol.train_loader, *banks)
+            banks = r[4:]
+            e = sol.evaluate(sol.valid_loader, *banks)
+            res.append((float(r[0]), float(r[1]), np.asarray(r[2], dtype=np.float64), float(e[0]), banks[1].cpu().numpy().copy()))
+        out[host] = res
+    for (a, b) in zip(out[False], out[True]):
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(a[3], b[3], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(a[4], b[4], rtol=1e-4, atol=1e-5)

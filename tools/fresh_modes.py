@@ -19,7 +19,7 @@ for mode, stepfn in ((True, eng.step), (2, lambda: mdist.ddp_two_stage_step(eng,
     a = timed(stepfn)
     eng.stage_batch(*host[0])
     def fresh():
-        eng.commit_batch(); i[0] += 1; eng.stage_batch(*host[i[0] % 4]); stepfn()
+        eng.commit_batch(); stepfn(); i[0] += 1; eng.stage_batch(*host[i[0] % 4])
     b = timed(fresh)
     eng.commit_batch()
     print("prefetch mode %s: resident %.3f  fresh batch %.3f" % (mode, a, b))
