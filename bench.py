@@ -285,6 +285,8 @@ def main():
     # ---- live per-phase and GEMM-family timing with HIP events on the launch streams (eager launches)
     phases, roof, kernels = {}, None, []
     if rank == 0 and args.profile_steps > 0:
+        if world > 1:
+            eng.set_stage2_prefetch(False)   # the lone stage calls below are the sequential schedule (deferred-tail mode refuses them)
         eng.profile(True)
         for _ in range(3):
             eng.stage1_step(); eng.stage2_step()

@@ -24,10 +24,12 @@ def init_from_env(backend: str = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # MIMRL_DIST_BACKEND=gloo: testing only (two ranks on ONE device, which RCCL refuses)
+            backend = os.environ.get("MIMRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 
