@@ -22,6 +22,7 @@ def init_from_env(backend: str = None):
     """Initialise torch.distributed from torchrun's environment; returns (world, rank, local_rank)."""
     world, rank, local = env_world()
     if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this pool's host driver only has dmabuf IPC (RCCL's xGMI transport needs it)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:   # MIMRL_DIST_BACKEND=gloo: testing only (two ranks on ONE device, which RCCL refuses)
