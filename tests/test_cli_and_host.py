@@ -55,3 +55,40 @@ def test_ddp_two_ranks_gloo():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DDP_OK" in r.stdout
+
+
+def test_upload_lookahead_order_and_host_data_flag():
+    """Solver._iter_loaded: batch i+1 is staged AFTER the caller's step on batch i has been enqueued (the generator resumes behind the
+    yield), committed in front of the next step, and a partial last batch (another engine handle) is bound with set_batch instead.
+    data.get_data_loader: --host_data parses; without a GPU the loaders hold plain host tensors either way."""
+    from types import SimpleNamespace
+    from mimrl_amd.Solver import Solver
+    from mimrl_amd.data import get_data_loader
+
+    log = []
+
+    class FakeEngine:
+        def __init__(self, b):
+            self.cfg = SimpleNamespace(batch=b)
+        def set_batch(self, t, a, v, y): log.append(("set", self.cfg.batch, int(y[0])))
+        def stage_batch(self, t, a, v, y): log.append(("stage", self.cfg.batch, int(y[0])))
+        def commit_batch(self): log.append(("commit", self.cfg.batch))
+
+    engines = {}
+    sol = Solver.__new__(Solver)
+    sol._engine_for = lambda b, training=True: engines.setdefault(b, FakeEngine(b))
+    mk = lambda i, b: (None, torch.zeros(b, 2, 3), torch.zeros(b, 2, 3), None, None, torch.full((b, 1), float(i)), torch.zeros(b, 2, 4),
+                       None, None, None, None)
+    loader = [mk(0, 4), mk(1, 4), mk(2, 4), mk(3, 2)]
+    for e, datas in sol._iter_loaded(loader):
+        log.append(("step", e.cfg.batch, int(datas[5][0])))
+    assert log == [("set", 4, 0), ("step", 4, 0), ("stage", 4, 1), ("commit", 4), ("step", 4, 1), ("stage", 4, 2), ("commit", 4),
+                   ("step", 4, 2), ("set", 2, 3), ("step", 2, 3)], log
+
+    argv = ["--dataset", "synthetic", "--synthetic_n", "20", "--batch_size", "8", "--time_len", "4"]
+    for extra in ([], ["--host_data"]):
+        opt = Parameters.parse_args(argv + extra)
+        assert bool(opt.host_data) == bool(extra)
+        if not torch.cuda.is_available():
+            tr = get_data_loader(opt)[0]
+            assert not tr.t.is_cuda and len(tr) == 3
