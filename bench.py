@@ -395,6 +395,7 @@ def main():
                            "peak_tflops": PEAK_TFLOPS["bf16" if _lib.PREC[args.precision] else "fp32"],
                            "frac_of_mfma_peak_executed": world * executed_flops(opt, N, (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX")) / (wall / args.steps) / 1e12 / (world * PEAK_TFLOPS["bf16" if _lib.PREC[args.precision] else "fp32"])},
             **extra,
+            "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MIMRL_")},   # every MIMRL_* variable of this run (none = defaults)
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,
             "stage1_loss": float(scal[_lib.S1_LOSS]), "stage2_loss": float(scal[_lib.S2_LOSS]),
         }

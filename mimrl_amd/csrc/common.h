@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 
 #include "../../include/mimrl.h"
@@ -30,6 +31,18 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 #define LAUNCH_CHECK() HIPX(hipGetLastError())
+
+// Environment knobs.  Tuning knobs (stream placement, kernel variants: results unchanged) are read with getenv() where they
+// are used.  DEBUG knobs change RESULTS (skip work, stop a kernel early, re-create a placement known to miscompute): they exist
+// only in a -DMIMRL_DEBUG_KNOBS build (`make DEBUG_KNOBS=1`); in the default build dbg_env() is a constant nullptr -- the
+// branches behind it fold away -- and mimrl_create() refuses to run while one of them is set in the environment.
+#ifdef MIMRL_DEBUG_KNOBS
+inline const char* dbg_env(const char* name) { return getenv(name); }
+#else
+inline const char* dbg_env(const char*) { return nullptr; }
+#endif
+// names of every result-changing knob (errors.cpp); mimrl_create checks them
+extern const char* const kDebugKnobs[];
 
 // ----------------------------------------------------------------------------------------------
 // device math

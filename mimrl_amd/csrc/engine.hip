@@ -1011,7 +1011,7 @@ int mimrl_handle::cube_forward(bool train, bool save) {
         fa.d_u = b.d.u; fa.d_h = b.d.h; fa.d_y = b.d.y; fa.d_mean = b.d.mean; fa.d_rstd = b.d.rstd;
       }
       fa.d_z = b.d.z;
-      fa.dbg_phase = getenv("MIMRL_CUBE_PHASE") ? atoi(getenv("MIMRL_CUBE_PHASE")) : 0;
+      fa.dbg_phase = dbg_env("MIMRL_CUBE_PHASE") ? atoi(dbg_env("MIMRL_CUBE_PHASE")) : 0;
       fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.K = ik; fa.act = cfg.activation; fa.save = save ? 1 : 0;
       if (fa.dbg_phase == 100) { fa.save = 0; fa.dbg_phase = 0; }   // timing-only: skip the saved-activation stores
       MX(cube_block_fwd_fused(stream, fa));
@@ -1305,13 +1305,13 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       // 2a -- data gradient on the chain, the parameter-gradient reductions as a parked kernel beside the BPTT, 0.97 ms -- was NOT
       // reproducible (see MIMRL_EARLY_FLUSH below), and starting that kernel early on side 3 with the BPTT waiting for it costs more
       // (1.02 ms: it fights the chain for CUs).  MIMRL_KMIX_PG_INCHAIN=0: the side-3 variant.
-      static const int kmix_inchain = getenv("MIMRL_KMIX_PG_INCHAIN") ? atoi(getenv("MIMRL_KMIX_PG_INCHAIN")) : 1;   // tuning knob
+      static const int kmix_inchain = dbg_env("MIMRL_KMIX_PG_INCHAIN") ? atoi(dbg_env("MIMRL_KMIX_PG_INCHAIN")) : 1;   // tuning knob
       if (defer && kmix_inchain) {
         MX(kmix_bwd(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id));
       } else if (defer) {   // data gradient on the chain; gbuf[cur] stays alive in deferred mode
         MX(kmix_bwd_part(stream, b.l.z, gbuf[cur], gbuf[q], kw, (long)B * ol, id, 1));
-        static const int kdbg = getenv("MIMRL_DBG_KMIX") ? atoi(getenv("MIMRL_DBG_KMIX")) : 0;
-        static const bool kmix_park = getenv("MIMRL_KMIX_PG_PARKED") != nullptr;   // debugging: the round-2a placement (not reproducible!)
+        static const int kdbg = dbg_env("MIMRL_DBG_KMIX") ? atoi(dbg_env("MIMRL_DBG_KMIX")) : 0;
+        static const bool kmix_park = dbg_env("MIMRL_KMIX_PG_PARKED") != nullptr;   // debugging: the round-2a placement (not reproducible!)
         if (kmix_park) {
           Deferred d{5, 2, GemmDesc(), b.l.z, (long)B * ol, id, 0, 0, nullptr};
           d.p3 = gbuf[cur]; d.kw = kw; d.kw.dbg = kdbg;
@@ -1449,7 +1449,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
     // loads of its inputs repair two of three components.  The mechanism is not understood (no out-of-bounds LDS / global write was
     // found in either kernel); until it is, nothing register-heavy runs beside the recurrence.  tests/test_gpu_step.py::
     // test_stage2_gradients_reproducible pins it.  Speed: neutral at cfg2 (0.984 vs 0.986 ms).
-    static const int early = getenv("MIMRL_EARLY_FLUSH") ? atoi(getenv("MIMRL_EARLY_FLUSH")) : 2;
+    static const int early = dbg_env("MIMRL_EARLY_FLUSH") ? atoi(dbg_env("MIMRL_EARLY_FLUSH")) : 2;
     if (defer && (early == 2 || (early == 1 && i == cfg.n_blocks - 1))) MX(flush_deferred(1));
   }
 #undef GRAB
@@ -1483,7 +1483,7 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   } else if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
   for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
   static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
-  static const int dbg_skip_kinds = getenv("MIMRL_DBG_SKIP_DEFERRED") ? atoi(getenv("MIMRL_DBG_SKIP_DEFERRED")) : 0;   // timing experiments only (bit = kind)
+  static const int dbg_skip_kinds = dbg_env("MIMRL_DBG_SKIP_DEFERRED") ? atoi(dbg_env("MIMRL_DBG_SKIP_DEFERRED")) : 0;   // timing experiments only (bit = kind)
   // the weight-gradient GEMMs as (at most) two grouped split-K launches, one per operand-layout class: D-axis products are
   // (RC,RC), the batch-reduced L-axis products (KC,KC).  Alone each is a ~20 us launch of 4..64 tiles.
   static const bool no_wg_groupk = getenv("MIMRL_NO_WG_GROUPK") != nullptr;   // tuning knob
@@ -1502,7 +1502,7 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
   for (const Deferred& d : deferred) {
     if ((dbg_skip_kinds >> d.kind) & 1) continue;
     if (groupk && d.kind == 0) continue;
-    static const bool dbg_defer_main = getenv("MIMRL_DBG_DEFER_MAIN") != nullptr;   // debugging: parked non-GEMM kernels on the main stream
+    static const bool dbg_defer_main = dbg_env("MIMRL_DBG_DEFER_MAIN") != nullptr;   // debugging: parked non-GEMM kernels on the main stream
     hipStream_t st = dbg_defer_main ? stream : only_side > 0 ? S(only_side) : S(1 + (groupk ? rr++ : d.side - 1) % wg_sides);
     if (d.kind == 0) MX(G_on(st, d.g));
     else if (d.kind == 1) MX(colsum(st, d.src, d.n0, (int)d.n1, (int)d.n2, d.dst));
@@ -1563,7 +1563,7 @@ int mimrl_handle::model_backward() {
   // than the ~100 us it waits behind their first wave; default off.
   // debugging: make the main stream wait for sides 1..3 (the parked kernels) at point n: 1 before the BPTT, 2 behind the layer-1 BPTT,
   // 3 behind the dh0 product, 4 behind the layer-0 BPTT
-  static const int dbg_join_at = getenv("MIMRL_DBG_JOIN_AT") ? atoi(getenv("MIMRL_DBG_JOIN_AT")) : 0;
+  static const int dbg_join_at = dbg_env("MIMRL_DBG_JOIN_AT") ? atoi(dbg_env("MIMRL_DBG_JOIN_AT")) : 0;
   static const bool bptt_first = getenv("MIMRL_BPTT_FIRST") != nullptr;
   hipEvent_t ev_pre = nullptr;
   if (bptt_first && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU && !deferred.empty()) {
@@ -2175,7 +2175,7 @@ int mimrl_handle::route_feature_grads() {
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
-  static const bool dbg_skip_imgt = getenv("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
+  static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
   static const bool imgt_first = getenv("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
   bool imgT_pending = false;
   imgT_ready = false;
@@ -2189,7 +2189,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     }
     imgT_ready = true;
   }
-  static const int dbg_skip = getenv("MIMRL_DBG_SKIP_EST") ? atoi(getenv("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
+  static const int dbg_skip = dbg_env("MIMRL_DBG_SKIP_EST") ? atoi(dbg_env("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
   MX(fork(5, 5));
   MX(chain(5, 4));                       // the CMI branch needs the kNN indices
   auto cmi_branch = [&]() -> int {
@@ -2574,6 +2574,13 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   *out = nullptr;
   MX(validate_cfg(*cfg));
   if (cfg->batch > 1024) return set_error(MIMRL_ERR_ARG, "batch per rank must be <= 1024");
+#ifndef MIMRL_DEBUG_KNOBS
+  // result-changing debug knobs do not exist in this build; a run that sets one expects something this library will not do
+  for (int i = 0; kDebugKnobs[i]; ++i)
+    if (getenv(kDebugKnobs[i]))
+      return set_error(MIMRL_ERR_ARG, "%s is set, but result-changing debug knobs are compiled out of this build "
+                       "(rebuild with `make DEBUG_KNOBS=1` for timing experiments; never for real runs)", kDebugKnobs[i]);
+#endif
   MX(mimrl_device_check());
   mimrl_handle* h = new (std::nothrow) mimrl_handle();
   if (!h) return set_error(MIMRL_ERR_STATE, "out of host memory");

@@ -796,7 +796,7 @@ int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, floa
     attr = true;
   }
   hipLaunchKernelGGL(mi_sep_fused_kernel, dim3(E), dim3(1024), (size_t)B * B * sizeof(float) + (size_t)B * (B + 2) * 2, s, tout, dtout, mi, mil, gscale, B,
-                     bound, lossform, do_bwd, lb, dlb, lb_stride, getenv("MIMRL_DBG_MI") ? atoi(getenv("MIMRL_DBG_MI")) : 0);
+                     bound, lossform, do_bwd, lb, dlb, lb_stride, dbg_env("MIMRL_DBG_MI") ? atoi(dbg_env("MIMRL_DBG_MI")) : 0);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -807,7 +807,7 @@ int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
 
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return MIMRL_OK;
-  static const int dbg_skip = getenv("MIMRL_DBG_SKIP_WGRAD") ? atoi(getenv("MIMRL_DBG_SKIP_WGRAD")) : 0;   // timing experiments only
+  static const int dbg_skip = dbg_env("MIMRL_DBG_SKIP_WGRAD") ? atoi(dbg_env("MIMRL_DBG_SKIP_WGRAD")) : 0;   // timing experiments only
   if (dbg_skip && d.atomic && (dbg_skip == 1 || (dbg_skip == 2 && d.batch > 1 && d.sc_b == 0))) return MIMRL_OK;
   if (!d.A || !d.B || !d.C) return set_error(MIMRL_ERR_ARG, "gemm: null operand");
   if ((d.A2 != nullptr) != (d.B2 != nullptr)) return set_error(MIMRL_ERR_ARG, "gemm: second product needs both operands");
@@ -825,7 +825,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
   static const int no_xcd = getenv("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
   ka.xcd_remap = !no_xcd;
-  static const int dbg_gemm = getenv("MIMRL_DBG_GEMM") ? atoi(getenv("MIMRL_DBG_GEMM")) : 0;
+  static const int dbg_gemm = dbg_env("MIMRL_DBG_GEMM") ? atoi(dbg_env("MIMRL_DBG_GEMM")) : 0;
   ka.dbg = dbg_gemm;
   ka.ksplit = pl.nsplit;
   ka.kt_per = pl.kt_per;

@@ -730,7 +730,7 @@ bool mlp_bwd_takes_top_wgrad(const MlpFusedArgs& a) {
 
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
   MlpFusedArgs a = a_;
-  a.dbg = getenv("MIMRL_DBG_MLPB") ? atoi(getenv("MIMRL_DBG_MLPB")) : 0;
+  a.dbg = dbg_env("MIMRL_DBG_MLPB") ? atoi(dbg_env("MIMRL_DBG_MLPB")) : 0;
   MX(check(a));
   if (a.dw_top && !mlp_bwd_takes_top_wgrad(a)) return set_error(MIMRL_ERR_ARG, "mlp_stack_bwd_fused: dw_top not supported for this stack");
   if (a.WbT[0]) {

@@ -1,0 +1,64 @@
+"""Register-budget tripwire (CPU tier): reads the kernel metadata of the gfx950 code objects inside libmimrl_hip.so.
+
+Why: round 2 found a miscompute that depended on code generation only -- a 223-VGPR kernel resident beside an AGPR-using
+BPTT build produced wrong K-axis gradients (root cause unknown, the structural fix keeps such kernels
+apart).  The facts that fix relies on are asserted here, so that a compiler or source change which silently alters them fails
+the CPU tier instead of corrupting gradients on the GPU: the bf16 recurrence kernels hold nothing in AGPRs, and no kernel of
+the benchmarked path spills to scratch."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import codeobj_meta as M  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(M.LIB) and os.path.exists(os.path.join(M.LLVM_BIN, "llvm-readelf")) and shutil.which("c++filt")),
+                                reason="needs the built library and the ROCm llvm tools")
+
+
+@pytest.fixture(scope="module")
+def ks():
+    return M.kernels()
+
+
+def test_every_tu_is_present(ks):
+    for name in ("gru_fwd_kernel<true, true>", "gru_bwd_kernel<true, true>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0>",
+                 "concat_fwd_kernel<3>", "mlp_img8_kernel<true, 4>", "adam_kernel", "knn_kernel<2, 4>", "lstm_fwd_kernel"):
+        assert name in ks, name
+    assert len(ks) > 120
+
+
+def test_bf16_recurrence_kernels_are_agpr_free(ks):
+    """gru_*_kernel<bf16> are what every side kernel of the backward pass is co-resident with."""
+    for name, v in ks.items():
+        if name.startswith(("gru_fwd_kernel<true", "gru_bwd_kernel<true")):
+            assert v["agpr_count"] == 0, (name, v)
+            assert v["vgpr_count"] <= 192 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
+            assert v["max_flat_workgroup_size"] == 256
+
+
+def test_bench_path_kernels_do_not_spill(ks):
+    hot = ("gemm_fast_kernel<", "gemm_fast_bf_kernel<", "gemm_group_kernel<", "gemm_groupk_kernel<", "cube_fwd_fused_kernel<false, 1, 2>",
+           "cube_fwd_fused_kernel<false, 3, 2>", "cube_fwd_fused_kernel<true, 3, 2>", "daxis_bwd_kernel", "laxis_bwd_kernel",
+           "kmix_bwd_kernel<4, 0>", "mlp_img8_kernel<", "mi_sep_nce_kernel", "concat_fwd_kernel<", "concat_bwd_kernel<", "tail_pre_kernel",
+           "adam_kernel", "head_fwd_kernel", "head_bwd_kernel", "cmi_loss_kernel", "daxis_param_grads_kernel", "colln_param_grads_kernel")
+    seen = set()
+    for name, v in ks.items():
+        if name.startswith(hot):
+            seen.add(name)
+            assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)   # (SGPR spills go to VGPR lanes, not memory)
+    assert len(seen) >= 40
+
+
+def test_chain_kernel_beside_nothing_register_heavy(ks):
+    """kmix_bwd<MODE 0> (K-axis data + parameter gradients, in the chain since round 2b): AGPR-free, no scratch."""
+    v = ks["kmix_bwd_kernel<4, 0>"]
+    assert v["agpr_count"] == 0 and v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, v
+
+
+def test_lds_budgets(ks):
+    for name, v in ks.items():
+        assert v["group_segment_fixed_size"] <= 160 * 1024, (name, v)
