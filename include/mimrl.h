@@ -224,6 +224,17 @@ int mimrl_op_mlp_stack_forward(void* stream, int nb, int rows, int brows, int nl
 int mimrl_op_mlp_stack_backward(void* stream, int nb, int rows, int brows, int nl, const int32_t* dims, const float* const* W,
                                 int64_t pstride, const float* const* act, const float* dout, float* const* dz, float* din,
                                 float* const* db);
+/* ---- test probes: ONE sub-block of the step run by the engine's own code path (same kernels, buffers, streams and precision mode as a
+ * step of this handle) on caller-supplied operands.  The fused bf16 kernels of the benchmarked mode have no stand-alone entry point;
+ * the parity tests reach them through these (tests/test_gpu_fused_oracle.py: float64 autograd of the oracle on rounded operands). */
+/* CubeMLP stack, MLPEncoder.forward (MLPProcess.py:124-137) and its autograd: x [B,time_len,3,128] -> out [B,ol,ok,128] of the last block;
+ * with dout (same shape as out): dx [B,time_len,3,128] and every mlp_encoder.* gradient in main_g (the bucket is zeroed first). */
+int mimrl_probe_cube(mimrl_handle* h, const float* x, float* out, const float* dout, float* dx);
+/* The five MI estimators of `stage` (Model.py:313-319 / 352-361, VMI.py:53-69) on the CALLER-WRITTEN mimrl_buffers.feats, forward +
+ * backward: mi [2][5] = bound values, loss terms; scores [5][B][B] (concat critic only, else NULL); stage 1: every vmi_estimator_*
+ * gradient in crit_g (zeroed first), objective sum_e -coef1[e] mi_e; stage 2: dtin_out [5][2][B][128] = gradient of
+ * sum_e g2[e] mi_e (g2 = -coef2[0], -coef2[1], -coef2[2], -coef2[3], -coef2[3], Model.py:364-386) w.r.t. the (x, y) operand of each estimator. */
+int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* dtin_out);
 int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,
                   float beta1, float beta2, float eps, float weight_decay, float clip);
 

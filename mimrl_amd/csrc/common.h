@@ -195,5 +195,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 __device__ __forceinline__ __bf16 to_bf16(float x) { return (__bf16)x; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+// fp16 MFMA operands (same rate as bf16, 11 instead of 8 significant bits) for FORWARD operands of bounded range (LayerNorm'd
+// activations, weights): see cube_fused.hip.  Gradients stay bf16 (range).  v_cvt_f16_f32 rounds to nearest even, overflow -> inf.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+__device__ __forceinline__ _Float16 to_f16(float x) { return (_Float16)x; }
+__device__ __forceinline__ _Float16 to_f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
 
 }  // namespace mimrl

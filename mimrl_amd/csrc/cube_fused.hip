@@ -1,4 +1,12 @@
-// Fused CubeMLP block forward for gfx950 (see cube_fused.h).  bf16 MFMA operands, fp32 accumulation / LayerNorm.
+// Fused CubeMLP block forward for gfx950 (see cube_fused.h).  16-bit MFMA operands, fp32 accumulation / LayerNorm.
+//
+// OPERAND TYPE: fp16, not bf16 (round 3).  The MFMA rate, the LDS footprint and every layout are the same, but fp16 keeps 11
+// significant bits instead of 8, and this block is where the model is sensitive: the head sends a gradient that is a broadcast over
+// (l, k), each LayerNorm of the backward pass cancels ~90 % of it, and what survives is decided by the forward values (act'(U), x-hat)
+// -- a 2^-9 perturbation of them moved individual gradient entries by 10-70 % and the main-bucket gradient to cosine 0.964 against
+// fp32 (float64 experiment per rounding point: weights 0.985, tile operands 0.992, tile write-backs 0.995; all in fp16: 0.9998).
+// Range is not a concern on this path: every operand is a LayerNorm output, an activation of one, a weight, or the block input
+// (text projection / relu(LN(gru))), which is converted with saturation.  Gradient operands (the backward kernels) stay bf16.
 //
 // One workgroup (4 waves) per sample.  The sample tile x[L, K, 128] (<= 64 x 512) is loaded once into LDS as bf16 and
 // never leaves the CU until the block output is written:
@@ -24,14 +32,14 @@ constexpr int ILD = 72;                  // image row length (bf16): 64 + 8 -> 1
 constexpr int IMG = 64 * ILD;            // elements per 64x64 image
 constexpr int CTL = 68, CTD = 132;       // fp32 staging tile row lengths
 
-typedef __bf16 bf;
+typedef _Float16 bf;   // the tile / operand element type of this kernel: fp16 (see the header comment)
 
 __device__ __forceinline__ void mma64(f32x16& acc, const bf* A, const bf* B, int wm, int wn, int lane) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (wm * 32 + (lane & 31)) * ILD + s * 16 + 8 * (lane >> 5));
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + (wn * 32 + (lane & 31)) * ILD + s * 16 + 8 * (lane >> 5));
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    const f16x8 a = *reinterpret_cast<const f16x8*>(A + (wm * 32 + (lane & 31)) * ILD + s * 16 + 8 * (lane >> 5));
+    const f16x8 b = *reinterpret_cast<const f16x8*>(B + (wn * 32 + (lane & 31)) * ILD + s * 16 + 8 * (lane >> 5));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
   }
 }
 __device__ __forceinline__ int acc_row(int r, int wm, int lane) { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -39,7 +47,7 @@ __device__ __forceinline__ int acc_row(int r, int wm, int lane) { return wm * 32
 // stage a 64(n) x 64(k) weight image  Bw[n][k] = W[(n0+n)*ld + k0 + k]  (fp32 global -> bf16 LDS), zero beyond (N, K)
 __device__ __forceinline__ void stage_weight(bf* img, const float* __restrict__ W, int ld, int n0, int k0, int N, int K, int tid) {
   const int n = tid >> 2, kc = (tid & 3) * 16;
-  bf16x8 lo, hi;
+  f16x8 lo, hi;
   // 16 UNCONDITIONAL loads from clamped addresses, zeroed afterwards: a guarded load is a branch whose join waits for every
   // outstanding load, i.e. 16 dependent round trips per image (this staging was 10 of the block's 18 us of set-up)
   const int gn = n0 + n, gnc = gn < N ? gn : N - 1;
@@ -53,10 +61,10 @@ __device__ __forceinline__ void stage_weight(bf* img, const float* __restrict__ 
   for (int j = 0; j < 16; ++j) {
     const int gk = k0 + kc + j;
     const float x = (gn < N && gk < K) ? v[j] : 0.f;
-    if (j < 8) lo[j] = to_bf16(x); else hi[j - 8] = to_bf16(x);
+    if (j < 8) lo[j] = to_f16(x); else hi[j - 8] = to_f16(x);
   }
-  *reinterpret_cast<bf16x8*>(img + n * ILD + kc) = lo;
-  *reinterpret_cast<bf16x8*>(img + n * ILD + kc + 8) = hi;
+  *reinterpret_cast<f16x8*>(img + n * ILD + kc) = lo;
+  *reinterpret_cast<f16x8*>(img + n * ILD + kc + 8) = hi;
 }
 // 128-wide row-major weights (D axis): a 64x64 image = 4 float4 per thread.  Split into issue (global -> registers)
 // and commit (registers -> bf16 LDS image) so that the next image's loads are in flight during the current MFMAs.
@@ -68,13 +76,13 @@ __device__ __forceinline__ WImg load_weight128(const float* __restrict__ W, int 
 }
 __device__ __forceinline__ void commit_weight128(bf* img, const WImg& w, int tid) {
   const int n = tid >> 2, kc = (tid & 3) * 16;
-  bf16x8 lo, hi;
-  lo[0] = to_bf16(w.q0.x); lo[1] = to_bf16(w.q0.y); lo[2] = to_bf16(w.q0.z); lo[3] = to_bf16(w.q0.w);
-  lo[4] = to_bf16(w.q1.x); lo[5] = to_bf16(w.q1.y); lo[6] = to_bf16(w.q1.z); lo[7] = to_bf16(w.q1.w);
-  hi[0] = to_bf16(w.q2.x); hi[1] = to_bf16(w.q2.y); hi[2] = to_bf16(w.q2.z); hi[3] = to_bf16(w.q2.w);
-  hi[4] = to_bf16(w.q3.x); hi[5] = to_bf16(w.q3.y); hi[6] = to_bf16(w.q3.z); hi[7] = to_bf16(w.q3.w);
-  *reinterpret_cast<bf16x8*>(img + n * ILD + kc) = lo;
-  *reinterpret_cast<bf16x8*>(img + n * ILD + kc + 8) = hi;
+  f16x8 lo, hi;
+  lo[0] = to_f16(w.q0.x); lo[1] = to_f16(w.q0.y); lo[2] = to_f16(w.q0.z); lo[3] = to_f16(w.q0.w);
+  lo[4] = to_f16(w.q1.x); lo[5] = to_f16(w.q1.y); lo[6] = to_f16(w.q1.z); lo[7] = to_f16(w.q1.w);
+  hi[0] = to_f16(w.q2.x); hi[1] = to_f16(w.q2.y); hi[2] = to_f16(w.q2.z); hi[3] = to_f16(w.q2.w);
+  hi[4] = to_f16(w.q3.x); hi[5] = to_f16(w.q3.y); hi[6] = to_f16(w.q3.z); hi[7] = to_f16(w.q3.w);
+  *reinterpret_cast<f16x8*>(img + n * ILD + kc) = lo;
+  *reinterpret_cast<f16x8*>(img + n * ILD + kc + 8) = hi;
 }
 
 struct Carve {          // byte offsets into dynamic LDS (all multiples of 16)
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
         const int i = i0 + NT * j;
         if (i < total) {
           const int l = i / nq, c4 = (i - l * nq) * 4;
-          bf16x4 p; p[0] = to_bf16(q[j].x); p[1] = to_bf16(q[j].y); p[2] = to_bf16(q[j].z); p[3] = to_bf16(q[j].w);
-          *reinterpret_cast<bf16x4*>(Xm + l * XP + c4) = p;
+          f16x4 p; p[0] = to_f16_sat(q[j].x); p[1] = to_f16_sat(q[j].y); p[2] = to_f16_sat(q[j].z); p[3] = to_f16_sat(q[j].w);   // (caller data: saturate)
+          *reinterpret_cast<f16x4*>(Xm + l * XP + c4) = p;
         }
       }
     }
@@ -173,11 +181,11 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     const bool on = n0 < C;                                   // (barriers are workgroup-wide: an idle group keeps step)
     if (on) {   // Bx[n][k] = X[k][n0+n]   (transpose within LDS; 16 consecutive k per thread -> two 16-byte stores)
       const int n = t & 63, kg = (t >> 6) * 16;
-      bf16x8 lo, hi;
+      f16x8 lo, hi;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { lo[j] = Xm[(kg + j) * XP + n0 + n]; hi[j] = Xm[(kg + 8 + j) * XP + n0 + n]; }
-      *reinterpret_cast<bf16x8*>(Bx + n * ILD + kg) = lo;
-      *reinterpret_cast<bf16x8*>(Bx + n * ILD + kg + 8) = hi;
+      *reinterpret_cast<f16x8*>(Bx + n * ILD + kg) = lo;
+      *reinterpret_cast<f16x8*>(Bx + n * ILD + kg + 8) = hi;
     }
     __syncthreads();
     f32x16 acc;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       const int n = wn * 32 + (lane & 31);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 p;
+        f16x4 p;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = acc_row(4 * g + q, wm, lane);
@@ -202,9 +210,9 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
               a.l_h[((long)b * hl + m) * C + n0 + n] = h;
             }
           }
-          p[q] = to_bf16(h);
+          p[q] = to_f16(h);
         }
-        *reinterpret_cast<bf16x4*>(Bh + n * ILD + wm * 32 + 8 * g + 4 * (lane >> 5)) = p;
+        *reinterpret_cast<f16x4*>(Bh + n * ILD + wm * 32 + 8 * g + 4 * (lane >> 5)) = p;
       }
     }
     __syncthreads();
@@ -251,10 +259,13 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
           const int m = q + 4 * j;
           if (m < ol) {
             const float z = (yv[j] - mu) * rs * prm[128 + m] + prm[192 + m];
-            Xm[m * XP + n0 + n] = to_bf16(z);                     // in place: this slab's X columns are dead
+            const bf zb = to_f16(z);
+            Xm[m * XP + n0 + n] = zb;                             // in place: this slab's X columns are dead
             if (SAVE) {
               a.l_y[((long)b * ol + m) * C + n0 + n] = yv[j];
-              a.l_z[((long)b * ol + m) * C + n0 + n] = z;
+              // the backward pass gets the value the K phase CONSUMED (the rounded one): kmix_bwd recomputes the K-axis forward from it,
+              // and LayerNorm over K = 3 amplifies a 2^-9 difference of the evaluation point into percents of the gradient
+              a.l_z[((long)b * ol + m) * C + n0 + n] = (float)zb;
             }
           }
         }
@@ -281,8 +292,9 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
 #pragma unroll
       for (int o = 0; o < 4; ++o)
         if (o < K) {
-          Xm[l * XP + o * D + d] = to_bf16(out[o]);
-          if (SAVE) a.k_z[(((long)b * ol + l) * K + o) * D + d] = out[o];
+          const bf ob = to_f16(out[o]);
+          Xm[l * XP + o * D + d] = ob;
+          if (SAVE) a.k_z[(((long)b * ol + l) * K + o) * D + d] = (float)ob;   // (what the D phase consumed)
         }
     }
   }
@@ -298,14 +310,14 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
   bf* Ah = reinterpret_cast<bf*>(smem + cv.ah);     // [NMT][2][64][ILD]   A-images of H
   for (int c = tid; c < NMT * 64 * 16; c += NT) {    // 16-byte chunks: row r, chunk ch (8 d-values)
     const int r = c >> 4, ch = c & 15;
-    bf16x8 v;
+    f16x8 v;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = to_bf16(0.f);
+    for (int j = 0; j < 8; ++j) v[j] = to_f16(0.f);
     if (r < R) {
       const int l = r / K, kk = r - l * K;
-      v = *reinterpret_cast<const bf16x8*>(Xm + l * XP + kk * D + ch * 8);
+      v = *reinterpret_cast<const f16x8*>(Xm + l * XP + kk * D + ch * 8);
     }
-    *reinterpret_cast<bf16x8*>(Az + ((r >> 6) * 2 + (ch >> 3)) * IMG + (r & 63) * ILD + (ch & 7) * 8) = v;
+    *reinterpret_cast<f16x8*>(Az + ((r >> 6) * 2 + (ch >> 3)) * IMG + (r & 63) * ILD + (ch & 7) * 8) = v;
   }
   __syncthreads();   // Xm is dead from here on (the weight-image buffers alias it)
   if (tid < D) { dgam[tid] = a.d_g[tid]; dbet[tid] = a.d_be[tid]; }   // visible after the barriers of the GEMM loops
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
             a.d_h[((long)b * R + row) * D + col] = h;
           }
         }
-        Ah[(mt * 2 + nt) * IMG + m * ILD + n] = to_bf16(h);     // A-image of the next product: k = this column
+        Ah[(mt * 2 + nt) * IMG + m * ILD + n] = to_f16(h);     // A-image of the next product: k = this column
         acc[mt][q][r] = 0.f;
       }
     }

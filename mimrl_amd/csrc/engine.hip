@@ -29,6 +29,7 @@ namespace {
 
 constexpr int H = 128, G = 384, HID = 256, EMB = 128;
 constexpr int NE_MI = 5, NE_CMI = 6;
+constexpr int ACT_SLACK = 4 * MLPF_MAX_WIDTH;   // floats behind every saved-activation buffer of the fused MLP stacks (MlpFusedArgs::act_slack)
 
 // feature slots: F,T,A,V ; 4 = labels (C)
 enum { FT_F = 0, FT_T = 1, FT_A = 2, FT_V = 3, FT_C = 4 };
@@ -272,6 +273,8 @@ struct mimrl_handle {
   bool fused_cube_bwd = true;          // bf16 mode: per-axis fused data-gradient chains of CubeMLP (MIMRL_NO_FUSED_CUBE_BWD=1 disables)
   bool fused_mlp = true;               // bf16 mode: estimator MLP stacks as one kernel per direction (MIMRL_NO_FUSED_MLP=1 disables)
   bool fused_cube = true;              // bf16 mode: CubeMLP blocks as one LDS-resident kernel (MIMRL_NO_FUSED_CUBE=1 disables)
+  int fwd_f16 = 1;                     // bf16 mode: the forward products in front of / inside CubeMLP round their operands to FP16, not bf16
+                                       // (GemmDesc::f16, cube_fused.hip: main-gradient cosine vs fp32 0.964 -> 0.998); MIMRL_FWD_BF16=1: off
   int next_event(hipEvent_t* e) {
     if (ev_next == ev_pool.size()) {
       hipEvent_t n;
@@ -427,6 +430,18 @@ struct mimrl_handle {
   int carve();
 
   int G_(const GemmDesc& d) { return G_on(stream, d); }
+  // diagnosis of bf16 fidelity (tools/bf16_diag.py): MIMRL_FWD_FP32_SITES=<mask> runs single forward sites with fp32 operands although the
+  // precision mode says bf16 -- 1: W_t projection, 2: GRU layer-0 input projections, 4: layer-1 input projections, 8: estimator stacks.
+  // Results stay valid (only more precise); tuning knob.
+  static bool fp32_site(int bit) {
+    static const int mask = getenv("MIMRL_FWD_FP32_SITES") ? atoi(getenv("MIMRL_FWD_FP32_SITES")) : 0;
+    return (mask & bit) != 0;
+  }
+  struct PrecGuard {   // run a scope with fp32 GEMM operands
+    mimrl_handle* h; bool saved;
+    PrecGuard(mimrl_handle* h_, bool force_fp32) : h(h_), saved(h_->bf16) { if (force_fp32) h->bf16 = false; }
+    ~PrecGuard() { h->bf16 = saved; }
+  };
   // weight-gradient work parked by cube_backward and issued on the side streams once the data-gradient chain is through
   // (it then overlaps the latency-bound GRU BPTT instead of competing with the chain for CUs and L2)
   struct Deferred { int kind; int side; GemmDesc g; const float* src; long n0, n1, n2, n3; float* dst;
@@ -684,7 +699,7 @@ int mimrl_handle::carve() {
   MX(take(&scores, NE_MI * B * B));
   MX(take(&dscores, NE_MI * B * B));
   if (sep) {
-    for (int l = 0; l < 3; ++l) MX(take(&ta[l], 10 * B * HID));
+    for (int l = 0; l < 3; ++l) MX(take(&ta[l], 10 * B * HID + ACT_SLACK));
     MX(take(&tout, 10 * B * EMB));
     MX(take(&dtout, 10 * B * EMB));
     for (int l = 0; l < 3; ++l) MX(take(&dta[l], 10 * B * HID));
@@ -698,12 +713,12 @@ int mimrl_handle::carve() {
   if (cfg.baseline_type != MIMRL_BASELINE_CONSTANT) {
     MX(take(&lbv, NE_MI * 2 * B)); MX(take(&dlbv, NE_MI * 2 * B)); MX(take(&bdin, NE_MI * 2 * B * EMB));
     if (cfg.baseline_type == MIMRL_BASELINE_UNNORMALIZED)
-      for (int l = 0; l < 3; ++l) { MX(take(&bact[l], NE_MI * 2 * B * HID)); MX(take(&bdz[l], NE_MI * 2 * B * HID)); }
+      for (int l = 0; l < 3; ++l) { MX(take(&bact[l], NE_MI * 2 * B * HID + ACT_SLACK)); MX(take(&bdz[l], NE_MI * 2 * B * HID)); }
   }
   const size_t n = nprod();
   MX(take(&knn_idx, NE_CMI * n)); MX(take(&knn_idx2, NE_CMI * n));
   MX(take(&cmi_in, NE_CMI * 2 * n * 384));
-  for (int l = 0; l < 3; ++l) MX(take(&cc[l], NE_CMI * 2 * n * HID));
+  for (int l = 0; l < 3; ++l) MX(take(&cc[l], NE_CMI * 2 * n * HID + ACT_SLACK));
   MX(take(&logits, NE_CMI * 2 * n * 2));
   MX(take(&dlogits, NE_CMI * 2 * n * 2));
   for (int l = 0; l < 3; ++l) MX(take(&dcc[l], NE_CMI * 2 * n * HID));
@@ -795,6 +810,8 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       gd.sa_b = 0; gd.sa_bo = BT_ * KP(); gd.sb_b = (long)G * KP(); gd.sb_bo = 2L * G * KP();
       gd.sc_b = gx[0][1] - gx[0][0]; gd.sc_bo = gx[1][0] - gx[0][0];
       gd.bias_n = bpack; gd.bias_n_b = G; gd.bias_n_bo = 2 * G;
+      gd.f16 = fwd_f16;
+      PrecGuard pg(this, fp32_site(2));
       MX(G_on(stream, gd));
     }
     for (int m = 0; m < 2; ++m) {
@@ -806,6 +823,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       GemmDesc gd = gemm_nt(in, gf.din, P(gf.w_ih), gf.din, gx[m][0], G, (int)BT_, G, gf.din);
       gd.batch = 2; gd.sa_b = 0; gd.sb_b = gr.w_ih - gf.w_ih; gd.sc_b = gx[m][1] - gx[m][0];
       gd.bias_n = P(gf.b_ih); gd.bias_n_b = gr.b_ih - gf.b_ih;
+      gd.f16 = fwd_f16;
       if (l == 1) {
         gd.batch = 4; gd.batch_in = 2;
         gd.sa_bo = h0[1] - h0[0]; gd.sb_bo = gru[1][l][0].w_ih - gf.w_ih; gd.sc_bo = gx[1][0] - gx[0][0];
@@ -813,7 +831,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       }
       // layer 1: the m == 0 launch covers both modalities; layer 0: video beside audio (side 2, or behind the length scan on side 4
       // when the overlap mode has masked side 2 off -- both are joined in front of the recurrence)
-      if ((l == 0 && !l0_packed) || (l == 1 && m == 0)) MX(G_on(m == 0 ? stream : (side_on(2) ? S(2) : S(4)), gd));
+      if ((l == 0 && !l0_packed) || (l == 1 && m == 0)) { PrecGuard pg(this, fp32_site(l == 0 ? 2 : 4)); MX(G_on(m == 0 ? stream : (side_on(2) ? S(2) : S(4)), gd)); }
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
@@ -944,7 +962,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
       MX(next_event(&ev_lens));
       HIPX(hipEventRecord(ev_lens, S(0)));
     }
-    { GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); MX(G_on(S(0), g)); }
+    { PrecGuard pg(this, fp32_site(1)); GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); g.f16 = fwd_f16; MX(G_on(S(0), g)); }
     MX(dbg_delay(S(0), 10));
     if (part == 0 && !fused_pre) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
     MX(encoders_forward(save, knn_stage));
@@ -1031,6 +1049,7 @@ int mimrl_handle::cube_forward(bool train, bool save) {
       g1.C = b.l.h; g1.sc_m = C; g1.sc_n = 1; g1.sc_b = (long)hl * C;
       g1.M = hl; g1.N = (int)C; g1.K = il; g1.batch = B;
       g1.bias_m = a.fc1.b >= 0 ? P(a.fc1.b) : nullptr; g1.act = cfg.activation; g1.pre = b.l.u;
+      g1.f16 = fwd_f16;
       MX(G_(g1));
       GemmDesc g2;   // Y = W2 . H_b + b2
       g2.A = P(a.fc2.w); g2.sa_m = hl; g2.sa_k = 1;
@@ -1773,6 +1792,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     MlpFusedArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.nb = nb; fa.rows = rows; fa.brows = brows; fa.nl = nl; fa.pstride = pstride; fa.in = in; fa.dout = dout; fa.din = din;
+    fa.act_slack = 1;   // ta / cc / bact are carved with ACT_SLACK floats behind them
     for (int l = 0; l <= nl; ++l) fa.dims[l] = dims[l];
     for (int l = 0; l < nl; ++l) {
       fa.W[l] = CP(p0 + l_off[l][0]);
@@ -2174,7 +2194,7 @@ int mimrl_handle::route_feature_grads() {
 
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
-  const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0 && !fp32_site(8), bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
   static const bool imgt_first = getenv("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
   bool imgT_pending = false;
@@ -2595,6 +2615,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   h->fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") == nullptr;
+  h->fwd_f16 = getenv("MIMRL_FWD_BF16") == nullptr;
   // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches: the four layer-0
   // weight-gradient GEMMs in a row are what closes the stage behind the BPTT.  (History: before the parked CubeMLP weight gradients
   // became two grouped launches the side streams were the bottleneck and packing lost at cfg2, 1.34 vs 1.32 ms; since then it
@@ -2713,6 +2734,76 @@ int mimrl_estimate(mimrl_handle* h, int stage) {
                        h->coef2(), 1);
   }
   LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+// ---- test probes: one sub-block of the step, run by the engine's OWN code path (same kernels, buffers and precision mode as a step of
+//      this handle) on caller-supplied operands.  The fused bf16 kernels (cube_fwd_fused, daxis / kmix / laxis_bwd, concat_fwd / concat_bwd,
+//      mlp_img8 + mi_sep_nce) have no stand-alone entry: these are how tests/test_gpu_fused_oracle.py compares them with the oracle.
+int mimrl_probe_cube(mimrl_handle* h, const float* x, float* out, const float* dout, float* dx) {
+  if (!h || !x || !out) return set_error(MIMRL_ERR_ARG, "null argument");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  if (dout && !dx) return set_error(MIMRL_ERR_ARG, "dout without dx");
+  const mimrl_cfg& c = h->cfg;
+  const int nb = c.n_blocks;
+  const size_t nin = (size_t)c.batch * c.time_len * 3 * c.d_common;
+  const size_t nout = (size_t)c.batch * c.d_outs[nb - 1][0] * c.d_outs[nb - 1][1] * c.d_outs[nb - 1][2];
+  h->ev_next = 0;
+  HIPX(hipMemcpyAsync(h->cube0, x, sizeof(float) * nin, hipMemcpyDeviceToDevice, h->stream));
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+  MX(h->cube_forward(false, dout != nullptr));
+  HIPX(hipMemcpyAsync(out, h->bb[nb - 1].d.z, sizeof(float) * nout, hipMemcpyDeviceToDevice, h->stream));
+  if (!dout) return MIMRL_OK;
+  if (nout > h->gbuf_floats) return set_error(MIMRL_ERR_STATE, "probe: gradient buffer too small");
+  HIPX(hipMemsetAsync(h->bufs.main_g, 0, sizeof(float) * h->layout.floats[MIMRL_GROUP_MAIN], h->stream));
+  HIPX(hipMemcpyAsync(h->gbuf[0], dout, sizeof(float) * nout, hipMemcpyDeviceToDevice, h->stream));
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  const bool pre = h->wtT_prebuilt;
+  h->wtT_prebuilt = false;                 // (the combined step builds the D-axis weight images beside the encoders; here: in place)
+  h->deferred.clear();
+  int ci = 0;
+  int r = h->cube_backward(0, &ci);
+  if (r == 0) r = h->flush_deferred();
+  h->wtT_prebuilt = pre;
+  h->kmix_pg_on_side3 = false;
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+  MX(r);
+  MX(h->join(0, 5));
+  HIPX(hipMemcpyAsync(dx, h->gbuf[ci], sizeof(float) * nin, hipMemcpyDeviceToDevice, h->stream));
+  h->grads_clean[2] = false;
+  return MIMRL_OK;
+}
+
+int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* dtin_out) {
+  if (!h || !mi) return set_error(MIMRL_ERR_ARG, "null argument");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
+  const int B = h->cfg.batch;
+  const bool bf_fwd = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (h->prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  h->ev_next = 0;
+  MX(h->ensure_images());
+  h->imgT_ready = false;
+  if (bf_bwd && h->fused_mlp && h->crit_imgT && h->ttab.n > 0) {   // as estimators_all does, but in line
+    MX(bf16_transposed_images(h->stream, h->bufs.crit_p, h->crit_imgT, h->ttab));
+    h->imgT_ready = true;
+  }
+  if (stage == 1) HIPX(hipMemsetAsync(h->bufs.crit_g, 0, sizeof(float) * h->layout.floats[MIMRL_GROUP_CRITIC], h->stream));
+  h->bf16 = bf_fwd;
+  int r = h->mi_forward(stage, true);
+  if (r == 0) { h->bf16 = bf_bwd; h->wg_helper = -1; r = h->mi_backward(stage); }
+  h->bf16 = bf_fwd;
+  MX(r);
+  MX(h->join(0, 5));
+  HIPX(hipMemcpyAsync(mi, h->mi_raw, sizeof(float) * 2 * NE_MI, hipMemcpyDeviceToDevice, h->stream));
+  if (scores) {
+    if (h->cfg.critic_type != MIMRL_CRITIC_CONCAT) return set_error(MIMRL_ERR_ARG, "probe: the separable fused path does not materialise scores");
+    HIPX(hipMemcpyAsync(scores, h->scores, sizeof(float) * NE_MI * B * B, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (dtin_out) {
+    if (stage != 2) return set_error(MIMRL_ERR_ARG, "probe: tower-input gradients exist in stage 2 only");
+    HIPX(hipMemcpyAsync(dtin_out, h->dtin, sizeof(float) * 2 * NE_MI * B * EMB, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (stage == 1) h->grads_clean[1] = false;
   return MIMRL_OK;
 }
 

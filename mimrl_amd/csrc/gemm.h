@@ -37,6 +37,11 @@ struct GemmDesc {
   // operand storage: A (and A2) / B (and B2) are bf16 arrays behind the float-typed pointers (strides in bf16 elements).  Fast
   // path only (16-byte pieces go straight to LDS, no conversion): everything must be 8-element aligned, else gemm() fails.
   int a_bf16 = 0, b_bf16 = 0;
+  // bf16 mode only: round the operands to FP16 instead of bf16 (v_mfma_f32_32x32x16_f16: same rate, 11 instead of 8 significant bits;
+  // saturating conversion).  For FORWARD products whose operands have a bounded range (inputs, weights, LayerNorm'd activations) and
+  // feed the ill-conditioned backward of CubeMLP (see cube_fused.hip).  Honoured by the fast path with both operands k-contiguous
+  // (every forward product of the step at aligned sizes); other kernels ignore it and round to bf16.
+  int f16 = 0;
 };
 
 // A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T

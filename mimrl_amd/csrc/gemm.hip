@@ -366,9 +366,16 @@ struct FT {
   static constexpr int KB = 2 * T;      // RC: consecutive k per thread (T=2: 32 row-quads x 8 k-quads; T=1: 16 x 16 k-pairs)
 };
 
+// F16: the 16-bit operand type is fp16 (saturating conversion), stored in the same LDS image as bit patterns (GemmDesc::f16)
+template <bool F16 = false>
 __device__ __forceinline__ bf16x4 cvt4(const float4& q) {
-  bf16x4 p; p[0] = to_bf16(q.x); p[1] = to_bf16(q.y); p[2] = to_bf16(q.z); p[3] = to_bf16(q.w);
-  return p;
+  if constexpr (F16) {
+    f16x4 h; h[0] = to_f16_sat(q.x); h[1] = to_f16_sat(q.y); h[2] = to_f16_sat(q.z); h[3] = to_f16_sat(q.w);
+    return __builtin_bit_cast(bf16x4, h);
+  } else {
+    bf16x4 p; p[0] = to_bf16(q.x); p[1] = to_bf16(q.y); p[2] = to_bf16(q.z); p[3] = to_bf16(q.w);
+    return p;
+  }
 }
 
 // every load is unconditional from a clamped (valid) address and zeroed afterwards: a guarded load is a branch whose
@@ -434,7 +441,7 @@ __device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, i
   }
 }
 
-template <int T, bool KC, bool BF>
+template <int T, bool KC, bool BF, bool F16 = false>
 __device__ __forceinline__ void fast_store(const float4* v, __bf16* __restrict__ img, int tid) {
   if constexpr (BF) {
     if constexpr (KC) {
@@ -452,13 +459,13 @@ __device__ __forceinline__ void fast_store(const float4* v, __bf16* __restrict__
 #pragma unroll
     for (int h = 0; h < FT<T>::NV; ++h) {
       const int idx = h * 256 + tid;
-      *reinterpret_cast<bf16x4*>(img + (idx >> 3) * FT<T>::KCP + (idx & 7) * 4) = cvt4(v[h]);
+      *reinterpret_cast<bf16x4*>(img + (idx >> 3) * FT<T>::KCP + (idx & 7) * 4) = cvt4<F16>(v[h]);
     }
   } else {
     constexpr int KB = FT<T>::KB;
     const int rq = tid & (16 * T - 1), kq = tid / (16 * T);
 #pragma unroll
-    for (int j = 0; j < KB; ++j) *reinterpret_cast<bf16x4*>(img + (kq * KB + j) * FT<T>::RCP + rq * 4) = cvt4(v[j]);
+    for (int j = 0; j < KB; ++j) *reinterpret_cast<bf16x4*>(img + (kq * KB + j) * FT<T>::RCP + rq * 4) = cvt4<F16>(v[j]);
   }
 }
 
@@ -479,7 +486,7 @@ __device__ __forceinline__ bf16x8 fast_frag(const __bf16* __restrict__ img, int 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool GEN, bool ABF = false, bool BBF = false>
+template <int TM, int TN, bool AKC, bool BKC, bool GEN, bool ABF = false, bool BBF = false, bool F16 = false>
 __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_per, int dbg, unsigned bx, unsigned by, unsigned bzr) {
   constexpr int BMf = 64 * TM, BNf = 64 * TN;
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][FT<TM>::ELEMS];
@@ -513,8 +520,8 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
     if (kt0 >= kt1) return;
     fast_load<TM, AKC, ABF>(Ap, sa, m0, d.M, ga_at, ga, K, kt0 * FBK, tid, ra);
     fast_load<TN, BKC, BBF>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, kt0 * FBK, tid, rb);
-    fast_store<TM, AKC, ABF>(ra, sA[0], tid);
-    fast_store<TN, BKC, BBF>(rb, sB[0], tid);
+    fast_store<TM, AKC, ABF, F16>(ra, sA[0], tid);
+    fast_store<TN, BKC, BBF, F16>(rb, sB[0], tid);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = (kt - kt0) & 1;
@@ -533,11 +540,14 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bfr[j]), acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          }
       }
       if (more) {
-        fast_store<TM, AKC, ABF>(ra, sA[cur ^ 1], tid);
-        fast_store<TN, BKC, BBF>(rb, sB[cur ^ 1], tid);
+        fast_store<TM, AKC, ABF, F16>(ra, sA[cur ^ 1], tid);
+        fast_store<TN, BKC, BBF, F16>(rb, sB[cur ^ 1], tid);
       }
       __syncthreads();
     }
@@ -570,6 +580,13 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(KernelArgs ka) {
   unsigned bx, by, bzr;
   tile_ids(ka.xcd_remap, bx, by, bzr);
   fast_body<TM, TN, AKC, BKC, GEN>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
+}
+// fp16 operands (GemmDesc::f16): forward products (KC,KC) only
+template <int TM, int TN, bool GEN>
+__global__ __launch_bounds__(256) void gemm_fast_f16_kernel(KernelArgs ka) {
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
+  fast_body<TM, TN, true, true, GEN, false, false, true>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
 }
 // bf16-stored operands (plain epilogue): A bf16 with B fp32 (data gradient dh0, dW_ih against fp32 inputs) or both bf16 (dW_hh)
 template <int TM, int TN, bool AKC, bool BKC, bool BBF>
@@ -836,7 +853,9 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if ((d.a_bf16 || d.b_bf16) && !pl.fast)
     return set_error(MIMRL_ERR_ARG, "gemm: bf16-stored operands need the fast path (bf16 mode, 8-element alignment, A bf16, layouts KC/RC or RC/RC, plain epilogue)");
 #define FASTK(TM_, TN_, A_, B_)                                                                               \
-  if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);         \
+  if (d.f16 && gen) hipLaunchKernelGGL((gemm_fast_f16_kernel<TM_, TN_, true>), grid, dim3(256), 0, s, ka);    \
+  else if (d.f16) hipLaunchKernelGGL((gemm_fast_f16_kernel<TM_, TN_, false>), grid, dim3(256), 0, s, ka);     \
+  else if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);    \
   else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \
   break
 #define FASTB(TM_, TN_, A_, B_)                                                                               \

@@ -33,6 +33,8 @@ struct MlpFusedArgs {
   float* db_top;                  // optional bias gradient of the TOP layer (column sums of dout), group g at + g*pstride
   float* dw_top;                  // optional WEIGHT gradient of a narrow top layer (dims[nl] * dims[nl-1] <= 512, e.g. the 2-logit CMI
                                   // head: dW = dout^T act[nl-2]), accumulated; only where mlp_bwd_takes_top_wgrad() says so
+  int act_slack;                  // backward: >= 4 * MLPF_MAX_WIDTH floats are readable behind the END of every act[] buffer (the engine's arena
+                                  // guarantees it; the operator-level ABI cannot and leaves it 0: ragged tiles then take the 4-wave kernel)
   int dbg;                        // timing experiments only (MIMRL_DBG_MLPB): 1 no ReLU mask, 2 no bias atomics, 4 no dz stores
 };
 

@@ -383,9 +383,8 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
   const long rowbase = (long)g * a.brows + r0;
   const int lr = lane & 31, lh = lane >> 5;
   const int srow = lane >> 3, sk = (lane & 7) * 8;            // staging map: 8 rows x 64 k (bf16) per 16-byte instruction
-  // ragged last row tile: loads use a clamped row = min(uniform part, rclamp) + lhoff (<= rows_here - 1), stores are guarded
+  // ragged last row tile: stores are guarded; the mask loads use a clamped wave-uniform row (see the mask loop)
   const int rows_here = min(RT, a.rows - r0);
-  const int lhoff = min(4 * lh, rows_here - 1), rclamp = max(rows_here - 5, 0);
 
   // geometry of the layer processed at `step`
   auto layer_of = [&](int step) { return BWD ? a.nl - 1 - step : step; };
@@ -470,10 +469,18 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
       //  they cost 32 registers per access group and the backward instantiation spilled)
       float mk[16];
       if (BWD && mask) {
-        const unsigned loff = (unsigned)(lhoff * N + min(nt * 32 + lr, N - 1));
+        // accumulator r of a lane is row mu + 4 * lh, mu = (r & 3) + 8 * (r >> 2).  Row pointer = wave-uniform min(mu, rows_here - 1), the
+        // upper half-wave adds 4 rows through the ONE lane offset: in a ragged tile it then reads up to 4 rows past the group's last row
+        // (the next group's rows, or -- last group -- the slack the caller guarantees behind the buffer: MlpFusedArgs::act_slack); those
+        // values are discarded (`ok` below).  Per-access clamps of the upper half cost registers this 256-VGPR kernel does not have
+        // (three variants tried: 3 / 15 / 49 spilled VGPRs).  Round 3 fix: the previous clamp min(mu, rows_here - 5) + 4 * lh was right for
+        // the upper half only -- in a ragged tile the LOWER half read row rows_here - 5 for every mu beyond it (rows 8..11 of a 12-row
+        // tile all saw row 7's mask), i.e. wrong hidden-layer gradients for every batch that is not a multiple of 32
+        // (tests/test_gpu_fused_oracle.py::test_mi_estimators_vs_rounded_oracle[tiny_odd-s1] found it).
+        const unsigned loff = (unsigned)(4 * lh * N + min(nt * 32 + lr, N - 1));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float* __restrict__ mrow = mask + (rowbase + min((r & 3) + 8 * (r >> 2), rclamp)) * (long)N;
+          const float* __restrict__ mrow = mask + (rowbase + min((r & 3) + 8 * (r >> 2), rows_here - 1)) * (long)N;
           mk[r] = mrow[loff];
         }
       }
@@ -699,6 +706,9 @@ static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wa
     if (K >= 16 && K % 8 != 0) return 0;
     kmax = K > kmax ? K : kmax;
   }
+  // backward, ragged last row tile: the 8-wave kernel's mask loads touch up to 4 rows behind a group's last row (see the kernel);
+  // without the caller's guarantee that this is mapped memory the 4-wave kernel (per-lane clamps) takes the stack
+  if (bwd && a.rows % RT != 0 && !a.act_slack) return 0;
   if (bwd) return kmax <= 256 ? 4 : 0;      // (the 6-chunk backward instantiation spills)
   return kmax <= 256 ? 4 : 6;
 }

@@ -230,6 +230,34 @@ class HipEngine:
         """Estimators only, on the features left by the last forward (Model.compute_vmi_loss_stage1/2)."""
         check(self.lib.mimrl_estimate(self.handle, stage))
 
+    # ------------------------------------------------------------------ test probes (include/mimrl.h: mimrl_probe_*)
+    def probe_cube(self, x, dout=None):
+        """The CubeMLP stack through the engine's own kernels (current precision mode).  x [B,L,3,128] -> out; with ``dout`` also
+        -> (out, dx) and every ``mlp_encoder.*`` gradient in ``self.grads`` (the main bucket is zeroed first)."""
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        c = self.cfg
+        nb = c.n_blocks
+        out = torch.empty(c.batch, c.d_outs[nb - 1][0], c.d_outs[nb - 1][1], c.d_outs[nb - 1][2], dtype=torch.float32, device=self.device)
+        if dout is None:
+            check(self.lib.mimrl_probe_cube(self.handle, _ptr(x), _ptr(out), None, None))
+            return out
+        dout = torch.as_tensor(dout, dtype=torch.float32, device=self.device).contiguous().reshape(out.shape)
+        dx = torch.empty_like(x)
+        check(self.lib.mimrl_probe_cube(self.handle, _ptr(x), _ptr(out), _ptr(dout), _ptr(dx)))
+        return out, dx
+
+    def probe_mi(self, stage: int, feats):
+        """The five MI estimators of ``stage`` forward + backward on ``feats`` [4,B,128] (F,T,A,V) through the engine's own kernels.
+        -> dict(mi [5], mi_loss [5], scores [5,B,B] (concat critic) or None, dtin [5,2,B,128] (stage 2) or None); stage 1 leaves
+        the ``vmi_estimator_*`` gradients in ``self.grads``."""
+        self.feats.copy_(torch.as_tensor(feats, dtype=torch.float32).reshape(self.feats.shape))
+        B = self.cfg.batch
+        mi = torch.empty(2, 5, dtype=torch.float32, device=self.device)
+        scores = torch.empty(5, B, B, dtype=torch.float32, device=self.device) if self.cfg.critic_type == 1 else None
+        dtin = torch.empty(5, 2, B, 128, dtype=torch.float32, device=self.device) if stage == 2 else None
+        check(self.lib.mimrl_probe_mi(self.handle, stage, _ptr(mi), _ptr(scores), _ptr(dtin)))
+        return {"mi": mi[0], "mi_loss": mi[1], "scores": scores, "dtin": dtin}
+
     def profile(self, on: bool):
         check(self.lib.mimrl_profile_enable(self.handle, int(on)))
 

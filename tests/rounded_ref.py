@@ -1,0 +1,181 @@
+"""float64 restatements of the fused bf16 sub-blocks with the kernels' ROUNDING POINTS made explicit (test infrastructure).
+
+Each function takes a ``Rounding`` (forward operand rounding + backward operand rounding).  With ``EXACT`` it is the oracle's function (tests/test_rounded_ref.py asserts
+equality with oracle.mimrl_ref.cube_block / critic_scores in float64, which pins these restatements to the oracle and through it to
+the reference: MLPProcess.py:94-122, VMI.py:53-69); with ``BF16`` / ``F16_FWD`` it is what the HIP kernels compute, up to fp32
+accumulation order: round-to-nearest-even of exactly the operands the kernels round -- in the forward products AND in the two
+backward products of every layer (data gradient: rounded incoming gradient x rounded weight; weight gradient: rounded incoming
+gradient x rounded saved input) -- and float64 everywhere else (biases, LayerNorm, activations and their derivatives, bias and
+LayerNorm parameter gradients, the K-axis mix: fp32 VALU code in the kernels).
+
+Rounding points (documented per kernel):
+  cube_fwd_fused_kernel (cube_fused.hip), per block -- its 16-bit type is FP16 (q = f16_ste), every other kernel's is bf16
+    L phase : X tile, W1, W2, Wr -> 16 bit (MFMA operands); U, act(U) in fp32; H -> bf16 (operand of W2.H); Y, LayerNorm(L) in fp32;
+              Z -> bf16 back into the LDS tile (the K phase reads the ROUNDED Z; the fp32 Z is only saved for the backward)
+    K phase : fp32 arithmetic on the bf16 tile, fp32 K-axis weights; output -> bf16 back into the tile
+    D phase : tile rows, W1, W2, Wr -> bf16 operands; U, act(U) fp32; H -> bf16; Y, LayerNorm(D) fp32; block output fp32
+              (the next block rounds it when it loads its tile)
+  unfused bf16 chain (engine.hip cube_forward, MIMRL_NO_FUSED_CUBE=1 / ln_first): only GEMM operands are rounded
+    (round_tile=False): LayerNorm outputs and the K-axis mix stay fp32
+  concat critic (concat_fused.hip + the two layer-0 GEMMs): x, y, W0 -> bf16 (P = x W0x^T, Q = y W0y^T + b0, fp32 accumulate);
+    a0 = relu(P_i + Q_j) -> bf16; W1, W2 bf16 images; a1 = relu(a0 W1^T + b1) -> bf16; a2 = relu(a1 W2^T + b2) stays fp32;
+    score = a2 . w3 + b3 with fp32 w3
+  separable critic (mlp_img8_kernel + mi_sep_nce_kernel): tower input, every W -> bf16; every hidden activation -> bf16 (it is the
+    next layer's MFMA operand); tower outputs fp32, rounded to bf16 as operands of scores = h g^T
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import mimrl_ref as R
+
+
+def r_bf16(x):
+    """bf16 round-to-nearest-even of a float64 tensor (through fp32, as the kernels convert)."""
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+def r_f16(x):
+    """fp16 round-to-nearest-even (the fused CubeMLP forward's and the forward projections' operand type since round 3)."""
+    return x.to(torch.float32).to(torch.float16).to(x.dtype)
+
+
+def identity(x):
+    return x
+
+
+class Rounding:
+    """fwd: rounding of both operands of a FORWARD product; bwd: rounding of the three operands of the two BACKWARD products of that
+    layer (the incoming gradient, the weight for the data gradient, the saved input for the weight gradient).  bwd=None: the backward
+    products reuse the forward's rounded operands (straight-through)."""
+    def __init__(self, fwd=identity, bwd=None):
+        self.fwd, self.bwd = fwd, bwd
+
+
+EXACT = Rounding()
+BF16 = Rounding(r_bf16, r_bf16)            # every bf16 GEMM / fused MLP kernel: operands rounded where they are staged, both passes
+F16_FWD = Rounding(r_f16, r_bf16)          # fp16 forward operands, bf16 gradient products (cube_fwd_fused + *_bwd kernels)
+
+
+class _MM(torch.autograd.Function):
+    """y = x @ w^T with the kernels' operand rounding in BOTH passes (see Rounding)."""
+    @staticmethod
+    def forward(ctx, x, w, rnd):
+        xf, wf = rnd.fwd(x), rnd.fwd(w)
+        ctx.rnd = rnd
+        ctx.save_for_backward(x, w, xf, wf)
+        return xf @ wf.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, xf, wf = ctx.saved_tensors
+        rnd = ctx.rnd
+        if rnd.bwd is None:
+            gq, xb, wb = g, xf, wf
+        else:
+            gq, xb, wb = rnd.bwd(g), rnd.bwd(x), rnd.bwd(w)
+        dx = gq @ wb
+        dw = gq.reshape(-1, gq.shape[-1]).t() @ xb.reshape(-1, xb.shape[-1])
+        return dx, dw, None
+
+
+def mm(x, w, rnd):
+    return _MM.apply(x, w, rnd)
+
+
+class _RoundSte(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fn):
+        return fn(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def ste(fn, x):
+    """value rounded by ``fn``, gradient passed through (a tile written back rounded; its consumers' backward reads what they consumed)"""
+    return x if fn is identity else _RoundSte.apply(x, fn)
+
+
+def _ln(p, name, y, eps=1e-6):
+    return F.layer_norm(y, (y.shape[-1],), p[name + ".weight"], p[name + ".bias"], eps)
+
+
+def _mlp_res(p, pre, ax, x_mlp, x_res, act, rnd):
+    """fc2(act(fc1 x_mlp)) + res x_res on the last dim; the three products round their operands as ``rnd`` says."""
+    b1, b2 = p.get(f"{pre}.mlp_{ax}.fc1.bias"), p.get(f"{pre}.mlp_{ax}.fc2.bias")
+    u = mm(x_mlp, p[f"{pre}.mlp_{ax}.fc1.weight"], rnd)
+    if b1 is not None:
+        u = u + b1
+    y = mm(act(u), p[f"{pre}.mlp_{ax}.fc2.weight"], rnd) + mm(x_res, p[f"{pre}.res_projection_{ax}.weight"], rnd)
+    return y if b2 is None else y + b2
+
+
+def cube_block_q(p, pre, x, act, rnd, round_tile=True, ln_first=False):
+    """MLPsBlock.forward_ln_last (MLPProcess.py:94-122) / forward_ln_first (:64-92) with res_projection, dropout 0.
+    x [B,L,K,D] float64.  ln_first exists only as the unfused chain (round_tile=False)."""
+    tile = rnd.fwd if round_tile else identity
+    if ln_first:
+        assert not round_tile
+        xl = x.permute(0, 2, 3, 1)
+        x = _mlp_res(p, pre, "l", _ln(p, f"{pre}.ln_l", xl), xl, act, rnd).permute(0, 3, 1, 2)
+        xk = x.permute(0, 1, 3, 2)
+        x = _mlp_res(p, pre, "k", _ln(p, f"{pre}.ln_k", xk), xk, act, EXACT).permute(0, 1, 3, 2)
+        return _mlp_res(p, pre, "d", _ln(p, f"{pre}.ln_d", x), x, act, rnd)
+    xl = x.permute(0, 2, 3, 1)
+    z = _ln(p, f"{pre}.ln_l", _mlp_res(p, pre, "l", xl, xl, act, rnd))                      # [B,K,D,L']
+    x = ste(tile, z).permute(0, 3, 1, 2)                                                     # tile <- rounded Z
+    xk = x.permute(0, 1, 3, 2)
+    zk = _ln(p, f"{pre}.ln_k", _mlp_res(p, pre, "k", xk, xk, act, EXACT))                    # fp32 K-axis mix on the tile values
+    x = ste(tile, zk).permute(0, 1, 3, 2)
+    return _ln(p, f"{pre}.ln_d", _mlp_res(p, pre, "d", x, x, act, rnd))
+
+
+def cube_mlp_q(p, opt, x, rnd, round_tile=True):
+    act = R._act(opt.activate)
+    for i in range(len(opt.d_hiddens)):
+        x = cube_block_q(p, f"mlp_encoder.layers_stack.{i}", x, act, rnd, round_tile, opt.ln_first)
+    return x
+
+
+def critic_scores_q(p, name, critic_type, x, y, rnd):
+    """CriticModel.forward (VMI.py:53-69) with the kernels' rounding points.  -> scores [B,B] (row i: y_i, column j: x_j)."""
+    pre = f"vmi_estimator_{name}.critic_model"
+
+    def tower(tp, v):
+        h = v
+        for j, i in enumerate((0, 2, 4, 6)):
+            h = mm(h, p[f"{tp}.{i}.weight"], rnd) + p[f"{tp}.{i}.bias"]
+            if j < 3:
+                h = F.relu(h)
+        return h
+
+    if critic_type == "separate":
+        g, h = tower(pre + ".MLP_g", x), tower(pre + ".MLP_h", y)
+        return mm(h, g, rnd)                                      # scores = h g^T: dh = dS g, dg = dS^T h with the same rounding
+    B, E = x.shape
+    w0, b0 = p[f"{pre}.MLP_f.0.weight"], p[f"{pre}.MLP_f.0.bias"]
+    P = mm(x, w0[:, :E], rnd)                                     # [B,256] the x half of layer 0
+    Q = mm(y, w0[:, E:], rnd) + b0
+    # raw[i,j] = f([x_j | y_i]) (VMI.py:61-65); scores = raw^T, i.e. scores[a,b] = f([x_a | y_b])
+    a0 = F.relu(P.unsqueeze(1) + Q.unsqueeze(0))                  # [a, b, 256]
+    a1 = F.relu(mm(a0, p[f"{pre}.MLP_f.2.weight"], rnd) + p[f"{pre}.MLP_f.2.bias"])
+    a2 = F.relu(mm(a1, p[f"{pre}.MLP_f.4.weight"], rnd) + p[f"{pre}.MLP_f.4.bias"])
+    s = a2 @ p[f"{pre}.MLP_f.6.weight"].t() + p[f"{pre}.MLP_f.6.bias"]     # score head: fp32 VALU on the fp32 accumulators
+    return s.squeeze(-1)
+
+
+MI_WIRE = {"f_t": (0, 1), "f_a": (0, 2), "f_v": (0, 3), "t_a": (1, 2), "t_v": (1, 3)}     # Model.py:313-319 (F,T,A,V slots)
+
+
+def mi_terms_q(p, opt, feats, rnd):
+    """The five InfoNCE values (Model.py:313-319, VMI.py:162-166) and score matrices on feats [4,B,128]."""
+    out, sc = [], []
+    for n in R.VMI_NAMES:
+        ix, iy = MI_WIRE[n]
+        s = critic_scores_q(p, n, opt.critic_type, feats[ix], feats[iy], rnd)
+        sc.append(s)
+        out.append(R.infonce_lower_bound(s))
+    return out, sc
