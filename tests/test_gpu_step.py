@@ -158,7 +158,8 @@ def test_bf16_mode_tracks_fp32():
     Every loss and MI/CMI term stays within 2e-2 relative (+ small absolute band: CMI is a difference of log-ratio
     sums) of the fp32 path and of the reference.  Gradients are compared by direction only: this model's backward
     (broadcast means through LayerNorms over K=3 / L) cancels most of the signal, so operand rounding in the
-    FORWARD pass perturbs individual gradient entries by O(10%) -- measured and documented in DESIGN.md."""
+    FORWARD pass perturbs individual gradient entries -- measured and documented in DESIGN.md: O(10 %) with bf16 forward operands,
+    which is why the forward products on the model path round to fp16 instead (same MFMA rate, 8x finer)."""
     res = {}
     for prec in ("fp32", "bf16"):
         c, opt, batch, banks, p, eng = make_engine("cfg1_sep", precision=prec)
@@ -180,7 +181,9 @@ def test_bf16_mode_tracks_fp32():
     assert_close(b[_lib.S1_MIS:_lib.S1_MIS + 11], a[_lib.S1_MIS:_lib.S1_MIS + 11], 2e-2, 2e-2, "bf16 MI/CMI")
     assert_close(b[_lib.S2_LOSS], a[_lib.S2_LOSS], 2e-2, 1e-3, "bf16 stage-2 loss")
     assert_close(b[_lib.S2_MIS:_lib.S2_MIS + 8], a[_lib.S2_MIS:_lib.S2_MIS + 8], 2e-2, 4e-2, "bf16 MI terms")
-    for i, nm, lim in ((1, "critic", 0.998), (2, "main", 0.95)):      # measured 0.9994 / 0.964
+    # measured 0.9994 / 0.9990.  The main bucket was 0.964 until round 3: fp16 instead of bf16 operands in the
+    # forward products of CubeMLP and of the projections in front of it (cube_fused.hip) -- the bound below is what pins that
+    for i, nm, lim in ((1, "critic", 0.998), (2, "main", 0.995)):
         va, vb = res["fp32"][i], res["bf16"][i]
         cos = float(va @ vb / (np.linalg.norm(va) * np.linalg.norm(vb)))
         assert cos > lim, f"bf16 {nm} gradient direction: cosine {cos}"
@@ -216,8 +219,11 @@ def test_fused_cube_forward_matches_unfused(name, monkeypatch):
     assert_close(sa[_lib.S1_LOSS], sb[_lib.S1_LOSS], 1e-2, 1e-3, "stage-1 loss")
     assert_close(sa[_lib.S2_LOSS], sb[_lib.S2_LOSS], 1e-2, 1e-3, "stage-2 loss")
     assert_close(sa[_lib.S2_MIS:_lib.S2_MIS + 8], sb[_lib.S2_MIS:_lib.S2_MIS + 8], 2e-2, 2e-2, "MI terms")
+    # (since round 3 the fused kernel's operands are fp16 and the unfused chain's bf16: the two gradients are no longer "the same
+    #  numbers in a different order" -- both are held against the oracle in tests/test_gpu_fused_oracle.py; here only the direction,
+    #  at the fixture where the bf16 gradient is not noise: L = 6 / 4 LayerNorm axes make tiny_sep's a coin toss, cos 0.96)
     cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
-    assert cos > 0.98, f"main gradient direction fused vs unfused: cosine {cos}"
+    assert cos > (0.98 if name != "tiny_sep" else 0.9), f"main gradient direction fused vs unfused: cosine {cos}"
 
 
 @pytest.mark.parametrize("precision,use_graph,split", [("fp32", False, False), ("fp32", True, False), ("bf16", True, False),
@@ -358,7 +364,7 @@ def test_bf16_fused_paths_on_every_fixture(name):
     # the hardtanh CMI head clamps probabilities to [1e-4, 1-1e-4]: with 8 samples one logit crossing the clamp moves a
     # CMI term by ~1 in any reduced precision (same numbers with every fused kernel switched off), so only MI terms there
     nmi = 4 if opt.cmi_last_acticate == "hardtanh" else 8
-    assert_close(a[_lib.S2_MIS:_lib.S2_MIS + nmi], b[_lib.S2_MIS:_lib.S2_MIS + nmi], 5e-2, 3e-2, "stage-2 MI terms")
+    assert_close(a[_lib.S2_MIS:_lib.S2_MIS + nmi], b[_lib.S2_MIS:_lib.S2_MIS + nmi], 5e-2, 5e-2, "stage-2 MI terms")   # (CMI terms of 8-sample fixtures: differences of log-ratio sums)
 
 
 @pytest.mark.parametrize("name", ["tiny_cat", "cfg1_cat"])
@@ -382,7 +388,9 @@ def test_fused_concat_forward_matches_gemm_chain(name, monkeypatch):
         res[tag] = (eng.read_scalars().copy(), {n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if "MLP_f" in n})
         eng.close()
     (sa, ga), (sb, gb) = res["fused"], res["chain"]
-    assert_close(sa[_lib.S1_MIS:_lib.S1_MIS + 5], sb[_lib.S1_MIS:_lib.S1_MIS + 5], 1e-4, 1e-5, "MI values fused vs chain")
+    # (InfoNCE at init is log B minus a mean of O(1) numbers, ~1e-5: one bf16 rounding of one activation that falls the other way
+    #  in the other summation order moves it by 1e-5)
+    assert_close(sa[_lib.S1_MIS:_lib.S1_MIS + 5], sb[_lib.S1_MIS:_lib.S1_MIS + 5], 1e-4, 5e-5, "MI values fused vs chain")
     assert len(ga) == 40
     for n in ga:
         grad_close(ga[n], gb[n], 2e-3, n)
