@@ -423,12 +423,14 @@ def test_cfg2_full_size_in_bench_mode():
     assert_close(sa[_lib.S1_LOSS], g["traj_s1_loss"][0], 1e-3, 1e-5, "fp32 stage-1 loss vs reference")
     assert_close(sa[_lib.S2_LOSS], g["traj_s2_loss"][0], 1e-3, 1e-5, "fp32 stage-2 loss vs reference")
     assert_close(sa[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 1e-3, 5e-5, "fp32 MI terms vs reference")
-    # bench mode vs the reference: bf16 band (operands rounded to 8 bits of mantissa; CMI terms are differences of log-ratio sums)
-    assert_close(sb[_lib.S1_LOSS], g["traj_s1_loss"][0], 5e-3, 1e-3, "bench-mode stage-1 loss vs reference")
-    assert_close(sb[_lib.S2_LOSS], g["traj_s2_loss"][0], 5e-3, 1e-3, "bench-mode stage-2 loss vs reference")
-    assert_close(sb[_lib.S2_TASK], g["traj_s2_task"][0], 5e-3, 1e-3, "bench-mode task loss vs reference")
-    assert_close(sb[_lib.S1_MIS:_lib.S1_MIS + 11], g["traj_s1_mis"][0], 2e-2, 1e-2, "bench-mode stage-1 MI/CMI vs reference")
-    assert_close(sb[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 2e-2, 2e-2, "bench-mode MI terms vs reference")
+    # bench mode vs the REFERENCE's values: bands = 3x the error measured in round 3 (three runs: losses 5e-6 relative; stage-1 MI / CMI
+    # values <= 1.8e-5 absolute on values of 1e-5 / 1.0; stage-2 MI terms <= 1.9e-3 absolute on values of 2e-4 .. 2.08 -- the CMI-derived
+    # terms are differences of log-ratio sums).  Until round 3 these bands were 5e-3 / 2e-2: wide enough to hide a wrong kernel.
+    assert_close(sb[_lib.S1_LOSS], g["traj_s1_loss"][0], 2e-5, 1e-6, "bench-mode stage-1 loss vs reference")
+    assert_close(sb[_lib.S2_LOSS], g["traj_s2_loss"][0], 2e-5, 1e-6, "bench-mode stage-2 loss vs reference")
+    assert_close(sb[_lib.S2_TASK], g["traj_s2_task"][0], 2e-5, 1e-6, "bench-mode task loss vs reference")
+    assert_close(sb[_lib.S1_MIS:_lib.S1_MIS + 11], g["traj_s1_mis"][0], 0, 6e-5, "bench-mode stage-1 MI/CMI vs reference")
+    assert_close(sb[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 0, 6e-3, "bench-mode MI terms vs reference")
     assert_close(pb, pa, 2e-2, 2e-2, "bench-mode predictions vs fp32")
     assert_close(fb, fa, 2e-2, 2e-2, "bench-mode features vs fp32")
 
@@ -485,27 +487,39 @@ def test_fused_concat_backward_matches_gemm_chain(stage, monkeypatch):
         grad_close(ga[n], gb[n], 3e-3 if stage == 1 else 5e-2, n)
 
 
-@pytest.mark.parametrize("workload,graph", [("cfg2", False), ("cfg1", False), ("cfg2", True)])
-def test_stage2_gradients_reproducible(workload, graph):
-    """Fresh engine, same inputs, the mode bench.py runs minus the graph: every main-model gradient of the stage-2 pass must come out
-    the same three times (float atomics reorder additions: 1e-4 of the tensor scale is generous, observed <= 3e-6).  Round 2b found
-    the block-0 K-axis parameter gradients off by 5-30 % from run to run while their kernel ran beside the layer-1 BPTT (engine.hip:
-    MIMRL_EARLY_FLUSH) -- every parity test passed, because bf16-vs-fp32 bands are wider than that."""
+REPRO = [("cfg2", 2, False), ("cfg1", 2, False), ("cfg2", 2, True), ("cfg2", 1, False), ("cfg2", 1, True), ("cfg2-concat", 1, False),
+         ("cfg2-concat", 2, True), ("cfg3", 1, False), ("cfg3", 2, True), ("cfg5", 2, False)]
+
+
+@pytest.mark.parametrize("workload,stage,graph", REPRO, ids=[f"{w}-s{s}-{'graph' if g else 'eager'}" for w, s, g in REPRO])
+def test_gradients_reproducible(workload, stage, graph):
+    """Fresh engine, same inputs, the mode bench.py runs: EVERY gradient tensor of the stage must come out the same three times
+    (float atomics reorder additions: observed <= 3e-6 of the tensor scale with the separable critic, <= 2.7e-4 in the concat critic's
+    split-K weight gradients over B*B rows; the band is 1e-3) -- both stages, eager and captured,
+    separable and concat critics, cfg3 (T = 500) and cfg5 (T = 1000) shapes.  Round 2b found the block-0 K-axis parameter gradients
+    off by 5-30 % from run to run while their kernel ran beside the layer-1 BPTT (the structural fix keeps
+    register-heavy kernels away from the recurrence, tests/test_codeobj.py pins the register facts it relies on) -- every parity test
+    passed at the time, because bf16-vs-fp32 bands are wider than that.  (tools/determinism.py is the same check as a CLI.)"""
     runs, anchors = [], None
     for r in range(3):
         opt, N, batch, banks, eng = _bench_engine(workload, "bf16", graph, device_anchors=False)
         if anchors is None:
             rng = np.random.default_rng(5)
             anchors = np.stack([rng.choice(N, size=opt.batch_size // opt.k_neighbor, replace=False) for _ in range(6)])
-        eng.set_anchors(2, anchors)
-        eng.stage_grads(2)
+        eng.set_anchors(stage, anchors)
+        eng.stage_grads(stage)
         torch.cuda.synchronize()
-        runs.append({n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if not n.startswith("v")})
+        runs.append({n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if n.startswith("v") == (stage == 1)})
         eng.close()
+    top = max(np.abs(v).max() for v in runs[0].values())
     for r in (1, 2):
         for n in runs[0]:
-            scale = np.abs(runs[0][n]).max() + 1e-12
-            assert np.abs(runs[r][n] - runs[0][n]).max() <= 1e-4 * scale, (r, n, np.abs(runs[r][n] - runs[0][n]).max() / scale)
+            # (a tensor whose gradient cancels to nothing is fp32 noise: the score head's bias of a concat critic has gradient
+            #  sum(dS) = 0 under InfoNCE's shift invariance -- 5 x 65536 terms at cfg3)
+            if n.endswith("MLP_f.6.bias"):
+                continue
+            scale = max(np.abs(runs[0][n]).max(), 1e-2 * top)
+            assert np.abs(runs[r][n] - runs[0][n]).max() <= 1e-3 * scale, (r, n, np.abs(runs[r][n] - runs[0][n]).max() / scale)
 
 
 def test_cfg3_full_size_properties(monkeypatch):
