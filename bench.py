@@ -35,13 +35,6 @@ def log(msg):
     print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def host_threads():
-    """Cores this process may actually use (cgroup/affinity aware), capped: the oracle's small ops stop scaling ~16."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 16))
 H = 128
 
 
@@ -101,12 +94,72 @@ def executed_flops(opt, N, shared_prefix):
     return 2.0 * ((3 if shared_prefix else 4) * F_pre + 4 * F_tail + 5 * F_c + 2 * F_k)
 
 
-def cpu_baseline(opt, N, budget_s=25.0):
-    """The CPU oracle (our PyTorch-CPU restatement, pinned to the reference by tests/golden) timed on this host's
-    cores on the SAME workload: a bounded sample of whole two-stage iterations."""
+def gru_launch_model(B, T, bf16_gru, dg_bf16):
+    """Algorithmic work of ONE launch of the persistent recurrence kernels (2 modalities x 2 directions, one layer).
+    FLOPs: one [B,128] x [128,384] product per cell step (forward: h W_hh^T; BPTT: dgh W_hh -- the weight gradients are GEMM-family
+    launches).  Bytes per (b, t, modality, direction), every operand once:
+      forward: gx 3H fp32 (1536) + out H fp32 (512) + saved gates 4H (bf16 1024 / fp32 2048)
+      BPTT   : saved gates (1024 / 2048) + dout H fp32 (512) + h H fp32 (512) + dg 4H (bf16 1024 / fp32 2048) + h_prev H (bf16 256 / fp32 512)
+    (round 2's model charged dg twice and fp32 widths: 145 MB against 90.8 MB measured; this one gives 85 MB at cfg2)."""
+    n = 4 * B * T
+    flops = 2.0 * n * 3 * H * H
+    sv = 4 * H * (2 if bf16_gru else 4)
+    fwd = n * (3 * H * 4 + H * 4 + sv) + 4 * (3 * H * H + 3 * H) * 4
+    bwd = n * (sv + H * 4 + H * 4 + 4 * H * (2 if dg_bf16 else 4) + H * (2 if dg_bf16 else 4)) + 4 * 3 * H * H * 4
+    return flops, float(fwd), float(bwd)
+
+
+def cube_bytes(opt, B, save):
+    """HBM bytes of one CubeMLP forward pass (fused kernels: block input read once, block output written once; with `save` the
+    activations the backward reads: u, h, y, z of the L axis, k_z, u, h, y of the D axis) and of one data-gradient chain."""
+    fwd = bwd = 0.0
+    il, K, D = opt.time_len, 3, 128
+    for hid, out in zip(opt.d_hiddens, opt.d_outs):
+        hl, ol = hid[0], out[0]
+        C = K * D
+        fwd += 4.0 * B * C * (il + ol)
+        if save:
+            fwd += 4.0 * B * C * (2 * hl + 2 * ol + ol + 3 * ol)
+        # D axis: dz, y, u in; dy, du, dx out.  K axis: z, dz in; dx out.  L axis: dz, y, u in; dy, du, dx out
+        bwd += 4.0 * B * C * (6 * ol + 3 * ol + (2 * ol + hl) + (ol + hl + il))
+        il = ol
+    return fwd, bwd
+
+
+def estimator_bytes(opt, B, N):
+    """HBM bytes of the MI + CMI estimator stacks of one stage: inputs, bf16 weight images (read once per stack), saved activations
+    written (forward) / read (backward), gradients written; kNN: every bank row once per call."""
+    n = (B // opt.k_neighbor) * opt.k_neighbor
+    w_sep = 10 * (128 * 256 + 2 * 256 * 256 + 256 * 128) * 2.0
+    w_cat = 5 * (256 * 256 * 3 + 256) * 2.0
+    w_cmi = 6 * (384 * 256 + 2 * 256 * 256 + 256 * 2) * 2.0
+    if opt.critic_type == "separate":
+        mi_f = 10 * B * 128 * 4 + w_sep + 10 * B * 4.0 * (3 * 256 + 128)
+        mi_b = w_sep + 10 * B * 4.0 * (3 * 256 + 128) * 2
+    else:
+        rows = 5.0 * B * B
+        mi_f = w_cat + rows * (2 * 256 * 2 + 256 * 4 + 4)       # bf16 a0, a1 + fp32 a2 + scores (stage-1 save mode)
+        mi_b = w_cat + rows * (2 * 256 * 2 + 256 * 4 + 256 * 4 + 2 * 256 * 2)
+    cmi_f = 6 * 2 * n * 384 * 4.0 + w_cmi + 6 * 2 * n * 4.0 * (3 * 256 + 2)
+    cmi_b = w_cmi + 6 * 2 * n * 4.0 * (3 * 256 + 2) * 2
+    knn = 6.0 * N * (128 * 4 + 4)
+    return mi_f + cmi_f + knn, mi_b + cmi_b
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_time(opt, N, threads, warmups, iters, budget_s):
     from oracle import mimrl_ref as R
     from mimrl_amd import layout
-    torch.set_num_threads(host_threads())
+    torch.set_num_threads(threads)
     p = {n: torch.from_numpy(synth.portable_tensor(n, s, 0)) for n, s in layout.named_shapes(opt, 768, 74, 35)}
     batch = tuple(torch.from_numpy(x) for x in synth.synthetic_batch(opt.batch_size, opt.time_len, seed=0))
     banks = {k: torch.from_numpy(v) for k, v in synth.synthetic_banks(N, seed=0).items()}
@@ -121,19 +174,57 @@ def cpu_baseline(opt, N, budget_s=25.0):
         R.two_stage_step(p, cpu_opt, av, am, batch, banks, synth.draw_anchors(N, m, 6), synth.draw_anchors(N, m, 6))
 
     tw = time.perf_counter()
-    one()                                 # warm-up
-    tw = time.perf_counter() - tw
-    log(f"cpu baseline warm-up iteration took {tw:.1f}s on {torch.get_num_threads()} threads")
-    t0, n = time.perf_counter(), 0
-    while True:
+    for _ in range(warmups):
         one()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt + tw > budget_s or n >= 12:   # bounded sample: stop once ~budget_s of CPU work is spent
-            break
-    return {"value": n / dt, "unit": "two-stage iters/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 warm-up + {n} two-stage iterations of the same workload (B={opt.batch_size}, T={opt.time_len}, "
-                      f"N={N}), fp32 PyTorch-CPU oracle incl. host kNN", "ms_per_step": 1e3 * dt / n}
+    tw = time.perf_counter() - tw
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < iters and (time.perf_counter() - t_all < budget_s or len(ts) < 3):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    return {"iters_per_sec": len(ts) / sum(ts), "ms_mean": 1e3 * sum(ts) / len(ts), "ms_min": 1e3 * min(ts), "timed_iterations": len(ts),
+            "warmups": warmups, "threads": torch.get_num_threads(), "warmup_s": tw}
+
+
+def cpu_baseline(workload_name):
+    """BASELINE.md section 3, the CPU-baseline plan of record: the CPU oracle (our PyTorch-CPU restatement, pinned to the reference by
+    tests/golden) on the SAME workload: 3 warm-ups + 20 timed two-stage iterations (or the stated budget, whichever comes first) at the
+    benchmarked shape, and the same at BASELINE configs[0] (cfg1, B=32).  Thread counts: ALL cores of the process's affinity mask (the
+    plan of record) and 16 (the oracle is ~55 k small PyTorch ops per iteration: beyond ~16 threads every op is a barrier over idle
+    threads) -- `value` is the faster of the two, `cores` says which.  Each measurement runs in a child process under a hard timeout, so
+    that an oversubscribed host cannot stall the GPU measurement (round 3, 256-core EPYC 9575F host: the all-core run does not finish
+    its three warm-ups within two minutes; 16 threads: 1.03 it/s).  A reported baseline, not the target."""
+    import subprocess
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+
+    def child(wl, threads, budget):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", wl, "--cpu-threads", str(threads),
+               "--cpu-budget", str(budget)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=(4 * budget + 20) if threads <= 16 else 45)
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:      # noqa: BLE001
+            return {"error": repr(e)[:160], "threads": threads}
+
+    runs = [child(workload_name, t, 10.0) for t in sorted({min(16, cores), cores})]
+    ok = [r for r in runs if "iters_per_sec" in r]
+    if not ok:
+        return {"value": None, "unit": "two-stage iters/sec", "cores": cores, "kind": "port", "sample": "CPU runs failed", "runs": runs}
+    best = max(ok, key=lambda r: r["iters_per_sec"])
+    c1 = child("cfg1", best["threads"], 6.0)
+    for r in runs:
+        log(f"cpu baseline ({workload_name}, {r.get('threads')} threads): {r.get('iters_per_sec')} it/s over {r.get('timed_iterations')} iterations {r.get('error', '')}")
+    return {"value": best["iters_per_sec"], "unit": "two-stage iters/sec", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['warmups']} warm-ups + {best['timed_iterations']} timed two-stage iterations (20, or a 10 s budget) of the same workload "
+                      f"({workload_name}), fp32 PyTorch-CPU oracle incl. host kNN; thread counts tried: "
+                      + ", ".join(f"{r.get('threads')} -> {r.get('iters_per_sec', 'failed')}" for r in runs)
+                      + f" it/s (affinity mask {cores} cores, os.cpu_count() {os.cpu_count()})",
+            "ms_per_step": best["ms_mean"], "ms_min": best["ms_min"], "host_cpu": host_cpu_model(), "os_cpu_count": os.cpu_count(),
+            "runs": runs, "cfg1": dict(c1, workload="BASELINE configs[0]: B=32, T=50, separable InfoNCE, N=1284")}
 
 
 def extra_schedules(eng, args, B, T, rank):
@@ -195,8 +286,15 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-extra", action="store_true", help="skip the sequential / fresh-batch schedules")
     ap.add_argument("--extras-only", action="store_true", help=argparse.SUPPRESS)   # child mode: print only the extra schedules
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child mode: one CPU-oracle timing
+    ap.add_argument("--cpu-threads", type=int, default=16, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:      # no GPU work in this child
+        o, n_ = workload(args.workload)
+        print(json.dumps(_cpu_time(o, n_, args.cpu_threads, 3, 20, args.cpu_budget)))
+        return
     world, rank, local = mdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -219,6 +317,11 @@ def main():
     # Solver.step() mode: both stages work on the same batch, so the stage-2 forward pass is issued beside stage 1
     # (same arithmetic and results as the sequential order; tests/test_gpu_step.py::test_stage2_prefetch_matches_sequential)
     eng.set_stage2_prefetch(0 if args.no_prefetch else (2 if world > 1 else 1))   # world > 1: deferred-tail variant (dist.py)
+    # launch stamps of the recurrence kernels (two atomics per workgroup): the roofline block is measured INSIDE the timed region,
+    # on the replayed graph, not on a separate eager schedule
+    use_stamps = rank == 0 and not args.extras_only and args.steps <= 8000
+    if use_stamps:
+        eng.kernel_stamps(1 << 14)
 
     def step():
         if world > 1 and args.no_prefetch:
@@ -233,8 +336,28 @@ def main():
         for _ in range(5):
             eng.step()
         torch.cuda.synchronize()
-        print(json.dumps(extra_schedules(eng, args, B, T, rank)))
+        ex = extra_schedules(eng, args, B, T, rank)
         eng.close()
+        if args.precision != "fp32":
+            # the PARITY-GRADE configuration (fp32 MFMA operands everywhere: the mode the 1e-3 north-star bar is tested in), same
+            # workload, same schedule (graph, Solver.step overlap): what the 1e-3 mode costs
+            e32 = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision="fp32", use_graph=not args.no_graph, seed=1234 + rank,
+                            device_anchors=True)
+            e32.load_params(synth.default_state(shapes, 0))
+            e32.set_batch(*synth.synthetic_batch(B, T, seed=rank))
+            e32.set_banks(*(banks[k] for k in "CFTAV"))
+            e32.set_stage2_prefetch(0 if args.no_prefetch else 1)
+            for _ in range(10):
+                e32.step()
+            torch.cuda.synchronize()
+            n32 = max(10, min(args.steps, 50))
+            t = time.perf_counter()
+            for _ in range(n32):
+                e32.step()
+            torch.cuda.synchronize()
+            ex["ms_per_step_fp32_parity_mode"] = 1e3 * (time.perf_counter() - t) / n32
+            e32.close()
+        print(json.dumps(ex))
         return
 
     log("engine ready; warm-up")
@@ -245,6 +368,8 @@ def main():
             log("first step done")
     torch.cuda.synchronize()
     log("warm-up done; timing")
+    if use_stamps:
+        eng.kernel_stamps(1 << 14)            # clear the ring: only launches of the timed region are in it
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -264,6 +389,9 @@ def main():
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     wall = float(el.item())
     log(f"timed region: {1e3 * wall / args.steps:.3f} ms/step")
+    stamps = eng.read_kernel_stamps() if use_stamps else {}
+    if use_stamps:
+        eng.lib.mimrl_set_kernel_stamps(eng.handle, None, 0)      # off for the eager phase profile below
     scal = eng.read_scalars()
     finite = bool(np.isfinite(scal).all())
 
@@ -310,66 +438,100 @@ def main():
         # --- kernel families, by time per step (summed launch durations; branches of a step overlap, so they do not add up
         #     to the step time).  GEMM: every gemm() launch bracketed by events on its own stream, algorithmic FLOPs/bytes
         #     from its descriptor.  GRU / CubeMLP / estimator stacks / Adam: the phase events.
-        save_frac = 1.0 if shared_prefix else 0.5
         gru_bf16 = bool(_lib.PREC[args.precision] & 4)
-        gru_fl = 2 * 2 * B * T * (H * 3 * H) * 2.0          # per launch: 2 modalities x 2 directions, [B,T] x (128 x 384) MACs
-        gru_by = (4 * B * T * 3 * H * 4 + 4 * (3 * H * H + 3 * H) * 4 + 2 * B * T * 2 * H * 4
-                  + save_frac * 4 * B * T * 4 * H * (2 if gru_bf16 else 4))
+        dg_bf16 = gru_bf16 and bool(_lib.PREC[args.precision] & 8) and bool(_lib.PREC[args.precision] & 2) and not os.environ.get("MIMRL_DG_FP32")
+        gru_fl, gru_fwd_by, gru_bwd_by = gru_launch_model(B, T, gru_bf16, dg_bf16)
         F_pre, F_tail, F_c, F_k = flop_terms(opt, N)
+        cube_f_by, cube_b_by = cube_bytes(opt, B, True)
+        est_f_by, est_b_by = estimator_bytes(opt, B, N)
 
         def row(name, ms_total, launches, flops_total, bytes_total, note=""):
             if not launches:
                 return None
             us = 1e3 * ms_total / launches
-            return {"kernel": name, "ms_per_step": ms_total / n, "launches_per_step": launches / n, "avg_launch_us": us,
+            return {"kernel": name, "schedule": "eager (phase events)", "ms_per_step": ms_total / n, "launches_per_step": launches / n, "avg_launch_us": us,
                     "gflop_per_launch": flops_total / launches / 1e9, "mbytes_per_launch": bytes_total / launches / 1e6,
                     "achieved_tflops": flops_total / (ms_total * 1e-3) / 1e12 if ms_total else 0.0,
                     "achieved_gbs": bytes_total / (ms_total * 1e-3) / 1e9 if ms_total else 0.0, "note": note}
 
         kernels = [r for r in (
-            row("gemm family (gemm_fast_kernel<*> / gemm_kernel<*>: projections, data and weight gradients)", gm["ms"], gm["launches"],
+            row("gemm family (gemm_fast_*_kernel / gemm_kernel: projections, data and weight gradients)", gm["ms"], gm["launches"],
                 gm["flops"], gm["bytes"], "per-launch events on each launch's own stream; operands + output counted once"),
             row("gru_fwd_kernel (persistent bi-GRU recurrence, one launch per layer)", pr["gru_fwd"][0], pr["gru_fwd"][1],
-                gru_fl * pr["gru_fwd"][1], gru_by * pr["gru_fwd"][1], f"{T} serial cell steps per launch"),
-            row("gru_bwd_kernel (BPTT, one launch per layer)", pr["gru_bwd"][0], pr["gru_bwd"][1], 2 * gru_fl * pr["gru_bwd"][1],
-                (4 * B * T * 4 * H * 4 + 4 * B * T * H * 4 + gru_by) * pr["gru_bwd"][1]),
+                gru_fl * pr["gru_fwd"][1], gru_fwd_by * pr["gru_fwd"][1], f"{T} serial cell steps per launch"),
+            row("gru_bwd_kernel (BPTT, one launch per layer)", pr["gru_bwd"][0], pr["gru_bwd"][1], gru_fl * pr["gru_bwd"][1],
+                gru_bwd_by * pr["gru_bwd"][1], "one [B,384]x[384,128] product per cell step; its weight gradients are gemm-family launches"),
             row("cube_fwd (fused CubeMLP block kernels, or the unfused chain)", pr["cube_fwd"][0], pr["cube_fwd"][1],
-                2.0 * F_tail * pr["cube_fwd"][1], 0.0, "phase = one whole CubeMLP forward"),
-            row("cube_bwd (CubeMLP data-gradient chain)", pr["cube_bwd"][0], pr["cube_bwd"][1], 2.0 * F_tail * pr["cube_bwd"][1], 0.0,
-                "phase = one whole CubeMLP backward chain (weight gradients are in the gemm family)"),
+                2.0 * F_tail * pr["cube_fwd"][1], cube_f_by * pr["cube_fwd"][1], "phase = one whole CubeMLP forward (bytes: with saved activations)"),
+            row("cube_bwd (CubeMLP data-gradient chain)", pr["cube_bwd"][0], pr["cube_bwd"][1], 2.0 * F_tail * pr["cube_bwd"][1],
+                cube_b_by * pr["cube_bwd"][1], "phase = one whole CubeMLP backward chain (weight gradients are in the gemm family)"),
             row("estimators forward (critic towers / classifiers + bounds; MI branch)", pr["est_fwd"][0], pr["est_fwd"][1],
-                2.0 * F_c * pr["est_fwd"][1], 0.0),
-            row("estimators backward (MI branch)", pr["est_bwd"][0], pr["est_bwd"][1], 2.0 * F_c * pr["est_bwd"][1], 0.0),
+                2.0 * F_c * pr["est_fwd"][1], est_f_by * pr["est_fwd"][1]),
+            row("estimators backward (MI branch)", pr["est_bwd"][0], pr["est_bwd"][1], 2.0 * F_c * pr["est_bwd"][1], est_b_by * pr["est_bwd"][1]),
             row("adam_kernel (fused clip + Adam, flat bucket)", pr["opt"][0], pr["opt"][1], 0.0,
                 7 * 4.0 * (eng.main["p"].numel() + eng.crit["p"].numel()) / 2 * pr["opt"][1], "HBM-bound: 7 words per parameter"),
         ) if r]
         kernels.sort(key=lambda r: -r["ms_per_step"])
-        top = kernels[0]
-        traffic, tsrc = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")   # rocprofv3 --pmc passes of THIS round (separate runs), committed
-        if os.path.exists(pmc) and args.workload == "cfg2" and args.precision == "bf16" and top["kernel"].startswith("gemm"):
-            ks = json.load(open(pmc))["kernels"]
-            tot = [(v["traffic_bytes_per_launch"], v["calls_per_step"]) for k, v in ks.items() if "gemm" in k]
-            if tot:
-                traffic = sum(a * b for a, b in tot) / sum(b for _, b in tot)
-                tsrc = "profiles/r02_pmc_hbm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), mean bytes per gemm launch"
-        mf = top["achieved_tflops"] / peak_mfma
-        hb = top["achieved_gbs"] / PEAK_HBM_GBS
-        bound = "mfma" if (top["kernel"].startswith("gemm") or mf >= hb) else "hbm"
-        roof = {"bound": bound, "kernel": top["kernel"],
-                "selection": "largest summed launch time per step among the kernel families measured live (see `kernels`)",
-                "achieved": top["achieved_tflops"] if bound == "mfma" else top["achieved_gbs"],
-                "peak": peak_mfma if bound == "mfma" else PEAK_HBM_GBS, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                "frac": mf if bound == "mfma" else hb, "traffic": traffic, "traffic_source": tsrc,
-                "algorithmic_flops_per_launch": top["gflop_per_launch"] * 1e9, "algorithmic_bytes_per_launch": top["mbytes_per_launch"] * 1e6,
-                "avg_launch_ms": top["avg_launch_us"] / 1e3, "launches_per_step": top["launches_per_step"],
-                "share_of_eager_step": top["ms_per_step"] / eager_ms,
-                "hbm_view": {"achieved_gbs": top["achieved_gbs"], "peak": PEAK_HBM_GBS, "frac": hb},
-                "mfma_view": {"achieved_tflops": top["achieved_tflops"], "peak": peak_mfma, "frac": mf}}
+
+    # ---- roofline of the dominant KERNEL, from the TIMED region (the replayed graph): gru_bwd_kernel<bf16> has the largest share of
+    #      kernel time of any single kernel in rocprofv3's stats of this very command (profiles/r03_bench_kernel_stats.csv: 7.5 %,
+    #      2 launches per step).  Its launch durations come from in-kernel stamps (min start / max end over the workgroups of a launch,
+    #      100 MHz wall clock): HIP events cannot bracket one kernel of a replayed hipGraph.
+    if rank == 0 and stamps and len(stamps.get("gru_bwd_l1", ())):
+        gru_bf16 = bool(_lib.PREC[args.precision] & 8)
+        dg_bf16 = gru_bf16 and bool(_lib.PREC[args.precision] & 2) and not os.environ.get("MIMRL_DG_FP32")
+        fl, fwd_by, bwd_by = gru_launch_model(B, T, gru_bf16, dg_bf16)
+        peak_mfma = PEAK_TFLOPS["bf16" if gru_bf16 else "fp32"]
+        durs = np.concatenate([stamps["gru_bwd_l1"], stamps["gru_bwd_l0"]])
+        avg_us = float(durs.mean())
+        traffic, tsrc, prof_avg, prof_src = None, None, None, None
+        kname = "gru_bwd_kernel<true, true>" if dg_bf16 else ("gru_bwd_kernel<true, false>" if gru_bf16 else "gru_bwd_kernel<false, false>")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")     # rocprofv3 --pmc passes of THIS round, committed
+        if os.path.exists(pmc) and args.workload == "cfg2" and args.precision == "bf16":
+            for k, v in json.load(open(pmc))["kernels"].items():
+                if k.startswith("gru_bwd_kernel"):
+                    traffic = v["traffic_bytes_per_launch"]
+                    tsrc = "profiles/r03_pmc_hbm_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction), bytes per launch"
+        st = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")    # rocprofv3 --kernel-trace --stats of this command, committed
+        if os.path.exists(st) and args.workload == "cfg2" and args.precision == "bf16":
+            import csv
+            for r_ in csv.DictReader(open(st)):
+                if "gru_bwd_kernel<true, true>" in r_["Name"]:
+                    prof_avg = float(r_["AverageNs"]) / 1e3
+                    prof_src = "profiles/r03_bench_kernel_stats.csv AverageNs (rocprofv3 --kernel-trace --stats -- python3 bench.py, same flags)"
+        mf = fl / (avg_us * 1e-6) / 1e12 / peak_mfma
+        hb = bwd_by / (avg_us * 1e-6) / 1e9 / PEAK_HBM_GBS
+        bound = "hbm" if hb >= mf else "mfma"
+        roof = {"bound": bound, "kernel": kname,
+                "selection": "the single kernel with the largest share of kernel time in rocprofv3's stats of this command (7.5 % at cfg2); "
+                             "latency-bound (T dependent cell steps per launch): neither roofline binds it, the nearer one is reported",
+                "achieved": bwd_by / (avg_us * 1e-6) / 1e9 if bound == "hbm" else fl / (avg_us * 1e-6) / 1e12,
+                "peak": PEAK_HBM_GBS if bound == "hbm" else peak_mfma, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                "frac": hb if bound == "hbm" else mf, "traffic": traffic, "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": bwd_by, "algorithmic_flops_per_launch": fl,
+                "avg_launch_ms": avg_us / 1e3, "launches_timed": int(durs.size), "launches_per_step": durs.size / args.steps,
+                "min_launch_us": float(durs.min()), "max_launch_us": float(durs.max()),
+                "us_per_cell_step": avg_us / T,
+                "timing": "in-kernel launch stamps over the timed region (mimrl_set_kernel_stamps): replayed hipGraph, the schedule `value` is measured on",
+                "rocprof_avg_launch_us": prof_avg, "rocprof_source": prof_src,
+                "hbm_view": {"achieved_gbs": bwd_by / (avg_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "frac": hb},
+                "mfma_view": {"achieved_tflops": fl / (avg_us * 1e-6) / 1e12, "peak": peak_mfma, "frac": mf,
+                              "mfma_busy_counter": "profiles/r03_pmc_mfma_busy_cfg2.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}}
+        fdur = np.concatenate([stamps["gru_fwd_l0"], stamps["gru_fwd_l1"]])
+        if fdur.size:
+            fus = float(fdur.mean())
+            kernels.insert(0, {"kernel": "gru_fwd_kernel<bf16> (in-graph stamps, timed region)", "schedule": "graph (timed region)",
+                               "ms_per_step": fus * fdur.size / args.steps / 1e3, "launches_per_step": fdur.size / args.steps, "avg_launch_us": fus,
+                               "gflop_per_launch": fl / 1e9, "mbytes_per_launch": fwd_by / 1e6, "achieved_tflops": fl / (fus * 1e-6) / 1e12,
+                               "achieved_gbs": fwd_by / (fus * 1e-6) / 1e9, "note": f"{fus / T:.3f} us per dependent cell step"})
+        kernels.insert(0, {"kernel": kname + " (in-graph stamps, timed region)", "schedule": "graph (timed region)",
+                           "ms_per_step": avg_us * durs.size / args.steps / 1e3, "launches_per_step": durs.size / args.steps, "avg_launch_us": avg_us,
+                           "gflop_per_launch": fl / 1e9, "mbytes_per_launch": bwd_by / 1e6, "achieved_tflops": fl / (avg_us * 1e-6) / 1e12,
+                           "achieved_gbs": bwd_by / (avg_us * 1e-6) / 1e9, "note": f"{avg_us / T:.3f} us per dependent cell step"})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(opt, N)
+        cpu = cpu_baseline(args.workload)
 
     if rank == 0:
         ms = 1e3 * wall / args.steps

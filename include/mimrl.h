@@ -159,6 +159,12 @@ int64_t mimrl_workspace_bytes(const mimrl_handle* h);
 enum { MIMRL_PH_GEMM_MISC = 0, MIMRL_PH_GRU_FWD, MIMRL_PH_GRU_BWD, MIMRL_PH_CUBE_FWD, MIMRL_PH_CUBE_BWD, MIMRL_PH_EST_FWD,
        MIMRL_PH_EST_BWD, MIMRL_PH_OPT, MIMRL_PH_MODEL_MISC, MIMRL_NPHASES };
 int mimrl_profile_enable(mimrl_handle* h, int on);     /* forces eager launches while on */
+/* Launch stamps of the two persistent recurrence kernels -- the largest single kernels of the step -- that also work INSIDE a
+ * replayed hipGraph, where HIP events cannot bracket one kernel: every workgroup records its start / end time (wall_clock64, 100 MHz
+ * ticks) with an atomicMin into ring[((rng_step & (slots-1)) * 4 + id) * 2 + {0: start, 1: ~end}] (device uint64, caller-owned,
+ * pre-filled with 0xFF; slots a power of two; id 0/1 = forward layer 0/1, 2/3 = BPTT layer 1/0; rng_step = counters[0], +1 per stage).
+ * bench.py derives its roofline block from these over the TIMED region.  ring = NULL: off (default).  Drops captured graphs. */
+int mimrl_set_kernel_stamps(mimrl_handle* h, unsigned long long* ring, int slots);
 int mimrl_profile_read(mimrl_handle* h, float* ms_sum /*[MIMRL_NPHASES]*/, int32_t* launches /*[MIMRL_NPHASES]*/);  /* syncs; resets */
 /* GEMM family of the eager steps since the last read: out = {algorithmic FLOPs, algorithmic bytes (operands and output once),
  * summed launch durations in ms (HIP events on each launch's own stream), launches}; syncs; resets */

@@ -245,6 +245,7 @@ struct mimrl_handle {
   bool tail2_needed = false;           // deferred tail still to be issued before stage 2 may run
   bool fwd2_pending = false;           // a prefetched stage-2 forward is waiting to be consumed
   float grad_scale = 1.f;              // folded into the fused clip+Adam (mimrl_set_grad_scale)
+  KernelStamp kstamp;                  // launch stamps of the recurrence kernels (mimrl_set_kernel_stamps); id: 0/1 forward layer 0/1, 2/3 BPTT layer 1/0
 
   int run_fwd2_tail();
   hipStream_t pre_stream = nullptr;
@@ -785,6 +786,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
     GruFwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.btv = gru_pick_btv(B, 2);
+    a.stamp = kstamp; a.stamp.id = l;
     if (l == 1) MX(fork(1, 3));
     if (l == 0 && !l0_packed && l0_bwd_pack && save) {   // packed copy of the inputs for the layer-0 weight gradients: side 0 has slack
       L0Pack pk;
@@ -1610,6 +1612,7 @@ int mimrl_handle::model_backward() {
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.dout_ld = l == 1 ? H : 2 * H; a.dout_off = l == 1 ? 0 : H;
     a.btv = gru_pick_btv(B, 2);
+    a.stamp = kstamp; a.stamp.id = l == 1 ? 2 : 3;
     // layer 0 without packed inputs keeps fp32 dg: its dW_ih product reads the caller's unaligned [rows, 74 / 35] inputs through
     // the generic kernel, which has no bf16-operand variant
     const bool lbf = dg_bf16 && (l == 1 || l0_packed || l0_bwd_pack);
@@ -2804,6 +2807,14 @@ int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* 
     HIPX(hipMemcpyAsync(dtin_out, h->dtin, sizeof(float) * 2 * NE_MI * B * EMB, hipMemcpyDeviceToDevice, h->stream));
   }
   if (stage == 1) h->grads_clean[1] = false;
+  return MIMRL_OK;
+}
+
+int mimrl_set_kernel_stamps(mimrl_handle* h, unsigned long long* ring, int slots) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if (ring && (slots < 1 || (slots & (slots - 1)))) return set_error(MIMRL_ERR_ARG, "stamp ring: slots must be a power of two");
+  h->kstamp.ring = ring; h->kstamp.step = h->d_ints; h->kstamp.slots = ring ? slots : 0;
+  h->drop_graphs();     // captured launches bake the kernel arguments in
   return MIMRL_OK;
 }
 

@@ -12,7 +12,13 @@ struct GruSeq {
   float* saved;        // gate slab for BPTT (gru_saved_floats(B,T) floats) or nullptr
 };
 
+// In-kernel launch stamps (bench.py's roofline block: the duration of a launch INSIDE a replayed hipGraph, where HIP events cannot
+// bracket a single kernel).  ring[((*step & (slots - 1)) * 4 + id) * 2 + {0, 1}] = {min over workgroups of the start time, min of
+// ~(end time)} in wall_clock64 ticks (100 MHz), accumulated with atomicMin into a ring the caller pre-fills with 0xFF.  Null: off.
+struct KernelStamp { unsigned long long* ring = nullptr; const int* step = nullptr; int slots = 0, id = 0; };
+
 struct GruFwdArgs {
+  KernelStamp stamp;
   GruSeq seq[2][2];        // [modality][direction]
   const int* lens[2];      // [modality][B] valid lengths (packed-sequence semantics)
   int B, T, out_ld, nmod;
@@ -31,6 +37,7 @@ struct GruSeqBwd {
 };
 
 struct GruBwdArgs {
+  KernelStamp stamp;
   GruSeqBwd seq[2][2];
   const int* lens[2];
   int B, T, out_ld, dout_ld, dout_off, nmod;

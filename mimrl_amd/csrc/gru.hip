@@ -153,12 +153,20 @@ __device__ __forceinline__ void load_gates(const float* p, Gates& g) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stamp_begin(const KernelStamp& k) {
+  if (k.ring && threadIdx.x == 0) atomicMin(&k.ring[(((unsigned)*k.step & (unsigned)(k.slots - 1)) * 4u + k.id) * 2u], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_end(const KernelStamp& k) {
+  if (k.ring && threadIdx.x == 0) atomicMin(&k.ring[(((unsigned)*k.step & (unsigned)(k.slots - 1)) * 4u + k.id) * 2u + 1u], ~(unsigned long long)wall_clock64());
+}
+
 #ifndef GRU_BF16_MINB
 #define GRU_BF16_MINB 2   // -DGRU_BF16_MINB=1: the AGPR-using build of the reproducibility hunt, debugging only
 #endif
 template <bool BF16, bool SAVE>
 __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
+  stamp_begin(a.stamp);
   __shared__ __attribute__((aligned(16))) Tile<BF16, H> hs[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.x, dir = blockIdx.y, mod = blockIdx.z;
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
     do_step(step + 1, 1, gxB);
   }
   if (step < T) do_step(step, 0, gxA);
+  stamp_end(a.stamp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
 template <bool BF16, bool DGBF>
 __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(GruBwdArgs a) {
   using C = Cfg<BF16>;
+  stamp_begin(a.stamp);
   __shared__ __attribute__((aligned(16))) Tile<BF16, G> ds[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.x, dir = blockIdx.y, mod = blockIdx.z;
@@ -443,6 +453,7 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
       }
     }
   }
+  stamp_end(a.stamp);
 }
 
 }  // namespace

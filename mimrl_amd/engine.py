@@ -258,6 +258,26 @@ class HipEngine:
         check(self.lib.mimrl_probe_mi(self.handle, stage, _ptr(mi), _ptr(scores), _ptr(dtin)))
         return {"mi": mi[0], "mi_loss": mi[1], "scores": scores, "dtin": dtin}
 
+    STAMP_IDS = ("gru_fwd_l0", "gru_fwd_l1", "gru_bwd_l1", "gru_bwd_l0")
+
+    def kernel_stamps(self, slots: int = 1 << 14):
+        """Switch the in-kernel launch stamps of the recurrence kernels on (include/mimrl.h: mimrl_set_kernel_stamps) and clear the
+        ring.  ``slots`` (power of two) >= 2 x the steps between two reads."""
+        if getattr(self, "_stamps", None) is None or self._stamps.shape[0] != slots:
+            self._stamps = torch.empty(slots, 4, 2, dtype=torch.int64, device=self.device)
+            check(self.lib.mimrl_set_kernel_stamps(self.handle, _ptr(self._stamps), slots))
+        self._stamps.fill_(-1)
+
+    def read_kernel_stamps(self) -> Dict[str, "np.ndarray"]:
+        """-> {kernel: launch durations in microseconds} of every launch stamped since ``kernel_stamps()`` (synchronises)."""
+        r = self._stamps.cpu().numpy().view(np.uint64)
+        out = {}
+        for i, name in enumerate(self.STAMP_IDS):
+            t0, t1 = r[:, i, 0], ~r[:, i, 1]
+            ok = (r[:, i, 0] != np.uint64(0xFFFFFFFFFFFFFFFF)) & (r[:, i, 1] != np.uint64(0xFFFFFFFFFFFFFFFF))
+            out[name] = (t1[ok].astype(np.float64) - t0[ok].astype(np.float64)) / 100.0     # 100 MHz ticks -> us
+        return out
+
     def profile(self, on: bool):
         check(self.lib.mimrl_profile_enable(self.handle, int(on)))
 
