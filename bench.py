@@ -249,7 +249,7 @@ def extra_schedules(eng, args, B, T, rank):
     if not args.no_prefetch:
         # the launch structure every rank runs at N > 1 (dist.ddp_two_stage_step: per-stage gradient graphs, deferred stage-2
         # forward tail, separate apply launches), here with world = 1, i.e. WITHOUT the two collectives: what the split costs
-        eng.set_stage2_prefetch(2)
+        eng.set_stage2_prefetch(mdist.ddp_prefetch_mode(2))
         extra["ms_per_step_ddp_schedule_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
         eng.set_stage2_prefetch(True)
     host = [tuple(torch.from_numpy(x).pin_memory() for x in synth.synthetic_batch(B, T, seed=100 + i)) for i in range(4)]
@@ -316,7 +316,7 @@ def main():
 
     # Solver.step() mode: both stages work on the same batch, so the stage-2 forward pass is issued beside stage 1
     # (same arithmetic and results as the sequential order; tests/test_gpu_step.py::test_stage2_prefetch_matches_sequential)
-    eng.set_stage2_prefetch(0 if args.no_prefetch else (2 if world > 1 else 1))   # world > 1: deferred-tail variant (dist.py)
+    eng.set_stage2_prefetch(0 if args.no_prefetch else mdist.ddp_prefetch_mode(world))
     # launch stamps of the recurrence kernels (two atomics per workgroup): the roofline block is measured INSIDE the timed region,
     # on the replayed graph, not on a separate eager schedule
     use_stamps = rank == 0 and not args.extras_only and args.steps <= 8000
@@ -328,7 +328,7 @@ def main():
             mdist.ddp_stage_step(eng, 1, world)
             mdist.ddp_stage_step(eng, 2, world)
         elif world > 1:
-            mdist.ddp_two_stage_step(eng, world)    # critic-bucket all-reduce under the stage-2 forward tail
+            mdist.ddp_two_stage_step(eng, world)    # per-stage gradient graphs, bucket all-reduce, fused clip+Adam (dist.py)
         else:
             eng.step()            # mimrl_two_stage_step: in overlap mode with graphs both stages are ONE captured graph
 

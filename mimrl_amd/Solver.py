@@ -40,12 +40,12 @@ class Solver:
             raise NotImplementedError(f"--loss {opt.loss}: only MAE is on the MI355X hot path (SURVEY.md section 2)")
         if opt.optm != "Adam":
             raise NotImplementedError(f"--optm {opt.optm}: only Adam is fused on the MI355X hot path")
+        if torch.cuda.is_available():   # BEFORE the loaders: a resident dataset lands on the current device (data.py)
+            torch.cuda.set_device(self.local_rank % torch.cuda.device_count())   # (more ranks than GPUs: ranks share devices)
         if loaders is None:
             from .data import get_data_loader
             loaders = get_data_loader(opt, self.rank, self.world)          # training data sharded by rank
         self.train_loader, self.valid_loader, self.test_loader, self.d_t, self.d_a, self.d_v = loaders
-        if torch.cuda.is_available():
-            torch.cuda.set_device(self.local_rank % torch.cuda.device_count())   # (more ranks than GPUs: ranks share devices)
         # banks hold one row per training sample of EVERY rank (all-gathered once per epoch)
         cap = _loader_samples(self.train_loader, opt.batch_size) * self.world
         self.model = Model(opt, self.d_t, self.d_a, self.d_v, bank_capacity=cap, rank=self.rank)
@@ -103,7 +103,7 @@ class Solver:
             self._active = e
         if e.bank_rows != self.engine.bank_rows:
             e.set_bank_rows(self.engine.bank_rows)
-        want = (2 if self.world > 1 else 1) if self._want_prefetch else 0     # data parallel: deferred-tail variant (dist.py)
+        want = mdist.ddp_prefetch_mode(self.world) if self._want_prefetch else 0
         if getattr(e, "_prefetch_on", 0) != want:
             e.set_stage2_prefetch(want)
             e._prefetch_on = want

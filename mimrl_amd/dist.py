@@ -35,10 +35,30 @@ def init_from_env(backend: str = None):
     return world, rank, local
 
 
+import contextlib
+
+
+def _engine_stream(engine):
+    """Context that makes the ENGINE's stream torch's current stream.  torch.distributed orders a collective against the current
+    stream at call time (the RCCL communication stream waits for it, and wait() makes it wait for the collective), while the engine
+    launches on the stream it captured at construction: if the caller's current stream were another one, the all-reduce could read
+    a gradient bucket before stage_grads has produced it and stage_apply could run before the reduce."""
+    st = getattr(engine, "stream", None)
+    if st is None or not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    return torch.cuda.stream(st)
+
+
+def _collectives_on(world: int) -> bool:
+    # MIMRL_DDP_FORCE_COLLECTIVES=1: issue the collectives at world == 1 too (a one-rank communicator) -- how the RCCL call path,
+    # its stream ordering against the engine's stream and the async work handle are exercised on a ONE-GPU box (tests/test_gpu_ddp.py)
+    return world > 1 or (dist.is_initialized() and os.environ.get("MIMRL_DDP_FORCE_COLLECTIVES") is not None)
+
+
 def allreduce_sum_(flat: torch.Tensor, world: int, async_op: bool = False):
     """In-place SUM over ranks of one flat bucket (a single collective; RCCL picks ring/tree/direct over xGMI).  The 1/world
     factor of the mean is folded into the engine's fused clip+Adam (``set_grad_scale``): no scaling pass over the bucket."""
-    if world <= 1:
+    if not _collectives_on(world):
         return None
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
@@ -61,37 +81,57 @@ def ddp_stage_step(engine, stage: int, world: int):
     stage_apply / bucket_grad(stage) / set_grad_scale.  The collective is enqueued behind the kernels in stream order: no host
     synchronisation (RCCL); value-clipping happens after averaging, as in a single process."""
     prepare_engine(engine, world)
-    engine.stage_grads(stage)
-    if world > 1 and engine.has_update(stage):
-        allreduce_sum_(engine.bucket_grad(stage), world)
-    engine.stage_apply(stage)
+    with _engine_stream(engine):
+        engine.stage_grads(stage)
+        if _collectives_on(world) and engine.has_update(stage):
+            allreduce_sum_(engine.bucket_grad(stage), world)
+        engine.stage_apply(stage)
+
+
+def deferred_tail() -> bool:
+    """MIMRL_DDP_DEFERRED_TAIL=1: the round-2 schedule (stage-2 forward tail issued UNDER the critic-bucket collective, engine
+    prefetch mode 2) instead of the default (tail beside stage 1, mode 1)."""
+    return os.environ.get("MIMRL_DDP_DEFERRED_TAIL") is not None
+
+
+def ddp_prefetch_mode(world: int) -> int:
+    """Engine overlap mode Solver.step / bench.py select for a data-parallel two-stage step."""
+    return 2 if (world > 1 and deferred_tail()) else 1
 
 
 def ddp_two_stage_step(engine, world: int):
-    """Solver.step() under data parallelism, with the critic-bucket collective hidden:
+    """Solver.step() under data parallelism (reference counterpart: nn.DataParallel's gradient reduce, Solver.py:33-35):
 
-        stage_grads(1)            shared encoder prefix, stage-1 tail, 11 estimators fwd+bwd  -> crit_g complete
-        all-reduce(crit_g) ASYNC  on RCCL's communication stream (13.4 MB, the larger bucket)
-        stage2_forward_tail()     LN+ReLU+dropout, CubeMLP, head of the stage-2 pass: needs neither crit_g nor the critic
-                                  update, so it runs UNDER the collective (engine in deferred-tail mode)
-        wait; stage_apply(1)      clip + Adam on crit_g / world  ->  stage 2's estimators see the updated critics
-        stage_grads(2); all-reduce(main_g); stage_apply(2)
+        stage_grads(1)            shared encoder prefix, BOTH forward tails (stage 1's, and stage 2's beside it: prefetch mode 1),
+                                  11 estimators fwd+bwd                                             -> crit_g complete
+        all-reduce(crit_g)        RCCL, 13.4 MB
+        stage_apply(1)            clip + Adam on crit_g / world  ->  stage 2's estimators see the updated critics
+        stage_grads(2); all-reduce(main_g) (4.3 MB); stage_apply(2)
 
-    The main bucket (4.3 MB) is reduced in one piece behind the backward pass: its last producers (GRU layer-0 and W_t
-    weight gradients) finish with the stage, and CubeMLP's weight gradients are deliberately issued late (beside the BPTT),
-    so there is no early-ready prefix of that bucket to reduce ahead of time.
-    Requires ``engine.set_stage2_prefetch(2)`` (Solver.step does it)."""
+    Round 3: the stage-2 forward tail runs BESIDE stage 1's estimators (where the single-GPU graph hides it too), not under the first
+    collective as in round 2 ("deferred tail", still available: MIMRL_DDP_DEFERRED_TAIL=1 + prefetch mode 2).  Arithmetic: the tail
+    (0.15 ms) is hidden either way, but beside stage 1 it is hidden even when the collective is shorter than the tail, and the
+    per-rank launch structure measured WITHOUT communication on one MI355X is 1.19 ms against 1.26 ms (single-GPU graph: 1.01 ms;
+    bench.py: ms_per_step_ddp_schedule_no_comm).  The dependency all-reduce -> Adam_vmi -> stage-2 critic forward is a true one
+    (SURVEY.md section 5); nothing of stage 2 that is independent of the updated critics is left to put under it.  The main bucket is
+    reduced in one piece: 90 % of it are GRU / W_t gradients that become final with the last kernels of the stage.
+    NOT MEASURED ON MORE THAN ONE GPU (no multi-GPU box available to the builder): see DESIGN.md section 6."""
     prepare_engine(engine, world)
-    engine.stage_grads(1)
-    work = allreduce_sum_(engine.bucket_grad(1), world, async_op=True) if (world > 1 and engine.has_update(1)) else None
-    engine.stage2_forward_tail()
-    if work is not None:
-        work.wait()
-    engine.stage_apply(1)
-    engine.stage_grads(2)
-    if world > 1:
-        allreduce_sum_(engine.bucket_grad(2), world)
-    engine.stage_apply(2)
+    on = _collectives_on(world)
+    with _engine_stream(engine):
+        engine.stage_grads(1)
+        if deferred_tail():
+            work = allreduce_sum_(engine.bucket_grad(1), world, async_op=True) if (on and engine.has_update(1)) else None
+            engine.stage2_forward_tail()
+            if work is not None:
+                work.wait()
+        elif on and engine.has_update(1):
+            allreduce_sum_(engine.bucket_grad(1), world)
+        engine.stage_apply(1)
+        engine.stage_grads(2)
+        if on:
+            allreduce_sum_(engine.bucket_grad(2), world)
+        engine.stage_apply(2)
 
 
 def allgather_rows(x: torch.Tensor, world: int) -> torch.Tensor:

@@ -24,11 +24,19 @@ def local_anchors(c, r, it):
     return [np.stack([g.choice(c["N"], size=c["B"] // 2, replace=False) for _ in range(6)]) for _ in range(2)]
 
 
-def engine_part(world, rank):
-    c = dict(CONFIGS["tiny_sep"], lr=1e-4)
+def engine_part(world, rank, name="tiny_sep", precision="fp32", critic=None, deferred=False):
+    """3 data-parallel two-stage steps of the real engine on rank-local batches: replicas bit-identical, and equal to single-process
+    Adam on the mean of the two local gradients.  ``precision="bf16"`` + ``name="cfg2_sep"`` is the bench mode at the bench shape."""
+    if deferred:
+        os.environ["MIMRL_DDP_DEFERRED_TAIL"] = "1"
+    else:
+        os.environ.pop("MIMRL_DDP_DEFERRED_TAIL", None)
+    c = dict(CONFIGS[name], lr=1e-4)
+    if critic:
+        c["critic"] = critic
     opt = make_opt(c)
     banks = synth.synthetic_banks(c["N"], seed=c["seed"])
-    mk = lambda graph: HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision="fp32", use_graph=graph, seed=rank)
+    mk = lambda graph: HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision=precision, use_graph=graph, seed=rank)
     eng = mk(True)
     p = oracle_params(opt, c["seed"])
     eng.load_params({k: v + (0.01 * rank) for k, v in p.items()})         # rank 1 starts elsewhere ...
@@ -36,7 +44,8 @@ def engine_part(world, rank):
     eng.params_changed()
     eng.set_batch(*local_batch(c, rank))
     eng.set_banks(*(banks[k] for k in "CFTAV"))
-    eng.set_stage2_prefetch(2)                                            # deferred-tail mode: collective under the stage-2 tail
+    eng.set_stage2_prefetch(mdist.ddp_prefetch_mode(world))               # 1: stage-2 tail beside stage 1; 2: deferred under the collective
+    assert mdist.ddp_prefetch_mode(world) == (2 if deferred else 1)
     for it in range(3):
         a = local_anchors(c, rank, it)
         eng.set_anchors(1, a[0]); eng.set_anchors(2, a[1])
@@ -63,8 +72,10 @@ def engine_part(world, rank):
             Bq.bucket_grad(stage).zero_()
     ref = torch.cat([A.main["p"], A.crit["p"]])
     d = (flat[0] - ref).abs()
-    # Adam's first steps are ~lr*sign(g): entries whose mean gradient is ~0 flip on summation order (2*lr each)
-    assert d.max().item() <= 6.5e-4 and d.mean().item() <= 2e-6, (d.max().item(), d.mean().item())
+    # Adam's first steps are ~lr*sign(g): entries whose mean gradient is ~0 flip on summation order (2*lr each).  bf16 mode adds the
+    # float atomics of the split-K weight gradients (run-to-run differences of ~1e-6 of a tensor's scale): more entries near a flip
+    lim = (6.5e-4, 2e-6) if precision == "fp32" else (6.5e-4, 2e-5)
+    assert d.max().item() <= lim[0] and d.mean().item() <= lim[1], (name, precision, critic, d.max().item(), d.mean().item())
     for e in (eng, A, Bq):
         e.close()
     return d.max().item()
@@ -103,6 +114,10 @@ def main():
     assert world == 2
     torch.cuda.set_device(0)
     worst = engine_part(world, rank)
+    engine_part(world, rank, deferred=True)                                    # the round-2 schedule stays correct
+    engine_part(world, rank, name="cfg2_sep", precision="bf16")                 # the bench mode at the bench shape (B = 128 per rank)
+    engine_part(world, rank, name="cfg2_sep", precision="bf16", critic="concat")  # + the fused concat critic
+    os.environ.pop("MIMRL_DDP_DEFERRED_TAIL", None)
     solver_part(world, rank)
     dist.barrier()
     if rank == 0:

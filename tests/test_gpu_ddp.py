@@ -12,8 +12,9 @@ ROOT = os.path.dirname(HERE)
 
 
 def test_ddp_two_processes_one_gpu(tmp_path):
-    """HipEngine through dist.ddp_two_stage_step (deferred-tail mode, async critic all-reduce, 1/world folded into Adam) on
-    different local batches: replicas bit-identical after 3 steps and equal to single-process Adam on the mean gradient;
+    """HipEngine through dist.ddp_two_stage_step (per-stage gradient graphs, bucket all-reduce, 1/world folded into Adam; default
+    schedule and the round-2 deferred-tail one; fp32 tiny, then the bf16 BENCH MODE at cfg2's shape with the separable and the fused
+    concat critic) on different local batches: replicas bit-identical after 3 steps and equal to single-process Adam on the mean gradient;
     broadcast -> params_changed; then Solver under world 2: rank-sharded loader (no duplicate bank rows after the
     all-gather), two epochs of train(), evaluate(), Solver.step(), replicas still identical."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -41,3 +42,18 @@ def test_bench_two_ranks_prints_its_line(tmp_path, extra):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["losses_finite"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp2"
+
+
+def test_rccl_call_path_single_rank(tmp_path):
+    """The `nccl` (= RCCL) branch of mimrl_amd/dist.py on hardware.  RCCL refuses two ranks on one device and the test box has one GPU,
+    so this is a ONE-rank communicator with the collectives forced on (MIMRL_DDP_FORCE_COLLECTIVES): process-group initialisation,
+    all_reduce on the gradient buckets ordered against the ENGINE's stream (constructed on a non-default stream while the caller's
+    current stream is the default one: ADVICE r02), the async work handle of the deferred-tail variant, Adam on the 'reduced' bucket.
+    A one-rank SUM is the identity, so the parameters must equal a plain engine's after 3 steps.  (What it cannot show: xGMI traffic
+    and multi-rank scaling -- no multi-GPU box is available to this builder)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29645", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MIMRL_DDP_FORCE_COLLECTIVES="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_single_rank_worker.py")], env=env, cwd=tmp_path, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "RCCL_SINGLE_RANK_OK" in r.stdout
