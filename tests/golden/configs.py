@@ -29,6 +29,10 @@ CONFIGS = {
     # BASELINE cfg1: B=32, T=50, canonical README flags, N=1000 as in the reference smoke test (Model.py:607)
     "cfg1_sep": dict(B=32, T=50, N=1000, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=6),
     "cfg1_cat": dict(B=32, T=50, N=1000, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
+    # N1 at benchmark scale: cfg1 / cfg2 with RAGGED a/v lengths -- packed-sequence GRU semantics (Model.py:425-447) with
+    # four batch rows of different lengths per recurrence workgroup at T = 50
+    "cfg1_ragged": dict(B=32, T=50, N=1000, seed=15, critic="separate", cube="50-3-128=10-3-128", traj=2, ragged=True),
+    "cfg2_ragged": dict(B=128, T=50, N=1284, seed=16, critic="separate", cube="50-3-128=10-3-128", traj=1, ragged=True),
     # BASELINE cfg2 at FULL size (the bench configuration: B=128, T=50, MOSI-sized banks)
     "cfg2_sep": dict(B=128, T=50, N=1284, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=1),
     # BASELINE cfg3 reduced in the batch only: T = time_len = 500 (L-axis MLP 500 -> 50), concat critic, k=2

@@ -15,7 +15,7 @@ TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mi
         "tiny_sum", "tiny_disc"]
 # cfg2_sep = BASELINE configs[1] at FULL size (the bench configuration); cfg3_small / cfg5_small = configs[2] / [4] with only the
 # batch reduced (T = time_len = 500 / 1000, concat critic for cfg3)
-ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg1_disc", "cfg2_sep", "cfg3_small", "cfg5_small"]
+ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg1_disc", "cfg1_ragged", "cfg2_sep", "cfg2_ragged", "cfg3_small", "cfg5_small"]
 
 
 def make_engine(name, precision="fp32", use_graph=False):
@@ -117,7 +117,7 @@ def test_stage_losses_and_all_gradients_vs_oracle(name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_lstm", "tiny_sum", "tiny_disc", "cfg1_sep", "cfg1_disc",
-                                  "cfg2_sep", "cfg3_small", "cfg5_small"])
+                                  "cfg1_ragged", "cfg2_sep", "cfg2_ragged", "cfg3_small", "cfg5_small"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_two_stage_trajectory(name, use_graph):
     """Alternating stage-1/stage-2 updates (Solver.step) vs the reference trajectory and the oracle."""
@@ -396,12 +396,13 @@ def test_fused_concat_forward_matches_gemm_chain(name, monkeypatch):
         grad_close(ga[n], gb[n], 2e-3, n)
 
 
-def test_cfg2_full_size_in_bench_mode():
-    """BASELINE configs[1] at full size (B=128, T=50, N=1284) in EXACTLY the mode bench.py times -- bf16 MFMA operands, every
+@pytest.mark.parametrize("name", ["cfg2_sep", "cfg2_ragged"])
+def test_cfg2_full_size_in_bench_mode(name):
+    """(cfg2_ragged: the same with ragged audio / video lengths -- four batch rows of different lengths per recurrence workgroup.)
+    BASELINE configs[1] at full size (B=128, T=50, N=1284) in EXACTLY the mode bench.py times -- bf16 MFMA operands, every
     fused kernel, one hipGraph per two-stage step, Solver.step() overlap mode with the shared encoder prefix -- against the
     reference's golden values and the fp32 engine.  (Anchors are host-supplied here so that both modes and the reference
     see the same kNN samples; bench.py draws them on the device.)"""
-    name = "cfg2_sep"
     g = load_golden(name)
     res = {}
     for precision in ("fp32", "bf16"):
@@ -575,6 +576,35 @@ def test_cfg3_full_size_properties(monkeypatch):
     assert_close(sb[_lib.S2_LOSS], sa[_lib.S2_LOSS], 1e-2, 1e-3, "stage-2 loss")
     assert_close(sb[_lib.S2_MIS:_lib.S2_MIS + 8], sa[_lib.S2_MIS:_lib.S2_MIS + 8], 3e-2, 3e-2, "MI terms")
     assert_close(pb, pa, 3e-2, 2e-2, "predictions")
+
+
+def test_cfg3_full_size_mi_values_vs_oracle():
+    """BASELINE configs[2] at FULL size (B=256, T=500, concat critic: 5 x 65,536 pair rows through 256-256-256-1; N=16326 banks, k=2),
+    fp32: both stage losses and all 11 + 8 MI / CMI values against the oracle under no_grad (VMI.py:58-65, Model.py:305-386) -- the
+    reference's B*B pair expansion, its host kNN and the CMI classifiers at the size the benchmark's MFMA fraction is quoted on.
+    (Gradients of this configuration are pinned with only the batch reduced: cfg3_small.)"""
+    opt, N, batch, banks, eng = _bench_engine("cfg3", "fp32", False, device_anchors=False)
+    rng = np.random.default_rng(6)
+    m = opt.batch_size // opt.k_neighbor
+    anchors = [np.stack([rng.choice(N, size=m, replace=False) for _ in range(6)]) for _ in range(2)]
+    eng.set_anchors(1, anchors[0]); eng.set_anchors(2, anchors[1])
+    p = {n: v.detach().cpu().clone() for n, v in eng.params.items()}
+    eng.stage_grads(1)
+    eng.stage_grads(2)
+    torch.cuda.synchronize()
+    s = eng.read_scalars()
+    tb = tuple(torch.from_numpy(x) for x in batch)
+    bk = {k: torch.from_numpy(v) for k, v in banks.items()}
+    with torch.no_grad():
+        l1, mis1, *_ = R.stage_loss(p, opt, 1, tb, bk, anchors[0])
+        l2, mis2, pred, feats, task = R.stage_loss(p, opt, 2, tb, bk, anchors[1])
+    assert_close(s[_lib.S1_LOSS], l1.item(), 1e-3, 1e-5, "stage-1 loss")
+    assert_close(s[_lib.S1_MIS:_lib.S1_MIS + 11], [x.item() for x in mis1], 1e-3, 2e-5, "stage-1 MI/CMI")
+    assert_close(s[_lib.S2_TASK], task.item(), 1e-3, 1e-6, "task loss")
+    assert_close(s[_lib.S2_LOSS], l2.item(), 1e-3, 1e-5, "stage-2 loss")
+    assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], [x.item() for x in mis2], 1e-3, 5e-5, "stage-2 MI terms")
+    assert_close(eng.pred.cpu().numpy(), pred.numpy().reshape(-1), 1e-3, 1e-5, "predictions")
+    eng.close()
 
 
 def test_cfg5_full_size_vs_oracle():
