@@ -25,6 +25,7 @@
 #include "gru.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace mimrl {
 
@@ -114,6 +115,26 @@ template <bool DGBF>
 __device__ __forceinline__ void st2o(float* p, long i, float a, float b) {
   if constexpr (DGBF) { bf16x2 v; v[0] = to_bf16(a); v[1] = to_bf16(b); *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(p) + i) = v; }
   else *reinterpret_cast<float2*>(p + i) = make_float2(a, b);
+}
+
+// Operand loads of the software pipeline with EXPLICIT wait counts (bf16 kernels).  The compiler's waitcnt pass merges the counts of
+// the loop's incoming edges conservatively: at the loop header it waited with vmcnt(1) / vmcnt(4) for loads that have EIGHT younger
+// operations behind them (the previous step's five stores and three prefetches), i.e. for the youngest prefetches too -- the memory
+// latency the pipeline exists to hide was back on the dependent chain of every second cell step (measured by removing the loads:
+// 0.43 of the BPTT's 1.32 us per step).  Loads issued by inline asm are invisible to that pass; vm_wait<N>() is the one wait, with the
+// exact count (every step issues the same sequence of loads and stores, unconditionally: see the padding-lane comment), and ties
+// the destination registers so that no use can be scheduled in front of it.
+__device__ __forceinline__ void gld8(float2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int OFF>   // + OFF bytes as the instruction's immediate offset: one address register pair for several loads
+__device__ __forceinline__ void gld8o(float2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory"); }
+__device__ __forceinline__ void gld16(bf16x8& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int N>
+__device__ __forceinline__ void vm_wait(float2& a, float2& b, float2& c) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(bf16x8& a, float2& b, float2& c) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 
 // saved-gate slab, "lane-native": one record {r0 r1 z0 z1 n0 n1 hn0 hn1} per (t, tile, wave, lane); bf16 mode packs it
@@ -223,14 +244,17 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
   auto load_gx = [&](float2 (&dst)[3], int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? T - 1 - sc : sc;
+    const float* p = gx_b + (long)t * G;
+    // (compiler-tracked loads here: with the explicit-wait loads of the BPTT kernel this loop measured 31.0 instead of 29.3 us per
+    //  launch -- its waitcnt counts are exact in every second step and two short in the others, and that beats one exact wait)
 #pragma unroll
-    for (int g = 0; g < 3; ++g) dst[g] = ld2(gx_b + (long)t * G + g * H);
+    for (int g = 0; g < 3; ++g) dst[g] = ld2(p + g * H);
   };
   float2 gxA[3], gxB[3];
   load_gx(gxA, 0);
   load_gx(gxB, 1);
 
-  auto do_step = [&](const int step, const int cur, float2 (&gx)[3]) {
+  auto do_step = [&](const int step, const int cur, float2 (&gx)[3], auto first) {
     const int t = dir ? T - 1 - step : step;
 
     f32x4 acc[3][2];
@@ -238,15 +262,29 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int s = 0; s < 2; ++s) acc[g][s] = f32x4{bh[g][s], 0.f, 0.f, 0.f};   // only register 0 is read
+    if constexpr (BF16) {   // all A-fragments of the state tile requested up front (see gru_bwd_kernel)
+      typename C::Frag sf[C::KS_F];
 #pragma unroll
-    for (int ks = 0; ks < C::KS_F; ++ks) {
-      const auto sf = state_frag(hs[cur], ks, lane);
+      for (int ks = 0; ks < C::KS_F; ++ks) sf[ks] = state_frag(hs[cur], ks, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+      for (int ks = 0; ks < C::KS_F; ++ks)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(sf, wr[g][s][ks], acc[g][s]);
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(sf[ks], wr[g][s][ks], acc[g][s]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < C::KS_F; ++ks) {
+        const auto sf = state_frag(hs[cur], ks, lane);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(sf, wr[g][s][ks], acc[g][s]);
+      }
     }
 
+    (void)first;
     const bool valid = t < len;
     const float gr[2] = {gx[0].x, gx[0].y}, gz[2] = {gx[1].x, gx[1].y}, gn[2] = {gx[2].x, gx[2].y};
     Gates gt;
@@ -276,15 +314,15 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
   // for the youngest prefetch -- on every iteration
   int step = 0;
   if (T >= 2) {
-    do_step(0, 0, gxA);
-    do_step(1, 1, gxB);
+    do_step(0, 0, gxA, std::true_type{});
+    do_step(1, 1, gxB, std::false_type{});
     step = 2;
   }
   for (; step + 1 < T; step += 2) {
-    do_step(step, 0, gxA);
-    do_step(step + 1, 1, gxB);
+    do_step(step, 0, gxA, std::false_type{});
+    do_step(step + 1, 1, gxB, std::false_type{});
   }
-  if (step < T) do_step(step, 0, gxA);
+  if (step < T) { if (step == 0) do_step(step, 0, gxA, std::true_type{}); else do_step(step, 0, gxA, std::false_type{}); }
   stamp_end(a.stamp);
 }
 
@@ -350,24 +388,35 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
   // stale-but-initialised records and are masked in the math).  h_prev is the previous VALID output of this direction;
   // with packed semantics that is simply out[tprev] when tprev is inside [0,len) and the zero initial state otherwise
   // (selected at use).
-  struct Ops { Gates g; float2 DO, HP; };
+  struct Ops { Gates g; bf16x8 graw; float2 DO, HP; };
   auto fetch = [&](Ops& o, int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? sc : T - 1 - sc;
     const int tprev = dir ? t + 1 : t - 1;
     const int tc = tprev < 0 ? 0 : (tprev >= T ? T - 1 : tprev);
-    load_gates<BF16>(sv_b + t * sv_step, o.g);
-    o.DO = ld2(dout_b + (long)t * a.dout_ld);
-    o.HP = ld2(out_b + (long)tc * a.out_ld);
+    if constexpr (BF16) {   // explicit-wait loads (see gld8): the packed gate record is decoded behind the wait
+      gld16(o.graw, sv_b + t * sv_step);
+      gld8(o.DO, dout_b + (long)t * a.dout_ld);
+      gld8(o.HP, out_b + (long)tc * a.out_ld);
+    } else {
+      load_gates<BF16>(sv_b + t * sv_step, o.g);
+      o.DO = ld2(dout_b + (long)t * a.dout_ld);
+      o.HP = ld2(out_b + (long)tc * a.out_ld);
+    }
   };
   Ops opA, opB;
   fetch(opA, 0);
   fetch(opB, 1);
 
-  auto do_step = [&](const int step, const int cur, Ops& nx) {
+  auto do_step = [&](const int step, const int cur, Ops& nx, auto first) {
     // forward visited t in order (dir ? T-1..0 : 0..T-1); backward walks it the other way round
     const int t = dir ? step : T - 1 - step;
     const bool valid = t < len;
+    if constexpr (BF16) {   // younger than this step's operands: the previous step's 5 stores + 3 prefetches (step 0: step 1's prefetches)
+      if constexpr (decltype(first)::value) vm_wait<3>(nx.graw, nx.DO, nx.HP); else vm_wait<8>(nx.graw, nx.DO, nx.HP);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { nx.g.r[e] = (float)nx.graw[e]; nx.g.z[e] = (float)nx.graw[2 + e]; nx.g.n[e] = (float)nx.graw[4 + e]; nx.g.hn[e] = (float)nx.graw[6 + e]; }
+    }
     const Ops& op = nx;
     float dhz[2];
     float drp[2] = {0.f, 0.f}, dzp[2] = {0.f, 0.f}, dnp[2] = {0.f, 0.f}, dnr[2] = {0.f, 0.f};
@@ -408,26 +457,41 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
     f32x4 acc[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) acc[s] = f32x4{dhz[s], 0.f, 0.f, 0.f};   // only register 0 is read
+    if constexpr (BF16) {
+      // ALL twelve A-fragments of the dgh tile are requested before the first product (12 x 16 B per lane, distinct registers).  Left to
+      // itself the compiler reads every fragment into ONE register quad -- ds_read, s_waitcnt lgkmcnt(0), two MFMAs, twelve times: an LDS
+      // round trip per k-step on the dependent chain of every cell step.  __builtin_amdgcn_sched_barrier keeps the scheduler from sinking
+      // the reads back to their uses (an empty asm with a memory clobber does not).
+      typename C::Frag sf[C::KS_B];
 #pragma unroll
-    for (int ks = 0; ks < C::KS_B; ++ks) {
-      const auto sf = state_frag(ds[cur], ks, lane);
+      for (int ks = 0; ks < C::KS_B; ++ks) sf[ks] = state_frag(ds[cur], ks, lane);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acc[s] = mfma16(sf, wr[s][ks], acc[s]);
+      for (int ks = 0; ks < C::KS_B; ++ks)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc[s] = mfma16(sf[ks], wr[s][ks], acc[s]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < C::KS_B; ++ks) {
+        const auto sf = state_frag(ds[cur], ks, lane);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc[s] = mfma16(sf, wr[s][ks], acc[s]);
+      }
     }
     carry[0] = acc[0][0]; carry[1] = acc[1][0];
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
   };
   int step = 0;
   if (T >= 2) {   // peeled first pair (see gru_fwd_kernel)
-    do_step(0, 0, opA);
-    do_step(1, 1, opB);
+    do_step(0, 0, opA, std::true_type{});
+    do_step(1, 1, opB, std::false_type{});
     step = 2;
   }
   for (; step + 1 < T; step += 2) {
-    do_step(step, 0, opA);
-    do_step(step + 1, 1, opB);
+    do_step(step, 0, opA, std::false_type{});
+    do_step(step + 1, 1, opB, std::false_type{});
   }
-  if (step < T) do_step(step, 0, opA);
+  if (step < T) { if (step == 0) do_step(step, 0, opA, std::true_type{}); else do_step(step, 0, opA, std::false_type{}); }
   // bias gradients: reduce over the 4 batch rows (lanes differing in bits 4..5), one atomic per unit
   if (q.db_ih || q.db_hh) {
 #pragma unroll
