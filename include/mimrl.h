@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIMRL_ABI_VERSION 2
+#define MIMRL_ABI_VERSION 3
 #define MIMRL_MAX_BLOCKS 4
 
 enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -3, MIMRL_ERR_NODEVICE = -4 };

@@ -4,7 +4,7 @@ pat=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 for ks in "$@"; do
   rm -rf /tmp/ks_prof
-  (cd /tmp && TMPDIR=/tmp env $ks rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_prof -- python3 $root/bench.py --steps 30 --warmup 5 --profile-steps 0 --no-cpu-baseline --no-extra > /tmp/ks.log 2>&1)
+  (cd /tmp && TMPDIR=/tmp env $ks rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_prof -- python3 $root/bench.py --steps 30 --warmup 5 --profile-steps 0 --no-cpu-baseline --prewarm-ms 0 --no-extra > /tmp/ks.log 2>&1)
   f=$(find /tmp/ks_prof -name "*kernel_stats.csv" | head -1)
   echo "[$ks]"
   python3 - "$f" "$pat" <<'PY'

@@ -5,7 +5,7 @@ set -u
 wl=$1; steps=$2; shift 2
 root=$PWD; out=gpurun_out/prof_$wl; mkdir -p $out
 export TMPDIR=/tmp
-(cd /tmp && rm -rf /tmp/p_$wl && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$wl -- python3 $root/bench.py --workload $wl --steps $steps --warmup 3 --no-cpu-baseline --profile-steps 0 --no-extra "$@" > $root/$out/bench.json 2> $root/$out/bench.err)
+(cd /tmp && rm -rf /tmp/p_$wl && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$wl -- python3 $root/bench.py --workload $wl --steps $steps --warmup 3 --no-cpu-baseline --prewarm-ms 0 --profile-steps 0 --no-extra "$@" > $root/$out/bench.json 2> $root/$out/bench.err)
 cp $(find /tmp/p_$wl -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 python3 - <<PY
 import csv
