@@ -271,21 +271,41 @@ class Solver:
     # checkpoints: the reference's keys (Solver.py:57-62); 'model' = state_dict with the reference's parameter names,
     # the optimizers as flat Adam-moment buckets + device step counters (a complete, resumable optimizer state)
     def checkpoint(self, epoch):
+        """Solver.py:57-62 ('epoch', 'model', 'optim_main', 'optim_vmi') + what a RESUMED run needs and the reference does not save:
+        the five feature banks of the epoch (Solver.py:223-227 rebuilds them only by training: resuming with empty banks would apply
+        the epoch-0 rule for a whole epoch), the device RNG step and numpy's global RNG state (host-drawn anchors,
+        Model.py:81).  Optimizer format: 'm' / 'v' are the flat moment buckets in the layout of `mimrl_layout_entry` (NOT a
+        torch.optim.Adam state_dict: parameters are not separate tensors here), 'step' is Adam's state['step'], 'lr' the current rate."""
         st = self.engine.optimizer_state()
         cpu = lambda d: {k: v.detach().cpu() for k, v in d.items()}
-        return {"epoch": epoch, "model": cpu(self.model.state_dict()),
-                "optim_main": cpu({"m": st["main_m"], "v": st["main_v"], "step": st["counters"][1:2], "lr": st["lr_main"]}),
-                "optim_vmi": cpu({"m": st["crit_m"], "v": st["crit_v"], "step": st["counters"][2:3], "lr": st["lr_critic"]}),
-                "rng_step": st["counters"][0:1].cpu()}
+        n = int(self.engine.bank_rows)
+        ck = {"epoch": epoch, "model": cpu(self.model.state_dict()),
+              "optim_main": cpu({"m": st["main_m"], "v": st["main_v"], "step": st["counters"][1:2], "lr": st["lr_main"]}),
+              "optim_vmi": cpu({"m": st["crit_m"], "v": st["crit_v"], "step": st["counters"][2:3], "lr": st["lr_critic"]}),
+              "rng_step": st["counters"][0:1].cpu(),
+              "banks": {k: self.engine.bank[k][:n].detach().cpu().clone() for k in "CFTAV"} if n else None}
+        rs = np.random.get_state()
+        ck["np_rng"] = (rs[0], torch.from_numpy(rs[1].astype(np.int64)), int(rs[2]), int(rs[3]), float(rs[4]))
+        return ck
 
     def load_checkpoint(self, ck):
-        ck = torch.load(ck, map_location="cpu") if isinstance(ck, (str, os.PathLike)) else ck
+        """-> epoch of the checkpoint.  Restores parameters, both optimizers, the RNG counters and -- when the checkpoint has them --
+        the feature banks (``self.resume_banks`` is then the tuple to pass to ``train(epoch + 1, loader, *banks)``)."""
+        ck = torch.load(ck, map_location="cpu", weights_only=False) if isinstance(ck, (str, os.PathLike)) else ck
         self.model.load_state_dict(ck["model"])
         cnt = torch.cat([ck["rng_step"].reshape(1), ck["optim_main"]["step"].reshape(1), ck["optim_vmi"]["step"].reshape(1),
                          torch.zeros(1, dtype=torch.int32)]).to(torch.int32)
         self.engine.load_optimizer_state({"main_m": ck["optim_main"]["m"], "main_v": ck["optim_main"]["v"],
                                           "crit_m": ck["optim_vmi"]["m"], "crit_v": ck["optim_vmi"]["v"], "counters": cnt,
                                           "lr_main": ck["optim_main"]["lr"], "lr_critic": ck["optim_vmi"]["lr"]})
+        self.resume_banks = ([], [], [], [], [])
+        b = ck.get("banks")
+        if b is not None:
+            self.engine.set_banks(*(b[k] for k in "CFTAV"))
+            self.resume_banks = tuple(self.engine.bank[k][:self.engine.bank_rows] for k in "CFTAV")
+        rs = ck.get("np_rng")
+        if rs is not None:
+            np.random.set_state((rs[0], rs[1].numpy().astype(np.uint32), rs[2], rs[3], rs[4]))
         return int(ck["epoch"])
 
     def save_results(self, best_predictions, best_targets, best_features, best_valid_state, best_test_state):

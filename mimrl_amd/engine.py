@@ -75,6 +75,11 @@ class HipEngine:
             self.params[name] = bucket["p"][off:off + n].view(*shape)
             self.grads[name] = bucket["g"][off:off + n].view(*shape)
         self.stream = torch.cuda.current_stream(self.device)
+        # Handles that share parameter buckets (``share``) each cache bf16 weight images of them: a version counter in the SHARED state
+        # says when another handle has stepped or loaded parameters since this one looked, and every compute call checks it (ADVICE r02:
+        # a caller alternating sibling handles would otherwise train the bf16 paths on stale weights with no error)
+        self._pver = share._pver if share is not None else {"v": 0}
+        self._seen = self._pver["v"]
         h = C.c_void_p()
         check(self.lib.mimrl_create(C.byref(self.cfg), C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.handle = h
@@ -121,6 +126,18 @@ class HipEngine:
     def params_changed(self):
         """Call after writing parameter tensors from outside the engine (the bf16 weight images are rebuilt lazily)."""
         check(self.lib.mimrl_params_changed(self.handle))
+        self._pver["v"] += 1                     # ... and the sibling handles' images are stale as well
+        self._seen = self._pver["v"]
+
+    def _coherent(self):
+        """Before any compute call: rebuild this handle's cached images if a sibling handle changed the shared parameters."""
+        if self._seen != self._pver["v"]:
+            check(self.lib.mimrl_params_changed(self.handle))
+            self._seen = self._pver["v"]
+
+    def _stepped(self):
+        self._pver["v"] += 1
+        self._seen = self._pver["v"]
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v.detach().clone() for k, v in self.params.items()}
@@ -189,10 +206,14 @@ class HipEngine:
 
     # ------------------------------------------------------------------ compute (all asynchronous)
     def stage1_step(self):
+        self._coherent()
         check(self.lib.mimrl_stage1_step(self.handle))
+        self._stepped()
 
     def stage2_step(self):
+        self._coherent()
         check(self.lib.mimrl_stage2_step(self.handle))
+        self._stepped()
 
     def set_stage2_prefetch(self, on):
         """Overlap mode of Solver.step(): the stage-2 forward pass runs beside stage 1 (see include/mimrl.h).
@@ -200,6 +221,7 @@ class HipEngine:
         check(self.lib.mimrl_set_stage2_prefetch(self.handle, int(on)))
 
     def stage2_forward_tail(self):
+        self._coherent()
         check(self.lib.mimrl_stage2_forward_tail(self.handle))
 
     def set_grad_scale(self, scale: float):
@@ -208,13 +230,18 @@ class HipEngine:
 
     def step(self):
         """One stage-1 (critics) + one stage-2 (model) update on the bound batch."""
+        self._coherent()
         check(self.lib.mimrl_two_stage_step(self.handle))
+        self._stepped()
 
     def stage_grads(self, stage: int):
+        self._coherent()
         check(self.lib.mimrl_stage_grads(self.handle, stage))
 
     def stage_apply(self, stage: int):
+        self._coherent()
         check(self.lib.mimrl_stage_apply(self.handle, stage))
+        self._stepped()
 
     def bucket_grad(self, stage: int) -> torch.Tensor:
         """Flat gradient bucket updated by ``stage`` (1: critics, 2: main model) -- the all-reduce payload."""
@@ -224,10 +251,12 @@ class HipEngine:
         return stage == 2 or self.bank_rows > 0          # epoch-0 rule: stage 1 does nothing without banks
 
     def forward(self, train: bool = False, with_losses: bool = False):
+        self._coherent()
         check(self.lib.mimrl_forward(self.handle, int(train), int(with_losses)))
 
     def estimate(self, stage: int):
         """Estimators only, on the features left by the last forward (Model.compute_vmi_loss_stage1/2)."""
+        self._coherent()
         check(self.lib.mimrl_estimate(self.handle, stage))
 
     # ------------------------------------------------------------------ test probes (include/mimrl.h: mimrl_probe_*)
