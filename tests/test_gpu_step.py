@@ -656,22 +656,19 @@ def test_bench_mode_trains_like_fp32():
     win = lambda r: r.reshape(5, 20, -1).mean(1)
     # (one fp32 pair is a noisy estimate of the floor: the bands are the fp32-vs-fp32 gaps seen over several boxes)
     band = np.array([0.25, 0.6, 0.3, 0.15, 0.15, 0.6, 2.5, 2.5, 2.5, 2.5])    # task, s1 loss, f_t f_a f_v inv | spec_t spec_a spec_v comp
-    # The trajectories are not reproducible run to run (float atomics in the split-K weight gradients order their additions by
-    # arrival), and a single (fp32, fp32, bf16) triple lands outside 3x its own floor + band about once in ten: criterion (a) must
-    # hold in EVERY attempt, criterion (b) in one of three independent attempts.
-    seen = []
-    for attempt in range(3):
-        a, b, c = mod.run("fp32", False, False), mod.run("fp32", True, True), mod.run("bf16", True, True)
-        assert np.isfinite(c).all()
-        wa, wb, wc = win(a), win(b), win(c)
-        for tag, w in (("fp32 eager", wa), ("fp32 graph+overlap", wb), ("bench mode", wc)):
-            assert w[-1, 0] < 0.5 * w[0, 0], f"{tag}: task MAE {w[0, 0]:.3f} -> {w[-1, 0]:.3f} did not halve in 100 steps"
-        floor = np.abs(wa - wb).max(0)
-        gap = np.minimum(np.abs(wc - wa), np.abs(wc - wb)).max(0)
-        if np.all(gap <= 3 * floor + band):
-            return
-        seen.append((np.round(gap, 3).tolist(), np.round(floor, 3).tolist()))
-    raise AssertionError("bench-vs-fp32 gaps outside 3x the fp32-vs-fp32 floor + band in three attempts (gap, floor): " + repr(seen))
+    # ONE attempt (round 3).  Through round 2 the gap criterion was accepted in one of three attempts: a single (fp32, fp32, bf16)
+    # triple landed outside 3x its own floor + band about once in ten.  With fp16 instead of bf16 forward operands on the model path
+    # (cube_fused.hip) the worst gap / (3 floor + band) over twelve independent attempts is 0.78 (tools/_t.py-style sweep, median
+    # 0.42), and the bench mode's final-window task MAE (0.14-0.29) is at or below fp32's (0.21-0.34).
+    a, b, c = mod.run("fp32", False, False), mod.run("fp32", True, True), mod.run("bf16", True, True)
+    assert np.isfinite(c).all()
+    wa, wb, wc = win(a), win(b), win(c)
+    for tag, w in (("fp32 eager", wa), ("fp32 graph+overlap", wb), ("bench mode", wc)):
+        assert w[-1, 0] < 0.5 * w[0, 0], f"{tag}: task MAE {w[0, 0]:.3f} -> {w[-1, 0]:.3f} did not halve in 100 steps"
+    floor = np.abs(wa - wb).max(0)
+    gap = np.minimum(np.abs(wc - wa), np.abs(wc - wb)).max(0)
+    assert np.all(gap <= 3 * floor + band), ("bench-vs-fp32 gaps outside 3x the fp32-vs-fp32 floor + band (gap, floor)",
+                                             np.round(gap, 3).tolist(), np.round(floor, 3).tolist())
 
 
 def test_bf16_stored_bptt_outputs_change_nothing(monkeypatch):
