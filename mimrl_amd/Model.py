@@ -74,8 +74,20 @@ class Model:
     __call__ = forward
 
     # ---- Model.compute_vmi_loss_stage1/2 (Model.py:305-386) ---------------------------------------
-    def _estimate(self, stage, labels, banks):
+    def _estimate(self, stage, labels, banks, predictions=None, feats=None):
         e = self.engine
+        # The engine estimates on ITS feature / prediction buffers (mimrl_buffers.feats / .pred).  Model.forward returns views of them,
+        # so the usual call passes them straight back; tensors that are NOT those views (a caller's own features) are copied in, so that
+        # the arguments mean what they mean in the reference (Model.py:305, 343) instead of being silently ignored
+        if feats is not None:
+            for i, f in enumerate(feats):
+                f = torch.as_tensor(f)
+                if not (f.is_cuda and f.data_ptr() == e.feats[i].data_ptr()):
+                    e.feats[i].copy_(f.reshape(e.feats[i].shape), non_blocking=True)
+        if predictions is not None:
+            pr = torch.as_tensor(predictions)
+            if not (pr.is_cuda and pr.data_ptr() == e.pred.data_ptr()):
+                e.pred.copy_(pr.reshape(-1), non_blocking=True)
         e.labels.copy_(torch.as_tensor(labels).reshape(-1), non_blocking=True)
         if banks is not None:
             e.set_banks(*banks)
@@ -84,12 +96,13 @@ class Model:
         e.estimate(stage)
 
     def compute_vmi_loss_stage1(self, predictions, labels, F_F, T_F, A_F, V_F, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
-        """Estimates on the features of the LAST forward (the tensors passed in are views of them).  -> (11 mis, 11 losses)"""
-        self._estimate(1, labels, (C_F_all, F_F_all, T_F_all, A_F_all, V_F_all))
+        """Model.py:305-341 on the given features (views of the last forward's buffers are used in place, other tensors are copied
+        into them).  -> (11 mis, 11 losses)"""
+        self._estimate(1, labels, (C_F_all, F_F_all, T_F_all, A_F_all, V_F_all), predictions, (F_F, T_F, A_F, V_F))
         s = self.engine.scalars
         return list(s[_lib.S1_MIS:_lib.S1_MIS + 11]), list(s[_lib.S1_LOSSES:_lib.S1_LOSSES + 11])
 
     def compute_vmi_loss_stage2(self, predictions, labels, F_F, T_F, A_F, V_F, C_F_all, F_F_all, T_F_all, A_F_all, V_F_all):
-        self._estimate(2, labels, (C_F_all, F_F_all, T_F_all, A_F_all, V_F_all))
+        self._estimate(2, labels, (C_F_all, F_F_all, T_F_all, A_F_all, V_F_all), predictions, (F_F, T_F, A_F, V_F))
         s = self.engine.scalars
         return list(s[_lib.S2_MIS:_lib.S2_MIS + 8]), list(s[_lib.S2_LOSSES:_lib.S2_LOSSES + 8])

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
+#include <dlfcn.h>
 
 #include "cube_fused.h"
 #include "mlp_fused.h"
@@ -137,6 +138,32 @@ __global__ void stage_boundary_kernel(float* scal, const float* mi, const float*
   __syncthreads();                       // the zeroing of scal[32..63] above is complete before the task loss lands in it
   if (threadIdx.x == 0) scal[MIMRL_S2_TASK] = s / B;
 }
+
+// roctx ranges (tracing): host-side ranges around the stages and their phases for `rocprofv3 --marker-trace`.  The library
+// is looked up at run time (libroctx64.so ships with ROCm): no link dependency, no cost when it is absent.  Inside a replayed hipGraph a
+// range brackets the graph launch; the phase ranges show up in the capture step and in eager (profile) steps.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    // rocprofv3 records the ranges of rocprofiler-sdk's roctx; roctracer's libroctx64 is what older tools see
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+    if (h) {
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (!push || !pop) push = nullptr;
+    }
+  }
+};
+inline Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~Range() { if (on) roctx().pop(); }
+};
 
 struct Lin { long w = -1, b = -1; int out = 0, in = 0; };
 struct GruDirW { long w_ih = 0, w_hh = 0, b_ih = 0, b_hh = 0; int din = 0; };
@@ -943,6 +970,7 @@ int mimrl_handle::conv_forward(int knn_stage) {
 // same batch and the same main parameters, so their prefixes are the same function of the same inputs: it is evaluated
 // once (into the primary set) and both tails read it.
 int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) {
+  Range rg(part == 1 ? "mimrl.model_forward.prefix (Model.py:395-458)" : part == 2 ? "mimrl.model_forward.tail (Model.py:461-515)" : "mimrl.model_forward (Model.py:388-519)");
   const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const long BT_ = (long)B * T;
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
@@ -1541,6 +1569,7 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
 // model backward (stage 2): needs dfeat (F,T,A,V contributions of the estimators) and dpred
 // =================================================================================================
 int mimrl_handle::model_backward() {
+  Range rg("mimrl.model_backward");
   const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const long BT_ = (long)B * T;
   const int nb = cfg.n_blocks;
@@ -2197,6 +2226,7 @@ int mimrl_handle::route_feature_grads() {
 
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
+  Range rg(stage == 1 ? "mimrl.estimators.stage1 (Model.py:305-341)" : "mimrl.estimators.stage2 (Model.py:343-386)");
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0 && !fp32_site(8), bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
   static const bool imgt_first = getenv("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
@@ -2260,6 +2290,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
 // stage drivers
 // =================================================================================================
 int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
+  Range rg(stage == 1 ? "mimrl.stage1.grads (Solver.py:205-210)" : "mimrl.stage2.grads (Solver.py:221-232)");
   const int B = cfg.batch;
   const bool have_banks = bank_rows > 0;
   if (!keep_events) ev_next = 0;
@@ -2422,6 +2453,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
 }
 
 int mimrl_handle::enqueue_apply(int stage) {
+  Range rg(stage == 1 ? "mimrl.stage1.clip+adam (Solver.py:211-213)" : "mimrl.stage2.clip+adam (Solver.py:233-235)");
   if (stage == 1 && bank_rows <= 0) return MIMRL_OK;
   AdamArgs a;
   if (stage == 1) {
@@ -2530,6 +2562,7 @@ int mimrl_handle::run_fwd2_tail() {
 // Solver.step(): stage 1 then stage 2 on the bound batch.  In overlap mode with graphs the two stages are ONE captured
 // graph (one launch, no idle device between the stage-1 Adam and the stage-2 estimators); otherwise two run() calls.
 int mimrl_handle::run_step() {
+  Range rg("mimrl.two_stage_step (Solver.step)");
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   static const bool no_step_graph = getenv("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
   const bool combined = cfg.use_graph && !prof_on && prefetch && !defer_tail && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;

@@ -172,6 +172,20 @@ def test_model_and_customization_surface(name):
     with torch.no_grad():
         _, mis_o, *_ = R.stage_loss(p, opt, 2, batch, banks, anchors[1])
     assert_close([float(m) for m in mis_a], [float(m) for m in mis_o], 1e-3, 5e-5, "8 stage-2 MI terms")
+    # the feature ARGUMENTS mean what they mean in the reference (Model.py:343): tensors that are not views of the engine's buffers
+    # (here: shuffled copies on the host) are what the estimators run on, not the last forward's features
+    perm = torch.randperm(c["B"], generator=torch.Generator().manual_seed(0))
+    feats_o = [f.detach().cpu()[perm].clone() for f in outputs[1:]]
+    pred_o, lab_o = outputs[0].detach().cpu()[perm].clone(), torch.as_tensor(labels).reshape(-1)[perm].clone()
+    seq = iter([anchors[1]])
+    synth.draw_anchors = lambda N, m, calls=6: next(seq)
+    try:
+        mis_b, _ = model.compute_vmi_loss_stage2(pred_o, lab_o, *feats_o, *bank_t)
+    finally:
+        synth.draw_anchors = real
+    with torch.no_grad():
+        mi_t, _ = R.stage2_terms(p, opt, lab_o, dict(zip("FTAV", feats_o)), banks, anchors[1])
+    assert_close([float(m) for m in mis_b], [float(m) for m in mi_t], 1e-3, 5e-5, "8 stage-2 MI terms on caller-owned features")
     model.engine.close()
 
 
