@@ -1,5 +1,6 @@
 // Non-GEMM kernels of the model forward/backward (see model_ops.h for the reference citations).
 #include "model_ops.h"
+#include <algorithm>
 
 #include <cstring>
 
@@ -136,6 +137,81 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
   for (int i = 0; i < PER; ++i) { atomicAdd(&sg[lane + 64 * i], ag[i]); atomicAdd(&sb[lane + 64 * i], ab[i]); }
   __syncthreads();
   for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(&dgamma[i], sg[i]); atomicAdd(&dbeta[i], sb[i]); }
+}
+
+// Round 3: the same backward with 16 lanes per row (D = 128: two float4 per lane and operand), FOUR rows per wave and pass, grid sized
+// by the rows.  The one-row-per-wave kernel above walks its rows as a dependent chain (4-byte loads -> two wave reductions -> stores,
+// ~2.9 us per row) on at most 1024 waves: 28 us at cfg2 (6 rows per wave) and 360 us at cfg3 (125 rows per wave, 1.4 TB/s), on the
+// critical chain in front of the BPTT.  Element indices of the dropout hash are unchanged.
+__global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSide s1, const float* __restrict__ dcube, long rows, int T, int L,
+                                                                  int K, RngKey key) {
+  constexpr int D = 128;
+  const LnSide& sd = blockIdx.y ? s1 : s0;
+  const float* __restrict__ h2 = sd.h2; const float* __restrict__ gamma = sd.gamma; const float* __restrict__ beta = sd.beta;
+  const float* __restrict__ mean = sd.mean; const float* __restrict__ rstd = sd.rstd;
+  float* __restrict__ ds = sd.ds;
+  const int slot = sd.slot; const float p = sd.p; const uint32_t stream = sd.stream;
+  const float* __restrict__ dmean = sd.dmean;
+  const float invT = 1.f / T;
+  __shared__ float sg[D], sb[D];
+  const int tid = threadIdx.x, sub = tid & 15, rw = tid >> 4;          // 16 row slots per workgroup
+  if (tid < D) { sg[tid] = 0.f; sb[tid] = 0.f; }
+  __syncthreads();
+  const int c0 = 4 * sub, c1 = 64 + 4 * sub;                            // this lane's two column quads
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c1);
+  const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c1);
+  float ag[8], ab[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  const long stride = (long)gridDim.x * 16;
+  for (long r = (long)blockIdx.x * 16 + rw; r < rows; r += stride) {   // (the 16 lanes of a row slot share r: the group reductions are whole)
+    const float* hr = h2 + r * 2 * D;
+    const long b = r / T, t = r - b * T;
+    const float* dc = dcube + ((b * L + t) * K + slot) * D;
+    const float4 hf0 = *reinterpret_cast<const float4*>(hr + c0), hf1 = *reinterpret_cast<const float4*>(hr + c1);
+    const float4 hb0 = *reinterpret_cast<const float4*>(hr + D + c0), hb1 = *reinterpret_cast<const float4*>(hr + D + c1);
+    const float4 d0 = *reinterpret_cast<const float4*>(dc + c0), d1 = *reinterpret_cast<const float4*>(dc + c1);
+    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+    if (dmean) { m0 = *reinterpret_cast<const float4*>(dmean + b * D + c0); m1 = *reinterpret_cast<const float4*>(dmean + b * D + c1); }
+    const float mu = mean[r], rs = rstd[r];
+    const float hv[8] = {hf0.x + hb0.x, hf0.y + hb0.y, hf0.z + hb0.z, hf0.w + hb0.w, hf1.x + hb1.x, hf1.y + hb1.y, hf1.z + hb1.z, hf1.w + hb1.w};
+    const float dv[8] = {d0.x + m0.x * invT, d0.y + m0.y * invT, d0.z + m0.z * invT, d0.w + m0.w * invT,
+                         d1.x + m1.x * invT, d1.y + m1.y * invT, d1.z + m1.z * invT, d1.w + m1.w * invT};
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = (i < 4 ? c0 : c1 - 4) + i;
+      xh[i] = (hv[i] - mu) * rs;
+      const float y = xh[i] * gv[i] + bv[i];
+      float dy = dv[i] * drop_scale(p, key, stream, (uint32_t)(r * D + j));
+      dy = y > 0.f ? dy : 0.f;
+      ag[i] += dy * xh[i];
+      ab[i] += dy;
+      dxh[i] = dy * gv[i];
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
+    }
+    s1 = group_sum<16>(s1) * (1.f / D);
+    s2 = group_sum<16>(s2) * (1.f / D);
+    {
+      float4 o0, o1;
+      o0.x = rs * (dxh[0] - s1 - xh[0] * s2); o0.y = rs * (dxh[1] - s1 - xh[1] * s2); o0.z = rs * (dxh[2] - s1 - xh[2] * s2); o0.w = rs * (dxh[3] - s1 - xh[3] * s2);
+      o1.x = rs * (dxh[4] - s1 - xh[4] * s2); o1.y = rs * (dxh[5] - s1 - xh[5] * s2); o1.z = rs * (dxh[6] - s1 - xh[6] * s2); o1.w = rs * (dxh[7] - s1 - xh[7] * s2);
+      *reinterpret_cast<float4*>(ds + r * D + c0) = o0;
+      *reinterpret_cast<float4*>(ds + r * D + c1) = o1;
+    }
+  }
+  // parameter gradients: the four row slots of a wave share columns (lanes that differ in bits 4, 5), then LDS, then one atomic per column
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float a = ag[i], bq = ab[i];
+    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+    bq += __shfl_xor(bq, 16, 64); bq += __shfl_xor(bq, 32, 64);
+    if ((tid & 63) < 16) { const int j = (i < 4 ? c0 : c1 - 4) + i; atomicAdd(&sg[j], a); atomicAdd(&sb[j], bq); }
+  }
+  __syncthreads();
+  if (tid < D) { atomicAdd(&sd.dgamma[tid], sg[tid]); atomicAdd(&sd.dbeta[tid], sb[tid]); }
 }
 
 // ------------------------------------------------------------------ the three pre-CubeMLP pieces of one forward tail in ONE launch
@@ -732,8 +808,7 @@ int ln_relu_drop_bwd(hipStream_t s, const float* h2, const float* gamma, const f
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
   const LnSide a{h2, gamma, beta, const_cast<float*>(mean), const_cast<float*>(rstd), ds, dgamma, dbeta, slot, p, stream_id, nullptr};
-  hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256)), dim3(256), 0, s, a, a, dcube, rows, T, L,
-                     K, key);
+  hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 1024)), dim3(256), 0, s, a, a, dcube, rows, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -754,8 +829,9 @@ int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const f
   const long rows = (long)B * T;
   const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, dmean_a};
   const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v};
-  hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T,
-                     L, K, key);
+  static const bool old_kernel = getenv("MIMRL_LN_BWD_WAVE_ROWS") != nullptr;   // tuning knob: the one-row-per-wave kernel of round 2
+  if (old_kernel) hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
+  else hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 1024), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
