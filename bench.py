@@ -364,7 +364,12 @@ def main():
 
     log("engine ready; warm-up")
     prewarm = 0
-    if args.prewarm_ms > 0:            # steady-state clocks / caches / captured graphs before the counted warm-up (see --prewarm-ms)
+    if args.prewarm_ms > 0 and world > 1:
+        prewarm = 200                  # a FIXED count under data parallelism: every rank must issue the same collectives
+        for _ in range(prewarm):
+            step()
+        torch.cuda.synchronize()
+    elif args.prewarm_ms > 0:          # steady-state clocks / caches / captured graphs before the counted warm-up (see --prewarm-ms)
         t_pw = time.perf_counter()
         while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
             for _ in range(10):
