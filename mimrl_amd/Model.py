@@ -13,6 +13,12 @@ from . import _lib, synth
 from .engine import HipEngine
 
 
+def _rebuild_model(opt, d_t, d_a, d_v, kw, state, training):
+    m = Model(opt, d_t, d_a, d_v, **kw)
+    m.load_state_dict(state)
+    return m.train(training)
+
+
 class Model:
     def __init__(self, opt, d_t: int, d_a: int, d_v: int, bank_capacity: int = 0, precision: str = None,
                  use_graph: bool = None, device_anchors: bool = None, seq_len: int = None, init: str = "default", rank: int = 0):
@@ -42,6 +48,27 @@ class Model:
 
     def cuda(self, *a, **k):
         return self
+
+    def to(self, *a, **k):
+        """nn.Module.to: the engine lives on the GPU it was created on; dtype / device moves do not apply (fails loudly on a CPU target)."""
+        tgt = [x for x in list(a) + list(k.values()) if isinstance(x, (str, torch.device))]
+        if any(torch.device(t).type == "cpu" for t in tgt):
+            raise _lib.MimrlError("Model.to('cpu'): this model has no CPU path (oracle/ is test infrastructure)")
+        return self
+
+    def zero_grad(self, set_to_none: bool = False):
+        """The fused clip+Adam leaves both gradient buckets zeroed; this is for callers that run stage_grads without stage_apply."""
+        self.engine.main["g"].zero_()
+        self.engine.crit["g"].zero_()
+
+    def __reduce__(self):
+        """torch.save(model) / pickle: the engine handle cannot travel; what is saved is how to rebuild it + the parameters
+        (optimizer state is the checkpoint's business: Solver.checkpoint)."""
+        c = self.engine.cfg
+        kw = dict(bank_capacity=int(c.bank_capacity), precision=self.engine.precision, use_graph=bool(c.use_graph),
+                  device_anchors=bool(c.device_anchors), seq_len=int(c.seq_len))
+        return (_rebuild_model, (self.opt, self.d_t, self.d_a, self.d_v, kw, {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                                 self.training))
 
     @property
     def module(self):          # the reference reaches through nn.DataParallel (Customization.py:99,107)

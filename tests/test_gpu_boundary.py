@@ -186,6 +186,23 @@ def test_model_and_customization_surface(name):
     with torch.no_grad():
         mi_t, _ = R.stage2_terms(p, opt, lab_o, dict(zip("FTAV", feats_o)), banks, anchors[1])
     assert_close([float(m) for m in mis_b], [float(m) for m in mi_t], 1e-3, 5e-5, "8 stage-2 MI terms on caller-owned features")
+    # nn.Module habits of the reference's callers: .to(device), torch.save(model) / torch.load
+    import io
+    assert model.to("cuda") is model and model.to(torch.device("cuda", 0)) is model
+    with pytest.raises(_lib.MimrlError):
+        model.to("cpu")
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), m2.state_dict()[k].cpu()), k
+    m2.eval()
+    out2 = m2(batch[0], None, None, batch[1], batch[2], return_features=True)
+    model.eval()
+    out1 = model(batch[0], None, None, batch[1], batch[2], return_features=True)
+    assert_close(out2[0].cpu().numpy(), out1[0].cpu().numpy(), 1e-6, 1e-7, "reloaded model's prediction")
+    m2.engine.close()
     model.engine.close()
 
 
