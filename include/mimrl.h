@@ -241,6 +241,12 @@ int mimrl_probe_cube(mimrl_handle* h, const float* x, float* out, const float* d
  * gradient in crit_g (zeroed first), objective sum_e -coef1[e] mi_e; stage 2: dtin_out [5][2][B][128] = gradient of
  * sum_e g2[e] mi_e (g2 = -coef2[0], -coef2[1], -coef2[2], -coef2[3], -coef2[3], Model.py:364-386) w.r.t. the (x, y) operand of each estimator. */
 int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* dtin_out);
+/* The six CMI classifiers of `stage` (MLP_For_CMI, Model.py:47-72; BCE and the NWJ-style CMI value, Model.py:185-219) on a CALLER-assembled
+ * batch cmi_in [6][2n][384] (n = (B / k) * k rows [x|y|z] of the joint, then n rows of the kNN product sample): logits [6][2n][2] (before the
+ * +-10 clamp), vals [2][6] = BCE, CMI; stage 1: every vcmi_estimator_* gradient in crit_g (zeroed first), objective sum_e coef1[5+e] BCE_e;
+ * stage 2: dcin_out [6][2n][384] (rows [0,n): the joint rows; the product rows come from the detached banks) = gradient of
+ * sum_e g2[e] CMI_e, g2 = (-c5, c4+c5-c7, -c6, c4+c6-c7, -c4, -c4) with c = coef2 (Model.py:381-386). */
+int mimrl_probe_cmi(mimrl_handle* h, int stage, const float* cmi_in, float* logits, float* vals, float* dcin_out);
 int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,
                   float beta1, float beta2, float eps, float weight_decay, float clip);
 

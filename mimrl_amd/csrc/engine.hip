@@ -2843,6 +2843,42 @@ int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* 
   return MIMRL_OK;
 }
 
+int mimrl_probe_cmi(mimrl_handle* h, int stage, const float* cmi_in_, float* logits_out, float* vals, float* dcin_out) {
+  if (!h || !cmi_in_ || !logits_out || !vals) return set_error(MIMRL_ERR_ARG, "null argument");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
+  const int n = h->nprod();
+  const bool bf_fwd = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0, bf_bwd = (h->prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  h->ev_next = 0;
+  MX(h->ensure_images());
+  h->imgT_ready = false;
+  if (bf_bwd && h->fused_mlp && h->crit_imgT && h->ttab.n > 0) {
+    MX(bf16_transposed_images(h->stream, h->bufs.crit_p, h->crit_imgT, h->ttab));
+    h->imgT_ready = true;
+  }
+  if (stage == 1) HIPX(hipMemsetAsync(h->bufs.crit_g, 0, sizeof(float) * h->layout.floats[MIMRL_GROUP_CRITIC], h->stream));
+  HIPX(hipMemcpyAsync(h->cmi_in, cmi_in_, sizeof(float) * NE_CMI * 2 * n * 384, hipMemcpyDeviceToDevice, h->stream));
+  // cmi_forward minus the kNN / assemble part (Model.py:185-219 on a caller-assembled batch) ...
+  h->bf16 = bf_fwd;
+  const int cdims[5] = {3 * EMB, HID, HID, HID, 2};
+  int r = h->mlp_stack_forward(NE_CMI, 2 * n, 2 * n, h->cmi0, h->cmi_stride, 4, h->cmi_l, cdims, h->cmi_in, h->cc, h->logits);
+  if (r == 0) r = cmi_loss_fwd_bwd(h->stream, h->logits, h->dlogits, h->bce_raw, h->cmi_raw, h->g_bce(stage), h->g_cmi(stage), NE_CMI, n, h->cfg.cmi_hardtanh);
+  // ... and cmi_backward as a step runs it
+  if (r == 0) { h->bf16 = bf_bwd; h->wg_helper = -1; r = h->cmi_backward(stage); }
+  h->bf16 = bf_fwd;
+  MX(r);
+  MX(h->join(0, 5));
+  HIPX(hipMemcpyAsync(logits_out, h->logits, sizeof(float) * NE_CMI * 2 * n * 2, hipMemcpyDeviceToDevice, h->stream));
+  HIPX(hipMemcpyAsync(vals, h->bce_raw, sizeof(float) * NE_CMI, hipMemcpyDeviceToDevice, h->stream));
+  HIPX(hipMemcpyAsync(vals + NE_CMI, h->cmi_raw, sizeof(float) * NE_CMI, hipMemcpyDeviceToDevice, h->stream));
+  if (dcin_out) {
+    if (stage != 2) return set_error(MIMRL_ERR_ARG, "probe: classifier-input gradients exist in stage 2 only");
+    HIPX(hipMemcpyAsync(dcin_out, h->dcin, sizeof(float) * NE_CMI * 2 * n * 384, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (stage == 1) h->grads_clean[1] = false;
+  return MIMRL_OK;
+}
+
 int mimrl_set_kernel_stamps(mimrl_handle* h, unsigned long long* ring, int slots) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (ring && (slots < 1 || (slots & (slots - 1)))) return set_error(MIMRL_ERR_ARG, "stamp ring: slots must be a power of two");

@@ -287,6 +287,18 @@ class HipEngine:
         check(self.lib.mimrl_probe_mi(self.handle, stage, _ptr(mi), _ptr(scores), _ptr(dtin)))
         return {"mi": mi[0], "mi_loss": mi[1], "scores": scores, "dtin": dtin}
 
+    def probe_cmi(self, stage: int, cmi_in):
+        """The six CMI classifiers of ``stage`` forward + loss + backward on a caller-assembled batch [6, 2n, 384] through the engine's
+        own kernels.  -> dict(logits [6,2n,2], bce [6], cmi [6], dcin [6,2n,384] (stage 2) or None); stage 1 leaves the
+        ``vcmi_estimator_*`` gradients in ``self.grads``."""
+        n = self.m_anchor * self.cfg.k_neighbor
+        x = torch.as_tensor(cmi_in, dtype=torch.float32, device=self.device).contiguous().reshape(6, 2 * n, 384)
+        logits = torch.empty(6, 2 * n, 2, dtype=torch.float32, device=self.device)
+        vals = torch.empty(2, 6, dtype=torch.float32, device=self.device)
+        dcin = torch.empty(6, 2 * n, 384, dtype=torch.float32, device=self.device) if stage == 2 else None
+        check(self.lib.mimrl_probe_cmi(self.handle, stage, _ptr(x), _ptr(logits), _ptr(vals), _ptr(dcin)))
+        return {"logits": logits, "bce": vals[0], "cmi": vals[1], "dcin": dcin}
+
     STAMP_IDS = ("gru_fwd_l0", "gru_fwd_l1", "gru_bwd_l1", "gru_bwd_l0")
 
     def kernel_stamps(self, slots: int = 1 << 14):

@@ -167,6 +167,33 @@ def critic_scores_q(p, name, critic_type, x, y, rnd):
     return s.squeeze(-1)
 
 
+def cmi_logits_q(p, name, batch, rnd):
+    """MLP_For_CMI's tower (Model.py:47-72: 384-256-256-256-2, ReLU) before the +-10 clamp, with the kernels' operand rounding."""
+    pre = f"vcmi_estimator_{name}.classifier.mlp"
+    h = batch
+    for j, i in enumerate((0, 2, 4, 6)):
+        h = mm(h, p[f"{pre}.{i}.weight"], rnd) + p[f"{pre}.{i}.bias"]
+        if j < 3:
+            h = F.relu(h)
+    return h
+
+
+def cmi_terms_q(p, name, batch, rnd, last_act="sigmoid"):
+    """-> (logits, bce, cmi) of one VCMIEstimator on an assembled batch [2n, 384] (joint rows first; Model.py:185-219)."""
+    n = batch.shape[0] // 2
+    logits = cmi_logits_q(p, name, batch, rnd)
+    h = torch.clamp(logits, -10, 10)
+    out = torch.sigmoid(h) if last_act == "sigmoid" else F.hardtanh(h, 1e-4, 1 - 1e-4)
+    target = torch.zeros(2 * n, 2, dtype=batch.dtype)
+    target[:n, 0] = 1.0
+    target[n:, 1] = 1.0
+    bce = F.binary_cross_entropy(out, target)
+    gamma = out[:, 0]
+    lr = torch.log(gamma / (1 - gamma + 1e-6))
+    cmi = 1.0 + lr[:n].sum() / (2 * n) - lr[n:].sum() / (2 * n)
+    return logits, bce, cmi
+
+
 MI_WIRE = {"f_t": (0, 1), "f_a": (0, 2), "f_v": (0, 3), "t_a": (1, 2), "t_v": (1, 3)}     # Model.py:313-319 (F,T,A,V slots)
 
 

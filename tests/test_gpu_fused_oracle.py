@@ -225,3 +225,66 @@ def test_mi_estimators_vs_rounded_oracle(name, stage, monkeypatch):
     gs = max(e["scale"] for e in gt.values())
     bad = {n: e for n, e in gt.items() if not tensor_ok(e, TOL, gs, e["chaos"])}
     assert not bad, (key, {n: (e["max_rel_scale"], e["l2_rel"], e["chaos"]) for n, e in bad.items()})
+
+
+@pytest.mark.parametrize("name,stage", [("cfg2_sep", 1), ("cfg2_sep", 2), ("cfg1_sep", 1), ("tiny_odd", 1), ("tiny_odd", 2)],
+                         ids=lambda v: str(v))
+def test_cmi_classifiers_vs_rounded_oracle(name, stage):
+    """The six CMI classifiers (MLP_For_CMI, Model.py:47-72; BCE / CMI value, Model.py:185-219): mlp_img8_kernel<fwd, 6 chunks> with its
+    384-wide first layer, cmi_loss_kernel, mlp_img8_kernel<bwd> with the narrow 2-logit top layer (its weight gradient is produced
+    inside the data-gradient kernel) and the grouped weight-gradient GEMMs -- logits, both values, stage 1: every vcmi_estimator_*
+    gradient, stage 2: the gradient w.r.t. the joint rows.  tiny_odd: 2n = 24 rows per classifier (ragged 32-row tiles), k = 3."""
+    c, opt, batch, banks = case(name)
+    eng = HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision="bf16")
+    p = perturbed_params(opt, c["seed"])
+    eng.load_params(p)
+    n = (c["B"] // opt.k_neighbor) * opt.k_neighbor
+    g = torch.Generator().manual_seed(9)
+    cin = 0.4 * torch.randn(6, 2 * n, 384, generator=g, dtype=torch.float64)
+    cin[:, :, 128:256] = cin[:, :, 128:256].abs()          # feature operands of the real batches include non-negative ones (A_F, V_F)
+    r = eng.probe_cmi(stage, cin)
+    torch.cuda.synchronize()
+    names = [k for k in p if k.startswith("vcmi_estimator_")]
+    k1, k2 = opt.loss_mi_coefficient1, opt.loss_mi_coefficient2
+    g2 = [-k2[5], k2[4] + k2[5] - k2[7], -k2[6], k2[4] + k2[6] - k2[7], -k2[4], -k2[4]]
+
+    def reference(jitter=0.0):
+        leaves = {k: (p[k] + jitter * torch.randn(p[k].shape, generator=g, dtype=torch.float64) if k.endswith(".bias") else p[k].clone()).requires_grad_(True)
+                  for k in names}
+        xs, lg, bces, cmis = [], [], [], []
+        for e, nm in enumerate(R.VCMI_NAMES):
+            xe = cin[e].clone().requires_grad_(True)
+            xs.append(xe)
+            l_, b_, c_ = Q.cmi_terms_q({**p, **leaves}, nm, xe, Q.BF16, opt.cmi_last_acticate)
+            lg.append(l_.detach()); bces.append(b_); cmis.append(c_)
+        if stage == 1:
+            obj = sum(k1[5 + e] * bces[e] for e in range(6))
+            gr_ = torch.autograd.grad(obj, [leaves[k] for k in names], allow_unused=True)
+            gr_ = [torch.zeros_like(leaves[k]) if gw is None else gw for k, gw in zip(names, gr_)]
+        else:
+            obj = sum(g2[e] * cmis[e] for e in range(6))
+            gr_ = [t[:n] for t in torch.autograd.grad(obj, xs)]
+        return torch.stack(lg), [float(b) for b in bces], [float(c_) for c_ in cmis], gr_
+
+    lg, bces, cmis, gr = reference()
+    _, _, _, gr2 = reference(JITTER)
+    chaos = chaos_floor(gr, gr2)
+    key = f"cmi/{name}/stage{stage}"
+    rec = {"logits": errs(r["logits"].cpu(), lg), "bce": [float(x) for x in r["bce"].cpu()], "cmi": [float(x) for x in r["cmi"].cpu()]}
+    if stage == 1:
+        got, labels = [eng.grads[k].cpu() for k in names], names
+    else:
+        got, labels = [r["dcin"][e, :n].cpu() for e in range(6)], [f"dcin[{nm}]" for nm in R.VCMI_NAMES]
+    for lab, gg, gw, ch in zip(labels, got, gr, chaos):
+        e_ = errs(gg, gw)
+        e_["chaos"] = ch
+        rec[lab] = e_
+    _record(key, rec)
+    eng.close()
+    assert rec["logits"]["max_rel_scale"] <= 3e-3, (key, rec["logits"])
+    np.testing.assert_allclose(rec["bce"], bces, rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(rec["cmi"], cmis, rtol=2e-3, atol=2e-4)
+    gt = {k: v for k, v in rec.items() if isinstance(v, dict) and k != "logits"}
+    gs = max(v["scale"] for v in gt.values())
+    bad = {k: v for k, v in gt.items() if not tensor_ok(v, TOL, gs, v["chaos"])}
+    assert not bad, (key, {k: (v["max_rel_scale"], v["l2_rel"], v["chaos"]) for k, v in bad.items()})

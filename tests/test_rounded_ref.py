@@ -40,6 +40,20 @@ def test_identity_hook_is_the_oracle_critics():
             assert abs(float(m) - float(mi)) < 1e-12
 
 
+def test_identity_hook_is_the_oracle_cmi():
+    c, opt, batch, banks = case("tiny_sep")
+    p = _p64(opt, c["seed"])
+    g = torch.Generator().manual_seed(4)
+    n = 8
+    x, y, z = (torch.randn(n, 128, dtype=torch.float64, generator=g) for _ in range(3))
+    kx, ky, kz = (torch.randn(n, 128, dtype=torch.float64, generator=g) for _ in range(3))
+    for name in R.VCMI_NAMES:
+        cmi_o, bce_o = R.vcmi_estimate(p, name, opt, x, y, z, kx, ky, kz)
+        batch_ = torch.cat([torch.cat([x, y, z], 1), torch.cat([kx, ky, kz], 1)], 0)
+        _, bce, cmi = Q.cmi_terms_q(p, name, batch_, Q.EXACT)
+        assert abs(float(cmi) - float(cmi_o)) < 1e-12 and abs(float(bce) - float(bce_o)) < 1e-12, name
+
+
 def test_identity_rounding_has_the_oracles_gradients():
     """the custom backward of rounded_ref.mm (dx = g w, dw = g^T x) is autograd's when nothing is rounded"""
     c, opt, batch, banks = case("tiny_sep")
