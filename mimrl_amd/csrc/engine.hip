@@ -200,6 +200,10 @@ struct mimrl_handle {
   // bf16 images of the critic bucket for the fused estimator stacks: straight (kept fresh by the critic Adam launch, rebuilt
   // after mimrl_bind / mimrl_params_changed) and per-matrix transposed (rebuilt beside every estimator forward pass)
   __bf16 *crit_img = nullptr, *crit_imgT = nullptr;
+  // MFMA-fragment-order images of the stacks mlp_frag_kernel takes (mlp_fused.h): forward product and data-gradient product, ONE launch
+  // for both; valid exactly when crit_img is (rebuilt by ensure_images and behind every critic Adam launch)
+  __bf16 *crit_frag = nullptr, *crit_fragT = nullptr;
+  FragTable ftab;
   bool img_valid = false;
   unsigned knn_ovr_mask[2] = {0u, 0u};  // per stage: CMI calls whose neighbour rows come from bufs.knn_override
   bool knn_pre = true;                 // prefetch mode: stage 2's kNN sampling also runs inside stage 1, beside the encoder prefix (MIMRL_NO_KNN_PREFETCH=1: off)
@@ -209,6 +213,7 @@ struct mimrl_handle {
   int ensure_images() {
     if (img_valid || !crit_img) return MIMRL_OK;
     MX(bf16_image(user_stream, bufs.crit_p, crit_img, layout.floats[MIMRL_GROUP_CRITIC]));
+    if (crit_frag && ftab.n > 0) MX(bf16_frag_images(user_stream, bufs.crit_p, crit_frag, ftab));
     img_valid = true;
     return MIMRL_OK;
   }
@@ -636,9 +641,25 @@ int mimrl_handle::resolve() {
     }
     const int c[5] = {3 * EMB, HID, HID, HID, 2};
     for (int l = 0; l < 4; ++l) add(cmi0 + cmi_l[l][0], c[l + 1], c[l], NE_CMI, cmi_stride);
+    // fragment-order images for the 4-layer stacks (separable towers, CMI classifiers, trainable baseline): a forward entry where
+    // [N, K] is [32k x 64k], a data-gradient entry where [K, N] is
+    std::memset(&ftab, 0, sizeof ftab);
+    auto addf = [&](long o, int N, int K, int nb, long gs) {
+      if (N % 32 == 0 && K % 64 == 0) { const int e = ftab.n++; ftab.off[e] = o; ftab.OUT[e] = N; ftab.RED[e] = K; ftab.nb[e] = nb; ftab.tr[e] = 0; ftab.gstride[e] = gs; }
+      if (K % 32 == 0 && N % 64 == 0) {   // the data-gradient image lives one bucket length behind the forward one (crit_fragT)
+        const int e = ftab.n++; ftab.off[e] = o; ftab.OUT[e] = K; ftab.RED[e] = N; ftab.nb[e] = nb; ftab.tr[e] = 1; ftab.gstride[e] = gs;
+        ftab.dshift[e] = layout.floats[MIMRL_GROUP_CRITIC];
+      }
+    };
+    if (cfg.critic_type == MIMRL_CRITIC_SEPARATE) {
+      const int d[5] = {EMB, HID, HID, HID, EMB};
+      for (int l = 0; l < 4; ++l) addf(tower0 + tower_l[l][0], d[l + 1], d[l], 10, tower_stride);
+    }
+    for (int l = 0; l < 3; ++l) addf(cmi0 + cmi_l[l][0], c[l + 1], c[l], NE_CMI, cmi_stride);
     if (cfg.baseline_type == MIMRL_BASELINE_UNNORMALIZED) {
       const int d[5] = {EMB, HID, HID, HID, 1};
       for (int l = 0; l < 4; ++l) add(bl0 + bl_l[l][0], d[l + 1], d[l], NE_MI, bl_stride);
+      for (int l = 0; l < 3; ++l) addf(bl0 + bl_l[l][0], d[l + 1], d[l], NE_MI, bl_stride);
     }
   }
   return MIMRL_OK;
@@ -714,6 +735,9 @@ int mimrl_handle::carve() {
     float *t1 = nullptr, *t2 = nullptr;
     MX(take(&t1, layout.floats[MIMRL_GROUP_CRITIC] / 2 + 64)); MX(take(&t2, layout.floats[MIMRL_GROUP_CRITIC] / 2 + 64));
     crit_img = reinterpret_cast<__bf16*>(t1); crit_imgT = reinterpret_cast<__bf16*>(t2);
+    float* t3 = nullptr;   // both fragment-order images, back to back (one table, one launch: T entries carry the distance as dshift)
+    MX(take(&t3, layout.floats[MIMRL_GROUP_CRITIC] + 64));
+    crit_frag = reinterpret_cast<__bf16*>(t3); crit_fragT = crit_frag + layout.floats[MIMRL_GROUP_CRITIC];
   }
   MX(take(&ff, B * D));
   MX(take(&dpred, B));
@@ -1786,6 +1810,7 @@ int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long p
       fa.W[l] = CP(p0 + l_off[l][0]); fa.b[l] = CP(p0 + l_off[l][1]);
       if (l < nl - 1) fa.act[l] = act[l];
       if (img_valid && crit_img) fa.Wb[l] = crit_img + p0 + l_off[l][0];
+      if (img_valid && crit_frag && ftab.n > 0) fa.Wf[l] = crit_frag + p0 + l_off[l][0];
     }
     return mlp_stack_fwd_fused(stream, fa);
   }
@@ -1829,6 +1854,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     for (int l = 0; l < nl; ++l) {
       fa.W[l] = CP(p0 + l_off[l][0]);
       fa.WbT[l] = crit_imgT + p0 + l_off[l][0];
+      if (img_valid && crit_fragT && ftab.n > 0) { fa.WfT[l] = crit_fragT + p0 + l_off[l][0]; fa.Wb[l] = crit_img + p0 + l_off[l][0]; }
       if (l < nl - 1) { fa.act[l] = act[l]; fa.dz[l + 1] = dtmp[l]; if (wgrad) fa.db[l] = CG(p0 + l_off[l][1]); }
     }
     if (wgrad) fa.db_top = CG(p0 + l_off[nl - 1][1]);   // the top layer's bias gradient rides along (was a separate column-sum launch)
@@ -2468,6 +2494,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   a.gscale = grad_scale;
   Scope sc(this, MIMRL_PH_OPT);
   MX(adam_step(stream, a));
+  if (stage == 1 && img_valid && crit_frag && ftab.n > 0) MX(bf16_frag_images(stream, bufs.crit_p, crit_frag, ftab));
   return dbg_delay(stream, 12);
 }
 

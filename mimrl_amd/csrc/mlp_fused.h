@@ -22,6 +22,11 @@ struct MlpFusedArgs {
   // to [dims[l], dims[l+1]] (data-gradient chain).  With images the kernels never touch the fp32 weights.
   const __bf16* Wb[MLPF_MAX_LAYERS];
   const __bf16* WbT[MLPF_MAX_LAYERS];
+  // optional FRAGMENT-ORDER images (bf16_frag_images below) at the same offsets: Wf[l] of the forward product, WfT[l] of the
+  // data-gradient product; only layers whose matrix is [32k x 64k] in that product have one (narrow top layers use Wb).  With them,
+  // a 4-layer stack of hidden width 256 takes mlp_frag_kernel (weights go global -> VGPR -> MFMA, no LDS staging)
+  const __bf16* Wf[MLPF_MAX_LAYERS];
+  const __bf16* WfT[MLPF_MAX_LAYERS];
   const float* in;                // [nb, brows, dims[0]]
   float* act[MLPF_MAX_LAYERS];    // post-ReLU outputs of layers 0..nl-2: [nb, brows, dims[l+1]]  (kept for the backward pass)
   float* out;                     // [nb, brows, dims[nl]]  (linear)
@@ -50,5 +55,10 @@ bool mlp_bwd_takes_top_wgrad(const MlpFusedArgs& a);
 int bf16_image(hipStream_t s, const float* src, __bf16* dst, long n);
 struct TransposeTable { long off[12]; int N[12], K[12], nb[12]; long gstride[12]; int n; };
 int bf16_transposed_images(hipStream_t s, const float* src, __bf16* dstT, const TransposeTable& t);
+// MFMA-fragment-order images (layout: frag_images_kernel in mlp_fused.hip).  Entry e: nb groups (pitch gstride floats) of a matrix at
+// float offset off with OUT output columns (multiple of 32) and reduction length RED (multiple of 64); tr = 0: element (c, r) =
+// src[c * RED + r] (forward weight), tr = 1: src[r * OUT + c] (the same matrix in the data-gradient product).  blk0 is filled in.
+struct FragTable { long off[24]; int OUT[24], RED[24], nb[24], tr[24]; long gstride[24], dshift[24]; int blk0[25]; int n; };   // dshift: added to the destination index (two images, one launch)
+int bf16_frag_images(hipStream_t s, const float* src, __bf16* dst, const FragTable& t);
 
 }  // namespace mimrl

@@ -370,6 +370,14 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// tools/hw/mlp_phase.hip compiles this file with MLP_PHASE_PROBE: workgroup 0 leaves wall_clock64 ticks (100 MHz) at the points below
+#ifdef MLP_PHASE_PROBE
+__device__ long long g_mlp_phase[64];
+#define PHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mlp_phase[i] = (long long)wall_clock64(); } while (0)
+#else
+#define PHASE(i) do { } while (0)
+#endif
+
 template <bool BWD, int NCH>   // NCH: 64-k chunks held in registers (4: every reduction width <= 256; 6: <= 384)
 __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
     });
   };
   // first layer's weights: in flight under the activation tile load
+  PHASE(0);
   fetch_layer(layer_of(0), wave);
 
   load_tile_bf16<512>(BWD ? a.dout : a.in, rowbase, r0, a.rows, BWD ? a.dims[a.nl] : a.dims[0], sa[0], tid);
@@ -440,6 +449,7 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
     }
   }
   __syncthreads();
+  PHASE(1);
   int cur = 0;
 #pragma unroll 1
   for (int step = 0; step < a.nl; ++step) {
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
       }
       // the registers are free again: the next tile (this layer's second one, else the next layer's) is requested now and arrives
       // under the epilogue and the barrier
+      PHASE(2 + 4 * step + 2 * pass);
       if (pass + 1 < npass) fetch_layer(l, wave + 8);
       else if (more) fetch_layer(ln, wave);
       // epilogue
@@ -542,13 +553,300 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
           if (lh == 0) atomicAdd(&db[n], csum);
         }
       }
+      PHASE(3 + 4 * step + 2 * pass);
     }
     __syncthreads();
     cur ^= 1;
   }
+  PHASE(20);
 }
 
 #undef RG
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the 8-wave kernel re-cut for the shapes the step actually runs (4 layers, hidden width 256; D0 = 128 / 384 inputs,
+// D4 = 128 / 2 / 1 outputs).  tools/hw/mlp_phase.hip showed ONE workgroup of mlp_img8_kernel taking 18 us forward / 33 us backward
+// (the whole grid is no slower): per layer 2.5 us between barrier and last MFMA, 1.6-2.2 us of epilogue.  Its ISA says why: with
+// run-time layer shapes every register chunk sits behind branches, so the wait in front of the FIRST chunk is vmcnt(3..0) -- all of
+// the layer's weights AND the previous epilogue's store acknowledgements -- and every MFMA waits for its own two ds_read_b128.
+// Here (a) the shapes are template parameters, the four layers are straight-line code and the compiler counts vmcnt exactly;
+// (b) the weights come from FRAGMENT-ORDER images (bf16_frag_images below): the 16 bytes lane (n = lane & 31, half = lane >> 5)
+// feeds to MFMA k-step u of output tile nt are contiguous per wave instruction (1 KiB), so a weight goes global -> VGPR -> MFMA
+// with no LDS staging (the old kernel wrote and re-read 16 KB per wave and layer); (c) the next layer's fragments are requested
+// as soon as the current layer's last MFMA has issued.  What bounds it now is the per-CU rate out of L2 (MI355X_MICROARCH.md:
+// 66-73 GB/s per CU): every workgroup streams the whole stack, 393-459 KB, i.e. >= 5.6-6.5 us per pass.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FR_HID = 256;
+
+template <int NF>
+__device__ __forceinline__ void load_frags(bf16x8 (&w)[NF], const __bf16* __restrict__ img, int nt, int lane) {
+  const bf16x8* __restrict__ p = reinterpret_cast<const bf16x8*>(img) + (long)nt * NF * 64 + lane;
+#pragma unroll
+  for (int u = 0; u < NF; ++u) w[u] = p[u * 64];
+}
+// narrow matrix [N < 32][K] read from the PLAIN image: lane n -> row min(n, N-1) (columns >= N are never stored)
+template <int NF>
+__device__ __forceinline__ void load_frags_plain(bf16x8 (&w)[NF], const __bf16* __restrict__ img, int N, int lane) {
+  const __bf16* __restrict__ p = img + (long)min(lane & 31, N - 1) * (NF * 16) + 8 * (lane >> 5);
+#pragma unroll
+  for (int u = 0; u < NF; ++u) w[u] = *reinterpret_cast<const bf16x8*>(p + u * 16);
+}
+template <int NF>
+__device__ __forceinline__ void mma_tile(f32x16& acc, const __bf16 (*t)[LDA], const bf16x8 (&w)[NF], int lr, int lh) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < NF; ++u) {
+    const bf16x8 af = *reinterpret_cast<const bf16x8*>(&t[lr][u * 16 + 8 * lh]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, w[u], acc, 0, 0, 0);
+  }
+}
+
+// FULL: rows is a multiple of 32 (a kernel-level choice, not a branch: where a guarded and an unguarded epilogue merge, the
+// compiler's wait counting assumes the stores may be absent and makes the next layer's first MFMA wait for their acknowledgements)
+// DIN (backward): the gradient w.r.t. the stack's input is wanted (also a kernel-level choice, for the same reason)
+template <bool BWD, int D0, int D4, bool FULL, bool DIN = false>
+__global__ __launch_bounds__(512) void mlp_frag_kernel(MlpFusedArgs a) {
+  static_assert(D0 % 64 == 0 && D0 <= MLPF_MAX_WIDTH && (D4 % 32 == 0 || D4 <= 2), "stack shape");
+  constexpr bool NARROW = D4 < 32;
+  __shared__ __attribute__((aligned(16))) __bf16 sa[2][RT][LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = (a.rows + RT - 1) / RT;
+  const int xslot = blockIdx.x >> 3;
+  const int g = (blockIdx.x & 7) + 8 * (xslot / tiles);      // a group (one weight set) is pinned to one XCD
+  const int r0 = (xslot % tiles) * RT;
+  if (g >= a.nb) return;
+  const long rowbase = (long)g * a.brows + r0;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int rows_here = min(RT, a.rows - r0);
+  const long pg = (long)g * a.pstride;
+  PHASE(0);
+
+  if constexpr (!BWD) {
+    // ---------------- forward: in -> act[0] -> act[1] -> act[2] -> out
+    // biases first in the memory queue (a load behind the next layer's weight requests would make the epilogue wait for all of them)
+    float bn[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) bn[l] = a.b[l][pg + min(wave * 32 + lr, (l == 3 ? D4 : FR_HID) - 1)];
+    auto epilogue = [&](const f32x16& acc, int nt, int N, float bias, float* __restrict__ dst, auto NX, auto RELU, __bf16 (*nx)[LDA])
+                        __attribute__((always_inline)) {
+      const int n = nt * 32 + lr;
+      if (NARROW && !decltype(NX)::value && n >= N) return;    // only the narrow top layer has columns without an owner
+      float* __restrict__ d0 = dst + rowbase * (long)N + n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = acc[r] + bias;
+        if constexpr (decltype(RELU)::value) v = fmaxf(v, 0.f);
+        if (FULL || m < rows_here) d0[m * N] = v;
+        if constexpr (decltype(NX)::value) nx[m][n] = to_bf16(v);
+      }
+    };
+    f32x16 acc;
+    bf16x8 w0[D0 / 16];
+    load_frags<D0 / 16>(w0, a.Wf[0] + pg, wave, lane);
+    load_tile_bf16<512>(a.in, rowbase, r0, a.rows, D0, sa[0], tid);
+    __syncthreads();
+    PHASE(1);
+    mma_tile<D0 / 16>(acc, sa[0], w0, lr, lh);
+    PHASE(2);
+    bf16x8 w1[FR_HID / 16];
+    load_frags<FR_HID / 16>(w1, a.Wf[1] + pg, wave, lane);
+    epilogue(acc, wave, FR_HID, bn[0], a.act[0], std::true_type{}, std::true_type{}, sa[1]);
+    PHASE(3);
+    __syncthreads();
+    mma_tile<FR_HID / 16>(acc, sa[1], w1, lr, lh);
+    PHASE(6);
+    bf16x8 w2[FR_HID / 16];
+    load_frags<FR_HID / 16>(w2, a.Wf[2] + pg, wave, lane);
+    epilogue(acc, wave, FR_HID, bn[1], a.act[1], std::true_type{}, std::true_type{}, sa[0]);
+    PHASE(7);
+    __syncthreads();
+    mma_tile<FR_HID / 16>(acc, sa[0], w2, lr, lh);
+    PHASE(10);
+    bf16x8 w3[FR_HID / 16];
+    constexpr int TOPT = NARROW ? 1 : D4 / 32;       // waves with a tile of the top layer
+    if (wave < TOPT) {
+      if constexpr (NARROW) load_frags_plain<FR_HID / 16>(w3, a.Wb[3] + pg, D4, lane);
+      else load_frags<FR_HID / 16>(w3, a.Wf[3] + pg, wave, lane);
+    }
+    epilogue(acc, wave, FR_HID, bn[2], a.act[2], std::true_type{}, std::true_type{}, sa[1]);
+    PHASE(11);
+    __syncthreads();
+    if (wave < TOPT) {
+      mma_tile<FR_HID / 16>(acc, sa[1], w3, lr, lh);
+      PHASE(14);
+      epilogue(acc, wave, D4, bn[3], a.out, std::false_type{}, std::false_type{}, sa[0]);
+      PHASE(15);
+    }
+  } else {
+    // ---------------- backward (data-gradient chain): dout -> dz[3] -> dz[2] -> dz[1] (-> din)
+    // dz_l = (dz_{l+1} W_l) masked by act[l-1] > 0; column sums -> db[l-1]; top layer's bias / narrow weight gradients from dout
+    if (!NARROW && a.db_top && tid < D4) {      // column sums of this tile's dout rows (fp32 source, L2-hot): all 32 loads in flight at once
+      const float* __restrict__ dp = a.dout + rowbase * D4 + tid;
+      float s = 0.f;
+      if (FULL) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) s += dp[r * D4];
+      } else {
+#pragma unroll 8
+        for (int r = 0; r < rows_here; ++r) s += dp[r * D4];
+      }
+      atomicAdd(a.db_top + pg + tid, s);
+    }
+    // mask values of one output tile: row min(m, rows_here - 1) (clamped rows are never stored)
+    auto load_mask = [&](float (&mk)[16], const float* __restrict__ mask, int n) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = min((r & 3) + 8 * (r >> 2) + 4 * lh, rows_here - 1);
+        mk[r] = mask[(rowbase + m) * (long)FR_HID + n];
+      }
+    };
+    auto epilogue = [&](const f32x16& acc, const float (&mk)[16], auto MASKED, int n, int N, float* __restrict__ dst, auto NX, __bf16 (*nx)[LDA],
+                        float* __restrict__ db) __attribute__((always_inline)) {
+      float csum = 0.f;
+      float* __restrict__ d0 = dst + rowbase * (long)N + n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool ok = FULL || m < rows_here;
+        float v = acc[r];
+        if constexpr (decltype(MASKED)::value) v = (ok && mk[r] > 0.f) ? v : 0.f;
+        if (ok) d0[m * N] = v;
+        if constexpr (decltype(NX)::value) nx[m][n] = to_bf16(v);
+        csum += v;
+      }
+      if (db) {
+        csum += __shfl_xor(csum, 32, 64);
+        if (lh == 0) atomicAdd(&db[n], csum);
+      }
+    };
+    f32x16 acc;
+    float mk[16];
+    const int n = wave * 32 + lr;
+    bf16x8 w2[FR_HID / 16];
+    // top layer: reduction over the D4 outputs
+    if constexpr (NARROW) {
+      // 1- or 2-wide top layer: plain FMAs.  The fp32 dout tile goes through LDS once (rows beyond the tile's last one: zeros); the top
+      // layer's bias gradient is its column sums and its WEIGHT gradient dW[c][k] = sum_r dout[r][c] * act2[r][k] is formed from the ReLU-mask
+      // values this lane holds anyway (mask of dz[3] = act[2]: rows m of column n), one cross-half shuffle and one atomic per (c, n)
+      __shared__ float sd[RT][2];
+      load_frags<FR_HID / 16>(w2, a.WfT[2] + pg, wave, lane);
+      load_mask(mk, a.act[2], n);
+      float wv[D4];
+#pragma unroll
+      for (int c = 0; c < D4; ++c) wv[c] = (float)a.Wb[3][pg + (long)c * FR_HID + n];
+      if (tid < RT * D4) {
+        const int r = tid / D4, c = tid - r * D4;
+        sd[r][c] = r < rows_here ? a.dout[(rowbase + r) * D4 + c] : 0.f;
+      }
+      __syncthreads();
+      if (a.db_top && tid < D4) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) s += sd[r][tid];
+        atomicAdd(a.db_top + pg + tid, s);
+      }
+      float dw[D4];
+#pragma unroll
+      for (int c = 0; c < D4; ++c) dw[c] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < D4; ++c) {
+          const float d = sd[m][c];
+          v += (float)to_bf16(d) * wv[c];
+          dw[c] += d * mk[r];
+        }
+        acc[r] = v;
+      }
+      if (a.dw_top) {
+#pragma unroll
+        for (int c = 0; c < D4; ++c) {
+          const float t = dw[c] + __shfl_xor(dw[c], 32, 64);
+          if (lh == 0) atomicAdd(a.dw_top + pg + (long)c * FR_HID + n, t);
+        }
+      }
+      PHASE(1);
+      PHASE(2);
+    } else {
+      bf16x8 w3[D4 / 16];
+      load_frags<D4 / 16>(w3, a.WfT[3] + pg, wave, lane);
+      load_mask(mk, a.act[2], n);
+      load_tile_bf16<512>(a.dout, rowbase, r0, a.rows, D4, sa[0], tid);
+      __syncthreads();
+      PHASE(1);
+      mma_tile<D4 / 16>(acc, sa[0], w3, lr, lh);
+      PHASE(2);
+      load_frags<FR_HID / 16>(w2, a.WfT[2] + pg, wave, lane);
+    }
+    epilogue(acc, mk, std::true_type{}, n, FR_HID, a.dz[3], std::true_type{}, sa[1], a.db[2] ? a.db[2] + pg : nullptr);
+    PHASE(3);
+    __syncthreads();
+    load_mask(mk, a.act[1], n);
+    mma_tile<FR_HID / 16>(acc, sa[1], w2, lr, lh);
+    PHASE(6);
+    bf16x8 w1[FR_HID / 16];
+    load_frags<FR_HID / 16>(w1, a.WfT[1] + pg, wave, lane);
+    epilogue(acc, mk, std::true_type{}, n, FR_HID, a.dz[2], std::true_type{}, sa[0], a.db[1] ? a.db[1] + pg : nullptr);
+    PHASE(7);
+    __syncthreads();
+    load_mask(mk, a.act[0], n);
+    mma_tile<FR_HID / 16>(acc, sa[0], w1, lr, lh);
+    PHASE(10);
+    constexpr int T0 = D0 / 32;                       // input-gradient tiles: 4 (waves 0..3) or 12 (waves 0..3 take a second one)
+    bf16x8 w0[FR_HID / 16];
+    // (every wave loads, waves without a tile a copy of the last one: a conditional request would cost the exact wait counts)
+    if constexpr (DIN) load_frags<FR_HID / 16>(w0, a.WfT[0] + pg, min(wave, T0 - 1), lane);
+    epilogue(acc, mk, std::true_type{}, n, FR_HID, a.dz[1], std::true_type{}, sa[1], a.db[0] ? a.db[0] + pg : nullptr);
+    PHASE(11);
+    if constexpr (DIN) {
+      __syncthreads();
+      if (wave < T0) {
+        mma_tile<FR_HID / 16>(acc, sa[1], w0, lr, lh);
+        PHASE(14);
+        if (T0 > 8 && wave + 8 < T0) load_frags<FR_HID / 16>(w0, a.WfT[0] + pg, wave + 8, lane);
+        epilogue(acc, mk, std::false_type{}, n, D0, a.din, std::false_type{}, sa[0], nullptr);
+        PHASE(15);
+        if (T0 > 8 && wave + 8 < T0) {
+          mma_tile<FR_HID / 16>(acc, sa[1], w0, lr, lh);
+          epilogue(acc, mk, std::false_type{}, n + 256, D0, a.din, std::false_type{}, sa[0], nullptr);
+        }
+      }
+    }
+  }
+  PHASE(20);
+}
+
+// Fragment-order image of a table of strided groups of matrices.  Entry e: a matrix with OUT output columns and RED reduction
+// length whose element (c, r) is src[c * RED + r] (tr = 0: the forward weight [N = OUT, K = RED]) or src[r * OUT + c] (tr = 1: the same
+// memory seen by the data-gradient product, OUT = K, RED = N).  dst holds, at the matrix's own offset and footprint,
+//   dst[((c / 32 * (RED / 16) + r / 16) * 64 + (c % 32) + 32 * ((r % 16) / 8)) * 8 + r % 8] = bf16(element (c, r)).
+// One workgroup = one 32-column tile x 64 reduction values: 4 KB written contiguously.
+__global__ __launch_bounds__(256) void frag_images_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, FragTable t) {
+  int b = blockIdx.x, e = 0;
+  while (e + 1 < t.n && b >= t.blk0[e + 1]) ++e;
+  b -= t.blk0[e];
+  const int OUT = t.OUT[e], RED = t.RED[e];
+  const int q64 = RED / 64, per = (OUT / 32) * q64;
+  const int g = b / per, rem = b - g * per;
+  const int nt = rem / q64, u = (rem - nt * q64) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+  const long base = t.off[e] + (long)g * t.gstride[e];
+  const int c = nt * 32 + lr, rr = u * 16 + 8 * lh;
+  bf16x8 p;
+  if (!t.tr[e]) {
+    const float4 x = *reinterpret_cast<const float4*>(src + base + (long)c * RED + rr);
+    const float4 y = *reinterpret_cast<const float4*>(src + base + (long)c * RED + rr + 4);
+    p = pack8(x, y);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = to_bf16(src[base + (long)(rr + i) * OUT + c]);
+  }
+  *reinterpret_cast<bf16x8*>(dst + t.dshift[e] + base + ((long)(nt * (RED / 16) + u) * 64 + lane) * 8) = p;
+}
 
 __global__ void bf16_image_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -713,6 +1011,20 @@ static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wa
   return kmax <= 256 ? 4 : 6;
 }
 
+// the fragment-image kernel takes: 4 layers, hidden 256, inputs 128 / 384, outputs 128 / 2 / 1, few workgroups; -> 0 or an id
+static int mlp_frag_shape(const MlpFusedArgs& a, bool bwd) {
+  static const bool off = getenv("MIMRL_MLP_NO_FRAG") != nullptr;    // tuning knob: the round-2 kernels
+  if (off || a.nl != 4 || !(bwd ? a.WfT[1] : a.Wf[0]) || !a.Wb[3]) return 0;
+  if (a.dims[1] != FR_HID || a.dims[2] != FR_HID || a.dims[3] != FR_HID) return 0;
+  const long wgs = (long)((a.rows + RT - 1) / RT) * a.nb;
+  if (wgs > 512) return 0;
+  const int d0 = a.dims[0], d4 = a.dims[4];
+  if (d0 == 128 && d4 == 128) return 1;
+  if (d0 == 384 && d4 == 2) return 2;
+  if (d0 == 128 && d4 == 1) return 3;
+  return 0;
+}
+
 static int check(const MlpFusedArgs& a) {
   if (!mlp_fused_supported(a.nb, a.rows, a.nl, a.dims)) return set_error(MIMRL_ERR_ARG, "mlp_fused: unsupported stack shape");
   if (a.pstride % 4 != 0) return set_error(MIMRL_ERR_ARG, "mlp_fused: group stride must be a multiple of 4 floats");
@@ -721,6 +1033,16 @@ static int check(const MlpFusedArgs& a) {
 
 int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
   MX(check(a));
+  if (const int id = mlp_frag_shape(a, false)) {
+    const dim3 grid(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8));
+    const bool full = a.rows % RT == 0;
+#define FRAGK(D0_, D4_) do { if (full) hipLaunchKernelGGL((mlp_frag_kernel<false, D0_, D4_, true>), grid, dim3(512), 0, s, a); \
+                             else hipLaunchKernelGGL((mlp_frag_kernel<false, D0_, D4_, false>), grid, dim3(512), 0, s, a); } while (0)
+    if (id == 1) FRAGK(128, 128); else if (id == 2) FRAGK(384, 2); else FRAGK(128, 1);
+#undef FRAGK
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
   if (a.Wb[0]) {
     if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<false, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
     else if (mlp_small8(a, false) == 4) hipLaunchKernelGGL((mlp_img8_kernel<false, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
@@ -735,6 +1057,7 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
 }
 
 bool mlp_bwd_takes_top_wgrad(const MlpFusedArgs& a) {
+  if (mlp_frag_shape(a, true)) return a.dims[4] <= 2;
   return a.WbT[0] && !mlp_direct(a) && mlp_small8(a, true) == 4 && a.nl >= 2 && a.dims[a.nl] * a.dims[a.nl - 1] <= 512;
 }
 
@@ -743,6 +1066,18 @@ int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
   a.dbg = dbg_env("MIMRL_DBG_MLPB") ? atoi(dbg_env("MIMRL_DBG_MLPB")) : 0;
   MX(check(a));
   if (a.dw_top && !mlp_bwd_takes_top_wgrad(a)) return set_error(MIMRL_ERR_ARG, "mlp_stack_bwd_fused: dw_top not supported for this stack");
+  if (const int id = mlp_frag_shape(a, true)) {
+    const dim3 grid(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8));
+    const bool full = a.rows % RT == 0;
+#define FRAGK(D0_, D4_) do { if (full && a.din) hipLaunchKernelGGL((mlp_frag_kernel<true, D0_, D4_, true, true>), grid, dim3(512), 0, s, a); \
+                             else if (full) hipLaunchKernelGGL((mlp_frag_kernel<true, D0_, D4_, true, false>), grid, dim3(512), 0, s, a); \
+                             else if (a.din) hipLaunchKernelGGL((mlp_frag_kernel<true, D0_, D4_, false, true>), grid, dim3(512), 0, s, a); \
+                             else hipLaunchKernelGGL((mlp_frag_kernel<true, D0_, D4_, false, false>), grid, dim3(512), 0, s, a); } while (0)
+    if (id == 1) FRAGK(128, 128); else if (id == 2) FRAGK(384, 2); else FRAGK(128, 1);
+#undef FRAGK
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
   if (a.WbT[0]) {
     if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<true, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
     else if (mlp_small8(a, true) == 4) hipLaunchKernelGGL((mlp_img8_kernel<true, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
@@ -768,6 +1103,22 @@ int bf16_transposed_images(hipStream_t s, const float* src, __bf16* dstT, const 
   int z = 0, kmax = 0, nmax = 0;
   for (int e = 0; e < t.n; ++e) { z += t.nb[e]; kmax = t.K[e] > kmax ? t.K[e] : kmax; nmax = t.N[e] > nmax ? t.N[e] : nmax; }
   hipLaunchKernelGGL(transpose_images_kernel, dim3((kmax + 31) / 32, (nmax + 31) / 32, z), dim3(256), 0, s, src, dstT, t);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+int bf16_frag_images(hipStream_t s, const float* src, __bf16* dst, const FragTable& t_) {
+  FragTable t = t_;
+  if (t.n < 1 || t.n > 24) return set_error(MIMRL_ERR_ARG, "bf16_frag_images: 1..24 table entries");
+  int blocks = 0;
+  for (int e = 0; e < t.n; ++e) {
+    if (t.OUT[e] % 32 != 0 || t.RED[e] % 64 != 0 || t.off[e] % 8 != 0 || t.gstride[e] % 8 != 0 || t.dshift[e] % 8 != 0)
+      return set_error(MIMRL_ERR_ARG, "bf16_frag_images: entry %d is not [32k x 64k] at a 16-byte image offset", e);
+    t.blk0[e] = blocks;
+    blocks += t.nb[e] * (t.OUT[e] / 32) * (t.RED[e] / 64);
+  }
+  t.blk0[t.n] = blocks;
+  hipLaunchKernelGGL(frag_images_kernel, dim3(blocks), dim3(256), 0, s, src, dst, t);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
