@@ -204,6 +204,7 @@ struct mimrl_handle {
   // for both; valid exactly when crit_img is (rebuilt by ensure_images and behind every critic Adam launch)
   __bf16 *crit_frag = nullptr, *crit_fragT = nullptr;
   FragTable ftab;
+  bool frag_side_pending = false;      // the refresh behind the critic Adam runs on side 3 and has not been joined yet
   bool img_valid = false;
   unsigned knn_ovr_mask[2] = {0u, 0u};  // per stage: CMI calls whose neighbour rows come from bufs.knn_override
   bool knn_pre = true;                 // prefetch mode: stage 2's kNN sampling also runs inside stage 1, beside the encoder prefix (MIMRL_NO_KNN_PREFETCH=1: off)
@@ -2258,6 +2259,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   static const bool imgt_first = getenv("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
   bool imgT_pending = false;
   imgT_ready = false;
+  if (frag_side_pending) { MX(join(3, 3)); frag_side_pending = false; }
   if (backward && bf_bwd && fused_mlp && crit_imgT && ttab.n > 0) {   // transposed weight images for the fused data-gradient chains,
     if (!(skip_imgT_refresh && stage == 1)) {                         // built beside the forward stacks (combined step: once per step,
       MX(fork(3, 3));                                                 // in stage 2 -- stage 1 of the NEXT step sees the same critics)
@@ -2494,7 +2496,12 @@ int mimrl_handle::enqueue_apply(int stage) {
   a.gscale = grad_scale;
   Scope sc(this, MIMRL_PH_OPT);
   MX(adam_step(stream, a));
-  if (stage == 1 && img_valid && crit_frag && ftab.n > 0) MX(bf16_frag_images(stream, bufs.crit_p, crit_frag, ftab));
+  if (stage == 1 && img_valid && crit_frag && ftab.n > 0) {
+    // combined step: beside the stage boundary on side 3 (the stage-2 estimators join it before their first stack)
+    static const bool inline_frag = getenv("MIMRL_FRAG_INLINE") != nullptr;   // tuning knob
+    if (fuse_boundary && side_on(3) && !inline_frag) { MX(fork(3, 3)); MX(bf16_frag_images(side[3], bufs.crit_p, crit_frag, ftab)); frag_side_pending = true; }
+    else MX(bf16_frag_images(stream, bufs.crit_p, crit_frag, ftab));
+  }
   return dbg_delay(stream, 12);
 }
 
