@@ -25,4 +25,8 @@ bool cube_fused_supported(int il, int hl, int ol, int ik, int hk, int ok, int id
                           bool res_project, bool bias, const float* dropout_mlp);
 int cube_block_fwd_fused(hipStream_t s, const CubeFusedArgs& a);
 
+#ifdef MIMRL_PHASE_PROBE
+int cube_fwd_read_phases(long long* out);   // 128 ticks, see cube_fused.hip
+#endif
+
 }  // namespace mimrl

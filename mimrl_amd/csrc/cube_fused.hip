@@ -23,6 +23,8 @@
 
 #include "kmix_device.h"
 
+#include <type_traits>
+
 namespace mimrl {
 
 namespace {
@@ -34,6 +36,14 @@ constexpr int CTL = 68, CTD = 132;       // fp32 staging tile row lengths
 
 typedef _Float16 bf;   // the tile / operand element type of this kernel: fp16 (see the header comment)
 
+// `make PHASE_PROBE=1` (tools/cube_phase.py): workgroup 0 leaves 100 MHz ticks at the phase boundaries of its last launch
+#ifdef MIMRL_PHASE_PROBE
+__device__ long long g_cube_phase[128];
+#define CPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cube_phase[(SAVE ? 64 : 0) + (NMT - 1) * 16 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define CPHASE(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void mma64(f32x16& acc, const bf* A, const bf* B, int wm, int wn, int lane) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -44,27 +54,38 @@ __device__ __forceinline__ void mma64(f32x16& acc, const bf* A, const bf* B, int
 }
 __device__ __forceinline__ int acc_row(int r, int wm, int lane) { return wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// stage a 64(n) x 64(k) weight image  Bw[n][k] = W[(n0+n)*ld + k0 + k]  (fp32 global -> bf16 LDS), zero beyond (N, K)
-__device__ __forceinline__ void stage_weight(bf* img, const float* __restrict__ W, int ld, int n0, int k0, int N, int K, int tid) {
+// stage a 64(n) x 64(k) weight image  Bw[n][k] = W[(n0+n)*ld + k0 + k]  (fp32 global -> bf16 LDS), zero beyond (N, K): request (registers)
+// and commit (LDS) are separate so that the kernel's whole set-up -- sample tile, per-row parameters, L-axis weights -- is ONE
+// memory round trip (as a sequence it was five: 7.9 of block 1's 54 us, tools/cube_phase.py)
+struct WReq { float v[16]; };
+__device__ __forceinline__ WReq stage_weight_request(const float* __restrict__ W, int ld, int n0, int k0, int N, int K, int tid) {
   const int n = tid >> 2, kc = (tid & 3) * 16;
-  f16x8 lo, hi;
   // 16 UNCONDITIONAL loads from clamped addresses, zeroed afterwards: a guarded load is a branch whose join waits for every
   // outstanding load, i.e. 16 dependent round trips per image (this staging was 10 of the block's 18 us of set-up)
   const int gn = n0 + n, gnc = gn < N ? gn : N - 1;
-  float v[16];
+  WReq r;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int gk = k0 + kc + j;
-    v[j] = W[(long)gnc * ld + (gk < K ? gk : K - 1)];
+    r.v[j] = W[(long)gnc * ld + (gk < K ? gk : K - 1)];
   }
+  return r;
+}
+__device__ __forceinline__ void stage_weight_commit(bf* img, const WReq& r, int n0, int k0, int N, int K, int tid) {
+  const int n = tid >> 2, kc = (tid & 3) * 16;
+  const int gn = n0 + n;
+  f16x8 lo, hi;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int gk = k0 + kc + j;
-    const float x = (gn < N && gk < K) ? v[j] : 0.f;
+    const float x = (gn < N && gk < K) ? r.v[j] : 0.f;
     if (j < 8) lo[j] = to_f16(x); else hi[j - 8] = to_f16(x);
   }
   *reinterpret_cast<f16x8*>(img + n * ILD + kc) = lo;
   *reinterpret_cast<f16x8*>(img + n * ILD + kc + 8) = hi;
+}
+__device__ __forceinline__ void stage_weight(bf* img, const float* __restrict__ W, int ld, int n0, int k0, int N, int K, int tid) {
+  stage_weight_commit(img, stage_weight_request(W, ld, n0, k0, N, K, tid), n0, k0, N, K, tid);
 }
 // 128-wide row-major weights (D axis): a 64x64 image = 4 float4 per thread.  Split into issue (global -> registers)
 // and commit (registers -> bf16 LDS image) so that the next image's loads are in flight during the current MFMAs.
@@ -138,20 +159,35 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
   float* ksw = reinterpret_cast<float*>(smem + cv.ksw);
   float* prm = reinterpret_cast<float*>(smem + cv.prm);   // [4][64] L-axis b1, b2, gamma, beta
 
+  CPHASE(0);
   // ------------------------------------------------------------------ load the sample tile (bf16), zero-pad rows >= il
   {
+    // every request first (L-axis weights, per-row parameters, the tile), then the commits: one round trip
+    WReq w0, w1;                                                      // group 0 (or the only group): W1 and Wr; group 1: W2
+    if (G == 1 || grp == 0) { w0 = stage_weight_request(a.l_w1, il, 0, 0, hl, il, t); w1 = stage_weight_request(a.l_wr, il, 0, 0, ol, il, t); }
+    else w0 = stage_weight_request(a.l_w2, hl, 0, 0, ol, hl, t);
+    WReq w2;
+    if (G == 1) w2 = stage_weight_request(a.l_w2, hl, 0, 0, ol, hl, t);
+    float pr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) {
+      pr[0] = (tid < hl && a.l_b1) ? a.l_b1[tid] : 0.f;
+      pr[1] = (tid < ol && a.l_b2) ? a.l_b2[tid] : 0.f;
+      pr[2] = tid < ol ? a.l_g[tid] : 0.f;
+      pr[3] = tid < ol ? a.l_be[tid] : 0.f;
+    }
     const float* xb = a.x + (long)b * il * C;
     const int nq = C / 4, total = 64 * nq;
-    for (int i0 = tid; i0 < total; i0 += NT * 8) {           // 8 independent 16-byte loads in flight per thread
-      float4 q[8];
+    constexpr int NQ = 12;                                            // 16-byte pieces per thread and pass: K = 3 (C = 384), two wave groups: ONE pass
+    for (int i0 = tid; i0 < total; i0 += NT * NQ) {
+      float4 q[NQ];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NQ; ++j) {
         const int i = i0 + NT * j;
         const int l = i / nq, c4 = (i - l * nq) * 4;
         q[j] = (i < total && l < il) ? *reinterpret_cast<const float4*>(xb + (long)l * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NQ; ++j) {
         const int i = i0 + NT * j;
         if (i < total) {
           const int l = i / nq, c4 = (i - l * nq) * 4;
@@ -161,18 +197,14 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       }
     }
     // small per-row / per-column parameters -> LDS once (they sit on the critical path of every epilogue otherwise)
-    if (tid < 64) {
-      prm[0 * 64 + tid] = (tid < hl && a.l_b1) ? a.l_b1[tid] : 0.f;
-      prm[1 * 64 + tid] = (tid < ol && a.l_b2) ? a.l_b2[tid] : 0.f;
-      prm[2 * 64 + tid] = tid < ol ? a.l_g[tid] : 0.f;
-      prm[3 * 64 + tid] = tid < ol ? a.l_be[tid] : 0.f;
-    }
+    if (tid < 64) { prm[0 * 64 + tid] = pr[0]; prm[1 * 64 + tid] = pr[1]; prm[2 * 64 + tid] = pr[2]; prm[3 * 64 + tid] = pr[3]; }
     // L-axis weights as A-images [m][k], zero padded to 64x64
-    if (G == 1 || grp == 0) stage_weight(Aw + 0 * IMG, a.l_w1, il, 0, 0, hl, il, t);
-    if (G == 1 || grp == 1) stage_weight(Aw + 1 * IMG, a.l_w2, hl, 0, 0, ol, hl, t);
-    if (G == 1 || grp == 0) stage_weight(Aw + 2 * IMG, a.l_wr, il, 0, 0, ol, il, t);
+    if (G == 1 || grp == 0) { stage_weight_commit(Aw + 0 * IMG, w0, 0, 0, hl, il, t); stage_weight_commit(Aw + 2 * IMG, w1, 0, 0, ol, il, t); }
+    else stage_weight_commit(Aw + 1 * IMG, w0, 0, 0, ol, hl, t);
+    if (G == 1) stage_weight_commit(Aw + 1 * IMG, w2, 0, 0, ol, hl, t);
   }
   __syncthreads();
+  CPHASE(1);
   if (a.dbg_phase == 1) return;
 
   // ------------------------------------------------------------------ phase L: 64-column slabs, one per wave group and round
@@ -275,31 +307,43 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     __syncthreads();
   }
 
+  CPHASE(2);
   if (a.dbg_phase == 2) return;
   // ------------------------------------------------------------------ phase K: K-axis mix in place on rows l < ol
+  // first D-axis weight image: requested here, a whole phase ahead of its use (it was a bare round trip in front of the D phase)
+  WImg wnext = load_weight128(a.d_w1, (G == 1 ? 0 : grp) * 64, 0, t);
   kmix_stage_weights(a.kw, ksw);
   {
-    const float* g = ksw + 3 * KM * KM + 2 * KM; const float* be = g + KM;
+    // compile-time K (1..4): the per-pair MLP is fully unrolled over it and this phase is VALU-bound (8 waves on 4 SIMDs)
+    auto phase_k = [&](auto NKc) __attribute__((always_inline)) {
+      constexpr int NK = decltype(NKc)::value;
+      KMixRegs<NK> kq;          // weights in registers for the whole loop (see KMixRegs)
+      kq.load(ksw);
 #pragma unroll 2
-    for (int i = tid; i < ol * D; i += NT) {   // (two (l, d) pairs interleaved: the VALU chains of one pair hide nothing)
-      const int l = i >> 7, d = i & 127;
-      KMixVals<4> v;
+      for (int i = tid; i < ol * D; i += NT) {   // (two (l, d) pairs interleaved: the VALU chains of one pair hide nothing)
+        const int l = i >> 7, d = i & 127;
+        KMixVals<NK> v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { v.x[k] = k < K ? (float)Xm[l * XP + k * D + d] : 0.f; v.sc[k] = 1.f; }
-      kmix_forward_vals<4>(a.kw, ksw, v);
-      float out[4];
-      ln_small<4>(v.y, K, g, be, out, v.xh, v.mu, v.rs);
+        for (int k = 0; k < NK; ++k) { v.x[k] = (float)Xm[l * XP + k * D + d]; v.sc[k] = 1.f; }
+        kmix_forward_regs<NK>(a.kw, kq, v);    // (cube_fused_supported: never ln_first, ik == hk == ok)
+        float out[NK];
+        ln_small<NK>(v.y, NK, kq.g, kq.be, out, v.xh, v.mu, v.rs);
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (o < K) {
+        for (int o = 0; o < NK; ++o) {
           const bf ob = to_f16(out[o]);
           Xm[l * XP + o * D + d] = ob;
-          if (SAVE) a.k_z[(((long)b * ol + l) * K + o) * D + d] = (float)ob;   // (what the D phase consumed)
+          if (SAVE) a.k_z[(((long)b * ol + l) * NK + o) * D + d] = (float)ob;   // (what the D phase consumed)
         }
-    }
+      }
+    };
+    if (K == 3) phase_k(std::integral_constant<int, 3>{});
+    else if (K == 1) phase_k(std::integral_constant<int, 1>{});
+    else if (K == 2) phase_k(std::integral_constant<int, 2>{});
+    else phase_k(std::integral_constant<int, 4>{});
   }
   __syncthreads();
 
+  CPHASE(3);
   if (a.dbg_phase == 3) return;
   // ------------------------------------------------------------------ phase D
   const int R = ol * K;
@@ -320,6 +364,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     *reinterpret_cast<f16x8*>(Az + ((r >> 6) * 2 + (ch >> 3)) * IMG + (r & 63) * ILD + (ch & 7) * 8) = v;
   }
   __syncthreads();   // Xm is dead from here on (the weight-image buffers alias it)
+  CPHASE(4);
   if (tid < D) { dgam[tid] = a.d_g[tid]; dbet[tid] = a.d_be[tid]; }   // visible after the barriers of the GEMM loops
   // a wave owns NTW of the two 64-column halves of the outputs (both for G = 1, its group's one for G = 2)
   constexpr int NTW = 2 / G, NI1 = 2 * NTW;        // weight images per product and group: (nt, kh)
@@ -349,7 +394,6 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     return load_weight128(W, (nt0 + (j >> 1)) * 64, (j & 1) * 64, t);
   };
   bf* Bw2[2] = {reinterpret_cast<bf*>(smem + cv.bw) + (2 * grp) * IMG, reinterpret_cast<bf*>(smem + cv.bw) + (2 * grp + 1) * IMG};
-  WImg wnext = wload(0);
   // H = act(Z W1^T + b1): NI1 weight images (nt, kh), each used by all row tiles
 #pragma unroll
   for (int i = 0; i < NI1; ++i) {
@@ -383,6 +427,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       }
     }
   __syncthreads();
+  CPHASE(5);
   if (a.dbg_phase == 4) return;
   // Y = H W2^T + Z Wr^T + b2: 2 * NI1 weight images
 #pragma unroll
@@ -396,6 +441,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][q], Asrc + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
   }
   __syncthreads();   // (the H images are dead: the LayerNorm tile below aliases them)
+  CPHASE(6);
   if (a.dbg_phase == 5) return;
   // LayerNorm over D per row, through an fp32 LDS tile
 #pragma unroll
@@ -444,9 +490,14 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     }
     __syncthreads();
   }
+  CPHASE(7);
 }
 
 }  // namespace
+
+#ifdef MIMRL_PHASE_PROBE
+int cube_fwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cube_phase), sizeof(long long) * 128) == hipSuccess ? 0 : 1; }
+#endif
 
 bool cube_fused_supported(int il, int hl, int ol, int ik, int hk, int ok, int id, int hd, int od, bool ln_first,
                           bool res_project, bool bias, const float* dropout_mlp) {

@@ -2645,6 +2645,10 @@ int mimrl_handle::run_step() {
 extern "C" {
 
 const char* mimrl_last_error(void) { return mimrl::last_error_slot().c_str(); }
+#ifdef MIMRL_PHASE_PROBE
+// `make PHASE_PROBE=1` only (not part of the ABI): in-kernel phase ticks of the fused CubeMLP forward (tools/cube_phase.py)
+int mimrl_dbg_cube_phases(long long* out) { return mimrl::cube_fwd_read_phases(out); }
+#endif
 int mimrl_abi_version(void) { return MIMRL_ABI_VERSION; }
 
 int mimrl_device_check(void) {

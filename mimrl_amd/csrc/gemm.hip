@@ -11,6 +11,8 @@
 //   * split-K for accumulate-into-zeroed-output GEMMs (weight gradients with K = B*T ... B*L*K rows, tiny M x N).
 #include "gemm.h"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 namespace mimrl {
@@ -355,6 +357,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(KernelArgs ka) {
 // (RC,RC) weight gradients cover every large GEMM of the step; anything else falls back to gemm_kernel.
 // =================================================================================================
 constexpr int FBK = 32;
+#ifndef MIMRL_GEMM_NPF
+#define MIMRL_GEMM_NPF 2
+#endif
+constexpr int FPF = MIMRL_GEMM_NPF;   // k-tiles in flight per workgroup of the fast kernels (register ring, see fast_body)
+template <int I, int N, class F>
+__device__ __forceinline__ void gemm_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); gemm_static_for<I + 1, N>(f); }
+}
 constexpr int GEMM_GROUP_MAX = 6;
 template <int T>
 struct FT {
@@ -368,22 +378,26 @@ struct FT {
 
 // F16: the 16-bit operand type is fp16 (saturating conversion), stored in the same LDS image as bit patterns (GemmDesc::f16)
 template <bool F16 = false>
-__device__ __forceinline__ bf16x4 cvt4(const float4& q) {
+__device__ __forceinline__ bf16x4 cvt4(const f32x4& q) {
   if constexpr (F16) {
-    f16x4 h; h[0] = to_f16_sat(q.x); h[1] = to_f16_sat(q.y); h[2] = to_f16_sat(q.z); h[3] = to_f16_sat(q.w);
+    f16x4 h; h[0] = to_f16_sat(q[0]); h[1] = to_f16_sat(q[1]); h[2] = to_f16_sat(q[2]); h[3] = to_f16_sat(q[3]);
     return __builtin_bit_cast(bf16x4, h);
   } else {
-    bf16x4 p; p[0] = to_bf16(q.x); p[1] = to_bf16(q.y); p[2] = to_bf16(q.z); p[3] = to_bf16(q.w);
+    bf16x4 p; p[0] = to_bf16(q[0]); p[1] = to_bf16(q[1]); p[2] = to_bf16(q[2]); p[3] = to_bf16(q[3]);
     return p;
   }
 }
 
-// every load is unconditional from a clamped (valid) address and zeroed afterwards: a guarded load is a branch whose
-// join waits for ALL outstanding loads
+// every load is unconditional from a clamped (valid) address and zeroed afterwards (fast_fix): a guarded load is a branch whose
+// join waits for ALL outstanding loads.  Round 3: the loads are inline asm with ONE explicit counted wait per register set
+// (fast_wait): across the k-loop's back edge the compiler's own wait insertion flushes to vmcnt(0), i.e. it waited for the tiles
+// requested in the same iteration and the register ring bought nothing.
 // bf16-stored operand (BF): 16 bytes = 8 elements, half as many pieces per thread, no conversion
+__device__ __forceinline__ void gld16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int T, bool BF> struct FL { static constexpr int N = BF ? T : 2 * T; };   // load instructions (= registers sets of 16 B) per thread and k-tile
 template <int T, bool KC, bool BF>
 __device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, int r0, int R, int gap_at, int gap, int K, int k0,
-                                          int tid, float4* v) {
+                                          int tid, f32x4* v) {
   if constexpr (BF) {
     const __bf16* __restrict__ Pb = reinterpret_cast<const __bf16*>(P);
     if constexpr (KC) {
@@ -393,23 +407,18 @@ __device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, i
         int gr = r0 + row < R ? r0 + row : R - 1;
         if (gr >= gap_at) gr += gap;
         const int gkc = gk < K ? gk : K - 8;               // K % 8 == 0
-        float4 q = *reinterpret_cast<const float4*>(Pb + (long)gr * s + gkc);
-        if (gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
-        v[h] = q;
+        gld16(v[h], Pb + (long)gr * s + gkc);
       }
     } else {
       const int rq = tid & (8 * T - 1), kq = tid / (8 * T);   // T=2: 16 row-octets x 16 k-pairs; T=1: 8 x 32 k
       int gr = r0 + rq * 8;
-      const bool rin = gr < R;                              // R % 8 == 0
-      if (!rin) gr = R - 8;
+      if (gr >= R) gr = R - 8;                              // R % 8 == 0
       if (gr >= gap_at) gr += gap;
 #pragma unroll
       for (int j = 0; j < T; ++j) {
         const int gk = k0 + kq * T + j;
         const int gkc = gk < K ? gk : K - 1;
-        float4 q = *reinterpret_cast<const float4*>(Pb + gr + (long)gkc * s);
-        if (!rin || gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
-        v[j] = q;
+        gld16(v[j], Pb + gr + (long)gkc * s);
       }
     }
   } else if constexpr (KC) {
@@ -419,41 +428,68 @@ __device__ __forceinline__ void fast_load(const float* __restrict__ P, long s, i
       int gr = r0 + row < R ? r0 + row : R - 1;          // ragged tiles: clamped rows land in outputs nobody stores
       if (gr >= gap_at) gr += gap;
       const int gkc = gk < K ? gk : K - 4;               // K % 4 == 0
-      float4 q = *reinterpret_cast<const float4*>(P + (long)gr * s + gkc);
-      if (gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
-      v[h] = q;
+      gld16(v[h], P + (long)gr * s + gkc);
     }
   } else {
     constexpr int KB = FT<T>::KB;
     const int rq = tid & (16 * T - 1), kq = tid / (16 * T);
     int gr = r0 + rq * 4;
-    const bool rin = gr < R;                              // R % 4 == 0: a row quad is inside or outside as a whole
-    if (!rin) gr = R - 4;
+    if (gr >= R) gr = R - 4;                              // R % 4 == 0: a row quad is inside or outside as a whole
     if (gr >= gap_at) gr += gap;
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
       const int gk = k0 + kq * KB + j;
       const int gkc = gk < K ? gk : K - 1;
-      float4 q = *reinterpret_cast<const float4*>(P + gr + (long)gkc * s);
-      if (!rin || gk >= K) q = make_float4(0.f, 0.f, 0.f, 0.f);
-      v[j] = q;
+      gld16(v[j], P + gr + (long)gkc * s);
     }
+  }
+}
+// the registers of one fast_load: wait until at most NEWER later-issued loads are outstanding (loads return in order)
+template <int N, int NEWER>
+__device__ __forceinline__ void fast_wait(f32x4* v) {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+#pragma unroll
+  for (int h = 0; h < N; ++h) asm volatile("" : "+v"(v[h]));
+}
+// ... and zero what fast_load fetched from a clamped address (k beyond K; rows beyond R in the row-contiguous layouts)
+template <int T, bool KC, bool BF>
+__device__ __forceinline__ void fast_fix(int r0, int R, int K, int k0, int tid, f32x4* v) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (BF) {
+    if constexpr (KC) {
+#pragma unroll
+      for (int h = 0; h < T; ++h) if (k0 + ((h * 256 + tid) & 3) * 8 >= K) v[h] = z;
+    } else {
+      const int rq = tid & (8 * T - 1), kq = tid / (8 * T);
+      const bool rin = r0 + rq * 8 < R;
+#pragma unroll
+      for (int j = 0; j < T; ++j) if (!rin || k0 + kq * T + j >= K) v[j] = z;
+    }
+  } else if constexpr (KC) {
+#pragma unroll
+    for (int h = 0; h < FT<T>::NV; ++h) if (k0 + ((h * 256 + tid) & 7) * 4 >= K) v[h] = z;
+  } else {
+    constexpr int KB = FT<T>::KB;
+    const int rq = tid & (16 * T - 1), kq = tid / (16 * T);
+    const bool rin = r0 + rq * 4 < R;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) if (!rin || k0 + kq * KB + j >= K) v[j] = z;
   }
 }
 
 template <int T, bool KC, bool BF, bool F16 = false>
-__device__ __forceinline__ void fast_store(const float4* v, __bf16* __restrict__ img, int tid) {
+__device__ __forceinline__ void fast_store(const f32x4* v, __bf16* __restrict__ img, int tid) {
   if constexpr (BF) {
     if constexpr (KC) {
 #pragma unroll
       for (int h = 0; h < T; ++h) {
         const int idx = h * 256 + tid;
-        *reinterpret_cast<float4*>(img + (idx >> 2) * FT<T>::KCP + (idx & 3) * 8) = v[h];
+        *reinterpret_cast<f32x4*>(img + (idx >> 2) * FT<T>::KCP + (idx & 3) * 8) = v[h];
       }
     } else {
       const int rq = tid & (8 * T - 1), kq = tid / (8 * T);
 #pragma unroll
-      for (int j = 0; j < T; ++j) *reinterpret_cast<float4*>(img + (kq * T + j) * FT<T>::RCP + rq * 8) = v[j];
+      for (int j = 0; j < T; ++j) *reinterpret_cast<f32x4*>(img + (kq * T + j) * FT<T>::RCP + rq * 8) = v[j];
     }
   } else if constexpr (KC) {
 #pragma unroll
@@ -515,42 +551,64 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
     bn_pre[j] = d.bias_n ? d.bias_n[obn + (n < d.N ? n : d.N - 1)] : 0.f;
   }
 
+  // Round 3: the k-loop keeps FPF k-tiles in flight in registers (a ring of FPF register sets), not one.  With one, every 32-wide
+  // k-tile cost a full memory round trip (8 MFMAs hide ~0.1 us of it): the K = 768 text projection took 31 us for 20 MB, the K = 256
+  // layer-1 input projection 28-32 us.  Every request is unconditional (a tile index past the last one re-reads the last tile into
+  // registers that are never stored) so that the compiler's vmcnt counts stay exact: the store of tile k + 1 waits for that tile only.
   auto segment = [&](const float* __restrict__ Ap, long sa, const float* __restrict__ Bp, long sb, int K, int kt0, int kt1, int ga_at, int ga) {
-    float4 ra[FT<TM>::NV], rb[FT<TN>::NV];
+    constexpr int LA = FL<TM, ABF>::N, LB = FL<TN, BBF>::N;
+    f32x4 ra[FPF][LA], rb[FPF][LB];
     if (kt0 >= kt1) return;
-    fast_load<TM, AKC, ABF>(Ap, sa, m0, d.M, ga_at, ga, K, kt0 * FBK, tid, ra);
-    fast_load<TN, BKC, BBF>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, kt0 * FBK, tid, rb);
-    fast_store<TM, AKC, ABF, F16>(ra, sA[0], tid);
-    fast_store<TN, BKC, BBF, F16>(rb, sB[0], tid);
+    const int last = kt1 - 1;
+    auto request = [&](auto J, int kt) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      const int t = kt < last ? kt : last;
+      fast_load<TM, AKC, ABF>(Ap, sa, m0, d.M, ga_at, ga, K, t * FBK, tid, ra[j]);
+      fast_load<TN, BKC, BBF>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, t * FBK, tid, rb[j]);
+    };
+    // set j holds tile kt (clamped like the request): FPF - 1 newer sets may still be in flight behind it
+    auto publish = [&](auto J, int buf, int kt) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;
+      const int t = kt < last ? kt : last;
+      fast_wait<LA, (FPF - 1) * (LA + LB) + LB>(ra[j]);
+      fast_wait<LB, (FPF - 1) * (LA + LB)>(rb[j]);
+      fast_fix<TM, AKC, ABF>(m0, d.M, K, t * FBK, tid, ra[j]);
+      fast_fix<TN, BKC, BBF>(n0, d.N, K, t * FBK, tid, rb[j]);
+      fast_store<TM, AKC, ABF, F16>(ra[j], sA[buf], tid);
+      fast_store<TN, BKC, BBF, F16>(rb[j], sB[buf], tid);
+    };
+    gemm_static_for<0, FPF>([&](auto J) __attribute__((always_inline)) { request(J, kt0 + decltype(J)::value); });
+    publish(std::integral_constant<int, 0>{}, 0, kt0);
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (kt - kt0) & 1;
-      const bool more = kt + 1 < kt1;
-      if (more) {
-        fast_load<TM, AKC, ABF>(Ap, sa, m0, d.M, ga_at, ga, K, (kt + 1) * FBK, tid, ra);
-        fast_load<TN, BKC, BBF>(Bp, sb, n0, d.N, 0x7fffffff, 0, K, (kt + 1) * FBK, tid, rb);
-      }
+    int cur = 0;
+    for (int kb = kt0; kb < kt1; kb += FPF) {
+      bool done = false;
+      gemm_static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value;
+        const int kt = kb + j;
+        if (done || kt >= kt1) { done = true; return; }
+        request(J, kt + FPF);                       // set j was published one iteration ago: free
 #pragma unroll
-      for (int s = 0; s < FBK / 16; ++s) {
-        bf16x8 af[TM], bfr[TN];
+        for (int s = 0; s < FBK / 16; ++s) {
+          bf16x8 af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = fast_frag<TM, AKC>(sA[cur], wm * 32 * TM + i * 32, s, lane);
+          for (int i = 0; i < TM; ++i) af[i] = fast_frag<TM, AKC>(sA[cur], wm * 32 * TM + i * 32, s, lane);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = fast_frag<TN, BKC>(sB[cur], wn * 32 * TN + j * 32, s, lane);
+          for (int jn = 0; jn < TN; ++jn) bfr[jn] = fast_frag<TN, BKC>(sB[cur], wn * 32 * TN + jn * 32, s, lane);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bfr[j]), acc[i][j], 0, 0, 0);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-          }
-      }
-      if (more) {
-        fast_store<TM, AKC, ABF, F16>(ra, sA[cur ^ 1], tid);
-        fast_store<TN, BKC, BBF, F16>(rb, sB[cur ^ 1], tid);
-      }
-      __syncthreads();
+            for (int jn = 0; jn < TN; ++jn) {
+              if constexpr (F16) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bfr[jn]), acc[i][jn], 0, 0, 0);
+              else acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
+            }
+        }
+        publish(std::integral_constant<int, (j + 1) % FPF>{}, cur ^ 1, kt + 1);   // tile kt + 1 (past the end: the last tile again, never read)
+        __syncthreads();
+        cur ^= 1;
+      });
     }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the ring's last (duplicate) requests: nothing may land in a dead register
   };
   {
     const int ktiles = (d.K + FBK - 1) / FBK;

@@ -62,6 +62,43 @@ __device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* s
   }
 }
 
+// The same mix with the (padded) weights held in REGISTERS: a caller whose loop also stores to LDS (the fused CubeMLP forward writes its
+// tile in place) would otherwise re-read all ~60 weight words from LDS for every (l, d) pair -- the stores may alias them
+template <int NK>
+struct KMixRegs {
+  float w1[NK][NK], b1[NK], w2[NK][NK], b2[NK], wr[NK][NK], g[NK], be[NK];
+  __device__ __forceinline__ void load(const float* sw) {
+    const float* pw1 = sw; const float* pb1 = pw1 + KM * KM; const float* pw2 = pb1 + KM; const float* pb2 = pw2 + KM * KM;
+    const float* pwr = pb2 + KM; const float* pg = pwr + KM * KM; const float* pbe = pg + KM;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      b1[i] = pb1[i]; b2[i] = pb2[i]; g[i] = pg[i]; be[i] = pbe[i];
+#pragma unroll
+      for (int j = 0; j < NK; ++j) { w1[i][j] = pw1[i * KM + j]; w2[i][j] = pw2[i * KM + j]; wr[i][j] = pwr[i * KM + j]; }
+    }
+  }
+};
+// (the ln_first = false, NK = ik = hk = ok form only: the fused forward kernel's case)
+template <int NK>
+__device__ __forceinline__ void kmix_forward_regs(const KMixW& w, const KMixRegs<NK>& q, KMixVals<NK>& v) {
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    float s = q.b1[j];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) s += q.w1[j][k] * v.x[k];
+    v.u[j] = s; v.h[j] = act_apply(w.act, s);
+  }
+#pragma unroll
+  for (int o = 0; o < NK; ++o) {
+    float s = q.b2[o], rr = 0.f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) s += q.w2[o][j] * v.h[j];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) rr += q.wr[o][k] * v.x[k];
+    v.y[o] = v.sc[o] * s + rr;
+  }
+}
+
 __device__ __forceinline__ void kmix_stage_weights(const KMixW& w, float* sw) {
   for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sw[i] = 0.f;
   __syncthreads();

@@ -945,7 +945,10 @@ int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   if (!w.wr && w.ik != w.ok) return set_error(MIMRL_ERR_ARG, "kmix: identity residual needs ik == ok");
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
-  if (mx <= 4) hipLaunchKernelGGL(kmix_fwd_kernel<4>, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
+  // (array sizes = loop trip counts of the per-element MLP: the model's K = 3 padded to 4 is 16 products where 9 are needed, and these
+  //  kernels are VALU-bound)
+  if (mx <= 3) hipLaunchKernelGGL(kmix_fwd_kernel<3>, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
+  else if (mx <= 4) hipLaunchKernelGGL(kmix_fwd_kernel<4>, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
   else hipLaunchKernelGGL(kmix_fwd_kernel<8>, dim3(grid_for(R * D)), dim3(256), 0, s, x, z, w, R, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
@@ -954,7 +957,8 @@ int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w,
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
   static const int wgs = getenv("MIMRL_KMIX_BWD_WGS") ? atoi(getenv("MIMRL_KMIX_BWD_WGS")) : 512;   // tuning knob
-  if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  else if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   else hipLaunchKernelGGL((kmix_bwd_kernel<8, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   LAUNCH_CHECK();
   return MIMRL_OK;
@@ -967,7 +971,8 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
   if (part == 1) {
     static const int dx_wgs = getenv("MIMRL_KMIX_DX_WGS") ? atoi(getenv("MIMRL_KMIX_DX_WGS")) : 4096;   // tuning knob
     const dim3 grid(grid_for(R * D, 256, dx_wgs));
-    if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+    if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+    else if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else hipLaunchKernelGGL((kmix_bwd_kernel<8, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
   } else {
     // workgroup count (tuning knob).  The kernel is ~33 us of fixed cost (weight staging, 64 wave reductions, LDS and global
@@ -977,7 +982,8 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
     static const int pg_wgs = getenv("MIMRL_KMIX_PG_WGS") ? atoi(getenv("MIMRL_KMIX_PG_WGS")) : 256;
     const int cap = pg_wgs > 0 ? pg_wgs : 256;
     const dim3 grid(grid_for(R * D, 256, cap));
-    if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+    if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
+    else if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else hipLaunchKernelGGL((kmix_bwd_kernel<8, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
   }
   LAUNCH_CHECK();

@@ -1,0 +1,40 @@
+"""In-kernel phase times of the fused CubeMLP forward (run on the GPU box with a `make PHASE_PROBE=1` build of the library:
+tools/cube_phase.sh).  Workgroup 0 of the last launch of every instantiation leaves 100 MHz ticks at its phase boundaries."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+def main():
+    from mimrl_amd.engine import HipEngine
+    from mimrl_amd import synth
+    wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    opt, N = bench.workload(wl)
+    B, T = opt.batch_size, opt.time_len
+    eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=N, precision="bf16", seed=1234, device_anchors=True)
+    eng.load_params(synth.default_state([(n, tuple(v.shape)) for n, v in eng.params.items()], 0))
+    eng.set_batch(*synth.synthetic_batch(B, T, seed=0))
+    banks = synth.synthetic_banks(N, seed=0)
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    eng.set_stage2_prefetch(1)
+    for _ in range(30):
+        eng.step()
+    torch.cuda.synchronize()
+    from mimrl_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_longlong * 128)()
+    lib.mimrl_dbg_cube_phases.argtypes = [C.POINTER(C.c_longlong)]
+    assert lib.mimrl_dbg_cube_phases(buf) == 0
+    names = ["entry", "tile+L weights", "phase L", "phase K", "Az images", "H = act(Z W1)", "Y = H W2 + Z Wr", "LayerNorm D / end"]
+    for save in (0, 1):
+        for nmt in (1, 2, 3):
+            o = save * 64 + (nmt - 1) * 16
+            t = [buf[o + i] for i in range(8)]
+            if t[0] == 0:
+                continue
+            print(f"cube_fwd_fused<save={save}, row tiles={nmt}>: total {(t[7] - t[0]) * 0.01:.2f} us")
+            for i in range(1, 8):
+                print(f"    {names[i]:22s} {(t[i] - t[i - 1]) * 0.01:7.2f} us")
+
+if __name__ == "__main__":
+    main()
