@@ -831,7 +831,10 @@ int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const f
   const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v};
   static const bool old_kernel = getenv("MIMRL_LN_BWD_WAVE_ROWS") != nullptr;   // tuning knob: the one-row-per-wave kernel of round 2
   if (old_kernel) hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
-  else hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, 1024), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
+  else {
+    static const int cap = getenv("MIMRL_LN_BWD_BLOCKS") ? atoi(getenv("MIMRL_LN_BWD_BLOCKS")) : 128;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)
+    hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, cap), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
+  }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
