@@ -531,6 +531,13 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
     for (int d = 0; d < 2; ++d)
       if ((a.seq[m][d].saved != nullptr) != save) return set_error(MIMRL_ERR_ARG, "gru_forward: saved slabs must be all set or all null");
   if (bf16) {
+    static const int fpad_kb = getenv("MIMRL_GRU_FWD_LDS_PAD") ? atoi(getenv("MIMRL_GRU_FWD_LDS_PAD")) : 0;   // tuning knob (experiment), as above
+    if (save && fpad_kb > 0) {
+      static bool attr = false;
+      auto kern = gru_fwd_kernel<true, true>;
+      if (!attr) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fpad_kb * 1024)); attr = true; }
+      hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)fpad_kb * 1024, s, a);
+    } else
     if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gru_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
   } else {
@@ -546,6 +553,19 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   if (a.btv < 1 || a.btv > BR) return set_error(MIMRL_ERR_ARG, "gru_backward: btv must be in [1,4]");
   dim3 grid((a.B + a.btv - 1) / a.btv, 2, a.nmod);
   if (a.dg_bf16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_backward: bf16 dg / h_prev storage needs the bf16 recurrence mode");
+  // LDS padding (round 3b): a BPTT launch that covers at most half of the CUs (cfg2: 128 workgroups) asks for 144 KiB of dynamic LDS it never
+  // touches, so that no LDS-using kernel parked beside the recurrence (the weight-gradient GEMMs) becomes resident on ITS CUs and shares
+  // its SIMDs: alone the two launches take 45 + 48 us, with the parked kernels on the same CUs 51 + 66 us.  cfg2: 0.916-0.917 -> 0.907-0.911 ms
+  // per step.  Larger launches keep their CUs shareable (at cfg3 every CU has a BPTT workgroup and the parked work needs a place).
+  // MIMRL_GRU_LDS_PAD=<KiB> overrides (0 = off).
+  static const int pad_env = getenv("MIMRL_GRU_LDS_PAD") ? atoi(getenv("MIMRL_GRU_LDS_PAD")) : -1;
+  const int pad_kb = pad_env >= 0 ? pad_env : ((long)grid.x * grid.y * grid.z <= 128 ? 144 : 0);
+  if (bf16 && a.dg_bf16 && pad_kb > 0) {
+    static bool attr = false;
+    auto kern = gru_bwd_kernel<true, true>;
+    if (!attr) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)(pad_kb > 150 ? 150 : pad_kb) * 1024, s, a);
+  } else
   if (bf16 && a.dg_bf16) hipLaunchKernelGGL((gru_bwd_kernel<true, true>), grid, dim3(256), 0, s, a);
   else if (bf16) hipLaunchKernelGGL((gru_bwd_kernel<true, false>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gru_bwd_kernel<false, false>), grid, dim3(256), 0, s, a);
