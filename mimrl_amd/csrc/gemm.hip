@@ -756,7 +756,10 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
     const int tm = cand[c][0], tn = cand[c][1];
     if (d.M < 64 * tm || d.N < 64 * tn) continue;
     const long t = tiles(tm, tn);
-    if (t * split(t) >= 224 || c == 2) { pick = c; break; }   // the largest tile that still gives (almost) every CU a workgroup
+    static const long min_wgs = getenv("MIMRL_GEMM_MIN_WGS") ? atol(getenv("MIMRL_GEMM_MIN_WGS")) : 700;   // tuning knob.  Round 3b: 224 -> 700 (cfg2, 4 interleaved runs each: 0.906-0.912 -> 0.886-0.901 ms; 1000 / 1250 the same): a workgroup is a serial prologue - loop - epilogue and a CU overlaps them only ACROSS workgroups, so ~3 per CU beat ~2 larger ones
+    // (not for split-K accumulations over a long reduction: at cfg3's K = 128,000 rows smaller tiles mean more splits and more atomics,
+    //  7.11 -> 7.52 ms with 700 for all)
+    if (t * split(t) >= ((acc && ktiles > 1024) ? 224 : min_wgs) || c == 2) { pick = c; break; }
   }
   p->fast = 1; p->tm = cand[pick][0]; p->tn = cand[pick][1]; p->ca = ca; p->cb = cb;
   p->tiles = tiles(p->tm, p->tn);
