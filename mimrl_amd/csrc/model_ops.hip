@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
   const int slot = sd.slot; const float p = sd.p; const uint32_t stream = sd.stream;
   const float* __restrict__ dmean = sd.dmean;
   const float invT = 1.f / T;
+  const uint32_t rstep = (uint32_t)(*key.step + key.add);   // once (see drop_scale_at)
   __shared__ float sg[D], sb[D];
   const int tid = threadIdx.x, sub = tid & 15, rw = tid >> 4;          // 16 row slots per workgroup
   if (tid < D) { sg[tid] = 0.f; sb[tid] = 0.f; }
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
       const int j = (i < 4 ? c0 : c1 - 4) + i;
       xh[i] = (hv[i] - mu) * rs;
       const float y = xh[i] * gv[i] + bv[i];
-      float dy = dv[i] * drop_scale(p, key, stream, (uint32_t)(r * D + j));
+      float dy = dv[i] * drop_scale_at(p, key, rstep, stream, (uint32_t)(r * D + j));
       dy = y > 0.f ? dy : 0.f;
       ag[i] += dy * xh[i];
       ab[i] += dy;
@@ -225,23 +226,28 @@ __global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __rest
   __shared__ float part[4][D];
   const int b = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float acc0 = 0.f, acc1 = 0.f;
+  const uint32_t rstep = (uint32_t)(*key.step + key.add);   // once (see drop_scale_at)
+  // RPP rows of a wave in flight per pass (round 3b: 2 -> 7; a pass is a dependent load -> LayerNorm -> store round trip and T = 50 was
+  // seven of them per wave: 13 us on the chain of the stage-1 forward).  Rows are still visited in increasing t per wave, so the
+  // temporal means keep their summation order.
+  constexpr int RPP = 7;
   if (slot == 0) {
-    for (int t0 = w; t0 < T; t0 += 8) {
-      float x[2][2];
+    for (int t0 = w; t0 < T; t0 += 4 * RPP) {
+      float x[RPP][2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < RPP; ++q) {
         const int t = t0 + 4 * q < T ? t0 + 4 * q : T - 1;
         const float* src = tp.tx_raw + ((long)b * T + t) * D;
         x[q][0] = src[lane]; x[q][1] = src[lane + 64];
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < RPP; ++q) {
         const int t = t0 + 4 * q;
         if (t < T) {
           const long r = (long)b * T + t;
           float* out = cube + (((long)b * L + t) * K + 0) * D;
-          const float y0 = x[q][0] * drop_scale(tp.p_text, key, 0u, (uint32_t)(r * D + lane));
-          const float y1 = x[q][1] * drop_scale(tp.p_text, key, 0u, (uint32_t)(r * D + lane + 64));
+          const float y0 = x[q][0] * drop_scale_at(tp.p_text, key, rstep, 0u, (uint32_t)(r * D + lane));
+          const float y1 = x[q][1] * drop_scale_at(tp.p_text, key, rstep, 0u, (uint32_t)(r * D + lane + 64));
           out[lane] = y0; out[lane + 64] = y1;
           acc0 += y0; acc1 += y1;
         }
@@ -250,16 +256,16 @@ __global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __rest
   } else {
     const LnSide& sd = slot == 1 ? tp.a : tp.v;
     const float g0 = sd.gamma[lane], g1 = sd.gamma[lane + 64], be0 = sd.beta[lane], be1 = sd.beta[lane + 64];
-    for (int t0 = w; t0 < T; t0 += 8) {
-      float v[2][2];
+    for (int t0 = w; t0 < T; t0 += 4 * RPP) {
+      float v[RPP][2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < RPP; ++q) {
         const int t = t0 + 4 * q < T ? t0 + 4 * q : T - 1;
         const float* hr = sd.h2 + ((long)b * T + t) * 2 * D;
         v[q][0] = hr[lane] + hr[D + lane]; v[q][1] = hr[lane + 64] + hr[D + lane + 64];
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < RPP; ++q) {
         const int t = t0 + 4 * q;
         if (t < T) {                                            // (wave-uniform)
           const long r = (long)b * T + t;
@@ -269,8 +275,8 @@ __global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __rest
           if (lane == 0) { sd.mean[r] = mu; sd.rstd[r] = rs; }
           float* out = cube + (((long)b * L + t) * K + sd.slot) * D;
           float y0 = c0 * rs * g0 + be0, y1 = c1 * rs * g1 + be1;
-          y0 = (y0 > 0.f ? y0 : 0.f) * drop_scale(sd.p, key, sd.stream, (uint32_t)(r * D + lane));
-          y1 = (y1 > 0.f ? y1 : 0.f) * drop_scale(sd.p, key, sd.stream, (uint32_t)(r * D + lane + 64));
+          y0 = (y0 > 0.f ? y0 : 0.f) * drop_scale_at(sd.p, key, rstep, sd.stream, (uint32_t)(r * D + lane));
+          y1 = (y1 > 0.f ? y1 : 0.f) * drop_scale_at(sd.p, key, rstep, sd.stream, (uint32_t)(r * D + lane + 64));
           out[lane] = y0; out[lane + 64] = y1;
           acc0 += y0; acc1 += y1;
         }
@@ -318,18 +324,36 @@ __global__ void feat_mean_bwd_kernel(const float* __restrict__ dfeats, float* __
 }
 
 // ------------------------------------------------------------------ head
+// (round 3b: 512 threads = D columns x 4 row phases for D = 128, each phase a stream of independent loads; one thread per column walking
+//  all L*K rows was an 11 us latency chain on the step's critical path)
 __global__ void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                 float* __restrict__ ff, float* __restrict__ pred, int L, int K, int D, float scale) {
   __shared__ float red[16];
+  __shared__ float ph[4][128];
   const int b = blockIdx.x;
   float part = 0.f;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+  if (D == 128 && blockDim.x == 512) {
+    const int d = threadIdx.x & 127, q = threadIdx.x >> 7, n = L * K;
+    const float* xb = x + (long)b * n * D + d;
     float s = 0.f;
-    const float* xb = x + (long)b * L * K * D + d;
-    for (int i = 0; i < L * K; ++i) s += xb[(long)i * D];
-    s *= scale;
-    ff[(long)b * D + d] = s;
-    part += s * w[d];
+#pragma unroll 8
+    for (int i = q; i < n; i += 4) s += xb[(long)i * D];
+    ph[q][d] = s;
+    __syncthreads();
+    if (q == 0) {
+      s = ((ph[0][d] + ph[1][d]) + (ph[2][d] + ph[3][d])) * scale;
+      ff[(long)b * D + d] = s;
+      part = s * w[d];
+    }
+  } else {
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+      float s = 0.f;
+      const float* xb = x + (long)b * L * K * D + d;
+      for (int i = 0; i < L * K; ++i) s += xb[(long)i * D];
+      s *= scale;
+      ff[(long)b * D + d] = s;
+      part += s * w[d];
+    }
   }
   part = block_sum(part, red);
   if (threadIdx.x == 0) pred[b] = part + bias[0];
@@ -866,7 +890,7 @@ int feat_mean_bwd(hipStream_t s, const float* dfeats, float* dcube, int B, int T
 int head_fwd(hipStream_t s, const float* x, const float* w, const float* bias, float* ff, float* pred, int B, int L,
              int K, int D, int sum_l, int sum_k) {
   const float scale = (sum_l ? 1.f : 1.f / L) * (sum_k ? 1.f : 1.f / K);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(128), 0, s, x, w, bias, ff, pred, L, K, D, scale);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(D == 128 ? 512 : 128), 0, s, x, w, bias, ff, pred, L, K, D, scale);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
