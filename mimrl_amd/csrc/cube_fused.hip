@@ -311,7 +311,8 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
   if (a.dbg_phase == 2) return;
   // ------------------------------------------------------------------ phase K: K-axis mix in place on rows l < ol
   // first D-axis weight image: requested here, a whole phase ahead of its use (it was a bare round trip in front of the D phase)
-  WImg wnext = load_weight128(a.d_w1, (G == 1 ? 0 : grp) * 64, 0, t);
+  WImg wnext;
+  if constexpr (!SAVE) wnext = load_weight128(a.d_w1, (G == 1 ? 0 : grp) * 64, 0, t);   // (the SAVE build has no register to spare across phase K)
   kmix_stage_weights(a.kw, ksw);
   {
     // compile-time K (1..4): the per-pair MLP is fully unrolled over it and this phase is VALU-bound (8 waves on 4 SIMDs)
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     return load_weight128(W, (nt0 + (j >> 1)) * 64, (j & 1) * 64, t);
   };
   bf* Bw2[2] = {reinterpret_cast<bf*>(smem + cv.bw) + (2 * grp) * IMG, reinterpret_cast<bf*>(smem + cv.bw) + (2 * grp + 1) * IMG};
+  if constexpr (SAVE) wnext = wload(0);
   // H = act(Z W1^T + b1): NI1 weight images (nt, kh), each used by all row tiles
 #pragma unroll
   for (int i = 0; i < NI1; ++i) {
