@@ -49,4 +49,8 @@ int daxis_param_grads(hipStream_t s, const float* y, const float* mean, const fl
 int rowln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,
                       float* dbeta, long R, int n);
 
+#ifdef MIMRL_PHASE_PROBE
+int cube_bwd_read_phases(long long* out);   // 64 ticks, see cube_bwd_fused.hip
+#endif
+
 }  // namespace mimrl

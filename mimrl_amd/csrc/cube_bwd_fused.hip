@@ -5,6 +5,15 @@ namespace mimrl {
 
 namespace {
 
+// `make PHASE_PROBE=1` (tools/cube_phase.py): workgroup (0, 0) leaves 100 MHz ticks at phase boundaries of its last launch;
+// slots: L axis 0..15 (ol <= 32) / 16..31 (ol > 32), D axis 32..47 (<= 200 workgroups) / 48..63
+#ifdef MIMRL_PHASE_PROBE
+__device__ long long g_cbwd_phase[64];
+#define BPHASE(base, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cbwd_phase[(base) + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define BPHASE(base, i) do { } while (0)
+#endif
+
 constexpr int CT = 128;       // L axis: columns per workgroup
 constexpr int KP = 64 + 8;    // bf16 pitch of a [.][<=64] operand image (144 B: conflict-free 16-byte fragment reads)
 
@@ -24,6 +33,8 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y, c0 = blockIdx.x * CT;
   const int il = a.il, hl = a.hl, ol = a.ol, C = a.C;
+  const int pb = ol > 32 ? 16 : 0;
+  BPHASE(pb, 0);
 
   // pre-activations for act'(U) of phase 2 (this wave's 32 columns x up to 64 rows h): requested before anything else
   // -- loaded in that phase's epilogue they were a dependent memory round trip in the middle of the kernel
@@ -45,10 +56,12 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
     if (tid < 64) { acc_l[0][tid] = 0.f; acc_l[1][tid] = 0.f; acc_l[2][tid] = 0.f; acc_h[tid] = 0.f; }
   }
   __syncthreads();
+  BPHASE(pb, 1);
   for (int idx = tid; idx < ol * hl; idx += 256) { const int o = idx / hl, h = idx - o * hl; wts[0][h][o] = to_bf16(a.w2[idx]); }
   for (int idx = tid; idx < hl * il; idx += 256) { const int h = idx / il, i = idx - h * il; wts[1][i][h] = to_bf16(a.w1[idx]); }
   for (int idx = tid; idx < ol * il; idx += 256) { const int o = idx / il, i = idx - o * il; wts[2][i][o] = to_bf16(a.wr[idx]); }
 
+  BPHASE(pb, 2);
   // ---- phase 1: LayerNorm over L, backward.  Thread = (column, half of the rows l = half, half+2, ...); two passes over
   // the (L2-resident) column instead of 64 live registers
   const int col = tid & (CT - 1), half = tid >> 7;
@@ -57,24 +70,36 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   const float* __restrict__ dzb = a.dz + (long)b * ol * C + c0 + col;
   const float* __restrict__ yb = a.y + (long)b * ol * C + c0 + col;
   float* __restrict__ dyb = a.dy + (long)b * ol * C + c0 + col;
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-  for (int l = half; l < ol; l += 2) {
-    const float gq = dzb[(long)l * C], xq = (yb[(long)l * C] - mu) * rs;
-    const float dxh = gq * a.gamma[l];
-    s1 += dxh; s2 += dxh * xq;
+  // Round 3b (tools/cube_phase.py: 9.2 + 6.1 of this kernel's 29 us per workgroup at ol = 50): the thread's <= 32 rows of dz and y are
+  // requested in ONE batch and stay in registers for the second pass -- they were four 8-row batches (four round trips), read twice
+  float gq[32], xq[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int l = min(half + 2 * j, ol - 1);          // clamped, unconditional (rows beyond ol are masked below)
+    gq[j] = dzb[(long)l * C]; xq[j] = yb[(long)l * C];
   }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int l = half + 2 * j;
+    xq[j] = (xq[j] - mu) * rs;
+    gq[j] = l < ol ? gq[j] * a.gamma[min(l, ol - 1)] : 0.f;
+    s1 += gq[j]; s2 += gq[j] * xq[j];
+  }
+  BPHASE(pb, 3);
   red[0][half][col] = s1;
   red[1][half][col] = s2;
   __syncthreads();
   s1 = (red[0][0][col] + red[0][1][col]) / ol;
   s2 = (red[1][0][col] + red[1][1][col]) / ol;
-#pragma unroll 8
-  for (int l = half; l < ol; l += 2) {   // no guard inside the loop: the loads of an unrolled batch go out together
-    const float gq = dzb[(long)l * C], xq = (yb[(long)l * C] - mu) * rs;
-    const float v = rs * (gq * a.gamma[l] - s1 - xq * s2);
-    dyb[(long)l * C] = v;
-    sdy[col][l] = to_bf16(v);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int l = half + 2 * j;
+    if (l < ol) {
+      const float v = rs * (gq[j] - s1 - xq[j] * s2);
+      dyb[(long)l * C] = v;
+      sdy[col][l] = to_bf16(v);
+    }
   }
   for (int l = ol + ((half ^ ol) & 1); l < 64; l += 2) sdy[col][l] = to_bf16(0.f);   // rows l >= ol: zero padding of the K axis
   __syncthreads();
@@ -84,6 +109,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
     for (int c = 0; c < CT; ++c) t += (float)sdy[(c + tid) & (CT - 1)][tid - 192];
     acc_l[2][tid - 192] = t;
   }
+  BPHASE(pb, 4);
   const int nt = wave;                 // this wave's 32-column tile; it owns both 32-row M tiles of it
   const int cc = c0 + nt * 32 + lr;
   // ---- phase 2: dU = (W2^T dY) * act'(U)
@@ -120,6 +146,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
       }
   }
   __syncthreads();
+  BPHASE(pb, 5);
   // ---- phase 3: dX = W1^T dU + Wr^T dY
   {
     f32x16 acc0, acc1;
@@ -146,11 +173,17 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
       }
   }
   __syncthreads();
+  BPHASE(pb, 6);
   if (a.db2 && tid < ol) atomicAdd(&a.db2[tid], acc_l[2][tid]);
   if (a.db1 && tid >= 64 && tid - 64 < hl) atomicAdd(&a.db1[tid - 64], acc_h[tid - 64]);
+  BPHASE(pb, 7);
 }
 
 }  // namespace
+
+#ifdef MIMRL_PHASE_PROBE
+int cube_bwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cbwd_phase), sizeof(long long) * 64) == hipSuccess ? 0 : 1; }
+#endif
 
 bool laxis_bwd_supported(int il, int hl, int ol, int C) {
   return il >= 1 && hl >= 1 && ol >= 1 && il <= 64 && hl <= 64 && ol <= 64 && C % CT == 0;
@@ -181,8 +214,23 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const long r0 = (long)blockIdx.x * DR;
   const bool pg = a.dgamma != nullptr;
+  const int pb = gridDim.x <= 200 ? 32 : 48;
+  BPHASE(pb, 0);
   if (pg) for (int i = tid; i < 3 * 128; i += 256) (&spg[0][0])[i] = 0.f;   // (visible after the barrier behind phase 1... see below)
-  // B-fragments of this wave's 32 output columns, all three products, issued before anything else
+  // Round 3b: the LayerNorm's own operands go out FIRST (loads return in order: behind the 24 weight fragments and the 16 u values they
+  // were the last to arrive although phase 1 is the first to need them)
+  const int row1 = tid >> 3, part1 = tid & 7;
+  const long r1 = r0 + row1;
+  const bool ok1 = r1 < a.R;
+  const long rc1 = ok1 ? r1 : a.R - 1;
+  const float mu1 = a.mean[rc1], rs1 = a.rstd[rc1];
+  float4 gz4[4], yv4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    gz4[q] = *reinterpret_cast<const float4*>(a.dz + rc1 * 128 + part1 * 16 + q * 4);
+    yv4[q] = *reinterpret_cast<const float4*>(a.y + rc1 * 128 + part1 * 16 + q * 4);
+  }
+  // B-fragments of this wave's 32 output columns, all three products
   const int n = wave * 32 + lr;
   bf16x8 bw2[8], bw1[8], bwr[8];
 #pragma unroll
@@ -200,19 +248,19 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
     const long row = min(r0 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.R - 1);
     uu[r] = a.u[row * 128 + n];
   }
+  BPHASE(pb, 1);
   // ---- phase 1: LayerNorm over D, backward: 8 threads per row, 16 consecutive columns each
   {
-    const int row = tid >> 3, part = tid & 7;
-    const long r = r0 + row;
-    const bool ok = r < a.R;
-    const long rc = ok ? r : a.R - 1;
+    const int row = row1, part = part1;
+    const long r = r1;
+    const bool ok = ok1;
     float g[16], xh[16], dyk[16];
     float s1 = 0.f, s2 = 0.f;
-    const float mu = a.mean[rc], rs = a.rstd[rc];
+    const float mu = mu1, rs = rs1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 gz = *reinterpret_cast<const float4*>(a.dz + rc * 128 + part * 16 + q * 4);
-      const float4 yv = *reinterpret_cast<const float4*>(a.y + rc * 128 + part * 16 + q * 4);
+      const float4 gz = gz4[q];
+      const float4 yv = yv4[q];
       const float gg[4] = {gz.x, gz.y, gz.z, gz.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -254,6 +302,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
     }
   }
   __syncthreads();
+  BPHASE(pb, 2);
   // ---- phase 2: dU = (dY W2) * act'(U)
   {
     f32x16 acc;
@@ -283,6 +332,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
     }
   }
   __syncthreads();
+  BPHASE(pb, 3);
   if (pg && tid < 128) {   // (spg complete: every wave's LDS atomics precede the barrier behind phase 1)
     atomicAdd(&a.dgamma[tid], spg[0][tid]);
     atomicAdd(&a.dbeta[tid], spg[1][tid]);
@@ -306,6 +356,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
       if (row < a.R) a.dx[row * 128 + n] = acc[r];
     }
   }
+  BPHASE(pb, 4);
 }
 
 __global__ void wt_transpose_kernel(WtTransposeArgs a) {

@@ -36,5 +36,24 @@ def main():
             for i in range(1, 8):
                 print(f"    {names[i]:22s} {(t[i] - t[i - 1]) * 0.01:7.2f} us")
 
+    b = (C.c_longlong * 64)()
+    lib.mimrl_dbg_cube_bwd_phases.argtypes = [C.POINTER(C.c_longlong)]
+    assert lib.mimrl_dbg_cube_bwd_phases(b) == 0
+    ln = ["entry", "u requests + zero fill", "weight scatter", "LN pass 1", "LN pass 2 -> dY", "dU = W2^T dY * act'", "dX = W1^T dU + Wr^T dY", "bias atomics / end"]
+    for base, what in ((0, "laxis_bwd (ol <= 32: block 2)"), (16, "laxis_bwd (ol > 32: block 1)")):
+        tt = [b[base + i] for i in range(8)]
+        if tt[0]:
+            print(f"{what}: total {(tt[7] - tt[0]) * 0.01:.2f} us")
+            for i in range(1, 8):
+                print(f"    {ln[i]:26s} {(tt[i] - tt[i - 1]) * 0.01:7.2f} us")
+    dn = ["entry", "requests (24 fragments, u)", "LayerNorm D backward", "dU = dY W2 * act'", "dX = dU W1 + dY Wr / end"]
+    for base, what in ((32, "daxis_bwd (<= 200 workgroups: block 2)"), (48, "daxis_bwd (block 1)")):
+        tt = [b[base + i] for i in range(5)]
+        if tt[0]:
+            print(f"{what}: total {(tt[4] - tt[0]) * 0.01:.2f} us")
+            for i in range(1, 5):
+                print(f"    {dn[i]:26s} {(tt[i] - tt[i - 1]) * 0.01:7.2f} us")
+
+
 if __name__ == "__main__":
     main()
