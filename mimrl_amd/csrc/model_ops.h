@@ -97,6 +97,9 @@ struct KMixW {
   int dbg;                                         // debugging only, MIMRL_DBG_KMIX (1: skip the element loop, 2: skip the final atomics; parked MODE 2: 8 / 16 device-scope loads of
                                                    // x / dz, 32 check the LDS weights, 64 / 128 / 256 accumulate x / y / u in place of the LayerNorm-gain term)
 };
+#ifdef MIMRL_PHASE_PROBE
+int kmix_bwd_read_phases(long long* out);   // 16 ticks, see model_ops.hip
+#endif
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D);
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D);
 int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D, int part);   // 1: dx only, 2: parameter gradients only

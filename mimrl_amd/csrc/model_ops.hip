@@ -542,12 +542,20 @@ __global__ __launch_bounds__(256) void kmix_fwd_kernel(const float* __restrict__
 #ifndef KMIX_MINB
 #define KMIX_MINB 1
 #endif
+// `make PHASE_PROBE=1` (tools/cube_phase.py): workgroup 0 of the last kmix_bwd launch leaves 100 MHz ticks (slots 0..7: <= 1000 rows, 8..15)
+#ifdef MIMRL_PHASE_PROBE
+__device__ long long g_kmix_phase[16];
+#define KPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_kmix_phase[(R <= 2000 ? 0 : 8) + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define KPHASE(i) do { } while (0)
+#endif
 template <int NK, int MODE>
 __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                        float* __restrict__ dx, KMixW w, long R, int D) {
   constexpr bool GRADS = MODE != 1, DX = MODE != 2;
   __shared__ float sw[3 * KM * KM + 4 * KM];
   __shared__ float sg[3 * KM * KM + 4 * KM];   // gradient accumulators, same packing
+  KPHASE(0);
   kmix_stage_weights(w, sw);
   for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sg[i] = 0.f;
   __syncthreads();
@@ -560,8 +568,12 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
 #pragma unroll
     for (int j = 0; j < NK; ++j) aw1[i][j] = aw2[i][j] = awr[i][j] = 0.f;
   }
+  KPHASE(1);
   const long total = (GRADS && (w.dbg & 1)) ? 0 : R * D;
   const bool pow2 = (D & (D - 1)) == 0; const int dsh = __ffs(D) - 1;
+  // (tools/cube_phase.py, cfg2 first block, per workgroup: weights 2.2, element loop 14.4, wave reductions + LDS atomics 3.4, global atomics
+  //  0.7 us.  The loop is VALU-bound at three waves per SIMD: requesting four elements per thread in one batch costs 58 registers, one wave
+  //  per SIMD, and the loop went to 16.8 us)
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = pow2 ? (i >> dsh) : i / D; const int d = pow2 ? (int)(i & (D - 1)) : (int)(i % D);   // (64-bit division: ~80 instructions)
     KMixVals<NK> v;
@@ -651,6 +663,7 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
       for (int k = 0; k < NK; ++k) aw1[j][k] += du[j] * (w.ln_first ? v.xn[k] : v.x[k]);
     }
   }
+  KPHASE(2);
   if (!GRADS) return;
   if (MODE == 2 && (w.dbg & 32)) {   // debugging: is the LDS copy of the weights still what was staged?  (+1000 on dbe[0] per mismatch)
     __syncthreads();
@@ -679,7 +692,9 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
     a = wave_sum(ag[i]); if (lane == 0) atomicAdd(&gg[i], a);
     a = wave_sum(abe[i]); if (lane == 0) atomicAdd(&gbe[i], a);
   }
+  KPHASE(3);
   __syncthreads();
+  KPHASE(4);
   const int t = threadIdx.x;
   if (w.dbg & 2) return;
   if (t < w.hk * w.ik) atomicAdd(&w.dw1[t], gw1[(t / w.ik) * KM + t % w.ik]);
@@ -689,6 +704,7 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
   if (t < w.ok * w.ik && w.dwr) atomicAdd(&w.dwr[t], gwr[(t / w.ik) * KM + t % w.ik]);
   const int nln = w.ln_first ? w.ik : w.ok;
   if (t < nln) { atomicAdd(&w.dg[t], gg[t]); atomicAdd(&w.dbe[t], gbe[t]); }
+  KPHASE(5);
 }
 
 // ------------------------------------------------------------------ reductions / misc
@@ -968,6 +984,9 @@ int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* me
   return MIMRL_OK;
 }
 
+#ifdef MIMRL_PHASE_PROBE
+int kmix_bwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kmix_phase), sizeof(long long) * 16) == hipSuccess ? 0 : 1; }
+#endif
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   if (!w.wr && w.ik != w.ok) return set_error(MIMRL_ERR_ARG, "kmix: identity residual needs ik == ok");

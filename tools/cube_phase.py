@@ -53,6 +53,16 @@ def main():
             print(f"{what}: total {(tt[4] - tt[0]) * 0.01:.2f} us")
             for i in range(1, 5):
                 print(f"    {dn[i]:26s} {(tt[i] - tt[i - 1]) * 0.01:7.2f} us")
+    k = (C.c_longlong * 16)()
+    lib.mimrl_dbg_kmix_phases.argtypes = [C.POINTER(C.c_longlong)]
+    assert lib.mimrl_dbg_kmix_phases(k) == 0
+    kn = ["entry", "weights -> LDS, zero accumulators", "element loop", "wave reductions + LDS atomics", "barrier", "global atomics / end"]
+    for base, what in ((0, "kmix_bwd (block 2)"), (8, "kmix_bwd (block 1)")):
+        tt = [k[base + i] for i in range(6)]
+        if tt[0]:
+            print(f"{what}: total {(tt[5] - tt[0]) * 0.01:.2f} us")
+            for i in range(1, 6):
+                print(f"    {kn[i]:34s} {(tt[i] - tt[i - 1]) * 0.01:7.2f} us")
 
 
 if __name__ == "__main__":
