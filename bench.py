@@ -529,6 +529,10 @@ def main():
                 "us_per_cell_step": avg_us / T,
                 "timing": "in-kernel launch stamps over the timed region (mimrl_set_kernel_stamps): replayed hipGraph, the schedule `value` is measured on",
                 "rocprof_avg_launch_us": prof_avg, "rocprof_source": prof_src,
+                # the same fraction priced at rocprofv3's dispatch-to-completion average: since round 3b the launch reserves 144 KiB of LDS per
+                # workgroup (gru.hip), so its workgroups wait in the dispatcher until CUs have drained of parked kernels -- time rocprof counts and
+                # the in-kernel stamps (first workgroup start .. last workgroup end) do not
+                "frac_at_rocprof_avg": (bwd_by / (prof_avg * 1e-6) / 1e9 / PEAK_HBM_GBS) if prof_avg else None,
                 "hbm_view": {"achieved_gbs": bwd_by / (avg_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "frac": hb},
                 "mfma_view": {"achieved_tflops": fl / (avg_us * 1e-6) / 1e12, "peak": peak_mfma, "frac": mf,
                               "mfma_busy_counter": "profiles/r03_pmc_mfma_busy_cfg2.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}}
