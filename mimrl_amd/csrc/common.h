@@ -60,10 +60,15 @@ __device__ __forceinline__ float fast_erf(float x) {
   return copysignf(e, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+// gelu'(x) = Phi(x) + x phi(x).  The exponential inside fast_erf(x / sqrt 2) IS exp(-x^2 / 2), the density's: one v_exp_f32 serves both
+// (the backward epilogues of the CubeMLP kernels evaluate this 16-32 times per lane and are VALU-bound, tools/cube_phase.py)
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
-  return cdf + x * pdf;
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float ex = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);     // exp(-x^2 / 2)
+  const float erfv = copysignf(1.0f - poly * ex, x);
+  return 0.5f * (1.0f + erfv) + x * (0.39894228040143267794f * ex);
 }
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {

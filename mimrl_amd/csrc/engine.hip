@@ -2650,6 +2650,7 @@ const char* mimrl_last_error(void) { return mimrl::last_error_slot().c_str(); }
 int mimrl_dbg_cube_phases(long long* out) { return mimrl::cube_fwd_read_phases(out); }
 int mimrl_dbg_cube_bwd_phases(long long* out) { return mimrl::cube_bwd_read_phases(out); }
 int mimrl_dbg_kmix_phases(long long* out) { return mimrl::kmix_bwd_read_phases(out); }
+int mimrl_dbg_nce_phases(long long* out) { return mimrl::nce_read_phases(out); }
 #endif
 int mimrl_abi_version(void) { return MIMRL_ABI_VERSION; }
 

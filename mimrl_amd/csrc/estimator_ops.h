@@ -90,4 +90,8 @@ struct AdamArgs {
 };
 int adam_step(hipStream_t s, const AdamArgs& a);
 
+#ifdef MIMRL_PHASE_PROBE
+int nce_read_phases(long long* out);   // 8 ticks, see estimator_ops.hip
+#endif
+
 }  // namespace mimrl

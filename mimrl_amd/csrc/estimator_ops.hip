@@ -322,12 +322,17 @@ __global__ __launch_bounds__(1024) void mi_sep_fused_kernel(const float* __restr
 // 4 waves; g(x) and the h(y) tile are staged once into LDS as bf16 (coalesced 16-byte loads), every fragment comes from there.
 // The one-workgroup-per-estimator kernel above is 5 workgroups of serial phases (37 us at B = 128); this one is 5 x B/32.
 constexpr int NXP = 128 + 8;       // bf16 pitch of a staged [.][128] operand (272 B: conflict-free 16-byte fragment reads)
+#ifdef MIMRL_PHASE_PROBE
+__device__ long long g_nce_phase[8];
+#define NPHASE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_nce_phase[i] = (long long)wall_clock64(); } while (0)
+#else
+#define NPHASE(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict__ tout, float* __restrict__ dtout,
                                                          float* __restrict__ mi, float* __restrict__ mil,
                                                          const float* __restrict__ gscale, int B, int do_bwd) {
   extern __shared__ __attribute__((aligned(16))) char nce_smem[];
   __shared__ float red[4];
-  __shared__ float lse_s[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int ti = blockIdx.x, e = blockIdx.y, i0 = ti * 32, nt = B / 32, SP = B + 1;
   __bf16* Xs = reinterpret_cast<__bf16*>(nce_smem);                       // [B][NXP]   g(x), all rows
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
   float* S = reinterpret_cast<float*>(Ys + 32 * NXP);                 // [32][SP]   scores, then their gradient
   const float* __restrict__ X = tout + (long)(2 * e) * B * 128;
   const float* __restrict__ Y = tout + (long)(2 * e + 1) * B * 128 + (long)i0 * 128;
+  NPHASE(0);
   // ---- stage (all loads of a batch in flight together)
   {
     float4 q[4];
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
     }
   }
   __syncthreads();
+  NPHASE(1);
   // ---- scores tile [32 x B]: wave -> column tiles tj = wave, wave + 4, ...
   for (int tj = wave; tj < nt; tj += 4) {
     f32x16 acc;
@@ -376,34 +383,57 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
     for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP + tj * 32 + lr] = acc[r];
   }
   __syncthreads();
-  // ---- row log-sum-exps and this tile's share of  mi = log B + mean_i(s_ii - lse_i)      (VMI.py:162-166)
+  NPHASE(2);
+  // ---- row log-sum-exps, this tile's share of  mi = log B + mean_i(s_ii - lse_i)  (VMI.py:162-166), and dS = gs / B * (I - softmax rows)
+  // in place.  Round 3b (tools/cube_phase.py: 4.1 + 2.0 of 12.1 us): a wave's 8 rows are worked on TOGETHER -- eight independent
+  // max / sum reduction chains the scheduler can interleave instead of eight dependent ones in a row -- and the exponentials of the
+  // sum are kept and scaled into the gradient (one exp per element and no separate pass behind a barrier)
+  const float gsb = (gscale ? gscale[e] : 0.f) / B;
   float part = 0.f;
-  for (int i = wave; i < 32; i += 4) {
-    float mx = -INFINITY;
-    for (int j = lane; j < B; j += 64) mx = fmaxf(mx, S[i * SP + j]);
-    mx = wave_max(mx);
-    float se = 0.f;
-    for (int j = lane; j < B; j += 64) se += __expf(S[i * SP + j] - mx);
-    se = wave_sum(se);
-    const float lse = mx + __logf(se);
-    if (lane == 0) { lse_s[i] = lse; part += S[i * SP + i0 + i] - lse; }
+  {
+    float sv[8][2], mx[8], se[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = wave + 4 * q;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; sv[q][h] = j < B ? S[i * SP + j] : -INFINITY; }
+      mx[q] = fmaxf(sv[q][0], sv[q][1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx[q] = wave_max(mx[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) sv[q][h] = lane + 64 * h < B ? __expf(sv[q][h] - mx[q]) : 0.f;
+      se[q] = sv[q][0] + sv[q][1];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) se[q] = wave_sum(se[q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = wave + 4 * q;
+      const float lse = mx[q] + __logf(se[q]);
+      if (lane == 0) part += S[i * SP + i0 + i] - lse;          // (read before this row is overwritten below: same lane order)
+      if (do_bwd) {
+        const float inv = 1.f / se[q];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = lane + 64 * h;
+          if (j < B) S[i * SP + j] = gsb * ((j == i0 + i ? 1.f : 0.f) - sv[q][h] * inv);
+        }
+      }
+    }
   }
   if (lane == 0) red[wave] = part;
   __syncthreads();
+  NPHASE(3);
   if (tid == 0) {
     const float v = (red[0] + red[1] + red[2] + red[3]) / B + (ti == 0 ? __logf((float)B) : 0.f);
     atomicAdd(&mi[e], v);
     if (mil) atomicAdd(&mil[e], -v);
   }
   if (!do_bwd) return;
-  // ---- dS = gs / B * (I - softmax rows), in place
-  const float gsb = (gscale ? gscale[e] : 0.f) / B;
-  for (int idx = tid; idx < 32 * B; idx += 256) {
-    const int i = idx / B, j = idx - i * B;
-    const float pij = __expf(S[i * SP + j] - lse_s[i]);
-    S[i * SP + j] = gsb * ((j == i0 + i ? 1.f : 0.f) - pij);
-  }
-  __syncthreads();
+  NPHASE(4);
   float* __restrict__ dX = dtout + (long)(2 * e) * B * 128;
   float* __restrict__ dY = dtout + (long)(2 * e + 1) * B * 128 + (long)i0 * 128;
   const int tn = wave;                       // this wave's 32 feature columns in both products
@@ -421,6 +451,7 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) dY[(long)((r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + tn * 32 + lr] = acc[r];
   }
+  NPHASE(5);
   // d g [B x 128] += dS^T [B x 32] . h_tile [32 x 128]   (reduction over this tile's 32 rows: two k-steps)
   for (int tr = 0; tr < nt; ++tr) {
     f32x16 acc;
@@ -437,7 +468,13 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) atomicAdd(&dX[(long)(tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + tn * 32 + lr], acc[r]);
   }
+  NPHASE(6);
 }
+#ifdef MIMRL_PHASE_PROBE
+}  // namespace
+int nce_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nce_phase), sizeof(long long) * 8) == hipSuccess ? 0 : 1; }
+namespace {
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // concat critic, first layer in its separable form

@@ -63,6 +63,13 @@ def main():
             print(f"{what}: total {(tt[5] - tt[0]) * 0.01:.2f} us")
             for i in range(1, 6):
                 print(f"    {kn[i]:34s} {(tt[i] - tt[i - 1]) * 0.01:7.2f} us")
+    q = (C.c_longlong * 8)()
+    lib.mimrl_dbg_nce_phases.argtypes = [C.POINTER(C.c_longlong)]
+    assert lib.mimrl_dbg_nce_phases(q) == 0
+    nn = ["entry", "stage g(x), h(y) tile", "scores (MFMA) -> LDS", "row log-sum-exps", "dS in place", "dh tile = dS . g", "dg += dS^T . h (atomics) / end"]
+    print(f"mi_sep_nce: total {(q[6] - q[0]) * 0.01:.2f} us")
+    for i in range(1, 7):
+        print(f"    {nn[i]:34s} {(q[i] - q[i - 1]) * 0.01:7.2f} us")
 
 
 if __name__ == "__main__":
