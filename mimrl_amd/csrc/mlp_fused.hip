@@ -1013,7 +1013,7 @@ static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wa
 
 // the fragment-image kernel takes: 4 layers, hidden 256, inputs 128 / 384, outputs 128 / 2 / 1, few workgroups; -> 0 or an id
 static int mlp_frag_shape(const MlpFusedArgs& a, bool bwd) {
-  static const bool off = getenv("MIMRL_MLP_NO_FRAG") != nullptr;    // tuning knob: the round-2 kernels
+  const bool off = getenv("MIMRL_MLP_NO_FRAG") != nullptr;    // tuning knob: the round-2 kernels (read per call: tests/test_gpu_fused_oracle.py toggles it)
   if (off || a.nl != 4 || !(bwd ? a.WfT[1] : a.Wf[0]) || !a.Wb[3]) return 0;
   if (a.dims[1] != FR_HID || a.dims[2] != FR_HID || a.dims[3] != FR_HID) return 0;
   const long wgs = (long)((a.rows + RT - 1) / RT) * a.nb;

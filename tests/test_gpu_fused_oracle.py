@@ -288,3 +288,41 @@ def test_cmi_classifiers_vs_rounded_oracle(name, stage):
     gs = max(v["scale"] for v in gt.values())
     bad = {k: v for k, v in gt.items() if not tensor_ok(v, TOL, gs, v["chaos"])}
     assert not bad, (key, {k: (v["max_rel_scale"], v["l2_rel"], v["chaos"]) for k, v in bad.items()})
+
+
+@pytest.mark.parametrize("name", ["cfg2_sep", "tiny_odd"])
+def test_fragment_image_mlp_kernel_equals_the_staged_one(name, monkeypatch):
+    """mlp_frag_kernel (round 3b: shapes as template parameters, weights from MFMA-fragment-order images) against mlp_img8_kernel / the
+    4-wave kernel it replaced (MIMRL_MLP_NO_FRAG=1), through the engine's own estimator paths: CMI classifiers and MI towers, forward
+    values and every gradient the probes return, stage 1 and stage 2, full and ragged (tiny_odd) row tiles.  Same products, same
+    rounding points; what may differ is the order of the float atomics of the bias / weight-gradient accumulation."""
+    c, opt, batch, banks = case(name)
+    n = (c["B"] // opt.k_neighbor) * opt.k_neighbor
+    g = torch.Generator().manual_seed(11)
+    cin = 0.4 * torch.randn(6, 2 * n, 384, generator=g, dtype=torch.float64)
+    out = {}
+    for tag in ("frag", "img8"):
+        if tag == "img8":
+            monkeypatch.setenv("MIMRL_MLP_NO_FRAG", "1")
+        else:
+            monkeypatch.delenv("MIMRL_MLP_NO_FRAG", raising=False)
+        eng = HipEngine(opt, 768, 74, 35, seq_len=c["T"], bank_capacity=c["N"], precision="bf16")
+        p = perturbed_params(opt, c["seed"])
+        eng.load_params(p)
+        res = {}
+        for stage in (1, 2):
+            r = eng.probe_cmi(stage, cin)
+            torch.cuda.synchronize()
+            res[f"cmi{stage}/logits"] = r["logits"].double().cpu()
+            if stage == 1:
+                for k in p:
+                    if k.startswith("vcmi_estimator_"):
+                        res[f"cmi1/{k}"] = eng.grads[k].double().cpu().clone()
+            else:
+                res["cmi2/dcin"] = r["dcin"][:, :n].double().cpu()
+        out[tag] = res
+        eng.close()
+    for k, a in out["frag"].items():
+        b = out["img8"][k]
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
