@@ -87,6 +87,25 @@ __device__ __forceinline__ float act_grad(int act, float u) {
     default: return 1.f;
   }
 }
+// Activation known at compile time (ACT >= 0) or not (ACT < 0: the run-time switch).  Round 3b: an epilogue that calls act_apply(act, u) per
+// element carries the whole switch -- three activations, ~13 scalar branches -- in every unrolled iteration; the fused CubeMLP forward spent
+// ~200 cycles per element there (7.9 us of block 1's 50).  act_dispatch() branches ONCE around the loop: GELU (the model's activation) gets
+// its own straight-line copy, everything else the generic one.
+template <int ACT>
+__device__ __forceinline__ float act_apply_c(int act, float x) {
+  if constexpr (ACT == ACT_GELU) return gelu_f(x);
+  else return act_apply(act, x);
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_c(int act, float u) {
+  if constexpr (ACT == ACT_GELU) return gelu_grad_f(u);
+  else return act_grad(act, u);
+}
+template <int V> struct ActTag { static constexpr int value = V; };
+template <class F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
+  if (act == ACT_GELU) f(ActTag<ACT_GELU>{}); else f(ActTag<-1>{});
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 // hardware-rate versions for the recurrent gate math: v_exp_f32 + v_rcp_f32 (~1 ulp each), no IEEE division, no libm
 __device__ __forceinline__ float fast_sigmoid(float x) {

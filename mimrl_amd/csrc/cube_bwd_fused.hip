@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
       }
     }
+    act_dispatch(a.act, [&](auto AT) __attribute__((always_inline)) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
         float v = 0.f;
         if (h < hl) {
           const long ui = ((long)b * hl + h) * C + cc;
-          v = (mt == 0 ? acc0[r] : acc1[r]) * act_grad(a.act, uu[mt][r]);
+          v = (mt == 0 ? acc0[r] : acc1[r]) * act_grad_c<decltype(AT)::value>(a.act, uu[mt][r]);
           a.du[ui] = v;
         }
         sdu[nt * 32 + lr][h] = to_bf16(v);
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
           if (lr == 16 && h < hl) atomicAdd(&acc_h[h], t);
         }
       }
+    });
   }
   __syncthreads();
   BPHASE(pb, 5);
@@ -314,18 +316,20 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw2[ks], acc, 0, 0, 0);
     }
     float csum = 0.f;
+    act_dispatch(a.act, [&](auto AT) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const long row = r0 + m;
       float v = 0.f;
       if (row < a.R) {
-        v = acc[r] * act_grad(a.act, uu[r]);
+        v = acc[r] * act_grad_c<decltype(AT)::value>(a.act, uu[r]);
         a.du[row * 128 + n] = v;
       }
       sdu[m][n] = to_bf16(v);
       csum += v;
     }
+    });
     if (pg) {   // db1[n] = sum over this tile's rows of dU (rows beyond R contributed zeros)
       csum += __shfl_xor(csum, 32, 64);
       if (lh == 0) atomicAdd(&a.db1[n], csum);

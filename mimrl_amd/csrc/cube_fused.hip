@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       *reinterpret_cast<f16x8*>(Bx + n * ILD + kg + 8) = hi;
     }
     __syncthreads();
+    if (nb == 0) CPHASE(8);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -227,27 +228,30 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       mma64(acc, Aw + 0 * IMG, Bx, wm, wn, lane);
       // U = acc + b1 ; H = act(U) -> Bh[n][m] (B-image of the second product), saved tensors to HBM
       const int n = wn * 32 + (lane & 31);
+      act_dispatch(a.act, [&](auto AT) __attribute__((always_inline)) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f16x4 p;
+        for (int g = 0; g < 4; ++g) {
+          f16x4 p;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = acc_row(4 * g + q, wm, lane);
-          float h = 0.f;
-          if (m < hl) {
-            const float u = acc[4 * g + q] + prm[m];
-            h = act_apply(a.act, u);
-            if (SAVE) {
-              a.l_u[((long)b * hl + m) * C + n0 + n] = u;
-              a.l_h[((long)b * hl + m) * C + n0 + n] = h;
+          for (int q = 0; q < 4; ++q) {
+            const int m = acc_row(4 * g + q, wm, lane);
+            float h = 0.f;
+            if (m < hl) {
+              const float u = acc[4 * g + q] + prm[m];
+              h = act_apply_c<decltype(AT)::value>(a.act, u);
+              if (SAVE) {
+                a.l_u[((long)b * hl + m) * C + n0 + n] = u;
+                a.l_h[((long)b * hl + m) * C + n0 + n] = h;
+              }
             }
+            p[q] = to_f16(h);
           }
-          p[q] = to_f16(h);
+          *reinterpret_cast<f16x4*>(Bh + n * ILD + wm * 32 + 8 * g + 4 * (lane >> 5)) = p;
         }
-        *reinterpret_cast<f16x4*>(Bh + n * ILD + wm * 32 + 8 * g + 4 * (lane >> 5)) = p;
-      }
+      });
     }
     __syncthreads();
+    if (nb == 0) CPHASE(9);
     if (on) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       }
     }
     __syncthreads();
+    if (nb == 0) CPHASE(10);
     {   // LayerNorm over the L axis (rows m < ol) for each of the 64 columns; 4 threads per column, rows in registers
       const int n = t & 63, q = t >> 6;
       float yv[16];
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       }
     }
     __syncthreads();
+    if (nb == 0) CPHASE(11);
   }
 
   CPHASE(2);
@@ -406,6 +412,8 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) mma64(acc[mt][q], Az + (mt * 2 + kh) * IMG, Bw2[i & 1], wm, wn, lane);
   }
+  CPHASE(12);
+  act_dispatch(a.act, [&](auto AT) __attribute__((always_inline)) {
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
         float h = 0.f;
         if (row < R) {
           const float u = acc[mt][q][r] + b1;
-          h = act_apply(a.act, u);
+          h = act_apply_c<decltype(AT)::value>(a.act, u);
           if (SAVE) {
             a.d_u[((long)b * R + row) * D + col] = u;
             a.d_h[((long)b * R + row) * D + col] = h;
@@ -428,6 +436,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
         acc[mt][q][r] = 0.f;
       }
     }
+  });
   __syncthreads();
   CPHASE(5);
   if (a.dbg_phase == 4) return;

@@ -35,6 +35,10 @@ def main():
             print(f"cube_fwd_fused<save={save}, row tiles={nmt}>: total {(t[7] - t[0]) * 0.01:.2f} us")
             for i in range(1, 8):
                 print(f"    {names[i]:22s} {(t[i] - t[i - 1]) * 0.01:7.2f} us")
+            x = [buf[o + i] for i in range(8, 13)]
+            if x[0]:
+                print(f"      phase L, first round: transpose {(x[0] - t[1]) * 0.01:.2f} | W1.X + act -> H {(x[1] - x[0]) * 0.01:.2f} | W2.H + Wr.X -> tile {(x[2] - x[1]) * 0.01:.2f} | LayerNorm {(x[3] - x[2]) * 0.01:.2f} us")
+                print(f"      H phase: weight images + MFMA {(x[4] - t[4]) * 0.01:.2f} | act epilogue {(t[5] - x[4]) * 0.01:.2f} us")
 
     b = (C.c_longlong * 64)()
     lib.mimrl_dbg_cube_bwd_phases.argtypes = [C.POINTER(C.c_longlong)]
