@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
     // compile-time K (1..4): the per-pair MLP is fully unrolled over it and this phase is VALU-bound (8 waves on 4 SIMDs)
     auto phase_k = [&](auto NKc) __attribute__((always_inline)) {
       constexpr int NK = decltype(NKc)::value;
+      act_dispatch(a.kw.act, [&](auto AT) __attribute__((always_inline)) {
       KMixRegs<NK> kq;          // weights in registers for the whole loop (see KMixRegs)
       kq.load(ksw);
 #pragma unroll 2
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
         KMixVals<NK> v;
 #pragma unroll
         for (int k = 0; k < NK; ++k) { v.x[k] = (float)Xm[l * XP + k * D + d]; v.sc[k] = 1.f; }
-        kmix_forward_regs<NK>(a.kw, kq, v);    // (cube_fused_supported: never ln_first, ik == hk == ok)
+        kmix_forward_regs<NK, decltype(AT)::value>(a.kw, kq, v);    // (cube_fused_supported: never ln_first, ik == hk == ok)
         float out[NK];
         ln_small<NK>(v.y, NK, kq.g, kq.be, out, v.xh, v.mu, v.rs);
 #pragma unroll
@@ -342,6 +343,7 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
           if (SAVE) a.k_z[(((long)b * ol + l) * NK + o) * D + d] = (float)ob;   // (what the D phase consumed)
         }
       }
+      });
     };
     if (K == 3) phase_k(std::integral_constant<int, 3>{});
     else if (K == 1) phase_k(std::integral_constant<int, 1>{});

@@ -46,7 +46,7 @@ __device__ __forceinline__ void ln_small(const float* v, int n, const float* g, 
 }
 
 // sw: LDS copy of [w1 | b1 | w2 | b2 | wr | g | be] with row stride KM (missing pieces zero / identity)
-template <int NK>
+template <int NK, int ACT = -1>   // ACT >= 0: activation known at compile time (common.h, act_dispatch)
 __device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* sw, KMixVals<NK>& v) {
   const float* w1 = sw; const float* b1 = w1 + KM * KM; const float* w2 = b1 + KM; const float* b2 = w2 + KM * KM;
   const float* wr = b2 + KM; const float* g = wr + KM * KM; const float* be = g + KM;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void kmix_forward_vals(const KMixW& w, const float* s
     float s = b1[j];
 #pragma unroll
     for (int k = 0; k < NK; ++k) s += w1[j * KM + k] * (w.ln_first ? v.xn[k] : v.x[k]);   // padded weights are zero
-    v.u[j] = s; v.h[j] = j < w.hk ? act_apply(w.act, s) : 0.f;
+    v.u[j] = s; v.h[j] = j < w.hk ? act_apply_c<ACT>(w.act, s) : 0.f;
   }
 #pragma unroll
   for (int o = 0; o < NK; ++o) {
@@ -86,14 +86,14 @@ struct KMixRegs {
   }
 };
 // (the ln_first = false, NK = ik = hk = ok form only: the fused forward kernel's case)
-template <int NK>
+template <int NK, int ACT = -1>
 __device__ __forceinline__ void kmix_forward_regs(const KMixW& w, const KMixRegs<NK>& q, KMixVals<NK>& v) {
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
     float s = q.b1[j];
 #pragma unroll
     for (int k = 0; k < NK; ++k) s += q.w1[j][k] * v.x[k];
-    v.u[j] = s; v.h[j] = act_apply(w.act, s);
+    v.u[j] = s; v.h[j] = act_apply_c<ACT>(w.act, s);
   }
 #pragma unroll
   for (int o = 0; o < NK; ++o) {

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
   // (tools/cube_phase.py, cfg2 first block, per workgroup: weights 2.2, element loop 14.4, wave reductions + LDS atomics 3.4, global atomics
   //  0.7 us.  The loop is VALU-bound at three waves per SIMD: requesting four elements per thread in one batch costs 58 registers, one wave
   //  per SIMD, and the loop went to 16.8 us)
+  act_dispatch(w.act, [&](auto AT) __attribute__((always_inline)) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = pow2 ? (i >> dsh) : i / D; const int d = pow2 ? (int)(i & (D - 1)) : (int)(i % D);   // (64-bit division: ~80 instructions)
     KMixVals<NK> v;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
       dzv[o] = o < w.ok ? gv : 0.f;
       v.sc[o] = o < w.ok ? drop_scale(w.drop_p, w.key, w.stream_id, (uint32_t)((r * w.ok + o) * D + d)) : 0.f;
     }
-    kmix_forward_vals<NK>(w, sw, v);
+    kmix_forward_vals<NK, decltype(AT)::value>(w, sw, v);
     if (w.ln_first) {
 #pragma unroll
       for (int o = 0; o < NK; ++o) dyv[o] = dzv[o];
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
       float s = 0.f;
 #pragma unroll
       for (int o = 0; o < NK; ++o) s += w2[o * KM + j] * dym[o];
-      du[j] = j < w.hk ? s * act_grad(w.act, v.u[j]) : 0.f;
+      du[j] = j < w.hk ? s * act_grad_c<decltype(AT)::value>(w.act, v.u[j]) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -663,6 +664,7 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
       for (int k = 0; k < NK; ++k) aw1[j][k] += du[j] * (w.ln_first ? v.xn[k] : v.x[k]);
     }
   }
+  });
   KPHASE(2);
   if (!GRADS) return;
   if (MODE == 2 && (w.dbg & 32)) {   // debugging: is the LDS copy of the weights still what was staged?  (+1000 on dbe[0] per mismatch)
