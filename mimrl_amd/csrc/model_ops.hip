@@ -549,9 +549,13 @@ __device__ long long g_kmix_phase[16];
 #else
 #define KPHASE(i) do { } while (0)
 #endif
-template <int NK, int MODE>
+// EXACT (round 3b): ik = hk = ok = NK, LayerNorm last, no dropout -- the model's configuration.  The kernel argument is copied with those
+// fields set to constants, so every `k < w.ik` select, both `w.ln_first` branches and the dropout hash fold away (the loop is VALU-bound)
+template <int NK, int MODE, bool EXACT = false>
 __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dz,
-                                                       float* __restrict__ dx, KMixW w, long R, int D) {
+                                                       float* __restrict__ dx, KMixW w_, long R, int D) {
+  KMixW w = w_;
+  if constexpr (EXACT) { w.ik = NK; w.hk = NK; w.ok = NK; w.ln_first = 0; w.drop_p = 0.f; }
   constexpr bool GRADS = MODE != 1, DX = MODE != 2;
   __shared__ float sw[3 * KM * KM + 4 * KM];
   __shared__ float sg[3 * KM * KM + 4 * KM];   // gradient accumulators, same packing
@@ -1005,7 +1009,9 @@ int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w,
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
   static const int wgs = getenv("MIMRL_KMIX_BWD_WGS") ? atoi(getenv("MIMRL_KMIX_BWD_WGS")) : 512;   // tuning knob
-  if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  const bool exact3 = w.ik == 3 && w.hk == 3 && w.ok == 3 && !w.ln_first && w.drop_p <= 0.f;
+  if (exact3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0, true>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
+  else if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   else if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   else hipLaunchKernelGGL((kmix_bwd_kernel<8, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   LAUNCH_CHECK();

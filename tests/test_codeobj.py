@@ -25,7 +25,7 @@ def ks():
 
 
 def test_every_tu_is_present(ks):
-    for name in ("gru_fwd_kernel<true, true>", "gru_bwd_kernel<true, true>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0>",
+    for name in ("gru_fwd_kernel<true, true>", "gru_bwd_kernel<true, true>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0, false>",
                  "concat_fwd_kernel<3>", "mlp_img8_kernel<true, 4>", "adam_kernel", "knn_kernel<2, 4>", "lstm_fwd_kernel"):
         assert name in ks, name
     assert len(ks) > 120
@@ -43,7 +43,7 @@ def test_bf16_recurrence_kernels_are_agpr_free(ks):
 def test_bench_path_kernels_do_not_spill(ks):
     hot = ("gemm_fast_kernel<", "gemm_fast_bf_kernel<", "gemm_group_kernel<", "gemm_groupk_kernel<", "cube_fwd_fused_kernel<false, 1, 2>",
            "cube_fwd_fused_kernel<false, 3, 2>", "cube_fwd_fused_kernel<true, 3, 2>", "daxis_bwd_kernel", "laxis_bwd_kernel",
-           "kmix_bwd_kernel<4, 0>", "kmix_bwd_kernel<3, 0>", "mlp_img8_kernel<", "mlp_frag_kernel<", "frag_images_kernel", "mi_sep_nce_kernel", "concat_fwd_kernel<", "concat_bwd_kernel<", "tail_pre_kernel",
+           "kmix_bwd_kernel<4, 0, ", "kmix_bwd_kernel<3, 0, ", "mlp_img8_kernel<", "mlp_frag_kernel<", "frag_images_kernel", "mi_sep_nce_kernel", "concat_fwd_kernel<", "concat_bwd_kernel<", "tail_pre_kernel",
            "adam_kernel", "head_fwd_kernel", "head_bwd_kernel", "cmi_loss_kernel", "daxis_param_grads_kernel", "colln_param_grads_kernel")
     seen = set()
     for name, v in ks.items():
@@ -60,7 +60,7 @@ def test_bench_path_kernels_do_not_spill(ks):
 
 def test_chain_kernel_beside_nothing_register_heavy(ks):
     """kmix_bwd<MODE 0> (K-axis data + parameter gradients, in the chain since round 2b): AGPR-free, no scratch."""
-    for name in ("kmix_bwd_kernel<4, 0>", "kmix_bwd_kernel<3, 0>"):
+    for name in ("kmix_bwd_kernel<4, 0, false>", "kmix_bwd_kernel<3, 0, false>", "kmix_bwd_kernel<3, 0, true>"):
         v = ks[name]
         assert v["agpr_count"] == 0 and v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (name, v)
 
