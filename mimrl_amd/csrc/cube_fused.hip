@@ -163,9 +163,11 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
   // ------------------------------------------------------------------ load the sample tile (bf16), zero-pad rows >= il
   {
     // every request first (L-axis weights, per-row parameters, the tile), then the commits: one round trip
-    WReq w0, w1;                                                      // group 0 (or the only group): W1 and Wr; group 1: W2
-    if (G == 1 || grp == 0) { w0 = stage_weight_request(a.l_w1, il, 0, 0, hl, il, t); w1 = stage_weight_request(a.l_wr, il, 0, 0, ol, il, t); }
-    else w0 = stage_weight_request(a.l_w2, hl, 0, 0, ol, hl, t);
+    // group 0 (or the only group): W1 and Wr; group 1: W2.  ONE unconditional request per register set with the operands selected
+    // beforehand: assigned in the two arms of an if / else, the merge copies the registers and waits for the loads right there
+    const bool g0 = G == 1 || grp == 0;
+    const WReq w0 = stage_weight_request(g0 ? a.l_w1 : a.l_w2, g0 ? il : hl, 0, 0, g0 ? hl : ol, g0 ? il : hl, t);
+    const WReq w1 = stage_weight_request(a.l_wr, il, 0, 0, ol, il, t);     // (group 1 of two requests it too and drops it)
     WReq w2;
     if (G == 1) w2 = stage_weight_request(a.l_w2, hl, 0, 0, ol, hl, t);
     float pr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -175,16 +177,26 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
       pr[2] = tid < ol ? a.l_g[tid] : 0.f;
       pr[3] = tid < ol ? a.l_be[tid] : 0.f;
     }
+    CPHASE(13);
     const float* xb = a.x + (long)b * il * C;
     const int nq = C / 4, total = 64 * nq;
-    constexpr int NQ = 12;                                            // 16-byte pieces per thread and pass: K = 3 (C = 384), two wave groups: ONE pass
+    constexpr int NQ = SAVE ? 6 : 12;   // (SAVE build: two passes -- twelve pieces in flight beside both weight request sets spill five registers)                                            // 16-byte pieces per thread and pass: K = 3 (C = 384), two wave groups: ONE pass
     for (int i0 = tid; i0 < total; i0 += NT * NQ) {
       float4 q[NQ];
+      // UNCONDITIONAL loads from clamped addresses, zeroed afterwards (the rule of DESIGN.md section 4, violated here until round 3b: the
+      // guarded form `cond ? *p : 0` compiled to twelve branches with an s_waitcnt vmcnt(0) behind each load -- twelve serialized
+      // round trips, the 7 us this set-up took)
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
         const int i = i0 + NT * j;
-        const int l = i / nq, c4 = (i - l * nq) * 4;
-        q[j] = (i < total && l < il) ? *reinterpret_cast<const float4*>(xb + (long)l * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ic = i < total ? i : total - 1;
+        const int l = ic / nq, c4 = (ic - l * nq) * 4;
+        q[j] = *reinterpret_cast<const float4*>(xb + (long)(l < il ? l : il - 1) * C + c4);
+      }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int i = i0 + NT * j;
+        if (!(i < total && i / nq < il)) q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
@@ -196,11 +208,12 @@ __global__ __launch_bounds__(256 * G) void cube_fwd_fused_kernel(CubeFusedArgs a
         }
       }
     }
+    CPHASE(14);
     // small per-row / per-column parameters -> LDS once (they sit on the critical path of every epilogue otherwise)
     if (tid < 64) { prm[0 * 64 + tid] = pr[0]; prm[1 * 64 + tid] = pr[1]; prm[2 * 64 + tid] = pr[2]; prm[3 * 64 + tid] = pr[3]; }
     // L-axis weights as A-images [m][k], zero padded to 64x64
-    if (G == 1 || grp == 0) { stage_weight_commit(Aw + 0 * IMG, w0, 0, 0, hl, il, t); stage_weight_commit(Aw + 2 * IMG, w1, 0, 0, ol, il, t); }
-    else stage_weight_commit(Aw + 1 * IMG, w0, 0, 0, ol, hl, t);
+    stage_weight_commit(g0 ? Aw + 0 * IMG : Aw + 1 * IMG, w0, 0, 0, g0 ? hl : ol, g0 ? il : hl, t);
+    if (g0) stage_weight_commit(Aw + 2 * IMG, w1, 0, 0, ol, il, t);
     if (G == 1) stage_weight_commit(Aw + 1 * IMG, w2, 0, 0, ol, hl, t);
   }
   __syncthreads();

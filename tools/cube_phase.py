@@ -35,6 +35,9 @@ def main():
             print(f"cube_fwd_fused<save={save}, row tiles={nmt}>: total {(t[7] - t[0]) * 0.01:.2f} us")
             for i in range(1, 8):
                 print(f"    {names[i]:22s} {(t[i] - t[i - 1]) * 0.01:7.2f} us")
+            y = [buf[o + 13], buf[o + 14]]
+            if y[0]:
+                print(f"      set-up: entry -> weight / parameter requests issued {(y[0] - t[0]) * 0.01:.2f} | tile requested, arrived, converted, stored {(y[1] - y[0]) * 0.01:.2f} | parameters + weight images committed, barrier {(t[1] - y[1]) * 0.01:.2f} us")
             x = [buf[o + i] for i in range(8, 13)]
             if x[0]:
                 print(f"      phase L, first round: transpose {(x[0] - t[1]) * 0.01:.2f} | W1.X + act -> H {(x[1] - x[0]) * 0.01:.2f} | W2.H + Wr.X -> tile {(x[2] - x[1]) * 0.01:.2f} | LayerNorm {(x[3] - x[2]) * 0.01:.2f} us")
