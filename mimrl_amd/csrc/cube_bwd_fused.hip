@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   float (*red)[2][CT] = reinterpret_cast<float (*)[2][CT]>(&sdu[0][0]);   // phase-1 scratch; sdu is first written in phase 2
   __shared__ float acc_l[3][64];   // per-l partial sums of dgamma, dbeta, db2
   __shared__ float acc_h[64];      // per-h partial sums of db1
+  __shared__ float sgam[64];       // LayerNorm gain (tools/isa_lint.py: read from global inside `l < ol ? ... gamma[l]` it was 32 guarded loads, each behind vmcnt(0))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y, c0 = blockIdx.x * CT;
   const int il = a.il, hl = a.hl, ol = a.ol, C = a.C;
@@ -53,13 +54,29 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   {
     uint4* z = reinterpret_cast<uint4*>(&wts[0][0][0]);
     for (int i = tid; i < 3 * 64 * KP * 2 / 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < 64) { acc_l[0][tid] = 0.f; acc_l[1][tid] = 0.f; acc_l[2][tid] = 0.f; acc_h[tid] = 0.f; }
+    if (tid < 64) { acc_l[0][tid] = 0.f; acc_l[1][tid] = 0.f; acc_l[2][tid] = 0.f; acc_h[tid] = 0.f; sgam[tid] = a.gamma[tid < ol ? tid : ol - 1]; }
   }
   __syncthreads();
   BPHASE(pb, 1);
-  for (int idx = tid; idx < ol * hl; idx += 256) { const int o = idx / hl, h = idx - o * hl; wts[0][h][o] = to_bf16(a.w2[idx]); }
-  for (int idx = tid; idx < hl * il; idx += 256) { const int h = idx / il, i = idx - h * il; wts[1][i][h] = to_bf16(a.w1[idx]); }
-  for (int idx = tid; idx < ol * il; idx += 256) { const int o = idx / il, i = idx - o * il; wts[2][i][o] = to_bf16(a.wr[idx]); }
+  {   // (tools/isa_lint.py: as three run-time-trip-count loops of load -> LDS store these were ~30 loads each behind an s_waitcnt vmcnt(0):
+      //  3 us per workgroup.  Now <= 16 elements per thread and matrix, requested together from clamped indices, then scattered)
+    const int n2 = ol * hl, n1 = hl * il, nr = ol * il;
+    float wv[3][16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int idx = tid + 256 * j;
+      wv[0][j] = a.w2[idx < n2 ? idx : n2 - 1];
+      wv[1][j] = a.w1[idx < n1 ? idx : n1 - 1];
+      wv[2][j] = a.wr[idx < nr ? idx : nr - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < n2) { const int o = idx / hl, h = idx - o * hl; wts[0][h][o] = to_bf16(wv[0][j]); }
+      if (idx < n1) { const int h = idx / il, i = idx - h * il; wts[1][i][h] = to_bf16(wv[1][j]); }
+      if (idx < nr) { const int o = idx / il, i = idx - o * il; wts[2][i][o] = to_bf16(wv[2][j]); }
+    }
+  }
 
   BPHASE(pb, 2);
   // ---- phase 1: LayerNorm over L, backward.  Thread = (column, half of the rows l = half, half+2, ...); two passes over
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   for (int j = 0; j < 32; ++j) {
     const int l = half + 2 * j;
     xq[j] = (xq[j] - mu) * rs;
-    gq[j] = l < ol ? gq[j] * a.gamma[min(l, ol - 1)] : 0.f;
+    gq[j] = l < ol ? gq[j] * sgam[min(l, 63)] : 0.f;
     s1 += gq[j]; s2 += gq[j] * xq[j];
   }
   BPHASE(pb, 3);

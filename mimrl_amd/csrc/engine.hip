@@ -112,20 +112,30 @@ __global__ void stage_boundary_kernel(float* scal, const float* mi, const float*
                                       float* __restrict__ dpred, int B) {
   __shared__ float red[16];
   if (threadIdx.x == 0) {
+    // every value is READ before the first store (tools/isa_lint.py: interleaved with the stores into `scal`, which may alias, these were
+    // 21 loads each followed by s_waitcnt vmcnt(0) -- 21 round trips in a one-thread kernel on the step's critical path, 7 us)
+    float vm[NE_MI], vl[NE_MI], vc[NE_CMI], vb[NE_CMI], c1[NE_MI + NE_CMI];
+#pragma unroll
+    for (int e = 0; e < NE_MI; ++e) { vm[e] = mi[e]; vl[e] = mi[NE_MI + e]; c1[e] = coef1[e]; }
+#pragma unroll
+    for (int e = 0; e < NE_CMI; ++e) { vc[e] = cmi[e]; vb[e] = bce[e]; c1[NE_MI + e] = coef1[NE_MI + e]; }
+    const int rs = *rng_step, as = *adam_step;
     float loss = 0.f;
+#pragma unroll
     for (int e = 0; e < NE_MI; ++e) {
-      scal[MIMRL_S1_MIS + e] = mi[e];
-      scal[MIMRL_S1_LOSSES + e] = mi[NE_MI + e];
-      loss += coef1[e] * mi[NE_MI + e];
+      scal[MIMRL_S1_MIS + e] = vm[e];
+      scal[MIMRL_S1_LOSSES + e] = vl[e];
+      loss += c1[e] * vl[e];
     }
+#pragma unroll
     for (int e = 0; e < NE_CMI; ++e) {
-      scal[MIMRL_S1_MIS + NE_MI + e] = cmi[e];
-      scal[MIMRL_S1_LOSSES + NE_MI + e] = bce[e];
-      loss += coef1[NE_MI + e] * bce[e];
+      scal[MIMRL_S1_MIS + NE_MI + e] = vc[e];
+      scal[MIMRL_S1_LOSSES + NE_MI + e] = vb[e];
+      loss += c1[NE_MI + e] * vb[e];
     }
     scal[MIMRL_S1_LOSS] = loss;
-    *rng_step += 1;
-    *adam_step += 1;
+    *rng_step = rs + 1;
+    *adam_step = as + 1;
   }
   for (int i = threadIdx.x; i < 32; i += blockDim.x) scal[32 + i] = 0.f;
   float s = 0.f;
