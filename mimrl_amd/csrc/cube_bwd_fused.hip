@@ -134,15 +134,15 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int ksteps = (ol + 15) / 16;
-    for (int ks = 0; ks < ksteps; ++ks) {
+    // (all four k-steps and both 32-row M tiles, always: every image is zero-padded to 64 x 64, and a run-time trip count / a run-time
+    //  `hl > 32` inside the loop is a branch between every MFMA and its fragment reads)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&sdy[nt * 32 + lr][ks * 16 + 8 * lh]);
       const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&wts[0][lr][ks * 16 + 8 * lh]);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf, acc0, 0, 0, 0);
-      if (hl > 32) {
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[0][32 + lr][ks * 16 + 8 * lh]);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
-      }
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[0][32 + lr][ks * 16 + 8 * lh]);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
     }
     act_dispatch(a.act, [&](auto AT) __attribute__((always_inline)) {
 #pragma unroll
@@ -171,17 +171,15 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int k1 = (hl + 15) / 16, k2 = (ol + 15) / 16;
-    for (int ks = 0; ks < k1 + k2; ++ks) {
-      const bool first = ks < k1;
-      const int kk = (first ? ks : ks - k1) * 16 + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bool first = ks < 4;
+      const int kk = (first ? ks : ks - 4) * 16 + 8 * lh;
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(first ? &sdu[nt * 32 + lr][kk] : &sdy[nt * 32 + lr][kk]);
       const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][lr][kk]);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf, acc0, 0, 0, 0);
-      if (il > 32) {
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][32 + lr][kk]);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
-      }
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][32 + lr][kk]);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
