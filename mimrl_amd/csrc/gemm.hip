@@ -74,36 +74,57 @@ template <int BK, bool LEAN>
 __device__ __forceinline__ void load_tile(const Operand& o, int K, int k0, int tid, float* v) {
   using M = Map<BK>;
   if (LEAN || o.vec) {
+    // Round 3b (tools/isa_lint.py): the per-piece guards (`if (gk + 3 < K) q = *src`) compiled to a branch + s_waitcnt vmcnt(0) per piece --
+    // every k-tile of the fp32 parity mode paid its loads as serialized round trips.  Now ONE tile-uniform branch: a k-tile that lies
+    // wholly inside K (all but the last one) issues its NV 16-byte loads unconditionally, back to back; only a ragged tile takes the
+    // guarded path.
+    const bool ragged = k0 + BK > K || (o.kfast && (K & 3) != 0);
+    float4 w[M::NV];
+    if (!ragged) {
 #pragma unroll
-    for (int h = 0; h < M::NV; ++h) {
-      int row, k;
-      M::vec(o.kfast, tid, h, row, k);
-      const int gk = k0 + k;
-      // k-contiguous operands may have a ragged last tile: rows beyond R are clamped (their products land in output
-      // rows/columns the epilogue never stores)
-      int gr = (LEAN && o.kfast) ? (o.r0 + row < o.R ? o.r0 + row : o.R - 1) : o.r0 + row;
-      if (gr >= o.gap_at) gr += o.gap;
-      const float* src = o.P + (long)gr * o.s_r + (long)gk * o.s_k;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o.kfast) {
-        if (gk + 3 < K) q = *reinterpret_cast<const float4*>(src);
-        else {
-          if (gk < K) q.x = src[0];
-          if (gk + 1 < K) q.y = src[1];
-          if (gk + 2 < K) q.z = src[2];
-        }
-      } else if (gk < K) {
-        q = *reinterpret_cast<const float4*>(src);
+      for (int h = 0; h < M::NV; ++h) {
+        int row, k;
+        M::vec(o.kfast, tid, h, row, k);
+        // k-contiguous operands may have a ragged last ROW tile: rows beyond R are clamped (their products land in output
+        // rows/columns the epilogue never stores)
+        int gr = (LEAN && o.kfast) ? (o.r0 + row < o.R ? o.r0 + row : o.R - 1) : o.r0 + row;
+        if (gr >= o.gap_at) gr += o.gap;
+        w[h] = *reinterpret_cast<const float4*>(o.P + (long)gr * o.s_r + (long)(k0 + k) * o.s_k);
       }
-      v[4 * h + 0] = q.x; v[4 * h + 1] = q.y; v[4 * h + 2] = q.z; v[4 * h + 3] = q.w;
+    } else {
+#pragma unroll
+      for (int h = 0; h < M::NV; ++h) {
+        int row, k;
+        M::vec(o.kfast, tid, h, row, k);
+        const int gk = k0 + k;
+        int gr = (LEAN && o.kfast) ? (o.r0 + row < o.R ? o.r0 + row : o.R - 1) : o.r0 + row;
+        if (gr >= o.gap_at) gr += o.gap;
+        const float* src = o.P + (long)gr * o.s_r + (long)gk * o.s_k;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o.kfast) {
+          if (gk + 3 < K) q = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk < K) q.x = src[0];
+            if (gk + 1 < K) q.y = src[1];
+            if (gk + 2 < K) q.z = src[2];
+          }
+        } else if (gk < K) {
+          q = *reinterpret_cast<const float4*>(src);
+        }
+        w[h] = q;
+      }
     }
+#pragma unroll
+    for (int h = 0; h < M::NV; ++h) { v[4 * h + 0] = w[h].x; v[4 * h + 1] = w[h].y; v[4 * h + 2] = w[h].z; v[4 * h + 3] = w[h].w; }
   } else {
 #pragma unroll
     for (int i = 0; i < M::NE; ++i) {
       int row, k;
       M::sc(o.kfast, tid, i, row, k);
       const int gr = o.r0 + row, gk = k0 + k;
-      v[i] = (gr < o.R && gk < K) ? o.P[(long)(gr >= o.gap_at ? gr + o.gap : gr) * o.s_r + (long)gk * o.s_k] : 0.f;
+      const int grc = gr < o.R ? gr : o.R - 1, gkc = gk < K ? gk : K - 1;      // clamped, unconditional (see above)
+      const float x = o.P[(long)(grc >= o.gap_at ? grc + o.gap : grc) * o.s_r + (long)gkc * o.s_k];
+      v[i] = (gr < o.R && gk < K) ? x : 0.f;
     }
   }
 }
