@@ -99,6 +99,7 @@ struct KMixW {
 };
 #ifdef MIMRL_PHASE_PROBE
 int kmix_bwd_read_phases(long long* out);   // 16 ticks, see model_ops.hip
+int model_ops_read_phases(long long* out);  // 16 ticks: tail_pre_kernel, ln_relu_drop_bwd16_kernel
 #endif
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D);
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D);

@@ -143,6 +143,12 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
 // by the rows.  The one-row-per-wave kernel above walks its rows as a dependent chain (4-byte loads -> two wave reductions -> stores,
 // ~2.9 us per row) on at most 1024 waves: 28 us at cfg2 (6 rows per wave) and 360 us at cfg3 (125 rows per wave, 1.4 TB/s), on the
 // critical chain in front of the BPTT.  Element indices of the dropout hash are unchanged.
+#ifdef MIMRL_PHASE_PROBE
+__device__ long long g_mo_phase[16];    // tail_pre_kernel: 0..5 (workgroup (0, slot 1)); ln_relu_drop_bwd16_kernel: 8..13 (workgroup (0, 0))
+#define MPHASE(c, i) do { if ((c) && threadIdx.x == 0) g_mo_phase[i] = (long long)wall_clock64(); } while (0)
+#else
+#define MPHASE(c, i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSide s1, const float* __restrict__ dcube, long rows, int T, int L,
                                                                   int K, RngKey key) {
   constexpr int D = 128;
@@ -156,8 +162,11 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
   const uint32_t rstep = (uint32_t)(*key.step + key.add);   // once (see drop_scale_at)
   __shared__ float sg[D], sb[D];
   const int tid = threadIdx.x, sub = tid & 15, rw = tid >> 4;          // 16 row slots per workgroup
+  const bool pb = blockIdx.x == 0 && blockIdx.y == 0;
+  MPHASE(pb, 8);
   if (tid < D) { sg[tid] = 0.f; sb[tid] = 0.f; }
   __syncthreads();
+  MPHASE(pb, 9);
   const int c0 = 4 * sub, c1 = 64 + 4 * sub;                            // this lane's two column quads
   const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c1);
   const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c1);
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
       *reinterpret_cast<float4*>(ds + r * D + c1) = o1;
     }
   }
+  MPHASE(pb, 10);
   // parameter gradients: the four row slots of a wave share columns (lanes that differ in bits 4, 5), then LDS, then one atomic per column
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -212,7 +222,9 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
     if ((tid & 63) < 16) { const int j = (i < 4 ? c0 : c1 - 4) + i; atomicAdd(&sg[j], a); atomicAdd(&sb[j], bq); }
   }
   __syncthreads();
+  MPHASE(pb, 11);
   if (tid < D) { atomicAdd(&sd.dgamma[tid], sg[tid]); atomicAdd(&sd.dbeta[tid], sb[tid]); }
+  MPHASE(pb, 12);
 }
 
 // ------------------------------------------------------------------ the three pre-CubeMLP pieces of one forward tail in ONE launch
@@ -226,7 +238,10 @@ __global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __rest
   __shared__ float part[4][D];
   const int b = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float acc0 = 0.f, acc1 = 0.f;
+  const bool pb = blockIdx.x == 0 && blockIdx.y == 1;
+  MPHASE(pb, 0);
   const uint32_t rstep = (uint32_t)(*key.step + key.add);   // once (see drop_scale_at)
+  MPHASE(pb, 1);
   // RPP rows of a wave in flight per pass (round 3b: 2 -> 7; a pass is a dependent load -> LayerNorm -> store round trip and T = 50 was
   // seven of them per wave: 13 us on the chain of the stage-1 forward).  Rows are still visited in increasing t per wave, so the
   // temporal means keep their summation order.
@@ -283,12 +298,14 @@ __global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __rest
       }
     }
   }
+  MPHASE(pb, 2);
   part[w][lane] = acc0; part[w][lane + 64] = acc1;
   __syncthreads();
   if (threadIdx.x < D) {
     const int d = threadIdx.x;
     feats[((long)slot * B + b) * D + d] = (part[0][d] + part[1][d] + part[2][d] + part[3][d]) / T;
   }
+  MPHASE(pb, 3);
 }
 
 // ------------------------------------------------------------------ temporal means
@@ -992,6 +1009,7 @@ int colln_bwd(hipStream_t s, const float* y, const float* gamma, const float* me
 
 #ifdef MIMRL_PHASE_PROBE
 int kmix_bwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kmix_phase), sizeof(long long) * 16) == hipSuccess ? 0 : 1; }
+int model_ops_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mo_phase), sizeof(long long) * 16) == hipSuccess ? 0 : 1; }
 #endif
 int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);

@@ -77,6 +77,11 @@ def main():
     print(f"mi_sep_nce: total {(q[6] - q[0]) * 0.01:.2f} us")
     for i in range(1, 7):
         print(f"    {nn[i]:34s} {(q[i] - q[i - 1]) * 0.01:7.2f} us")
+    mo = (C.c_longlong * 16)()
+    lib.mimrl_dbg_model_ops_phases.argtypes = [C.POINTER(C.c_longlong)]
+    assert lib.mimrl_dbg_model_ops_phases(mo) == 0
+    print(f"tail_pre (sample 0, audio slot): step counter read {(mo[1] - mo[0]) * 0.01:.2f} | rows {(mo[2] - mo[1]) * 0.01:.2f} | means {(mo[3] - mo[2]) * 0.01:.2f} us")
+    print(f"ln_relu_drop_bwd16 (workgroup 0): zero + barrier {(mo[9] - mo[8]) * 0.01:.2f} | rows {(mo[10] - mo[9]) * 0.01:.2f} | parameter-gradient shuffles + LDS atomics + barrier {(mo[11] - mo[10]) * 0.01:.2f} | global atomics {(mo[12] - mo[11]) * 0.01:.2f} us")
 
 
 if __name__ == "__main__":
