@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIMRL_ABI_VERSION 3
+#define MIMRL_ABI_VERSION 4
 #define MIMRL_MAX_BLOCKS 4
 
 enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -3, MIMRL_ERR_NODEVICE = -4 };
@@ -64,7 +64,7 @@ typedef struct mimrl_cfg {
   float beta1, beta2, adam_eps;  /* torch.optim.Adam defaults 0.9 / 0.999 / 1e-8 */
   int32_t precision;             /* MIMRL_PREC_* */
   int32_t use_graph;             /* capture each stage into a hipGraph on first use */
-  int32_t device_anchors;        /* 1: draw the kNN anchors on the device each step (overwrites buffers.anchors); 0: host-provided */
+  int32_t device_anchors;        /* 1: draw the kNN anchors on the device each step (overwrites buffers.anchors, where the caller can read the draws of the last step back); 0: host-provided */
   int32_t baseline_type;         /* --baseline_type: MIMRL_BASELINE_CONSTANT | _GAUSSAIN | _UNNORMALIZED (VMI.py:72-110; read by tuba / interpolate) */
   int32_t encoder;               /* --encoders: MIMRL_ENCODER_GRU (Model.py:253-255), _CONV (:247-249,437-439) or _LSTM (:250-252) */
   uint64_t seed;                 /* dropout stream seed */
@@ -210,6 +210,12 @@ int mimrl_op_mi_bound_baseline(void* stream, float* scores, float* dscores, floa
 int mimrl_op_mi_sep_infonce(void* stream, const float* tout, float* dtout, float* mi, float* mi_loss, const float* gscale, int E,
                             int B, int tiled);
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out);
+/* The device-side anchor draw of a step (Model.py:81, `np.random.choice(range(N), m, replace=False)` per CMI estimator): anchors_out
+ * [ncall][m] = for every call c the m rows with the smallest (hash(seed, *step + step_add, stream_id, c, row), row) keys, in key order.
+ * The engine calls it with stream_id = 100 + stage and *step = counters[0] (ABI 4; tests/test_gpu_ops.py checks it against the same hash
+ * restated in numpy: distinct rows, the exact selection, uniform inclusion frequencies). */
+int mimrl_op_sample_anchors(void* stream, int32_t* anchors_out, int ncall, int m, int N, uint64_t seed, const int32_t* step,
+                            uint32_t stream_id, int step_add);
 /* HOST routine (no device work): the k nearest non-anchor rows of a 1-column bank Z (the labels) for every anchor, with
  * scikit-learn's KDTree tie order (Model.py:82-86 with sklearn 1.7.2; see csrc/knn_r1.cpp).  idx_out [m*k]: ORIGINAL bank rows,
  * nearest first, anchor-major.  Real labels are discrete, so ties decide the product sample of the ta_c / tv_c estimators. */
@@ -247,6 +253,10 @@ int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* 
  * stage 2: dcin_out [6][2n][384] (rows [0,n): the joint rows; the product rows come from the detached banks) = gradient of
  * sum_e g2[e] CMI_e, g2 = (-c5, c4+c5-c7, -c6, c4+c6-c7, -c4, -c4) with c = coef2 (Model.py:381-386). */
 int mimrl_probe_cmi(mimrl_handle* h, int stage, const float* cmi_in, float* logits, float* vals, float* dcin_out);
+/* Neighbour rows of the last kNN product sample of `stage` (Model.py:82-93): idx_out [6][(B/k)*k] device int32, anchor-major, nearest
+ * first -- what cmi_assemble gathered the product rows from.  Asynchronous copy on the engine's stream (ABI 4; the device-anchor parity
+ * test compares it with the oracle's kNN on the anchors read back from mimrl_buffers.anchors). */
+int mimrl_probe_knn(mimrl_handle* h, int stage, int32_t* idx_out);
 int mimrl_op_adam(void* stream, float* p, float* g, float* m, float* v, int64_t n, const float* lr, const int32_t* step,
                   float beta1, float beta2, float eps, float weight_decay, float clip);
 

@@ -87,6 +87,7 @@ def load() -> C.CDLL:
     lib.mimrl_op_mi_bound_baseline.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_knn.argtypes = [_FP, _FP, C.c_int, C.c_int, _FP, C.c_int, C.c_int, _FP]
     lib.mimrl_op_cmi_loss.argtypes = [_FP] * 7 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_sample_anchors.argtypes = [_FP, _FP, C.c_int, C.c_int, C.c_int, C.c_uint64, _FP, C.c_uint32, C.c_int]
     lib.mimrl_create.argtypes = [C.POINTER(Cfg), _FP, C.POINTER(_FP)]
     lib.mimrl_bind.argtypes = [_FP, C.POINTER(Buffers)]
     lib.mimrl_profile_read.argtypes = [_FP, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -105,6 +106,7 @@ def load() -> C.CDLL:
     lib.mimrl_probe_cube.argtypes = [_FP] * 5
     lib.mimrl_probe_mi.argtypes = [_FP, C.c_int, _FP, _FP, _FP]
     lib.mimrl_probe_cmi.argtypes = [_FP, C.c_int, _FP, _FP, _FP, _FP]
+    lib.mimrl_probe_knn.argtypes = [_FP, C.c_int, _FP]
     lib.mimrl_layout_count.argtypes = [C.POINTER(Cfg)]
     lib.mimrl_layout_entry_dim2.argtypes = [C.POINTER(Cfg), C.c_int]
     lib.mimrl_bucket_floats.argtypes = [C.POINTER(Cfg), C.c_int]
@@ -123,8 +125,8 @@ EXPORTS = [
     "mimrl_stage_grads", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read", "mimrl_profile_read_gemm",
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_stage2_forward_tail", "mimrl_set_grad_scale", "mimrl_destroy", "mimrl_op_gemm", "mimrl_op_gemm_ex", "mimrl_op_gemm_wgrad_group",
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_mi_sep_infonce", "mimrl_op_knn",
-    "mimrl_op_cmi_loss", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
-    "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_set_kernel_stamps",
+    "mimrl_op_cmi_loss", "mimrl_op_sample_anchors", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
+    "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_set_kernel_stamps",
 ]
 
 

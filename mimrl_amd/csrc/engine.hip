@@ -298,6 +298,8 @@ struct mimrl_handle {
   float *tin = nullptr, *ta[3], *tout = nullptr, *scores = nullptr, *dscores = nullptr;
   float *cP = nullptr, *cQ = nullptr, *ca[3];
   int *knn_idx = nullptr, *knn_idx2 = nullptr;   // neighbour indices; stage 2 has its own set (prefetch mode samples it early)
+  char* knn_scr[2] = {nullptr, nullptr};         // candidate lists of the MFMA kNN (knn_mfma.hip), one per stage
+  size_t knn_scr_bytes = 0;
   float *cmi_in = nullptr, *cc[3], *logits = nullptr, *dlogits = nullptr;
   float *mi_raw = nullptr, *cmi_raw = nullptr, *bce_raw = nullptr;
   // backward temporaries
@@ -780,6 +782,8 @@ int mimrl_handle::carve() {
   }
   const size_t n = nprod();
   MX(take(&knn_idx, NE_CMI * n)); MX(take(&knn_idx2, NE_CMI * n));
+  knn_scr_bytes = knn_scratch_bytes(std::max(cfg.bank_capacity, 1), std::max(m_anchor(), 1), std::max(cfg.k_neighbor, 1));
+  MX(take(&knn_scr[0], knn_scr_bytes)); MX(take(&knn_scr[1], knn_scr_bytes));
   MX(take(&cmi_in, NE_CMI * 2 * n * 384));
   for (int l = 0; l < 3; ++l) MX(take(&cc[l], NE_CMI * 2 * n * HID + ACT_SLACK));
   MX(take(&logits, NE_CMI * 2 * n * 2));
@@ -1967,7 +1971,7 @@ int mimrl_handle::knn_launch(int stage, hipStream_t st) {
     ka.call[e].Z = ((ovr >> e) & 1u) ? nullptr : bank[z];     // null: the kernel leaves this call's rows alone
     ka.call[e].dz = z == FT_C ? 1 : EMB;
   }
-  MX(knn_sample(st, ka));
+  MX(knn_sample(st, ka, knn_scr[stage - 1], knn_scr_bytes));
   for (int e = 0; e < NE_CMI; ++e)   // caller-supplied neighbour rows (mimrl_set_knn_override_mask): copied in at every step
     if ((ovr >> e) & 1u)
       HIPX(hipMemcpyAsync(ka.idx_x + (size_t)e * nprod(), bufs.knn_override + ((size_t)(stage - 1) * NE_CMI + e) * nprod(),
@@ -2765,8 +2769,6 @@ int mimrl_set_bank_rows(mimrl_handle* h, int rows) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (rows < 0 || rows > h->cfg.bank_capacity) return set_error(MIMRL_ERR_ARG, "bank rows %d outside [0,%d]", rows, h->cfg.bank_capacity);
   if (rows > 0) {
-    if (h->cfg.device_anchors && rows > 16384)
-      return set_error(MIMRL_ERR_ARG, "device anchor sampling supports banks up to 16384 rows (got %d)", rows);
     if (!h->bufs.bank_c || !h->bufs.bank_f || !h->bufs.bank_t || !h->bufs.bank_a || !h->bufs.bank_v || !h->bufs.anchors)
       return set_error(MIMRL_ERR_STATE, "banks/anchors must be bound before enabling them");
     if (rows - h->m_anchor() < h->cfg.k_neighbor)
@@ -3137,6 +3139,19 @@ int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anc
   a.call[0] = KnnCall{Z, dz};
   a.anchors = anchors; a.idx_x = idx_out; a.N = N; a.m = m; a.k = k; a.ncall = 1;
   return knn_sample(reinterpret_cast<hipStream_t>(stream), a);
+}
+
+int mimrl_probe_knn(mimrl_handle* h, int stage, int32_t* idx_out) {
+  if (!h || !idx_out) return set_error(MIMRL_ERR_ARG, "mimrl_probe_knn: null argument");
+  if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
+  HIPX(hipMemcpyAsync(idx_out, stage == 2 ? h->knn_idx2 : h->knn_idx, sizeof(int32_t) * NE_CMI * h->nprod(), hipMemcpyDeviceToDevice, h->user_stream));
+  return MIMRL_OK;
+}
+
+int mimrl_op_sample_anchors(void* stream, int32_t* anchors_out, int ncall, int m, int N, uint64_t seed, const int32_t* step,
+                            uint32_t stream_id, int step_add) {
+  if (!anchors_out || !step || ncall < 1) return set_error(MIMRL_ERR_ARG, "mimrl_op_sample_anchors: null argument");
+  return sample_anchors(reinterpret_cast<hipStream_t>(stream), anchors_out, ncall, m, N, (uint32_t)seed, (uint32_t)(seed >> 32), step, stream_id, step_add);
 }
 
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,

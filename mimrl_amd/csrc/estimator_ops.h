@@ -41,7 +41,9 @@ int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n);
 int top1_bwd(hipStream_t s, const float* dout, const float* W, const float* act, float* dz, float* dW, float* db_top, float* db_below,
              int nb, int rows, int brows, int din, long pstride);
 
-// exact kNN product sampler (Model.py:75-106): for call c and anchor a: the k nearest non-anchor rows of Z.
+// exact kNN product sampler (Model.py:75-106): for call c and anchor a: the k nearest non-anchor rows of Z (knn_mfma.hip).
+// 128-column banks: fp32 MFMA distance tiles (every bank slab read once for all anchors of a call) + exact refinement of the k + 2
+// survivors, proven complete or re-done by an exact scan; 1-column banks: exact scan.  Ties -> lower row.
 struct KnnCall { const float* Z; int dz; };
 struct KnnArgs {
   KnnCall call[6];
@@ -49,11 +51,16 @@ struct KnnArgs {
   int* idx_x;           // [6][m*k]   nearest first, anchor-major
   int N, m, k, ncall;
 };
-int knn_sample(hipStream_t s, const KnnArgs& a);
+struct KnnPlan { int KP, nab, S, NTW, RP, ppw, nchunks, nlists; size_t scratch_bytes; };
+KnnPlan knn_plan(int N, int m, int k);
+size_t knn_scratch_bytes(int Ncap, int m, int k);   // candidate-list scratch that serves every bank size up to Ncap
+// scratch = nullptr: a process-wide buffer grown on demand (operator-level ABI; not for captured graphs)
+int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch = nullptr, size_t scratch_bytes = 0);
 
 // device-side replacement of `np.random.choice(range(N), m, replace=False)` (Model.py:81): every row gets a random
-// 32-bit key (counter hash of seed/step/call/row); the m rows with the smallest keys, in key order, are the
-// anchors -- a uniformly random m-subset in uniformly random order.  One workgroup per call, bitonic sort in LDS.
+// 32-bit key (counter hash of seed/step/call/row); the m rows with the smallest (key, row), in that order, are the
+// anchors -- a uniformly random m-subset in uniformly random order.  One workgroup per call: rows under a hash threshold
+// are collected and ranked by counting (knn_mfma.hip); any bank size.
 int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
                    const int* step, uint32_t stream_id, int step_add = 0);
 

@@ -522,118 +522,6 @@ __global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// exact kNN among non-anchor rows; one workgroup per (tile of anchors, call).  Thread-per-row distance evaluation with
-// the anchor vectors in LDS and 16-byte row loads; per-thread sorted top-K (K compile-time), merged through LDS.
-// ------------------------------------------------------------------------------------------------
-constexpr int KNN_KMAX = 8;
-
-template <int K>
-struct TopK {
-  float d[K];
-  int i[K];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int q = 0; q < K; ++q) { d[q] = INFINITY; i[q] = 0x7fffffff; }
-  }
-  __device__ __forceinline__ void push(float dist, int idx) {   // keep ascending (dist, idx)
-    float cd = dist; int ci = idx;
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      const bool lt = cd < d[q] || (cd == d[q] && ci < i[q]);
-      const float td = d[q]; const int tix = i[q];
-      d[q] = lt ? cd : td; i[q] = lt ? ci : tix;
-      cd = lt ? td : cd; ci = lt ? tix : ci;
-    }
-  }
-};
-
-// AT anchors of one call per workgroup: every bank row a thread loads is used for AT distances (the row loads, one
-// scattered 16-byte piece per lane, are what the kernel costs), each pair summed in exactly the order of the
-// single-anchor form -- the selected indices do not depend on AT.
-template <int K, int AT>
-__global__ __launch_bounds__(256) void knn_kernel(KnnArgs a) {
-  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask | [AT][256] anchor vectors | candidate lists
-  const int a0 = blockIdx.x * AT, c = blockIdx.y;
-  const int tid = threadIdx.x;
-  const int nwords = (a.N + 31) / 32;
-  unsigned* mask = smem;
-  float* av = reinterpret_cast<float*>(smem + ((nwords + 3) & ~3));
-  float* cd = av + AT * 256;
-  int* ci = reinterpret_cast<int*>(cd + AT * 256 * K);
-  for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
-  __syncthreads();
-  const float* __restrict__ Z = a.call[c].Z;
-  if (!Z) return;                                // this call's neighbour rows are supplied by the caller (whole workgroup leaves)
-  const int* anc = a.anchors + (long)c * a.m;
-  for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
-  const int dz = a.call[c].dz;
-#pragma unroll
-  for (int t = 0; t < AT; ++t) {
-    const int me = anc[min(a0 + t, a.m - 1)];  // a ragged last tile repeats its last anchor (never stored)
-    if (tid < dz) av[t * 256 + tid] = Z[(long)me * dz + tid];
-  }
-  __syncthreads();
-  TopK<K> tk[AT];
-#pragma unroll
-  for (int t = 0; t < AT; ++t) tk[t].init();
-  if (dz == 1) {
-    for (int r = tid; r < a.N; r += 256) {
-      if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
-      const float zr = Z[r];
-#pragma unroll
-      for (int t = 0; t < AT; ++t) {
-        const float df = zr - av[t * 256];
-        tk[t].push(df * df, r);
-      }
-    }
-  } else {
-    for (int r = tid; r < a.N; r += 256) {
-      if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
-      const float4* row = reinterpret_cast<const float4*>(Z + (long)r * dz);
-      float s[AT][4];
-#pragma unroll
-      for (int t = 0; t < AT; ++t) s[t][0] = s[t][1] = s[t][2] = s[t][3] = 0.f;
-      for (int j = 0; j < dz / 4; ++j) {
-        const float4 q = row[j];
-#pragma unroll
-        for (int t = 0; t < AT; ++t) {
-          const float4 w = *reinterpret_cast<const float4*>(av + t * 256 + 4 * j);
-          const float d0 = q.x - w.x, d1 = q.y - w.y, d2 = q.z - w.z, d3 = q.w - w.w;
-          s[t][0] += d0 * d0; s[t][1] += d1 * d1; s[t][2] += d2 * d2; s[t][3] += d3 * d3;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < AT; ++t) tk[t].push((s[t][0] + s[t][1]) + (s[t][2] + s[t][3]), r);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < AT; ++t)
-#pragma unroll
-    for (int q = 0; q < K; ++q) { cd[(t * 256 + tid) * K + q] = tk[t].d[q]; ci[(t * 256 + tid) * K + q] = tk[t].i[q]; }
-  __syncthreads();
-  // tree merge of the 256 sorted lists of every anchor: 8 rounds, list t absorbs list t+stride
-  for (int stride = 128; stride > 0; stride >>= 1) {
-    if (tid < stride) {
-#pragma unroll
-      for (int t = 0; t < AT; ++t) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) tk[t].push(cd[(t * 256 + tid + stride) * K + q], ci[(t * 256 + tid + stride) * K + q]);
-#pragma unroll
-        for (int q = 0; q < K; ++q) { cd[(t * 256 + tid) * K + q] = tk[t].d[q]; ci[(t * 256 + tid) * K + q] = tk[t].i[q]; }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-#pragma unroll
-    for (int t = 0; t < AT; ++t)
-#pragma unroll
-      for (int q = 0; q < K; ++q)
-        if (q < a.k && a0 + t < a.m) a.idx_x[((long)c * a.m + a0 + t) * a.k + q] = tk[t].i[q];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 __global__ void cmi_assemble_kernel(CmiAssembleArgs a) {
   const int row = blockIdx.x, c = blockIdx.y;
   float* out = a.out + ((long)c * 2 * a.n + row) * 384;
@@ -693,37 +581,6 @@ __global__ __launch_bounds__(256) void cmi_loss_kernel(const float* __restrict__
     bce[e] = sb * inv4n;
     cmi[e] = 1.f + s1 * inv2n - s2 * inv2n;                            // Model.py:219 (divisor = stacked batch 2n)
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sample_anchors_kernel(int* __restrict__ anchors, int m, int N, int npow2,
-                                                              uint32_t seed_lo, uint32_t seed_hi,
-                                                              const int* __restrict__ step, uint32_t stream_id, int step_add) {
-  extern __shared__ unsigned long long keys[];   // (hash << 32) | row ; padding = ~0
-  const int c = blockIdx.x;
-  const uint32_t st = (uint32_t)(*step + step_add);
-  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-    unsigned long long k = ~0ull;
-    if (i < N) {
-      uint32_t h = mix32((uint32_t)i ^ mix32(st * 0x9E3779B9U + stream_id + 977u * c) ^ seed_lo);
-      h = mix32(h + seed_hi * 0x85ebca6bU + 0x632be5abU);
-      k = ((unsigned long long)h << 32) | (unsigned)i;
-    }
-    keys[i] = k;
-  }
-  __syncthreads();
-  for (int size = 2; size <= npow2; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = threadIdx.x; i < npow2 / 2; i += blockDim.x) {
-        const int lo = 2 * i - (i & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-      }
-      __syncthreads();
-    }
-  for (int i = threadIdx.x; i < m; i += blockDim.x) anchors[(long)c * m + i] = (int)(keys[i] & 0xffffffffu);
 }
 
 __global__ void gather_sum_kernel(float* __restrict__ dst, GatherSum g, int B, int D, int accumulate) {
@@ -874,41 +731,6 @@ int pair_reduce_q(hipStream_t s, const float* du1, float* dQ, int E, int B, int 
 }
 int relu_bwd_inplace(hipStream_t s, const float* a, float* g, long n) {
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, g, n);
-  LAUNCH_CHECK();
-  return MIMRL_OK;
-}
-
-int knn_sample(hipStream_t s, const KnnArgs& a) {
-  if (a.k > KNN_KMAX || a.k < 1) return set_error(MIMRL_ERR_ARG, "knn: k_neighbor must be in [1,%d]", KNN_KMAX);
-  if (a.N - a.m < a.k) return set_error(MIMRL_ERR_ARG, "knn: bank too small (N=%d, m=%d, k=%d)", a.N, a.m, a.k);
-  for (int c = 0; c < a.ncall; ++c)
-    if (a.call[c].dz != 1 && (a.call[c].dz > 256 || a.call[c].dz % 4 != 0))
-      return set_error(MIMRL_ERR_ARG, "knn: feature width must be 1 or a multiple of 4 up to 256");
-  const int K = a.k <= 2 ? 2 : (a.k <= 4 ? 4 : 8);
-  constexpr int AT = 4;   // anchors per workgroup (m = 128, 6 calls: 192 workgroups)
-  const size_t sh = (((a.N + 31) / 32 + 3) & ~3) * sizeof(unsigned) + AT * 256 * sizeof(float) +
-                    AT * 256 * (size_t)K * (sizeof(float) + sizeof(int));
-  const dim3 grid((a.m + AT - 1) / AT, a.ncall);
-  if (sh > 64 * 1024) return set_error(MIMRL_ERR_ARG, "knn: bank too large for the LDS bitmask (N=%d)", a.N);
-  if (K == 2) hipLaunchKernelGGL((knn_kernel<2, AT>), grid, dim3(256), sh, s, a);
-  else if (K == 4) hipLaunchKernelGGL((knn_kernel<4, AT>), grid, dim3(256), sh, s, a);
-  else hipLaunchKernelGGL((knn_kernel<8, AT>), grid, dim3(256), sh, s, a);
-  LAUNCH_CHECK();
-  return MIMRL_OK;
-}
-
-int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
-                   const int* step, uint32_t stream_id, int step_add) {
-  int npow2 = 1;
-  while (npow2 < N) npow2 <<= 1;
-  if (npow2 < 2) npow2 = 2;
-  if (npow2 > 16384) return set_error(MIMRL_ERR_ARG, "device anchor sampling supports banks up to 16384 rows (got %d)", N);
-  if (m > N) return set_error(MIMRL_ERR_ARG, "more anchors than bank rows");
-  const size_t sh = (size_t)npow2 * sizeof(unsigned long long);
-  if (sh > 64 * 1024)
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_anchors_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-  hipLaunchKernelGGL(sample_anchors_kernel, dim3(ncall), dim3(1024), sh, s, anchors, m, N, npow2, seed_lo, seed_hi, step,
-                     stream_id, step_add);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

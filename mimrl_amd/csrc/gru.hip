@@ -405,15 +405,16 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
     }
   };
   Ops opA, opB;
-  fetch(opA, 0);
-  fetch(opB, 1);
 
-  auto do_step = [&](const int step, const int cur, Ops& nx, auto first) {
+  // `wait` = integral_constant<int, N>: operations younger than this step's operands -- 8 in the steady state (the previous step's 5 stores
+  // + 3 prefetches), 3 for the first step of the pipeline (the second buffer's prefetches), 0 for the un-pipelined single step of an odd
+  // T; `pf` = false_type: no prefetch behind the barrier (single step)
+  auto do_step = [&](const int step, const int cur, Ops& nx, auto wait, auto pf) {
     // forward visited t in order (dir ? T-1..0 : 0..T-1); backward walks it the other way round
     const int t = dir ? step : T - 1 - step;
     const bool valid = t < len;
-    if constexpr (BF16) {   // younger than this step's operands: the previous step's 5 stores + 3 prefetches (step 0: step 1's prefetches)
-      if constexpr (decltype(first)::value) vm_wait<3>(nx.graw, nx.DO, nx.HP); else vm_wait<8>(nx.graw, nx.DO, nx.HP);
+    if constexpr (BF16) {
+      vm_wait<decltype(wait)::value>(nx.graw, nx.DO, nx.HP);
 #pragma unroll
       for (int e = 0; e < 2; ++e) { nx.g.r[e] = (float)nx.graw[e]; nx.g.z[e] = (float)nx.graw[2 + e]; nx.g.n[e] = (float)nx.graw[4 + e]; nx.g.hn[e] = (float)nx.graw[6 + e]; }
     }
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
     st2o<DGBF>(q.dg, dgt + 2 * H, dnp[0], dnp[1]);
     st2o<DGBF>(q.dg, dgt + 3 * H, dnr[0], dnr[1]);
     lds_barrier();
-    fetch(nx, step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
+    if constexpr (decltype(pf)::value) fetch(nx, step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
     asm volatile("" ::: "memory");
     f32x4 acc[2];
 #pragma unroll
@@ -481,17 +482,36 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
     carry[0] = acc[0][0]; carry[1] = acc[1][0];
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
   };
+  // An ODD T runs one un-pipelined step FIRST (operands fetched, waited for with vmcnt(0), no prefetch), then the even remainder through
+  // the pipeline -- never a single step BEHIND the loop.  Round 3 had that tail, and in its code the compiler re-homed the loop-carried
+  // operand registers with v_mov copies placed IN FRONT of the explicit wait, i.e. it copied the destination of an asm load that was still
+  // in flight (the loads are invisible to it by design): the last cell step of every odd-T sequence read stale gates, the BPTT gradients
+  // were off by ~10 % and different from run to run (found in round 4 by the odd-T case of test_gradients_reproducible, which ADVICE r03
+  // asked for; even T never ran that code).  Now the only place where in-flight asm destinations cross a block boundary is the loop's own
+  // back edge, and tests/test_codeobj.py checks the ISA there (no VALU read of an asm-load destination between its load and its wait).
+  using W0 = std::integral_constant<int, 0>; using W3 = std::integral_constant<int, 3>; using W8 = std::integral_constant<int, 8>;
   int step = 0;
-  if (T >= 2) {   // peeled first pair (see gru_fwd_kernel)
-    do_step(0, 0, opA, std::true_type{});
-    do_step(1, 1, opB, std::false_type{});
-    step = 2;
+  if (T & 1) {
+    fetch(opA, 0);
+    do_step(0, 0, opA, W0{}, std::false_type{});
+    step = 1;
   }
-  for (; step + 1 < T; step += 2) {
-    do_step(step, 0, opA, std::false_type{});
-    do_step(step + 1, 1, opB, std::false_type{});
+  const int c0 = step;      // LDS tile of a step = step & 1 (a tile is rewritten two steps after it was read)
+  if (step < T) {           // (T - step is even: whole pairs)
+    fetch(opA, step);
+    fetch(opB, step + 1);
+    do_step(step, c0, opA, W3{}, std::true_type{});       // peeled first pair (see gru_fwd_kernel)
+    do_step(step + 1, c0 ^ 1, opB, W8{}, std::true_type{});
+    step += 2;
   }
-  if (step < T) { if (step == 0) do_step(step, 0, opA, std::true_type{}); else do_step(step, 0, opA, std::false_type{}); }
+  for (; step < T; step += 2) {
+    do_step(step, c0, opA, W8{}, std::true_type{});
+    do_step(step + 1, c0 ^ 1, opB, W8{}, std::true_type{});
+  }
+  // DRAIN the asm prefetches: the last two steps still issued fetch(nx, step + 2) -- six loads the compiler knows nothing about, into
+  // registers it considers dead and is free to reuse (address arithmetic, the data of the bias-gradient atomics below) while they
+  // are still in flight.  One vmcnt(0) behind the loop, in front of anything else; the ties keep the registers reserved.
+  if constexpr (BF16) asm volatile("s_waitcnt vmcnt(0)" : "+v"(opA.graw), "+v"(opA.DO), "+v"(opA.HP), "+v"(opB.graw), "+v"(opB.DO), "+v"(opB.HP) :: "memory");
   // bias gradients: reduce over the 4 batch rows (lanes differing in bits 4..5), one atomic per unit
   if (q.db_ih || q.db_hh) {
 #pragma unroll

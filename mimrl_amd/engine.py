@@ -299,6 +299,12 @@ class HipEngine:
         check(self.lib.mimrl_probe_cmi(self.handle, stage, _ptr(x), _ptr(logits), _ptr(vals), _ptr(dcin)))
         return {"logits": logits, "bce": vals[0], "cmi": vals[1], "dcin": dcin}
 
+    def probe_knn(self, stage: int) -> torch.Tensor:
+        """Neighbour rows [6, B//k, k] of the last kNN product sample of ``stage`` (include/mimrl.h: mimrl_probe_knn)."""
+        out = torch.empty(6, self.m_anchor, self.cfg.k_neighbor, dtype=torch.int32, device=self.device)
+        check(self.lib.mimrl_probe_knn(self.handle, stage, _ptr(out)))
+        return out
+
     STAMP_IDS = ("gru_fwd_l0", "gru_fwd_l1", "gru_bwd_l1", "gru_bwd_l0")
 
     def kernel_stamps(self, slots: int = 1 << 14):

@@ -326,10 +326,36 @@ def test_mine_bound_loss_term_and_both_gradient_forms(lib, B):
         grad_close(dS[e].cpu().numpy(), st.grad.numpy(), 1e-3, f"mine gradient (lossform={lossform})")
 
 
-@pytest.mark.parametrize("dz,N,m,k", [(128, 300, 16, 2), (1, 300, 16, 2), (128, 1284, 64, 2), (1, 1284, 64, 3), (128, 70, 33, 4)])
-def test_knn_matches_exact_bruteforce(lib, dz, N, m, k):
+def _knn_bank(kind, g, N, dz):
+    """Banks for the kNN tests.  `dup`: every row occurs three times (exact ties in both the expansion score and the exact distance: the
+    MFMA filter cannot prove itself complete and the kernel must take its exact-scan fallback); `collapsed`: rows = one vector + 1e-4
+    noise (feature collapse: distances ~1e-6 of the norms, below the rounding bound of the norm expansion -> fallback as well);
+    `offset`: a large common mean (|z|^2 >> distances: the regime where the expansion loses most bits)."""
+    if dz == 1:
+        return g.uniform(-3, 3, size=(N, 1)).astype(np.float32)
+    Z = g.standard_normal((N, dz)).astype(np.float32)
+    if kind == "dup":
+        Z = Z[np.arange(N) % ((N + 2) // 3)]
+    elif kind == "collapsed":
+        Z = (Z[:1] + 1e-4 * Z).astype(np.float32)
+    elif kind == "offset":
+        Z = (Z + 30.0).astype(np.float32)
+    return np.ascontiguousarray(Z)
+
+
+KNN_CASES = [(128, 300, 16, 2, "normal"), (1, 300, 16, 2, "normal"), (128, 1284, 64, 2, "normal"), (1, 1284, 64, 3, "normal"),
+             (128, 70, 33, 4, "normal"),
+             # round 4 (fp32 MFMA tiles + exact refinement, knn_mfma.hip): cfg3's shape, two anchor blocks, one / three / seven N-tiles,
+             # k = 3..4 (six survivors), k = 5 (exact scan), a generic width, and the banks that defeat the filter
+             (128, 16326, 128, 2, "normal"), (128, 5000, 256, 2, "normal"), (128, 1284, 40, 2, "normal"), (128, 3000, 100, 4, "normal"),
+             (128, 3000, 100, 3, "offset"), (128, 2000, 64, 5, "normal"), (64, 500, 32, 2, "normal"), (1, 16326, 128, 2, "normal"),
+             (128, 1284, 64, 2, "dup"), (128, 900, 32, 4, "dup"), (128, 1284, 64, 2, "collapsed"), (128, 16326, 128, 2, "offset")]
+
+
+@pytest.mark.parametrize("dz,N,m,k,kind", KNN_CASES)
+def test_knn_matches_exact_bruteforce(lib, dz, N, m, k, kind):
     g = np.random.default_rng(5)
-    Z = g.standard_normal((N, dz)).astype(np.float32) if dz > 1 else g.uniform(-3, 3, size=(N, 1)).astype(np.float32)
+    Z = _knn_bank(kind, g, N, dz)
     anchors = g.choice(N, size=m, replace=False).astype(np.int32)
     out = torch.full((m, k), -1, dtype=torch.int32, device="cuda")
     Zd, Ad = dev(Z), torch.from_numpy(anchors).cuda()      # keep both alive across the asynchronous launch
@@ -342,8 +368,79 @@ def test_knn_matches_exact_bruteforce(lib, dz, N, m, k):
         for i, j in zip(*np.nonzero(got != ref)):
             dg = ((Z64[got[i, j]] - Z64[anchors[i]]) ** 2).sum()
             dr = ((Z64[ref[i, j]] - Z64[anchors[i]]) ** 2).sum()
-            assert abs(dg - dr) <= 1e-6 * dr, f"anchor {i} slot {j}: got row {got[i, j]} (d2={dg}) want {ref[i, j]} (d2={dr})"
+            assert abs(dg - dr) <= 1e-6 * dr + 1e-30, f"anchor {i} slot {j}: got row {got[i, j]} (d2={dg}) want {ref[i, j]} (d2={dr})"
             assert got[i, j] not in anchors
+    assert got.min() >= 0 and got.max() < N and not np.isin(got, anchors).any()
+    assert all(len(set(r)) == k for r in got.tolist())          # k DISTINCT neighbours per anchor
+    if kind == "dup":                                            # exact ties resolve to the lower row, as in the brute force / np.argsort(stable)
+        Z64 = Z.astype(np.float64)
+        for i in range(m):
+            d = ((Z64[got[i]] - Z64[anchors[i]]) ** 2).sum(1)
+            assert np.all(np.diff(d) >= 0)
+            for j in range(k - 1):
+                if d[j] == d[j + 1]:
+                    assert got[i, j] < got[i, j + 1]
+
+
+def _mix32(x):
+    M = np.uint64(0xFFFFFFFF)
+    x = x & M
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & M
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & M
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def _anchor_keys(N, seed, st, stream_id, c):
+    """The key of every bank row, restated from csrc/knn_mfma.hip::anchor_hash (host-side numpy; the device draw = the m smallest keys)."""
+    M = np.uint64(0xFFFFFFFF)
+    rows = np.arange(N, dtype=np.uint64)
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    salt = _mix32(np.uint64((st * 0x9E3779B9 + stream_id + 977 * c) & 0xFFFFFFFF))
+    h = _mix32(rows ^ salt ^ lo)
+    h = _mix32((h + ((hi * np.uint64(0x85ebca6b)) & M) + np.uint64(0x632be5ab)) & M)
+    return (h << np.uint64(32)) | rows
+
+
+@pytest.mark.parametrize("N,m", [(1284, 64), (16326, 128), (70, 33), (64, 64), (40000, 128), (163, 16), (1284, 1), (100000, 512)])
+def test_sample_anchors_is_the_m_smallest_keys(lib, N, m):
+    """Model.py:81 on the device (the mode bench.py times): per call, m DISTINCT rows in [0, N) = exactly the m smallest (hash, row) keys in
+    key order (the definition the round-1 bitonic sort implemented), different per call / step / stream id -- any bank size."""
+    seed, ncall = 0x1234567811223344, 6
+    step = torch.tensor([41], dtype=torch.int32, device="cuda")
+    out = torch.full((ncall, m), -1, dtype=torch.int32, device="cuda")
+    seen = set()
+    for stream_id, step_add in ((101, 0), (102, 0), (101, 1)):
+        _lib.check(lib.mimrl_op_sample_anchors(stream(), P(out), ncall, m, N, seed, P(step), stream_id, step_add))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for c in range(ncall):
+            keys = _anchor_keys(N, seed, 41 + step_add, stream_id, c)
+            want = (np.sort(keys)[:m] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+            assert np.array_equal(got[c], want), (stream_id, step_add, c)
+            assert len(set(got[c].tolist())) == m and got[c].min() >= 0 and got[c].max() < N
+            if m >= 16 and N >= 4 * m:
+                seen.add(tuple(got[c].tolist()))
+    if m >= 16 and N >= 4 * m:
+        assert len(seen) == 3 * ncall                           # every (call, step, stage) draws its own subset
+
+
+def test_sample_anchors_inclusion_is_uniform(lib):
+    """400 steps x 6 calls of m = 20 out of N = 200: every row is drawn with frequency m / N (binomial 5 sigma), and the position of a row in
+    the draw is uniform too (first-slot frequencies)."""
+    N, m, ncall, steps = 200, 20, 6, 400
+    step = torch.tensor([0], dtype=torch.int32, device="cuda")
+    out = torch.empty(steps, ncall, m, dtype=torch.int32, device="cuda")
+    for s in range(steps):
+        _lib.check(lib.mimrl_op_sample_anchors(stream(), P(out[s]), ncall, m, N, 7, P(step), 101, s))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(-1, m)
+    n = got.shape[0]
+    cnt = np.bincount(got.reshape(-1), minlength=N)
+    p = m / N
+    assert np.abs(cnt - n * p).max() <= 5 * np.sqrt(n * p * (1 - p)), (cnt.min(), cnt.max(), n * p)
+    first = np.bincount(got[:, 0], minlength=N)
+    assert np.abs(first - n / N).max() <= 5 * np.sqrt(n / N) + 1
 
 
 @pytest.mark.parametrize("hardtanh", [0, 1])
