@@ -242,6 +242,12 @@ int mimrl_op_mlp_stack_backward(void* stream, int nb, int rows, int brows, int n
 /* CubeMLP stack, MLPEncoder.forward (MLPProcess.py:124-137) and its autograd: x [B,time_len,3,128] -> out [B,ol,ok,128] of the last block;
  * with dout (same shape as out): dx [B,time_len,3,128] and every mlp_encoder.* gradient in main_g (the bucket is zeroed first). */
 int mimrl_probe_cube(mimrl_handle* h, const float* x, float* out, const float* dout, float* dx);
+/* The encoders of Model.forward on the BOUND batch (Model.py:395-466: W_t projection, both 2-layer bi-GRUs on packed sequences, LayerNorm +
+ * ReLU + dropout, zero padding to time_len, the stack) and their autograd: cube_x [B,time_len,3,128] = the CubeMLP's input; with dcube (same
+ * shape; dmean [3][B,128] = gradient of the T_F / A_F / V_F temporal means, or NULL = 0): every W_t / rnn_* / ln_* gradient in main_g (the
+ * bucket is zeroed first) through the step's own kernels -- gemm_fast_f16, gru_fwd / gru_bwd_kernel, ln_relu_drop_*, the weight-gradient
+ * GEMMs (ABI 4; tests/test_gpu_fused_oracle.py::test_encoders_vs_rounded_oracle). */
+int mimrl_probe_encoders(mimrl_handle* h, float* cube_x, const float* dcube, const float* dmean);
 /* The five MI estimators of `stage` (Model.py:313-319 / 352-361, VMI.py:53-69) on the CALLER-WRITTEN mimrl_buffers.feats, forward +
  * backward: mi [2][5] = bound values, loss terms; scores [5][B][B] (concat critic only, else NULL); stage 1: every vmi_estimator_*
  * gradient in crit_g (zeroed first), objective sum_e -coef1[e] mi_e; stage 2: dtin_out [5][2][B][128] = gradient of

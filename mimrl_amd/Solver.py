@@ -291,7 +291,9 @@ class Solver:
     def load_checkpoint(self, ck):
         """-> epoch of the checkpoint.  Restores parameters, both optimizers, the RNG counters and -- when the checkpoint has them --
         the feature banks (``self.resume_banks`` is then the tuple to pass to ``train(epoch + 1, loader, *banks)``)."""
-        ck = torch.load(ck, map_location="cpu", weights_only=False) if isinstance(ck, (str, os.PathLike)) else ck
+        # weights_only=True: everything checkpoint() stores is a tensor / int / float / str / dict / tuple (the numpy RNG state as a
+        # tuple of those) -- no pickle code execution on a checkpoint path (ADVICE r03)
+        ck = torch.load(ck, map_location="cpu", weights_only=True) if isinstance(ck, (str, os.PathLike)) else ck
         self.model.load_state_dict(ck["model"])
         cnt = torch.cat([ck["rng_step"].reshape(1), ck["optim_main"]["step"].reshape(1), ck["optim_vmi"]["step"].reshape(1),
                          torch.zeros(1, dtype=torch.int32)]).to(torch.int32)

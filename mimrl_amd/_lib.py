@@ -107,6 +107,7 @@ def load() -> C.CDLL:
     lib.mimrl_probe_mi.argtypes = [_FP, C.c_int, _FP, _FP, _FP]
     lib.mimrl_probe_cmi.argtypes = [_FP, C.c_int, _FP, _FP, _FP, _FP]
     lib.mimrl_probe_knn.argtypes = [_FP, C.c_int, _FP]
+    lib.mimrl_probe_encoders.argtypes = [_FP] * 4
     lib.mimrl_layout_count.argtypes = [C.POINTER(Cfg)]
     lib.mimrl_layout_entry_dim2.argtypes = [C.POINTER(Cfg), C.c_int]
     lib.mimrl_bucket_floats.argtypes = [C.POINTER(Cfg), C.c_int]
@@ -126,7 +127,7 @@ EXPORTS = [
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_stage2_forward_tail", "mimrl_set_grad_scale", "mimrl_destroy", "mimrl_op_gemm", "mimrl_op_gemm_ex", "mimrl_op_gemm_wgrad_group",
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_mi_sep_infonce", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_sample_anchors", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
-    "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_set_kernel_stamps",
+    "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_probe_encoders", "mimrl_set_kernel_stamps",
 ]
 
 

@@ -502,6 +502,7 @@ struct mimrl_handle {
   int cube_backward(int cur_in, int* cur_out);
   int wt_images(hipStream_t st, bool bwd_bf16, bool launch, bool* d_fused);
   int model_backward();
+  int encoders_backward(float* dcube);
   struct StreamGuard {   // route every launch of a scope to another stream
     mimrl_handle* h; hipStream_t saved;
     StreamGuard(mimrl_handle* h_, hipStream_t st) : h(h_), saved(h_->stream) { h->stream = st; }
@@ -771,7 +772,7 @@ int mimrl_handle::carve() {
   } else {
     MX(take(&cP, NE_MI * B * HID)); MX(take(&cQ, NE_MI * B * HID));
     MX(take(&dP, NE_MI * B * HID)); MX(take(&dQ, NE_MI * B * HID));
-    for (int l = 0; l < 3; ++l) MX(take(&ca[l], NE_MI * B * B * HID));
+    for (int l = 0; l < 3; ++l) MX(take(&ca[l], NE_MI * B * B * HID + ACT_SLACK));   // (mlp_stack_backward's 8-wave kernel may read 4 rows past a ragged last tile: ADVICE r03)
     for (int l = 0; l < 3; ++l) MX(take(&dca[l], NE_MI * B * B * HID));
   }
   MX(take(&dtin, 10 * B * EMB));
@@ -1620,7 +1621,15 @@ int mimrl_handle::model_backward() {
   deferred.clear();
   { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
   MX(dbg_delay(stream, 7));
-  float* dcube = gbuf[ci];
+  return encoders_backward(gbuf[ci]);
+}
+
+// Everything of the backward pass in front of the CubeMLP: text dropout + W_t gradient, LayerNorm / ReLU / dropout of both recurrent
+// encoders, BPTT of both bi-GRU layers and their weight gradients (Model.py:395-466 under autograd).  dcube [B, L, 3, D] = gradient of
+// the stacked cube input; the T_F / A_F / V_F mean gradients are read from dfeat.  (Also the body of mimrl_probe_encoders.)
+int mimrl_handle::encoders_backward(float* dcube) {
+  const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+  const long BT_ = (long)B * T;
   // T_F/A_F/V_F means (Model.py:466): dcube[b,t,k,:] += dfeat[1+k][b,:]/T -- folded into the two consumers of dcube below
   // (no feat_mean_bwd launch on the chain).  The critical consumer goes first in capture order; the text branch has slack.
   const float* dmean = dfeat + (size_t)B * D;      // [3][B, D]: gradients of T_F, A_F, V_F
@@ -1957,25 +1966,39 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
 // estimators.  Three independent branches: kNN sampling (needs only banks + anchors -> launched before the model
 // forward on side 4), the CMI classifiers (side 5) and the MI critics (main stream).
 // =================================================================================================
-int mimrl_handle::knn_launch(int stage, hipStream_t st) {
+// stages: 1, 2, or 3 = BOTH stages' samplers as one set of launches (overlap mode: stage 2 draws with the RNG step begin_stage(2) will set)
+int mimrl_handle::knn_launch(int stages, hipStream_t st) {
   const int m = m_anchor(), k = cfg.k_neighbor;
   const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
-  int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
-  if (cfg.device_anchors)
-    MX(sample_anchors(st, anc, NE_CMI, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints, 100 + stage, rng_add));
   KnnArgs ka;
-  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = NE_CMI; ka.anchors = anc; ka.idx_x = stage == 2 ? knn_idx2 : knn_idx;
-  const unsigned ovr = bufs.knn_override ? knn_ovr_mask[stage - 1] : 0u;
-  for (int e = 0; e < NE_CMI; ++e) {
-    const int z = kCmiWire[e][2];
-    ka.call[e].Z = ((ovr >> e) & 1u) ? nullptr : bank[z];     // null: the kernel leaves this call's rows alone
-    ka.call[e].dz = z == FT_C ? 1 : EMB;
+  AnchorDraws ad;
+  ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = 0; ad.n = 0;
+  for (int stage = 1; stage <= 2; ++stage) {
+    if (!((stages >> (stage - 1)) & 1)) continue;
+    int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
+    int* idx = stage == 2 ? knn_idx2 : knn_idx;
+    const unsigned ovr = bufs.knn_override ? knn_ovr_mask[stage - 1] : 0u;
+    const int add = stages == 3 && stage == 2 ? 1 : rng_add;
+    for (int e = 0; e < NE_CMI; ++e) {
+      const int z = kCmiWire[e][2];
+      KnnCall& kc = ka.call[ka.ncall++];
+      kc.Z = ((ovr >> e) & 1u) ? nullptr : bank[z];     // null: the kernel leaves this call's rows alone
+      kc.dz = z == FT_C ? 1 : EMB;
+      kc.anchors = anc + (size_t)e * m; kc.idx_x = idx + (size_t)e * nprod();
+      ad.out[ad.n] = anc + (size_t)e * m; ad.call[ad.n] = e; ad.stream_id[ad.n] = 100u + stage; ad.step_add[ad.n] = add; ++ad.n;
+    }
   }
-  MX(knn_sample(st, ka, knn_scr[stage - 1], knn_scr_bytes));
-  for (int e = 0; e < NE_CMI; ++e)   // caller-supplied neighbour rows (mimrl_set_knn_override_mask): copied in at every step
-    if ((ovr >> e) & 1u)
-      HIPX(hipMemcpyAsync(ka.idx_x + (size_t)e * nprod(), bufs.knn_override + ((size_t)(stage - 1) * NE_CMI + e) * nprod(),
-                          sizeof(int32_t) * nprod(), hipMemcpyDeviceToDevice, st));
+  if (cfg.device_anchors) MX(sample_anchors(st, ad, m, bank_rows, (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), d_ints));
+  MX(knn_sample(st, ka, knn_scr[stages == 2 ? 1 : 0], knn_scr_bytes));
+  for (int stage = 1; stage <= 2; ++stage) {
+    if (!((stages >> (stage - 1)) & 1)) continue;
+    const unsigned ovr = bufs.knn_override ? knn_ovr_mask[stage - 1] : 0u;
+    int* idx = stage == 2 ? knn_idx2 : knn_idx;
+    for (int e = 0; e < NE_CMI; ++e)   // caller-supplied neighbour rows (mimrl_set_knn_override_mask): copied in at every step
+      if ((ovr >> e) & 1u)
+        HIPX(hipMemcpyAsync(idx + (size_t)e * nprod(), bufs.knn_override + ((size_t)(stage - 1) * NE_CMI + e) * nprod(),
+                            sizeof(int32_t) * nprod(), hipMemcpyDeviceToDevice, st));
+  }
   return MIMRL_OK;
 }
 
@@ -2386,7 +2409,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       //     side 4).  It has to be the capture's origin stream that forks the sides: a fork / join pair hanging off
       //     another captured stream sends this HIP runtime's EndCapture into an endless recursion.
       side_mask = 0x11u;
-      r1 = model_forward(true, true, 1, 1);
+      r1 = model_forward(true, true, knn_pre ? 3 : 1, 1);   // knn_pre: BOTH stages' samplers as one set of launches on side 4 (round 4)
       side_mask = ~0u;
       MX(r1);
       if (wtT_prebuilt) {   // combined step: the CubeMLP backward's weight images (main parameters only) on side 0 -- captured BEHIND the
@@ -2395,12 +2418,8 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
         MX(wt_images(S(0), (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0, true, df));
         wtT_built = true;
       }
-      if (knn_pre) {                     // stage 2's kNN sampler rides on side 4 behind stage 1's, both beside the prefix (the
-        rng_add = 1;                     // recurrence leaves half the CUs idle); anchor key = the step counter begin_stage(2) will set
-        r1 = knn_launch(2, S(4));
-        rng_add = 0;
-        MX(r1);
-      }
+      // (stage 2's kNN sampler runs beside the prefix too -- the recurrence leaves half the CUs idle; its anchor key is the step counter
+      //  begin_stage(2) will set: knn_launch(3))
       hipEvent_t e_prefix = nullptr;
       MX(next_event(&e_prefix));
       HIPX(hipEventRecord(e_prefix, stream));
@@ -2431,14 +2450,9 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       // behind one another (measured: with 5+ concurrent branches the step falls back to the sequential time, and the
       // prefetch chain as a separate graph on its own HIP stream is slower too), so stage 1's own forward pass keeps
       // two sides only
-      side_mask = 0x11u;                 // text branch (side 0) + kNN sampler (side 4)
-      r1 = model_forward(true, false, 1);
+      side_mask = 0x11u;                 // text branch (side 0) + kNN sampler (side 4; knn_pre: stage 2's as well, one set of launches)
+      r1 = model_forward(true, false, knn_pre ? 3 : 1);
       side_mask = ~0u;
-      if (r1 == 0 && knn_pre) {          // stage 2's kNN sampler rides on side 4 behind stage 1's: stage 2 then starts
-        rng_add = 1;                     // straight at its estimators (anchor key = the step counter begin_stage(2) will set)
-        r1 = knn_launch(2, S(4));
-        rng_add = 0;
-      }
     } else {
       r1 = model_forward(true, false, 1);
     }
@@ -2864,6 +2878,31 @@ int mimrl_probe_cube(mimrl_handle* h, const float* x, float* out, const float* d
   return MIMRL_OK;
 }
 
+int mimrl_probe_encoders(mimrl_handle* h, float* cube_x, const float* dcube, const float* dmean) {
+  if (!h || !cube_x) return set_error(MIMRL_ERR_ARG, "null argument");
+  if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
+  const mimrl_cfg& c = h->cfg;
+  const size_t nin = (size_t)c.batch * c.time_len * 3 * c.d_common, nf = (size_t)c.batch * c.d_common;
+  MX(h->ensure_images());
+  h->ev_next = 0;
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+  MX(h->model_forward(true, dcube != nullptr, 0, 0));
+  HIPX(hipMemcpyAsync(cube_x, h->cube0, sizeof(float) * nin, hipMemcpyDeviceToDevice, h->stream));
+  if (!dcube) return MIMRL_OK;
+  if (nin > h->gbuf_floats) return set_error(MIMRL_ERR_STATE, "probe: gradient buffer too small");
+  HIPX(hipMemsetAsync(h->bufs.main_g, 0, sizeof(float) * h->layout.floats[MIMRL_GROUP_MAIN], h->stream));
+  HIPX(hipMemcpyAsync(h->gbuf[0], dcube, sizeof(float) * nin, hipMemcpyDeviceToDevice, h->stream));
+  if (dmean) HIPX(hipMemcpyAsync(h->dfeat + nf, dmean, sizeof(float) * 3 * nf, hipMemcpyDeviceToDevice, h->stream));
+  else HIPX(hipMemsetAsync(h->dfeat, 0, sizeof(float) * 4 * nf, h->stream));
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  h->deferred.clear();
+  h->head_gather_on = false; h->ev_dmean = nullptr; h->kmix_pg_on_side3 = false;
+  const int r = h->encoders_backward(h->gbuf[0]);
+  h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+  h->grads_clean[2] = false;
+  return r;
+}
+
 int mimrl_probe_mi(mimrl_handle* h, int stage, float* mi, float* scores, float* dtin_out) {
   if (!h || !mi) return set_error(MIMRL_ERR_ARG, "null argument");
   if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
@@ -3136,8 +3175,8 @@ int mimrl_op_mi_sep_infonce(void* stream, const float* tout, float* dtout, float
 int mimrl_op_knn(void* stream, const float* Z, int dz, int N, const int32_t* anchors, int m, int k, int32_t* idx_out) {
   KnnArgs a;
   std::memset(&a, 0, sizeof a);
-  a.call[0] = KnnCall{Z, dz};
-  a.anchors = anchors; a.idx_x = idx_out; a.N = N; a.m = m; a.k = k; a.ncall = 1;
+  a.call[0] = KnnCall{Z, dz, anchors, idx_out};
+  a.N = N; a.m = m; a.k = k; a.ncall = 1;
   return knn_sample(reinterpret_cast<hipStream_t>(stream), a);
 }
 
@@ -3150,8 +3189,11 @@ int mimrl_probe_knn(mimrl_handle* h, int stage, int32_t* idx_out) {
 
 int mimrl_op_sample_anchors(void* stream, int32_t* anchors_out, int ncall, int m, int N, uint64_t seed, const int32_t* step,
                             uint32_t stream_id, int step_add) {
-  if (!anchors_out || !step || ncall < 1) return set_error(MIMRL_ERR_ARG, "mimrl_op_sample_anchors: null argument");
-  return sample_anchors(reinterpret_cast<hipStream_t>(stream), anchors_out, ncall, m, N, (uint32_t)seed, (uint32_t)(seed >> 32), step, stream_id, step_add);
+  if (!anchors_out || !step || ncall < 1 || ncall > KNN_MAX_CALLS) return set_error(MIMRL_ERR_ARG, "mimrl_op_sample_anchors: bad argument");
+  AnchorDraws d;
+  d.n = ncall;
+  for (int c = 0; c < ncall; ++c) { d.out[c] = anchors_out + (size_t)c * m; d.call[c] = c; d.stream_id[c] = stream_id; d.step_add[c] = step_add; }
+  return sample_anchors(reinterpret_cast<hipStream_t>(stream), d, m, N, (uint32_t)seed, (uint32_t)(seed >> 32), step);
 }
 
 int mimrl_op_cmi_loss(void* stream, const float* logits, float* dlogits, float* bce, float* cmi, const float* g_bce,

@@ -44,11 +44,10 @@ int top1_bwd(hipStream_t s, const float* dout, const float* W, const float* act,
 // exact kNN product sampler (Model.py:75-106): for call c and anchor a: the k nearest non-anchor rows of Z (knn_mfma.hip).
 // 128-column banks: fp32 MFMA distance tiles (every bank slab read once for all anchors of a call) + exact refinement of the k + 2
 // survivors, proven complete or re-done by an exact scan; 1-column banks: exact scan.  Ties -> lower row.
-struct KnnCall { const float* Z; int dz; };
+constexpr int KNN_MAX_CALLS = 12;   // the six CMI estimators of both stages in one launch (overlap mode samples stage 2 beside stage 1)
+struct KnnCall { const float* Z; int dz; const int* anchors; int* idx_x; };   // anchors [m]; idx_x [m*k] nearest first, anchor-major
 struct KnnArgs {
-  KnnCall call[6];
-  const int* anchors;   // [6][m]
-  int* idx_x;           // [6][m*k]   nearest first, anchor-major
+  KnnCall call[KNN_MAX_CALLS];
   int N, m, k, ncall;
 };
 struct KnnPlan { int KP, nab, S, NTW, RP, ppw, nchunks, nlists; size_t scratch_bytes; };
@@ -58,11 +57,12 @@ size_t knn_scratch_bytes(int Ncap, int m, int k);   // candidate-list scratch th
 int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch = nullptr, size_t scratch_bytes = 0);
 
 // device-side replacement of `np.random.choice(range(N), m, replace=False)` (Model.py:81): every row gets a random
-// 32-bit key (counter hash of seed/step/call/row); the m rows with the smallest (key, row), in that order, are the
-// anchors -- a uniformly random m-subset in uniformly random order.  One workgroup per call: rows under a hash threshold
-// are collected and ranked by counting (knn_mfma.hip); any bank size.
-int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
-                   const int* step, uint32_t stream_id, int step_add = 0);
+// 32-bit key (counter hash of seed / step / stream id / call / row); the m rows with the smallest (key, row), in that order, are the
+// anchors -- a uniformly random m-subset in uniformly random order.  One workgroup per draw: rows under a hash threshold
+// are collected and ranked by counting (knn_mfma.hip); any bank size.  Draw e: out[e][m], call index call[e] (0..5), stream id
+// stream_id[e] (the engine: 100 + stage), RNG step *step + step_add[e].
+struct AnchorDraws { int* out[KNN_MAX_CALLS]; int call[KNN_MAX_CALLS]; uint32_t stream_id[KNN_MAX_CALLS]; int step_add[KNN_MAX_CALLS]; int n; };
+int sample_anchors(hipStream_t s, const AnchorDraws& d, int m, int N, uint32_t seed_lo, uint32_t seed_hi, const int* step);
 
 // classifier input batch (Model.py:160-174):
 //   rows [0,n): joint = [x | y | z] of the current batch (operand = feature block [B,128] or the label column)

@@ -19,7 +19,9 @@
 //                          [32 kq, 32 kq + 32) of its row and feeds element ks at k-step ks (no LDS, no transposes); the row norm
 //                          rides on a 33rd k-step (A = the lane's partial sum of squares, B = 1).  Every lane keeps the KP = k + 2
 //                          best (score, row) pairs of the rows it sees; the four row-quarters of an anchor are merged by
-//                          shuffles and one list per (anchor, slab) goes to a scratch buffer.
+//                          shuffles and one list per (anchor, slab) goes to a scratch buffer.  Phase elimination at cfg3 (one call, 128
+//                          workgroups): set-up + final merges 11.7, products 6.8, top-k epilogue 13.8 us with a short-circuit insertion
+//                          (~110 instructions, nested exec-mask branches) -> 3 us with the branch-free min / max network.
 //  knn_merge_kernel        one wave per anchor: merges the lists, RE-RANKS the KP survivors by the exact fp32 sum of squared
 //                          differences (the arithmetic of the round-1 brute force: ties -> lower row) and proves the filter
 //                          complete: a row outside the list has score >= the list's worst, so if  worst + |a|^2 - E_k  exceeds the
@@ -49,15 +51,36 @@ struct TopL {                      // ascending (score, row)
 #pragma unroll
     for (int q = 0; q < K; ++q) { d[q] = INFINITY; i[q] = 0x7fffffff; }
   }
+  // exact order (score, then row): where ties must go to the lower row.  Bitwise, not short-circuit, logic: `a || (b && c)` compiled to
+  // nested exec-mask branches, ~110 instructions per insertion (the tile kernel's epilogue was 14 of its 35 us at cfg3)
   __device__ __forceinline__ void push(float dist, int idx) {
     float cd = dist; int ci = idx;
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      const bool lt = cd < d[q] || (cd == d[q] && ci < i[q]);
+      const bool lt = (cd < d[q]) | ((cd == d[q]) & (ci < i[q]));
       const float td = d[q]; const int tix = i[q];
       d[q] = lt ? cd : td; i[q] = lt ? ci : tix;
       cd = lt ? td : cd; ci = lt ? tix : ci;
     }
+  }
+  // score order only (min / max network, the row follows its score): for the expansion-score candidate lists, whose ties are settled
+  // by the exact refinement (a row that ties with the list's worst entry and is left out still satisfies "score >= worst")
+  __device__ __forceinline__ void push_fast(float dist, int idx) {
+    float cd = dist; int ci = idx;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const bool lt = cd < d[q];
+      const float lo = fminf(cd, d[q]), hi = fmaxf(cd, d[q]);
+      const int li = lt ? ci : i[q], hi_i = lt ? i[q] : ci;
+      d[q] = lo; i[q] = li; cd = hi; ci = hi_i;
+    }
+  }
+  __device__ __forceinline__ void absorb_xor_fast(int mask) {
+    float od[K]; int oi[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { od[q] = __shfl_xor(d[q], mask, 64); oi[q] = __shfl_xor(i[q], mask, 64); }
+#pragma unroll
+    for (int q = 0; q < K; ++q) push_fast(od[q], oi[q]);
   }
   // absorb the list of lane ^ mask (every lane ends with the merged list of the pair)
   __device__ __forceinline__ void absorb_xor(int mask) {
@@ -87,12 +110,25 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ row, const
 // distance tiles on the fp32 matrix cores
 // ------------------------------------------------------------------------------------------------
 struct KnnTileArgs {
-  const float* Z[6];     // banks of the wide (128-column) calls, compacted
-  int call_id[6];        // their call index (anchors / lists are indexed by it)
-  const int* anchors;    // [ncall][m]
+  const float* Z[12];    // banks of the wide (128-column) calls, compacted
+  const int* anc[12];    // their anchors [m]
+  int call_id[12];       // their call index (the candidate lists are indexed by it)
   float2* cand;          // [call][m][nlists][KP]  (score, row as int bits)
   int N, m, S, RP, ppw, nlists;
 };
+
+// k-mapping of both MFMA operands (any bijection works as long as A and B share it: the product contracts over all of k): register
+// element e = 4 j + c of lane (row, kq) holds column 16 j + 4 kq + c, i.e. load j of a lane is the 16-byte piece 4 j + kq of its row -- the
+// four kq-lanes of a row read 64 contiguous bytes per instruction (a lane that owned 32 CONTIGUOUS floats touched 64 different cache
+// lines per load instruction: 16.2 us per launch at cfg2 for 1 us of products)
+__device__ __forceinline__ void load_row32(const float* __restrict__ row, int kq, float (&v)[32], float scale) {
+  const float4* p = reinterpret_cast<const float4*>(row) + kq;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 x = p[4 * j];
+    v[4 * j + 0] = scale * x.x; v[4 * j + 1] = scale * x.y; v[4 * j + 2] = scale * x.z; v[4 * j + 3] = scale * x.w;
+  }
+}
 
 template <int NTW, int KP>
 __global__ __launch_bounds__(256, 2) void knn_tile_kernel(KnnTileArgs a) {
@@ -102,13 +138,23 @@ __global__ __launch_bounds__(256, 2) void knn_tile_kernel(KnnTileArgs a) {
   const int wc = blockIdx.y, ab = blockIdx.z;
   const float* __restrict__ Z = a.Z[wc];
   const int c = a.call_id[wc];
-  const int* __restrict__ anc = a.anchors + (long)c * a.m;
+  const int* __restrict__ anc = a.anc[wc];
   const int slot = w % a.S, rp = w / a.S;
   const int m0 = ab * 128;
   const int NT = (min(128, a.m - m0) + 15) >> 4;
   const int wg_rows = a.RP * a.ppw * 32;
   const int row_lo = blockIdx.x * wg_rows;
+  const int pair0 = (blockIdx.x * a.RP + rp) * a.ppw;
 
+  // the first pair of row tiles is requested before anything else: it depends on nothing but the bank.  Two register sets: the NEXT pair
+  // is requested in front of the current pair's products (a full memory round trip under ~4000 cycles of MFMA issue + epilogue)
+  float afA[2][32], afB[2][32];
+  auto fetch = [&](float (&dst)[2][32], int p) __attribute__((always_inline)) {
+    const int r0 = p * 32;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) load_row32(Z + (long)min(r0 + 16 * h + n, a.N - 1) * DZ, kq, dst[h], 1.f);
+  };
+  fetch(afA, pair0);
   for (int i = tid; i < MAXW; i += 256) mask[i] = 0u;
   __syncthreads();
   for (int i = tid; i < a.m; i += 256) {
@@ -127,32 +173,16 @@ __global__ __launch_bounds__(256, 2) void knn_tile_kernel(KnnTileArgs a) {
     const int nt = slot + t * a.S;
     live[t] = nt < NT;
     const int ai = min(m0 + nt * 16 + n, a.m - 1);
-    const float4* p = reinterpret_cast<const float4*>(Z + (long)anc[ai] * DZ + 32 * kq);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float4 v = p[j];
-      bf[t][4 * j + 0] = -2.f * v.x; bf[t][4 * j + 1] = -2.f * v.y; bf[t][4 * j + 2] = -2.f * v.z; bf[t][4 * j + 3] = -2.f * v.w;
-    }
+    load_row32(Z + (long)anc[ai] * DZ, kq, bf[t], -2.f);
   }
   TopL<KP> tk[NTW];
 #pragma unroll
   for (int t = 0; t < NTW; ++t) tk[t].init();
 
-  const int pair0 = (blockIdx.x * a.RP + rp) * a.ppw;
-  for (int p = pair0; p < pair0 + a.ppw; ++p) {
+  auto do_pair = [&](float (&af)[2][32], float (&nx)[2][32], int p) __attribute__((always_inline)) {
     const int r0 = p * 32;
-    if (r0 >= a.N) break;
-    float af[2][32], ps[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = min(r0 + 16 * h + n, a.N - 1);
-      const float4* q = reinterpret_cast<const float4*>(Z + (long)row * DZ + 32 * kq);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 v = q[j];
-        af[h][4 * j + 0] = v.x; af[h][4 * j + 1] = v.y; af[h][4 * j + 2] = v.z; af[h][4 * j + 3] = v.w;
-      }
-    }
+    fetch(nx, p + 1 < pair0 + a.ppw ? p + 1 : p);          // (the last pair re-reads itself: unconditional, never used)
+    float ps[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float s = 0.f;
@@ -177,28 +207,36 @@ __global__ __launch_bounds__(256, 2) void knn_tile_kernel(KnnTileArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ps[h], 1.0f, acc[h][t], 0, 0, 0);
-    // accumulator register j of lane (n, kq): row 4 kq + j of the 16-row tile, anchor n of the N-tile
+    // accumulator register j of lane (n, kq): row 4 kq + j of the 16-row tile, anchor n of the N-tile.  Masked rows become +inf; one
+    // test of the quad's minimum against the list's worst entry guards the four insertions
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int rb = r0 + 16 * h + 4 * kq;
       const unsigned mw = mask[(rb - row_lo) >> 5] >> ((rb - row_lo) & 31);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = rb + j < a.N && !((mw >> j) & 1u);
+      for (int t = 0; t < NTW; ++t) {
+        float sc[4];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const float sc = acc[h][t][j];
-          if (ok && sc < tk[t].d[KP - 1]) tk[t].push(sc, rb + j);
+        for (int j = 0; j < 4; ++j) sc[j] = (rb + j < a.N && !((mw >> j) & 1u)) ? acc[h][t][j] : INFINITY;
+        if (fminf(fminf(sc[0], sc[1]), fminf(sc[2], sc[3])) < tk[t].d[KP - 1]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tk[t].push_fast(sc[j], sc[j] == INFINITY ? 0x7fffffff : rb + j);   // (a masked row never enters a list)
         }
       }
     }
+  };
+  {
+    int p = pair0;
+    const int pe = min(pair0 + a.ppw, (a.N + 31) >> 5);     // pairs with at least one real row
+    for (; p + 1 < pe; p += 2) { do_pair(afA, afB, p); do_pair(afB, afA, p + 1); }
+    if (p < pe) do_pair(afA, afB, p);
   }
   const int list = blockIdx.x * a.RP + rp;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     if (!live[t]) continue;        // wave-uniform
-    tk[t].absorb_xor(16);
-    tk[t].absorb_xor(32);
+    tk[t].absorb_xor_fast(16);
+    tk[t].absorb_xor_fast(32);
     const int ai = m0 + (slot + t * a.S) * 16 + n;
     if (kq == 0 && ai < a.m) {
       float2* o = a.cand + (((long)c * a.m + ai) * a.nlists + list) * KP;
@@ -212,103 +250,136 @@ __global__ __launch_bounds__(256, 2) void knn_tile_kernel(KnnTileArgs a) {
 // merge + exact refinement (wide calls), exact scan (1-column calls)
 // ------------------------------------------------------------------------------------------------
 struct KnnMergeArgs {
-  KnnCall call[6];
-  const int* anchors;
-  int* idx_x;
+  KnnCall call[12];
   const float2* cand;
   int N, m, k, ncall, nlists;
+  int zlds;            // 1: the dynamic LDS holds a whole 1-column bank behind the bitmask (label calls stage it once per workgroup)
 };
 
 constexpr int AT = 4;              // anchors per workgroup (one wave each on the wide path)
 
+// exact squared distance with both operands in LDS (same arithmetic as exact_dist)
+__device__ __forceinline__ float exact_dist_lds(const float* row, const float* av) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int j = 0; j < DZ / 4; ++j) {
+    const float4 q = reinterpret_cast<const float4*>(row)[j];
+    const float4 w = reinterpret_cast<const float4*>(av)[j];
+    const float d0 = q.x - w.x, d1 = q.y - w.y, d2 = q.z - w.z, d3 = q.w - w.w;
+    s0 = fmaf(d0, d0, s0); s1 = fmaf(d1, d1, s1); s2 = fmaf(d2, d2, s2); s3 = fmaf(d3, d3, s3);
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
 template <int K, int KP>
 __global__ __launch_bounds__(256) void knn_merge_kernel(KnnMergeArgs a) {
-  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask | [AT][256] anchor vectors | candidate lists (1-column path)
+  extern __shared__ unsigned smem[];           // [nwords] anchor bitmask | [AT][256] anchor vectors | candidate lists / candidate rows
   const int a0 = blockIdx.x * AT, c = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nwords = (a.N + 31) / 32;
   unsigned* mask = smem;
   float* av = reinterpret_cast<float*>(smem + ((nwords + 3) & ~3));
+  float* cd = av + AT * 256;
   const float* __restrict__ Z = a.call[c].Z;
   if (!Z) return;                              // this call's neighbour rows are supplied by the caller (whole workgroup leaves)
-  for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
-  __syncthreads();
-  const int* anc = a.anchors + (long)c * a.m;
-  for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
+  const int* __restrict__ anc = a.call[c].anchors;
+  int* __restrict__ out = a.call[c].idx_x;
   const int dz = a.call[c].dz;
   if (dz == 1) {
-    // ---- label bank: m x N scalar differences, thread per row, AT anchors per workgroup (round-1 kernel body)
-    float* cd = av + AT * 256;
-    int* ci = reinterpret_cast<int*>(cd + AT * 256 * K);
-#pragma unroll
-    for (int t = 0; t < AT; ++t)
-      if (tid == 0) av[t * 256] = Z[anc[min(a0 + t, a.m - 1)]];
+    // ---- label bank: m x N scalar differences.  One wave per anchor; the wave's lanes take the rows EIGHT at a time (a plain
+    //      `for (r = tid; r < N; r += 256)` waited one memory round trip per row -- 64 of them at N = 16326 -- and the 8-round LDS tree
+    //      merge of 256 per-thread lists that followed cost as much again: 109 us per launch at cfg3); lists merge by shuffles.
+    for (int i = tid; i < nwords; i += 256) mask[i] = 0u;
     __syncthreads();
-    TopL<K> tk[AT];
+    for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
+    __syncthreads();
+    // the whole label bank comes into LDS with ONE batch of coalesced requests per thread (N = 16326: 64 KiB, 16 x 16 bytes per thread in
+    // flight together); scanning it from memory, even eight rows per lane at a time, was 32 dependent round trips per wave (50 us)
+    float* zs = reinterpret_cast<float*>(smem + ((nwords + 3) & ~3));
+    if (a.zlds) {
+      const int n4 = a.N >> 2;
+      for (int i = tid; i < n4; i += 256) reinterpret_cast<float4*>(zs)[i] = reinterpret_cast<const float4*>(Z)[i];
+      for (int i = (n4 << 2) + tid; i < a.N; i += 256) zs[i] = Z[i];
+    }
+    __syncthreads();
+    const int ai = a0 + w;
+    if (ai >= a.m) return;
+    const float za = Z[anc[ai]];
+    TopL<K> tk;
+    tk.init();
+    if (a.zlds) {
+      for (int r = lane; r < a.N; r += 64) {
+        const bool ok = !((mask[r >> 5] >> (r & 31)) & 1u);
+        const float df = zs[r] - za;
+        const float d2 = df * df;
+        if (ok & ((d2 < tk.d[K - 1]) | ((d2 == tk.d[K - 1]) & (r < tk.i[K - 1])))) tk.push(d2, r);
+      }
+    } else
+    for (int r0 = 0; r0 < a.N; r0 += 8 * 64) {
+      float zr[8];
 #pragma unroll
-    for (int t = 0; t < AT; ++t) tk[t].init();
-    for (int r = tid; r < a.N; r += 256) {
-      if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
-      const float zr = Z[r];
+      for (int u = 0; u < 8; ++u) zr[u] = Z[min(r0 + u * 64 + lane, a.N - 1)];
 #pragma unroll
-      for (int t = 0; t < AT; ++t) {
-        const float df = zr - av[t * 256];
-        tk[t].push(df * df, r);
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u * 64 + lane;
+        const int rc = min(r, a.N - 1);
+        const bool ok = r < a.N && !((mask[rc >> 5] >> (rc & 31)) & 1u);
+        const float df = zr[u] - za;
+        const float d2 = df * df;
+        if (ok && (d2 < tk.d[K - 1] || (d2 == tk.d[K - 1] && r < tk.i[K - 1]))) tk.push(d2, r);
       }
     }
+#pragma unroll 1
+    for (int o = 1; o < 64; o <<= 1) tk.absorb_xor(o);
+    if (lane == 0) {
 #pragma unroll
-    for (int t = 0; t < AT; ++t)
-#pragma unroll
-      for (int q = 0; q < K; ++q) { cd[(t * 256 + tid) * K + q] = tk[t].d[q]; ci[(t * 256 + tid) * K + q] = tk[t].i[q]; }
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-      if (tid < stride) {
-#pragma unroll
-        for (int t = 0; t < AT; ++t) {
-#pragma unroll
-          for (int q = 0; q < K; ++q) tk[t].push(cd[(t * 256 + tid + stride) * K + q], ci[(t * 256 + tid + stride) * K + q]);
-#pragma unroll
-          for (int q = 0; q < K; ++q) { cd[(t * 256 + tid) * K + q] = tk[t].d[q]; ci[(t * 256 + tid) * K + q] = tk[t].i[q]; }
-        }
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-#pragma unroll
-      for (int t = 0; t < AT; ++t)
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-          if (q < a.k && a0 + t < a.m) a.idx_x[((long)c * a.m + a0 + t) * a.k + q] = tk[t].i[q];
+      for (int q = 0; q < K; ++q)
+        if (q < a.k) out[(long)ai * a.k + q] = tk.i[q];
     }
     return;
   }
-  // ---- wide call: one wave per anchor
+  // ---- wide call: one wave per anchor, no block-level synchronisation at all (the anchor bitmask is only built by a wave that has to
+  //      fall back to the exact scan)
   const int ai = a0 + w;
-  const int me = anc[min(ai, a.m - 1)];
-  float* my = av + w * 256;
-  for (int j = lane; j < DZ; j += 64) my[j] = Z[(long)me * DZ + j];
-  __syncthreads();                             // mask + anchor vectors
-  if (ai >= a.m) return;                       // (no block-level barrier below)
-  float na = my[lane] * my[lane] + my[lane + 64] * my[lane + 64];
-  na = wave_sum(na);
+  if (ai >= a.m) return;
+  const int me = anc[ai];
+  float* my = av + w * 256;                    // this wave's anchor vector, then KP candidate rows behind the four anchors
+  float* rows = cd + w * (KP * DZ);
+  // candidate lists: every lane requests its share up front (lists of this anchor are contiguous: [nlists][KP])
+  const float2* L = a.cand + ((long)c * a.m + ai) * a.nlists * KP;
+  const int total = a.nlists * KP;
   TopL<KP> tk;
   tk.init();
-  {
-    const float2* L = a.cand + ((long)c * a.m + ai) * a.nlists * KP;
-    const int total = a.nlists * KP;
-    for (int i = lane; i < total; i += 64) {
-      const float2 e = L[i];
-      if (e.x < tk.d[KP - 1] || (e.x == tk.d[KP - 1] && __float_as_int(e.y) < tk.i[KP - 1])) tk.push(e.x, __float_as_int(e.y));
+  my[lane] = Z[(long)me * DZ + lane];
+  my[lane + 64] = Z[(long)me * DZ + 64 + lane];
+  for (int i0 = 0; i0 < total; i0 += 8 * 64) {
+    float2 e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = L[min(i0 + u * 64 + lane, total - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ix = __float_as_int(e[u].y);
+      if (i0 + u * 64 + lane < total && e[u].x < tk.d[KP - 1]) tk.push_fast(e[u].x, ix);
     }
   }
 #pragma unroll 1
-  for (int o = 1; o < 64; o <<= 1) tk.absorb_xor(o);
-  // every lane now holds the KP best rows by expansion score; lane q < KP refines candidate q
+  for (int o = 1; o < 64; o <<= 1) tk.absorb_xor_fast(o);
+  // every lane now holds the KP best rows by expansion score.  Their rows come in with coalesced 16-byte loads (KP x 512 B), the exact
+  // distances are then LDS arithmetic of lanes 0..KP-1
+#pragma unroll
+  for (int q = 0; q < KP; ++q) {
+    const int r = tk.i[q] == 0x7fffffff ? me : tk.i[q];
+    if (lane < 32) reinterpret_cast<float4*>(rows + q * DZ)[lane] = reinterpret_cast<const float4*>(Z + (long)r * DZ)[lane];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes (in-order) before its own reads
+  __builtin_amdgcn_wave_barrier();
+  float na = my[lane] * my[lane] + my[lane + 64] * my[lane + 64];
+  na = wave_sum(na);
   float ed = INFINITY; int er = 0x7fffffff;
 #pragma unroll
   for (int q = 0; q < KP; ++q)
     if (lane == q) er = tk.i[q];
-  if (lane < KP && er != 0x7fffffff) ed = exact_dist(Z + (long)er * DZ, my);
+  if (lane < KP && er != 0x7fffffff) ed = exact_dist_lds(rows + lane * DZ, my);
   int rank = 0;
 #pragma unroll
   for (int q = 0; q < KP; ++q) {
@@ -322,22 +393,30 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(KnnMergeArgs a) {
   const float rb = sqrtf(na) + sqrtf(Ek);
   const bool proven = kth != 0ull && (worst == INFINITY || (worst + na) - Ek > 4e-5f * (na + rb * rb));
   if (proven) {
-    if (lane < KP && rank < a.k && er != 0x7fffffff) a.idx_x[((long)c * a.m + ai) * a.k + rank] = er;
+    if (lane < KP && rank < a.k && er != 0x7fffffff) out[(long)ai * a.k + rank] = er;
     return;
   }
-  // ---- fallback: exact scan of the bank by this wave (ties in the expansion: duplicate rows, collapsed features)
+  // ---- fallback: exact scan of the bank by this wave (ties in the expansion: duplicate rows, collapsed features).  The anchors are
+  //      excluded by a linear membership test against the (<= a few hundred) anchor rows kept in LDS by this wave.
+  int* alist = reinterpret_cast<int*>(rows);   // candidate rows are dead now
+  const bool in_lds = a.m <= KP * DZ;          // (every configuration; otherwise the membership test reads the anchors from memory)
+  __builtin_amdgcn_wave_barrier();
+  if (in_lds)
+    for (int i = lane; i < a.m; i += 64) alist[i] = anc[i];
+  __builtin_amdgcn_wave_barrier();
   TopL<K> ex;
   ex.init();
   for (int r = lane; r < a.N; r += 64) {
-    if ((mask[r >> 5] >> (r & 31)) & 1u) continue;
-    ex.push(exact_dist(Z + (long)r * DZ, my), r);
+    bool is_anchor = false;
+    for (int i = 0; i < a.m; ++i) is_anchor |= (in_lds ? alist[i] : anc[i]) == r;
+    if (!is_anchor) ex.push(exact_dist(Z + (long)r * DZ, my), r);
   }
 #pragma unroll 1
   for (int o = 1; o < 64; o <<= 1) ex.absorb_xor(o);
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < K; ++q)
-      if (q < a.k) a.idx_x[((long)c * a.m + ai) * a.k + q] = ex.i[q];
+      if (q < a.k) out[(long)ai * a.k + q] = ex.i[q];
   }
 }
 
@@ -358,7 +437,8 @@ __global__ __launch_bounds__(256) void knn_brute_kernel(KnnArgs a) {
   __syncthreads();
   const float* __restrict__ Z = a.call[c].Z;
   if (!Z) return;
-  const int* anc = a.anchors + (long)c * a.m;
+  const int* anc = a.call[c].anchors;
+  int* __restrict__ out = a.call[c].idx_x;
   for (int i = tid; i < a.m; i += 256) atomicOr(&mask[anc[i] >> 5], 1u << (anc[i] & 31));
   const int dz = a.call[c].dz;
 #pragma unroll
@@ -410,7 +490,7 @@ __global__ __launch_bounds__(256) void knn_brute_kernel(KnnArgs a) {
     for (int t = 0; t < AT; ++t)
 #pragma unroll
       for (int q = 0; q < K; ++q)
-        if (q < a.k && a0 + t < a.m) a.idx_x[((long)c * a.m + a0 + t) * a.k + q] = tk[t].i[q];
+        if (q < a.k && a0 + t < a.m) out[(long)(a0 + t) * a.k + q] = tk[t].i[q];
   }
 }
 
@@ -422,20 +502,21 @@ __device__ __forceinline__ uint32_t anchor_hash(uint32_t row, uint32_t st, uint3
   return mix32(h + seed_hi * 0x85ebca6bU + 0x632be5abU);
 }
 
-__global__ __launch_bounds__(1024) void sample_anchors_kernel(int* __restrict__ anchors, int m, int N, int cap, uint32_t thr0,
-                                                              uint32_t seed_lo, uint32_t seed_hi, const int* __restrict__ step,
-                                                              uint32_t stream_id, int step_add) {
+__global__ __launch_bounds__(1024) void sample_anchors_kernel(AnchorDraws d, int m, int N, int cap, uint32_t thr0, uint32_t seed_lo,
+                                                              uint32_t seed_hi, const int* __restrict__ step) {
   extern __shared__ unsigned long long keys[];   // [cap] (hash << 32) | row
   __shared__ int cnt;
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const uint32_t st = (uint32_t)(*step + step_add);
+  const int tid = threadIdx.x;
+  int* __restrict__ anchors = d.out[blockIdx.x];
+  const uint32_t c = (uint32_t)d.call[blockIdx.x], stream_id = d.stream_id[blockIdx.x];
+  const uint32_t st = (uint32_t)(*step + d.step_add[blockIdx.x]);
   uint32_t thr = thr0;
   int n;
   for (;;) {                                     // (expected: one pass)
     if (tid == 0) cnt = 0;
     __syncthreads();
     for (int i = tid; i < N; i += 1024) {
-      const uint32_t h = anchor_hash((uint32_t)i, st, stream_id, (uint32_t)c, seed_lo, seed_hi);
+      const uint32_t h = anchor_hash((uint32_t)i, st, stream_id, c, seed_lo, seed_hi);
       if (h <= thr) {
         const int pos = atomicAdd(&cnt, 1);
         if (pos < cap) keys[pos] = ((unsigned long long)h << 32) | (unsigned)i;
@@ -456,7 +537,7 @@ __global__ __launch_bounds__(1024) void sample_anchors_kernel(int* __restrict__ 
     for (int q = sub; q < n; q += 4) r += keys[q] < key ? 1 : 0;
     r += __shfl_xor(r, 1, 64);
     r += __shfl_xor(r, 2, 64);
-    if (sub == 0 && j < n && r < m) anchors[(long)c * m + r] = (int)(key & 0xffffffffu);
+    if (sub == 0 && j < n && r < m) anchors[r] = (int)(key & 0xffffffffu);
   }
 }
 
@@ -492,45 +573,47 @@ KnnPlan knn_plan(int N, int m, int k) {
   p.ppw = ppw;
   p.nchunks = (pairs + p.RP * ppw - 1) / (p.RP * ppw);
   p.nlists = p.nchunks * p.RP;
-  p.scratch_bytes = (size_t)6 * m * p.nlists * p.KP * sizeof(float2);
+  p.scratch_bytes = (size_t)KNN_MAX_CALLS * m * p.nlists * p.KP * sizeof(float2);
   return p;
 }
 
 size_t knn_scratch_bytes(int Ncap, int m, int k) {   // enough for every bank size up to Ncap
   const KnnPlan p = knn_plan(Ncap, m, k);
   const int nl = std::max(p.nlists, (128 / p.nab + 1) * p.RP);
-  return (size_t)6 * m * nl * p.KP * sizeof(float2);
+  return (size_t)KNN_MAX_CALLS * m * nl * p.KP * sizeof(float2);
 }
 
 int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch, size_t scratch_bytes) {
   constexpr int KMAX = 8;
   if (a.k > KMAX || a.k < 1) return set_error(MIMRL_ERR_ARG, "knn: k_neighbor must be in [1,%d]", KMAX);
   if (a.N - a.m < a.k) return set_error(MIMRL_ERR_ARG, "knn: bank too small (N=%d, m=%d, k=%d)", a.N, a.m, a.k);
-  bool generic = false;
+  if (a.ncall < 1 || a.ncall > KNN_MAX_CALLS) return set_error(MIMRL_ERR_ARG, "knn: 1..%d calls per launch", KNN_MAX_CALLS);
+  bool generic = false, narrow = false;
   int nwide = 0;
   for (int c = 0; c < a.ncall; ++c) {
     const int dz = a.call[c].dz;
     if (dz != 1 && (dz > 256 || dz % 4 != 0)) return set_error(MIMRL_ERR_ARG, "knn: feature width must be 1 or a multiple of 4 up to 256");
     if (dz != 1 && dz != DZ) generic = true;
+    if (dz == 1 && a.call[c].Z) narrow = true;
     if (dz == DZ && a.call[c].Z) ++nwide;
   }
   const int K = a.k <= 2 ? 2 : (a.k <= 4 ? 4 : 8);
   const size_t mask_b = (((a.N + 31) / 32 + 3) & ~3) * sizeof(unsigned);
-  const size_t sh = mask_b + AT * 256 * sizeof(float) + AT * 256 * (size_t)K * (sizeof(float) + sizeof(int));
-  if (sh > 150 * 1024) return set_error(MIMRL_ERR_ARG, "knn: bank too large for the LDS bitmask (N=%d)", a.N);
+  const size_t shb = mask_b + AT * 256 * sizeof(float) + AT * 256 * (size_t)K * (sizeof(float) + sizeof(int));   // exact-scan kernel
+  if (shb > 150 * 1024) return set_error(MIMRL_ERR_ARG, "knn: bank too large for the LDS bitmask (N=%d)", a.N);
   const dim3 mgrid((a.m + AT - 1) / AT, a.ncall);
   static const bool force_brute = getenv("MIMRL_KNN_BRUTE") != nullptr;   // tuning / cross-check knob: the round-1 exact scan for every call
   // k > 4 (no BASELINE configuration; the reference's default is k = 2): the exact scan -- a k + 2 = 10-deep register list per lane and
   // tile makes the tile kernel's epilogue the bottleneck (and costs minutes of compile time)
   if (generic || force_brute || a.k > 4) {
-    if (sh > 64 * 1024) {   // (k > 4: 64 KiB of candidate lists alone)
+    if (shb > 64 * 1024) {   // (k > 4: 64 KiB of candidate lists alone)
       const void* f = K == 2 ? reinterpret_cast<const void*>(knn_brute_kernel<2>) : K == 4 ? reinterpret_cast<const void*>(knn_brute_kernel<4>)
                                                                                            : reinterpret_cast<const void*>(knn_brute_kernel<8>);
       HIPX(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     }
-    if (K == 2) hipLaunchKernelGGL((knn_brute_kernel<2>), mgrid, dim3(256), sh, s, a);
-    else if (K == 4) hipLaunchKernelGGL((knn_brute_kernel<4>), mgrid, dim3(256), sh, s, a);
-    else hipLaunchKernelGGL((knn_brute_kernel<8>), mgrid, dim3(256), sh, s, a);
+    if (K == 2) hipLaunchKernelGGL((knn_brute_kernel<2>), mgrid, dim3(256), shb, s, a);
+    else if (K == 4) hipLaunchKernelGGL((knn_brute_kernel<4>), mgrid, dim3(256), shb, s, a);
+    else hipLaunchKernelGGL((knn_brute_kernel<8>), mgrid, dim3(256), shb, s, a);
     LAUNCH_CHECK();
     return MIMRL_OK;
   }
@@ -541,8 +624,8 @@ int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch, size_t scratch_by
     KnnTileArgs t;
     int q = 0;
     for (int c = 0; c < a.ncall; ++c)
-      if (a.call[c].dz == DZ && a.call[c].Z) { t.Z[q] = a.call[c].Z; t.call_id[q] = c; ++q; }
-    t.anchors = a.anchors; t.cand = reinterpret_cast<float2*>(scratch);
+      if (a.call[c].dz == DZ && a.call[c].Z) { t.Z[q] = a.call[c].Z; t.anc[q] = a.call[c].anchors; t.call_id[q] = c; ++q; }
+    t.cand = reinterpret_cast<float2*>(scratch);
     t.N = a.N; t.m = a.m; t.S = p.S; t.RP = p.RP; t.ppw = p.ppw; t.nlists = p.nlists;
     const dim3 grid(p.nchunks, nwide, p.nab);
 #define MIMRL_KNN_TILE(NTW_, KP_) hipLaunchKernelGGL((knn_tile_kernel<NTW_, KP_>), grid, dim3(256), 0, s, t)
@@ -551,10 +634,16 @@ int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch, size_t scratch_by
 #undef MIMRL_KNN_TILE
     LAUNCH_CHECK();
   }
+  if (nwide == 0 && !narrow) return MIMRL_OK;
   KnnMergeArgs g;
-  for (int c = 0; c < 6; ++c) g.call[c] = c < a.ncall ? a.call[c] : KnnCall{nullptr, 0};
-  g.anchors = a.anchors; g.idx_x = a.idx_x; g.cand = reinterpret_cast<const float2*>(scratch);
+  for (int c = 0; c < KNN_MAX_CALLS; ++c) g.call[c] = c < a.ncall ? a.call[c] : KnnCall{nullptr, 0, nullptr, nullptr};
+  g.cand = reinterpret_cast<const float2*>(scratch);
   g.N = a.N; g.m = a.m; g.k = a.k; g.ncall = a.ncall; g.nlists = p.nlists;
+  size_t shm = mask_b + AT * 256 * sizeof(float) + (size_t)AT * (p.KP * DZ) * sizeof(float);   // bitmask | anchor vectors | candidate rows
+  const size_t sh_z = mask_b + (size_t)a.N * sizeof(float) + 16;
+  g.zlds = narrow && sh_z <= 150 * 1024 ? 1 : 0;
+  if (g.zlds && sh_z > shm) shm = sh_z;
+  const size_t sh = shm;
   if (sh > 64 * 1024) {
     const void* f = K == 2 ? reinterpret_cast<const void*>(knn_merge_kernel<2, 4>) : reinterpret_cast<const void*>(knn_merge_kernel<4, 6>);
     HIPX(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -565,8 +654,8 @@ int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch, size_t scratch_by
   return MIMRL_OK;
 }
 
-int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_t seed_lo, uint32_t seed_hi,
-                   const int* step, uint32_t stream_id, int step_add) {
+int sample_anchors(hipStream_t s, const AnchorDraws& d, int m, int N, uint32_t seed_lo, uint32_t seed_hi, const int* step) {
+  if (d.n < 1 || d.n > KNN_MAX_CALLS) return set_error(MIMRL_ERR_ARG, "sample_anchors: 1..%d draws per launch", KNN_MAX_CALLS);
   if (m > N) return set_error(MIMRL_ERR_ARG, "more anchors than bank rows");
   if (m < 1) return set_error(MIMRL_ERR_ARG, "no anchors to draw");
   // threshold: the number of rows with hash <= thr is Binomial(N, (thr + 1) / 2^32); aim at m + 6 sqrt(m) + 16 (a miss -- fewer than m
@@ -577,7 +666,7 @@ int sample_anchors(hipStream_t s, int* anchors, int ncall, int m, int N, uint32_
   const int cap = (int)std::min<long>((long)N, 4L * m + 256);
   const size_t sh = (size_t)cap * sizeof(unsigned long long);
   if (sh > 60 * 1024) return set_error(MIMRL_ERR_ARG, "sample_anchors: %d anchors per call exceed the LDS candidate list", m);
-  hipLaunchKernelGGL(sample_anchors_kernel, dim3(ncall), dim3(1024), sh, s, anchors, m, N, cap, thr0, seed_lo, seed_hi, step, stream_id, step_add);
+  hipLaunchKernelGGL(sample_anchors_kernel, dim3(d.n), dim3(1024), sh, s, d, m, N, cap, thr0, seed_lo, seed_hi, step);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

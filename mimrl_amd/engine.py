@@ -299,6 +299,20 @@ class HipEngine:
         check(self.lib.mimrl_probe_cmi(self.handle, stage, _ptr(x), _ptr(logits), _ptr(vals), _ptr(dcin)))
         return {"logits": logits, "bce": vals[0], "cmi": vals[1], "dcin": dcin}
 
+    def probe_encoders(self, dcube=None, dmean=None):
+        """Model.forward's encoders on the bound batch through the engine's own kernels (include/mimrl.h: mimrl_probe_encoders):
+        -> cube_x [B,L,3,128]; with ``dcube`` (and optionally ``dmean`` [3,B,128]) every W_t / rnn_* / ln_* gradient lands in ``self.grads``."""
+        c = self.cfg
+        x = torch.empty(c.batch, c.time_len, 3, 128, dtype=torch.float32, device=self.device)
+        if dcube is None:
+            check(self.lib.mimrl_probe_encoders(self.handle, _ptr(x), None, None))
+            return x
+        dcube = torch.as_tensor(dcube, dtype=torch.float32, device=self.device).contiguous().reshape(x.shape)
+        dm = None if dmean is None else torch.as_tensor(dmean, dtype=torch.float32, device=self.device).contiguous().reshape(3, c.batch, 128)
+        check(self.lib.mimrl_probe_encoders(self.handle, _ptr(x), _ptr(dcube), _ptr(dm)))
+        self._keep = (dcube, dm)          # alive until the asynchronous copies have run
+        return x
+
     def probe_knn(self, stage: int) -> torch.Tensor:
         """Neighbour rows [6, B//k, k] of the last kNN product sample of ``stage`` (include/mimrl.h: mimrl_probe_knn)."""
         out = torch.empty(6, self.m_anchor, self.cfg.k_neighbor, dtype=torch.int32, device=self.device)

@@ -206,3 +206,105 @@ def mi_terms_q(p, opt, feats, rnd):
         sc.append(s)
         out.append(R.infonce_lower_bound(s))
     return out, sc
+
+
+# --------------------------------------------------------------------------------------
+# encoders: W_t projection + 2-layer bi-GRU (gemm_fast_f16 + gru.hip) with the kernels' rounding points
+# --------------------------------------------------------------------------------------
+class _GruDirQ(torch.autograd.Function):
+    """One direction of one nn.GRU layer on the hoisted input projection gx = x W_ih^T + b_ih, forward AND backward written out as
+    gru.hip computes them (Model.py:254-255,441-447 packed semantics), with ``rq`` at the kernels' rounding points:
+      gru_fwd_kernel<bf16>   per cell step the fp32 state h and W_hh are rounded for the product h W_hh^T (fp32 accumulate, b_hh added
+                             in fp32); gates in fp32; the state itself stays fp32; the gates saved for BPTT -- r, z, n and W_hn h + b_hn --
+                             are stored rounded.
+      gru_bwd_kernel<bf16>   dh = dout + carry; dn, dz, dn', dz', dr' from the ROUNDED saved gates and the fp32 h_prev; the carry product
+                             [dr'|dz'|dn' r] W_hh with both operands rounded; dW_hh = sum_t rq(dgh_t)^T rq(h_prev_t) (bf16-stored BPTT
+                             outputs feed the weight-gradient GEMM); db_hh = sum_t dgh_t from the un-rounded fp32 values (in-kernel
+                             sums); the gradient w.r.t. gx (= [dr'|dz'|dn']) leaves un-rounded -- its consumers (dW_ih, the gradient to
+                             the layer below, both products of `mm`) round it themselves, the same value the bf16-stored dg holds.
+    With rq = identity this IS autograd of oracle.gru_direction (tests/test_rounded_ref.py)."""
+    @staticmethod
+    def forward(ctx, gx, w_hh, b_hh, lengths, reverse, rq):
+        B, T, G = gx.shape
+        H = G // 3
+        wq = rq(w_hh)
+        h = gx.new_zeros(B, H)
+        out = gx.new_zeros(B, T, H)
+        gates = gx.new_zeros(B, T, 4, H)
+        order = list(range(T - 1, -1, -1)) if reverse else list(range(T))
+        for t in order:
+            gh = rq(h) @ wq.t() + b_hh
+            r = torch.sigmoid(gx[:, t, :H] + gh[:, :H])
+            z = torch.sigmoid(gx[:, t, H:2 * H] + gh[:, H:2 * H])
+            hn = gh[:, 2 * H:]
+            n = torch.tanh(gx[:, t, 2 * H:] + r * hn)
+            hnew = n + z * (h - n)
+            valid = (lengths > t).unsqueeze(1)
+            out[:, t] = torch.where(valid, hnew, torch.zeros_like(hnew))
+            h = torch.where(valid, hnew, h)
+            gates[:, t] = torch.stack([r, z, n, hn], 1)
+        ctx.save_for_backward(rq(gates), out, wq, lengths)
+        ctx.meta = (order, rq)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        gates, out, wq, lengths = ctx.saved_tensors
+        order, rq = ctx.meta
+        B, T, H = out.shape
+        carry = out.new_zeros(B, H)
+        dgx = out.new_zeros(B, T, 3 * H)
+        dw = torch.zeros_like(wq)
+        db = out.new_zeros(3 * H)
+        for k in range(len(order) - 1, -1, -1):
+            t = order[k]
+            valid = (lengths > t).unsqueeze(1)
+            if k > 0:
+                tp = order[k - 1]
+                hp_ok = valid & (lengths > tp).unsqueeze(1)
+                hp = torch.where(hp_ok, out[:, tp], torch.zeros_like(carry))
+            else:
+                hp = torch.zeros_like(carry)
+            r, z, n, hn = gates[:, t, 0], gates[:, t, 1], gates[:, t, 2], gates[:, t, 3]
+            dh = dout[:, t] + carry
+            dn = dh * (1 - z)
+            dz = dh * (hp - n)
+            dnp = dn * (1 - n * n)
+            dzp = dz * z * (1 - z)
+            drp = dnp * hn * r * (1 - r)
+            dnr = dnp * r
+            zero = torch.zeros_like(dh)
+            drp, dzp, dnp, dnr = (torch.where(valid, x, zero) for x in (drp, dzp, dnp, dnr))
+            dhz = torch.where(valid, dh * z, carry)
+            dgh = torch.cat([drp, dzp, dnr], 1)
+            dgx[:, t] = torch.cat([drp, dzp, dnp], 1)
+            carry = dhz + rq(dgh) @ wq
+            dw = dw + rq(dgh).t() @ rq(hp)
+            db = db + dgh.sum(0)
+        return dgx, dw, db, None, None, None
+
+
+def bigru2_q(p, prefix, x, lengths, rnd, rq):
+    """oracle.bigru2 with the kernels' rounding: hoisted projections through ``mm`` (``rnd``: fp16 forward operands, bf16 gradient
+    operands), recurrences through _GruDirQ (``rq``: bf16)."""
+    inp = x
+    for layer in range(2):
+        outs = []
+        for rev, sfx in ((False, ""), (True, "_reverse")):
+            gx = mm(inp, p[f"{prefix}.weight_ih_l{layer}{sfx}"], rnd) + p[f"{prefix}.bias_ih_l{layer}{sfx}"]
+            outs.append(_GruDirQ.apply(gx, p[f"{prefix}.weight_hh_l{layer}{sfx}"], p[f"{prefix}.bias_hh_l{layer}{sfx}"], lengths, rev, rq))
+        inp = torch.cat(outs, dim=-1)
+    H = inp.shape[-1] // 2
+    return inp[..., :H] + inp[..., H:]
+
+
+def encoders_q(p, opt, t_feat, a, v, rnd, rq):
+    """Model.forward up to the stacked cube input (Model.py:395-475; oracle.model_forward lines 187-206), dropout 0.
+    -> (x [B,L,3,D], T_F, A_F, V_F)."""
+    D, L = opt.d_common, opt.time_len
+    t = mm(t_feat, p["W_t.weight"], rnd)
+    la, lv = R.infer_lengths(a), R.infer_lengths(v)
+    ah = F.relu(F.layer_norm(bigru2_q(p, "rnn_a", a, la, rnd, rq), (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))
+    vh = F.relu(F.layer_norm(bigru2_q(p, "rnn_v", v, lv, rnd, rq), (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
+    pad = lambda y: F.pad(y, (0, 0, 0, L - y.shape[1]))
+    return torch.stack([pad(t), pad(ah), pad(vh)], dim=2), t.mean(1), ah.mean(1), vh.mean(1)

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from mimrl_amd.engine import HipEngine
 from oracle import mimrl_ref as R
@@ -49,18 +50,15 @@ def errs(got, want):
 
 
 def tensor_ok(e, tol, group_scale, chaos=0.0):
-    """One gradient tensor against the rounded-operand float64 reference.  Max-norm error relative to the tensor's scale within
-    ``tol`` -- or, for the two documented exceptions, L2 within ``tol`` and no entry off by more than 15 x tol:
-    (i) ReLU kinks: a unit whose pre-activation is within fp32 noise of zero has a different mask in two equally valid evaluation
-    orders, and every entry it feeds moves by one row's contribution (tests/gpu_helpers.py::grad_close, DESIGN.md section 2);
-    (ii) rounding is chaotic: once kernel and reference differ by 1e-3 somewhere upstream, a quarter of the bf16 roundings of the
-    next gradient operand land on different neighbours -- single entries carry a full 2^-9 step of one operand.
+    """One gradient tensor against the rounded-operand float64 reference: max-norm error relative to the tensor's scale within ``tol``, or
+    within 3 x the reference's OWN chaos (chaos_floor) where that is larger.  Round 4: the third way out of round 3 -- L2 within tol
+    and no entry beyond 15 x tol -- is gone, and the separable-critic test point was moved off the kinks (critics after ten oracle updates
+    on real features, compared WITHOUT any chaos band), so that a 10-30 % gradient bug cannot hide.
     A tensor whose own scale is below 2 % of the largest gradient of the probe (a sum that cancels, e.g. the last-layer bias under
     InfoNCE's shift invariance) is held to ``tol`` of THAT scale: it is noise in both implementations."""
     scale = max(e["scale"], 0.02 * group_scale)
     mx = e["max_rel_scale"] * e["scale"] / scale
-    tol = max(tol, 3.0 * chaos * e["scale"] / scale)      # (iii) see chaos_floor()
-    return mx <= tol or (e["l2_rel"] * e["scale"] / scale <= tol and mx <= 15 * tol)
+    return mx <= max(tol, 3.0 * chaos * e["scale"] / scale)
 
 
 def chaos_floor(g_a, g_b):
@@ -137,8 +135,11 @@ def test_cube_stack_vs_rounded_oracle(name, fused, env, ln_first, upstream, monk
     eng.close()
     assert rec["out"]["max_rel_scale"] <= (6e-3 if fused else 1e-2), (key, rec["out"])
     gs = max(e["scale"] for n, e in rec.items() if isinstance(e, dict) and n.startswith("mlp_encoder."))
+    # (the UNFUSED bf16 chain under the broadcast gradient -- not a path bench.py times -- is the one case beyond 3 x chaos: ln_d.weight of
+    #  block 0 at 5.0e-2 with chaos 0.9e-2, ten more tensors at 1-3 %; it gets an explicit 6e-2 instead of the old blanket 15 x tol)
+    tol = 6e-2 if (not fused and upstream == "broadcast" and not ln_first) else TOL
     bad = {n: e for n, e in rec.items() if isinstance(e, dict) and (n == "dx" or n.startswith("mlp_encoder.")) and
-           not tensor_ok(e, TOL, gs if n != "dx" else e["scale"], e["chaos"])}
+           not tensor_ok(e, tol, gs if n != "dx" else e["scale"], e["chaos"])}
     assert not bad, (key, {n: (e["max_rel_scale"], e["l2_rel"], e["chaos"]) for n, e in bad.items()})
 
 
@@ -168,11 +169,29 @@ def test_mi_estimators_vs_rounded_oracle(name, stage, monkeypatch):
     eng.load_params(p)
     B = c["B"]
     g = torch.Generator().manual_seed(5)
-    feats = 0.25 * torch.randn(4, B, 128, generator=g, dtype=torch.float64)      # the scale of real features (means over T of O(1) rows)
-    feats[2:] = feats[2:].abs()                                                    # A_F, V_F are means of ReLU outputs
+    names = [n for n in p if n.startswith("vmi_estimator_")]
+    if opt.critic_type == "separate" and B >= 32:
+        # Test point (round 4).  At initialisation InfoNCE ~ 0, the softmax over the scores is uniform and the tower gradients are what is
+        # left of a near-total cancellation: the rounded-operand reference itself moves by up to 20 % of a tensor's scale under a 1e-6 nudge
+        # of the biases (72 of 80 tensors above 1 %), so round 3's band for the h towers of f_a / f_v was 3 x 12 %.  The REAL features of the
+        # fixture batch (oracle forward pass) and critics after ten float64 oracle Adam steps on them (InfoNCE 0.01 ... 0.34, lr 4e-3) are a
+        # well-conditioned point: the kernels agree with the reference to 1.6e-3 there and the test needs no chaos band (below).
+        with torch.no_grad():
+            _, F_F, T_F, A_F, V_F = R.model_forward(p, opt, *[b.double() for b in batch[:3]])
+        feats = torch.stack([F_F, T_F, A_F, V_F])
+        adam = R.AdamState(p, names)
+        for _ in range(10):
+            leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+            obj = sum(-R.infonce_lower_bound(R.critic_scores({**p, **leaves}, n, opt.critic_type, feats[Q.MI_WIRE[n][0]], feats[Q.MI_WIRE[n][1]]))
+                      for n in R.VMI_NAMES)
+            gs = torch.autograd.grad(obj, [leaves[n] for n in names], allow_unused=True)
+            adam.step(p, {n: gw for n, gw in zip(names, gs) if gw is not None}, 4e-3)
+        eng.load_params(p)
+    else:
+        feats = 0.25 * torch.randn(4, B, 128, generator=g, dtype=torch.float64)      # the scale of real features (means over T of O(1) rows)
+        feats[2:] = feats[2:].abs()                                                    # A_F, V_F are means of ReLU outputs
     r = eng.probe_mi(stage, feats)
     torch.cuda.synchronize()
-    names = [n for n in p if n.startswith("vmi_estimator_")]
     k1, k2 = opt.loss_mi_coefficient1, opt.loss_mi_coefficient2
     gsc = [-k1[e] for e in range(5)] if stage == 1 else [-k2[0], -k2[1], -k2[2], -k2[3], -k2[3]]
 
@@ -223,7 +242,10 @@ def test_mi_estimators_vs_rounded_oracle(name, stage, monkeypatch):
         assert rec["scores"]["max_rel_scale"] <= 3e-3, (key, rec["scores"])
     gt = {n: e for n, e in rec.items() if isinstance(e, dict) and n not in ("mi", "scores")}
     gs = max(e["scale"] for e in gt.values())
-    bad = {n: e for n, e in gt.items() if not tensor_ok(e, TOL, gs, e["chaos"])}
+    # trained test point: NO chaos band at all -- every tensor within 1e-2 of its scale (measured: <= 1.6e-3 for the 70 tensors above 2 % of
+    # the probe's largest gradient, <= 7.7e-3 for the cancelling last-layer biases)
+    trained = opt.critic_type == "separate" and B >= 32
+    bad = {n: e for n, e in gt.items() if not tensor_ok(e, TOL, gs, 0.0 if trained else e["chaos"])}
     assert not bad, (key, {n: (e["max_rel_scale"], e["l2_rel"], e["chaos"]) for n, e in bad.items()})
 
 
@@ -326,3 +348,82 @@ def test_fragment_image_mlp_kernel_equals_the_staged_one(name, monkeypatch):
         b = out["img8"][k]
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
+
+
+# (name, T override, dcube kind).  cfg2_sep / cfg2_ragged = the bench shape (B = 128, T = 50; ragged: four batch rows of different lengths per
+# recurrence workgroup); T = 49 / 1: the odd-T path of the BPTT kernel (an un-pipelined first step, round 4); cfg1: B = 32 (one batch row per
+# recurrence workgroup)
+ENC = [("cfg2_sep", None, True), ("cfg2_ragged", None, True), ("cfg2_ragged", 49, True), ("cfg1_ragged", None, True), ("cfg2_sep", 1, True),
+       ("tiny_ragged", None, True), ("cfg2_sep", None, False), ("cfg2_ragged", None, False)]
+
+
+@pytest.mark.parametrize("name,T_,margin", ENC, ids=[f"{n}{'' if t is None else '-T' + str(t)}{'' if mg else '-full'}" for n, t, mg in ENC])
+def test_encoders_vs_rounded_oracle(name, T_, margin):
+    """The recurrence kernels of the benchmarked mode -- gru_bwd_kernel<bf16, bf16 dg> is the largest kernel of the step, gru_fwd_kernel<bf16>
+    the fourth -- with the fp16 input projections, LayerNorm / ReLU and every weight-gradient GEMM around them, driven through
+    mimrl_probe_encoders (the step's own code path) on a fixture batch, against float64 autograd of the oracle (Model.py:395-466; nn.GRU on
+    packed sequences: Model.py:254-255,441-447) with operands rounded exactly where gru.hip / gemm_fast_f16 / gemm_fast_bf round
+    (tests/rounded_ref.py::_GruDirQ, bigru2_q, encoders_q: the state tile and W_hh -> bf16 per cell step, the saved gates -> bf16, the dgh
+    tile -> bf16 for the carry product, projection operands -> fp16 forward / bf16 backward, dg and h_prev -> bf16).  Until round 4 these
+    kernels were held to the oracle only at B = 16, T = 12, one layer, against the un-rounded fp32 cell at 2e-2 / 4e-2.
+    Every gradient tensor (W_t, the 32 rnn_* tensors, ln_a / ln_v) <= 3x the measured error, no escape hatch; the upstream gradient is
+    random in the cube input AND in the three temporal means."""
+    c, opt, batch, banks = case(name)
+    T = c["T"] if T_ is None else T_
+    batch = tuple(b[:, :T] if b.dim() == 3 else b for b in batch)
+    eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=c["N"], precision="bf16")
+    p = perturbed_params(opt, c["seed"])
+    eng.load_params(p)
+    eng.set_batch(*batch)
+    B, L = c["B"], opt.time_len
+    g = torch.Generator().manual_seed(21)
+    dcube = torch.randn(B, L, 3, 128, generator=g, dtype=torch.float64) / T
+    dmean = torch.randn(3, B, 128, generator=g, dtype=torch.float64)
+    tb = tuple(b.double() for b in batch)
+    if margin:
+        # ReLU kinks (DESIGN.md section 2): kernel and reference agree to 2e-4 in the LayerNorm outputs (rounding-boundary flips of the fp16 /
+        # bf16 operands), so ~1e-4 of the 1.6 M ReLU units have different masks in the two evaluations and each flip moves a gradient
+        # by one unit's whole contribution: 1-3 % of the layer-1 weight gradients' scale, the size of the bug this test is for.  The
+        # upstream gradient is therefore zero wherever a unit's pre-activation is within 2e-3 of the kink (10x the forward difference; 0.2 %
+        # of the units) and the A_F / V_F mean gradients -- which reach every unit -- are off; `full` keeps both and a kink-aware band.
+        with torch.no_grad():
+            D = opt.d_common
+            la, lv = R.infer_lengths(tb[1]), R.infer_lengths(tb[2])
+            pre = [F.layer_norm(Q.bigru2_q(p, f"rnn_{m}", tb[1 + i], ln_, Q.F16_FWD, Q.r_bf16), (D,), p[f"ln_{m}.weight"], p[f"ln_{m}.bias"], 1e-6)
+                   for i, (m, ln_) in enumerate((("a", la), ("v", lv)))]
+        for i in range(2):
+            dcube[:, :T, 1 + i][pre[i].abs() < 2e-3] = 0.0
+        dmean[1:] = 0.0
+    x = eng.probe_encoders(dcube, dmean)
+    torch.cuda.synchronize()
+    names = [n for n in p if n.startswith(("W_t", "rnn_", "ln_a", "ln_v"))]
+
+    def reference(rnd, rq):
+        leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+        xr, tf, af, vf = Q.encoders_q({**p, **leaves}, opt, tb[0], tb[1], tb[2], rnd, rq)
+        obj = (xr * dcube).sum() + (tf * dmean[0]).sum() + (af * dmean[1]).sum() + (vf * dmean[2]).sum()
+        return xr.detach(), torch.autograd.grad(obj, [leaves[n] for n in names])
+
+    ref, gr = reference(Q.F16_FWD, Q.r_bf16)
+    exact, gx = reference(Q.EXACT, Q.identity)              # the un-rounded oracle: how far the 16-bit mode is from fp32 / fp64
+    key = f"encoders/{name}{'' if T_ is None else '-T' + str(T_)}{'' if margin else '-full'}"
+    rec = {"cube_x": errs(x.cpu(), ref), "cube_x_vs_unrounded_oracle": errs(x.cpu(), exact)}
+    worst = ("", 0.0)
+    for n, gw, ge in zip(names, gr, gx):
+        e = errs(eng.grads[n].cpu(), gw)
+        e["vs_unrounded_oracle"] = errs(eng.grads[n].cpu(), ge)["max_rel_scale"]
+        rec[n] = e
+        if e["max_rel_scale"] > worst[1]:
+            worst = (n, e["max_rel_scale"])
+    rec["worst_grad"] = worst
+    _record(key, rec)
+    eng.close()
+    assert len(names) == 37
+    assert rec["cube_x"]["max_rel_scale"] <= 3e-3, (key, rec["cube_x"])
+    tol = ENC_TOL if margin else ENC_TOL_FULL
+    bad = {n: e["max_rel_scale"] for n, e in rec.items() if isinstance(e, dict) and n in names and e["max_rel_scale"] > tol}
+    assert not bad, (key, bad)
+
+
+ENC_TOL = 6e-3        # margin-filtered upstream gradient (no ReLU-mask flips between kernel and reference): 3x the measured 2.0e-3
+ENC_TOL_FULL = 6e-2   # every unit carries gradient: 3x the measured 2e-2 (mask flips of ~1e-4 of the units, see above)

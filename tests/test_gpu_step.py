@@ -613,7 +613,7 @@ REPRO = [("cfg2", 2, False), ("cfg1", 2, False), ("cfg2", 2, True), ("cfg2", 1, 
 def test_gradients_reproducible(workload, stage, graph):
     """Fresh engine, same inputs, the mode bench.py runs: EVERY gradient tensor of the stage must come out the same three times
     (float atomics reorder additions: observed <= 3e-6 of the tensor scale with the separable critic, <= 2.7e-4 in the concat critic's
-    split-K weight gradients over B*B rows; the band is 1e-3) -- both stages, eager and captured,
+    split-K weight gradients over B*B rows; bands 1e-4 / 1e-3) -- both stages, eager and captured, odd T (49, 1),
     separable and concat critics, cfg3 (T = 500) and cfg5 (T = 1000) shapes.  Round 2b found the block-0 K-axis parameter gradients
     off by 5-30 % from run to run while their kernel ran beside the layer-1 BPTT (the structural fix keeps
     register-heavy kernels away from the recurrence, tests/test_codeobj.py pins the register facts it relies on) -- every parity test
@@ -630,14 +630,20 @@ def test_gradients_reproducible(workload, stage, graph):
         runs.append({n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if n.startswith("v") == (stage == 1)})
         eng.close()
     top = max(np.abs(v).max() for v in runs[0].values())
+    concat = "concat" in workload or workload.startswith("cfg3")
     for r in (1, 2):
         for n in runs[0]:
-            # (a tensor whose gradient cancels to nothing is fp32 noise: the score head's bias of a concat critic has gradient
-            #  sum(dS) = 0 under InfoNCE's shift invariance -- 5 x 65536 terms at cfg3)
-            if n.endswith("MLP_f.6.bias"):
+            # Per-tensor band 1e-4 of the tensor's own scale (observed <= 3e-6: float atomics reorder additions); only the concat critic's
+            # tensors -- split-K weight gradients over B * B pair rows, observed 2.7e-4 -- get 1e-3 (the round-3 version applied
+            # 1e-3 and a 1 %-of-the-largest-tensor floor to everything, under which a K-axis-class bug in a small tensor could pass).
+            # (A tensor whose gradient cancels to nothing is fp32 noise: the score head's bias of a concat critic has gradient
+            #  sum(dS) = 0 under InfoNCE's shift invariance -- 5 x 65536 terms at cfg3.)
+            wide = concat and ".MLP_f." in n
+            if wide and n.endswith("MLP_f.6.bias"):
                 continue
-            scale = max(np.abs(runs[0][n]).max(), 1e-2 * top)
-            assert np.abs(runs[r][n] - runs[0][n]).max() <= 1e-3 * scale, (r, n, np.abs(runs[r][n] - runs[0][n]).max() / scale)
+            band = 1e-3 if wide else 1e-4
+            scale = max(np.abs(runs[0][n]).max(), (1e-2 if wide else 1e-3) * top)
+            assert np.abs(runs[r][n] - runs[0][n]).max() <= band * scale, (r, n, np.abs(runs[r][n] - runs[0][n]).max() / scale)
 
 
 def test_cfg3_full_size_properties(monkeypatch):

@@ -85,3 +85,31 @@ def test_rounding_hooks():
     assert float(out) == 3.0 * (1.0 + 2.0 ** -10)
     out.backward()
     assert float(ww.grad) == 1.0 and float(xx.grad) == 3.0                   # bf16(1 + 2^-10) = 1
+
+
+def test_identity_rounding_is_the_oracles_gru_and_its_autograd():
+    """_GruDirQ writes the recurrence kernels' forward AND backward out by hand (the BPTT formulas of gru.hip, so that the rounding points of
+    the backward kernel can be placed); with the rounding hooks set to the identity it must be oracle.gru_direction and torch autograd of it
+    -- ragged lengths, both directions -- and encoders_q must be the first half of oracle.model_forward."""
+    torch.manual_seed(0)
+    B, T, D, H = 5, 7, 6, 128
+    x = torch.randn(B, T, D, dtype=torch.float64, requires_grad=True)
+    lens = torch.tensor([7, 3, 1, 5, 7])
+    ws = [(torch.randn(3 * H, D, dtype=torch.float64) * 0.3).requires_grad_(True), (torch.randn(3 * H, H, dtype=torch.float64) * 0.1).requires_grad_(True),
+          (torch.randn(3 * H, dtype=torch.float64) * 0.1).requires_grad_(True), (torch.randn(3 * H, dtype=torch.float64) * 0.1).requires_grad_(True)]
+    do = torch.randn(B, T, H, dtype=torch.float64)
+    for rev in (False, True):
+        o1 = R.gru_direction(x, lens, ws[0], ws[1], ws[2], ws[3], rev)
+        g1 = torch.autograd.grad((o1 * do).sum(), [x] + ws)
+        o2 = Q._GruDirQ.apply(Q.mm(x, ws[0], Q.EXACT) + ws[2], ws[1], ws[3], lens, rev, Q.identity)
+        g2 = torch.autograd.grad((o2 * do).sum(), [x] + ws)
+        assert (o1 - o2).abs().max() < 1e-12
+        for a, b in zip(g1, g2):
+            assert (a - b).abs().max() < 1e-12
+    c, opt, batch, banks = case("tiny_ragged", torch.float64)
+    p = oracle_params(opt, c["seed"], torch.float64)
+    xq, tf, af, vf = Q.encoders_q(p, opt, batch[0], batch[1], batch[2], Q.EXACT, Q.identity)
+    pred, F_F, T_F, A_F, V_F = R.model_forward(p, opt, batch[0], batch[1], batch[2])
+    for a, b in ((tf, T_F), (af, A_F), (vf, V_F)):
+        assert (a - b).abs().max() < 1e-12
+    assert (R.cube_mlp(p, opt, xq).mean(2).mean(1) - F_F).abs().max() < 1e-12
