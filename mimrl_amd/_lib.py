@@ -7,7 +7,9 @@ import os
 from typing import List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmimrl_hip.so")
+# MIMRL_LIB_PATH: another build of the library -- in practice the host-only AddressSanitizer build (`make -C mimrl_amd/csrc asan`,
+# tools/asan_host.sh), which carries the layout / error / KDTree entry points only: the bindings of symbols it lacks are skipped
+LIB_PATH = os.environ.get("MIMRL_LIB_PATH") or os.path.join(_HERE, "libmimrl_hip.so")
 MAX_BLOCKS = 4
 NSCALARS = 64
 PHASES = ["gemm_misc", "gru_fwd", "gru_bwd", "cube_fwd", "cube_bwd", "est_fwd", "est_bwd", "opt", "model_misc"]
@@ -66,6 +68,17 @@ def load() -> C.CDLL:
         raise MimrlError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          f"or `make -C mimrl_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    if os.environ.get("MIMRL_LIB_PATH"):
+        class _Partial:                      # attribute access on a missing symbol yields a throw-away object for the argtypes below
+            def __init__(self, lib):
+                object.__setattr__(self, "_lib", lib)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._lib, name)
+                except AttributeError:
+                    return type("_Missing", (), {})()
+        real, lib = lib, _Partial(lib)
     lib.mimrl_last_error.restype = C.c_char_p
     lib.mimrl_bucket_floats.restype = C.c_int64
     lib.mimrl_workspace_bytes.restype = C.c_int64
@@ -113,6 +126,8 @@ def load() -> C.CDLL:
     lib.mimrl_bucket_floats.argtypes = [C.POINTER(Cfg), C.c_int]
     lib.mimrl_layout_entry.argtypes = [C.POINTER(Cfg), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    if os.environ.get("MIMRL_LIB_PATH"):
+        lib = real
     _lib = lib
     return lib
 

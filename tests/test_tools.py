@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -44,3 +46,19 @@ def test_timeline(tmp_path):
     lines = open(out).read().strip().split("\n")
     assert lines[-1].startswith("step span") and "kernels 4" in lines[-1]
     assert "sample_anchors_kernel" in lines[0]
+
+
+def test_host_code_is_clean_under_asan_and_ubsan():
+    """`make asan` + tools/asan_host.sh: the host-side translation units (knn_r1.cpp -- the scikit-learn KDTree restatement, layout.cpp,
+    errors.cpp) built with -fsanitize=address,undefined and driven by the CPU tests of tests/test_knn_ties.py / test_layout.py with the
+    sanitizer runtime preloaded into python (the reference has no sanitizer story; GPU sanitizers are not available on
+    this pool, so this is the host half only)."""
+    import shutil
+    import subprocess
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip() \
+        if os.path.exists("/opt/rocm/lib/llvm/bin/clang") else ""
+    if not (rt and os.path.exists(rt) and shutil.which("make")):
+        pytest.skip("no clang AddressSanitizer runtime in this image")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "asan_host.sh")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert " passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
