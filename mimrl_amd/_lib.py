@@ -17,8 +17,8 @@ S1_LOSS, S1_MIS, S1_LOSSES, S2_LOSS, S2_TASK, S2_MIS, S2_LOSSES = 0, 1, 12, 32, 
 
 BOUNDS = {"infonce": 0, "nwj": 1, "tuba": 2, "dv": 3, "js_fgan": 4, "js": 5, "smile": 6, "mine": 7, "interpolate": 8}
 ACTS = {"none": 0, "relu": 1, "gelu": 2, "tanh": 3}
-PREC = {"fp32": 0, "bf16": 15, "bf16_fwd": 5, "bf16_gemm_fwd": 1, "bf16_gemm_bwd": 2, "bf16_gru": 12, "bf16_gru_fwd": 4,
-        "bf16_gru_bwd": 8, "bf16_nogemmbwd": 13}
+# (the two GRU bits go together: the forward kernel writes the gate slab in the format the BPTT kernel of the same mode reads)
+PREC = {"fp32": 0, "bf16": 15, "bf16_gemm_fwd": 1, "bf16_gemm_bwd": 2, "bf16_gemm": 3, "bf16_gru": 12, "bf16_nogemmbwd": 13}
 
 
 class MimrlError(RuntimeError):

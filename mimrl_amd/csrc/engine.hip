@@ -2733,8 +2733,13 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->dg_bf16 = cfg->encoder == MIMRL_ENCODER_GRU && (cfg->precision & MIMRL_PREC_BF16_GRU_BWD) && (cfg->precision & MIMRL_PREC_BF16_GEMM_BWD) &&
                getenv("MIMRL_DG_FP32") == nullptr;
   h->l0_bwd_pack = getenv("MIMRL_L0_BWD_PACK") ? atoi(getenv("MIMRL_L0_BWD_PACK")) != 0 : false;
+  if (cfg->encoder == MIMRL_ENCODER_GRU && ((cfg->precision & MIMRL_PREC_BF16_GRU_FWD) != 0) != ((cfg->precision & MIMRL_PREC_BF16_GRU_BWD) != 0)) {
+    mimrl_destroy(h);   // the forward kernel writes the gate slab in the format (bf16 / fp32 records) the BPTT kernel of the SAME mode reads
+    return set_error(MIMRL_ERR_ARG, "MIMRL_PREC_BF16_GRU_FWD and MIMRL_PREC_BF16_GRU_BWD must be set together");
+  }
   for (int i = 0; i < mimrl_handle::NSIDE; ++i)
     if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) { mimrl_destroy(h); return set_error(MIMRL_ERR_HIP, "hipStreamCreate failed"); }
+  gru_probe_setup();
   h->prec = cfg->precision;
   h->bf16 = (h->prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
   std::memset(&h->bufs, 0, sizeof h->bufs);

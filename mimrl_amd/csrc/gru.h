@@ -51,5 +51,6 @@ long gru_saved_floats(int B, int T);
 // batch rows per workgroup (<= 4): the kernels are bound by the per-step instruction latency of one wave, so the batch
 // is spread over as many CUs as possible
 int gru_pick_btv(int B, int nmod);
+void gru_probe_setup();   // `make PHASE_PROBE=1` builds: reads MIMRL_GRU_SKIP (gru.hip); a no-op otherwise
 
 }  // namespace mimrl

@@ -107,14 +107,35 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-__device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
-// BPTT outputs as packed bf16 pairs (DGBF): `p` is the fp32-typed base of a bf16 array, `i` the element index
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-template <bool DGBF>
-__device__ __forceinline__ void st2o(float* p, long i, float a, float b) {
-  if constexpr (DGBF) { bf16x2 v; v[0] = to_bf16(a); v[1] = to_bf16(b); *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(p) + i) = v; }
-  else *reinterpret_cast<float2*>(p + i) = make_float2(a, b);
+// UPL consecutive values (units u0 .. u0 + UPL - 1) of one lane: 4- or 8-byte accesses
+template <int UPL> struct Pack;
+template <> struct Pack<2> { using F = float2; using G = bf16x8; };      // F: UPL floats; G: packed bf16 gate record {r z n hn} x UPL
+template <> struct Pack<1> { using F = float;  using G = bf16x4; };
+template <int UPL>
+__device__ __forceinline__ void ldu(const float* p, float (&v)[UPL]) {
+  if constexpr (UPL == 2) { const float2 x = *reinterpret_cast<const float2*>(p); v[0] = x.x; v[1] = x.y; } else v[0] = *p;
+}
+template <int UPL>
+__device__ __forceinline__ void stu(float* p, const float (&v)[UPL]) {
+  if constexpr (UPL == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); else *p = v[0];
+}
+template <int UPL, int K>
+__device__ __forceinline__ void putu(Tile<true, K>& t, int b, int k0, const float (&v)[UPL]) {
+  if constexpr (UPL == 2) { bf16x2 q; q[0] = to_bf16(v[0]); q[1] = to_bf16(v[1]); *reinterpret_cast<bf16x2*>(&t.v[b][k0]) = q; }
+  else t.v[b][k0] = to_bf16(v[0]);
+}
+template <int UPL, int K>
+__device__ __forceinline__ void putu(Tile<false, K>& t, int b, int k0, const float (&v)[UPL]) {
+#pragma unroll
+  for (int e = 0; e < UPL; ++e) t.v[k0 + e][b] = v[e];
+}
+// BPTT outputs as packed bf16 (DGBF): `p` is the fp32-typed base of a bf16 array, `i` the element index
+template <bool DGBF, int UPL>
+__device__ __forceinline__ void stuo(float* p, long i, const float (&v)[UPL]) {
+  if constexpr (DGBF) {
+    if constexpr (UPL == 2) { bf16x2 q; q[0] = to_bf16(v[0]); q[1] = to_bf16(v[1]); *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(p) + i) = q; }
+    else reinterpret_cast<__bf16*>(p)[i] = to_bf16(v[0]);
+  } else stu<UPL>(p + i, v);
 }
 
 // Operand loads of the software pipeline with EXPLICIT wait counts (bf16 kernels).  The compiler's waitcnt pass merges the counts of
@@ -124,50 +145,52 @@ __device__ __forceinline__ void st2o(float* p, long i, float a, float b) {
 // 0.43 of the BPTT's 1.32 us per step).  Loads issued by inline asm are invisible to that pass; vm_wait<N>() is the one wait, with the
 // exact count (every step issues the same sequence of loads and stores, unconditionally: see the padding-lane comment), and ties
 // the destination registers so that no use can be scheduled in front of it.
-__device__ __forceinline__ void gld8(float2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-template <int OFF>   // + OFF bytes as the instruction's immediate offset: one address register pair for several loads
-__device__ __forceinline__ void gld8o(float2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory"); }
-__device__ __forceinline__ void gld16(bf16x8& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-template <int N>
-__device__ __forceinline__ void vm_wait(float2& a, float2& b, float2& c) {
+__device__ __forceinline__ void gld(float& d, const float* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gld(float2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gld(bf16x4& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gld(bf16x8& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int N, class A, class B, class C>
+__device__ __forceinline__ void vm_wait(A& a, B& b, C& c) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void vm_wait(bf16x8& a, float2& b, float2& c) {
-  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
-}
+__device__ __forceinline__ float comp(const float2& v, int e) { return e ? v.y : v.x; }
+__device__ __forceinline__ float comp(const float& v, int) { return v; }
 
-// saved-gate slab, "lane-native": one record {r0 r1 z0 z1 n0 n1 hn0 hn1} per (t, tile, wave, lane); bf16 mode packs it
-// into ONE 16-byte vector (a wave instruction stores 1 KiB contiguous), fp32 mode into two.
-template <bool BF16>
-struct SvRec { static constexpr int F = BF16 ? 4 : 8; };   // floats per record
-template <bool BF16>
+// saved-gate slab, "lane-native": one record {r z n hn} x UPL per (t, tile, wave, lane); bf16 mode packs it into ONE 8 x UPL-byte
+// vector (a wave instruction stores 512 x UPL bytes contiguous), fp32 mode into UPL 16-byte ones.
+template <bool BF16, int UPL>
+struct SvRec { static constexpr int F = (BF16 ? 2 : 4) * UPL; };   // floats per record
+template <bool BF16, int UPL>
 __device__ __forceinline__ long sv_index(int t, int ntile, int tile, int w, int lane) {
-  return ((((long)t * ntile + tile) * 4 + w) * 64 + lane) * SvRec<BF16>::F;
+  return ((((long)t * ntile + tile) * (8 / UPL) + w) * 64 + lane) * SvRec<BF16, UPL>::F;
 }
-struct Gates { float r[2], z[2], n[2], hn[2]; };
+template <int UPL>
+struct Gates { float r[UPL], z[UPL], n[UPL], hn[UPL]; };
 
-template <bool BF16>
-__device__ __forceinline__ void save_gates(float* p, const Gates& g) {
+template <bool BF16, int UPL>
+__device__ __forceinline__ void save_gates(float* p, const Gates<UPL>& g) {
   if constexpr (BF16) {
-    bf16x8 a;
+    typename Pack<UPL>::G a;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { a[e] = to_bf16(g.r[e]); a[2 + e] = to_bf16(g.z[e]); a[4 + e] = to_bf16(g.n[e]); a[6 + e] = to_bf16(g.hn[e]); }
-    *reinterpret_cast<bf16x8*>(p) = a;
+    for (int e = 0; e < UPL; ++e) { a[e] = to_bf16(g.r[e]); a[UPL + e] = to_bf16(g.z[e]); a[2 * UPL + e] = to_bf16(g.n[e]); a[3 * UPL + e] = to_bf16(g.hn[e]); }
+    *reinterpret_cast<typename Pack<UPL>::G*>(p) = a;
   } else {
-    *reinterpret_cast<float4*>(p) = make_float4(g.r[0], g.r[1], g.z[0], g.z[1]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(g.n[0], g.n[1], g.hn[0], g.hn[1]);
+#pragma unroll
+    for (int e = 0; e < UPL; ++e) *reinterpret_cast<float4*>(p + 4 * e) = make_float4(g.r[e], g.z[e], g.n[e], g.hn[e]);
   }
 }
-template <bool BF16>
-__device__ __forceinline__ void load_gates(const float* p, Gates& g) {
-  if constexpr (BF16) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+template <int UPL>
+__device__ __forceinline__ void decode_gates(const typename Pack<UPL>::G& a, Gates<UPL>& g) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { g.r[e] = (float)a[e]; g.z[e] = (float)a[2 + e]; g.n[e] = (float)a[4 + e]; g.hn[e] = (float)a[6 + e]; }
+  for (int e = 0; e < UPL; ++e) { g.r[e] = (float)a[e]; g.z[e] = (float)a[UPL + e]; g.n[e] = (float)a[2 * UPL + e]; g.hn[e] = (float)a[3 * UPL + e]; }
+}
+template <bool BF16, int UPL>
+__device__ __forceinline__ void load_gates(const float* p, Gates<UPL>& g) {
+  if constexpr (BF16) {
+    decode_gates<UPL>(*reinterpret_cast<const typename Pack<UPL>::G*>(p), g);
   } else {
-    const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-    g.r[0] = x.x; g.r[1] = x.y; g.z[0] = x.z; g.z[1] = x.w; g.n[0] = y.x; g.n[1] = y.y; g.hn[0] = y.z; g.hn[1] = y.w;
+#pragma unroll
+    for (int e = 0; e < UPL; ++e) { const float4 x = *reinterpret_cast<const float4*>(p + 4 * e); g.r[e] = x.x; g.z[e] = x.y; g.n[e] = x.z; g.hn[e] = x.w; }
   }
 }
 
@@ -181,11 +204,25 @@ __device__ __forceinline__ void stamp_end(const KernelStamp& k) {
   if (k.ring && threadIdx.x == 0) atomicMin(&k.ring[(((unsigned)*k.step & (unsigned)(k.slots - 1)) * 4u + k.id) * 2u + 1u], ~(unsigned long long)wall_clock64());
 }
 
+// `make PHASE_PROBE=1` builds only (tools/gru_phase.sh): MIMRL_GRU_SKIP=<mask> removes one phase of the cell step from BOTH recurrence
+// kernels -- results become wrong, the launch time shows what that phase costs on the dependent chain (the method that found the
+// guarded loads in round 2 and the waitcnt merges in round 3).  1: products; 2: transcendental / gradient math; 4: global stores;
+// 8: operand loads; 16: s_barrier; 32: LDS state tile (write + fragment reads).  Compiled out of the default build.
+// (COMPILE-time: the kernels carry the mask as a template parameter and the probe build instantiates one copy per mask -- a run-time test
+//  of the mask in the step loop is itself a branch whose join degrades the wait counts: that version of the probe ran 2x slower than
+//  the kernel it was meant to explain.)
+#define GSKIP(bit) ((SKIP & (bit)) != 0)
+
 #ifndef GRU_BF16_MINB
-#define GRU_BF16_MINB 2   // -DGRU_BF16_MINB=1: the AGPR-using build of the reproducibility hunt (DESIGN section 5), debugging only
+#define GRU_BF16_MINB 2   // -DGRU_BF16_MINB=1: the AGPR-using build of the reproducibility hunt (DESIGN.md section 5), debugging only
 #endif
-template <bool BF16, bool SAVE>
-__global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(GruFwdArgs a) {
+// UPL = hidden units per lane: 2 -> 4 waves x 32 units (256 threads), 1 -> 8 waves x 16 units (512 threads: two waves per SIMD).
+// Round 4.  The per-step chain of a wave is  LDS read -> its MFMAs -> gate math (quarter-rate v_exp / v_rcp) -> LDS write -> barrier,
+// and with ONE wave per SIMD nothing runs under any of it.  With two waves per SIMD each wave has half the products (12 instead of 24)
+// and half the gate math (one unit per lane), and one wave's transcendentals run under the other's MFMAs; the matrix pipe of a SIMD
+// still sees the same 24 products per step -- its floor, 384 cycles -- but no longer waits for 2 x the gate math in between.
+template <bool BF16, bool SAVE, int UPL, int SKIP = 0>
+__global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   stamp_begin(a.stamp);
   __shared__ __attribute__((aligned(16))) Tile<BF16, H> hs[2];
@@ -194,7 +231,7 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
   const GruSeq& q = a.seq[mod][dir];
   const int B = a.B, T = a.T, ntile = gridDim.x;
   const int n = lane & 15, kq = lane >> 4;
-  const int u0 = 32 * w + 2 * n;
+  const int u0 = 16 * UPL * w + UPL * n;
   // padding lanes (kq >= btv, or rows past B) MIRROR the last real row of the tile instead of idling: they compute
   // and store exactly the same values, so no load or store in the loop is guarded and the waitcnt bookkeeping of the
   // software pipeline stays exact (a guarded access is a branch, and the wait after a branch merge is vmcnt(0))
@@ -202,11 +239,11 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
   const int len = a.lens[mod][b];
 
   // ---- W_hh slice -> registers as MFMA B fragments: column n of N-tile (g, s) is gate row g*H + u0 + s
-  typename C::Frag wr[3][2][C::KS_F];
+  typename C::Frag wr[3][UPL][C::KS_F];
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < UPL; ++s) {
       const float* row = q.w_hh + (long)(g * H + u0 + s) * H;
 #pragma unroll
       for (int ks = 0; ks < C::KS_F; ++ks) {
@@ -222,57 +259,69 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
         }
       }
     }
-  float bh[3][2];
+  float bh[3][UPL];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const float2 v = ld2(q.b_hh + g * H + u0);
-    bh[g][0] = v.x; bh[g][1] = v.y;
-  }
+  for (int g = 0; g < 3; ++g) ldu<UPL>(q.b_hh + g * H + u0, bh[g]);
 
   // ---- state
-  float hreg[2] = {0.f, 0.f};
-  put2(hs[0], kq, u0, 0.f, 0.f);
+  float hreg[UPL];
+#pragma unroll
+  for (int s = 0; s < UPL; ++s) hreg[s] = 0.f;
+  putu<UPL>(hs[0], kq, u0, hreg);
   __syncthreads();
 
   const float* gx_b = q.gx + (long)b * T * G + u0;                       // gx [B,T,3H]
   float* out_b = q.out + (long)b * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
-  float* sv_b = SAVE ? q.saved + sv_index<BF16>(0, ntile, tile, w, lane) : nullptr;
-  const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
+  float* sv_b = SAVE ? q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane) : nullptr;
+  const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
 
   // software pipeline, distance 2: gx of step+2 is requested at the end of step (two named buffers, loop unrolled by
   // two, so that no register copy has to wait for the youngest load); the tail re-reads the last step
-  auto load_gx = [&](float2 (&dst)[3], int step) {
+  using GX = float[3][UPL];
+  auto load_gx = [&](GX& dst, int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? T - 1 - sc : sc;
     const float* p = gx_b + (long)t * G;
     // (compiler-tracked loads here: with the explicit-wait loads of the BPTT kernel this loop measured 31.0 instead of 29.3 us per
     //  launch -- its waitcnt counts are exact in every second step and two short in the others, and that beats one exact wait)
 #pragma unroll
-    for (int g = 0; g < 3; ++g) dst[g] = ld2(p + g * H);
+    for (int g = 0; g < 3; ++g) ldu<UPL>(p + g * H, dst[g]);
   };
-  float2 gxA[3], gxB[3];
+  GX gxA, gxB;
   load_gx(gxA, 0);
   load_gx(gxB, 1);
 
-  auto do_step = [&](const int step, const int cur, float2 (&gx)[3], auto first) {
+  auto do_step = [&](const int step, const int cur, GX& gx) {
     const int t = dir ? T - 1 - step : step;
 
-    f32x4 acc[3][2];
+    f32x4 acc[3][UPL];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acc[g][s] = f32x4{bh[g][s], 0.f, 0.f, 0.f};   // only register 0 is read
+      for (int s = 0; s < UPL; ++s) acc[g][s] = f32x4{bh[g][s], 0.f, 0.f, 0.f};   // only register 0 is read
     if constexpr (BF16) {   // all A-fragments of the state tile requested up front (see gru_bwd_kernel)
       typename C::Frag sf[C::KS_F];
+      if constexpr (!GSKIP(32)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS_F; ++ks) sf[ks] = state_frag(hs[cur], ks, lane);
+      } else {
+#pragma unroll
+      for (int ks = 0; ks < C::KS_F; ++ks) sf[ks] = wr[0][0][ks];
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!GSKIP(1)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS_F; ++ks)
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-          for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(sf[ks], wr[g][s][ks], acc[g][s]);
+          for (int s = 0; s < UPL; ++s) acc[g][s] = mfma16(sf[ks], wr[g][s][ks], acc[g][s]);
+      } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int s = 0; s < UPL; ++s) acc[g][s][0] += (float)sf[g & 3][s];
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < C::KS_F; ++ks) {
@@ -280,33 +329,39 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
-          for (int s = 0; s < 2; ++s) acc[g][s] = mfma16(sf, wr[g][s][ks], acc[g][s]);
+          for (int s = 0; s < UPL; ++s) acc[g][s] = mfma16(sf, wr[g][s][ks], acc[g][s]);
       }
     }
 
-    (void)first;
     const bool valid = t < len;
-    const float gr[2] = {gx[0].x, gx[0].y}, gz[2] = {gx[1].x, gx[1].y}, gn[2] = {gx[2].x, gx[2].y};
-    Gates gt;
-    float ho[2];
+    Gates<UPL> gt;
+    float ho[UPL];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      gt.r[s] = fast_sigmoid(gr[s] + acc[0][s][0]);
-      gt.z[s] = fast_sigmoid(gz[s] + acc[1][s][0]);
+    for (int s = 0; s < UPL; ++s) {
       gt.hn[s] = acc[2][s][0];
-      gt.n[s] = fast_tanh(gn[s] + gt.r[s] * gt.hn[s]);
+      if constexpr (!GSKIP(2)) {
+        gt.r[s] = fast_sigmoid(gx[0][s] + acc[0][s][0]);
+        gt.z[s] = fast_sigmoid(gx[1][s] + acc[1][s][0]);
+        gt.n[s] = fast_tanh(gx[2][s] + gt.r[s] * gt.hn[s]);
+      } else {
+        gt.r[s] = 0.25f * (gx[0][s] + acc[0][s][0]);
+        gt.z[s] = 0.25f * (gx[1][s] + acc[1][s][0]);
+        gt.n[s] = 0.5f * (gx[2][s] + gt.r[s] * gt.hn[s]);
+      }
       const float hnew = gt.n[s] + gt.z[s] * (hreg[s] - gt.n[s]);
       ho[s] = valid ? hnew : 0.f;
       hreg[s] = valid ? hnew : hreg[s];
     }
-    put2(hs[cur ^ 1], kq, u0, hreg[0], hreg[1]);
-    st2(out_b + (long)t * a.out_ld, ho[0], ho[1]);
-    if constexpr (SAVE) save_gates<BF16>(sv_b + t * sv_step, gt);
-    lds_barrier();
+    if constexpr (!GSKIP(32)) putu<UPL>(hs[cur ^ 1], kq, u0, hreg);
+    if constexpr (!GSKIP(4)) {
+      stu<UPL>(out_b + (long)t * a.out_ld, ho);
+      if constexpr (SAVE) save_gates<BF16, UPL>(sv_b + t * sv_step, gt);
+    }
+    if constexpr (!GSKIP(16)) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // refill this buffer only now, behind the barrier (a compiler fence): its old contents are dead, so the loop-carried
     // value stays in the same registers.  Issued earlier, old and new values would be live together and the copy at the
     // loop back-edge would wait for the youngest load -- the whole latency back on the critical path.
-    load_gx(gx, step + 2);
+    if constexpr (!GSKIP(8)) load_gx(gx, step + 2);
     asm volatile("" ::: "memory");   // ... and do not let the scheduler sink the loads towards their use either
   };
   // the first pair is peeled: the waitcnt bookkeeping at the loop header merges the counts of all incoming edges
@@ -314,15 +369,15 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
   // for the youngest prefetch -- on every iteration
   int step = 0;
   if (T >= 2) {
-    do_step(0, 0, gxA, std::true_type{});
-    do_step(1, 1, gxB, std::false_type{});
+    do_step(0, 0, gxA);
+    do_step(1, 1, gxB);
     step = 2;
   }
   for (; step + 1 < T; step += 2) {
-    do_step(step, 0, gxA, std::false_type{});
-    do_step(step + 1, 1, gxB, std::false_type{});
+    do_step(step, 0, gxA);
+    do_step(step + 1, 1, gxB);
   }
-  if (step < T) { if (step == 0) do_step(step, 0, gxA, std::true_type{}); else do_step(step, 0, gxA, std::false_type{}); }
+  if (step < T) do_step(step, 0, gxA);
   stamp_end(a.stamp);
 }
 
@@ -338,10 +393,13 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_fwd_kernel(
 // __launch_bounds__(256, 2) for the bf16 instantiations: with (256, 1) the compiler parks 12 (backward) / 48 (forward) values in AGPRs,
 // and next to THAT build a 223-VGPR kernel of another stream (kmix_bwd<MODE 2>) produced non-reproducible results (DESIGN.md section 5:
 // 30 of 30 fresh engines exact with the AGPR-free build, ~70 % of them wrong with the other; mechanism not understood).  190 VGPRs, no
-// AGPRs, no scratch, same speed.  The fp32 instantiations need more than 256 registers and keep (256, 1).
-template <bool BF16, bool DGBF>
-__global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(GruBwdArgs a) {
+// AGPRs, no scratch, same speed.  The fp32 instantiations need more than 256 registers and keep (256, 1).  (UPL = 1: 512 threads, one
+// workgroup per CU, at most 256 registers per lane by construction.)
+template <bool BF16, bool DGBF, int UPL, int SKIP = 0>
+__global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_bwd_kernel(GruBwdArgs a) {
   using C = Cfg<BF16>;
+  using F = typename Pack<UPL>::F;
+  using GR = typename Pack<UPL>::G;
   stamp_begin(a.stamp);
   __shared__ __attribute__((aligned(16))) Tile<BF16, G> ds[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -349,16 +407,16 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
   const GruSeqBwd& q = a.seq[mod][dir];
   const int B = a.B, T = a.T, ntile = gridDim.x;
   const int n = lane & 15, kq = lane >> 4;
-  const int u0 = 32 * w + 2 * n;
+  const int u0 = 16 * UPL * w + UPL * n;
   // padding lanes mirror the last real row of the tile (see gru_fwd_kernel); only the bias sums must not count them
   const bool own = kq < a.btv && tile * a.btv + kq < B;
   const int b = min(tile * a.btv + min(kq, a.btv - 1), B - 1);
   const int len = a.lens[mod][b];
 
   // B fragments of W_hh (k = gate row 0..383, column = unit u0 + s)
-  typename C::Frag wr[2][C::KS_B];
+  typename C::Frag wr[UPL][C::KS_B];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < UPL; ++s) {
 #pragma unroll
     for (int ks = 0; ks < C::KS_B; ++ks) {
       if constexpr (BF16) {
@@ -372,36 +430,39 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
     }
   }
 
-  float carry[2] = {0.f, 0.f};
-  float sb[4][2];     // running bias-gradient sums of this lane's (unit, batch) slots: [dr', dz', dn', dn'*r]
+  float carry[UPL];
+  float sb[4][UPL];     // running bias-gradient sums of this lane's (unit, batch) slots: [dr', dz', dn', dn'*r]
 #pragma unroll
-  for (int g = 0; g < 4; ++g) sb[g][0] = sb[g][1] = 0.f;
+  for (int e = 0; e < UPL; ++e) { carry[e] = 0.f; sb[0][e] = sb[1][e] = sb[2][e] = sb[3][e] = 0.f; }
 
   const long bb = b;
   const float* out_b = q.out + bb * T * a.out_ld + dir * H + u0;        // forward outputs of THIS direction (h_prev source)
   const float* dout_b = q.dout + bb * T * a.dout_ld + a.dout_off * dir + u0;
   const long dg_o = bb * (long)T * 4 * H + u0, hp_o = bb * (long)T * H + u0;   // element offsets (fp32 or bf16 elements: DGBF)
-  const float* sv_b = q.saved + sv_index<BF16>(0, ntile, tile, w, lane);
-  const long sv_step = (long)ntile * 4 * 64 * SvRec<BF16>::F;
+  const float* sv_b = q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane);
+  const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
 
   // software pipeline, distance 2 (see gru_fwd_kernel): every load is unconditional and in bounds (padded steps read
   // stale-but-initialised records and are masked in the math).  h_prev is the previous VALID output of this direction;
   // with packed semantics that is simply out[tprev] when tprev is inside [0,len) and the zero initial state otherwise
   // (selected at use).
-  struct Ops { Gates g; bf16x8 graw; float2 DO, HP; };
+  struct Ops { Gates<UPL> g; GR graw; F DO, HP; };
   auto fetch = [&](Ops& o, int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? sc : T - 1 - sc;
     const int tprev = dir ? t + 1 : t - 1;
     const int tc = tprev < 0 ? 0 : (tprev >= T ? T - 1 : tprev);
-    if constexpr (BF16) {   // explicit-wait loads (see gld8): the packed gate record is decoded behind the wait
-      gld16(o.graw, sv_b + t * sv_step);
-      gld8(o.DO, dout_b + (long)t * a.dout_ld);
-      gld8(o.HP, out_b + (long)tc * a.out_ld);
+    if constexpr (BF16) {   // explicit-wait loads (see gld): the packed gate record is decoded behind the wait
+      gld(o.graw, sv_b + t * sv_step);
+      gld(o.DO, dout_b + (long)t * a.dout_ld);
+      gld(o.HP, out_b + (long)tc * a.out_ld);
     } else {
-      load_gates<BF16>(sv_b + t * sv_step, o.g);
-      o.DO = ld2(dout_b + (long)t * a.dout_ld);
-      o.HP = ld2(out_b + (long)tc * a.out_ld);
+      load_gates<BF16, UPL>(sv_b + t * sv_step, o.g);
+      float x[UPL];
+      ldu<UPL>(dout_b + (long)t * a.dout_ld, x);
+      if constexpr (UPL == 2) o.DO = make_float2(x[0], x[1]); else o.DO = x[0];
+      ldu<UPL>(out_b + (long)tc * a.out_ld, x);
+      if constexpr (UPL == 2) o.HP = make_float2(x[0], x[1]); else o.HP = x[0];
     }
   };
   Ops opA, opB;
@@ -415,21 +476,19 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
     const bool valid = t < len;
     if constexpr (BF16) {
       vm_wait<decltype(wait)::value>(nx.graw, nx.DO, nx.HP);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { nx.g.r[e] = (float)nx.graw[e]; nx.g.z[e] = (float)nx.graw[2 + e]; nx.g.n[e] = (float)nx.graw[4 + e]; nx.g.hn[e] = (float)nx.graw[6 + e]; }
+      decode_gates<UPL>(nx.graw, nx.g);
     }
     const Ops& op = nx;
-    float dhz[2];
-    float drp[2] = {0.f, 0.f}, dzp[2] = {0.f, 0.f}, dnp[2] = {0.f, 0.f}, dnr[2] = {0.f, 0.f};
+    float dhz[UPL], drp[UPL], dzp[UPL], dnp[UPL], dnr[UPL], hp[UPL];
     const int tprev = dir ? t + 1 : t - 1;
     const bool hp_ok = valid && tprev >= 0 && tprev < len;
-    const float hp[2] = {hp_ok ? op.HP.x : 0.f, hp_ok ? op.HP.y : 0.f};
-    if (valid) {
-      const float dd[2] = {op.DO.x, op.DO.y};
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < UPL; ++e) { drp[e] = dzp[e] = dnp[e] = dnr[e] = 0.f; hp[e] = hp_ok ? comp(op.HP, e) : 0.f; }
+    if (valid && !GSKIP(2)) {
+#pragma unroll
+      for (int e = 0; e < UPL; ++e) {
         const float rr = op.g.r[e], zz = op.g.z[e], nn = op.g.n[e], hn = op.g.hn[e];
-        const float dh = dd[e] + carry[e];
+        const float dh = comp(op.DO, e) + carry[e];
         const float dn = dh * (1.f - zz);
         const float dz = dh * (hp[e] - nn);
         dnp[e] = dn * (1.f - nn * nn);
@@ -439,47 +498,64 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
         dhz[e] = dh * zz;
       }
     } else {
-      dhz[0] = carry[0]; dhz[1] = carry[1];
+#pragma unroll
+      for (int e = 0; e < UPL; ++e) dhz[e] = carry[e];
     }
-    put2(ds[cur], kq, 0 * H + u0, drp[0], drp[1]);
-    put2(ds[cur], kq, 1 * H + u0, dzp[0], dzp[1]);
-    put2(ds[cur], kq, 2 * H + u0, dnr[0], dnr[1]);
+    if constexpr (!GSKIP(32)) {
+      putu<UPL>(ds[cur], kq, 0 * H + u0, drp);
+      putu<UPL>(ds[cur], kq, 1 * H + u0, dzp);
+      putu<UPL>(ds[cur], kq, 2 * H + u0, dnr);
+    }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { sb[0][e] += drp[e]; sb[1][e] += dzp[e]; sb[2][e] += dnp[e]; sb[3][e] += dnr[e]; }
-    st2o<DGBF>(q.hprev, hp_o + (long)t * H, hp[0], hp[1]);
-    const long dgt = dg_o + (long)t * 4 * H;
-    st2o<DGBF>(q.dg, dgt + 0 * H, drp[0], drp[1]);
-    st2o<DGBF>(q.dg, dgt + 1 * H, dzp[0], dzp[1]);
-    st2o<DGBF>(q.dg, dgt + 2 * H, dnp[0], dnp[1]);
-    st2o<DGBF>(q.dg, dgt + 3 * H, dnr[0], dnr[1]);
-    lds_barrier();
-    if constexpr (decltype(pf)::value) fetch(nx, step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
+    for (int e = 0; e < UPL; ++e) { sb[0][e] += drp[e]; sb[1][e] += dzp[e]; sb[2][e] += dnp[e]; sb[3][e] += dnr[e]; }
+    // (probe builds: the skipped stores / loads are replaced by the same NUMBER of cheap operations on one cache line, so that the
+    //  explicit wait counts stay exact)
+    constexpr bool sk4 = GSKIP(4), sk8 = GSKIP(8);
+    stuo<DGBF, UPL>(q.hprev, sk4 ? hp_o : hp_o + (long)t * H, hp);
+    const long dgt = sk4 ? dg_o : dg_o + (long)t * 4 * H;
+    stuo<DGBF, UPL>(q.dg, dgt + 0 * H, drp);
+    stuo<DGBF, UPL>(q.dg, dgt + (sk4 ? 0 : 1) * H, dzp);
+    stuo<DGBF, UPL>(q.dg, dgt + (sk4 ? 0 : 2) * H, dnp);
+    stuo<DGBF, UPL>(q.dg, dgt + (sk4 ? 0 : 3) * H, dnr);
+    if constexpr (!GSKIP(16)) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (decltype(pf)::value) fetch(nx, sk8 ? 0 : step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
     asm volatile("" ::: "memory");
-    f32x4 acc[2];
+    f32x4 acc[UPL];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) acc[s] = f32x4{dhz[s], 0.f, 0.f, 0.f};   // only register 0 is read
+    for (int s = 0; s < UPL; ++s) acc[s] = f32x4{dhz[s], 0.f, 0.f, 0.f};   // only register 0 is read
     if constexpr (BF16) {
       // ALL twelve A-fragments of the dgh tile are requested before the first product (12 x 16 B per lane, distinct registers).  Left to
       // itself the compiler reads every fragment into ONE register quad -- ds_read, s_waitcnt lgkmcnt(0), two MFMAs, twelve times: an LDS
       // round trip per k-step on the dependent chain of every cell step.  __builtin_amdgcn_sched_barrier keeps the scheduler from sinking
       // the reads back to their uses (an empty asm with a memory clobber does not).
       typename C::Frag sf[C::KS_B];
+      if constexpr (!GSKIP(32)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks) sf[ks] = state_frag(ds[cur], ks, lane);
+      } else {
+#pragma unroll
+      for (int ks = 0; ks < C::KS_B; ++ks) sf[ks] = wr[0][ks];
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!GSKIP(1)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc[s] = mfma16(sf[ks], wr[s][ks], acc[s]);
+        for (int s = 0; s < UPL; ++s) acc[s] = mfma16(sf[ks], wr[s][ks], acc[s]);
+      } else {
+#pragma unroll
+      for (int s = 0; s < UPL; ++s) acc[s][0] += (float)sf[s][0];
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks) {
         const auto sf = state_frag(ds[cur], ks, lane);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc[s] = mfma16(sf, wr[s][ks], acc[s]);
+        for (int s = 0; s < UPL; ++s) acc[s] = mfma16(sf, wr[s][ks], acc[s]);
       }
     }
-    carry[0] = acc[0][0]; carry[1] = acc[1][0];
+#pragma unroll
+    for (int s = 0; s < UPL; ++s) carry[s] = acc[s][0];
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
   };
   // An ODD T runs one un-pipelined step FIRST (operands fetched, waited for with vmcnt(0), no prefetch), then the even remainder through
@@ -488,7 +564,7 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
   // in flight (the loads are invisible to it by design): the last cell step of every odd-T sequence read stale gates, the BPTT gradients
   // were off by ~10 % and different from run to run (found in round 4 by the odd-T case of test_gradients_reproducible, which ADVICE r03
   // asked for; even T never ran that code).  Now the only place where in-flight asm destinations cross a block boundary is the loop's own
-  // back edge, and tests/test_codeobj.py checks the ISA there (no VALU read of an asm-load destination between its load and its wait).
+  // back edge, and tests/test_codeobj.py checks the ISA there (no instruction touches an asm-load destination between its load and its wait).
   using W0 = std::integral_constant<int, 0>; using W3 = std::integral_constant<int, 3>; using W8 = std::integral_constant<int, 8>;
   int step = 0;
   if (T & 1) {
@@ -517,14 +593,14 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
+      for (int e = 0; e < UPL; ++e) {
         float v = own ? sb[g][e] : 0.f;
         v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
         sb[g][e] = v;
       }
     if (kq == 0) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
+      for (int e = 0; e < UPL; ++e) {
         const int unit = u0 + e;
         if (q.db_ih) {
           atomicAdd(&q.db_ih[0 * H + unit], sb[0][e]); atomicAdd(&q.db_ih[1 * H + unit], sb[1][e]);
@@ -542,6 +618,37 @@ __global__ __launch_bounds__(256, BF16 ? GRU_BF16_MINB : 1) void gru_bwd_kernel(
 
 }  // namespace
 
+// waves per workgroup of the bf16 recurrence kernels: 4 (two units per lane); MIMRL_GRU_WAVES=8: one unit per lane, two waves per SIMD.
+// Round 4 measured both at cfg2 (interleaved runs, in-graph launch stamps): forward 28.7 (8 waves) vs 30.0 us (4), BPTT 47.6 vs 44.0 us,
+// step 0.855-0.858 vs 0.853-0.863 ms -- the 8-wave BPTT loses more than the forward gains, and the phase elimination of the forward
+// kernel (tools/gru_phase.sh, profiles/r04_gru_phase.json) says why the halved per-wave work buys so little: of 0.62 us per cell step the
+// 24 products per SIMD are 0.16 us (the matrix pipe's floor: 24 x 16 cycles, whatever the wave count), the LDS tile round trip 0.08, the
+// barrier 0.06, the stores 0.06, the six transcendentals 0.04, the operand loads 0.02 -- and 0.2 us are neither (address / select / wait
+// instructions of the step itself).  Default stays 4.
+static int gru_upl() {
+  static const int waves = getenv("MIMRL_GRU_WAVES") ? atoi(getenv("MIMRL_GRU_WAVES")) : 4;   // tuning knob
+  return waves == 8 ? 1 : 2;
+}
+
+static int gru_skip() {
+#ifdef MIMRL_PHASE_PROBE
+  static const int v = getenv("MIMRL_GRU_SKIP") ? atoi(getenv("MIMRL_GRU_SKIP")) : 0;
+  return v;
+#else
+  return 0;
+#endif
+}
+void gru_probe_setup() {}
+
+#ifdef MIMRL_PHASE_PROBE
+// probe build: one instantiation per mask of tools/gru_phase.sh (bf16, saved gates, bf16 dg: the benchmarked kernels)
+template <int UPL, int SKIP>
+static void probe_fwd(dim3 grid, hipStream_t s, const GruFwdArgs& a) { hipLaunchKernelGGL((gru_fwd_kernel<true, true, UPL, SKIP>), grid, dim3(512 / UPL), 0, s, a); }
+template <int UPL, int SKIP>
+static void probe_bwd(dim3 grid, hipStream_t s, const GruBwdArgs& a, size_t pad) { hipLaunchKernelGGL((gru_bwd_kernel<true, true, UPL, SKIP>), grid, dim3(512 / UPL), pad, s, a); }
+#define GRU_PROBE_CASES(X) X(1) X(2) X(4) X(8) X(16) X(32) X(3)
+#endif
+
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
   if (a.B <= 0 || a.T <= 0) return set_error(MIMRL_ERR_ARG, "gru_forward: empty batch");
   if (a.btv < 1 || a.btv > BR) return set_error(MIMRL_ERR_ARG, "gru_forward: btv must be in [1,4]");
@@ -550,19 +657,26 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
   for (int m = 0; m < a.nmod; ++m)
     for (int d = 0; d < 2; ++d)
       if ((a.seq[m][d].saved != nullptr) != save) return set_error(MIMRL_ERR_ARG, "gru_forward: saved slabs must be all set or all null");
+#ifdef MIMRL_PHASE_PROBE
+  if (bf16 && save && gru_skip()) {
+#define X(M) if (gru_skip() == M) { if (gru_upl() == 1) probe_fwd<1, M>(grid, s, a); else probe_fwd<2, M>(grid, s, a); }
+    GRU_PROBE_CASES(X)
+#undef X
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
+#endif
   if (bf16) {
-    static const int fpad_kb = getenv("MIMRL_GRU_FWD_LDS_PAD") ? atoi(getenv("MIMRL_GRU_FWD_LDS_PAD")) : 0;   // tuning knob (experiment), as above
-    if (save && fpad_kb > 0) {
-      static bool attr = false;
-      auto kern = gru_fwd_kernel<true, true>;
-      if (!attr) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, fpad_kb * 1024)); attr = true; }
-      hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)fpad_kb * 1024, s, a);
-    } else
-    if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gru_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+    if (gru_upl() == 1) {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1>), grid, dim3(512), 0, s, a);
+    } else {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 2>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 2>), grid, dim3(256), 0, s, a);
+    }
   } else {
-    if (save) hipLaunchKernelGGL((gru_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gru_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+    if (save) hipLaunchKernelGGL((gru_fwd_kernel<false, true, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gru_fwd_kernel<false, false, 2>), grid, dim3(256), 0, s, a);
   }
   LAUNCH_CHECK();
   return MIMRL_OK;
@@ -580,15 +694,36 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   // MIMRL_GRU_LDS_PAD=<KiB> overrides (0 = off).
   static const int pad_env = getenv("MIMRL_GRU_LDS_PAD") ? atoi(getenv("MIMRL_GRU_LDS_PAD")) : -1;
   const int pad_kb = pad_env >= 0 ? pad_env : ((long)grid.x * grid.y * grid.z <= 128 ? 144 : 0);
-  if (bf16 && a.dg_bf16 && pad_kb > 0) {
-    static bool attr = false;
-    auto kern = gru_bwd_kernel<true, true>;
-    if (!attr) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)(pad_kb > 150 ? 150 : pad_kb) * 1024, s, a);
-  } else
-  if (bf16 && a.dg_bf16) hipLaunchKernelGGL((gru_bwd_kernel<true, true>), grid, dim3(256), 0, s, a);
-  else if (bf16) hipLaunchKernelGGL((gru_bwd_kernel<true, false>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gru_bwd_kernel<false, false>), grid, dim3(256), 0, s, a);
+  const size_t pad = bf16 && a.dg_bf16 && pad_kb > 0 ? (size_t)(pad_kb > 150 ? 150 : pad_kb) * 1024 : 0;
+#ifdef MIMRL_PHASE_PROBE
+  if (bf16 && a.dg_bf16 && gru_skip()) {
+#define X(M) if (gru_skip() == M) { if (gru_upl() == 1) probe_bwd<1, M>(grid, s, a, 0); else probe_bwd<2, M>(grid, s, a, 0); }
+    GRU_PROBE_CASES(X)
+#undef X
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
+#endif
+  if (bf16 && gru_upl() == 1) {
+    auto k1 = gru_bwd_kernel<true, true, 1>;
+    auto k0 = gru_bwd_kernel<true, false, 1>;
+    if (pad) {
+      static bool attr = false;
+      if (!attr) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    }
+    if (a.dg_bf16) hipLaunchKernelGGL(k1, grid, dim3(512), pad, s, a);
+    else hipLaunchKernelGGL(k0, grid, dim3(512), 0, s, a);
+  } else if (bf16) {
+    auto k1 = gru_bwd_kernel<true, true, 2>;
+    if (pad) {
+      static bool attr = false;
+      if (!attr) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    }
+    if (a.dg_bf16) hipLaunchKernelGGL(k1, grid, dim3(256), pad, s, a);
+    else hipLaunchKernelGGL((gru_bwd_kernel<true, false, 2>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gru_bwd_kernel<false, false, 2>), grid, dim3(256), 0, s, a);
+  }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
