@@ -42,6 +42,10 @@ struct GemmDesc {
   // feed the ill-conditioned backward of CubeMLP (see cube_fused.hip).  Honoured by the fast path with both operands k-contiguous
   // (every forward product of the step at aligned sizes); other kernels ignore it and round to bf16.
   int f16 = 0;
+  // output storage: C is an FP16 array behind the float-typed pointer (strides in fp16 elements); plain store only (no atomic / split-K /
+  // beta / pre).  For the hoisted GRU input projections gx[B,T,3H] of long sequences, which are written once and read once: at cfg3 the
+  // projection is bound by its 786 MB of fp32 stores.
+  int c_f16 = 0;
 };
 
 // A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T

@@ -206,6 +206,13 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
         const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < d.M) { atomicAdd(Cn + (long)m * d.sc_m, v[r]); csum += v[r]; }
       }
+    } else if (d.c_f16) {   // fp16-stored output (saturating): half the bytes of a store-bound tall projection
+      _Float16* __restrict__ Ch = reinterpret_cast<_Float16*>(d.C) + oc + (long)n * d.sc_n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < d.M) { Ch[(long)m * d.sc_m] = to_f16_sat(v[r]); csum += v[r]; }
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -916,6 +923,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
     return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
+  if (d.c_f16 && (d.atomic || pl.nsplit > 1 || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.colsum))
+    return set_error(MIMRL_ERR_ARG, "gemm: an fp16-stored output takes the plain store only (no atomic / split-K / beta / pre / column sums)");
   KernelArgs ka;
   ka.d = d;
   ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0;

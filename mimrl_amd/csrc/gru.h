@@ -23,6 +23,7 @@ struct GruFwdArgs {
   const int* lens[2];      // [modality][B] valid lengths (packed-sequence semantics)
   int B, T, out_ld, nmod;
   int btv;             // batch rows per workgroup (1..4)
+  int gx_f16 = 0;      // gx is an FP16 array behind the float-typed pointer (bf16 mode only; written by a GemmDesc::c_f16 projection)
 };
 
 struct GruSeqBwd {

@@ -221,7 +221,7 @@ __device__ __forceinline__ void stamp_end(const KernelStamp& k) {
 // and with ONE wave per SIMD nothing runs under any of it.  With two waves per SIMD each wave has half the products (12 instead of 24)
 // and half the gate math (one unit per lane), and one wave's transcendentals run under the other's MFMAs; the matrix pipe of a SIMD
 // still sees the same 24 products per step -- its floor, 384 cycles -- but no longer waits for 2 x the gate math in between.
-template <bool BF16, bool SAVE, int UPL, int SKIP = 0>
+template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false>   // GXH: gx stored as fp16
 __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   stamp_begin(a.stamp);
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   __syncthreads();
 
   const float* gx_b = q.gx + (long)b * T * G + u0;                       // gx [B,T,3H]
+  const _Float16* gxh_b = reinterpret_cast<const _Float16*>(q.gx) + (long)b * T * G + u0;   // (GXH: the same array as fp16 elements)
   float* out_b = q.out + (long)b * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
   float* sv_b = SAVE ? q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane) : nullptr;
   const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
@@ -281,11 +282,20 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   auto load_gx = [&](GX& dst, int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? T - 1 - sc : sc;
-    const float* p = gx_b + (long)t * G;
     // (compiler-tracked loads here: with the explicit-wait loads of the BPTT kernel this loop measured 31.0 instead of 29.3 us per
     //  launch -- its waitcnt counts are exact in every second step and two short in the others, and that beats one exact wait)
+    if constexpr (GXH) {
+      const _Float16* p = gxh_b + (long)t * G;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) ldu<UPL>(p + g * H, dst[g]);
+      for (int g = 0; g < 3; ++g) {
+        if constexpr (UPL == 2) { typedef __attribute__((ext_vector_type(2))) _Float16 h2; const h2 x = *reinterpret_cast<const h2*>(p + g * H); dst[g][0] = (float)x[0]; dst[g][1] = (float)x[1]; }
+        else dst[g][0] = (float)p[g * H];
+      }
+    } else {
+      const float* p = gx_b + (long)t * G;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) ldu<UPL>(p + g * H, dst[g]);
+    }
   };
   GX gxA, gxB;
   load_gx(gxA, 0);
@@ -666,7 +676,16 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
     return MIMRL_OK;
   }
 #endif
-  if (bf16) {
+  if (a.gx_f16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_forward: fp16-stored gx needs the bf16 recurrence mode");
+  if (bf16 && a.gx_f16) {
+    if (gru_upl() == 1) {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, true>), grid, dim3(512), 0, s, a);
+    } else {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 2, 0, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 2, 0, true>), grid, dim3(256), 0, s, a);
+    }
+  } else if (bf16) {
     if (gru_upl() == 1) {
       if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1>), grid, dim3(512), 0, s, a);

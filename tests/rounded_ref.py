@@ -284,27 +284,28 @@ class _GruDirQ(torch.autograd.Function):
         return dgx, dw, db, None, None, None
 
 
-def bigru2_q(p, prefix, x, lengths, rnd, rq):
+def bigru2_q(p, prefix, x, lengths, rnd, rq, gxq=identity):
     """oracle.bigru2 with the kernels' rounding: hoisted projections through ``mm`` (``rnd``: fp16 forward operands, bf16 gradient
-    operands), recurrences through _GruDirQ (``rq``: bf16)."""
+    operands), recurrences through _GruDirQ (``rq``: bf16); ``gxq``: storage rounding of the projection's OUTPUT gx (fp16 for long
+    sequences, engine.hip gx_f16; straight-through: the BPTT's gradient w.r.t. gx does not see it)."""
     inp = x
     for layer in range(2):
         outs = []
         for rev, sfx in ((False, ""), (True, "_reverse")):
-            gx = mm(inp, p[f"{prefix}.weight_ih_l{layer}{sfx}"], rnd) + p[f"{prefix}.bias_ih_l{layer}{sfx}"]
+            gx = ste(gxq, mm(inp, p[f"{prefix}.weight_ih_l{layer}{sfx}"], rnd) + p[f"{prefix}.bias_ih_l{layer}{sfx}"])
             outs.append(_GruDirQ.apply(gx, p[f"{prefix}.weight_hh_l{layer}{sfx}"], p[f"{prefix}.bias_hh_l{layer}{sfx}"], lengths, rev, rq))
         inp = torch.cat(outs, dim=-1)
     H = inp.shape[-1] // 2
     return inp[..., :H] + inp[..., H:]
 
 
-def encoders_q(p, opt, t_feat, a, v, rnd, rq):
+def encoders_q(p, opt, t_feat, a, v, rnd, rq, gxq=identity):
     """Model.forward up to the stacked cube input (Model.py:395-475; oracle.model_forward lines 187-206), dropout 0.
     -> (x [B,L,3,D], T_F, A_F, V_F)."""
     D, L = opt.d_common, opt.time_len
     t = mm(t_feat, p["W_t.weight"], rnd)
     la, lv = R.infer_lengths(a), R.infer_lengths(v)
-    ah = F.relu(F.layer_norm(bigru2_q(p, "rnn_a", a, la, rnd, rq), (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))
-    vh = F.relu(F.layer_norm(bigru2_q(p, "rnn_v", v, lv, rnd, rq), (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
+    ah = F.relu(F.layer_norm(bigru2_q(p, "rnn_a", a, la, rnd, rq, gxq), (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))
+    vh = F.relu(F.layer_norm(bigru2_q(p, "rnn_v", v, lv, rnd, rq, gxq), (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
     pad = lambda y: F.pad(y, (0, 0, 0, L - y.shape[1]))
     return torch.stack([pad(t), pad(ah), pad(vh)], dim=2), t.mean(1), ah.mean(1), vh.mean(1)

@@ -353,12 +353,14 @@ def test_fragment_image_mlp_kernel_equals_the_staged_one(name, monkeypatch):
 # (name, T override, dcube kind).  cfg2_sep / cfg2_ragged = the bench shape (B = 128, T = 50; ragged: four batch rows of different lengths per
 # recurrence workgroup); T = 49 / 1: the odd-T path of the BPTT kernel (an un-pipelined first step, round 4); cfg1: B = 32 (one batch row per
 # recurrence workgroup)
-ENC = [("cfg2_sep", None, True), ("cfg2_ragged", None, True), ("cfg2_ragged", 49, True), ("cfg1_ragged", None, True), ("cfg2_sep", 1, True),
-       ("tiny_ragged", None, True), ("cfg2_sep", None, False), ("cfg2_ragged", None, False)]
+# gxh: fp16-stored input projections (MIMRL_GX_F16=1: an opt-in path, slower at cfg3 with the present store pattern -- engine.hip)
+ENC = [("cfg2_sep", None, True, False), ("cfg2_ragged", None, True, False), ("cfg2_ragged", 49, True, False), ("cfg1_ragged", None, True, False),
+       ("cfg2_sep", 1, True, False), ("tiny_ragged", None, True, False), ("cfg2_sep", None, False, False), ("cfg2_ragged", None, False, False),
+       ("cfg2_ragged", None, True, True), ("cfg2_ragged", 49, True, True)]
 
 
-@pytest.mark.parametrize("name,T_,margin", ENC, ids=[f"{n}{'' if t is None else '-T' + str(t)}{'' if mg else '-full'}" for n, t, mg in ENC])
-def test_encoders_vs_rounded_oracle(name, T_, margin):
+@pytest.mark.parametrize("name,T_,margin,gxh", ENC, ids=[f"{n}{'' if t is None else '-T' + str(t)}{'' if mg else '-full'}{'-gxf16' if gh else ''}" for n, t, mg, gh in ENC])
+def test_encoders_vs_rounded_oracle(name, T_, margin, gxh, monkeypatch):
     """The recurrence kernels of the benchmarked mode -- gru_bwd_kernel<bf16, bf16 dg> is the largest kernel of the step, gru_fwd_kernel<bf16>
     the fourth -- with the fp16 input projections, LayerNorm / ReLU and every weight-gradient GEMM around them, driven through
     mimrl_probe_encoders (the step's own code path) on a fixture batch, against float64 autograd of the oracle (Model.py:395-466; nn.GRU on
@@ -371,6 +373,8 @@ def test_encoders_vs_rounded_oracle(name, T_, margin):
     c, opt, batch, banks = case(name)
     T = c["T"] if T_ is None else T_
     batch = tuple(b[:, :T] if b.dim() == 3 else b for b in batch)
+    monkeypatch.setenv("MIMRL_GX_F16", "1" if gxh else "0")
+    gxq = Q.r_f16 if gxh else Q.identity
     eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=c["N"], precision="bf16")
     p = perturbed_params(opt, c["seed"])
     eng.load_params(p)
@@ -389,7 +393,7 @@ def test_encoders_vs_rounded_oracle(name, T_, margin):
         with torch.no_grad():
             D = opt.d_common
             la, lv = R.infer_lengths(tb[1]), R.infer_lengths(tb[2])
-            pre = [F.layer_norm(Q.bigru2_q(p, f"rnn_{m}", tb[1 + i], ln_, Q.F16_FWD, Q.r_bf16), (D,), p[f"ln_{m}.weight"], p[f"ln_{m}.bias"], 1e-6)
+            pre = [F.layer_norm(Q.bigru2_q(p, f"rnn_{m}", tb[1 + i], ln_, Q.F16_FWD, Q.r_bf16, gxq), (D,), p[f"ln_{m}.weight"], p[f"ln_{m}.bias"], 1e-6)
                    for i, (m, ln_) in enumerate((("a", la), ("v", lv)))]
         for i in range(2):
             dcube[:, :T, 1 + i][pre[i].abs() < 2e-3] = 0.0
@@ -400,13 +404,13 @@ def test_encoders_vs_rounded_oracle(name, T_, margin):
 
     def reference(rnd, rq):
         leaves = {n: p[n].clone().requires_grad_(True) for n in names}
-        xr, tf, af, vf = Q.encoders_q({**p, **leaves}, opt, tb[0], tb[1], tb[2], rnd, rq)
+        xr, tf, af, vf = Q.encoders_q({**p, **leaves}, opt, tb[0], tb[1], tb[2], rnd, rq, gxq if rq is not Q.identity else Q.identity)
         obj = (xr * dcube).sum() + (tf * dmean[0]).sum() + (af * dmean[1]).sum() + (vf * dmean[2]).sum()
         return xr.detach(), torch.autograd.grad(obj, [leaves[n] for n in names])
 
     ref, gr = reference(Q.F16_FWD, Q.r_bf16)
     exact, gx = reference(Q.EXACT, Q.identity)              # the un-rounded oracle: how far the 16-bit mode is from fp32 / fp64
-    key = f"encoders/{name}{'' if T_ is None else '-T' + str(T_)}{'' if margin else '-full'}"
+    key = f"encoders/{name}{'' if T_ is None else '-T' + str(T_)}{'' if margin else '-full'}{'-gxf16' if gxh else ''}"
     rec = {"cube_x": errs(x.cpu(), ref), "cube_x_vs_unrounded_oracle": errs(x.cpu(), exact)}
     worst = ("", 0.0)
     for n, gw, ge in zip(names, gr, gx):

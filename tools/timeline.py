@@ -12,9 +12,10 @@ for r in rows:
     name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void mimrl::", "").replace("mimrl::", "")
     ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 ks.sort()
-# a step starts at each stage-1 anchor draw (two sample_anchors launches per step: take every second one)
+# a step starts at its anchor draw (round 4: ONE sample_anchors launch per step for both stages; rounds 1-3: two -- every second one)
 marks = [i for i, k in enumerate(ks) if k[2].startswith("sample_anchors")]
-marks = marks[::2]
+if not any(k[2].startswith("knn_tile_kernel") for k in ks):
+    marks = marks[::2]
 lo, hi = marks[-back - 1], marks[-back]
 step = ks[lo:hi]
 t0 = step[0][0]
