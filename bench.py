@@ -266,7 +266,15 @@ def extra_schedules(eng, args, B, T, rank):
         # the launch structure every rank runs at N > 1 (dist.ddp_two_stage_step: per-stage gradient graphs, deferred stage-2
         # forward tail, separate apply launches), here with world = 1, i.e. WITHOUT the two collectives: what the split costs
         eng.set_stage2_prefetch(mdist.ddp_prefetch_mode(2))
+        os.environ["MIMRL_DDP_SPLIT"] = "0"
         extra["ms_per_step_ddp_schedule_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
+        # ... and the same with the split main-bucket reduce (MIMRL_DDP_SPLIT=1: stage 2 as two launches so that the early piece of the
+        # bucket can travel under the layer-0 BPTT; dist.ddp_stage2_split) -- what the split costs a rank before a byte moves
+        os.environ["MIMRL_DDP_SPLIT"] = "1"
+        try:
+            extra["ms_per_step_ddp_split_schedule_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
+        finally:
+            os.environ.pop("MIMRL_DDP_SPLIT", None)
         eng.set_stage2_prefetch(True)
     host = [tuple(torch.from_numpy(x).pin_memory() for x in synth.synthetic_batch(B, T, seed=100 + i)) for i in range(4)]
     state = {"i": 0}

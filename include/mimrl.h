@@ -129,6 +129,11 @@ int mimrl_stage2_step(mimrl_handle* h);                /* Solver.py:221-236 : ma
 int mimrl_two_stage_step(mimrl_handle* h);             /* the new Solver.step(datas): mimrl_stage1_step then mimrl_stage2_step on the bound batch; in overlap mode with graphs ONE captured graph, one launch */
 int mimrl_stage_grads(mimrl_handle* h, int stage);     /* forward+backward only (data-parallel: all-reduce follows) */
 int mimrl_stage_apply(mimrl_handle* h, int stage);     /* value-clip + Adam on that stage's bucket         */
+/* mimrl_stage_grads(h, 2) in two launches, for a data-parallel caller that starts reducing gradients while the rest of the backward pass
+ * still runs (north_star: "all-reduce ... overlapped with ... backward"; the reference's nn.DataParallel reduces after backward,
+ * Solver.py:33-35): part 0 = everything up to and including the layer-1 GRU weight gradients -- afterwards every main-bucket gradient
+ * EXCEPT rnn_*_l0* (the layer-0 GRU tensors) is final --, part 1 = the layer-0 BPTT and its weight gradients.  ABI 4. */
+int mimrl_stage_grads_part(mimrl_handle* h, int stage, int part);
 int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses);  /* Solver.evaluate body (Solver.py:255-258) */
 int mimrl_estimate(mimrl_handle* h, int stage);        /* estimators only, on the features of the last forward (Model.py:305/343) */
 /* Overlap mode for Solver.step() (one stage-1 + one stage-2 update on ONE batch).  When on,

@@ -297,6 +297,7 @@ struct mimrl_handle {
   // estimators
   float *tin = nullptr, *ta[3], *tout = nullptr, *scores = nullptr, *dscores = nullptr;
   float *cP = nullptr, *cQ = nullptr, *ca[3];
+  int split_part = 0;                  // 1: encoders_backward stops behind the layer-1 weight gradients (mimrl_stage_grads_part); 0: whole pass
   bool gx_f16 = false;                 // the hoisted GRU input projections gx[B,T,3H] are stored as fp16 (long sequences, bf16 mode: create)
   int *knn_idx = nullptr, *knn_idx2 = nullptr;   // neighbour indices; stage 2 has its own set (prefetch mode samples it early)
   char* knn_scr[2] = {nullptr, nullptr};         // candidate lists of the MFMA kNN (knn_mfma.hip), one per stage
@@ -420,8 +421,8 @@ struct mimrl_handle {
   // sets of (text, audio, video, labels) buffers (mimrl_set_inputs) -- the next batch is uploaded into the idle set while the
   // step runs on the active one, and switching costs no device work.
   struct GraphSet {
-    hipGraphExec_t graph[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    int rows[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+    hipGraphExec_t graph[3][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [..][2], [..][3]: the two halves of a split stage-2 gradient pass
+    int rows[3][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}};
     hipGraphExec_t tail = nullptr; int tail_rows = -1;
     const void* in[4] = {nullptr, nullptr, nullptr, nullptr};
   } gsets[2];
@@ -438,7 +439,7 @@ struct mimrl_handle {
     for (int q = 0; q < 2; ++q) {
       if (set >= 0 && q != set) continue;
       for (int s = 0; s <= 2; ++s)
-        for (int k = 0; k < 2; ++k) retire(gsets[q].graph[s][k]);
+        for (int k = 0; k < 4; ++k) retire(gsets[q].graph[s][k]);
       retire(gsets[q].tail);
     }
   }
@@ -504,6 +505,7 @@ struct mimrl_handle {
   int wt_images(hipStream_t st, bool bwd_bf16, bool launch, bool* d_fused);
   int model_backward();
   int encoders_backward(float* dcube);
+  int gru_layer_backward(int l);
   struct StreamGuard {   // route every launch of a scope to another stream
     mimrl_handle* h; hipStream_t saved;
     StreamGuard(mimrl_handle* h_, hipStream_t st) : h(h_), saved(h_->stream) { h->stream = st; }
@@ -518,6 +520,7 @@ struct mimrl_handle {
   GatherSum head_gather;               // sources of the F_F gradient (summed inside head_bwd) while head_gather_on
   bool head_gather_on = false;
   hipEvent_t ev_dmean = nullptr;       // T / A / V feature gradients ready (gathered on side 0)
+  hipEvent_t ev_pre = nullptr;         // MIMRL_BPTT_FIRST: the point the parked kernels are flushed behind (encoders_backward -> gru_layer_backward)
   int estimators_all(int stage, bool want_grad, bool backward);
   // grouped MLP stacks living in the critic bucket (nb groups, uniform parameter stride `pstride`)
   int mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2], const int* dims,
@@ -1667,7 +1670,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
   // 3 behind the dh0 product, 4 behind the layer-0 BPTT
   static const int dbg_join_at = dbg_env("MIMRL_DBG_JOIN_AT") ? atoi(dbg_env("MIMRL_DBG_JOIN_AT")) : 0;
   static const bool bptt_first = getenv("MIMRL_BPTT_FIRST") != nullptr;
-  hipEvent_t ev_pre = nullptr;
+  ev_pre = nullptr;
   if (bptt_first && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU && !deferred.empty()) {
     MX(next_event(&ev_pre));
     HIPX(hipEventRecord(ev_pre, stream));
@@ -1687,8 +1690,19 @@ int mimrl_handle::encoders_backward(float* dcube) {
     return MIMRL_OK;
   }
   if (kmix_pg_on_side3) { MX(join(3, 3)); kmix_pg_on_side3 = false; }   // (long finished by now: they started beside the CubeMLP chain)
+  MX(gru_layer_backward(1));
+  if (split_part == 1) return join(0, 5);   // data parallel, split reduce: everything but the layer-0 GRU gradients is final here
+  MX(gru_layer_backward(0));
+  return join(0, 5);
+}
+
+// BPTT of one bi-GRU layer (both modalities, both directions) + its weight gradients (+ the gradient to the layer below)
+int mimrl_handle::gru_layer_backward(int l) {
+  const int B = cfg.batch, T = cfg.seq_len;
+  const long BT_ = (long)B * T;
+  static const int dbg_join_at = dbg_env("MIMRL_DBG_JOIN_AT") ? atoi(dbg_env("MIMRL_DBG_JOIN_AT")) : 0;
   const float* xin[2] = {bufs.audio, bufs.video};
-  for (int l = 1; l >= 0; --l) {
+  {
     GruBwdArgs a;
     a.B = B; a.T = T; a.out_ld = 2 * H; a.nmod = 2;
     a.dout_ld = l == 1 ? H : 2 * H; a.dout_off = l == 1 ? 0 : H;
@@ -1759,7 +1773,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
       }
       up.dwih_pack = dwih_pack; up.dwhh_pack = dwhh_pack; up.KP = KP();
       MX(l0_unpack_grads(stream, up));
-      continue;
+      return MIMRL_OK;
     }
     int rr = 0;
     for (int m = 0; m < 2; ++m) {
@@ -1788,7 +1802,6 @@ int mimrl_handle::encoders_backward(float* dcube) {
     }
     if (l == 1 && dh0_last) MX(dh0_gemm());
   }
-  MX(join(0, 5));
   return MIMRL_OK;
 }
 
@@ -2546,7 +2559,9 @@ int mimrl_handle::run(int stage, int kind) {
   if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
   // an all-reduce): always zero first -- the caller may call it repeatedly
-  if (prefetch && bank_rows > 0) {
+  if (kind == 4 && (stage != 2 || cfg.encoder != MIMRL_ENCODER_GRU))
+    return set_error(MIMRL_ERR_ARG, "mimrl_stage_grads_part: only stage 2 of the GRU encoders splits");
+  if (prefetch && bank_rows > 0 && kind != 4) {
     if (stage == 1) { fwd2_pending = true; tail2_needed = defer_tail; }
     else if (!fwd2_pending)
       return set_error(MIMRL_ERR_STATE, "stage-2 prefetch mode: stage 2 must follow a stage-1 call on the same batch");
@@ -2556,7 +2571,18 @@ int mimrl_handle::run(int stage, int kind) {
   }
   const bool skip_zero = kind == 0 && grads_clean[stage];
   auto body = [&]() -> int {
-    MX(enqueue_grads(stage, skip_zero));
+    if (kind == 4) {                 // second half of a split stage-2 gradient pass: the layer-0 GRU backward
+      if (!keep_events) ev_next = 0;
+      bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+      int r = gru_layer_backward(0);
+      if (r == 0) r = join(0, 5);
+      bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+      return r;
+    }
+    split_part = kind == 3 ? 1 : 0;
+    const int r = enqueue_grads(stage, skip_zero);
+    split_part = 0;
+    MX(r);
     if (kind == 0) MX(enqueue_apply(stage));
     return MIMRL_OK;
   };
@@ -2564,10 +2590,11 @@ int mimrl_handle::run(int stage, int kind) {
     grads_clean[stage] = true;
     return body();
   }
-  if (kind == 1) grads_clean[stage] = false;
+  if (kind == 1 || kind == 3) grads_clean[stage] = false;
   if (!cfg.use_graph || prof_on) return body();
-  hipGraphExec_t& ex = GS().graph[stage][kind];
-  if (ex && GS().rows[stage][kind] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
+  const int gk = kind >= 3 ? kind - 1 : kind;     // graph cache slot: 0 step, 1 grads, 2 / 3 the halves of a split stage-2 pass
+  hipGraphExec_t& ex = GS().graph[stage][gk];
+  if (ex && GS().rows[stage][gk] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
   if (!ex) {
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
@@ -2581,7 +2608,7 @@ int mimrl_handle::run(int stage, int kind) {
     const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
-    GS().rows[stage][kind] = bank_rows;
+    GS().rows[stage][gk] = bank_rows;
   }
   HIPX(hipGraphLaunch(ex, stream));
   return MIMRL_OK;
@@ -2815,6 +2842,12 @@ int mimrl_stage2_step(mimrl_handle* h) { return h ? h->run(2, 0) : set_error(MIM
 int mimrl_two_stage_step(mimrl_handle* h) { return h ? h->run_step() : set_error(MIMRL_ERR_ARG, "null handle"); }
 int mimrl_stage_grads(mimrl_handle* h, int stage) { return h ? h->run(stage, 1) : set_error(MIMRL_ERR_ARG, "null handle"); }
 int mimrl_stage_apply(mimrl_handle* h, int stage) { return h ? h->run(stage, 2) : set_error(MIMRL_ERR_ARG, "null handle"); }
+int mimrl_stage_grads_part(mimrl_handle* h, int stage, int part) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if (stage != 2 || (part != 0 && part != 1)) return set_error(MIMRL_ERR_ARG, "mimrl_stage_grads_part: stage 2, part 0 or 1");
+  if (h->cfg.encoder != MIMRL_ENCODER_GRU) return set_error(MIMRL_ERR_ARG, "mimrl_stage_grads_part: GRU encoders only");
+  return h->run(2, part == 0 ? 3 : 4);
+}
 
 int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");

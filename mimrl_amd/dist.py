@@ -128,10 +128,68 @@ def ddp_two_stage_step(engine, world: int):
         elif on and engine.has_update(1):
             allreduce_sum_(engine.bucket_grad(1), world)
         engine.stage_apply(1)
+        if split_reduce(world) and hasattr(engine, "stage_grads_part") and getattr(getattr(engine, "cfg", None), "encoder", 0) == 0:
+            ddp_stage2_split(engine, world)
+            return
         engine.stage_grads(2)
         if on:
             allreduce_sum_(engine.bucket_grad(2), world)
         engine.stage_apply(2)
+
+
+def split_reduce(world: int = 2) -> bool:
+    """Reduce the main bucket in two pieces, the first one UNDER the rest of the stage-2 backward pass (ddp_stage2_split): the default at
+    world > 1 since round 4 (the split costs a rank 12 us per step without communication -- bench.py:
+    ms_per_step_ddp_split_schedule_no_comm 1.026 vs 1.013 ms -- and takes 3.2 of the bucket's 4.3 MB off the exposed path).
+    MIMRL_DDP_SPLIT=0 / 1 forces it off / on (1 also at world == 1, for the one-GPU tests and the bench extra)."""
+    v = os.environ.get("MIMRL_DDP_SPLIT")
+    if v is not None:
+        return v != "0"
+    return world > 1
+
+
+def _complement(ranges, n):
+    out, at = [], 0
+    for a, b in sorted(ranges):
+        if a > at:
+            out.append((at, a))
+        at = max(at, b)
+    if at < n:
+        out.append((at, n))
+    return out
+
+
+def ddp_stage2_split(engine, world: int):
+    """Stage 2 with the gradient all-reduce overlapped with the backward pass (north_star; reference counterpart: nn.DataParallel's
+    reduce AFTER backward, Solver.py:33-35):
+
+        stage_grads_part(2, 0)   forward tail / estimators / CubeMLP + head backward, layer-1 BPTT and its weight gradients, W_t gradient
+        all-reduce(EARLY) async  every main-bucket range except the layer-0 GRU tensors: 0.80 M of 1.08 M floats (3.2 of 4.3 MB), on the
+                                 communication stream, ordered behind part 0
+        stage_grads_part(2, 1)   layer-0 BPTT + its weight gradients (~0.1 ms at cfg2) -- the early piece travels under it
+        all-reduce(LATE)         the two layer-0 ranges (rnn_v.*_l0*, rnn_a.*_l0*: 1.1 MB)
+        wait(EARLY); stage_apply(2)
+
+    What it costs a rank: one more graph launch, and the layer-1 weight-gradient GEMMs no longer run beside the layer-0 BPTT (they must be
+    final before the early piece leaves) -- bench.py reports the no-communication step time of this schedule next to the unsplit one
+    (``ms_per_step_ddp_split_schedule_no_comm``: +12 us at cfg2).  The communication side is NOT measured (one-GPU boxes only); RCCL's
+    call path for it -- asynchronous all-reduces of bucket views under a running graph -- is exercised with a one-rank communicator
+    (tests/rccl_single_rank_worker.py), the arithmetic with two gloo ranks on one GPU: replicas bit-identical, equal to mean-gradient
+    Adam (tests/ddp_gpu_worker.py), and on CPU with a NaN-poisoned late range (tests/ddp_gloo_worker.py)."""
+    on = _collectives_on(world)
+    engine.stage_grads_part(2, 0)
+    g = engine.bucket_grad(2)
+    late = engine.late_grad_ranges()
+    early = _complement(late, g.numel())
+    works = [allreduce_sum_(g[a:b], world, async_op=True) for a, b in early] if on else []
+    engine.stage_grads_part(2, 1)
+    if on:
+        for a, b in late:
+            allreduce_sum_(g[a:b], world)
+        for w in works:
+            if w is not None:
+                w.wait()
+    engine.stage_apply(2)
 
 
 def allgather_rows(x: torch.Tensor, world: int) -> torch.Tensor:

@@ -238,6 +238,28 @@ class HipEngine:
         self._coherent()
         check(self.lib.mimrl_stage_grads(self.handle, stage))
 
+    def stage_grads_part(self, stage: int, part: int):
+        """``stage_grads(2)`` in two launches (include/mimrl.h: mimrl_stage_grads_part): after part 0 every main-bucket gradient except the
+        layer-0 GRU tensors is final (``late_grad_ranges``), part 1 finishes those."""
+        self._coherent()
+        check(self.lib.mimrl_stage_grads_part(self.handle, stage, part))
+
+    def late_grad_ranges(self):
+        """[(start, stop)] float ranges of the main gradient bucket that are final only after ``stage_grads_part(2, 1)``: the layer-0 GRU
+        tensors (rnn_a / rnn_v ``*_l0*``), each modality one contiguous run of the flat bucket; the complement is final after part 0."""
+        main = sorted((off, int(np.prod(shape)), name) for name, group, off, shape in self.entries if group == 0)
+        n_main = self.main["g"].numel()
+        out = []
+        for i, (off, n, name) in enumerate(main):
+            if "_l0" not in name or not name.startswith("rnn_"):
+                continue
+            stop = main[i + 1][0] if i + 1 < len(main) else n_main          # (alignment padding up to the next tensor rides along)
+            if out and out[-1][1] == off:
+                out[-1] = (out[-1][0], stop)
+            else:
+                out.append((off, stop))
+        return out
+
     def stage_apply(self, stage: int):
         self._coherent()
         check(self.lib.mimrl_stage_apply(self.handle, stage))

@@ -40,6 +40,31 @@ class OracleEngine:
                                       for n, g in zip(self.names[stage], gs)])
         self.loss = loss.detach()
 
+    # the split stage-2 pass of the data-parallel step (HipEngine.stage_grads_part / late_grad_ranges): part 0 leaves every range but the
+    # layer-0 GRU tensors final, part 1 fills those in
+    def late_grad_ranges(self):
+        out, o = [], 0
+        for n in self.names[2]:
+            k = self.p[n].numel()
+            if n.startswith("rnn_") and "_l0" in n:
+                if out and out[-1][1] == o:
+                    out[-1] = (out[-1][0], o + k)
+                else:
+                    out.append((o, o + k))
+            o += k
+        return out
+
+    def stage_grads_part(self, stage, part):
+        assert stage == 2
+        if part == 0:
+            self.stage_grads(2)
+            self._full = self.flat[2].clone()
+            for a, b in self.late_grad_ranges():
+                self.flat[2][a:b] = float("nan")              # not final yet: a reduce of these before part 1 would poison the result
+        else:
+            for a, b in self.late_grad_ranges():
+                self.flat[2][a:b] = self._full[a:b]
+
     def stage_apply(self, stage):
         clip = float(self.opt.gradient_clip)
         grads, o = {}, 0
@@ -82,8 +107,16 @@ def main():
     flat = torch.cat([eng.p[n].reshape(-1) for n in sorted(eng.p)])
     both = mdist.allgather_rows(flat.reshape(1, -1), world)
     assert torch.equal(both[0], both[1]), "replicas diverged"
+    # round 4: Solver.step's data-parallel schedule with the SPLIT main-bucket reduce (dist.ddp_stage2_split): same result
+    os.environ["MIMRL_DDP_SPLIT"] = "1"
+    eng2 = OracleEngine(opt, oracle_params(opt, c["seed"]), local_batch(rank), banks, anchors)
+    assert len(eng2.late_grad_ranges()) == 2
+    mdist.ddp_two_stage_step(eng2, world)
+    os.environ.pop("MIMRL_DDP_SPLIT")
+    worst2 = max((eng2.p[n] - ref.p[n]).abs().max().item() for n in eng2.p)
+    assert worst2 < 1e-5 and all(torch.isfinite(v).all() for v in eng2.p.values()), f"rank {rank}: split reduce differs by {worst2}"
     if rank == 0:
-        print("DDP_OK", worst)
+        print("DDP_OK", worst, worst2)
 
 
 if __name__ == "__main__":

@@ -24,13 +24,17 @@ def local_anchors(c, r, it):
     return [np.stack([g.choice(c["N"], size=c["B"] // 2, replace=False) for _ in range(6)]) for _ in range(2)]
 
 
-def engine_part(world, rank, name="tiny_sep", precision="fp32", critic=None, deferred=False):
+def engine_part(world, rank, name="tiny_sep", precision="fp32", critic=None, deferred=False, split=False):
     """3 data-parallel two-stage steps of the real engine on rank-local batches: replicas bit-identical, and equal to single-process
     Adam on the mean of the two local gradients.  ``precision="bf16"`` + ``name="cfg2_sep"`` is the bench mode at the bench shape."""
     if deferred:
         os.environ["MIMRL_DDP_DEFERRED_TAIL"] = "1"
     else:
         os.environ.pop("MIMRL_DDP_DEFERRED_TAIL", None)
+    if split:          # round 4: main bucket reduced in two pieces, the early one under the layer-0 BPTT (dist.ddp_stage2_split)
+        os.environ["MIMRL_DDP_SPLIT"] = "1"
+    else:
+        os.environ.pop("MIMRL_DDP_SPLIT", None)
     c = dict(CONFIGS[name], lr=1e-4)
     if critic:
         c["critic"] = critic
@@ -117,7 +121,10 @@ def main():
     engine_part(world, rank, deferred=True)                                    # the round-2 schedule stays correct
     engine_part(world, rank, name="cfg2_sep", precision="bf16")                 # the bench mode at the bench shape (B = 128 per rank)
     engine_part(world, rank, name="cfg2_sep", precision="bf16", critic="concat")  # + the fused concat critic
+    engine_part(world, rank, split=True)                                        # split reduce: fp32 tiny ...
+    engine_part(world, rank, name="cfg2_sep", precision="bf16", split=True)     # ... and the bench mode at the bench shape
     os.environ.pop("MIMRL_DDP_DEFERRED_TAIL", None)
+    os.environ.pop("MIMRL_DDP_SPLIT", None)
     solver_part(world, rank)
     dist.barrier()
     if rank == 0:

@@ -13,11 +13,12 @@ from tests.golden.configs import CONFIGS, make_opt  # noqa: E402
 from tests.helpers import oracle_params  # noqa: E402
 
 
-def run(precision, name, deferred, use_dist):
+def run(precision, name, deferred, use_dist, split=False):
     if deferred:
         os.environ["MIMRL_DDP_DEFERRED_TAIL"] = "1"
     else:
         os.environ.pop("MIMRL_DDP_DEFERRED_TAIL", None)
+    os.environ["MIMRL_DDP_SPLIT"] = "1" if split else "0"      # the split main-bucket reduce: async RCCL all-reduces of bucket views
     c = dict(CONFIGS[name], lr=1e-4)
     opt = make_opt(c)
     banks = synth.synthetic_banks(c["N"], seed=c["seed"])
@@ -55,6 +56,9 @@ def main():
             d = (a - b).abs()
             # same arithmetic; float atomics reorder additions (Adam's lr * sign(g) steps flip entries with g ~ 0: 2 * lr each)
             assert torch.isfinite(a).all() and d.max().item() <= 6.5e-4 and d.mean().item() <= 2e-5, (precision, deferred, d.max().item(), d.mean().item())
+        a = run(precision, name, False, True, split=True)      # early piece in flight (async work handles on views) under stage_grads_part(2, 1)
+        d = (a - b).abs()
+        assert torch.isfinite(a).all() and d.max().item() <= 6.5e-4 and d.mean().item() <= 2e-5, (precision, "split", d.max().item(), d.mean().item())
     t = torch.ones(1 << 20, device="cuda")
     w = dist.all_reduce(t, async_op=True)
     w.wait()

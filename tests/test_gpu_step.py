@@ -817,3 +817,38 @@ def test_bf16_stored_bptt_outputs_change_nothing(monkeypatch):
         gb = res["fp32"][n]
         scale = np.abs(gb).max() + 1e-30
         assert np.abs(ga - gb).max() <= 2e-5 * scale, f"{n}: rel diff {np.abs(ga - gb).max() / scale:.2e}"
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_split_stage2_gradients_equal_the_whole_pass(graph):
+    """mimrl_stage_grads_part (the data-parallel split reduce, dist.ddp_stage2_split): part 0 + part 1 leave the SAME main gradient bucket as
+    one mimrl_stage_grads(2) -- and after part 0 alone every range outside HipEngine.late_grad_ranges() (everything but the layer-0 GRU
+    tensors) already holds its final value, which is what allows its all-reduce to start under part 1."""
+    res = {}
+    for tag in ("whole", "split"):
+        opt, N, batch, banks, eng = _bench_engine("cfg2", "bf16", graph, device_anchors=False)
+        rng = np.random.default_rng(5)
+        anchors = np.stack([rng.choice(N, size=opt.batch_size // opt.k_neighbor, replace=False) for _ in range(6)])
+        eng.set_anchors(2, anchors)
+        if tag == "whole":
+            eng.stage_grads(2)
+            torch.cuda.synchronize()
+        else:
+            eng.stage_grads_part(2, 0)
+            torch.cuda.synchronize()
+            early = eng.main["g"].clone()
+            eng.stage_grads_part(2, 1)
+            torch.cuda.synchronize()
+            late = eng.late_grad_ranges()
+            assert len(late) == 2 and sum(b - a for a, b in late) > 250000        # rnn_v.*_l0*, rnn_a.*_l0*
+            keep = torch.ones(early.numel(), dtype=torch.bool, device=early.device)
+            for a, b in late:
+                keep[a:b] = False
+            assert torch.equal(early[keep], eng.main["g"][keep]), "a gradient outside the late ranges changed in part 1"
+            assert (early[~keep] != eng.main["g"][~keep]).any(), "part 1 wrote nothing"
+        res[tag] = {n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if not n.startswith("v")}
+        eng.close()
+    top = max(np.abs(v).max() for v in res["whole"].values())
+    for n, want in res["whole"].items():
+        scale = max(np.abs(want).max(), 1e-3 * top)
+        assert np.abs(res["split"][n] - want).max() <= 1e-4 * scale, n      # (float atomics reorder additions: the reproducibility band)
