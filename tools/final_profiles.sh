@@ -33,6 +33,6 @@ if [ "${1:-}" != "quick" ]; then
   timeout 200 python bench.py --no-cpu-baseline --workload cfg2-concat > $out/bench_cfg2_concat.json 2>/dev/null
   timeout 300 python bench.py --no-cpu-baseline --workload cfg3 --steps 30 --warmup 5 --profile-steps 5 > $out/bench_cfg3.json 2>/dev/null
   timeout 300 python bench.py --no-cpu-baseline --workload cfg5 --steps 50 --warmup 5 --profile-steps 5 > $out/bench_cfg5_bf16.json 2>/dev/null
-  timeout 300 tools/critical_path.sh 100 > $out/critical_path.txt 2>&1; tail -3 $out/critical_path.txt
+  timeout 900 tools/critical_path.sh 100 > $out/critical_path.txt 2>&1; tail -3 $out/critical_path.txt
 fi
 tail -c 400 $out/bench_default_1.err

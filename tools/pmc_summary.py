@@ -18,7 +18,7 @@ def collect(d, counter):
 ft, fc = collect(fdir, "FETCH_SIZE")
 wt, wc = collect(wdir, "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes) -- "
-                 "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-steps 0 --no-graph",
+                 "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --prewarm-ms 0 --profile-steps 0 --no-extra (the replayed-graph schedule `value` is measured on; tools/final_profiles.sh)",
        "units": "rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KB; bytes = KB*1024",
        "correction": "MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> doubled here; WRITE_SIZE taken as is",
        "steps_in_trace": steps, "kernels": {}}
