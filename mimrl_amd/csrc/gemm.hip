@@ -206,7 +206,7 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
         const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < d.M) { atomicAdd(Cn + (long)m * d.sc_m, v[r]); csum += v[r]; }
       }
-    } else if (d.c_f16) {   // fp16-stored output (saturating): half the bytes of a store-bound tall projection
+    } else if (!GEN && d.c_f16) {   // fp16-stored output (saturating; plain instantiations only: in the GEN ones the extra path cost scratch)
       _Float16* __restrict__ Ch = reinterpret_cast<_Float16*>(d.C) + oc + (long)n * d.sc_n;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -25,7 +25,8 @@ def ks():
 
 
 def test_every_tu_is_present(ks):
-    for name in ("gru_fwd_kernel<true, true, 1>", "gru_bwd_kernel<true, true, 1>", "gru_fwd_kernel<true, true, 2>", "gru_bwd_kernel<true, true, 2>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0, false>",
+    for name in ("gru_fwd_kernel<true, true, 1, 0, false>", "gru_bwd_kernel<true, true, 1, 0>", "gru_fwd_kernel<true, true, 2, 0, false>",
+                 "gru_bwd_kernel<true, true, 2, 0>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0, false>",
                  "concat_fwd_kernel<3>", "mlp_img8_kernel<true, 4>", "adam_kernel", "knn_tile_kernel<1, 4>", "knn_merge_kernel<2, 4>", "sample_anchors_kernel", "lstm_fwd_kernel"):
         assert name in ks, name
     assert len(ks) > 120
@@ -37,7 +38,7 @@ def test_bf16_recurrence_kernels_are_agpr_free(ks):
         if name.startswith(("gru_fwd_kernel<true", "gru_bwd_kernel<true")):
             assert v["agpr_count"] == 0, (name, v)
             assert v["vgpr_count"] <= 224 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
-            assert v["max_flat_workgroup_size"] == 256
+            assert v["max_flat_workgroup_size"] == (512 if ", 1, 0" in name else 256), (name, v)      # 8-wave variants (one unit per lane): 512
 
 
 def test_bench_path_kernels_do_not_spill(ks):
