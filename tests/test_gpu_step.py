@@ -613,7 +613,7 @@ REPRO = [("cfg2", 2, False), ("cfg1", 2, False), ("cfg2", 2, True), ("cfg2", 1, 
 def test_gradients_reproducible(workload, stage, graph):
     """Fresh engine, same inputs, the mode bench.py runs: EVERY gradient tensor of the stage must come out the same three times
     (float atomics reorder additions: observed <= 3e-6 of the tensor scale with the separable critic, <= 2.7e-4 in the concat critic's
-    split-K weight gradients over B*B rows; bands 1e-4 / 1e-3) -- both stages, eager and captured, odd T (49, 1),
+    split-K weight gradients over B*B rows; bands 1e-4 (3e-4 at cfg3 / cfg5) / 1e-3) -- both stages, eager and captured, odd T (49, 1),
     separable and concat critics, cfg3 (T = 500) and cfg5 (T = 1000) shapes.  Round 2b found the block-0 K-axis parameter gradients
     off by 5-30 % from run to run while their kernel ran beside the layer-1 BPTT (the structural fix keeps
     register-heavy kernels away from the recurrence, tests/test_codeobj.py pins the register facts it relies on) -- every parity test
@@ -641,7 +641,9 @@ def test_gradients_reproducible(workload, stage, graph):
             wide = concat and ".MLP_f." in n
             if wide and n.endswith("MLP_f.6.bias"):
                 continue
-            band = 1e-3 if wide else 1e-4
+            # cfg3 / cfg5 sum each recurrence weight gradient over T * B = 128 000+ rows with float atomics: 1.0006e-4 of the tensor's scale
+            # was seen once in eight runs (rnn_v.weight_ih_l0_reverse), so the long shapes get 3e-4 -- the bug class this guards is 5-30 %.
+            band = 1e-3 if wide else 3e-4 if workload[:4] in ("cfg3", "cfg5") else 1e-4
             scale = max(np.abs(runs[0][n]).max(), (1e-2 if wide else 1e-3) * top)
             assert np.abs(runs[r][n] - runs[0][n]).max() <= band * scale, (r, n, np.abs(runs[r][n] - runs[0][n]).max() / scale)
 
