@@ -465,6 +465,18 @@ def main():
             except Exception as e:      # noqa: BLE001 -- optional figure only
                 extra["cfg3"] = {"error": repr(e)[:200]}
             log(f"cfg3 (child process): {extra['cfg3']}")
+            # the same cfg2 step through the DETERMINISTIC build (MIMRL_DETERMINISTIC=1 -> libmimrl_hip_det.so, csrc/det.h: order-independent
+            # fixed-point accumulation instead of float atomics, one stream; bit-identical run to run): what reproducibility costs
+            cmdd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg2", "--steps", "30", "--warmup", "5", "--prewarm-ms", "0",
+                    "--profile-steps", "0", "--no-cpu-baseline", "--no-extra"]
+            try:
+                rd = json.loads(subprocess.run(cmdd, capture_output=True, text=True, timeout=600,
+                                               env=dict(os.environ, MIMRL_DETERMINISTIC="1")).stdout.strip().splitlines()[-1])
+                extra["deterministic_build"] = {"ms_per_step": rd["ms_per_step"], "iters_per_sec": rd["value"], "steps": rd["steps"],
+                                                "loaded": rd["config"].get("deterministic_build")}
+            except Exception as e:      # noqa: BLE001 -- optional figure only
+                extra["deterministic_build"] = {"error": repr(e)[:200]}
+            log(f"deterministic build (child process): {extra['deterministic_build']}")
 
     # ---- live per-phase and GEMM-family timing with HIP events on the launch streams (eager launches)
     phases, roof, kernels = {}, None, []
@@ -614,7 +626,8 @@ def main():
                        "unit_definition": f"one iter = stage-1 + stage-2 update over one B={B} batch; under weak-scaling DP every "
                                           "global step processes n_gpus such batches (gradients all-reduced), so value = n_gpus*steps/time",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch,
+                       "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch and not _lib.DETERMINISTIC,
+                       "deterministic_build": bool(_lib.DETERMINISTIC),
                        "shared_encoder_prefix": (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX"), "samples_per_sec": B * world * args.steps / wall},
             "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,
             "achieved_tflops_whole_step": world * algorithmic_flops(opt, N) / (wall / args.steps) / 1e12,

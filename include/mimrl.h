@@ -105,6 +105,12 @@ enum {
 
 const char* mimrl_last_error(void);
 int mimrl_abi_version(void);
+/* 1 in the deterministic build of this library (libmimrl_hip_det.so, `make det`; loaded when MIMRL_DETERMINISTIC=1 -- the reference's
+ * switch is torch.backends.cudnn.deterministic + the seeds of Main.py:14-20): every floating-point accumulation that the default build does
+ * with float atomics is order-independent there (64-bit fixed point, csrc/det.h), the engine runs on one stream, and two runs of a stage
+ * on the same inputs give bit-identical gradients (2: its accumulation table -- 8 M distinct target addresses per launch -- ran full at
+ * some launch since load, which then fell back to float atomics; synchronises).  0 in the default build. */
+int mimrl_deterministic(void);
 int mimrl_device_check(void);   /* 0 iff a gfx950 device is usable by this process */
 
 /* ---- parameter layout (host only; callable without a GPU) ---- */

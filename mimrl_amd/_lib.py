@@ -9,7 +9,10 @@ from typing import List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MIMRL_LIB_PATH: another build of the library -- in practice the host-only AddressSanitizer build (`make -C mimrl_amd/csrc asan`,
 # tools/asan_host.sh), which carries the layout / error / KDTree entry points only: the bindings of symbols it lacks are skipped
-LIB_PATH = os.environ.get("MIMRL_LIB_PATH") or os.path.join(_HERE, "libmimrl_hip.so")
+# MIMRL_DETERMINISTIC=1: the deterministic build (`make -C mimrl_amd/csrc det`; csrc/det.h): same sources, every float atomic replaced by
+# order-independent 64-bit fixed-point accumulation, one stream.  Missing library = error, as for the default one.
+DETERMINISTIC = os.environ.get("MIMRL_DETERMINISTIC", "0") not in ("", "0")
+LIB_PATH = os.environ.get("MIMRL_LIB_PATH") or os.path.join(_HERE, "libmimrl_hip_det.so" if DETERMINISTIC else "libmimrl_hip.so")
 MAX_BLOCKS = 4
 NSCALARS = 64
 PHASES = ["gemm_misc", "gru_fwd", "gru_bwd", "cube_fwd", "cube_bwd", "est_fwd", "est_bwd", "opt", "model_misc"]
@@ -137,7 +140,7 @@ ENCODERS = {"gru": 0, "conv": 1, "lstm": 2}
 BASELINES = {"constant": 0, "gaussain": 1, "unnormalized": 2}                 # MIMRL_BASELINE_* (the reference spells it "gaussain")                                             # MIMRL_ENCODER_*
 
 EXPORTS = [
-    "mimrl_last_error", "mimrl_abi_version", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry", "mimrl_layout_entry_dim2",
+    "mimrl_last_error", "mimrl_abi_version", "mimrl_deterministic", "mimrl_device_check", "mimrl_layout_count", "mimrl_layout_entry", "mimrl_layout_entry_dim2",
     "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_set_inputs", "mimrl_stage1_step", "mimrl_stage2_step", "mimrl_two_stage_step",
     "mimrl_stage_grads", "mimrl_stage_grads_part", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read", "mimrl_profile_read_gemm",
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_stage2_forward_tail", "mimrl_set_grad_scale", "mimrl_destroy", "mimrl_op_gemm", "mimrl_op_gemm_ex", "mimrl_op_gemm_wgrad_group",

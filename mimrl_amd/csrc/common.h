@@ -31,6 +31,19 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 #define LAUNCH_CHECK() HIPX(hipGetLastError())
+}  // namespace mimrl
+#include "det.h"
+#ifdef MIMRL_DET
+// deterministic build: every launch is followed, on its own stream, by the flush of the fixed-point accumulation table (det.h)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                 \
+  do {                                                                            \
+    (void)::mimrl::det_init();                                                    \
+    hipLaunchKernelGGLInternal((kernel), (grid), (block), (lds), (stream), __VA_ARGS__); \
+    (void)::mimrl::det_flush(stream);                                             \
+  } while (0)
+#endif
+namespace mimrl {
 
 // Environment knobs.  Tuning knobs (stream placement, kernel variants: results unchanged) are read with getenv() where they
 // are used.  DEBUG knobs change RESULTS (skip work, stop a kernel early, re-create a placement known to miscompute): they exist

@@ -17,7 +17,7 @@ template <int SAVE>   // what the backward pass gets: see ConcatFwdArgs::save (c
 __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 act[CR][AP];
   __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
-  __shared__ float sc[CR];
+  __shared__ LdsAcc sc[CR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;
   const int e = blockIdx.y, B = a.B;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
       }
     }
   }
-  if (tid < CR) sc[tid] = 0.f;
+  if (tid < CR) sc[tid].zero();
   float hp[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) hp[r] = 0.f;
@@ -137,10 +137,10 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float t = half_sum_hi(hp[r]);                       // valid in lanes 16..31 / 48..63
-    if (lr == 16) atomicAdd(&sc[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh], t);
+    if (lr == 16) sc[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh].add(t);
   }
   __syncthreads();
-  if (tid < CR) a.scores[ebase + row0 + tid] = sc[tid] + a.b3[(long)e * a.pstride];
+  if (tid < CR) a.scores[ebase + row0 + tid] = sc[tid].get() + a.b3[(long)e * a.pstride];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -189,13 +189,13 @@ template <bool COMPACT, bool WG>   // COMPACT: bitmask / bf16 inputs; WG: stage 
 __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 gt[CR][AP];
   __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
-  __shared__ float cs[2][CH];            // column sums of the tile (two quantities at a time)
+  __shared__ LdsAcc cs[2][CH];            // column sums of the tile (two quantities at a time)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;
   const int e = blockIdx.y, B = a.B;
   const long row0 = (long)blockIdx.x * CR, ebase = (long)e * B * B, tile = (ebase + row0) * CH;
   constexpr bool wg = WG;
-  if (tid < CH) { cs[0][tid] = 0.f; cs[1][tid] = 0.f; }
+  if (tid < CH) { cs[0][tid].zero(); cs[1][tid].zero(); }
   __syncthreads();
   // ---- dZ2 = ds w3^T (.) [a2 > 0]; this thread owns one column quad (c4) and 16 of the 128 rows
   {
@@ -238,18 +238,18 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
       }
     }
     if (wg) {
-      atomicAdd(&cs[0][c4], sdb.x); atomicAdd(&cs[0][c4 + 1], sdb.y); atomicAdd(&cs[0][c4 + 2], sdb.z); atomicAdd(&cs[0][c4 + 3], sdb.w);
-      atomicAdd(&cs[1][c4], sdw.x); atomicAdd(&cs[1][c4 + 1], sdw.y); atomicAdd(&cs[1][c4 + 2], sdw.z); atomicAdd(&cs[1][c4 + 3], sdw.w);
+      cs[0][c4].add(sdb.x); cs[0][c4 + 1].add(sdb.y); cs[0][c4 + 2].add(sdb.z); cs[0][c4 + 3].add(sdb.w);
+      cs[1][c4].add(sdw.x); cs[1][c4 + 1].add(sdw.y); cs[1][c4 + 2].add(sdw.z); cs[1][c4 + 3].add(sdw.w);
       sds = wave_sum(sds);                       // (only lane 0 of each wave, whose column quad is 0, carries a value)
     }
     __syncthreads();
     if (wg) {
       if (tid < CH) {
-        atomicAdd(a.db2 + (long)e * a.pstride + tid, cs[0][tid]);
-        atomicAdd(a.dw3 + (long)e * a.pstride + tid, cs[1][tid]);
-        cs[0][tid] = 0.f; cs[1][tid] = 0.f;
+        acc_add(a.db2 + (long)e * a.pstride + tid, cs[0][tid].get());
+        acc_add(a.dw3 + (long)e * a.pstride + tid, cs[1][tid].get());
+        cs[0][tid].zero(); cs[1][tid].zero();
       }
-      if (lane == 0) atomicAdd(a.db3 + (long)e * a.pstride, sds);
+      if (lane == 0) acc_add(a.db3 + (long)e * a.pstride, sds);
     }
   }
   // ---- dZ1 = (dZ2 W2) (.) [a1 > 0]
@@ -283,11 +283,11 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
     }
     if (wg) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) atomicAdd(&cs[0][wn * 128 + ct * 32 + lr], csum[ct]);
+      for (int ct = 0; ct < 4; ++ct) cs[0][wn * 128 + ct * 32 + lr].add(csum[ct]);
     }
   }
   __syncthreads();
-  if (wg && tid < CH) { atomicAdd(a.db1 + (long)e * a.pstride + tid, cs[0][tid]); cs[0][tid] = 0.f; }
+  if (wg && tid < CH) { acc_add(a.db1 + (long)e * a.pstride + tid, cs[0][tid].get()); cs[0][tid].zero(); }
   // ---- dZ0 = (dZ1 W1) (.) [a0 > 0]  -> dz0 (fp32) and its column sums = dP[i]
   bwd_product(acc, gt, wb, a.W1T + (long)e * a.pstride, tid, lr, lh, wm, wn);
   {
@@ -318,13 +318,13 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
       }
     }
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) atomicAdd(&cs[0][wn * 128 + ct * 32 + lr], csum[ct]);
+    for (int ct = 0; ct < 4; ++ct) cs[0][wn * 128 + ct * 32 + lr].add(csum[ct]);
   }
   __syncthreads();
   if (tid < CH) {
     const long i = row0 / B;                               // B % 128 == 0: the whole tile belongs to one x row
     float* dp = a.dP + ((long)e * B + i) * CH + tid;
-    if (B == CR) *dp = cs[0][tid]; else atomicAdd(dp, cs[0][tid]);
+    if (B == CR) *dp = cs[0][tid].get(); else acc_add(dp, cs[0][tid].get());
   }
 }
 

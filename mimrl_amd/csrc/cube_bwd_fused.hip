@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   // wts[0] = W2^T [h][o], wts[1] = W1^T [i][h], wts[2] = Wr^T [i][o]
   float (*red)[2][CT] = reinterpret_cast<float (*)[2][CT]>(&sdu[0][0]);   // phase-1 scratch; sdu is first written in phase 2
   __shared__ float acc_l[3][64];   // per-l partial sums of dgamma, dbeta, db2
-  __shared__ float acc_h[64];      // per-h partial sums of db1
+  __shared__ LdsAcc acc_h[64];      // per-h partial sums of db1
   __shared__ float sgam[64];       // LayerNorm gain (tools/isa_lint.py: read from global inside `l < ol ? ... gamma[l]` it was 32 guarded loads, each behind vmcnt(0))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int b = blockIdx.y, c0 = blockIdx.x * CT;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   {
     uint4* z = reinterpret_cast<uint4*>(&wts[0][0][0]);
     for (int i = tid; i < 3 * 64 * KP * 2 / 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < 64) { acc_l[0][tid] = 0.f; acc_l[1][tid] = 0.f; acc_l[2][tid] = 0.f; acc_h[tid] = 0.f; sgam[tid] = a.gamma[tid < ol ? tid : ol - 1]; }
+    if (tid < 64) { acc_l[0][tid] = 0.f; acc_l[1][tid] = 0.f; acc_l[2][tid] = 0.f; acc_h[tid].zero(); sgam[tid] = a.gamma[tid < ol ? tid : ol - 1]; }
   }
   __syncthreads();
   BPHASE(pb, 1);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
         sdu[nt * 32 + lr][h] = to_bf16(v);
         if (a.db1) {
           const float t = half_sum_hi(v);                        // (valid in lanes 16..31 / 48..63)
-          if (lr == 16 && h < hl) atomicAdd(&acc_h[h], t);
+          if (lr == 16 && h < hl) acc_h[h].add(t);
         }
       }
     });
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
   }
   __syncthreads();
   BPHASE(pb, 6);
-  if (a.db2 && tid < ol) atomicAdd(&a.db2[tid], acc_l[2][tid]);
-  if (a.db1 && tid >= 64 && tid - 64 < hl) atomicAdd(&a.db1[tid - 64], acc_h[tid - 64]);
+  if (a.db2 && tid < ol) acc_add(&a.db2[tid], acc_l[2][tid]);
+  if (a.db1 && tid >= 64 && tid - 64 < hl) acc_add(&a.db1[tid - 64], acc_h[tid - 64].get());
   BPHASE(pb, 7);
 }
 
@@ -227,13 +227,13 @@ constexpr int DP = 128 + 8;    // bf16 pitch (272 B)
 __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sdy[DR][DP];
   __shared__ __attribute__((aligned(16))) __bf16 sdu[DR][DP];
-  __shared__ float spg[3][128];     // this workgroup's column sums: dgamma, dbeta, db2
+  __shared__ LdsAcc spg[3][128];     // this workgroup's column sums: dgamma, dbeta, db2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const long r0 = (long)blockIdx.x * DR;
   const bool pg = a.dgamma != nullptr;
   const int pb = gridDim.x <= 200 ? 32 : 48;
   BPHASE(pb, 0);
-  if (pg) for (int i = tid; i < 3 * 128; i += 256) (&spg[0][0])[i] = 0.f;   // (visible after the barrier behind phase 1... see below)
+  if (pg) for (int i = tid; i < 3 * 128; i += 256) (&spg[0][0])[i].zero();   // (visible after the barrier behind phase 1... see below)
   // Round 3b: the LayerNorm's own operands go out FIRST (loads return in order: behind the 24 weight fragments and the 16 u values they
   // were the last to arrive although phase 1 is the first to need them)
   const int row1 = tid >> 3, part1 = tid & 7;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
         float sa = xh[j], sb = g[j], sc = dyk[j];
 #pragma unroll
         for (int o = 8; o < 64; o <<= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); sc += __shfl_xor(sc, o, 64); }
-        if (lane < 8) { atomicAdd(&spg[0][part * 16 + j], sa); atomicAdd(&spg[1][part * 16 + j], sb); atomicAdd(&spg[2][part * 16 + j], sc); }
+        if (lane < 8) { spg[0][part * 16 + j].add(sa); spg[1][part * 16 + j].add(sb); spg[2][part * 16 + j].add(sc); }
       }
     }
   }
@@ -347,15 +347,15 @@ __global__ __launch_bounds__(256) void daxis_bwd_kernel(DAxisBwdArgs a) {
     });
     if (pg) {   // db1[n] = sum over this tile's rows of dU (rows beyond R contributed zeros)
       csum += __shfl_xor(csum, 32, 64);
-      if (lh == 0) atomicAdd(&a.db1[n], csum);
+      if (lh == 0) acc_add(&a.db1[n], csum);
     }
   }
   __syncthreads();
   BPHASE(pb, 3);
   if (pg && tid < 128) {   // (spg complete: every wave's LDS atomics precede the barrier behind phase 1)
-    atomicAdd(&a.dgamma[tid], spg[0][tid]);
-    atomicAdd(&a.dbeta[tid], spg[1][tid]);
-    atomicAdd(&a.db2[tid], spg[2][tid]);
+    acc_add(&a.dgamma[tid], spg[0][tid].get());
+    acc_add(&a.dbeta[tid], spg[1][tid].get());
+    acc_add(&a.db2[tid], spg[2][tid].get());
   }
   // ---- phase 3: dX = dU W1 + dY Wr
   {
@@ -400,8 +400,8 @@ __global__ void rowln_param_grads_kernel(const float* __restrict__ y, const floa
     sg += g * (y[r * n + j] - mean[r]) * rstd[r];
     sb += g;
   }
-  atomicAdd(&dgamma[j], sg);
-  atomicAdd(&dbeta[j], sb);
+  acc_add(&dgamma[j], sg);
+  acc_add(&dbeta[j], sb);
 }
 
 // All four column-sum parameter gradients of the D axis in one streaming pass over dz, y, dY, dU ([R,128] each):
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void daxis_param_grads_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < 8; ++j) sum += base[j * 128 + c];
     float* dst = q == 0 ? dgamma : (q == 1 ? dbeta : (q == 2 ? db2 : db1));
-    if (dst) atomicAdd(&dst[c], sum);
+    if (dst) acc_add(&dst[c], sum);
   }
 }
 

@@ -1,0 +1,99 @@
+// Order-independent accumulation for the deterministic build (`make det` -> libmimrl_hip_det.so, selected by MIMRL_DETERMINISTIC=1;
+// the reference's switch is torch.backends.cudnn.deterministic, Main.py:19-20).
+//
+// Every float atomicAdd in this library goes through acc_add() (global targets) or LdsAcc (LDS targets).  In the default build both ARE
+// the float atomics they replace.  With -DMIMRL_DET:
+//   * LdsAcc holds a 64-bit fixed-point sum (2^-40 units): integer addition is associative, so the order in which the waves of a
+//     workgroup arrive no longer matters;
+//   * acc_add(p, v) adds round(v * 2^40) into a 64-bit slot of an open-addressing table keyed by the target ADDRESS (first touch claims
+//     the slot with a CAS and appends it to a dirty list).  det_flush() -- enqueued on the launch stream behind EVERY kernel launch of the
+//     build (common.h redefines hipLaunchKernelGGL) -- walks the dirty list once: *p += float(sum * 2^-40), one rounding per address,
+//     and hands the slots back.  The engine runs single-stream in this build, so a flush never sees a half-finished producer.
+// Cost: a table probe + two 64-bit atomics per contribution, ~170 extra launches per step; bench.py reports the step time of this build
+// beside the default one.  |v| < 2^23 per sum (gradient sums are orders of magnitude below it; values >= 2^-16 convert exactly).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mimrl {
+
+#ifdef MIMRL_DET
+struct DetCtx {
+  unsigned long long* keys;   // target address, 0 = free
+  long long* vals;            // fixed-point sum
+  unsigned* list;             // claimed slots, in claim order (order is irrelevant: one add per address)
+  unsigned* ctl;              // [0] = number of claimed slots, [1] = workgroups done (flush), [2] = overflow flag (sticky)
+  unsigned mask;              // slots - 1
+};
+static __device__ DetCtx g_det;   // one copy per translation unit: det_register_tu() below
+constexpr float kDetScale = 0x1p40f, kDetInv = 0x1p-40f;
+
+__device__ __forceinline__ long long det_fix(float v) { return __float2ll_rn(v * kDetScale); }
+
+__device__ __forceinline__ void acc_add(float* p, float v) {
+  const long long fx = det_fix(v);
+  if (fx == 0) return;
+  const DetCtx c = g_det;
+  if (!c.keys) { atomicAdd(p, v); return; }   // no table (det_init failed)
+  // slot = (hash of the 64-byte line, float within the line): the 16 floats of a line share one 128-byte run of `vals`, so a tile epilogue
+  // touches as many lines of the table as of its target; a collision moves the whole line to the next group
+  const unsigned long long key = reinterpret_cast<unsigned long long>(p);
+  const unsigned low = (unsigned)(key >> 2) & 15u, gmask = c.mask >> 4;
+  unsigned g = (unsigned)(((key >> 6) * 0x9E3779B97F4A7C15ull) >> 37) & gmask, h = 0;
+  bool claimed = false;
+  for (unsigned probe = 0;; ++probe) {
+    h = (g << 4) | low;
+    unsigned long long k = __atomic_load_n(&c.keys[h], __ATOMIC_RELAXED);
+    if (k == 0) {
+      k = atomicCAS(&c.keys[h], 0ull, key);
+      if (k == 0) { claimed = true; break; }
+    }
+    if (k == key) break;
+    if (probe > gmask) { c.ctl[2] = 1u; atomicAdd(p, v); return; }   // table full: flagged (mimrl_deterministic_overflowed)
+    g = (g + 1) & gmask;
+  }
+  // first touches join the dirty list: ONE counter bump per wave (a bump per address serialised millions of atomics on one word:
+  // 18 ms per cfg2 step)
+  const unsigned long long m = __ballot(claimed);
+  if (claimed) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(&c.ctl[0], (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    c.list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = h;
+  }
+  atomicAdd(reinterpret_cast<unsigned long long*>(&c.vals[h]), (unsigned long long)fx);
+}
+
+struct LdsAcc {
+  long long v;
+  __device__ __forceinline__ void zero() { v = 0; }
+  __device__ __forceinline__ void add(float x) { atomicAdd(reinterpret_cast<unsigned long long*>(&v), (unsigned long long)det_fix(x)); }
+  __device__ __forceinline__ float get() const { return (float)v * kDetInv; }
+};
+
+// host side (det.cpp)
+typedef void (*DetSetter)(const DetCtx&);
+void det_register_tu(DetSetter f);
+int det_init();                              // allocates the table, hands it to every translation unit (first launch; idempotent)
+int det_flush(hipStream_t s);                // apply and clear what the launches so far accumulated
+int det_overflowed();                        // 1 once the table ran full (results then came from plain float atomics)
+namespace {
+struct DetTuReg {
+  DetTuReg() { det_register_tu([](const DetCtx& c) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_det), &c, sizeof(DetCtx)); }); }
+};
+static DetTuReg det_tu_reg_;
+}  // namespace
+
+#else   // ---------------------------------------------------------------- default build: plain float atomics
+
+__device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }
+struct LdsAcc {
+  float v;
+  __device__ __forceinline__ void zero() { v = 0.f; }
+  __device__ __forceinline__ void add(float x) { atomicAdd(&v, x); }
+  __device__ __forceinline__ float get() const { return v; }
+};
+#endif
+
+}  // namespace mimrl

@@ -1,0 +1,83 @@
+// Host side and flush kernel of the deterministic build (det.h).  In the default build this file only answers mimrl_deterministic() = 0.
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace mimrl {
+
+#ifdef MIMRL_DET
+namespace {
+constexpr unsigned kSlots = 1u << 23;      // 8 M addresses per launch (the grouped critic weight gradients touch ~2.5 M at cfg2)
+DetCtx h_ctx = {};
+std::atomic<bool> ready{false};
+bool failed = false;
+std::mutex mu;
+std::vector<DetSetter>& setters() { static std::vector<DetSetter> v; return v; }
+
+__global__ __launch_bounds__(256) void det_flush_kernel(DetCtx c) {
+  // n changes only when the last PARTICIPATING workgroup of this launch resets it, i.e. after every participant has read it; a workgroup
+  // that starts after that sees 0 and leaves (most launches of a step accumulate nothing: their flush is this one load)
+  const unsigned n = __atomic_load_n(&c.ctl[0], __ATOMIC_RELAXED);
+  const unsigned nb = min(gridDim.x, (n + 255u) / 256u);
+  if (blockIdx.x >= nb) return;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) {
+    const unsigned h = c.list[i];
+    float* p = reinterpret_cast<float*>(c.keys[h]);
+    *p += (float)c.vals[h] * kDetInv;       // the ONE rounding of this address's sum
+    c.keys[h] = 0ull;
+    c.vals[h] = 0ll;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&c.ctl[1], 1u) == nb - 1) { c.ctl[1] = 0u; __threadfence(); c.ctl[0] = 0u; }
+}
+}  // namespace
+
+void det_register_tu(DetSetter f) { setters().push_back(f); }
+
+int det_init() {
+  if (ready.load(std::memory_order_acquire)) return MIMRL_OK;
+  std::lock_guard<std::mutex> g(mu);
+  if (ready.load() || failed) return failed ? MIMRL_ERR_HIP : MIMRL_OK;
+  failed = true;                            // (until the last line: a box without a GPU lands here once, not on every launch)
+  HIPX(hipMalloc(&h_ctx.keys, sizeof(unsigned long long) * kSlots));
+  HIPX(hipMalloc(&h_ctx.vals, sizeof(long long) * kSlots));
+  HIPX(hipMalloc(&h_ctx.list, sizeof(unsigned) * kSlots));
+  HIPX(hipMalloc(&h_ctx.ctl, sizeof(unsigned) * 4));
+  HIPX(hipMemset(h_ctx.keys, 0, sizeof(unsigned long long) * kSlots));
+  HIPX(hipMemset(h_ctx.vals, 0, sizeof(long long) * kSlots));
+  HIPX(hipMemset(h_ctx.ctl, 0, sizeof(unsigned) * 4));
+  h_ctx.mask = kSlots - 1;
+  for (DetSetter f : setters()) f(h_ctx);
+  HIPX(hipDeviceSynchronize());
+  HIPX(hipGetLastError());
+  failed = false;
+  ready.store(true, std::memory_order_release);
+  return MIMRL_OK;
+}
+
+int det_flush(hipStream_t s) {
+  if (!ready.load(std::memory_order_acquire)) return MIMRL_OK;   // no table (init failed): acc_add fell back to float atomics
+  det_flush_kernel<<<dim3(256), dim3(256), 0, s>>>(h_ctx);
+  return MIMRL_OK;
+}
+
+int det_overflowed() {
+  if (!ready.load()) return 0;
+  unsigned f = 0;
+  if (hipMemcpy(&f, h_ctx.ctl + 2, sizeof f, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return f != 0;
+}
+#endif
+
+}  // namespace mimrl
+
+extern "C" int mimrl_deterministic(void) {
+#ifdef MIMRL_DET
+  return ::mimrl::det_overflowed() ? 2 : 1;   // 2: the accumulation table ran full at some launch (that launch fell back to float atomics)
+#else
+  return 0;
+#endif
+}

@@ -2747,6 +2747,10 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   if (h->cfg.adam_eps == 0.f) h->cfg.adam_eps = 1e-8f;
   h->stream = h->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
   h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
+#ifdef MIMRL_DET
+  h->multi_stream = false;   // deterministic build: one stream, so the flush behind a launch never meets a half-finished producer (det.h)
+  MX(det_init());
+#endif
   h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
@@ -3100,6 +3104,9 @@ int mimrl_set_grad_scale(mimrl_handle* h, float scale) {
 
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+#ifdef MIMRL_DET
+  on = 0;                    // deterministic build: no second forward pass on its own stream (same results, sequential schedule)
+#endif
   if ((on != 0) == h->prefetch && (on == 2) == h->defer_tail) return MIMRL_OK;
   if (on && !h->pre_stream) HIPX(hipStreamCreateWithFlags(&h->pre_stream, hipStreamNonBlocking));
   HIPX(hipStreamSynchronize(h->user_stream));

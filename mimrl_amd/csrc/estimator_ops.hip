@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
   NPHASE(3);
   if (tid == 0) {
     const float v = (red[0] + red[1] + red[2] + red[3]) / B + (ti == 0 ? __logf((float)B) : 0.f);
-    atomicAdd(&mi[e], v);
-    if (mil) atomicAdd(&mil[e], -v);
+    acc_add(&mi[e], v);
+    if (mil) acc_add(&mil[e], -v);
   }
   if (!do_bwd) return;
   NPHASE(4);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void mi_sep_nce_kernel(const float* __restrict
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(&dX[(long)(tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + tn * 32 + lr], acc[r]);
+    for (int r = 0; r < 16; ++r) acc_add(&dX[(long)(tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + tn * 32 + lr], acc[r]);
   }
   NPHASE(6);
 }
@@ -640,13 +640,13 @@ __global__ __launch_bounds__(256) void top1_bwd_kernel(const float* __restrict__
     const int c = threadIdx.x, slot = c >> 2, sub = c & 3;
     float a1 = 0.f, a2 = 0.f;
     for (int q = 0; q < rpp; ++q) { a1 += red[0][(q * tpr + slot) * 4 + sub]; a2 += red[1][(q * tpr + slot) * 4 + sub]; }
-    if (dW) atomicAdd(dW + (long)g * pstride + c, a1);
-    if (db_below) atomicAdd(db_below + (long)g * pstride + c, a2);
+    if (dW) acc_add(dW + (long)g * pstride + c, a1);
+    if (db_below) acc_add(db_below + (long)g * pstride + c, a2);
   }
   if (threadIdx.x == 0 && db_top) {
     float t = 0.f;
     for (int q = 0; q < rpp; ++q) t += red[2][q * tpr];
-    atomicAdd(db_top + (long)g * pstride, t);
+    acc_add(db_top + (long)g * pstride, t);
   }
 }
 

@@ -204,7 +204,7 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < d.M) { atomicAdd(Cn + (long)m * d.sc_m, v[r]); csum += v[r]; }
+        if (m < d.M) { acc_add(Cn + (long)m * d.sc_m, v[r]); csum += v[r]; }
       }
     } else if (!GEN && d.c_f16) {   // fp16-stored output (saturating; plain instantiations only: in the GEN ones the extra path cost scratch)
       _Float16* __restrict__ Ch = reinterpret_cast<_Float16*>(d.C) + oc + (long)n * d.sc_n;
@@ -261,7 +261,7 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
       if (atomic) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (row(q) < d.M) { atomicAdd(&C[offs(q)], v[q]); csum += v[q]; }
+          if (row(q) < d.M) { acc_add(&C[offs(q)], v[q]); csum += v[q]; }
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -271,7 +271,7 @@ __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz,
   }
   if (d.colsum) {   // fused bias gradient: lanes l and l^32 hold the same column
     csum += __shfl_xor(csum, 32, 64);
-    if (lane < 32) atomicAdd(&d.colsum[(long)bz * d.colsum_b + n], csum);
+    if (lane < 32) acc_add(&d.colsum[(long)bz * d.colsum_b + n], csum);
   }
 }
 

@@ -613,12 +613,12 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
       for (int e = 0; e < UPL; ++e) {
         const int unit = u0 + e;
         if (q.db_ih) {
-          atomicAdd(&q.db_ih[0 * H + unit], sb[0][e]); atomicAdd(&q.db_ih[1 * H + unit], sb[1][e]);
-          atomicAdd(&q.db_ih[2 * H + unit], sb[2][e]);
+          acc_add(&q.db_ih[0 * H + unit], sb[0][e]); acc_add(&q.db_ih[1 * H + unit], sb[1][e]);
+          acc_add(&q.db_ih[2 * H + unit], sb[2][e]);
         }
         if (q.db_hh) {
-          atomicAdd(&q.db_hh[0 * H + unit], sb[0][e]); atomicAdd(&q.db_hh[1 * H + unit], sb[1][e]);
-          atomicAdd(&q.db_hh[2 * H + unit], sb[3][e]);
+          acc_add(&q.db_hh[0 * H + unit], sb[0][e]); acc_add(&q.db_hh[1 * H + unit], sb[1][e]);
+          acc_add(&q.db_hh[2 * H + unit], sb[3][e]);
         }
       }
     }

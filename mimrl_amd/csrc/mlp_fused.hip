@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
     const int nr = min(RT, a.rows - r0);
     float s = 0.f;
     for (int r = 0; r < nr; ++r) s += a.dout[(rowbase + r) * w + tid];
-    atomicAdd(a.db_top + (long)g * a.pstride + tid, s);
+    acc_add(a.db_top + (long)g * a.pstride + tid, s);
   }
   __syncthreads();
   int cur = 0;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void mlp_img_kernel(MlpFusedArgs a) {
       }
       if (db) {
         csum += __shfl_xor(csum, 32, 64);
-        if (lh == 0) atomicAdd(&db[n], csum);
+        if (lh == 0) acc_add(&db[n], csum);
       }
     };
     finish(acc0, wave, mk0, bn3[0]); finish(acc1, wave + 4, mk1, bn3[1]); finish(acc2, wave + 8, mk2, bn3[2]);
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
     const int nr = min(RT, a.rows - r0);
     float s = 0.f;
     for (int r = 0; r < nr; ++r) s += a.dout[(rowbase + r) * w + tid];
-    atomicAdd(a.db_top + (long)g * a.pstride + tid, s);
+    acc_add(a.db_top + (long)g * a.pstride + tid, s);
   }
   if (BWD && a.dw_top && a.nl >= 2) {   // narrow top layer: dW[c][k] = sum over this tile's rows of dout[r][c] * act[r][k]  (fp32, L2-hot)
     const int w = a.dims[a.nl], K1 = a.dims[a.nl - 1];
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
       const float* __restrict__ dp = a.dout + rowbase * w + c;
       float s = 0.f;
       for (int r = 0; r < nr; ++r) s += dp[(long)r * w] * ap[(long)r * K1];
-      atomicAdd(a.dw_top + (long)g * a.pstride + tid, s);
+      acc_add(a.dw_top + (long)g * a.pstride + tid, s);
     }
   }
   __syncthreads();
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) void mlp_img8_kernel(MlpFusedArgs a) {
         }
         if (db) {
           csum += __shfl_xor(csum, 32, 64);
-          if (lh == 0) atomicAdd(&db[n], csum);
+          if (lh == 0) acc_add(&db[n], csum);
         }
       }
       PHASE(3 + 4 * step + 2 * pass);
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(512) void mlp_frag_kernel(MlpFusedArgs a) {
 #pragma unroll 8
         for (int r = 0; r < rows_here; ++r) s += dp[r * D4];
       }
-      atomicAdd(a.db_top + pg + tid, s);
+      acc_add(a.db_top + pg + tid, s);
     }
     // mask values of one output tile: row min(m, rows_here - 1) (clamped rows are never stored)
     auto load_mask = [&](float (&mk)[16], const float* __restrict__ mask, int n) __attribute__((always_inline)) {
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(512) void mlp_frag_kernel(MlpFusedArgs a) {
       }
       if (db) {
         csum += __shfl_xor(csum, 32, 64);
-        if (lh == 0) atomicAdd(&db[n], csum);
+        if (lh == 0) acc_add(&db[n], csum);
       }
     };
     f32x16 acc;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(512) void mlp_frag_kernel(MlpFusedArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < RT; ++r) s += sd[r][tid];
-        atomicAdd(a.db_top + pg + tid, s);
+        acc_add(a.db_top + pg + tid, s);
       }
       float dw[D4];
 #pragma unroll
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(512) void mlp_frag_kernel(MlpFusedArgs a) {
 #pragma unroll
         for (int c = 0; c < D4; ++c) {
           const float t = dw[c] + __shfl_xor(dw[c], 32, 64);
-          if (lh == 0) atomicAdd(a.dw_top + pg + (long)c * FR_HID + n, t);
+          if (lh == 0) acc_add(a.dw_top + pg + (long)c * FR_HID + n, t);
         }
       }
       PHASE(1);
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpFusedArgs a) {
       }
       if (db) {
         csum += __shfl_xor(csum, 32, 64);
-        if (lh == 0) atomicAdd(&db[kc], csum);
+        if (lh == 0) acc_add(&db[kc], csum);
       }
     }
     __syncthreads();

@@ -101,9 +101,9 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
   const float* __restrict__ dmean = sd.dmean;       // optional: gradient of this slot's temporal mean [B, D] (feat_mean backward folded in)
   const float invT = 1.f / T;
   constexpr int D = 64 * PER;
-  __shared__ float sg[D], sb[D];
+  __shared__ LdsAcc sg[D], sb[D];
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < D; i += blockDim.x) { sg[i] = 0.f; sb[i] = 0.f; }
+  for (int i = threadIdx.x; i < D; i += blockDim.x) { sg[i].zero(); sb[i].zero(); }
   __syncthreads();
   const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
   float ag[PER], ab[PER];
@@ -134,9 +134,9 @@ __global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __res
     for (int i = 0; i < PER; ++i) ds[r * D + lane + 64 * i] = rs * (dxh[i] - s1 - xh[i] * s2);
   }
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { atomicAdd(&sg[lane + 64 * i], ag[i]); atomicAdd(&sb[lane + 64 * i], ab[i]); }
+  for (int i = 0; i < PER; ++i) { sg[lane + 64 * i].add(ag[i]); sb[lane + 64 * i].add(ab[i]); }
   __syncthreads();
-  for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(&dgamma[i], sg[i]); atomicAdd(&dbeta[i], sb[i]); }
+  for (int i = threadIdx.x; i < D; i += blockDim.x) { acc_add(&dgamma[i], sg[i].get()); acc_add(&dbeta[i], sb[i].get()); }
 }
 
 // Round 3: the same backward with 16 lanes per row (D = 128: two float4 per lane and operand), FOUR rows per wave and pass, grid sized
@@ -160,11 +160,11 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
   const float* __restrict__ dmean = sd.dmean;
   const float invT = 1.f / T;
   const uint32_t rstep = (uint32_t)(*key.step + key.add);   // once (see drop_scale_at)
-  __shared__ float sg[D], sb[D];
+  __shared__ LdsAcc sg[D], sb[D];
   const int tid = threadIdx.x, sub = tid & 15, rw = tid >> 4;          // 16 row slots per workgroup
   const bool pb = blockIdx.x == 0 && blockIdx.y == 0;
   MPHASE(pb, 8);
-  if (tid < D) { sg[tid] = 0.f; sb[tid] = 0.f; }
+  if (tid < D) { sg[tid].zero(); sb[tid].zero(); }
   __syncthreads();
   MPHASE(pb, 9);
   const int c0 = 4 * sub, c1 = 64 + 4 * sub;                            // this lane's two column quads
@@ -219,11 +219,11 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
     float a = ag[i], bq = ab[i];
     a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
     bq += __shfl_xor(bq, 16, 64); bq += __shfl_xor(bq, 32, 64);
-    if ((tid & 63) < 16) { const int j = (i < 4 ? c0 : c1 - 4) + i; atomicAdd(&sg[j], a); atomicAdd(&sb[j], bq); }
+    if ((tid & 63) < 16) { const int j = (i < 4 ? c0 : c1 - 4) + i; sg[j].add(a); sb[j].add(bq); }
   }
   __syncthreads();
   MPHASE(pb, 11);
-  if (tid < D) { atomicAdd(&sd.dgamma[tid], sg[tid]); atomicAdd(&sd.dbeta[tid], sb[tid]); }
+  if (tid < D) { acc_add(&sd.dgamma[tid], sg[tid].get()); acc_add(&sd.dbeta[tid], sb[tid].get()); }
   MPHASE(pb, 12);
 }
 
@@ -390,9 +390,9 @@ __global__ void head_bwd_kernel(const float* __restrict__ dff_ext, const float* 
     const float g = scale * (de + dp * w[d]);
     float* xb = dx + (long)b * L * K * D + d;
     for (int i = 0; i < L * K; ++i) xb[(long)i * D] = g;
-    atomicAdd(&dw[d], dp * ff[(long)b * D + d]);
+    acc_add(&dw[d], dp * ff[(long)b * D + d]);
   }
-  if (threadIdx.x == 0) atomicAdd(dbias, dp);
+  if (threadIdx.x == 0) acc_add(dbias, dp);
 }
 
 // ------------------------------------------------------------------ row LayerNorm (one wave per row)
@@ -418,9 +418,9 @@ __global__ void rowln_bwd_kernel(const float* __restrict__ y, const float* __res
                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                  const float* __restrict__ dz, float* __restrict__ dy, float* __restrict__ dgamma,
                                  float* __restrict__ dbeta, long R, int n) {
-  __shared__ float sh[2 * 64 * PER];
+  __shared__ LdsAcc sh[2 * 64 * PER];
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 2 * 64 * PER; i += blockDim.x) sh[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * 64 * PER; i += blockDim.x) sh[i].zero();
   __syncthreads();
   float gam[PER], ag[PER], ab[PER];
 #pragma unroll
@@ -447,9 +447,9 @@ __global__ void rowln_bwd_kernel(const float* __restrict__ y, const float* __res
     }
   }
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { atomicAdd(&sh[lane + 64 * i], ag[i]); atomicAdd(&sh[64 * PER + lane + 64 * i], ab[i]); }
+  for (int i = 0; i < PER; ++i) { sh[lane + 64 * i].add(ag[i]); sh[64 * PER + lane + 64 * i].add(ab[i]); }
   __syncthreads();
-  for (int j = threadIdx.x; j < n; j += blockDim.x) { atomicAdd(&dgamma[j], sh[j]); atomicAdd(&dbeta[j], sh[64 * PER + j]); }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) { acc_add(&dgamma[j], sh[j].get()); acc_add(&dbeta[j], sh[64 * PER + j].get()); }
 }
 
 // ------------------------------------------------------------------ column LayerNorm (thread per (b,c))
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void colln_bwd_kernel(const float* __restrict_
   for (int q = threadIdx.x; q < 2 * n; q += blockDim.x) {
     float t = 0.f;
     for (int j = 0; j < 64; ++j) t += sh[q * 64 + ((j + q) & 63)];
-    atomicAdd(q < n ? &dgamma[q] : &dbeta[q - n], t);
+    acc_add(q < n ? &dgamma[q] : &dbeta[q - n], t);
   }
 }
 
@@ -575,10 +575,10 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
   if constexpr (EXACT) { w.ik = NK; w.hk = NK; w.ok = NK; w.ln_first = 0; w.drop_p = 0.f; }
   constexpr bool GRADS = MODE != 1, DX = MODE != 2;
   __shared__ float sw[3 * KM * KM + 4 * KM];
-  __shared__ float sg[3 * KM * KM + 4 * KM];   // gradient accumulators, same packing
+  __shared__ LdsAcc sg[3 * KM * KM + 4 * KM];   // gradient accumulators, same packing
   KPHASE(0);
   kmix_stage_weights(w, sw);
-  for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sg[i] = 0.f;
+  for (int i = threadIdx.x; i < 3 * KM * KM + 4 * KM; i += blockDim.x) sg[i].zero();
   __syncthreads();
   const float* w1 = sw; const float* w2 = w1 + KM * KM + KM; const float* wr = w2 + KM * KM + KM;
   const float* g = wr + KM * KM;
@@ -696,37 +696,37 @@ __global__ __launch_bounds__(256, KMIX_MINB) void kmix_bwd_kernel(const float* _
     if (t < w.ok * w.hk && sw[KM * KM + KM + (t / w.hk) * KM + t % w.hk] != w.w2[t]) ++bad;
     if (w.wr && t < w.ok * w.ik && sw[2 * (KM * KM + KM) + (t / w.ik) * KM + t % w.ik] != w.wr[t]) ++bad;
     if (t < w.ok && (sw[3 * KM * KM + 2 * KM + t] != w.g[t] || sw[3 * KM * KM + 3 * KM + t] != w.be[t])) ++bad;
-    if (bad) atomicAdd(&w.dbe[0], 1000.f * bad);
+    if (bad) acc_add(&w.dbe[0], 1000.f * bad);
   }
   // one wave reduction + LDS + global atomic per scalar, once per kernel
-  float* gw1 = sg; float* gb1 = gw1 + KM * KM; float* gw2 = gb1 + KM; float* gb2 = gw2 + KM * KM;
-  float* gwr = gb2 + KM; float* gg = gwr + KM * KM; float* gbe = gg + KM;
+  LdsAcc* gw1 = sg; LdsAcc* gb1 = gw1 + KM * KM; LdsAcc* gw2 = gb1 + KM; LdsAcc* gb2 = gw2 + KM * KM;
+  LdsAcc* gwr = gb2 + KM; LdsAcc* gg = gwr + KM * KM; LdsAcc* gbe = gg + KM;
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < NK; ++i) {
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
-      float a = wave_sum(aw1[i][j]); if (lane == 0) atomicAdd(&gw1[i * KM + j], a);
-      a = wave_sum(aw2[i][j]); if (lane == 0) atomicAdd(&gw2[i * KM + j], a);
-      a = wave_sum(awr[i][j]); if (lane == 0) atomicAdd(&gwr[i * KM + j], a);
+      float a = wave_sum(aw1[i][j]); if (lane == 0) gw1[i * KM + j].add(a);
+      a = wave_sum(aw2[i][j]); if (lane == 0) gw2[i * KM + j].add(a);
+      a = wave_sum(awr[i][j]); if (lane == 0) gwr[i * KM + j].add(a);
     }
-    float a = wave_sum(ab1[i]); if (lane == 0) atomicAdd(&gb1[i], a);
-    a = wave_sum(ab2[i]); if (lane == 0) atomicAdd(&gb2[i], a);
-    a = wave_sum(ag[i]); if (lane == 0) atomicAdd(&gg[i], a);
-    a = wave_sum(abe[i]); if (lane == 0) atomicAdd(&gbe[i], a);
+    float a = wave_sum(ab1[i]); if (lane == 0) gb1[i].add(a);
+    a = wave_sum(ab2[i]); if (lane == 0) gb2[i].add(a);
+    a = wave_sum(ag[i]); if (lane == 0) gg[i].add(a);
+    a = wave_sum(abe[i]); if (lane == 0) gbe[i].add(a);
   }
   KPHASE(3);
   __syncthreads();
   KPHASE(4);
   const int t = threadIdx.x;
   if (w.dbg & 2) return;
-  if (t < w.hk * w.ik) atomicAdd(&w.dw1[t], gw1[(t / w.ik) * KM + t % w.ik]);
-  if (t < w.hk && w.db1) atomicAdd(&w.db1[t], gb1[t]);
-  if (t < w.ok * w.hk) atomicAdd(&w.dw2[t], gw2[(t / w.hk) * KM + t % w.hk]);
-  if (t < w.ok && w.db2) atomicAdd(&w.db2[t], gb2[t]);
-  if (t < w.ok * w.ik && w.dwr) atomicAdd(&w.dwr[t], gwr[(t / w.ik) * KM + t % w.ik]);
+  if (t < w.hk * w.ik) acc_add(&w.dw1[t], gw1[(t / w.ik) * KM + t % w.ik].get());
+  if (t < w.hk && w.db1) acc_add(&w.db1[t], gb1[t].get());
+  if (t < w.ok * w.hk) acc_add(&w.dw2[t], gw2[(t / w.hk) * KM + t % w.hk].get());
+  if (t < w.ok && w.db2) acc_add(&w.db2[t], gb2[t].get());
+  if (t < w.ok * w.ik && w.dwr) acc_add(&w.dwr[t], gwr[(t / w.ik) * KM + t % w.ik].get());
   const int nln = w.ln_first ? w.ik : w.ok;
-  if (t < nln) { atomicAdd(&w.dg[t], gg[t]); atomicAdd(&w.dbe[t], gbe[t]); }
+  if (t < nln) { acc_add(&w.dg[t], gg[t].get()); acc_add(&w.dbe[t], gbe[t].get()); }
   KPHASE(5);
 }
 
@@ -744,7 +744,7 @@ __global__ void colsum_kernel(const float* __restrict__ X, long M, int N, long l
   if (n < N) for (long m = m0 + rr; m < m1; m += 4) s += X[m * ld + n];
   red[rr][c] = s;
   __syncthreads();
-  if (rr == 0 && n < N) atomicAdd(&out[n], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (rr == 0 && n < N) acc_add(&out[n], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 __global__ void rowsum_batched_kernel(const float* __restrict__ X, int B, int R, int C, float* __restrict__ out) {
   __shared__ float red[16];
@@ -756,7 +756,7 @@ __global__ void rowsum_batched_kernel(const float* __restrict__ X, int B, int R,
     for (int c = threadIdx.x; c < C; c += blockDim.x) s += p[c];
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(&out[r], s);
+  if (threadIdx.x == 0) acc_add(&out[r], s);
 }
 __global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += x[i];
@@ -987,7 +987,7 @@ __global__ void colln_param_grads_kernel(const float* __restrict__ y, const floa
   }
   sg = block_sum(sg, red);
   sb = block_sum(sb, red);
-  if (threadIdx.x == 0) { atomicAdd(&dgamma[l], sg); atomicAdd(&dbeta[l], sb); }
+  if (threadIdx.x == 0) { acc_add(&dgamma[l], sg); acc_add(&dbeta[l], sb); }
 }
 int colln_param_grads(hipStream_t s, const float* y, const float* mean, const float* rstd, const float* dz, float* dgamma,
                       float* dbeta, int B, int n, int C) {

@@ -1,5 +1,7 @@
 """Diagnostic: are the stage-2 main-model gradients of a bench workload reproducible run to run (fresh engine, same inputs)?
-usage: python tools/determinism.py [workload] [reps] [stage] [graph]   -- prints the worst tensors (relative to the tensor's scale)"""
+usage: python tools/determinism.py [workload] [reps] [stage] [graph] [exact]   -- prints the worst tensors (relative to the tensor's scale)
+and how many tensors are bit-identical; with `exact` the exit code is 1 unless ALL are (what MIMRL_DETERMINISTIC=1 promises:
+tests/test_gpu_step.py::test_deterministic_build_is_bit_exact runs this file under that switch)."""
 import sys
 
 import numpy as np
@@ -12,6 +14,9 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 stage = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 graph = len(sys.argv) > 4 and sys.argv[4] == "graph"
+exact = "exact" in sys.argv[5:]
+from mimrl_amd import _lib   # noqa: E402
+print("deterministic build:", _lib.load().mimrl_deterministic())
 runs = []
 anchors = None
 for r in range(reps):
@@ -29,4 +34,7 @@ for r in range(1, reps):
     # (tensors whose gradient is identically zero -- e.g. the last bias of an InfoNCE g-tower: rows of dS sum to zero -- are fp32 noise)
     rows = sorted(((np.abs(runs[r][n] - runs[0][n]).max() / (np.abs(runs[0][n]).max() + 1e-12), n) for n in runs[0]
                    if np.abs(runs[0][n]).max() > 1e-7), reverse=True)
-    print("run %d vs 0:" % r, [(float("%.2e" % a), n) for a, n in rows[:3]])
+    same = sum(np.array_equal(runs[r][n], runs[0][n]) for n in runs[0])
+    print("run %d vs 0:" % r, [(float("%.2e" % a), n) for a, n in rows[:3]], "bit-identical tensors: %d of %d" % (same, len(runs[0])))
+    if exact and same != len(runs[0]):
+        sys.exit(1)
