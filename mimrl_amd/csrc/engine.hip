@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <vector>
 #include <dlfcn.h>
 
@@ -298,6 +299,10 @@ struct mimrl_handle {
   float *tin = nullptr, *ta[3], *tout = nullptr, *scores = nullptr, *dscores = nullptr;
   float *cP = nullptr, *cQ = nullptr, *ca[3];
   int split_part = 0;                  // 1: encoders_backward stops behind the layer-1 weight gradients (mimrl_stage_grads_part); 0: whole pass
+  std::function<int()> pending_text;   // MIMRL_TEXT_LATE: the text branch captured behind the layer-0 input projection (1) / recurrence (2)
+  int pending_text_at = 0;
+  bool fold_unpack = false, unpack_pending = false;   // the packed layer-0 GRU weight gradients are scattered by the Adam launch (AdamArgs::fold)
+  bool fold_unpack_on = true;          // MIMRL_NO_FOLD_UNPACK=1: keep the separate scatter kernel (tuning knob)
   bool gx_f16 = false;                 // the hoisted GRU input projections gx[B,T,3H] are stored as fp16 (long sequences, bf16 mode: create)
   int *knn_idx = nullptr, *knn_idx2 = nullptr;   // neighbour indices; stage 2 has its own set (prefetch mode samples it early)
   char* knn_scr[2] = {nullptr, nullptr};         // candidate lists of the MFMA kNN (knn_mfma.hip), one per stage
@@ -888,6 +893,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       if (gx_f16) { gd.c_f16 = 1; gd.sc_b *= 2; gd.sc_bo *= 2; }   // buffer distances are fp32-element counts; fp16 elements: x2
       PrecGuard pg(this, fp32_site(2));
       MX(G_on(stream, gd));
+      if (pending_text && pending_text_at == 1) { MX(pending_text()); pending_text = nullptr; }
     }
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
@@ -921,6 +927,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       MX(dbg_delay(S(4), 11));
     }
     { Scope sc(this, MIMRL_PH_GRU_FWD); MX(gru_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) != 0)); }
+    if (l == 0 && pending_text && pending_text_at == 2) { MX(pending_text()); pending_text = nullptr; }
     MX(dbg_delay(stream, 1));
   }
   return MIMRL_OK;
@@ -1031,7 +1038,9 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     // text branch (side 0): W_t projection (Model.py:395) + dropout -> cube slot 0.  Captured BEFORE the encoders although it
     // has slack until the tail starts: graph nodes start in capture order, and a branch captured behind the two GRU layers is
     // dispatched behind them too and then delays the tail (measured: 1.46 vs 1.34 ms).
-    static const bool prefix_split = getenv("MIMRL_LENS_SIDE0") != nullptr;   // tuning knob
+    // (default since round 4 -- with the kNN sampler's two launches on side 4 the scan there delayed the layer-0 input projection:
+    //  cfg2 0.840 -> 0.829 ms, cfg3 6.97 -> 6.87; MIMRL_LENS_SIDE0=0 puts it back)
+    static const bool prefix_split = !(getenv("MIMRL_LENS_SIDE0") && atoi(getenv("MIMRL_LENS_SIDE0")) == 0);   // tuning knob
     if (prefix_split && cfg.encoder == MIMRL_ENCODER_GRU && side_on(0)) {
       // lengths (Model.py:425-432): only the recurrence needs them.  Side 0 has slack (the text projection is needed at the tail);
       // on side 4 the scan sat in front of the video input projection, the longest chain ahead of the layer-0 recurrence
@@ -1039,10 +1048,17 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
       MX(next_event(&ev_lens));
       HIPX(hipEventRecord(ev_lens, S(0)));
     }
-    { PrecGuard pg(this, fp32_site(1)); GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); g.f16 = fwd_f16; MX(G_on(S(0), g)); }
-    MX(dbg_delay(S(0), 10));
-    if (part == 0 && !fused_pre) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+    static const int text_late = getenv("MIMRL_TEXT_LATE") ? atoi(getenv("MIMRL_TEXT_LATE")) : 0;   // tuning knob (capture order)
+    auto text_branch = [this, BT_, D, part, fused_pre, B, T, L, pdrop]() -> int {
+      { PrecGuard pg(this, fp32_site(1)); GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); g.f16 = fwd_f16; MX(G_on(S(0), g)); }
+      MX(dbg_delay(S(0), 10));
+      if (part == 0 && !fused_pre) MX(text_post_fwd(S(0), tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
+      return MIMRL_OK;
+    };
+    if (text_late && cfg.encoder == MIMRL_ENCODER_GRU && l0_packed) { pending_text = text_branch; pending_text_at = text_late; }
+    else MX(text_branch());
     MX(encoders_forward(save, knn_stage));
+    if (pending_text) { MX(pending_text()); pending_text = nullptr; }
     MX(join(0, 0));
     if (part == 1) return MIMRL_OK;
   } else if (!fused_pre) {
@@ -1772,7 +1788,8 @@ int mimrl_handle::gru_layer_backward(int l) {
         for (int d = 0; d < 2; ++d) { up.g_ih[m][d] = Gm(gru[m][0][d].w_ih); up.g_hh[m][d] = Gm(gru[m][0][d].w_hh); }
       }
       up.dwih_pack = dwih_pack; up.dwhh_pack = dwhh_pack; up.KP = KP();
-      MX(l0_unpack_grads(stream, up));
+      if (fold_unpack) unpack_pending = true;      // the Adam launch behind this pass takes the packed pieces itself (enqueue_apply)
+      else MX(l0_unpack_grads(stream, up));
       return MIMRL_OK;
     }
     int rr = 0;
@@ -2539,6 +2556,22 @@ int mimrl_handle::enqueue_apply(int stage) {
   }
   a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
   a.gscale = grad_scale;
+  if (stage == 2 && unpack_pending) {
+    unpack_pending = false;
+    const int G = 3 * 128;
+    for (int m = 0; m < 2; ++m)
+      for (int d = 0; d < 2; ++d) {
+        const int md = m * 2 + d, din = gru[m][0][0].din;
+        int q = a.fold.n++;
+        a.fold.lo[q] = Gm(gru[m][0][d].w_ih) - bufs.main_g; a.fold.hi[q] = a.fold.lo[q] + (long)G * din;
+        a.fold.src[q] = dwih_pack + (long)md * G * KP(); a.fold.d[q] = din; a.fold.ld[q] = KP();
+        q = a.fold.n++;
+        a.fold.lo[q] = Gm(gru[m][0][d].w_hh) - bufs.main_g; a.fold.hi[q] = a.fold.lo[q] + (long)G * 128;
+        a.fold.src[q] = dwhh_pack + (long)md * G * 128; a.fold.d[q] = 128; a.fold.ld[q] = 128;
+      }
+    a.fold.lo_all = a.fold.lo[0]; a.fold.hi_all = a.fold.hi[0];
+    for (int q = 1; q < a.fold.n; ++q) { a.fold.lo_all = std::min(a.fold.lo_all, a.fold.lo[q]); a.fold.hi_all = std::max(a.fold.hi_all, a.fold.hi[q]); }
+  }
   Scope sc(this, MIMRL_PH_OPT);
   MX(adam_step(stream, a));
   if (stage == 1 && img_valid && crit_frag && ftab.n > 0) {
@@ -2580,8 +2613,10 @@ int mimrl_handle::run(int stage, int kind) {
       return r;
     }
     split_part = kind == 3 ? 1 : 0;
+    fold_unpack = kind == 0 && stage == 2 && fold_unpack_on;   // the update follows in the same enqueue: it scatters the packed layer-0 pieces
     const int r = enqueue_grads(stage, skip_zero);
-    split_part = 0;
+    split_part = 0; fold_unpack = false;
+    if (r != 0) unpack_pending = false;
     MX(r);
     if (kind == 0) MX(enqueue_apply(stage));
     return MIMRL_OK;
@@ -2679,10 +2714,11 @@ int mimrl_handle::run_step() {
     wtT_built = false;
     int r = enqueue_grads(1, true);
     if (r == 0) r = enqueue_apply(1);
-    keep_events = true;
+    keep_events = true; fold_unpack = fold_unpack_on;
     if (r == 0) r = enqueue_grads(2, true);
-    keep_events = false;
+    keep_events = false; fold_unpack = false;
     if (r == 0) r = enqueue_apply(2);
+    unpack_pending = false;
     fuse_boundary = false; skip_imgT_refresh = false; wtT_prebuilt = false;
     stream = user_stream;
     const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
@@ -2754,6 +2790,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
+  h->fold_unpack_on = getenv("MIMRL_NO_FOLD_UNPACK") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   h->fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") == nullptr;
   h->fwd_f16 = getenv("MIMRL_FWD_BF16") == nullptr;

@@ -656,7 +656,17 @@ __global__ void adam_kernel(AdamArgs a) {
   const float bc1 = 1.f - powf(a.beta1, (float)t), bc2 = 1.f - powf(a.beta2, (float)t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
-    float g = a.g[i] * a.gscale;
+    float g = a.g[i];
+    if (i >= a.fold.lo_all && i < a.fold.hi_all) {
+      for (int q = 0; q < a.fold.n; ++q)
+        if (i >= a.fold.lo[q] && i < a.fold.hi[q]) {
+          const long j = i - a.fold.lo[q];
+          float* src = a.fold.src[q] + (j / a.fold.d[q]) * a.fold.ld[q] + j % a.fold.d[q];
+          g += *src;
+          *src = 0.f;
+        }
+    }
+    g *= a.gscale;
     if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);             // clip_grad_value_ (Solver.py:211-212)
     const float p = a.p[i];
     if (a.weight_decay != 0.f) g += a.weight_decay * p;

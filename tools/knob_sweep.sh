@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage: tools/knob_sweep.sh "ENV1=a ENV2=b" "ENV1=c" ...   -- one bench line (ms/step) per knob set, two repeats each (same box)
+# A/B of scheduling knobs on the cfg2 bench line (GPU box): tools/knob_sweep.sh "KNOB=V" "KNOB2=V" ...  -> gpurun_out/knob_sweep.txt
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; : > gpurun_out/knob_sweep.txt
+run() { env "$@" timeout 300 python bench.py --no-cpu-baseline --no-extra --profile-steps 0 2>/dev/null | tail -1 | grep -o "ms_per_step\": [0-9.]*" | head -1; }
 for rep in 1 2; do
-  for ks in "$@"; do
-    ms=$(env $ks timeout 200 python bench.py --profile-steps 0 --no-cpu-baseline --no-extra --steps 400 2>/dev/null | tail -1 | python -c "import sys,json; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "rep$rep [$ks] $ms"
-  done
+  echo "default $(run A=1)" >> gpurun_out/knob_sweep.txt
+  for k in "$@"; do echo "$k $(run $k)" >> gpurun_out/knob_sweep.txt; done
 done
+cat gpurun_out/knob_sweep.txt
