@@ -179,6 +179,24 @@ __device__ __forceinline__ void store_tile(const Operand& o, int tid, const floa
 // epilogue of one 32x32 accumulator tile: lane holds column n, 16 rows (mbase + MFMA row pattern)
 // GEN: the kernel instantiation that also serves bias_m / beta / pre / gradact_u outputs (it needs ~80 more VGPRs for the
 // loads-first schedule below; plain GEMMs run the GEN = false instantiation at twice the occupancy)
+// fp16-stored output of a wave that owns TWO adjacent 32-column blocks (TN = 2; N % 64 == 0, sc_n == 1): lane l holds column l & 31 of both
+// blocks, rows m (lanes < 32) and m + 4 (lanes >= 32).  One v_permlane32_swap per row pair turns that into "all 64 lanes = one row, 64
+// consecutive columns", so every store instruction writes a whole 128-byte line -- the per-block fp16 store wrote two 64-byte half lines
+// and lost to the fp32 store it was meant to halve (round 4: cfg3 7.24 vs 6.83 ms).
+__device__ __forceinline__ void epilogue_f16_pair(const GemmDesc& d, long oc, float bn0, float bn1, const f32x16& a0, const f32x16& a1, int mbase,
+                                                  int ncol0, int lane) {
+  _Float16* __restrict__ Ch = reinterpret_cast<_Float16*>(d.C) + oc + ncol0 + lane;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float x = d.alpha * a0[r] + bn0, y = d.alpha * a1[r] + bn1;
+    if (d.act != ACT_NONE) { x = act_apply(d.act, x); y = act_apply(d.act, y); }
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    const int m = mbase + (r & 3) + 8 * (r >> 2);
+    if (m < d.M) Ch[(long)m * d.sc_m] = to_f16_sat(__builtin_bit_cast(float, sw[0]));
+    if (m + 4 < d.M) Ch[(long)(m + 4) * d.sc_m] = to_f16_sat(__builtin_bit_cast(float, sw[1]));
+  }
+}
+
 template <bool GEN>
 __device__ __forceinline__ void epilogue(const GemmDesc& d, bool atomic, int bz, long oc, const float bn, const f32x16& acc, int mbase,
                                          int n, int lane) {
@@ -654,6 +672,14 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
     segment(Ab, AKC ? d.sa2_m : d.sa2_k, Bb, BKC ? d.sb2_n : d.sb2_k, d.K2, 0, (d.K2 + FBK - 1) / FBK, 0x7fffffff, 0);
   }
   if (dbg == 1) { if (acc[0][0][0] == 123.456f) d.C[0] = 1.f; return; }
+  if constexpr (!GEN && TN == 2) {
+    if (d.c_f16 && d.sc_n == 1 && d.N % 64 == 0) {   // (gemm() guarantees the plain store for c_f16)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        epilogue_f16_pair(d, oc, bn_pre[0], bn_pre[1], acc[i][0], acc[i][1], m0 + wm * 32 * TM + i * 32, n0 + wn * 64, lane);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
