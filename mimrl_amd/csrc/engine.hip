@@ -256,6 +256,12 @@ struct mimrl_handle {
   float* cube0 = nullptr;
   // layer-0 GRU operands in a common aligned shape (model_ops.h: L0Pack): one batched input projection, two batched weight gradients
   float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;
+  // 16-bit operands of the layer-1 input projection and of the dh0 product (round 4: those GEMMs are bound by L2 -> LDS operand bytes):
+  // h0h = fp16 copy of the layer-0 outputs written by the recurrence kernel itself (per forward set), w1h / w1b = fp16 / bf16 images of
+  // the four W_ih_l1 written by the layer-0 pack launch of the same forward pass
+  _Float16* h0h[2] = {nullptr, nullptr}; _Float16* w1h = nullptr; __bf16* w1b = nullptr;
+  bool h16_on = true;                  // MIMRL_NO_H16=1: fp32 operands as before (tuning knob; results are bit-identical either way)
+  bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
   bool concat_compact = false;         // the last concat forward saved bitmasks (+ bf16 values) for the fused backward, not fp32 activations
@@ -271,11 +277,12 @@ struct mimrl_handle {
     int* lens[2] = {nullptr, nullptr};
     float *tx_raw = nullptr, *gx[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *h0[2] = {nullptr, nullptr}, *h1[2] = {nullptr, nullptr};
     float *ln_mean[2] = {nullptr, nullptr}, *ln_rstd[2] = {nullptr, nullptr}, *cube0 = nullptr, *feats = nullptr, *pred = nullptr;
+    _Float16* h0h[2] = {nullptr, nullptr};
     BlockBuf bb[MIMRL_MAX_BLOCKS];
   } alt;
   void swap_fwd_set() {
     for (int m = 0; m < 2; ++m) {
-      std::swap(lens[m], alt.lens[m]); std::swap(h0[m], alt.h0[m]); std::swap(h1[m], alt.h1[m]);
+      std::swap(lens[m], alt.lens[m]); std::swap(h0[m], alt.h0[m]); std::swap(h1[m], alt.h1[m]); std::swap(h0h[m], alt.h0h[m]);
       std::swap(ln_mean[m], alt.ln_mean[m]); std::swap(ln_rstd[m], alt.ln_rstd[m]);
       for (int d = 0; d < 2; ++d) std::swap(gx[m][d], alt.gx[m][d]);
     }
@@ -697,6 +704,7 @@ int mimrl_handle::carve_fwd(size_t* gmax_out) {
   for (int m = 0; m < 2; ++m) {
     for (int d = 0; d < 2; ++d) MX(take(&gx[m][d], BT_ * (cfg.encoder == MIMRL_ENCODER_LSTM ? 4 * H : G)));
     MX(take(&h0[m], BT_ * 2 * H));
+    if (cfg.encoder == MIMRL_ENCODER_GRU) { float* t = nullptr; MX(take(&t, BT_ * H)); h0h[m] = reinterpret_cast<_Float16*>(t); }
     MX(take(&h1[m], BT_ * 2 * H));
     MX(take(&ln_mean[m], BT_));
     MX(take(&ln_rstd[m], BT_));
@@ -767,6 +775,7 @@ int mimrl_handle::carve() {
   if (cfg.encoder == MIMRL_ENCODER_GRU) {
     MX(take(&xpack, 2 * BT_ * KP())); MX(take(&wpack, (size_t)4 * G * KP())); MX(take(&bpack, (size_t)4 * G));
     MX(take(&dwih_pack, (size_t)4 * G * KP())); MX(take(&dwhh_pack, (size_t)4 * G * H));
+    { float* t = nullptr; MX(take(&t, (size_t)4 * G * H)); w1h = reinterpret_cast<_Float16*>(t); MX(take(&t, (size_t)4 * G * H)); w1b = reinterpret_cast<__bf16*>(t); }
   }
   // estimators
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
@@ -857,6 +866,9 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   const int dmod[2] = {cfg.d_a, cfg.d_v};
   // lengths (Model.py:425-432): only the recurrence needs them -> sides 4/5, next to the input projections
   if (!ev_lens) MX(seq_lengths2(S(4), xin[0], dmod[0], lens[0], xin[1], dmod[1], lens[1], B, T));
+  // 16-bit operands for the layer-1 projection (see h0h): bf16 recurrence + fp16 forward operands + the packed layer-0 launch that also
+  // writes the weight images; a site forced to fp32 (MIMRL_FWD_FP32_SITES) or fp16-stored gx keeps the fp32-operand kernel
+  const bool use_h16 = h16_on && l0_packed && bf16 && fwd_f16 && (prec & MIMRL_PREC_BF16_GRU_FWD) && !fp32_site(4) && !fp32_site(2) && h0h[0] && w1h;
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
@@ -879,6 +891,11 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         for (int d = 0; d < 2; ++d) { pk.w_ih[m][d] = P(gru[m][0][d].w_ih); pk.b_ih[m][d] = P(gru[m][0][d].b_ih); }
       }
       pk.xpack = xpack; pk.wpack = wpack; pk.bpack = bpack; pk.rows = BT_; pk.KP = KP();
+      if (use_h16) {
+        for (int m = 0; m < 2; ++m) for (int d = 0; d < 2; ++d) pk.w_ih1[m][d] = P(gru[m][1][d].w_ih);
+        pk.w1h = w1h; pk.w1b = w1b;
+        w1_img_valid = true;
+      }
       if (begin_in_pack) {   // begin_stage(1) of the shared-prefix step rides on this launch (enqueue_grads)
         pk.bs_rng = d_ints; pk.bs_adam = d_ints + 2; pk.bs_scal = bufs.scalars; pk.bs_off = 0; pk.bs_n = 32;
         begin_in_pack = false;
@@ -911,12 +928,17 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         gd.bias_n_bo = gru[1][l][0].b_ih - gf.b_ih;
       }
       if (gx_f16) { gd.c_f16 = 1; gd.sc_b *= 2; gd.sc_bo *= 2; }
+      if (l == 1 && use_h16) {   // both operands as stored fp16 (strides in fp16 elements; the images are [modality][direction][G, 2H])
+        gd.A = reinterpret_cast<const float*>(h0h[0]); gd.a_bf16 = 1; gd.sa_bo = h0h[1] - h0h[0];
+        gd.B = reinterpret_cast<const float*>(w1h); gd.b_bf16 = 1; gd.sb_b = (long)G * 2 * H; gd.sb_bo = 2L * G * 2 * H;
+      }
       // layer 1: the m == 0 launch covers both modalities; layer 0: video beside audio (side 2, or behind the length scan on side 4
       // when the overlap mode has masked side 2 off -- both are joined in front of the recurrence)
       if ((l == 0 && !l0_packed) || (l == 1 && m == 0)) { PrecGuard pg(this, fp32_site(l == 0 ? 2 : 4)); MX(G_on(m == 0 ? stream : (side_on(2) ? S(2) : S(4)), gd)); }
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeq{gx[m][d], P(g.w_hh), P(g.b_hh), l == 0 ? h0[m] : h1[m], save ? sv[l][m][d] : nullptr};
+        if (l == 0 && use_h16) a.seq[m][d].out16 = h0h[m];
       }
     }
     MX(join(1, l == 0 ? 4 : 3));
@@ -1758,6 +1780,10 @@ int mimrl_handle::gru_layer_backward(int l) {
         q.sb_b = gru[1][l][0].w_ih - gru[0][l][0].w_ih; q.sb2_b = gru[1][l][1].w_ih - gru[0][l][1].w_ih;
         q.sc_b = dh0[1] - dh0[0];
         if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa2_b *= 2; }   // buffer distances are fp32-element counts; bf16 elements: x2
+        if (lbf && w1_img_valid && h16_on && w1b) {   // the weights from the bf16 image of this step's forward pass: half the B bytes
+          q.B = reinterpret_cast<const float*>(w1b); q.B2 = reinterpret_cast<const float*>(w1b + (long)G * 2 * H);
+          q.b_bf16 = 1; q.sb_b = 2L * G * 2 * H; q.sb2_b = 2L * G * 2 * H;
+        }
         MX(G_(q));
       }
       return MIMRL_OK;
@@ -2556,6 +2582,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   }
   a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
   a.gscale = grad_scale;
+  if (stage == 2) w1_img_valid = false;
   if (stage == 2 && unpack_pending) {
     unpack_pending = false;
     const int G = 3 * 128;
@@ -2791,6 +2818,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fold_unpack_on = getenv("MIMRL_NO_FOLD_UNPACK") == nullptr;
+  h->h16_on = getenv("MIMRL_NO_H16") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   h->fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") == nullptr;
   h->fwd_f16 = getenv("MIMRL_FWD_BF16") == nullptr;

@@ -36,6 +36,7 @@ struct GemmDesc {
   long sa2_m = 0, sa2_k = 0, sa2_b = 0, sb2_k = 0, sb2_n = 0, sb2_b = 0;
   // operand storage: A (and A2) / B (and B2) are bf16 arrays behind the float-typed pointers (strides in bf16 elements).  Fast
   // path only (16-byte pieces go straight to LDS, no conversion): everything must be 8-element aligned, else gemm() fails.
+  // With f16 = 1 (below) and BOTH flags set the 16-bit storage type is fp16 and the layouts are (KC, KC): gemm_fast_f16s_kernel.
   int a_bf16 = 0, b_bf16 = 0;
   // bf16 mode only: round the operands to FP16 instead of bf16 (v_mfma_f32_32x32x16_f16: same rate, 11 instead of 8 significant bits;
   // saturating conversion).  For FORWARD products whose operands have a bounded range (inputs, weights, LayerNorm'd activations) and

@@ -700,6 +700,16 @@ __global__ __launch_bounds__(256) void gemm_fast_f16_kernel(KernelArgs ka) {
   tile_ids(ka.xcd_remap, bx, by, bzr);
   fast_body<TM, TN, true, true, GEN, false, false, true>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
 }
+// both operands STORED as fp16, k-contiguous (a forward product whose operands the producer already wrote in 16 bits: the layer-1 GRU
+// input projection reads the layer-0 recurrence's fp16 copy of h and an fp16 weight image -- half the L2 -> LDS bytes of the kernel
+// above, which is what bounds it: 235 MB per launch at cfg2, 3.1 GB at cfg3, ~7 TB/s either way).  Same values, same MFMA, same
+// accumulation order as gemm_fast_f16_kernel: the conversion happened at the producer's store instead of at this kernel's load.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_fast_f16s_kernel(KernelArgs ka) {
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
+  fast_body<TM, TN, true, true, false, true, true, true>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
+}
 // bf16-stored operands (plain epilogue): A bf16 with B fp32 (data gradient dh0, dW_ih against fp32 inputs) or both bf16 (dW_hh)
 template <int TM, int TN, bool AKC, bool BKC, bool BBF>
 __global__ __launch_bounds__(256) void gemm_fast_bf_kernel(KernelArgs ka) {
@@ -792,7 +802,9 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   if (d.A2 && (fast_class(d.A2, d.sa2_m, d.sa2_k, d.sa2_b, 0, d.M, d.K2, d.a_bf16) != ca || fast_class(d.B2, d.sb2_n, d.sb2_k, d.sb2_b, 0, d.N, d.K2, d.b_bf16) != cb))
     return false;
   if (d.a_bf16 || d.b_bf16) {   // instantiated: A bf16 (+ B bf16), plain epilogue, layouts (KC,RC) and (RC,RC); gaps in 8-row units
-    if (!d.a_bf16 || (ca == 1 && cb == 1) || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u) return false;
+    // (KC, KC) -- a forward product -- only as the fp16-operand kernel: both operands stored as fp16 (GemmDesc::f16)
+    if (!d.a_bf16 || (ca == 1 && cb == 1 && !(d.f16 && d.b_bf16)) || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u) return false;
+    if (d.f16 && !(ca == 1 && cb == 1 && d.b_bf16)) return false;   // fp16 storage exists for that product only
     if (d.a_gap_rows && (d.a_gap_at % 8 != 0 || d.a_gap_rows % 8 != 0)) return false;
   }
   const int ktiles = (d.K + FBK - 1) / FBK;
@@ -970,7 +982,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if ((d.a_bf16 || d.b_bf16) && !pl.fast)
     return set_error(MIMRL_ERR_ARG, "gemm: bf16-stored operands need the fast path (bf16 mode, 8-element alignment, A bf16, layouts KC/RC or RC/RC, plain epilogue)");
 #define FASTK(TM_, TN_, A_, B_)                                                                               \
-  if (d.f16 && gen) hipLaunchKernelGGL((gemm_fast_f16_kernel<TM_, TN_, true>), grid, dim3(256), 0, s, ka);    \
+  if (d.f16 && d.a_bf16) hipLaunchKernelGGL((gemm_fast_f16s_kernel<TM_, TN_>), grid, dim3(256), 0, s, ka);    \
+  else if (d.f16 && gen) hipLaunchKernelGGL((gemm_fast_f16_kernel<TM_, TN_, true>), grid, dim3(256), 0, s, ka);    \
   else if (d.f16) hipLaunchKernelGGL((gemm_fast_f16_kernel<TM_, TN_, false>), grid, dim3(256), 0, s, ka);     \
   else if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);    \
   else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \

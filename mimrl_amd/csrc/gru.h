@@ -10,6 +10,8 @@ struct GruSeq {
   const float* b_hh;   // [3H]
   float* out;          // [B,T,out_ld]; this direction writes columns [dir*H, dir*H+H)
   float* saved;        // gate slab for BPTT (gru_saved_floats(B,T) floats) or nullptr
+  _Float16* out16 = nullptr;   // optional (bf16 mode; all sequences of a launch or none): the same outputs again as fp16, same indexing -- the
+                               // operand the next layer's input projection reads (gemm_fast_f16s_kernel: it rounded them to fp16 anyway)
 };
 
 // In-kernel launch stamps (bench.py's roofline block: the duration of a launch INSIDE a replayed hipGraph, where HIP events cannot

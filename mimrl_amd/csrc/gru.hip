@@ -221,7 +221,7 @@ __device__ __forceinline__ void stamp_end(const KernelStamp& k) {
 // and with ONE wave per SIMD nothing runs under any of it.  With two waves per SIMD each wave has half the products (12 instead of 24)
 // and half the gate math (one unit per lane), and one wave's transcendentals run under the other's MFMAs; the matrix pipe of a SIMD
 // still sees the same 24 products per step -- its floor, 384 cycles -- but no longer waits for 2 x the gate math in between.
-template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false>   // GXH: gx stored as fp16
+template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false, bool H16 = false>   // GXH: gx stored as fp16
 __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   stamp_begin(a.stamp);
@@ -273,12 +273,23 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   const float* gx_b = q.gx + (long)b * T * G + u0;                       // gx [B,T,3H]
   const _Float16* gxh_b = reinterpret_cast<const _Float16*>(q.gx) + (long)b * T * G + u0;   // (GXH: the same array as fp16 elements)
   float* out_b = q.out + (long)b * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
+  _Float16* out16_b = H16 ? q.out16 + (long)b * T * a.out_ld + dir * H + u0 : nullptr;   // (H16: the fp16 copy, same indexing)
   float* sv_b = SAVE ? q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane) : nullptr;
   const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
 
   // software pipeline, distance 2: gx of step+2 is requested at the end of step (two named buffers, loop unrolled by
   // two, so that no register copy has to wait for the youngest load); the tail re-reads the last step
-  using GX = float[3][UPL];
+  // (GXH: the buffer holds the RAW fp16 values; they are converted where the gate math reads them.  The first version converted inside
+  //  load_gx -- a use right behind the load, i.e. a full memory latency on every cell step: 632 instead of 380 us at cfg3)
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  struct GX {
+    typename std::conditional<GXH, typename std::conditional<UPL == 2, h2, _Float16>::type, float>::type v[3][GXH ? 1 : UPL];
+    __device__ __forceinline__ float at(int g, int s) const {
+      if constexpr (GXH && UPL == 2) return (float)v[g][0][s];
+      else if constexpr (GXH) return (float)v[g][0];
+      else return v[g][s];
+    }
+  };
   auto load_gx = [&](GX& dst, int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? T - 1 - sc : sc;
@@ -288,13 +299,13 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
       const _Float16* p = gxh_b + (long)t * G;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        if constexpr (UPL == 2) { typedef __attribute__((ext_vector_type(2))) _Float16 h2; const h2 x = *reinterpret_cast<const h2*>(p + g * H); dst[g][0] = (float)x[0]; dst[g][1] = (float)x[1]; }
-        else dst[g][0] = (float)p[g * H];
+        if constexpr (UPL == 2) dst.v[g][0] = *reinterpret_cast<const h2*>(p + g * H);
+        else dst.v[g][0] = p[g * H];
       }
     } else {
       const float* p = gx_b + (long)t * G;
 #pragma unroll
-      for (int g = 0; g < 3; ++g) ldu<UPL>(p + g * H, dst[g]);
+      for (int g = 0; g < 3; ++g) ldu<UPL>(p + g * H, dst.v[g]);
     }
   };
   GX gxA, gxB;
@@ -350,13 +361,13 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     for (int s = 0; s < UPL; ++s) {
       gt.hn[s] = acc[2][s][0];
       if constexpr (!GSKIP(2)) {
-        gt.r[s] = fast_sigmoid(gx[0][s] + acc[0][s][0]);
-        gt.z[s] = fast_sigmoid(gx[1][s] + acc[1][s][0]);
-        gt.n[s] = fast_tanh(gx[2][s] + gt.r[s] * gt.hn[s]);
+        gt.r[s] = fast_sigmoid(gx.at(0, s) + acc[0][s][0]);
+        gt.z[s] = fast_sigmoid(gx.at(1, s) + acc[1][s][0]);
+        gt.n[s] = fast_tanh(gx.at(2, s) + gt.r[s] * gt.hn[s]);
       } else {
-        gt.r[s] = 0.25f * (gx[0][s] + acc[0][s][0]);
-        gt.z[s] = 0.25f * (gx[1][s] + acc[1][s][0]);
-        gt.n[s] = 0.5f * (gx[2][s] + gt.r[s] * gt.hn[s]);
+        gt.r[s] = 0.25f * (gx.at(0, s) + acc[0][s][0]);
+        gt.z[s] = 0.25f * (gx.at(1, s) + acc[1][s][0]);
+        gt.n[s] = 0.5f * (gx.at(2, s) + gt.r[s] * gt.hn[s]);
       }
       const float hnew = gt.n[s] + gt.z[s] * (hreg[s] - gt.n[s]);
       ho[s] = valid ? hnew : 0.f;
@@ -365,6 +376,10 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     if constexpr (!GSKIP(32)) putu<UPL>(hs[cur ^ 1], kq, u0, hreg);
     if constexpr (!GSKIP(4)) {
       stu<UPL>(out_b + (long)t * a.out_ld, ho);
+      if constexpr (H16) {
+        if constexpr (UPL == 2) { typedef __attribute__((ext_vector_type(2))) _Float16 h2; h2 x; x[0] = to_f16_sat(ho[0]); x[1] = to_f16_sat(ho[1]); *reinterpret_cast<h2*>(out16_b + (long)t * a.out_ld) = x; }
+        else out16_b[(long)t * a.out_ld] = to_f16_sat(ho[0]);
+      }
       if constexpr (SAVE) save_gates<BF16, UPL>(sv_b + t * sv_step, gt);
     }
     if constexpr (!GSKIP(16)) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -677,13 +692,34 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
   }
 #endif
   if (a.gx_f16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_forward: fp16-stored gx needs the bf16 recurrence mode");
-  if (bf16 && a.gx_f16) {
+  const bool h16 = a.seq[0][0].out16 != nullptr;
+  for (int m = 0; m < a.nmod; ++m)
+    for (int d = 0; d < 2; ++d)
+      if ((a.seq[m][d].out16 != nullptr) != h16) return set_error(MIMRL_ERR_ARG, "gru_forward: fp16 output copies must be all set or all null");
+  if (h16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_forward: the fp16 output copy exists in the bf16 recurrence mode only");
+  if (bf16 && a.gx_f16 && h16) {
+    if (gru_upl() == 1) {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, true, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, true, true>), grid, dim3(512), 0, s, a);
+    } else {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 2, 0, true, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 2, 0, true, true>), grid, dim3(256), 0, s, a);
+    }
+  } else if (bf16 && a.gx_f16) {
     if (gru_upl() == 1) {
       if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, true>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, true>), grid, dim3(512), 0, s, a);
     } else {
       if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 2, 0, true>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 2, 0, true>), grid, dim3(256), 0, s, a);
+    }
+  } else if (bf16 && h16) {
+    if (gru_upl() == 1) {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, false, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, false, true>), grid, dim3(512), 0, s, a);
+    } else {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 2, 0, false, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 2, 0, false, true>), grid, dim3(256), 0, s, a);
     }
   } else if (bf16) {
     if (gru_upl() == 1) {

@@ -41,6 +41,9 @@ struct L0Pack {
   // optional: the stage's begin-of-stage bookkeeping rides on workgroup (0,0) of this launch (step counters += 1, scalar block zeroed):
   // the pack is the first launch of the captured step, and a separate single-thread kernel in front of it was a launch + a gap
   int* bs_rng = nullptr; int* bs_adam = nullptr; float* bs_scal = nullptr; int bs_off = 0, bs_n = 0;
+  // optional (with pack_weights): 16-bit images of the four LAYER-1 input matrices W_ih_l1 [384, 256], [modality][direction] back to back --
+  // fp16 for the forward projection (gemm_fast_f16s_kernel), bf16 for the data-gradient product dh0 (the kernels rounded them at every load)
+  const float* w_ih1[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; _Float16* w1h = nullptr; __bf16* w1b = nullptr;
 };
 int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights = true);
 struct L0Unpack {

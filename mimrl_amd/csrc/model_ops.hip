@@ -774,13 +774,22 @@ inline int grid_for(long n, int block = 256, int cap = 2048) {
 __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
   const int m = blockIdx.y;
   const long nx = pack_inputs ? a.rows * a.KP : 0, nw = pack_weights ? 2L * 384 * a.KP : 0, nb = pack_weights ? 2L * 384 : 0;
+  const long n1 = (pack_weights && a.w1h) ? 2L * 384 * 256 / 4 : 0;   // float4 pieces of this modality's two W_ih_l1
   const int d = a.d[m];
   if (a.bs_rng && blockIdx.x == 0 && m == 0) {
     if (threadIdx.x == 0) { *a.bs_rng += 1; if (a.bs_adam) *a.bs_adam += 1; }
     for (int i = threadIdx.x; i < a.bs_n; i += blockDim.x) a.bs_scal[a.bs_off + i] = 0.f;
   }
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx + nw + nb; i += (long)gridDim.x * blockDim.x) {
-    if (i < nx) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx + nw + nb + n1; i += (long)gridDim.x * blockDim.x) {
+    if (i >= nx + nw + nb) {
+      const long j = i - nx - nw - nb; const int dir = (int)(j / (384L * 256 / 4)); const long q = j - dir * (384L * 256 / 4);
+      const float4 v = reinterpret_cast<const float4*>(a.w_ih1[m][dir])[q];
+      const long o = ((long)m * 2 + dir) * 384 * 256 + q * 4;
+      f16x4 h; h[0] = to_f16_sat(v.x); h[1] = to_f16_sat(v.y); h[2] = to_f16_sat(v.z); h[3] = to_f16_sat(v.w);
+      bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
+      *reinterpret_cast<f16x4*>(a.w1h + o) = h;
+      *reinterpret_cast<bf16x4*>(a.w1b + o) = b;
+    } else if (i < nx) {
       const long r = i / a.KP; const int c = (int)(i - r * a.KP);
       a.xpack[(long)m * a.rows * a.KP + i] = c < d ? a.x[m][r * d + c] : 0.f;
     } else if (i < nx + nw) {
@@ -816,7 +825,7 @@ __global__ void l0_unpack_kernel(L0Unpack a) {
 }  // namespace
 
 int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights) {
-  const long n = (pack_inputs ? a.rows * a.KP : 0) + (pack_weights ? 2L * 384 * a.KP + 2L * 384 : 0);
+  const long n = (pack_inputs ? a.rows * a.KP : 0) + (pack_weights ? 2L * 384 * a.KP + 2L * 384 : 0) + ((pack_weights && a.w1h) ? 2L * 384 * 256 / 4 : 0);
   if (n <= 0) return MIMRL_OK;
   hipLaunchKernelGGL(l0_pack_kernel, dim3(grid_for(n, 256, 1024), 2), dim3(256), 0, s, a, pack_inputs ? 1 : 0, pack_weights ? 1 : 0);
   LAUNCH_CHECK();

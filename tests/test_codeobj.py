@@ -25,7 +25,8 @@ def ks():
 
 
 def test_every_tu_is_present(ks):
-    for name in ("gru_fwd_kernel<true, true, 1, 0, false>", "gru_bwd_kernel<true, true, 1, 0>", "gru_fwd_kernel<true, true, 2, 0, false>",
+    for name in ("gru_fwd_kernel<true, true, 1, 0, false, false>", "gru_bwd_kernel<true, true, 1, 0>", "gru_fwd_kernel<true, true, 2, 0, false, false>",
+                 "gru_fwd_kernel<true, true, 2, 0, false, true>", "gemm_fast_f16s_kernel<2, 1>",
                  "gru_bwd_kernel<true, true, 2, 0>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0, false>",
                  "concat_fwd_kernel<3>", "mlp_img8_kernel<true, 4>", "adam_kernel", "knn_tile_kernel<1, 4>", "knn_merge_kernel<2, 4>", "sample_anchors_kernel", "lstm_fwd_kernel"):
         assert name in ks, name
@@ -42,7 +43,7 @@ def test_bf16_recurrence_kernels_are_agpr_free(ks):
 
 
 def test_bench_path_kernels_do_not_spill(ks):
-    hot = ("gemm_fast_kernel<", "gemm_fast_bf_kernel<", "gemm_group_kernel<", "gemm_groupk_kernel<", "cube_fwd_fused_kernel<false, 1, 2>",
+    hot = ("gemm_fast_kernel<", "gemm_fast_bf_kernel<", "gemm_fast_f16_kernel<", "gemm_fast_f16s_kernel<", "gemm_group_kernel<", "gemm_groupk_kernel<", "cube_fwd_fused_kernel<false, 1, 2>",
            "cube_fwd_fused_kernel<false, 3, 2>", "cube_fwd_fused_kernel<true, 3, 2>", "daxis_bwd_kernel", "laxis_bwd_kernel",
            "kmix_bwd_kernel<4, 0, ", "kmix_bwd_kernel<3, 0, ", "mlp_img8_kernel<", "mlp_frag_kernel<", "frag_images_kernel", "mi_sep_nce_kernel", "concat_fwd_kernel<", "concat_bwd_kernel<", "tail_pre_kernel",
            "adam_kernel", "head_fwd_kernel", "head_bwd_kernel", "cmi_loss_kernel", "daxis_param_grads_kernel", "colln_param_grads_kernel")

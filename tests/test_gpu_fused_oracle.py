@@ -359,6 +359,38 @@ ENC = [("cfg2_sep", None, True, False), ("cfg2_ragged", None, True, False), ("cf
        ("cfg2_ragged", None, True, True), ("cfg2_ragged", 49, True, True)]
 
 
+@pytest.mark.parametrize("name,T_", [("cfg2_sep", None), ("cfg2_sep", 49), ("cfg2_ragged", None)])
+def test_16bit_stored_projection_operands_change_nothing(name, T_, monkeypatch):
+    """Round 4: the layer-1 GRU input projection reads its operands as STORED fp16 (the layer-0 recurrence writes an fp16 copy of h next to the
+    fp32 one, the layer-0 pack launch an fp16 image of W_ih_l1: gemm_fast_f16s_kernel) and the dh0 product reads W_ih_l1 from a bf16 image
+    -- half the L2 -> LDS bytes of two GEMMs on the step's chain.  The fp32-operand kernels rounded the same values with the same
+    conversions at every load, so NOTHING may change: the encoder outputs (no atomics on that path) bit for bit, every gradient within the
+    run-to-run band of the float atomics in the weight-gradient GEMMs.  (MIMRL_NO_H16=1: the fp32-operand kernels.)"""
+    c, opt, batch, banks = case(name)
+    T = c["T"] if T_ is None else T_
+    batch = tuple(b[:, :T] if b.dim() == 3 else b for b in batch)
+    g = torch.Generator().manual_seed(3)
+    dcube = torch.randn(c["B"], opt.time_len, 3, 128, generator=g) / T
+    out = {}
+    for tag, env in (("h16", None), ("fp32", "1")):
+        if env:
+            monkeypatch.setenv("MIMRL_NO_H16", env)
+        else:
+            monkeypatch.delenv("MIMRL_NO_H16", raising=False)
+        eng = HipEngine(opt, 768, 74, 35, seq_len=T, bank_capacity=c["N"], precision="bf16")
+        eng.load_params(perturbed_params(opt, c["seed"]))
+        eng.set_batch(*batch)
+        x = eng.probe_encoders(dcube)
+        torch.cuda.synchronize()
+        out[tag] = (x.cpu().numpy().copy(), {n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if n.startswith(("W_t", "rnn_", "ln_a", "ln_v"))})
+        eng.close()
+    assert np.array_equal(out["h16"][0], out["fp32"][0]), "encoder outputs differ"
+    top = max(np.abs(v).max() for v in out["fp32"][1].values())
+    for n, want in out["fp32"][1].items():
+        scale = max(np.abs(want).max(), 1e-3 * top)
+        assert np.abs(out["h16"][1][n] - want).max() <= 1e-4 * scale, n
+
+
 @pytest.mark.parametrize("name,T_,margin,gxh", ENC, ids=[f"{n}{'' if t is None else '-T' + str(t)}{'' if mg else '-full'}{'-gxf16' if gh else ''}" for n, t, mg, gh in ENC])
 def test_encoders_vs_rounded_oracle(name, T_, margin, gxh, monkeypatch):
     """The recurrence kernels of the benchmarked mode -- gru_bwd_kernel<bf16, bf16 dg> is the largest kernel of the step, gru_fwd_kernel<bf16>
