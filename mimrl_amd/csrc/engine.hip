@@ -261,6 +261,7 @@ struct mimrl_handle {
   // the four W_ih_l1 written by the layer-0 pack launch of the same forward pass
   _Float16* h0h[2] = {nullptr, nullptr}; _Float16* w1h = nullptr; __bf16* w1b = nullptr;
   bool h16_on = true;                  // MIMRL_NO_H16=1: fp32 operands as before (tuning knob; results are bit-identical either way)
+  bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
   bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
@@ -891,10 +892,18 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
         for (int d = 0; d < 2; ++d) { pk.w_ih[m][d] = P(gru[m][0][d].w_ih); pk.b_ih[m][d] = P(gru[m][0][d].b_ih); }
       }
       pk.xpack = xpack; pk.wpack = wpack; pk.bpack = bpack; pk.rows = BT_; pk.KP = KP();
+      // ... and of the layer-0 projection itself: the pack launch writes its operands as fp16 (+ a bf16 copy of the inputs for the W_ih
+      // weight gradient, whose other operand -- dg -- is bf16) INSTEAD of fp32, in the same buffers
+      const bool l0_16 = use_h16 && dg_bf16 && KP() % 8 == 0;
+      xpack16 = l0_16;
       if (use_h16) {
         for (int m = 0; m < 2; ++m) for (int d = 0; d < 2; ++d) pk.w_ih1[m][d] = P(gru[m][1][d].w_ih);
         pk.w1h = w1h; pk.w1b = w1b;
         w1_img_valid = true;
+      }
+      if (l0_16) {
+        pk.xh = reinterpret_cast<_Float16*>(xpack); pk.xb = reinterpret_cast<__bf16*>(xpack + BT_ * KP());   // 2 * BT * KP halves each
+        pk.wh = reinterpret_cast<_Float16*>(wpack);
       }
       if (begin_in_pack) {   // begin_stage(1) of the shared-prefix step rides on this launch (enqueue_grads)
         pk.bs_rng = d_ints; pk.bs_adam = d_ints + 2; pk.bs_scal = bufs.scalars; pk.bs_off = 0; pk.bs_n = 32;
@@ -908,6 +917,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       gd.bias_n = bpack; gd.bias_n_b = G; gd.bias_n_bo = 2 * G;
       gd.f16 = fwd_f16;
       if (gx_f16) { gd.c_f16 = 1; gd.sc_b *= 2; gd.sc_bo *= 2; }   // buffer distances are fp32-element counts; fp16 elements: x2
+      if (l0_16) { gd.a_bf16 = gd.b_bf16 = 1; }                    // (same element strides: the 16-bit arrays keep the fp32 ones' shapes)
       PrecGuard pg(this, fp32_site(2));
       MX(G_on(stream, gd));
       if (pending_text && pending_text_at == 1) { MX(pending_text()); pending_text = nullptr; }
@@ -1801,6 +1811,7 @@ int mimrl_handle::gru_layer_backward(int l) {
       { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, xpack, KP(), dwih_pack, KP(), G, KP(), (int)BT_);
         q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = 0; q.sb_bo = BT_ * KP(); q.sc_b = (long)G * KP(); q.sc_bo = 2L * G * KP();
         if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; }
+        if (lbf && xpack16) { q.B = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(xpack + BT_ * KP())); q.b_bf16 = 1; }   // the bf16 copy of the packed inputs
         q.atomic = 1; MX(G_on(stream, q)); }
       { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, hprev[0][0][0], H, dwhh_pack, H, G, H, (int)BT_);
         q.a_gap_at = 2 * H; q.a_gap_rows = H;

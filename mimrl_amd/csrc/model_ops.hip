@@ -780,6 +780,43 @@ __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
     if (threadIdx.x == 0) { *a.bs_rng += 1; if (a.bs_adam) *a.bs_adam += 1; }
     for (int i = threadIdx.x; i < a.bs_n; i += blockDim.x) a.bs_scal[a.bs_off + i] = 0.f;
   }
+  if (a.xh) {   // 16-bit packed operands: four columns per thread (KP % 4 == 0), 8-byte stores
+    const long nx4 = nx / 4, nw4 = nw / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx4 + nw4 + nb + n1; i += (long)gridDim.x * blockDim.x) {
+      if (i < nx4) {
+        const long e = i * 4; const long r = e / a.KP; const int c = (int)(e - r * a.KP);
+        const float* src = a.x[m] + r * d + c;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = c + q < d ? src[q] : 0.f;
+        f16x4 h; bf16x4 b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = to_f16_sat(v[q]); b[q] = to_bf16(v[q]); }
+        *reinterpret_cast<f16x4*>(a.xh + (long)m * a.rows * a.KP + e) = h;
+        *reinterpret_cast<bf16x4*>(a.xb + (long)m * a.rows * a.KP + e) = b;
+      } else if (i < nx4 + nw4) {
+        const long e = (i - nx4) * 4; const int dir = (int)(e / (384L * a.KP)); const long q0 = e - dir * 384L * a.KP;
+        const int r = (int)(q0 / a.KP), c = (int)(q0 - (long)r * a.KP);
+        const float* src = a.w_ih[m][dir] + (long)r * d + c;
+        f16x4 h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = to_f16_sat(c + q < d ? src[q] : 0.f);
+        *reinterpret_cast<f16x4*>(a.wh + ((long)m * 2 + dir) * 384 * a.KP + q0) = h;
+      } else if (i < nx4 + nw4 + nb) {
+        const long j = i - nx4 - nw4; const int dir = (int)(j / 384), r = (int)(j - dir * 384L);
+        a.bpack[((long)m * 2 + dir) * 384 + r] = a.b_ih[m][dir][r];
+      } else {
+        const long j = i - nx4 - nw4 - nb; const int dir = (int)(j / (384L * 256 / 4)); const long q = j - dir * (384L * 256 / 4);
+        const float4 v = reinterpret_cast<const float4*>(a.w_ih1[m][dir])[q];
+        const long o = ((long)m * 2 + dir) * 384 * 256 + q * 4;
+        f16x4 h; h[0] = to_f16_sat(v.x); h[1] = to_f16_sat(v.y); h[2] = to_f16_sat(v.z); h[3] = to_f16_sat(v.w);
+        bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
+        *reinterpret_cast<f16x4*>(a.w1h + o) = h;
+        *reinterpret_cast<bf16x4*>(a.w1b + o) = b;
+      }
+    }
+    return;
+  }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx + nw + nb + n1; i += (long)gridDim.x * blockDim.x) {
     if (i >= nx + nw + nb) {
       const long j = i - nx - nw - nb; const int dir = (int)(j / (384L * 256 / 4)); const long q = j - dir * (384L * 256 / 4);
@@ -825,6 +862,8 @@ __global__ void l0_unpack_kernel(L0Unpack a) {
 }  // namespace
 
 int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights) {
+  if (a.xh && (!a.xb || !a.wh || !a.w1h || !pack_inputs || !pack_weights || a.KP % 4 != 0))
+    return set_error(MIMRL_ERR_ARG, "l0_pack: the 16-bit packed operands come as a set (inputs + weights + the layer-1 images)");
   const long n = (pack_inputs ? a.rows * a.KP : 0) + (pack_weights ? 2L * 384 * a.KP + 2L * 384 : 0) + ((pack_weights && a.w1h) ? 2L * 384 * 256 / 4 : 0);
   if (n <= 0) return MIMRL_OK;
   hipLaunchKernelGGL(l0_pack_kernel, dim3(grid_for(n, 256, 1024), 2), dim3(256), 0, s, a, pack_inputs ? 1 : 0, pack_weights ? 1 : 0);
