@@ -261,6 +261,8 @@ struct mimrl_handle {
   // the four W_ih_l1 written by the layer-0 pack launch of the same forward pass
   _Float16* h0h[2] = {nullptr, nullptr}; _Float16* w1h = nullptr; __bf16* w1b = nullptr;
   bool h16_on = true;                  // MIMRL_NO_H16=1: fp32 operands as before (tuning knob; results are bit-identical either way)
+  float* w2p[MIMRL_MAX_BLOCKS] = {};   // unfused L axis: fc2 [ol, hl] copied to row pitch roundup4(hl) when hl % 4 != 0 (GemmDesc::a_pad4)
+  bool w2p_valid[MIMRL_MAX_BLOCKS] = {};   // ... holds the current parameters (set by the forward pass, cleared by the main update)
   bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
   bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
@@ -772,6 +774,10 @@ int mimrl_handle::carve() {
     crit_frag = reinterpret_cast<__bf16*>(t3); crit_fragT = crit_frag + layout.floats[MIMRL_GROUP_CRITIC];
   }
   MX(take(&ff, B * D));
+  for (int i = 0; i < cfg.n_blocks; ++i) {
+    const int hl = cfg.d_hiddens[i][0], ol = cfg.d_outs[i][0];
+    if (hl % 4 != 0) MX(take(&w2p[i], (size_t)ol * ((hl + 3) & ~3) + 64));
+  }
   MX(take(&dpred, B));
   if (cfg.encoder == MIMRL_ENCODER_GRU) {
     MX(take(&xpack, 2 * BT_ * KP())); MX(take(&wpack, (size_t)4 * G * KP())); MX(take(&bpack, (size_t)4 * G));
@@ -1178,6 +1184,12 @@ int mimrl_handle::cube_forward(bool train, bool save) {
       MX(G_(g1));
       GemmDesc g2;   // Y = W2 . H_b + b2
       g2.A = P(a.fc2.w); g2.sa_m = hl; g2.sa_k = 1;
+      if (bf16 && w2p[i] && hl % 4 != 0) {   // a 50-wide fc2 has 200-byte rows: without the padded copy this product (and dU in the
+        const int hp = (hl + 3) & ~3;        // backward pass) falls to the scalar-load kernel -- 0.2-0.27 ms each at cfg3
+        MX(pad_rows(stream, P(a.fc2.w), w2p[i], ol, hl, hp));
+        w2p_valid[i] = true;
+        g2.A = w2p[i]; g2.sa_m = hp; g2.a_pad4 = 1;
+      }
       g2.B = b.l.h; g2.sb_k = C; g2.sb_n = 1; g2.sb_b = (long)hl * C;
       g2.C = b.l.y; g2.sc_m = C; g2.sc_n = 1; g2.sc_b = (long)ol * C;
       g2.M = ol; g2.N = (int)C; g2.K = hl; g2.batch = B;
@@ -1541,6 +1553,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       }
       GRAB(i_du);                                            // dU_b[hl,C] = (W2^T . dYm_b) * act'(U)
       { GemmDesc g; g.A = P(a.fc2.w); g.sa_m = 1; g.sa_k = hl; g.sa_b = 0;
+        if (bf16 && w2p[i] && w2p_valid[i] && hl % 4 != 0) { g.A = w2p[i]; g.sa_k = (hl + 3) & ~3; g.a_pad4 = 1; }
         g.B = dym; g.sb_k = C; g.sb_n = 1; g.sb_b = (long)ol * C;
         g.C = gbuf[i_du]; g.sc_m = C; g.sc_n = 1; g.sc_b = (long)hl * C; g.M = hl; g.N = (int)C; g.K = ol; g.batch = B;
         g.act = cfg.activation; g.gradact_u = b.l.u;
@@ -2593,7 +2606,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   }
   a.beta1 = cfg.beta1; a.beta2 = cfg.beta2; a.eps = cfg.adam_eps; a.weight_decay = cfg.weight_decay; a.clip = cfg.grad_clip;
   a.gscale = grad_scale;
-  if (stage == 2) w1_img_valid = false;
+  if (stage == 2) { w1_img_valid = false; for (bool& v : w2p_valid) v = false; }
   if (stage == 2 && unpack_pending) {
     unpack_pending = false;
     const int G = 3 * 128;

@@ -36,6 +36,10 @@ struct GemmDesc {
   long sa2_m = 0, sa2_k = 0, sa2_b = 0, sb2_k = 0, sb2_n = 0, sb2_b = 0;
   // operand storage: A (and A2) / B (and B2) are bf16 arrays behind the float-typed pointers (strides in bf16 elements).  Fast
   // path only (16-byte pieces go straight to LDS, no conversion): everything must be 8-element aligned, else gemm() fails.
+  // a_pad4: A is readable -- and ZERO -- up to the next multiple of 4 along its contiguous axis (a padded copy of a weight matrix whose
+  // width is not a multiple of 4, e.g. the 50 x 50 L-axis fc2 of CubeMLP: with it the product takes the 16-byte-load kernels although
+  // K % 4 != 0 (k-contiguous A) or M % 4 != 0 (row-contiguous A); the surplus columns multiply into outputs as zeros / are never stored)
+  int a_pad4 = 0;
   // With f16 = 1 (below) and BOTH flags set the 16-bit storage type is fp16 and the layouts are (KC, KC): gemm_fast_f16s_kernel.
   int a_bf16 = 0, b_bf16 = 0;
   // bf16 mode only: round the operands to FP16 instead of bf16 (v_mfma_f32_32x32x16_f16: same rate, 11 instead of 8 significant bits;

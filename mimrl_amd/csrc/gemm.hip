@@ -9,6 +9,7 @@
 //   * epilogue: bias (per row/column), beta*C, activation / activation-gradient, pre-activation copy, fused column
 //     sums (bias gradients), plain or atomic store;
 //   * split-K for accumulate-into-zeroed-output GEMMs (weight gradients with K = B*T ... B*L*K rows, tiny M x N).
+#include <cstdio>
 #include "gemm.h"
 
 #include <type_traits>
@@ -771,11 +772,12 @@ __global__ __launch_bounds__(256) void gemm_groupk_kernel(GroupKArgs ga) {
 }
 
 // layout class of one operand for the fast path: 1 = KC, 2 = RC, 0 = not eligible.  (row axis = m for A, n for B)
-inline int fast_class(const float* P, long s_r, long s_k, long s_b, long s_bo, int R, int K, int bf = 0) {
+inline int fast_class(const float* P, long s_r, long s_k, long s_b, long s_bo, int R, int K, int bf = 0, int pad4 = 0) {
   const int q = bf ? 8 : 4;   // elements per 16-byte piece
   if (!aligned16(P) || s_b % q != 0 || s_bo % q != 0) return 0;
-  if (s_k == 1 && s_r % q == 0 && K % q == 0 && K >= q && s_r != 1) return 1;
-  if (s_r == 1 && s_k % q == 0 && R % q == 0 && R >= q) return 2;
+  const bool pad = pad4 && !bf;   // GemmDesc::a_pad4: the contiguous axis is readable (zero) up to the next multiple of 4
+  if (s_k == 1 && s_r % q == 0 && (K % q == 0 || pad) && K >= q && s_r != 1) return 1;
+  if (s_r == 1 && s_k % q == 0 && (R % q == 0 || pad) && R >= q) return 2;
   return 0;
 }
 
@@ -797,7 +799,7 @@ static bool plain_accumulate(const GemmDesc& d) {
 static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   static const int no_fast = getenv("MIMRL_GEMM_NO_FAST") != nullptr;   // tuning knob
   if (!bf16 || no_fast) return false;
-  const int ca = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16), cb = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K, d.b_bf16);
+  const int ca = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16, d.a_pad4), cb = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K, d.b_bf16);
   if (!ca || !cb || (ca == 2 && cb == 1)) return false;
   if (d.A2 && (fast_class(d.A2, d.sa2_m, d.sa2_k, d.sa2_b, 0, d.M, d.K2, d.a_bf16) != ca || fast_class(d.B2, d.sb2_n, d.sb2_k, d.sb2_b, 0, d.N, d.K2, d.b_bf16) != cb))
     return false;
@@ -961,6 +963,12 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
     return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
+  static const bool trace = getenv("MIMRL_GEMM_TRACE") != nullptr;   // diagnostic: which products miss the fast path, and why
+  if (trace && bf16 && !pl.fast)
+    fprintf(stderr, "[gemm] generic: M %d N %d K %d batch %d | A %p sa %ld %ld %ld cls %d | B %p sb %ld %ld %ld cls %d | A2 %d K2 %d bias_m %d beta %g pre %d gu %d atomic %d\n",
+            d.M, d.N, d.K, d.batch, (const void*)d.A, d.sa_m, d.sa_k, d.sa_b, fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16),
+            (const void*)d.B, d.sb_k, d.sb_n, d.sb_b, fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K, d.b_bf16), d.A2 != nullptr, d.K2,
+            d.bias_m != nullptr, (double)d.beta, d.pre != nullptr, d.gradact_u != nullptr, d.atomic);
   if (d.c_f16 && (d.atomic || pl.nsplit > 1 || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.colsum))
     return set_error(MIMRL_ERR_ARG, "gemm: an fp16-stored output takes the plain store only (no atomic / split-K / beta / pre / column sums)");
   KernelArgs ka;

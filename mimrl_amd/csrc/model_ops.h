@@ -56,6 +56,8 @@ struct L0Unpack {
   int KP;
 };
 int l0_unpack_grads(hipStream_t s, const L0Unpack& a);
+// dst[r][0..Cp) = src[r][0..C) followed by zeros (Cp = C rounded up to a multiple of 4): the padded copy GemmDesc::a_pad4 asks for
+int pad_rows(hipStream_t s, const float* src, float* dst, int R, int C, int Cp);
 int seq_lengths2(hipStream_t s, const float* xa, int da, int* lens_a, const float* xv, int dv, int* lens_v, int B, int T);
 int ln_relu_drop_fwd(hipStream_t s, const float* h2, const float* gamma, const float* beta, float* cube, float* mean,
                      float* rstd, int B, int T, int L, int K, int D, int slot, float p, RngKey key, uint32_t stream_id);

@@ -840,6 +840,13 @@ __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
   }
 }
 
+__global__ void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int Cp) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)R * Cp; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Cp), c = (int)(i - (long)r * Cp);
+    dst[i] = c < C ? src[(long)r * C + c] : 0.f;
+  }
+}
+
 __global__ void l0_unpack_kernel(L0Unpack a) {
   const int md = blockIdx.y, m = md >> 1, dir = md & 1;
   const int d = a.d[m];
@@ -861,6 +868,11 @@ __global__ void l0_unpack_kernel(L0Unpack a) {
 
 }  // namespace
 
+int pad_rows(hipStream_t s, const float* src, float* dst, int R, int C, int Cp) {
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((long)R * Cp, 256, 64)), dim3(256), 0, s, src, dst, R, C, Cp);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
 int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights) {
   if (a.xh && (!a.xb || !a.wh || !a.w1h || !pack_inputs || !pack_weights || a.KP % 4 != 0))
     return set_error(MIMRL_ERR_ARG, "l0_pack: the 16-bit packed operands come as a set (inputs + weights + the layer-1 images)");
