@@ -33,14 +33,29 @@ int set_error(int code, const char* fmt, ...);
 #define LAUNCH_CHECK() HIPX(hipGetLastError())
 }  // namespace mimrl
 #include "det.h"
+#include <unordered_map>
+namespace mimrl {
+// Stream-capture bookkeeping (det.hip): while capture_track(true) is in effect every kernel launch notes which stream its graph node was
+// captured on -- the information graph_postprocess() (engine.hip) needs to keep the chain of dependent launches on ONE hardware queue.
+void capture_track(bool on);
+void capture_note(hipStream_t s);
+const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams();
+}  // namespace mimrl
+#undef hipLaunchKernelGGL
 #ifdef MIMRL_DET
 // deterministic build: every launch is followed, on its own stream, by the flush of the fixed-point accumulation table (det.h)
-#undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                 \
   do {                                                                            \
     (void)::mimrl::det_init();                                                    \
     hipLaunchKernelGGLInternal((kernel), (grid), (block), (lds), (stream), __VA_ARGS__); \
+    ::mimrl::capture_note(stream);                                                \
     (void)::mimrl::det_flush(stream);                                             \
+  } while (0)
+#else
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                 \
+  do {                                                                            \
+    hipLaunchKernelGGLInternal((kernel), (grid), (block), (lds), (stream), __VA_ARGS__); \
+    ::mimrl::capture_note(stream);                                                \
   } while (0)
 #endif
 namespace mimrl {

@@ -2738,6 +2738,81 @@ int mimrl_handle::run_fwd2_tail() {
   return MIMRL_OK;
 }
 
+// Captured-graph post-processing (diagnostics / tuning knobs, off by default):
+//   MIMRL_GRAPH_DOT=<file>   dump the captured two-stage step (hipGraphDebugDotPrint: kernel names, edges)
+//   MIMRL_GRAPH_REORDER=1    re-insert every node's outgoing edges so that the child with the LONGEST path to a sink comes first.  This
+//                            HIP runtime maps graph nodes to hardware queues by a depth-first walk in which a node's first edge keeps
+//                            the parent's queue and every further edge moves to the next one (tools/hw/graph_order.hip): with the chain's
+//                            continuation first, the chain of dependent launches stays on one in-order queue.
+static int graph_postprocess(hipGraph_t g) {
+  static const char* dot = getenv("MIMRL_GRAPH_DOT");
+  static const bool reorder = getenv("MIMRL_GRAPH_REORDER") != nullptr;
+  if (reorder) {
+    size_t nn = 0, ne = 0;
+    HIPX(hipGraphGetNodes(g, nullptr, &nn));
+    std::vector<hipGraphNode_t> nodes(nn);
+    HIPX(hipGraphGetNodes(g, nodes.data(), &nn));
+    HIPX(hipGraphGetEdges(g, nullptr, nullptr, &ne));
+    std::vector<hipGraphNode_t> from(ne), to(ne);
+    HIPX(hipGraphGetEdges(g, from.data(), to.data(), &ne));
+    std::vector<std::vector<int>> out(nn);
+    {
+      std::vector<std::pair<hipGraphNode_t, int>> ix(nn);
+      for (size_t i = 0; i < nn; ++i) ix[i] = {nodes[i], (int)i};
+      std::sort(ix.begin(), ix.end());
+      auto idx = [&](hipGraphNode_t n) { return std::lower_bound(ix.begin(), ix.end(), std::make_pair(n, -1))->second; };
+      for (size_t e = 0; e < ne; ++e) out[idx(from[e])].push_back(idx(to[e]));
+    }
+    std::vector<int> h(nn, -1);
+    std::function<int(int)> height = [&](int v) -> int { if (h[v] >= 0) return h[v]; int m = 0; for (int c : out[v]) m = std::max(m, 1 + height(c)); return h[v] = m; };
+    for (size_t v = 0; v < nn; ++v) height((int)v);
+    static const int mode = atoi(getenv("MIMRL_GRAPH_REORDER"));   // 1: by height; 2: the child captured on the parent's stream first
+    const auto& ns = capture_streams();
+    auto stream_of = [&](int v) -> hipStream_t { auto it = ns.find(nodes[v]); return it == ns.end() ? (hipStream_t)-1 : it->second; };
+    int changed = 0;
+    for (size_t v = 0; v < nn; ++v) {
+      if (out[v].size() < 2) continue;
+      std::vector<int> o = out[v];
+      if (mode == 4) {   // MIMRL_GRAPH_PERM: digit i = which child of the i-th fork node comes first (0 = as captured)
+        static const char* perm = getenv("MIMRL_GRAPH_PERM");
+        static int fork_no = 0;
+        int k = perm && fork_no < (int)strlen(perm) ? (perm[fork_no] >= 'a' ? perm[fork_no] - 'a' + 10 : perm[fork_no] - '0') : 0;
+        ++fork_no;
+        if (k > 0 && k < (int)o.size()) { const int c = o[k]; o.erase(o.begin() + k); o.insert(o.begin(), c); }   // child k first, the others keep their order
+        if (getenv("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] fork %d: node %zu, %zu children\n", fork_no - 1, v, o.size());
+      } else if (mode >= 2) {
+        const hipStream_t ps = stream_of((int)v);
+        if (ps == (hipStream_t)-1) continue;
+        std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return (stream_of(a) == ps) > (stream_of(b) == ps); });
+      } else {
+      std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return h[a] > h[b]; });
+      }
+      // mode 3: as 2, and the side children of successive forks are spread over the other queues: k empty nodes in front of them push
+      // them from queue s + 1 to s + 1 + k (k cycles 0, 1, 2 over the forks; MIMRL_GRAPH_PAD=<list of k per fork> overrides)
+      int pads = 0;
+      if (mode == 3 && stream_of(o[0]) == stream_of((int)v)) {
+        static const char* padlist = getenv("MIMRL_GRAPH_PAD");
+        static int fork_no = 0;
+        pads = padlist && fork_no < (int)strlen(padlist) ? padlist[fork_no] - '0' : fork_no % 3;
+        ++fork_no;
+      }
+      if (o == out[v] && pads == 0) continue;
+      std::vector<hipGraphNode_t> f(o.size(), nodes[v]), t;
+      for (int c : out[v]) t.push_back(nodes[c]);
+      HIPX(hipGraphRemoveDependencies(g, f.data(), t.data(), t.size()));
+      HIPX(hipGraphAddDependencies(g, &nodes[v], &nodes[o[0]], 1));
+      for (int k = 0; k < pads; ++k) { hipGraphNode_t pn; HIPX(hipGraphAddEmptyNode(&pn, g, &nodes[v], 1)); }
+      t.clear();
+      for (size_t c = 1; c < o.size(); ++c) t.push_back(nodes[o[c]]);
+      if (!t.empty()) HIPX(hipGraphAddDependencies(g, f.data(), t.data(), t.size()));
+      ++changed;
+    }
+    if (getenv("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] %zu nodes, %zu edges, %d fork nodes re-ordered\n", nn, ne, changed);
+  }
+  if (dot) HIPX(hipGraphDebugDotPrint(g, dot, hipGraphDebugDotFlagsVerbose));
+  return MIMRL_OK;
+}
+
 // Solver.step(): stage 1 then stage 2 on the bound batch.  In overlap mode with graphs the two stages are ONE captured
 // graph (one launch, no idle device between the stage-1 Adam and the stage-2 estimators); otherwise two run() calls.
 int mimrl_handle::run_step() {
@@ -2760,6 +2835,7 @@ int mimrl_handle::run_step() {
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+    capture_track(getenv("MIMRL_GRAPH_REORDER") != nullptr);
     stream = cap_stream;
     fuse_boundary = !no_boundary; skip_imgT_refresh = use_imgT && !no_boundary; wtT_prebuilt = bf_bwd && fused_cube_bwd && !no_boundary;
     wtT_built = false;
@@ -2775,6 +2851,7 @@ int mimrl_handle::run_step() {
     const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
     if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
     if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    { const int pr = graph_postprocess(g); capture_track(false); if (pr != 0) { (void)hipGraphDestroy(g); return pr; } }
     const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
