@@ -2744,6 +2744,7 @@ int mimrl_handle::run_fwd2_tail() {
 //                            HIP runtime maps graph nodes to hardware queues by a depth-first walk in which a node's first edge keeps
 //                            the parent's queue and every further edge moves to the next one (tools/hw/graph_order.hip): with the chain's
 //                            continuation first, the chain of dependent launches stays on one in-order queue.
+__global__ void graph_pad_kernel() {}
 static int graph_postprocess(hipGraph_t g) {
   static const char* dot = getenv("MIMRL_GRAPH_DOT");
   static const bool reorder = getenv("MIMRL_GRAPH_REORDER") != nullptr;
@@ -2801,7 +2802,13 @@ static int graph_postprocess(hipGraph_t g) {
       for (int c : out[v]) t.push_back(nodes[c]);
       HIPX(hipGraphRemoveDependencies(g, f.data(), t.data(), t.size()));
       HIPX(hipGraphAddDependencies(g, &nodes[v], &nodes[o[0]], 1));
-      for (int k = 0; k < pads; ++k) { hipGraphNode_t pn; HIPX(hipGraphAddEmptyNode(&pn, g, &nodes[v], 1)); }
+      for (int k = 0; k < pads; ++k) {   // (a one-thread kernel: an EMPTY node in that place cost 200-400 us per step)
+        hipGraphNode_t pn;
+        hipKernelNodeParams kp = {};
+        kp.func = reinterpret_cast<void*>(graph_pad_kernel); kp.gridDim = dim3(1); kp.blockDim = dim3(1); kp.sharedMemBytes = 0;
+        kp.kernelParams = nullptr; kp.extra = nullptr;
+        HIPX(hipGraphAddKernelNode(&pn, g, &nodes[v], 1, &kp));
+      }
       t.clear();
       for (size_t c = 1; c < o.size(); ++c) t.push_back(nodes[o[c]]);
       if (!t.empty()) HIPX(hipGraphAddDependencies(g, f.data(), t.data(), t.size()));
