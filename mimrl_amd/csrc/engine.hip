@@ -2454,7 +2454,8 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     // shared-prefix step with packed layer-0 operands: the pack launch is the first kernel of the prefix on this stream and nothing in
     // front of the recurrence reads the counters or the scalars -- the bookkeeping rides on it (one launch + one gap less on the chain)
     // (measured neutral, 0.970 vs 0.966 ms: the single-thread kernel hides in the gap between two graph launches -- opt-in)
-    static const bool want_begin_in_pack = getenv("MIMRL_BEGIN_IN_PACK") != nullptr;   // tuning knob
+    // (round 4, with the length scan on side 0: -4 us on average over four alternating runs, cfg3 neutral -- on by default; =0: the separate kernel)
+    static const bool want_begin_in_pack = !(getenv("MIMRL_BEGIN_IN_PACK") && atoi(getenv("MIMRL_BEGIN_IN_PACK")) == 0);   // tuning knob
     begin_in_pack = want_begin_in_pack && share && have_banks && skip_zero && !begin_on_side && l0_packed && cfg.encoder == MIMRL_ENCODER_GRU;
     if (!begin_in_pack) {
       hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, begin_on_side ? side[4] : stream, d_ints, have_banks ? d_ints + 2 : nullptr,
