@@ -263,6 +263,8 @@ struct mimrl_handle {
   bool h16_on = true;                  // MIMRL_NO_H16=1: fp32 operands as before (tuning knob; results are bit-identical either way)
   float* w2p[MIMRL_MAX_BLOCKS] = {};   // unfused L axis: fc2 [ol, hl] copied to row pitch roundup4(hl) when hl % 4 != 0 (GemmDesc::a_pad4)
   bool w2p_valid[MIMRL_MAX_BLOCKS] = {};   // ... holds the current parameters (set by the forward pass, cleared by the main update)
+  bool xin_on = true;                  // MIMRL_NO_XIN=1: the layer-0 input projection as its own GEMM (tuning knob)
+  bool l0_xin = false;                 // this step's layer-0 forward ran the fused-projection (8-wave) kernel: its BPTT launch must match
   bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
   bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
@@ -924,8 +926,19 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       gd.f16 = fwd_f16;
       if (gx_f16) { gd.c_f16 = 1; gd.sc_b *= 2; gd.sc_bo *= 2; }   // buffer distances are fp32-element counts; fp16 elements: x2
       if (l0_16) { gd.a_bf16 = gd.b_bf16 = 1; }                    // (same element strides: the 16-bit arrays keep the fp32 ones' shapes)
+      // Fused input projection (round 4): with the operands packed as fp16 the layer-0 recurrence kernel computes x W_ih^T + b_ih itself,
+      // three k-steps per gate and cell step on a matrix pipe that is busy a quarter of the step: no GEMM launch, no gx round trip.
+      l0_xin = l0_16 && xin_on && KP() <= 96 && !gx_f16;
+      if (l0_xin) {
+        a.xin_on = 1; a.kp = KP();
+        for (int m = 0; m < 2; ++m) {
+          a.xin[m] = pk.xh + (long)m * BT_ * KP();
+          for (int d = 0; d < 2; ++d) { a.wih[m][d] = pk.wh + ((long)m * 2 + d) * G * KP(); a.bih[m][d] = bpack + ((long)m * 2 + d) * G; }
+        }
+      } else {
       PrecGuard pg(this, fp32_site(2));
       MX(G_on(stream, gd));
+      }
       if (pending_text && pending_text_at == 1) { MX(pending_text()); pending_text = nullptr; }
     }
     for (int m = 0; m < 2; ++m) {
@@ -2928,6 +2941,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
   h->fold_unpack_on = getenv("MIMRL_NO_FOLD_UNPACK") == nullptr;
   h->h16_on = getenv("MIMRL_NO_H16") == nullptr;
+  h->xin_on = getenv("MIMRL_NO_XIN") == nullptr;
   h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
   h->fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") == nullptr;
   h->fwd_f16 = getenv("MIMRL_FWD_BF16") == nullptr;

@@ -26,6 +26,15 @@ struct GruFwdArgs {
   int B, T, out_ld, nmod;
   int btv;             // batch rows per workgroup (1..4)
   int gx_f16 = 0;      // gx is an FP16 array behind the float-typed pointer (bf16 mode only; written by a GemmDesc::c_f16 projection)
+  // Fused input projection (bf16 mode, layer 0 of the packed path): gx = x W_ih^T + b_ih is NOT read; the kernel computes it per cell step
+  // from the fp16 packed inputs xin[modality] [B*T, kp] and the fp16 packed weights wih[modality][direction] [3H, kp] (kp % 8 == 0,
+  // kp <= 96; columns >= the true width are zero in both) with three more k-steps per gate on a matrix pipe that is idle most of the
+  // step -- they do not depend on h.  Runs the 8-wave kernel (one unit per lane: the 4-wave one has no registers left for the 9 extra
+  // weight fragments) and writes the saved-gate slab in the 4-wave layout, so the BPTT launch of the layer is the usual one.
+  int xin_on = 0, kp = 0;
+  const _Float16* xin[2] = {nullptr, nullptr};
+  const _Float16* wih[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  const float* bih[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 };
 
 struct GruSeqBwd {
@@ -46,6 +55,7 @@ struct GruBwdArgs {
   int B, T, out_ld, dout_ld, dout_off, nmod;
   int btv;             // must equal the forward launch's value (addresses the saved-gate slab)
   int dg_bf16 = 0;     // dg / hprev are written as bf16 (same element indices): their only consumers are bf16-operand GEMMs
+  int upl = 0;         // 1: the 8-wave kernel (the forward launch of this layer ran with one unit per lane: GruFwdArgs::xin_on); 0: the default
 };
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);

@@ -221,7 +221,7 @@ __device__ __forceinline__ void stamp_end(const KernelStamp& k) {
 // and with ONE wave per SIMD nothing runs under any of it.  With two waves per SIMD each wave has half the products (12 instead of 24)
 // and half the gate math (one unit per lane), and one wave's transcendentals run under the other's MFMAs; the matrix pipe of a SIMD
 // still sees the same 24 products per step -- its floor, 384 cycles -- but no longer waits for 2 x the gate math in between.
-template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false, bool H16 = false>   // GXH: gx stored as fp16
+template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false, bool H16 = false, bool XIN = false>   // GXH: gx stored as fp16; XIN: fused input projection
 __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   stamp_begin(a.stamp);
@@ -263,6 +263,30 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
 #pragma unroll
   for (int g = 0; g < 3; ++g) ldu<UPL>(q.b_hh + g * H + u0, bh[g]);
 
+  // ---- XIN: W_ih slice of this lane's unit as fp16 B fragments (k >= kp: zero), b_ih, and the batch row whose inputs feed this lane's
+  //      A-fragment row (MFMA row m carries batch row m >> 2, like the state tile)
+  [[maybe_unused]] f16x8 wx[3][3];
+  [[maybe_unused]] float bi[3] = {0.f, 0.f, 0.f};
+  [[maybe_unused]] const _Float16* x_b = nullptr;
+  if constexpr (XIN) {
+    static_assert(UPL == 1 && BF16 && !GXH, "fused input projection: 8-wave bf16 kernel, fp32 gate inputs");
+    const _Float16* __restrict__ wih = a.wih[mod][dir];
+    const int kp = a.kp;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      bi[g] = a.bih[mod][dir][g * H + u0];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int k = ks * 32 + 8 * kq;
+        f16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k < kp) f = *reinterpret_cast<const f16x8*>(wih + (long)(g * H + u0) * kp + k);
+        wx[g][ks] = f;
+      }
+    }
+    const int bx = min(tile * a.btv + min((lane & 15) >> 2, a.btv - 1), B - 1);
+    x_b = a.xin[mod] + (long)bx * T * kp;
+  }
+
   // ---- state
   float hreg[UPL];
 #pragma unroll
@@ -274,8 +298,11 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   const _Float16* gxh_b = reinterpret_cast<const _Float16*>(q.gx) + (long)b * T * G + u0;   // (GXH: the same array as fp16 elements)
   float* out_b = q.out + (long)b * T * a.out_ld + dir * H + u0;          // out [B,T,out_ld]
   _Float16* out16_b = H16 ? q.out16 + (long)b * T * a.out_ld + dir * H + u0 : nullptr;   // (H16: the fp16 copy, same indexing)
-  float* sv_b = SAVE ? q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane) : nullptr;
-  const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
+  // (XIN: this 8-wave launch writes the slab in the FOUR-wave layout -- the record of lane pair (n, n ^ 1) -- so that the BPTT launch of the
+  //  layer stays the 4-wave kernel: unit 16 w + n is element n & 1 of the record of 4-wave lane (kq, 8 (w & 1) + n / 2) of wave w / 2)
+  float* sv_b = !SAVE ? nullptr : XIN ? q.saved + sv_index<BF16, 2>(0, ntile, tile, w >> 1, kq * 16 + 8 * (w & 1) + (n >> 1))
+                                      : q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane);
+  const long sv_step = XIN ? (long)ntile * 4 * 64 * SvRec<BF16, 2>::F : (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
 
   // software pipeline, distance 2: gx of step+2 is requested at the end of step (two named buffers, loop unrolled by
   // two, so that no register copy has to wait for the youngest load); the tail re-reads the last step
@@ -283,6 +310,7 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   //  load_gx -- a use right behind the load, i.e. a full memory latency on every cell step: 632 instead of 380 us at cfg3)
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   struct GX {
+    f16x8 xf[XIN ? 3 : 1];   // XIN: the raw input fragments of the step (no gx)
     typename std::conditional<GXH, typename std::conditional<UPL == 2, h2, _Float16>::type, float>::type v[3][GXH ? 1 : UPL];
     __device__ __forceinline__ float at(int g, int s) const {
       if constexpr (GXH && UPL == 2) return (float)v[g][0][s];
@@ -295,7 +323,15 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     const int t = dir ? T - 1 - sc : sc;
     // (compiler-tracked loads here: with the explicit-wait loads of the BPTT kernel this loop measured 31.0 instead of 29.3 us per
     //  launch -- its waitcnt counts are exact in every second step and two short in the others, and that beats one exact wait)
-    if constexpr (GXH) {
+    if constexpr (XIN) {
+      const _Float16* p = x_b + (long)t * a.kp;
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        int k = ks * 32 + 8 * (lane >> 4);
+        k = k < a.kp ? k : a.kp - 8;                        // (past the packed width: any valid address, its weight fragment is zero)
+        dst.xf[ks] = *reinterpret_cast<const f16x8*>(p + k);
+      }
+    } else if constexpr (GXH) {
       const _Float16* p = gxh_b + (long)t * G;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
@@ -320,6 +356,15 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     for (int g = 0; g < 3; ++g)
 #pragma unroll
       for (int s = 0; s < UPL; ++s) acc[g][s] = f32x4{bh[g][s], 0.f, 0.f, 0.f};   // only register 0 is read
+    [[maybe_unused]] f32x4 accx[3];
+    if constexpr (XIN) {   // x_t W_ih^T + b_ih: independent of h, issued in front of the state fragments' LDS reads
+#pragma unroll
+      for (int g = 0; g < 3; ++g) accx[g] = f32x4{bi[g], 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) accx[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gx.xf[ks], wx[g][ks], accx[g], 0, 0, 0);
+    }
     if constexpr (BF16) {   // all A-fragments of the state tile requested up front (see gru_bwd_kernel)
       typename C::Frag sf[C::KS_F];
       if constexpr (!GSKIP(32)) {
@@ -361,13 +406,13 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     for (int s = 0; s < UPL; ++s) {
       gt.hn[s] = acc[2][s][0];
       if constexpr (!GSKIP(2)) {
-        gt.r[s] = fast_sigmoid(gx.at(0, s) + acc[0][s][0]);
-        gt.z[s] = fast_sigmoid(gx.at(1, s) + acc[1][s][0]);
-        gt.n[s] = fast_tanh(gx.at(2, s) + gt.r[s] * gt.hn[s]);
+        gt.r[s] = fast_sigmoid((XIN ? accx[0][0] : gx.at(0, s)) + acc[0][s][0]);
+        gt.z[s] = fast_sigmoid((XIN ? accx[1][0] : gx.at(1, s)) + acc[1][s][0]);
+        gt.n[s] = fast_tanh((XIN ? accx[2][0] : gx.at(2, s)) + gt.r[s] * gt.hn[s]);
       } else {
-        gt.r[s] = 0.25f * (gx.at(0, s) + acc[0][s][0]);
-        gt.z[s] = 0.25f * (gx.at(1, s) + acc[1][s][0]);
-        gt.n[s] = 0.5f * (gx.at(2, s) + gt.r[s] * gt.hn[s]);
+        gt.r[s] = 0.25f * ((XIN ? accx[0][0] : gx.at(0, s)) + acc[0][s][0]);
+        gt.z[s] = 0.25f * ((XIN ? accx[1][0] : gx.at(1, s)) + acc[1][s][0]);
+        gt.n[s] = 0.5f * ((XIN ? accx[2][0] : gx.at(2, s)) + gt.r[s] * gt.hn[s]);
       }
       const float hnew = gt.n[s] + gt.z[s] * (hreg[s] - gt.n[s]);
       ho[s] = valid ? hnew : 0.f;
@@ -380,7 +425,16 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
         if constexpr (UPL == 2) { typedef __attribute__((ext_vector_type(2))) _Float16 h2; h2 x; x[0] = to_f16_sat(ho[0]); x[1] = to_f16_sat(ho[1]); *reinterpret_cast<h2*>(out16_b + (long)t * a.out_ld) = x; }
         else out16_b[(long)t * a.out_ld] = to_f16_sat(ho[0]);
       }
-      if constexpr (SAVE) save_gates<BF16, UPL>(sv_b + t * sv_step, gt);
+      if constexpr (SAVE && XIN) {   // both lanes of a pair store the same 16 bytes (no guarded store in the loop)
+        Gates<2> g2;
+        const bool odd = (lane & 1) != 0;
+        const float rn = dpp_take<0xB1>(0.f, gt.r[0]), zn = dpp_take<0xB1>(0.f, gt.z[0]), nn = dpp_take<0xB1>(0.f, gt.n[0]), hnn = dpp_take<0xB1>(0.f, gt.hn[0]);
+        g2.r[0] = odd ? rn : gt.r[0];   g2.r[1] = odd ? gt.r[0] : rn;
+        g2.z[0] = odd ? zn : gt.z[0];   g2.z[1] = odd ? gt.z[0] : zn;
+        g2.n[0] = odd ? nn : gt.n[0];   g2.n[1] = odd ? gt.n[0] : nn;
+        g2.hn[0] = odd ? hnn : gt.hn[0]; g2.hn[1] = odd ? gt.hn[0] : hnn;
+        save_gates<BF16, 2>(sv_b + t * sv_step, g2);
+      } else if constexpr (SAVE) save_gates<BF16, UPL>(sv_b + t * sv_step, gt);
     }
     if constexpr (!GSKIP(16)) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // refill this buffer only now, behind the barrier (a compiler fence): its old contents are dead, so the loop-carried
@@ -697,7 +751,16 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
     for (int d = 0; d < 2; ++d)
       if ((a.seq[m][d].out16 != nullptr) != h16) return set_error(MIMRL_ERR_ARG, "gru_forward: fp16 output copies must be all set or all null");
   if (h16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_forward: the fp16 output copy exists in the bf16 recurrence mode only");
-  if (bf16 && a.gx_f16 && h16) {
+  if (a.xin_on) {
+    if (!bf16 || a.gx_f16 || a.kp % 8 != 0 || a.kp > 96 || a.kp < 8) return set_error(MIMRL_ERR_ARG, "gru_forward: the fused input projection needs the bf16 mode and kp in 8..96, a multiple of 8");
+    if (h16) {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, false, true, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, false, true, true>), grid, dim3(512), 0, s, a);
+    } else {
+      if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, false, false, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, false, false, true>), grid, dim3(512), 0, s, a);
+    }
+  } else if (bf16 && a.gx_f16 && h16) {
     if (gru_upl() == 1) {
       if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, true, true>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, true, true>), grid, dim3(512), 0, s, a);
@@ -759,7 +822,7 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
     return MIMRL_OK;
   }
 #endif
-  if (bf16 && gru_upl() == 1) {
+  if (bf16 && (gru_upl() == 1 || a.upl == 1)) {
     auto k1 = gru_bwd_kernel<true, true, 1>;
     auto k0 = gru_bwd_kernel<true, false, 1>;
     if (pad) {
