@@ -108,8 +108,10 @@ int mimrl_abi_version(void);
 /* 1 in the deterministic build of this library (libmimrl_hip_det.so, `make det`; loaded when MIMRL_DETERMINISTIC=1 -- the reference's
  * switch is torch.backends.cudnn.deterministic + the seeds of Main.py:14-20): every floating-point accumulation that the default build does
  * with float atomics is order-independent there (64-bit fixed point, csrc/det.h), the engine runs on one stream, and two runs of a stage
- * on the same inputs give bit-identical gradients (2: its accumulation table -- 8 M distinct target addresses per launch -- ran full at
- * some launch since load, which then fell back to float atomics; synchronises).  0 in the default build. */
+ * on the same inputs give bit-identical gradients.  Flag bits on top of the 1 (sticky since load; the call synchronises): | 2 its
+ * accumulation table -- 8 M distinct target addresses per launch -- ran full at some launch; | 4 some contribution was NaN / Inf / >= 2^22
+ * in magnitude.  Either way that contribution went through a plain float atomic (so a NaN propagates as in the default build) and the
+ * run is not bit-reproducible.  0 in the default build. */
 int mimrl_deterministic(void);
 int mimrl_device_check(void);   /* 0 iff a gfx950 device is usable by this process */
 
@@ -191,6 +193,14 @@ int mimrl_op_gemm(void* stream, const float* A, const float* B, float* C, int M,
 int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int M, int N, int K, int batch, const int64_t strides[9],
                      const float* A2, const float* B2, int K2, const int64_t strides2[6], int a_gap_at, int a_gap_rows,
                      const float* bias_n, const float* gradact_u, float* colsum, int act, int precision);
+/* (ABI v5) mimrl_op_gemm_ex with operands STORED in 16 bits behind the float-typed pointers (strides in 16-bit elements) and the two-level
+ * batch of the engine's projections: entry b = (b / batch_in, b % batch_in), outer strides strides_bo = {sa_bo, sb_bo, sc_bo, bias_n_bo, bias_n_b}
+ * (batch_in = 0: flat batch, only bias_n_b is read; NULL = all zero).  flags: bit 0 A stored 16-bit, bit 1 B stored 16-bit, bit 2 the 16-bit type is fp16 (else bf16), bit 3 C is
+ * stored as fp16 (strides in fp16 elements).  Tall k-contiguous products (M >= 16384, both operands stored) take the LDS-DMA kernel of
+ * csrc/gemm_tall.hip -- the GRU layer-1 input projection and its data gradient dh0 at cfg3 (Model.py:254-255 and autograd). */
+int mimrl_op_gemm16(void* stream, const void* A, const void* B, void* C, int M, int N, int K, int batch, const int64_t strides[9],
+                    const void* A2, const void* B2, int K2, const int64_t strides2[6], int batch_in, const int64_t strides_bo[5],
+                    const float* bias_n, int flags);
 /* n <= 12 weight-gradient products C_i += A_i . B_i (float atomics into caller-zeroed outputs; a batch with sc_b = 0 is reduced too) as
  * ONE grouped split-K launch when all share one operand-layout class, else n launches.  dims = n x {M, N, K, batch}, strides = n x 9 as
  * in mimrl_op_gemm.  (The engine's parked CubeMLP weight gradients, Model.py:150-214 backward.) */

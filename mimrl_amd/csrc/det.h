@@ -10,7 +10,8 @@
 //     build (common.h redefines hipLaunchKernelGGL) -- walks the dirty list once: *p += float(sum * 2^-40), one rounding per address,
 //     and hands the slots back.  The engine runs single-stream in this build, so a flush never sees a half-finished producer.
 // Cost: a table probe + two 64-bit atomics per contribution, ~170 extra launches per step; bench.py reports the step time of this build
-// beside the default one.  |v| < 2^23 per sum (gradient sums are orders of magnitude below it; values >= 2^-16 convert exactly).
+// beside the default one.  |sum| < 2^21 (gradient sums are orders of magnitude below it; values >= 2^-16 convert exactly); a NaN / Inf /
+// |v| >= 2^22 contribution is NOT converted: it takes the float atomic (global) or poisons the LDS sum to NaN, and is flagged.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,7 +22,8 @@ struct DetCtx {
   unsigned long long* keys;   // target address, 0 = free
   long long* vals;            // fixed-point sum
   unsigned* list;             // claimed slots, in claim order (order is irrelevant: one add per address)
-  unsigned* ctl;              // [0] = number of claimed slots, [1] = workgroups done (flush), [2] = overflow flag (sticky)
+  unsigned* ctl;              // [0] = number of claimed slots, [1] = workgroups done (flush), [2] = overflow flag (sticky),
+                              // [3] = a non-finite / out-of-range contribution fell back to the float atomic (sticky)
   unsigned mask;              // slots - 1
 };
 static __device__ DetCtx g_det;   // one copy per translation unit: det_register_tu() below
@@ -29,10 +31,17 @@ constexpr float kDetScale = 0x1p40f, kDetInv = 0x1p-40f;
 
 __device__ __forceinline__ long long det_fix(float v) { return __float2ll_rn(v * kDetScale); }
 
+// largest |v| a contribution may have: 2^40 * 2^22 = 2^62 keeps one contribution inside int64
+constexpr float kDetMaxAbs = 0x1p22f;
+
 __device__ __forceinline__ void acc_add(float* p, float v) {
+  const DetCtx c = g_det;
+  // NaN, Inf and |v| >= 2^22 do not convert (NaN -> 0 would silently DROP a divergence the default build propagates; large values
+  // saturate): such a contribution goes through the float atomic, so the target becomes NaN / Inf exactly as in the default build, and
+  // the sticky flag says this launch was not order-independent (mimrl_deterministic() bit 2)
+  if (!(fabsf(v) < kDetMaxAbs)) { if (c.ctl) c.ctl[3] = 1u; atomicAdd(p, v); return; }
   const long long fx = det_fix(v);
   if (fx == 0) return;
-  const DetCtx c = g_det;
   if (!c.keys) { atomicAdd(p, v); return; }   // no table (det_init failed)
   // slot = (hash of the 64-byte line, float within the line): the 16 floats of a line share one 128-byte run of `vals`, so a tile epilogue
   // touches as many lines of the table as of its target; a collision moves the whole line to the next group
@@ -68,8 +77,15 @@ __device__ __forceinline__ void acc_add(float* p, float v) {
 struct LdsAcc {
   long long v;
   __device__ __forceinline__ void zero() { v = 0; }
-  __device__ __forceinline__ void add(float x) { atomicAdd(reinterpret_cast<unsigned long long*>(&v), (unsigned long long)det_fix(x)); }
-  __device__ __forceinline__ float get() const { return (float)v * kDetInv; }
+  // a non-finite / out-of-range term poisons the sum (INT64_MIN marker, sticky under further adds of |x| < 2^22 for ~2^40 terms): get()
+  // then answers NaN, which is what a float sum with a NaN / Inf term would (nearly always) give -- never a silently dropped term
+  __device__ __forceinline__ void add(float x) {
+    if (!(fabsf(x) < kDetMaxAbs)) { atomicExch(reinterpret_cast<unsigned long long*>(&v), 0x8000000000000000ull); return; }
+    atomicAdd(reinterpret_cast<unsigned long long*>(&v), (unsigned long long)det_fix(x));
+  }
+  __device__ __forceinline__ float get() const {
+    return (v < -(1ll << 61) || v > (1ll << 61)) ? __builtin_nanf("") : (float)v * kDetInv;
+  }
 };
 
 // host side (det.cpp)
@@ -77,7 +93,8 @@ typedef void (*DetSetter)(const DetCtx&);
 void det_register_tu(DetSetter f);
 int det_init();                              // allocates the table, hands it to every translation unit (first launch; idempotent)
 int det_flush(hipStream_t s);                // apply and clear what the launches so far accumulated
-int det_overflowed();                        // 1 once the table ran full (results then came from plain float atomics)
+int det_overflowed();                        // bit 0: the table ran full; bit 1: a non-finite / out-of-range contribution (both: that
+                                             // contribution went through a plain float atomic)
 namespace {
 struct DetTuReg {
   DetTuReg() { det_register_tu([](const DetCtx& c) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_det), &c, sizeof(DetCtx)); }); }

@@ -66,9 +66,9 @@ int det_flush(hipStream_t s) {
 
 int det_overflowed() {
   if (!ready.load()) return 0;
-  unsigned f = 0;
-  if (hipMemcpy(&f, h_ctx.ctl + 2, sizeof f, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-  return f != 0;
+  unsigned f[2] = {0, 0};
+  if (hipMemcpy(f, h_ctx.ctl + 2, sizeof f, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return (f[0] != 0 ? 1 : 0) | (f[1] != 0 ? 2 : 0);
 }
 #endif
 
@@ -93,7 +93,11 @@ const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams() { retur
 
 extern "C" int mimrl_deterministic(void) {
 #ifdef MIMRL_DET
-  return ::mimrl::det_overflowed() ? 2 : 1;   // 2: the accumulation table ran full at some launch (that launch fell back to float atomics)
+  // 1 = deterministic build, every sum so far order-independent; | 2: the accumulation table ran full at some launch; | 4: some
+  // contribution was NaN / Inf / >= 2^22 in magnitude -- in both cases that contribution went through a plain float atomic (a NaN
+  // propagates exactly as in the default build) and the run was not bit-reproducible
+  const int f = ::mimrl::det_overflowed();
+  return 1 | ((f & 1) ? 2 : 0) | ((f & 2) ? 4 : 0);
 #else
   return 0;
 #endif

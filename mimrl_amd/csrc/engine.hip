@@ -264,6 +264,7 @@ struct mimrl_handle {
   float* w2p[MIMRL_MAX_BLOCKS] = {};   // unfused L axis: fc2 [ol, hl] copied to row pitch roundup4(hl) when hl % 4 != 0 (GemmDesc::a_pad4)
   bool w2p_valid[MIMRL_MAX_BLOCKS] = {};   // ... holds the current parameters (set by the forward pass, cleared by the main update)
   bool xin_on = true;                  // MIMRL_NO_XIN=1: the layer-0 input projection as its own GEMM (tuning knob)
+  bool part0_done = false;             // mimrl_stage_grads_part(h, 2, 0) ran on the bound batch and nothing since: part 1 may follow
   bool l0_xin = false;                 // this step's layer-0 forward ran the fused-projection (8-wave) kernel: its BPTT launch must match
   bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
   bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
@@ -1786,6 +1787,7 @@ int mimrl_handle::gru_layer_backward(int l) {
     // the generic kernel, which has no bf16-operand variant
     const bool lbf = dg_bf16 && (l == 1 || l0_packed || l0_bwd_pack);
     a.dg_bf16 = lbf ? 1 : 0;
+    a.slab_upl = l == 0 && l0_xin ? 2 : 0;   // the fused-projection forward wrote the 4-wave slab layout whatever MIMRL_GRU_WAVES says
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       for (int d = 0; d < 2; ++d) {
@@ -2659,6 +2661,11 @@ int mimrl_handle::run(int stage, int kind) {
   // an all-reduce): always zero first -- the caller may call it repeatedly
   if (kind == 4 && (stage != 2 || cfg.encoder != MIMRL_ENCODER_GRU))
     return set_error(MIMRL_ERR_ARG, "mimrl_stage_grads_part: only stage 2 of the GRU encoders splits");
+  // part 1 (the layer-0 BPTT) consumes dh0 and the saved gates part 0 left behind: out of order it would add gradients of a stale
+  // batch into main_g without a word.  Any other staged call in between invalidates the hand-over.
+  if (kind == 4 && !part0_done)
+    return set_error(MIMRL_ERR_STATE, "mimrl_stage_grads_part: part 1 must directly follow part 0 of the same stage-2 pass");
+  part0_done = false;
   if (prefetch && bank_rows > 0 && kind != 4) {
     if (stage == 1) { fwd2_pending = true; tail2_needed = defer_tail; }
     else if (!fwd2_pending)
@@ -2691,7 +2698,7 @@ int mimrl_handle::run(int stage, int kind) {
     return body();
   }
   if (kind == 1 || kind == 3) grads_clean[stage] = false;
-  if (!cfg.use_graph || prof_on) return body();
+  if (!cfg.use_graph || prof_on) { const int r = body(); part0_done = r == 0 && kind == 3; return r; }
   const int gk = kind >= 3 ? kind - 1 : kind;     // graph cache slot: 0 step, 1 grads, 2 / 3 the halves of a split stage-2 pass
   hipGraphExec_t& ex = GS().graph[stage][gk];
   if (ex && GS().rows[stage][gk] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
@@ -2711,6 +2718,7 @@ int mimrl_handle::run(int stage, int kind) {
     GS().rows[stage][gk] = bank_rows;
   }
   HIPX(hipGraphLaunch(ex, stream));
+  part0_done = kind == 3;
   return MIMRL_OK;
 }
 
@@ -2991,6 +2999,7 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
     if (!p) return set_error(MIMRL_ERR_ARG, "mimrl_bind: a required buffer is null");
   h->bufs = *b;
   h->bound = true;
+  h->part0_done = false;
   h->cur_set = 0;
   for (int q = 0; q < 2; ++q) for (int i = 0; i < 4; ++i) h->gsets[q].in[i] = nullptr;
   h->gsets[0].in[0] = b->text; h->gsets[0].in[1] = b->audio; h->gsets[0].in[2] = b->video; h->gsets[0].in[3] = b->labels;
@@ -3012,6 +3021,7 @@ int mimrl_set_inputs(mimrl_handle* h, int set, const float* text, const float* a
   }
   for (int i = 0; i < 4; ++i) g.in[i] = p[i];
   h->cur_set = set;
+  h->part0_done = false;                      // another batch: a pending part-0 hand-over is void
   h->bufs.text = text; h->bufs.audio = audio; h->bufs.video = video; h->bufs.labels = labels;
   return MIMRL_OK;
 }
@@ -3355,6 +3365,27 @@ int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int
   d.a_gap_at = a_gap_at; d.a_gap_rows = a_gap_rows;
   d.bias_n = bias_n; d.gradact_u = gradact_u; d.colsum = colsum; d.act = act & 0xff; d.atomic = (act >> 8) & 1;
   return gemm(reinterpret_cast<hipStream_t>(stream), d, (precision & 1) != 0);
+}
+
+int mimrl_op_gemm16(void* stream, const void* A, const void* B, void* C, int M, int N, int K, int batch, const int64_t st[9],
+                    const void* A2, const void* B2, int K2, const int64_t st2[6], int batch_in, const int64_t st_bo[5],
+                    const float* bias_n, int flags) {
+  if (!st || (A2 && !st2) || (batch_in > 0 && !st_bo)) return set_error(MIMRL_ERR_ARG, "null strides");
+  if (batch_in < 0 || (batch_in > 0 && batch % batch_in != 0)) return set_error(MIMRL_ERR_ARG, "batch_in must divide batch");
+  GemmDesc d;
+  d.A = static_cast<const float*>(A); d.B = static_cast<const float*>(B); d.C = static_cast<float*>(C);
+  d.M = M; d.N = N; d.K = K; d.batch = batch;
+  d.sa_m = st[0]; d.sa_k = st[1]; d.sa_b = st[2]; d.sb_k = st[3]; d.sb_n = st[4]; d.sb_b = st[5];
+  d.sc_m = st[6]; d.sc_n = st[7]; d.sc_b = st[8];
+  if (A2) {
+    d.A2 = static_cast<const float*>(A2); d.B2 = static_cast<const float*>(B2); d.K2 = K2;
+    d.sa2_m = st2[0]; d.sa2_k = st2[1]; d.sa2_b = st2[2]; d.sb2_k = st2[3]; d.sb2_n = st2[4]; d.sb2_b = st2[5];
+  }
+  if (batch_in > 0) { d.batch_in = batch_in; d.sa_bo = st_bo[0]; d.sb_bo = st_bo[1]; d.sc_bo = st_bo[2]; d.bias_n_bo = st_bo[3]; }
+  if (st_bo) d.bias_n_b = st_bo[4];
+  d.bias_n = bias_n;
+  d.a_bf16 = flags & 1; d.b_bf16 = (flags >> 1) & 1; d.f16 = (flags >> 2) & 1; d.c_f16 = (flags >> 3) & 1;
+  return gemm(reinterpret_cast<hipStream_t>(stream), d, true);
 }
 
 int mimrl_op_gemm_wgrad_group(void* stream, int n, const float* const* A, const float* const* B, float* const* C, const int32_t* dims,

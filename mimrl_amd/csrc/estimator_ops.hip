@@ -691,9 +691,15 @@ __global__ void adam_kernel(AdamArgs a) {
       for (int q = 0; q < a.fold.n; ++q)
         if (i >= a.fold.lo[q] && i < a.fold.hi[q]) {
           const long j = i - a.fold.lo[q];
-          float* src = a.fold.src[q] + (j / a.fold.d[q]) * a.fold.ld[q] + j % a.fold.d[q];
+          const int c = (int)(j % a.fold.d[q]);
+          float* src = a.fold.src[q] + (j / a.fold.d[q]) * a.fold.ld[q] + c;
           g += *src;
           *src = 0.f;
+          // the zero-padded columns [d, ld) of a packed row receive atomic adds too (products of zero operands: 0, or NaN once an
+          // upstream gradient is non-finite) and belong to no parameter: the thread of the row's last real column resets them, so
+          // the WHOLE packed buffer is zero again after the update, as l0_unpack_kernel left it
+          if (c == a.fold.d[q] - 1)
+            for (int e = a.fold.d[q]; e < a.fold.ld[q]; ++e) src[e - c] = 0.f;
         }
     }
     g *= a.gscale;

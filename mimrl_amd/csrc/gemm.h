@@ -82,6 +82,11 @@ struct GemmPlan {
 };
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p);
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
+// gemm_tall.hip: C[M, N] = A[M, K] . W[N, K]^T (+ A2 . W2^T) (+ bias_n) for M >= 16384 with BOTH operands stored in 16 bits and k-contiguous
+// (a_bf16 = b_bf16 = 1, sa_k = sb_k = 1; bf16, or fp16 with f16 = 1), plain epilogue, fp32 or fp16 (c_f16) output: 256 x 128 tiles, 3-stage
+// LDS ring filled by LDS-DMA.  gemm() routes there by itself; gemm_tall_ok() is the eligibility test.
+bool gemm_tall_ok(const GemmDesc& d);
+int gemm_tall(hipStream_t s, const GemmDesc& d);
 // up to 6 independent GEMMs as ONE launch when they are plain (no second product / operand-reading epilogue), bf16 and of one
 // operand-layout class of the fast path; otherwise n ordinary launches.  No split-K: meant for many small products.
 int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16);

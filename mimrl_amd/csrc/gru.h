@@ -55,7 +55,10 @@ struct GruBwdArgs {
   int B, T, out_ld, dout_ld, dout_off, nmod;
   int btv;             // must equal the forward launch's value (addresses the saved-gate slab)
   int dg_bf16 = 0;     // dg / hprev are written as bf16 (same element indices): their only consumers are bf16-operand GEMMs
-  int upl = 0;         // 1: the 8-wave kernel (the forward launch of this layer ran with one unit per lane: GruFwdArgs::xin_on); 0: the default
+  // record layout of the saved-gate slab the forward launch of this layer wrote: 0 = whatever gru_upl() says (the forward ran the
+  // kernel MIMRL_GRU_WAVES picked), 2 = the 4-wave layout regardless (the fused-projection forward, GruFwdArgs::xin_on, always writes
+  // that one): the BPTT kernel is chosen by the slab it has to read, not by the knob
+  int slab_upl = 0;
 };
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);

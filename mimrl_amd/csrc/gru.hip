@@ -822,7 +822,8 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
     return MIMRL_OK;
   }
 #endif
-  if (bf16 && (gru_upl() == 1 || a.upl == 1)) {
+  const int upl = a.slab_upl ? a.slab_upl : gru_upl();
+  if (bf16 && upl == 1) {
     auto k1 = gru_bwd_kernel<true, true, 1>;
     auto k0 = gru_bwd_kernel<true, false, 1>;
     if (pad) {

@@ -39,6 +39,11 @@ CONFIGS = {
     "cfg3_small": dict(B=16, T=500, N=400, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1),
     # BASELINE cfg5, reference-supported subset (gru, d_common=128, fp32), T = 1000: 2000 serial cell steps per pass
     "cfg5_small": dict(B=8, T=1000, N=163, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=1),
+    # BASELINE cfg3 at FULL size (B=256, T=500, concat critic, MOSEI-sized banks N=16326) and the cfg5 subset at the size the step tests
+    # run (B=32, T=1000): one reference step each, run ONCE in the build container (minutes of CPU autograd).  `slices`: per-tensor
+    # gradient norms / sums for every tensor plus a 512-entry strided slice of each (the fixture stays small); no forward feature dump.
+    "cfg3_full": dict(B=256, T=500, N=16326, seed=0, critic="concat", cube="50-3-128=10-3-128", traj=1, slices=True),
+    "cfg5_full": dict(B=32, T=1000, N=163, seed=0, critic="separate", cube="50-3-128=10-3-128", traj=1, slices=True),
     # --features_compose_t/k sum (Model.py:473-485)
     "tiny_sum": dict(B=8, T=6, N=40, seed=12, critic="separate", cube="6-3-128=4-3-128", traj=1, compose="sum"),
     # DISCRETE labels (steps of 0.2 like MOSI's annotator averages) in the batch and in the label bank: the R^1 kNN of the
@@ -56,6 +61,12 @@ EPOCH_CONFIGS = {
     "epoch_tail": dict(B=8, T=6, seed=22, critic="separate", cube="6-3-128=4-3-128", n_train=36, n_valid=12, n_test=8,
                        epochs=2, stage1_n=1, lr=1e-4, lr_iter="1-2", lr_rate=0.5),
 }
+
+
+def grad_slice_index(numel, n=512):
+    """Entries of a flattened gradient tensor a `slices` fixture stores: all of it up to n entries, else n evenly strided ones."""
+    import numpy as np
+    return np.arange(numel) if numel <= n else (np.arange(n, dtype=np.int64) * numel) // n
 
 
 def parse_cube(s):

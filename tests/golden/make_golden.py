@@ -30,7 +30,8 @@ import Model as RM  # noqa: E402  (reference)
 import Customization as RC  # noqa: E402  (reference)
 
 from mimrl_amd import synth  # noqa: E402
-from tests.golden.configs import CONFIGS, EPOCH_CONFIGS, epoch_data, make_opt, quantize_labels, split_batches  # noqa: E402
+from tests.golden.configs import (CONFIGS, EPOCH_CONFIGS, epoch_data, grad_slice_index, make_opt, quantize_labels,  # noqa: E402
+                                  split_batches)  # noqa: E402
 
 
 class StubBert(torch.nn.Module):
@@ -121,6 +122,7 @@ def gen(name, c):
         o = run_forward(model, *batch[:3])
     for k, val in zip(["pred", "F_F", "T_F", "A_F", "V_F"], o):
         out["fwd_" + k] = val.numpy().copy()
+    slices = c.get("slices", False)
 
     # ---- F9: epoch-0 rule (empty banks)
     loss0, mis0, _, _, task0 = stage_pass(model, opt, 2, batch, [[]] * 5, 0)
@@ -146,6 +148,8 @@ def gen(name, c):
             for n, p in vmi:
                 if p.numel() <= 512:
                     out["s1_grad:" + n] = p.grad.numpy().copy()
+                elif slices:
+                    out["s1_gslice:" + n] = p.grad.numpy().reshape(-1)[grad_slice_index(p.numel())].copy()
         torch.nn.utils.clip_grad_value_(all_params, opt.gradient_clip)
         opt_vmi.step()
         traj["s1_loss"].append(loss.item())
@@ -166,6 +170,8 @@ def gen(name, c):
             for n, p in main:
                 if p.numel() <= 512:
                     out["s2_grad:" + n] = p.grad.numpy().copy()
+                elif slices:
+                    out["s2_gslice:" + n] = p.grad.numpy().reshape(-1)[grad_slice_index(p.numel())].copy()
             out["s2_pred"] = outputs[0].detach().numpy().copy()
         torch.nn.utils.clip_grad_value_(all_params, opt.gradient_clip)
         opt_main.step()

@@ -503,3 +503,17 @@ def test_encoders_vs_rounded_oracle(name, T_, margin, gxh, monkeypatch):
 
 ENC_TOL = 6e-3        # margin-filtered upstream gradient (no ReLU-mask flips between kernel and reference): 3x the measured 2.0e-3
 ENC_TOL_FULL = 6e-2   # every unit carries gradient: 3x the measured 2e-2 (mask flips of ~1e-4 of the units, see above)
+
+
+def test_encoders_with_8_wave_recurrence_knob():
+    """MIMRL_GRU_WAVES=8 picks the one-unit-per-lane recurrence kernels, but the fused layer-0 projection forward always
+    writes its saved-gate slab in the 4-wave record layout -- the layer-0 BPTT launch has to follow the SLAB (GruBwdArgs::slab_upl), not the
+    knob.  The knob is read once per process, so the encoder parity cases run again in a child process with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MIMRL_GRU_WAVES="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_encoders_vs_rounded_oracle and (cfg2_sep or cfg1_ragged) and not gxf16"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
