@@ -4,202 +4,293 @@
 // and output BYTES, not by the matrix pipe: dh0 moves 0.66 GB for 100 GFLOP.  What the 128x128 register-staged kernel of gemm.hip lost
 // there: A re-read per column tile, a ds_write pass per 32-wide k-tile, one barrier-to-barrier memory round trip per k-tile.
 //
-// Structure (one workgroup = 4 waves, TWO workgroups per CU so that one's epilogue stores overlap the other's k-loop):
-//   * tile 256 (M) x 128 (N), BK = 32, a 3-stage LDS ring (72 KiB) filled by LDS-DMA (global_load_lds_dwordx4: no staging registers,
-//     no ds_write) with TWO k-tiles in flight across raw s_barriers under a counted s_waitcnt vmcnt(6) -- never 0 inside the loop;
-//   * LDS image [row][32 k] = 64-byte rows; the DMA writes lane-linear, so the bank swizzle (16-byte chunk ^= (row >> 2) & 3) is applied
-//     to the per-lane SOURCE address and again on the fragment read (ds_read_b128, conflict-free per 16-lane group);
-//   * wave tile 128 (M) x 64 (N) = 8 accumulators of v_mfma_f32_32x32x16_{bf16,f16}, 6 fragment reads per 8 MFMAs;
-//   * the product is computed TRANSPOSED (D[n][m]: W is the MFMA A operand): a lane then owns 4 consecutive n of one output row per
-//     register quad -- 16-byte stores (8-byte for an fp16 output) instead of sixteen 4-byte ones;
-//   * workgroup ids are dealt so that all column tiles (and all inner-batch entries that share A, e.g. the two GRU directions) of one
-//     256-row block run back to back on ONE XCD: A leaves HBM once.
+// Structure -- PERSISTENT workgroups (one per CU) that walk a list of output tiles as ONE flattened sequence of k-steps:
+//   * tile 256 (M) x NCB column blocks of 128 (N): 8 waves for NCB = 2 (the 256 x 256 tile), 4 for NCB = 1; wave tile 128 x 64 = 8
+//     accumulators of v_mfma_f32_32x32x16_{bf16,f16}.  A column block is (inner batch entry, 128 columns) -- the two GRU directions of
+//     the input projection are column blocks of the same row block, so A is staged once for both;
+//   * BK = 64, two LDS stages (2 x 64 KiB at NCB = 2) filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).
+//     One DMA instruction moves 8 rows x 128 B -- FULL cache lines (the first version moved 16 rows x 64 B and ran at half the L2 -> LDS
+//     rate) -- into a [k-half][8 rows][64 B] piece: lanes 0-31 take the first 64 bytes of the 8 rows, lanes 32-63 the second;
+//   * the DMA writes lane-linear, so the bank swizzle (16-byte chunk ^= (row >> 2) & 3) is applied to the per-lane SOURCE address and
+//     again on the fragment read (ds_read_b128, conflict-free per 16-lane group);
+//   * the k-step sequence does not stop at a tile boundary: the DMA of the NEXT tile's first k-step is issued before the last k-step of
+//     this tile is computed, so it lands while the epilogue stores drain -- no per-tile prologue bubble with one workgroup per CU;
+//   * epilogue straight from the accumulators: lane = output column, one store instruction = 2 rows x 128 B, full lines (a transposed
+//     product with 16-byte stores per lane was tried first: 32 partial lines per instruction, 7.9 us of store ISSUE per 128 KB tile);
+//   * tile ids are dealt so that the column groups of one 256-row block run at the same time on ONE XCD: A leaves HBM once.
 // Dispatched by gemm() for (k-contiguous, k-contiguous) 16-bit-stored operands with a plain epilogue when M >= 16384.
 #include "gemm.h"
+
+#include <type_traits>
 
 namespace mimrl {
 
 namespace {
 
-constexpr int TBM = 256, TBN = 128, TBK = 32, TSTAGES = 3;
-constexpr int TA_BYTES = TBM * TBK * 2, TW_BYTES = TBN * TBK * 2, TSTAGE_BYTES = TA_BYTES + TW_BYTES;   // 16 KiB + 8 KiB
-constexpr int TLDS_BYTES = TSTAGES * TSTAGE_BYTES;                                                      // 72 KiB
-constexpr int TLOADS = TA_BYTES / 4096 + TW_BYTES / 4096;                                               // 6 DMA instructions per wave and k-tile
+constexpr int TBM = 256, TBN = 128, TBK = 64;
+constexpr int TA_BYTES = TBM * TBK * 2, TW_BYTES = TBN * TBK * 2;   // 32 KiB, 16 KiB per column block
 
 struct TallArgs {
   const char* A[2]; const char* W[2];   // segment bases (bytes)
   long lda, ldw;                        // row pitches in elements (same for both segments)
-  int kt0, kt;                          // k-tiles of segment 0 / in total
+  int kt0, kt;                          // k-tiles (64 wide) of segment 0 / in total
   char* C; long ldc; int c_f16;
   const float* bias;
   int M, N, mt, nt, nbi, nbo;
-  long sa_bi[2], sa_bo[2], sw_bi[2], sw_bo[2], sc_bi, sc_bo, sbias_bi, sbias_bo;   // batch strides in elements
+  int ncg;                              // column groups (of NCB column blocks) per row block
+  long tiles;                           // ceil(mt * nbo / 8) * 8 * ncg tile ids (ids whose row block does not exist are skipped)
+  long sa_bo[2], sw_bi[2], sw_bo[2], sc_bi, sc_bo, sbias_bi, sbias_bo;   // batch strides in elements (A is shared by the inner batch)
 };
+
+#ifdef TALL_PROBE
+__device__ int g_tall_dbg = 0;   // ablations: 1 no A requests, 2 no W requests, 4 no MFMA, 8 A requests non-temporal, 16 no stores, 32 W nt
+#define TALL_DBG(b) (tall_dbg_ & (b))
+#define TALL_DBG_INIT() const int tall_dbg_ = __builtin_amdgcn_readfirstlane(g_tall_dbg)
+#else
+#define TALL_DBG(b) 0
+#define TALL_DBG_INIT() do { } while (0)
+#endif
+#ifdef TALL_PROBE   // tools/hw/tall_probe.hip: 100 MHz ticks per workgroup: [0] start, [1] end, [2] sum of epilogues, [3] sum of waits, [4] tiles
+__device__ unsigned long long* g_tall_stamps = nullptr;
+#define TALL_STAMP(i) do { if (g_tall_stamps && threadIdx.x == 0) g_tall_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define TALL_ADD(i, v) do { if (g_tall_stamps && threadIdx.x == 0) g_tall_stamps[(size_t)blockIdx.x * 8 + (i)] += (v); } while (0)
+#define TALL_NOW() wall_clock64()
+#else
+#define TALL_STAMP(i) do { } while (0)
+#define TALL_ADD(i, v) do { } while (0)
+#define TALL_NOW() 0ull
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-// acc[ni][mi] register quad g of lane (r31, hh) = output row mrow + 32 mi, columns ncol + 32 ni + 8 g .. + 3
-template <bool CF16, bool FULLN>
-__device__ __forceinline__ void tall_store(const TallArgs& a, const f32x16 (&acc)[2][4], const float* __restrict__ bias, long ocb, int mrow, int ncol) {
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    f32x4 bv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ncol + 32 * ni + 8 * g;
-        if constexpr (FULLN) bv[g] = *reinterpret_cast<const f32x4*>(bias + n);
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[g][e] = bias[n + e < a.N ? n + e : a.N - 1];
-      }
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = mrow + 32 * mi;
-      if (m < a.M) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = ncol + 32 * ni + 8 * g;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * g + e] + bv[g][e];
-          if constexpr (CF16) {
-            _Float16* c = reinterpret_cast<_Float16*>(a.C) + ocb + (long)m * a.ldc + n;
-            if constexpr (FULLN) {
-              f16x4 h; h[0] = to_f16_sat(v[0]); h[1] = to_f16_sat(v[1]); h[2] = to_f16_sat(v[2]); h[3] = to_f16_sat(v[3]);
-              *reinterpret_cast<f16x4*>(c) = h;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (n + e < a.N) c[e] = to_f16_sat(v[e]);
-            }
-          } else {
-            float* c = reinterpret_cast<float*>(a.C) + ocb + (long)m * a.ldc + n;
-            if constexpr (FULLN) *reinterpret_cast<f32x4*>(c) = v;
-            else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (n + e < a.N) c[e] = v[e];
-            }
-          }
-        }
-      }
-    }
-  }
+struct TallTile { int m0, cg; unsigned bo; bool ok; };
+
+__device__ __forceinline__ TallTile tall_decode(const TallArgs& a, long T) {
+  TallTile t;
+  t.ok = T < a.tiles;
+  const unsigned id = (unsigned)(t.ok ? T : 0), xcd = id & 7u, j = id >> 3;
+  const unsigned rbl = j / (unsigned)a.ncg;
+  t.cg = (int)(j - rbl * (unsigned)a.ncg);
+  const unsigned rb = rbl * 8u + xcd, nrb = (unsigned)(a.mt * a.nbo);
+  if (rb >= nrb) t.ok = false;
+  const unsigned rbc = rb < nrb ? rb : 0u;
+  t.bo = rbc / (unsigned)a.mt;
+  t.m0 = (int)(rbc - t.bo * (unsigned)a.mt) * TBM;
+  return t;
+}
+// next existing tile of this workgroup at or after T (ids of missing row blocks are skipped); >= a.tiles when none
+__device__ __forceinline__ long tall_next(const TallArgs& a, long T) {
+  while (T < a.tiles && !tall_decode(a, T).ok) T += gridDim.x;
+  return T;
 }
 
-template <bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_tall_kernel(TallArgs a) {
+template <bool F16, int NCB>
+__global__ __launch_bounds__(256 * NCB, NCB) void gemm_tall_kernel(TallArgs a) {
+  constexpr int STAGE = TA_BYTES + NCB * TW_BYTES;
+  constexpr int APW = 32 / (4 * NCB);      // A pieces (8 rows x 128 B) per wave and k-step: 8 (NCB 1, 4 waves) or 4 (NCB 2, 8 waves)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  TALL_DBG_INIT();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- tile of this workgroup: ids equal mod 8 share an XCD; inside one XCD run [row block][inner batch][column tile]
-  const unsigned id = blockIdx.x, xcd = id & 7u, j = id >> 3;
-  const unsigned per = (unsigned)(a.nt * a.nbi);
-  const unsigned rbl = j / per, rem = j - rbl * per, bi = rem / (unsigned)a.nt, ntile = rem - bi * (unsigned)a.nt;
-  const unsigned rb = rbl * 8u + xcd;
-  if (rb >= (unsigned)(a.mt * a.nbo)) return;
-  const unsigned bo = rb / (unsigned)a.mt, mtile = rb - bo * (unsigned)a.mt;
-  const int m0 = (int)mtile * TBM, n0 = (int)ntile * TBN;
-  const char* Ab[2]; const char* Wb[2];
+  const int wm = wave & 1, wn = (wave >> 1) & 1, wq = wave >> 2;   // row half, 64-column half inside the column block, column block
+  const int rowin = (lane >> 2) & 7, khalf = lane >> 5, chunk = lane & 3;
+
+  // ---- DMA side.  Per k-step this wave requests APW pieces of A (rows (wave * APW + i) * 8 ..) and 4 pieces of W (column block wq,
+  // rows ((wave & 3) * 4 + i) * 8 ..); lane -> (k-half, row in piece, LDS chunk) reads SOURCE chunk (LDS chunk) ^ ((row >> 2) & 3)
+  unsigned voa[APW], vow[4];
+  const char* Ad[2]; const char* Wd[2];
+  auto dma_setup = [&](const TallTile& t) __attribute__((always_inline)) {
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    Ab[s] = a.A[s] + 2 * ((long)bo * a.sa_bo[s] + (long)bi * a.sa_bi[s]);
-    Wb[s] = a.W[s] + 2 * ((long)bo * a.sw_bo[s] + (long)bi * a.sw_bi[s]);
-  }
-  // ---- per-lane DMA sources: instruction i of this wave fills the 1 KiB LDS piece q = 4 i + wave = rows 16 q .. 16 q + 15 (4 lanes per
-  // 64-byte row); lane -> (row = 16 q + lane / 4, LDS chunk lane % 4) reads SOURCE chunk (lane % 4) ^ ((row >> 2) & 3)
-  const int lrow = lane >> 2, csrc = (lane & 3) ^ ((lane >> 4) & 3);
-  unsigned voa[4], vow[2];
+    for (int i = 0; i < APW; ++i) {
+      const int r = (wave * APW + i) * 8 + rowin;
+      int gm = t.m0 + r;
+      gm = gm < a.M ? gm : a.M - 1;                                 // ragged last block: clamped rows land in outputs nobody stores
+      voa[i] = (unsigned)gm * (unsigned)(a.lda * 2) + (unsigned)(khalf * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
+    }
+    const int cb = t.cg * NCB + wq;
+    const int bi = cb / a.nt, nb = cb - bi * a.nt;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int gm = m0 + 16 * (4 * i + wave) + lrow;
-    gm = gm < a.M ? gm : a.M - 1;                       // ragged last block: clamped rows land in outputs nobody stores
-    voa[i] = (unsigned)gm * (unsigned)(a.lda * 2) + (unsigned)csrc * 16u;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int r = ((wave & 3) * 4 + i) * 8 + rowin;
+      int gn = nb * TBN + r;
+      gn = gn < a.N ? gn : a.N - 1;
+      vow[i] = (unsigned)gn * (unsigned)(a.ldw * 2) + (unsigned)(khalf * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
+    }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int gn = n0 + 16 * (4 * i + wave) + lrow;
-    gn = gn < a.N ? gn : a.N - 1;
-    vow[i] = (unsigned)gn * (unsigned)(a.ldw * 2) + (unsigned)csrc * 16u;
-  }
-  auto issue = [&](int t, int stage) __attribute__((always_inline)) {
-    const int seg = t >= a.kt0 ? 1 : 0;
-    const long kb = (long)(t - (seg ? a.kt0 : 0)) * (TBK * 2);
-    const char* As = Ab[seg] + kb;
-    const char* Ws = Wb[seg] + kb;
-    char* sa = smem + stage * TSTAGE_BYTES + wave * 1024;
+    for (int s = 0; s < 2; ++s) {
+      Ad[s] = a.A[s] + 2 * ((long)t.bo * a.sa_bo[s]);
+      Wd[s] = a.W[s] + 2 * ((long)t.bo * a.sw_bo[s] + (long)bi * a.sw_bi[s]);
+    }
+  };
+  // the requests of one k-step in four parts (q = 0 .. 3), one behind each 16-wide k-slice of the step in front: eight DMA instructions
+  // back to back right after the barrier kept ALL waves of the workgroup in the vector-memory issue queue for ~1.35 us per k-step (the
+  // L2 -> LDS path takes ~47 GB/s per CU, 64 KiB per step) with the matrix pipe idle, and then all of them in the MFMAs with the DMA path idle
+  constexpr int NPIECE = APW + 4, PPQ = NPIECE / 4;
+  const char* As_cur = nullptr; const char* Ws_cur = nullptr; char* sa_cur = nullptr; char* sw_cur = nullptr;
+  auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) {
+    const int seg = kt >= a.kt0 ? 1 : 0;
+    const long kb = (long)(kt - (seg ? a.kt0 : 0)) * (TBK * 2);
+    As_cur = Ad[seg] + kb;
+    Ws_cur = Wd[seg] + kb;
+    sa_cur = smem + stage * STAGE + wave * (APW * 1024);
+    sw_cur = smem + stage * STAGE + TA_BYTES + wq * TW_BYTES + (wave & 3) * 4096;
+  };
+  auto issue_part = [&](auto Q) __attribute__((always_inline)) {
+    constexpr int q = decltype(Q)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(As + voa[i]), (lds_void*)(sa + i * 4096), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(Ws + vow[i]), (lds_void*)(sa + TA_BYTES + i * 4096), 16, 0, 0);
+    for (int p = q * PPQ; p < (q + 1) * PPQ; ++p) {
+      if (p < APW) {
+        if (TALL_DBG(1)) continue;
+        if (TALL_DBG(8)) __builtin_amdgcn_global_load_lds((gbl_void*)(As_cur + voa[p < APW ? p : 0]), (lds_void*)(sa_cur + p * 1024), 16, 0, 2);
+        else __builtin_amdgcn_global_load_lds((gbl_void*)(As_cur + voa[p < APW ? p : 0]), (lds_void*)(sa_cur + p * 1024), 16, 0, 0);
+      } else {
+        if (TALL_DBG(2)) continue;
+        if (TALL_DBG(32)) __builtin_amdgcn_global_load_lds((gbl_void*)(Ws_cur + vow[p >= APW ? p - APW : 0]), (lds_void*)(sw_cur + (p - APW) * 1024), 16, 0, 2);
+        else __builtin_amdgcn_global_load_lds((gbl_void*)(Ws_cur + vow[p >= APW ? p - APW : 0]), (lds_void*)(sw_cur + (p - APW) * 1024), 16, 0, 0);
+      }
+    }
+  };
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    issue_begin(kt, stage);
+    issue_part(std::integral_constant<int, 0>{}); issue_part(std::integral_constant<int, 1>{});
+    issue_part(std::integral_constant<int, 2>{}); issue_part(std::integral_constant<int, 3>{});
   };
 
-  // ---- fragment addresses: lane holds row (lane & 31), k = 8 (lane >> 5) .. + 7 of a 16-wide k-step: chunk 2 ks + (lane >> 5), swizzled
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r31 = lane & 31, hh = lane >> 5, sw = (lane >> 2) & 3;
-  const int fa = (wm * 128 + r31) * 64, fw = TA_BYTES + (wn * 64 + r31) * 64;
-  const int c0 = (hh ^ sw) * 16, c1 = ((2 + hh) ^ sw) * 16;
+  // ---- fragment addresses: lane holds row (lane & 31), k = 16 ks + 8 (lane >> 5) .. + 7: piece (row >> 3), k-half ks >> 1, chunk
+  // 2 (ks & 1) + (lane >> 5), swizzled by (row >> 2) & 3
+  const int r31 = lane & 31, hh = lane >> 5, swz = (lane >> 2) & 3;
+  const int fa = (wm * 16 + (r31 >> 3)) * 1024 + (r31 & 7) * 64;                                       // + mi * 4096
+  const int fw = TA_BYTES + wq * TW_BYTES + (wn * 8 + (r31 >> 3)) * 1024 + (r31 & 7) * 64;             // + ni * 4096
+  const int c0 = (hh ^ swz) * 16, c1 = ((2 + hh) ^ swz) * 16;
 
-  f32x16 acc[2][4];   // [n sub-tile][m sub-tile]
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  const int KT = a.kt;
+  long Tc = tall_next(a, blockIdx.x);     // tile being computed
+  if (Tc >= a.tiles) return;
+  long Td = Tc;                           // tile / k-tile being requested
+  int ktd = 0;
+  dma_setup(tall_decode(a, Td));
+  TALL_STAMP(0);
+  issue(0, 0);
+  // advance the DMA cursor by one k-tile (scalars only); false when the tile list is exhausted.  The per-lane source offsets of a NEW tile
+  // are formed lazily at the top of the next k-step, behind its vmcnt(0): the compiler guards an overwrite of a DMA's address registers
+  // with a full wait, and here that wait would sit between the request of a k-step and the MFMAs it is meant to hide under
+  bool need_setup = false;
+  auto dma_advance = [&]() __attribute__((always_inline)) {
+    if (++ktd < KT) return true;
+    ktd = 0;
+    Td = tall_next(a, Td + gridDim.x);
+    need_setup = true;
+    return Td < a.tiles;
+  };
+  bool more = dma_advance();
+  int g = 0;                              // flattened k-step counter: stage = g & 1
+
+  while (true) {
+    const TallTile tc = tall_decode(a, Tc);
+    f32x16 acc[4][2];   // [m sub-tile][n sub-tile]
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-
-  const int KT = a.kt;
-  issue(0, 0);
-  if (KT > 1) issue(1, 1);
-  int st = 0, st2 = 2;   // stage of tile t / of tile t + 2
-  for (int t = 0; t < KT; ++t) {
-    // tile t has landed (this wave's pieces) once at most the 6 requests of tile t + 1 are outstanding; the barrier then makes every
-    // wave's pieces visible AND says every wave has finished reading stage (t - 1) % 3, which the requests for tile t + 2 overwrite
-    if (t + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TLOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t + 2 < KT) issue(t + 2, st2);
-    const char* sb = smem + st * TSTAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int cc = ks ? c1 : c0;
-      bf16x8 wf[2], af[4];
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sb + fw + ni * 2048 + cc);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sb + fa + mi * 2048 + cc);
-#pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          if constexpr (F16)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ni]), __builtin_bit_cast(f16x8, af[mi]), acc[ni][mi], 0, 0, 0);
-          else
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int t = 0; t < KT; ++t, ++g) {
+      // k-step g has landed (this wave's pieces: one k-step is in flight, plus the previous tile's stores, which retire within ~1 us of
+      // their issue); the barrier makes every wave's pieces visible AND says every wave has finished reading the other stage
+      [[maybe_unused]] const unsigned long long tw = TALL_NOW();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      TALL_ADD(3, TALL_NOW() - tw);
+      const bool req = more;               // (uniform)
+      if (req) {
+        if (need_setup) { dma_setup(tall_decode(a, Td)); need_setup = false; }
+        issue_begin(ktd, (g + 1) & 1);
+        more = dma_advance();
+      }
+      const char* sb = smem + (g & 1) * STAGE;
+      auto kslice = [&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        const int cc = (ks >> 1) * 512 + ((ks & 1) ? c1 : c0);
+        bf16x8 af[4], wf[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sb + fw + ni * 4096 + cc);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(sb + fa + mi * 4096 + cc);
+        if (!TALL_DBG(4))
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (F16)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, wf[ni]), acc[mi][ni], 0, 0, 0);
+            else
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
+          }
+        // this slice's share of the next k-step's requests, pinned behind its MFMAs (sched_barrier: neither hoisted nor sunk)
+        __builtin_amdgcn_sched_barrier(0);
+        if (req) issue_part(KS);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      kslice(std::integral_constant<int, 0>{}); kslice(std::integral_constant<int, 1>{});
+      kslice(std::integral_constant<int, 2>{}); kslice(std::integral_constant<int, 3>{});
     }
-    st = st == 2 ? 0 : st + 1;
-    st2 = st2 == 2 ? 0 : st2 + 1;
+    // ---- epilogue: D[i][j] with i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> m, j = lane & 31 -> n: one store = 2 rows x 128 B
+    [[maybe_unused]] const unsigned long long te = TALL_NOW();
+    {
+      const int cb = tc.cg * NCB + wq;
+      const int bi = cb / a.nt, nb = cb - bi * a.nt;
+      const long ocb = (long)tc.bo * a.sc_bo + (long)bi * a.sc_bi;
+      const float* bias = a.bias ? a.bias + (long)tc.bo * a.sbias_bo + (long)bi * a.sbias_bi : nullptr;
+      const int nbase = nb * TBN + wn * 64 + r31, mbase = tc.m0 + wm * 128 + 4 * hh;
+      // one branch per tile picks a straight-line store loop: FULL = every row and column of the wave tile exists (no per-store guards)
+      auto store = [&](auto CF, auto FULL) __attribute__((always_inline)) {
+        typedef typename std::conditional<decltype(CF)::value, _Float16, float>::type CT;
+        // 32-bit byte offsets from a uniform base (gemm_tall_ok bounds M * ldc): one VGPR per address instead of two
+        char* cbase = a.C + ocb * (long)sizeof(CT);
+        const unsigned ldcb = (unsigned)a.ldc * (unsigned)sizeof(CT);
+        // both bias values first: a load between the two store runs would wait for the 64 stores in front of it (one counter, in order)
+        float bvs[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = nbase + ni * 32;
+          bvs[ni] = bias ? bias[(decltype(FULL)::value || n < a.N) ? n : a.N - 1] : 0.f;
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int n = nbase + ni * 32;
+          const bool nok = decltype(FULL)::value || n < a.N;
+          const float bv = bvs[ni];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const int mb = mbase + mi * 32;
+            const unsigned off0 = (unsigned)mb * ldcb + (unsigned)n * (unsigned)sizeof(CT);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int dm = (r & 3) + 8 * (r >> 2);
+              const float v = acc[mi][ni][r] + bv;
+              if (decltype(FULL)::value || (nok && mb + dm < a.M)) {
+                CT* c = reinterpret_cast<CT*>(cbase + (off0 + (unsigned)dm * ldcb));
+                if constexpr (decltype(CF)::value) *c = to_f16_sat(v);
+                else *c = v;
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (without it all 128 store addresses are formed up front: 256 VGPRs + scratch)
+          }
+        }
+      };
+      const bool full = tc.m0 + TBM <= a.M && (nb + 1) * TBN <= a.N;
+      if (TALL_DBG(16)) { if (acc[0][0][0] == 123.25f && acc[3][1][7] == 7.f) a.C[0] = 1; }
+      else if (a.c_f16) { if (full) store(std::true_type{}, std::true_type{}); else store(std::true_type{}, std::false_type{}); }
+      else { if (full) store(std::false_type{}, std::true_type{}); else store(std::false_type{}, std::false_type{}); }
+    }
+    TALL_ADD(2, TALL_NOW() - te);
+    TALL_ADD(4, 1);
+    Tc = tall_next(a, Tc + gridDim.x);
+    if (Tc >= a.tiles) break;
   }
-
-  // ---- epilogue: D[i][j] with j = lane & 31 -> m, i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> n: registers 4 g .. 4 g + 3 are 4 consecutive n
-  const long ocb = (long)bo * a.sc_bo + (long)bi * a.sc_bi;
-  const float* bias = a.bias ? a.bias + (long)bo * a.sbias_bo + (long)bi * a.sbias_bi : nullptr;
-  const int mrow = m0 + wm * 128 + r31, ncol = n0 + wn * 64 + 4 * hh;
-  const bool full_n = n0 + TBN <= a.N;   // (one branch per workgroup picks the straight-line store loop: nothing uniform inside it)
-  if (a.c_f16) {
-    if (full_n) tall_store<true, true>(a, acc, bias, ocb, mrow, ncol);
-    else tall_store<true, false>(a, acc, bias, ocb, mrow, ncol);
-  } else {
-    if (full_n) tall_store<false, true>(a, acc, bias, ocb, mrow, ncol);
-    else tall_store<false, false>(a, acc, bias, ocb, mrow, ncol);
-  }
+  TALL_STAMP(1);
 }
 
 }  // namespace
@@ -209,20 +300,20 @@ bool gemm_tall_ok(const GemmDesc& d) {
   static const long min_m = getenv("MIMRL_GEMM_TALL_MIN_M") ? atol(getenv("MIMRL_GEMM_TALL_MIN_M")) : 16384;
   if (off || !d.a_bf16 || !d.b_bf16 || d.M < min_m) return false;
   if (d.sa_k != 1 || d.sb_k != 1 || d.sc_n != 1) return false;
-  if (d.K % TBK != 0 || d.K <= 0 || d.N % 4 != 0 || d.N < 32) return false;
+  if (d.K % TBK != 0 || d.K <= 0 || d.N < 32) return false;
   if (d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.atomic || d.colsum || d.act != ACT_NONE || d.alpha != 1.f) return false;
   if (d.a_gap_rows || d.a_pad4) return false;
-  if (d.sa_m % 8 != 0 || d.sb_n % 8 != 0 || (d.c_f16 ? d.sc_m % 4 != 0 : d.sc_m % 4 != 0)) return false;
-  if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B) | reinterpret_cast<uintptr_t>(d.C)) & 15) return false;
-  if (d.bias_n && (reinterpret_cast<uintptr_t>(d.bias_n) & 15)) return false;
-  if (d.sa_b % 8 || d.sa_bo % 8 || d.sb_b % 8 || d.sb_bo % 8 || d.sc_b % 4 || d.sc_bo % 4 || d.bias_n_b % 4 || d.bias_n_bo % 4) return false;
+  if (d.sa_m % 8 != 0 || d.sb_n % 8 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B)) & 15) return false;
+  if (d.sa_b % 8 || d.sa_bo % 8 || d.sb_b % 8 || d.sb_bo % 8) return false;
+  if (d.batch_in > 0 && d.sa_b != 0) return false;   // the inner batch must SHARE A (column blocks of one row block)
   if (d.A2) {
     if (d.sa2_k != 1 || d.sb2_k != 1 || d.K2 % TBK != 0 || d.K2 <= 0 || d.sa2_m != d.sa_m || d.sb2_n != d.sb_n) return false;
     if ((reinterpret_cast<uintptr_t>(d.A2) | reinterpret_cast<uintptr_t>(d.B2)) & 15) return false;
     if (d.sa2_b % 8 || d.sb2_b % 8 || d.batch_in > 0) return false;
   }
   // 32-bit byte offsets inside one batch entry
-  if ((double)d.M * d.sa_m * 2 >= 4.0e9 || (double)d.N * d.sb_n * 2 >= 4.0e9) return false;
+  if ((double)d.M * d.sa_m * 2 >= 4.0e9 || (double)d.N * d.sb_n * 2 >= 4.0e9 || ((double)d.M + 256) * d.sc_m * 4 >= 4.0e9) return false;
   return true;
 }
 
@@ -236,27 +327,45 @@ int gemm_tall(hipStream_t s, const GemmDesc& d) {
   a.bias = d.bias_n;
   a.M = d.M; a.N = d.N;
   a.mt = (d.M + TBM - 1) / TBM; a.nt = (d.N + TBN - 1) / TBN;
-  if (d.batch_in > 0) { a.nbi = d.batch_in; a.nbo = d.batch / d.batch_in; }
-  else { a.nbi = 1; a.nbo = d.batch; }   // a flat batch: every entry has its own A as far as this kernel knows
-  for (int q = 0; q < 2; ++q) { a.sa_bi[q] = a.sa_bo[q] = a.sw_bi[q] = a.sw_bo[q] = 0; }
+  for (int q = 0; q < 2; ++q) { a.sa_bo[q] = a.sw_bi[q] = a.sw_bo[q] = 0; }
   if (d.batch_in > 0) {
-    a.sa_bi[0] = d.sa_b; a.sa_bo[0] = d.sa_bo; a.sw_bi[0] = d.sb_b; a.sw_bo[0] = d.sb_bo;
+    a.nbi = d.batch_in; a.nbo = d.batch / d.batch_in;
+    a.sa_bo[0] = d.sa_bo; a.sw_bi[0] = d.sb_b; a.sw_bo[0] = d.sb_bo;
     a.sc_bi = d.sc_b; a.sc_bo = d.sc_bo; a.sbias_bi = d.bias_n_b; a.sbias_bo = d.bias_n_bo;
-  } else {
+  } else {                               // a flat batch: every entry has its own A
+    a.nbi = 1; a.nbo = d.batch;
     a.sa_bo[0] = d.sa_b; a.sw_bo[0] = d.sb_b; a.sa_bo[1] = d.sa2_b; a.sw_bo[1] = d.sb2_b;
     a.sc_bi = 0; a.sc_bo = d.sc_b; a.sbias_bi = 0; a.sbias_bo = d.bias_n_b;
   }
+  const int ncb_total = a.nt * a.nbi;                 // column blocks that share one row block of A
+  const int ncb = ncb_total % 2 == 0 ? 2 : 1;         // 256 x 256 tiles when they pair up
+  a.ncg = ncb_total / ncb;
   const long rbs = (long)a.mt * a.nbo;
-  const long grid = ((rbs + 7) / 8) * 8 * a.nt * a.nbi;
-  if (grid <= 0 || grid > 0x7fffffffL) return set_error(MIMRL_ERR_ARG, "gemm_tall: grid out of range");
+  a.tiles = ((rbs + 7) / 8) * 8 * a.ncg;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t p;
+    HIPX(hipGetDevice(&dev)); HIPX(hipGetDeviceProperties(&p, dev));
+    cus = p.multiProcessorCount >= 8 ? p.multiProcessorCount / 8 * 8 : 256;
+  }
+  // persistent: one workgroup per CU; a multiple of 8 keeps (tile id % 8) = (workgroup id % 8) = one XCD per workgroup
+  const unsigned grid = (unsigned)(a.tiles < cus ? a.tiles : cus);
+  const int lds1 = 2 * (TA_BYTES + TW_BYTES), lds2 = 2 * (TA_BYTES + 2 * TW_BYTES);
   static bool attr = false;
   if (!attr) {
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES));
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES));
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     attr = true;
   }
-  if (d.f16) hipLaunchKernelGGL(gemm_tall_kernel<true>, dim3((unsigned)grid), dim3(256), TLDS_BYTES, s, a);
-  else hipLaunchKernelGGL(gemm_tall_kernel<false>, dim3((unsigned)grid), dim3(256), TLDS_BYTES, s, a);
+  if (ncb == 2) {
+    if (d.f16) hipLaunchKernelGGL((gemm_tall_kernel<true, 2>), dim3(grid), dim3(512), lds2, s, a);
+    else hipLaunchKernelGGL((gemm_tall_kernel<false, 2>), dim3(grid), dim3(512), lds2, s, a);
+  } else {
+    if (d.f16) hipLaunchKernelGGL((gemm_tall_kernel<true, 1>), dim3(grid), dim3(256), lds1, s, a);
+    else hipLaunchKernelGGL((gemm_tall_kernel<false, 1>), dim3(grid), dim3(256), lds1, s, a);
+  }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -558,3 +558,49 @@ def test_fused_mlp_stack_forward_backward(lib, nb, rows, brows, dims):
                 assert_close(din[g, :rows].cpu().numpy(), d.cpu().numpy(), 1e-2, 1e-2, f"g{g} din")
         if rows < brows:
             assert float(out[g, rows:].abs().max()) == 0.0 and float(din[g, rows:].abs().max()) == 0.0
+
+
+def _gemm16(lib, A, B, Cm, M, N, K, batch, st, flags, A2=None, B2=None, K2=0, st2=None, batch_in=0, st_bo=None, bias=None):
+    arr = (C.c_int64 * 9)(*st)
+    arr2 = (C.c_int64 * 6)(*st2) if st2 else None
+    arrb = (C.c_int64 * 5)(*st_bo) if st_bo else None
+    _lib.check(lib.mimrl_op_gemm16(stream(), P(A), P(B), P(Cm), M, N, K, batch, arr, P(A2), P(B2), K2, arr2, batch_in, arrb, P(bias), flags))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,f16,cf16", [(16384 + 100, 384, 256, True, False), (16384 + 100, 384, 256, True, True), (20000, 160, 64, False, False),
+                                            (16384, 128, 192, False, True), (16640, 36, 64, True, False), (70000, 256, 128, False, False)])
+def test_gemm_tall_projection_shape(lib, M, N, K, f16, cf16):
+    """csrc/gemm_tall.hip (round 5): the LDS-DMA kernel gemm() picks for tall products with both operands stored in 16 bits and
+    k-contiguous -- here the shape class of the GRU layer-1 input projection (Model.py:254-255): batch = (modality, direction) with the
+    directions sharing A, bias per output column, fp32 or fp16 output, ragged last row block, N not a multiple of the 128-column tile,
+    K = one k-tile.  Reference: float64 product of the SAME 16-bit operands (only the fp32 accumulation order differs)."""
+    g = np.random.default_rng(M + N + K)
+    t16 = torch.float16 if f16 else torch.bfloat16
+    a = torch.from_numpy(g.standard_normal((2, M, K)).astype(np.float32)).to(t16).cuda()            # [modality][M, K]
+    w = torch.from_numpy(g.standard_normal((2, 2, N, K)).astype(np.float32) * 0.1).to(t16).cuda()   # [modality][direction][N, K]
+    b = dev(g.standard_normal((2, 2, N)))
+    out = torch.zeros(2, 2, M, N, device="cuda", dtype=torch.float16 if cf16 else torch.float32)
+    flags = 3 | (4 if f16 else 0) | (8 if cf16 else 0)
+    _gemm16(lib, a, w, out, M, N, K, 4, (K, 1, 0, 1, K, N * K, N, 1, M * N), flags, batch_in=2,
+            st_bo=(M * K, 2 * N * K, 2 * M * N, 2 * N, N), bias=b)
+    ref = torch.einsum("mrk,mdnk->mdrn", a.double(), w.double()) + b.double()[:, :, None, :]
+    got = out.double()
+    tol = 2e-6 * K + 1e-5 + (2e-3 * ref.abs().max().item() if cf16 else 0.0)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"tall {M}x{N}x{K} f16={f16} cf16={cf16}: max |err| {err} > {tol}"
+
+
+def test_gemm_tall_two_segments(lib):
+    """The dh0 shape class (autograd of Model.py:254-255): C = A1 . W1^T + A2 . W2^T with A1 / A2 = the first 384 of 512 columns of two
+    bf16 row arrays (the two directions' dg rows) and W = one [N, 768] image holding both directions' k ranges, batch = modality."""
+    g = np.random.default_rng(11)
+    M, N, K = 16384 + 77, 256, 384
+    a = torch.from_numpy(g.standard_normal((2, 2, M, 512)).astype(np.float32)).to(torch.bfloat16).cuda()   # [modality][direction][M, 512]
+    w = torch.from_numpy(g.standard_normal((2, N, 2 * K)).astype(np.float32) * 0.1).to(torch.bfloat16).cuda()
+    out = torch.full((2, M, N), 7.0, device="cuda")
+    _gemm16(lib, a[:, 0], w, out, M, N, K, 2, (512, 1, 2 * M * 512, 1, 2 * K, N * 2 * K, N, 1, M * N), 3,
+            A2=a[:, 1], B2=w[:, :, K:], K2=K, st2=(512, 1, 2 * M * 512, 1, 2 * K, N * 2 * K))
+    ref = torch.einsum("mdrk,mndk->mrn", a[..., :K].double(), w.double().reshape(2, N, 2, K))
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-6 * 2 * K + 1e-5, f"two-segment tall product: max |err| {err}"

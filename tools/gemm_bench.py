@@ -1,5 +1,6 @@
 """GPU microbenchmark of libmimrl_hip's strided GEMM on the shapes of the cfg2 step (run on the GPU box)."""
-import ctypes as C, sys, torch
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mimrl_amd import _lib
 lib = _lib.load(); _lib.check(lib.mimrl_device_check())
 S = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -40,3 +41,37 @@ run("concat wgrad: TN 256x256x65536 x5", 256, 256, 65536, 5, (1,256,65536*256, 2
 run("cfg3 L-mix: W[50,500].X_b[500,384] x256", 50, 384, 500, 256, (500,1,0, 384,1,500*384, 384,1,50*384), (50,500), (256,500,384), (256,50,384), iters=10)
 run("cfg3 D-axis wgrad TN 128x128x38400", 128, 128, 38400, 1, (1,128,0, 128,1,0, 128,1,0), (38400,128), (38400,128), (128,128), act=256, iters=10)
 run("cfg3 concat dW0 TN 256x128x256 x5", 256, 128, 256, 5, (1,256,256*256, 128,1,2*256*128, 256,1,256*256), (5,256,256), (5,2,256,128), (5,256,256), act=0, iters=10)
+
+
+# ---- round 5: the same cfg3 products with BOTH operands stored in 16 bits, k-contiguous (csrc/gemm_tall.hip when M >= 16384)
+def run16(name, M, N, K, batch, st, a_shape, w_shape, c_shape, flags, batch_in=0, st_bo=None, K2=0, st2=None, a2=None, w2=None, iters=10, bias=False):
+    t16 = torch.float16 if flags & 4 else torch.bfloat16
+    A = torch.randn(*a_shape, device="cuda").to(t16); W = (torch.randn(*w_shape, device="cuda") * 0.1).to(t16)
+    Cm = torch.zeros(*c_shape, device="cuda", dtype=torch.float16 if flags & 8 else torch.float32)
+    bv = torch.randn(batch * N, device="cuda") if bias else None
+    arr = (C.c_int64 * 9)(*st); arr2 = (C.c_int64 * 6)(*st2) if st2 else None; arrb = (C.c_int64 * 5)(*st_bo) if st_bo else None
+    A2 = a2(A) if a2 else None; W2 = w2(W) if w2 else None
+    f = lambda: lib.mimrl_op_gemm16(S, P(A), P(W), P(Cm), M, N, K, batch, arr, P(A2) if A2 is not None else None, P(W2) if W2 is not None else None, K2, arr2,
+                                    batch_in, arrb, P(bv) if bv is not None else None, flags)
+    for _ in range(3): _lib.check(f())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    flops = 2.0 * M * N * (K + K2) * batch
+    byts = A.numel() * 2 * (K + K2) / A.shape[-1] + W.numel() * 2 + Cm.numel() * Cm.element_size()
+    print(f"{name:58s} {us:8.1f} us  {flops/us/1e6:8.1f} TF/s  {byts/us/1e6:6.2f} TB/s")
+
+for tall in ("1", "0"):
+    if tall == "0":
+        if os.environ.get("MIMRL_NO_GEMM_TALL"): break
+        print("(re-run with MIMRL_NO_GEMM_TALL=1 for the round-4 kernels on the same descriptors)"); break
+    run16("cfg3 gx l1 f16s: 128000x384x256 x(2 mod x 2 dir), fp32 out", BT3, 384, 256, 4, (256,1,0, 1,256,384*256, 384,1,BT3*384), (2,BT3,256), (2,2,384,256), (2,2,BT3,384), 7,
+          batch_in=2, st_bo=(BT3*256, 2*384*256, 2*BT3*384, 2*384, 384), bias=True)
+    run16("cfg3 gx l1 f16s: same, fp16 out", BT3, 384, 256, 4, (256,1,0, 1,256,384*256, 384,1,BT3*384), (2,BT3,256), (2,2,384,256), (2,2,BT3,384), 15,
+          batch_in=2, st_bo=(BT3*256, 2*384*256, 2*BT3*384, 2*384, 384), bias=True)
+    run16("cfg3 dh0 bf16 (KC,KC): 128000x256x(384+384) x2 mod", BT3, 256, 384, 2, (512,1,2*BT3*512, 1,768,256*768, 256,1,BT3*256), (2,2,BT3,512), (2,256,768), (2,BT3,256), 3,
+          K2=384, st2=(512,1,2*BT3*512, 1,768,256*768), a2=lambda A: A[:, 1], w2=lambda W: W[:, :, 384:])
+    run16("cfg2 gx l1 f16s: 6400x384x256 x4 (below the tall threshold)", BT, 384, 256, 4, (256,1,0, 1,256,384*256, 384,1,BT*384), (2,BT,256), (2,2,384,256), (2,2,BT,384), 7,
+          batch_in=2, st_bo=(BT*256, 2*384*256, 2*BT*384, 2*384, 384), bias=True, iters=50)
