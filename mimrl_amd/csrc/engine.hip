@@ -260,6 +260,7 @@ struct mimrl_handle {
   // h0h = fp16 copy of the layer-0 outputs written by the recurrence kernel itself (per forward set), w1h / w1b = fp16 / bf16 images of
   // the four W_ih_l1 written by the layer-0 pack launch of the same forward pass
   _Float16* h0h[2] = {nullptr, nullptr}; _Float16* w1h = nullptr; __bf16* w1b = nullptr;
+  __bf16* w1bt = nullptr;              // w1b transposed + direction-concatenated [modality][256][768]: B operand of the tall (k-contiguous) dh0 product
   bool h16_on = true;                  // MIMRL_NO_H16=1: fp32 operands as before (tuning knob; results are bit-identical either way)
   float* w2p[MIMRL_MAX_BLOCKS] = {};   // unfused L axis: fc2 [ol, hl] copied to row pitch roundup4(hl) when hl % 4 != 0 (GemmDesc::a_pad4)
   bool w2p_valid[MIMRL_MAX_BLOCKS] = {};   // ... holds the current parameters (set by the forward pass, cleared by the main update)
@@ -785,7 +786,8 @@ int mimrl_handle::carve() {
   if (cfg.encoder == MIMRL_ENCODER_GRU) {
     MX(take(&xpack, 2 * BT_ * KP())); MX(take(&wpack, (size_t)4 * G * KP())); MX(take(&bpack, (size_t)4 * G));
     MX(take(&dwih_pack, (size_t)4 * G * KP())); MX(take(&dwhh_pack, (size_t)4 * G * H));
-    { float* t = nullptr; MX(take(&t, (size_t)4 * G * H)); w1h = reinterpret_cast<_Float16*>(t); MX(take(&t, (size_t)4 * G * H)); w1b = reinterpret_cast<__bf16*>(t); }
+    { float* t = nullptr; MX(take(&t, (size_t)4 * G * H)); w1h = reinterpret_cast<_Float16*>(t); MX(take(&t, (size_t)4 * G * H)); w1b = reinterpret_cast<__bf16*>(t);
+      MX(take(&t, (size_t)4 * G * H)); w1bt = reinterpret_cast<__bf16*>(t); }
   }
   // estimators
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
@@ -907,7 +909,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       xpack16 = l0_16;
       if (use_h16) {
         for (int m = 0; m < 2; ++m) for (int d = 0; d < 2; ++d) pk.w_ih1[m][d] = P(gru[m][1][d].w_ih);
-        pk.w1h = w1h; pk.w1b = w1b;
+        pk.w1h = w1h; pk.w1b = w1b; pk.w1bt = w1bt;
         w1_img_valid = true;
       }
       if (l0_16) {
@@ -1821,6 +1823,14 @@ int mimrl_handle::gru_layer_backward(int l) {
         if (lbf && w1_img_valid && h16_on && w1b) {   // the weights from the bf16 image of this step's forward pass: half the B bytes
           q.B = reinterpret_cast<const float*>(w1b); q.B2 = reinterpret_cast<const float*>(w1b + (long)G * 2 * H);
           q.b_bf16 = 1; q.sb_b = 2L * G * 2 * H; q.sb2_b = 2L * G * 2 * H;
+          // long sequences (B * T >= 16384 rows): both operands k-contiguous -- the transposed image of the same bf16 values, the two
+          // directions as two k-segments of one [256, 768] matrix per modality -- so that the LDS-DMA kernel of gemm_tall.hip takes it
+          if (w1bt) {
+            GemmDesc t = q;
+            t.B = reinterpret_cast<const float*>(w1bt); t.B2 = reinterpret_cast<const float*>(w1bt + G);
+            t.sb_k = 1; t.sb_n = 2 * G; t.sb2_k = 1; t.sb2_n = 2 * G; t.sb_b = 2L * H * 2 * G; t.sb2_b = 2L * H * 2 * G;
+            if (gemm_tall_ok(t)) q = t;
+          }
         }
         MX(G_(q));
       }

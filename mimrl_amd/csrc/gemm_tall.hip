@@ -37,7 +37,7 @@ struct TallArgs {
   char* C; long ldc; int c_f16;
   const float* bias;
   int M, N, mt, nt, nbi, nbo;
-  int ncg;                              // column groups (of NCB column blocks) per row block
+  int ncg;                              // column blocks per row block
   long tiles;                           // ceil(mt * nbo / 8) * 8 * ncg tile ids (ids whose row block does not exist are skipped)
   long sa_bo[2], sw_bi[2], sw_bo[2], sc_bi, sc_bo, sbias_bi, sbias_bo;   // batch strides in elements (A is shared by the inner batch)
 };
@@ -85,108 +85,105 @@ __device__ __forceinline__ long tall_next(const TallArgs& a, long T) {
   return T;
 }
 
-template <bool F16, int NCB>
-__global__ __launch_bounds__(256 * NCB, NCB) void gemm_tall_kernel(TallArgs a) {
-  constexpr int STAGE = TA_BYTES + NCB * TW_BYTES;
-  constexpr int APW = 32 / (4 * NCB);      // A pieces (8 rows x 128 B) per wave and k-step: 8 (NCB 1, 4 waves) or 4 (NCB 2, 8 waves)
+// Wave roles (round 5, third structure).  Ablations of the second one (all 8 waves request AND compute; tools/hw/tall_probe.hip) on the
+// layer-1 projection: requests alone 71 us, requests + MFMA 125 us, the stores alone 152 us, everything 246 us -- nothing overlapped.
+// A wave that has reached a DMA request while the vector-memory queue is full sits there, and with it its MFMAs; the L2 -> LDS path moves
+// ~63 GB/s per CU, so the queue is always full.  Now waves 0-3 only compute (tile 256 x 128, wave tile 128 x 64) and waves 4-7 only
+// request: a three-stage ring (3 x 48 KiB), TWO k-steps in flight, one s_barrier per k-step that both roles join:
+//   loader:   wait until k-step g has landed (vmcnt <= its own requests of g + 1) -> barrier g -> request k-step g + 2 into the stage that
+//             k-step g - 1 occupied (every compute wave has passed barrier g, i.e. finished reading it)
+//   compute:  barrier g -> fragments + MFMAs of stage g % 3
+// The epilogue stores belong to the compute waves; the loaders run up to two k-steps into the next tile meanwhile.
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void gemm_tall_kernel(TallArgs a) {
+  constexpr int STAGE = TA_BYTES + TW_BYTES, NST = 3;
+  constexpr int NPW = 12;                  // DMA pieces (8 rows x 128 B) per loader wave and k-step: 8 of A + 4 of W
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TALL_DBG_INIT();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 1, wn = (wave >> 1) & 1, wq = wave >> 2;   // row half, 64-column half inside the column block, column block
-  const int rowin = (lane >> 2) & 7, khalf = lane >> 5, chunk = lane & 3;
+  const int KT = a.kt;
+  const long T0 = tall_next(a, blockIdx.x);
+  if (T0 >= a.tiles) return;
+  long nsteps = 0;                          // k-steps of this workgroup (both roles count the same barriers)
+  for (long T = T0; T < a.tiles; T = tall_next(a, T + gridDim.x)) nsteps += KT;
 
-  // ---- DMA side.  Per k-step this wave requests APW pieces of A (rows (wave * APW + i) * 8 ..) and 4 pieces of W (column block wq,
-  // rows ((wave & 3) * 4 + i) * 8 ..); lane -> (k-half, row in piece, LDS chunk) reads SOURCE chunk (LDS chunk) ^ ((row >> 2) & 3)
-  unsigned voa[APW], vow[4];
-  const char* Ad[2]; const char* Wd[2];
-  auto dma_setup = [&](const TallTile& t) __attribute__((always_inline)) {
+  if (wave >= 4) {
+    // ================================================================== loader waves
+    const int lw = wave - 4;
+    const int rowin = (lane >> 2) & 7, khalf = lane >> 5, chunk = lane & 3;
+    unsigned voa[8], vow[4];
+    const char* Ad[2]; const char* Wd[2];
+    auto dma_setup = [&](const TallTile& t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < APW; ++i) {
-      const int r = (wave * APW + i) * 8 + rowin;
-      int gm = t.m0 + r;
-      gm = gm < a.M ? gm : a.M - 1;                                 // ragged last block: clamped rows land in outputs nobody stores
-      voa[i] = (unsigned)gm * (unsigned)(a.lda * 2) + (unsigned)(khalf * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
-    }
-    const int cb = t.cg * NCB + wq;
-    const int bi = cb / a.nt, nb = cb - bi * a.nt;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = ((wave & 3) * 4 + i) * 8 + rowin;
-      int gn = nb * TBN + r;
-      gn = gn < a.N ? gn : a.N - 1;
-      vow[i] = (unsigned)gn * (unsigned)(a.ldw * 2) + (unsigned)(khalf * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      Ad[s] = a.A[s] + 2 * ((long)t.bo * a.sa_bo[s]);
-      Wd[s] = a.W[s] + 2 * ((long)t.bo * a.sw_bo[s] + (long)bi * a.sw_bi[s]);
-    }
-  };
-  // the requests of one k-step in four parts (q = 0 .. 3), one behind each 16-wide k-slice of the step in front: eight DMA instructions
-  // back to back right after the barrier kept ALL waves of the workgroup in the vector-memory issue queue for ~1.35 us per k-step (the
-  // L2 -> LDS path takes ~47 GB/s per CU, 64 KiB per step) with the matrix pipe idle, and then all of them in the MFMAs with the DMA path idle
-  constexpr int NPIECE = APW + 4, PPQ = NPIECE / 4;
-  const char* As_cur = nullptr; const char* Ws_cur = nullptr; char* sa_cur = nullptr; char* sw_cur = nullptr;
-  auto issue_begin = [&](int kt, int stage) __attribute__((always_inline)) {
-    const int seg = kt >= a.kt0 ? 1 : 0;
-    const long kb = (long)(kt - (seg ? a.kt0 : 0)) * (TBK * 2);
-    As_cur = Ad[seg] + kb;
-    Ws_cur = Wd[seg] + kb;
-    sa_cur = smem + stage * STAGE + wave * (APW * 1024);
-    sw_cur = smem + stage * STAGE + TA_BYTES + wq * TW_BYTES + (wave & 3) * 4096;
-  };
-  auto issue_part = [&](auto Q) __attribute__((always_inline)) {
-    constexpr int q = decltype(Q)::value;
-#pragma unroll
-    for (int p = q * PPQ; p < (q + 1) * PPQ; ++p) {
-      if (p < APW) {
-        if (TALL_DBG(1)) continue;
-        if (TALL_DBG(8)) __builtin_amdgcn_global_load_lds((gbl_void*)(As_cur + voa[p < APW ? p : 0]), (lds_void*)(sa_cur + p * 1024), 16, 0, 2);
-        else __builtin_amdgcn_global_load_lds((gbl_void*)(As_cur + voa[p < APW ? p : 0]), (lds_void*)(sa_cur + p * 1024), 16, 0, 0);
-      } else {
-        if (TALL_DBG(2)) continue;
-        if (TALL_DBG(32)) __builtin_amdgcn_global_load_lds((gbl_void*)(Ws_cur + vow[p >= APW ? p - APW : 0]), (lds_void*)(sw_cur + (p - APW) * 1024), 16, 0, 2);
-        else __builtin_amdgcn_global_load_lds((gbl_void*)(Ws_cur + vow[p >= APW ? p - APW : 0]), (lds_void*)(sw_cur + (p - APW) * 1024), 16, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        const int r = (lw * 8 + i) * 8 + rowin;
+        int gm = t.m0 + r;
+        gm = gm < a.M ? gm : a.M - 1;                               // ragged last block: clamped rows land in outputs nobody stores
+        voa[i] = (unsigned)gm * (unsigned)(a.lda * 2) + (unsigned)(khalf * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
       }
+      const int bi = t.cg / a.nt, nb = t.cg - bi * a.nt;            // column block = (inner batch entry, 128 columns)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (lw * 4 + i) * 8 + rowin;
+        int gn = nb * TBN + r;
+        gn = gn < a.N ? gn : a.N - 1;
+        vow[i] = (unsigned)gn * (unsigned)(a.ldw * 2) + (unsigned)(khalf * 64 + ((chunk ^ ((r >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Ad[s] = a.A[s] + 2 * ((long)t.bo * a.sa_bo[s]);
+        Wd[s] = a.W[s] + 2 * ((long)t.bo * a.sw_bo[s] + (long)bi * a.sw_bi[s]);
+      }
+    };
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+      const int seg = kt >= a.kt0 ? 1 : 0;
+      const long kb = (long)(kt - (seg ? a.kt0 : 0)) * (TBK * 2);
+      const char* As = Ad[seg] + kb;
+      const char* Ws = Wd[seg] + kb;
+      char* sa = smem + stage * STAGE + lw * 8192;
+      char* sw = smem + stage * STAGE + TA_BYTES + lw * 4096;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (!TALL_DBG(1)) __builtin_amdgcn_global_load_lds((gbl_void*)(As + voa[i]), (lds_void*)(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (!TALL_DBG(2)) __builtin_amdgcn_global_load_lds((gbl_void*)(Ws + vow[i]), (lds_void*)(sw + i * 1024), 16, 0, 0);
+    };
+    long Td = T0; int ktd = 0; bool more = true, need_setup = true;
+    // request the next k-step of the flattened sequence (if any) into `stage`
+    auto request = [&](int stage) __attribute__((always_inline)) {
+      if (!more) return;
+      if (need_setup) { dma_setup(tall_decode(a, Td)); need_setup = false; }
+      issue(ktd, stage);
+      if (++ktd == KT) { ktd = 0; Td = tall_next(a, Td + gridDim.x); need_setup = true; more = Td < a.tiles; }
+    };
+    request(0);
+    request(1);
+    int st2 = 2;
+    for (long g = 0; g < nsteps; ++g) {
+      // k-step g has landed once at most the NPW requests of k-step g + 1 are outstanding (none behind the last one)
+      if (g + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      request(st2);                          // (the new tile's offsets overwrite registers of requests that may still be in flight: the
+      st2 = st2 == 2 ? 0 : st2 + 1;          //  hardware read them at issue; the compiler's guard wait there costs a loader nothing it needs)
     }
-  };
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-    issue_begin(kt, stage);
-    issue_part(std::integral_constant<int, 0>{}); issue_part(std::integral_constant<int, 1>{});
-    issue_part(std::integral_constant<int, 2>{}); issue_part(std::integral_constant<int, 3>{});
-  };
+    return;
+  }
 
-  // ---- fragment addresses: lane holds row (lane & 31), k = 16 ks + 8 (lane >> 5) .. + 7: piece (row >> 3), k-half ks >> 1, chunk
+  // ==================================================================== compute waves
+  const int wm = wave & 1, wn = wave >> 1;   // row half, 64-column half of the 256 x 128 tile
+  // fragment addresses: lane holds row (lane & 31), k = 16 ks + 8 (lane >> 5) .. + 7: piece (row >> 3), k-half ks >> 1, chunk
   // 2 (ks & 1) + (lane >> 5), swizzled by (row >> 2) & 3
   const int r31 = lane & 31, hh = lane >> 5, swz = (lane >> 2) & 3;
-  const int fa = (wm * 16 + (r31 >> 3)) * 1024 + (r31 & 7) * 64;                                       // + mi * 4096
-  const int fw = TA_BYTES + wq * TW_BYTES + (wn * 8 + (r31 >> 3)) * 1024 + (r31 & 7) * 64;             // + ni * 4096
+  const int fa = (wm * 16 + (r31 >> 3)) * 1024 + (r31 & 7) * 64;                       // + mi * 4096
+  const int fw = TA_BYTES + (wn * 8 + (r31 >> 3)) * 1024 + (r31 & 7) * 64;             // + ni * 4096
   const int c0 = (hh ^ swz) * 16, c1 = ((2 + hh) ^ swz) * 16;
-
-  const int KT = a.kt;
-  long Tc = tall_next(a, blockIdx.x);     // tile being computed
-  if (Tc >= a.tiles) return;
-  long Td = Tc;                           // tile / k-tile being requested
-  int ktd = 0;
-  dma_setup(tall_decode(a, Td));
   TALL_STAMP(0);
-  issue(0, 0);
-  // advance the DMA cursor by one k-tile (scalars only); false when the tile list is exhausted.  The per-lane source offsets of a NEW tile
-  // are formed lazily at the top of the next k-step, behind its vmcnt(0): the compiler guards an overwrite of a DMA's address registers
-  // with a full wait, and here that wait would sit between the request of a k-step and the MFMAs it is meant to hide under
-  bool need_setup = false;
-  auto dma_advance = [&]() __attribute__((always_inline)) {
-    if (++ktd < KT) return true;
-    ktd = 0;
-    Td = tall_next(a, Td + gridDim.x);
-    need_setup = true;
-    return Td < a.tiles;
-  };
-  bool more = dma_advance();
-  int g = 0;                              // flattened k-step counter: stage = g & 1
-
-  while (true) {
+  int st = 0;
+  for (long Tc = T0; Tc < a.tiles; Tc = tall_next(a, Tc + gridDim.x)) {
     const TallTile tc = tall_decode(a, Tc);
     f32x16 acc[4][2];   // [m sub-tile][n sub-tile]
 #pragma unroll
@@ -195,23 +192,17 @@ __global__ __launch_bounds__(256 * NCB, NCB) void gemm_tall_kernel(TallArgs a) {
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    for (int t = 0; t < KT; ++t, ++g) {
-      // k-step g has landed (this wave's pieces: one k-step is in flight, plus the previous tile's stores, which retire within ~1 us of
-      // their issue); the barrier makes every wave's pieces visible AND says every wave has finished reading the other stage
+    for (int t = 0; t < KT; ++t) {
       [[maybe_unused]] const unsigned long long tw = TALL_NOW();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       TALL_ADD(3, TALL_NOW() - tw);
-      const bool req = more;               // (uniform)
-      if (req) {
-        if (need_setup) { dma_setup(tall_decode(a, Td)); need_setup = false; }
-        issue_begin(ktd, (g + 1) & 1);
-        more = dma_advance();
-      }
-      const char* sb = smem + (g & 1) * STAGE;
-      auto kslice = [&](auto KS) __attribute__((always_inline)) {
-        constexpr int ks = decltype(KS)::value;
+      const char* sb = smem + st * STAGE;
+      st = st == NST - 1 ? 0 : st + 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        // (one k-half at a time: the scheduler would otherwise hoist all 24 fragment reads of the k-step in front of the first MFMA)
+        if (ks == 2) __builtin_amdgcn_sched_barrier(0);
         const int cc = (ks >> 1) * 512 + ((ks & 1) ? c1 : c0);
         bf16x8 af[4], wf[2];
 #pragma unroll
@@ -228,19 +219,12 @@ __global__ __launch_bounds__(256 * NCB, NCB) void gemm_tall_kernel(TallArgs a) {
             else
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
           }
-        // this slice's share of the next k-step's requests, pinned behind its MFMAs (sched_barrier: neither hoisted nor sunk)
-        __builtin_amdgcn_sched_barrier(0);
-        if (req) issue_part(KS);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      kslice(std::integral_constant<int, 0>{}); kslice(std::integral_constant<int, 1>{});
-      kslice(std::integral_constant<int, 2>{}); kslice(std::integral_constant<int, 3>{});
+      }
     }
     // ---- epilogue: D[i][j] with i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> m, j = lane & 31 -> n: one store = 2 rows x 128 B
     [[maybe_unused]] const unsigned long long te = TALL_NOW();
     {
-      const int cb = tc.cg * NCB + wq;
-      const int bi = cb / a.nt, nb = cb - bi * a.nt;
+      const int bi = tc.cg / a.nt, nb = tc.cg - bi * a.nt;
       const long ocb = (long)tc.bo * a.sc_bo + (long)bi * a.sc_bi;
       const float* bias = a.bias ? a.bias + (long)tc.bo * a.sbias_bo + (long)bi * a.sbias_bi : nullptr;
       const int nbase = nb * TBN + wn * 64 + r31, mbase = tc.m0 + wm * 128 + 4 * hh;
@@ -287,8 +271,6 @@ __global__ __launch_bounds__(256 * NCB, NCB) void gemm_tall_kernel(TallArgs a) {
     }
     TALL_ADD(2, TALL_NOW() - te);
     TALL_ADD(4, 1);
-    Tc = tall_next(a, Tc + gridDim.x);
-    if (Tc >= a.tiles) break;
   }
   TALL_STAMP(1);
 }
@@ -296,8 +278,12 @@ __global__ __launch_bounds__(256 * NCB, NCB) void gemm_tall_kernel(TallArgs a) {
 }  // namespace
 
 bool gemm_tall_ok(const GemmDesc& d) {
-  static const bool off = getenv("MIMRL_NO_GEMM_TALL") != nullptr;   // tuning knob: the 128x128 register-staged kernels as before
-  static const long min_m = getenv("MIMRL_GEMM_TALL_MIN_M") ? atol(getenv("MIMRL_GEMM_TALL_MIN_M")) : 16384;
+  // tuning knobs, read per call (a handful of launches per captured step) so that one test process can run both paths:
+  // MIMRL_NO_GEMM_TALL=1 the 128x128 register-staged kernels as before; MIMRL_GEMM_TALL_MIN_M=<rows> the row threshold (default 16384)
+  const char* e_off = getenv("MIMRL_NO_GEMM_TALL");
+  const bool off = e_off != nullptr && e_off[0] != '0';
+  const char* e_min = getenv("MIMRL_GEMM_TALL_MIN_M");
+  const long min_m = e_min ? atol(e_min) : 16384;
   if (off || !d.a_bf16 || !d.b_bf16 || d.M < min_m) return false;
   if (d.sa_k != 1 || d.sb_k != 1 || d.sc_n != 1) return false;
   if (d.K % TBK != 0 || d.K <= 0 || d.N < 32) return false;
@@ -337,9 +323,7 @@ int gemm_tall(hipStream_t s, const GemmDesc& d) {
     a.sa_bo[0] = d.sa_b; a.sw_bo[0] = d.sb_b; a.sa_bo[1] = d.sa2_b; a.sw_bo[1] = d.sb2_b;
     a.sc_bi = 0; a.sc_bo = d.sc_b; a.sbias_bi = 0; a.sbias_bo = d.bias_n_b;
   }
-  const int ncb_total = a.nt * a.nbi;                 // column blocks that share one row block of A
-  const int ncb = ncb_total % 2 == 0 ? 2 : 1;         // 256 x 256 tiles when they pair up
-  a.ncg = ncb_total / ncb;
+  a.ncg = a.nt * a.nbi;                               // column blocks (inner batch entry, 128 columns) that share one row block of A
   const long rbs = (long)a.mt * a.nbo;
   a.tiles = ((rbs + 7) / 8) * 8 * a.ncg;
   static int cus = 0;
@@ -350,22 +334,15 @@ int gemm_tall(hipStream_t s, const GemmDesc& d) {
   }
   // persistent: one workgroup per CU; a multiple of 8 keeps (tile id % 8) = (workgroup id % 8) = one XCD per workgroup
   const unsigned grid = (unsigned)(a.tiles < cus ? a.tiles : cus);
-  const int lds1 = 2 * (TA_BYTES + TW_BYTES), lds2 = 2 * (TA_BYTES + 2 * TW_BYTES);
+  const int lds = 3 * (TA_BYTES + TW_BYTES);          // 144 KiB: one workgroup per CU
   static bool attr = false;
   if (!attr) {
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr = true;
   }
-  if (ncb == 2) {
-    if (d.f16) hipLaunchKernelGGL((gemm_tall_kernel<true, 2>), dim3(grid), dim3(512), lds2, s, a);
-    else hipLaunchKernelGGL((gemm_tall_kernel<false, 2>), dim3(grid), dim3(512), lds2, s, a);
-  } else {
-    if (d.f16) hipLaunchKernelGGL((gemm_tall_kernel<true, 1>), dim3(grid), dim3(256), lds1, s, a);
-    else hipLaunchKernelGGL((gemm_tall_kernel<false, 1>), dim3(grid), dim3(256), lds1, s, a);
-  }
+  if (d.f16) hipLaunchKernelGGL((gemm_tall_kernel<true>), dim3(grid), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((gemm_tall_kernel<false>), dim3(grid), dim3(512), lds, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

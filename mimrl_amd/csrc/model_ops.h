@@ -44,6 +44,9 @@ struct L0Pack {
   // optional (with pack_weights): 16-bit images of the four LAYER-1 input matrices W_ih_l1 [384, 256], [modality][direction] back to back --
   // fp16 for the forward projection (gemm_fast_f16s_kernel), bf16 for the data-gradient product dh0 (the kernels rounded them at every load)
   const float* w_ih1[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; _Float16* w1h = nullptr; __bf16* w1b = nullptr;
+  // optional (with w1b): the same bf16 values TRANSPOSED and direction-concatenated, w1bt[modality][n = 256][k = direction * 384 + g] -- both
+  // operands of dh0 = sum_dir dgx_dir . W_ih_dir are then k-contiguous (gemm_tall.hip)
+  __bf16* w1bt = nullptr;
   // optional: the packed operands THEMSELVES as 16-bit arrays instead of fp32 (same shapes and indices): xh = fp16 inputs (forward projection),
   // xb = bf16 inputs (the W_ih weight-gradient product, whose other operand is bf16), wh = fp16 weights.  All three or none; xpack / wpack are
   // then not written.

@@ -813,6 +813,12 @@ __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
         bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
         *reinterpret_cast<f16x4*>(a.w1h + o) = h;
         *reinterpret_cast<bf16x4*>(a.w1b + o) = b;
+        if (a.w1bt) {   // transposed bf16 image [modality][n = 256][k = direction * 384 + g]: the k-contiguous B operand of the tall dh0 product
+          const int gg = (int)((q * 4) >> 8), n0 = (int)((q * 4) & 255);
+          __bf16* t = a.w1bt + (long)m * 256 * 768 + (long)n0 * 768 + dir * 384 + gg;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e * 768] = b[e];
+        }
       }
     }
     return;
@@ -826,6 +832,12 @@ __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
       bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
       *reinterpret_cast<f16x4*>(a.w1h + o) = h;
       *reinterpret_cast<bf16x4*>(a.w1b + o) = b;
+      if (a.w1bt) {
+        const int gg = (int)((q * 4) >> 8), n0 = (int)((q * 4) & 255);
+        __bf16* t = a.w1bt + (long)m * 256 * 768 + (long)n0 * 768 + dir * 384 + gg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e * 768] = b[e];
+      }
     } else if (i < nx) {
       const long r = i / a.KP; const int c = (int)(i - r * a.KP);
       a.xpack[(long)m * a.rows * a.KP + i] = c < d ? a.x[m][r * d + c] : 0.f;

@@ -433,6 +433,21 @@ def test_16bit_stored_projection_operands_change_nothing(name, T_, monkeypatch):
 
 @pytest.mark.parametrize("name,T_,margin,gxh", ENC, ids=[f"{n}{'' if t is None else '-T' + str(t)}{'' if mg else '-full'}{'-gxf16' if gh else ''}" for n, t, mg, gh in ENC])
 def test_encoders_vs_rounded_oracle(name, T_, margin, gxh, monkeypatch):
+    _encoders_case(name, T_, margin, gxh, monkeypatch)
+
+
+@pytest.mark.parametrize("name,T_,gxh", [("cfg2_sep", None, False), ("cfg2_ragged", 49, False), ("cfg2_ragged", None, True)])
+def test_encoders_through_the_tall_gemm_kernel(name, T_, gxh, monkeypatch):
+    """Round 5: the layer-1 input projection and the dh0 data gradient of long sequences (B * T >= 16384 rows: cfg3 / cfg5) run on the LDS-DMA
+    kernel of csrc/gemm_tall.hip (256 x 128 tiles, 16-bit stored k-contiguous operands; dh0 reads the transposed, direction-concatenated bf16
+    image of W_ih_l1).  MIMRL_GEMM_TALL_MIN_M lowers the row threshold so that the cfg2-shaped encoder parity cases -- every W_t / rnn_* / ln_*
+    gradient against the rounded-operand float64 oracle, same bands -- exercise that path too (ragged rows: B * T = 6272 is not a multiple of
+    the 256-row tile; fp16-stored gx)."""
+    monkeypatch.setenv("MIMRL_GEMM_TALL_MIN_M", "1024")
+    _encoders_case(name, T_, True, gxh, monkeypatch, tag="-tall")
+
+
+def _encoders_case(name, T_, margin, gxh, monkeypatch, tag=""):
     """The recurrence kernels of the benchmarked mode -- gru_bwd_kernel<bf16, bf16 dg> is the largest kernel of the step, gru_fwd_kernel<bf16>
     the fourth -- with the fp16 input projections, LayerNorm / ReLU and every weight-gradient GEMM around them, driven through
     mimrl_probe_encoders (the step's own code path) on a fixture batch, against float64 autograd of the oracle (Model.py:395-466; nn.GRU on
@@ -482,7 +497,7 @@ def test_encoders_vs_rounded_oracle(name, T_, margin, gxh, monkeypatch):
 
     ref, gr = reference(Q.F16_FWD, Q.r_bf16)
     exact, gx = reference(Q.EXACT, Q.identity)              # the un-rounded oracle: how far the 16-bit mode is from fp32 / fp64
-    key = f"encoders/{name}{'' if T_ is None else '-T' + str(T_)}{'' if margin else '-full'}{'-gxf16' if gxh else ''}"
+    key = f"encoders/{name}{'' if T_ is None else '-T' + str(T_)}{'' if margin else '-full'}{'-gxf16' if gxh else ''}{tag}"
     rec = {"cube_x": errs(x.cpu(), ref), "cube_x_vs_unrounded_oracle": errs(x.cpu(), exact)}
     worst = ("", 0.0)
     for n, gw, ge in zip(names, gr, gx):
