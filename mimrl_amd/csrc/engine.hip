@@ -3394,7 +3394,8 @@ int mimrl_op_gemm16(void* stream, const void* A, const void* B, void* C, int M, 
   if (batch_in > 0) { d.batch_in = batch_in; d.sa_bo = st_bo[0]; d.sb_bo = st_bo[1]; d.sc_bo = st_bo[2]; d.bias_n_bo = st_bo[3]; }
   if (st_bo) d.bias_n_b = st_bo[4];
   d.bias_n = bias_n;
-  d.a_bf16 = flags & 1; d.b_bf16 = (flags >> 1) & 1; d.f16 = (flags >> 2) & 1; d.c_f16 = (flags >> 3) & 1;
+  d.a_bf16 = flags & 1; d.b_bf16 = (flags >> 1) & 1; d.f16 = (flags >> 2) & 1; d.c_f16 = (flags >> 3) & 1; d.atomic = (flags >> 4) & 1;
+  if (flags >> 8) { d.a_gap_at = (flags >> 8) & 0xfff; d.a_gap_rows = (flags >> 20) & 0xfff; }
   return gemm(reinterpret_cast<hipStream_t>(stream), d, true);
 }
 

@@ -962,6 +962,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (d.batch_in > 0 && (d.A2 || d.bias_m || d.colsum || d.batch % d.batch_in != 0))
     return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   if (bf16 && gemm_tall_ok(d)) return gemm_tall(s, d);   // tall 16-bit-stored (KC, KC) products: the LDS-DMA kernel of gemm_tall.hip
+  if (bf16 && gemm_tall_tn_ok(d)) return gemm_tall_tn(s, d);   // ... and tall reductions (weight gradients over B*T rows)
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
   static const bool trace = getenv("MIMRL_GEMM_TRACE") != nullptr;   // diagnostic: which products miss the fast path, and why

@@ -604,3 +604,28 @@ def test_gemm_tall_two_segments(lib):
     ref = torch.einsum("mdrk,mndk->mrn", a[..., :K].double(), w.double().reshape(2, N, 2, K))
     err = (out.double() - ref).abs().max().item()
     assert err <= 2e-6 * 2 * K + 1e-5, f"two-segment tall product: max |err| {err}"
+
+
+@pytest.mark.parametrize("M,N,K,gap,shared_b", [(384, 128, 20000 + 17, True, False), (384, 256, 16384 + 32 * 5, False, True), (384, 80, 16400, False, True),
+                                                 (256, 256, 16384, False, False)])
+def test_gemm_tall_weight_gradient_shape(lib, M, N, K, gap, shared_b, monkeypatch):
+    """csrc/gemm_tall.hip, reduction form (round 5; opt-in with MIMRL_GEMM_TALL_TN=1, it ties the split-K kernel it would replace): C[M, N] += A^T B over K = B*T rows with A [K, 512] / B [K, N] stored bf16 and
+    row-contiguous -- dW_hh = dgh^T h_prev (A rows [0, 256) u [384, 512) of dg: the gap) and dW_ih = dgx^T x (both directions share B) of
+    Model.py:254-255's autograd; batch = (modality, direction); K not a multiple of the 32-row k-step (zero page), N = 80 (the packed
+    layer-0 inputs).  Reference: float64 product of the same bf16 operands; the output is accumulated with float atomics over the k-split."""
+    monkeypatch.setenv("MIMRL_GEMM_TALL_TN", "1")
+    g = np.random.default_rng(M + N + K)
+    a = torch.from_numpy(g.standard_normal((2, 2, K, 512)).astype(np.float32)).to(torch.bfloat16).cuda()       # [modality][direction][K, 512]
+    nbm = 1 if shared_b else 2
+    b = torch.from_numpy(g.standard_normal((2, nbm, K, N)).astype(np.float32) * 0.1).to(torch.bfloat16).cuda()
+    out = torch.zeros(2, 2, M, N, device="cuda")
+    flags = 3 | 16 | ((256 << 8) | (128 << 20) if gap else 0)
+    _gemm16(lib, a, b, out, M, N, K, 4, (1, 512, K * 512, N, 1, 0 if shared_b else K * N, N, 1, M * N), flags, batch_in=2,
+            st_bo=(2 * K * 512, nbm * K * N, 2 * M * N, 0, 0))
+    cols = np.r_[0:256, 384:512] if gap else np.r_[0:M]
+    ad = a.double()[..., cols]
+    bd = b.double().expand(2, 2, K, N) if shared_b else b.double()
+    ref = torch.einsum("mdkr,mdkn->mdrn", ad, bd)
+    err = (out.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 3e-6 * scale + 1e-4, f"tall TN {M}x{N}x{K}: max |err| {err} (scale {scale})"

@@ -60,9 +60,10 @@ def run16(name, M, N, K, batch, st, a_shape, w_shape, c_shape, flags, batch_in=0
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     flops = 2.0 * M * N * (K + K2) * batch
-    byts = A.numel() * 2 * (K + K2) / A.shape[-1] + W.numel() * 2 + Cm.numel() * Cm.element_size()
+    byts = A.numel() * 2 * (M if flags & 16 else K) / A.shape[-1] + W.numel() * 2 + Cm.numel() * Cm.element_size()
     print(f"{name:58s} {us:8.1f} us  {flops/us/1e6:8.1f} TF/s  {byts/us/1e6:6.2f} TB/s")
 
+os.environ.setdefault("MIMRL_GEMM_TALL_TN", "1")   # (opt-in kernel: time it here; MIMRL_GEMM_TALL_TN=0 for the split-K kernel)
 for tall in ("1", "0"):
     if tall == "0":
         if os.environ.get("MIMRL_NO_GEMM_TALL"): break
@@ -73,5 +74,9 @@ for tall in ("1", "0"):
           batch_in=2, st_bo=(BT3*256, 2*384*256, 2*BT3*384, 2*384, 384), bias=True)
     run16("cfg3 dh0 bf16 (KC,KC): 128000x256x(384+384) x2 mod", BT3, 256, 384, 2, (512,1,2*BT3*512, 1,768,256*768, 256,1,BT3*256), (2,2,BT3,512), (2,256,768), (2,BT3,256), 3,
           K2=384, st2=(512,1,2*BT3*512, 1,768,256*768), a2=lambda A: A[:, 1], w2=lambda W: W[:, :, 384:])
+    run16("cfg3 dW_ih l1 TN bf16: 384x256x128000 x(2x2), shared B", 384, 256, BT3, 4, (1,512,BT3*512, 256,1,0, 256,1,384*256), (2,2,BT3,512), (2,BT3,256), (2,2,384,256), 3 | 16,
+          batch_in=2, st_bo=(2*BT3*512, BT3*256, 2*384*256, 0, 0))
+    run16("cfg3 dW_hh l1 TN bf16 (gap): 384x128x128000 x(2x2)", 384, 128, BT3, 4, (1,512,BT3*512, 128,1,BT3*128, 128,1,384*128), (2,2,BT3,512), (2,2,BT3,128), (2,2,384,128), 3 | 16 | (256 << 8) | (128 << 20),
+          batch_in=2, st_bo=(2*BT3*512, 2*BT3*128, 2*384*128, 0, 0))
     run16("cfg2 gx l1 f16s: 6400x384x256 x4 (below the tall threshold)", BT, 384, 256, 4, (256,1,0, 1,256,384*256, 384,1,BT*384), (2,BT,256), (2,2,384,256), (2,2,BT,384), 7,
           batch_in=2, st_bo=(BT*256, 2*384*256, 2*BT*384, 2*384, 384), bias=True, iters=50)

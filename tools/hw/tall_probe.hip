@@ -70,11 +70,46 @@ static int run(const char* name, int M, int N, int K, int K2, int lda, int nmod,
   return 0;
 }
 
+static int run_tn(const char* name, int M, int N, int K, int gap, bool shared_b) {
+  const int nb = 4;
+  size_t na = (size_t)nb * K * 512, nbel = (size_t)(shared_b ? 2 : 4) * K * N, nc = (size_t)nb * M * N;
+  unsigned short *A, *Bm; float* Cm;
+  CK(hipMalloc(&A, na * 2)); CK(hipMalloc(&Bm, nbel * 2)); CK(hipMalloc(&Cm, nc * 4));
+  { std::vector<unsigned short> h(na); unsigned x = 12345; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3e00 | ((x >> 9) & 0x83ff)); } CK(hipMemcpy(A, h.data(), na * 2, hipMemcpyHostToDevice)); }
+  { std::vector<unsigned short> h(nbel); unsigned x = 777; for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3d00 | ((x >> 9) & 0x83ff)); } CK(hipMemcpy(Bm, h.data(), nbel * 2, hipMemcpyHostToDevice)); }
+  CK(hipMemset(Cm, 0, nc * 4));
+  GemmDesc d;
+  d.A = (const float*)A; d.B = (const float*)Bm; d.C = Cm; d.M = M; d.N = N; d.K = K;
+  d.sa_m = 1; d.sa_k = 512; d.sb_k = N; d.sb_n = 1; d.sc_m = N; d.sc_n = 1;
+  d.a_bf16 = d.b_bf16 = 1; d.atomic = 1;
+  d.batch = 4; d.batch_in = 2; d.sa_b = (long)K * 512; d.sa_bo = 2L * K * 512; d.sb_b = shared_b ? 0 : (long)K * N; d.sb_bo = (shared_b ? 1L : 2L) * K * N;
+  d.sc_b = (long)M * N; d.sc_bo = 2L * M * N;
+  if (gap) { d.a_gap_at = 256; d.a_gap_rows = gap; }
+  if (!gemm_tall_tn_ok(d)) { printf("%s: not eligible\n", name); return 1; }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) if (gemm_tall_tn(0, d)) { printf("launch failed\n"); return 1; }
+  CK(hipEventRecord(e0, 0));
+  const int iters = 20;
+  for (int i = 0; i < iters; ++i) gemm_tall_tn(0, d);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / iters, fl = 2.0 * M * N * (double)K * nb;
+  const double bytes = (double)nb * K * M * 2 + nbel * 2.0;
+  printf("%-44s %8.1f us  %7.1f TF/s  %5.2f TB/s (operands once)\n", name, us, fl / us / 1e6, bytes / us / 1e6);
+  (void)hipFree(A); (void)hipFree(Bm); (void)hipFree(Cm);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int BT3 = 128000;
   const int dbg = argc > 1 ? atoi(argv[1]) : 0;
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_tall_dbg), &dbg, sizeof dbg));
   printf("ablation mask %d (1 no A, 2 no W, 4 no MFMA, 8 A nt, 16 no stores, 32 W nt)\n", dbg);
+  if (argc > 2) {
+    if (run_tn("dW_ih l1 TN: 384x256x128000 x4, shared B", 384, 256, BT3, 0, true)) return 1;
+    if (run_tn("dW_hh l1 TN (gap): 384x128x128000 x4", 384, 128, BT3, 128, false)) return 1;
+    return 0;
+  }
   if (run("gx l1 (f16, fp32 out): 128000x384x256 x2x2", BT3, 384, 256, 0, 256, 2, 2, true, false, true)) return 1;
   if (run("gx l1 (f16, fp16 out)", BT3, 384, 256, 0, 256, 2, 2, true, true, true)) return 1;
   if (run("dh0 (bf16): 128000x256x(384+384) x2", BT3, 256, 384, 384, 512, 2, 1, false, false, false)) return 1;
