@@ -67,6 +67,9 @@ long gru_saved_floats(int B, int T);
 // batch rows per workgroup (<= 4): the kernels are bound by the per-step instruction latency of one wave, so the batch
 // is spread over as many CUs as possible
 int gru_pick_btv(int B, int nmod);
+#ifdef MIMRL_PHASE_PROBE
+int gru_bwd_read_phases(long long* out);   // 2 layers x 16 slots, see gru.hip
+#endif
 void gru_probe_setup();   // `make PHASE_PROBE=1` builds: reads MIMRL_GRU_SKIP (gru.hip); a no-op otherwise
 
 }  // namespace mimrl

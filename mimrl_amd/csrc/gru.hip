@@ -213,6 +213,24 @@ __device__ __forceinline__ void stamp_end(const KernelStamp& k) {
 //  the kernel it was meant to explain.)
 #define GSKIP(bit) ((SKIP & (bit)) != 0)
 
+// `make PHASE_PROBE=1` builds only (tools/gru_bwd_phase.py, round 5): a cycle budget of the BPTT cell step from in-kernel stamps.  Phase
+// elimination (above) does not work for this kernel -- removing a phase changes the register allocation around the explicit-wait loads and
+// the table comes out non-monotone (profiles/r04_gru_phase.json).  Wave 0 of workgroup (0, 0, 0) reads the shader clock (s_memtime) at the
+// phase boundaries of every cell step and sums the differences; the values are consumed at the END of the step only (an s_memtime result
+// is waited for with lgkmcnt(0), which in the middle of the step would also wait for the LDS traffic it is meant to time).
+// slots per layer (16): 0 operand wait, 1 gate / gradient math + LDS tile writes, 2 five global stores issued, 3 lgkmcnt(0) + s_barrier,
+// 4 three prefetches issued, 5 twelve fragment reads returned, 6 24 MFMAs retired, 7 steps, 8 / 9 wall clock (100 MHz) at entry / exit
+#ifdef MIMRL_PHASE_PROBE
+__device__ long long g_gru_bwd_phase[32];
+#define GPH_DECL unsigned long long gph_t[8]; long long gph_s[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GPH(i) gph_t[i] = __builtin_amdgcn_s_memtime()
+#define GPH_SUM() do { _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_) gph_s[i_] += (long long)(gph_t[i_ + 1] - gph_t[i_]); gph_s[7] += 1; } while (0)
+#else
+#define GPH_DECL
+#define GPH(i) do { } while (0)
+#define GPH_SUM() do { } while (0)
+#endif
+
 #ifndef GRU_BF16_MINB
 #define GRU_BF16_MINB 2   // -DGRU_BF16_MINB=1: the AGPR-using build of the reproducibility hunt, debugging only
 #endif
@@ -480,6 +498,10 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   using F = typename Pack<UPL>::F;
   using GR = typename Pack<UPL>::G;
   stamp_begin(a.stamp);
+  GPH_DECL;
+#ifdef MIMRL_PHASE_PROBE
+  const long long gph_w0 = (long long)wall_clock64();
+#endif
   __shared__ __attribute__((aligned(16))) Tile<BF16, G> ds[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.x, dir = blockIdx.y, mod = blockIdx.z;
@@ -520,6 +542,10 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   const long dg_o = bb * (long)T * 4 * H + u0, hp_o = bb * (long)T * H + u0;   // element offsets (fp32 or bf16 elements: DGBF)
   const float* sv_b = q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane);
   const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
+  // per-lane output bases in registers: with `q.dg` / `q.hprev` named inside the loop the compiler re-read them from the kernel arguments
+  // on EVERY cell step (s_load_dwordx4 + s_waitcnt lgkmcnt(0) in front of the five stores: round-5 stamp budget)
+  float* dg_lane = q.dg; float* hp_lane = q.hprev;
+  asm volatile("" : "+v"(dg_lane), "+v"(hp_lane));
 
   // software pipeline, distance 2 (see gru_fwd_kernel): every load is unconditional and in bounds (padded steps read
   // stale-but-initialised records and are masked in the math).  h_prev is the previous VALID output of this direction;
@@ -553,10 +579,12 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     // forward visited t in order (dir ? T-1..0 : 0..T-1); backward walks it the other way round
     const int t = dir ? step : T - 1 - step;
     const bool valid = t < len;
+    GPH(0);
     if constexpr (BF16) {
       vm_wait<decltype(wait)::value>(nx.graw, nx.DO, nx.HP);
       decode_gates<UPL>(nx.graw, nx.g);
     }
+    GPH(1);
     const Ops& op = nx;
     float dhz[UPL], drp[UPL], dzp[UPL], dnp[UPL], dnr[UPL], hp[UPL];
     const int tprev = dir ? t + 1 : t - 1;
@@ -587,18 +615,26 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     }
 #pragma unroll
     for (int e = 0; e < UPL; ++e) { sb[0][e] += drp[e]; sb[1][e] += dzp[e]; sb[2][e] += dnp[e]; sb[3][e] += dnr[e]; }
+#ifdef MIMRL_PHASE_PROBE
+    asm volatile("" : "+v"(sb[0][0]), "+v"(sb[3][UPL - 1]), "+v"(dhz[0]));   // (the math has been ISSUED up to here)
+#endif
+    GPH(2);
     // (probe builds: the skipped stores / loads are replaced by the same NUMBER of cheap operations on one cache line, so that the
     //  explicit wait counts stay exact)
     constexpr bool sk4 = GSKIP(4), sk8 = GSKIP(8);
-    stuo<DGBF, UPL>(q.hprev, sk4 ? hp_o : hp_o + (long)t * H, hp);
+    stuo<DGBF, UPL>(hp_lane, sk4 ? hp_o : hp_o + (long)t * H, hp);
     const long dgt = sk4 ? dg_o : dg_o + (long)t * 4 * H;
-    stuo<DGBF, UPL>(q.dg, dgt + 0 * H, drp);
-    stuo<DGBF, UPL>(q.dg, dgt + (sk4 ? 0 : 1) * H, dzp);
-    stuo<DGBF, UPL>(q.dg, dgt + (sk4 ? 0 : 2) * H, dnp);
-    stuo<DGBF, UPL>(q.dg, dgt + (sk4 ? 0 : 3) * H, dnr);
+    stuo<DGBF, UPL>(dg_lane, dgt + 0 * H, drp);
+    stuo<DGBF, UPL>(dg_lane, dgt + (sk4 ? 0 : 1) * H, dzp);
+    stuo<DGBF, UPL>(dg_lane, dgt + (sk4 ? 0 : 2) * H, dnp);
+    stuo<DGBF, UPL>(dg_lane, dgt + (sk4 ? 0 : 3) * H, dnr);
+    asm volatile("" ::: "memory");
+    GPH(3);
     if constexpr (!GSKIP(16)) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GPH(4);
     if constexpr (decltype(pf)::value) fetch(nx, sk8 ? 0 : step + 2);   // behind the barrier: the old operands are dead (see gru_fwd_kernel)
     asm volatile("" ::: "memory");
+    GPH(5);
     f32x4 acc[UPL];
 #pragma unroll
     for (int s = 0; s < UPL; ++s) acc[s] = f32x4{dhz[s], 0.f, 0.f, 0.f};   // only register 0 is read
@@ -616,6 +652,11 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
       for (int ks = 0; ks < C::KS_B; ++ks) sf[ks] = wr[0][ks];
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef MIMRL_PHASE_PROBE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the twelve fragments are in registers)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      GPH(6);
       if constexpr (!GSKIP(1)) {
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks)
@@ -635,8 +676,26 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     }
 #pragma unroll
     for (int s = 0; s < UPL; ++s) carry[s] = acc[s][0];
+#ifdef MIMRL_PHASE_PROBE
+    if constexpr (BF16) {
+      asm volatile("v_mov_b32 %0, %0\n\ts_nop 0" : "+v"(carry[0]), "+v"(carry[UPL - 1]));   // (issues only once the last MFMA has retired)
+      __builtin_amdgcn_sched_barrier(0);
+      GPH(7);
+      GPH_SUM();
+    }
+#endif
     // ds[cur] is rewritten two steps from now; the barrier of the next step orders that write after these reads
   };
+  // Round 5, measured and NOT kept: the cell step re-cut around its dependent chain (carry -> dh -> five products -> tile -> barrier ->
+  // fragments -> MFMAs), with everything else -- decode, the gate derivatives folded into per-unit coefficients one step ahead, the five
+  // stores, bias sums, prefetch and operand wait -- moved behind the barrier / into the shadow of the 24 MFMAs.  The compiler interleaved
+  // it as intended (stores and coefficient math between the products) and the bare chain alone runs at 0.52 us per step (26 us per launch
+  // with the stores, prefetch and coefficients compiled out), but the full kernel took 46.2 us against 44.4 (three alternating runs):
+  // one wave per SIMD issues every instruction of the step itself, the "shadow" work still takes its issue slots (an MFMA frees 8 of its
+  // 16 cycles), and the coefficient form costs ~20 more VALU instructions than the direct one.  A second, mask-free copy of the loop for
+  // full-length batches made the compiler re-home in-flight operand registers (tools/isa_inflight.py caught it before a GPU test did).
+  // What the stamp budget (tools/gru_bwd_phase.py, profiles/r05_gru_bwd_phase.json) did give: the store phase contained a kernel-argument
+  // reload -- s_load_dwordx4 + lgkmcnt(0) for q.hprev / q.dg on every step; the per-lane store bases now live in registers.
   // An ODD T runs one un-pipelined step FIRST (operands fetched, waited for with vmcnt(0), no prefetch), then the even remainder through
   // the pipeline -- never a single step BEHIND the loop.  Round 3 had that tail, and in its code the compiler re-homed the loop-carried
   // operand registers with v_mov copies placed IN FRONT of the explicit wait, i.e. it copied the destination of an asm load that was still
@@ -692,10 +751,22 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
       }
     }
   }
+#ifdef MIMRL_PHASE_PROBE
+  if (BF16 && DGBF && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    const int o = a.dout_off == 0 ? 0 : 16;      // layer 1 (dout = [B, T, H] slices) / layer 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_gru_bwd_phase[o + i] = gph_s[i];
+    g_gru_bwd_phase[o + 8] = gph_w0; g_gru_bwd_phase[o + 9] = (long long)wall_clock64();
+  }
+#endif
   stamp_end(a.stamp);
 }
 
 }  // namespace
+
+#ifdef MIMRL_PHASE_PROBE
+int gru_bwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gru_bwd_phase), sizeof(long long) * 32) == hipSuccess ? 0 : 1; }
+#endif
 
 // waves per workgroup of the bf16 recurrence kernels: 4 (two units per lane); MIMRL_GRU_WAVES=8: one unit per lane, two waves per SIMD.
 // Round 4 measured both at cfg2 (interleaved runs, in-graph launch stamps): forward 28.7 (8 waves) vs 30.0 us (4), BPTT 47.6 vs 44.0 us,

@@ -38,7 +38,7 @@ def test_bf16_recurrence_kernels_are_agpr_free(ks):
     for name, v in ks.items():
         if name.startswith(("gru_fwd_kernel<true", "gru_bwd_kernel<true")):
             assert v["agpr_count"] == 0, (name, v)
-            assert v["vgpr_count"] <= 224 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
+            assert v["vgpr_count"] <= 240 and v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
             assert v["max_flat_workgroup_size"] == (512 if ", 1, 0" in name else 256), (name, v)      # 8-wave variants (one unit per lane): 512
 
 

@@ -26,6 +26,10 @@ import codeobj_meta as cm  # noqa: E402
 VMEM = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load", "flat_store", "flat_atomic",
         "scratch_load", "scratch_store")
 LOADS = ("global_load", "buffer_load", "flat_load", "scratch_load")
+# LDS-DMA (global_load_lds_* / buffer_load ... lds, round 5: gemm_tall.hip): the data lands in LDS, there is NO register destination -- the
+# first operand is the ADDRESS, which the hardware has read at issue.  They still count on vmcnt like every other VMEM operation.
+def _is_reg_load(mn, line):
+    return mn.startswith(LOADS) and not mn.startswith("global_load_lds") and " lds" not in line.split("//")[0]
 CAP = 63   # vmcnt is a 6-bit counter: the 64th outstanding operation cannot issue before the oldest has retired
 
 
@@ -81,7 +85,7 @@ def analyse(body, base_addr, ring_excuse=False):
             named |= _regs(t)
         hit = named & set(st)
         origin = {r: st[r][1] for r in hit}
-        if hit and mn.startswith(LOADS) and toks:                 # a second load into a register whose first load is still outstanding is
+        if hit and _is_reg_load(mn, line) and toks:               # a second load into a register whose first load is still outstanding is
             hit -= _regs(toks[0]) - set().union(*[_regs(t) for t in toks[1:]] or [set()])   # fine (in-order return); its ADDRESS must not be in flight
         if hit:
             bad[i] = (addr, line.strip().split("//")[0].strip(), sorted(hit), sorted({origin[r] for r in hit}))
@@ -92,7 +96,7 @@ def analyse(body, base_addr, ring_excuse=False):
                 st = {r: v for r, v in st.items() if v[0] < k}
         if is_vmem:
             st = {r: (v[0] + 1, v[1]) for r, v in st.items() if v[0] + 1 < CAP}
-            if mn.startswith(LOADS) and toks:
+            if _is_reg_load(mn, line) and toks:
                 for r in _regs(toks[0]):
                     st[r] = (0, addr)
         succ = []
