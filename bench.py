@@ -263,16 +263,25 @@ def extra_schedules(eng, args, B, T, rank):
         extra["ms_per_step_sequential"] = timed(eng.step, n_x)
         eng.set_stage2_prefetch(True)
     if not args.no_prefetch:
-        # the launch structure every rank runs at N > 1 (dist.ddp_two_stage_step: per-stage gradient graphs, deferred stage-2
-        # forward tail, separate apply launches), here with world = 1, i.e. WITHOUT the two collectives: what the split costs
+        # The step every rank runs at N > 1 (round 5): the SAME captured two-stage graph with the engine's own RCCL communicator inside it
+        # (dist.attach_comm) -- here a ONE-rank communicator, i.e. the collectives are issued but no byte moves: what data parallelism costs
+        # a rank before communication (split reduce of the main bucket on; packed layer-0 gradients through the unpack kernel)
+        try:
+            if mdist.attach_comm(eng, 1, 0):
+                extra["ms_per_step_ddp_schedule_no_comm"] = timed(eng.step, n_x)
+                extra["ddp_schedule"] = "one captured graph per step, RCCL collectives inside it (one-rank communicator: no bytes moved)"
+                eng.set_comm(None, 1, 0)
+                eng.set_grad_scale(1.0)
+        except Exception as e:   # (RCCL missing on the box: the line still prints)
+            extra["ddp_schedule_error"] = repr(e)[:200]
+        # ... and the round-4 transport (torch.distributed collectives between per-stage graph launches; MIMRL_DDP_TORCH=1), with world = 1
+        # and no collectives: per-stage gradient graphs + separate apply launches, unsplit and split main bucket
         eng.set_stage2_prefetch(mdist.ddp_prefetch_mode(2))
         os.environ["MIMRL_DDP_SPLIT"] = "0"
-        extra["ms_per_step_ddp_schedule_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
-        # ... and the same with the split main-bucket reduce (MIMRL_DDP_SPLIT=1: stage 2 as two launches so that the early piece of the
-        # bucket can travel under the layer-0 BPTT; dist.ddp_stage2_split) -- what the split costs a rank before a byte moves
+        extra["ms_per_step_ddp_torch_transport_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
         os.environ["MIMRL_DDP_SPLIT"] = "1"
         try:
-            extra["ms_per_step_ddp_split_schedule_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
+            extra["ms_per_step_ddp_torch_transport_split_no_comm"] = timed(lambda: mdist.ddp_two_stage_step(eng, 1), n_x)
         finally:
             os.environ.pop("MIMRL_DDP_SPLIT", None)
         eng.set_stage2_prefetch(True)
@@ -351,8 +360,19 @@ def main():
     if use_stamps:
         eng.kernel_stamps(1 << 14)
 
+    # data parallel: the engine's own RCCL communicator -- the collectives become nodes of the captured step graph (dist.attach_comm);
+    # MIMRL_DDP_TORCH=1: the round-4 transport (torch.distributed between per-stage graphs)
+    in_lib = False
+    if world > 1 or os.environ.get("MIMRL_DDP_FORCE_COLLECTIVES") is not None:
+        in_lib = mdist.attach_comm(eng, world, rank)
+        if in_lib:
+            eng.set_stage2_prefetch(0 if args.no_prefetch else 1)
+        log(f"data-parallel transport: {'RCCL inside the library (in-graph)' if in_lib else 'torch.distributed between graph launches'}")
+
     def step():
-        if world > 1 and args.no_prefetch:
+        if in_lib:
+            eng.step()
+        elif world > 1 and args.no_prefetch:
             mdist.ddp_stage_step(eng, 1, world)
             mdist.ddp_stage_step(eng, 2, world)
         elif world > 1:
@@ -385,7 +405,8 @@ def main():
             torch.cuda.synchronize()
             ex["ms_per_step_fp32_parity_mode"] = 1e3 * (time.perf_counter() - t) / n32
             e32.close()
-        print(json.dumps(ex))
+        mdist.flush_c_stdio()
+        print(json.dumps(ex), flush=True)
         return
 
     log("engine ready; warm-up")
@@ -446,7 +467,7 @@ def main():
                "--steps", str(args.steps)] + (["--no-graph"] if args.no_graph else []) + (["--no-prefetch"] if args.no_prefetch else [])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-            extra = json.loads(r.stdout.strip().splitlines()[-1])
+            extra = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])   # (RCCL prints a version banner on stdout)
         except Exception as e:      # noqa: BLE001 -- optional figures only
             extra = {"extras_error": repr(e)[:200]}
         log(f"extra schedules (child process): {extra.get('ms_per_step_sequential')} ms sequential, {extra.get('ms_per_step_fresh_batch')} ms fresh-batch")
@@ -642,7 +663,8 @@ def main():
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "phases": phases, "losses_finite": finite,
             "stage1_loss": float(scal[_lib.S1_LOSS]), "stage2_loss": float(scal[_lib.S2_LOSS]),
         }
-        print(json.dumps(out))
+        mdist.flush_c_stdio()          # (anything RCCL left in the C stdio buffer goes out BEFORE the line)
+        print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIMRL_ABI_VERSION 4
+#define MIMRL_ABI_VERSION 5
 #define MIMRL_MAX_BLOCKS 4
 
 enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -3, MIMRL_ERR_NODEVICE = -4 };
@@ -178,6 +178,18 @@ int mimrl_profile_enable(mimrl_handle* h, int on);     /* forces eager launches 
  * pre-filled with 0xFF; slots a power of two; id 0/1 = forward layer 0/1, 2/3 = BPTT layer 1/0; rng_step = counters[0], +1 per stage).
  * bench.py derives its roofline block from these over the TIMED region.  ring = NULL: off (default).  Drops captured graphs. */
 int mimrl_set_kernel_stamps(mimrl_handle* h, unsigned long long* ring, int slots);
+/* ---- data parallel (ABI v5): RCCL inside the library.  Reference counterpart: nn.DataParallel's gradient reduce (Solver.py:33-35).
+ * One process per GPU, every rank a full replica with its own batch.  mimrl_comm_unique_id (rank 0) fills 128 bytes (ncclUniqueId) that
+ * the caller hands to every rank by its own means (torch.distributed broadcast, MPI, a file); mimrl_set_comm (all ranks, after
+ * mimrl_bind, collective) creates the handle's communicator on the current device.  From then on every update pass of the handle --
+ * mimrl_stage1_step / mimrl_stage2_step / mimrl_two_stage_step, eager or captured -- all-reduces (SUM) the stage's gradient bucket
+ * between the gradient pass and clip + Adam, on the engine's own streams, as part of the same graph; the 1/world of the mean is the
+ * caller's mimrl_set_grad_scale.  The main bucket travels in two pieces: floats [0, mimrl_main_late_offset) under the layer-0 BPTT,
+ * the layer-0 recurrence tensors behind it (MIMRL_DDP_SPLIT=0: one piece).  world = 1 is a valid (one-rank) communicator.
+ * unique_id = NULL removes the communicator.  librccl.so.1 is dlopen'ed on first use; single-GPU runs never load it. */
+int mimrl_comm_unique_id(void* out128);
+int mimrl_set_comm(mimrl_handle* h, const void* unique_id128, int world, int rank);
+int64_t mimrl_main_late_offset(const mimrl_handle* h);
 int mimrl_profile_read(mimrl_handle* h, float* ms_sum /*[MIMRL_NPHASES]*/, int32_t* launches /*[MIMRL_NPHASES]*/);  /* syncs; resets */
 /* GEMM family of the eager steps since the last read: out = {algorithmic FLOPs, algorithmic bytes (operands and output once),
  * summed launch durations in ms (HIP events on each launch's own stream), launches}; syncs; resets */

@@ -23,6 +23,7 @@
 #include "gru.h"
 #include "lstm.h"
 #include "layout.h"
+#include "comm.h"
 #include "model_ops.h"
 
 namespace mimrl {
@@ -303,6 +304,13 @@ struct mimrl_handle {
   bool tail2_needed = false;           // deferred tail still to be issued before stage 2 may run
   bool fwd2_pending = false;           // a prefetched stage-2 forward is waiting to be consumed
   float grad_scale = 1.f;              // folded into the fused clip+Adam (mimrl_set_grad_scale)
+  // data parallel (round 5): an RCCL communicator of this handle's own (mimrl_set_comm).  With it every update pass of the handle --
+  // mimrl_stage{1,2}_step, mimrl_two_stage_step, captured or not -- all-reduces (SUM) the stage's gradient bucket between the gradient
+  // pass and the fused clip + Adam, on the engine's own streams: the collectives are nodes of the captured step graph, and the main
+  // bucket travels in two pieces -- [0, late_offset) on `comm_s` under the layer-0 BPTT, the layer-0 tail behind it.
+  void* comm = nullptr; int comm_world = 1, comm_rank = 0;
+  hipStream_t comm_s = nullptr;
+  bool comm_split = true;              // MIMRL_DDP_SPLIT=0: the main bucket in one piece behind the whole backward pass
   KernelStamp kstamp;                  // launch stamps of the recurrence kernels (mimrl_set_kernel_stamps); id: 0/1 forward layer 0/1, 2/3 BPTT layer 1/0
 
   int run_fwd2_tail();
@@ -391,6 +399,14 @@ struct mimrl_handle {
     HIPX(hipStreamWaitEvent(S(i), e, 0));
     return MIMRL_OK;
   }
+  // all-reduce of a stage's whole gradient bucket on `stream` (no communicator: nothing)
+  int reduce_bucket(int stage) {
+    if (!comm) return MIMRL_OK;
+    Range rg(stage == 1 ? "mimrl.stage1.allreduce(crit_g) [RCCL]" : "mimrl.stage2.allreduce(main_g) [RCCL]");
+    return comm_allreduce_sum(comm, stage == 1 ? bufs.crit_g : bufs.main_g, (size_t)layout.floats[stage == 1 ? MIMRL_GROUP_CRITIC : MIMRL_GROUP_MAIN], stream);
+  }
+  // stage 2 with a communicator: the gradient pass in two parts with the early range of the main bucket in flight under the second
+  int enqueue_grads2_reduced(bool skip_zero);
   // GEMM family accounting of the phase profiler: HIP events on the launch stream around every gemm() of an eager step,
   // with the algorithmic FLOPs / bytes of the launch (operands and output counted once)
   struct GemmProf { hipEvent_t a, b; double flops, bytes; };
@@ -2660,6 +2676,41 @@ int mimrl_handle::enqueue_apply(int stage) {
   return dbg_delay(stream, 12);
 }
 
+// Stage-2 gradient pass under data parallelism (reference counterpart: nn.DataParallel reduces AFTER backward, Solver.py:33-35; north_star:
+// "all-reduce ... overlapped with the other stage's backward"): everything but the layer-0 recurrence gradients is final behind part 0
+// (layout.cpp puts those tensors at the tail of the bucket), so [0, late_offset) -- 0.80 M of 1.08 M floats -- is all-reduced on its own
+// stream while the layer-0 BPTT and its weight gradients run; the tail follows on the main stream.  Captured like everything else.
+int mimrl_handle::enqueue_grads2_reduced(bool skip_zero) {
+  const bool ke = keep_events;
+  split_part = 1; fold_unpack = false;
+  int r = enqueue_grads(2, skip_zero);
+  split_part = 0;
+  MX(r);
+  const long n_main = layout.floats[MIMRL_GROUP_MAIN], early = layout.late_offset;
+  hipEvent_t e0, e1;
+  MX(next_event(&e0)); MX(next_event(&e1));
+  if (early > 0) {
+    Range rg("mimrl.stage2.allreduce(main_g[early]) [RCCL, under the layer-0 BPTT]");
+    HIPX(hipEventRecord(e0, stream));
+    HIPX(hipStreamWaitEvent(comm_s, e0, 0));
+    MX(comm_allreduce_sum(comm, bufs.main_g, (size_t)early, comm_s));
+    HIPX(hipEventRecord(e1, comm_s));
+  }
+  keep_events = true;                       // (the events above stay reserved while part 1 draws its own)
+  bf16 = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
+  r = gru_layer_backward(0);
+  if (r == 0) r = join(0, 5);
+  bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+  keep_events = ke;
+  MX(r);
+  if (n_main > early) {
+    Range rg("mimrl.stage2.allreduce(main_g[layer-0 tail]) [RCCL]");
+    MX(comm_allreduce_sum(comm, bufs.main_g + early, (size_t)(n_main - early), stream));
+  }
+  if (early > 0) HIPX(hipStreamWaitEvent(stream, e1, 0));
+  return MIMRL_OK;
+}
+
 // kind 0: grads + apply (single-GPU step); kind 1: grads only; kind 2: apply only (never captured: one kernel)
 int mimrl_handle::run(int stage, int kind) {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
@@ -2693,6 +2744,11 @@ int mimrl_handle::run(int stage, int kind) {
       if (r == 0) r = join(0, 5);
       bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
       return r;
+    }
+    if (kind == 0 && comm && !(stage == 1 && bank_rows <= 0)) {   // data parallel: gradient pass, all-reduce, update -- one enqueue
+      if (stage == 2 && comm_split && cfg.encoder == MIMRL_ENCODER_GRU) MX(enqueue_grads2_reduced(skip_zero));
+      else { MX(enqueue_grads(stage, skip_zero)); MX(reduce_bucket(stage)); }
+      return enqueue_apply(stage);
     }
     split_part = kind == 3 ? 1 : 0;
     fold_unpack = kind == 0 && stage == 2 && fold_unpack_on;   // the update follows in the same enqueue: it scatters the packed layer-0 pieces
@@ -2879,9 +2935,13 @@ int mimrl_handle::run_step() {
     fuse_boundary = !no_boundary; skip_imgT_refresh = use_imgT && !no_boundary; wtT_prebuilt = bf_bwd && fused_cube_bwd && !no_boundary;
     wtT_built = false;
     int r = enqueue_grads(1, true);
+    if (r == 0) r = reduce_bucket(1);
     if (r == 0) r = enqueue_apply(1);
-    keep_events = true; fold_unpack = fold_unpack_on;
-    if (r == 0) r = enqueue_grads(2, true);
+    keep_events = true; fold_unpack = fold_unpack_on && !comm;   // (data parallel: the packed layer-0 pieces must be IN the bucket before it is reduced)
+    if (r == 0) {
+      if (comm && comm_split && cfg.encoder == MIMRL_ENCODER_GRU) r = enqueue_grads2_reduced(true);
+      else { r = enqueue_grads(2, true); if (r == 0) r = reduce_bucket(2); }
+    }
     keep_events = false; fold_unpack = false;
     if (r == 0) r = enqueue_apply(2);
     unpack_pending = false;
@@ -3311,6 +3371,32 @@ int mimrl_set_grad_scale(mimrl_handle* h, float scale) {
   return MIMRL_OK;
 }
 
+int mimrl_comm_unique_id(void* out128) { return mimrl::comm_unique_id(out128); }
+
+int mimrl_set_comm(mimrl_handle* h, const void* unique_id128, int world, int rank) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  HIPX(hipStreamSynchronize(h->user_stream));
+  h->drop_graphs();
+  if (h->comm) { MX(mimrl::comm_destroy(h->comm)); h->comm = nullptr; }
+  h->comm_world = 1; h->comm_rank = 0;
+  if (!unique_id128) return MIMRL_OK;                       // NULL: back to a replica without collectives
+  MX(mimrl::comm_init(&h->comm, unique_id128, world, rank));
+  h->comm_world = world; h->comm_rank = rank;
+  if (!h->comm_s) HIPX(hipStreamCreateWithFlags(&h->comm_s, hipStreamNonBlocking));
+  const char* sp = getenv("MIMRL_DDP_SPLIT");
+  h->comm_split = !(sp && sp[0] == '0');
+  // one eager collective now: RCCL's lazy set-up (buffers, proxy threads) must not happen inside a stream capture
+  if (h->bound) {
+    HIPX(hipMemsetAsync(h->bufs.scalars, 0, sizeof(float), h->user_stream));
+    MX(mimrl::comm_allreduce_sum(h->comm, h->bufs.scalars, 1, h->user_stream));
+    MX(mimrl::comm_allreduce_sum(h->comm, h->bufs.scalars, 1, h->comm_s));
+    HIPX(hipStreamSynchronize(h->user_stream)); HIPX(hipStreamSynchronize(h->comm_s));
+  }
+  return MIMRL_OK;
+}
+
+int64_t mimrl_main_late_offset(const mimrl_handle* h) { return h ? (int64_t)h->layout.late_offset : 0; }
+
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
 #ifdef MIMRL_DET
@@ -3343,6 +3429,8 @@ void mimrl_destroy(mimrl_handle* h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
+  if (h->comm) (void)mimrl::comm_destroy(h->comm);
+  if (h->comm_s) (void)hipStreamDestroy(h->comm_s);
   if (h->ws) (void)hipFree(h->ws);
   delete h;
 }

@@ -58,8 +58,7 @@ int build_layout(const mimrl_cfg& c, Layout* out) {
     e.d2 = d2 > 0 ? d2 : 0;
     e.group = (name.find("vmi") != std::string::npos || name.find("vcmi") != std::string::npos) ? MIMRL_GROUP_CRITIC
                                                                                                 : MIMRL_GROUP_MAIN;
-    e.offset = out->floats[e.group];
-    out->floats[e.group] += (e.numel() + 63) / 64 * 64;
+    e.offset = -1;                                   // assigned below, in two passes (the layer-0 recurrence tensors last)
     out->index[name] = (int)out->entries.size();
     out->entries.push_back(e);
   };
@@ -145,7 +144,24 @@ int build_layout(const mimrl_cfg& c, Layout* out) {
       add(p + ".bias", dims[l][0], 0);
     }
   }
+  // Offsets.  The ENTRY order above is the reference's registration order (state_dict / optimizer order); the OFFSETS put the layer-0
+  // recurrence tensors (rnn_*.*_l0*: the gradients that become final LAST in the backward pass, behind the layer-0 BPTT) at the tail
+  // of the main bucket, so that under data parallelism everything in front of `late_offset` is ONE contiguous range that can be
+  // all-reduced while the layer-0 BPTT still runs, and the tail a second one (round 5; rounds 3-4 had five ranges).
+  for (int pass = 0; pass < 2; ++pass)
+    for (auto& e : out->entries) {
+      if ((layout_is_late(e.name) ? 1 : 0) != pass) continue;
+      e.offset = out->floats[e.group];
+      out->floats[e.group] += (e.numel() + 63) / 64 * 64;
+    }
+  out->late_offset = out->floats[MIMRL_GROUP_MAIN];
+  for (const auto& e : out->entries)
+    if (layout_is_late(e.name) && e.offset < out->late_offset) out->late_offset = e.offset;
   return MIMRL_OK;
+}
+
+bool layout_is_late(const std::string& name) {
+  return name.compare(0, 4, "rnn_") == 0 && name.find("_l0") != std::string::npos;
 }
 
 }  // namespace mimrl

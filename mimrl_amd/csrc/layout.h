@@ -21,6 +21,7 @@ struct Layout {
   std::vector<LayoutEntry> entries;
   std::map<std::string, int> index;
   long floats[2] = {0, 0};
+  long late_offset = 0;   // main bucket: floats [late_offset, floats[MAIN]) are the layer-0 recurrence tensors (final last in the backward pass)
   const LayoutEntry* find(const std::string& n) const {
     auto it = index.find(n);
     return it == index.end() ? nullptr : &entries[it->second];
@@ -30,5 +31,6 @@ struct Layout {
 // returns 0 or MIMRL_ERR_ARG (message set)
 int build_layout(const mimrl_cfg& c, Layout* out);
 int validate_cfg(const mimrl_cfg& c);
+bool layout_is_late(const std::string& name);   // rnn_*.*_l0*: laid out at the tail of the main bucket
 
 }  // namespace mimrl

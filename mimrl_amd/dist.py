@@ -1,10 +1,17 @@
-"""Data-parallel replicas: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+"""Data-parallel replicas: one process per GPU, RCCL over xGMI.
 
 The reference only has single-process nn.DataParallel (Solver.py:33-35).  Here every rank owns a full replica and a
 local batch; the estimators are local to the rank (B_local x B_local InfoNCE), so the only exchange
-per stage is ONE all-reduce(mean) of that stage's flat gradient bucket (critics: 3.36 M floats, main: 1.08 M floats),
+per stage is the all-reduce(mean) of that stage's flat gradient bucket (critics: 3.36 M floats, main: 1.08 M floats),
 followed by the fused clip+Adam -- value-clipping the averaged gradient, as a single process would.
-The helpers are backend-agnostic so the world_size-2 gloo tests can drive them on CPU.
+
+Two transports (round 5):
+  * IN THE LIBRARY (default on GPUs): ``attach_comm`` gives the engine its own RCCL communicator (mimrl_set_comm); the collectives are
+    then nodes of the engine's captured step graph -- world > 1 runs the SAME single graph per step as world = 1 (cross-stage overlap and
+    in-graph Adam included), with three collectives in it: critic bucket, main bucket [0, late) under the layer-0 BPTT, its layer-0 tail.
+    torch.distributed only carries the 128-byte unique id to the ranks.
+  * torch.distributed collectives between per-stage graph launches (rounds 1-4; MIMRL_DDP_TORCH=1, and whenever the process group is not
+    RCCL: the world_size-2 gloo tests on CPU / on one GPU, which RCCL refuses).
 """
 from __future__ import annotations
 
@@ -69,6 +76,42 @@ def broadcast_(flat: torch.Tensor, src: int = 0):
     return flat
 
 
+def attach_comm(engine, world: int, rank: int) -> bool:
+    """Create the engine's own RCCL communicator (collective).  Rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes.
+    Returns False (and leaves the torch.distributed transport in charge) when MIMRL_DDP_TORCH=1, on CPU, or when the process group is
+    not RCCL.  world == 1: a one-rank communicator without any process group (MIMRL_DDP_FORCE_COLLECTIVES=1: the one-GPU tests / bench)."""
+    if os.environ.get("MIMRL_DDP_TORCH") is not None or not torch.cuda.is_available() or not hasattr(engine, "set_comm"):
+        return False
+    if world > 1:
+        if not dist.is_initialized() or dist.get_backend() != "nccl":
+            return False
+        payload = torch.zeros(128, dtype=torch.uint8, device=engine.device)
+        if rank == 0:
+            payload.copy_(torch.frombuffer(bytearray(type(engine).comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(payload, src=0)
+        uid = bytes(payload.cpu().numpy().tobytes())
+    else:
+        uid = type(engine).comm_unique_id()
+    engine.set_comm(uid, world, rank)
+    engine._ddp_world = world
+    flush_c_stdio()
+    return True
+
+
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator is created; on a pipe that buffer is written at exit, i.e. BEHIND
+    whatever Python printed meanwhile (bench.py's one JSON line must be the last thing on stdout)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+
+
+def has_comm(engine, world: int) -> bool:
+    return getattr(engine, "comm_world", 0) == world and world >= 1
+
+
 def prepare_engine(engine, world: int):
     """Once per engine: fold the mean's 1/world into Adam."""
     if getattr(engine, "_ddp_world", None) != world:
@@ -80,6 +123,9 @@ def ddp_stage_step(engine, stage: int, world: int):
     """grads -> all-reduce(sum) of the stage's bucket -> clip+Adam on bucket/world.  ``engine`` needs stage_grads /
     stage_apply / bucket_grad(stage) / set_grad_scale.  The collective is enqueued behind the kernels in stream order: no host
     synchronisation (RCCL); value-clipping happens after averaging, as in a single process."""
+    if has_comm(engine, world):          # the library reduces inside the stage's own enqueue
+        (engine.stage1_step if stage == 1 else engine.stage2_step)()
+        return
     prepare_engine(engine, world)
     with _engine_stream(engine):
         engine.stage_grads(stage)
@@ -115,7 +161,13 @@ def ddp_two_stage_step(engine, world: int):
     bench.py: ms_per_step_ddp_schedule_no_comm).  The dependency all-reduce -> Adam_vmi -> stage-2 critic forward is a true one
     (SURVEY.md section 5); nothing of stage 2 that is independent of the updated critics is left to put under it.  The main bucket is
     reduced in one piece: 90 % of it are GRU / W_t gradients that become final with the last kernels of the stage.
-    NOT MEASURED ON MORE THAN ONE GPU (no multi-GPU box available to the builder): see DESIGN.md section 6."""
+    NOT MEASURED ON MORE THAN ONE GPU (no multi-GPU box available to the builder): see DESIGN.md section 6.
+
+    Round 5: with the engine's own communicator (``attach_comm``) none of the above is driven from here -- ``engine.step()`` is the one
+    captured graph of the single-GPU step with the three collectives inside it."""
+    if has_comm(engine, world):
+        engine.step()
+        return
     prepare_engine(engine, world)
     on = _collectives_on(world)
     with _engine_stream(engine):

@@ -228,6 +228,26 @@ class HipEngine:
         """Multiply the gradient buckets by ``scale`` inside the fused clip+Adam (1 / world_size after a SUM all-reduce)."""
         check(self.lib.mimrl_set_grad_scale(self.handle, float(scale)))
 
+    def set_comm(self, unique_id: bytes, world: int, rank: int):
+        """Give the engine its own RCCL communicator (include/mimrl.h: mimrl_set_comm; collective over the ranks).  From then on ``step`` /
+        ``stage1_step`` / ``stage2_step`` all-reduce the stage's gradient bucket themselves, inside the captured graph.  ``unique_id`` =
+        ``HipEngine.comm_unique_id()`` of rank 0, handed to every rank by the caller; ``None`` removes the communicator."""
+        self._coherent()
+        if unique_id is None:
+            check(self.lib.mimrl_set_comm(self.handle, None, 1, 0))
+            self.comm_world = 0
+            return
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        check(self.lib.mimrl_set_comm(self.handle, C.cast(buf, C.c_void_p), int(world), int(rank)))
+        self.comm_world = int(world)
+        self.set_grad_scale(1.0 / world)
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        check(_lib.load().mimrl_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
     def step(self):
         """One stage-1 (critics) + one stage-2 (model) update on the bound batch."""
         self._coherent()
@@ -245,20 +265,12 @@ class HipEngine:
         check(self.lib.mimrl_stage_grads_part(self.handle, stage, part))
 
     def late_grad_ranges(self):
-        """[(start, stop)] float ranges of the main gradient bucket that are final only after ``stage_grads_part(2, 1)``: the layer-0 GRU
-        tensors (rnn_a / rnn_v ``*_l0*``), each modality one contiguous run of the flat bucket; the complement is final after part 0."""
-        main = sorted((off, int(np.prod(shape)), name) for name, group, off, shape in self.entries if group == 0)
-        n_main = self.main["g"].numel()
-        out = []
-        for i, (off, n, name) in enumerate(main):
-            if "_l0" not in name or not name.startswith("rnn_"):
-                continue
-            stop = main[i + 1][0] if i + 1 < len(main) else n_main          # (alignment padding up to the next tensor rides along)
-            if out and out[-1][1] == off:
-                out[-1] = (out[-1][0], stop)
-            else:
-                out.append((off, stop))
-        return out
+        """[(start, stop)] float ranges of the main gradient bucket that are final only after ``stage_grads_part(2, 1)``: the layer-0
+        recurrence tensors (rnn_a / rnn_v ``*_l0*``), which the layout puts at the TAIL of the bucket (round 5) -- one range; everything
+        in front of it is final after part 0."""
+        off = int(self.lib.mimrl_main_late_offset(self.handle))
+        n = self.main["g"].numel()
+        return [(off, n)] if off < n else []
 
     def stage_apply(self, stage: int):
         self._coherent()

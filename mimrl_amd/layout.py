@@ -106,13 +106,27 @@ def is_critic(name: str) -> bool:
     return ("vmi" in name) or ("vcmi" in name)
 
 
+def is_late(name: str) -> bool:
+    """The layer-0 recurrence tensors: their gradients are final last in the backward pass (behind the layer-0 BPTT), so they sit at the
+    TAIL of the main bucket -- everything in front of them is one contiguous range a data-parallel step can all-reduce early."""
+    return name.startswith("rnn_") and "_l0" in name
+
+
 def build_layout(opt, d_t: int, d_a: int, d_v: int) -> Tuple[List[Entry], Dict[str, int]]:
-    """-> (entries, sizes) with sizes = {"main": floats, "critic": floats} (each padded to ALIGN)."""
+    """-> (entries, sizes) with sizes = {"main": floats, "critic": floats} (each padded to ALIGN).  Entries come in the reference's
+    registration order; offsets are assigned in two passes (``is_late`` tensors last), exactly as csrc/layout.cpp does."""
     cursor = {"main": 0, "critic": 0}
-    entries: List[Entry] = []
-    for name, shape in named_shapes(opt, d_t, d_a, d_v):
-        g = "critic" if is_critic(name) else "main"
-        e = Entry(name, tuple(int(s) for s in shape), g, cursor[g])
-        entries.append(e)
-        cursor[g] += (e.numel + ALIGN - 1) // ALIGN * ALIGN
+    shapes = [(n, tuple(int(s) for s in shp)) for n, shp in named_shapes(opt, d_t, d_a, d_v)]
+    offset: Dict[str, int] = {}
+    for late in (False, True):
+        for name, shape in shapes:
+            if is_late(name) != late:
+                continue
+            g = "critic" if is_critic(name) else "main"
+            n = 1
+            for s_ in shape:
+                n *= s_
+            offset[name] = cursor[g]
+            cursor[g] += (n + ALIGN - 1) // ALIGN * ALIGN
+    entries = [Entry(name, shape, "critic" if is_critic(name) else "main", offset[name]) for name, shape in shapes]
     return entries, dict(cursor)

@@ -57,3 +57,20 @@ def test_rccl_call_path_single_rank(tmp_path):
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
     assert "RCCL_SINGLE_RANK_OK" in r.stdout
+
+
+@pytest.mark.parametrize("cfg4_shape", [False, True], ids=["cfg2", "cfg4-per-rank-shape"])
+def test_rccl_inside_the_library_single_rank(tmp_path, cfg4_shape):
+    """Round 5: the engine's OWN RCCL communicator (mimrl_set_comm, librccl dlopen'ed by the library) with one rank: the
+    collectives -- critic bucket, main bucket [0, late) on the communication stream under the layer-0 BPTT, the layer-0 tail -- are nodes of
+    the captured two-stage graph (and of the per-stage graphs / the eager path with overlap off), so a data-parallel rank replays the SAME
+    single graph as a single GPU.  A one-rank SUM is the identity: parameters after 3 steps equal a plain engine's (fp32 tiny; the bf16
+    bench mode at cfg2 with and without graphs, split reduce off, overlap off; the fused concat critic; and -- second case -- BASELINE
+    configs[3]'s per-rank shape: B = 256, T = 500, concat critic, N = 16326).  What it cannot show: xGMI traffic and N > 1 scaling."""
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if cfg4_shape:
+        env["MIMRL_TEST_CFG4_SHAPE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_inlib_worker.py")], env=env, cwd=tmp_path, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "RCCL_INLIB_OK" in r.stdout
