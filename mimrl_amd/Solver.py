@@ -58,6 +58,9 @@ class Solver:
             mdist.broadcast_(self.engine.main["p"])
             mdist.broadcast_(self.engine.crit["p"])
             self.engine.params_changed()
+            # the engine's own RCCL communicator: the gradient all-reduces become part of its captured graphs (dist.attach_comm); on a
+            # process group that is not RCCL (the gloo tests) the torch.distributed transport of dist.ddp_* stays in charge
+            mdist.attach_comm(self.engine, self.world, self.rank)
         self.base_lr = float(opt.learning_rate)
         self.epoch = 0
         self.task_path = os.path.join("./TaskRuning", str(opt.task_name))                  # Solver.py:107-112
@@ -103,7 +106,7 @@ class Solver:
             self._active = e
         if e.bank_rows != self.engine.bank_rows:
             e.set_bank_rows(self.engine.bank_rows)
-        want = mdist.ddp_prefetch_mode(self.world) if self._want_prefetch else 0
+        want = (1 if mdist.has_comm(e, self.world) else mdist.ddp_prefetch_mode(self.world)) if self._want_prefetch else 0
         if getattr(e, "_prefetch_on", 0) != want:
             e.set_stage2_prefetch(want)
             e._prefetch_on = want

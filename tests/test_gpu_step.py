@@ -34,11 +34,11 @@ def make_engine(name, precision="fp32", use_graph=False):
 
 
 def _record_errors(key, value):
-    """Measured errors of the round's new parity tests -> gpurun_out/r04_step_errors.json (copied to profiles/ by hand)."""
+    """Measured errors of the round's new parity tests -> gpurun_out/r05_step_errors.json (copied to profiles/ by hand)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "gpurun_out", "r04_step_errors.json")
+    path = os.path.join(root, "gpurun_out", "r05_step_errors.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         try:
@@ -905,3 +905,82 @@ def test_split_stage2_gradients_equal_the_whole_pass(graph):
     for n, want in res["whole"].items():
         scale = max(np.abs(want).max(), 1e-3 * top)
         assert np.abs(res["split"][n] - want).max() <= 1e-4 * scale, n      # (float atomics reorder additions: the reproducibility band)
+
+
+# fp32 engine: per-tensor band on the stored slices (fraction of the tensor's own scale; 3x the measured 4.9e-3 / 1.7e-3) -- bench mode:
+# (critic bucket, main bucket) cosine floors.  Measured: fp32 cosines 1 - 3e-8; bench 0.99980 / 0.98935 (cfg3_full), 0.99948 / 0.97537
+# (cfg5_full): 3x the measured distance from 1.  Per TENSOR the bench mode is off by up to the tensor's whole scale in the small
+# ill-conditioned ones at this depth (mlp_k.fc1.bias, ln_a.bias, single rows of rnn_a.weight_ih_l1: the backward of the broadcast means
+# through LayerNorms over K = 3 / L cancels most of the signal) -- recorded in profiles/r05_step_errors.json, not asserted.
+FULL_BANDS = {"cfg3_full": (1.5e-2, (0.9994, 0.968)), "cfg5_full": (6e-3, (0.9984, 0.926))}
+
+
+@pytest.mark.parametrize("name", ["cfg3_full", "cfg5_full"])
+@pytest.mark.parametrize("mode", ["fp32", "bench"])
+def test_full_size_gradients_vs_reference(name, mode):
+    """the gradients of BASELINE configs[2] at FULL size (cfg3_full: B = 256, T = 500, concat critic, N = 16326) and of the
+    configs[4] subset at the size the step tests run (cfg5_full: B = 32, T = 1000) against the REAL reference -- tests/golden/make_golden.py
+    ran the reference's own Solver-body once in the build container (minutes of CPU autograd) and stored, per tensor, the gradient norm,
+    the gradient sum and a 512-entry strided slice, plus the 11 + 8 values and both losses (Model.py:305-386, Solver.py:205-236).
+    fp32 engine: the losses and the 11 + 8 values at 1e-3, every slice within the band of FULL_BANDS, norms within 3e-3; bench mode (bf16 /
+    fp16 MFMA operands, fused kernels, captured): losses 2e-3, values 2e-2, and the DIRECTION of each gradient bucket (cosine over the
+    re-weighted slices) -- see FULL_BANDS for what is and is not asserted per tensor."""
+    from tests.golden.configs import grad_slice_index
+    c, opt, batch, banks, p, eng = make_engine(name, precision="fp32" if mode == "fp32" else "bf16", use_graph=mode == "bench")
+    g = load_golden(name)
+    anchors = g["anchors"][0]
+    eng.set_banks(*(banks[k] for k in "CFTAV"))
+    eng.set_anchors(1, anchors[0]); eng.set_anchors(2, anchors[1])
+    band = FULL_BANDS[name][0 if mode == "fp32" else 1]
+    rec, cosines = {}, {}
+    for stage, key, bucket in ((1, "s1", eng.crit), (2, "s2", eng.main)):
+        eng.stage_grads(stage)             # (the reference's stage-2 pass sees the critics AFTER their update: Solver.py:211-214, 221)
+        torch.cuda.synchronize()
+        s = eng.read_scalars()
+        if stage == 1:
+            assert_close(s[_lib.S1_LOSS], g["traj_s1_loss"][0], 1e-3 if mode == "fp32" else 2e-3, 2e-5, "stage-1 loss vs reference")
+            assert_close(s[_lib.S1_MIS:_lib.S1_MIS + 11], g["traj_s1_mis"][0], 1e-3 if mode == "fp32" else 2e-2, 5e-5 if mode == "fp32" else 2e-3, "stage-1 MI / CMI vs reference")
+        else:
+            assert_close(s[_lib.S2_LOSS], g["traj_s2_loss"][0], 1e-3 if mode == "fp32" else 2e-3, 2e-5, "stage-2 loss vs reference")
+            assert_close(s[_lib.S2_TASK], g["traj_s2_task"][0], 1e-3 if mode == "fp32" else 2e-3, 2e-5, "task loss vs reference")
+            assert_close(s[_lib.S2_MIS:_lib.S2_MIS + 8], g["traj_s2_mis"][0], 1e-3 if mode == "fp32" else 2e-2, 5e-5 if mode == "fp32" else 6e-3, "stage-2 MI terms vs reference")
+        names = [str(x) for x in g[key + "_gnorm_names"]]
+        grads = {n: eng.grads[n].double().cpu().numpy() for n in names}
+        top = max(float(x) for x in g[key + "_gnorm"] / np.sqrt([max(grads[n].size, 1) for n in names])) + 1e-30   # largest RMS gradient
+        worst = ("", 0.0)
+        cat_got, cat_want = [], []
+        for i, n in enumerate(names):
+            got = grads[n].reshape(-1)
+            want = g[key + "_grad:" + n].reshape(-1) if key + "_grad:" + n in g.files else g[key + "_gslice:" + n]
+            idx = np.arange(got.size) if want.size == got.size else grad_slice_index(got.size)
+            scale = max(float(np.abs(want).max()), float(g[key + "_gnorm"][i]) / np.sqrt(got.size), 1e-3 * top)
+            err = float(np.abs(got[idx] - want).max()) / scale
+            nerr = abs(float(np.linalg.norm(got)) - float(g[key + "_gnorm"][i])) / max(float(g[key + "_gnorm"][i]), 1e-3 * top * np.sqrt(got.size))
+            rec[n] = {"slice_max_rel_scale": err, "norm_rel": nerr}
+            # (slices weighted back to their tensors: sqrt(numel / slice) -- the cosine below estimates the whole bucket's direction)
+            wgt = np.sqrt(got.size / max(len(idx), 1))
+            cat_got.append(got[idx] * wgt); cat_want.append(want * wgt)
+            if err > worst[1]:
+                worst = (n, err)
+            if stage == 1 and i == len(names) - 1:
+                pass
+            # (the concat critic's score head sums 65 536 pair rows of an InfoNCE whose gradient sums to zero: its bias is pure cancellation)
+            if n.endswith("MLP_f.6.bias"):
+                continue
+        cg, cw = np.concatenate(cat_got), np.concatenate(cat_want)
+        cosines[key] = float(cg @ cw / (np.linalg.norm(cg) * np.linalg.norm(cw) + 1e-300))
+        if stage == 1:
+            eng.stage_apply(1)
+    top5 = sorted(((v["slice_max_rel_scale"], n) for n, v in rec.items() if not n.endswith("MLP_f.6.bias")), reverse=True)[:5]
+    topn = sorted(((v["norm_rel"], n) for n, v in rec.items() if not n.endswith("MLP_f.6.bias")), reverse=True)[:3]
+    _record_errors(f"full_size_gradients/{name}/{mode}", {"worst_slices": top5, "worst_norms": topn, "band": band, "tensors": len(rec), "bucket_cosine": cosines})
+    eng.close()
+    if mode == "fp32":
+        assert min(cosines.values()) >= 1 - 1e-6, cosines
+        for n, v in rec.items():
+            if n.endswith("MLP_f.6.bias"):
+                continue
+            assert v["slice_max_rel_scale"] <= band, (name, mode, n, v)
+            assert v["norm_rel"] <= 3e-3, (name, mode, n, "norm", v)
+    else:
+        assert cosines["s1"] >= band[0] and cosines["s2"] >= band[1], (name, cosines, band)

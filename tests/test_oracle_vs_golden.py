@@ -135,3 +135,31 @@ def test_unit_cmi_matches_reference():
         assert rel_close(bce.item(), g[f"cmi_{last}_bce"], 1e-4, 1e-6)
         np.testing.assert_allclose(xt.grad.numpy(), g[f"cmi_{last}_dx"], rtol=2e-3, atol=1e-7)
         np.testing.assert_allclose(yt.grad.numpy(), g[f"cmi_{last}_dy"], rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["cfg3_full", "cfg5_full"])
+def test_full_size_fixtures_are_reference_outputs(name):
+    """The full-size fixtures (round 5: one reference step at B = 256 / T = 500 / concat / N = 16326 and at B = 32 / T = 1000, generated by
+    tests/golden/make_golden.py from the REAL reference) hold what the GPU tests read -- 11 + 8 values, both losses, per-tensor gradient
+    norms / sums and a 512-entry slice of every tensor.  The oracle's autograd at this size takes minutes, so the CPU tier pins the oracle to
+    them through the part that takes seconds: the cfg5_full forward pass (2000 serial cell steps, T = 1000); cfg3_full's forward pass is
+    pinned on the GPU box (tests/test_gpu_step.py::test_cfg3_full_size_properties uses the same inputs)."""
+    from tests.golden.configs import grad_slice_index
+    g = load_golden(name)
+    c, opt, batch, banks = case(name)
+    p = oracle_params(opt, c["seed"])
+    for key, crit in (("s1", True), ("s2", False)):
+        names = [str(x) for x in g[key + "_gnorm_names"]]
+        assert all(R.is_critic_param(n) == crit for n in names) and len(names) > 60
+        assert np.all(np.isfinite(g[key + "_gnorm"])) and np.all(g[key + "_gnorm"] >= 0)
+        for n in names:
+            numel = int(p[n].numel())
+            k = key + ("_grad:" if numel <= 512 else "_gslice:") + n
+            assert k in g.files and g[k].size == min(numel, 512), k
+            assert grad_slice_index(numel).size == min(numel, 512)
+    assert g["traj_s1_mis"].shape == (1, 11) and g["traj_s2_mis"].shape == (1, 8) and g["anchors"].shape[:3] == (1, 2, 6)
+    if name == "cfg5_full":
+        with torch.no_grad():
+            pred, F_F, T_F, A_F, V_F = R.model_forward(p, opt, *batch[:3])
+        for k, val in zip(["pred", "F_F", "T_F", "A_F", "V_F"], [pred, F_F, T_F, A_F, V_F]):
+            np.testing.assert_allclose(val.numpy(), g["fwd_" + k], rtol=2e-4, atol=2e-5, err_msg=k)
