@@ -234,7 +234,8 @@ def cpu_baseline(workload_name):
     c1 = child("cfg1", tbest, 20.0, 3, 20, 60)
     for r in probes + [best]:
         log(f"cpu baseline ({workload_name}, {r.get('threads')} threads): {r.get('iters_per_sec')} it/s over {r.get('timed_iterations')} iterations {r.get('error', '')}")
-    return {"value": best["iters_per_sec"], "unit": "two-stage iters/sec", "cores": best["threads"], "kind": "port",
+    # `cores` = the threads the timed run actually used (the contract's definition); `host_cores` = what the box has (affinity mask)
+    return {"value": best["iters_per_sec"], "unit": "two-stage iters/sec", "cores": best["threads"], "threads": best["threads"], "host_cores": cores, "kind": "port",
             "sample": f"{best['warmups']} warm-ups + {best['timed_iterations']} timed two-stage iterations of the same workload "
                       f"({workload_name}), fp32 PyTorch-CPU oracle incl. host kNN, at the fastest of the probed thread counts: "
                       + ", ".join(f"{r.get('threads')} -> {r.get('iters_per_sec', 'failed')}" for r in probes)
@@ -647,7 +648,11 @@ def main():
                        "unit_definition": f"one iter = stage-1 + stage-2 update over one B={B} batch; under weak-scaling DP every "
                                           "global step processes n_gpus such batches (gradients all-reduced), so value = n_gpus*steps/time",
                        "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "precision": args.precision, "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch and not _lib.DETERMINISTIC,
+                       "precision": args.precision,
+                       "operand_types": ("fp16 MFMA operands in the forward products of the model path (W_t, GRU input projections, CubeMLP), bf16 in the "
+                                         "recurrence, the estimators and every backward product; fp32 accumulate, state, statistics and optimizer"
+                                         if _lib.PREC[args.precision] else "fp32 MFMA operands (v_mfma_f32_*_f32), fp32 everywhere"),
+                       "hipgraph": not args.no_graph, "stage2_forward_overlap": not args.no_prefetch and not _lib.DETERMINISTIC,
                        "deterministic_build": bool(_lib.DETERMINISTIC),
                        "shared_encoder_prefix": (not args.no_prefetch) and not os.environ.get("MIMRL_NO_SHARED_PREFIX"), "samples_per_sec": B * world * args.steps / wall},
             "algorithmic_gflop_per_step": algorithmic_flops(opt, N) / 1e9,

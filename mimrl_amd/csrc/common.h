@@ -33,6 +33,7 @@ int set_error(int code, const char* fmt, ...);
 #define LAUNCH_CHECK() HIPX(hipGetLastError())
 }  // namespace mimrl
 #include "det.h"
+#include "knobs.h"
 #include <unordered_map>
 namespace mimrl {
 // Stream-capture bookkeeping (det.hip): while capture_track(true) is in effect every kernel launch notes which stream its graph node was
@@ -60,7 +61,7 @@ const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams();
 #endif
 namespace mimrl {
 
-// Environment knobs.  Tuning knobs (stream placement, kernel variants: results unchanged) are read with getenv() where they
+// Environment knobs.  Tuning knobs (stream placement, kernel variants: results unchanged) are read with knob() (knobs.h: one table) where they
 // are used.  DEBUG knobs change RESULTS (skip work, stop a kernel early, re-create a placement known to miscompute): they exist
 // only in a -DMIMRL_DEBUG_KNOBS build (`make DEBUG_KNOBS=1`); in the default build dbg_env() is a constant nullptr -- the
 // branches behind it fold away -- and mimrl_create() refuses to run while one of them is set in the environment.

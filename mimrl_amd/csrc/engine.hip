@@ -517,7 +517,7 @@ struct mimrl_handle {
   // precision mode says bf16 -- 1: W_t projection, 2: GRU layer-0 input projections, 4: layer-1 input projections, 8: estimator stacks.
   // Results stay valid (only more precise); tuning knob.
   static bool fp32_site(int bit) {
-    static const int mask = getenv("MIMRL_FWD_FP32_SITES") ? atoi(getenv("MIMRL_FWD_FP32_SITES")) : 0;
+    static const int mask = knob("MIMRL_FWD_FP32_SITES") ? atoi(knob("MIMRL_FWD_FP32_SITES")) : 0;
     return (mask & bit) != 0;
   }
   struct PrecGuard {   // run a scope with fp32 GEMM operands
@@ -1101,7 +1101,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   if (part != 1 && T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
   // text_post + ln_relu_drop + feat_mean as one launch, one workgroup per (sample, slot): for short sequences, where the three
   // launches are latency (cfg2: -15 us per tail); a workgroup walking T = 1000 rows loses to the row-parallel kernels (cfg5: +60 us)
-  static const bool fused_pre_on = getenv("MIMRL_NO_FUSED_TAIL_PRE") == nullptr;   // tuning knob
+  static const bool fused_pre_on = knob("MIMRL_NO_FUSED_TAIL_PRE") == nullptr;   // tuning knob
   const bool fused_pre = fused_pre_on && T <= 128;
   if (part != 2) {
     MX(fork(0, 5));
@@ -1110,7 +1110,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     // dispatched behind them too and then delays the tail (measured: 1.46 vs 1.34 ms).
     // (default since round 4 -- with the kNN sampler's two launches on side 4 the scan there delayed the layer-0 input projection:
     //  cfg2 0.840 -> 0.829 ms, cfg3 6.97 -> 6.87; MIMRL_LENS_SIDE0=0 puts it back)
-    static const bool prefix_split = !(getenv("MIMRL_LENS_SIDE0") && atoi(getenv("MIMRL_LENS_SIDE0")) == 0);   // tuning knob
+    static const bool prefix_split = !(knob("MIMRL_LENS_SIDE0") && atoi(knob("MIMRL_LENS_SIDE0")) == 0);   // tuning knob
     if (prefix_split && cfg.encoder == MIMRL_ENCODER_GRU && side_on(0)) {
       // lengths (Model.py:425-432): only the recurrence needs them.  Side 0 has slack (the text projection is needed at the tail);
       // on side 4 the scan sat in front of the video input projection, the longest chain ahead of the layer-0 recurrence
@@ -1118,7 +1118,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
       MX(next_event(&ev_lens));
       HIPX(hipEventRecord(ev_lens, S(0)));
     }
-    static const int text_late = getenv("MIMRL_TEXT_LATE") ? atoi(getenv("MIMRL_TEXT_LATE")) : 0;   // tuning knob (capture order)
+    static const int text_late = knob("MIMRL_TEXT_LATE") ? atoi(knob("MIMRL_TEXT_LATE")) : 0;   // tuning knob (capture order)
     auto text_branch = [this, BT_, D, part, fused_pre, B, T, L, pdrop]() -> int {
       { PrecGuard pg(this, fp32_site(1)); GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); g.f16 = fwd_f16; MX(G_on(S(0), g)); }
       MX(dbg_delay(S(0), 10));
@@ -1320,7 +1320,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   for (int i = 0; i < cfg.n_blocks; ++i)
     for (int ax = 0; ax < 3; ++ax) dims[i + 1][ax] = cfg.d_outs[i][ax];
   // deferred mode: every gradient buffer is used once (weight-gradient GEMMs read dY / dU after the chain has moved on)
-  static const bool no_defer = getenv("MIMRL_NO_DEFER_WGRAD") != nullptr;   // tuning knob
+  static const bool no_defer = knob("MIMRL_NO_DEFER_WGRAD") != nullptr;   // tuning knob
   const int per_block = 7 + (cfg.dropout_mlp[0] > 0.f) + (cfg.dropout_mlp[2] > 0.f);   // buffers one block consumes
   const bool defer = multi_stream && !cfg.ln_first && !no_defer && per_block * cfg.n_blocks + 1 <= NGBUF;
   const int npool = defer ? NGBUF : 4;
@@ -1402,8 +1402,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       // LayerNorm and bias gradients (column sums over the rows of dz, y, dY, dU).  Folded into the data-gradient kernel they cost
       // the chain 13 us per block (MIMRL_DAXIS_PG_FUSE=1: 19 -> 32 us); as ONE streaming side kernel instead of rowln_param_grads +
       // 2 x colsum (3 launches of 30-40 us each) they are ~10 us beside the BPTT (MIMRL_NO_DAXIS_PG_ONE=1: the three launches)
-      static const bool pg_fuse = getenv("MIMRL_DAXIS_PG_FUSE") != nullptr;        // tuning knobs
-      static const bool no_pg_one = getenv("MIMRL_NO_DAXIS_PG_ONE") != nullptr;
+      static const bool pg_fuse = knob("MIMRL_DAXIS_PG_FUSE") != nullptr;        // tuning knobs
+      static const bool no_pg_one = knob("MIMRL_NO_DAXIS_PG_ONE") != nullptr;
       const bool pg_fused = pg_fuse && a.fc2.b >= 0 && a.fc1.b >= 0;
       const bool pg_one = !pg_fused && !no_pg_one;
       fa.dgamma = fa.dbeta = fa.db2 = fa.db1 = nullptr;
@@ -1654,8 +1654,8 @@ __global__ void dbg_spin_kernel(long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 int mimrl_handle::dbg_delay(hipStream_t st, int tag) {
-  static const int want = getenv("MIMRL_DBG_DELAY_TAG") ? atoi(getenv("MIMRL_DBG_DELAY_TAG")) : -1;
-  static const int us = getenv("MIMRL_DBG_DELAY_US") ? atoi(getenv("MIMRL_DBG_DELAY_US")) : 50;
+  static const int want = knob("MIMRL_DBG_DELAY_TAG") ? atoi(knob("MIMRL_DBG_DELAY_TAG")) : -1;
+  static const int us = knob("MIMRL_DBG_DELAY_US") ? atoi(knob("MIMRL_DBG_DELAY_US")) : 50;
   if (tag != want) return MIMRL_OK;
   hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, st, (long)us * 100);   // wall_clock64 ticks at 100 MHz
   LAUNCH_CHECK();
@@ -1671,11 +1671,11 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
     for (int i = 1; i <= 3; ++i) if (side_on(i)) HIPX(hipStreamWaitEvent(side[i], after, 0));
   } else if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
   for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
-  static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
+  static const int wg_sides = knob("MIMRL_WG_SIDES") ? atoi(knob("MIMRL_WG_SIDES")) : 3;
   static const int dbg_skip_kinds = dbg_env("MIMRL_DBG_SKIP_DEFERRED") ? atoi(dbg_env("MIMRL_DBG_SKIP_DEFERRED")) : 0;   // timing experiments only (bit = kind)
   // the weight-gradient GEMMs as (at most) two grouped split-K launches, one per operand-layout class: D-axis products are
   // (RC,RC), the batch-reduced L-axis products (KC,KC).  Alone each is a ~20 us launch of 4..64 tiles.
-  static const bool no_wg_groupk = getenv("MIMRL_NO_WG_GROUPK") != nullptr;   // tuning knob
+  static const bool no_wg_groupk = knob("MIMRL_NO_WG_GROUPK") != nullptr;   // tuning knob
   // (short sequences only: at T = 1000 the recurrence beside them runs for a millisecond, launch latencies are hidden and one
   // chip-filling launch in front of the BPTT costs more than it saves -- cfg5: 3.85 vs 3.74 ms)
   const bool groupk = !no_wg_groupk && !prof_on && bf16 && !((dbg_skip_kinds >> 0) & 1) && cfg.seq_len <= 128;
@@ -1737,7 +1737,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
   // BPTT chain, first; the text branch (35 us of W_t weight gradient with slack until the end of the stage) behind it.  History: while
   // the side streams were congested by the parked CubeMLP weight gradients the opposite order was faster (1.229 vs 1.259 ms); with the
   // grouped / fused parameter-gradient kernels it is this one (0.980 vs 0.988 ms).  MIMRL_TEXT_BWD_FIRST=1: the other order.
-  static const bool text_bwd_first = getenv("MIMRL_TEXT_BWD_FIRST") != nullptr;
+  static const bool text_bwd_first = knob("MIMRL_TEXT_BWD_FIRST") != nullptr;
   auto text_bwd = [&]() -> int {   // text branch (side 0): dW_t = dtx^T . text
     MX(fork(0, 0));
     MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0, dmean));
@@ -1762,7 +1762,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
   // debugging: make the main stream wait for sides 1..3 (the parked kernels) at point n: 1 before the BPTT, 2 behind the layer-1 BPTT,
   // 3 behind the dh0 product, 4 behind the layer-0 BPTT
   static const int dbg_join_at = dbg_env("MIMRL_DBG_JOIN_AT") ? atoi(dbg_env("MIMRL_DBG_JOIN_AT")) : 0;
-  static const bool bptt_first = getenv("MIMRL_BPTT_FIRST") != nullptr;
+  static const bool bptt_first = knob("MIMRL_BPTT_FIRST") != nullptr;
   ev_pre = nullptr;
   if (bptt_first && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU && !deferred.empty()) {
     MX(next_event(&ev_pre));
@@ -1820,11 +1820,11 @@ int mimrl_handle::gru_layer_backward(int l) {
     MX(dbg_delay(stream, 8));
     // side streams of the GRU weight gradients (tuning knobs).  Sides 1..3 still carry the parked CubeMLP parameter-gradient
     // kernels at this point; sides 0 (text branch), 4 and 5 (kNN sampler, CMI branch) have been idle since the forward pass.
-    static const int l0_side = getenv("MIMRL_L0_WG_SIDE") ? atoi(getenv("MIMRL_L0_WG_SIDE")) : 1;
-    static const int l1_side0 = getenv("MIMRL_L1_WG_SIDE") ? atoi(getenv("MIMRL_L1_WG_SIDE")) : 1;
+    static const int l0_side = knob("MIMRL_L0_WG_SIDE") ? atoi(knob("MIMRL_L0_WG_SIDE")) : 1;
+    static const int l1_side0 = knob("MIMRL_L1_WG_SIDE") ? atoi(knob("MIMRL_L1_WG_SIDE")) : 1;
     MX(fork(1, (l == 0 || l1_side0 == 4) ? 5 : 3));   // the weight gradients below depend on the BPTT only
     if (l0_side == 0 && l == 0) MX(fork(0, 0));
-    static const bool dh0_last = getenv("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
+    static const bool dh0_last = knob("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
     auto dh0_gemm = [&]() -> int {   // gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
       // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
       {
@@ -1895,8 +1895,8 @@ int mimrl_handle::gru_layer_backward(int l) {
       auto two = [&](GemmDesc& q, long a_o, long b_o, long c_o) { if (both) { q.batch = 4; q.batch_in = 2; q.sa_bo = a_o; q.sb_bo = b_o; q.sc_bo = c_o; } };
       const long o_dg = dg[l][1][0] - dg[l][0][0], o_hp = hprev[l][1][0] - hprev[l][0][0], o_in = both ? h0[1] - h0[0] : 0;
       const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
-      static const int tail_n = getenv("MIMRL_TAIL_STREAMS") ? atoi(getenv("MIMRL_TAIL_STREAMS")) : 1;   // tuning knobs
-      static const int wg_sides = getenv("MIMRL_WG_SIDES") ? atoi(getenv("MIMRL_WG_SIDES")) : 3;
+      static const int tail_n = knob("MIMRL_TAIL_STREAMS") ? atoi(knob("MIMRL_TAIL_STREAMS")) : 1;   // tuning knobs
+      static const int wg_sides = knob("MIMRL_WG_SIDES") ? atoi(knob("MIMRL_WG_SIDES")) : 3;
       auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return l1_side0 == 4 ? S(4 + rr++ % 2) : S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih);
@@ -1948,7 +1948,7 @@ int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long p
                                     const int* dims, const float* in, float* const* act, float* out) {
   // concat-critic tail (thousands of row tiles): the direct-from-L2 fused variant was the faster one in round 1; with the round-2
   // GEMM kernels the plain chain wins (cfg3 9.80 vs 10.15 ms), so it is opt-in now (MIMRL_FUSED_MLP_BIG=1)
-  static const bool use_big = getenv("MIMRL_FUSED_MLP_BIG") != nullptr;   // tuning knob
+  static const bool use_big = knob("MIMRL_FUSED_MLP_BIG") != nullptr;   // tuning knob
   const bool big_ok = use_big && img_valid && crit_img && rows >= 2048 && dims[0] <= 256;
   if (bf16 && fused_mlp && (rows <= 512 || big_ok) && mlp_fused_supported(nb, rows, nl, dims)) {   // one launch (mlp_fused.hip)
     MlpFusedArgs fa;
@@ -1983,12 +1983,12 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
   float* dz = dout;
   int pp = 0;
   // the fused data-gradient chain runs on the transposed bf16 images (the same coalesced loop as the forward pass)
-  static const bool fused_bwd = getenv("MIMRL_NO_FUSED_MLP_BWD") == nullptr;
+  static const bool fused_bwd = knob("MIMRL_NO_FUSED_MLP_BWD") == nullptr;
   // (stacks with thousands of row tiles -- the concat critic -- keep the GEMM chain here: measured faster than the fused one)
   const bool use_fused = bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims);
   // single-output top layer (the concat critic's score head) over many rows: one streaming kernel instead of three GEMMs with
   // one real column in 64 (dz, dW, both bias gradients)
-  static const bool no_top1 = getenv("MIMRL_NO_TOP1") != nullptr;   // tuning knob
+  static const bool no_top1 = knob("MIMRL_NO_TOP1") != nullptr;   // tuning knob
   const bool top1 = !use_fused && !no_top1 && dims[nl] == 1 && nl >= 2 && dims[nl - 1] % 4 == 0 && dims[nl - 1] <= 1024 && 1024 % dims[nl - 1] == 0 &&
                     dtmp[0] != nullptr;
   if (wgrad && !use_fused && !top1)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
@@ -2009,14 +2009,14 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     if (wgrad) fa.db_top = CG(p0 + l_off[nl - 1][1]);   // the top layer's bias gradient rides along (was a separate column-sum launch)
     // ... and so does the weight gradient of a narrow top layer (the 2-logit CMI head: not eligible for the grouped launch, it was a
     // 17 us generic GEMM in front of it on the CMI branch of stage 1)
-    static const bool no_top_wg = getenv("MIMRL_NO_TOP_WGRAD_FUSE") != nullptr;   // tuning knob
+    static const bool no_top_wg = knob("MIMRL_NO_TOP_WGRAD_FUSE") != nullptr;   // tuning knob
     const bool top_wg = wgrad && !no_top_wg && dims[nl] % 4 != 0 && mlp_bwd_takes_top_wgrad(fa);
     if (top_wg) fa.dw_top = CG(p0 + l_off[nl - 1][0]);
     MX(mlp_stack_bwd_fused(stream, fa));
     if (!wgrad) return MIMRL_OK;
     // the nl weight-gradient GEMMs are independent of each other: on the critical branch (wg_helper >= 0) every second
     // one goes to a helper side stream
-    static const bool no_split = getenv("MIMRL_NO_WG_SPLIT") != nullptr;   // tuning knob
+    static const bool no_split = knob("MIMRL_NO_WG_SPLIT") != nullptr;   // tuning knob
     const int hs = (multi_stream && !no_split) ? wg_helper : -1;
     if (hs >= 0) MX(fork(hs, hs));
     GemmDesc gs[MLPF_MAX_LAYERS];
@@ -2031,20 +2031,20 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     }
     // the nl weight-gradient products are independent of each other: ONE grouped launch (gemm_group; it falls back to nl launches
     // when a product is not eligible, e.g. the 2-row top layer of the CMI classifiers, which then goes alone)
-    static const bool no_group = getenv("MIMRL_NO_WG_GROUP") != nullptr;   // tuning knob: the round-1 schedule (helper stream, alternating)
+    static const bool no_group = knob("MIMRL_NO_WG_GROUP") != nullptr;   // tuning knob: the round-1 schedule (helper stream, alternating)
     if (!no_group) {
       int lo = 0;
       if (top_wg) lo = 1;                                                             // done inside the data-gradient kernel
       else if (dims[nl] % 4 != 0) { MX(G_on(hs >= 0 ? S(hs) : stream, gs[0])); lo = 1; }   // not row-contiguous-eligible: beside the group
       MX(G_group(stream, gs + lo, nl - lo));
     } else {
-      static const int helper_par = getenv("MIMRL_WG_SPLIT_PARITY") ? atoi(getenv("MIMRL_WG_SPLIT_PARITY")) : 0;   // tuning knob
+      static const int helper_par = knob("MIMRL_WG_SPLIT_PARITY") ? atoi(knob("MIMRL_WG_SPLIT_PARITY")) : 0;   // tuning knob
       for (int q = top_wg ? 1 : 0; q < nl; ++q) MX(G_on((hs >= 0 && (q & 1) == helper_par) ? S(hs) : stream, gs[q]));
     }
     if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;
   }
-  static const bool no_big_side = getenv("MIMRL_NO_WG_BIG_SIDE") != nullptr;   // tuning knob
+  static const bool no_big_side = knob("MIMRL_NO_WG_BIG_SIDE") != nullptr;   // tuning knob
   const bool big_side = wgrad && multi_stream && !no_big_side && wg_helper >= 0 && rows >= 2048 && nl <= 3;
   for (int l = nl - 1; l >= 0; --l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
@@ -2131,8 +2131,8 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
   const int B = cfg.batch;
   const size_t BD = (size_t)B * EMB;
   const bool sep = cfg.critic_type == MIMRL_CRITIC_SEPARATE;
-  static const bool no_fused_mi = getenv("MIMRL_NO_FUSED_MI") != nullptr;        // tuning knobs
-  static const bool no_nce_tiled = getenv("MIMRL_NO_MI_NCE_TILED") != nullptr;
+  static const bool no_fused_mi = knob("MIMRL_NO_FUSED_MI") != nullptr;        // tuning knobs
+  static const bool no_nce_tiled = knob("MIMRL_NO_MI_NCE_TILED") != nullptr;
   const bool fused_mi = sep && !no_fused_mi && (prec & MIMRL_PREC_BF16_GEMM_FWD) && (prec & MIMRL_PREC_BF16_GEMM_BWD) && mi_sep_fused_supported(B);
   const bool nce_tiled = fused_mi && !no_nce_tiled && cfg.bound_type == MIMRL_BOUND_INFONCE && !has_baseline();
   {   // tower inputs: x operand -> slot 2e, y operand -> slot 2e+1
@@ -2402,7 +2402,7 @@ int mimrl_handle::route_feature_grads() {
   }
   // The F slot's sum is folded into head_bwd (its only consumer); T / A / V are needed only behind the CubeMLP backward: side 0,
   // off the chain (was one launch + a queue hop between the stage-2 estimators and the head: ~20 us)
-  static const bool no_head_gather = getenv("MIMRL_NO_HEAD_GATHER") != nullptr;   // tuning knob
+  static const bool no_head_gather = knob("MIMRL_NO_HEAD_GATHER") != nullptr;   // tuning knob
   head_gather_on = !no_head_gather && multi_stream && side_on(0);
   if (!head_gather_on) return gather_sum4(stream, g4, B, EMB);
   head_gather = g4.g[0];
@@ -2418,7 +2418,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   Range rg(stage == 1 ? "mimrl.estimators.stage1 (Model.py:305-341)" : "mimrl.estimators.stage2 (Model.py:343-386)");
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0 && !fp32_site(8), bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
-  static const bool imgt_first = getenv("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
+  static const bool imgt_first = knob("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
   bool imgT_pending = false;
   imgT_ready = false;
   if (frag_side_pending) { MX(join(3, 3)); frag_side_pending = false; }
@@ -2468,7 +2468,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     return MIMRL_OK;
   };
   // capture order of the two branches (graph nodes are dispatched in capture order; bit 0: stage 1, bit 1: stage 2 -> MI first)
-  static const int mi_first = getenv("MIMRL_EST_MI_FIRST") ? atoi(getenv("MIMRL_EST_MI_FIRST")) : 0;
+  static const int mi_first = knob("MIMRL_EST_MI_FIRST") ? atoi(knob("MIMRL_EST_MI_FIRST")) : 0;
   if ((mi_first >> (stage - 1)) & 1) { MX(mi_branch()); MX(cmi_branch()); }
   else { MX(cmi_branch()); MX(mi_branch()); }
   bf16 = bf_fwd;
@@ -2485,8 +2485,8 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   const bool have_banks = bank_rows > 0;
   if (!keep_events) ev_next = 0;
   if (stage == 1) {
-    static const bool no_share = getenv("MIMRL_NO_SHARED_PREFIX") != nullptr;   // tuning knob: evaluate the prefix twice
-    static const bool prefix_split = getenv("MIMRL_BEGIN_ON_SIDE") != nullptr;   // tuning knob
+    static const bool no_share = knob("MIMRL_NO_SHARED_PREFIX") != nullptr;   // tuning knob: evaluate the prefix twice
+    static const bool prefix_split = knob("MIMRL_BEGIN_ON_SIDE") != nullptr;   // tuning knob
     const bool share = prefetch && !no_share;
     // counters + scalar reset: the first consumers are the kNN sampler and the recurrence, both behind the join of side 4 in
     // encoders_forward -- in the shared-prefix step it runs on side 4 beside the input projections instead of in front of them
@@ -2496,7 +2496,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     // front of the recurrence reads the counters or the scalars -- the bookkeeping rides on it (one launch + one gap less on the chain)
     // (measured neutral, 0.970 vs 0.966 ms: the single-thread kernel hides in the gap between two graph launches -- opt-in)
     // (round 4, with the length scan on side 0: -4 us on average over four alternating runs, cfg3 neutral -- on by default; =0: the separate kernel)
-    static const bool want_begin_in_pack = !(getenv("MIMRL_BEGIN_IN_PACK") && atoi(getenv("MIMRL_BEGIN_IN_PACK")) == 0);   // tuning knob
+    static const bool want_begin_in_pack = !(knob("MIMRL_BEGIN_IN_PACK") && atoi(knob("MIMRL_BEGIN_IN_PACK")) == 0);   // tuning knob
     begin_in_pack = want_begin_in_pack && share && have_banks && skip_zero && !begin_on_side && l0_packed && cfg.encoder == MIMRL_ENCODER_GRU;
     if (!begin_in_pack) {
       hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, begin_on_side ? side[4] : stream, d_ints, have_banks ? d_ints + 2 : nullptr,
@@ -2506,7 +2506,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (!have_banks) return MIMRL_OK;
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-    static const bool pre_first = getenv("MIMRL_PREFETCH_FIRST") != nullptr;   // tuning knob: capture order of the two chains
+    static const bool pre_first = knob("MIMRL_PREFETCH_FIRST") != nullptr;   // tuning knob: capture order of the two chains
     auto issue_prefetch = [&](hipEvent_t e) -> int {
       // the stage-2 forward pass of this batch depends on nothing stage 1 changes: one sequential branch on its own
       // stream, into the primary buffers (stage 1 itself works on the alternate set)
@@ -2669,7 +2669,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   MX(adam_step(stream, a));
   if (stage == 1 && img_valid && crit_frag && ftab.n > 0) {
     // combined step: beside the stage boundary on side 3 (the stage-2 estimators join it before their first stack)
-    static const bool inline_frag = getenv("MIMRL_FRAG_INLINE") != nullptr;   // tuning knob
+    static const bool inline_frag = knob("MIMRL_FRAG_INLINE") != nullptr;   // tuning knob
     if (fuse_boundary && side_on(3) && !inline_frag) { MX(fork(3, 3)); MX(bf16_frag_images(side[3], bufs.crit_p, crit_frag, ftab)); frag_side_pending = true; }
     else MX(bf16_frag_images(stream, bufs.crit_p, crit_frag, ftab));
   }
@@ -2834,8 +2834,8 @@ int mimrl_handle::run_fwd2_tail() {
 //                            continuation first, the chain of dependent launches stays on one in-order queue.
 __global__ void graph_pad_kernel() {}
 static int graph_postprocess(hipGraph_t g) {
-  static const char* dot = getenv("MIMRL_GRAPH_DOT");
-  static const bool reorder = getenv("MIMRL_GRAPH_REORDER") != nullptr;
+  static const char* dot = knob("MIMRL_GRAPH_DOT");
+  static const bool reorder = knob("MIMRL_GRAPH_REORDER") != nullptr;
   if (reorder) {
     size_t nn = 0, ne = 0;
     HIPX(hipGraphGetNodes(g, nullptr, &nn));
@@ -2855,7 +2855,7 @@ static int graph_postprocess(hipGraph_t g) {
     std::vector<int> h(nn, -1);
     std::function<int(int)> height = [&](int v) -> int { if (h[v] >= 0) return h[v]; int m = 0; for (int c : out[v]) m = std::max(m, 1 + height(c)); return h[v] = m; };
     for (size_t v = 0; v < nn; ++v) height((int)v);
-    static const int mode = atoi(getenv("MIMRL_GRAPH_REORDER"));   // 1: by height; 2: the child captured on the parent's stream first
+    static const int mode = atoi(knob("MIMRL_GRAPH_REORDER"));   // 1: by height; 2: the child captured on the parent's stream first
     const auto& ns = capture_streams();
     auto stream_of = [&](int v) -> hipStream_t { auto it = ns.find(nodes[v]); return it == ns.end() ? (hipStream_t)-1 : it->second; };
     int changed = 0;
@@ -2863,12 +2863,12 @@ static int graph_postprocess(hipGraph_t g) {
       if (out[v].size() < 2) continue;
       std::vector<int> o = out[v];
       if (mode == 4) {   // MIMRL_GRAPH_PERM: digit i = which child of the i-th fork node comes first (0 = as captured)
-        static const char* perm = getenv("MIMRL_GRAPH_PERM");
+        static const char* perm = knob("MIMRL_GRAPH_PERM");
         static int fork_no = 0;
         int k = perm && fork_no < (int)strlen(perm) ? (perm[fork_no] >= 'a' ? perm[fork_no] - 'a' + 10 : perm[fork_no] - '0') : 0;
         ++fork_no;
         if (k > 0 && k < (int)o.size()) { const int c = o[k]; o.erase(o.begin() + k); o.insert(o.begin(), c); }   // child k first, the others keep their order
-        if (getenv("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] fork %d: node %zu, %zu children\n", fork_no - 1, v, o.size());
+        if (knob("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] fork %d: node %zu, %zu children\n", fork_no - 1, v, o.size());
       } else if (mode >= 2) {
         const hipStream_t ps = stream_of((int)v);
         if (ps == (hipStream_t)-1) continue;
@@ -2880,7 +2880,7 @@ static int graph_postprocess(hipGraph_t g) {
       // them from queue s + 1 to s + 1 + k (k cycles 0, 1, 2 over the forks; MIMRL_GRAPH_PAD=<list of k per fork> overrides)
       int pads = 0;
       if (mode == 3 && stream_of(o[0]) == stream_of((int)v)) {
-        static const char* padlist = getenv("MIMRL_GRAPH_PAD");
+        static const char* padlist = knob("MIMRL_GRAPH_PAD");
         static int fork_no = 0;
         pads = padlist && fork_no < (int)strlen(padlist) ? padlist[fork_no] - '0' : fork_no % 3;
         ++fork_no;
@@ -2902,7 +2902,7 @@ static int graph_postprocess(hipGraph_t g) {
       if (!t.empty()) HIPX(hipGraphAddDependencies(g, f.data(), t.data(), t.size()));
       ++changed;
     }
-    if (getenv("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] %zu nodes, %zu edges, %d fork nodes re-ordered\n", nn, ne, changed);
+    if (knob("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] %zu nodes, %zu edges, %d fork nodes re-ordered\n", nn, ne, changed);
   }
   if (dot) HIPX(hipGraphDebugDotPrint(g, dot, hipGraphDebugDotFlagsVerbose));
   return MIMRL_OK;
@@ -2913,7 +2913,7 @@ static int graph_postprocess(hipGraph_t g) {
 int mimrl_handle::run_step() {
   Range rg("mimrl.two_stage_step (Solver.step)");
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
-  static const bool no_step_graph = getenv("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
+  static const bool no_step_graph = knob("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
   const bool combined = cfg.use_graph && !prof_on && prefetch && !defer_tail && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
   if (!combined) { MX(run(1, 0)); if (defer_tail) MX(run_fwd2_tail()); return run(2, 0); }
   MX(ensure_images());
@@ -2926,11 +2926,11 @@ int mimrl_handle::run_step() {
   hipGraphExec_t& ex = GS().graph[0][0];
   if (ex && GS().rows[0][0] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
   if (!ex) {
-    static const bool no_boundary = getenv("MIMRL_NO_FUSED_BOUNDARY") != nullptr;   // tuning knob: the round-1 stage boundary
+    static const bool no_boundary = knob("MIMRL_NO_FUSED_BOUNDARY") != nullptr;   // tuning knob: the round-1 stage boundary
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-    capture_track(getenv("MIMRL_GRAPH_REORDER") != nullptr);
+    capture_track(knob("MIMRL_GRAPH_REORDER") != nullptr);
     stream = cap_stream;
     fuse_boundary = !no_boundary; skip_imgT_refresh = use_imgT && !no_boundary; wtT_prebuilt = bf_bwd && fused_cube_bwd && !no_boundary;
     wtT_built = false;
@@ -3003,6 +3003,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
                        "(rebuild with `make DEBUG_KNOBS=1` for timing experiments; never for real runs)", kDebugKnobs[i]);
 #endif
   MX(mimrl_device_check());
+  if (knob_on("MIMRL_KNOBS")) knobs_print(stderr);
   mimrl_handle* h = new (std::nothrow) mimrl_handle();
   if (!h) return set_error(MIMRL_ERR_STATE, "out of host memory");
   h->cfg = *cfg;
@@ -3010,31 +3011,31 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   if (h->cfg.beta2 == 0.f) h->cfg.beta2 = 0.999f;
   if (h->cfg.adam_eps == 0.f) h->cfg.adam_eps = 1e-8f;
   h->stream = h->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
-  h->multi_stream = getenv("MIMRL_SINGLE_STREAM") == nullptr;
+  h->multi_stream = knob("MIMRL_SINGLE_STREAM") == nullptr;
 #ifdef MIMRL_DET
   h->multi_stream = false;   // deterministic build: one stream, so the flush behind a launch never meets a half-finished producer (det.h)
   MX(det_init());
 #endif
-  h->fused_cube = getenv("MIMRL_NO_FUSED_CUBE") == nullptr;
-  h->fused_mlp = getenv("MIMRL_NO_FUSED_MLP") == nullptr;
-  h->knn_pre = getenv("MIMRL_NO_KNN_PREFETCH") == nullptr;
-  h->fold_unpack_on = getenv("MIMRL_NO_FOLD_UNPACK") == nullptr;
-  h->h16_on = getenv("MIMRL_NO_H16") == nullptr;
-  h->xin_on = getenv("MIMRL_NO_XIN") == nullptr;
-  h->fused_cube_bwd = getenv("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
-  h->fused_concat = getenv("MIMRL_NO_FUSED_CONCAT") == nullptr;
-  h->fwd_f16 = getenv("MIMRL_FWD_BF16") == nullptr;
+  h->fused_cube = knob("MIMRL_NO_FUSED_CUBE") == nullptr;
+  h->fused_mlp = knob("MIMRL_NO_FUSED_MLP") == nullptr;
+  h->knn_pre = knob("MIMRL_NO_KNN_PREFETCH") == nullptr;
+  h->fold_unpack_on = knob("MIMRL_NO_FOLD_UNPACK") == nullptr;
+  h->h16_on = knob("MIMRL_NO_H16") == nullptr;
+  h->xin_on = knob("MIMRL_NO_XIN") == nullptr;
+  h->fused_cube_bwd = knob("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
+  h->fused_concat = knob("MIMRL_NO_FUSED_CONCAT") == nullptr;
+  h->fwd_f16 = knob("MIMRL_FWD_BF16") == nullptr;
   // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches: the four layer-0
   // weight-gradient GEMMs in a row are what closes the stage behind the BPTT.  (History: before the parked CubeMLP weight gradients
   // became two grouped launches the side streams were the bottleneck and packing lost at cfg2, 1.34 vs 1.32 ms; since then it
   // wins, 1.14 vs 1.18 ms.)  MIMRL_L0_PACK=0 / 1 forces it.
-  h->l0_packed = getenv("MIMRL_L0_PACK") ? atoi(getenv("MIMRL_L0_PACK")) != 0 : true;
+  h->l0_packed = knob("MIMRL_L0_PACK") ? atoi(knob("MIMRL_L0_PACK")) != 0 : true;
   // (inputs packed on side 0, only the layer-0 weight gradients batched: MIMRL_L0_BWD_PACK=1 with MIMRL_L0_PACK=0; 1.15 ms at cfg2)
   // dg[B,T,4H] / h_prev are consumed only by GEMMs that round their operands to bf16 anyway: storing them as bf16 changes no
   // number in this mode and halves what the BPTT writes and the weight-gradient / dh0 products read
   h->dg_bf16 = cfg->encoder == MIMRL_ENCODER_GRU && (cfg->precision & MIMRL_PREC_BF16_GRU_BWD) && (cfg->precision & MIMRL_PREC_BF16_GEMM_BWD) &&
-               getenv("MIMRL_DG_FP32") == nullptr;
-  h->l0_bwd_pack = getenv("MIMRL_L0_BWD_PACK") ? atoi(getenv("MIMRL_L0_BWD_PACK")) != 0 : false;
+               knob("MIMRL_DG_FP32") == nullptr;
+  h->l0_bwd_pack = knob("MIMRL_L0_BWD_PACK") ? atoi(knob("MIMRL_L0_BWD_PACK")) != 0 : false;
   // gx[B,T,3H] -- written once by the input projection, read once by the recurrence -- as fp16 (MIMRL_GX_F16=1; OFF by default).  Round 4
   // built it for cfg3, whose two projections on the chain are bound by 786 MB of fp32 stores each (449 / 302 us), and measured a LOSS:
   // 7.24 against 6.83 ms per step.  The accumulator layout gives a lane one column of 16 rows, so an fp16 store instruction writes two
@@ -3042,7 +3043,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   // and written back as whole rows -- a different epilogue.  The path stays (tests/test_gpu_fused_oracle.py holds it to the rounded oracle).
   {
     const bool can = cfg->encoder == MIMRL_ENCODER_GRU && (cfg->precision & MIMRL_PREC_BF16_GRU_FWD) && (cfg->precision & MIMRL_PREC_BF16_GEMM_FWD);
-    h->gx_f16 = can && getenv("MIMRL_GX_F16") && atoi(getenv("MIMRL_GX_F16")) != 0;
+    h->gx_f16 = can && knob("MIMRL_GX_F16") && atoi(knob("MIMRL_GX_F16")) != 0;
   }
   if (cfg->encoder == MIMRL_ENCODER_GRU && ((cfg->precision & MIMRL_PREC_BF16_GRU_FWD) != 0) != ((cfg->precision & MIMRL_PREC_BF16_GRU_BWD) != 0)) {
     mimrl_destroy(h);   // the forward kernel writes the gate slab in the format (bf16 / fp32 records) the BPTT kernel of the SAME mode reads
@@ -3383,7 +3384,7 @@ int mimrl_set_comm(mimrl_handle* h, const void* unique_id128, int world, int ran
   MX(mimrl::comm_init(&h->comm, unique_id128, world, rank));
   h->comm_world = world; h->comm_rank = rank;
   if (!h->comm_s) HIPX(hipStreamCreateWithFlags(&h->comm_s, hipStreamNonBlocking));
-  const char* sp = getenv("MIMRL_DDP_SPLIT");
+  const char* sp = knob("MIMRL_DDP_SPLIT");
   h->comm_split = !(sp && sp[0] == '0');
   // one eager collective now: RCCL's lazy set-up (buffers, proxy threads) must not happen inside a stream capture
   if (h->bound) {

@@ -797,7 +797,7 @@ static bool plain_accumulate(const GemmDesc& d) {
 
 // fast-path eligibility and tile shape; returns false when the generic kernel has to take the GEMM
 static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
-  static const int no_fast = getenv("MIMRL_GEMM_NO_FAST") != nullptr;   // tuning knob
+  static const int no_fast = knob("MIMRL_GEMM_NO_FAST") != nullptr;   // tuning knob
   if (!bf16 || no_fast) return false;
   const int ca = fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16, d.a_pad4), cb = fast_class(d.B, d.sb_n, d.sb_k, d.sb_b, d.sb_bo, d.N, d.K, d.b_bf16);
   if (!ca || !cb || (ca == 2 && cb == 1)) return false;
@@ -824,7 +824,7 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
     const int tm = cand[c][0], tn = cand[c][1];
     if (d.M < 64 * tm || d.N < 64 * tn) continue;
     const long t = tiles(tm, tn);
-    static const long min_wgs = getenv("MIMRL_GEMM_MIN_WGS") ? atol(getenv("MIMRL_GEMM_MIN_WGS")) : 700;   // tuning knob.  Round 3b: 224 -> 700 (cfg2, 4 interleaved runs each: 0.906-0.912 -> 0.886-0.901 ms; 1000 / 1250 the same): a workgroup is a serial prologue - loop - epilogue and a CU overlaps them only ACROSS workgroups, so ~3 per CU beat ~2 larger ones
+    static const long min_wgs = knob("MIMRL_GEMM_MIN_WGS") ? atol(knob("MIMRL_GEMM_MIN_WGS")) : 700;   // tuning knob.  Round 3b: 224 -> 700 (cfg2, 4 interleaved runs each: 0.906-0.912 -> 0.886-0.901 ms; 1000 / 1250 the same): a workgroup is a serial prologue - loop - epilogue and a CU overlaps them only ACROSS workgroups, so ~3 per CU beat ~2 larger ones
     // (not for split-K accumulations over a long reduction: at cfg3's K = 128,000 rows smaller tiles mean more splits and more atomics,
     //  7.11 -> 7.52 ms with 700 for all)
     if (t * split(t) >= ((acc && ktiles > 1024) ? 224 : min_wgs) || c == 2) { pick = c; break; }
@@ -840,13 +840,13 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   p->fast = 0; p->tm = p->tn = 1; p->ca = p->cb = 0;
   if (fast_plan(d, bf16, p)) return;
-  static const int no_lean = getenv("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knobs
-  static const int no_big = getenv("MIMRL_GEMM_NO_BK128") != nullptr;
+  static const int no_lean = knob("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knobs
+  static const int no_big = knob("MIMRL_GEMM_NO_BK128") != nullptr;
   const bool va = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0, vb = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
   const bool va2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : true, vb2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : true;
   // lean = 16-byte loads only.  Ragged M / N are fine for k-contiguous operands (rows are clamped in the loader).
   const bool a_kfast = d.sa_k == 1 && (!d.A2 || d.sa2_k == 1), b_kfast = d.sb_k == 1 && d.sb_n != 1 && (!d.B2 || (d.sb2_k == 1 && d.sb2_n != 1));
-  static const int no_ragged = getenv("MIMRL_GEMM_NO_RAGGED") != nullptr;
+  static const int no_ragged = knob("MIMRL_GEMM_NO_RAGGED") != nullptr;
   const bool lean = bf16 && !no_lean && (d.M % BM == 0 || (a_kfast && !no_ragged)) && (d.N % BN == 0 || (b_kfast && !no_ragged)) &&
                     va && vb && va2 && vb2 && d.K >= 64;
   const long tiles = (long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
@@ -867,7 +867,7 @@ void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
 }
 
 int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
-  static const int no_group = getenv("MIMRL_GEMM_NO_GROUP") != nullptr;   // tuning knob
+  static const int no_group = knob("MIMRL_GEMM_NO_GROUP") != nullptr;   // tuning knob
   bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUP_MAX;
   int ca = 0, cb = 0;
   long total = 0;
@@ -900,7 +900,7 @@ int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
 }
 
 int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
-  static const int no_group = getenv("MIMRL_GEMM_NO_GROUPK") != nullptr;   // tuning knob
+  static const int no_group = knob("MIMRL_GEMM_NO_GROUPK") != nullptr;   // tuning knob
   bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUPK_MAX;
   int ca = 0, cb = 0;
   long tiles = 0;
@@ -965,7 +965,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (bf16 && gemm_tall_tn_ok(d)) return gemm_tall_tn(s, d);   // ... and tall reductions (weight gradients over B*T rows)
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
-  static const bool trace = getenv("MIMRL_GEMM_TRACE") != nullptr;   // diagnostic: which products miss the fast path, and why
+  static const bool trace = knob("MIMRL_GEMM_TRACE") != nullptr;   // diagnostic: which products miss the fast path, and why
   if (trace && bf16 && !pl.fast)
     fprintf(stderr, "[gemm] generic: M %d N %d K %d batch %d | A %p sa %ld %ld %ld cls %d | B %p sb %ld %ld %ld cls %d | A2 %d K2 %d bias_m %d beta %g pre %d gu %d atomic %d\n",
             d.M, d.N, d.K, d.batch, (const void*)d.A, d.sa_m, d.sa_k, d.sa_b, fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16),
@@ -979,7 +979,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   ka.vec_b = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
   ka.vec_a2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : 1;
   ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
-  static const int no_xcd = getenv("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
+  static const int no_xcd = knob("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
   ka.xcd_remap = !no_xcd;
   static const int dbg_gemm = dbg_env("MIMRL_DBG_GEMM") ? atoi(dbg_env("MIMRL_DBG_GEMM")) : 0;
   ka.dbg = dbg_gemm;

@@ -425,9 +425,9 @@ __global__ __launch_bounds__(512, 4) void gemm_tall_tn_kernel(TallTnArgs a) {
 bool gemm_tall_ok(const GemmDesc& d) {
   // tuning knobs, read per call (a handful of launches per captured step) so that one test process can run both paths:
   // MIMRL_NO_GEMM_TALL=1 the 128x128 register-staged kernels as before; MIMRL_GEMM_TALL_MIN_M=<rows> the row threshold (default 16384)
-  const char* e_off = getenv("MIMRL_NO_GEMM_TALL");
+  const char* e_off = knob("MIMRL_NO_GEMM_TALL");
   const bool off = e_off != nullptr && e_off[0] != '0';
-  const char* e_min = getenv("MIMRL_GEMM_TALL_MIN_M");
+  const char* e_min = knob("MIMRL_GEMM_TALL_MIN_M");
   const long min_m = e_min ? atol(e_min) : 16384;
   if (off || !d.a_bf16 || !d.b_bf16 || d.M < min_m) return false;
   if (d.sa_k != 1 || d.sb_k != 1 || d.sc_n != 1) return false;
@@ -496,9 +496,9 @@ int gemm_tall(hipStream_t s, const GemmDesc& d) {
 bool gemm_tall_tn_ok(const GemmDesc& d) {
   // OPT-IN (MIMRL_GEMM_TALL_TN=1): measured on cfg3's four recurrence weight gradients it ties the 128 x 128 register-staged split-K
   // kernel (dW_hh 128 vs 137 us, dW_ih 267 vs 230 us alone; 6.20 vs 6.12-6.21 ms per step) -- see DESIGN "measured and not kept"
-  const char* e_on = getenv("MIMRL_GEMM_TALL_TN");
+  const char* e_on = knob("MIMRL_GEMM_TALL_TN");
   if (e_on == nullptr || e_on[0] == '0') return false;
-  const char* e_min = getenv("MIMRL_GEMM_TALL_TN_MIN_K");
+  const char* e_min = knob("MIMRL_GEMM_TALL_TN_MIN_K");
   const long min_k = e_min ? atol(e_min) : 16384;
   if (!d.a_bf16 || !d.b_bf16 || d.f16 || d.K < min_k) return false;
   if (d.sa_m != 1 || d.sb_n != 1 || d.sc_n != 1) return false;                    // A[k][m], B[k][n], C[m][n]

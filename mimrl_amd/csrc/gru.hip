@@ -776,13 +776,13 @@ int gru_bwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SY
 // barrier 0.06, the stores 0.06, the six transcendentals 0.04, the operand loads 0.02 -- and 0.2 us are neither (address / select / wait
 // instructions of the step itself).  Default stays 4.
 static int gru_upl() {
-  static const int waves = getenv("MIMRL_GRU_WAVES") ? atoi(getenv("MIMRL_GRU_WAVES")) : 4;   // tuning knob
+  static const int waves = knob("MIMRL_GRU_WAVES") ? atoi(knob("MIMRL_GRU_WAVES")) : 4;   // tuning knob
   return waves == 8 ? 1 : 2;
 }
 
 static int gru_skip() {
 #ifdef MIMRL_PHASE_PROBE
-  static const int v = getenv("MIMRL_GRU_SKIP") ? atoi(getenv("MIMRL_GRU_SKIP")) : 0;
+  static const int v = knob("MIMRL_GRU_SKIP") ? atoi(knob("MIMRL_GRU_SKIP")) : 0;
   return v;
 #else
   return 0;
@@ -881,7 +881,7 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   // its SIMDs: alone the two launches take 45 + 48 us, with the parked kernels on the same CUs 51 + 66 us.  cfg2: 0.916-0.917 -> 0.907-0.911 ms
   // per step.  Larger launches keep their CUs shareable (at cfg3 every CU has a BPTT workgroup and the parked work needs a place).
   // MIMRL_GRU_LDS_PAD=<KiB> overrides (0 = off).
-  static const int pad_env = getenv("MIMRL_GRU_LDS_PAD") ? atoi(getenv("MIMRL_GRU_LDS_PAD")) : -1;
+  static const int pad_env = knob("MIMRL_GRU_LDS_PAD") ? atoi(knob("MIMRL_GRU_LDS_PAD")) : -1;
   const int pad_kb = pad_env >= 0 ? pad_env : ((long)grid.x * grid.y * grid.z <= 128 ? 144 : 0);
   const size_t pad = bf16 && a.dg_bf16 && pad_kb > 0 ? (size_t)(pad_kb > 150 ? 150 : pad_kb) * 1024 : 0;
 #ifdef MIMRL_PHASE_PROBE
@@ -923,7 +923,7 @@ long gru_saved_floats(int B, int T) {
 }
 
 int gru_pick_btv(int B, int nmod) {
-  static const int force = getenv("MIMRL_GRU_BTV") ? atoi(getenv("MIMRL_GRU_BTV")) : 0;   // tuning knob
+  static const int force = knob("MIMRL_GRU_BTV") ? atoi(knob("MIMRL_GRU_BTV")) : 0;   // tuning knob
   if (force >= 1 && force <= BR) return force;
   int btv = (B * nmod * 2 + 127) / 128;      // ~128 workgroups (measured best at B=128: 4 rows per workgroup)
   if (btv < 1) btv = 1;

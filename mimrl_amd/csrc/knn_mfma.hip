@@ -567,7 +567,7 @@ KnnPlan knn_plan(int N, int m, int k) {
   p.NTW = (NT + p.S - 1) / p.S;
   p.RP = 4 / p.S;
   const int pairs = (N + 31) / 32;
-  static const int target = getenv("MIMRL_KNN_WGS") ? atoi(getenv("MIMRL_KNN_WGS")) : 512;   // tuning knob: workgroups per launch
+  static const int target = knob("MIMRL_KNN_WGS") ? atoi(knob("MIMRL_KNN_WGS")) : 512;   // tuning knob: workgroups per launch
   int ppw = (int)(((long)pairs * std::max(nwide, 1) * p.nab + (long)p.RP * target - 1) / ((long)p.RP * target));
   ppw = std::max(1, std::min(ppw, MAXW / p.RP));
   p.ppw = ppw;
@@ -602,7 +602,7 @@ int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch, size_t scratch_by
   const size_t shb = mask_b + AT * 256 * sizeof(float) + AT * 256 * (size_t)K * (sizeof(float) + sizeof(int));   // exact-scan kernel
   if (shb > 150 * 1024) return set_error(MIMRL_ERR_ARG, "knn: bank too large for the LDS bitmask (N=%d)", a.N);
   const dim3 mgrid((a.m + AT - 1) / AT, a.ncall);
-  static const bool force_brute = getenv("MIMRL_KNN_BRUTE") != nullptr;   // tuning / cross-check knob: the round-1 exact scan for every call
+  static const bool force_brute = knob("MIMRL_KNN_BRUTE") != nullptr;   // tuning / cross-check knob: the round-1 exact scan for every call
   // k > 4 (no BASELINE configuration; the reference's default is k = 2): the exact scan -- a k + 2 = 10-deep register list per lane and
   // tile makes the tile kernel's epilogue the bottleneck (and costs minutes of compile time)
   if (generic || force_brute || a.k > 4) {

@@ -994,7 +994,7 @@ static bool mlp_direct(const MlpFusedArgs& a) {
 // few workgroups (latency-bound stack): the 8-wave kernel with the register-resident, prefetched weight tile.  Every reduction
 // width must be a whole number of 8-element pieces (16-byte loads) or < 16 (the FMA path).
 static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wave kernel), or the register chunks needed: 4 / 6
-  static const int waves = getenv("MIMRL_MLP_IMG_WAVES") ? atoi(getenv("MIMRL_MLP_IMG_WAVES")) : 0;   // tuning knob: 4 = never, 8 = both directions
+  static const int waves = knob("MIMRL_MLP_IMG_WAVES") ? atoi(knob("MIMRL_MLP_IMG_WAVES")) : 0;   // tuning knob: 4 = never, 8 = both directions
   if (waves == 4) return 0;
   const long wgs = (long)((a.rows + RT - 1) / RT) * a.nb;
   if (wgs > 512) return 0;
@@ -1013,7 +1013,7 @@ static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wa
 
 // the fragment-image kernel takes: 4 layers, hidden 256, inputs 128 / 384, outputs 128 / 2 / 1, few workgroups; -> 0 or an id
 static int mlp_frag_shape(const MlpFusedArgs& a, bool bwd) {
-  const bool off = getenv("MIMRL_MLP_NO_FRAG") != nullptr;    // tuning knob: the round-2 kernels (read per call: tests/test_gpu_fused_oracle.py toggles it)
+  const bool off = knob("MIMRL_MLP_NO_FRAG") != nullptr;    // tuning knob: the round-2 kernels (read per call: tests/test_gpu_fused_oracle.py toggles it)
   if (off || a.nl != 4 || !(bwd ? a.WfT[1] : a.Wf[0]) || !a.Wb[3]) return 0;
   if (a.dims[1] != FR_HID || a.dims[2] != FR_HID || a.dims[3] != FR_HID) return 0;
   const long wgs = (long)((a.rows + RT - 1) / RT) * a.nb;

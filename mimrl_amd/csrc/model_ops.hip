@@ -964,10 +964,10 @@ int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const f
   const long rows = (long)B * T;
   const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, dmean_a};
   const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v};
-  static const bool old_kernel = getenv("MIMRL_LN_BWD_WAVE_ROWS") != nullptr;   // tuning knob: the one-row-per-wave kernel of round 2
+  static const bool old_kernel = knob("MIMRL_LN_BWD_WAVE_ROWS") != nullptr;   // tuning knob: the one-row-per-wave kernel of round 2
   if (old_kernel) hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   else {
-    static const int cap = getenv("MIMRL_LN_BWD_BLOCKS") ? atoi(getenv("MIMRL_LN_BWD_BLOCKS")) : 128;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)
+    static const int cap = knob("MIMRL_LN_BWD_BLOCKS") ? atoi(knob("MIMRL_LN_BWD_BLOCKS")) : 128;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)
     hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, cap), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   }
   LAUNCH_CHECK();
@@ -1098,7 +1098,7 @@ int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
-  static const int wgs = getenv("MIMRL_KMIX_BWD_WGS") ? atoi(getenv("MIMRL_KMIX_BWD_WGS")) : 512;   // tuning knob
+  static const int wgs = knob("MIMRL_KMIX_BWD_WGS") ? atoi(knob("MIMRL_KMIX_BWD_WGS")) : 512;   // tuning knob
   const bool exact3 = w.ik == 3 && w.hk == 3 && w.ok == 3 && !w.ln_first && w.drop_p <= 0.f;
   if (exact3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0, true>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   else if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
@@ -1113,7 +1113,7 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
   if (part == 1) {
-    static const int dx_wgs = getenv("MIMRL_KMIX_DX_WGS") ? atoi(getenv("MIMRL_KMIX_DX_WGS")) : 4096;   // tuning knob
+    static const int dx_wgs = knob("MIMRL_KMIX_DX_WGS") ? atoi(knob("MIMRL_KMIX_DX_WGS")) : 4096;   // tuning knob
     const dim3 grid(grid_for(R * D, 256, dx_wgs));
     if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
@@ -1123,7 +1123,7 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
     // atomics) + ~25 us of element work at cfg2; 256 workgroups is the measured optimum (128: 67 us, 256: 53 us, 512: 75 us).  A
     // two-level reduction through scratch slots with a last-arriver finisher was tried and lost (the __threadfence it needs is an
     // L2 write-back on this multi-XCD part: 157 us).
-    static const int pg_wgs = getenv("MIMRL_KMIX_PG_WGS") ? atoi(getenv("MIMRL_KMIX_PG_WGS")) : 256;
+    static const int pg_wgs = knob("MIMRL_KMIX_PG_WGS") ? atoi(knob("MIMRL_KMIX_PG_WGS")) : 256;
     const int cap = pg_wgs > 0 ? pg_wgs : 256;
     const dim3 grid(grid_for(R * D, 256, cap));
     if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);

@@ -69,3 +69,24 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(_lib.MimrlError):
         HipEngine(make_opt(CONFIGS["tiny_sep"]), 768, 74, 35)
     assert _lib.load().mimrl_device_check() < 0
+
+
+def test_every_knob_is_in_the_table():
+    """csrc/knobs.cpp is the ONE table of the native library's environment knobs: every knob("MIMRL_...") /
+    knob_on / knob_int site names a registered knob, no raw getenv("MIMRL_...") is left outside the debug-knob accessor of common.h,
+    and every registered name is read somewhere."""
+    import glob
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimrl_amd", "csrc")
+    table_src = open(os.path.join(csrc, "knobs.cpp")).read()
+    table = set(re.findall(r'^\s*\{"(MIMRL_[A-Z0-9_]+)",', table_src, re.M))
+    assert len(table) > 80
+    used = set()
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")):
+        if f.endswith("knobs.cpp"):
+            continue
+        s = open(f).read()
+        assert 'getenv("MIMRL_' not in s, f
+        used |= set(re.findall(r'knob(?:_on|_int)?\("(MIMRL_[A-Z0-9_]+)"', s))
+    assert used <= table, sorted(used - table)
+    assert table - used <= {"MIMRL_KNOBS"}, sorted(table - used)
