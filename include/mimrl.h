@@ -209,7 +209,7 @@ int mimrl_op_gemm_ex(void* stream, const float* A, const float* B, float* C, int
  * batch of the engine's projections: entry b = (b / batch_in, b % batch_in), outer strides strides_bo = {sa_bo, sb_bo, sc_bo, bias_n_bo, bias_n_b}
  * (batch_in = 0: flat batch, only bias_n_b is read; NULL = all zero).  flags: bit 0 A stored 16-bit, bit 1 B stored 16-bit, bit 2 the 16-bit type is fp16 (else bf16), bit 3 C is
  * stored as fp16 (strides in fp16 elements), bit 4 accumulate into C with float atomics (weight gradients: C must be zeroed by the caller),
- * bits 8-19 / 20-31 the A-row gap of mimrl_op_gemm_ex (a_gap_at / a_gap_rows).  Tall k-contiguous products (M >= 16384, both operands stored) and tall
+ * bits 8-19 / 20-31 the A-row gap of mimrl_op_gemm_ex (a_gap_at / a_gap_rows).  Tall k-contiguous products (M >= 4096, both operands stored) and tall
  * row-contiguous reductions (K >= 16384, atomic) take the LDS-DMA kernels of csrc/gemm_tall.hip -- the GRU layer-1 input projection and its data gradient dh0 at cfg3 (Model.py:254-255 and autograd). */
 int mimrl_op_gemm16(void* stream, const void* A, const void* B, void* C, int M, int N, int K, int batch, const int64_t strides[9],
                     const void* A2, const void* B2, int K2, const int64_t strides2[6], int batch_in, const int64_t strides_bo[5],

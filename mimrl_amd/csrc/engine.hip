@@ -1029,7 +1029,7 @@ int mimrl_handle::lstm_encoders_forward(bool save, int knn_stage) {
   MX(join(2, 2));
   MX(join(4, 4));
   if (knn_stage) { MX(fork(4, 4)); MX(knn_launch(knn_stage, S(4))); }
-  { Scope sc(this, MIMRL_PH_GRU_FWD); MX(lstm_forward(stream, a)); }
+  { Scope sc(this, MIMRL_PH_GRU_FWD); MX(lstm_forward(stream, a, (prec & MIMRL_PREC_BF16_GRU_FWD) ? 2 : 1)); }
   return MIMRL_OK;
 }
 
@@ -1044,7 +1044,7 @@ int mimrl_handle::lstm_encoders_backward() {
     for (int d = 0; d < 2; ++d)
       a.seq[m][d] = LstmSeqBwd{P(gru[m][0][d].w_hh), sv[0][m][d], h1[m], ds[m], dg[0][m][d], hprev[0][m][d]};
   }
-  { Scope sc(this, MIMRL_PH_GRU_BWD); MX(lstm_backward(stream, a)); }
+  { Scope sc(this, MIMRL_PH_GRU_BWD); MX(lstm_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) ? 2 : 1)); }
   MX(fork(1, 3));
   int rr = 0;
   for (int m = 0; m < 2; ++m)
@@ -1839,7 +1839,7 @@ int mimrl_handle::gru_layer_backward(int l) {
         if (lbf && w1_img_valid && h16_on && w1b) {   // the weights from the bf16 image of this step's forward pass: half the B bytes
           q.B = reinterpret_cast<const float*>(w1b); q.B2 = reinterpret_cast<const float*>(w1b + (long)G * 2 * H);
           q.b_bf16 = 1; q.sb_b = 2L * G * 2 * H; q.sb2_b = 2L * G * 2 * H;
-          // long sequences (B * T >= 16384 rows): both operands k-contiguous -- the transposed image of the same bf16 values, the two
+          // B * T >= 4096 rows: both operands k-contiguous -- the transposed image of the same bf16 values, the two
           // directions as two k-segments of one [256, 768] matrix per modality -- so that the LDS-DMA kernel of gemm_tall.hip takes it
           if (w1bt) {
             GemmDesc t = q;

@@ -82,7 +82,7 @@ struct GemmPlan {
 };
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p);
 int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
-// gemm_tall.hip: C[M, N] = A[M, K] . W[N, K]^T (+ A2 . W2^T) (+ bias_n) for M >= 16384 with BOTH operands stored in 16 bits and k-contiguous
+// gemm_tall.hip: C[M, N] = A[M, K] . W[N, K]^T (+ A2 . W2^T) (+ bias_n) for M >= 4096 with BOTH operands stored in 16 bits and k-contiguous
 // (a_bf16 = b_bf16 = 1, sa_k = sb_k = 1; bf16, or fp16 with f16 = 1), plain epilogue, fp32 or fp16 (c_f16) output: 256 x 128 tiles, 3-stage
 // LDS ring filled by LDS-DMA.  gemm() routes there by itself; gemm_tall_ok() is the eligibility test.
 bool gemm_tall_ok(const GemmDesc& d);

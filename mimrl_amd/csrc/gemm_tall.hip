@@ -18,7 +18,7 @@
 //   * epilogue straight from the accumulators: lane = output column, one store instruction = 2 rows x 128 B, full lines (a transposed
 //     product with 16-byte stores per lane was tried first: 32 partial lines per instruction, 7.9 us of store ISSUE per 128 KB tile);
 //   * tile ids are dealt so that the column groups of one 256-row block run at the same time on ONE XCD: A leaves HBM once.
-// Dispatched by gemm() for (k-contiguous, k-contiguous) 16-bit-stored operands with a plain epilogue when M >= 16384.
+// Dispatched by gemm() for (k-contiguous, k-contiguous) 16-bit-stored operands with a plain epilogue when M >= 4096.
 #include "gemm.h"
 
 #include <type_traits>
@@ -424,11 +424,11 @@ __global__ __launch_bounds__(512, 4) void gemm_tall_tn_kernel(TallTnArgs a) {
 
 bool gemm_tall_ok(const GemmDesc& d) {
   // tuning knobs, read per call (a handful of launches per captured step) so that one test process can run both paths:
-  // MIMRL_NO_GEMM_TALL=1 the 128x128 register-staged kernels as before; MIMRL_GEMM_TALL_MIN_M=<rows> the row threshold (default 16384)
+  // MIMRL_NO_GEMM_TALL=1 the 128x128 register-staged kernels as before; MIMRL_GEMM_TALL_MIN_M=<rows> the row threshold (default 4096)
   const char* e_off = knob("MIMRL_NO_GEMM_TALL");
   const bool off = e_off != nullptr && e_off[0] != '0';
   const char* e_min = knob("MIMRL_GEMM_TALL_MIN_M");
-  const long min_m = e_min ? atol(e_min) : 16384;
+  const long min_m = e_min ? atol(e_min) : 4096;   // (cfg2: B * T = 6400 rows -- 0.801-0.811 vs 0.813-0.825 ms per step against the 128x128 kernels)
   if (off || !d.a_bf16 || !d.b_bf16 || d.M < min_m) return false;
   if (d.sa_k != 1 || d.sb_k != 1 || d.sc_n != 1) return false;
   if (d.K % TBK != 0 || d.K <= 0 || d.N < 32) return false;

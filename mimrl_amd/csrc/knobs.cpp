@@ -36,7 +36,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_GEMM_NO_LEAN", "gemm.hip", "", "generic GEMM: no 16-byte-load (lean) instantiations"},
   {"MIMRL_GEMM_NO_RAGGED", "gemm.hip", "", "generic GEMM: lean kernels only for tile-aligned M / N"},
   {"MIMRL_GEMM_NO_XCD", "gemm.hip", "", "no XCD-aware tile order in the GEMM kernels"},
-  {"MIMRL_GEMM_TALL_MIN_M", "gemm_tall.hip", "", "row threshold of the tall LDS-DMA GEMM (default 16384)"},
+  {"MIMRL_GEMM_TALL_MIN_M", "gemm_tall.hip", "", "row threshold of the tall LDS-DMA GEMM (default 4096)"},
   {"MIMRL_GEMM_TALL_TN", "gemm_tall.hip", "", "1: tall weight-gradient LDS-DMA kernel on (opt-in: ties the split-K kernel)"},
   {"MIMRL_GEMM_TALL_TN_MIN_K", "gemm_tall.hip", "", "reduction-length threshold of the tall weight-gradient kernel (default 16384)"},
   {"MIMRL_GEMM_TRACE", "gemm.hip", "", "diagnostic: which products miss the fast path, and why"},
@@ -63,6 +63,8 @@ const KnobDef kKnobs[] = {
   {"MIMRL_LENS_SIDE0", "engine.hip", "", "0: sequence-length scan on side 4 in front of the layer-0 projection instead of side 0"},
   {"MIMRL_LN_BWD_BLOCKS", "model_ops.hip", "128", "workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)"},
   {"MIMRL_LN_BWD_WAVE_ROWS", "model_ops.hip", "", "the one-row-per-wave kernel of round 2"},
+  {"MIMRL_LSTM_MFMA_FP32", "lstm.hip", "", "1: fp32 precision mode runs the fp32-MFMA LSTM kernels instead of the scalar ones (measured slower)"},
+  {"MIMRL_LSTM_SCALAR", "lstm.hip", "", "1: the scalar fp32 LSTM kernels of round 1 instead of the MFMA ones"},
   {"MIMRL_MLP_IMG_WAVES", "mlp_fused.hip", "0", "4 = never, 8 = both directions"},
   {"MIMRL_MLP_NO_FRAG", "mlp_fused.hip", "", "the round-2 kernels (read per call: tests/test_gpu_fused_oracle.py toggles it)"},
   {"MIMRL_NO_DAXIS_PG_ONE", "engine.hip", "", "D-axis parameter gradients as three launches instead of daxis_param_grads"},

@@ -1,7 +1,7 @@
 // 1-layer bidirectional LSTM encoder of `--encoders lstm` (Model.py:250-252,441-447), packed-sequence semantics.
-// Not the benchmark configuration: a plain fp32 design -- one workgroup per (sample, direction, modality), 512 threads = the
-// 512 gate rows, every thread keeps its W_hh row (forward) / its 128-row slice of a W_hh column (BPTT) in registers, the
-// state goes through LDS.  Exact fp32 arithmetic in every precision mode.
+// Round 5: on the matrix cores like the bi-GRU (persistent workgroups of 4 batch rows, W_hh as register-resident MFMA B fragments, fp32
+// MFMA = exact parity mode, bf16 operands in the bf16 mode); the round-1 scalar design -- one workgroup per (sample, direction,
+// modality), 512 threads = the 512 gate rows -- stays as the reference the operator test compares with (MIMRL_LSTM_SCALAR=1).
 #pragma once
 #include "common.h"
 
@@ -21,7 +21,8 @@ struct LstmFwdArgs {
   const int* lens[2];
   int B, T, out_ld, nmod;
 };
-int lstm_forward(hipStream_t s, const LstmFwdArgs& a);
+// mode: 0 scalar fp32 reference kernels, 1 fp32 MFMA (exact), 2 bf16 MFMA operands -- see lstm.hip
+int lstm_forward(hipStream_t s, const LstmFwdArgs& a, int mode = 1);
 
 struct LstmSeqBwd {
   const float* w_hh;   // [4H,H]
@@ -36,6 +37,6 @@ struct LstmBwdArgs {
   const int* lens[2];
   int B, T, out_ld, dout_ld, nmod;
 };
-int lstm_backward(hipStream_t s, const LstmBwdArgs& a);
+int lstm_backward(hipStream_t s, const LstmBwdArgs& a, int mode = 1);
 
 }  // namespace mimrl

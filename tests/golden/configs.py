@@ -21,6 +21,9 @@ CONFIGS = {
                            baseline="gaussain"),
     # --encoders lstm (1-layer bi-LSTM, Model.py:250-252), ragged inputs
     "tiny_lstm": dict(B=8, T=6, N=40, seed=9, critic="separate", cube="6-3-128=4-3-128", traj=2, ragged=True, encoders="lstm"),
+    # --encoders lstm at BASELINE cfg1's shape (B = 32, T = 50, ragged lengths: four rows of different lengths per recurrence workgroup):
+    # the MFMA LSTM kernels of round 5 (lstm.hip) against the reference's nn.LSTM on packed sequences
+    "cfg1_lstm": dict(B=32, T=50, N=1000, seed=17, critic="separate", cube="50-3-128=10-3-128", traj=2, ragged=True, encoders="lstm"),
     # interpolated bound (VMI.py:201-250) with the constant baseline, concat critic
     "tiny_interp": dict(B=8, T=6, N=40, seed=8, critic="concat", cube="6-3-128=4-3-128", traj=2, bound="interpolate"),
     # awkward sizes: batch not a multiple of the tile sizes, inputs shorter than --time_len (zero padding of the cube,

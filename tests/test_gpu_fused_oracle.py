@@ -438,7 +438,7 @@ def test_encoders_vs_rounded_oracle(name, T_, margin, gxh, monkeypatch):
 
 @pytest.mark.parametrize("name,T_,gxh", [("cfg2_sep", None, False), ("cfg2_ragged", 49, False), ("cfg2_ragged", None, True)])
 def test_encoders_through_the_tall_gemm_kernel(name, T_, gxh, monkeypatch):
-    """Round 5: the layer-1 input projection and the dh0 data gradient of long sequences (B * T >= 16384 rows: cfg3 / cfg5) run on the LDS-DMA
+    """Round 5: the layer-1 input projection and the dh0 data gradient at B * T >= 4096 rows (cfg2 and up) run on the LDS-DMA
     kernel of csrc/gemm_tall.hip (256 x 128 tiles, 16-bit stored k-contiguous operands; dh0 reads the transposed, direction-concatenated bf16
     image of W_ih_l1).  MIMRL_GEMM_TALL_MIN_M lowers the row threshold so that the cfg2-shaped encoder parity cases -- every W_t / rnn_* / ln_*
     gradient against the rounded-operand float64 oracle, same bands -- exercise that path too (ragged rows: B * T = 6272 is not a multiple of

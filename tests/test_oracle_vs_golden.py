@@ -9,7 +9,7 @@ from tests.helpers import case, load_golden, oracle_params, rel_close
 
 TINY = ["tiny_sep", "tiny_cat", "tiny_ragged", "tiny_alt", "tiny_conv", "tiny_mine", "tiny_odd", "tiny_interp", "tiny_lstm", "tiny_tuba_un", "tiny_interp_ga",
         "tiny_sum", "tiny_disc"]
-ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg1_disc", "cfg1_ragged", "cfg2_sep", "cfg2_ragged", "cfg3_small", "cfg5_small"]
+ALL = TINY + ["cfg1_sep", "cfg1_cat", "cfg1_disc", "cfg1_ragged", "cfg1_lstm", "cfg2_sep", "cfg2_ragged", "cfg3_small", "cfg5_small"]
 
 
 @pytest.mark.parametrize("name", ALL)
