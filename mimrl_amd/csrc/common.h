@@ -37,7 +37,7 @@ int set_error(int code, const char* fmt, ...);
 #include <unordered_map>
 namespace mimrl {
 // Stream-capture bookkeeping (det.hip): while capture_track(true) is in effect every kernel launch notes which stream its graph node was
-// captured on -- the information graph_postprocess() (engine.hip) needs to keep the chain of dependent launches on ONE hardware queue.
+// captured on -- the information graph_postprocess() (engine_step.hip) needs to keep the chain of dependent launches on ONE hardware queue.
 void capture_track(bool on);
 void capture_note(hipStream_t s);
 const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams();

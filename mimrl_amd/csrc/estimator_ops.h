@@ -94,7 +94,7 @@ struct AdamArgs {
   float beta1, beta2, eps, weight_decay, clip;
   __bf16* pimg = nullptr; // optional: bf16 image of the updated parameters (the fused estimator kernels read weights from it)
   float gscale = 1.f;     // the gradient is multiplied by this first (1 / world_size after a SUM all-reduce: no separate scaling pass)
-  // optional: gradient pieces still parked in scratch (the packed layer-0 GRU weight gradients, engine.hip): element j of bucket range
+  // optional: gradient pieces still parked in scratch (the packed layer-0 GRU weight gradients, engine_step.hip): element j of bucket range
   // [lo[q], hi[q]) also takes src[q][(j / d[q]) * ld[q] + j % d[q]], which is re-zeroed -- the scatter kernel that used to sit between the
   // last weight-gradient GEMM and this launch (one launch + one dependent-launch gap on the chain) rides on the update
   struct Fold { int n = 0; long lo[8], hi[8]; float* src[8]; int d[8], ld[8]; long lo_all = 0, hi_all = 0; } fold;

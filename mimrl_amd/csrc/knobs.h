@@ -1,4 +1,4 @@
-// One table of every environment knob the native library reads (round 5, VERDICT r04 item 8: 61 getenv sites in engine.hip alone, 84
+// One table of every environment knob the native library reads (round 5, VERDICT r04 item 8: 61 getenv sites in the then one-file engine alone, 84
 // distinct names over the library).  Every site calls knob("NAME") -- getenv for a REGISTERED name (an unregistered one is reported once on
 // stderr: a typo in a tuning script no longer silently measures the default) -- and MIMRL_KNOBS=1 prints the table with the values in
 // effect when a handle is created.  Knobs are tuning / debugging switches: the defaults are what bench.py measures, none changes a

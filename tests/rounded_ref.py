@@ -15,7 +15,7 @@ Rounding points (documented per kernel):
     K phase : fp32 arithmetic on the bf16 tile, fp32 K-axis weights; output -> bf16 back into the tile
     D phase : tile rows, W1, W2, Wr -> bf16 operands; U, act(U) fp32; H -> bf16; Y, LayerNorm(D) fp32; block output fp32
               (the next block rounds it when it loads its tile)
-  unfused bf16 chain (engine.hip cube_forward, MIMRL_NO_FUSED_CUBE=1 / ln_first): only GEMM operands are rounded
+  unfused bf16 chain (engine_forward.hip cube_forward, MIMRL_NO_FUSED_CUBE=1 / ln_first): only GEMM operands are rounded
     (round_tile=False): LayerNorm outputs and the K-axis mix stay fp32
   concat critic (concat_fused.hip + the two layer-0 GEMMs): x, y, W0 -> bf16 (P = x W0x^T, Q = y W0y^T + b0, fp32 accumulate);
     a0 = relu(P_i + Q_j) -> bf16; W1, W2 bf16 images; a1 = relu(a0 W1^T + b1) -> bf16; a2 = relu(a1 W2^T + b2) stays fp32;
@@ -287,7 +287,7 @@ class _GruDirQ(torch.autograd.Function):
 def bigru2_q(p, prefix, x, lengths, rnd, rq, gxq=identity):
     """oracle.bigru2 with the kernels' rounding: hoisted projections through ``mm`` (``rnd``: fp16 forward operands, bf16 gradient
     operands), recurrences through _GruDirQ (``rq``: bf16); ``gxq``: storage rounding of the projection's OUTPUT gx (fp16 for long
-    sequences, engine.hip gx_f16; straight-through: the BPTT's gradient w.r.t. gx does not see it)."""
+    sequences, engine_abi.hip gx_f16; straight-through: the BPTT's gradient w.r.t. gx does not see it)."""
     inp = x
     for layer in range(2):
         outs = []

@@ -353,7 +353,7 @@ def test_fragment_image_mlp_kernel_equals_the_staged_one(name, monkeypatch):
 # (name, T override, dcube kind).  cfg2_sep / cfg2_ragged = the bench shape (B = 128, T = 50; ragged: four batch rows of different lengths per
 # recurrence workgroup); T = 49 / 1: the odd-T path of the BPTT kernel (an un-pipelined first step, round 4); cfg1: B = 32 (one batch row per
 # recurrence workgroup)
-# gxh: fp16-stored input projections (MIMRL_GX_F16=1: an opt-in path, slower at cfg3 with the present store pattern -- engine.hip)
+# gxh: fp16-stored input projections (MIMRL_GX_F16=1: an opt-in path, slower at cfg3 with the present store pattern -- engine_abi.hip: mimrl_create)
 ENC = [("cfg2_sep", None, True, False), ("cfg2_ragged", None, True, False), ("cfg2_ragged", 49, True, False), ("cfg1_ragged", None, True, False),
        ("cfg2_sep", 1, True, False), ("tiny_ragged", None, True, False), ("cfg2_sep", None, False, False), ("cfg2_ragged", None, False, False),
        ("cfg2_ragged", None, True, True), ("cfg2_ragged", 49, True, True)]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Critical-path sensitivity of the captured two-stage step: inject a spin kernel of US microseconds behind one phase
-# (MIMRL_DBG_DELAY_TAG, engine.hip: dbg_delay) and report the step-time increase per injected microsecond.
+# (MIMRL_DBG_DELAY_TAG, engine_backward.hip: dbg_delay) and report the step-time increase per injected microsecond.
 # usage: tools/critical_path.sh [US]      (run on the GPU box from the repo root)
 US=${1:-100}
 run() { env "$@" timeout 200 python bench.py --profile-steps 0 --no-cpu-baseline --no-extra --steps 150 2>/dev/null | tail -1 | python -c "import sys,json; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])"; }

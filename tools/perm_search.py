@@ -1,5 +1,5 @@
 """Coordinate search over MIMRL_GRAPH_PERM (GPU box): the order of every fork node's outgoing edges in the captured step graph decides
-which hardware queue each child gets (engine.hip: graph_postprocess).  usage: python tools/perm_search.py <children per fork, e.g. 4232...>
+which hardware queue each child gets (engine_step.hip: graph_postprocess).  usage: python tools/perm_search.py <children per fork, e.g. 4232...>
 [passes] [start]  -> gpurun_out/perm_search.txt"""
 import json
 import math
