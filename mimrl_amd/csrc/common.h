@@ -44,13 +44,16 @@ const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams();
 }  // namespace mimrl
 #undef hipLaunchKernelGGL
 #ifdef MIMRL_DET
-// deterministic build: every launch is followed, on its own stream, by the flush of the fixed-point accumulation table (det.h)
+// deterministic build: a launch that may have accumulated (acc_add) is followed, on its own stream, by the flush of the fixed-point
+// accumulation table (det.h).  Round 5: not EVERY launch any more -- 92 flushes of ~7 us per cfg2 step were a quarter of the build's step
+// time; det_launch_accumulates() knows the kernels that never call acc_add by name, and a host scope (DetNoFlush) says so for a template
+// instantiation whose name does not (a GEMM without atomics / column sums).
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                 \
   do {                                                                            \
     (void)::mimrl::det_init();                                                    \
     hipLaunchKernelGGLInternal((kernel), (grid), (block), (lds), (stream), __VA_ARGS__); \
     ::mimrl::capture_note(stream);                                                \
-    (void)::mimrl::det_flush(stream);                                             \
+    if (::mimrl::det_launch_accumulates(#kernel)) (void)::mimrl::det_flush(stream); \
   } while (0)
 #else
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                 \

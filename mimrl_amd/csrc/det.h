@@ -93,6 +93,14 @@ typedef void (*DetSetter)(const DetCtx&);
 void det_register_tu(DetSetter f);
 int det_init();                              // allocates the table, hands it to every translation unit (first launch; idempotent)
 int det_flush(hipStream_t s);                // apply and clear what the launches so far accumulated
+// may the kernel just launched have called acc_add?  `name` = the launch macro's kernel expression as text.  False for the kernels known
+// never to (forward / bookkeeping / image / sampler kernels, by name) and inside a DetNoFlush scope; anything unknown answers true.
+bool det_launch_accumulates(const char* name);
+struct DetNoFlush {                          // host scope: "the launches in here do not accumulate" (when `on`)
+  explicit DetNoFlush(bool on);
+  ~DetNoFlush();
+  bool on_, prev_;
+};
 int det_overflowed();                        // bit 0: the table ran full; bit 1: a non-finite / out-of-range contribution (both: that
                                              // contribution went through a plain float atomic)
 namespace {
@@ -103,6 +111,7 @@ static DetTuReg det_tu_reg_;
 }  // namespace
 
 #else   // ---------------------------------------------------------------- default build: plain float atomics
+struct DetNoFlush { explicit DetNoFlush(bool) {} };
 
 __device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }
 struct LdsAcc {

@@ -1,5 +1,6 @@
 // Host side and flush kernel of the deterministic build (det.h).  In the default build this file only answers mimrl_deterministic() = 0.
 #include <atomic>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -62,6 +63,25 @@ int det_flush(hipStream_t s) {
   if (!ready.load(std::memory_order_acquire)) return MIMRL_OK;   // no table (init failed): acc_add fell back to float atomics
   det_flush_kernel<<<dim3(256), dim3(256), 0, s>>>(h_ctx);
   return MIMRL_OK;
+}
+
+namespace {
+thread_local bool t_no_flush = false;
+}
+DetNoFlush::DetNoFlush(bool on) : on_(on), prev_(t_no_flush) { if (on_) t_no_flush = true; }
+DetNoFlush::~DetNoFlush() { if (on_) t_no_flush = prev_; }
+
+bool det_launch_accumulates(const char* name) {
+  if (t_no_flush) return false;
+  // kernels that never call acc_add (tests/test_layout.py::test_det_flush_rule_matches_the_sources checks this list against the sources)
+  static const char* const kSafe[] = {"_fwd", "adam_kernel", "images_kernel", "bf16_image", "knn_", "sample_anchors", "seq_lengths", "l0_pack", "l0_unpack",
+                                      "text_post", "feat_mean", "tail_pre", "begin_stage", "mae_kernel", "finalize_stage", "stage_boundary",
+                                      "cmi_assemble", "copy_rows", "gather_sum4", "wt_transpose", "pad_rows", "mi_bound", "cmi_loss", "pair_expand",
+                                      "pair_reduce", "gauss_baseline", "dbg_spin", "graph_pad", "det_flush", "dropout_inplace", "add_inplace",
+                                      "mi_sep_fused", "gemm_tall_kernel"};
+  for (const char* k : kSafe)
+    if (std::strstr(name, k)) return false;
+  return true;
 }
 
 int det_overflowed() {

@@ -973,6 +973,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
             d.bias_m != nullptr, (double)d.beta, d.pre != nullptr, d.gradact_u != nullptr, d.atomic);
   if (d.c_f16 && (d.atomic || pl.nsplit > 1 || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.colsum))
     return set_error(MIMRL_ERR_ARG, "gemm: an fp16-stored output takes the plain store only (no atomic / split-K / beta / pre / column sums)");
+  // (deterministic build: only a product that accumulates -- atomics, split-K, fused column sums -- needs the table flushed behind it)
+  DetNoFlush det_nf(!(d.atomic || pl.nsplit > 1 || d.colsum));
   KernelArgs ka;
   ka.d = d;
   ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0;

@@ -90,3 +90,36 @@ def test_every_knob_is_in_the_table():
         used |= set(re.findall(r'knob(?:_on|_int)?\("(MIMRL_[A-Z0-9_]+)"', s))
     assert used <= table, sorted(used - table)
     assert table - used <= {"MIMRL_KNOBS"}, sorted(table - used)
+
+
+def test_det_flush_rule_matches_the_sources():
+    """Deterministic build (csrc/det.h): the accumulation table is flushed only behind launches that may have called acc_add.  The rule
+    (det.hip: det_launch_accumulates) knows the kernels that never do BY NAME; this test derives, from the sources, every __global__ kernel
+    that reaches acc_add -- directly or through a __device__ helper -- and checks that none of them matches a 'safe' substring."""
+    import glob
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimrl_amd", "csrc")
+    det = open(os.path.join(csrc, "det.hip")).read()
+    safe = re.findall(r'"([^"]+)"', re.search(r"kSafe\[\] = \{(.*?)\};", det, re.S).group(1))
+    assert len(safe) > 20
+    accumulating = []
+    for f in glob.glob(os.path.join(csrc, "*.hip")):
+        src = open(f).read()
+        src += "".join(open(os.path.join(csrc, h)).read() for h in re.findall(r'#include "([a-z_]+\.h)"', src) if h not in ("common.h", "det.h"))
+        src = re.sub(r"__launch_bounds__\([^)]*\)", "", src)
+        # top-level function bodies: "name(args) {" at the start of a definition ... up to the next line that is just "}"
+        funcs = {}
+        for m in re.finditer(r"(?m)^(?:template[^\n]*\n)?((?:__global__|__device__|static|inline)[^\n;{]*?\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*(?:__attribute__\(\([^)]*\)\)\s*)?\{)", src):
+            end = src.find("\n}\n", m.end())
+            funcs[m.group(2)] = (m.group(1), src[m.end():end if end > 0 else len(src)])
+        acc = {n for n, (_, body) in funcs.items() if "acc_add(" in body}
+        changed = True
+        while changed:
+            changed = False
+            for n, (_, body) in funcs.items():
+                if n not in acc and any(re.search(r"\b%s\s*(?:<[^;{}]*>)?\s*\(" % re.escape(h), body) for h in acc):
+                    acc.add(n); changed = True
+        accumulating += [n for n in acc if "__global__" in funcs[n][0]]
+    assert len(accumulating) >= 20, accumulating
+    bad = [n for n in accumulating if any(s in n for s in safe)]
+    assert not bad, bad
