@@ -20,11 +20,13 @@ struct ConcatFwdArgs {
   // 2 compact: bf16 values a0b, a1b (operands of the weight-gradient GEMMs, which round to bf16 anyway), fp32 a2 (the score head's
   //   weight gradient sum ds * a2 cancels to ~1e-3 of its terms: bf16 values are not good enough) + ReLU bitmasks m1, m2 (one 32-bit
   //   word per row and 32 columns; the fused backward, stage 1),
-  // 3 bitmasks only (the fused backward of stage 2: no weight gradients, only the signs are needed; layer 0's sign is recomputed from P, Q)
+  // 3 bitmasks only (the fused backward of stage 2: no weight gradients, only the signs are needed)
+  // (round 5: save >= 2 also writes m0, the sign of the pair-expanded layer 0 -- the backward recomputed it from P_i + Q_j with 64 loads
+  //  per lane and tile)
   int save;
   float *a0, *a1, *a2;                        // [E][B*B][256] fp32 (save == 1)
   __bf16 *a0b, *a1b;                          // [E][B*B][256] bf16 (save == 2)
-  uint32_t *m1, *m2;                          // [E][B*B][8]        (save == 2, 3)
+  uint32_t *m0, *m1, *m2;                     // [E][B*B][8]        (save == 2, 3): bit c of word [row][g] = sign of column 32 g + c
   float* scores;                              // [E][B*B]   row p = i*B + j
   int E, B;
 };
@@ -38,12 +40,14 @@ bool concat_fwd_fused_supported(int B, int hid);
 struct ConcatBwdArgs {
   const float* ds;                            // [E][B*B]   d loss / d score
   const float *a0, *a1, *a2;                  // saved post-ReLU activations, fp32 (the forward kernel's save == 1) -- or, compact:
-  int compact;                                // 1: masks m1, m2 (+ fp32 a2 for dw3 in stage 1) and P, Q (layer 0's sign) instead
-  const uint32_t *m1, *m2; const float *P, *Q;
+  int compact;                                // 1: masks m0, m1, m2 (+ fp32 a2 for dw3 in stage 1) instead
+  const uint32_t *m0, *m1, *m2; const float *P, *Q;   // (P, Q: unused since round 5)
   const float* w3;                            // score-head weight [256], estimator e at + e*pstride
   const __bf16 *W2T, *W1T;                    // transposed bf16 images [256 in][256 out], estimator e at + e*pstride
   long pstride;
-  float* dz0;                                 // [E][B*B][256] fp32
+  float* dz0;                                 // [E][B*B][256] fp32 (not written when dQ is set)
+  float* dQ;                                  // optional (compact saves), [E][B][256], zeroed by the caller: dQ[j] += sum_i dZ0[i, j] from inside
+                                              // the kernel (runs of tiles per workgroup, partial sums in registers) -- dz0 / pair_reduce_q not needed
   float* dP;                                  // [E][B][256]; B == 128: plain stores, else accumulated (caller zeroes it)
   __bf16 *dz2, *dz1;                          // [E][B*B][256] bf16 or null (stage 2: no weight gradients)
   float *db1, *db2, *dw3, *db3;               // gradient slots (estimator e at + e*pstride) or null

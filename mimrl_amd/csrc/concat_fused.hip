@@ -47,6 +47,13 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
         bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
         if (SAVE == 1) *reinterpret_cast<float4*>(o0 + (long)row * CH + c4) = v;
         else if (SAVE == 2) *reinterpret_cast<bf16x4*>(o0b + (long)row * CH + c4) = b;
+        if (SAVE >= 2) {   // sign word of (row, 32 columns) = the nibbles of 8 neighbouring lanes (a wave holds one row: lane = column quad)
+          uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+          nib |= (uint32_t)__shfl_down((int)nib, 1) << 4;
+          nib |= (uint32_t)__shfl_down((int)nib, 2) << 8;
+          nib |= (uint32_t)__shfl_down((int)nib, 4) << 16;
+          if ((lane & 7) == 0) a.m0[(ebase + row0 + row) * 8 + (lane >> 3)] = nib;
+        }
         *reinterpret_cast<bf16x4*>(&act[row][c4]) = b;
       }
     }
@@ -185,16 +192,37 @@ __device__ __forceinline__ void bwd_product(f32x16 (&acc)[4], const __bf16 (*g)[
   }
 }
 
-template <bool COMPACT, bool WG>   // COMPACT: bitmask / bf16 inputs; WG: stage 1 (weight-gradient operands and column-sum gradients)
+// RUNS (round 5): a workgroup owns a contiguous RUN of tiles in (estimator, y block of 128 rows, x row i) order and keeps dQ = sum_i dZ0 of
+// its (estimator, y block) in registers (the accumulator layout of the last product: 64 values per lane), added into a.dQ when the run
+// leaves the block or ends: dz0 is not written at all (it was 335 MB out and, through pair_reduce_q, 335 MB back in per pass at cfg3).
+template <bool COMPACT, bool WG, bool RUNS>   // COMPACT: bitmask / bf16 inputs; WG: stage 1 (weight-gradient operands and column-sum gradients)
 __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 gt[CR][AP];
   __shared__ __attribute__((aligned(16))) __bf16 wb[2][CH][WP];
   __shared__ LdsAcc cs[2][CH];            // column sums of the tile (two quantities at a time)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;
-  const int e = blockIdx.y, B = a.B;
-  const long row0 = (long)blockIdx.x * CR, ebase = (long)e * B * B, tile = (ebase + row0) * CH;
+  const int B = a.B;
   constexpr bool wg = WG;
+  const int tiles_e = (int)(((long)B * B) / CR);
+  int lin, lin_end;
+  if (RUNS) {
+    const int total = a.E * tiles_e, per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    lin = blockIdx.x * per; lin_end = min(total, lin + per);
+  } else { lin = blockIdx.y * tiles_e + blockIdx.x; lin_end = lin + 1; }
+  float dq[RUNS ? 4 : 1][RUNS ? 16 : 1];
+  if (RUNS) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[RUNS ? ct : 0][RUNS ? r : 0] = 0.f;
+  }
+#pragma unroll 1
+ for (; lin < lin_end; ++lin) {
+  const int e = lin / tiles_e, rem = lin - e * tiles_e;
+  // RUNS: tile order (y block, x row) inside an estimator; otherwise the natural row order (x row, y block)
+  const long row0 = RUNS ? (long)(rem % B) * B + (long)(rem / B) * CR : (long)rem * CR;
+  const long ebase = (long)e * B * B, tile = (ebase + row0) * CH;
   if (tid < CH) { cs[0][tid].zero(); cs[1][tid].zero(); }
   __syncthreads();
   // ---- dZ2 = ds w3^T (.) [a2 > 0]; this thread owns one column quad (c4) and 16 of the 128 rows
@@ -258,6 +286,10 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   bwd_product(acc, gt, wb, a.W2T + (long)e * a.pstride, tid, lr, lh, wm, wn);
   {
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    // compact: the sign words of this wave's 32 rows x 4 column groups are ONE 16-byte load per lane (lane l and l + 32: row l of the
+    // block); the word of (row, group) then comes out of lane `row` with v_readlane (round 5: 64 broadcast loads and 64 registers before)
+    u32x4 mrow4 = {0u, 0u, 0u, 0u};
+    if (COMPACT) mrow4 = *reinterpret_cast<const u32x4*>(a.m1 + (ebase + row0 + wm * 32 + lr) * 8 + wn * 4);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       float mk[16];
@@ -265,7 +297,9 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int mu = wm * 32 + (r & 3) + 8 * (r >> 2);
         if (COMPACT) {
-          const uint32_t wrd = a.m1[(ebase + row0 + mu + 4 * lh) * 8 + wn * 4 + ct];
+          const int rl = (r & 3) + 8 * (r >> 2);
+          const uint32_t w_lo = __builtin_amdgcn_readlane(mrow4[ct], rl), w_hi = __builtin_amdgcn_readlane(mrow4[ct], rl + 4);
+          const uint32_t wrd = lh ? w_hi : w_lo;
           mk[r] = ((wrd >> lr) & 1u) ? 1.f : 0.f;
         } else {
           const float* __restrict__ mrow = a.a1 + tile + (long)mu * CH + ct * 32;
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
         const float v = mk[r] > 0.f ? acc[ct][r] : 0.f;
         const __bf16 vb = to_bf16(v);
         gt[m][col] = vb;                                   // (every wave left the product loop through its last barrier)
-        if (wg) { __bf16* __restrict__ drow = a.dz1 + tile + (long)mu * CH + ct * 32; drow[soff] = vb; csum[ct] += v; }
+        if (wg) csum[ct] += v;
       }
     }
     if (wg) {
@@ -288,21 +322,31 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   }
   __syncthreads();
   if (wg && tid < CH) { acc_add(a.db1 + (long)e * a.pstride + tid, cs[0][tid].get()); cs[0][tid].zero(); }
+  if (wg) {
+    // dZ1 leaves from the finished LDS tile in whole 512-byte rows (round 5; it left as 2-byte stores from the accumulator layout:
+    // 64 store instructions per lane and two 64-byte row pieces per instruction)
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+      const int row = p8 * 16 + (tid >> 5), c8 = (tid & 31) * 8;
+      *reinterpret_cast<u32x4*>(a.dz1 + tile + (long)row * CH + c8) = *reinterpret_cast<const u32x4*>(&gt[row][c8]);
+    }
+  }
   // ---- dZ0 = (dZ1 W1) (.) [a0 > 0]  -> dz0 (fp32) and its column sums = dP[i]
   bwd_product(acc, gt, wb, a.W1T + (long)e * a.pstride, tid, lr, lh, wm, wn);
   {
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    u32x4 mrow4 = {0u, 0u, 0u, 0u};
+    if (COMPACT) mrow4 = *reinterpret_cast<const u32x4*>(a.m0 + (ebase + row0 + wm * 32 + lr) * 8 + wn * 4);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       float mk[16];
-      const int colg = wn * 128 + ct * 32 + lr;
-      const long irow = row0 / B, j0 = row0 - irow * B;                      // the tile's x row and its first y row
-      const float pv = COMPACT ? a.P[((long)e * B + irow) * CH + colg] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int mu = wm * 32 + (r & 3) + 8 * (r >> 2);
-        if (COMPACT) {   // layer 0 is relu(P_i + Q_j): its sign is recomputed (the same fp32 sum the forward kernel formed)
-          mk[r] = pv + a.Q[((long)e * B + j0 + mu + 4 * lh) * CH + colg];
+        if (COMPACT) {   // (rounds 2-4 recomputed layer 0's sign from P_i + Q_j: 64 loads per lane)
+          const int rl = (r & 3) + 8 * (r >> 2);
+          const uint32_t w_lo = __builtin_amdgcn_readlane(mrow4[ct], rl), w_hi = __builtin_amdgcn_readlane(mrow4[ct], rl + 4);
+          mk[r] = (((lh ? w_hi : w_lo) >> lr) & 1u) ? 1.f : 0.f;
         } else {
           const float* __restrict__ mrow = a.a0 + tile + (long)mu * CH + ct * 32;
           mk[r] = mrow[soff];
@@ -312,8 +356,8 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int mu = wm * 32 + (r & 3) + 8 * (r >> 2);
         const float v = mk[r] > 0.f ? acc[ct][r] : 0.f;
-        float* __restrict__ drow = a.dz0 + tile + (long)mu * CH + ct * 32;
-        drow[soff] = v;
+        if (RUNS) dq[RUNS ? ct : 0][RUNS ? r : 0] += v;
+        else { float* __restrict__ drow = a.dz0 + tile + (long)mu * CH + ct * 32; drow[soff] = v; }
         csum[ct] += v;
       }
     }
@@ -326,6 +370,18 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
     float* dp = a.dP + ((long)e * B + i) * CH + tid;
     if (B == CR) *dp = cs[0][tid].get(); else acc_add(dp, cs[0][tid].get());
   }
+  if (RUNS && (lin + 1 == lin_end || (rem + 1) % B == 0)) {   // the run leaves this (estimator, y block): add its dQ partial
+    const long qbase = ((long)e * B + (long)(rem / B) * CR) * CH;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = wn * 128 + ct * 32 + lr;
+        acc_add(a.dQ + qbase + (long)m * CH + col, dq[RUNS ? ct : 0][RUNS ? r : 0]);
+        dq[RUNS ? ct : 0][RUNS ? r : 0] = 0.f;
+      }
+  }
+ }
 }
 
 }  // namespace
@@ -334,15 +390,26 @@ bool concat_bwd_fused_supported(int B, int hid) { return hid == CH && B >= CR &&
 
 int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a) {
   if (!concat_bwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: batch %d unsupported", a.B);
-  if (!a.dz0 || !a.dP || !a.ds) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null argument");
-  if (a.compact ? !(a.m1 && a.m2 && a.P && a.Q && (a.a2 || !a.dz2)) : !(a.a0 && a.a1 && a.a2))
+  if (!(a.dz0 || a.dQ) || !a.dP || !a.ds) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null argument");
+  if (a.compact ? !(a.m0 && a.m1 && a.m2 && (a.a2 || !a.dz2)) : !(a.a0 && a.a1 && a.a2))
     return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null activation input");
   if ((a.dz2 != nullptr) != (a.dz1 != nullptr) || (a.dz2 && !(a.db1 && a.db2 && a.dw3 && a.db3)))
     return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the weight-gradient outputs come together");
-  const dim3 grid((unsigned)(((long)a.B * a.B) / CR), a.E);
   const bool wg = a.dz2 != nullptr;
-  if (a.compact) { if (wg) hipLaunchKernelGGL((concat_bwd_kernel<true, true>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((concat_bwd_kernel<true, false>), grid, dim3(512), 0, s, a); }
-  else { if (wg) hipLaunchKernelGGL((concat_bwd_kernel<false, true>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((concat_bwd_kernel<false, false>), grid, dim3(512), 0, s, a); }
+  if (a.dQ) {   // runs of tiles with dQ in registers: one workgroup per CU, ceil(tiles / CUs) tiles each
+    if (!a.compact) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the in-kernel dQ reduction exists for the compact saves only");
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t pr; int dev = 0; HIPX(hipGetDevice(&dev)); HIPX(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int total = a.E * (int)(((long)a.B * a.B) / CR), per = (total + cus - 1) / cus;
+    const dim3 grid((unsigned)((total + per - 1) / per));
+    if (wg) hipLaunchKernelGGL((concat_bwd_kernel<true, true, true>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((concat_bwd_kernel<true, false, true>), grid, dim3(512), 0, s, a);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
+  const dim3 grid((unsigned)(((long)a.B * a.B) / CR), a.E);
+  if (a.compact) { if (wg) hipLaunchKernelGGL((concat_bwd_kernel<true, true, false>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((concat_bwd_kernel<true, false, false>), grid, dim3(512), 0, s, a); }
+  else { if (wg) hipLaunchKernelGGL((concat_bwd_kernel<false, true, false>), grid, dim3(512), 0, s, a); else hipLaunchKernelGGL((concat_bwd_kernel<false, false, false>), grid, dim3(512), 0, s, a); }
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -352,7 +419,7 @@ bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 &&
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a) {
   if (!concat_fwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: batch %d unsupported", a.B);
   if (!a.scores || a.save < 0 || a.save > 3) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: bad arguments");
-  if ((a.save == 1 && !(a.a0 && a.a1 && a.a2)) || (a.save == 2 && !(a.a0b && a.a1b && a.a2)) || (a.save >= 2 && !a.m1) || (a.save == 3 && !a.m2))
+  if ((a.save == 1 && !(a.a0 && a.a1 && a.a2)) || (a.save == 2 && !(a.a0b && a.a1b && a.a2)) || (a.save >= 2 && !(a.m0 && a.m1)) || (a.save == 3 && !a.m2))
     return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: null save buffer");
   const dim3 grid((unsigned)(((long)a.B * a.B) / CR), a.E);
   if (a.save == 0) hipLaunchKernelGGL(concat_fwd_kernel<0>, grid, dim3(512), 0, s, a);

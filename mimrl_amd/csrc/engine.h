@@ -167,6 +167,9 @@ struct mimrl_handle {
   bool begin_in_pack = false;          // the stage-1 begin-of-stage bookkeeping is owed by the next layer-0 pack launch
   hipEvent_t ev_lens = nullptr;        // set while the length scan of this forward pass runs on side 0 (in front of the text projection)
   float *tx_raw = nullptr, *gx[2][2], *h0[2], *h1[2], *sv[2][2][2], *ln_mean[2], *ln_rstd[2];
+  float* tailp_part = nullptr;   // chunk sums of dual_tail_pre()
+  bool pre_done = false;         // the pre-CubeMLP pieces of the forward tails were written by dual_tail_pre(): model_forward(part 2) skips them
+  int dual_tail_pre();           // engine_forward.hip
   float* cube0 = nullptr;
   // layer-0 GRU operands in a common aligned shape (model_ops.h: L0Pack): one batched input projection, two batched weight gradients
   float *xpack = nullptr, *wpack = nullptr, *bpack = nullptr, *dwih_pack = nullptr, *dwhh_pack = nullptr;

@@ -209,6 +209,11 @@ int mimrl_handle::carve() {
     bufs.feats = f0; bufs.pred = p0;
     MX(r);
   }
+  {   // chunk sums of the two-tail pre-CubeMLP launch (model_ops.hip: tail_pre2_kernel); one chunk = none needed
+    int nchunk = 1, rpc = 0;
+    tail_pre2_chunks(cfg.batch, cfg.seq_len, &nchunk, &rpc);
+    if (nchunk > 1) MX(take(&tailp_part, 2 * 3 * B * (size_t)nchunk * D));
+  }
   for (int i = 0; i < cfg.n_blocks; ++i)
     for (int q = 0; q < 3; ++q) { float* t = nullptr; MX(take(&t, 128 * 128 / 2)); wtT[i][q] = reinterpret_cast<__bf16*>(t); }
   {

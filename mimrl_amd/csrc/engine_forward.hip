@@ -219,7 +219,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const long BT_ = (long)B * T;
   const float pdrop[3] = {train ? cfg.dropout[0] : 0.f, train ? cfg.dropout[1] : 0.f, train ? cfg.dropout[2] : 0.f};
-  if (part != 1 && T < L) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
+  if (part != 1 && T < L && !pre_done) HIPX(hipMemsetAsync(cube0, 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
   // text_post + ln_relu_drop + feat_mean as one launch, one workgroup per (sample, slot): for short sequences, where the three
   // launches are latency (cfg2: -15 us per tail); a workgroup walking T = 1000 rows loses to the row-parallel kernels (cfg5: +60 us)
   static const bool fused_pre_on = knob("MIMRL_NO_FUSED_TAIL_PRE") == nullptr;   // tuning knob
@@ -252,11 +252,11 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     if (pending_text) { MX(pending_text()); pending_text = nullptr; }
     MX(join(0, 0));
     if (part == 1) return MIMRL_OK;
-  } else if (!fused_pre) {
+  } else if (!fused_pre && !pre_done) {
     MX(text_post_fwd(stream, tx_raw, cube0, B, T, L, 3, D, 0, pdrop[0], key(), 0));
   }
   // text dropout -> cube slot 0; fwd+bwd sum, LN, ReLU, dropout (Model.py:452-461) -> cube slots 1,2; T_F, A_F, V_F (Model.py:466)
-  {
+  if (!pre_done) {
     LnSide2 sd[2];
     for (int m = 0; m < 2; ++m)
       sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], nullptr, nullptr, nullptr, 1 + m, pdrop[1 + m],
@@ -277,6 +277,24 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
   MX(head_fwd(stream, last.d.z, P(cls_w), P(cls_b), bufs.feats, bufs.pred, B, ol, ok, od, cfg.compose_t_sum,
               cfg.compose_k_sum));
   (void)ff;
+  return MIMRL_OK;
+}
+
+// The pre-CubeMLP pieces (text dropout, LN + ReLU + dropout of the encoder outputs, temporal means: Model.py:452-466) of BOTH forward tails
+// of a shared-prefix training step in one launch on `stream`: the primary set (stage 2's tail, dropout key of the step counter
+// begin_stage(2) will set: +1) and the alternate set (stage 1's tail, the current counter).  Long sequences only: below 129 steps each
+// tail has its own one-launch tail_pre_fwd, which is latency and runs beside the other tail's.
+int mimrl_handle::dual_tail_pre() {
+  const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
+  float* const cubes[2] = {cube0, alt.cube0};
+  float* const feats[2] = {bufs.feats + (size_t)B * D, alt.feats + (size_t)B * D};
+  const int add[2] = {1, 0};
+  if (T < L)
+    for (int o = 0; o < 2; ++o) HIPX(hipMemsetAsync(cubes[o], 0, sizeof(float) * (size_t)B * L * 3 * D, stream));
+  LnSide2 sd[2];
+  for (int m = 0; m < 2; ++m)
+    sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], nullptr, nullptr, nullptr, 1 + m, cfg.dropout[1 + m], (uint32_t)(1 + m)};
+  MX(tail_pre2_fwd(stream, tx_raw, cfg.dropout[0], sd[0], sd[1], cubes, feats, add, tailp_part, B, T, L, 3, D, key()));
   return MIMRL_OK;
 }
 

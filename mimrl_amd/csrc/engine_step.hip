@@ -71,6 +71,11 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
       }
       // (stage 2's kNN sampler runs beside the prefix too -- the recurrence leaves half the CUs idle; its anchor key is the step counter
       //  begin_stage(2) will set: knn_launch(3))
+      // (1b) long sequences: the pre-CubeMLP pieces of both tails in one launch (each source row read once)
+      static const bool dual_pre_on = knob("MIMRL_NO_DUAL_TAIL_PRE") == nullptr;   // tuning knob
+      const bool dual_pre = dual_pre_on && !defer_tail && cfg.seq_len > 128 && cfg.d_common == 128 && rng_add == 0;
+      if (dual_pre) { MX(dual_tail_pre()); pre_done = true; }
+      struct PreDone { bool& f; ~PreDone() { f = false; } } pre_done_guard{pre_done};
       hipEvent_t e_prefix = nullptr;
       MX(next_event(&e_prefix));
       HIPX(hipEventRecord(e_prefix, stream));

@@ -77,6 +77,8 @@ const KnobDef kKnobs[] = {
   {"MIMRL_NO_FUSED_MI", "engine_estimators.hip", "", "separable critic: scores / bound / gradients as separate kernels instead of mi_sep_fused / mi_sep_nce"},
   {"MIMRL_NO_FUSED_MLP", "engine_abi.hip", "", "bf16 mode: estimator MLP stacks as grouped GEMMs"},
   {"MIMRL_NO_FUSED_MLP_BWD", "engine_estimators.hip", "", "estimator MLP stacks: data-gradient chain as GEMMs instead of the fused kernel"},
+  {"MIMRL_NO_CONCAT_DQ", "engine_estimators.hip", "", "concat critic backward: dZ0 goes out in fp32 and pair_reduce_q sums it over the x rows (rounds 2-4) instead of the in-kernel dQ partial sums"},
+  {"MIMRL_NO_DUAL_TAIL_PRE", "engine_step.hip", "", "long sequences (T > 128): each forward tail runs its own text dropout / LN + ReLU + dropout / temporal-mean launches instead of one launch for both"},
   {"MIMRL_NO_FUSED_TAIL_PRE", "engine_forward.hip", "", "forward tail: text dropout, LN + ReLU + dropout and the temporal means as separate launches"},
   {"MIMRL_NO_GEMM_TALL", "gemm_tall.hip", "", "tall LDS-DMA GEMM (gemm_tall.hip) off: the 128x128 register-staged kernels"},
   {"MIMRL_NO_H16", "engine_abi.hip", "", "fp32-stored operands for the layer-1 projection / dh0 (bit-identical results)"},

@@ -75,6 +75,12 @@ int feat_mean_fwd(hipStream_t s, const float* cube, float* feats, int B, int T, 
 // dropout keys; feats = [3][B, D] = T_F, A_F, V_F)
 int tail_pre_fwd(hipStream_t s, const float* tx_raw, float p_text, const LnSide2& a, const LnSide2& v, float* cube, float* feats, int B, int T,
                  int L, int K, int D, RngKey key);
+// The same for BOTH forward tails of a shared-prefix step in one launch (round 5): every source row is read once and written to
+// cube[0] / cube[1] under the dropout keys key.step + add[0] / add[1]; feats[o] = the temporal means of cube[o].  `part`: scratch of
+// 2 * 3 * B * nchunk * D floats when tail_pre2_chunks() says nchunk > 1 (then a second small launch adds the chunk sums in order).
+void tail_pre2_chunks(int B, int T, int* nchunk, int* rpc);
+int tail_pre2_fwd(hipStream_t s, const float* tx_raw, float p_text, const LnSide2& a, const LnSide2& v, float* const cube[2], float* const feats[2],
+                  const int add[2], float* part, int B, int T, int L, int K, int D, RngKey key);
 // dcube[b,t,k,:] += dfeats[k][b,:]/T  for t<T
 int feat_mean_bwd(hipStream_t s, const float* dfeats, float* dcube, int B, int T, int L, int K, int D);
 

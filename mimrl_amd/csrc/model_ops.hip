@@ -308,6 +308,114 @@ __global__ __launch_bounds__(256) void tail_pre_kernel(TailPre tp, float* __rest
   MPHASE(pb, 3);
 }
 
+// ------------------------------------------------------------------ the same three pieces for BOTH forward tails of a step in one launch
+// (round 5).  The shared-prefix step runs two tails on the same encoder outputs -- stage 1's (critic update) and stage 2's (main update) --
+// which differ only in their dropout keys.  As separate launches each tail read tx_raw and the bi-GRU outputs again, and read its cube
+// slot a third time for the temporal means: at T = 500 (cfg3) 1.44 GB of HBM traffic on the chain of both tails (0.34 ms).  Here a row is
+// read ONCE, its LayerNorm statistics are computed once, and the two masked copies go to the two cubes, the temporal means ride on the
+// values in registers: 0.72 GB.  Workgroup = (sample, slot, chunk of `rpc` rows, rpc % 4 == 0); wave w owns rows t = w (mod 4) in
+// increasing order, so with one chunk the means have the summation order of feat_mean_fwd_kernel / tail_pre_kernel.  Lane l owns
+// columns 2l, 2l+1 (8-byte accesses).  With more than one chunk the partial sums go to `part` and tail_pre2_finish_kernel adds them in
+// chunk order (fixed order: the means stay run-to-run reproducible).
+struct TailPre2 {
+  const float* tx_raw; LnSide a, v; float p_text;
+  float* cube[2]; float* feats[2]; int add[2];
+  float* part; int nchunk, rpc;
+};
+__global__ __launch_bounds__(256) void tail_pre2_kernel(TailPre2 tp, int B, int T, int L, int K, RngKey key) {
+  constexpr int D = 128, RPP = 8;
+  __shared__ float part[2][4][D];
+  const int b = blockIdx.x, slot = blockIdx.y, ch = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t_begin = ch * tp.rpc, t_end = min(T, t_begin + tp.rpc);
+  const int c = 2 * lane;
+  const uint32_t step = (uint32_t)*key.step;
+  const uint32_t rs0 = step + (uint32_t)tp.add[0], rs1 = step + (uint32_t)tp.add[1];
+  float* __restrict__ cube0 = tp.cube[0];
+  float* __restrict__ cube1 = tp.cube[1];
+  float2 acc0 = make_float2(0.f, 0.f), acc1 = acc0;
+  if (slot == 0) {
+    const float p = tp.p_text;
+    for (int t0 = t_begin + w; t0 < t_end; t0 += 4 * RPP) {
+      float2 x[RPP];
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) {
+        const int t = min(t0 + 4 * q, t_end - 1);
+        x[q] = *reinterpret_cast<const float2*>(tp.tx_raw + ((long)b * T + t) * D + c);
+      }
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) {
+        const int t = t0 + 4 * q;
+        if (t < t_end) {
+          const long r = (long)b * T + t;
+          const long o = (((long)b * L + t) * K + 0) * D + c;
+          const uint32_t e = (uint32_t)(r * D + c);
+          float2 y0, y1;
+          y0.x = x[q].x * drop_scale_at(p, key, rs0, 0u, e); y0.y = x[q].y * drop_scale_at(p, key, rs0, 0u, e + 1);
+          y1.x = x[q].x * drop_scale_at(p, key, rs1, 0u, e); y1.y = x[q].y * drop_scale_at(p, key, rs1, 0u, e + 1);
+          *reinterpret_cast<float2*>(cube0 + o) = y0;
+          *reinterpret_cast<float2*>(cube1 + o) = y1;
+          acc0.x += y0.x; acc0.y += y0.y; acc1.x += y1.x; acc1.y += y1.y;
+        }
+      }
+    }
+  } else {
+    const LnSide& sd = slot == 1 ? tp.a : tp.v;
+    const float* __restrict__ h2 = sd.h2;
+    const float2 g = *reinterpret_cast<const float2*>(sd.gamma + c), be = *reinterpret_cast<const float2*>(sd.beta + c);
+    const float p = sd.p; const uint32_t sid = sd.stream; const int oslot = sd.slot;
+    for (int t0 = t_begin + w; t0 < t_end; t0 += 4 * RPP) {
+      float2 v[RPP];
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) {
+        const int t = min(t0 + 4 * q, t_end - 1);
+        const float* hr = h2 + ((long)b * T + t) * 2 * D + c;
+        const float2 f = *reinterpret_cast<const float2*>(hr), r = *reinterpret_cast<const float2*>(hr + D);
+        v[q].x = f.x + r.x; v[q].y = f.y + r.y;
+      }
+#pragma unroll
+      for (int q = 0; q < RPP; ++q) {
+        const int t = t0 + 4 * q;
+        if (t < t_end) {                                        // (wave-uniform)
+          const long r = (long)b * T + t;
+          const float mu = wave_sum(v[q].x + v[q].y) * (1.f / D);
+          const float c0 = v[q].x - mu, c1 = v[q].y - mu;
+          const float rs = rsqrtf(wave_sum(c0 * c0 + c1 * c1) * (1.f / D) + LN_EPS);
+          if (lane == 0) { sd.mean[r] = mu; sd.rstd[r] = rs; }
+          float z0 = c0 * rs * g.x + be.x, z1 = c1 * rs * g.y + be.y;
+          z0 = z0 > 0.f ? z0 : 0.f; z1 = z1 > 0.f ? z1 : 0.f;
+          const long o = (((long)b * L + t) * K + oslot) * D + c;
+          const uint32_t e = (uint32_t)(r * D + c);
+          float2 y0, y1;
+          y0.x = z0 * drop_scale_at(p, key, rs0, sid, e); y0.y = z1 * drop_scale_at(p, key, rs0, sid, e + 1);
+          y1.x = z0 * drop_scale_at(p, key, rs1, sid, e); y1.y = z1 * drop_scale_at(p, key, rs1, sid, e + 1);
+          *reinterpret_cast<float2*>(cube0 + o) = y0;
+          *reinterpret_cast<float2*>(cube1 + o) = y1;
+          acc0.x += y0.x; acc0.y += y0.y; acc1.x += y1.x; acc1.y += y1.y;
+        }
+      }
+    }
+  }
+  part[0][w][c] = acc0.x; part[0][w][c + 1] = acc0.y;
+  part[1][w][c] = acc1.x; part[1][w][c + 1] = acc1.y;
+  __syncthreads();
+  {
+    const int o = threadIdx.x >> 7, d = threadIdx.x & 127;
+    const float sum = part[o][0][d] + part[o][1][d] + part[o][2][d] + part[o][3][d];
+    if (tp.nchunk == 1) tp.feats[o][((long)slot * B + b) * D + d] = sum / T;
+    else tp.part[((((long)o * 3 + slot) * B + b) * tp.nchunk + ch) * D + d] = sum;
+  }
+}
+__global__ __launch_bounds__(256) void tail_pre2_finish_kernel(TailPre2 tp, int B, int T) {
+  constexpr int D = 128;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;      // over [2][3][B][D]
+  if (i >= 2L * 3 * B * D) return;
+  const int d = i % D; const long sb = (i / D) % (3L * B); const int o = (int)(i / (3L * B * D));
+  const float* p = tp.part + (((long)o * 3 * B + sb) * tp.nchunk) * D + d;
+  float sum = 0.f;
+  for (int ch = 0; ch < tp.nchunk; ++ch) sum += p[(long)ch * D];
+  tp.feats[o][sb * D + d] = sum / T;
+}
+
 // ------------------------------------------------------------------ temporal means
 __global__ void feat_mean_fwd_kernel(const float* __restrict__ cube, float* __restrict__ feats, int B, int T, int L,
                                      int K, int D) {
@@ -983,6 +1091,32 @@ int tail_pre_fwd(hipStream_t s, const float* tx_raw, float p_text, const LnSide2
   tp.v = LnSide{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, nullptr};
   hipLaunchKernelGGL(tail_pre_kernel, dim3(B, 3), dim3(256), 0, s, tp, cube, feats, B, T, L, K, key);
   LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+void tail_pre2_chunks(int B, int T, int* nchunk, int* rpc) {
+  int n = (1024 + 3 * B - 1) / (3 * B);                     // ~1024 workgroups (4 per CU) ...
+  n = std::max(1, std::min(n, std::min(16, (T + 31) / 32)));   // ... of at least 32 rows
+  const int r = ((T + n - 1) / n + 3) & ~3;                  // rows per chunk, a multiple of 4 (the waves' time phases stay aligned)
+  *nchunk = (T + r - 1) / r; *rpc = r;
+}
+int tail_pre2_fwd(hipStream_t s, const float* tx_raw, float p_text, const LnSide2& a, const LnSide2& v, float* const cube[2], float* const feats[2],
+                  const int add[2], float* part, int B, int T, int L, int K, int D, RngKey key) {
+  if (D != 128 || K != 3 || a.slot != 1 || v.slot != 2) return set_error(MIMRL_ERR_ARG, "tail_pre2_fwd: d_common 128, 3 modality slots");
+  TailPre2 tp;
+  tp.tx_raw = tx_raw; tp.p_text = p_text;
+  tp.a = LnSide{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, nullptr};
+  tp.v = LnSide{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, nullptr};
+  for (int o = 0; o < 2; ++o) { tp.cube[o] = cube[o]; tp.feats[o] = feats[o]; tp.add[o] = add[o]; }
+  tail_pre2_chunks(B, T, &tp.nchunk, &tp.rpc);
+  tp.part = part;
+  if (tp.nchunk > 1 && !part) return set_error(MIMRL_ERR_ARG, "tail_pre2_fwd: partial-sum scratch missing");
+  hipLaunchKernelGGL(tail_pre2_kernel, dim3(B, 3, tp.nchunk), dim3(256), 0, s, tp, B, T, L, K, key);
+  LAUNCH_CHECK();
+  if (tp.nchunk > 1) {
+    hipLaunchKernelGGL(tail_pre2_finish_kernel, dim3((unsigned)((2L * 3 * B * D + 255) / 256)), dim3(256), 0, s, tp, B, T);
+    LAUNCH_CHECK();
+  }
   return MIMRL_OK;
 }
 
