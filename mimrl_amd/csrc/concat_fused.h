@@ -18,8 +18,8 @@ struct ConcatFwdArgs {
   long pstride;                               // parameter stride between estimators (elements, same for the image and the fp32 bucket)
   // what the backward pass gets (save): 0 nothing (evaluation), 1 fp32 activations a0, a1, a2 (the unfused GEMM-chain backward),
   // 2 compact: bf16 values a0b, a1b (operands of the weight-gradient GEMMs, which round to bf16 anyway), fp32 a2 (the score head's
-  //   weight gradient sum ds * a2 cancels to ~1e-3 of its terms: bf16 values are not good enough) + ReLU bitmasks m1, m2 (one 32-bit
-  //   word per row and 32 columns; the fused backward, stage 1),
+  //   weight gradient sum ds * a2 cancels to ~1e-3 of its terms: bf16 values are not good enough; read by concat_dw3 only) + ReLU
+  //   bitmasks m0, m1, m2 (one 32-bit word per row and 32 columns; the fused backward, stage 1),
   // 3 bitmasks only (the fused backward of stage 2: no weight gradients, only the signs are needed)
   // (round 5: save >= 2 also writes m0, the sign of the pair-expanded layer 0 -- the backward recomputed it from P_i + Q_j with 64 loads
   //  per lane and tile)
@@ -40,21 +40,30 @@ bool concat_fwd_fused_supported(int B, int hid);
 struct ConcatBwdArgs {
   const float* ds;                            // [E][B*B]   d loss / d score
   const float *a0, *a1, *a2;                  // saved post-ReLU activations, fp32 (the forward kernel's save == 1) -- or, compact:
-  int compact;                                // 1: masks m0, m1, m2 (+ fp32 a2 for dw3 in stage 1) instead
+  int compact;                                // 1: masks m0, m1, m2 instead (dw3 is then NOT computed here: concat_dw3)
   const uint32_t *m0, *m1, *m2; const float *P, *Q;   // (P, Q: unused since round 5)
   const float* w3;                            // score-head weight [256], estimator e at + e*pstride
   const __bf16 *W2T, *W1T;                    // transposed bf16 images [256 in][256 out], estimator e at + e*pstride
   long pstride;
   float* dz0;                                 // [E][B*B][256] fp32 (not written when dQ is set)
-  float* dQ;                                  // optional (compact saves), [E][B][256], zeroed by the caller: dQ[j] += sum_i dZ0[i, j] from inside
-                                              // the kernel (runs of tiles per workgroup, partial sums in registers) -- dz0 / pair_reduce_q not needed
+  float* dQ;                                  // optional (compact saves), [E][B][256]: dQ[j] = sum_i dZ0[i, j] from inside the launch (runs of tiles per
+                                              // workgroup, partial sums in registers, then a fixed-order reduction of the partials) -- dz0 / pair_reduce_q
+                                              // not needed.  Needs dq_part = scratch of concat_bwd_dq_scratch(E, B) floats (> 0: else not available)
+  float* dq_part; int dq_slots;               // (dq_slots: filled in by concat_bwd_fused)
   float* dP;                                  // [E][B][256]; B == 128: plain stores, else accumulated (caller zeroes it)
   __bf16 *dz2, *dz1;                          // [E][B*B][256] bf16 or null (stage 2: no weight gradients)
   float *db1, *db2, *dw3, *db3;               // gradient slots (estimator e at + e*pstride) or null
   int E, B;
 };
 bool concat_bwd_fused_supported(int B, int hid);
+bool concat_bwd_dq_plan(int E, int B, int* per, int* nwg, int* slots);
+long concat_bwd_dq_scratch(int E, int B);
 int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a);
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a);
+// dw3[e] += ds[e]^T a2[e]  (compact saves: concat_bwd_fused leaves the score head's weight gradient to this streaming launch)
+int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride);
+#ifdef MIMRL_PHASE_PROBE
+int concat_bwd_read_phases(long long* out);   // 16 slots, read-and-clear (concat_fused.hip)
+#endif
 
 }  // namespace mimrl

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
         const int mu = wm * 32 + (r & 3) + 8 * (r >> 2), m = mu + 4 * lh, col = wn * 128 + ct * 32 + lr;
         const float v = fmaxf(acc[ct][r] + bn[ct], 0.f);
         if (SAVE == 1 || (SAVE == 2 && layer == 2)) { float* __restrict__ drow = dst + (long)mu * CH + ct * 32; drow[soff] = v; }
-        if (SAVE == 3 || (SAVE == 2 && layer == 1)) {   // ReLU sign of (row, these 32 columns): the ballot's low word is row mu (lanes 0..31), its high word row mu + 4.
+        if (SAVE >= 2) {   // ReLU sign of (row, these 32 columns): the ballot's low word is row mu (lanes 0..31), its high word row mu + 4.
           // Every lane of a half stores the same word to the same address (no divergent branch in the unrolled loop)
           const unsigned long long bal = __ballot(v > 0.f);
           dstm[(long)m * 8 + wn * 4 + ct] = lh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
@@ -149,6 +149,19 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
   __syncthreads();
   if (tid < CR) a.scores[ebase + row0 + tid] = sc[tid].get() + a.b3[(long)e * a.pstride];
 }
+
+#ifdef MIMRL_PHASE_PROBE
+// probe build: wall-clock ticks (100 MHz) per phase of concat_bwd_kernel, summed over the tiles of workgroup 0's run, [8 * WG + phase]:
+// 0 dZ2 generation, 1 product W2, 2 epilogue 1 (+ dZ1 out), 3 product W1, 4 epilogue 0 (+ dP), 5 dQ flush, 6 tiles (tools/concat_phase.py)
+__device__ long long g_cc_phase[16];
+#define CPH_DECL long long cph_t = (long long)wall_clock64()
+#define CPH(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const long long n_ = (long long)wall_clock64(); g_cc_phase[(WG ? 8 : 0) + (i)] += n_ - cph_t; cph_t = n_; } } while (0)
+#define CPH_COUNT() do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_cc_phase[(WG ? 8 : 0) + 6] += 1; } while (0)
+#else
+#define CPH_DECL do { } while (0)
+#define CPH(i) do { } while (0)
+#define CPH_COUNT() do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward data-gradient chain (see concat_fused.h); same wave mapping and weight streaming as the forward kernel
@@ -225,19 +238,31 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   const long ebase = (long)e * B * B, tile = (ebase + row0) * CH;
   if (tid < CH) { cs[0][tid].zero(); cs[1][tid].zero(); }
   __syncthreads();
+  CPH_DECL; CPH_COUNT();
+  // compact: the sign words of this wave's 32 rows x 4 column groups are ONE 16-byte load per lane and layer (lane l and l + 32: row l of
+  // the block), requested here, a whole phase ahead of their use; the word of (row, group) then comes out of lane `row` with v_readlane
+  // (round 5: 64 broadcast loads and 64 registers per layer before)
+  u32x4 m1row4 = {0u, 0u, 0u, 0u}, m0row4 = m1row4;
+  if (COMPACT) {
+    m1row4 = *reinterpret_cast<const u32x4*>(a.m1 + (ebase + row0 + wm * 32 + lr) * 8 + wn * 4);
+    m0row4 = *reinterpret_cast<const u32x4*>(a.m0 + (ebase + row0 + wm * 32 + lr) * 8 + wn * 4);
+  }
   // ---- dZ2 = ds w3^T (.) [a2 > 0]; this thread owns one column quad (c4) and 16 of the 128 rows
   {
     const int c4 = (tid & 63) * 4;
     const float4 w3v = *reinterpret_cast<const float4*>(a.w3 + (long)e * a.pstride + c4);
     float4 sdb = make_float4(0.f, 0.f, 0.f, 0.f), sdw = sdb;
     float sds = 0.f;
+    // (compact: all 16 rows' sign words and ds values of this thread requested at once -- one round trip; the 4-at-a-time loop that the
+    //  fp32 a2 path needs was four, and in stage 1 each waited for the previous batch's dZ2 stores as well: stores count on vmcnt)
+    constexpr int NQ = COMPACT ? 16 : 4;
 #pragma unroll 1
-    for (int base = 0; base < CR * 64; base += 512 * 4) {
-      float4 av[4]; float dsv[4]; uint32_t mw[4];
+    for (int base = 0; base < CR * 64; base += 512 * NQ) {
+      float4 av[NQ]; float dsv[NQ]; uint32_t mw[NQ];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int row = (base + tid + 512 * q) >> 6;
-        if (COMPACT && !wg) {
+        if (COMPACT) {
           mw[q] = a.m2[(ebase + row0 + row) * 8 + (c4 >> 5)];
         } else {
           av[q] = *reinterpret_cast<const float4*>(a.a2 + tile + (long)row * CH + c4);
@@ -245,51 +270,63 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
         dsv[q] = a.ds[ebase + row0 + row];
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int row = (base + tid + 512 * q) >> 6;
         const float d = dsv[q];
-        if (COMPACT && !wg) {   // stage 2: only the signs are needed (bitmask)
-          const uint32_t bits = mw[q] >> (c4 & 31);
-          av[q].x = (bits & 1u) ? 1.f : 0.f; av[q].y = (bits & 2u) ? 1.f : 0.f; av[q].z = (bits & 4u) ? 1.f : 0.f; av[q].w = (bits & 8u) ? 1.f : 0.f;
-        }
         float4 v;
-        v.x = av[q].x > 0.f ? d * w3v.x : 0.f; v.y = av[q].y > 0.f ? d * w3v.y : 0.f;
-        v.z = av[q].z > 0.f ? d * w3v.z : 0.f; v.w = av[q].w > 0.f ? d * w3v.w : 0.f;
+        if (COMPACT) {   // only the signs are needed (bitmask); round 5: in stage 1 too -- dw3 = sum ds a2 is concat_dw3_kernel's
+          const uint32_t bits = mw[q] >> (c4 & 31);
+          v.x = (bits & 1u) ? d * w3v.x : 0.f; v.y = (bits & 2u) ? d * w3v.y : 0.f;
+          v.z = (bits & 4u) ? d * w3v.z : 0.f; v.w = (bits & 8u) ? d * w3v.w : 0.f;
+        } else {
+          v.x = av[q].x > 0.f ? d * w3v.x : 0.f; v.y = av[q].y > 0.f ? d * w3v.y : 0.f;
+          v.z = av[q].z > 0.f ? d * w3v.z : 0.f; v.w = av[q].w > 0.f ? d * w3v.w : 0.f;
+        }
         bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
         *reinterpret_cast<bf16x4*>(&gt[row][c4]) = b;
         if (wg) {
-          *reinterpret_cast<bf16x4*>(a.dz2 + tile + (long)row * CH + c4) = b;
+          if (!COMPACT) *reinterpret_cast<bf16x4*>(a.dz2 + tile + (long)row * CH + c4) = b;
           sdb.x += v.x; sdb.y += v.y; sdb.z += v.z; sdb.w += v.w;
-          sdw.x += d * av[q].x; sdw.y += d * av[q].y; sdw.z += d * av[q].z; sdw.w += d * av[q].w;
+          if (!COMPACT) { sdw.x += d * av[q].x; sdw.y += d * av[q].y; sdw.z += d * av[q].z; sdw.w += d * av[q].w; }
           if (c4 == 0) sds += d;
         }
       }
     }
     if (wg) {
       cs[0][c4].add(sdb.x); cs[0][c4 + 1].add(sdb.y); cs[0][c4 + 2].add(sdb.z); cs[0][c4 + 3].add(sdb.w);
-      cs[1][c4].add(sdw.x); cs[1][c4 + 1].add(sdw.y); cs[1][c4 + 2].add(sdw.z); cs[1][c4 + 3].add(sdw.w);
+      if (!COMPACT) { cs[1][c4].add(sdw.x); cs[1][c4 + 1].add(sdw.y); cs[1][c4 + 2].add(sdw.z); cs[1][c4 + 3].add(sdw.w); }
       sds = wave_sum(sds);                       // (only lane 0 of each wave, whose column quad is 0, carries a value)
     }
     __syncthreads();
     if (wg) {
       if (tid < CH) {
         acc_add(a.db2 + (long)e * a.pstride + tid, cs[0][tid].get());
-        acc_add(a.dw3 + (long)e * a.pstride + tid, cs[1][tid].get());
+        if (!COMPACT) acc_add(a.dw3 + (long)e * a.pstride + tid, cs[1][tid].get());
         cs[0][tid].zero(); cs[1][tid].zero();
       }
       if (lane == 0) acc_add(a.db3 + (long)e * a.pstride, sds);
     }
   }
+  CPH(0);
   // ---- dZ1 = (dZ2 W2) (.) [a1 > 0]
   f32x16 acc[4];
   const unsigned soff = (unsigned)(4 * lh * CH + wn * 128 + lr);
   bwd_product(acc, gt, wb, a.W2T + (long)e * a.pstride, tid, lr, lh, wm, wn);
+  if (wg && COMPACT) {
+    // dZ2 leaves from the LDS tile in whole 512-byte rows, HERE: stores count on vmcnt like loads on this ISA, so the next wait for a load
+    // also waits for every older store -- behind the product's last weight chunk the next load is an epilogue (no loads) away; in front
+    // of the product its first chunk waited for them (stage-1 products 6.5 us per tile against 4.1 in stage 2)
+#pragma unroll
+    for (int p8 = 0; p8 < 8; ++p8) {
+      const int row = p8 * 16 + (tid >> 5), c8 = (tid & 31) * 8;
+      *reinterpret_cast<u32x4*>(a.dz2 + tile + (long)row * CH + c8) = *reinterpret_cast<const u32x4*>(&gt[row][c8]);
+    }
+    __syncthreads();     // (the epilogue below overwrites the tile in place)
+  }
+  CPH(1);
   {
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    // compact: the sign words of this wave's 32 rows x 4 column groups are ONE 16-byte load per lane (lane l and l + 32: row l of the
-    // block); the word of (row, group) then comes out of lane `row` with v_readlane (round 5: 64 broadcast loads and 64 registers before)
-    u32x4 mrow4 = {0u, 0u, 0u, 0u};
-    if (COMPACT) mrow4 = *reinterpret_cast<const u32x4*>(a.m1 + (ebase + row0 + wm * 32 + lr) * 8 + wn * 4);
+    const u32x4 mrow4 = m1row4;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       float mk[16];
@@ -322,21 +359,23 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
   }
   __syncthreads();
   if (wg && tid < CH) { acc_add(a.db1 + (long)e * a.pstride + tid, cs[0][tid].get()); cs[0][tid].zero(); }
+  CPH(2);
+  // ---- dZ0 = (dZ1 W1) (.) [a0 > 0]  -> dz0 (fp32) and its column sums = dP[i]
+  bwd_product(acc, gt, wb, a.W1T + (long)e * a.pstride, tid, lr, lh, wm, wn);
   if (wg) {
-    // dZ1 leaves from the finished LDS tile in whole 512-byte rows (round 5; it left as 2-byte stores from the accumulator layout:
-    // 64 store instructions per lane and two 64-byte row pieces per instruction)
+    // dZ1 leaves from the LDS tile in whole 512-byte rows (round 5; it left as 2-byte stores from the accumulator layout: 64 store
+    // instructions per lane, two 64-byte row pieces each) -- behind the product for the reason given at dZ2; the tile is not written again
+    // before the next tile's first barrier
 #pragma unroll
     for (int p8 = 0; p8 < 8; ++p8) {
       const int row = p8 * 16 + (tid >> 5), c8 = (tid & 31) * 8;
       *reinterpret_cast<u32x4*>(a.dz1 + tile + (long)row * CH + c8) = *reinterpret_cast<const u32x4*>(&gt[row][c8]);
     }
   }
-  // ---- dZ0 = (dZ1 W1) (.) [a0 > 0]  -> dz0 (fp32) and its column sums = dP[i]
-  bwd_product(acc, gt, wb, a.W1T + (long)e * a.pstride, tid, lr, lh, wm, wn);
+  CPH(3);
   {
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    u32x4 mrow4 = {0u, 0u, 0u, 0u};
-    if (COMPACT) mrow4 = *reinterpret_cast<const u32x4*>(a.m0 + (ebase + row0 + wm * 32 + lr) * 8 + wn * 4);
+    const u32x4 mrow4 = m0row4;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
       float mk[16];
@@ -370,40 +409,131 @@ __global__ __launch_bounds__(512) void concat_bwd_kernel(ConcatBwdArgs a) {
     float* dp = a.dP + ((long)e * B + i) * CH + tid;
     if (B == CR) *dp = cs[0][tid].get(); else acc_add(dp, cs[0][tid].get());
   }
-  if (RUNS && (lin + 1 == lin_end || (rem + 1) % B == 0)) {   // the run leaves this (estimator, y block): add its dQ partial
-    const long qbase = ((long)e * B + (long)(rem / B) * CR) * CH;
+  CPH(4);
+  if (RUNS && (lin + 1 == lin_end || (rem + 1) % B == 0)) {
+    // the run leaves this (estimator, y block) = block `blk` of B tiles: its dQ partial goes to the block's slot for this workgroup
+    // (plain stores; concat_dq_reduce_kernel adds a block's slots in workgroup order: run-to-run reproducible, unlike float atomics --
+    //  whose 1-ulp order noise in dQ the bf16 roundings of the whole main-model backward amplified to 1.4e-4 of a GRU weight gradient)
+    const int per = (a.E * tiles_e + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int blk = lin / B, wfirst = (blk * B) / per;
+    float* __restrict__ slot = a.dq_part + ((long)blk * a.dq_slots + ((int)blockIdx.x - wfirst)) * (CR * CH);   // (wave-uniform base ...
+    const unsigned lane_off = (unsigned)((wm * 32 + 4 * lh) * CH + wn * 128 + lr);                             //  ... + one 32-bit lane offset)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col = wn * 128 + ct * 32 + lr;
-        acc_add(a.dQ + qbase + (long)m * CH + col, dq[RUNS ? ct : 0][RUNS ? r : 0]);
+        slot[lane_off + (unsigned)(((r & 3) + 8 * (r >> 2)) * CH + ct * 32)] = dq[RUNS ? ct : 0][RUNS ? r : 0];
         dq[RUNS ? ct : 0][RUNS ? r : 0] = 0.f;
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  CPH(5);
  }
 }
 
 }  // namespace
+
+// dQ[block][m][c] = sum over the block's slots, in workgroup order (see the flush in concat_bwd_kernel).  Grid (blocks, 16): 8 rows each.
+namespace {
+__global__ __launch_bounds__(512) void concat_dq_reduce_kernel(const float* __restrict__ part, float* __restrict__ dQ, int B, int per, int slots) {
+  const int blk = blockIdx.x, wfirst = (blk * B) / per, wlast = ((blk + 1) * B - 1) / per, n = wlast - wfirst + 1;
+  const int off = blockIdx.y * (8 * CH) + threadIdx.x * 4;            // 512 threads x float4 = 8 rows of 256
+  const float* __restrict__ p = part + (long)blk * slots * (CR * CH) + off;
+  float4 s = *reinterpret_cast<const float4*>(p);
+  for (int k = 1; k < n; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (long)k * (CR * CH));
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dQ + (long)blk * (CR * CH) + off) = s;   // block = (estimator, y block of 128 rows): dQ is [E][B][256]
+}
+}  // namespace
+
+// dw3[e][c] += sum_rows ds[e][row] * a2[e][row][c]: the score head's weight gradient (VMI.py:33), the one consumer of the fp32 a2 values.
+// Its own streaming launch since round 5 (beside the weight-gradient GEMMs on the helper stream): inside concat_bwd_kernel the 128 KB a2
+// tile was read in front of every tile's products (12 of 34 us per tile at cfg3, HBM-bound, nothing to overlap it with).
+// Workgroup = 256 threads = 64 column quads x 4 row phases, 512 rows; 8 rows per thread in flight.
+namespace {
+__global__ __launch_bounds__(256) void concat_dw3_kernel(const float* __restrict__ ds, const float* __restrict__ a2, float* __restrict__ dw3,
+                                                         long rows, long pstride) {
+  __shared__ float part[4][CH];
+  const int e = blockIdx.y, c4 = (threadIdx.x & 63) * 4, ph = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * 512, r1 = min(rows, r0 + 512);
+  const float* __restrict__ dse = ds + (long)e * rows;
+  const float* __restrict__ ae = a2 + (long)e * rows * CH;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long r = r0 + ph; r < r1; r += 32) {
+    float4 v[8]; float d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long rr = min(r + 4 * q, r1 - 1);
+      v[q] = *reinterpret_cast<const float4*>(ae + rr * CH + c4);
+      d[q] = r + 4 * q < r1 ? dse[rr] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sum.x += d[q] * v[q].x; sum.y += d[q] * v[q].y; sum.z += d[q] * v[q].z; sum.w += d[q] * v[q].w; }
+  }
+  *reinterpret_cast<float4*>(&part[ph][c4]) = sum;
+  __syncthreads();
+  const int c = threadIdx.x;
+  acc_add(dw3 + (long)e * pstride + c, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+}  // namespace
+int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride) {
+  const long rows = (long)B * B;
+  hipLaunchKernelGGL(concat_dw3_kernel, dim3((unsigned)((rows + 511) / 512), E), dim3(256), 0, s, ds, a2, dw3, rows, pstride);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+#ifdef MIMRL_PHASE_PROBE
+int concat_bwd_read_phases(long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cc_phase), sizeof(long long) * 16) != hipSuccess) return 1;
+  long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_cc_phase), z, sizeof z) == hipSuccess ? 0 : 1;
+}
+#endif
+
+// Partition of the E * B * B / 128 tiles into one run per CU (per tiles each); a block of B tiles = one (estimator, y block) is covered by
+// at most `slots` consecutive workgroups.  False: too few tiles for runs (per < 2) -- the caller keeps dz0 + pair_reduce_q.
+bool concat_bwd_dq_plan(int E, int B, int* per, int* nwg, int* slots) {
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t pr; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false; cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+  if (B < CR || B % CR != 0) return false;
+  const int total = E * (int)(((long)B * B) / CR);
+  const int p = (total + cus - 1) / cus;
+  if (p < 2) return false;
+  *per = p; *nwg = (total + p - 1) / p; *slots = (B + p - 1) / p + 1;
+  return true;
+}
+// floats of scratch the plan needs (<= E * B * B * 256, the dz0 buffer it replaces)
+long concat_bwd_dq_scratch(int E, int B) {
+  int per, nwg, slots;
+  if (!concat_bwd_dq_plan(E, B, &per, &nwg, &slots)) return 0;
+  return (long)E * (B / CR) * slots * CR * CH;
+}
 
 bool concat_bwd_fused_supported(int B, int hid) { return hid == CH && B >= CR && B % CR == 0; }
 
 int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a) {
   if (!concat_bwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: batch %d unsupported", a.B);
   if (!(a.dz0 || a.dQ) || !a.dP || !a.ds) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null argument");
-  if (a.compact ? !(a.m0 && a.m1 && a.m2 && (a.a2 || !a.dz2)) : !(a.a0 && a.a1 && a.a2))
+  if (a.compact ? !(a.m0 && a.m1 && a.m2) : !(a.a0 && a.a1 && a.a2))
     return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: null activation input");
   if ((a.dz2 != nullptr) != (a.dz1 != nullptr) || (a.dz2 && !(a.db1 && a.db2 && a.dw3 && a.db3)))
     return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the weight-gradient outputs come together");
   const bool wg = a.dz2 != nullptr;
   if (a.dQ) {   // runs of tiles with dQ in registers: one workgroup per CU, ceil(tiles / CUs) tiles each
-    if (!a.compact) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the in-kernel dQ reduction exists for the compact saves only");
-    static int cus = 0;
-    if (!cus) { hipDeviceProp_t pr; int dev = 0; HIPX(hipGetDevice(&dev)); HIPX(hipGetDeviceProperties(&pr, dev)); cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-    const int total = a.E * (int)(((long)a.B * a.B) / CR), per = (total + cus - 1) / cus;
-    const dim3 grid((unsigned)((total + per - 1) / per));
-    if (wg) hipLaunchKernelGGL((concat_bwd_kernel<true, true, true>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((concat_bwd_kernel<true, false, true>), grid, dim3(512), 0, s, a);
+    if (!a.compact || !a.dq_part) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the in-kernel dQ reduction needs the compact saves and its scratch");
+    int per = 0, nwg = 0, slots = 0;
+    if (!concat_bwd_dq_plan(a.E, a.B, &per, &nwg, &slots)) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: no dQ plan for E = %d, B = %d", a.E, a.B);
+    ConcatBwdArgs b = a;
+    b.dq_slots = slots;
+    const dim3 grid((unsigned)nwg);
+    if (wg) hipLaunchKernelGGL((concat_bwd_kernel<true, true, true>), grid, dim3(512), 0, s, b);
+    else hipLaunchKernelGGL((concat_bwd_kernel<true, false, true>), grid, dim3(512), 0, s, b);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(concat_dq_reduce_kernel, dim3((unsigned)(a.E * (a.B / CR)), 16), dim3(512), 0, s, a.dq_part, a.dQ, a.B, per, slots);
     LAUNCH_CHECK();
     return MIMRL_OK;
   }
@@ -419,7 +549,7 @@ bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 &&
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a) {
   if (!concat_fwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: batch %d unsupported", a.B);
   if (!a.scores || a.save < 0 || a.save > 3) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: bad arguments");
-  if ((a.save == 1 && !(a.a0 && a.a1 && a.a2)) || (a.save == 2 && !(a.a0b && a.a1b && a.a2)) || (a.save >= 2 && !(a.m0 && a.m1)) || (a.save == 3 && !a.m2))
+  if ((a.save == 1 && !(a.a0 && a.a1 && a.a2)) || (a.save == 2 && !(a.a0b && a.a1b && a.a2)) || (a.save >= 2 && !(a.m0 && a.m1 && a.m2)))
     return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: null save buffer");
   const dim3 grid((unsigned)(((long)a.B * a.B) / CR), a.E);
   if (a.save == 0) hipLaunchKernelGGL(concat_fwd_kernel<0>, grid, dim3(512), 0, s, a);

@@ -12,6 +12,7 @@ int mimrl_dbg_kmix_phases(long long* out) { return mimrl::kmix_bwd_read_phases(o
 int mimrl_dbg_nce_phases(long long* out) { return mimrl::nce_read_phases(out); }
 int mimrl_dbg_model_ops_phases(long long* out) { return mimrl::model_ops_read_phases(out); }
 int mimrl_dbg_gru_bwd_phases(long long* out) { return mimrl::gru_bwd_read_phases(out); }
+int mimrl_dbg_concat_bwd_phases(long long* out) { return mimrl::concat_bwd_read_phases(out); }
 #endif
 int mimrl_abi_version(void) { return MIMRL_ABI_VERSION; }
 

@@ -261,8 +261,9 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
       fa.save = !want_grad ? 0 : !concat_compact ? 1 : stage == 1 ? 2 : 3;
       fa.a0 = ca[0]; fa.a1 = ca[1]; fa.a2 = ca[2];
       fa.a0b = reinterpret_cast<__bf16*>(ca[0]); fa.a1b = reinterpret_cast<__bf16*>(ca[1]);
-      fa.m1 = reinterpret_cast<uint32_t*>(ca[1] + half); fa.m2 = reinterpret_cast<uint32_t*>(ca[2] + half);   // (written in stage 2 only: in stage 1 a2 stays fp32 and fills its buffer)
-      fa.m0 = reinterpret_cast<uint32_t*>(ca[0] + half);
+      // sign bitmasks: m1 behind the bf16 a1, m0 and m2 behind the bf16 a0 (in stage 1 the fp32 a2 fills its own buffer)
+      fa.m1 = reinterpret_cast<uint32_t*>(ca[1] + half);
+      fa.m0 = reinterpret_cast<uint32_t*>(ca[0] + half); fa.m2 = fa.m0 + (size_t)NE_MI * B * B * 8;
       MX(concat_fwd_fused(stream, fa));
     } else {
       concat_compact = false;
@@ -372,8 +373,8 @@ int mimrl_handle::mi_backward(int stage) {
     std::memset(&fa, 0, sizeof fa);
     const size_t half = (size_t)NE_MI * B * B * (HID / 2);
     fa.ds = dscores; fa.compact = 1;
-    fa.m1 = reinterpret_cast<const uint32_t*>(ca[1] + half); fa.m2 = reinterpret_cast<const uint32_t*>(ca[2] + half);
-    fa.m0 = reinterpret_cast<const uint32_t*>(ca[0] + half);
+    fa.m1 = reinterpret_cast<const uint32_t*>(ca[1] + half);
+    fa.m0 = reinterpret_cast<const uint32_t*>(ca[0] + half); fa.m2 = fa.m0 + (size_t)NE_MI * B * B * 8;
     fa.a2 = ca[2]; fa.P = cP; fa.Q = cQ;
     fa.w3 = CP(tower0 + tower_l[3][0]);
     fa.W2T = crit_imgT + tower0 + tower_l[2][0]; fa.W1T = crit_imgT + tower0 + tower_l[1][0];
@@ -387,8 +388,10 @@ int mimrl_handle::mi_backward(int stage) {
     if (B > 128) HIPX(hipMemsetAsync(dP, 0, sizeof(float) * NE_MI * B * HID, stream));   // two or more tiles add into each dP row
     // dQ[j] = sum_i dZ0[i, j] inside the kernel (round 5: runs of tiles per workgroup, the partial sums in registers); before, dZ0 went
     // out in fp32 and pair_reduce_q read it back: 2 x 335 MB per pass at cfg3.  MIMRL_NO_CONCAT_DQ=1: that path
-    static const bool dq_in_kernel = knob("MIMRL_NO_CONCAT_DQ") == nullptr;   // tuning knob
-    if (dq_in_kernel) { fa.dQ = dQ; HIPX(hipMemsetAsync(dQ, 0, sizeof(float) * NE_MI * B * HID, stream)); }
+    static const bool dq_knob = knob("MIMRL_NO_CONCAT_DQ") == nullptr;   // tuning knob
+    const long dq_need = concat_bwd_dq_scratch(NE_MI, B);
+    const bool dq_in_kernel = dq_knob && dq_need > 0 && dq_need <= (long)NE_MI * B * B * HID;
+    if (dq_in_kernel) { fa.dQ = dQ; fa.dq_part = dca[2]; }   // (the partials live in the dz0 buffer they replace)
     MX(concat_bwd_fused(stream, fa));
     const bool side_wg = wgrad && multi_stream && wg_helper >= 0;
     if (wgrad) {   // dW2 = dZ2^T a1, dW1 = dZ1^T a0: K = B*B rows, split-K with atomics, beside pair_reduce_q on the helper stream
@@ -401,6 +404,9 @@ int mimrl_handle::mi_backward(int stage) {
         g.M = HID; g.N = HID; g.K = B * B; g.batch = NE_MI; g.atomic = 1;
         MX(G_on(side_wg ? S(wg_helper) : stream, g));
       }
+      // the score head's weight gradient streams a2 on the main stream, under the products on the helper (one of the two products on the
+      // main stream as well: no change, 5.87-5.90 vs 5.87-5.92 ms at cfg3)
+      MX(concat_dw3(stream, dscores, ca[2], CG(tower0 + tower_l[3][0]), NE_MI, B, tower_stride));
     }
     if (!dq_in_kernel) MX(pair_reduce_q(stream, dca[2], dQ, NE_MI, B, HID));
     if (side_wg) MX(join(wg_helper, wg_helper));
