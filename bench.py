@@ -608,6 +608,11 @@ def main():
                 "algorithmic_bytes_per_launch": bwd_by, "algorithmic_flops_per_launch": fl,
                 "avg_launch_ms": avg_us / 1e3, "launches_timed": int(durs.size), "launches_per_step": durs.size / args.steps,
                 "min_launch_us": float(durs.min()), "max_launch_us": float(durs.max()),
+                # the two launches of a step separately: the layer-1 one runs with nothing beside it on its CUs; the layer-0 one shares the
+                # chip with the layer-1 weight-gradient GEMMs since round 5 (the persistent dh0 kernel in front of it holds every CU's LDS, so
+                # those GEMMs start WITH the layer-0 BPTT instead of beside dh0: dh0 + BPTT l0 is 85 us either way)
+                "avg_launch_us_by_layer": {"layer1": float(stamps["gru_bwd_l1"].mean()), "layer0": float(stamps["gru_bwd_l0"].mean())},
+                "frac_layer1_launch": bwd_by / (float(stamps["gru_bwd_l1"].mean()) * 1e-6) / 1e9 / PEAK_HBM_GBS,
                 "us_per_cell_step": avg_us / T,
                 "timing": "in-kernel launch stamps over the timed region (mimrl_set_kernel_stamps): replayed hipGraph, the schedule `value` is measured on",
                 "rocprof_avg_launch_us": prof_avg, "rocprof_source": prof_src,
