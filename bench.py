@@ -271,6 +271,9 @@ def extra_schedules(eng, args, B, T, rank):
             if mdist.attach_comm(eng, 1, 0):
                 extra["ms_per_step_ddp_schedule_no_comm"] = timed(eng.step, n_x)
                 extra["ddp_schedule"] = "one captured graph per step, RCCL collectives inside it (one-rank communicator: no bytes moved)"
+                eng.set_comm_critic_bf16(True)       # + the critic bucket as bf16 on the wire: two conversion launches in the graph
+                extra["ms_per_step_ddp_schedule_bf16_critic_no_comm"] = timed(eng.step, n_x)
+                eng.set_comm_critic_bf16(False)
                 eng.set_comm(None, 1, 0)
                 eng.set_grad_scale(1.0)
         except Exception as e:   # (RCCL missing on the box: the line still prints)

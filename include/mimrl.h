@@ -190,6 +190,10 @@ int mimrl_set_kernel_stamps(mimrl_handle* h, unsigned long long* ring, int slots
 int mimrl_comm_unique_id(void* out128);
 int mimrl_set_comm(mimrl_handle* h, const void* unique_id128, int world, int rank);
 int64_t mimrl_main_late_offset(const mimrl_handle* h);
+/* on != 0: the CRITIC bucket's all-reduce moves bf16 (half the bytes of the larger collective: SURVEY section 5): every rank rounds its
+ * gradients to bf16 once, RCCL sums in bf16, the sum is widened in front of clip + Adam -- two conversion launches inside the same graph.
+ * Changes the update at the 2^-9 level of each gradient (Adam normalises the scale away); the main bucket stays fp32.  Default off. */
+int mimrl_set_comm_critic_bf16(mimrl_handle* h, int on);
 int mimrl_profile_read(mimrl_handle* h, float* ms_sum /*[MIMRL_NPHASES]*/, int32_t* launches /*[MIMRL_NPHASES]*/);  /* syncs; resets */
 /* GEMM family of the eager steps since the last read: out = {algorithmic FLOPs, algorithmic bytes (operands and output once),
  * summed launch durations in ms (HIP events on each launch's own stream), launches}; syncs; resets */

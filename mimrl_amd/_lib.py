@@ -93,6 +93,7 @@ def load() -> C.CDLL:
                                      C.POINTER(C.c_int64), C.c_int, C.c_int, _FP, _FP, _FP, C.c_int, C.c_int]
     lib.mimrl_comm_unique_id.argtypes = [_FP]
     lib.mimrl_set_comm.argtypes = [_FP, _FP, C.c_int, C.c_int]
+    lib.mimrl_set_comm_critic_bf16.argtypes = [_FP, C.c_int]
     lib.mimrl_main_late_offset.argtypes = [_FP]
     lib.mimrl_main_late_offset.restype = C.c_int64
     lib.mimrl_op_gemm16.argtypes = [_FP, _FP, _FP, _FP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _FP, _FP, C.c_int,
@@ -152,7 +153,7 @@ EXPORTS = [
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_stage2_forward_tail", "mimrl_set_grad_scale", "mimrl_destroy", "mimrl_op_gemm", "mimrl_op_gemm_ex", "mimrl_op_gemm16", "mimrl_op_gemm_wgrad_group",
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_mi_sep_infonce", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_sample_anchors", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
-    "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_probe_encoders", "mimrl_set_kernel_stamps", "mimrl_comm_unique_id", "mimrl_set_comm", "mimrl_main_late_offset",
+    "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_probe_encoders", "mimrl_set_kernel_stamps", "mimrl_comm_unique_id", "mimrl_set_comm", "mimrl_main_late_offset", "mimrl_set_comm_critic_bf16",
 ]
 
 

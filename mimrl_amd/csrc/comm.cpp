@@ -73,6 +73,13 @@ int comm_allreduce_sum(void* comm, float* buf, size_t n, hipStream_t s) {
   return MIMRL_OK;
 }
 
+int comm_allreduce_sum_bf16(void* comm, void* buf, size_t n, hipStream_t s) {
+  if (!comm) return set_error(MIMRL_ERR_STATE, "no communicator");
+  if (n == 0) return MIMRL_OK;
+  NCX(g_rccl.AllReduce(buf, buf, n, ncclBfloat16, ncclSum, static_cast<ncclComm_t>(comm), s));
+  return MIMRL_OK;
+}
+
 int comm_destroy(void* comm) {
   if (!comm) return MIMRL_OK;
   MX(rccl_load());

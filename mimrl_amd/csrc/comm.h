@@ -12,6 +12,7 @@ namespace mimrl {
 int comm_unique_id(void* out128);                                         // rank 0: ncclGetUniqueId (128 bytes)
 int comm_init(void** comm, const void* id128, int world, int rank);       // ncclCommInitRank on the current device (collective over the ranks)
 int comm_allreduce_sum(void* comm, float* buf, size_t n, hipStream_t s);  // in place, fp32 sum, stream-ordered (capturable)
+int comm_allreduce_sum_bf16(void* comm, void* buf, size_t n, hipStream_t s);   // the same on n bf16 values (RCCL sums them in bf16)
 int comm_destroy(void* comm);
 
 }  // namespace mimrl

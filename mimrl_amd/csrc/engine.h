@@ -56,6 +56,8 @@ static const char* const kVcmi[NE_CMI] = {"ac_t", "ta_c", "vc_t", "tv_c", "tc_a"
 
 // engine_kernels.hip: the step's own kernels (one thread block each), enqueued on `s`
 void launch_begin_stage(hipStream_t s, int* rng_step, int* adam_step, float* scalars, int scal_off, int scal_n);
+void launch_bucket_to_bf16(hipStream_t s, const float* src, void* dst, long n);
+void launch_bucket_from_bf16(hipStream_t s, const void* src, float* dst, long n);
 void launch_mae(hipStream_t s, const float* pred, const float* y, float* dpred, float* task, int B);
 void launch_finalize_stage1(hipStream_t s, float* scal, const float* mi, const float* cmi, const float* bce, const float* coef1);
 void launch_finalize_stage2(hipStream_t s, float* scal, const float* mi, const float* cmi, const float* coef2, int have_mi);
@@ -225,6 +227,9 @@ struct mimrl_handle {
   // pass and the fused clip + Adam, on the engine's own streams: the collectives are nodes of the captured step graph, and the main
   // bucket travels in two pieces -- [0, late_offset) on `comm_s` under the layer-0 BPTT, the layer-0 tail behind it.
   void* comm = nullptr; int comm_world = 1, comm_rank = 0;
+  // mimrl_set_comm_critic_bf16: the critic bucket (13.4 MB at the benchmark sizes, the larger of the two collectives) crosses the links as
+  // bf16 -- rounded once before the all-reduce, summed by RCCL in bf16, widened again in front of clip + Adam
+  bool comm_crit_bf16 = false; void* comm_crit16 = nullptr;
   hipStream_t comm_s = nullptr;
   bool comm_split = true;              // MIMRL_DDP_SPLIT=0: the main bucket in one piece behind the whole backward pass
   KernelStamp kstamp;                  // launch stamps of the recurrence kernels (mimrl_set_kernel_stamps); id: 0/1 forward layer 0/1, 2/3 BPTT layer 1/0
@@ -319,6 +324,15 @@ struct mimrl_handle {
   int reduce_bucket(int stage) {
     if (!comm) return MIMRL_OK;
     Range rg(stage == 1 ? "mimrl.stage1.allreduce(crit_g) [RCCL]" : "mimrl.stage2.allreduce(main_g) [RCCL]");
+    if (stage == 1 && comm_crit_bf16) {
+      const long n = layout.floats[MIMRL_GROUP_CRITIC];
+      launch_bucket_to_bf16(stream, bufs.crit_g, comm_crit16, n);
+      LAUNCH_CHECK();
+      MX(comm_allreduce_sum_bf16(comm, comm_crit16, (size_t)n, stream));
+      launch_bucket_from_bf16(stream, comm_crit16, bufs.crit_g, n);
+      LAUNCH_CHECK();
+      return MIMRL_OK;
+    }
     return comm_allreduce_sum(comm, stage == 1 ? bufs.crit_g : bufs.main_g, (size_t)layout.floats[stage == 1 ? MIMRL_GROUP_CRITIC : MIMRL_GROUP_MAIN], stream);
   }
   // stage 2 with a communicator: the gradient pass in two parts with the early range of the main bucket in flight under the second

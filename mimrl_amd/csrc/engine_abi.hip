@@ -434,6 +434,21 @@ int mimrl_set_comm(mimrl_handle* h, const void* unique_id128, int world, int ran
   return MIMRL_OK;
 }
 
+int mimrl_set_comm_critic_bf16(mimrl_handle* h, int on) {
+  if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
+  if ((on != 0) == h->comm_crit_bf16) return MIMRL_OK;
+  HIPX(hipStreamSynchronize(h->user_stream));
+  h->drop_graphs();
+  if (on && !h->comm_crit16) HIPX(hipMalloc(&h->comm_crit16, sizeof(uint16_t) * (size_t)h->layout.floats[MIMRL_GROUP_CRITIC]));
+  h->comm_crit_bf16 = on != 0;
+  if (on && h->comm && h->bound) {   // RCCL's set-up for the new datatype outside any capture
+    HIPX(hipMemsetAsync(h->comm_crit16, 0, 16, h->user_stream));
+    MX(mimrl::comm_allreduce_sum_bf16(h->comm, h->comm_crit16, 8, h->user_stream));
+    HIPX(hipStreamSynchronize(h->user_stream));
+  }
+  return MIMRL_OK;
+}
+
 int64_t mimrl_main_late_offset(const mimrl_handle* h) { return h ? (int64_t)h->layout.late_offset : 0; }
 
 int mimrl_set_stage2_prefetch(mimrl_handle* h, int on) {
@@ -470,6 +485,7 @@ void mimrl_destroy(mimrl_handle* h) {
   if (h->pre_stream) (void)hipStreamDestroy(h->pre_stream);
   if (h->comm) (void)mimrl::comm_destroy(h->comm);
   if (h->comm_s) (void)hipStreamDestroy(h->comm_s);
+  if (h->comm_crit16) (void)hipFree(h->comm_crit16);
   if (h->ws) (void)hipFree(h->ws);
   delete h;
 }

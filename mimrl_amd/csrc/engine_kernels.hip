@@ -118,6 +118,27 @@ __global__ void stage_boundary_kernel(float* scal, const float* mi, const float*
 
 namespace eng {
 
+// fp32 <-> bf16 images of a gradient bucket around its bf16 all-reduce (mimrl_set_comm_critic_bf16); n a multiple of 4 (buckets are)
+__global__ void bucket_to_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    bf16x4 p; p[0] = to_bf16(v.x); p[1] = to_bf16(v.y); p[2] = to_bf16(v.z); p[3] = to_bf16(v.w);
+    reinterpret_cast<bf16x4*>(dst)[i] = p;
+  }
+}
+__global__ void bucket_from_bf16_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const bf16x4 p = reinterpret_cast<const bf16x4*>(src)[i];
+    reinterpret_cast<float4*>(dst)[i] = make_float4((float)p[0], (float)p[1], (float)p[2], (float)p[3]);
+  }
+}
+void launch_bucket_to_bf16(hipStream_t s, const float* src, void* dst, long n) {
+  hipLaunchKernelGGL(bucket_to_bf16_kernel, dim3((unsigned)std::min<long>((n / 4 + 255) / 256, 2048)), dim3(256), 0, s, src, static_cast<__bf16*>(dst), n / 4);
+}
+void launch_bucket_from_bf16(hipStream_t s, const void* src, float* dst, long n) {
+  hipLaunchKernelGGL(bucket_from_bf16_kernel, dim3((unsigned)std::min<long>((n / 4 + 255) / 256, 2048)), dim3(256), 0, s, static_cast<const __bf16*>(src), dst, n / 4);
+}
+
 void launch_begin_stage(hipStream_t s, int* rng_step, int* adam_step, float* scalars, int scal_off, int scal_n) {
   hipLaunchKernelGGL(begin_stage_kernel, dim3(1), dim3(64), 0, s, rng_step, adam_step, scalars, scal_off, scal_n);
 }

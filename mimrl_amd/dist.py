@@ -93,6 +93,8 @@ def attach_comm(engine, world: int, rank: int) -> bool:
     else:
         uid = type(engine).comm_unique_id()
     engine.set_comm(uid, world, rank)
+    if os.environ.get("MIMRL_DDP_BF16_CRITIC") is not None:      # opt-in: the 13.4 MB critic bucket crosses the links as bf16
+        engine.set_comm_critic_bf16(True)
     engine._ddp_world = world
     flush_c_stdio()
     return True

@@ -242,6 +242,11 @@ class HipEngine:
         self.comm_world = int(world)
         self.set_grad_scale(1.0 / world)
 
+    def set_comm_critic_bf16(self, on: bool):
+        """The critic bucket's all-reduce in bf16 (include/mimrl.h: mimrl_set_comm_critic_bf16): half the bytes of the larger collective."""
+        self._coherent()
+        check(self.lib.mimrl_set_comm_critic_bf16(self.handle, int(bool(on))))
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = (C.c_char * 128)()
