@@ -233,6 +233,61 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* scores, flo
                 dlb ? dlb + e * lb_stride : nullptr);
 }
 
+// InfoNCE on score matrices that live in memory (the concat critic; round 5): the bound is ROW-wise -- mi = log B + mean_i(s_ii - lse_i),
+// dS_ij = gs / B ((i == j) - e^{s_ij - lse_i}) (VMI.py:162-166) -- so one wave per row, 16 rows per workgroup, B / 16 workgroups per
+// estimator instead of ONE: mi_bound_kernel walked each 256 x 256 matrix of cfg3 with a single workgroup (5 CUs busy, 68 + 49 us on the
+// chain of the two stages).  The row sums of a workgroup go to a slot, the last workgroup of an estimator (ticket) adds the slots in order:
+// the value does not depend on arrival order.  B <= 1024 (a row in registers: 16 values per lane).
+constexpr int NCE_MAX_EST = 16;
+__device__ unsigned g_nce_ticket[NCE_MAX_EST];
+__device__ float g_nce_part[NCE_MAX_EST][64];
+__global__ __launch_bounds__(1024) void mi_infonce_rows_kernel(const float* __restrict__ scores, float* __restrict__ dscores, float* __restrict__ mi,
+                                                               float* __restrict__ mil, const float* __restrict__ gscale, int B) {
+  __shared__ float red[16];
+  __shared__ int last;
+  const int e = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = blk * 16 + w;
+  const float invB = 1.f / B, gs = gscale ? gscale[e] : 0.f;
+  float part = 0.f;
+  if (i < B) {                                                     // (wave-uniform)
+    const float* __restrict__ row = scores + ((long)e * B + i) * B;
+    float v[16], mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int j = lane + 64 * q; v[q] = j < B ? row[j] : -INFINITY; mx = fmaxf(mx, v[q]); }
+    const float sii = row[i];
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) se += __expf(v[q] - mx);           // (padding: e^{-inf} = 0)
+    se = wave_sum(se);
+    const float lse = mx + __logf(se);
+    if (lane == 0) part = sii - lse;
+    if (dscores) {
+      float* __restrict__ drow = dscores + ((long)e * B + i) * B;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = lane + 64 * q;
+        if (j < B) drow[j] = gs * invB * ((i == j ? 1.f : 0.f) - __expf(v[q] - lse));
+      }
+    }
+  }
+  const float tot = block_sum(part, red);
+  if (tid == 0) {
+    g_nce_part[e][blk] = tot;
+    __threadfence();
+    last = atomicAdd(&g_nce_ticket[e], 1u) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (last && tid == 0) {
+    __threadfence();
+    float s = 0.f;
+    for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&g_nce_part[e][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mi[e] = __logf((float)B) + s * invB;
+    if (mil) mil[e] = -mi[e];
+    g_nce_ticket[e] = 0u;
+  }
+}
+
 // Separable critic, one estimator per workgroup, everything between the tower outputs and their gradients on chip:
 //   scores = h(y) g(x)^T (VMI.py:55-57) -> bound (+ d/dscores, in place in LDS) -> d h = dS g,  d g = dS^T h.
 // 16 waves: one 32x32 MFMA tile each (B <= 128, B % 32 == 0); bf16 operands, fp32 accumulate.
@@ -752,6 +807,11 @@ int mi_sep_nce_tiled(hipStream_t s, const float* tout, float* dtout, float* mi, 
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
                      int B, int bound, unsigned lossform, const float* lb, float* dlb, long lb_stride) {
   if (B > 1024) return set_error(MIMRL_ERR_ARG, "mi_bound: batch %d > 1024 per rank", B);
+  if (bound == BOUND_INFONCE && E <= NCE_MAX_EST) {   // row-wise bound: one wave per row (the general kernel is one workgroup per estimator)
+    hipLaunchKernelGGL(mi_infonce_rows_kernel, dim3((B + 15) / 16, E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
   hipLaunchKernelGGL(mi_bound_kernel, dim3(E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B, bound, lossform, lb, dlb,
                      lb_stride);
   LAUNCH_CHECK();
