@@ -28,35 +28,44 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
   {
     float* __restrict__ o0 = a.a0 + (ebase + row0) * CH;
     __bf16* __restrict__ o0b = a.a0b + (ebase + row0) * CH;
+    // B a multiple of 128 (every benchmark shape): the tile is ONE x row, so this thread's P quad is the same for all 16 of its pair rows --
+    // loaded once, and the Q quads in two batches of 8 (round 5: 4 batches of 4 + 4 = four dependent round trips in front of the products)
+    auto gen = [&](auto ONE_I) __attribute__((always_inline)) {
+      constexpr bool one_i = decltype(ONE_I)::value;
+      constexpr int NQ = one_i ? 8 : 4;
+      float4 xone = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (one_i) xone = *reinterpret_cast<const float4*>(P + (row0 / B) * CH + (tid & 63) * 4);
 #pragma unroll 1
-    for (int base = 0; base < CR * 64; base += 512 * 4) {
-      float4 x[4], y[4];
+      for (int base = 0; base < CR * 64; base += 512 * NQ) {
+        float4 x[NQ], y[NQ];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
-        const long p = row0 + row;
-        const int i = (int)(p / B), j = (int)(p - (long)i * B);
-        x[q] = *reinterpret_cast<const float4*>(P + (long)i * CH + c4);
-        y[q] = *reinterpret_cast<const float4*>(Q + (long)j * CH + c4);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
-        float4 v;
-        v.x = fmaxf(x[q].x + y[q].x, 0.f); v.y = fmaxf(x[q].y + y[q].y, 0.f); v.z = fmaxf(x[q].z + y[q].z, 0.f); v.w = fmaxf(x[q].w + y[q].w, 0.f);
-        bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
-        if (SAVE == 1) *reinterpret_cast<float4*>(o0 + (long)row * CH + c4) = v;
-        else if (SAVE == 2) *reinterpret_cast<bf16x4*>(o0b + (long)row * CH + c4) = b;
-        if (SAVE >= 2) {   // sign word of (row, 32 columns) = the nibbles of 8 neighbouring lanes (a wave holds one row: lane = column quad)
-          uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-          nib |= (uint32_t)__shfl_down((int)nib, 1) << 4;
-          nib |= (uint32_t)__shfl_down((int)nib, 2) << 8;
-          nib |= (uint32_t)__shfl_down((int)nib, 4) << 16;
-          if ((lane & 7) == 0) a.m0[(ebase + row0 + row) * 8 + (lane >> 3)] = nib;
+        for (int q = 0; q < NQ; ++q) {
+          const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
+          const long p = row0 + row;
+          const int i = (int)(p / B), j = (int)(p - (long)i * B);
+          x[q] = one_i ? xone : *reinterpret_cast<const float4*>(P + (long)i * CH + c4);
+          y[q] = *reinterpret_cast<const float4*>(Q + (long)j * CH + c4);
         }
-        *reinterpret_cast<bf16x4*>(&act[row][c4]) = b;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int idx = base + tid + 512 * q, row = idx >> 6, c4 = (idx & 63) * 4;
+          float4 v;
+          v.x = fmaxf(x[q].x + y[q].x, 0.f); v.y = fmaxf(x[q].y + y[q].y, 0.f); v.z = fmaxf(x[q].z + y[q].z, 0.f); v.w = fmaxf(x[q].w + y[q].w, 0.f);
+          bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
+          if (SAVE == 1) *reinterpret_cast<float4*>(o0 + (long)row * CH + c4) = v;
+          else if (SAVE == 2) *reinterpret_cast<bf16x4*>(o0b + (long)row * CH + c4) = b;
+          if (SAVE >= 2) {   // sign word of (row, 32 columns) = the nibbles of 8 neighbouring lanes (a wave holds one row: lane = column quad)
+            uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            nib |= (uint32_t)__shfl_down((int)nib, 1) << 4;
+            nib |= (uint32_t)__shfl_down((int)nib, 2) << 8;
+            nib |= (uint32_t)__shfl_down((int)nib, 4) << 16;
+            if ((lane & 7) == 0) a.m0[(ebase + row0 + row) * 8 + (lane >> 3)] = nib;
+          }
+          *reinterpret_cast<bf16x4*>(&act[row][c4]) = b;
+        }
       }
-    }
+    };
+    if (B % CR == 0) gen(std::true_type{}); else gen(std::false_type{});
   }
   if (tid < CR) sc[tid].zero();
   float hp[16];
@@ -123,7 +132,9 @@ __global__ __launch_bounds__(512) void concat_fwd_kernel(ConcatFwdArgs a) {
         const float v = fmaxf(acc[ct][r] + bn[ct], 0.f);
         if (SAVE == 1 || (SAVE == 2 && layer == 2)) { float* __restrict__ drow = dst + (long)mu * CH + ct * 32; drow[soff] = v; }
         if (SAVE >= 2) {   // ReLU sign of (row, these 32 columns): the ballot's low word is row mu (lanes 0..31), its high word row mu + 4.
-          // Every lane of a half stores the same word to the same address (no divergent branch in the unrolled loop)
+          // Every lane of a half stores the same word to the same address (no divergent branch in the unrolled loop).  Round 5 tried collecting
+          // the words in the lane that owns their row (two v_cndmask per word) for ONE 16-byte store per row: 20 us SLOWER per launch
+          // (300 / 210 vs 280 / 194 us, same box) -- the selects are a dependent chain on the epilogue, the 64 small stores are not
           const unsigned long long bal = __ballot(v > 0.f);
           dstm[(long)m * 8 + wn * 4 + ct] = lh ? (uint32_t)(bal >> 32) : (uint32_t)bal;
         }
