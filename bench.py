@@ -368,7 +368,17 @@ def main():
     # MIMRL_DDP_TORCH=1: the round-4 transport (torch.distributed between per-stage graphs)
     in_lib = False
     if world > 1 or os.environ.get("MIMRL_DDP_FORCE_COLLECTIVES") is not None:
-        in_lib = mdist.attach_comm(eng, world, rank)
+        try:
+            in_lib = mdist.attach_comm(eng, world, rank)
+        except Exception as e:      # noqa: BLE001 -- librccl missing / communicator creation refused: the round-4 transport still works
+            log(f"in-library RCCL communicator not available ({e!r}); falling back to torch.distributed between graph launches")
+            in_lib = False
+        if world > 1:               # every rank must take the same path
+            flag = torch.tensor([1 if in_lib else 0], device="cuda")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if in_lib and int(flag.item()) == 0:
+                eng.set_comm(None, 1, 0)
+                in_lib = False
         if in_lib:
             eng.set_stage2_prefetch(0 if args.no_prefetch else 1)
         log(f"data-parallel transport: {'RCCL inside the library (in-graph)' if in_lib else 'torch.distributed between graph launches'}")
