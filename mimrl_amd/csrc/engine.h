@@ -132,6 +132,10 @@ struct mimrl_handle {
   __bf16 *crit_frag = nullptr, *crit_fragT = nullptr;
   FragTable ftab;
   bool frag_side_pending = false;      // the refresh behind the critic Adam runs on side 3 and has not been joined yet
+  bool frag_tr_deferred = false;       // the data-gradient fragment images are still to be launched (enqueue_apply -> estimators_all: ftab_tr)
+  FragTable ftab_tr;
+  bool adam_frag_on = true;            // MIMRL_ADAM_FRAG=0 (mimrl_create)
+  bool boundary_in_adam = false;       // the stage boundary rode on the critic Adam launch (enqueue_apply -> run)
   bool img_valid = false;
   unsigned knn_ovr_mask[2] = {0u, 0u};  // per stage: CMI calls whose neighbour rows come from bufs.knn_override
   bool knn_pre = true;                 // prefetch mode: stage 2's kNN sampling also runs inside stage 1, beside the encoder prefix (MIMRL_NO_KNN_PREFETCH=1: off)
@@ -187,6 +191,7 @@ struct mimrl_handle {
   bool part0_done = false;             // mimrl_stage_grads_part(h, 2, 0) ran on the bound batch and nothing since: part 1 may follow
   bool l0_xin = false;                 // this step's layer-0 forward ran the fused-projection (8-wave) kernel: its BPTT launch must match
   bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
+  bool h16_live = false;               // h0h holds the fp16 copy of THIS pass's layer-0 outputs (set by the forward pass)
   bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
@@ -484,6 +489,8 @@ struct mimrl_handle {
   int route_feature_grads();
   GatherSum head_gather;               // sources of the F_F gradient (summed inside head_bwd) while head_gather_on
   bool head_gather_on = false;
+  bool ln_tail_fuse = false;           // MIMRL_LN_TAIL_FUSE=1 (mimrl_create; opt-in)
+  bool ln_tail_want = false, ln_tail_done = false;   // model_backward -> cube_backward: fuse the encoders' LN backward into block 0's L-axis kernel; -> encoders_backward: done
   hipEvent_t ev_dmean = nullptr;       // T / A / V feature gradients ready (gathered on side 0)
   hipEvent_t ev_pre = nullptr;         // MIMRL_BPTT_FIRST: the point the parked kernels are flushed behind (encoders_backward -> gru_layer_backward)
   int estimators_all(int stage, bool want_grad, bool backward);

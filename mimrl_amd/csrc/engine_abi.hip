@@ -61,6 +61,10 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->h16_on = knob("MIMRL_NO_H16") == nullptr;
   h->xin_on = knob("MIMRL_NO_XIN") == nullptr;
   h->fused_cube_bwd = knob("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
+  h->adam_frag_on = !(knob("MIMRL_ADAM_FRAG") && atoi(knob("MIMRL_ADAM_FRAG")) == 0);
+  // opt-in (measured slower at cfg2, 0.814-0.819 vs 0.799-0.800 ms: the parked block-0 weight gradients then start together with the layer-1 BPTT
+  // instead of 30 us ahead of it, and the BPTT beside them takes 74 instead of 53 us -- DESIGN section 7)
+  h->ln_tail_fuse = knob("MIMRL_LN_TAIL_FUSE") && atoi(knob("MIMRL_LN_TAIL_FUSE")) != 0;
   h->fused_concat = knob("MIMRL_NO_FUSED_CONCAT") == nullptr;
   h->fwd_f16 = knob("MIMRL_FWD_BF16") == nullptr;
   // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches: the four layer-0

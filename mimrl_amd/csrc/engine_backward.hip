@@ -219,6 +219,21 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       fa.dy = gbuf[i_dy]; fa.du = gbuf[i_du]; fa.dx = gbuf[i_dx];
       fa.db2 = a.fc2.b >= 0 ? Gm(a.fc2.b) : nullptr; fa.db1 = a.fc1.b >= 0 ? Gm(a.fc1.b) : nullptr;
       fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.C = (int)C; fa.act = cfg.activation;
+      // block 0 inside the model's backward: the encoders' LayerNorm + ReLU + dropout backward rides on this launch (LAxisLnSide) -- one launch
+      // and one queue hop less in front of the layer-1 BPTT (cfg2: ln_relu_drop_bwd16 22 us + 10-20 us of hop).  Opt-in, MIMRL_LN_TAIL_FUSE=1: see mimrl_create.
+      if (i == 0 && ln_tail_want && ln_tail_fuse && ik == 3 && id == 128 && cfg.d_common == 128 && cfg.seq_len <= il) {
+        const size_t BD = (size_t)B * cfg.d_common;
+        const float* dmean = dfeat + BD;
+        if (head_gather_on && ev_dmean) { HIPX(hipStreamWaitEvent(stream, ev_dmean, 0)); ev_dmean = nullptr; }   // dmean gathered on side 0
+        for (int m = 0; m < 2; ++m)
+          fa.lt[m] = LAxisLnSide{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dmean + (1 + m) * BD, ds[m], Gm(ln_g[m]), Gm(ln_b[m]),
+                                 cfg.dropout[1 + m], (uint32_t)(1 + m)};
+        fa.lt_on = 1; fa.lt_T = cfg.seq_len; fa.lt_key = key();
+        ln_tail_done = true;
+        // this block's D-axis parked work goes out NOW, beside this launch: behind it it would start together with the layer-1 BPTT
+        static const bool split_flush = knob("MIMRL_LN_TAIL_SPLIT_FLUSH") == nullptr || atoi(knob("MIMRL_LN_TAIL_SPLIT_FLUSH")) != 0;
+        if (defer && split_flush) MX(flush_deferred(1));
+      }
       MX(laxis_bwd_fused(stream, fa));
       MX(W_fork(1, 3));
       MX(W_lnpar(1, b.l.y, b.l.mean, b.l.rstd, gbuf[cur], Gm(a.ln_g), Gm(a.ln_b), B, ol, (int)C));
@@ -407,7 +422,8 @@ int mimrl_handle::model_backward() {
               cfg.compose_t_sum, cfg.compose_k_sum, head_gather_on ? &head_gather : nullptr));
   int ci = 0;
   deferred.clear();
-  { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
+  ln_tail_want = true; ln_tail_done = false;
+  { Scope sc(this, MIMRL_PH_CUBE_BWD); const int r = cube_backward(0, &ci); ln_tail_want = false; MX(r); }
   MX(dbg_delay(stream, 7));
   return encoders_backward(gbuf[ci]);
 }
@@ -434,8 +450,11 @@ int mimrl_handle::encoders_backward(float* dcube) {
   };
   if (text_bwd_first) MX(text_bwd());
   if (head_gather_on && ev_dmean) { HIPX(hipStreamWaitEvent(stream, ev_dmean, 0)); ev_dmean = nullptr; }   // dmean gathered on side 0
-  // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
-  {
+  // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1); already done when it rode on the L-axis kernel
+  // of CubeMLP block 0 (cube_backward: LAxisLnSide)
+  const bool ln_done = ln_tail_done;
+  ln_tail_done = false;
+  if (!ln_done) {
     LnSide2 sd[2];
     for (int m = 0; m < 2; ++m)
       sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], ds[m], Gm(ln_g[m]), Gm(ln_b[m]), 1 + m,
@@ -589,6 +608,13 @@ int mimrl_handle::gru_layer_backward(int l) {
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih);
         if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; }
+        // layer 1: the layer-0 outputs from the recurrence kernel's fp16 copy (half the bytes of an operand the 128-wide tiles fetch ~2x;
+        // fp16 -> bf16 in registers: the product rounds to bf16 anyway, the double rounding moves a value by <= 2^-11 of itself).
+        // MIMRL_DWIH_H16=0: the fp32 outputs.
+        static const bool dwih_h16 = !(knob("MIMRL_DWIH_H16") && atoi(knob("MIMRL_DWIH_H16")) == 0);   // tuning knob
+        if (lbf && both && dwih_h16 && h16_live && h0h[0] && h0h[1]) {
+          q.B = reinterpret_cast<const float*>(h0h[0]); q.b_bf16 = 1; q.b_f16cvt = 1; q.sb_bo = h0h[1] - h0h[0];
+        }
         MX(G_on(pick(), q)); }
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, hprev[l][m][0], H, Gm(gf.w_hh), H, G, H, (int)BT_);   // dgh = dg columns [0,2H) u [3H,4H)
         q.a_gap_at = 2 * H; q.a_gap_rows = H;

@@ -496,40 +496,59 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   bool imgT_pending = false;
   imgT_ready = false;
   if (frag_side_pending) { MX(join(3, 3)); frag_side_pending = false; }
+  // data-gradient fragment images whose launch enqueue_apply left to this stage (the forward ones came with the critic update): on side 3
+  // in front of the transposed-image refresh, which the backward stacks join -- or right here when that refresh does not happen
+  auto frag_tr_launch = [&](hipStream_t st) -> int {
+    if (!frag_tr_deferred) return MIMRL_OK;
+    frag_tr_deferred = false;
+    return bf16_frag_images(st, bufs.crit_p, crit_frag, ftab_tr);
+  };
   if (backward && bf_bwd && fused_mlp && crit_imgT && ttab.n > 0) {   // transposed weight images for the fused data-gradient chains,
     if (!(skip_imgT_refresh && stage == 1)) {                         // built beside the forward stacks (combined step: once per step,
       MX(fork(3, 3));                                                 // in stage 2 -- stage 1 of the NEXT step sees the same critics)
       // capture order: the launch itself goes BEHIND the CMI branch's forward kernels (see cmi_branch) -- graph nodes are dispatched in
       // capture order, and as the first child of the stage boundary it held up both forward branches by ~18 us (MIMRL_IMGT_FIRST=1)
       imgT_pending = !imgt_first && multi_stream && side_on(3) && side_on(5);
+      if (!imgT_pending) MX(frag_tr_launch(S(3)));
       if (!imgT_pending && !dbg_skip_imgt) MX(bf16_transposed_images(S(3), bufs.crit_p, crit_imgT, ttab));
     }
     imgT_ready = true;
   }
+  if (!imgT_pending) MX(frag_tr_launch(stream));   // (no refresh on side 3 in this stage: on the chain, as before round 5b)
   static const int dbg_skip = dbg_env("MIMRL_DBG_SKIP_EST") ? atoi(dbg_env("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
   MX(fork(5, 5));
   MX(chain(5, 4));                       // the CMI branch needs the kNN indices
-  auto cmi_branch = [&]() -> int {
-    if (dbg_skip & 1) return MIMRL_OK;
-    StreamGuard g(this, S(5));
-    bf16 = bf_fwd;
-    MX(cmi_forward(stage, want_grad));
-    if (imgT_pending) {   // side 3 already waits for the stage boundary (fork above); only the launch was held back
-      imgT_pending = false;
-      if (!dbg_skip_imgt) MX(bf16_transposed_images(side[3], bufs.crit_p, crit_imgT, ttab));
-    }
-    MX(dbg_delay(stream, stage == 1 ? 4 : 14));
-    // (no helper side stream for this branch's weight gradients: it runs on side 5, and a fork / join pair hanging off a captured stream
-    //  other than the capture's origin sends this HIP runtime's EndCapture into an endless recursion -- tried, core dump)
-    if (backward) { bf16 = bf_bwd; if (imgT_ready && !(skip_imgT_refresh && stage == 1)) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
+  static const int interleave = knob("MIMRL_EST_INTERLEAVE") ? atoi(knob("MIMRL_EST_INTERLEAVE")) : 0;
+  const bool imgT_late = ((interleave >> (stage - 1)) & 1) && interleave >= 4;   // 4 + mask: the image launches on side 3 are captured behind BOTH forward halves
+  auto imgT_launch = [&]() -> int {   // side 3 already waits for the stage boundary (fork above); only the launch was held back
+    imgT_pending = false;
+    MX(frag_tr_launch(side[3]));
+    if (!dbg_skip_imgt) MX(bf16_transposed_images(side[3], bufs.crit_p, crit_imgT, ttab));
     return MIMRL_OK;
   };
-  auto mi_branch = [&]() -> int {
-    bf16 = bf_fwd;
+  // part: 1 = forward, 2 = backward, 3 = both
+  auto cmi_branch = [&](int part) -> int {
+    if (dbg_skip & 1) return MIMRL_OK;
+    StreamGuard g(this, S(5));
+    if (part & 1) {
+      bf16 = bf_fwd;
+      MX(cmi_forward(stage, want_grad));
+      if (imgT_pending && !imgT_late) MX(imgT_launch());
+      MX(dbg_delay(stream, stage == 1 ? 4 : 14));
+    }
+    // (no helper side stream for this branch's weight gradients: it runs on side 5, and a fork / join pair hanging off a captured stream
+    //  other than the capture's origin sends this HIP runtime's EndCapture into an endless recursion -- tried, core dump)
+    if ((part & 2) && backward) { bf16 = bf_bwd; if (imgT_ready && !(skip_imgT_refresh && stage == 1)) MX(chain(5, 3)); MX(cmi_backward(stage)); MX(dbg_delay(stream, stage == 1 ? 6 : 16)); }
+    return MIMRL_OK;
+  };
+  auto mi_branch = [&](int part) -> int {
     if (dbg_skip & 2) return MIMRL_OK;
-    { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
-    MX(dbg_delay(stream, stage == 1 ? 3 : 15));
-    if (backward) {
+    if (part & 1) {
+      bf16 = bf_fwd;
+      { Scope sc(this, MIMRL_PH_EST_FWD); MX(mi_forward(stage, want_grad)); }
+      MX(dbg_delay(stream, stage == 1 ? 3 : 15));
+    }
+    if ((part & 2) && backward) {
       bf16 = bf_bwd;
       if (imgT_ready && !(skip_imgT_refresh && stage == 1)) MX(join(3, 3));
       Scope sc(this, MIMRL_PH_EST_BWD);
@@ -543,8 +562,17 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   };
   // capture order of the two branches (graph nodes are dispatched in capture order; bit 0: stage 1, bit 1: stage 2 -> MI first)
   static const int mi_first = knob("MIMRL_EST_MI_FIRST") ? atoi(knob("MIMRL_EST_MI_FIRST")) : 0;
-  if ((mi_first >> (stage - 1)) & 1) { MX(mi_branch()); MX(cmi_branch()); }
-  else { MX(cmi_branch()); MX(mi_branch()); }
+  // round 5b: both FORWARD halves are captured in front of either backward half (bit mask like mi_first; default: stage 2).  With the stage
+  // boundary inside the critic update both branches hang off the update node directly, and with a whole branch captured first the other
+  // branch's first kernel landed on a hardware queue BEHIND the first branch's weight-gradient launch (head-of-line: 49 us late).
+  if ((interleave >> (stage - 1)) & 1) {
+    if ((mi_first >> (stage - 1)) & 1) { MX(mi_branch(1)); MX(cmi_branch(1)); }
+    else { MX(cmi_branch(1)); MX(mi_branch(1)); }
+    if (imgT_pending) MX(imgT_launch());
+    if ((mi_first >> (stage - 1)) & 1) { MX(mi_branch(2)); MX(cmi_branch(2)); }
+    else { MX(cmi_branch(2)); MX(mi_branch(2)); }
+  } else if ((mi_first >> (stage - 1)) & 1) { MX(mi_branch(3)); MX(cmi_branch(3)); }
+  else { MX(cmi_branch(3)); MX(mi_branch(3)); }
   bf16 = bf_fwd;
   if (!multi_stream) return MIMRL_OK;
   return join(5, 5);

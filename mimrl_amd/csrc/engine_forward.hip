@@ -18,6 +18,7 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   // 16-bit operands for the layer-1 projection (see h0h): bf16 recurrence + fp16 forward operands + the packed layer-0 launch that also
   // writes the weight images; a site forced to fp32 (MIMRL_FWD_FP32_SITES) or fp16-stored gx keeps the fp32-operand kernel
   const bool use_h16 = h16_on && l0_packed && bf16 && fwd_f16 && (prec & MIMRL_PREC_BF16_GRU_FWD) && !fp32_site(4) && !fp32_site(2) && h0h[0] && w1h;
+  h16_live = use_h16;   // (the backward's dW_ih product of layer 1 reads the same copy: gru_layer_backward)
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;

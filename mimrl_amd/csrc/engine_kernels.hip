@@ -1,5 +1,6 @@
 // The step's own small kernels (see engine.h): stage bookkeeping, MAE, the two loss finalisers, the fused stage boundary.
 #include "engine.h"
+#include "stage_boundary.h"
 
 namespace mimrl {
 
@@ -71,47 +72,12 @@ __global__ void finalize_stage2_kernel(float* scal, const float* mi, const float
 }
 
 // Stage boundary of a combined two-stage step as ONE launch: finalize_stage1 (Model.py:341) + begin_stage(2) + MAE (Solver.py:181-182).
-// Behind the critic Adam; the stage-1 raw terms are still intact (stage 2's estimators overwrite them later).
-__global__ void stage_boundary_kernel(float* scal, const float* mi, const float* cmi, const float* bce, const float* coef1, int* rng_step,
-                                      int* adam_step, const float* __restrict__ pred, const float* __restrict__ y,
-                                      float* __restrict__ dpred, int B) {
+// Behind the critic Adam; the stage-1 raw terms are still intact (stage 2's estimators overwrite them later).  (Body: stage_boundary.h --
+// by default it rides on the critic Adam launch instead, estimator_ops.hip: adam8_kernel.)
+static_assert(SB_NE_MI == NE_MI && SB_NE_CMI == NE_CMI, "stage_boundary.h restates the estimator counts");
+__global__ void stage_boundary_kernel(StageBoundaryArgs a) {
   __shared__ float red[16];
-  if (threadIdx.x == 0) {
-    // every value is READ before the first store (tools/isa_lint.py: interleaved with the stores into `scal`, which may alias, these were
-    // 21 loads each followed by s_waitcnt vmcnt(0) -- 21 round trips in a one-thread kernel on the step's critical path, 7 us)
-    float vm[NE_MI], vl[NE_MI], vc[NE_CMI], vb[NE_CMI], c1[NE_MI + NE_CMI];
-#pragma unroll
-    for (int e = 0; e < NE_MI; ++e) { vm[e] = mi[e]; vl[e] = mi[NE_MI + e]; c1[e] = coef1[e]; }
-#pragma unroll
-    for (int e = 0; e < NE_CMI; ++e) { vc[e] = cmi[e]; vb[e] = bce[e]; c1[NE_MI + e] = coef1[NE_MI + e]; }
-    const int rs = *rng_step, as = *adam_step;
-    float loss = 0.f;
-#pragma unroll
-    for (int e = 0; e < NE_MI; ++e) {
-      scal[MIMRL_S1_MIS + e] = vm[e];
-      scal[MIMRL_S1_LOSSES + e] = vl[e];
-      loss += c1[e] * vl[e];
-    }
-#pragma unroll
-    for (int e = 0; e < NE_CMI; ++e) {
-      scal[MIMRL_S1_MIS + NE_MI + e] = vc[e];
-      scal[MIMRL_S1_LOSSES + NE_MI + e] = vb[e];
-      loss += c1[NE_MI + e] * vb[e];
-    }
-    scal[MIMRL_S1_LOSS] = loss;
-    *rng_step = rs + 1;
-    *adam_step = as + 1;
-  }
-  for (int i = threadIdx.x; i < 32; i += blockDim.x) scal[32 + i] = 0.f;
-  float s = 0.f;
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const float d = pred[b] - y[b];
-    s += fabsf(d);
-    dpred[b] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / B;
-  }
-  s = block_sum(s, red);
-  __syncthreads();                       // the zeroing of scal[32..63] above is complete before the task loss lands in it
-  if (threadIdx.x == 0) scal[MIMRL_S2_TASK] = s / B;
+  stage_boundary_body(a, red);
 }
 
 }  // namespace
@@ -153,7 +119,7 @@ void launch_finalize_stage2(hipStream_t s, float* scal, const float* mi, const f
 }
 void launch_stage_boundary(hipStream_t s, float* scal, const float* mi, const float* cmi, const float* bce, const float* coef1, int* rng_step,
                            int* adam_step, const float* pred, const float* y, float* dpred, int B) {
-  hipLaunchKernelGGL(stage_boundary_kernel, dim3(1), dim3(256), 0, s, scal, mi, cmi, bce, coef1, rng_step, adam_step, pred, y, dpred, B);
+  hipLaunchKernelGGL(stage_boundary_kernel, dim3(1), dim3(256), 0, s, StageBoundaryArgs{scal, mi, cmi, bce, coef1, rng_step, adam_step, pred, y, dpred, B});
 }
 
 }  // namespace eng

@@ -129,8 +129,10 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     return MIMRL_OK;
   }
   if (fuse_boundary) {
-    launch_stage_boundary(stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1(), d_ints, d_ints + 1,
-                       bufs.pred, bufs.labels, dpred, B);
+    if (!boundary_in_adam)   // (else: workgroup 0 of the critic Adam launch did it -- enqueue_apply)
+      launch_stage_boundary(stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1(), d_ints, d_ints + 1,
+                         bufs.pred, bufs.labels, dpred, B);
+    boundary_in_adam = false;
   } else {
     launch_begin_stage(stream, d_ints, d_ints + 1, bufs.scalars, 32, 32);
   }
@@ -196,12 +198,52 @@ int mimrl_handle::enqueue_apply(int stage) {
     for (int q = 1; q < a.fold.n; ++q) { a.fold.lo_all = std::min(a.fold.lo_all, a.fold.lo[q]); a.fold.hi_all = std::max(a.fold.hi_all, a.fold.hi[q]); }
   }
   Scope sc(this, MIMRL_PH_OPT);
+  // Combined step (round 5b): the critic update writes the FORWARD fragment images itself and does the stage boundary in its workgroup 0
+  // (AdamArgs::frag / ::sb) -- what used to sit between the update and the stage-2 estimators (frag_images 10 us on side 3 beside a 5 us
+  // boundary launch, two dependent-launch gaps) is gone from the chain; the data-gradient fragment images, first read by the stage-2
+  // backward stacks, stay a launch on side 3 that those stacks join through the transposed-image refresh.  MIMRL_ADAM_FRAG=0: the round-5a sequence.
+  boundary_in_adam = false;
+  const bool have_frag = stage == 1 && img_valid && crit_frag && ftab.n > 0;
+  bool fwd_in_adam = false;
+  if (stage == 1 && fuse_boundary && adam_frag_on && a.n % 8 == 0) {
+    if (have_frag) {
+      for (int e = 0; e < ftab.n && a.frag.n < 12; ++e)
+        if (!ftab.tr[e] && ftab.dshift[e] == 0) {
+          const int q = a.frag.n++;
+          a.frag.lo[q] = ftab.off[e]; a.frag.gstride[q] = ftab.gstride[e]; a.frag.nb[q] = ftab.nb[e];
+          a.frag.mat[q] = ftab.OUT[e] * ftab.RED[e]; a.frag.RED[q] = ftab.RED[e];
+          a.frag.inv_gs[q] = 1.f / (float)ftab.gstride[e]; a.frag.inv_red[q] = 1.f / (float)ftab.RED[e];
+        }
+      int nfwd = 0;
+      for (int e = 0; e < ftab.n; ++e) nfwd += !ftab.tr[e];
+      if (a.frag.n == nfwd) { a.frag.dst = crit_frag; fwd_in_adam = true; } else a.frag.n = 0;
+    }
+    a.sb_on = 1;
+    a.sb = StageBoundaryArgs{bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1(), d_ints, d_ints + 1, bufs.pred, bufs.labels, dpred, cfg.batch};
+    boundary_in_adam = true;
+  }
   MX(adam_step(stream, a));
-  if (stage == 1 && img_valid && crit_frag && ftab.n > 0) {
+  if (have_frag) {
     // combined step: beside the stage boundary on side 3 (the stage-2 estimators join it before their first stack)
     static const bool inline_frag = knob("MIMRL_FRAG_INLINE") != nullptr;   // tuning knob
-    if (fuse_boundary && side_on(3) && !inline_frag) { MX(fork(3, 3)); MX(bf16_frag_images(side[3], bufs.crit_p, crit_frag, ftab)); frag_side_pending = true; }
-    else MX(bf16_frag_images(stream, bufs.crit_p, crit_frag, ftab));
+    FragTable ft = ftab;
+    if (fwd_in_adam) {   // only the data-gradient entries are left for the launch
+      ft.n = 0;
+      for (int e = 0; e < ftab.n; ++e)
+        if (ftab.tr[e]) {
+          const int q = ft.n++;
+          ft.off[q] = ftab.off[e]; ft.OUT[q] = ftab.OUT[e]; ft.RED[q] = ftab.RED[e]; ft.nb[q] = ftab.nb[e]; ft.tr[q] = 1;
+          ft.gstride[q] = ftab.gstride[e]; ft.dshift[q] = ftab.dshift[e];
+        }
+    }
+    if (ft.n > 0) {
+      // (fwd_in_adam: not even the launch happens here -- as the update's FIRST captured child it would keep the update's hardware queue and
+      //  push the stage-2 estimators' first kernels onto other queues, 21 us behind the update; estimators_all issues it on side 3 in front
+      //  of the transposed-image refresh, in capture order behind the forward stacks)
+      if (fwd_in_adam && fuse_boundary && side_on(3) && !inline_frag) { ftab_tr = ft; frag_tr_deferred = true; }
+      else if (fuse_boundary && side_on(3) && !inline_frag) { MX(fork(3, 3)); MX(bf16_frag_images(side[3], bufs.crit_p, crit_frag, ft)); frag_side_pending = true; }
+      else MX(bf16_frag_images(stream, bufs.crit_p, crit_frag, ft));
+    }
   }
   return dbg_delay(stream, 12);
 }

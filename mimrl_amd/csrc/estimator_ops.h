@@ -1,6 +1,7 @@
 // Kernels of the 5 variational-MI and 6 classifier-CMI estimators (VMI.py:53-69,162-166; Model.py:75-225,305-386).
 #pragma once
 #include "common.h"
+#include "stage_boundary.h"
 
 namespace mimrl {
 
@@ -98,6 +99,14 @@ struct AdamArgs {
   // [lo[q], hi[q]) also takes src[q][(j / d[q]) * ld[q] + j % d[q]], which is re-zeroed -- the scatter kernel that used to sit between the
   // last weight-gradient GEMM and this launch (one launch + one dependent-launch gap on the chain) rides on the update
   struct Fold { int n = 0; long lo[8], hi[8]; float* src[8]; int d[8], ld[8]; long lo_all = 0, hi_all = 0; } fold;
+  // optional (round 5b, critic bucket of a combined step; n % 8 == 0, no fold): the FORWARD fragment-order images of the estimator stacks
+  // (mlp_fused.h: bf16_frag_images, entries with tr = 0) written by this launch -- 8 consecutive elements of a row are one 16-byte piece of
+  // the image -- so that the stage-2 stacks depend on the update itself and frag_images leaves the chain (its data-gradient entries, needed
+  // only by the stage's backward, stay a side-stream launch).  Entry e covers nb[e] matrices [OUT x RED] at lo[e] + g * gstride[e].
+  struct Frag { int n = 0; long lo[12], gstride[12]; int nb[12], mat[12], RED[12]; float inv_gs[12], inv_red[12]; __bf16* dst = nullptr; } frag;
+  // optional: the stage boundary (stage_boundary.h) is the first thing workgroup 0 does
+  int sb_on = 0;
+  StageBoundaryArgs sb;
 };
 int adam_step(hipStream_t s, const AdamArgs& a);
 

@@ -771,6 +771,68 @@ __global__ void adam_kernel(AdamArgs a) {
   }
 }
 
+// The same update, 8 consecutive elements per thread (two 16-byte pieces per array), for buckets without parked pieces (AdamArgs::Frag,
+// ::sb): same per-element arithmetic as adam_kernel, so parameters and moments are bit-identical to it.
+__global__ __launch_bounds__(256) void adam8_kernel(AdamArgs a) {
+  __shared__ float red[16];
+  if (a.sb_on && blockIdx.x == 0) stage_boundary_body(a.sb, red);
+  const int t = *a.step;
+  const float lr = *a.lr;
+  const float bc1 = 1.f - powf(a.beta1, (float)t), bc2 = 1.f - powf(a.beta2, (float)t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const long n8 = a.n >> 3;
+  for (long i8 = blockIdx.x * (long)blockDim.x + threadIdx.x; i8 < n8; i8 += (long)gridDim.x * blockDim.x) {
+    const long i = i8 << 3;
+    const float4 g0 = *reinterpret_cast<const float4*>(a.g + i), g1 = *reinterpret_cast<const float4*>(a.g + i + 4);
+    const float4 p0 = *reinterpret_cast<const float4*>(a.p + i), p1 = *reinterpret_cast<const float4*>(a.p + i + 4);
+    const float4 m0 = *reinterpret_cast<const float4*>(a.m + i), m1 = *reinterpret_cast<const float4*>(a.m + i + 4);
+    const float4 v0 = *reinterpret_cast<const float4*>(a.v + i), v1 = *reinterpret_cast<const float4*>(a.v + i + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, pp[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+    const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w}, vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float pn[8], mn[8], vn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g = gg[e] * a.gscale;
+      if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);             // clip_grad_value_ (Solver.py:211-212)
+      if (a.weight_decay != 0.f) g += a.weight_decay * pp[e];
+      mn[e] = a.beta1 * mm[e] + (1.f - a.beta1) * g;
+      vn[e] = a.beta2 * vv[e] + (1.f - a.beta2) * g * g;
+      pn[e] = pp[e] - step_size * mn[e] / (sqrtf(vn[e]) * inv_sqrt_bc2 + a.eps);
+    }
+    *reinterpret_cast<float4*>(a.m + i) = make_float4(mn[0], mn[1], mn[2], mn[3]); *reinterpret_cast<float4*>(a.m + i + 4) = make_float4(mn[4], mn[5], mn[6], mn[7]);
+    *reinterpret_cast<float4*>(a.v + i) = make_float4(vn[0], vn[1], vn[2], vn[3]); *reinterpret_cast<float4*>(a.v + i + 4) = make_float4(vn[4], vn[5], vn[6], vn[7]);
+    *reinterpret_cast<float4*>(a.p + i) = make_float4(pn[0], pn[1], pn[2], pn[3]); *reinterpret_cast<float4*>(a.p + i + 4) = make_float4(pn[4], pn[5], pn[6], pn[7]);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(a.g + i) = z; *reinterpret_cast<float4*>(a.g + i + 4) = z;   // the bucket is left zeroed for the next accumulation pass
+    if (a.pimg || a.frag.n > 0) {
+      bf16x8 q;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = to_bf16(pn[e]);
+      if (a.pimg) *reinterpret_cast<bf16x8*>(a.pimg + i) = q;
+      // forward fragment image: element (c, r) of matrix g of entry e sits at lo + g * gstride + c * RED + r; its image position is
+      // ((c / 32 * (RED / 16) + r / 16) * 64 + c % 32 + 32 * ((r % 16) / 8)) * 8 + r % 8 (mlp_fused.hip: frag_images_kernel).  r is a multiple
+      // of 8 here (offsets, strides and RED are multiples of 8): the piece is one 16-byte store.
+      // (32-bit arithmetic -- a bucket has < 2^31 elements --, quotients through one float reciprocal + a one-step correction: the 64-bit
+      //  divisions of the first version cost this launch 5 us)
+      const int ii = (int)i;
+      for (int e = 0; e < a.frag.n; ++e) {
+        const int j = ii - (int)a.frag.lo[e], gs = (int)a.frag.gstride[e];
+        if (j < 0 || j >= a.frag.nb[e] * gs) continue;
+        int g = (int)((float)j * a.frag.inv_gs[e]);
+        g -= g * gs > j; g += (g + 1) * gs <= j;
+        const int rem = j - g * gs;
+        if (rem >= a.frag.mat[e]) continue;
+        const int RED = a.frag.RED[e];
+        int c = (int)((float)rem * a.frag.inv_red[e]);
+        c -= c * RED > rem; c += (c + 1) * RED <= rem;
+        const int r = rem - c * RED;
+        const int pos = (int)a.frag.lo[e] + g * gs + (((c >> 5) * (RED >> 4) + (r >> 4)) * 64 + (c & 31) + 32 * ((r & 15) >> 3)) * 8;
+        *reinterpret_cast<bf16x8*>(a.frag.dst + pos) = q;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int copy_rows(hipStream_t s, const CopyTable& t, long n) {
@@ -876,6 +938,12 @@ int top1_bwd(hipStream_t s, const float* dout, const float* W, const float* act,
 }
 
 int adam_step(hipStream_t s, const AdamArgs& a) {
+  if (a.frag.n > 0 || a.sb_on) {
+    if (a.n % 8 != 0 || a.fold.n != 0 || a.frag.n > 12 || (a.frag.n > 0 && a.n >= (1L << 24))) return set_error(MIMRL_ERR_ARG, "adam_step: the 8-wide kernel needs n %% 8 == 0, no parked pieces, <= 12 image entries");
+    hipLaunchKernelGGL(adam8_kernel, dim3(grid_for(a.n / 8, 256, 2048)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return MIMRL_OK;
+  }
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(a.n, 256, 2048)), dim3(256), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;

@@ -42,6 +42,10 @@ struct GemmDesc {
   int a_pad4 = 0;
   // With f16 = 1 (below) and BOTH flags set the 16-bit storage type is fp16 and the layouts are (KC, KC): gemm_fast_f16s_kernel.
   int a_bf16 = 0, b_bf16 = 0;
+  // with a_bf16 = b_bf16 = 1, both operands row-contiguous (a weight gradient): B is stored as FP16 (a forward pass wrote it for an fp16
+  // product) and is converted to bf16 in registers on its way to LDS -- dW_ih of GRU layer 1 reads the layer-0 recurrence's fp16 copy of h
+  // (256 MB at cfg3) instead of the fp32 outputs (512 MB, fetched ~2x by the 128-wide tiles)
+  int b_f16cvt = 0;
   // bf16 mode only: round the operands to FP16 instead of bf16 (v_mfma_f32_32x32x16_f16: same rate, 11 instead of 8 significant bits;
   // saturating conversion).  For FORWARD products whose operands have a bounded range (inputs, weights, LayerNorm'd activations) and
   // feed the ill-conditioned backward of CubeMLP (see cube_fused.hip).  Honoured by the fast path with both operands k-contiguous

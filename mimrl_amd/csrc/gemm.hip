@@ -569,7 +569,16 @@ __device__ __forceinline__ bf16x8 fast_frag(const __bf16* __restrict__ img, int 
   }
 }
 
-template <int TM, int TN, bool AKC, bool BKC, bool GEN, bool ABF = false, bool BBF = false, bool F16 = false>
+// BH: the bf16-typed B pieces hold fp16 values (GemmDesc::b_f16cvt): 8 halves -> 8 bf16, in place, between the load's wait and the LDS store
+__device__ __forceinline__ void h8_to_bf8(f32x4& v) {
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = to_bf16((float)h[i]);
+  v = __builtin_bit_cast(f32x4, o);
+}
+
+template <int TM, int TN, bool AKC, bool BKC, bool GEN, bool ABF = false, bool BBF = false, bool F16 = false, bool BH = false>
 __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_per, int dbg, unsigned bx, unsigned by, unsigned bzr) {
   constexpr int BMf = 64 * TM, BNf = 64 * TN;
   __shared__ __attribute__((aligned(16))) __bf16 sA[2][FT<TM>::ELEMS];
@@ -621,6 +630,10 @@ __device__ __forceinline__ void fast_body(const GemmDesc& d, int ksplit, int kt_
       fast_wait<LB, (FPF - 1) * (LA + LB)>(rb[j]);
       fast_fix<TM, AKC, ABF>(m0, d.M, K, t * FBK, tid, ra[j]);
       fast_fix<TN, BKC, BBF>(n0, d.N, K, t * FBK, tid, rb[j]);
+      if constexpr (BH) {
+#pragma unroll
+        for (int h = 0; h < LB; ++h) h8_to_bf8(rb[j][h]);
+      }
       fast_store<TM, AKC, ABF, F16>(ra[j], sA[buf], tid);
       fast_store<TN, BKC, BBF, F16>(rb[j], sB[buf], tid);
     };
@@ -719,6 +732,14 @@ __global__ __launch_bounds__(256) void gemm_fast_bf_kernel(KernelArgs ka) {
   fast_body<TM, TN, AKC, BKC, false, true, BBF>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
 }
 
+// A bf16, B stored as fp16 and converted (GemmDesc::b_f16cvt), both row-contiguous: the layer-1 dW_ih product
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_fast_bfh_kernel(KernelArgs ka) {
+  unsigned bx, by, bzr;
+  tile_ids(ka.xcd_remap, bx, by, bzr);
+  fast_body<TM, TN, false, false, false, true, true, false, true>(ka.d, ka.ksplit, ka.kt_per, ka.dbg, bx, by, bzr);
+}
+
 // GROUPED launch: up to GEMM_GROUP_MAX independent plain GEMMs of one layout class (64x64 tiles, no split-K) in ONE launch --
 // the weight gradients of an estimator MLP stack (4 layers x 10 towers / 6 classifiers) are 4-5 launches of ~10 us of work
 // each on the critical branch of stage 1; as one launch they fill the chip once.
@@ -808,6 +829,7 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
     if (!d.a_bf16 || (ca == 1 && cb == 1 && !(d.f16 && d.b_bf16)) || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u) return false;
     if (d.f16 && !(ca == 1 && cb == 1 && d.b_bf16)) return false;   // fp16 storage exists for that product only
     if (d.a_gap_rows && (d.a_gap_at % 8 != 0 || d.a_gap_rows % 8 != 0)) return false;
+    if (d.b_f16cvt && !(ca == 2 && cb == 2 && d.b_bf16 && !d.A2)) return false;   // instantiated for the weight-gradient layout only
   }
   const int ktiles = (d.K + FBK - 1) / FBK;
   const bool acc = plain_accumulate(d) && ktiles >= 32;
@@ -993,6 +1015,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   const bool gen = d.bias_m || d.beta != 0.f || d.pre || d.gradact_u;
   if ((d.a_bf16 || d.b_bf16) && !pl.fast)
     return set_error(MIMRL_ERR_ARG, "gemm: bf16-stored operands need the fast path (bf16 mode, 8-element alignment, A bf16, layouts KC/RC or RC/RC, plain epilogue)");
+  if (d.b_f16cvt && !(d.a_bf16 && d.b_bf16)) return set_error(MIMRL_ERR_ARG, "gemm: b_f16cvt needs a_bf16 = b_bf16 = 1");
 #define FASTK(TM_, TN_, A_, B_)                                                                               \
   if (d.f16 && d.a_bf16) hipLaunchKernelGGL((gemm_fast_f16s_kernel<TM_, TN_>), grid, dim3(256), 0, s, ka);    \
   else if (d.f16 && gen) hipLaunchKernelGGL((gemm_fast_f16_kernel<TM_, TN_, true>), grid, dim3(256), 0, s, ka);    \
@@ -1001,7 +1024,8 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \
   break
 #define FASTB(TM_, TN_, A_, B_)                                                                               \
-  if (d.a_bf16 && d.b_bf16) hipLaunchKernelGGL((gemm_fast_bf_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);   \
+  if (d.b_f16cvt) { if constexpr (!(A_) && !(B_)) hipLaunchKernelGGL((gemm_fast_bfh_kernel<TM_, TN_>), grid, dim3(256), 0, s, ka); } \
+  else if (d.a_bf16 && d.b_bf16) hipLaunchKernelGGL((gemm_fast_bf_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);   \
   else if (d.a_bf16) hipLaunchKernelGGL((gemm_fast_bf_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);         \
   else if (gen) hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, true>), grid, dim3(256), 0, s, ka);    \
   else hipLaunchKernelGGL((gemm_fast_kernel<TM_, TN_, A_, B_, false>), grid, dim3(256), 0, s, ka);            \

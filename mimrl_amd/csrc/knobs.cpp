@@ -13,6 +13,7 @@ namespace {
 struct KnobDef { const char* name; const char* where; const char* dflt; const char* help; };
 const KnobDef kKnobs[] = {
   {"MIMRL_KNOBS", "engine_abi.hip", "", "1: print this table (values in effect) to stderr when a handle is created"},
+  {"MIMRL_ADAM_FRAG", "engine_abi.hip", "", "0: combined step with frag_images + stage_boundary as launches behind the critic Adam (round 5a) instead of inside it"},
   {"MIMRL_BEGIN_IN_PACK", "engine_step.hip", "", "0: the begin-of-stage bookkeeping as its own launch instead of riding on the layer-0 pack launch"},
   {"MIMRL_BEGIN_ON_SIDE", "engine_step.hip", "", "begin-of-stage bookkeeping on a side stream (older placement)"},
   {"MIMRL_BPTT_FIRST", "engine_backward.hip", "", "capture order: the layer-1 BPTT in front of the LayerNorm-backward side work"},
@@ -23,6 +24,8 @@ const KnobDef kKnobs[] = {
   {"MIMRL_DDP_SPLIT", "engine_abi.hip", "", "0: the main gradient bucket all-reduced in one piece (in-library RCCL and dist.py)"},
   {"MIMRL_DG_FP32", "engine_abi.hip", "", "BPTT outputs dg / h_prev stored as fp32 instead of bf16"},
   {"MIMRL_DH0_LAST", "engine_backward.hip", "", "capture order of dh0 vs the side-stream weight gradients"},
+  {"MIMRL_DWIH_H16", "engine_backward.hip", "", "0: the layer-1 dW_ih product reads the fp32 layer-0 outputs instead of the recurrence's fp16 copy"},
+  {"MIMRL_EST_INTERLEAVE", "engine_estimators.hip", "0", "bit mask (1: stage 1, 2: stage 2): capture both estimator branches' forward halves in front of either backward half; + 4: the image launches on side 3 behind both (measured: within process-to-process noise)"},
   {"MIMRL_EST_MI_FIRST", "engine_estimators.hip", "0", "capture order of the MI and the CMI estimator branches"},
   {"MIMRL_FRAG_INLINE", "engine_step.hip", "", "fragment images of the critics on the main stream instead of side 3"},
   {"MIMRL_FUSED_MLP_BIG", "engine_estimators.hip", "", "concat-critic tail through the direct-from-L2 fused MLP variant (round 1)"},
@@ -63,6 +66,8 @@ const KnobDef kKnobs[] = {
   {"MIMRL_LENS_SIDE0", "engine_forward.hip", "", "0: sequence-length scan on side 4 in front of the layer-0 projection instead of side 0"},
   {"MIMRL_LN_BWD_BLOCKS", "model_ops.hip", "128", "workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)"},
   {"MIMRL_LN_BWD_WAVE_ROWS", "model_ops.hip", "", "the one-row-per-wave kernel of round 2"},
+  {"MIMRL_LN_TAIL_SPLIT_FLUSH", "engine_backward.hip", "", "0: with the fused LayerNorm tail, block 0's D-axis parked work is flushed behind the L-axis kernel instead of beside it"},
+  {"MIMRL_LN_TAIL_FUSE", "engine_abi.hip", "", "1: the encoders' LayerNorm + ReLU + dropout backward rides on block 0's L-axis backward kernel (opt-in: measured slower at cfg2)"},
   {"MIMRL_LSTM_MFMA_FP32", "lstm.hip", "", "1: fp32 precision mode runs the fp32-MFMA LSTM kernels instead of the scalar ones (measured slower)"},
   {"MIMRL_LSTM_SCALAR", "lstm.hip", "", "1: the scalar fp32 LSTM kernels of round 1 instead of the MFMA ones"},
   {"MIMRL_MLP_IMG_WAVES", "mlp_fused.hip", "0", "4 = never, 8 = both directions"},

@@ -426,9 +426,16 @@ def test_16bit_stored_projection_operands_change_nothing(name, T_, monkeypatch):
         eng.close()
     assert np.array_equal(out["h16"][0], out["fp32"][0]), "encoder outputs differ"
     top = max(np.abs(v).max() for v in out["fp32"][1].values())
+    worst = {}
     for n, want in out["fp32"][1].items():
         scale = max(np.abs(want).max(), 1e-3 * top)
-        assert np.abs(out["h16"][1][n] - want).max() <= 1e-4 * scale, n
+        # round 5b: dW_ih of layer 1 reads the fp16 copy too and converts it to bf16 in registers (GemmDesc::b_f16cvt): fp32 -> fp16 -> bf16 differs
+        # from fp32 -> bf16 for the ~3 % of the values that sit within 2^-12 of a bf16 rounding midpoint, by one bf16 ulp each -- a perturbation of
+        # that one product's operand, far below the bf16 rounding itself (measured <= the band below; every other tensor: atomics order only)
+        band = 2e-3 if "weight_ih_l1" in n else 1e-4
+        worst[n] = float(np.abs(out["h16"][1][n] - want).max() / scale)
+        assert worst[n] <= band, (n, worst[n])
+    print("h16-vs-fp32 worst relative differences:", sorted(worst.items(), key=lambda kv: -kv[1])[:6])
 
 
 @pytest.mark.parametrize("name,T_,margin,gxh", ENC, ids=[f"{n}{'' if t is None else '-T' + str(t)}{'' if mg else '-full'}{'-gxf16' if gh else ''}" for n, t, mg, gh in ENC])

@@ -872,6 +872,67 @@ def test_bf16_stored_bptt_outputs_change_nothing(monkeypatch):
         assert np.abs(ga - gb).max() <= 2e-5 * scale, f"{n}: rel diff {np.abs(ga - gb).max() / scale:.2e}"
 
 
+@pytest.mark.parametrize("workload", ["cfg2", "cfg1"])
+def test_critic_update_with_fragment_images_and_stage_boundary_changes_nothing(workload, monkeypatch):
+    """Round 5b: in the combined (captured) step the critic clip + Adam launch writes the forward fragment-order images of the estimator stacks
+    itself and its workgroup 0 does the stage boundary (finalize_stage1 + begin_stage(2) + MAE: Model.py:341, Solver.py:181-182) -- estimator_ops.hip:
+    adam8_kernel, AdamArgs::frag / ::sb.  Against the round-5a sequence (MIMRL_ADAM_FRAG=0: scalar Adam kernel, frag_images on side 3, stage_boundary
+    as a launch) a step must leave the same 64 scalars and predictions up to the run-to-run noise of the float atomics in the gradients (device-drawn
+    anchors: the RNG step counters must have advanced identically, or the draws -- and everything else -- differ); a second step, which runs on
+    the parameters and images the first one left, stays within the band that noise grows to (measured 1.9e-4 on values of 0.1 - 4: Adam's first
+    steps are sign-like, a last-bit difference in a near-zero gradient moves a parameter by 2 lr), and all but a sliver of the parameters agree."""
+    res = {}
+    for tag, env in (("in_adam", None), ("launches", "0")):
+        if env:
+            monkeypatch.setenv("MIMRL_ADAM_FRAG", env)
+        else:
+            monkeypatch.delenv("MIMRL_ADAM_FRAG", raising=False)
+        opt, N, batch, banks, eng = _bench_engine(workload, "bf16", True)
+        sc = []
+        for _ in range(2):
+            eng.step()
+            torch.cuda.synchronize()
+            sc.append(eng.read_scalars().copy())
+        res[tag] = (np.stack(sc), {n: v.double().cpu().numpy().copy() for n, v in eng.params.items()})
+        eng.close()
+    a, b = res["in_adam"], res["launches"]
+    assert np.isfinite(a[0]).all() and np.abs(a[0][0]).max() > 1 and a[0][0][33] > 0      # (33 = MIMRL_S2_TASK: the boundary's MAE)
+    assert np.allclose(a[0][0], b[0][0], rtol=1e-5, atol=2e-6), np.abs(a[0][0] - b[0][0]).max()
+    assert np.allclose(a[0][1], b[0][1], rtol=2e-3, atol=2e-3), np.abs(a[0][1] - b[0][1]).max()
+    far = tot = 0
+    for n, pa in a[1].items():
+        far += int((np.abs(pa - b[1][n]) > 1e-4).sum())
+        tot += pa.size
+    assert far <= 0.02 * tot, (far, tot)
+
+
+@pytest.mark.parametrize("name", ["cfg1_ragged", "cfg2_sep"])
+def test_ln_backward_riding_on_the_laxis_kernel_changes_nothing(name, monkeypatch):
+    """Round 5b (opt-in, MIMRL_LN_TAIL_FUSE=1): in bf16 mode the encoders' LayerNorm + ReLU + dropout backward (Model.py:452-461 under autograd) can ride as the tail of CubeMLP block 0's
+    L-axis backward kernel (cube_bwd_fused.hip: laxis_bwd_kernel<true>, LAxisLnSide): the (sample, slot) dX tile goes through it from LDS with the
+    lane mapping and arithmetic of ln_relu_drop_bwd16_kernel, so ds -- the layer-1 BPTT's input -- is the same bit pattern and every gradient of the
+    main model equals the default two-launch run up to the order of the float atomics (ln_a / ln_v sums, split-K weight gradients)."""
+    res = {}
+    for tag, env in (("two", None), ("fused", "1")):
+        if env:
+            monkeypatch.setenv("MIMRL_LN_TAIL_FUSE", env)
+        else:
+            monkeypatch.delenv("MIMRL_LN_TAIL_FUSE", raising=False)
+        c, opt, batch, banks, p, eng = make_engine(name, precision="bf16")
+        g = load_golden(name)
+        eng.set_banks(*(banks[k] for k in "CFTAV"))
+        eng.set_anchors(2, g["anchors"][0, 1])
+        eng.stage_grads(2)
+        torch.cuda.synchronize()
+        res[tag] = {n: eng.grads[n].double().cpu().numpy().copy() for n in eng.grads if n.startswith(("rnn_", "ln_", "W_t", "mlp_encoder"))}
+        eng.close()
+    assert sum(n.startswith("rnn_") for n in res["fused"]) == 32 and any(n.startswith("ln_a") for n in res["fused"])
+    for n, ga in res["fused"].items():
+        gb = res["two"][n]
+        scale = np.abs(gb).max() + 1e-30
+        assert np.isfinite(ga).all() and np.abs(ga - gb).max() <= 5e-5 * scale, f"{n}: rel diff {np.abs(ga - gb).max() / scale:.2e}"
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_split_stage2_gradients_equal_the_whole_pass(graph):
     """mimrl_stage_grads_part (the data-parallel split reduce, dist.ddp_stage2_split): part 0 + part 1 leave the SAME main gradient bucket as
