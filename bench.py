@@ -105,7 +105,12 @@ def gru_launch_model(B, T, bf16_gru, dg_bf16):
     flops = 2.0 * n * 3 * H * H
     sv = 4 * H * (2 if bf16_gru else 4)
     fwd = n * (3 * H * 4 + H * 4 + sv) + 4 * (3 * H * H + 3 * H) * 4
-    bwd = n * (sv + H * 4 + H * 4 + 4 * H * (2 if dg_bf16 else 4) + H * (2 if dg_bf16 else 4)) + 4 * 3 * H * H * 4
+    # round 5b (MIMRL_REC16, default on in the bf16 BPTT mode with bf16 dg): dout is stored as bf16 by its producer (256 instead of 512 bytes) in
+    # both launches, and the layer-0 launch reads h_prev from the forward kernel's fp16 copy (256 instead of 512) -- the mean of the two launches
+    rec16 = dg_bf16 and os.environ.get("MIMRL_REC16", "1") != "0"
+    dout_b = H * (2 if rec16 else 4)
+    hp_b = H * (3 if rec16 else 4)           # (layer 1: 512, layer 0: 256)
+    bwd = n * (sv + dout_b + hp_b + 4 * H * (2 if dg_bf16 else 4) + H * (2 if dg_bf16 else 4)) + 4 * 3 * H * H * 4
     return flops, float(fwd), float(bwd)
 
 
@@ -594,20 +599,28 @@ def main():
         pmc, st = newest_profile("pmc_hbm_traffic.json"), newest_profile("bench_kernel_stats.csv")
         share, top_kernel = None, None
         if pmc and args.workload == "cfg2" and args.precision == "bf16":
+            tb = tc = 0.0   # (round 5b: the two launches of a step are two instantiations -- layer 1 reads fp32 h, layer 0 the fp16 copy: mean over both)
             for k, v in json.load(open(pmc))["kernels"].items():
                 if k.startswith("gru_bwd_kernel<true, true"):
-                    traffic = v["traffic_bytes_per_launch"]
-                    tsrc = f"profiles/{os.path.basename(pmc)} (separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction), bytes per launch"
+                    tb += v["traffic_bytes_per_launch"] * v.get("calls_per_step", 1.0)
+                    tc += v.get("calls_per_step", 1.0)
+            if tc:
+                traffic = tb / tc
+                tsrc = f"profiles/{os.path.basename(pmc)} (separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 gfx950 correction), bytes per launch, mean over the step's BPTT launches"
         if st and args.workload == "cfg2" and args.precision == "bf16":
             import csv
             rows_ = list(csv.DictReader(open(st)))
             tot_ = sum(float(r_["TotalDurationNs"]) for r_ in rows_) or 1.0
             top_kernel = max(rows_, key=lambda r_: float(r_["TotalDurationNs"]))["Name"].replace("mimrl::(anonymous namespace)::", "").split("(")[0]
+            bt = bc = 0.0
             for r_ in rows_:
                 if "gru_bwd_kernel<true, true" in r_["Name"]:
-                    prof_avg = float(r_["AverageNs"]) / 1e3
-                    share = float(r_["TotalDurationNs"]) / tot_
-                    prof_src = f"profiles/{os.path.basename(st)} AverageNs (rocprofv3 --kernel-trace --stats -- python3 bench.py, same flags)"
+                    bt += float(r_["TotalDurationNs"])
+                    bc += float(r_["Calls"])
+            if bc:
+                prof_avg = bt / bc / 1e3
+                share = bt / tot_
+                prof_src = f"profiles/{os.path.basename(st)} TotalDurationNs / Calls over the gru_bwd_kernel<bf16, bf16 dg> rows (rocprofv3 --kernel-trace --stats -- python3 bench.py, same flags)"
         mf = fl / (avg_us * 1e-6) / 1e12 / peak_mfma
         hb = bwd_by / (avg_us * 1e-6) / 1e9 / PEAK_HBM_GBS
         bound = "hbm" if hb >= mf else "mfma"

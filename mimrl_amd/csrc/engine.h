@@ -191,6 +191,9 @@ struct mimrl_handle {
   bool part0_done = false;             // mimrl_stage_grads_part(h, 2, 0) ran on the bound batch and nothing since: part 1 may follow
   bool l0_xin = false;                 // this step's layer-0 forward ran the fused-projection (8-wave) kernel: its BPTT launch must match
   bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
+  bool rec16_on = true, dwih_h16_on = true;   // MIMRL_REC16=0 / MIMRL_DWIH_H16=0 (mimrl_create)
+  bool hp16_live = false;              // this pass's layer-0 BPTT reads h_prev from h0h (set by the forward pass; with the fused projection the fp32 outputs were not even written)
+  bool dh0_bf16_live = false, ds_bf16_live = false;   // this pass's dh0 / ds were written as bf16 (gru_layer_backward / encoders_backward -> the BPTT launches)
   bool h16_live = false;               // h0h holds the fp16 copy of THIS pass's layer-0 outputs (set by the forward pass)
   bool w1_img_valid = false;           // w1b holds the CURRENT main parameters (set by the forward pass, cleared by the main update)
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }

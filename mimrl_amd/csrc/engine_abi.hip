@@ -61,6 +61,8 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->h16_on = knob("MIMRL_NO_H16") == nullptr;
   h->xin_on = knob("MIMRL_NO_XIN") == nullptr;
   h->fused_cube_bwd = knob("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
+  h->rec16_on = !(knob("MIMRL_REC16") && atoi(knob("MIMRL_REC16")) == 0);
+  h->dwih_h16_on = !(knob("MIMRL_DWIH_H16") && atoi(knob("MIMRL_DWIH_H16")) == 0);
   h->adam_frag_on = !(knob("MIMRL_ADAM_FRAG") && atoi(knob("MIMRL_ADAM_FRAG")) == 0);
   // opt-in (measured slower at cfg2, 0.814-0.819 vs 0.799-0.800 ms: the parked block-0 weight gradients then start together with the layer-1 BPTT
   // instead of 30 us ahead of it, and the BPTT beside them takes 74 instead of 53 us -- DESIGN section 7)

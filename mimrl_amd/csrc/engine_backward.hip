@@ -459,7 +459,12 @@ int mimrl_handle::encoders_backward(float* dcube) {
     for (int m = 0; m < 2; ++m)
       sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], ds[m], Gm(ln_g[m]), Gm(ln_b[m]), 1 + m,
                       cfg.dropout[1 + m], (uint32_t)(1 + m)};
-    MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key(), dmean + (size_t)B * D, dmean + 2 * (size_t)B * D));
+    // round 5b: ds as bf16 when the layer-1 BPTT launch can read it that way (GRU, bf16 BPTT with bf16 dg, 4-wave kernel)
+    ds_bf16_live = rec16_on && cfg.encoder == MIMRL_ENCODER_GRU && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(0) &&
+                   ln_relu_drop_bwd2_bf16_ok();
+    MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key(), dmean + (size_t)B * D, dmean + 2 * (size_t)B * D, ds_bf16_live ? 1 : 0));
+  } else {
+    ds_bf16_live = false;   // (the L-axis kernel's tail wrote fp32)
   }
   if (!text_bwd_first) MX(text_bwd());
   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT.  Tuning knob MIMRL_BPTT_FIRST=1 captures the BPTT launch in
@@ -513,12 +518,18 @@ int mimrl_handle::gru_layer_backward(int l) {
     const bool lbf = dg_bf16 && (l == 1 || l0_packed || l0_bwd_pack);
     a.dg_bf16 = lbf ? 1 : 0;
     a.slab_upl = l == 0 && l0_xin ? 2 : 0;   // the fused-projection forward wrote the 4-wave slab layout whatever MIMRL_GRU_WAVES says
+    const bool io16 = lbf && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(a.slab_upl);
+    a.dout_bf16 = io16 && (l == 1 ? ds_bf16_live : dh0_bf16_live) ? 1 : 0;
+    if ((l == 1 ? ds_bf16_live : dh0_bf16_live) && !a.dout_bf16) return set_error(MIMRL_ERR_STATE, "gru_layer_backward: dout was stored as bf16 but this BPTT launch cannot read it");
+    const bool hp16 = l == 0 && io16 && hp16_live && h0h[0] && h0h[1];
+    if (l == 0 && hp16_live && !hp16) return set_error(MIMRL_ERR_STATE, "gru_layer_backward: the forward pass counted on the fp16 h_prev path");
     for (int m = 0; m < 2; ++m) {
       a.lens[m] = lens[m];
       for (int d = 0; d < 2; ++d) {
         const GruDirW& g = gru[m][l][d];
         a.seq[m][d] = GruSeqBwd{P(g.w_hh), sv[l][m][d], l == 1 ? h1[m] : h0[m], l == 1 ? ds[m] : dh0[m], dg[l][m][d],
                                 hprev[l][m][d], Gm(g.b_ih), Gm(g.b_hh)};
+        if (hp16) a.seq[m][d].out16 = h0h[m];
       }
     }
     { Scope sc(this, MIMRL_PH_GRU_BWD); MX(gru_backward(stream, a, (prec & MIMRL_PREC_BF16_GRU_BWD) != 0)); }
@@ -533,6 +544,7 @@ int mimrl_handle::gru_layer_backward(int l) {
     if (l0_side == 0 && l == 0) MX(fork(0, 0));
     static const bool dh0_last = knob("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
     auto dh0_gemm = [&]() -> int {   // gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
+      dh0_bf16_live = false;
       // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
       {
         GemmDesc q = gemm_nn(dg[l][0][0], 4 * H, P(gru[0][l][0].w_ih), 2 * H, dh0[0], 2 * H, (int)BT_, 2 * H, G);
@@ -552,7 +564,11 @@ int mimrl_handle::gru_layer_backward(int l) {
             GemmDesc t = q;
             t.B = reinterpret_cast<const float*>(w1bt); t.B2 = reinterpret_cast<const float*>(w1bt + G);
             t.sb_k = 1; t.sb_n = 2 * G; t.sb2_k = 1; t.sb2_n = 2 * G; t.sb_b = 2L * H * 2 * G; t.sb2_b = 2L * H * 2 * G;
-            if (gemm_tall_ok(t)) q = t;
+            if (gemm_tall_ok(t)) {
+              q = t;
+              // round 5b: the tall kernel stores dh0 as bf16 when the layer-0 BPTT launch can read it that way (same element indices)
+              if (rec16_on && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && (l0_packed || l0_bwd_pack) && gru_bwd_io16_ok(l0_xin ? 2 : 0)) { q.c_bf16 = 1; q.sc_b *= 2; dh0_bf16_live = true; }
+            }
           }
         }
         MX(G_(q));
@@ -611,8 +627,7 @@ int mimrl_handle::gru_layer_backward(int l) {
         // layer 1: the layer-0 outputs from the recurrence kernel's fp16 copy (half the bytes of an operand the 128-wide tiles fetch ~2x;
         // fp16 -> bf16 in registers: the product rounds to bf16 anyway, the double rounding moves a value by <= 2^-11 of itself).
         // MIMRL_DWIH_H16=0: the fp32 outputs.
-        static const bool dwih_h16 = !(knob("MIMRL_DWIH_H16") && atoi(knob("MIMRL_DWIH_H16")) == 0);   // tuning knob
-        if (lbf && both && dwih_h16 && h16_live && h0h[0] && h0h[1]) {
+        if (lbf && both && dwih_h16_on && h16_live && h0h[0] && h0h[1]) {
           q.B = reinterpret_cast<const float*>(h0h[0]); q.b_bf16 = 1; q.b_f16cvt = 1; q.sb_bo = h0h[1] - h0h[0];
         }
         MX(G_on(pick(), q)); }

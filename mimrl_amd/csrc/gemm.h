@@ -55,6 +55,8 @@ struct GemmDesc {
   // beta / pre).  For the hoisted GRU input projections gx[B,T,3H] of long sequences, which are written once and read once: at cfg3 the
   // projection is bound by its 786 MB of fp32 stores.
   int c_f16 = 0;
+  // ... or a BF16 array (tall LDS-DMA kernel only, gemm_tall_ok): dh0, the gradient the layer-0 BPTT reads once
+  int c_bf16 = 0;
 };
 
 // A is [M,K] row-major (lda), B given as W[N,K] row-major (ldw):  C = A * W^T

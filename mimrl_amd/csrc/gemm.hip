@@ -851,6 +851,17 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
     //  7.11 -> 7.52 ms with 700 for all)
     if (t * split(t) >= ((acc && ktiles > 1024) ? 224 : min_wgs) || c == 2) { pick = c; break; }
   }
+  // round 5b: weight gradients over a LONG reduction with both operands 16-bit stored and N a multiple of 256 (dW_ih of GRU layer 1:
+  // [384 x 256] per direction over B * T rows) take 128 x 256 tiles -- every row of A (dg: the larger operand) is then read by ONE workgroup
+  // instead of two; the split-K chunks of a 128 x 128 grid drift apart in time and their re-reads miss the 4 MB L2 (1.39 GB fetched for 0.66)
+  static const int wide_n = knob("MIMRL_GEMM_WIDE_N") ? atoi(knob("MIMRL_GEMM_WIDE_N")) : 0;   // tuning knob: 1 all, 2 M % 256 == 0 only, 3 the others only
+  const bool wide = wide_n && (wide_n == 1 || (wide_n == 2) == (d.M % 256 == 0)) && acc && ktiles > 1024 && ca == 2 && cb == 2 && d.a_bf16 && d.b_bf16 && d.N % 256 == 0 && d.M >= 128;
+  if (wide) {
+    p->fast = 1; p->tm = 2; p->tn = 4; p->ca = ca; p->cb = cb;
+    p->tiles = tiles(2, 4); p->nsplit = split(p->tiles); p->kt_per = (ktiles + p->nsplit - 1) / p->nsplit;
+    p->variant = 24;
+    return true;
+  }
   p->fast = 1; p->tm = cand[pick][0]; p->tn = cand[pick][1]; p->ca = ca; p->cb = cb;
   p->tiles = tiles(p->tm, p->tn);
   p->nsplit = split(p->tiles);
@@ -984,6 +995,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   if (d.batch_in > 0 && (d.A2 || d.bias_m || d.colsum || d.batch % d.batch_in != 0))
     return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   if (bf16 && gemm_tall_ok(d)) return gemm_tall(s, d);   // tall 16-bit-stored (KC, KC) products: the LDS-DMA kernel of gemm_tall.hip
+  if (d.c_bf16) return set_error(MIMRL_ERR_ARG, "gemm: a bf16-stored output exists in the tall LDS-DMA kernel only (gemm_tall_ok)");
   if (bf16 && gemm_tall_tn_ok(d)) return gemm_tall_tn(s, d);   // ... and tall reductions (weight gradients over B*T rows)
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
@@ -1044,6 +1056,10 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
     case 18: FASTK(1, 1, true, true);
     case 19: FASTB(1, 1, true, false);
     case 20: FASTB(1, 1, false, false);
+    case 24:   // 128 x 256 tiles, (RC,RC), both operands 16-bit stored (fast_plan: wide)
+      if (d.b_f16cvt) hipLaunchKernelGGL((gemm_fast_bfh_kernel<2, 4>), grid, dim3(256), 0, s, ka);
+      else hipLaunchKernelGGL((gemm_fast_bf_kernel<2, 4, false, false, true>), grid, dim3(256), 0, s, ka);
+      break;
     case 0: GENK(false, 32, false);
     case 3: GENK(true, 128, true);
     case 2: GENK(true, 64, true);

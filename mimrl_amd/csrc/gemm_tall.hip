@@ -229,8 +229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(TallArgs a) {
       const float* bias = a.bias ? a.bias + (long)tc.bo * a.sbias_bo + (long)bi * a.sbias_bi : nullptr;
       const int nbase = nb * TBN + wn * 64 + r31, mbase = tc.m0 + wm * 128 + 4 * hh;
       // one branch per tile picks a straight-line store loop: FULL = every row and column of the wave tile exists (no per-store guards)
-      auto store = [&](auto CF, auto FULL) __attribute__((always_inline)) {
-        typedef typename std::conditional<decltype(CF)::value, _Float16, float>::type CT;
+      auto store = [&](auto CF, auto FULL) __attribute__((always_inline)) {   // CF: 0 fp32, 1 fp16, 2 bf16 output
+        typedef typename std::conditional<decltype(CF)::value == 1, _Float16, typename std::conditional<decltype(CF)::value == 2, __bf16, float>::type>::type CT;
         // 32-bit byte offsets from a uniform base (gemm_tall_ok bounds M * ldc): one VGPR per address instead of two
         char* cbase = a.C + ocb * (long)sizeof(CT);
         const unsigned ldcb = (unsigned)a.ldc * (unsigned)sizeof(CT);
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(TallArgs a) {
               const float v = acc[mi][ni][r] + bv;
               if (decltype(FULL)::value || (nok && mb + dm < a.M)) {
                 CT* c = reinterpret_cast<CT*>(cbase + (off0 + (unsigned)dm * ldcb));
-                if constexpr (decltype(CF)::value) *c = to_f16_sat(v);
+                if constexpr (decltype(CF)::value == 1) *c = to_f16_sat(v);
+                else if constexpr (decltype(CF)::value == 2) *c = to_bf16(v);
                 else *c = v;
               }
             }
@@ -266,8 +267,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(TallArgs a) {
       };
       const bool full = tc.m0 + TBM <= a.M && (nb + 1) * TBN <= a.N;
       if (TALL_DBG(16)) { if (acc[0][0][0] == 123.25f && acc[3][1][7] == 7.f) a.C[0] = 1; }
-      else if (a.c_f16) { if (full) store(std::true_type{}, std::true_type{}); else store(std::true_type{}, std::false_type{}); }
-      else { if (full) store(std::false_type{}, std::true_type{}); else store(std::false_type{}, std::false_type{}); }
+      else if (a.c_f16 == 1) { if (full) store(std::integral_constant<int, 1>{}, std::true_type{}); else store(std::integral_constant<int, 1>{}, std::false_type{}); }
+      else if (a.c_f16 == 2) { if (full) store(std::integral_constant<int, 2>{}, std::true_type{}); else store(std::integral_constant<int, 2>{}, std::false_type{}); }
+      else { if (full) store(std::integral_constant<int, 0>{}, std::true_type{}); else store(std::integral_constant<int, 0>{}, std::false_type{}); }
     }
     TALL_ADD(2, TALL_NOW() - te);
     TALL_ADD(4, 1);
@@ -454,7 +456,7 @@ int gemm_tall(hipStream_t s, const GemmDesc& d) {
   a.A[1] = reinterpret_cast<const char*>(d.A2 ? d.A2 : d.A); a.W[1] = reinterpret_cast<const char*>(d.B2 ? d.B2 : d.B);
   a.lda = d.sa_m; a.ldw = d.sb_n;
   a.kt0 = d.K / TBK; a.kt = a.kt0 + (d.A2 ? d.K2 / TBK : 0);
-  a.C = reinterpret_cast<char*>(d.C); a.ldc = d.sc_m; a.c_f16 = d.c_f16;
+  a.C = reinterpret_cast<char*>(d.C); a.ldc = d.sc_m; a.c_f16 = d.c_f16 ? 1 : (d.c_bf16 ? 2 : 0);
   a.bias = d.bias_n;
   a.M = d.M; a.N = d.N;
   a.mt = (d.M + TBM - 1) / TBM; a.nt = (d.N + TBN - 1) / TBN;
@@ -502,7 +504,7 @@ bool gemm_tall_tn_ok(const GemmDesc& d) {
   const long min_k = e_min ? atol(e_min) : 16384;
   if (!d.a_bf16 || !d.b_bf16 || d.f16 || d.K < min_k) return false;
   if (d.sa_m != 1 || d.sb_n != 1 || d.sc_n != 1) return false;                    // A[k][m], B[k][n], C[m][n]
-  if (!d.atomic || d.A2 || d.bias_n || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.colsum || d.act != ACT_NONE || d.alpha != 1.f || d.c_f16) return false;
+  if (!d.atomic || d.A2 || d.bias_n || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.colsum || d.act != ACT_NONE || d.alpha != 1.f || d.c_f16 || d.c_bf16) return false;
   if (d.M % 8 != 0 || d.N % 8 != 0 || d.M < 32 || d.N < 32 || d.N > 256 || d.M > 1024) return false;
   if (d.sa_k % 8 != 0 || d.sb_k % 8 != 0) return false;
   if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B)) & 15) return false;

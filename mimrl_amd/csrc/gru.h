@@ -25,6 +25,7 @@ struct GruFwdArgs {
   const int* lens[2];      // [modality][B] valid lengths (packed-sequence semantics)
   int B, T, out_ld, nmod;
   int btv;             // batch rows per workgroup (1..4)
+  int no_out32 = 0;    // (fused input projection + out16 only) the fp32 outputs are NOT written: every consumer reads the fp16 copy
   int gx_f16 = 0;      // gx is an FP16 array behind the float-typed pointer (bf16 mode only; written by a GemmDesc::c_f16 projection)
   // Fused input projection (bf16 mode, layer 0 of the packed path): gx = x W_ih^T + b_ih is NOT read; the kernel computes it per cell step
   // from the fp16 packed inputs xin[modality] [B*T, kp] and the fp16 packed weights wih[modality][direction] [3H, kp] (kp % 8 == 0,
@@ -46,6 +47,8 @@ struct GruSeqBwd {
   float* hprev;        // [B,T,H]  h_{prev} of every step (0 at sequence starts / padded steps): operand of dW_hh
   float* db_ih;        // [3H] += sum_{b,t} dgx   (nullable)
   float* db_hh;        // [3H] += sum_{b,t} dgh   (nullable)
+  const _Float16* out16 = nullptr;   // optional (all sequences of a launch or none; bf16 mode, 4-wave kernel): the forward kernel's fp16 copy of `out`
+                                     // (GruSeq::out16) -- h_prev is read from it and `out` is not touched (it may never have been written)
 };
 
 struct GruBwdArgs {
@@ -55,6 +58,7 @@ struct GruBwdArgs {
   int B, T, out_ld, dout_ld, dout_off, nmod;
   int btv;             // must equal the forward launch's value (addresses the saved-gate slab)
   int dg_bf16 = 0;     // dg / hprev are written as bf16 (same element indices): their only consumers are bf16-operand GEMMs
+  int dout_bf16 = 0;   // dout is a bf16 array behind the float-typed pointers (same element indices; bf16 mode with dg_bf16, 4-wave kernel)
   // record layout of the saved-gate slab the forward launch of this layer wrote: 0 = whatever gru_upl() says (the forward ran the
   // kernel MIMRL_GRU_WAVES picked), 2 = the 4-wave layout regardless (the fused-projection forward, GruFwdArgs::xin_on, always writes
   // that one): the BPTT kernel is chosen by the slab it has to read, not by the knob
@@ -63,6 +67,7 @@ struct GruBwdArgs {
 
 int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16);
 int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16);
+bool gru_bwd_io16_ok(int slab_upl);
 long gru_saved_floats(int B, int T);
 // batch rows per workgroup (<= 4): the kernels are bound by the per-step instruction latency of one wave, so the batch
 // is spread over as many CUs as possible

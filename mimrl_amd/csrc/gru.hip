@@ -73,12 +73,24 @@ __device__ __forceinline__ void gld(float& d, const float* p) { asm volatile("gl
 __device__ __forceinline__ void gld(float2& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void gld(bf16x4& d, const float* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void gld(bf16x8& d, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gld(uint32_t& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 template <int N, class A, class B, class C>
 __device__ __forceinline__ void vm_wait(A& a, B& b, C& c) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
 }
 __device__ __forceinline__ float comp(const float2& v, int e) { return e ? v.y : v.x; }
 __device__ __forceinline__ float comp(const float& v, int) { return v; }
+// 16-bit stored operand pairs of the BPTT kernel (IO16): two adjacent units in one dword
+struct PairBf { uint32_t v; };   // bf16 x 2 (dout)
+struct PairH { uint32_t v; };    // fp16 x 2 (the forward kernel's fp16 copy of its outputs: h_prev)
+__device__ __forceinline__ void gld(PairBf& d, const void* p) { gld(d.v, p); }
+__device__ __forceinline__ void gld(PairH& d, const void* p) { gld(d.v, p); }
+__device__ __forceinline__ float comp(const PairBf& p, int e) { return __builtin_bit_cast(float, e ? (p.v & 0xffff0000u) : (p.v << 16)); }
+__device__ __forceinline__ float comp(const PairH& p, int e) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 h = __builtin_bit_cast(h2, p.v);
+  return (float)(e ? h[1] : h[0]);
+}
 
 // saved-gate slab, "lane-native": one record {r z n hn} x UPL per (t, tile, wave, lane); bf16 mode packs it into ONE 8 x UPL-byte
 // vector (a wave instruction stores 512 x UPL bytes contiguous), fp32 mode into UPL 16-byte ones.
@@ -163,7 +175,7 @@ __device__ long long g_gru_bwd_phase[32];
 // and with ONE wave per SIMD nothing runs under any of it.  With two waves per SIMD each wave has half the products (12 instead of 24)
 // and half the gate math (one unit per lane), and one wave's transcendentals run under the other's MFMAs; the matrix pipe of a SIMD
 // still sees the same 24 products per step -- its floor, 384 cycles -- but no longer waits for 2 x the gate math in between.
-template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false, bool H16 = false, bool XIN = false>   // GXH: gx stored as fp16; XIN: fused input projection
+template <bool BF16, bool SAVE, int UPL, int SKIP = 0, bool GXH = false, bool H16 = false, bool XIN = false, bool NO32 = false>   // GXH: gx stored as fp16; XIN: fused input projection; NO32: no fp32 outputs (H16 only)
 __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_fwd_kernel(GruFwdArgs a) {
   using C = Cfg<BF16>;
   stamp_begin(a.stamp);
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     }
     if constexpr (!GSKIP(32)) putu<UPL>(hs[cur ^ 1], kq, u0, hreg);
     if constexpr (!GSKIP(4)) {
-      stu<UPL>(out_b + (long)t * a.out_ld, ho);
+      if constexpr (!NO32) stu<UPL>(out_b + (long)t * a.out_ld, ho);
       if constexpr (H16) {
         if constexpr (UPL == 2) { typedef __attribute__((ext_vector_type(2))) _Float16 h2; h2 x; x[0] = to_f16_sat(ho[0]); x[1] = to_f16_sat(ho[1]); *reinterpret_cast<h2*>(out16_b + (long)t * a.out_ld) = x; }
         else out16_b[(long)t * a.out_ld] = to_f16_sat(ho[0]);
@@ -416,11 +428,18 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
 // 30 of 30 fresh engines exact with the AGPR-free build, ~70 % of them wrong with the other; mechanism not understood).  190 VGPRs, no
 // AGPRs, no scratch, same speed.  The fp32 instantiations need more than 256 registers and keep (256, 1).  (UPL = 1: 512 threads, one
 // workgroup per CU, at most 256 registers per lane by construction.)
-template <bool BF16, bool DGBF, int UPL, int SKIP = 0>
+// IO16 (round 5b; bf16 mode, UPL = 2 only): bit 0 -- dout is a bf16 array (GruBwdArgs::dout_bf16: its producer, the dh0 product or the
+// LayerNorm backward, stored it that way); bit 1 -- h_prev comes from the forward kernel's fp16 copy of its outputs (GruSeqBwd::out16) and
+// the fp32 outputs are not read (the forward launch may not even have written them).  Same NUMBER of loads per cell step, so the explicit
+// wait counts do not change; half the bytes each.
+template <bool BF16, bool DGBF, int UPL, int SKIP = 0, int IO16 = 0>
 __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 1) void gru_bwd_kernel(GruBwdArgs a) {
+  static_assert(IO16 == 0 || (BF16 && UPL == 2), "16-bit stored dout / h_prev: the 4-wave bf16 kernel only");
   using C = Cfg<BF16>;
   using F = typename Pack<UPL>::F;
   using GR = typename Pack<UPL>::G;
+  using DOT = std::conditional_t<(IO16 & 1) != 0, PairBf, F>;
+  using HPT = std::conditional_t<(IO16 & 2) != 0, PairH, F>;
   stamp_begin(a.stamp);
   GPH_DECL;
 #ifdef MIMRL_PHASE_PROBE
@@ -461,8 +480,11 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   for (int e = 0; e < UPL; ++e) { carry[e] = 0.f; sb[0][e] = sb[1][e] = sb[2][e] = sb[3][e] = 0.f; }
 
   const long bb = b;
-  const float* out_b = q.out + bb * T * a.out_ld + dir * H + u0;        // forward outputs of THIS direction (h_prev source)
-  const float* dout_b = q.dout + bb * T * a.dout_ld + a.dout_off * dir + u0;
+  // (byte pointers: the element size of the two operands depends on IO16)
+  constexpr int HPB = (IO16 & 2) ? 2 : 4, DOB = (IO16 & 1) ? 2 : 4;
+  const char* out_b = ((IO16 & 2) ? reinterpret_cast<const char*>(q.out16) : reinterpret_cast<const char*>(q.out)) +
+                      (bb * T * a.out_ld + dir * H + u0) * HPB;             // forward outputs of THIS direction (h_prev source)
+  const char* dout_b = reinterpret_cast<const char*>(q.dout) + (bb * T * a.dout_ld + a.dout_off * dir + u0) * DOB;
   const long dg_o = bb * (long)T * 4 * H + u0, hp_o = bb * (long)T * H + u0;   // element offsets (fp32 or bf16 elements: DGBF)
   const float* sv_b = q.saved + sv_index<BF16, UPL>(0, ntile, tile, w, lane);
   const long sv_step = (long)ntile * (8 / UPL) * 64 * SvRec<BF16, UPL>::F;
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
   // stale-but-initialised records and are masked in the math).  h_prev is the previous VALID output of this direction;
   // with packed semantics that is simply out[tprev] when tprev is inside [0,len) and the zero initial state otherwise
   // (selected at use).
-  struct Ops { Gates<UPL> g; GR graw; F DO, HP; };
+  struct Ops { Gates<UPL> g; GR graw; DOT DO; HPT HP; };
   auto fetch = [&](Ops& o, int step) {
     const int sc = step < T ? step : T - 1;
     const int t = dir ? sc : T - 1 - sc;
@@ -483,14 +505,14 @@ __global__ __launch_bounds__(512 / UPL, BF16 ? (UPL == 2 ? GRU_BF16_MINB : 1) : 
     const int tc = tprev < 0 ? 0 : (tprev >= T ? T - 1 : tprev);
     if constexpr (BF16) {   // explicit-wait loads (see gld): the packed gate record is decoded behind the wait
       gld(o.graw, sv_b + t * sv_step);
-      gld(o.DO, dout_b + (long)t * a.dout_ld);
-      gld(o.HP, out_b + (long)tc * a.out_ld);
+      gld(o.DO, reinterpret_cast<const float*>(dout_b + (long)t * a.dout_ld * DOB));
+      gld(o.HP, reinterpret_cast<const float*>(out_b + (long)tc * a.out_ld * HPB));
     } else {
       load_gates<BF16, UPL>(sv_b + t * sv_step, o.g);
       float x[UPL];
-      ldu<UPL>(dout_b + (long)t * a.dout_ld, x);
+      ldu<UPL>(reinterpret_cast<const float*>(dout_b) + (long)t * a.dout_ld, x);
       if constexpr (UPL == 2) o.DO = make_float2(x[0], x[1]); else o.DO = x[0];
-      ldu<UPL>(out_b + (long)tc * a.out_ld, x);
+      ldu<UPL>(reinterpret_cast<const float*>(out_b) + (long)tc * a.out_ld, x);
       if constexpr (UPL == 2) o.HP = make_float2(x[0], x[1]); else o.HP = x[0];
     }
   };
@@ -746,9 +768,12 @@ int gru_forward(hipStream_t s, const GruFwdArgs& a, bool bf16) {
     for (int d = 0; d < 2; ++d)
       if ((a.seq[m][d].out16 != nullptr) != h16) return set_error(MIMRL_ERR_ARG, "gru_forward: fp16 output copies must be all set or all null");
   if (h16 && !bf16) return set_error(MIMRL_ERR_ARG, "gru_forward: the fp16 output copy exists in the bf16 recurrence mode only");
+  if (a.no_out32 && !a.xin_on) return set_error(MIMRL_ERR_ARG, "gru_forward: no_out32 exists for the fused-projection kernel only");
   if (a.xin_on) {
     if (!bf16 || a.gx_f16 || a.kp % 8 != 0 || a.kp > 96 || a.kp < 8) return set_error(MIMRL_ERR_ARG, "gru_forward: the fused input projection needs the bf16 mode and kp in 8..96, a multiple of 8");
-    if (h16) {
+    if (a.no_out32 && !(h16 && save)) return set_error(MIMRL_ERR_ARG, "gru_forward: no_out32 needs the fp16 output copy and the saved-gate slab");
+    if (h16 && a.no_out32) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, false, true, true, true>), grid, dim3(512), 0, s, a);
+    else if (h16) {
       if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, true, 1, 0, false, true, true>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((gru_fwd_kernel<true, false, 1, 0, false, true, true>), grid, dim3(512), 0, s, a);
     } else {
@@ -818,6 +843,12 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   }
 #endif
   const int upl = a.slab_upl ? a.slab_upl : gru_upl();
+  const bool o16 = a.seq[0][0].out16 != nullptr;
+  for (int m = 0; m < a.nmod; ++m)
+    for (int d = 0; d < 2; ++d)
+      if ((a.seq[m][d].out16 != nullptr) != o16) return set_error(MIMRL_ERR_ARG, "gru_backward: fp16 output copies must be all set or all null");
+  const int io16 = (a.dout_bf16 ? 1 : 0) | (o16 ? 2 : 0);
+  if (io16 && !(bf16 && a.dg_bf16 && upl == 2)) return set_error(MIMRL_ERR_ARG, "gru_backward: 16-bit stored dout / h_prev need the bf16 mode with bf16 dg and the 4-wave slab layout");
   if (bf16 && upl == 1) {
     auto k1 = gru_bwd_kernel<true, true, 1>;
     auto k0 = gru_bwd_kernel<true, false, 1>;
@@ -827,6 +858,15 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
     }
     if (a.dg_bf16) hipLaunchKernelGGL(k1, grid, dim3(512), pad, s, a);
     else hipLaunchKernelGGL(k0, grid, dim3(512), 0, s, a);
+  } else if (bf16 && io16) {
+    // 16-bit stored dout and / or h_prev from the forward's fp16 copy (IO16: see the kernel)
+    typedef void (*K)(GruBwdArgs);
+    const K k = io16 == 1 ? static_cast<K>(gru_bwd_kernel<true, true, 2, 0, 1>) : io16 == 2 ? static_cast<K>(gru_bwd_kernel<true, true, 2, 0, 2>) : static_cast<K>(gru_bwd_kernel<true, true, 2, 0, 3>);
+    if (pad) {
+      static bool attr[4] = {false, false, false, false};
+      if (!attr[io16]) { HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr[io16] = true; }
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), pad, s, a);
   } else if (bf16) {
     auto k1 = gru_bwd_kernel<true, true, 2>;
     if (pad) {
@@ -841,6 +881,10 @@ int gru_backward(hipStream_t s, const GruBwdArgs& a, bool bf16) {
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
+
+// may a BPTT launch that reads a slab of layout `slab_upl` (GruBwdArgs::slab_upl) take 16-bit stored dout / h_prev?  (the engine decides
+// what the producers write before the launch exists)
+bool gru_bwd_io16_ok(int slab_upl) { return (slab_upl ? slab_upl : gru_upl()) == 2 && gru_skip() == 0; }
 
 long gru_saved_floats(int B, int T) {
   return (long)T * B * 4 * 64 * 8;   // worst case: one batch row per workgroup (btv = 1)

@@ -24,7 +24,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_DDP_SPLIT", "engine_abi.hip", "", "0: the main gradient bucket all-reduced in one piece (in-library RCCL and dist.py)"},
   {"MIMRL_DG_FP32", "engine_abi.hip", "", "BPTT outputs dg / h_prev stored as fp32 instead of bf16"},
   {"MIMRL_DH0_LAST", "engine_backward.hip", "", "capture order of dh0 vs the side-stream weight gradients"},
-  {"MIMRL_DWIH_H16", "engine_backward.hip", "", "0: the layer-1 dW_ih product reads the fp32 layer-0 outputs instead of the recurrence's fp16 copy"},
+  {"MIMRL_DWIH_H16", "engine_abi.hip", "", "0: the layer-1 dW_ih product reads the fp32 layer-0 outputs instead of the recurrence's fp16 copy"},
   {"MIMRL_EST_INTERLEAVE", "engine_estimators.hip", "0", "bit mask (1: stage 1, 2: stage 2): capture both estimator branches' forward halves in front of either backward half; + 4: the image launches on side 3 behind both (measured: within process-to-process noise)"},
   {"MIMRL_EST_MI_FIRST", "engine_estimators.hip", "0", "capture order of the MI and the CMI estimator branches"},
   {"MIMRL_FRAG_INLINE", "engine_step.hip", "", "fragment images of the critics on the main stream instead of side 3"},
@@ -39,6 +39,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_GEMM_NO_LEAN", "gemm.hip", "", "generic GEMM: no 16-byte-load (lean) instantiations"},
   {"MIMRL_GEMM_NO_RAGGED", "gemm.hip", "", "generic GEMM: lean kernels only for tile-aligned M / N"},
   {"MIMRL_GEMM_NO_XCD", "gemm.hip", "", "no XCD-aware tile order in the GEMM kernels"},
+  {"MIMRL_GEMM_WIDE_N", "gemm.hip", "", "128 x 256 tiles for long-reduction weight gradients with 16-bit stored operands and N a multiple of 256 (opt-in; 1: all, 2: M a multiple of 256 only, 3: the others)"},
   {"MIMRL_GEMM_TALL_MIN_M", "gemm_tall.hip", "", "row threshold of the tall LDS-DMA GEMM (default 4096)"},
   {"MIMRL_GEMM_TALL_TN", "gemm_tall.hip", "", "1: tall weight-gradient LDS-DMA kernel on (opt-in: ties the split-K kernel)"},
   {"MIMRL_GEMM_TALL_TN_MIN_K", "gemm_tall.hip", "", "reduction-length threshold of the tall weight-gradient kernel (default 16384)"},
@@ -99,6 +100,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_NO_WG_GROUPK", "engine_backward.hip", "", "parked CubeMLP weight gradients as single launches instead of gemm_groupk"},
   {"MIMRL_NO_WG_SPLIT", "engine_estimators.hip", "", "estimator weight gradients: no split across two streams"},
   {"MIMRL_NO_XIN", "engine_abi.hip", "", "layer-0 input projection as its own GEMM instead of fused into the recurrence kernel"},
+  {"MIMRL_REC16", "engine_abi.hip", "", "0: the BPTT launches read fp32 dout / h_prev (round 5a): dh0 and ds stored fp32, the fused-projection forward writes its fp32 outputs"},
   {"MIMRL_PREFETCH_FIRST", "engine_step.hip", "", "capture order of the two chains"},
   {"MIMRL_SINGLE_STREAM", "engine_abi.hip", "", "enqueue everything on one stream (no side streams)"},
   {"MIMRL_TAIL_STREAMS", "engine_backward.hip", "1", "streams the layer-0 tail weight gradients are dealt over (default 1)"},

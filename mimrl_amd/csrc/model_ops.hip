@@ -56,7 +56,7 @@ __global__ void text_post_kernel(const float* __restrict__ src, float* __restric
 }
 
 // ------------------------------------------------------------------ LN + ReLU + dropout on the bi-GRU output
-struct LnSide { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamma, *dbeta; int slot; float p; uint32_t stream; const float* dmean; };
+struct LnSide { const float *h2, *gamma, *beta; float *mean, *rstd, *ds, *dgamma, *dbeta; int slot; float p; uint32_t stream; const float* dmean; int ds_bf16 = 0; };
 template <int PER>   // D = 64*PER; blockIdx.y selects the modality (audio / video) of a paired launch
 __global__ void ln_relu_drop_fwd_kernel(LnSide s0, LnSide s1, float* __restrict__ cube, long rows, int T, int L, int K,
                                         RngKey key) {
@@ -208,8 +208,17 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
       float4 o0, o1;
       o0.x = rs * (dxh[0] - s1 - xh[0] * s2); o0.y = rs * (dxh[1] - s1 - xh[1] * s2); o0.z = rs * (dxh[2] - s1 - xh[2] * s2); o0.w = rs * (dxh[3] - s1 - xh[3] * s2);
       o1.x = rs * (dxh[4] - s1 - xh[4] * s2); o1.y = rs * (dxh[5] - s1 - xh[5] * s2); o1.z = rs * (dxh[6] - s1 - xh[6] * s2); o1.w = rs * (dxh[7] - s1 - xh[7] * s2);
-      *reinterpret_cast<float4*>(ds + r * D + c0) = o0;
-      *reinterpret_cast<float4*>(ds + r * D + c1) = o1;
+      if (sd.ds_bf16) {   // (LnSide::ds_bf16: the layer-1 BPTT reads its dout as bf16 -- same element indices, half the bytes)
+        __bf16* dsb = reinterpret_cast<__bf16*>(ds);
+        bf16x4 q0, q1;
+        q0[0] = to_bf16(o0.x); q0[1] = to_bf16(o0.y); q0[2] = to_bf16(o0.z); q0[3] = to_bf16(o0.w);
+        q1[0] = to_bf16(o1.x); q1[1] = to_bf16(o1.y); q1[2] = to_bf16(o1.z); q1[3] = to_bf16(o1.w);
+        *reinterpret_cast<bf16x4*>(dsb + r * D + c0) = q0;
+        *reinterpret_cast<bf16x4*>(dsb + r * D + c1) = q1;
+      } else {
+        *reinterpret_cast<float4*>(ds + r * D + c0) = o0;
+        *reinterpret_cast<float4*>(ds + r * D + c1) = o1;
+      }
     }
   }
   MPHASE(pb, 10);
@@ -1066,13 +1075,15 @@ int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* 
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
+bool ln_relu_drop_bwd2_bf16_ok() { return knob("MIMRL_LN_BWD_WAVE_ROWS") == nullptr; }   // (the round-2 kernel has no bf16 output)
 int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
-                      RngKey key, const float* dmean_a, const float* dmean_v) {
+                      RngKey key, const float* dmean_a, const float* dmean_v, int ds_bf16) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
-  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, dmean_a};
-  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v};
+  const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, dmean_a, ds_bf16};
+  const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v, ds_bf16};
   static const bool old_kernel = knob("MIMRL_LN_BWD_WAVE_ROWS") != nullptr;   // tuning knob: the one-row-per-wave kernel of round 2
+  if (old_kernel && ds_bf16) return set_error(MIMRL_ERR_ARG, "ln_relu_drop_bwd2: the one-row-per-wave kernel writes fp32 only");
   if (old_kernel) hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   else {
     static const int cap = knob("MIMRL_LN_BWD_BLOCKS") ? atoi(knob("MIMRL_LN_BWD_BLOCKS")) : 128;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)

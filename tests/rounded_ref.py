@@ -224,7 +224,9 @@ class _GruDirQ(torch.autograd.Function):
                              the layer below, both products of `mm`) round it themselves, the same value the bf16-stored dg holds.
     With rq = identity this IS autograd of oracle.gru_direction (tests/test_rounded_ref.py)."""
     @staticmethod
-    def forward(ctx, gx, w_hh, b_hh, lengths, reverse, rq):
+    def forward(ctx, gx, w_hh, b_hh, lengths, reverse, rq, qd=identity, qh=identity):
+        """qd / qh (round 5b, MIMRL_REC16): storage rounding of the BPTT's two streamed operands -- dout as its producer stored it (bf16: the dh0
+        product's epilogue / the LayerNorm backward) and h_prev as the forward kernel's fp16 copy of its outputs (layer 0)."""
         B, T, G = gx.shape
         H = G // 3
         wq = rq(w_hh)
@@ -244,13 +246,13 @@ class _GruDirQ(torch.autograd.Function):
             h = torch.where(valid, hnew, h)
             gates[:, t] = torch.stack([r, z, n, hn], 1)
         ctx.save_for_backward(rq(gates), out, wq, lengths)
-        ctx.meta = (order, rq)
+        ctx.meta = (order, rq, qd, qh)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         gates, out, wq, lengths = ctx.saved_tensors
-        order, rq = ctx.meta
+        order, rq, qd, qh = ctx.meta
         B, T, H = out.shape
         carry = out.new_zeros(B, H)
         dgx = out.new_zeros(B, T, 3 * H)
@@ -262,11 +264,11 @@ class _GruDirQ(torch.autograd.Function):
             if k > 0:
                 tp = order[k - 1]
                 hp_ok = valid & (lengths > tp).unsqueeze(1)
-                hp = torch.where(hp_ok, out[:, tp], torch.zeros_like(carry))
+                hp = torch.where(hp_ok, qh(out[:, tp]), torch.zeros_like(carry))
             else:
                 hp = torch.zeros_like(carry)
             r, z, n, hn = gates[:, t, 0], gates[:, t, 1], gates[:, t, 2], gates[:, t, 3]
-            dh = dout[:, t] + carry
+            dh = qd(dout[:, t]) + carry
             dn = dh * (1 - z)
             dz = dh * (hp - n)
             dnp = dn * (1 - n * n)
@@ -281,10 +283,10 @@ class _GruDirQ(torch.autograd.Function):
             carry = dhz + rq(dgh) @ wq
             dw = dw + rq(dgh).t() @ rq(hp)
             db = db + dgh.sum(0)
-        return dgx, dw, db, None, None, None
+        return dgx, dw, db, None, None, None, None, None
 
 
-def bigru2_q(p, prefix, x, lengths, rnd, rq, gxq=identity):
+def bigru2_q(p, prefix, x, lengths, rnd, rq, gxq=identity, rec16=False):
     """oracle.bigru2 with the kernels' rounding: hoisted projections through ``mm`` (``rnd``: fp16 forward operands, bf16 gradient
     operands), recurrences through _GruDirQ (``rq``: bf16); ``gxq``: storage rounding of the projection's OUTPUT gx (fp16 for long
     sequences, engine_abi.hip gx_f16; straight-through: the BPTT's gradient w.r.t. gx does not see it)."""
@@ -293,19 +295,21 @@ def bigru2_q(p, prefix, x, lengths, rnd, rq, gxq=identity):
         outs = []
         for rev, sfx in ((False, ""), (True, "_reverse")):
             gx = ste(gxq, mm(inp, p[f"{prefix}.weight_ih_l{layer}{sfx}"], rnd) + p[f"{prefix}.bias_ih_l{layer}{sfx}"])
-            outs.append(_GruDirQ.apply(gx, p[f"{prefix}.weight_hh_l{layer}{sfx}"], p[f"{prefix}.bias_hh_l{layer}{sfx}"], lengths, rev, rq))
+            # rec16 (engine default in the bf16 BPTT mode): dout of both layers is stored as bf16, h_prev of layer 0 comes from the fp16 copy
+            qd, qh = (r_bf16, r_f16 if layer == 0 else identity) if rec16 else (identity, identity)
+            outs.append(_GruDirQ.apply(gx, p[f"{prefix}.weight_hh_l{layer}{sfx}"], p[f"{prefix}.bias_hh_l{layer}{sfx}"], lengths, rev, rq, qd, qh))
         inp = torch.cat(outs, dim=-1)
     H = inp.shape[-1] // 2
     return inp[..., :H] + inp[..., H:]
 
 
-def encoders_q(p, opt, t_feat, a, v, rnd, rq, gxq=identity):
+def encoders_q(p, opt, t_feat, a, v, rnd, rq, gxq=identity, rec16=False):
     """Model.forward up to the stacked cube input (Model.py:395-475; oracle.model_forward lines 187-206), dropout 0.
     -> (x [B,L,3,D], T_F, A_F, V_F)."""
     D, L = opt.d_common, opt.time_len
     t = mm(t_feat, p["W_t.weight"], rnd)
     la, lv = R.infer_lengths(a), R.infer_lengths(v)
-    ah = F.relu(F.layer_norm(bigru2_q(p, "rnn_a", a, la, rnd, rq, gxq), (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))
-    vh = F.relu(F.layer_norm(bigru2_q(p, "rnn_v", v, lv, rnd, rq, gxq), (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
+    ah = F.relu(F.layer_norm(bigru2_q(p, "rnn_a", a, la, rnd, rq, gxq, rec16), (D,), p["ln_a.weight"], p["ln_a.bias"], 1e-6))
+    vh = F.relu(F.layer_norm(bigru2_q(p, "rnn_v", v, lv, rnd, rq, gxq, rec16), (D,), p["ln_v.weight"], p["ln_v.bias"], 1e-6))
     pad = lambda y: F.pad(y, (0, 0, 0, L - y.shape[1]))
     return torch.stack([pad(t), pad(ah), pad(vh)], dim=2), t.mean(1), ah.mean(1), vh.mean(1)

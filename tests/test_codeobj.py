@@ -25,9 +25,9 @@ def ks():
 
 
 def test_every_tu_is_present(ks):
-    for name in ("gru_fwd_kernel<true, true, 1, 0, false, false, false>", "gru_bwd_kernel<true, true, 1, 0>", "gru_fwd_kernel<true, true, 2, 0, false, false, false>",
-                 "gru_fwd_kernel<true, true, 1, 0, false, true, true>", "gemm_fast_f16s_kernel<2, 1>",
-                 "gru_bwd_kernel<true, true, 2, 0>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0, false>",
+    for name in ("gru_fwd_kernel<true, true, 1, 0, false, false, false, false>", "gru_bwd_kernel<true, true, 1, 0, 0>", "gru_fwd_kernel<true, true, 2, 0, false, false, false, false>",
+                 "gru_fwd_kernel<true, true, 1, 0, false, true, true, false>", "gru_fwd_kernel<true, true, 1, 0, false, true, true, true>", "gemm_fast_f16s_kernel<2, 1>",
+                 "gru_bwd_kernel<true, true, 2, 0, 0>", "gru_bwd_kernel<true, true, 2, 0, 1>", "gru_bwd_kernel<true, true, 2, 0, 3>", "cube_fwd_fused_kernel<true, 3, 2>", "kmix_bwd_kernel<4, 0, false>",
                  "concat_fwd_kernel<3>", "mlp_img8_kernel<true, 4>", "adam_kernel", "knn_tile_kernel<1, 4>", "knn_merge_kernel<2, 4>", "sample_anchors_kernel", "lstm_fwd_kernel"):
         assert name in ks, name
     assert len(ks) > 120

@@ -852,6 +852,8 @@ def test_bf16_stored_bptt_outputs_change_nothing(monkeypatch):
     noise of the split-K atomics (MIMRL_DG_FP32=1 = the fp32-stored run)."""
     res = {}
     monkeypatch.setenv("MIMRL_NO_XIN", "1")   # (the fused layer-0 projection exists with bf16 dg only: keep the forward pass the same in both runs)
+    monkeypatch.setenv("MIMRL_REC16", "0")    # (round 5b: 16-bit stored dout / h_prev exist with bf16 dg only and are new rounding points: tests/test_gpu_fused_oracle.py)
+    monkeypatch.setenv("MIMRL_DWIH_H16", "0") # (... and so does the layer-1 dW_ih product's fp16 -> bf16 operand: test_16bit_stored_projection_operands_change_nothing)
     for tag, env in (("bf16", None), ("fp32", "1")):
         if env:
             monkeypatch.setenv("MIMRL_DG_FP32", env)
@@ -880,7 +882,7 @@ def test_critic_update_with_fragment_images_and_stage_boundary_changes_nothing(w
     as a launch) a step must leave the same 64 scalars and predictions up to the run-to-run noise of the float atomics in the gradients (device-drawn
     anchors: the RNG step counters must have advanced identically, or the draws -- and everything else -- differ); a second step, which runs on
     the parameters and images the first one left, stays within the band that noise grows to (measured 1.9e-4 on values of 0.1 - 4: Adam's first
-    steps are sign-like, a last-bit difference in a near-zero gradient moves a parameter by 2 lr), and all but a sliver of the parameters agree."""
+    steps are sign-like, a last-bit difference in a near-zero gradient moves a parameter by 2 lr -- ~2 % of them after two steps)."""
     res = {}
     for tag, env in (("in_adam", None), ("launches", "0")):
         if env:
@@ -899,11 +901,8 @@ def test_critic_update_with_fragment_images_and_stage_boundary_changes_nothing(w
     assert np.isfinite(a[0]).all() and np.abs(a[0][0]).max() > 1 and a[0][0][33] > 0      # (33 = MIMRL_S2_TASK: the boundary's MAE)
     assert np.allclose(a[0][0], b[0][0], rtol=1e-5, atol=2e-6), np.abs(a[0][0] - b[0][0]).max()
     assert np.allclose(a[0][1], b[0][1], rtol=2e-3, atol=2e-3), np.abs(a[0][1] - b[0][1]).max()
-    far = tot = 0
     for n, pa in a[1].items():
-        far += int((np.abs(pa - b[1][n]) > 1e-4).sum())
-        tot += pa.size
-    assert far <= 0.02 * tot, (far, tot)
+        assert np.isfinite(pa).all() and np.abs(pa - b[1][n]).max() <= 2 * 2 * 4e-3 + 1e-6, n      # (at most two sign-like Adam steps apart)
 
 
 @pytest.mark.parametrize("name", ["cfg1_ragged", "cfg2_sep"])
@@ -912,6 +911,7 @@ def test_ln_backward_riding_on_the_laxis_kernel_changes_nothing(name, monkeypatc
     L-axis backward kernel (cube_bwd_fused.hip: laxis_bwd_kernel<true>, LAxisLnSide): the (sample, slot) dX tile goes through it from LDS with the
     lane mapping and arithmetic of ln_relu_drop_bwd16_kernel, so ds -- the layer-1 BPTT's input -- is the same bit pattern and every gradient of the
     main model equals the default two-launch run up to the order of the float atomics (ln_a / ln_v sums, split-K weight gradients)."""
+    monkeypatch.setenv("MIMRL_REC16", "0")    # (the tail writes fp32 ds; the default two-launch path stores it as bf16 for the layer-1 BPTT -- another rounding point)
     res = {}
     for tag, env in (("two", None), ("fused", "1")):
         if env:
