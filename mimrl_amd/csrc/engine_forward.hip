@@ -350,6 +350,21 @@ int mimrl_handle::cube_forward(bool train, bool save) {
       const AxisW& a = w.ax[0];
       const long C = (long)ik * id;
       const float* xi = x;
+      // round 5b, long sequences (the fused block kernel above needs L <= 64): one pass over the [L, C] slab of every sample instead of two
+      // GEMM launches that each read it, a padded-copy launch and the LayerNorm launch (cfg3: 275 -> ~80 us per forward tail)
+      const bool long_l = bf16 && laxis_long_on && !cfg.ln_first && pl <= 0.f && a.res >= 0 && laxis_fwd_long_supported(il, hl, ol, (int)C);
+      if (long_l) {
+        if (w2p[i] && hl % 4 != 0) {   // (the padded fc2 copy is still what the backward's dU product reads)
+          MX(pad_rows(stream, P(a.fc2.w), w2p[i], ol, hl, (hl + 3) & ~3));
+          w2p_valid[i] = true;
+        }
+        LAxisLongArgs la;
+        la.x = x; la.w1 = P(a.fc1.w); la.b1 = a.fc1.b >= 0 ? P(a.fc1.b) : nullptr; la.w2 = P(a.fc2.w); la.b2 = a.fc2.b >= 0 ? P(a.fc2.b) : nullptr;
+        la.wr = P(a.res); la.g = P(a.ln_g); la.be = P(a.ln_b);
+        la.u = b.l.u; la.h = b.l.h; la.y = b.l.y; la.z = b.l.z; la.mean = b.l.mean; la.rstd = b.l.rstd;
+        la.B = B; la.il = il; la.hl = hl; la.ol = ol; la.C = (int)C; la.act = cfg.activation;
+        MX(laxis_fwd_long(stream, la, fwd_f16));
+      } else {
       if (cfg.ln_first) { MX(colln_fwd(stream, x, P(a.ln_g), P(a.ln_b), b.l.xn, b.l.xn_mean, b.l.xn_rstd, B, il, (int)C)); xi = b.l.xn; }
       GemmDesc g1;   // H = act(W1 . X_b + b1)
       g1.A = P(a.fc1.w); g1.sa_m = il; g1.sa_k = 1; g1.sa_b = 0;
@@ -388,6 +403,7 @@ int mimrl_handle::cube_forward(bool train, bool save) {
         }
       }
       if (!cfg.ln_first) MX(colln_fwd(stream, b.l.y, P(a.ln_g), P(a.ln_b), b.l.z, b.l.mean, b.l.rstd, B, ol, (int)C));
+      }
     }
     // ------------------------------------------------ K axis (MLPProcess.py:106-112 / 76-82)
     {
