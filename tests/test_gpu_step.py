@@ -970,11 +970,13 @@ def test_split_stage2_gradients_equal_the_whole_pass(graph):
 
 
 # fp32 engine: per-tensor band on the stored slices (fraction of the tensor's own scale; 3x the measured 4.9e-3 / 1.7e-3) -- bench mode:
-# (critic bucket, main bucket) cosine floors.  Measured: fp32 cosines 1 - 3e-8; bench 0.99980 / 0.98935 (cfg3_full), 0.99948 / 0.97537
-# (cfg5_full): 3x the measured distance from 1.  Per TENSOR the bench mode is off by up to the tensor's whole scale in the small
+# (critic bucket, main bucket) cosine floors.  Measured: fp32 cosines 1 - 3e-8; bench 0.99981 / 0.99772 (cfg3_full), 0.99948 / 0.99751
+# (cfg5_full): 3x the measured distance from 1.  (Round 5a measured 0.98935 / 0.97537 for the main bucket: the GEMM chain of the long-sequence
+# L axis rounded the residual product's operands to bf16; the one-pass kernel of round 5b -- csrc/cube_long.hip -- rounds them to fp16 like every
+# other forward product, and the timed mode's main-model gradient is within 3.9 / 4.0 degrees of the reference's instead of 8.4 / 12.8.)  Per TENSOR the bench mode is off by up to the tensor's whole scale in the small
 # ill-conditioned ones at this depth (mlp_k.fc1.bias, ln_a.bias, single rows of rnn_a.weight_ih_l1: the backward of the broadcast means
 # through LayerNorms over K = 3 / L cancels most of the signal) -- recorded in profiles/r05_step_errors.json, not asserted.
-FULL_BANDS = {"cfg3_full": (1.5e-2, (0.9994, 0.968)), "cfg5_full": (6e-3, (0.9984, 0.926))}
+FULL_BANDS = {"cfg3_full": (1.5e-2, (0.9994, 0.9931)), "cfg5_full": (6e-3, (0.9984, 0.9925))}
 
 
 @pytest.mark.parametrize("name", ["cfg3_full", "cfg5_full"])
