@@ -29,8 +29,13 @@ static_assert(64 * SXP * sizeof(float) <= 2 * CT * KP * sizeof(__bf16), "the fp3
 // LT (ln tail, see LAxisLnSide): workgroups of slots 1 / 2 run their dX tile through the encoders' LayerNorm + ReLU + dropout backward.
 // Same lane mapping, arithmetic and summation order per row as ln_relu_drop_bwd16_kernel (16 lanes per row, two column quads per lane), so
 // ds is bit-identical to the two-launch path; only the order of the dgamma / dbeta atomics differs.
-template <bool LT>
+// LONG (round 5b): il > 64 -- the input axis of a long-sequence block (cfg3 / cfg5: L = 500 / 1000 -> 50 -> 50).  Phases 1 and 2 are the short
+// kernel's (LayerNorm backward over the <= 64 output rows, dU over the <= 64 hidden rows); phase 3, dX = W1^T dU + Wr^T dY, walks the il output
+// rows in tiles of 64 and stages the two transposed weight tiles per step (requested one tile ahead).  One launch instead of colln_bwd + two
+// GEMM launches with dY / dU round trips in between (192 us of the cfg3 chain).
+template <bool LT, bool LONG = false>
 __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
+  static_assert(!(LT && LONG), "the LayerNorm tail exists for il <= 64 only");
   __shared__ __attribute__((aligned(16))) __bf16 sdyu[2][CT][KP];
   auto& sdy = sdyu[0];
   auto& sdu = sdyu[1];
@@ -77,15 +82,19 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
     for (int j = 0; j < 16; ++j) {
       const int idx = tid + 256 * j;
       wv[0][j] = a.w2[idx < n2 ? idx : n2 - 1];
-      wv[1][j] = a.w1[idx < n1 ? idx : n1 - 1];
-      wv[2][j] = a.wr[idx < nr ? idx : nr - 1];
+      if constexpr (!LONG) {
+        wv[1][j] = a.w1[idx < n1 ? idx : n1 - 1];
+        wv[2][j] = a.wr[idx < nr ? idx : nr - 1];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int idx = tid + 256 * j;
       if (idx < n2) { const int o = idx / hl, h = idx - o * hl; wts[0][h][o] = to_bf16(wv[0][j]); }
-      if (idx < n1) { const int h = idx / il, i = idx - h * il; wts[1][i][h] = to_bf16(wv[1][j]); }
-      if (idx < nr) { const int o = idx / il, i = idx - o * il; wts[2][i][o] = to_bf16(wv[2][j]); }
+      if constexpr (!LONG) {
+        if (idx < n1) { const int h = idx / il, i = idx - h * il; wts[1][i][h] = to_bf16(wv[1][j]); }
+        if (idx < nr) { const int o = idx / il, i = idx - o * il; wts[2][i][o] = to_bf16(wv[2][j]); }
+      }
     }
   }
 
@@ -203,7 +212,56 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
     }
   }
   // ---- phase 3: dX = W1^T dU + Wr^T dY
-  {
+  if constexpr (LONG) {
+    // tiles of 64 output rows i: W1^T [i][h] and Wr^T [i][o] of the tile go through wts[1] / wts[2]; thread = (i = tid & 63, rows h / o =
+    // (tid >> 6) + 4 j): a wave reads 64 consecutive i of one weight row (256 B).  The next tile's 32 values are requested before this tile's products.
+    float w1v[16], wrv[16];
+    auto wreq = [&](int i0) __attribute__((always_inline)) {
+      const int i = min(i0 + (tid & 63), il - 1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = (tid >> 6) + 4 * j;
+        w1v[j] = a.w1[(long)min(r, hl - 1) * il + i];
+        wrv[j] = a.wr[(long)min(r, ol - 1) * il + i];
+      }
+    };
+    wreq(0);
+    for (int i0 = 0; i0 < il; i0 += 64) {
+      __syncthreads();                      // the previous tile's fragment reads of wts[1] / wts[2] (first trip: phase 2's of sdy / wts[0]) are done
+      {
+        const int ii = tid & 63;
+        const bool iok = i0 + ii < il;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int r = (tid >> 6) + 4 * j;
+          wts[1][ii][r] = to_bf16(iok && r < hl ? w1v[j] : 0.f);
+          wts[2][ii][r] = to_bf16(iok && r < ol ? wrv[j] : 0.f);
+        }
+      }
+      __syncthreads();
+      wreq(i0 + 64 < il ? i0 + 64 : i0);    // unconditional (past the end: this tile again, never stored)
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bool first = ks < 4;
+        const int kk = (first ? ks : ks - 4) * 16 + 8 * lh;
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(first ? &sdu[nt * 32 + lr][kk] : &sdy[nt * 32 + lr][kk]);
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][lr][kk]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bf, acc0, 0, 0, 0);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][32 + lr][kk]);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (i < il) a.dx[((long)b * il + i) * C + cc] = mt == 0 ? acc0[r] : acc1[r];
+        }
+    }
+  } else {
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -306,16 +364,18 @@ __global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
 int cube_bwd_read_phases(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cbwd_phase), sizeof(long long) * 64) == hipSuccess ? 0 : 1; }
 #endif
 
-bool laxis_bwd_supported(int il, int hl, int ol, int C) {
-  return il >= 1 && hl >= 1 && ol >= 1 && il <= 64 && hl <= 64 && ol <= 64 && C % CT == 0;
+bool laxis_bwd_supported(int il, int hl, int ol, int C) {   // (il > 64: the LONG instantiation)
+  return il >= 1 && hl >= 1 && ol >= 1 && hl <= 64 && ol <= 64 && C % CT == 0;
 }
 
 int laxis_bwd_fused(hipStream_t s, const LAxisBwdArgs& a) {
   if (!laxis_bwd_supported(a.il, a.hl, a.ol, a.C)) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: unsupported shape");
   if (!a.wr) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: needs the residual projection");
   if (a.lt_on) {
-    if (a.C != 3 * CT || a.lt_T < 1 || a.lt_T > a.il) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: ln tail needs C = 384 and T <= il");
+    if (a.C != 3 * CT || a.lt_T < 1 || a.lt_T > a.il || a.il > 64) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: ln tail needs C = 384 and T <= il");
     hipLaunchKernelGGL(laxis_bwd_kernel<true>, dim3(a.C / CT, a.B), dim3(256), 0, s, a);
+  } else if (a.il > 64) {
+    hipLaunchKernelGGL((laxis_bwd_kernel<false, true>), dim3(a.C / CT, a.B), dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL(laxis_bwd_kernel<false>, dim3(a.C / CT, a.B), dim3(256), 0, s, a);
   }

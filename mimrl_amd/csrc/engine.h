@@ -192,6 +192,7 @@ struct mimrl_handle {
   bool part0_done = false;             // mimrl_stage_grads_part(h, 2, 0) ran on the bound batch and nothing since: part 1 may follow
   bool l0_xin = false;                 // this step's layer-0 forward ran the fused-projection (8-wave) kernel: its BPTT launch must match
   bool xpack16 = false;                // the packed layer-0 operands of this step are the 16-bit arrays (set by the forward pass)
+  bool laxis_bwd_long_on = true;       // MIMRL_LAXIS_BWD_LONG=0 (mimrl_create): colln_bwd + GEMM chain for the L-axis backward of long sequences
   bool laxis_long_on = true;           // MIMRL_LAXIS_LONG=0 (mimrl_create): the GEMM chain for the L axis of long sequences
   bool rec16_on = true, dwih_h16_on = true;   // MIMRL_REC16=0 / MIMRL_DWIH_H16=0 (mimrl_create)
   bool hp16_live = false;              // this pass's layer-0 BPTT reads h_prev from h0h (set by the forward pass; with the fused projection the fp32 outputs were not even written)

@@ -208,7 +208,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       cur = q;
     }
     // ------------------------------------------------ L axis backward (per-sample [.,C] tiles, C = ik*id)
-    if (bf16 && fused_cube_bwd && !cfg.ln_first && pl <= 0.f && w.ax[0].res >= 0 && laxis_bwd_supported(il, hl, ol, ik * id)) {
+    if (bf16 && fused_cube_bwd && !cfg.ln_first && pl <= 0.f && w.ax[0].res >= 0 && laxis_bwd_supported(il, hl, ol, ik * id) &&
+        (il <= 64 || laxis_bwd_long_on)) {   // (il > 64: the LONG instantiation, round 5b; MIMRL_LAXIS_BWD_LONG=0: the GEMM chain below)
       // one launch: LayerNorm(L) backward -> dY -> dU -> dX (+ LayerNorm and bias gradients); weight gradients stay GEMMs
       const AxisW& a = w.ax[0];
       const long C = (long)ik * id;

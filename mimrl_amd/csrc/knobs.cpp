@@ -64,6 +64,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_L0_PACK", "engine_abi.hip", "", "0: no packed layer-0 operands (2 + 4 launches instead of 1 + 2)"},
   {"MIMRL_L0_WG_SIDE", "engine_backward.hip", "1", "side stream of the packed layer-0 W_hh weight gradient"},
   {"MIMRL_L1_WG_SIDE", "engine_backward.hip", "1", "first side stream of the layer-1 weight gradients (4: sides 4-5)"},
+  {"MIMRL_LAXIS_BWD_LONG", "engine_abi.hip", "", "0: the L-axis backward of a long-sequence CubeMLP block (L > 64) as colln_bwd + GEMM chain instead of the LONG instantiation of laxis_bwd_kernel"},
   {"MIMRL_LAXIS_LONG", "engine_abi.hip", "", "0: the L-axis MLP of a long-sequence CubeMLP block (L > 64) as the GEMM chain instead of the one-pass kernel of cube_long.hip"},
   {"MIMRL_LENS_SIDE0", "engine_forward.hip", "", "0: sequence-length scan on side 4 in front of the layer-0 projection instead of side 0"},
   {"MIMRL_LN_BWD_BLOCKS", "model_ops.hip", "128", "workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)"},

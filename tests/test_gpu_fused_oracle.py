@@ -89,6 +89,39 @@ CUBE = [("cfg1_sep", True, (), False), ("cfg2_sep", True, (), False), ("tiny_odd
 
 
 @pytest.mark.parametrize("name", ["cfg3_small", "cfg5_small"])
+def test_long_sequence_laxis_backward_kernel_matches_the_gemm_chain(name, monkeypatch):
+    """Round 5b: the L-axis BACKWARD of block 0 at L = 500 / 1000 is the LONG instantiation of laxis_bwd_kernel (csrc/cube_bwd_fused.hip: phases 1 / 2
+    of the short kernel, then dX = W1^T dU + Wr^T dY walked in tiles of 64 input rows) instead of colln_bwd + two GEMM launches
+    (MLPProcess.py:95-104 under autograd).  Same operands and roundings (bf16) as the chain up to the accumulation order: dx and every parameter
+    gradient within 2e-3 in L2 of MIMRL_LAXIS_BWD_LONG=0, outputs (the forward is untouched) bit-identical."""
+    out = {}
+    for tag, env in (("long", None), ("chain", "0")):
+        if env:
+            monkeypatch.setenv("MIMRL_LAXIS_BWD_LONG", env)
+        else:
+            monkeypatch.delenv("MIMRL_LAXIS_BWD_LONG", raising=False)
+        c, opt, p, eng = make(name, monkeypatch)
+        B, L = c["B"], opt.time_len
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(B, L, 3, 128, generator=g, dtype=torch.float64)
+        x[:, :, 1:] = torch.relu(x[:, :, 1:])
+        ol, ok = opt.d_outs[-1][0], opt.d_outs[-1][1]
+        dout = torch.randn(B, ol, ok, 128, generator=g, dtype=torch.float64)
+        o, dx = eng.probe_cube(x, dout)
+        torch.cuda.synchronize()
+        out[tag] = {"out": o.double().cpu().numpy().copy(), "dx": dx.double().cpu().numpy().copy(),
+                    **{n: v.double().cpu().numpy().copy() for n, v in eng.grads.items() if n.startswith("mlp_encoder.")}}
+        eng.close()
+    assert L > 64 and np.array_equal(out["long"]["out"], out["chain"]["out"])
+    assert not np.array_equal(out["long"]["dx"], out["chain"]["dx"]), "the LONG instantiation did not run"
+    rec = {}
+    for n, want in out["chain"].items():
+        rec[n] = float(np.linalg.norm(out["long"][n] - want) / max(np.linalg.norm(want), 1e-30))
+        assert np.isfinite(out["long"][n]).all() and rec[n] <= 2e-3, (n, rec[n])
+    _record(f"laxis_bwd_long_vs_chain/{name}", dict(sorted(rec.items(), key=lambda kv: -kv[1])[:8]))
+
+
+@pytest.mark.parametrize("name", ["cfg3_small", "cfg5_small"])
 def test_long_sequence_laxis_kernel_matches_the_gemm_chain(name, monkeypatch):
     """Round 5b: the L-axis MLP of CubeMLP block 0 at L = 500 / 1000 (cfg3 / cfg5: too long for the LDS-resident block kernel) is ONE launch that
     reads the [L, 384] slab of every sample once (csrc/cube_long.hip: [W1; Wr] stacked as one MFMA left operand, the second product straight from
