@@ -34,7 +34,7 @@ static_assert(64 * SXP * sizeof(float) <= 2 * CT * KP * sizeof(__bf16), "the fp3
 // rows in tiles of 64 and stages the two transposed weight tiles per step (requested one tile ahead).  One launch instead of colln_bwd + two
 // GEMM launches with dY / dU round trips in between (192 us of the cfg3 chain).
 template <bool LT, bool LONG = false>
-__global__ __launch_bounds__(256) void laxis_bwd_kernel(LAxisBwdArgs a) {
+__global__ __launch_bounds__(256, LONG ? 2 : 1) void laxis_bwd_kernel(LAxisBwdArgs a) {   // (LONG: two workgroups per CU -- 768 workgroups of ~45 us each at cfg3)
   static_assert(!(LT && LONG), "the LayerNorm tail exists for il <= 64 only");
   __shared__ __attribute__((aligned(16))) __bf16 sdyu[2][CT][KP];
   auto& sdy = sdyu[0];

@@ -67,7 +67,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_LAXIS_BWD_LONG", "engine_abi.hip", "", "0: the L-axis backward of a long-sequence CubeMLP block (L > 64) as colln_bwd + GEMM chain instead of the LONG instantiation of laxis_bwd_kernel"},
   {"MIMRL_LAXIS_LONG", "engine_abi.hip", "", "0: the L-axis MLP of a long-sequence CubeMLP block (L > 64) as the GEMM chain instead of the one-pass kernel of cube_long.hip"},
   {"MIMRL_LENS_SIDE0", "engine_forward.hip", "", "0: sequence-length scan on side 4 in front of the layer-0 projection instead of side 0"},
-  {"MIMRL_LN_BWD_BLOCKS", "model_ops.hip", "128", "workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)"},
+  {"MIMRL_LN_BWD_BLOCKS", "model_ops.hip", "0", "workgroups per modality of the LayerNorm + ReLU + dropout backward (default: 128 up to 16384 rows, 512 above)"},
   {"MIMRL_LN_BWD_WAVE_ROWS", "model_ops.hip", "", "the one-row-per-wave kernel of round 2"},
   {"MIMRL_LN_TAIL_SPLIT_FLUSH", "engine_backward.hip", "", "0: with the fused LayerNorm tail, block 0's D-axis parked work is flushed behind the L-axis kernel instead of beside it"},
   {"MIMRL_LN_TAIL_FUSE", "engine_abi.hip", "", "1: the encoders' LayerNorm + ReLU + dropout backward rides on block 0's L-axis backward kernel (opt-in: measured slower at cfg2)"},

@@ -174,50 +174,66 @@ __global__ __launch_bounds__(256) void ln_relu_drop_bwd16_kernel(LnSide s0, LnSi
 #pragma unroll
   for (int i = 0; i < 8; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
   const long stride = (long)gridDim.x * 16;
-  for (long r = (long)blockIdx.x * 16 + rw; r < rows; r += stride) {   // (the 16 lanes of a row slot share r: the group reductions are whole)
-    const float* hr = h2 + r * 2 * D;
-    const long b = r / T, t = r - b * T;
-    const float* dc = dcube + ((b * L + t) * K + slot) * D;
-    const float4 hf0 = *reinterpret_cast<const float4*>(hr + c0), hf1 = *reinterpret_cast<const float4*>(hr + c1);
-    const float4 hb0 = *reinterpret_cast<const float4*>(hr + D + c0), hb1 = *reinterpret_cast<const float4*>(hr + D + c1);
-    const float4 d0 = *reinterpret_cast<const float4*>(dc + c0), d1 = *reinterpret_cast<const float4*>(dc + c1);
-    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
-    if (dmean) { m0 = *reinterpret_cast<const float4*>(dmean + b * D + c0); m1 = *reinterpret_cast<const float4*>(dmean + b * D + c1); }
-    const float mu = mean[r], rs = rstd[r];
-    const float hv[8] = {hf0.x + hb0.x, hf0.y + hb0.y, hf0.z + hb0.z, hf0.w + hb0.w, hf1.x + hb1.x, hf1.y + hb1.y, hf1.z + hb1.z, hf1.w + hb1.w};
-    const float dv[8] = {d0.x + m0.x * invT, d0.y + m0.y * invT, d0.z + m0.z * invT, d0.w + m0.w * invT,
-                         d1.x + m1.x * invT, d1.y + m1.y * invT, d1.z + m1.z * invT, d1.w + m1.w * invT};
-    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+  // round 5b: TWO rows per 16-lane slot and trip, every operand of both requested before the first reduction (one row per slot in flight
+  // was 6 KB per wave: at 4 waves per CU the launch moved 3.2 TB/s at cfg3, 145 us on the chain in front of the layer-1 BPTT).  Loads are
+  // unconditional from clamped rows; rows are still visited in increasing order per slot, so the parameter-gradient sums keep their order.
+  const float invTm = dmean ? invT : 0.f;
+  for (long r0 = (long)blockIdx.x * 16 + rw; r0 < rows; r0 += 2 * stride) {   // (the 16 lanes of a row slot share r: the group reductions are whole)
+    float4 hf0[2], hf1[2], hb0[2], hb1[2], d0[2], d1[2], m0[2], m1[2];
+    float mus[2], rss[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = (i < 4 ? c0 : c1 - 4) + i;
-      xh[i] = (hv[i] - mu) * rs;
-      const float y = xh[i] * gv[i] + bv[i];
-      float dy = dv[i] * drop_scale_at(p, key, rstep, stream, (uint32_t)(r * D + j));
-      dy = y > 0.f ? dy : 0.f;
-      ag[i] += dy * xh[i];
-      ab[i] += dy;
-      dxh[i] = dy * gv[i];
-      s1 += dxh[i];
-      s2 += dxh[i] * xh[i];
+    for (int u = 0; u < 2; ++u) {
+      const long r = min(r0 + u * stride, rows - 1);
+      const float* hr = h2 + r * 2 * D;
+      const long b = r / T, t = r - b * T;
+      const float* dc = dcube + ((b * L + t) * K + slot) * D;
+      const float* dm = dmean ? dmean + b * D : gamma;      // (no gradient of the mean: any readable address, the values are multiplied by 0)
+      hf0[u] = *reinterpret_cast<const float4*>(hr + c0); hf1[u] = *reinterpret_cast<const float4*>(hr + c1);
+      hb0[u] = *reinterpret_cast<const float4*>(hr + D + c0); hb1[u] = *reinterpret_cast<const float4*>(hr + D + c1);
+      d0[u] = *reinterpret_cast<const float4*>(dc + c0); d1[u] = *reinterpret_cast<const float4*>(dc + c1);
+      m0[u] = *reinterpret_cast<const float4*>(dm + c0); m1[u] = *reinterpret_cast<const float4*>(dm + c1);
+      mus[u] = mean[r]; rss[u] = rstd[r];
     }
-    s1 = group_sum<16>(s1) * (1.f / D);
-    s2 = group_sum<16>(s2) * (1.f / D);
-    {
-      float4 o0, o1;
-      o0.x = rs * (dxh[0] - s1 - xh[0] * s2); o0.y = rs * (dxh[1] - s1 - xh[1] * s2); o0.z = rs * (dxh[2] - s1 - xh[2] * s2); o0.w = rs * (dxh[3] - s1 - xh[3] * s2);
-      o1.x = rs * (dxh[4] - s1 - xh[4] * s2); o1.y = rs * (dxh[5] - s1 - xh[5] * s2); o1.z = rs * (dxh[6] - s1 - xh[6] * s2); o1.w = rs * (dxh[7] - s1 - xh[7] * s2);
-      if (sd.ds_bf16) {   // (LnSide::ds_bf16: the layer-1 BPTT reads its dout as bf16 -- same element indices, half the bytes)
-        __bf16* dsb = reinterpret_cast<__bf16*>(ds);
-        bf16x4 q0, q1;
-        q0[0] = to_bf16(o0.x); q0[1] = to_bf16(o0.y); q0[2] = to_bf16(o0.z); q0[3] = to_bf16(o0.w);
-        q1[0] = to_bf16(o1.x); q1[1] = to_bf16(o1.y); q1[2] = to_bf16(o1.z); q1[3] = to_bf16(o1.w);
-        *reinterpret_cast<bf16x4*>(dsb + r * D + c0) = q0;
-        *reinterpret_cast<bf16x4*>(dsb + r * D + c1) = q1;
-      } else {
-        *reinterpret_cast<float4*>(ds + r * D + c0) = o0;
-        *reinterpret_cast<float4*>(ds + r * D + c1) = o1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long r = r0 + u * stride;
+      const bool ok = r < rows;
+      const float mu = mus[u], rs = rss[u];
+      const float hv[8] = {hf0[u].x + hb0[u].x, hf0[u].y + hb0[u].y, hf0[u].z + hb0[u].z, hf0[u].w + hb0[u].w, hf1[u].x + hb1[u].x, hf1[u].y + hb1[u].y, hf1[u].z + hb1[u].z, hf1[u].w + hb1[u].w};
+      const float dv[8] = {d0[u].x + m0[u].x * invTm, d0[u].y + m0[u].y * invTm, d0[u].z + m0[u].z * invTm, d0[u].w + m0[u].w * invTm,
+                           d1[u].x + m1[u].x * invTm, d1[u].y + m1[u].y * invTm, d1[u].z + m1[u].z * invTm, d1[u].w + m1[u].w * invTm};
+      const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = (i < 4 ? c0 : c1 - 4) + i;
+        xh[i] = (hv[i] - mu) * rs;
+        const float y = xh[i] * gv[i] + bv[i];
+        float dy = dv[i] * drop_scale_at(p, key, rstep, stream, (uint32_t)(r * D + j));
+        dy = (ok && y > 0.f) ? dy : 0.f;
+        ag[i] += dy * xh[i];
+        ab[i] += dy;
+        dxh[i] = dy * gv[i];
+        s1 += dxh[i];
+        s2 += dxh[i] * xh[i];
+      }
+      s1 = group_sum<16>(s1) * (1.f / D);
+      s2 = group_sum<16>(s2) * (1.f / D);
+      if (ok) {
+        float4 o0, o1;
+        o0.x = rs * (dxh[0] - s1 - xh[0] * s2); o0.y = rs * (dxh[1] - s1 - xh[1] * s2); o0.z = rs * (dxh[2] - s1 - xh[2] * s2); o0.w = rs * (dxh[3] - s1 - xh[3] * s2);
+        o1.x = rs * (dxh[4] - s1 - xh[4] * s2); o1.y = rs * (dxh[5] - s1 - xh[5] * s2); o1.z = rs * (dxh[6] - s1 - xh[6] * s2); o1.w = rs * (dxh[7] - s1 - xh[7] * s2);
+        if (sd.ds_bf16) {   // (LnSide::ds_bf16: the layer-1 BPTT reads its dout as bf16 -- same element indices, half the bytes)
+          __bf16* dsb = reinterpret_cast<__bf16*>(ds);
+          bf16x4 q0, q1;
+          q0[0] = to_bf16(o0.x); q0[1] = to_bf16(o0.y); q0[2] = to_bf16(o0.z); q0[3] = to_bf16(o0.w);
+          q1[0] = to_bf16(o1.x); q1[1] = to_bf16(o1.y); q1[2] = to_bf16(o1.z); q1[3] = to_bf16(o1.w);
+          *reinterpret_cast<bf16x4*>(dsb + r * D + c0) = q0;
+          *reinterpret_cast<bf16x4*>(dsb + r * D + c1) = q1;
+        } else {
+          *reinterpret_cast<float4*>(ds + r * D + c0) = o0;
+          *reinterpret_cast<float4*>(ds + r * D + c1) = o1;
+        }
       }
     }
   }
@@ -901,11 +917,14 @@ __global__ void l0_pack_kernel(L0Pack a, int pack_inputs, int pack_weights) {
     const long nx4 = nx / 4, nw4 = nw / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nx4 + nw4 + nb + n1; i += (long)gridDim.x * blockDim.x) {
       if (i < nx4) {
-        const long e = i * 4; const long r = e / a.KP; const int c = (int)(e - r * a.KP);
-        const float* src = a.x[m] + r * d + c;
+        const long e = i * 4; const unsigned r32 = (unsigned)e / (unsigned)a.KP; const long r = r32; const int c = (int)((unsigned)e - r32 * (unsigned)a.KP);   // (l0_pack(): rows * KP < 2^31)
+        const float* src = a.x[m] + r * d;
         float v[4];
+        // (unconditional loads from clamped columns, masked afterwards: `c + q < d ? src[q] : 0` is four branches, each with its own vmcnt(0))
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = c + q < d ? src[q] : 0.f;
+        for (int q = 0; q < 4; ++q) v[q] = src[min(c + q, d - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = c + q < d ? v[q] : 0.f;
         f16x4 h; bf16x4 b;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { h[q] = to_f16_sat(v[q]); b[q] = to_bf16(v[q]); }
@@ -1007,6 +1026,7 @@ int l0_pack(hipStream_t s, const L0Pack& a, bool pack_inputs, bool pack_weights)
     return set_error(MIMRL_ERR_ARG, "l0_pack: the 16-bit packed operands come as a set (inputs + weights + the layer-1 images)");
   const long n = (pack_inputs ? a.rows * a.KP : 0) + (pack_weights ? 2L * 384 * a.KP + 2L * 384 : 0) + ((pack_weights && a.w1h) ? 2L * 384 * 256 / 4 : 0);
   if (n <= 0) return MIMRL_OK;
+  if (a.xh && a.rows * a.KP >= (1L << 31)) return set_error(MIMRL_ERR_ARG, "l0_pack: rows * KP must stay below 2^31 (32-bit piece indices)");
   hipLaunchKernelGGL(l0_pack_kernel, dim3(grid_for(n, 256, 1024), 2), dim3(256), 0, s, a, pack_inputs ? 1 : 0, pack_weights ? 1 : 0);
   LAUNCH_CHECK();
   return MIMRL_OK;
@@ -1086,7 +1106,10 @@ int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const f
   if (old_kernel && ds_bf16) return set_error(MIMRL_ERR_ARG, "ln_relu_drop_bwd2: the one-row-per-wave kernel writes fp32 only");
   if (old_kernel) hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   else {
-    static const int cap = knob("MIMRL_LN_BWD_BLOCKS") ? atoi(knob("MIMRL_LN_BWD_BLOCKS")) : 128;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)
+    static const int cap_env = knob("MIMRL_LN_BWD_BLOCKS") ? atoi(knob("MIMRL_LN_BWD_BLOCKS")) : 0;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)
+    // (round 5b, long inputs: 128 workgroups per modality are one wave per SIMD -- 143 us at cfg3's 128 000 rows; 256 -> 139, 512 -> 121,
+    //  1024 -> 129 us: more workgroups hide more latency, and every workgroup ends in 256 same-address float atomics)
+    const int cap = cap_env > 0 ? cap_env : (rows > 16384 ? 512 : 128);
     hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, cap), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   }
   LAUNCH_CHECK();
