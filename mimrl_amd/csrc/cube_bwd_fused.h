@@ -25,7 +25,7 @@ struct LAxisBwdArgs {
                                                // gradients are row sums over (b, c): colln_param_grads, off the critical path
   int B, il, hl, ol, C, act;
   // ln tail (lt_on: C == 3 * 128, lt_T <= il): slot 0 (text) keeps the plain dX store; the dX rows of slots 1 / 2 are NOT written
-  int lt_on = 0, lt_T = 0;
+  int lt_on = 0, lt_T = 0, lt_ds_bf16 = 0;   // lt_ds_bf16 (long kernel only): ds is written as bf16 (GruBwdArgs::dout_bf16)
   LAxisLnSide lt[2];
   RngKey lt_key;
 };

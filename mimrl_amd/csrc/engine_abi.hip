@@ -61,6 +61,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->h16_on = knob("MIMRL_NO_H16") == nullptr;
   h->xin_on = knob("MIMRL_NO_XIN") == nullptr;
   h->fused_cube_bwd = knob("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
+  h->ln_tail_long_on = knob("MIMRL_LN_TAIL_LONG") && atoi(knob("MIMRL_LN_TAIL_LONG")) != 0;
   h->laxis_bwd_long_on = !(knob("MIMRL_LAXIS_BWD_LONG") && atoi(knob("MIMRL_LAXIS_BWD_LONG")) == 0);
   h->laxis_long_on = !(knob("MIMRL_LAXIS_LONG") && atoi(knob("MIMRL_LAXIS_LONG")) == 0);
   h->rec16_on = !(knob("MIMRL_REC16") && atoi(knob("MIMRL_REC16")) == 0);

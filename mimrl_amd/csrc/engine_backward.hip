@@ -222,7 +222,10 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.C = (int)C; fa.act = cfg.activation;
       // block 0 inside the model's backward: the encoders' LayerNorm + ReLU + dropout backward rides on this launch (LAxisLnSide) -- one launch
       // and one queue hop less in front of the layer-1 BPTT (cfg2: ln_relu_drop_bwd16 22 us + 10-20 us of hop).  Opt-in, MIMRL_LN_TAIL_FUSE=1: see mimrl_create.
-      if (i == 0 && ln_tail_want && ln_tail_fuse && ik == 3 && id == 128 && cfg.d_common == 128 && cfg.seq_len <= il) {
+      // (long sequences, il > 64: the LONG instantiation's tail, MIMRL_LN_TAIL_LONG -- cfg3's 256-workgroup BPTT launches do not use the LDS
+      //  padding that made the short kernel's tail lose at cfg2; it writes ds as bf16 when the layer-1 BPTT reads it that way)
+      ln_tail_ds_bf16 = false;
+      if (i == 0 && ln_tail_want && (il <= 64 ? ln_tail_fuse : ln_tail_long_on) && ik == 3 && id == 128 && cfg.d_common == 128 && cfg.seq_len <= il) {
         const size_t BD = (size_t)B * cfg.d_common;
         const float* dmean = dfeat + BD;
         if (head_gather_on && ev_dmean) { HIPX(hipStreamWaitEvent(stream, ev_dmean, 0)); ev_dmean = nullptr; }   // dmean gathered on side 0
@@ -230,6 +233,10 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
           fa.lt[m] = LAxisLnSide{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dmean + (1 + m) * BD, ds[m], Gm(ln_g[m]), Gm(ln_b[m]),
                                  cfg.dropout[1 + m], (uint32_t)(1 + m)};
         fa.lt_on = 1; fa.lt_T = cfg.seq_len; fa.lt_key = key();
+        if (il > 64) {
+          ln_tail_ds_bf16 = rec16_on && cfg.encoder == MIMRL_ENCODER_GRU && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(0);
+          fa.lt_ds_bf16 = ln_tail_ds_bf16 ? 1 : 0;
+        }
         ln_tail_done = true;
         // this block's D-axis parked work goes out NOW, beside this launch: behind it it would start together with the layer-1 BPTT
         static const bool split_flush = knob("MIMRL_LN_TAIL_SPLIT_FLUSH") == nullptr || atoi(knob("MIMRL_LN_TAIL_SPLIT_FLUSH")) != 0;
@@ -465,7 +472,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
                    ln_relu_drop_bwd2_bf16_ok();
     MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key(), dmean + (size_t)B * D, dmean + 2 * (size_t)B * D, ds_bf16_live ? 1 : 0));
   } else {
-    ds_bf16_live = false;   // (the L-axis kernel's tail wrote fp32)
+    ds_bf16_live = ln_tail_ds_bf16;   // (what the L-axis kernel's tail wrote)
   }
   if (!text_bwd_first) MX(text_bwd());
   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT.  Tuning knob MIMRL_BPTT_FIRST=1 captures the BPTT launch in

@@ -70,6 +70,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_LN_BWD_BLOCKS", "model_ops.hip", "0", "workgroups per modality of the LayerNorm + ReLU + dropout backward (default: 128 up to 16384 rows, 512 above)"},
   {"MIMRL_LN_BWD_WAVE_ROWS", "model_ops.hip", "", "the one-row-per-wave kernel of round 2"},
   {"MIMRL_LN_TAIL_SPLIT_FLUSH", "engine_backward.hip", "", "0: with the fused LayerNorm tail, block 0's D-axis parked work is flushed behind the L-axis kernel instead of beside it"},
+  {"MIMRL_LN_TAIL_LONG", "engine_abi.hip", "", "1: the encoders' LayerNorm + ReLU + dropout backward rides on the LONG L-axis backward kernel of block 0 (long sequences)"},
   {"MIMRL_LN_TAIL_FUSE", "engine_abi.hip", "", "1: the encoders' LayerNorm + ReLU + dropout backward rides on block 0's L-axis backward kernel (opt-in: measured slower at cfg2)"},
   {"MIMRL_LSTM_MFMA_FP32", "lstm.hip", "", "1: fp32 precision mode runs the fp32-MFMA LSTM kernels instead of the scalar ones (measured slower)"},
   {"MIMRL_LSTM_SCALAR", "lstm.hip", "", "1: the scalar fp32 LSTM kernels of round 1 instead of the MFMA ones"},

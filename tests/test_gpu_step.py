@@ -905,19 +905,20 @@ def test_critic_update_with_fragment_images_and_stage_boundary_changes_nothing(w
         assert np.isfinite(pa).all() and np.abs(pa - b[1][n]).max() <= 2 * 2 * 4e-3 + 1e-6, n      # (at most two sign-like Adam steps apart)
 
 
-@pytest.mark.parametrize("name", ["cfg1_ragged", "cfg2_sep"])
-def test_ln_backward_riding_on_the_laxis_kernel_changes_nothing(name, monkeypatch):
+@pytest.mark.parametrize("name,knob", [("cfg1_ragged", "MIMRL_LN_TAIL_FUSE"), ("cfg2_sep", "MIMRL_LN_TAIL_FUSE"), ("cfg3_small", "MIMRL_LN_TAIL_LONG")])
+def test_ln_backward_riding_on_the_laxis_kernel_changes_nothing(name, knob, monkeypatch):
     """Round 5b (opt-in, MIMRL_LN_TAIL_FUSE=1): in bf16 mode the encoders' LayerNorm + ReLU + dropout backward (Model.py:452-461 under autograd) can ride as the tail of CubeMLP block 0's
     L-axis backward kernel (cube_bwd_fused.hip: laxis_bwd_kernel<true>, LAxisLnSide): the (sample, slot) dX tile goes through it from LDS with the
     lane mapping and arithmetic of ln_relu_drop_bwd16_kernel, so ds -- the layer-1 BPTT's input -- is the same bit pattern and every gradient of the
     main model equals the default two-launch run up to the order of the float atomics (ln_a / ln_v sums, split-K weight gradients)."""
-    monkeypatch.setenv("MIMRL_REC16", "0")    # (the tail writes fp32 ds; the default two-launch path stores it as bf16 for the layer-1 BPTT -- another rounding point)
+    if knob == "MIMRL_LN_TAIL_FUSE":          # (the short kernel's tail writes fp32 ds; the default two-launch path stores it as bf16 for the layer-1 BPTT --
+        monkeypatch.setenv("MIMRL_REC16", "0")  #  another rounding point; the LONG instantiation's tail (L > 64) writes bf16 like the two-launch path)
     res = {}
     for tag, env in (("two", None), ("fused", "1")):
         if env:
-            monkeypatch.setenv("MIMRL_LN_TAIL_FUSE", env)
+            monkeypatch.setenv(knob, env)
         else:
-            monkeypatch.delenv("MIMRL_LN_TAIL_FUSE", raising=False)
+            monkeypatch.delenv(knob, raising=False)
         c, opt, batch, banks, p, eng = make_engine(name, precision="bf16")
         g = load_golden(name)
         eng.set_banks(*(banks[k] for k in "CFTAV"))
