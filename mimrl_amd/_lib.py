@@ -70,6 +70,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise MimrlError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          f"or `make -C mimrl_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch first: it ships its own libamdhip64, and whichever HIP runtime is loaded FIRST is the one libmimrl_hip.so binds to.  Loaded before
+    # torch, the library bound to /opt/rocm's runtime while torch used its bundled one -- two runtimes in one process, and mimrl_create failed with
+    # "no HIP device visible" (found by running __graft_entry__.build() and smoke() in one process).  The engine holds its tensors in torch anyway.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     if os.environ.get("MIMRL_LIB_PATH"):
         class _Partial:                      # attribute access on a missing symbol yields a throw-away object for the argtypes below
