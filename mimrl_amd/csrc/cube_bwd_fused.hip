@@ -219,11 +219,13 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
     // tiles of 64 output rows i: W1^T [i][h] and Wr^T [i][o] of the tile go through wts[1] / wts[2]; thread = (i = tid & 63, rows h / o =
     // (tid >> 6) + 4 j): a wave reads 64 consecutive i of one weight row (256 B).  The next tile's 32 values are requested before this tile's products.
     float w1v[16], wrv[16];
+    // (thread = (i = tid & 63, 16 CONSECUTIVE rows h / o = 16 (tid >> 6) + j): its 16 values of a tile are 32 contiguous bytes of the transposed
+    //  image -- two 16-byte LDS stores per matrix instead of 32 two-byte ones with 8-way bank conflicts, 2-3 us per tile and workgroup)
     auto wreq = [&](int i0) __attribute__((always_inline)) {
       const int i = min(i0 + (tid & 63), il - 1);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int r = (tid >> 6) + 4 * j;
+        const int r = 16 * (tid >> 6) + j;
         w1v[j] = a.w1[(long)min(r, hl - 1) * il + i];
         wrv[j] = a.wr[(long)min(r, ol - 1) * il + i];
       }
@@ -232,14 +234,16 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
     for (int i0 = 0; i0 < il; i0 += 64) {
       __syncthreads();                      // the previous tile's fragment reads of wts[1] / wts[2] (first trip: phase 2's of sdy / wts[0]) are done
       {
-        const int ii = tid & 63;
+        const int ii = tid & 63, r0 = 16 * (tid >> 6);
         const bool iok = i0 + ii < il;
+        bf16x8 p1[2], p2[2];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const int r = (tid >> 6) + 4 * j;
-          wts[1][ii][r] = to_bf16(iok && r < hl ? w1v[j] : 0.f);
-          wts[2][ii][r] = to_bf16(iok && r < ol ? wrv[j] : 0.f);
+          p1[j >> 3][j & 7] = to_bf16(iok && r0 + j < hl ? w1v[j] : 0.f);
+          p2[j >> 3][j & 7] = to_bf16(iok && r0 + j < ol ? wrv[j] : 0.f);
         }
+        *reinterpret_cast<bf16x8*>(&wts[1][ii][r0]) = p1[0]; *reinterpret_cast<bf16x8*>(&wts[1][ii][r0 + 8]) = p1[1];
+        *reinterpret_cast<bf16x8*>(&wts[2][ii][r0]) = p2[0]; *reinterpret_cast<bf16x8*>(&wts[2][ii][r0 + 8]) = p2[1];
       }
       __syncthreads();
       wreq(i0 + 64 < il ? i0 + 64 : i0);    // unconditional (past the end: this tile again, never stored)
