@@ -18,10 +18,11 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
   // 16-bit operands for the layer-1 projection (see h0h): bf16 recurrence + fp16 forward operands + the packed layer-0 launch that also
   // writes the weight images; a site forced to fp32 (MIMRL_FWD_FP32_SITES) or fp16-stored gx keeps the fp32-operand kernel
   const bool use_h16 = h16_on && l0_packed && bf16 && fwd_f16 && (prec & MIMRL_PREC_BF16_GRU_FWD) && !fp32_site(4) && !fp32_site(2) && h0h[0] && w1h;
-  h16_live = use_h16;   // (the backward's dW_ih product of layer 1 reads the same copy: gru_layer_backward)
   // round 5b: with the fp16 copy feeding the layer-1 projection, dW_ih of layer 1 AND the layer-0 BPTT (h_prev), nobody reads the fp32 layer-0
-  // outputs of a training pass any more -- the fused-projection forward then does not write them (262 MB per pass at cfg3)
-  hp16_live = false;    // (set below, once the layer-0 kernel is chosen: the layer-0 BPTT reads h_prev from the fp16 copy)
+  // outputs of a training pass any more -- the fused-projection forward then does not write them (262 MB per pass at cfg3).  The two flags
+  // describe the pass whose activations the backward will read, i.e. they are recorded by SAVING passes only: in the non-shared prefetch mode
+  // (MIMRL_NO_SHARED_PREFIX) stage 1's own, non-saving forward pass is captured behind the saving stage-2 pass and must not overwrite them.
+  if (save) { h16_live = use_h16; hp16_live = false; }   // (hp16_live: set below, once the layer-0 kernel is chosen)
   // bi-GRU, 2 layers (Model.py:441-447); the four (modality,direction) input projections run on four streams
   for (int l = 0; l < 2; ++l) {
     GruFwdArgs a;
@@ -73,10 +74,11 @@ int mimrl_handle::encoders_forward(bool save, int knn_stage) {
       // Fused input projection (round 4): with the operands packed as fp16 the layer-0 recurrence kernel computes x W_ih^T + b_ih itself,
       // three k-steps per gate and cell step on a matrix pipe that is busy a quarter of the step: no GEMM launch, no gx round trip.
       l0_xin = l0_16 && xin_on && KP() <= 96 && !gx_f16;
-      hp16_live = use_h16 && rec16_on && save && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(l0_xin ? 2 : 0);
+      const bool hp16_now = use_h16 && rec16_on && save && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(l0_xin ? 2 : 0);
+      if (save) hp16_live = hp16_now;
       if (l0_xin) {
         a.xin_on = 1; a.kp = KP();
-        a.no_out32 = hp16_live && dwih_h16_on ? 1 : 0;   // every consumer of this pass's layer-0 outputs reads the fp16 copy
+        a.no_out32 = hp16_now && dwih_h16_on ? 1 : 0;   // every consumer of this pass's layer-0 outputs reads the fp16 copy
         for (int m = 0; m < 2; ++m) {
           a.xin[m] = pk.xh + (long)m * BT_ * KP();
           for (int d = 0; d < 2; ++d) { a.wih[m][d] = pk.wh + ((long)m * 2 + d) * G * KP(); a.bih[m][d] = bpack + ((long)m * 2 + d) * G; }

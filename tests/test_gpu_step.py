@@ -253,6 +253,24 @@ def test_fused_cube_forward_matches_unfused(name, monkeypatch):
 @pytest.mark.parametrize("precision,use_graph,split", [("fp32", False, False), ("fp32", True, False), ("bf16", True, False),
                                                        ("fp32", True, True)])
 def test_stage2_prefetch_matches_sequential(precision, use_graph, split):
+    _prefetch_matches_sequential(precision, use_graph, split)
+
+
+def test_prefetch_without_the_shared_prefix_matches_sequential():
+    """MIMRL_NO_SHARED_PREFIX=1 (a tuning knob: both forward passes evaluate the encoders): stage 1's own, NON-saving forward pass is captured
+    behind the saving stage-2 pass, so per-pass facts the backward relies on -- which 16-bit copies the saving pass wrote, whether it wrote its
+    fp32 layer-0 outputs at all (round 5b: MIMRL_REC16) -- must be those of the SAVING pass.  The knob is read once per process: the overlap
+    parity cases run again in a child process with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MIMRL_NO_SHARED_PREFIX="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_stage2_prefetch_matches_sequential and bf16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
+
+
+def _prefetch_matches_sequential(precision, use_graph, split):
     """Solver.step() overlap mode (mimrl_set_stage2_prefetch): the stage-2 forward pass runs beside stage 1.
     Same parameters, inputs and dropout keys => same losses / predictions / parameters as the sequential order
     (dropout is ON here so that a wrong mask key between forward and backward would show)."""
