@@ -101,6 +101,22 @@ struct DetNoFlush {                          // host scope: "the launches in her
   ~DetNoFlush();
   bool on_, prev_;
 };
+// Round 5b: launches that accumulate ONLY into gradient buckets (weight / bias / LayerNorm gradients: nobody reads them before the pass that
+// produced them is over) need no flush of their own.  Inside a DetDefer scope (mimrl_handle::model_backward / estimators_all) such launches --
+// known by kernel name, or a GEMM whose output lies in a registered bucket range -- skip it; the scope's end flushes once.  Every other launch
+// flushes as before (and takes the pending sums along: the flush walks the whole dirty list).
+void det_set_bucket_ranges(const void* const* lo, const size_t* bytes, int n);   // (<= 6 ranges; the handle registers its buckets at bind)
+bool det_target_in_bucket(const void* p);
+struct DetGemmTarget {                        // gemm(): "the launch below accumulates into this output" (deferred inside a DetDefer scope if it is a bucket)
+  explicit DetGemmTarget(const void* c);
+  ~DetGemmTarget();
+  bool prev_;
+};
+struct DetDefer {
+  explicit DetDefer(hipStream_t s);
+  ~DetDefer();
+  hipStream_t s_; bool prev_;
+};
 int det_overflowed();                        // bit 0: the table ran full; bit 1: a non-finite / out-of-range contribution (both: that
                                              // contribution went through a plain float atomic)
 namespace {
@@ -112,6 +128,10 @@ static DetTuReg det_tu_reg_;
 
 #else   // ---------------------------------------------------------------- default build: plain float atomics
 struct DetNoFlush { explicit DetNoFlush(bool) {} };
+struct DetDefer { explicit DetDefer(hipStream_t) {} };
+struct DetGemmTarget { explicit DetGemmTarget(const void*) {} };
+inline void det_set_bucket_ranges(const void* const*, const size_t*, int) {}
+inline bool det_target_in_bucket(const void*) { return false; }
 
 __device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }
 struct LdsAcc {

@@ -67,12 +67,44 @@ int det_flush(hipStream_t s) {
 
 namespace {
 thread_local bool t_no_flush = false;
+thread_local bool t_defer = false, t_pending = false, t_gemm_in_bucket = false;
+struct Range { const char* lo; size_t bytes; };
+Range g_ranges[6];
+int g_nranges = 0;
+}
+void det_set_bucket_ranges(const void* const* lo, const size_t* bytes, int n) {
+  g_nranges = n < 6 ? n : 6;
+  for (int i = 0; i < g_nranges; ++i) g_ranges[i] = Range{static_cast<const char*>(lo[i]), bytes[i]};
+}
+bool det_target_in_bucket(const void* p) {
+  const char* c = static_cast<const char*>(p);
+  for (int i = 0; i < g_nranges; ++i)
+    if (g_ranges[i].lo && c >= g_ranges[i].lo && c < g_ranges[i].lo + g_ranges[i].bytes) return true;
+  return false;
+}
+DetGemmTarget::DetGemmTarget(const void* c) : prev_(t_gemm_in_bucket) { t_gemm_in_bucket = det_target_in_bucket(c); }
+DetGemmTarget::~DetGemmTarget() { t_gemm_in_bucket = prev_; }
+DetDefer::DetDefer(hipStream_t s) : s_(s), prev_(t_defer) { t_defer = true; }
+DetDefer::~DetDefer() {
+  t_defer = prev_;
+  if (!t_defer && t_pending) { t_pending = false; (void)det_flush(s_); }
 }
 DetNoFlush::DetNoFlush(bool on) : on_(on), prev_(t_no_flush) { if (on_) t_no_flush = true; }
 DetNoFlush::~DetNoFlush() { if (on_) t_no_flush = prev_; }
 
 bool det_launch_accumulates(const char* name) {
   if (t_no_flush) return false;
+  if (t_defer) {
+    // kernels whose every acc_add target is a gradient-bucket tensor (checked against the sources, round 5b): LayerNorm / bias / weight
+    // gradients of the model backward and the estimator stacks, the BPTT's bias gradients, column / row sums into the buckets
+    static const char* const kBucketOnly[] = {"ln_relu_drop_bwd", "head_bwd_kernel", "colln_bwd_kernel", "rowln_bwd_kernel", "kmix_bwd_kernel",
+                                              "colsum_kernel", "rowsum_batched", "colln_param_grads", "daxis_param_grads", "rowln_param_grads",
+                                              "laxis_bwd_kernel", "daxis_bwd_kernel", "gru_bwd_kernel", "top1_bwd_kernel", "concat_dw3_kernel",
+                                              "mlp_frag_kernel", "gemm_group_kernel", "gemm_groupk_kernel"};
+    for (const char* k : kBucketOnly)
+      if (std::strstr(name, k)) { t_pending = true; return false; }
+    if (t_gemm_in_bucket && std::strstr(name, "gemm_")) { t_pending = true; return false; }
+  }
   // kernels that never call acc_add (tests/test_layout.py::test_det_flush_rule_matches_the_sources checks this list against the sources)
   static const char* const kSafe[] = {"_fwd", "adam_kernel", "images_kernel", "bf16_image", "knn_", "sample_anchors", "seq_lengths", "l0_pack", "l0_unpack",
                                       "text_post", "feat_mean", "tail_pre", "begin_stage", "mae_kernel", "finalize_stage", "stage_boundary",

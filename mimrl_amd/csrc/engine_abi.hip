@@ -118,6 +118,12 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
     if (!p) return set_error(MIMRL_ERR_ARG, "mimrl_bind: a required buffer is null");
   h->bufs = *b;
   h->bound = true;
+  {   // deterministic build (det.h: DetDefer): the tensors whose accumulated sums nobody reads before the end of a gradient pass -- the two
+      // gradient buckets (NOT the packed layer-0 scratch: l0_unpack_grads reads it inside the pass)
+    const void* lo[2] = {b->main_g, b->crit_g};
+    const size_t by[2] = {sizeof(float) * (size_t)h->layout.floats[MIMRL_GROUP_MAIN], sizeof(float) * (size_t)h->layout.floats[MIMRL_GROUP_CRITIC]};
+    det_set_bucket_ranges(lo, by, 2);
+  }
   h->part0_done = false;
   h->cur_set = 0;
   for (int q = 0; q < 2; ++q) for (int i = 0; i < 4; ++i) h->gsets[q].in[i] = nullptr;

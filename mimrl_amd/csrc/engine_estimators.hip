@@ -490,6 +490,7 @@ int mimrl_handle::route_feature_grads() {
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   Range rg(stage == 1 ? "mimrl.estimators.stage1 (Model.py:305-341)" : "mimrl.estimators.stage2 (Model.py:343-386)");
+  DetDefer det_defer(stream);   // (deterministic build, det.h: the stacks' weight / bias gradients are flushed once, at the end of the stage's estimator work)
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0 && !fp32_site(8), bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
   static const bool imgt_first = knob("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob

@@ -1009,6 +1009,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
     return set_error(MIMRL_ERR_ARG, "gemm: an fp16-stored output takes the plain store only (no atomic / split-K / beta / pre / column sums)");
   // (deterministic build: only a product that accumulates -- atomics, split-K, fused column sums -- needs the table flushed behind it)
   DetNoFlush det_nf(!(d.atomic || pl.nsplit > 1 || d.colsum));
+  DetGemmTarget det_gt(d.colsum ? nullptr : d.C);   // (a weight gradient into a bucket: flushed at the end of the pass, det.h DetDefer)
   KernelArgs ka;
   ka.d = d;
   ka.vec_a = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0;
