@@ -206,7 +206,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   const bool have_frag = stage == 1 && img_valid && crit_frag && ftab.n > 0;
   bool fwd_in_adam = false;
   if (stage == 1 && fuse_boundary && adam_frag_on && a.n % 8 == 0) {
-    if (have_frag) {
+    if (have_frag && a.n < (1L << 24)) {   // (the kernel's image index arithmetic is exact for buckets below 2^24 elements; larger: the frag_images launch)
       for (int e = 0; e < ftab.n && a.frag.n < 12; ++e)
         if (!ftab.tr[e] && ftab.dshift[e] == 0) {
           const int q = a.frag.n++;
