@@ -24,6 +24,36 @@ from .Model import Model
 from .Utils import log_message, set_logger
 
 
+class _Plateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau with its defaults (threshold 1e-4 'rel', cooldown 0, min_lr 0, eps 1e-8), as the
+    reference builds it for `--lr_decrease plateau` (Solver.py:163-166: mode 'min' for regression else 'max', patience
+    `--lr_decrease_iter`, factor `--lr_decrease_rate`), one instance per optimizer group; stepped with the epoch's validation loss
+    (Solver.py:50-52).  The rates live in the engine's fused Adam, so the schedule is host arithmetic on two floats."""
+
+    def __init__(self, lr, mode, patience, factor, threshold=1e-4, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        self.lr, self.mode, self.patience, self.factor, self.threshold, self.eps = float(lr), mode, int(patience), float(factor), threshold, eps
+        self.best = float("inf") if mode == "min" else -float("inf")
+        self.num_bad_epochs = 0
+
+    def is_better(self, a):
+        return a < self.best * (1.0 - self.threshold) if self.mode == "min" else a > self.best * (self.threshold + 1.0)
+
+    def step(self, metric):
+        current = float(metric)
+        if self.is_better(current):
+            self.best, self.num_bad_epochs = current, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            new_lr = max(self.lr * self.factor, 0.0)
+            if self.lr - new_lr > self.eps:
+                self.lr = new_lr
+            self.num_bad_epochs = 0
+        return self.lr
+
+
 def _loader_samples(loader, batch_size):
     if hasattr(loader, "num_samples"):
         return int(loader.num_samples())
@@ -63,6 +93,11 @@ class Solver:
             mdist.attach_comm(self.engine, self.world, self.rank)
         self.base_lr = float(opt.learning_rate)
         self.epoch = 0
+        self._plateau = None
+        if opt.lr_decrease == "plateau":                                                   # Solver.py:163-166
+            mode = "min" if getattr(opt, "task", "regression") == "regression" else "max"
+            self._plateau = [_Plateau(lr, mode, int(opt.lr_decrease_iter), float(opt.lr_decrease_rate))
+                             for lr in (self.base_lr, self.base_lr * float(opt.mi_lr_rate))]
         self.task_path = os.path.join("./TaskRuning", str(opt.task_name))                  # Solver.py:107-112
         self.best_valid_model_path = os.path.join(self.task_path, "best_valid_model.pth.tar")
         self.best_test_model_path = os.path.join(self.task_path, "best_test_model.pth.tar")
@@ -77,11 +112,23 @@ class Solver:
             return o.lr_decrease_rate ** sum(epoch >= m for m in ms)
         if o.lr_decrease == "exp":
             return o.lr_decrease_rate ** epoch
+        if o.lr_decrease == "plateau":
+            return self._plateau[0].lr / self.base_lr
         raise NotImplementedError(f"--lr_decrease {o.lr_decrease}")
 
     def _apply_lr(self, epoch: int):
+        if self._plateau is not None:            # metric-driven: the rates move in lr_schedule_step, not with the epoch number
+            self.engine.set_lr(self._plateau[0].lr, self._plateau[1].lr)
+            return
         f = self.lr_factor(epoch)
         self.engine.set_lr(self.base_lr * f, self.base_lr * float(self.opt.mi_lr_rate) * f)
+
+    def lr_schedule_step(self, val_loss=None):
+        """End-of-epoch scheduler step (Solver.py:49-55).  step / multi_step / exp are closed forms of the epoch number (`lr_factor`);
+        'plateau' feeds the validation loss to both groups' ReduceLROnPlateau."""
+        if self._plateau is not None:
+            for s in self._plateau:
+                s.step(val_loss)
 
     # ------------------------------------------------------------------ engines
     def get_label_from_datas(self, datas):
@@ -347,6 +394,7 @@ class Solver:
             banks = r[4:]
             val_loss, val_mis, val_score, val_pred, val_targ, val_feat = self.evaluate(self.valid_loader, *banks)
             test_loss, test_mis, test_score, test_pred, test_targ, test_feat = self.evaluate(self.test_loader, *banks)
+            self.lr_schedule_step(val_loss)                                    # Solver.py:49-55
             if self.current_result_better(best_score[0], val_score):
                 if self.rank == 0:
                     best_valid_state = self.checkpoint(epoch)

@@ -47,6 +47,37 @@ def test_lr_schedules():
     assert [s.lr_factor(e) for e in range(3)] == [1, 0.5, 0.25]                              # ExponentialLR
 
 
+@pytest.mark.parametrize("mode,task", [("min", "regression"), ("max", "classification")])
+def test_lr_plateau_matches_torch_scheduler(mode, task):
+    """--lr_decrease plateau (reference Solver.py:163-166 builds ReduceLROnPlateau(mode, patience=lr_decrease_iter, factor=lr_decrease_rate)
+    for BOTH optimizers and steps them with val_loss, :50-52): the host-side schedule equals torch's scheduler on synthetic loss series,
+    for the main and the critic rate (mi_lr_rate scaled), including the eps rule once the rates are tiny."""
+    from mimrl_amd.Solver import Solver, _Plateau
+    rng = np.random.default_rng(3)
+    series = [np.concatenate([np.linspace(2.0, 1.0, 6), 1.0 + 0.3 * rng.random(40)]),         # improves, then a noisy plateau
+              1.0 + 1e-5 * np.arange(60),                                                       # inside the relative threshold
+              rng.random(120) * 3.0, np.full(80, 0.7)]
+    for ser, patience, factor, lr0, rate in ((series[0], 2, 0.5, 4e-3, 1.0), (series[1], 0, 0.1, 1e-3, 0.5), (series[2], 3, 0.3, 4e-3, 2.0),
+                                            (series[3], 1, 0.01, 1e-3, 1.0)):
+        if mode == "max":
+            ser = -ser + 4.0
+        ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+        opts = [torch.optim.Adam([ps[0]], lr=lr0), torch.optim.Adam([ps[1]], lr=lr0 * rate)]
+        refs = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, mode=mode, patience=patience, factor=factor) for o in opts]
+        s = Solver.__new__(Solver)
+        s.opt = Parameters.parse_args(["--lr_decrease", "plateau", "--lr_decrease_iter", str(patience), "--lr_decrease_rate", str(factor),
+                                       "--task", task, "--learning_rate", str(lr0), "--mi_lr_rate", str(rate)])
+        s.base_lr = lr0
+        s._plateau = [_Plateau(lr0, mode, patience, factor), _Plateau(lr0 * rate, mode, patience, factor)]
+        for v in ser:
+            for r in refs:
+                r.step(float(v))
+            s.lr_schedule_step(float(v))
+            assert s._plateau[0].lr == opts[0].param_groups[0]["lr"] and s._plateau[1].lr == opts[1].param_groups[0]["lr"]
+            assert s.lr_factor(0) == pytest.approx(opts[0].param_groups[0]["lr"] / lr0)
+        assert s._plateau[0].lr < lr0 or patience >= len(ser)          # (every series does reduce)
+
+
 def test_ddp_two_ranks_gloo():
     """world_size 2 on CPU (gloo): grads -> all-reduce(mean) -> clip+Adam equals single-process Adam on the mean."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
