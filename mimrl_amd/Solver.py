@@ -324,16 +324,22 @@ class Solver:
         """Solver.py:57-62 ('epoch', 'model', 'optim_main', 'optim_vmi') + what a RESUMED run needs and the reference does not save:
         the five feature banks of the epoch (Solver.py:223-227 rebuilds them only by training: resuming with empty banks would apply
         the epoch-0 rule for a whole epoch), the device RNG step and numpy's global RNG state (host-drawn anchors,
-        Model.py:81).  Optimizer format: 'm' / 'v' are the flat moment buckets in the layout of `mimrl_layout_entry` (NOT a
-        torch.optim.Adam state_dict: parameters are not separate tensors here), 'step' is Adam's state['step'], 'lr' the current rate."""
+        Model.py:81).  Optimizer format: 'm' / 'v' are dicts {reference parameter name: exp_avg / exp_avg_sq of that parameter's shape}
+        (NOT a torch.optim.Adam state_dict: parameters are not separate tensors here), 'step' is Adam's state['step'], 'lr' the current
+        rate; 'layout' is the fingerprint of the writer's flat-bucket layout (`HipEngine.layout_fingerprint`)."""
         st = self.engine.optimizer_state()
-        cpu = lambda d: {k: v.detach().cpu() for k, v in d.items()}
+        nm = self.engine.named_moments()
+        cpu = lambda d: {k: ({n: t.detach().cpu() for n, t in v.items()} if isinstance(v, dict) else v.detach().cpu()) for k, v in d.items()}
         n = int(self.engine.bank_rows)
-        ck = {"epoch": epoch, "model": cpu(self.model.state_dict()),
-              "optim_main": cpu({"m": st["main_m"], "v": st["main_v"], "step": st["counters"][1:2], "lr": st["lr_main"]}),
-              "optim_vmi": cpu({"m": st["crit_m"], "v": st["crit_v"], "step": st["counters"][2:3], "lr": st["lr_critic"]}),
+        # 'm' / 'v' per parameter NAME (round 6, ADVICE r05: the flat buckets were stored raw and round 5 permuted the main bucket -- an
+        # older checkpoint would have loaded without error onto the wrong parameters); 'layout' tags the bucket layout of the writer
+        ck = {"epoch": epoch, "model": cpu(self.model.state_dict()), "layout": self.engine.layout_fingerprint(),
+              "optim_main": cpu({"m": nm["main"]["m"], "v": nm["main"]["v"], "step": st["counters"][1:2], "lr": st["lr_main"]}),
+              "optim_vmi": cpu({"m": nm["critic"]["m"], "v": nm["critic"]["v"], "step": st["counters"][2:3], "lr": st["lr_critic"]}),
               "rng_step": st["counters"][0:1].cpu(),
               "banks": {k: self.engine.bank[k][:n].detach().cpu().clone() for k in "CFTAV"} if n else None}
+        if self._plateau is not None:
+            ck["lr_plateau"] = [(s.lr, s.best, s.num_bad_epochs) for s in self._plateau]
         rs = np.random.get_state()
         ck["np_rng"] = (rs[0], torch.from_numpy(rs[1].astype(np.int64)), int(rs[2]), int(rs[3]), float(rs[4]))
         return ck
@@ -347,9 +353,21 @@ class Solver:
         self.model.load_state_dict(ck["model"])
         cnt = torch.cat([ck["rng_step"].reshape(1), ck["optim_main"]["step"].reshape(1), ck["optim_vmi"]["step"].reshape(1),
                          torch.zeros(1, dtype=torch.int32)]).to(torch.int32)
-        self.engine.load_optimizer_state({"main_m": ck["optim_main"]["m"], "main_v": ck["optim_main"]["v"],
-                                          "crit_m": ck["optim_vmi"]["m"], "crit_v": ck["optim_vmi"]["v"], "counters": cnt,
-                                          "lr_main": ck["optim_main"]["lr"], "lr_critic": ck["optim_vmi"]["lr"]})
+        flat = {"counters": cnt, "lr_main": ck["optim_main"]["lr"], "lr_critic": ck["optim_vmi"]["lr"]}
+        for grp, key, pre in (("main", "optim_main", "main"), ("critic", "optim_vmi", "crit")):
+            m, v = ck[key]["m"], ck[key]["v"]
+            if isinstance(m, dict):                     # per parameter name: layout-independent
+                self.engine.load_named_moments(grp, m, v)
+            elif ck.get("layout") == self.engine.layout_fingerprint():
+                flat[pre + "_m"], flat[pre + "_v"] = m, v
+            else:                                       # a raw flat bucket is only valid in the layout that wrote it
+                raise _lib.MimrlError(f"checkpoint stores {key} as a flat bucket written under layout {ck.get('layout')!r}; this build's "
+                                      f"layout is {self.engine.layout_fingerprint()!r} (the main bucket was re-ordered in round 5): "
+                                      "refusing to assign Adam moments to the wrong parameters")
+        self.engine.load_optimizer_state(flat)
+        if self._plateau is not None and ck.get("lr_plateau") is not None:
+            for s, (lr, best, bad) in zip(self._plateau, ck["lr_plateau"]):
+                s.lr, s.best, s.num_bad_epochs = float(lr), float(best), int(bad)
         self.resume_banks = ([], [], [], [], [])
         b = ck.get("banks")
         if b is not None:

@@ -76,24 +76,54 @@ def broadcast_(flat: torch.Tensor, src: int = 0):
     return flat
 
 
+def torch_transport_forced() -> bool:
+    """MIMRL_DDP_TORCH=1 (any value but '' / '0'): keep the torch.distributed transport even where the in-library one is available."""
+    return os.environ.get("MIMRL_DDP_TORCH", "0") not in ("", "0")
+
+
 def attach_comm(engine, world: int, rank: int) -> bool:
     """Create the engine's own RCCL communicator (collective).  Rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes.
-    Returns False (and leaves the torch.distributed transport in charge) when MIMRL_DDP_TORCH=1, on CPU, or when the process group is
-    not RCCL.  world == 1: a one-rank communicator without any process group (MIMRL_DDP_FORCE_COLLECTIVES=1: the one-GPU tests / bench)."""
-    if os.environ.get("MIMRL_DDP_TORCH") is not None or not torch.cuda.is_available() or not hasattr(engine, "set_comm"):
+    Returns False (and leaves the torch.distributed transport in charge) when MIMRL_DDP_TORCH=1, on CPU, when the process group is
+    not RCCL, or when ANY rank failed to create its communicator: every rank reports success / failure through a MIN all-reduce and all of
+    them take the same transport (a rank that raised alone would leave the others inside ncclCommInitRank or, later, in a collective
+    its peers never issue -- ADVICE r05).  world == 1: a one-rank communicator without any process group (MIMRL_DDP_FORCE_COLLECTIVES=1:
+    the one-GPU tests / bench); there a failure raises, nobody else is waiting.
+    ``engine.ddp_transport_reason`` says why the answer was False."""
+    engine.ddp_transport_reason = None
+    if torch_transport_forced() or not torch.cuda.is_available() or not hasattr(engine, "set_comm"):
+        engine.ddp_transport_reason = "MIMRL_DDP_TORCH set" if torch_transport_forced() else "no GPU / engine without set_comm"
         return False
     if world > 1:
         if not dist.is_initialized() or dist.get_backend() != "nccl":
+            engine.ddp_transport_reason = "process group is not RCCL"
             return False
+        err = None
         payload = torch.zeros(128, dtype=torch.uint8, device=engine.device)
-        if rank == 0:
-            payload.copy_(torch.frombuffer(bytearray(type(engine).comm_unique_id()), dtype=torch.uint8))
+        try:
+            if rank == 0:
+                payload.copy_(torch.frombuffer(bytearray(type(engine).comm_unique_id()), dtype=torch.uint8))
+        except Exception as e:      # noqa: BLE001 -- librccl missing on rank 0: the others learn it from the all-zero id + the MIN reduce below
+            err = e
         dist.broadcast(payload, src=0)
         uid = bytes(payload.cpu().numpy().tobytes())
+        if err is None and any(uid):
+            try:
+                engine.set_comm(uid, world, rank)
+            except Exception as e:  # noqa: BLE001
+                err = e
+        elif err is None:
+            err = RuntimeError("rank 0 could not draw an RCCL unique id")
+        flag = torch.tensor([0 if err is not None else 1], device=engine.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if err is None:         # this rank has a communicator its peers do not: drop it
+                engine.set_comm(None, 1, 0)
+            engine.ddp_transport_reason = f"in-library communicator failed on {'this' if err is not None else 'another'} rank: {err!r}"[:300]
+            flush_c_stdio()
+            return False
     else:
-        uid = type(engine).comm_unique_id()
-    engine.set_comm(uid, world, rank)
-    if os.environ.get("MIMRL_DDP_BF16_CRITIC") is not None:      # opt-in: the 13.4 MB critic bucket crosses the links as bf16
+        engine.set_comm(type(engine).comm_unique_id(), world, rank)
+    if os.environ.get("MIMRL_DDP_BF16_CRITIC", "0") not in ("", "0"):      # opt-in: the 13.4 MB critic bucket crosses the links as bf16
         engine.set_comm_critic_bf16(True)
     engine._ddp_world = world
     flush_c_stdio()

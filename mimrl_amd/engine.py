@@ -168,15 +168,49 @@ class HipEngine:
         check(self.lib.mimrl_set_bank_rows(self.handle, int(n)))
 
     def optimizer_state(self) -> Dict[str, torch.Tensor]:
-        """Both Adam optimizers (Solver.py:57-62 'optim_main' / 'optim_vmi'): moments as flat buckets + the step counters."""
+        """Both Adam optimizers (Solver.py:57-62 'optim_main' / 'optim_vmi'): moments as flat buckets + the step counters.  The flat
+        buckets are only meaningful together with ``layout_fingerprint()`` (offsets moved in round 5: the layer-0 recurrence tensors went to
+        the tail of the main bucket); ``named_moments()`` is the layout-independent form checkpoints store."""
         return {"main_m": self.main["m"].clone(), "main_v": self.main["v"].clone(), "crit_m": self.crit["m"].clone(),
                 "crit_v": self.crit["v"].clone(), "counters": self.counters.clone(), "lr_main": self.lr_main.clone(),
                 "lr_critic": self.lr_critic.clone()}
 
+    def layout_fingerprint(self) -> str:
+        """Hash of the ABI version and every (name, bucket, offset, shape) of the flat-bucket layout (csrc/layout.cpp)."""
+        import hashlib
+        h = hashlib.sha256(f"abi{int(self.lib.mimrl_abi_version())}".encode())
+        for name, group, off, shape in self.entries:
+            h.update(f"|{name}:{group}:{off}:{tuple(int(x) for x in shape)}".encode())
+        return h.hexdigest()[:32]
+
+    def named_moments(self) -> Dict[str, Dict[str, Dict[str, torch.Tensor]]]:
+        """{'main' | 'critic': {'m' | 'v': {parameter name: tensor of the parameter's shape}}} -- Adam's exp_avg / exp_avg_sq per
+        parameter, under the reference's state_dict names: independent of where the tensor sits in its bucket."""
+        out = {"main": {"m": {}, "v": {}}, "critic": {"m": {}, "v": {}}}
+        for name, group, off, shape in self.entries:
+            bucket, key = (self.crit, "critic") if group == 1 else (self.main, "main")
+            n = int(np.prod(shape))
+            for k in "mv":
+                out[key][k][name] = bucket[k][off:off + n].view(*shape).clone()
+        return out
+
+    def load_named_moments(self, group: str, m: Dict[str, torch.Tensor], v: Dict[str, torch.Tensor]):
+        """Inverse of ``named_moments`` for one optimizer ('main' | 'critic'); every parameter of the group must be present."""
+        for name, g, off, shape in self.entries:
+            if (g == 1) != (group == "critic"):
+                continue
+            bucket = self.crit if g == 1 else self.main
+            n = int(np.prod(shape))
+            for k, src in (("m", m), ("v", v)):
+                if name not in src:
+                    raise KeyError(f"optimizer state of {name!r} missing from the checkpoint")
+                bucket[k][off:off + n].copy_(torch.as_tensor(src[name]).to(torch.float32).reshape(-1))
+
     def load_optimizer_state(self, st: Dict[str, torch.Tensor]):
         for k, dst in (("main_m", self.main["m"]), ("main_v", self.main["v"]), ("crit_m", self.crit["m"]), ("crit_v", self.crit["v"]),
                        ("counters", self.counters), ("lr_main", self.lr_main), ("lr_critic", self.lr_critic)):
-            dst.copy_(torch.as_tensor(st[k]).to(dst.dtype).reshape(dst.shape))
+            if k in st and st[k] is not None:
+                dst.copy_(torch.as_tensor(st[k]).to(dst.dtype).reshape(dst.shape))
 
     def set_anchors(self, stage: int, anchors, exact_ties: bool = False, bank_c=None):
         """anchors: int array [6, B//k] -- the six ``np.random.choice`` draws of one stage (Model.py:81).

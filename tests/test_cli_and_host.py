@@ -88,6 +88,38 @@ def test_ddp_two_ranks_gloo():
     assert "DDP_OK" in r.stdout
 
 
+def test_bench_launcher_ladder_never_comes_back_empty():
+    """`python bench.py --gpus 2` WITHOUT torchrun's environment is the launcher: it starts the ranks as children,
+    and a rung that hangs (test hook) is killed by the watchdog -- ranks included, although torchrun puts them in their own sessions -- and
+    replaced by fresh children on the next rung.  Without a GPU every rung fails, and the launcher STILL prints one JSON line with the
+    reason of every rung, exit code 1; no rank process survives it."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MIMRL_DIST_BACKEND="gloo", MIMRL_BENCH_TEST_FAIL="rccl-in-graph:hang")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7331", "--warmup", "1", "--ddp-timeout", "8"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, r.stdout[-1000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    at = d["launcher"]["attempts"]
+    assert d["value"] is None and d["n_gpus"] == 2 and [a["rung"] for a in at] == ["rccl-in-graph", "torch-between-graphs", "torch-between-graphs-sequential"]
+    assert at[0]["reason"].startswith("watchdog") and at[0]["seconds"] < 40 and not any(a["ok"] for a in at)
+    assert "needs an MI355X" in at[1]["stderr_tail"]                       # the ranks' own message, not torchrun's exit-code table
+    left = []
+    for pid in filter(str.isdigit, os.listdir("/proc")):
+        try:
+            cl = open(f"/proc/{pid}/cmdline", "rb").read()
+        except OSError:
+            continue
+        if b"bench.py" in cl and b"7331" in cl:
+            left.append(pid)
+    assert not left, f"rank processes survived the watchdog: {left}"
+    # the torchrun form with a mismatching --gpus still fails loudly
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=dict(env, WORLD_SIZE="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
 def test_upload_lookahead_order_and_host_data_flag():
     """Solver._iter_loaded: batch i+1 is staged AFTER the caller's step on batch i has been enqueued (the generator resumes behind the
     yield), committed in front of the next step, and a partial last batch (another engine handle) is bound with set_batch instead.

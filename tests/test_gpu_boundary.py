@@ -230,6 +230,26 @@ def test_checkpoint_round_trip(tmp_path, monkeypatch):
     np.testing.assert_array_equal(sol2.engine.bank["F"][:c["N"]].cpu().numpy(), np.asarray(banks["F"], np.float32))
     got = [tuple(float(x) for x in sol2.step(datas)[:2]) for _ in range(2)]
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
+    # the moments are stored per parameter NAME (raw flat buckets loaded silently onto the wrong parameters once the main bucket
+    # was re-ordered); a checkpoint with flat buckets loads only under the layout fingerprint that wrote it
+    assert isinstance(ck["optim_main"]["m"], dict) and set(ck["optim_main"]["m"]) | set(ck["optim_vmi"]["m"]) == set(ck["model"])
+    assert ck["optim_main"]["m"]["W_t.weight"].shape == ck["model"]["W_t.weight"].shape
+    st = sol.engine.optimizer_state()
+    flat = dict(ck, optim_main=dict(ck["optim_main"], m=st["main_m"].cpu(), v=st["main_v"].cpu()),
+                optim_vmi=dict(ck["optim_vmi"], m=st["crit_m"].cpu(), v=st["crit_v"].cpu()))
+    sol3 = Solver(o, loaders)
+    assert sol3.load_checkpoint(dict(flat)) == 0                                  # tagged with this build's layout: accepted
+    torch.testing.assert_close(sol3.engine.main["m"], sol.engine.main["m"])
+    for bad in (dict(flat, layout="0" * 32), {k: v for k, v in flat.items() if k != "layout"}):   # another layout / an untagged (pre-round-6) file
+        with pytest.raises(_lib.MimrlError, match="flat bucket"):
+            sol3.load_checkpoint(bad)
+    # per-name loading really scatters by name: a permuted dict order gives the same buckets
+    rev = dict(ck, optim_main=dict(ck["optim_main"], m=dict(reversed(list(ck["optim_main"]["m"].items())))))
+    sol3.engine.main["m"].zero_()
+    sol3.load_checkpoint(rev)
+    for n_, t_ in ck["optim_main"]["m"].items():
+        e_ = [x for x in sol3.engine.entries if x[0] == n_][0]
+        torch.testing.assert_close(sol3.engine.main["m"][e_[2]:e_[2] + t_.numel()].cpu(), t_.reshape(-1))
 
 
 def test_main_cli_subprocess_smoke(tmp_path):

@@ -44,6 +44,54 @@ def test_bench_two_ranks_prints_its_line(tmp_path, extra):
     assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp2"
 
 
+def test_bench_self_launch_falls_back_to_the_next_rung(tmp_path):
+    """`python bench.py --gpus 2` with NO torchrun environment (how a driver that runs `--gpus 1` would run it): the launcher starts the two
+    ranks itself as children (both on this box's one GPU over gloo), the first rung is told to fail (test hook), the second rung's FRESH
+    children deliver the line -- with the transport that ran, every rank's own ms/step and the replica-identity checksums in it."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MIMRL_DIST_BACKEND="gloo", MIMRL_BENCH_TEST_FAIL="rccl-in-graph:exit")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-extra", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    at = d["launcher"]["attempts"]
+    assert [(a["rung"], a["ok"]) for a in at] == [("rccl-in-graph", False), ("torch-between-graphs", True)], at
+    assert d["n_gpus"] == 2 and d["losses_finite"] and d["ddp_transport"] == "torch-between-graphs" and d["launcher_rung"] == "torch-between-graphs"
+    assert d["ddp_backend"] == "gloo" and d["rccl_ranks"] == 0 and "not RCCL" in d["ddp_transport_reason"] or "MIMRL_DDP_TORCH" in d["ddp_transport_reason"]
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.0001
+    assert d["replica_check"]["identical"] is True and len(d["replica_check"]["checksums_main_critic"]) == 2
+
+
+def test_two_real_rccl_ranks_in_graph(tmp_path):
+    """TWO real RCCL ranks on TWO GPUs through the in-library, in-graph transport (dist.attach_comm -> mimrl_set_comm; the default of
+    `Solver` and `bench.py --gpus N`): 3 two-stage steps on rank-local batches, replicas bit-identical and equal to single-process Adam on
+    the mean gradient; then `bench.py --gpus 2` self-launched, first rung.  Auto-skips on a one-GPU box (every box this builder has had:
+    DESIGN.md section 6 keeps saying "unmeasured on N > 1" until this has run somewhere)."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("MIMRL_DIST_BACKEND", "MIMRL_DDP_TORCH", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29647", os.path.join(HERE, "rccl_two_rank_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert "RCCL_TWO_RANK_OK" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["losses_finite"] and d["replica_check"]["identical"] is True
+    assert d["launcher"]["attempts"][0] == dict(d["launcher"]["attempts"][0], rung="rccl-in-graph", ok=True), d["launcher"]
+    assert d["ddp_transport"] == "rccl-in-graph" and d["rccl_ranks"] == 2
+
+
 def test_rccl_call_path_single_rank(tmp_path):
     """The `nccl` (= RCCL) branch of mimrl_amd/dist.py on hardware.  RCCL refuses two ranks on one device and the test box has one GPU,
     so this is a ONE-rank communicator with the collectives forced on (MIMRL_DDP_FORCE_COLLECTIVES): process-group initialisation,
