@@ -34,14 +34,6 @@ int set_error(int code, const char* fmt, ...);
 }  // namespace mimrl
 #include "det.h"
 #include "knobs.h"
-#include <unordered_map>
-namespace mimrl {
-// Stream-capture bookkeeping (det.hip): while capture_track(true) is in effect every kernel launch notes which stream its graph node was
-// captured on -- the information graph_postprocess() (engine_step.hip) needs to keep the chain of dependent launches on ONE hardware queue.
-void capture_track(bool on);
-void capture_note(hipStream_t s);
-const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams();
-}  // namespace mimrl
 #undef hipLaunchKernelGGL
 #ifdef MIMRL_DET
 // deterministic build: a launch that may have accumulated (acc_add) is followed, on its own stream, by the flush of the fixed-point
@@ -52,14 +44,12 @@ const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams();
   do {                                                                            \
     (void)::mimrl::det_init();                                                    \
     hipLaunchKernelGGLInternal((kernel), (grid), (block), (lds), (stream), __VA_ARGS__); \
-    ::mimrl::capture_note(stream);                                                \
     if (::mimrl::det_launch_accumulates(#kernel)) (void)::mimrl::det_flush(stream); \
   } while (0)
 #else
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                 \
   do {                                                                            \
     hipLaunchKernelGGLInternal((kernel), (grid), (block), (lds), (stream), __VA_ARGS__); \
-    ::mimrl::capture_note(stream);                                                \
   } while (0)
 #endif
 namespace mimrl {

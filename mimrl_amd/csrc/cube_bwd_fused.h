@@ -10,12 +10,6 @@
 
 namespace mimrl {
 
-// Optional tail of the L-axis kernel of block 0 (round 5b): the cube's slots 1 / 2 ARE the LayerNorm + ReLU + dropout outputs of the two
-// recurrent encoders (Model.py:452-461) and a workgroup's dX tile (sample b, slot k, rows t) is exactly the set of rows whose backward
-// (ln_relu_drop_bwd: dropout mask, ReLU mask, LayerNorm over d_common, temporal-mean gradient folded in) needs nothing else -- so the tile
-// goes through that backward from LDS instead of through HBM and a launch + queue hop in front of the layer-1 BPTT.
-struct LAxisLnSide { const float *h2, *gamma, *beta, *mean, *rstd, *dmean; float *ds, *dgamma, *dbeta; float p; uint32_t stream; };
-
 struct LAxisBwdArgs {
   const float *dz, *y, *mean, *rstd, *gamma;   // [B,ol,C] [B,ol,C] [B,C] [B,C] [ol]
   const float* u;                              // pre-activation [B,hl,C]
@@ -24,10 +18,6 @@ struct LAxisBwdArgs {
   float *db2, *db1;                            // [ol] or null, [hl] or null (accumulated); the LayerNorm parameter
                                                // gradients are row sums over (b, c): colln_param_grads, off the critical path
   int B, il, hl, ol, C, act;
-  // ln tail (lt_on: C == 3 * 128, lt_T <= il): slot 0 (text) keeps the plain dX store; the dX rows of slots 1 / 2 are NOT written
-  int lt_on = 0, lt_T = 0, lt_ds_bf16 = 0;   // lt_ds_bf16 (long kernel only): ds is written as bf16 (GruBwdArgs::dout_bf16)
-  LAxisLnSide lt[2];
-  RngKey lt_key;
 };
 bool laxis_bwd_supported(int il, int hl, int ol, int C);
 int laxis_bwd_fused(hipStream_t s, const LAxisBwdArgs& a);

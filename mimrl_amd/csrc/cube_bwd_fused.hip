@@ -23,24 +23,17 @@ constexpr int KP = 64 + 8;    // bf16 pitch of a [.][<=64] operand image (144 B:
 // K = o or h.  dY / dU are kept TRANSPOSED in LDS ([column][k]) so that B-fragments are 16-byte reads; the weights
 // are staged transposed and zero-padded to 64x64, which also takes care of ragged hl / ol / il.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int SXP = 128 + 4;   // LT: fp32 pitch of the dX tile [64][SXP] that aliases the dead dY / dU images (16-byte rows)
-static_assert(64 * SXP * sizeof(float) <= 2 * CT * KP * sizeof(__bf16), "the fp32 dX tile must fit the two operand images");
 
-// LT (ln tail, see LAxisLnSide): workgroups of slots 1 / 2 run their dX tile through the encoders' LayerNorm + ReLU + dropout backward.
-// Same lane mapping, arithmetic and summation order per row as ln_relu_drop_bwd16_kernel (16 lanes per row, two column quads per lane), so
-// ds is bit-identical to the two-launch path; only the order of the dgamma / dbeta atomics differs.
 // LONG (round 5b): il > 64 -- the input axis of a long-sequence block (cfg3 / cfg5: L = 500 / 1000 -> 50 -> 50).  Phases 1 and 2 are the short
 // kernel's (LayerNorm backward over the <= 64 output rows, dU over the <= 64 hidden rows); phase 3, dX = W1^T dU + Wr^T dY, walks the il output
 // rows in tiles of 64 and stages the two transposed weight tiles per step (requested one tile ahead).  One launch instead of colln_bwd + two
 // GEMM launches with dY / dU round trips in between (192 us of the cfg3 chain).
-template <bool LT, bool LONG = false>
-__global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(LAxisBwdArgs a) {   // (LONG: two workgroups per CU -- 768 workgroups of ~45 us each at cfg3; with the tail: its fp32 tile makes it one)
+template <bool LONG = false>
+__global__ __launch_bounds__(256, LONG ? 2 : 1) void laxis_bwd_kernel(LAxisBwdArgs a) {   // (LONG: two workgroups per CU -- 768 workgroups of ~45 us each at cfg3)
   __shared__ __attribute__((aligned(16))) __bf16 sdyu[2][CT][KP];
   auto& sdy = sdyu[0];
   auto& sdu = sdyu[1];
   __shared__ __attribute__((aligned(16))) __bf16 wts[3][64][KP];
-  __shared__ LdsAcc slt[LT ? 256 : 1];   // LT: this workgroup's dgamma [0,128) / dbeta [128,256) sums
-  __shared__ __attribute__((aligned(16))) float sxl[(LT && LONG) ? 64 * SXP : 4];   // LT && LONG: the fp32 dX tile of one step (the dY / dU images stay live)
   // wts[0] = W2^T [h][o], wts[1] = W1^T [i][h], wts[2] = Wr^T [i][o]
   float (*red)[2][CT] = reinterpret_cast<float (*)[2][CT]>(&sdu[0][0]);   // phase-1 scratch; sdu is first written in phase 2
   __shared__ float acc_l[3][64];   // per-l partial sums of dgamma, dbeta, db2
@@ -70,7 +63,6 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
     uint4* z = reinterpret_cast<uint4*>(&wts[0][0][0]);
     for (int i = tid; i < 3 * 64 * KP * 2 / 16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 64) { acc_l[0][tid] = 0.f; acc_l[1][tid] = 0.f; acc_l[2][tid] = 0.f; acc_h[tid].zero(); sgam[tid] = a.gamma[tid < ol ? tid : ol - 1]; }
-    if constexpr (LT) slt[tid].zero();
   }
   __syncthreads();
   BPHASE(pb, 1);
@@ -186,34 +178,6 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
   }
   __syncthreads();
   BPHASE(pb, 5);
-  // LT: everything the tail needs from memory is requested HERE, in front of phase 3's products (rule 1: no dependent load behind a product).
-  // Lane = (row slot rw = tid >> 4, sub = tid & 15): rows t = rw + 16 * pass, column quads c0 = 4 sub and c1 = 64 + 4 sub.
-  const bool tail = LT && blockIdx.x >= 1;
-  const LAxisLnSide& ls = a.lt[LT && blockIdx.x == 2 ? 1 : 0];
-  const int sub = tid & 15, rw = tid >> 4, lc0 = 4 * sub, lc1 = 64 + 4 * sub;
-  float4 hq[4][4], lg0, lg1, lb0, lb1, lm0, lm1;
-  float lmu[4], lrs[4];
-  float lag[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lab[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // LT && LONG: running dgamma / dbeta terms over the tiles
-  uint32_t rstep = 0;
-  if constexpr (LT) {
-    if (tail) {
-      rstep = (uint32_t)(*a.lt_key.step + a.lt_key.add);
-      lg0 = *reinterpret_cast<const float4*>(ls.gamma + lc0); lg1 = *reinterpret_cast<const float4*>(ls.gamma + lc1);
-      lb0 = *reinterpret_cast<const float4*>(ls.beta + lc0); lb1 = *reinterpret_cast<const float4*>(ls.beta + lc1);
-      lm0 = make_float4(0.f, 0.f, 0.f, 0.f); lm1 = lm0;
-      if (ls.dmean) { lm0 = *reinterpret_cast<const float4*>(ls.dmean + (long)b * 128 + lc0); lm1 = *reinterpret_cast<const float4*>(ls.dmean + (long)b * 128 + lc1); }
-      if constexpr (!LONG) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const long r = (long)b * a.lt_T + min(rw + 16 * ps, a.lt_T - 1);   // clamped, unconditional
-          const float* hr = ls.h2 + r * 256;
-          hq[ps][0] = *reinterpret_cast<const float4*>(hr + lc0); hq[ps][1] = *reinterpret_cast<const float4*>(hr + lc1);
-          hq[ps][2] = *reinterpret_cast<const float4*>(hr + 128 + lc0); hq[ps][3] = *reinterpret_cast<const float4*>(hr + 128 + lc1);
-          lmu[ps] = ls.mean[r]; lrs[ps] = ls.rstd[r];
-        }
-      }
-    }
-  }
   // ---- phase 3: dX = W1^T dU + Wr^T dY
   if constexpr (LONG) {
     // tiles of 64 output rows i: W1^T [i][h] and Wr^T [i][o] of the tile go through wts[1] / wts[2]; thread = (i = tid & 63, rows h / o =
@@ -247,18 +211,6 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
       }
       __syncthreads();
       wreq(i0 + 64 < il ? i0 + 64 : i0);    // unconditional (past the end: this tile again, never stored)
-      if constexpr (LT) {
-        if (tail) {   // operands of this tile's four row passes (rows t = i0 + rw + 16 ps): requested in front of the products
-#pragma unroll
-          for (int ps = 0; ps < 4; ++ps) {
-            const long r = (long)b * a.lt_T + min(i0 + rw + 16 * ps, a.lt_T - 1);
-            const float* hr = ls.h2 + r * 256;
-            hq[ps][0] = *reinterpret_cast<const float4*>(hr + lc0); hq[ps][1] = *reinterpret_cast<const float4*>(hr + lc1);
-            hq[ps][2] = *reinterpret_cast<const float4*>(hr + 128 + lc0); hq[ps][3] = *reinterpret_cast<const float4*>(hr + 128 + lc1);
-            lmu[ps] = ls.mean[r]; lrs[ps] = ls.rstd[r];
-          }
-        }
-      }
       f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -272,7 +224,7 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][32 + lr][kk]);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
       }
-      if (!tail) {
+      {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -280,73 +232,6 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
             const int i = i0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (i < il) a.dx[((long)b * il + i) * C + cc] = mt == 0 ? acc0[r] : acc1[r];
           }
-      }
-      if constexpr (LT) {
-        if (tail) {   // the tile through the encoders' LayerNorm + ReLU + dropout backward, from LDS (see the short kernel's tail below)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sxl[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * SXP + nt * 32 + lr] = mt == 0 ? acc0[r] : acc1[r];
-          __syncthreads();
-          const float invT = 1.f / a.lt_T;
-          const float gv[8] = {lg0.x, lg0.y, lg0.z, lg0.w, lg1.x, lg1.y, lg1.z, lg1.w}, bv[8] = {lb0.x, lb0.y, lb0.z, lb0.w, lb1.x, lb1.y, lb1.z, lb1.w};
-          const float mv[8] = {lm0.x, lm0.y, lm0.z, lm0.w, lm1.x, lm1.y, lm1.z, lm1.w};
-#pragma unroll
-          for (int ps = 0; ps < 4; ++ps) {
-            const int tl = rw + 16 * ps, t = i0 + tl;
-            const bool ok = t < a.lt_T;
-            const long r = (long)b * a.lt_T + min(t, a.lt_T - 1);
-            const float4 d0 = *reinterpret_cast<const float4*>(sxl + tl * SXP + lc0), d1 = *reinterpret_cast<const float4*>(sxl + tl * SXP + lc1);
-            const float4 hf0 = hq[ps][0], hf1 = hq[ps][1], hb0 = hq[ps][2], hb1 = hq[ps][3];
-            const float mu = lmu[ps], rs = lrs[ps];
-            const float hv[8] = {hf0.x + hb0.x, hf0.y + hb0.y, hf0.z + hb0.z, hf0.w + hb0.w, hf1.x + hb1.x, hf1.y + hb1.y, hf1.z + hb1.z, hf1.w + hb1.w};
-            const float dv[8] = {d0.x + mv[0] * invT, d0.y + mv[1] * invT, d0.z + mv[2] * invT, d0.w + mv[3] * invT,
-                                 d1.x + mv[4] * invT, d1.y + mv[5] * invT, d1.z + mv[6] * invT, d1.w + mv[7] * invT};
-            float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int j = (q < 4 ? lc0 : lc1 - 4) + q;
-              xh[q] = (hv[q] - mu) * rs;
-              const float y = xh[q] * gv[q] + bv[q];
-              float dy = dv[q] * drop_scale_at(ls.p, a.lt_key, rstep, ls.stream, (uint32_t)(r * 128 + j));
-              dy = (ok && y > 0.f) ? dy : 0.f;
-              lag[q] += dy * xh[q];
-              lab[q] += dy;
-              dxh[q] = dy * gv[q];
-              s1 += dxh[q];
-              s2 += dxh[q] * xh[q];
-            }
-            s1 = group_sum<16>(s1) * (1.f / 128.f);
-            s2 = group_sum<16>(s2) * (1.f / 128.f);
-            if (ok) {
-              float4 o0, o1;
-              o0.x = rs * (dxh[0] - s1 - xh[0] * s2); o0.y = rs * (dxh[1] - s1 - xh[1] * s2); o0.z = rs * (dxh[2] - s1 - xh[2] * s2); o0.w = rs * (dxh[3] - s1 - xh[3] * s2);
-              o1.x = rs * (dxh[4] - s1 - xh[4] * s2); o1.y = rs * (dxh[5] - s1 - xh[5] * s2); o1.z = rs * (dxh[6] - s1 - xh[6] * s2); o1.w = rs * (dxh[7] - s1 - xh[7] * s2);
-              if (a.lt_ds_bf16) {
-                __bf16* dsb = reinterpret_cast<__bf16*>(ls.ds);
-                bf16x4 q0, q1;
-                q0[0] = to_bf16(o0.x); q0[1] = to_bf16(o0.y); q0[2] = to_bf16(o0.z); q0[3] = to_bf16(o0.w);
-                q1[0] = to_bf16(o1.x); q1[1] = to_bf16(o1.y); q1[2] = to_bf16(o1.z); q1[3] = to_bf16(o1.w);
-                *reinterpret_cast<bf16x4*>(dsb + r * 128 + lc0) = q0;
-                *reinterpret_cast<bf16x4*>(dsb + r * 128 + lc1) = q1;
-              } else {
-                *reinterpret_cast<float4*>(ls.ds + r * 128 + lc0) = o0;
-                *reinterpret_cast<float4*>(ls.ds + r * 128 + lc1) = o1;
-              }
-            }
-          }
-        }
-      }
-    }
-    if constexpr (LT) {
-      if (tail) {   // parameter gradients of the tail: the four row slots of a wave share columns, then LDS, then one atomic per column (below)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float sa = lag[q], sb = lab[q];
-          sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-          sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-          if (lane < 16) { const int j = (q < 4 ? lc0 : lc1 - 4) + q; slt[j].add(sa); slt[128 + j].add(sb); }
-        }
       }
     }
   } else {
@@ -363,7 +248,7 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
       const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&wts[first ? 1 : 2][32 + lr][kk]);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bf, acc1, 0, 0, 0);
     }
-    if (!tail) {
+    {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -372,75 +257,9 @@ __global__ __launch_bounds__(256, (LONG && !LT) ? 2 : 1) void laxis_bwd_kernel(L
           if (i < il) a.dx[((long)b * il + i) * C + cc] = mt == 0 ? acc0[r] : acc1[r];
         }
     }
-    if constexpr (LT) {
-      if (tail) {
-        float* sx = reinterpret_cast<float*>(&sdyu[0][0][0]);   // [64][SXP] fp32 over the dY / dU images: every wave is through with them ...
-        __syncthreads();                                        // ... behind this barrier
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sx[i * SXP + nt * 32 + lr] = mt == 0 ? acc0[r] : acc1[r];     // (rows i >= il: zero, the weight images are zero-padded)
-          }
-        __syncthreads();
-        const float invT = 1.f / a.lt_T;
-        const float gv[8] = {lg0.x, lg0.y, lg0.z, lg0.w, lg1.x, lg1.y, lg1.z, lg1.w}, bv[8] = {lb0.x, lb0.y, lb0.z, lb0.w, lb1.x, lb1.y, lb1.z, lb1.w};
-        const float mv[8] = {lm0.x, lm0.y, lm0.z, lm0.w, lm1.x, lm1.y, lm1.z, lm1.w};
-        float ag[8], ab[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { ag[q] = 0.f; ab[q] = 0.f; }
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-          const int t = rw + 16 * ps;
-          const bool ok = t < a.lt_T;
-          const long r = (long)b * a.lt_T + min(t, a.lt_T - 1);
-          const float4 d0 = *reinterpret_cast<const float4*>(sx + t * SXP + lc0), d1 = *reinterpret_cast<const float4*>(sx + t * SXP + lc1);
-          const float4 hf0 = hq[ps][0], hf1 = hq[ps][1], hb0 = hq[ps][2], hb1 = hq[ps][3];
-          const float mu = lmu[ps], rs = lrs[ps];
-          const float hv[8] = {hf0.x + hb0.x, hf0.y + hb0.y, hf0.z + hb0.z, hf0.w + hb0.w, hf1.x + hb1.x, hf1.y + hb1.y, hf1.z + hb1.z, hf1.w + hb1.w};
-          const float dv[8] = {d0.x + mv[0] * invT, d0.y + mv[1] * invT, d0.z + mv[2] * invT, d0.w + mv[3] * invT,
-                               d1.x + mv[4] * invT, d1.y + mv[5] * invT, d1.z + mv[6] * invT, d1.w + mv[7] * invT};
-          float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int j = (q < 4 ? lc0 : lc1 - 4) + q;
-            xh[q] = (hv[q] - mu) * rs;
-            const float y = xh[q] * gv[q] + bv[q];
-            float dy = dv[q] * drop_scale_at(ls.p, a.lt_key, rstep, ls.stream, (uint32_t)(r * 128 + j));
-            dy = (ok && y > 0.f) ? dy : 0.f;
-            ag[q] += dy * xh[q];
-            ab[q] += dy;
-            dxh[q] = dy * gv[q];
-            s1 += dxh[q];
-            s2 += dxh[q] * xh[q];
-          }
-          s1 = group_sum<16>(s1) * (1.f / 128.f);
-          s2 = group_sum<16>(s2) * (1.f / 128.f);
-          if (ok) {
-            float4 o0, o1;
-            o0.x = rs * (dxh[0] - s1 - xh[0] * s2); o0.y = rs * (dxh[1] - s1 - xh[1] * s2); o0.z = rs * (dxh[2] - s1 - xh[2] * s2); o0.w = rs * (dxh[3] - s1 - xh[3] * s2);
-            o1.x = rs * (dxh[4] - s1 - xh[4] * s2); o1.y = rs * (dxh[5] - s1 - xh[5] * s2); o1.z = rs * (dxh[6] - s1 - xh[6] * s2); o1.w = rs * (dxh[7] - s1 - xh[7] * s2);
-            *reinterpret_cast<float4*>(ls.ds + r * 128 + lc0) = o0;
-            *reinterpret_cast<float4*>(ls.ds + r * 128 + lc1) = o1;
-          }
-        }
-        // parameter gradients: the four row slots of a wave share columns (lanes that differ in bits 4, 5), then LDS, then one atomic per column
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float sa = ag[q], sb = ab[q];
-          sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-          sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-          if (lane < 16) { const int j = (q < 4 ? lc0 : lc1 - 4) + q; slt[j].add(sa); slt[128 + j].add(sb); }
-        }
-      }
-    }
   }
   __syncthreads();
   BPHASE(pb, 6);
-  if constexpr (LT) {
-    if (tail) { if (tid < 128) acc_add(&ls.dgamma[tid], slt[tid].get()); else acc_add(&ls.dbeta[tid - 128], slt[tid].get()); }
-  }
   if (a.db2 && tid < ol) acc_add(&a.db2[tid], acc_l[2][tid]);
   if (a.db1 && tid >= 64 && tid - 64 < hl) acc_add(&a.db1[tid - 64], acc_h[tid - 64].get());
   BPHASE(pb, 7);
@@ -459,16 +278,8 @@ bool laxis_bwd_supported(int il, int hl, int ol, int C) {   // (il > 64: the LON
 int laxis_bwd_fused(hipStream_t s, const LAxisBwdArgs& a) {
   if (!laxis_bwd_supported(a.il, a.hl, a.ol, a.C)) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: unsupported shape");
   if (!a.wr) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: needs the residual projection");
-  if (a.lt_on) {
-    if (a.C != 3 * CT || a.lt_T < 1 || a.lt_T > a.il) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: ln tail needs C = 384 and T <= il");
-    if (a.lt_ds_bf16 && a.il <= 64) return set_error(MIMRL_ERR_ARG, "laxis_bwd_fused: the short kernel's tail writes fp32 ds");
-    if (a.il > 64) hipLaunchKernelGGL((laxis_bwd_kernel<true, true>), dim3(a.C / CT, a.B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(laxis_bwd_kernel<true>, dim3(a.C / CT, a.B), dim3(256), 0, s, a);
-  } else if (a.il > 64) {
-    hipLaunchKernelGGL((laxis_bwd_kernel<false, true>), dim3(a.C / CT, a.B), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(laxis_bwd_kernel<false>, dim3(a.C / CT, a.B), dim3(256), 0, s, a);
-  }
+  if (a.il > 64) hipLaunchKernelGGL(laxis_bwd_kernel<true>, dim3(a.C / CT, a.B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(laxis_bwd_kernel<false>, dim3(a.C / CT, a.B), dim3(256), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

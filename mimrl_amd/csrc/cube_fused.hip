@@ -541,7 +541,7 @@ int cube_block_fwd_fused(hipStream_t s, const CubeFusedArgs& a) {
   const int R = a.ol * a.K;
   const int nmt = (R + 63) / 64;
   if (nmt < 1 || nmt > 3) return set_error(MIMRL_ERR_ARG, "cube_fused: unsupported row count %d", R);
-  static const int groups = knob("MIMRL_CUBE_FWD_GROUPS") ? atoi(knob("MIMRL_CUBE_FWD_GROUPS")) : 2;   // tuning knob: wave groups per workgroup
+  constexpr int groups = 2;   // (an environment knob until round 5: fixed at its measured optimum): wave groups per workgroup
   const int G = groups == 1 ? 1 : 2;
   const Carve cv = carve(a.K, nmt, G);
   if (cv.total > 160 * 1024) return set_error(MIMRL_ERR_ARG, "cube_fused: LDS budget exceeded (%d B)", cv.total);

@@ -126,23 +126,6 @@ int det_overflowed() {
 
 }  // namespace mimrl
 
-namespace mimrl {
-namespace {
-bool g_track = false;
-std::unordered_map<hipGraphNode_t, hipStream_t> g_node_stream;
-}  // namespace
-void capture_track(bool on) { g_track = on; if (on) g_node_stream.clear(); }
-void capture_note(hipStream_t s) {
-  if (!g_track) return;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  const hipGraphNode_t* deps = nullptr;
-  size_t n = 0;
-  if (hipStreamGetCaptureInfo_v2(s, &st, nullptr, nullptr, &deps, &n) != hipSuccess) { (void)hipGetLastError(); return; }
-  if (st == hipStreamCaptureStatusActive && n == 1 && deps) g_node_stream[deps[0]] = s;   // behind a launch the stream's dependency set is that node
-}
-const std::unordered_map<hipGraphNode_t, hipStream_t>& capture_streams() { return g_node_stream; }
-}  // namespace mimrl
-
 extern "C" int mimrl_deterministic(void) {
 #ifdef MIMRL_DET
   // 1 = deterministic build, every sum so far order-independent; | 2: the accumulation table ran full at some launch; | 4: some

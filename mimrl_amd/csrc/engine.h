@@ -495,10 +495,6 @@ struct mimrl_handle {
   int route_feature_grads();
   GatherSum head_gather;               // sources of the F_F gradient (summed inside head_bwd) while head_gather_on
   bool head_gather_on = false;
-  bool ln_tail_fuse = false;           // MIMRL_LN_TAIL_FUSE=1 (mimrl_create; opt-in)
-  bool ln_tail_long_on = false;        // MIMRL_LN_TAIL_LONG (mimrl_create): the same tail in the LONG instantiation (il > 64)
-  bool ln_tail_ds_bf16 = false;        // the tail wrote ds as bf16 (cube_backward -> encoders_backward)
-  bool ln_tail_want = false, ln_tail_done = false;   // model_backward -> cube_backward: fuse the encoders' LN backward into block 0's L-axis kernel; -> encoders_backward: done
   hipEvent_t ev_dmean = nullptr;       // T / A / V feature gradients ready (gathered on side 0)
   hipEvent_t ev_pre = nullptr;         // MIMRL_BPTT_FIRST: the point the parked kernels are flushed behind (encoders_backward -> gru_layer_backward)
   int estimators_all(int stage, bool want_grad, bool backward);

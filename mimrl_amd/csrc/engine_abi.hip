@@ -56,12 +56,11 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
 #endif
   h->fused_cube = knob("MIMRL_NO_FUSED_CUBE") == nullptr;
   h->fused_mlp = knob("MIMRL_NO_FUSED_MLP") == nullptr;
-  h->knn_pre = knob("MIMRL_NO_KNN_PREFETCH") == nullptr;
+  h->knn_pre = true;
   h->fold_unpack_on = knob("MIMRL_NO_FOLD_UNPACK") == nullptr;
   h->h16_on = knob("MIMRL_NO_H16") == nullptr;
   h->xin_on = knob("MIMRL_NO_XIN") == nullptr;
   h->fused_cube_bwd = knob("MIMRL_NO_FUSED_CUBE_BWD") == nullptr;
-  h->ln_tail_long_on = knob("MIMRL_LN_TAIL_LONG") && atoi(knob("MIMRL_LN_TAIL_LONG")) != 0;
   h->laxis_bwd_long_on = !(knob("MIMRL_LAXIS_BWD_LONG") && atoi(knob("MIMRL_LAXIS_BWD_LONG")) == 0);
   h->laxis_long_on = !(knob("MIMRL_LAXIS_LONG") && atoi(knob("MIMRL_LAXIS_LONG")) == 0);
   h->rec16_on = !(knob("MIMRL_REC16") && atoi(knob("MIMRL_REC16")) == 0);
@@ -69,7 +68,6 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   h->adam_frag_on = !(knob("MIMRL_ADAM_FRAG") && atoi(knob("MIMRL_ADAM_FRAG")) == 0);
   // opt-in (measured slower at cfg2, 0.814-0.819 vs 0.799-0.800 ms: the parked block-0 weight gradients then start together with the layer-1 BPTT
   // instead of 30 us ahead of it, and the BPTT beside them takes 74 instead of 53 us -- DESIGN section 7)
-  h->ln_tail_fuse = knob("MIMRL_LN_TAIL_FUSE") && atoi(knob("MIMRL_LN_TAIL_FUSE")) != 0;
   h->fused_concat = knob("MIMRL_NO_FUSED_CONCAT") == nullptr;
   h->fwd_f16 = knob("MIMRL_FWD_BF16") == nullptr;
   // packed layer-0 operands: one batched projection + two batched weight gradients instead of 2 + 4 launches: the four layer-0
@@ -82,7 +80,7 @@ int mimrl_create(const mimrl_cfg* cfg, void* hip_stream, mimrl_handle** out) {
   // number in this mode and halves what the BPTT writes and the weight-gradient / dh0 products read
   h->dg_bf16 = cfg->encoder == MIMRL_ENCODER_GRU && (cfg->precision & MIMRL_PREC_BF16_GRU_BWD) && (cfg->precision & MIMRL_PREC_BF16_GEMM_BWD) &&
                knob("MIMRL_DG_FP32") == nullptr;
-  h->l0_bwd_pack = knob("MIMRL_L0_BWD_PACK") ? atoi(knob("MIMRL_L0_BWD_PACK")) != 0 : false;
+  h->l0_bwd_pack = false;
   // gx[B,T,3H] -- written once by the input projection, read once by the recurrence -- as fp16 (MIMRL_GX_F16=1; OFF by default).  Round 4
   // built it for cfg3, whose two projections on the chain are bound by 786 MB of fp32 stores each (449 / 302 us), and measured a LOSS:
   // 7.24 against 6.83 ms per step.  The accumulator layout gives a lane one column of 16 rows, so an fp16 store instruction writes two

@@ -8,7 +8,7 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
   for (int i = 0; i < cfg.n_blocks; ++i)
     for (int ax = 0; ax < 3; ++ax) dims[i + 1][ax] = cfg.d_outs[i][ax];
   // deferred mode: every gradient buffer is used once (weight-gradient GEMMs read dY / dU after the chain has moved on)
-  static const bool no_defer = knob("MIMRL_NO_DEFER_WGRAD") != nullptr;   // tuning knob
+  constexpr bool no_defer = false;   // (an environment knob until round 5: fixed at its measured optimum)
   const int per_block = 7 + (cfg.dropout_mlp[0] > 0.f) + (cfg.dropout_mlp[2] > 0.f);   // buffers one block consumes
   const bool defer = multi_stream && !cfg.ln_first && !no_defer && per_block * cfg.n_blocks + 1 <= NGBUF;
   const int npool = defer ? NGBUF : 4;
@@ -90,8 +90,8 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       // LayerNorm and bias gradients (column sums over the rows of dz, y, dY, dU).  Folded into the data-gradient kernel they cost
       // the chain 13 us per block (MIMRL_DAXIS_PG_FUSE=1: 19 -> 32 us); as ONE streaming side kernel instead of rowln_param_grads +
       // 2 x colsum (3 launches of 30-40 us each) they are ~10 us beside the BPTT (MIMRL_NO_DAXIS_PG_ONE=1: the three launches)
-      static const bool pg_fuse = knob("MIMRL_DAXIS_PG_FUSE") != nullptr;        // tuning knobs
-      static const bool no_pg_one = knob("MIMRL_NO_DAXIS_PG_ONE") != nullptr;
+      constexpr bool pg_fuse = false;        // (an environment knob until round 5: fixed at its measured optimum)
+      constexpr bool no_pg_one = false;
       const bool pg_fused = pg_fuse && a.fc2.b >= 0 && a.fc1.b >= 0;
       const bool pg_one = !pg_fused && !no_pg_one;
       fa.dgamma = fa.dbeta = fa.db2 = fa.db1 = nullptr;
@@ -220,28 +220,6 @@ int mimrl_handle::cube_backward(int cur_in, int* cur_out) {
       fa.dy = gbuf[i_dy]; fa.du = gbuf[i_du]; fa.dx = gbuf[i_dx];
       fa.db2 = a.fc2.b >= 0 ? Gm(a.fc2.b) : nullptr; fa.db1 = a.fc1.b >= 0 ? Gm(a.fc1.b) : nullptr;
       fa.B = B; fa.il = il; fa.hl = hl; fa.ol = ol; fa.C = (int)C; fa.act = cfg.activation;
-      // block 0 inside the model's backward: the encoders' LayerNorm + ReLU + dropout backward rides on this launch (LAxisLnSide) -- one launch
-      // and one queue hop less in front of the layer-1 BPTT (cfg2: ln_relu_drop_bwd16 22 us + 10-20 us of hop).  Opt-in, MIMRL_LN_TAIL_FUSE=1: see mimrl_create.
-      // (long sequences, il > 64: the LONG instantiation's tail, MIMRL_LN_TAIL_LONG -- cfg3's 256-workgroup BPTT launches do not use the LDS
-      //  padding that made the short kernel's tail lose at cfg2; it writes ds as bf16 when the layer-1 BPTT reads it that way)
-      ln_tail_ds_bf16 = false;
-      if (i == 0 && ln_tail_want && (il <= 64 ? ln_tail_fuse : ln_tail_long_on) && ik == 3 && id == 128 && cfg.d_common == 128 && cfg.seq_len <= il) {
-        const size_t BD = (size_t)B * cfg.d_common;
-        const float* dmean = dfeat + BD;
-        if (head_gather_on && ev_dmean) { HIPX(hipStreamWaitEvent(stream, ev_dmean, 0)); ev_dmean = nullptr; }   // dmean gathered on side 0
-        for (int m = 0; m < 2; ++m)
-          fa.lt[m] = LAxisLnSide{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], dmean + (1 + m) * BD, ds[m], Gm(ln_g[m]), Gm(ln_b[m]),
-                                 cfg.dropout[1 + m], (uint32_t)(1 + m)};
-        fa.lt_on = 1; fa.lt_T = cfg.seq_len; fa.lt_key = key();
-        if (il > 64) {
-          ln_tail_ds_bf16 = rec16_on && cfg.encoder == MIMRL_ENCODER_GRU && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(0);
-          fa.lt_ds_bf16 = ln_tail_ds_bf16 ? 1 : 0;
-        }
-        ln_tail_done = true;
-        // this block's D-axis parked work goes out NOW, beside this launch: behind it it would start together with the layer-1 BPTT
-        static const bool split_flush = knob("MIMRL_LN_TAIL_SPLIT_FLUSH") == nullptr || atoi(knob("MIMRL_LN_TAIL_SPLIT_FLUSH")) != 0;
-        if (defer && split_flush) MX(flush_deferred(1));
-      }
       MX(laxis_bwd_fused(stream, fa));
       MX(W_fork(1, 3));
       MX(W_lnpar(1, b.l.y, b.l.mean, b.l.rstd, gbuf[cur], Gm(a.ln_g), Gm(a.ln_b), B, ol, (int)C));
@@ -365,8 +343,10 @@ __global__ void dbg_spin_kernel(long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 int mimrl_handle::dbg_delay(hipStream_t st, int tag) {
-  static const int want = knob("MIMRL_DBG_DELAY_TAG") ? atoi(knob("MIMRL_DBG_DELAY_TAG")) : -1;
-  static const int us = knob("MIMRL_DBG_DELAY_US") ? atoi(knob("MIMRL_DBG_DELAY_US")) : 50;
+  // MIMRL_DBG_DELAY_TAG=<tag>[:<microseconds>] (default 50 us)
+  static const char* spec = knob("MIMRL_DBG_DELAY_TAG");
+  static const int want = spec ? atoi(spec) : -1;
+  static const int us = spec && strchr(spec, ':') ? atoi(strchr(spec, ':') + 1) : 50;
   if (tag != want) return MIMRL_OK;
   hipLaunchKernelGGL(dbg_spin_kernel, dim3(1), dim3(64), 0, st, (long)us * 100);   // wall_clock64 ticks at 100 MHz
   LAUNCH_CHECK();
@@ -382,11 +362,11 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
     for (int i = 1; i <= 3; ++i) if (side_on(i)) HIPX(hipStreamWaitEvent(side[i], after, 0));
   } else if (only_side > 0) MX(fork(only_side, only_side)); else MX(fork(1, 3));
   for (int q = 1; q <= 3; ++q) MX(dbg_delay(S(q), 9));
-  static const int wg_sides = knob("MIMRL_WG_SIDES") ? atoi(knob("MIMRL_WG_SIDES")) : 3;
+  constexpr int wg_sides = 3;
   static const int dbg_skip_kinds = dbg_env("MIMRL_DBG_SKIP_DEFERRED") ? atoi(dbg_env("MIMRL_DBG_SKIP_DEFERRED")) : 0;   // timing experiments only (bit = kind)
   // the weight-gradient GEMMs as (at most) two grouped split-K launches, one per operand-layout class: D-axis products are
   // (RC,RC), the batch-reduced L-axis products (KC,KC).  Alone each is a ~20 us launch of 4..64 tiles.
-  static const bool no_wg_groupk = knob("MIMRL_NO_WG_GROUPK") != nullptr;   // tuning knob
+  constexpr bool no_wg_groupk = false;   // (an environment knob until round 5: fixed at its measured optimum)
   // (short sequences only: at T = 1000 the recurrence beside them runs for a millisecond, launch latencies are hidden and one
   // chip-filling launch in front of the BPTT costs more than it saves -- cfg5: 3.85 vs 3.74 ms)
   const bool groupk = !no_wg_groupk && !prof_on && bf16 && !((dbg_skip_kinds >> 0) & 1) && cfg.seq_len <= 128;
@@ -431,8 +411,7 @@ int mimrl_handle::model_backward() {
               cfg.compose_t_sum, cfg.compose_k_sum, head_gather_on ? &head_gather : nullptr));
   int ci = 0;
   deferred.clear();
-  ln_tail_want = true; ln_tail_done = false;
-  { Scope sc(this, MIMRL_PH_CUBE_BWD); const int r = cube_backward(0, &ci); ln_tail_want = false; MX(r); }
+  { Scope sc(this, MIMRL_PH_CUBE_BWD); MX(cube_backward(0, &ci)); }
   MX(dbg_delay(stream, 7));
   return encoders_backward(gbuf[ci]);
 }
@@ -450,7 +429,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
   // BPTT chain, first; the text branch (35 us of W_t weight gradient with slack until the end of the stage) behind it.  History: while
   // the side streams were congested by the parked CubeMLP weight gradients the opposite order was faster (1.229 vs 1.259 ms); with the
   // grouped / fused parameter-gradient kernels it is this one (0.980 vs 0.988 ms).  MIMRL_TEXT_BWD_FIRST=1: the other order.
-  static const bool text_bwd_first = knob("MIMRL_TEXT_BWD_FIRST") != nullptr;
+  constexpr bool text_bwd_first = false;
   auto text_bwd = [&]() -> int {   // text branch (side 0): dW_t = dtx^T . text
     MX(fork(0, 0));
     MX(text_post_bwd(S(0), dcube, dtx, B, T, L, 3, D, 0, cfg.dropout[0], key(), 0, dmean));
@@ -459,21 +438,15 @@ int mimrl_handle::encoders_backward(float* dcube) {
   };
   if (text_bwd_first) MX(text_bwd());
   if (head_gather_on && ev_dmean) { HIPX(hipStreamWaitEvent(stream, ev_dmean, 0)); ev_dmean = nullptr; }   // dmean gathered on side 0
-  // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1); already done when it rode on the L-axis kernel
-  // of CubeMLP block 0 (cube_backward: LAxisLnSide)
-  const bool ln_done = ln_tail_done;
-  ln_tail_done = false;
-  if (!ln_done) {
+  // audio / video: LN+ReLU+dropout backward -> ds (shared by both directions of layer 1)
+  {
     LnSide2 sd[2];
     for (int m = 0; m < 2; ++m)
       sd[m] = LnSide2{h1[m], P(ln_g[m]), P(ln_b[m]), ln_mean[m], ln_rstd[m], ds[m], Gm(ln_g[m]), Gm(ln_b[m]), 1 + m,
                       cfg.dropout[1 + m], (uint32_t)(1 + m)};
     // round 5b: ds as bf16 when the layer-1 BPTT launch can read it that way (GRU, bf16 BPTT with bf16 dg, 4-wave kernel)
-    ds_bf16_live = rec16_on && cfg.encoder == MIMRL_ENCODER_GRU && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(0) &&
-                   ln_relu_drop_bwd2_bf16_ok();
+    ds_bf16_live = rec16_on && cfg.encoder == MIMRL_ENCODER_GRU && dg_bf16 && (prec & MIMRL_PREC_BF16_GRU_BWD) != 0 && gru_bwd_io16_ok(0);
     MX(ln_relu_drop_bwd2(stream, sd[0], sd[1], dcube, B, T, L, 3, D, key(), dmean + (size_t)B * D, dmean + 2 * (size_t)B * D, ds_bf16_live ? 1 : 0));
-  } else {
-    ds_bf16_live = ln_tail_ds_bf16;   // (what the L-axis kernel's tail wrote)
   }
   if (!text_bwd_first) MX(text_bwd());
   // CubeMLP weight gradients: side 1..3, beside the layer-1 BPTT.  Tuning knob MIMRL_BPTT_FIRST=1 captures the BPTT launch in
@@ -483,7 +456,7 @@ int mimrl_handle::encoders_backward(float* dcube) {
   // debugging: make the main stream wait for sides 1..3 (the parked kernels) at point n: 1 before the BPTT, 2 behind the layer-1 BPTT,
   // 3 behind the dh0 product, 4 behind the layer-0 BPTT
   static const int dbg_join_at = dbg_env("MIMRL_DBG_JOIN_AT") ? atoi(dbg_env("MIMRL_DBG_JOIN_AT")) : 0;
-  static const bool bptt_first = knob("MIMRL_BPTT_FIRST") != nullptr;
+  constexpr bool bptt_first = false;
   ev_pre = nullptr;
   if (bptt_first && multi_stream && cfg.encoder == MIMRL_ENCODER_GRU && !deferred.empty()) {
     MX(next_event(&ev_pre));
@@ -547,11 +520,11 @@ int mimrl_handle::gru_layer_backward(int l) {
     MX(dbg_delay(stream, 8));
     // side streams of the GRU weight gradients (tuning knobs).  Sides 1..3 still carry the parked CubeMLP parameter-gradient
     // kernels at this point; sides 0 (text branch), 4 and 5 (kNN sampler, CMI branch) have been idle since the forward pass.
-    static const int l0_side = knob("MIMRL_L0_WG_SIDE") ? atoi(knob("MIMRL_L0_WG_SIDE")) : 1;
-    static const int l1_side0 = knob("MIMRL_L1_WG_SIDE") ? atoi(knob("MIMRL_L1_WG_SIDE")) : 1;
+    constexpr int l0_side = 1;
+    constexpr int l1_side0 = 1;
     MX(fork(1, (l == 0 || l1_side0 == 4) ? 5 : 3));   // the weight gradients below depend on the BPTT only
     if (l0_side == 0 && l == 0) MX(fork(0, 0));
-    static const bool dh0_last = knob("MIMRL_DH0_LAST") != nullptr;   // tuning knob: capture order of dh0 vs the side-stream weight gradients
+    constexpr bool dh0_last = false;   // (an environment knob until round 5: fixed at its measured optimum): capture order of dh0 vs the side-stream weight gradients
     auto dh0_gemm = [&]() -> int {   // gradient to the layer-0 outputs, dh0 = sum_dir dgx_dir . W_ih_l1_dir
       dh0_bf16_live = false;
       // one dual-product GEMM (both directions accumulate in the same output tile), batch = modality
@@ -627,8 +600,8 @@ int mimrl_handle::gru_layer_backward(int l) {
       auto two = [&](GemmDesc& q, long a_o, long b_o, long c_o) { if (both) { q.batch = 4; q.batch_in = 2; q.sa_bo = a_o; q.sb_bo = b_o; q.sc_bo = c_o; } };
       const long o_dg = dg[l][1][0] - dg[l][0][0], o_hp = hprev[l][1][0] - hprev[l][0][0], o_in = both ? h0[1] - h0[0] : 0;
       const long o_wih = gru[1][l][0].w_ih - gru[0][l][0].w_ih, o_whh = gru[1][l][0].w_hh - gru[0][l][0].w_hh;
-      static const int tail_n = knob("MIMRL_TAIL_STREAMS") ? atoi(knob("MIMRL_TAIL_STREAMS")) : 1;   // tuning knobs
-      static const int wg_sides = knob("MIMRL_WG_SIDES") ? atoi(knob("MIMRL_WG_SIDES")) : 3;
+      constexpr int tail_n = 1;   // (an environment knob until round 5: fixed at its measured optimum)
+      constexpr int wg_sides = 3;
       auto pick = [&]() { if (l == 0) { const int q = rr++ % tail_n; return q == 0 ? stream : S(q); } return l1_side0 == 4 ? S(4 + rr++ % 2) : S(1 + rr++ % wg_sides); };
       { GemmDesc q = gemm_tn(dg[l][m][0], 4 * H, in, gf.din, Gm(gf.w_ih), gf.din, G, gf.din, (int)BT_);
         q.batch = 2; q.sa_b = s_dg; q.sb_b = 0; q.sc_b = gr.w_ih - gf.w_ih; q.atomic = 1; two(q, o_dg, o_in, o_wih);

@@ -8,11 +8,8 @@
 // =================================================================================================
 int mimrl_handle::mlp_stack_forward(int nb, int rows, int brows, long p0, long pstride, int nl, const long (*l_off)[2],
                                     const int* dims, const float* in, float* const* act, float* out) {
-  // concat-critic tail (thousands of row tiles): the direct-from-L2 fused variant was the faster one in round 1; with the round-2
-  // GEMM kernels the plain chain wins (cfg3 9.80 vs 10.15 ms), so it is opt-in now (MIMRL_FUSED_MLP_BIG=1)
-  static const bool use_big = knob("MIMRL_FUSED_MLP_BIG") != nullptr;   // tuning knob
-  const bool big_ok = use_big && img_valid && crit_img && rows >= 2048 && dims[0] <= 256;
-  if (bf16 && fused_mlp && (rows <= 512 || big_ok) && mlp_fused_supported(nb, rows, nl, dims)) {   // one launch (mlp_fused.hip)
+  // (stacks with thousands of row tiles -- the unfused concat-critic tail -- take the GEMM chain: cfg3 9.80 vs 10.15 ms in round 2)
+  if (bf16 && fused_mlp && rows <= 512 && mlp_fused_supported(nb, rows, nl, dims)) {   // one launch (mlp_fused.hip)
     MlpFusedArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.nb = nb; fa.rows = rows; fa.brows = brows; fa.nl = nl; fa.pstride = pstride; fa.in = in; fa.out = out;
@@ -50,7 +47,7 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
   const bool use_fused = bf16 && fused_mlp && fused_bwd && imgT_ready && rows <= 512 && nl <= 4 && mlp_fused_supported(nb, rows, nl, dims);
   // single-output top layer (the concat critic's score head) over many rows: one streaming kernel instead of three GEMMs with
   // one real column in 64 (dz, dW, both bias gradients)
-  static const bool no_top1 = knob("MIMRL_NO_TOP1") != nullptr;   // tuning knob
+  constexpr bool no_top1 = false;   // (an environment knob until round 5: fixed at its measured optimum)
   const bool top1 = !use_fused && !no_top1 && dims[nl] == 1 && nl >= 2 && dims[nl - 1] % 4 == 0 && dims[nl - 1] <= 1024 && 1024 % dims[nl - 1] == 0 &&
                     dtmp[0] != nullptr;
   if (wgrad && !use_fused && !top1)   // bias gradient of the top layer; the lower ones come out of the dA GEMM epilogues below
@@ -71,14 +68,14 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     if (wgrad) fa.db_top = CG(p0 + l_off[nl - 1][1]);   // the top layer's bias gradient rides along (was a separate column-sum launch)
     // ... and so does the weight gradient of a narrow top layer (the 2-logit CMI head: not eligible for the grouped launch, it was a
     // 17 us generic GEMM in front of it on the CMI branch of stage 1)
-    static const bool no_top_wg = knob("MIMRL_NO_TOP_WGRAD_FUSE") != nullptr;   // tuning knob
+    constexpr bool no_top_wg = false;   // (an environment knob until round 5: fixed at its measured optimum)
     const bool top_wg = wgrad && !no_top_wg && dims[nl] % 4 != 0 && mlp_bwd_takes_top_wgrad(fa);
     if (top_wg) fa.dw_top = CG(p0 + l_off[nl - 1][0]);
     MX(mlp_stack_bwd_fused(stream, fa));
     if (!wgrad) return MIMRL_OK;
     // the nl weight-gradient GEMMs are independent of each other: on the critical branch (wg_helper >= 0) every second
     // one goes to a helper side stream
-    static const bool no_split = knob("MIMRL_NO_WG_SPLIT") != nullptr;   // tuning knob
+    constexpr bool no_split = false;   // (an environment knob until round 5: fixed at its measured optimum)
     const int hs = (multi_stream && !no_split) ? wg_helper : -1;
     if (hs >= 0) MX(fork(hs, hs));
     GemmDesc gs[MLPF_MAX_LAYERS];
@@ -93,20 +90,20 @@ int mimrl_handle::mlp_stack_backward(int nb, int rows, int brows, long p0, long 
     }
     // the nl weight-gradient products are independent of each other: ONE grouped launch (gemm_group; it falls back to nl launches
     // when a product is not eligible, e.g. the 2-row top layer of the CMI classifiers, which then goes alone)
-    static const bool no_group = knob("MIMRL_NO_WG_GROUP") != nullptr;   // tuning knob: the round-1 schedule (helper stream, alternating)
+    constexpr bool no_group = false;   // (an environment knob until round 5: fixed at its measured optimum): the round-1 schedule (helper stream, alternating)
     if (!no_group) {
       int lo = 0;
       if (top_wg) lo = 1;                                                             // done inside the data-gradient kernel
       else if (dims[nl] % 4 != 0) { MX(G_on(hs >= 0 ? S(hs) : stream, gs[0])); lo = 1; }   // not row-contiguous-eligible: beside the group
       MX(G_group(stream, gs + lo, nl - lo));
     } else {
-      static const int helper_par = knob("MIMRL_WG_SPLIT_PARITY") ? atoi(knob("MIMRL_WG_SPLIT_PARITY")) : 0;   // tuning knob
+      constexpr int helper_par = 0;   // (an environment knob until round 5: fixed at its measured optimum)
       for (int q = top_wg ? 1 : 0; q < nl; ++q) MX(G_on((hs >= 0 && (q & 1) == helper_par) ? S(hs) : stream, gs[q]));
     }
     if (hs >= 0) MX(join(hs, hs));
     return MIMRL_OK;
   }
-  static const bool no_big_side = knob("MIMRL_NO_WG_BIG_SIDE") != nullptr;   // tuning knob
+  constexpr bool no_big_side = false;   // (an environment knob until round 5: fixed at its measured optimum)
   const bool big_side = wgrad && multi_stream && !no_big_side && wg_helper >= 0 && rows >= 2048 && nl <= 3;
   for (int l = nl - 1; l >= 0; --l) {
     const int din_ = dims[l], dout_ = dims[l + 1];
@@ -476,7 +473,7 @@ int mimrl_handle::route_feature_grads() {
   }
   // The F slot's sum is folded into head_bwd (its only consumer); T / A / V are needed only behind the CubeMLP backward: side 0,
   // off the chain (was one launch + a queue hop between the stage-2 estimators and the head: ~20 us)
-  static const bool no_head_gather = knob("MIMRL_NO_HEAD_GATHER") != nullptr;   // tuning knob
+  constexpr bool no_head_gather = false;   // (an environment knob until round 5: fixed at its measured optimum)
   head_gather_on = !no_head_gather && multi_stream && side_on(0);
   if (!head_gather_on) return gather_sum4(stream, g4, B, EMB);
   head_gather = g4.g[0];
@@ -493,7 +490,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   DetDefer det_defer(stream);   // (deterministic build, det.h: the stacks' weight / bias gradients are flushed once, at the end of the stage's estimator work)
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0 && !fp32_site(8), bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
-  static const bool imgt_first = knob("MIMRL_IMGT_FIRST") != nullptr;         // tuning knob
+  constexpr bool imgt_first = false;         // (an environment knob until round 5: fixed at its measured optimum)
   bool imgT_pending = false;
   imgT_ready = false;
   if (frag_side_pending) { MX(join(3, 3)); frag_side_pending = false; }
@@ -519,7 +516,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   static const int dbg_skip = dbg_env("MIMRL_DBG_SKIP_EST") ? atoi(dbg_env("MIMRL_DBG_SKIP_EST")) : 0;   // timing experiments only
   MX(fork(5, 5));
   MX(chain(5, 4));                       // the CMI branch needs the kNN indices
-  static const int interleave = knob("MIMRL_EST_INTERLEAVE") ? atoi(knob("MIMRL_EST_INTERLEAVE")) : 0;
+  constexpr int interleave = 0;
   const bool imgT_late = ((interleave >> (stage - 1)) & 1) && interleave >= 4;   // 4 + mask: the image launches on side 3 are captured behind BOTH forward halves
   auto imgT_launch = [&]() -> int {   // side 3 already waits for the stage boundary (fork above); only the launch was held back
     imgT_pending = false;
@@ -562,7 +559,7 @@ int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
     return MIMRL_OK;
   };
   // capture order of the two branches (graph nodes are dispatched in capture order; bit 0: stage 1, bit 1: stage 2 -> MI first)
-  static const int mi_first = knob("MIMRL_EST_MI_FIRST") ? atoi(knob("MIMRL_EST_MI_FIRST")) : 0;
+  constexpr int mi_first = 0;
   // round 5b: both FORWARD halves are captured in front of either backward half (bit mask like mi_first; default: stage 2).  With the stage
   // boundary inside the critic update both branches hang off the update node directly, and with a whole branch captured first the other
   // branch's first kernel landed on a hardware queue BEHIND the first branch's weight-gradient launch (head-of-line: 49 us late).

@@ -239,7 +239,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
     // dispatched behind them too and then delays the tail (measured: 1.46 vs 1.34 ms).
     // (default since round 4 -- with the kNN sampler's two launches on side 4 the scan there delayed the layer-0 input projection:
     //  cfg2 0.840 -> 0.829 ms, cfg3 6.97 -> 6.87; MIMRL_LENS_SIDE0=0 puts it back)
-    static const bool prefix_split = !(knob("MIMRL_LENS_SIDE0") && atoi(knob("MIMRL_LENS_SIDE0")) == 0);   // tuning knob
+    constexpr bool prefix_split = true;   // (an environment knob until round 5: fixed at its measured optimum)
     if (prefix_split && cfg.encoder == MIMRL_ENCODER_GRU && side_on(0)) {
       // lengths (Model.py:425-432): only the recurrence needs them.  Side 0 has slack (the text projection is needed at the tail);
       // on side 4 the scan sat in front of the video input projection, the longest chain ahead of the layer-0 recurrence
@@ -247,7 +247,7 @@ int mimrl_handle::model_forward(bool train, bool save, int knn_stage, int part) 
       MX(next_event(&ev_lens));
       HIPX(hipEventRecord(ev_lens, S(0)));
     }
-    static const int text_late = knob("MIMRL_TEXT_LATE") ? atoi(knob("MIMRL_TEXT_LATE")) : 0;   // tuning knob (capture order)
+    constexpr int text_late = 0;   // (an environment knob until round 5: fixed at its measured optimum)
     auto text_branch = [this, BT_, D, part, fused_pre, B, T, L, pdrop]() -> int {
       { PrecGuard pg(this, fp32_site(1)); GemmDesc g = gemm_nt(bufs.text, cfg.d_t, P(w_t), cfg.d_t, tx_raw, D, (int)BT_, D, cfg.d_t); g.f16 = fwd_f16; MX(G_on(S(0), g)); }
       MX(dbg_delay(S(0), 10));

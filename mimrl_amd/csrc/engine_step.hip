@@ -11,7 +11,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
   if (!keep_events) ev_next = 0;
   if (stage == 1) {
     static const bool no_share = knob("MIMRL_NO_SHARED_PREFIX") != nullptr;   // tuning knob: evaluate the prefix twice
-    static const bool prefix_split = knob("MIMRL_BEGIN_ON_SIDE") != nullptr;   // tuning knob
+    constexpr bool prefix_split = false;   // (an environment knob until round 5: fixed at its measured optimum)
     const bool share = prefetch && !no_share;
     // counters + scalar reset: the first consumers are the kNN sampler and the recurrence, both behind the join of side 4 in
     // encoders_forward -- in the shared-prefix step it runs on side 4 beside the input projections instead of in front of them
@@ -21,7 +21,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     // front of the recurrence reads the counters or the scalars -- the bookkeeping rides on it (one launch + one gap less on the chain)
     // (measured neutral, 0.970 vs 0.966 ms: the single-thread kernel hides in the gap between two graph launches -- opt-in)
     // (round 4, with the length scan on side 0: -4 us on average over four alternating runs, cfg3 neutral -- on by default; =0: the separate kernel)
-    static const bool want_begin_in_pack = !(knob("MIMRL_BEGIN_IN_PACK") && atoi(knob("MIMRL_BEGIN_IN_PACK")) == 0);   // tuning knob
+    constexpr bool want_begin_in_pack = true;   // (an environment knob until round 5: fixed at its measured optimum)
     begin_in_pack = want_begin_in_pack && share && have_banks && skip_zero && !begin_on_side && l0_packed && cfg.encoder == MIMRL_ENCODER_GRU;
     if (!begin_in_pack) {
       launch_begin_stage(begin_on_side ? side[4] : stream, d_ints, have_banks ? d_ints + 2 : nullptr,
@@ -31,7 +31,7 @@ int mimrl_handle::enqueue_grads(int stage, bool skip_zero) {
     if (!have_banks) return MIMRL_OK;
     if (!skip_zero) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));   // epoch-0 rule: zero loss, no update (Customization.py:97-98, Solver.py:201-203)
     bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
-    static const bool pre_first = knob("MIMRL_PREFETCH_FIRST") != nullptr;   // tuning knob: capture order of the two chains
+    constexpr bool pre_first = false;   // (an environment knob until round 5: fixed at its measured optimum): capture order of the two chains
     auto issue_prefetch = [&](hipEvent_t e) -> int {
       // the stage-2 forward pass of this batch depends on nothing stage 1 changes: one sequential branch on its own
       // stream, into the primary buffers (stage 1 itself works on the alternate set)
@@ -225,7 +225,7 @@ int mimrl_handle::enqueue_apply(int stage) {
   MX(adam_step(stream, a));
   if (have_frag) {
     // combined step: beside the stage boundary on side 3 (the stage-2 estimators join it before their first stack)
-    static const bool inline_frag = knob("MIMRL_FRAG_INLINE") != nullptr;   // tuning knob
+    constexpr bool inline_frag = false;   // (an environment knob until round 5: fixed at its measured optimum)
     FragTable ft = ftab;
     if (fwd_in_adam) {   // only the data-gradient entries are left for the launch
       ft.n = 0;
@@ -398,84 +398,11 @@ int mimrl_handle::run_fwd2_tail() {
   return MIMRL_OK;
 }
 
-// Captured-graph post-processing (diagnostics / tuning knobs, off by default):
-//   MIMRL_GRAPH_DOT=<file>   dump the captured two-stage step (hipGraphDebugDotPrint: kernel names, edges)
-//   MIMRL_GRAPH_REORDER=1    re-insert every node's outgoing edges so that the child with the LONGEST path to a sink comes first.  This
-//                            HIP runtime maps graph nodes to hardware queues by a depth-first walk in which a node's first edge keeps
-//                            the parent's queue and every further edge moves to the next one (tools/hw/graph_order.hip): with the chain's
-//                            continuation first, the chain of dependent launches stays on one in-order queue.
-__global__ void graph_pad_kernel() {}
+// Captured-graph diagnostics: MIMRL_GRAPH_DOT=<file> dumps the captured two-stage step (hipGraphDebugDotPrint: kernel names, edges).
+// (Rounds 4-5 also re-inserted fork edges here -- by height, captured-stream-first, pad nodes, a searched permutation: the captured order
+// was a local optimum of all of them; the machinery went in round 6, git keeps it.)
 static int graph_postprocess(hipGraph_t g) {
   static const char* dot = knob("MIMRL_GRAPH_DOT");
-  static const bool reorder = knob("MIMRL_GRAPH_REORDER") != nullptr;
-  if (reorder) {
-    size_t nn = 0, ne = 0;
-    HIPX(hipGraphGetNodes(g, nullptr, &nn));
-    std::vector<hipGraphNode_t> nodes(nn);
-    HIPX(hipGraphGetNodes(g, nodes.data(), &nn));
-    HIPX(hipGraphGetEdges(g, nullptr, nullptr, &ne));
-    std::vector<hipGraphNode_t> from(ne), to(ne);
-    HIPX(hipGraphGetEdges(g, from.data(), to.data(), &ne));
-    std::vector<std::vector<int>> out(nn);
-    {
-      std::vector<std::pair<hipGraphNode_t, int>> ix(nn);
-      for (size_t i = 0; i < nn; ++i) ix[i] = {nodes[i], (int)i};
-      std::sort(ix.begin(), ix.end());
-      auto idx = [&](hipGraphNode_t n) { return std::lower_bound(ix.begin(), ix.end(), std::make_pair(n, -1))->second; };
-      for (size_t e = 0; e < ne; ++e) out[idx(from[e])].push_back(idx(to[e]));
-    }
-    std::vector<int> h(nn, -1);
-    std::function<int(int)> height = [&](int v) -> int { if (h[v] >= 0) return h[v]; int m = 0; for (int c : out[v]) m = std::max(m, 1 + height(c)); return h[v] = m; };
-    for (size_t v = 0; v < nn; ++v) height((int)v);
-    static const int mode = atoi(knob("MIMRL_GRAPH_REORDER"));   // 1: by height; 2: the child captured on the parent's stream first
-    const auto& ns = capture_streams();
-    auto stream_of = [&](int v) -> hipStream_t { auto it = ns.find(nodes[v]); return it == ns.end() ? (hipStream_t)-1 : it->second; };
-    int changed = 0;
-    for (size_t v = 0; v < nn; ++v) {
-      if (out[v].size() < 2) continue;
-      std::vector<int> o = out[v];
-      if (mode == 4) {   // MIMRL_GRAPH_PERM: digit i = which child of the i-th fork node comes first (0 = as captured)
-        static const char* perm = knob("MIMRL_GRAPH_PERM");
-        static int fork_no = 0;
-        int k = perm && fork_no < (int)strlen(perm) ? (perm[fork_no] >= 'a' ? perm[fork_no] - 'a' + 10 : perm[fork_no] - '0') : 0;
-        ++fork_no;
-        if (k > 0 && k < (int)o.size()) { const int c = o[k]; o.erase(o.begin() + k); o.insert(o.begin(), c); }   // child k first, the others keep their order
-        if (knob("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] fork %d: node %zu, %zu children\n", fork_no - 1, v, o.size());
-      } else if (mode >= 2) {
-        const hipStream_t ps = stream_of((int)v);
-        if (ps == (hipStream_t)-1) continue;
-        std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return (stream_of(a) == ps) > (stream_of(b) == ps); });
-      } else {
-      std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return h[a] > h[b]; });
-      }
-      // mode 3: as 2, and the side children of successive forks are spread over the other queues: k empty nodes in front of them push
-      // them from queue s + 1 to s + 1 + k (k cycles 0, 1, 2 over the forks; MIMRL_GRAPH_PAD=<list of k per fork> overrides)
-      int pads = 0;
-      if (mode == 3 && stream_of(o[0]) == stream_of((int)v)) {
-        static const char* padlist = knob("MIMRL_GRAPH_PAD");
-        static int fork_no = 0;
-        pads = padlist && fork_no < (int)strlen(padlist) ? padlist[fork_no] - '0' : fork_no % 3;
-        ++fork_no;
-      }
-      if (o == out[v] && pads == 0) continue;
-      std::vector<hipGraphNode_t> f(o.size(), nodes[v]), t;
-      for (int c : out[v]) t.push_back(nodes[c]);
-      HIPX(hipGraphRemoveDependencies(g, f.data(), t.data(), t.size()));
-      HIPX(hipGraphAddDependencies(g, &nodes[v], &nodes[o[0]], 1));
-      for (int k = 0; k < pads; ++k) {   // (a one-thread kernel: an EMPTY node in that place cost 200-400 us per step)
-        hipGraphNode_t pn;
-        hipKernelNodeParams kp = {};
-        kp.func = reinterpret_cast<void*>(graph_pad_kernel); kp.gridDim = dim3(1); kp.blockDim = dim3(1); kp.sharedMemBytes = 0;
-        kp.kernelParams = nullptr; kp.extra = nullptr;
-        HIPX(hipGraphAddKernelNode(&pn, g, &nodes[v], 1, &kp));
-      }
-      t.clear();
-      for (size_t c = 1; c < o.size(); ++c) t.push_back(nodes[o[c]]);
-      if (!t.empty()) HIPX(hipGraphAddDependencies(g, f.data(), t.data(), t.size()));
-      ++changed;
-    }
-    if (knob("MIMRL_GRAPH_VERBOSE")) fprintf(stderr, "[graph] %zu nodes, %zu edges, %d fork nodes re-ordered\n", nn, ne, changed);
-  }
   if (dot) HIPX(hipGraphDebugDotPrint(g, dot, hipGraphDebugDotFlagsVerbose));
   return MIMRL_OK;
 }
@@ -498,11 +425,10 @@ int mimrl_handle::run_step() {
   hipGraphExec_t& ex = GS().graph[0][0];
   if (ex && GS().rows[0][0] != bank_rows) retire(ex);   // bank size is baked into the kernel arguments
   if (!ex) {
-    static const bool no_boundary = knob("MIMRL_NO_FUSED_BOUNDARY") != nullptr;   // tuning knob: the round-1 stage boundary
+    constexpr bool no_boundary = false;   // (an environment knob until round 5: fixed at its measured optimum): the round-1 stage boundary
     hipGraph_t g = nullptr;
     if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-    capture_track(knob("MIMRL_GRAPH_REORDER") != nullptr);
     stream = cap_stream;
     fuse_boundary = !no_boundary; skip_imgT_refresh = use_imgT && !no_boundary; wtT_prebuilt = bf_bwd && fused_cube_bwd && !no_boundary;
     wtT_built = false;
@@ -522,7 +448,7 @@ int mimrl_handle::run_step() {
     const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
     if (r != 0) { if (g) (void)hipGraphDestroy(g); return r; }
     if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-    { const int pr = graph_postprocess(g); capture_track(false); if (pr != 0) { (void)hipGraphDestroy(g); return pr; } }
+    { const int pr = graph_postprocess(g); if (pr != 0) { (void)hipGraphDestroy(g); return pr; } }
     const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }

@@ -93,10 +93,6 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16);
 // LDS ring filled by LDS-DMA.  gemm() routes there by itself; gemm_tall_ok() is the eligibility test.
 bool gemm_tall_ok(const GemmDesc& d);
 int gemm_tall(hipStream_t s, const GemmDesc& d);
-// ... and the weight-gradient form C[M, N] += A^T B over K >= 16384 rows, A [K, .] / B [K, .] bf16-stored and row-contiguous (atomic = 1,
-// M <= 1024 in 128-row blocks with the optional A-row gap, N <= 256): LDS-DMA + transposing fragment reads, k split over ~2 workgroups per CU
-bool gemm_tall_tn_ok(const GemmDesc& d);
-int gemm_tall_tn(hipStream_t s, const GemmDesc& d);
 // up to 6 independent GEMMs as ONE launch when they are plain (no second product / operand-reading epilogue), bf16 and of one
 // operand-layout class of the fast path; otherwise n ordinary launches.  No split-K: meant for many small products.
 int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16);

@@ -846,7 +846,7 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
     const int tm = cand[c][0], tn = cand[c][1];
     if (d.M < 64 * tm || d.N < 64 * tn) continue;
     const long t = tiles(tm, tn);
-    static const long min_wgs = knob("MIMRL_GEMM_MIN_WGS") ? atol(knob("MIMRL_GEMM_MIN_WGS")) : 700;   // tuning knob.  Round 3b: 224 -> 700 (cfg2, 4 interleaved runs each: 0.906-0.912 -> 0.886-0.901 ms; 1000 / 1250 the same): a workgroup is a serial prologue - loop - epilogue and a CU overlaps them only ACROSS workgroups, so ~3 per CU beat ~2 larger ones
+    constexpr long min_wgs = 700;   // (an environment knob until round 5: fixed at its measured optimum).  Round 3b: 224 -> 700 (cfg2, 4 interleaved runs each: 0.906-0.912 -> 0.886-0.901 ms; 1000 / 1250 the same): a workgroup is a serial prologue - loop - epilogue and a CU overlaps them only ACROSS workgroups, so ~3 per CU beat ~2 larger ones
     // (not for split-K accumulations over a long reduction: at cfg3's K = 128,000 rows smaller tiles mean more splits and more atomics,
     //  7.11 -> 7.52 ms with 700 for all)
     if (t * split(t) >= ((acc && ktiles > 1024) ? 224 : min_wgs) || c == 2) { pick = c; break; }
@@ -854,7 +854,7 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   // round 5b: weight gradients over a LONG reduction with both operands 16-bit stored and N a multiple of 256 (dW_ih of GRU layer 1:
   // [384 x 256] per direction over B * T rows) take 128 x 256 tiles -- every row of A (dg: the larger operand) is then read by ONE workgroup
   // instead of two; the split-K chunks of a 128 x 128 grid drift apart in time and their re-reads miss the 4 MB L2 (1.39 GB fetched for 0.66)
-  static const int wide_n = knob("MIMRL_GEMM_WIDE_N") ? atoi(knob("MIMRL_GEMM_WIDE_N")) : 0;   // tuning knob: 1 all, 2 M % 256 == 0 only, 3 the others only
+  constexpr int wide_n = 0;   // (an environment knob until round 5: fixed at its measured optimum): 1 all, 2 M % 256 == 0 only, 3 the others only
   const bool wide = wide_n && (wide_n == 1 || (wide_n == 2) == (d.M % 256 == 0)) && acc && ktiles > 1024 && ca == 2 && cb == 2 && d.a_bf16 && d.b_bf16 && d.N % 256 == 0 && d.M >= 128;
   if (wide) {
     p->fast = 1; p->tm = 2; p->tn = 4; p->ca = ca; p->cb = cb;
@@ -873,13 +873,13 @@ static bool fast_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
 void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
   p->fast = 0; p->tm = p->tn = 1; p->ca = p->cb = 0;
   if (fast_plan(d, bf16, p)) return;
-  static const int no_lean = knob("MIMRL_GEMM_NO_LEAN") != nullptr;   // tuning knobs
-  static const int no_big = knob("MIMRL_GEMM_NO_BK128") != nullptr;
+  constexpr int no_lean = 0;   // (an environment knob until round 5: fixed at its measured optimum)
+  constexpr int no_big = 0;
   const bool va = vec_ok_a(d.A, d.sa_m, d.sa_k, d.sa_b) && d.sa_bo % 4 == 0, vb = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
   const bool va2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : true, vb2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : true;
   // lean = 16-byte loads only.  Ragged M / N are fine for k-contiguous operands (rows are clamped in the loader).
   const bool a_kfast = d.sa_k == 1 && (!d.A2 || d.sa2_k == 1), b_kfast = d.sb_k == 1 && d.sb_n != 1 && (!d.B2 || (d.sb2_k == 1 && d.sb2_n != 1));
-  static const int no_ragged = knob("MIMRL_GEMM_NO_RAGGED") != nullptr;
+  constexpr int no_ragged = 0;
   const bool lean = bf16 && !no_lean && (d.M % BM == 0 || (a_kfast && !no_ragged)) && (d.N % BN == 0 || (b_kfast && !no_ragged)) &&
                     va && vb && va2 && vb2 && d.K >= 64;
   const long tiles = (long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM) * d.batch;
@@ -900,7 +900,7 @@ void gemm_plan(const GemmDesc& d, bool bf16, GemmPlan* p) {
 }
 
 int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
-  static const int no_group = knob("MIMRL_GEMM_NO_GROUP") != nullptr;   // tuning knob
+  constexpr int no_group = 0;   // (an environment knob until round 5: fixed at its measured optimum)
   bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUP_MAX;
   int ca = 0, cb = 0;
   long total = 0;
@@ -933,7 +933,7 @@ int gemm_group(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
 }
 
 int gemm_group_splitk(hipStream_t s, const GemmDesc* ds, int n, bool bf16) {
-  static const int no_group = knob("MIMRL_GEMM_NO_GROUPK") != nullptr;   // tuning knob
+  constexpr int no_group = 0;   // (an environment knob until round 5: fixed at its measured optimum)
   bool ok = bf16 && !no_group && n >= 2 && n <= GEMM_GROUPK_MAX;
   int ca = 0, cb = 0;
   long tiles = 0;
@@ -996,10 +996,13 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
     return set_error(MIMRL_ERR_ARG, "gemm: two-level batch supports A, B, C, bias_n only");
   if (bf16 && gemm_tall_ok(d)) return gemm_tall(s, d);   // tall 16-bit-stored (KC, KC) products: the LDS-DMA kernel of gemm_tall.hip
   if (d.c_bf16) return set_error(MIMRL_ERR_ARG, "gemm: a bf16-stored output exists in the tall LDS-DMA kernel only (gemm_tall_ok)");
-  if (bf16 && gemm_tall_tn_ok(d)) return gemm_tall_tn(s, d);   // ... and tall reductions (weight gradients over B*T rows)
   GemmPlan pl;
   gemm_plan(d, bf16, &pl);
-  static const bool trace = knob("MIMRL_GEMM_TRACE") != nullptr;   // diagnostic: which products miss the fast path, and why
+#ifdef MIMRL_GEMM_TRACE_BUILD     // diagnostic build (-DMIMRL_GEMM_TRACE_BUILD): which products miss the fast path, and why
+  constexpr bool trace = true;
+#else
+  constexpr bool trace = false;
+#endif
   if (trace && bf16 && !pl.fast)
     fprintf(stderr, "[gemm] generic: M %d N %d K %d batch %d | A %p sa %ld %ld %ld cls %d | B %p sb %ld %ld %ld cls %d | A2 %d K2 %d bias_m %d beta %g pre %d gu %d atomic %d\n",
             d.M, d.N, d.K, d.batch, (const void*)d.A, d.sa_m, d.sa_k, d.sa_b, fast_class(d.A, d.sa_m, d.sa_k, d.sa_b, d.sa_bo, d.M, d.K, d.a_bf16),
@@ -1016,7 +1019,7 @@ int gemm(hipStream_t s, const GemmDesc& d, bool bf16) {
   ka.vec_b = vec_ok_b(d.B, d.sb_k, d.sb_n, d.sb_b) && d.sb_bo % 4 == 0;
   ka.vec_a2 = d.A2 ? vec_ok_a(d.A2, d.sa2_m, d.sa2_k, d.sa2_b) : 1;
   ka.vec_b2 = d.B2 ? vec_ok_b(d.B2, d.sb2_k, d.sb2_n, d.sb2_b) : 1;
-  static const int no_xcd = knob("MIMRL_GEMM_NO_XCD") != nullptr;   // tuning knob
+  constexpr int no_xcd = 0;   // (an environment knob until round 5: fixed at its measured optimum)
   ka.xcd_remap = !no_xcd;
   static const int dbg_gemm = dbg_env("MIMRL_DBG_GEMM") ? atoi(dbg_env("MIMRL_DBG_GEMM")) : 0;
   ka.dbg = dbg_gemm;

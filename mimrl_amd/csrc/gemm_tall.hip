@@ -277,161 +277,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tall_kernel(TallArgs a) {
   TALL_STAMP(1);
 }
 
-// =====================================================================================================================================
-// Tall REDUCTION products (weight gradients):  C[M, N] += sum_k A[k, am(m)] . B[k, n],  k = B*T rows (128 000 at cfg3), M = 384, N <= 256,
-// both operands stored bf16 and ROW-contiguous ([k][m] / [k][n]: the BPTT's dg rows, h_prev, the layer outputs) -- dW_ih = dgx^T x,
-// dW_hh = dgh^T h_prev of Model.py:254-255's autograd.  In the step these four launches took 1.3 - 1.7 ms of GPU time at cfg3 on the
-// 128 x 128 register-staged split-K kernel (~220 TFLOP/s alone, a third of that beside the layer-0 BPTT).
-//   * workgroup = one 128-row block of M (column offset am: the dgh gap) x all of N x a chunk of k; 8 waves, wave tile 64 x 64 (N = 256)
-//     or 32 x 64 (N = 128); 72 / 48 KiB of LDS: two workgroups per CU;
-//   * BK = 32, three LDS stages filled by LDS-DMA, two k-steps in flight, counted vmcnt, one raw barrier per k-step.  One DMA instruction
-//     = 4 k-rows x 256 B (whole lines); images [k][128 columns] with the 64-byte segment index XOR (k & 3) (applied to the SOURCE address):
-//     the transposing fragment reads (ds_read_b64_tr_b16: 4 k-rows x 16 columns per 16-lane group) then hit four different bank groups;
-//   * rows k >= K of the last k-step are fetched from a zero page; columns >= N / M from a clamped (valid) address into outputs nobody adds;
-//   * epilogue: float atomics (acc_add: order-independent in the deterministic build) into the caller-zeroed output, 2 x 128 B per
-//     instruction.  The k-split is sized for ~2 workgroups per CU: the atomics are (#workgroups x tile) bytes whatever the split.
-// =====================================================================================================================================
-__device__ __attribute__((aligned(256))) unsigned int g_tall_zero[64];
-
-struct TallTnArgs {
-  const char* A; const char* B; float* C;
-  long lda, ldb, ldc;                  // row pitches in elements
-  int M, N, K;
-  int nmb, gap_at, gap;                // 128-row blocks of M; rows >= gap_at live `gap` columns further on in A
-  int nbi, nb;                         // inner batch size (0 = flat), batch entries
-  long sa_bi, sa_bo, sb_bi, sb_bo, sc_bi, sc_bo;
-  int ksplit, steps_per, ksteps;       // k-chunks per (batch entry, m-block); k-steps (of 32) per chunk / in total
-  long wgs;                            // real workgroups = nb * ksplit * nmb (grid is rounded up to a multiple of 8 * nmb)
-};
-
-template <int NB>
-__global__ __launch_bounds__(512, 4) void gemm_tall_tn_kernel(TallTnArgs a) {
-  constexpr int KB = 32, A_BYTES = KB * 256, STAGE = A_BYTES * (1 + NB), NST = 3;
-  constexpr int PPW = (8 + 8 * NB) / 8;        // DMA pieces per wave and k-step: 2 (NB 1) or 3 (NB 2)
-  constexpr int WM = NB == 2 ? 2 : 4, TM = 128 / WM / 32;   // waves along M, 32-row sub-tiles per wave (2 or 1); 64 columns (2 sub-tiles) per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  TALL_DBG_INIT();
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ids equal mod 8 share an XCD; the m-blocks of one (batch entry, k-chunk) -- they read the same B rows -- run side by side on it
-  const unsigned id = blockIdx.x, xcd = id & 7u, j = id >> 3;
-  const unsigned mb = j % (unsigned)a.nmb, grp = (j / (unsigned)a.nmb) * 8u + xcd;
-  if (grp >= (unsigned)(a.nb * a.ksplit)) return;
-  const int b = (int)(grp / (unsigned)a.ksplit), ks = (int)(grp - (unsigned)b * (unsigned)a.ksplit);
-  const int bo = a.nbi > 0 ? b / a.nbi : b, bi = a.nbi > 0 ? b - bo * a.nbi : 0;
-  const char* Ab = a.A + 2 * ((long)bo * a.sa_bo + (long)bi * a.sa_bi);
-  const char* Bb = a.B + 2 * ((long)bo * a.sb_bo + (long)bi * a.sb_bi);
-  float* Cb = a.C + (long)bo * a.sc_bo + (long)bi * a.sc_bi;
-  const int s0 = ks * a.steps_per, s1 = s0 + a.steps_per < a.ksteps ? s0 + a.steps_per : a.ksteps;
-  if (s0 >= s1) return;
-  const int m0 = (int)mb * 128, amo = m0 + (m0 >= a.gap_at ? a.gap : 0);   // first row of the block / its column in A
-
-  // ---- DMA: piece p (0 .. 8 + 8 NB - 1) = 4 k-rows x 256 B of A (p < 8) or of column block (p - 8) / 8 of B; wave w takes p = w, w + 8, w + 16.
-  // lane -> (k-row lane / 16, LDS 64-byte segment (lane / 4) % 4, 16-byte chunk lane % 4) reads source segment (LDS segment) ^ (k & 3)
-  const int krow = lane >> 4, seg = ((lane >> 2) & 3) ^ krow, ch = lane & 3;
-  const char* src[PPW]; long pitch[PPW]; int kro[PPW];
-#pragma unroll
-  for (int q = 0; q < PPW; ++q) {
-    const int p = wave + 8 * q;
-    const bool isA = p < 8;
-    const int pr = isA ? p : (p - 8) & 7, blk = isA ? 0 : (p - 8) >> 3;
-    int col = (isA ? amo : blk * 128) + seg * 32 + ch * 8;          // first of this lane's 8 columns
-    const int lim = isA ? amo + (a.M - m0 < 128 ? a.M - m0 : 128) : a.N;
-    col = col + 8 <= lim ? col : lim - 8;                            // columns past the edge: any valid address (their outputs are never added)
-    src[q] = (isA ? Ab : Bb) + 2 * (long)col;
-    pitch[q] = 2 * (isA ? a.lda : a.ldb);
-    kro[q] = pr * 4 + krow;
-  }
-  const char* zero = reinterpret_cast<const char*>(g_tall_zero) + (lane & 15) * 16;
-  auto issue = [&](int step, int stage) __attribute__((always_inline)) {
-    const int k0 = step * KB;
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-      const int p = wave + 8 * q;
-      const int k = k0 + kro[q];
-      const char* g = k < a.K ? src[q] + (long)k * pitch[q] : zero;
-      if (TALL_DBG(p < 8 ? 1 : 2)) continue;
-      __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(smem + stage * STAGE + p * 1024), 16, 0, 0);
-    }
-  };
-
-  // ---- fragments: lane l of a 32 x 32 x 16 operand holds column (l & 31), k = 8 (l >> 5) .. + 7 of the 16-wide k-slice: two transposing
-  // reads of 4 k-rows x 16 columns per 16-lane group (lane 4 q + p of a group addresses block row q, columns 4 p .. 4 p + 3)
-  typedef __attribute__((address_space(3))) bf16x4 lds4;
-  const int hh = lane >> 5, g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int wmi = wave % WM, wni = wave / WM;          // m part, 64-column part
-  // byte offset inside an image of (k-row 8 hh + q4 (+ 4), 32-column sub-tile t, column 16 g1 + 4 p4): k * 256 + ((t ^ (k & 3)) << 6) + ..
-  const int frow = (8 * hh + q4) * 256 + (16 * g1 + 4 * p4) * 2;
-  auto frag = [&](const char* img, int ksl, int t) __attribute__((always_inline)) {
-    const char* pz = img + ksl * 16 * 256 + frow + ((t ^ q4) << 6);
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4*)(pz));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4*)(pz + 4 * 256));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  };
-  f32x16 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
-
-  const int n = s1 - s0;
-  issue(s0, 0);
-  if (n > 1) issue(s0 + 1, 1);
-  int st = 0, st2 = 2;
-  for (int g = 0; g < n; ++g) {
-    if (g + 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (g + 2 < n) issue(s0 + g + 2, st2);
-    const char* sa = smem + st * STAGE;
-    const char* sb = sa + A_BYTES + (wni >> 1) * A_BYTES;      // column block of this wave (NB = 1: wni < 2)
-#pragma unroll
-    for (int ksl = 0; ksl < 2; ++ksl) {
-      bf16x8 af[TM], bfr[2];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = frag(sa, ksl, wmi * TM + i);
-#pragma unroll
-      for (int jn = 0; jn < 2; ++jn) bfr[jn] = frag(sb, ksl, (wni & 1) * 2 + jn);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) if (!TALL_DBG(4)) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
-    }
-    st = st == NST - 1 ? 0 : st + 1;
-    st2 = st2 == NST - 1 ? 0 : st2 + 1;
-  }
-  // ---- epilogue: D[i][j], i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) -> m, j = lane & 31 -> n
-  if (TALL_DBG(16)) { if (acc[0][0][0] == 123.25f) a.C[0] = 1.f; return; }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-      const int nn = wni * 64 + jn * 32 + (lane & 31);
-      const int mb0 = m0 + (wmi * TM + i) * 32 + 4 * hh;
-      float* c = Cb + (long)mb0 * a.ldc + nn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dm = (r & 3) + 8 * (r >> 2);
-        if (nn < a.N && mb0 + dm < a.M) acc_add(c + (long)dm * a.ldc, acc[i][jn][r]);
-      }
-    }
-}
-
 }  // namespace
 
 bool gemm_tall_ok(const GemmDesc& d) {
   // tuning knobs, read per call (a handful of launches per captured step) so that one test process can run both paths:
-  // MIMRL_NO_GEMM_TALL=1 the 128x128 register-staged kernels as before; MIMRL_GEMM_TALL_MIN_M=<rows> the row threshold (default 4096)
+  // MIMRL_NO_GEMM_TALL=1 the 128x128 register-staged kernels as before (row threshold 4096)
   const char* e_off = knob("MIMRL_NO_GEMM_TALL");
   const bool off = e_off != nullptr && e_off[0] != '0';
-  const char* e_min = knob("MIMRL_GEMM_TALL_MIN_M");
+  const char* e_min = knob("MIMRL_GEMM_TALL_MIN_M");      // (tests lower it so that cfg2-shaped parity cases reach this kernel)
   const long min_m = e_min ? atol(e_min) : 4096;   // (cfg2: B * T = 6400 rows -- 0.801-0.811 vs 0.813-0.825 ms per step against the 128x128 kernels)
-  if (off || !d.a_bf16 || !d.b_bf16 || d.M < min_m) return false;
+  if (off || !d.a_bf16 || !d.b_bf16 || d.b_f16cvt || d.M < min_m) return false;   // (b_f16cvt: fp16 bits to be converted -- only fast_plan's loaders do that)
   if (d.sa_k != 1 || d.sb_k != 1 || d.sc_n != 1) return false;
   if (d.K % TBK != 0 || d.K <= 0 || d.N < 32) return false;
   if (d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.atomic || d.colsum || d.act != ACT_NONE || d.alpha != 1.f) return false;
@@ -490,65 +345,6 @@ int gemm_tall(hipStream_t s, const GemmDesc& d) {
   }
   if (d.f16) hipLaunchKernelGGL((gemm_tall_kernel<true>), dim3(grid), dim3(512), lds, s, a);
   else hipLaunchKernelGGL((gemm_tall_kernel<false>), dim3(grid), dim3(512), lds, s, a);
-  LAUNCH_CHECK();
-  return MIMRL_OK;
-}
-
-// weight-gradient form: C += A^T B with A [K, lda] / B [K, ldb] bf16-stored and row-contiguous, float atomics into a zeroed output
-bool gemm_tall_tn_ok(const GemmDesc& d) {
-  // OPT-IN (MIMRL_GEMM_TALL_TN=1): measured on cfg3's four recurrence weight gradients it ties the 128 x 128 register-staged split-K
-  // kernel (dW_hh 128 vs 137 us, dW_ih 267 vs 230 us alone; 6.20 vs 6.12-6.21 ms per step) -- see DESIGN "measured and not kept"
-  const char* e_on = knob("MIMRL_GEMM_TALL_TN");
-  if (e_on == nullptr || e_on[0] == '0') return false;
-  const char* e_min = knob("MIMRL_GEMM_TALL_TN_MIN_K");
-  const long min_k = e_min ? atol(e_min) : 16384;
-  if (!d.a_bf16 || !d.b_bf16 || d.f16 || d.K < min_k) return false;
-  if (d.sa_m != 1 || d.sb_n != 1 || d.sc_n != 1) return false;                    // A[k][m], B[k][n], C[m][n]
-  if (!d.atomic || d.A2 || d.bias_n || d.bias_m || d.beta != 0.f || d.pre || d.gradact_u || d.colsum || d.act != ACT_NONE || d.alpha != 1.f || d.c_f16 || d.c_bf16) return false;
-  if (d.M % 8 != 0 || d.N % 8 != 0 || d.M < 32 || d.N < 32 || d.N > 256 || d.M > 1024) return false;
-  if (d.sa_k % 8 != 0 || d.sb_k % 8 != 0) return false;
-  if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.B)) & 15) return false;
-  if (d.sa_b % 8 || d.sa_bo % 8 || d.sb_b % 8 || d.sb_bo % 8) return false;
-  if (d.a_gap_rows && (d.a_gap_at % 128 != 0 || d.a_gap_rows % 8 != 0)) return false;
-  if (d.a_pad4 || (d.batch > 1 && d.sc_b == 0 && d.batch_in == 0)) return false;  // (a batch-reduced output is fine too, but untested here)
-  return true;
-}
-
-int gemm_tall_tn(hipStream_t s, const GemmDesc& d) {
-  TallTnArgs a;
-  a.A = reinterpret_cast<const char*>(d.A); a.B = reinterpret_cast<const char*>(d.B); a.C = d.C;
-  a.lda = d.sa_k; a.ldb = d.sb_k; a.ldc = d.sc_m;
-  a.M = d.M; a.N = d.N; a.K = d.K;
-  a.nmb = (d.M + 127) / 128; a.gap_at = d.a_gap_rows ? d.a_gap_at : 0x7fffffff; a.gap = d.a_gap_rows;
-  a.nb = d.batch;
-  if (d.batch_in > 0) { a.nbi = d.batch_in; a.sa_bi = d.sa_b; a.sa_bo = d.sa_bo; a.sb_bi = d.sb_b; a.sb_bo = d.sb_bo; a.sc_bi = d.sc_b; a.sc_bo = d.sc_bo; }
-  else { a.nbi = 0; a.sa_bi = 0; a.sa_bo = d.sa_b; a.sb_bi = 0; a.sb_bo = d.sb_b; a.sc_bi = 0; a.sc_bo = d.sc_b; }
-  a.ksteps = (d.K + 31) / 32;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0; hipDeviceProp_t p;
-    HIPX(hipGetDevice(&dev)); HIPX(hipGetDeviceProperties(&p, dev));
-    cus = p.multiProcessorCount >= 8 ? p.multiProcessorCount : 256;
-  }
-  // ~2 workgroups per CU, at least 16 k-steps each
-  int ksplit = (2 * cus + a.nb * a.nmb - 1) / (a.nb * a.nmb);
-  if (ksplit > a.ksteps / 16) ksplit = a.ksteps / 16;
-  if (ksplit < 1) ksplit = 1;
-  a.steps_per = (a.ksteps + ksplit - 1) / ksplit;
-  a.ksplit = (a.ksteps + a.steps_per - 1) / a.steps_per;
-  const long groups = (long)a.nb * a.ksplit;
-  a.wgs = groups * a.nmb;
-  const long grid = ((groups + 7) / 8) * 8 * a.nmb;
-  const int nbk = d.N > 128 ? 2 : 1;
-  const int lds = 3 * 32 * 256 * (1 + nbk);
-  static bool attr = false;
-  if (!attr) {
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 256 * 2));
-    HIPX(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tall_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 256 * 3));
-    attr = true;
-  }
-  if (nbk == 2) hipLaunchKernelGGL((gemm_tall_tn_kernel<2>), dim3((unsigned)grid), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((gemm_tall_tn_kernel<1>), dim3((unsigned)grid), dim3(512), lds, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

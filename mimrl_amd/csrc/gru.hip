@@ -891,7 +891,7 @@ long gru_saved_floats(int B, int T) {
 }
 
 int gru_pick_btv(int B, int nmod) {
-  static const int force = knob("MIMRL_GRU_BTV") ? atoi(knob("MIMRL_GRU_BTV")) : 0;   // tuning knob
+  constexpr int force = 0;   // (an environment knob until round 5: fixed at its measured optimum)
   if (force >= 1 && force <= BR) return force;
   int btv = (B * nmod * 2 + 127) / 128;      // ~128 workgroups (measured best at B=128: 4 rows per workgroup)
   if (btv < 1) btv = 1;

@@ -567,7 +567,7 @@ KnnPlan knn_plan(int N, int m, int k) {
   p.NTW = (NT + p.S - 1) / p.S;
   p.RP = 4 / p.S;
   const int pairs = (N + 31) / 32;
-  static const int target = knob("MIMRL_KNN_WGS") ? atoi(knob("MIMRL_KNN_WGS")) : 512;   // tuning knob: workgroups per launch
+  constexpr int target = 512;   // (an environment knob until round 5: fixed at its measured optimum): workgroups per launch
   int ppw = (int)(((long)pairs * std::max(nwide, 1) * p.nab + (long)p.RP * target - 1) / ((long)p.RP * target));
   ppw = std::max(1, std::min(ppw, MAXW / p.RP));
   p.ppw = ppw;

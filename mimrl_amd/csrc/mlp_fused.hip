@@ -983,18 +983,12 @@ bool mlp_fused_supported(int nb, int rows, int nl, const int* dims) {
   return dims[nl] >= 1 && dims[nl] <= 256;
 }
 
-// many row tiles per group and every layer width <= 256: weights are hot in L2, read the fragments directly
-static bool mlp_direct(const MlpFusedArgs& a) {
-  if (a.rows < 2048) return false;
-  for (int l = 0; l <= a.nl; ++l)
-    if (a.dims[l] > 256) return false;
-  return true;
-}
-
+// (round 1's direct-from-L2 instantiation for stacks with thousands of row tiles -- mlp_img_kernel<*, true> -- lost to the GEMM chain in round 2
+// and is no longer instantiated: round 6)
 // few workgroups (latency-bound stack): the 8-wave kernel with the register-resident, prefetched weight tile.  Every reduction
 // width must be a whole number of 8-element pieces (16-byte loads) or < 16 (the FMA path).
 static int mlp_small8(const MlpFusedArgs& a, bool bwd) {   // -> 0 (use the 4-wave kernel), or the register chunks needed: 4 / 6
-  static const int waves = knob("MIMRL_MLP_IMG_WAVES") ? atoi(knob("MIMRL_MLP_IMG_WAVES")) : 0;   // tuning knob: 4 = never, 8 = both directions
+  constexpr int waves = 0;   // (an environment knob until round 5: fixed at its measured optimum): 4 = never, 8 = both directions
   if (waves == 4) return 0;
   const long wgs = (long)((a.rows + RT - 1) / RT) * a.nb;
   if (wgs > 512) return 0;
@@ -1044,8 +1038,7 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
     return MIMRL_OK;
   }
   if (a.Wb[0]) {
-    if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<false, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
-    else if (mlp_small8(a, false) == 4) hipLaunchKernelGGL((mlp_img8_kernel<false, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
+    if (mlp_small8(a, false) == 4) hipLaunchKernelGGL((mlp_img8_kernel<false, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
     else if (mlp_small8(a, false) == 6) hipLaunchKernelGGL((mlp_img8_kernel<false, 6>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((mlp_img_kernel<false, false>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
@@ -1058,7 +1051,7 @@ int mlp_stack_fwd_fused(hipStream_t s, const MlpFusedArgs& a) {
 
 bool mlp_bwd_takes_top_wgrad(const MlpFusedArgs& a) {
   if (mlp_frag_shape(a, true)) return a.dims[4] <= 2;
-  return a.WbT[0] && !mlp_direct(a) && mlp_small8(a, true) == 4 && a.nl >= 2 && a.dims[a.nl] * a.dims[a.nl - 1] <= 512;
+  return a.WbT[0] && mlp_small8(a, true) == 4 && a.nl >= 2 && a.dims[a.nl] * a.dims[a.nl - 1] <= 512;
 }
 
 int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
@@ -1079,8 +1072,7 @@ int mlp_stack_bwd_fused(hipStream_t s, const MlpFusedArgs& a_) {
     return MIMRL_OK;
   }
   if (a.WbT[0]) {
-    if (mlp_direct(a)) hipLaunchKernelGGL((mlp_img_kernel<true, true>), dim3((a.rows + RT - 1) / RT, a.nb), dim3(256), 0, s, a);
-    else if (mlp_small8(a, true) == 4) hipLaunchKernelGGL((mlp_img8_kernel<true, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
+    if (mlp_small8(a, true) == 4) hipLaunchKernelGGL((mlp_img8_kernel<true, 4>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((mlp_img_kernel<true, false>), dim3(8 * ((a.rows + RT - 1) / RT) * ((a.nb + 7) / 8)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return MIMRL_OK;

@@ -29,7 +29,6 @@ int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* 
 // ds_bf16: ds is written as a bf16 array (same element indices) -- the layer-1 BPTT reads it as such (GruBwdArgs::dout_bf16)
 int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
                       RngKey key, const float* dmean_a = nullptr, const float* dmean_v = nullptr, int ds_bf16 = 0);
-bool ln_relu_drop_bwd2_bf16_ok();
 // Layer-0 GRU operands in a common, 16-byte-aligned shape.  audio [rows, d_a] and video [rows, d_v] (d = 74 / 35 for MOSI: rows
 // of 296 / 140 bytes, no 16-byte loads possible, and different widths, so no batching) are copied into xpack[2][rows, KP]
 // (zero padded), the four W_ih matrices [384, d] into wpack[2][2][384, KP] and the four b_ih into bpack[2][2][384]: the input

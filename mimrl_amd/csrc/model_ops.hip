@@ -90,54 +90,6 @@ __global__ void ln_relu_drop_fwd_kernel(LnSide s0, LnSide s1, float* __restrict_
   }
 }
 
-template <int PER>
-__global__ void ln_relu_drop_bwd_kernel(LnSide s0, LnSide s1, const float* __restrict__ dcube, long rows, int T, int L, int K,
-                                        RngKey key) {
-  const LnSide& sd = blockIdx.y ? s1 : s0;
-  const float* __restrict__ h2 = sd.h2; const float* __restrict__ gamma = sd.gamma; const float* __restrict__ beta = sd.beta;
-  const float* __restrict__ mean = sd.mean; const float* __restrict__ rstd = sd.rstd;
-  float* __restrict__ ds = sd.ds; float* __restrict__ dgamma = sd.dgamma; float* __restrict__ dbeta = sd.dbeta;
-  const int slot = sd.slot; const float p = sd.p; const uint32_t stream = sd.stream;
-  const float* __restrict__ dmean = sd.dmean;       // optional: gradient of this slot's temporal mean [B, D] (feat_mean backward folded in)
-  const float invT = 1.f / T;
-  constexpr int D = 64 * PER;
-  __shared__ LdsAcc sg[D], sb[D];
-  const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < D; i += blockDim.x) { sg[i].zero(); sb[i].zero(); }
-  __syncthreads();
-  const long wid = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwv = ((long)gridDim.x * blockDim.x) >> 6;
-  float ag[PER], ab[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
-  for (long r = wid; r < rows; r += nwv) {
-    const float* hr = h2 + r * 2 * D;
-    const float mu = mean[r], rs = rstd[r];
-    const long b = r / T, t = r % T;
-    const float* dc = dcube + ((b * L + t) * K + slot) * D;
-    float xh[PER], dxh[PER], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int j = lane + 64 * i;
-      xh[i] = (hr[j] + hr[D + j] - mu) * rs;
-      const float y = xh[i] * gamma[j] + beta[j];
-      float dy = (dc[j] + (dmean ? dmean[b * D + j] * invT : 0.f)) * drop_scale(p, key, stream, (uint32_t)(r * D + j));
-      dy = y > 0.f ? dy : 0.f;
-      ag[i] += dy * xh[i];
-      ab[i] += dy;
-      dxh[i] = dy * gamma[j];
-      s1 += dxh[i];
-      s2 += dxh[i] * xh[i];
-    }
-    s1 = wave_sum(s1) * (1.f / D);
-    s2 = wave_sum(s2) * (1.f / D);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) ds[r * D + lane + 64 * i] = rs * (dxh[i] - s1 - xh[i] * s2);
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) { sg[lane + 64 * i].add(ag[i]); sb[lane + 64 * i].add(ab[i]); }
-  __syncthreads();
-  for (int i = threadIdx.x; i < D; i += blockDim.x) { acc_add(&dgamma[i], sg[i].get()); acc_add(&dbeta[i], sb[i].get()); }
-}
 
 // Round 3: the same backward with 16 lanes per row (D = 128: two float4 per lane and operand), FOUR rows per wave and pass, grid sized
 // by the rows.  The one-row-per-wave kernel above walks its rows as a dependent chain (4-byte loads -> two wave reductions -> stores,
@@ -1095,23 +1047,17 @@ int ln_relu_drop_fwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, float* 
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
-bool ln_relu_drop_bwd2_bf16_ok() { return knob("MIMRL_LN_BWD_WAVE_ROWS") == nullptr; }   // (the round-2 kernel has no bf16 output)
 int ln_relu_drop_bwd2(hipStream_t s, const LnSide2& a, const LnSide2& v, const float* dcube, int B, int T, int L, int K, int D,
                       RngKey key, const float* dmean_a, const float* dmean_v, int ds_bf16) {
   if (D != 128) return set_error(MIMRL_ERR_ARG, "ln_relu_drop: d_common must be 128 (got %d)", D);
   const long rows = (long)B * T;
   const LnSide sa{a.h2, a.gamma, a.beta, a.mean, a.rstd, a.ds, a.dgamma, a.dbeta, a.slot, a.p, a.stream, dmean_a, ds_bf16};
   const LnSide sv{v.h2, v.gamma, v.beta, v.mean, v.rstd, v.ds, v.dgamma, v.dbeta, v.slot, v.p, v.stream, dmean_v, ds_bf16};
-  static const bool old_kernel = knob("MIMRL_LN_BWD_WAVE_ROWS") != nullptr;   // tuning knob: the one-row-per-wave kernel of round 2
-  if (old_kernel && ds_bf16) return set_error(MIMRL_ERR_ARG, "ln_relu_drop_bwd2: the one-row-per-wave kernel writes fp32 only");
-  if (old_kernel) hipLaunchKernelGGL(ln_relu_drop_bwd_kernel<2>, dim3(grid_for(rows * 64, 256, 256), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
-  else {
-    static const int cap_env = knob("MIMRL_LN_BWD_BLOCKS") ? atoi(knob("MIMRL_LN_BWD_BLOCKS")) : 0;   // tuning knob: workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step)
-    // (round 5b, long inputs: 128 workgroups per modality are one wave per SIMD -- 143 us at cfg3's 128 000 rows; 256 -> 139, 512 -> 121,
-    //  1024 -> 129 us: more workgroups hide more latency, and every workgroup ends in 256 same-address float atomics)
-    const int cap = cap_env > 0 ? cap_env : (rows > 16384 ? 512 : 128);
-    hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, cap), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
-  }
+  // workgroups per modality (cfg2: 400 -> 0.935, 200 -> 0.929, 100 -> 0.927, 50 -> 0.939 ms/step; round 5b, long inputs: 128 workgroups per
+  // modality are one wave per SIMD -- 143 us at cfg3's 128 000 rows; 256 -> 139, 512 -> 121, 1024 -> 129 us: more workgroups hide more
+  // latency, and every workgroup ends in 256 same-address float atomics)
+  const int cap = rows > 16384 ? 512 : 128;
+  hipLaunchKernelGGL(ln_relu_drop_bwd16_kernel, dim3((unsigned)std::min<long>((rows + 15) / 16, cap), 2), dim3(256), 0, s, sa, sv, dcube, rows, T, L, K, key);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -1266,7 +1212,7 @@ int kmix_fwd(hipStream_t s, const float* x, float* z, KMixW w, long R, int D) {
 int kmix_bwd(hipStream_t s, const float* x, const float* dz, float* dx, KMixW w, long R, int D) {
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
-  static const int wgs = knob("MIMRL_KMIX_BWD_WGS") ? atoi(knob("MIMRL_KMIX_BWD_WGS")) : 512;   // tuning knob
+  constexpr int wgs = 512;   // (an environment knob until round 5: fixed at its measured optimum)
   const bool exact3 = w.ik == 3 && w.hk == 3 && w.ok == 3 && !w.ln_first && w.drop_p <= 0.f;
   if (exact3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0, true>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
   else if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 0>), dim3(grid_for(R * D, 256, wgs)), dim3(256), 0, s, x, dz, dx, w, R, D);
@@ -1281,7 +1227,7 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
   if (w.ik > KM || w.hk > KM || w.ok > KM) return set_error(MIMRL_ERR_ARG, "kmix: K-axis sizes must be <= %d", KM);
   const int mx = w.ik > w.hk ? (w.ik > w.ok ? w.ik : w.ok) : (w.hk > w.ok ? w.hk : w.ok);
   if (part == 1) {
-    static const int dx_wgs = knob("MIMRL_KMIX_DX_WGS") ? atoi(knob("MIMRL_KMIX_DX_WGS")) : 4096;   // tuning knob
+    constexpr int dx_wgs = 4096;   // (an environment knob until round 5: fixed at its measured optimum)
     const dim3 grid(grid_for(R * D, 256, dx_wgs));
     if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
     else if (mx <= 4) hipLaunchKernelGGL((kmix_bwd_kernel<4, 1>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);
@@ -1291,7 +1237,7 @@ int kmix_bwd_part(hipStream_t s, const float* x, const float* dz, float* dx, KMi
     // atomics) + ~25 us of element work at cfg2; 256 workgroups is the measured optimum (128: 67 us, 256: 53 us, 512: 75 us).  A
     // two-level reduction through scratch slots with a last-arriver finisher was tried and lost (the __threadfence it needs is an
     // L2 write-back on this multi-XCD part: 157 us).
-    static const int pg_wgs = knob("MIMRL_KMIX_PG_WGS") ? atoi(knob("MIMRL_KMIX_PG_WGS")) : 256;
+    constexpr int pg_wgs = 256;
     const int cap = pg_wgs > 0 ? pg_wgs : 256;
     const dim3 grid(grid_for(R * D, 256, cap));
     if (mx <= 3) hipLaunchKernelGGL((kmix_bwd_kernel<3, 2>), grid, dim3(256), 0, s, x, dz, dx, w, R, D);

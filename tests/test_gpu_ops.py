@@ -609,11 +609,11 @@ def test_gemm_tall_two_segments(lib):
 @pytest.mark.parametrize("M,N,K,gap,shared_b", [(384, 128, 20000 + 17, True, False), (384, 256, 16384 + 32 * 5, False, True), (384, 80, 16400, False, True),
                                                  (256, 256, 16384, False, False)])
 def test_gemm_tall_weight_gradient_shape(lib, M, N, K, gap, shared_b, monkeypatch):
-    """csrc/gemm_tall.hip, reduction form (round 5; opt-in with MIMRL_GEMM_TALL_TN=1, it ties the split-K kernel it would replace): C[M, N] += A^T B over K = B*T rows with A [K, 512] / B [K, N] stored bf16 and
+    """The recurrence weight-gradient shapes on the split-K fast path gemm() gives them (round 5 also had an opt-in LDS-DMA kernel for them that
+    tied it; removed in round 6): C[M, N] += A^T B over K = B*T rows with A [K, 512] / B [K, N] stored bf16 and
     row-contiguous -- dW_hh = dgh^T h_prev (A rows [0, 256) u [384, 512) of dg: the gap) and dW_ih = dgx^T x (both directions share B) of
     Model.py:254-255's autograd; batch = (modality, direction); K not a multiple of the 32-row k-step (zero page), N = 80 (the packed
     layer-0 inputs).  Reference: float64 product of the same bf16 operands; the output is accumulated with float atomics over the k-split."""
-    monkeypatch.setenv("MIMRL_GEMM_TALL_TN", "1")
     g = np.random.default_rng(M + N + K)
     a = torch.from_numpy(g.standard_normal((2, 2, K, 512)).astype(np.float32)).to(torch.bfloat16).cuda()       # [modality][direction][K, 512]
     nbm = 1 if shared_b else 2

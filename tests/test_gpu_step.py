@@ -1,5 +1,7 @@
 """-m gpu: the full two-stage step through the C ABI vs (a) reference-generated goldens, (b) the CPU oracle."""
+import json
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -38,7 +40,7 @@ def _record_errors(key, value):
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "gpurun_out", "r05_step_errors.json")
+    path = os.path.join(root, "gpurun_out", "r06_step_errors.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         try:
@@ -923,33 +925,93 @@ def test_critic_update_with_fragment_images_and_stage_boundary_changes_nothing(w
         assert np.isfinite(pa).all() and np.abs(pa - b[1][n]).max() <= 2 * 2 * 4e-3 + 1e-6, n      # (at most two sign-like Adam steps apart)
 
 
-@pytest.mark.parametrize("name,knob", [("cfg1_ragged", "MIMRL_LN_TAIL_FUSE"), ("cfg2_sep", "MIMRL_LN_TAIL_FUSE"), ("cfg3_small", "MIMRL_LN_TAIL_LONG")])
-def test_ln_backward_riding_on_the_laxis_kernel_changes_nothing(name, knob, monkeypatch):
-    """Round 5b (opt-in, MIMRL_LN_TAIL_FUSE=1): in bf16 mode the encoders' LayerNorm + ReLU + dropout backward (Model.py:452-461 under autograd) can ride as the tail of CubeMLP block 0's
-    L-axis backward kernel (cube_bwd_fused.hip: laxis_bwd_kernel<true>, LAxisLnSide): the (sample, slot) dX tile goes through it from LDS with the
-    lane mapping and arithmetic of ln_relu_drop_bwd16_kernel, so ds -- the layer-1 BPTT's input -- is the same bit pattern and every gradient of the
-    main model equals the default two-launch run up to the order of the float atomics (ln_a / ln_v sums, split-K weight gradients)."""
-    if knob == "MIMRL_LN_TAIL_FUSE":          # (the short kernel's tail writes fp32 ds; the default two-launch path stores it as bf16 for the layer-1 BPTT --
-        monkeypatch.setenv("MIMRL_REC16", "0")  #  another rounding point; the LONG instantiation's tail (L > 64) writes bf16 like the two-launch path)
-    res = {}
-    for tag, env in (("two", None), ("fused", "1")):
-        if env:
-            monkeypatch.setenv(knob, env)
-        else:
-            monkeypatch.delenv(knob, raising=False)
-        c, opt, batch, banks, p, eng = make_engine(name, precision="bf16")
-        g = load_golden(name)
-        eng.set_banks(*(banks[k] for k in "CFTAV"))
-        eng.set_anchors(2, g["anchors"][0, 1])
-        eng.stage_grads(2)
-        torch.cuda.synchronize()
-        res[tag] = {n: eng.grads[n].double().cpu().numpy().copy() for n in eng.grads if n.startswith(("rnn_", "ln_", "W_t", "mlp_encoder"))}
-        eng.close()
-    assert sum(n.startswith("rnn_") for n in res["fused"]) == 32 and any(n.startswith("ln_a") for n in res["fused"])
-    for n, ga in res["fused"].items():
-        gb = res["two"][n]
-        scale = np.abs(gb).max() + 1e-30
-        assert np.isfinite(ga).all() and np.abs(ga - gb).max() <= 5e-5 * scale, f"{n}: rel diff {np.abs(ga - gb).max() / scale:.2e}"
+def _registered_knobs():
+    """(name, help) of every row of csrc/knobs.cpp's table -- the one list of environment knobs the native library reads."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimrl_amd", "csrc", "knobs.cpp")).read()
+    return re.findall(r'^\s*\{"(MIMRL_[A-Z0-9_]+)",\s*"[^"]*",\s*"[^"]*",\s*"((?:[^"\\]|\\.)*)"\}', src, flags=re.M)
+
+
+# the value each knob is exercised with (default "1"; knobs whose help starts with "0:" are switched with "0")
+_KNOB_VALUES = {"MIMRL_GRU_WAVES": "8", "MIMRL_GRU_LDS_PAD": "64", "MIMRL_GEMM_TALL_MIN_M": "64", "MIMRL_DBG_DELAY_TAG": "7:20", "MIMRL_FWD_FP32_SITES": "15",
+                "MIMRL_DDP_SPLIT": "0"}
+_KNOB_RUNS = {}
+
+
+def _knob_value(knob, help_):
+    return _KNOB_VALUES.get(knob, "0" if help_.startswith("0:") else "1")
+
+
+def _knob_run(tmp_path_factory, knob, value):
+    """Result of the worker under (knob, value).  The FIRST call runs the whole table (and the default run) four processes at a time -- one
+    process per knob because the library reads most of them once per process -- and caches it: ~40 x 10 s of mostly host time."""
+    if not _KNOB_RUNS:
+        from concurrent.futures import ThreadPoolExecutor
+        root = tmp_path_factory.mktemp("knobs")
+
+        def one(kv):
+            k, v = kv
+            d = root / (k or "default")
+            d.mkdir()
+            env = dict(os.environ, PYTHONPATH=ROOT)
+            for name in [n for n in env if n.startswith("MIMRL_") and n != "MIMRL_LIB_PATH"]:
+                env.pop(name)
+            if k:
+                env[k] = str(d / "graph.dot") if k == "MIMRL_GRAPH_DOT" else v
+            r = subprocess.run([sys.executable, os.path.join(HERE, "knob_worker.py"), str(d / "g.npz")], env=env, capture_output=True, text=True, timeout=900)
+            return (k, v), (r, d)
+
+        jobs = [(None, "")] + [(n, _knob_value(n, h)) for n, h in _registered_knobs()]
+        with ThreadPoolExecutor(4) as ex:
+            _KNOB_RUNS.update(dict(ex.map(one, jobs)))
+    return _KNOB_RUNS[(knob, value)]
+
+
+def test_knob_table_is_small_and_complete():
+    """Round 6: <= 40 registered knobs (99 in round 5: the measured-and-lost kernels and the capture-order switches whose
+    optimum is known are gone), and every knob() site in the sources names a registered row (an unregistered read is only reported at run time)."""
+    import glob
+    import re
+    names = [n for n, _ in _registered_knobs()]
+    assert 20 <= len(names) <= 40 and len(set(names)) == len(names), len(names)
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimrl_amd", "csrc")
+    read = set()
+    for f in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.cpp")):
+        if not f.endswith("knobs.cpp"):
+            read |= set(re.findall(r'knob(?:_on|_int)?\("(MIMRL_[A-Z0-9_]+)"', open(f).read()))
+    assert read == set(names), (sorted(read - set(names)), sorted(set(names) - read))
+
+
+@pytest.mark.parametrize("knob,help_", _registered_knobs(), ids=[n for n, _ in _registered_knobs()])
+def test_every_registered_knob_vs_oracle(knob, help_, tmp_path_factory):
+    """Every environment knob the library still reads (csrc/knobs.cpp) is a pinned path: with the knob set, the bf16 bench mode on `tiny_sep`
+    and `cfg1_cat` gives stage losses / MI / CMI values within the bf16 bands of the ORACLE (autograd of oracle/mimrl_ref.py, itself held to the
+    reference's fixtures), gradient buckets at cosine >= 0.995 / 0.98 to the oracle's, and -- knobs are result-neutral up to rounding points
+    and summation order -- every gradient tensor within 3e-2 (L2, of the tensor's norm) of the default run's; two captured-graph steps stay finite.
+    (ADVICE r04 / r05 both found wrong gradients behind exactly such switches.)"""
+    value = _knob_value(knob, help_)
+    r0, d0 = _knob_run(tmp_path_factory, None, "")
+    assert r0.returncode == 0 and "KNOB_OK" in r0.stdout, "default run: " + r0.stdout[-1500:] + r0.stderr[-3000:]
+    r, d = _knob_run(tmp_path_factory, knob, value)
+    assert r.returncode == 0 and "KNOB_OK" in r.stdout, f"{knob}={value}: " + r.stdout[-1500:] + r.stderr[-3000:]
+    assert "is read but not registered" not in r.stderr
+    if knob == "MIMRL_KNOBS":
+        assert "environment knobs" in r.stderr and all(n in r.stderr for n, _ in _registered_knobs())
+    if knob == "MIMRL_GRAPH_DOT":
+        assert os.path.getsize(d / "graph.dot") > 1000
+    a, b = np.load(d / "g.npz"), np.load(d0 / "g.npz")
+    assert set(a.files) == set(b.files) and len(a.files) > 100
+    worst = ("", 0.0)
+    for k in a.files:
+        ga, gb = a[k].astype(np.float64), b[k].astype(np.float64)
+        nb = np.linalg.norm(gb)
+        rel = np.linalg.norm(ga - gb) / (nb + 1e-30) if nb > 1e-12 else np.abs(ga).max()
+        if rel > worst[1]:
+            worst = (k, float(rel))
+        # (tensors whose gradient cancels to ~0 -- the InfoNCE score-head bias -- are held by the absolute floor)
+        assert np.isfinite(ga).all() and (rel <= 3e-2 or np.abs(ga - gb).max() <= 2e-6), f"{knob}={value}: {k} rel L2 {rel:.3e} vs the default run"
+    _record_errors(f"knob/{knob}={value}", {"worst_tensor": worst[0], "worst_rel_l2_vs_default": worst[1],
+                                           "vs_oracle": json.loads(r.stdout.split("KNOB_OK ", 1)[1].splitlines()[0])})
 
 
 @pytest.mark.parametrize("graph", [False, True])

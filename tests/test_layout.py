@@ -80,7 +80,7 @@ def test_every_knob_is_in_the_table():
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mimrl_amd", "csrc")
     table_src = open(os.path.join(csrc, "knobs.cpp")).read()
     table = set(re.findall(r'^\s*\{"(MIMRL_[A-Z0-9_]+)",', table_src, re.M))
-    assert len(table) > 80
+    assert 20 <= len(table) <= 40     # (99 in round 5)
     used = set()
     for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")):
         if f.endswith("knobs.cpp"):

@@ -8,7 +8,7 @@ b1=$(run X=0);
 names=(x "gru_fwd(x2)" "cube_fwd tail s2" "MI fwd s1" "CMI fwd s1" "MI bwd s1" "CMI bwd s1" "cube_bwd" "gru_bwd(x2)" "wgrad sides(3 streams)" "text GEMM" "kNN s1" "adam(x2)" "cube_fwd tail s1" "CMI fwd s2" "MI fwd s2" "CMI bwd s2" "MI bwd s2" "kNN s2")
 mult=(0 2 1 1 1 1 1 1 2 1 1 1 2 1 1 1 1 1 1)
 for tag in 1 13 2 10 11 3 4 5 6 12 18 15 14 17 16 7 8 9; do
-  ms=$(run MIMRL_DBG_DELAY_TAG=$tag MIMRL_DBG_DELAY_US=$US)
+  ms=$(run MIMRL_DBG_DELAY_TAG=$tag:$US)
   echo "$tag|${names[$tag]}|${mult[$tag]}|$ms"
 done > /tmp/cp.txt
 b2=$(run X=0)

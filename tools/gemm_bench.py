@@ -63,7 +63,6 @@ def run16(name, M, N, K, batch, st, a_shape, w_shape, c_shape, flags, batch_in=0
     byts = A.numel() * 2 * (M if flags & 16 else K) / A.shape[-1] + W.numel() * 2 + Cm.numel() * Cm.element_size()
     print(f"{name:58s} {us:8.1f} us  {flops/us/1e6:8.1f} TF/s  {byts/us/1e6:6.2f} TB/s")
 
-os.environ.setdefault("MIMRL_GEMM_TALL_TN", "1")   # (opt-in kernel: time it here; MIMRL_GEMM_TALL_TN=0 for the split-K kernel)
 for tall in ("1", "0"):
     if tall == "0":
         if os.environ.get("MIMRL_NO_GEMM_TALL"): break
