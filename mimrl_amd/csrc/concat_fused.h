@@ -60,6 +60,10 @@ bool concat_bwd_dq_plan(int E, int B, int* per, int* nwg, int* slots);
 long concat_bwd_dq_scratch(int E, int B);
 int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a);
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a);
+// concat_ws.hip (round 6): the same forward pass with the hidden-layer weights resident in registers (persistent workgroups, two-stage wave
+// pipeline over 32-row units); concat_fwd_fused routes there when concat_fwd_ws_supported
+bool concat_fwd_ws_supported(int B, int hid, int save);
+int concat_fwd_ws(hipStream_t s, const ConcatFwdArgs& a);
 // dw3[e] += ds[e]^T a2[e]  (compact saves: concat_bwd_fused leaves the score head's weight gradient to this streaming launch)
 int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride);
 #ifdef MIMRL_PHASE_PROBE

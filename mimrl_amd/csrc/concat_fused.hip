@@ -559,6 +559,9 @@ bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 &&
 
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a) {
   if (!concat_fwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: batch %d unsupported", a.B);
+  // round 6: the weights-stationary persistent kernel (concat_ws.hip) wherever it applies (B a multiple of 32, compact or no saves);
+  // MIMRL_CONCAT_STREAMED=1 keeps the weight-streaming kernel below (read per call: tests run both in one process)
+  if (concat_fwd_ws_supported(a.B, CH, a.save) && !knob_on("MIMRL_CONCAT_STREAMED")) return concat_fwd_ws(s, a);
   if (!a.scores || a.save < 0 || a.save > 3) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: bad arguments");
   if ((a.save == 1 && !(a.a0 && a.a1 && a.a2)) || (a.save == 2 && !(a.a0b && a.a1b && a.a2)) || (a.save >= 2 && !(a.m0 && a.m1 && a.m2)))
     return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: null save buffer");

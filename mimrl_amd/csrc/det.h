@@ -17,6 +17,9 @@
 
 namespace mimrl {
 
+// gradient-bucket address ranges of ONE engine handle (deterministic build: what a DetDefer scope may defer; unused by the default build)
+struct DetRanges { const void* lo[2] = {nullptr, nullptr}; size_t bytes[2] = {0, 0}; int n = 0; };
+
 #ifdef MIMRL_DET
 struct DetCtx {
   unsigned long long* keys;   // target address, 0 = free
@@ -105,17 +108,16 @@ struct DetNoFlush {                          // host scope: "the launches in her
 // produced them is over) need no flush of their own.  Inside a DetDefer scope (mimrl_handle::model_backward / estimators_all) such launches --
 // known by kernel name, or a GEMM whose output lies in a registered bucket range -- skip it; the scope's end flushes once.  Every other launch
 // flushes as before (and takes the pending sums along: the flush walks the whole dirty list).
-void det_set_bucket_ranges(const void* const* lo, const size_t* bytes, int n);   // (<= 6 ranges; the handle registers its buckets at bind)
-bool det_target_in_bucket(const void* p);
+bool det_target_in_bucket(const void* p);     // inside the innermost DetDefer scope's ranges
 struct DetGemmTarget {                        // gemm(): "the launch below accumulates into this output" (deferred inside a DetDefer scope if it is a bucket)
   explicit DetGemmTarget(const void* c);
   ~DetGemmTarget();
   bool prev_;
 };
-struct DetDefer {
-  explicit DetDefer(hipStream_t s);
+struct DetDefer {                             // `r`: the opening handle's bucket ranges (mimrl_handle::det_ranges, set at bind)
+  DetDefer(hipStream_t s, const DetRanges* r);
   ~DetDefer();
-  hipStream_t s_; bool prev_;
+  hipStream_t s_; bool prev_; const DetRanges* prev_r_;
 };
 int det_overflowed();                        // bit 0: the table ran full; bit 1: a non-finite / out-of-range contribution (both: that
                                              // contribution went through a plain float atomic)
@@ -128,9 +130,8 @@ static DetTuReg det_tu_reg_;
 
 #else   // ---------------------------------------------------------------- default build: plain float atomics
 struct DetNoFlush { explicit DetNoFlush(bool) {} };
-struct DetDefer { explicit DetDefer(hipStream_t) {} };
+struct DetDefer { DetDefer(hipStream_t, const DetRanges*) {} };
 struct DetGemmTarget { explicit DetGemmTarget(const void*) {} };
-inline void det_set_bucket_ranges(const void* const*, const size_t*, int) {}
 inline bool det_target_in_bucket(const void*) { return false; }
 
 __device__ __forceinline__ void acc_add(float* p, float v) { atomicAdd(p, v); }

@@ -68,25 +68,23 @@ int det_flush(hipStream_t s) {
 namespace {
 thread_local bool t_no_flush = false;
 thread_local bool t_defer = false, t_pending = false, t_gemm_in_bucket = false;
-struct Range { const char* lo; size_t bytes; };
-Range g_ranges[6];
-int g_nranges = 0;
-}
-void det_set_bucket_ranges(const void* const* lo, const size_t* bytes, int n) {
-  g_nranges = n < 6 ? n : 6;
-  for (int i = 0; i < g_nranges; ++i) g_ranges[i] = Range{static_cast<const char*>(lo[i]), bytes[i]};
+// the bucket ranges of the handle whose DetDefer scope is open on this thread (round 6: one process-global table, overwritten at every
+// handle's bind and never cleared, classified handle A's GEMM outputs against handle B's ranges -- ADVICE r05)
+thread_local const DetRanges* t_ranges = nullptr;
 }
 bool det_target_in_bucket(const void* p) {
   const char* c = static_cast<const char*>(p);
-  for (int i = 0; i < g_nranges; ++i)
-    if (g_ranges[i].lo && c >= g_ranges[i].lo && c < g_ranges[i].lo + g_ranges[i].bytes) return true;
+  if (!t_ranges) return false;
+  for (int i = 0; i < t_ranges->n; ++i)
+    if (t_ranges->lo[i] && c >= static_cast<const char*>(t_ranges->lo[i]) && c < static_cast<const char*>(t_ranges->lo[i]) + t_ranges->bytes[i]) return true;
   return false;
 }
 DetGemmTarget::DetGemmTarget(const void* c) : prev_(t_gemm_in_bucket) { t_gemm_in_bucket = det_target_in_bucket(c); }
 DetGemmTarget::~DetGemmTarget() { t_gemm_in_bucket = prev_; }
-DetDefer::DetDefer(hipStream_t s) : s_(s), prev_(t_defer) { t_defer = true; }
+DetDefer::DetDefer(hipStream_t s, const DetRanges* r) : s_(s), prev_(t_defer), prev_r_(t_ranges) { t_defer = true; t_ranges = r; }
 DetDefer::~DetDefer() {
   t_defer = prev_;
+  t_ranges = prev_r_;
   if (!t_defer && t_pending) { t_pending = false; (void)det_flush(s_); }
 }
 DetNoFlush::DetNoFlush(bool on) : on_(on), prev_(t_no_flush) { if (on_) t_no_flush = true; }
@@ -109,7 +107,7 @@ bool det_launch_accumulates(const char* name) {
   static const char* const kSafe[] = {"_fwd", "adam_kernel", "images_kernel", "bf16_image", "knn_", "sample_anchors", "seq_lengths", "l0_pack", "l0_unpack",
                                       "text_post", "feat_mean", "tail_pre", "begin_stage", "mae_kernel", "finalize_stage", "stage_boundary",
                                       "cmi_assemble", "copy_rows", "gather_sum4", "wt_transpose", "pad_rows", "mi_bound", "cmi_loss", "pair_expand",
-                                      "pair_reduce", "gauss_baseline", "dbg_spin", "graph_pad", "det_flush", "dropout_inplace", "add_inplace",
+                                      "pair_reduce", "gauss_baseline", "dbg_spin", "det_flush", "dropout_inplace", "add_inplace",
                                       "mi_sep_fused", "gemm_tall_kernel"};
   for (const char* k : kSafe)
     if (std::strstr(name, k)) return false;

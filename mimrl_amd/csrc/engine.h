@@ -115,6 +115,8 @@ struct mimrl_handle {
   Layout layout;
   mimrl_buffers bufs;
   bool bound = false;
+  DetRanges det_ranges;                // deterministic build: this handle's gradient buckets (det.h: DetDefer)
+  float* nce_ws = nullptr;             // per-handle workspace of the row-tiled InfoNCE kernel (estimator_ops.h: NCE_WS_FLOATS)
   bool grads_clean[3] = {true, true, true};   // bucket known to be all-zero (fresh buffers / zeroed by the fused Adam)
   int bank_rows = 0;
   bool bf16 = false;                   // current GEMM operand mode (switched between forward / backward sections)
@@ -454,13 +456,9 @@ struct mimrl_handle {
   int carve();
 
   int G_(const GemmDesc& d) { return G_on(stream, d); }
-  // diagnosis of bf16 fidelity (tools/bf16_diag.py): MIMRL_FWD_FP32_SITES=<mask> runs single forward sites with fp32 operands although the
-  // precision mode says bf16 -- 1: W_t projection, 2: GRU layer-0 input projections, 4: layer-1 input projections, 8: estimator stacks.
-  // Results stay valid (only more precise); tuning knob.
-  static bool fp32_site(int bit) {
-    static const int mask = knob("MIMRL_FWD_FP32_SITES") ? atoi(knob("MIMRL_FWD_FP32_SITES")) : 0;
-    return (mask & bit) != 0;
-  }
+  // (rounds 2-5 had an accuracy-bisection knob here -- MIMRL_FWD_FP32_SITES: single forward sites with fp32 operands in bf16 mode; the rounded-
+  //  operand oracle tests of round 4 replaced that use, the knob went in round 6)
+  static constexpr bool fp32_site(int) { return false; }
   struct PrecGuard {   // run a scope with fp32 GEMM operands
     mimrl_handle* h; bool saved;
     PrecGuard(mimrl_handle* h_, bool force_fp32) : h(h_), saved(h_->bf16) { if (force_fp32) h->bf16 = false; }

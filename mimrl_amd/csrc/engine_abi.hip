@@ -118,9 +118,10 @@ int mimrl_bind(mimrl_handle* h, const mimrl_buffers* b) {
   h->bound = true;
   {   // deterministic build (det.h: DetDefer): the tensors whose accumulated sums nobody reads before the end of a gradient pass -- the two
       // gradient buckets (NOT the packed layer-0 scratch: l0_unpack_grads reads it inside the pass)
-    const void* lo[2] = {b->main_g, b->crit_g};
-    const size_t by[2] = {sizeof(float) * (size_t)h->layout.floats[MIMRL_GROUP_MAIN], sizeof(float) * (size_t)h->layout.floats[MIMRL_GROUP_CRITIC]};
-    det_set_bucket_ranges(lo, by, 2);
+    h->det_ranges.lo[0] = b->main_g; h->det_ranges.lo[1] = b->crit_g;
+    h->det_ranges.bytes[0] = sizeof(float) * (size_t)h->layout.floats[MIMRL_GROUP_MAIN];
+    h->det_ranges.bytes[1] = sizeof(float) * (size_t)h->layout.floats[MIMRL_GROUP_CRITIC];
+    h->det_ranges.n = 2;       // (per handle, handed to every DetDefer scope this handle opens: no process-global table)
   }
   h->part0_done = false;
   h->cur_set = 0;

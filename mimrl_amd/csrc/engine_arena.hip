@@ -193,6 +193,7 @@ int mimrl_handle::carve() {
   MX(take(&d_ints_own, 16));
   d_ints = d_ints_own;
   MX(take(&d_consts, 64));
+  MX(take(&nce_ws, NCE_WS_FLOATS));   // ticket + slots of mi_infonce_rows_kernel (the arena is zeroed once; the kernel resets its ticket)
   size_t gmax = 0;
   MX(carve_fwd(&gmax));
   for (int l = 0; l < 2; ++l)

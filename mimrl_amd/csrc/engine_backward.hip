@@ -401,7 +401,7 @@ int mimrl_handle::flush_deferred(int only_side, hipEvent_t after) {
 // =================================================================================================
 int mimrl_handle::model_backward() {
   Range rg("mimrl.model_backward");
-  DetDefer det_defer(stream);   // deterministic build: one flush of the accumulation table at the end of the pass for everything that only feeds the gradient buckets
+  DetDefer det_defer(stream, &det_ranges);   // deterministic build: one flush of the accumulation table at the end of the pass for everything that only feeds the gradient buckets
   const int B = cfg.batch, T = cfg.seq_len, L = cfg.time_len, D = cfg.d_common;
   const long BT_ = (long)B * T;
   const int nb = cfg.n_blocks;

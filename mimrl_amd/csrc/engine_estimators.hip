@@ -272,7 +272,7 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
   if (has_baseline()) MX(baseline_forward());
   return mi_bound_fwd_bwd(stream, scores, want_grad ? dscores : nullptr, mi_raw, mi_raw + NE_MI, gs_mi(stage), NE_MI, B,
                           cfg.bound_type, stage == 1 ? 0x1fu : 0x07u, has_baseline() ? lbv : nullptr,
-                          has_baseline() && want_grad ? dlbv : nullptr, 2L * B);
+                          has_baseline() && want_grad ? dlbv : nullptr, 2L * B, nce_ws);
 }
 
 int mimrl_handle::cmi_forward(int stage, bool want_grad) {
@@ -487,7 +487,7 @@ int mimrl_handle::route_feature_grads() {
 // all estimator work of one stage, given that knn_launch() already runs on side 4 and the features are ready on `stream`
 int mimrl_handle::estimators_all(int stage, bool want_grad, bool backward) {
   Range rg(stage == 1 ? "mimrl.estimators.stage1 (Model.py:305-341)" : "mimrl.estimators.stage2 (Model.py:343-386)");
-  DetDefer det_defer(stream);   // (deterministic build, det.h: the stacks' weight / bias gradients are flushed once, at the end of the stage's estimator work)
+  DetDefer det_defer(stream, &det_ranges);   // (deterministic build, det.h: the stacks' weight / bias gradients are flushed once, at the end of the stage's estimator work)
   const bool bf_fwd = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0 && !fp32_site(8), bf_bwd = (prec & MIMRL_PREC_BF16_GEMM_BWD) != 0;
   static const bool dbg_skip_imgt = dbg_env("MIMRL_DBG_SKIP_IMGT") != nullptr;   // timing experiments only (stale images: wrong gradients)
   constexpr bool imgt_first = false;         // (an environment knob until round 5: fixed at its measured optimum)

@@ -23,8 +23,12 @@ bool mi_sep_fused_supported(int B);
 int mi_sep_nce_tiled(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B, int do_bwd);
 int mi_sep_fused(hipStream_t s, const float* tout, float* dtout, float* mi, float* mil, const float* gscale, int E, int B,
                  int bound, unsigned lossform, int do_bwd, const float* lb = nullptr, float* dlb = nullptr, long lb_stride = 0);
+// `nce_ws`: NCE_WS_FLOATS zero-initialised floats owned by the caller (one per engine handle): ticket + slots of the row-tiled InfoNCE kernel;
+// nullptr = the one-workgroup-per-estimator kernel, which shares no state between launches
+constexpr int NCE_WS_FLOATS = 16 + 16 * 64;
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
-                     int B, int bound, unsigned lossform, const float* lb = nullptr, float* dlb = nullptr, long lb_stride = 0);
+                     int B, int bound, unsigned lossform, const float* lb = nullptr, float* dlb = nullptr, long lb_stride = 0,
+                     float* nce_ws = nullptr);
 
 // concat critic layer 1:  a1[(i*B+j), c] = relu(P[i,c] + Q[j,c])     P = x Wx^T, Q = y Wy^T + b   (VMI.py:59-65)
 int pair_expand_fwd(hipStream_t s, const float* P, const float* Q, float* a1, int E, int B, int Hd);

@@ -238,11 +238,13 @@ __global__ __launch_bounds__(1024) void mi_bound_kernel(const float* scores, flo
 // estimator instead of ONE: mi_bound_kernel walked each 256 x 256 matrix of cfg3 with a single workgroup (5 CUs busy, 68 + 49 us on the
 // chain of the two stages).  The row sums of a workgroup go to a slot, the last workgroup of an estimator (ticket) adds the slots in order:
 // the value does not depend on arrival order.  B <= 1024 (a row in registers: 16 values per lane).
+// Ticket counters and slots live in a CALLER-owned workspace (NceWs: zeroed once, self-resetting) -- per engine handle, so that two handles
+// on different streams (or an op-level call beside a step) never share a ticket (round 5 kept them in process-global arrays).
 constexpr int NCE_MAX_EST = 16;
-__device__ unsigned g_nce_ticket[NCE_MAX_EST];
-__device__ float g_nce_part[NCE_MAX_EST][64];
+struct NceWs { unsigned ticket[NCE_MAX_EST]; float part[NCE_MAX_EST][64]; };
+static_assert(sizeof(NceWs) <= NCE_WS_FLOATS * sizeof(float), "NCE_WS_FLOATS (estimator_ops.h) too small");
 __global__ __launch_bounds__(1024) void mi_infonce_rows_kernel(const float* __restrict__ scores, float* __restrict__ dscores, float* __restrict__ mi,
-                                                               float* __restrict__ mil, const float* __restrict__ gscale, int B) {
+                                                               float* __restrict__ mil, const float* __restrict__ gscale, int B, NceWs* __restrict__ ws) {
   __shared__ float red[16];
   __shared__ int last;
   const int e = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -273,18 +275,18 @@ __global__ __launch_bounds__(1024) void mi_infonce_rows_kernel(const float* __re
   }
   const float tot = block_sum(part, red);
   if (tid == 0) {
-    g_nce_part[e][blk] = tot;
+    ws->part[e][blk] = tot;
     __threadfence();
-    last = atomicAdd(&g_nce_ticket[e], 1u) == gridDim.x - 1 ? 1 : 0;
+    last = atomicAdd(&ws->ticket[e], 1u) == gridDim.x - 1 ? 1 : 0;
   }
   __syncthreads();
   if (last && tid == 0) {
     __threadfence();
     float s = 0.f;
-    for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&g_nce_part[e][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned b = 0; b < gridDim.x; ++b) s += __hip_atomic_load(&ws->part[e][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     mi[e] = __logf((float)B) + s * invB;
     if (mil) mil[e] = -mi[e];
-    g_nce_ticket[e] = 0u;
+    ws->ticket[e] = 0u;
   }
 }
 
@@ -867,10 +869,10 @@ int mi_sep_nce_tiled(hipStream_t s, const float* tout, float* dtout, float* mi, 
 }
 
 int mi_bound_fwd_bwd(hipStream_t s, const float* scores, float* dscores, float* mi, float* mil, const float* gscale, int E,
-                     int B, int bound, unsigned lossform, const float* lb, float* dlb, long lb_stride) {
+                     int B, int bound, unsigned lossform, const float* lb, float* dlb, long lb_stride, float* nce_ws) {
   if (B > 1024) return set_error(MIMRL_ERR_ARG, "mi_bound: batch %d > 1024 per rank", B);
-  if (bound == BOUND_INFONCE && E <= NCE_MAX_EST) {   // row-wise bound: one wave per row (the general kernel is one workgroup per estimator)
-    hipLaunchKernelGGL(mi_infonce_rows_kernel, dim3((B + 15) / 16, E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B);
+  if (bound == BOUND_INFONCE && E <= NCE_MAX_EST && nce_ws) {   // row-wise bound: one wave per row (the general kernel -- no shared state -- is one workgroup per estimator)
+    hipLaunchKernelGGL(mi_infonce_rows_kernel, dim3((B + 15) / 16, E), dim3(1024), 0, s, scores, dscores, mi, mil, gscale, B, reinterpret_cast<NceWs*>(nce_ws));
     LAUNCH_CHECK();
     return MIMRL_OK;
   }

@@ -14,12 +14,12 @@ struct KnobDef { const char* name; const char* where; const char* dflt; const ch
 const KnobDef kKnobs[] = {
   {"MIMRL_KNOBS", "engine_abi.hip", "", "1: print this table (values in effect) to stderr when a handle is created"},
   {"MIMRL_ADAM_FRAG", "engine_abi.hip", "", "0: combined step with frag_images + stage_boundary as launches behind the critic Adam (round 5a) instead of inside it"},
+  {"MIMRL_CONCAT_STREAMED", "concat_fused.hip", "", "1: the concat critic on the weight-streaming kernels of rounds 2-5 (concat_fused.hip) instead of the weights-stationary ones (concat_ws.hip)"},
   {"MIMRL_DBG_DELAY_TAG", "engine_backward.hip", "-1", "critical-path probe: <tag>[:<us>] -- the phase tag behind which a spin kernel of <us> (default 50) microseconds is injected (tools/critical_path.sh)"},
   {"MIMRL_DDP_SPLIT", "engine_abi.hip", "", "0: the main gradient bucket all-reduced in one piece (in-library RCCL and dist.py)"},
   {"MIMRL_DG_FP32", "engine_abi.hip", "", "BPTT outputs dg / h_prev stored as fp32 instead of bf16"},
   {"MIMRL_DWIH_H16", "engine_abi.hip", "", "0: the layer-1 dW_ih product reads the fp32 layer-0 outputs instead of the recurrence's fp16 copy"},
   {"MIMRL_FWD_BF16", "engine_abi.hip", "", "forward products round to bf16 instead of fp16"},
-  {"MIMRL_FWD_FP32_SITES", "engine.h", "0", "bit mask of forward product sites that keep fp32 MFMA operands in bf16 mode (accuracy bisection)"},
   {"MIMRL_GEMM_NO_FAST", "gemm.hip", "", "no 128x128 / 128x64 / 64x64 fast-path kernels: everything on the generic GEMM"},
   {"MIMRL_GEMM_TALL_MIN_M", "gemm_tall.hip", "", "row threshold of the tall LDS-DMA GEMM (default 4096)"},
   {"MIMRL_GRAPH_DOT", "engine_step.hip", "", "dump the captured two-stage graph to this file (hipGraphDebugDotPrint)"},

@@ -7,8 +7,11 @@ import json
 import os
 import sys
 
+os.environ.setdefault("OMP_NUM_THREADS", "8")      # (the oracle is ~55 k small CPU ops: on a 256-core host all-core threading makes each op a barrier over idle threads)
 import numpy as np
 import torch
+
+torch.set_num_threads(8)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mimrl_amd import _lib  # noqa: E402
