@@ -13,10 +13,9 @@
 //     tile the B operand (one 16-byte LDS read per lane and k-step, shared by the wave's two feature tiles).  A lane then owns ONE pair row and
 //     4 consecutive features per accumulator quad: the next layer's operand tile is written with 8-byte LDS stores (not 2-byte ones), the
 //     ReLU sign word of (row, 32 features) is built in the lane, and the 256 -> 1 score head is a per-lane dot product;
-//   * a two-stage pipeline over UNITS of 32 pair rows: in step s the layer-1 waves work on unit s while the layer-2 waves work on unit s - 1
-//     and all waves generate layer 0 (relu(P_i + Q_j), the separable form of the first Linear) of unit s + 1 -- one barrier per step, every
-//     SIMD always has one wave in its product and one in an epilogue.  LDS reads per unit and layer: 4 waves x 16 KB (the activation tile,
-//     once per 64-feature slice) instead of 160 KB.
+//   * a pipeline over UNITS of 32 pair rows: in iteration t the layer-1 waves work on unit t while the layer-2 waves work on unit t - 2 and
+//     all waves generate layer 0 (relu(P_i + Q_j), the separable form of the first Linear) of unit t + 2; one barrier per TWO iterations.
+//     LDS reads per unit and layer: 4 waves x 16 KB (the activation tile, once per 64-feature slice) instead of 160 KB.
 // The bias is the accumulator's initial value; results are those of concat_fused.hip up to fp32 summation order inside a product.
 #include "concat_fused.h"
 
@@ -28,25 +27,123 @@ constexpr int CH = 256;            // hidden width (VMI.py:13-22 with hidden_dim
 constexpr int UR = 32;             // pair rows per pipeline unit
 constexpr int AP = CH + 8;         // bf16 pitch of an activation tile row (528 B: conflict-free 16-byte fragment reads)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t sign_bits4(float a, float b, float c, float d) {
-  return (a > 0.f ? 1u : 0u) | (b > 0.f ? 2u : 0u) | (c > 0.f ? 4u : 0u) | (d > 0.f ? 8u : 0u);
+// ReLU as ONE v_max_f32 (fmaxf lowers to a canonicalising v_max x, x followed by the max with 0: the accumulators cannot hold a signalling NaN)
+__device__ __forceinline__ float relu1(float x) {
+#ifdef WS_RELU_FMAXF
+  return fmaxf(x, 0.f);
+#else
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+#endif
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// (x, y) -> packed bf16 pair of (relu x, relu y): v_cvt_pk_bf16_f32 + v_pk_max_i16 (a negative bf16 is a negative int16; rounding to bf16 and
+// ReLU commute) -- one vector instruction per VALUE where fp32 v_max + conversion took 1.5.  The matrix pipe and the vector ALU of a SIMD do
+// not overlap across its two waves (measured: tools/hw/concat_ws_bench _xSYNTH), so every vector instruction of an epilogue is step time.
+// (inline asm: from vector builtins the compiler built these pairs element by element -- 88 v_cmp + 97 v_cndmask + 72 v_perm per iteration)
+__device__ __forceinline__ uint32_t relu_pack2(float x, float y) {
+  uint32_t h, r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(x), "v"(y));
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(h));
+  return r;
+}
+// bits |= (lo > 0) << K | (hi > 0) << (K + 1) for a packed pair of ReLU outputs: v_pk_min_u16 with (1, 1), then v_dot2_u32_u16 with
+// (2^K, 2^(K+1)); K <= 14.  `ones` = 0x00010001 in a register.
+template <int K> __device__ __forceinline__ uint32_t sign_pair(uint32_t w, uint32_t bits, uint32_t ones) {
+  uint32_t t;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(w), "v"(ones));
+  const u16x2 wt = {(unsigned short)(1u << K), (unsigned short)(2u << K)};
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, t), wt, bits, false);
+}
+// the 16 accumulator values of a lane in one 32 x 32 tile (features 8 q + 4 lh + i of the tile, q = i-quad) -> their ReLU as four packed bf16x4
+// and their sign bits at the places they have in the (row, 32 features) word
+__device__ __forceinline__ uint32_t relu_tile(const f32x16& acc, uint32_t (&out)[8], unsigned sh_lo, unsigned sh_hi, uint32_t ones) {
+  uint32_t lo = 0u, hi = 0u;                    // quads 0, 1 -> bits 0-3, 8-11 of `lo`; quads 2, 3 -> the same places of `hi` (= bits 16-19, 24-27)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { out[2 * q] = relu_pack2(acc[4 * q], acc[4 * q + 1]); out[2 * q + 1] = relu_pack2(acc[4 * q + 2], acc[4 * q + 3]); }
+  lo = sign_pair<0>(out[0], lo, ones); lo = sign_pair<2>(out[1], lo, ones); lo = sign_pair<8>(out[2], lo, ones); lo = sign_pair<10>(out[3], lo, ones);
+  hi = sign_pair<0>(out[4], hi, ones); hi = sign_pair<2>(out[5], hi, ones); hi = sign_pair<8>(out[6], hi, ones); hi = sign_pair<10>(out[7], hi, ones);
+  return (lo << sh_lo) | (hi << sh_hi);         // sh_lo = 4 lh, sh_hi = 16 + 4 lh
+}
+// DPP move (a VALU instruction, where __shfl_* is an LDS crossbar round trip): 0xB1 / 0x4E = quad_perm [1,0,3,2] / [2,3,0,1], 0x141 = row_half_mirror
+template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true); }
+// x of this lane OR x of the lane 32 away (v_permlane32_swap: the upper half of the first operand trades places with the lower half of the second)
+__device__ __forceinline__ uint32_t or_halves(uint32_t x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return r[0] | r[1];
+}
+__device__ __forceinline__ float add_halves(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// a wave-uniform pointer the optimiser cannot fold a lane offset into (it re-associated base + uniform + lane into a per-lane 64-bit pointer per
+// access site, hoisted all of them out of the step loop and spilled them): the halves pass through v_readfirstlane, the access then uses the
+// scalar-base + 32-bit-lane-offset addressing mode
+// The result is typed as a GLOBAL (address space 1) pointer: through the integer round trip the compiler loses track of the kernel argument
+// the address came from and would emit flat_load / flat_store (which also count on lgkmcnt, i.e. tie the LDS waits to memory traffic).
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ GLOBAL_AS T* uptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (GLOBAL_AS T*)(((unsigned long long)hi << 32) | lo);
+}
+
+// position of a pipeline unit in the [E][B*B] pair-row space, advanced one unit at a time (everything here is wave-uniform: SALU -- the first
+// version divided by runtime values four times per step, half a microsecond of dependent scalar / vector arithmetic per step)
+struct UnitPos {
+  int e, row0;       // estimator, first pair row inside it
+  int gi, gj0;       // x row i and first y row j of the unit (B % 32 == 0: one x row, 32 consecutive y rows)
+  int base;          // e * B*B + row0 (pair rows: < 2^31)
+  __device__ __forceinline__ void advance(int B, int BB) {
+    row0 += UR; base += UR; gj0 += UR;
+    if (gj0 == B) { gj0 = 0; ++gi; }
+    if (row0 == BB) { row0 = 0; gi = 0; ++e; }
+  }
+};
+struct UnitRef { int e, base; };
+
+#ifdef WS_PHASE
+// probe build (tools/hw/concat_ws_bench): 100 MHz ticks per phase, summed over the iterations of workgroup 0, for wave 0 (layer 1) and wave 4
+// (layer 2): 0 phase A, 1 product, 2 phase C, 3 (layer 1: epilogue part of C), 4 copy-out, 5 scores, 6 barrier wait, 7 iterations
+__device__ long long g_ws_phase[2][8];
+__device__ long long g_ws_clk[2];   // shader-clock cycles / 100 MHz ticks of workgroup 0's whole run
+#define WPH_DECL long long wph_t = (long long)wall_clock64()
+#define WPH(i) do { if (blockIdx.x == 0 && (tid == 0 || tid == 256)) { const long long n_ = (long long)wall_clock64(); g_ws_phase[tid >> 8][i] += n_ - wph_t; wph_t = n_; } } while (0)
+#else
+#define WPH_DECL do { } while (0)
+#define WPH(i) do { } while (0)
+#endif
+
 // SAVE: what the backward pass gets (ConcatFwdArgs::save): 0 nothing, 2 bf16 a0 / a1 + fp32 a2 + sign words (stage 1), 3 sign words only
+//
+// Iteration t of a run of U units (t = -2 .. U + 4); a barrier behind every ODD iteration (operand tiles live in rings of four units, every
+// producer is two iterations ahead of its consumer: exactly one barrier in between -- half the barriers of a one-unit step):
+//   layer-1 wave:  P / Q loads of unit t + 2 | product of unit t | epilogue -> act1[t & 3] | layer 0 of unit t + 2 -> act0[(t + 2) & 3]
+//   layer-2 wave:  epilogue of unit t - 3 (the accumulators of its last product) | layer 0 of unit t + 2 from the loads it requested in
+//                  iteration t - 1 | P / Q loads of unit t + 3 | product of unit t - 2
+//   all waves:     stage 1: act1 of unit t - 2 leaves as bf16;  wave 0: scores of unit t - 5
 template <int SAVE>
 __global__ __launch_bounds__(512) void concat_fwd_ws_kernel(ConcatFwdArgs a, int units_e, int total, int per) {
-  __shared__ __attribute__((aligned(16))) __bf16 act0[2][UR][AP];   // layer-0 outputs (operand of layer 1), double-buffered over units
-  __shared__ __attribute__((aligned(16))) __bf16 act1[2][UR][AP];   // layer-1 outputs (operand of layer 2)
+#ifdef WS_PHASE
+  const long long clk0 = (long long)clock64(), wall0 = (long long)wall_clock64();
+#endif
+  __shared__ __attribute__((aligned(16))) __bf16 act0[4][UR][AP];   // layer-0 outputs (operand of layer 1), ring over units
+  __shared__ __attribute__((aligned(16))) __bf16 act1[4][UR][AP];   // layer-1 outputs (operand of layer 2)
   __shared__ __attribute__((aligned(16))) float sbias[2][CH];       // [layer][feature]: each wave writes and reads only its own 64-feature slice
   __shared__ __attribute__((aligned(16))) float sw3[CH];            // score-head weight (layer-2 waves, own slice)
-  __shared__ LdsAcc sc[2][UR];                                      // score sums of a unit over the four layer-2 waves
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  __shared__ LdsAcc sc[4][UR];                                      // score sums of a unit over the four layer-2 waves
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // (uniform: the role branches and every unit index below stay on the scalar unit)
   const int role = wave >> 2, ws = wave & 3;       // role 0: layer 1, role 1: layer 2; ws: 64-feature slice
-  const int B = a.B;
+  const int B = a.B, BB = B * B;
   const int u0 = blockIdx.x * per, U = min(total, u0 + per) - u0;
   if (U <= 0) return;
-  if (tid < 2 * UR) sc[tid >> 5][tid & 31].zero();
+  if (tid < 4 * UR) sc[tid >> 5][tid & 31].zero();
   bf16x8 wf[2][16];                                // this wave's weight slice: [feature tile][k-step], A fragments of v_mfma_f32_32x32x16_bf16
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
@@ -55,138 +152,278 @@ __global__ __launch_bounds__(512) void concat_fwd_ws_kernel(ConcatFwdArgs a, int
 #pragma unroll
       for (int i = 0; i < 8; ++i) wf[ct][ks][i] = (__bf16)0.f;
   int my_e = -1;
-  const int c4 = lane * 4;                         // layer-0 generation: lane = column quad, wave w = rows w, w + 8, w + 16, w + 24 of the unit
+  float b3e = 0.f;                                 // score-head bias of the current estimator (layer-2 waves)
+  const unsigned c4 = lane * 4;                    // layer-0 generation: lane = column quad, wave w = rows w, w + 8, w + 16, w + 24 of the unit
+  const unsigned nib_sh = 4 * (lane & 7);
+  const unsigned lane8 = lane >> 3, lr8 = lr * 8;  // sign-word slots: (row of the wave, 32-column group of the lane) / (row of the lane)
+  const unsigned row_k = lr * CH + 8 * lh;         // [row of the lane][k half] in a [.][256] array: weight fragments
+  const unsigned row_f = lr * CH + 4 * lh;         // [row of the lane][feature quad half]: fp32 a2
+  const unsigned sh_lo = 4 * lh, sh_hi = 16 + 4 * lh;
+  uint32_t ones = 0x00010001u;
+  asm volatile("" : "+v"(ones));                  // (a register operand of v_pk_min_u16: kept out of constant folding)
   float4 xq = make_float4(0.f, 0.f, 0.f, 0.f), yq[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) yq[q] = xq;
-#pragma unroll 1
-  for (int s = -1; s <= U + 1; ++s) {
-    // ---- (1) layer 0 of unit s + 1: request P_i / Q_j now, use them behind the product
-    const bool gen_on = s + 1 < U;
-    long gbase = 0;                                // first pair row of unit s + 1 in the [E][B*B] row space
-    if (gen_on) {
-      const int lin = u0 + s + 1, ge = lin / units_e, grow0 = (lin - ge * units_e) * UR;
-      gbase = (long)ge * B * B + grow0;
-      const int gi = grow0 / B, gj0 = grow0 - gi * B;      // B % 32 == 0: a unit is one x row i and 32 consecutive y rows j
-      const float* __restrict__ Pp = a.P + ((long)ge * B + gi) * CH + c4;
-      const float* __restrict__ Qp = a.Q + ((long)ge * B + gj0 + wave) * CH + c4;
-      xq = *reinterpret_cast<const float4*>(Pp);
+  f32x16 acc[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) yq[q] = *reinterpret_cast<const float4*>(Qp + (long)(8 * q) * CH);
-    }
-    // ---- (2) this wave's layer on its unit: layer 1 on unit s, layer 2 on unit s - 1
-    const int pu = s - role;
-    if (pu >= 0 && pu < U) {
-      const int lin = u0 + pu, e = lin / units_e, row0 = (lin - e * units_e) * UR;
-      const long prow = (long)e * B * B + row0 + lr;       // this lane's pair row
-      if (e != my_e) {                                     // (wave-uniform) first unit / the run entered the next estimator: this wave's slice
-        my_e = e;
-        const __bf16* __restrict__ W = (role ? a.W2 : a.W1) + (long)e * a.pstride + (long)(ws * 64 + lr) * CH + 8 * lh;
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  // unit cursors: G2 / G3 = units t + 2 / t + 3 (layer-0 generation), R[k] = unit t - k (k = -1 .. 5 kept as R1m, R0 .. R5)
+  UnitPos G2, G3;
+  G2.e = u0 / units_e; G2.row0 = (u0 - G2.e * units_e) * UR; G2.base = G2.e * BB + G2.row0;
+  G2.gi = G2.row0 / B; G2.gj0 = G2.row0 - G2.gi * B;
+  G3 = G2; G3.advance(B, BB);                      // (t = -2: unit t + 2 = unit 0)
+  UnitRef R1m = {G2.e, G2.base}, R0 = R1m, R1 = R1m, R2 = R1m, R3 = R1m, R4 = R1m, R5 = R1m;
+
+  auto issue_gen_loads = [&](const UnitPos& u) __attribute__((always_inline)) {
+    // (every global address below = a wave-uniform 64-bit base + ONE of a handful of unsigned 32-bit lane offsets: saddr + voffset addressing.
+    //  Per-lane 64-bit pointers for each of the ~12 access sites were hoisted out of the step loop and spilled: 26-43 scratch registers)
+    const GLOBAL_AS float* Pp = uptr(a.P + ((long)u.e * B + u.gi) * CH);
+    const GLOBAL_AS float* Qp = uptr(a.Q + ((long)u.e * B + u.gj0 + wave) * CH);
+    { const f32x4v t_ = *(const GLOBAL_AS f32x4v*)(Pp + c4); xq = make_float4(t_[0], t_[1], t_[2], t_[3]); }
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) wf[ct][ks] = *reinterpret_cast<const bf16x8*>(W + (long)(ct * 32) * CH + ks * 16);
-        sbias[role][ws * 64 + lane] = ((role ? a.b2 : a.b1) + (long)e * a.pstride)[ws * 64 + lane];
-        if (role) sw3[ws * 64 + lane] = a.w3[(long)e * a.pstride + ws * 64 + lane];
-        __builtin_amdgcn_wave_barrier();                   // (LDS operations of one wave complete in order: the reads below see these)
+    for (int q = 0; q < 4; ++q) { const f32x4v t_ = *(const GLOBAL_AS f32x4v*)(Qp + (long)(8 * q) * CH + c4); yq[q] = make_float4(t_[0], t_[1], t_[2], t_[3]); }
+  };
+  // layer 0 of unit u -> act0[buf] (read by the layer-1 waves two iterations on), its sign words, stage 1: its bf16 copy.
+  // ALL the arithmetic first, then the stores, and no store sits behind a lane branch: stores count on vmcnt like loads, and behind a branch
+  // the compiler waits with vmcnt(0) -- the second quad's P / Q values then waited for the FIRST quad's sign-word store to complete (a memory
+  // round trip per quad: 40 of the first version's 148 us).  Every lane of an 8-lane group stores the group's word (same address, same value).
+  auto gen_finish = [&](const UnitPos& u, int buf) __attribute__((always_inline)) {
+    uint32_t bq[4][2];
+    uint32_t nq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bq[q][0] = relu_pack2(xq.x + yq[q].x, xq.y + yq[q].y);
+      bq[q][1] = relu_pack2(xq.z + yq[q].z, xq.w + yq[q].w);
+      if (SAVE >= 2) {   // sign word of (row, 32 columns) = the nibbles of 8 neighbouring lanes (this wave holds one row: lane = column quad)
+        uint32_t w = sign_pair<2>(bq[q][1], sign_pair<0>(bq[q][0], 0u, ones), ones) << nib_sh;   // this lane's nibble at its place in its group's word ...
+        w |= dpp<0xB1>(w);                                          // ... OR over the group, butterfly: lane ^ 1 (quad_perm [1,0,3,2]),
+        w |= dpp<0x4E>(w);                                          //     lane ^ 2 (quad_perm [2,3,0,1]),
+        w |= dpp<0x141>(w);                                         //     the other quad of the group (row_half_mirror)
+        nq[q] = w;                                                  // every lane of the group holds the word
       }
-      f32x16 acc[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = wave + 8 * q;
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      u32x2 b; b[0] = bq[q][0]; b[1] = bq[q][1];
+      *reinterpret_cast<u32x2*>(&act0[buf][row][c4]) = b;
+      if (SAVE == 2) { GLOBAL_AS __bf16* o = uptr(a.a0b + ((long)u.base + row) * CH); *(GLOBAL_AS u32x2*)(o + c4) = b; }
+      if (SAVE >= 2) { GLOBAL_AS uint32_t* o = uptr(a.m0 + ((long)u.base + row) * 8); o[lane8] = nq[q]; }
+    }
+  };
+  // this wave's slice of its layer for estimator e (first unit / the run entered the next estimator)
+  auto ensure_weights = [&](int e) __attribute__((always_inline)) {
+    if (e != my_e) {
+      my_e = e;
+      const GLOBAL_AS __bf16* W = uptr((role ? a.W2 : a.W1) + (long)e * a.pstride + (long)(ws * 64) * CH);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                      // accumulator quad q of tile ct = features 64 ws + 32 ct + 8 q + 4 lh + (0..3): starts at the bias
-          const float4 bb = *reinterpret_cast<const float4*>(&sbias[role][ws * 64 + ct * 32 + 8 * q + 4 * lh]);
-          acc[ct][4 * q] = bb.x; acc[ct][4 * q + 1] = bb.y; acc[ct][4 * q + 2] = bb.z; acc[ct][4 * q + 3] = bb.w;
-        }
-      const __bf16 (*src)[AP] = role ? act1[(s - 1) & 1] : act0[s & 1];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&src[lr][ks * 16 + 8 * lh]);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], bfr, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], bfr, acc[1], 0, 0, 0);
-      }
-      if (role == 0) {
-        // layer 1 epilogue: ReLU -> bf16 operand tile of layer 2 (8-byte LDS stores) + the sign word of (row, 32 features)
-        __bf16 (*dst)[AP] = act1[s & 1];
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          uint32_t bits = 0u;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float v0 = fmaxf(acc[ct][4 * q], 0.f), v1 = fmaxf(acc[ct][4 * q + 1], 0.f), v2 = fmaxf(acc[ct][4 * q + 2], 0.f), v3 = fmaxf(acc[ct][4 * q + 3], 0.f);
-            bf16x4 b; b[0] = to_bf16(v0); b[1] = to_bf16(v1); b[2] = to_bf16(v2); b[3] = to_bf16(v3);
-            *reinterpret_cast<bf16x4*>(&dst[lr][ws * 64 + ct * 32 + 8 * q + 4 * lh]) = b;
-            if (SAVE >= 2) bits |= sign_bits4(v0, v1, v2, v3) << (8 * q);
-          }
-          if (SAVE >= 2) {
-            bits <<= 4 * lh;
-            bits |= (uint32_t)__shfl_xor((int)bits, 32);
-            if (lh == 0) a.m1[prow * 8 + ws * 2 + ct] = bits;
-          }
-        }
-      } else {
-        // layer 2 epilogue: ReLU -> sign word, fp32 a2 (stage 1: the score head's weight gradient reads it), score head partial dot product
-        float hp = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          uint32_t bits = 0u;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f0 = ws * 64 + ct * 32 + 8 * q + 4 * lh;
-            float4 v;
-            v.x = fmaxf(acc[ct][4 * q], 0.f); v.y = fmaxf(acc[ct][4 * q + 1], 0.f); v.z = fmaxf(acc[ct][4 * q + 2], 0.f); v.w = fmaxf(acc[ct][4 * q + 3], 0.f);
-            const float4 w3v = *reinterpret_cast<const float4*>(&sw3[f0]);
-            hp += v.x * w3v.x + v.y * w3v.y + v.z * w3v.z + v.w * w3v.w;
-            if (SAVE == 2) *reinterpret_cast<float4*>(a.a2 + prow * CH + f0) = v;
-            if (SAVE >= 2) bits |= sign_bits4(v.x, v.y, v.z, v.w) << (8 * q);
-          }
-          if (SAVE >= 2) {
-            bits <<= 4 * lh;
-            bits |= (uint32_t)__shfl_xor((int)bits, 32);
-            if (lh == 0) a.m2[prow * 8 + ws * 2 + ct] = bits;
-          }
-        }
-        hp += __shfl_xor(hp, 32);
-        if (lh == 0) sc[(s - 1) & 1][lr].add(hp);
-      }
+        for (int ks = 0; ks < 16; ++ks) wf[ct][ks] = *(const GLOBAL_AS bf16x8*)(W + (long)(ct * 32) * CH + ks * 16 + row_k);
+      sbias[role][ws * 64 + lane] = ((role ? a.b2 : a.b1) + (long)e * a.pstride)[ws * 64 + lane];
+      if (role) { sw3[ws * 64 + lane] = a.w3[(long)e * a.pstride + ws * 64 + lane]; b3e = a.b3[(long)e * a.pstride]; }
+      __builtin_amdgcn_wave_barrier();                   // (LDS operations of one wave complete in order: the reads below see these)
     }
-    // ---- (3) stage 1: the finished layer-1 tile of unit s - 1 leaves as bf16 in whole 512-byte rows (operand of the dW2 product)
-    if (SAVE == 2 && s >= 1 && s <= U) {
-      const int lin = u0 + s - 1, e = lin / units_e, row0 = (lin - e * units_e) * UR;
-      __bf16* __restrict__ o = a.a1b + ((long)e * B * B + row0) * CH;
+  };
+  auto product = [&](const __bf16 (*src)[AP]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int idx = tid + 512 * q, row = idx >> 5, c8 = (idx & 31) * 8;
-        *reinterpret_cast<u32x4*>(o + (long)row * CH + c8) = *reinterpret_cast<const u32x4*>(&act1[(s - 1) & 1][row][c8]);
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                      // accumulator quad q of tile ct = features 64 ws + 32 ct + 8 q + 4 lh + (0..3): starts at the bias
+#ifdef WS_X_NOBIAS
+        const float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+        const float4 bb = *reinterpret_cast<const float4*>(&sbias[role][ws * 64 + ct * 32 + 8 * q + 4 * lh]);
+#endif
+        acc[ct][4 * q] = bb.x; acc[ct][4 * q + 1] = bb.y; acc[ct][4 * q + 2] = bb.z; acc[ct][4 * q + 3] = bb.w;
       }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+#ifdef WS_X_NOLDSREAD
+      const bf16x8 bfr = wf[1][15 - ks];
+      (void)src;
+#else
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&src[lr][ks * 16 + 8 * lh]);
+#endif
+#ifdef WS_X_NOMFMA
+      acc[0][ks] += (float)bfr[0] * (float)wf[0][ks][0]; acc[1][ks] += (float)bfr[1] * (float)wf[1][ks][0];
+#else
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], bfr, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], bfr, acc[1], 0, 0, 0);
+#endif
     }
-    // ---- (4) layer 0 of unit s + 1 -> act0[(s + 1) & 1] (read by the layer-1 waves in the next step), its sign words, stage 1: its bf16 copy
-    if (gen_on) {
+  };
+  // layer 1: ReLU -> bf16 operand tile of layer 2 (8-byte LDS stores) + the sign word of (row, 32 features)
+  auto epilogue1 = [&](const UnitRef& u, int buf) __attribute__((always_inline)) {
+#ifdef WS_X_NOEPI
+    { float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[0][r] + acc[1][r];
+      if (t == 1.2345f) { GLOBAL_AS float* o = uptr(a.scores + u.base); o[(unsigned)lr] = t; } }
+    return;
+#endif
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      uint32_t pk[8];
+      uint32_t bits = relu_tile(acc[ct], pk, sh_lo, sh_hi, ones);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = wave + 8 * q;
-        float4 v;
-        v.x = fmaxf(xq.x + yq[q].x, 0.f); v.y = fmaxf(xq.y + yq[q].y, 0.f); v.z = fmaxf(xq.z + yq[q].z, 0.f); v.w = fmaxf(xq.w + yq[q].w, 0.f);
-        bf16x4 b; b[0] = to_bf16(v.x); b[1] = to_bf16(v.y); b[2] = to_bf16(v.z); b[3] = to_bf16(v.w);
-        if (SAVE == 2) *reinterpret_cast<bf16x4*>(a.a0b + (gbase + row) * CH + c4) = b;
-        if (SAVE >= 2) {   // sign word of (row, 32 columns) = the nibbles of 8 neighbouring lanes (this wave holds one row: lane = column quad)
-          uint32_t nib = sign_bits4(v.x, v.y, v.z, v.w);
-          nib |= (uint32_t)__shfl_down((int)nib, 1) << 4;
-          nib |= (uint32_t)__shfl_down((int)nib, 2) << 8;
-          nib |= (uint32_t)__shfl_down((int)nib, 4) << 16;
-          if ((lane & 7) == 0) a.m0[(gbase + row) * 8 + (lane >> 3)] = nib;
-        }
-        *reinterpret_cast<bf16x4*>(&act0[(s + 1) & 1][row][c4]) = b;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 b; b[0] = pk[2 * q]; b[1] = pk[2 * q + 1];
+        *reinterpret_cast<u32x2*>(&act1[buf][lr][ws * 64 + ct * 32 + 8 * q + 4 * lh]) = b;
+      }
+      if (SAVE >= 2) {
+        bits = or_halves(bits);
+        { GLOBAL_AS uint32_t* o = uptr(a.m1 + (long)u.base * 8 + ws * 2 + ct); o[lr8] = bits; }   // (both halves hold the word: no lane branch around a store)
       }
     }
-    // ---- (5) scores of unit s - 2 (complete since the last barrier)
-    if (s >= 2 && tid < UR) {
-      const int lin = u0 + s - 2, e = lin / units_e, row0 = (lin - e * units_e) * UR;
-      a.scores[(long)e * B * B + row0 + tid] = sc[s & 1][tid].get() + a.b3[(long)e * a.pstride];
-      sc[s & 1][tid].zero();
+  };
+  // layer 2: ReLU -> sign word, fp32 a2 (stage 1: the score head's weight gradient reads it), score head partial dot product
+  auto epilogue2 = [&](const UnitRef& u, int slot) __attribute__((always_inline)) {
+#ifdef WS_X_NOEPI
+    { float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[0][r] + acc[1][r];
+      if (t == 1.2345f) { GLOBAL_AS float* o = uptr(a.scores + u.base); o[(unsigned)lr] = t; } }
+    return;
+#endif
+    float hp = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      if (SAVE >= 2) {
+        uint32_t pk[8];
+        const uint32_t bits = or_halves(relu_tile(acc[ct], pk, sh_lo, sh_hi, ones));
+        { GLOBAL_AS uint32_t* o = uptr(a.m2 + (long)u.base * 8 + ws * 2 + ct); o[lr8] = bits; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = ws * 64 + ct * 32 + 8 * q + 4 * lh;
+        float4 v;
+        v.x = relu1(acc[ct][4 * q]); v.y = relu1(acc[ct][4 * q + 1]); v.z = relu1(acc[ct][4 * q + 2]); v.w = relu1(acc[ct][4 * q + 3]);
+        const float4 w3v = *reinterpret_cast<const float4*>(&sw3[f0]);
+        hp += v.x * w3v.x + v.y * w3v.y + v.z * w3v.z + v.w * w3v.w;
+        if (SAVE == 2) { GLOBAL_AS float* o = uptr(a.a2 + (long)u.base * CH + ws * 64 + ct * 32 + 8 * q); f32x4v t_ = {v.x, v.y, v.z, v.w}; *(GLOBAL_AS f32x4v*)(o + row_f) = t_; }
+      }
     }
+    hp = add_halves(hp);
+    if (ws == 0) hp += b3e;                              // (the score head's bias, once per row)
+    if (lh == 0) sc[slot][lr].add(hp);
+  };
+
+#ifdef WS_X_NOGEN
+  const bool gen_any = false;
+#else
+  const bool gen_any = true;
+#endif
+  if (role == 1 && gen_any) issue_gen_loads(G2);         // (layer-2 waves use their loads at the START of an iteration: unit 0's go out here)
+  WPH_DECL;
+#pragma unroll 1
+  for (int t = -2; t <= U + 4; ++t) {
+    const bool gen_on = gen_any && t + 2 < U;            // unit t + 2 exists: its layer 0 is generated in this iteration
+    // phase A (vector work of the layer-2 waves; the layer-1 waves only request their loads)
+    if (role == 0) {
+      if (gen_on) issue_gen_loads(G2);
+    } else {
+      if (t >= 3 && t - 3 < U) epilogue2(R3, (t - 3) & 3);   // (the accumulators of the product at the end of the last iteration)
+      if (gen_on) gen_finish(G2, (t + 2) & 3);
+      if (gen_any && t + 3 < U) issue_gen_loads(G3);     // (used at the start of the NEXT iteration: in flight over this one's product --
+                                                         //  requested behind the product they arrived ~0.5 us late, every iteration)
+    }
+    WPH(0);
+#ifdef WS_X_SYNTH
+    // synthetic co-issue test: layer-1 waves = 64 MFMAs per iteration (SYNTH & 1), layer-2 waves = 512 independent VALU FMAs (SYNTH & 2)
+    if (role == 0 && (WS_X_SYNTH & 1)) {
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], wf[1][15 - ks], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], wf[0][15 - ks], acc[1], 0, 0, 0);
+        }
+    }
+    if (role == 0 && (WS_X_SYNTH & 4)) {     // ONE wave: 8 independent vector FMAs behind every MFMA
+      float f[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f[r] = xq.x + r;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][ks], wf[1][15 - ks], acc[0], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) f[r] = f[r] * 1.0001f + 0.5f;
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][ks], wf[0][15 - ks], acc[1], 0, 0, 0);
+#pragma unroll
+          for (int r = 8; r < 16; ++r) f[r] = f[r] * 0.9999f + 0.25f;
+        }
+      float x = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x += f[r];
+      xq.x = x * 1e-30f;
+    }
+    if (role == 1 && (WS_X_SYNTH & 2)) {
+#pragma unroll 1
+      for (int rep = 0; rep < 16; ++rep) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = acc[0][r] * 1.0001f + 0.5f; acc[1][r] = acc[1][r] * 0.9999f + 0.25f; }
+      }
+    }
+    if (t == U + 4) { float x = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x += acc[0][r] + acc[1][r];
+      if (x == 1.2345f) a.scores[lane] = x; }
     __syncthreads();
+    continue;
+#endif
+    // phase B: this wave's product -- layer 1 on unit t, layer 2 on unit t - 2 (ONE call site: the 128 weight registers are not duplicated)
+    {
+      const int pu = t - 2 * role;
+      if (pu >= 0 && pu < U) {
+        ensure_weights(role ? R2.e : R0.e);
+        product(role ? act1[(t - 2) & 3] : act0[t & 3]);
+      }
+    }
+    WPH(1);
+    // phase C (vector work of the layer-1 waves)
+    if (role == 0) {
+      if (t >= 0 && t < U) epilogue1(R0, t & 3);
+      WPH(3);
+      if (gen_on) gen_finish(G2, (t + 2) & 3);
+    }
+    WPH(2);
+    // ---- stage 1: the finished layer-1 tile of unit t - 2 leaves as bf16 in whole 512-byte rows (operand of the dW2 product)
+    if (SAVE == 2 && t >= 2 && t - 2 < U) {
+      GLOBAL_AS __bf16* o = uptr(a.a1b + (long)R2.base * CH);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned idx = tid + 512 * q, row = idx >> 5, c8 = (idx & 31) * 8;
+        *(GLOBAL_AS u32x4*)(o + (row * CH + c8)) = *reinterpret_cast<const u32x4*>(&act1[(t - 2) & 3][row][c8]);
+      }
+    }
+    WPH(4);
+    // ---- scores of unit t - 5 (its four layer-2 waves added their parts during iteration t - 2: a barrier has passed since)
+    if (t >= 5 && wave == 0) {                           // (lanes 32 .. 63 repeat lanes 0 .. 31: same address, same value)
+      GLOBAL_AS float* o = uptr(a.scores + R5.base);
+      o[(unsigned)lr] = sc[(t - 5) & 3][lr].get();
+      sc[(t - 5) & 3][lr].zero();
+    }
+    WPH(5);
+    // ---- next iteration's cursors
+    R5 = R4; R4 = R3; R3 = R2; R2 = R1; R1 = R0; R0 = R1m; R1m = UnitRef{G2.e, G2.base};
+    G2 = G3;
+    G3.advance(B, BB);
+    if (t & 1) __syncthreads();
+    WPH(6);
+#ifdef WS_PHASE
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256)) g_ws_phase[tid >> 8][7] += 1;
+#endif
   }
+#ifdef WS_PHASE
+  if (blockIdx.x == 0 && tid == 0) { g_ws_clk[0] += (long long)clock64() - clk0; g_ws_clk[1] += (long long)wall_clock64() - wall0; }
+#endif
 }
 
 int device_cus() {
@@ -200,6 +437,16 @@ int device_cus() {
 }
 
 }  // namespace
+
+#ifdef WS_PHASE
+int concat_ws_read_phases(long long* out) {   // 16 phase slots + 2 clock slots, read-and-clear
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_phase), sizeof(long long) * 16) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_ws_clk), sizeof(long long) * 2) != hipSuccess) return 1;
+  long long z[18] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ws_clk), z, sizeof(long long) * 2) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ws_phase), z, sizeof(long long) * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 bool concat_fwd_ws_supported(int B, int hid, int save) { return hid == CH && B >= UR && B % UR == 0 && (save == 0 || save == 2 || save == 3); }
 
