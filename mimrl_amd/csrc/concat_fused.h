@@ -64,6 +64,12 @@ int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a);
 // pipeline over 32-row units); concat_fwd_fused routes there when concat_fwd_ws_supported
 bool concat_fwd_ws_supported(int B, int hid, int save);
 int concat_fwd_ws(hipStream_t s, const ConcatFwdArgs& a);
+// concat_ws_bwd.hip (round 6): the backward chain with both transposed weight images resident in registers; concat_bwd_fused routes there
+// when the in-kernel dQ reduction is requested (compact saves + dq_part of concat_bwd_dq_scratch floats)
+bool concat_bwd_ws_supported(int B, int hid);
+long concat_bwd_ws_scratch(int E, int B);
+int concat_bwd_ws(hipStream_t s, const ConcatBwdArgs& a);
+int concat_fwd_ws4(hipStream_t s, const ConcatFwdArgs& a);   // tools/hw/concat_ws4.hip (experiment, not in the library): one wave per SIMD
 // dw3[e] += ds[e]^T a2[e]  (compact saves: concat_bwd_fused leaves the score head's weight gradient to this streaming launch)
 int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride);
 #ifdef MIMRL_PHASE_PROBE

@@ -521,7 +521,7 @@ bool concat_bwd_dq_plan(int E, int B, int* per, int* nwg, int* slots) {
 long concat_bwd_dq_scratch(int E, int B) {
   int per, nwg, slots;
   if (!concat_bwd_dq_plan(E, B, &per, &nwg, &slots)) return 0;
-  return (long)E * (B / CR) * slots * CR * CH;
+  return std::max((long)E * (B / CR) * slots * CR * CH, concat_bwd_ws_scratch(E, B));   // (either kernel may be the one that runs)
 }
 
 bool concat_bwd_fused_supported(int B, int hid) { return hid == CH && B >= CR && B % CR == 0; }
@@ -534,6 +534,8 @@ int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a) {
   if ((a.dz2 != nullptr) != (a.dz1 != nullptr) || (a.dz2 && !(a.db1 && a.db2 && a.dw3 && a.db3)))
     return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the weight-gradient outputs come together");
   const bool wg = a.dz2 != nullptr;
+  // round 6: the weights-stationary kernel (concat_ws_bwd.hip) wherever the in-kernel dQ reduction is on; MIMRL_CONCAT_STREAMED=1: the kernel below
+  if (a.dQ && a.compact && a.dq_part && concat_bwd_ws_supported(a.B, CH) && !knob_on("MIMRL_CONCAT_STREAMED")) return concat_bwd_ws(s, a);
   if (a.dQ) {   // runs of tiles with dQ in registers: one workgroup per CU, ceil(tiles / CUs) tiles each
     if (!a.compact || !a.dq_part) return set_error(MIMRL_ERR_ARG, "concat_bwd_fused: the in-kernel dQ reduction needs the compact saves and its scratch");
     int per = 0, nwg = 0, slots = 0;

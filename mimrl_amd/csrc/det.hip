@@ -108,7 +108,7 @@ bool det_launch_accumulates(const char* name) {
                                       "text_post", "feat_mean", "tail_pre", "begin_stage", "mae_kernel", "finalize_stage", "stage_boundary",
                                       "cmi_assemble", "copy_rows", "gather_sum4", "wt_transpose", "pad_rows", "mi_bound", "cmi_loss", "pair_expand",
                                       "pair_reduce", "gauss_baseline", "dbg_spin", "det_flush", "dropout_inplace", "add_inplace",
-                                      "mi_sep_fused", "gemm_tall_kernel"};
+                                      "mi_sep_fused", "gemm_tall_kernel", "concat_ws_reduce"};
   for (const char* k : kSafe)
     if (std::strstr(name, k)) return false;
   return true;

@@ -1002,14 +1002,19 @@ def test_every_registered_knob_vs_oracle(knob, help_, tmp_path_factory):
     a, b = np.load(d / "g.npz"), np.load(d0 / "g.npz")
     assert set(a.files) == set(b.files) and len(a.files) > 100
     worst = ("", 0.0)
+    top = {}                                             # largest RMS gradient of each (fixture, stage) bucket of the default run
+    for k in b.files:
+        key = k.rsplit("|", 1)[0]
+        top[key] = max(top.get(key, 0.0), float(np.linalg.norm(b[k].astype(np.float64)) / np.sqrt(max(b[k].size, 1))))
     for k in a.files:
         ga, gb = a[k].astype(np.float64), b[k].astype(np.float64)
-        nb = np.linalg.norm(gb)
-        rel = np.linalg.norm(ga - gb) / (nb + 1e-30) if nb > 1e-12 else np.abs(ga).max()
+        # relative to the tensor's own norm, floored at 1 % of what a tensor of this size has at the bucket's largest RMS: tensors whose gradient
+        # cancels to ~0 at the initial point (InfoNCE ~ 0: the critics' first layers, score-head biases) are float-atomic-order noise, run to run
+        den = max(np.linalg.norm(gb), 1e-2 * top[k.rsplit("|", 1)[0]] * np.sqrt(gb.size), 1e-30)
+        rel = float(np.linalg.norm(ga - gb) / den)
         if rel > worst[1]:
-            worst = (k, float(rel))
-        # (tensors whose gradient cancels to ~0 -- the InfoNCE score-head bias -- are held by the absolute floor)
-        assert np.isfinite(ga).all() and (rel <= 3e-2 or np.abs(ga - gb).max() <= 2e-6), f"{knob}={value}: {k} rel L2 {rel:.3e} vs the default run"
+            worst = (k, rel)
+        assert np.isfinite(ga).all() and rel <= 3e-2, f"{knob}={value}: {k} rel L2 {rel:.3e} vs the default run"
     _record_errors(f"knob/{knob}={value}", {"worst_tensor": worst[0], "worst_rel_l2_vs_default": worst[1],
                                            "vs_oracle": json.loads(r.stdout.split("KNOB_OK ", 1)[1].splitlines()[0])})
 
