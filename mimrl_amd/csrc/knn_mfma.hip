@@ -602,7 +602,7 @@ int knn_sample(hipStream_t s, const KnnArgs& a, void* scratch, size_t scratch_by
   const size_t shb = mask_b + AT * 256 * sizeof(float) + AT * 256 * (size_t)K * (sizeof(float) + sizeof(int));   // exact-scan kernel
   if (shb > 150 * 1024) return set_error(MIMRL_ERR_ARG, "knn: bank too large for the LDS bitmask (N=%d)", a.N);
   const dim3 mgrid((a.m + AT - 1) / AT, a.ncall);
-  static const bool force_brute = knob("MIMRL_KNN_BRUTE") != nullptr;   // tuning / cross-check knob: the round-1 exact scan for every call
+  constexpr bool force_brute = false;   // (MIMRL_KNN_BRUTE went in round 6: the exact scan stays the path of k > 4 / odd widths, held to the host brute force by test_knn_matches_exact_bruteforce)
   // k > 4 (no BASELINE configuration; the reference's default is k = 2): the exact scan -- a k + 2 = 10-deep register list per lane and
   // tile makes the tile kernel's epilogue the bottleneck (and costs minutes of compile time)
   if (generic || force_brute || a.k > 4) {

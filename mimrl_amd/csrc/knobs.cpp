@@ -20,14 +20,12 @@ const KnobDef kKnobs[] = {
   {"MIMRL_DG_FP32", "engine_abi.hip", "", "BPTT outputs dg / h_prev stored as fp32 instead of bf16"},
   {"MIMRL_DWIH_H16", "engine_abi.hip", "", "0: the layer-1 dW_ih product reads the fp32 layer-0 outputs instead of the recurrence's fp16 copy"},
   {"MIMRL_FWD_BF16", "engine_abi.hip", "", "forward products round to bf16 instead of fp16"},
-  {"MIMRL_GEMM_NO_FAST", "gemm.hip", "", "no 128x128 / 128x64 / 64x64 fast-path kernels: everything on the generic GEMM"},
   {"MIMRL_GEMM_TALL_MIN_M", "gemm_tall.hip", "", "row threshold of the tall LDS-DMA GEMM (default 4096)"},
   {"MIMRL_GRAPH_DOT", "engine_step.hip", "", "dump the captured two-stage graph to this file (hipGraphDebugDotPrint)"},
   {"MIMRL_GRU_LDS_PAD", "gru.hip", "-1", "KiB of dynamic LDS a small BPTT launch reserves to keep parked kernels off its CUs (default 144 below 129 workgroups)"},
   {"MIMRL_GRU_SKIP", "gru.hip", "0", "probe build only (make probe): phase-elimination mask of the recurrence kernels; ignored by the default build"},
   {"MIMRL_GRU_WAVES", "gru.hip", "4", "8: one hidden unit per lane, two waves per SIMD, in the bf16 recurrence kernels (default 4)"},
   {"MIMRL_GX_F16", "engine_abi.hip", "", "1: hoisted GRU input projections stored as fp16 (measured slower at cfg3)"},
-  {"MIMRL_KNN_BRUTE", "knn_mfma.hip", "", "tuning / cross-check knob: the round-1 exact scan for every call"},
   {"MIMRL_L0_PACK", "engine_abi.hip", "", "0: no packed layer-0 operands (2 + 4 launches instead of 1 + 2)"},
   {"MIMRL_LAXIS_BWD_LONG", "engine_abi.hip", "", "0: the L-axis backward of a long-sequence CubeMLP block (L > 64) as colln_bwd + GEMM chain instead of the LONG instantiation of laxis_bwd_kernel"},
   {"MIMRL_LAXIS_LONG", "engine_abi.hip", "", "0: the L-axis MLP of a long-sequence CubeMLP block (L > 64) as the GEMM chain instead of the one-pass kernel of cube_long.hip"},
