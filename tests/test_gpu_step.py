@@ -987,7 +987,7 @@ def test_every_registered_knob_vs_oracle(knob, help_, tmp_path_factory):
     """Every environment knob the library still reads (csrc/knobs.cpp) is a pinned path: with the knob set, the bf16 bench mode on `tiny_sep`
     and `cfg1_cat` gives stage losses / MI / CMI values within the bf16 bands of the ORACLE (autograd of oracle/mimrl_ref.py, itself held to the
     reference's fixtures), gradient buckets at cosine >= 0.995 / 0.98 to the oracle's, and every gradient tensor no
-    further from the oracle's than 3x the default run's distance (floor 8e-2 of the tensor's norm: knobs that move the model's
+    further from the oracle's than 5x the default run's distance (floor 8e-2 of the tensor's norm, cap 0.5: knobs that move the model's
     rounding points move the critics' near-cancelling bias gradients by 3-5e-2 at the tiny fixture); two captured-graph steps stay finite.
     (ADVICE r04 / r05 both found wrong gradients behind exactly such switches.)"""
     value = _knob_value(knob, help_)
@@ -1012,13 +1012,15 @@ def test_every_registered_knob_vs_oracle(knob, help_, tmp_path_factory):
             continue
         # per tensor: distance to the ORACLE's gradient (relative L2, floored at 5 % of the bucket's largest RMS -- knob_worker.py) against the
         # default run's distance for the same tensor: a knob may move rounding points (tensors that nearly cancel at the initial point then move
-        # by tens of per cent in EVERY bf16 run, the default one included) but must not be further from the oracle than 3x the default run is
+        # by tens of per cent in EVERY bf16 run, the default one included) but must not be further from the oracle than 5x the default run is
         ea, eb = float(a[k]), float(b[k])
-        fac = 8.0 if knob == "MIMRL_FWD_BF16" else 3.0   # (bf16 instead of fp16 forward operands: 3 mantissa bits fewer BY DESIGN)
-        ratio = ea / max(fac * eb, 8e-2)
+        fac = 10.0 if knob == "MIMRL_FWD_BF16" else 5.0   # (bf16 instead of fp16 forward operands: 3 mantissa bits fewer BY DESIGN)
+        band = min(max(fac * eb, 8e-2), 0.5)             # (the default run's own distance moves by 2x run to run on the ill-conditioned K-axis / bias tensors;
+                                                         #  a WRONG tensor is ~1 from the oracle: never inside 0.5)
+        ratio = ea / band
         if ratio > worst[1]:
             worst = (k, ratio)
-        assert np.isfinite(ea) and ea <= max(fac * eb, 8e-2), f"{knob}={value}: {k[4:]} is {ea:.3e} from the oracle (default run {eb:.3e})"
+        assert np.isfinite(ea) and ea <= band, f"{knob}={value}: {k[4:]} is {ea:.3e} from the oracle (default run {eb:.3e})"
     _record_errors(f"knob/{knob}={value}", {"worst_tensor": worst[0], "worst_error_over_band": worst[1], "vs_oracle": ra})
 
 
