@@ -292,36 +292,43 @@ __global__ __launch_bounds__(512) void concat_bwd_ws_kernel(ConcatBwdArgs a, int
   }
 }
 
-// dQ[block][32][256] = sum of the block's slots in workgroup order; dP[e][i][256] = sum over the y blocks.  512 threads x float4 = 8 rows of 256.
-__global__ __launch_bounds__(512) void concat_ws_reduce_kernel(const float* __restrict__ dq_part, float* __restrict__ dQ, const float* __restrict__ dp_part,
+// dQ[block][32][256] = sum of the block's slots in workgroup order; dP[e][i][256] = sum over the y blocks.  256 threads x float4 = 4 rows of 256.
+// All the terms of an output are requested before the first add (groups of 8 clamped loads: the first version walked its 8-9 terms as a
+// chain of dependent round trips -- 20 us per launch at cfg3 for 21 MB).
+__global__ __launch_bounds__(256) void concat_ws_reduce_kernel(const float* __restrict__ dq_part, float* __restrict__ dQ, const float* __restrict__ dp_part,
                                                                float* __restrict__ dP, int E, int B, int per, int slots) {
-  const int nyb = B / UR, nblk = E * nyb, nq = nblk * 4;
-  const int off = threadIdx.x * 4;
+  const int nyb = B / UR, nblk = E * nyb, nq = nblk * 8;
+  const int off = threadIdx.x * 4;                       // 0 .. 1020: 4 rows x 256 columns
+  const float* __restrict__ p;
+  float* __restrict__ o;
+  long stride;
+  int n;
   if ((int)blockIdx.x < nq) {
-    const int blk = blockIdx.x >> 2, part = blockIdx.x & 3;
-    const int wfirst = (blk * B) / per, wlast = ((blk + 1) * B - 1) / per, n = wlast - wfirst + 1;
-    const float* __restrict__ p = dq_part + (long)blk * slots * (UR * CH) + part * (8 * CH) + off;
-    float4 s = *reinterpret_cast<const float4*>(p);
-    for (int k = 1; k < n; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (long)k * (UR * CH));
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    // block = (estimator e, y block yb): rows yb * 32 .. of dQ[e]
-    *reinterpret_cast<float4*>(dQ + (long)blk * (UR * CH) + part * (8 * CH) + off) = s;
+    const int blk = blockIdx.x >> 3, part = blockIdx.x & 7;
+    const int wfirst = (blk * B) / per, wlast = ((blk + 1) * B - 1) / per;
+    n = wlast - wfirst + 1;
+    p = dq_part + (long)blk * slots * (UR * CH) + part * (4 * CH) + off;
+    stride = UR * CH;
+    o = dQ + (long)blk * (UR * CH) + part * (4 * CH) + off;   // block = (estimator e, y block yb): rows yb * 32 .. of dQ[e]
   } else {
-    const long row8 = (long)((int)blockIdx.x - nq) * 8;          // 8 rows (e, i) of dP
-    const long rows = (long)E * B;
-    const long r = row8 + (off >> 8);
-    if (r >= rows) return;
+    const long r = (long)((int)blockIdx.x - nq) * 4 + (off >> 8);   // row (e, i) of dP
+    if (r >= (long)E * B) return;
     const int e = (int)(r / B), i = (int)(r - (long)e * B), c = off & 255;
-    const float* __restrict__ p = dp_part + (((long)e * nyb) * B + i) * CH + c;
-    float4 s = *reinterpret_cast<const float4*>(p);
-    for (int yb = 1; yb < nyb; ++yb) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (long)yb * B * CH);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    *reinterpret_cast<float4*>(dP + r * CH + c) = s;
+    n = nyb;
+    p = dp_part + (((long)e * nyb) * B + i) * CH + c;
+    stride = (long)B * CH;
+    o = dP + r * CH + c;
   }
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(p + (long)min(k0 + k, n - 1) * stride);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k0 + k < n) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }   // (in slot order: fixed summation order)
+  }
+  *reinterpret_cast<float4*>(o) = s;
 }
 
 void bwd_ws_plan(int E, int B, int* total, int* per, int* nwg, int* slots) {
@@ -355,8 +362,8 @@ int concat_bwd_ws(hipStream_t s, const ConcatBwdArgs& a) {
   if (a.dz2) hipLaunchKernelGGL(concat_bwd_ws_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, s, a, total, per, slots, dp_part);
   else hipLaunchKernelGGL(concat_bwd_ws_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, s, a, total, per, slots, dp_part);
   LAUNCH_CHECK();
-  const int nq = a.E * (a.B / UR) * 4, np = (a.E * a.B + 7) / 8;
-  hipLaunchKernelGGL(concat_ws_reduce_kernel, dim3((unsigned)(nq + np)), dim3(512), 0, s, a.dq_part, a.dQ, dp_part, a.dP, a.E, a.B, per, slots);
+  const int nq = a.E * (a.B / UR) * 8, np = (a.E * a.B + 3) / 4;
+  hipLaunchKernelGGL(concat_ws_reduce_kernel, dim3((unsigned)(nq + np)), dim3(256), 0, s, a.dq_part, a.dQ, dp_part, a.dP, a.E, a.B, per, slots);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
