@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MIMRL_ABI_VERSION 5
+#define MIMRL_ABI_VERSION 6
 #define MIMRL_MAX_BLOCKS 4
 
 enum { MIMRL_OK = 0, MIMRL_ERR_ARG = -1, MIMRL_ERR_HIP = -2, MIMRL_ERR_STATE = -3, MIMRL_ERR_NODEVICE = -4 };
@@ -132,6 +132,15 @@ int mimrl_set_bank_rows(mimrl_handle* h, int rows);    /* 0 => epoch-0 rule (Cus
  * alternates between two fixed buffer sets uploads batch i+1 into the idle set while the step on batch i runs, and pays
  * nothing to switch (the reference's loop does a synchronous .cuda() per batch, Customization.py:47-50).  mimrl_bind sets set 0. */
 int mimrl_set_inputs(mimrl_handle* h, int set, const float* text, const float* audio, const float* video, const float* labels);
+/* Epoch-ordered critic pass (round 6; replaces the body of the reference's stage-1 loop, Solver.py:200-216: `stage1_n` passes of critic
+ * updates over the whole loader with the main model frozen).  mimrl_stage1_pipe_prime: forward pass (Model.forward, Model.py:388-519, training
+ * mode) of the BOUND batch into the primary forward set.  mimrl_stage1_pipe(next_valid): stage-1 loss + critic gradients + clip + Adam
+ * (Solver.py:205-214) on the bound batch, whose forward pass a previous call left behind; with next_valid != 0 the forward pass of the batch
+ * in the OTHER input set (mimrl_set_inputs) runs beside it -- the caller then switches to that set before the next call.  Losses, MI / CMI
+ * values, dropout masks and anchor draws are those of mimrl_stage1_step on the same batches in the same order.  Not in stage-2 prefetch mode,
+ * not with a communicator; any other step / forward call in between needs a new mimrl_stage1_pipe_prime. */
+int mimrl_stage1_pipe_prime(mimrl_handle* h);
+int mimrl_stage1_pipe(mimrl_handle* h, int next_valid);
 int mimrl_stage1_step(mimrl_handle* h);                /* Solver.py:205-214 : critics update               */
 int mimrl_stage2_step(mimrl_handle* h);                /* Solver.py:221-236 : main-model update            */
 int mimrl_two_stage_step(mimrl_handle* h);             /* the new Solver.step(datas): mimrl_stage1_step then mimrl_stage2_step on the bound batch; in overlap mode with graphs ONE captured graph, one launch */

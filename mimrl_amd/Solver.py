@@ -208,6 +208,28 @@ class Solver:
         else:
             e.stage2_step()
 
+    def _stage1_pass_pipelined(self, acc) -> bool:
+        """One critic pass over ``self.train_loader`` with the NEXT batch's forward pass beside each update (HipEngine.stage1_pass): the main
+        model is frozen in such a pass (Solver.py:204-216), so Model.forward(batch i + 1) does not depend on the critic update on batch i.
+        Only when every batch is device-resident, full-size and the anchors are drawn on the device (no per-batch host work), single
+        process; otherwise False and the caller runs the sequential pass.  Same numbers as the sequential pass, batch by batch."""
+        e = self.engine
+        if self.world > 1 or not e.cfg.use_graph or not e.cfg.device_anchors or os.environ.get("MIMRL_NO_EPOCH_PIPE"):
+            return False
+        B = e.cfg.batch
+        batches = []
+        for d in self.train_loader:
+            if len(d[5]) != B or not all(torch.is_tensor(d[k]) and d[k].is_cuda for k in (6, 1, 2, 5)):
+                return False
+            batches.append((d[6], d[1], d[2], d[5]))
+        if not batches:
+            return False
+        e = self._engine_for(B)
+        def on_step(eng):
+            acc[_lib.S1_LOSS] += eng.scalars[_lib.S1_LOSS]
+        e.stage1_pass(batches, on_step)
+        return True
+
     def stage1_step(self, datas=None, draw_anchors=True):
         """Critic update (Solver.py:205-214).  Returns the stage-1 loss as a device scalar."""
         self._prefetch(False)                       # a lone stage call is the sequential schedule
@@ -253,6 +275,8 @@ class Solver:
         nb = len(train_loader)
         if epoch > 0 and len(C_F_all) > 0:                                     # Solver.py:200-203: epoch 0 skips stage 1
             for _ in range(self.opt.stage1_n):
+                if self._stage1_pass_pipelined(acc):
+                    continue
                 for e, datas in self._iter_loaded(self.train_loader):
                     self._anchors(e, 1)
                     self._stage(e, 1)

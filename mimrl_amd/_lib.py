@@ -161,6 +161,7 @@ EXPORTS = [
     "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_mi_sep_infonce", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_sample_anchors", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
     "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_probe_encoders", "mimrl_set_kernel_stamps", "mimrl_comm_unique_id", "mimrl_set_comm", "mimrl_main_late_offset", "mimrl_set_comm_critic_bf16",
+    "mimrl_stage1_pipe_prime", "mimrl_stage1_pipe",
 ]
 
 

@@ -402,6 +402,7 @@ struct mimrl_handle {
     hipGraphExec_t graph[3][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [..][2], [..][3]: the two halves of a split stage-2 gradient pass
     int rows[3][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}};
     hipGraphExec_t tail = nullptr; int tail_rows = -1;
+    hipGraphExec_t pipe[2] = {nullptr, nullptr}; int pipe_tag[2] = {-1, -1};   // mimrl_stage1_pipe without / with the look-ahead forward pass
     const void* in[4] = {nullptr, nullptr, nullptr, nullptr};
   } gsets[2];
   int cur_set = 0;
@@ -419,6 +420,7 @@ struct mimrl_handle {
       for (int s = 0; s <= 2; ++s)
         for (int k = 0; k < 4; ++k) retire(gsets[q].graph[s][k]);
       retire(gsets[q].tail);
+      retire(gsets[q].pipe[0]); retire(gsets[q].pipe[1]);
     }
   }
   float* P(long off) const { return bufs.main_p + off; }
@@ -486,6 +488,11 @@ struct mimrl_handle {
     ~StreamGuard() { h->stream = saved; }
   };
   int knn_launch(int stage, hipStream_t st);
+  // epoch-ordered critic pass with the next batch's forward pass beside the update (engine_step.hip)
+  bool pipe_primed = false; int fwd_parity = 0, pipe_set = 0;   // pipe_set: the input set whose batch's features the primary forward set holds
+  int pipe_forward_body(bool other_inputs);
+  int run_stage1_pipe_prime();
+  int run_stage1_pipe(bool next_valid);
   int mi_forward(int stage, bool want_grad);
   int cmi_forward(int stage, bool want_grad);
   int mi_backward(int stage);

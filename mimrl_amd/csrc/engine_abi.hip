@@ -150,6 +150,9 @@ int mimrl_set_inputs(mimrl_handle* h, int set, const float* text, const float* a
   return MIMRL_OK;
 }
 
+int mimrl_stage1_pipe_prime(mimrl_handle* h) { return h ? h->run_stage1_pipe_prime() : set_error(MIMRL_ERR_ARG, "null handle"); }
+int mimrl_stage1_pipe(mimrl_handle* h, int next_valid) { return h ? h->run_stage1_pipe(next_valid != 0) : set_error(MIMRL_ERR_ARG, "null handle"); }
+
 int mimrl_set_bank_rows(mimrl_handle* h, int rows) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (rows < 0 || rows > h->cfg.bank_capacity) return set_error(MIMRL_ERR_ARG, "bank rows %d outside [0,%d]", rows, h->cfg.bank_capacity);
@@ -179,6 +182,7 @@ int mimrl_forward(mimrl_handle* h, int train_mode, int with_losses) {
   if (!h) return set_error(MIMRL_ERR_ARG, "null handle");
   if (!h->bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called first");
   MX(h->ensure_images());
+  h->pipe_primed = false;
   launch_begin_stage(h->stream, h->d_ints, (int*)nullptr, h->bufs.scalars, 32, 32);
   LAUNCH_CHECK();
   h->ev_next = 0;

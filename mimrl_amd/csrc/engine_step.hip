@@ -288,6 +288,7 @@ int mimrl_handle::run(int stage, int kind) {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
   MX(ensure_images());
+  pipe_primed = false;                                  // (this call's forward pass overwrites the primary forward set)
   if (stage == 1 && kind != 1) imgT_valid = false;     // a critic update outside the combined step: its periodic image state is gone
   if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
@@ -360,6 +361,115 @@ int mimrl_handle::run(int stage, int kind) {
   return MIMRL_OK;
 }
 
+// Epoch-ordered critic pass (round 6; reference: Solver.py:200-216 runs `stage1_n` full passes of critic updates over the loader with the main
+// model frozen, THEN one model pass).  In such a pass Model.forward of batch i + 1 depends on nothing the critic update on batch i changes,
+// so one call = the estimators + clip + Adam of the bound batch, whose forward pass a previous call (or mimrl_stage1_pipe_prime) already left
+// in the primary forward set, with the forward pass of the NEXT batch -- the other input set -- beside them on `pre_stream`, into the
+// alternate forward set.  Afterwards the two forward sets trade places (host pointers; graphs are cached per (input set, forward-set parity)).
+// Arithmetic, dropout keys and anchor draws are those of the sequential order: the look-ahead pass uses the key the next call's
+// begin-of-stage will set (rng_add = 1), exactly like the stage-2 forward prefetch of a two-stage step.
+int mimrl_handle::pipe_forward_body(bool other_inputs) {
+  // forward pass (no saved activations: stage 1 trains the critics only) of the bound batch, or of the OTHER input set's batch into the
+  // alternate forward set
+  const void* keep_in[3] = {bufs.text, bufs.audio, bufs.video};
+  if (other_inputs) {
+    const GraphSet& o = gsets[1 - cur_set];
+    bufs.text = static_cast<const float*>(o.in[0]); bufs.audio = static_cast<const float*>(o.in[1]); bufs.video = static_cast<const float*>(o.in[2]);
+    swap_fwd_set();
+  }
+  const bool ms = multi_stream;
+  if (other_inputs) multi_stream = false;      // one sequential branch on pre_stream (a fork hanging off a non-origin captured stream breaks EndCapture)
+  rng_add = 1;                                 // the begin-of-stage that belongs to this batch has not run yet
+  bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+  const int r = model_forward(true, false, 0);
+  rng_add = 0; multi_stream = ms;
+  if (other_inputs) {
+    swap_fwd_set();
+    bufs.text = static_cast<const float*>(keep_in[0]); bufs.audio = static_cast<const float*>(keep_in[1]); bufs.video = static_cast<const float*>(keep_in[2]);
+  }
+  return r;
+}
+
+int mimrl_handle::run_stage1_pipe_prime() {
+  if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
+  if (bank_rows <= 0) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe_prime: stage 1 needs the feature banks (epoch-0 rule)");
+  if (prefetch || comm) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe_prime: not in stage-2 prefetch mode / with a communicator");
+  MX(ensure_images());
+  if (!keep_events) ev_next = 0;
+  MX(pipe_forward_body(false));
+  pipe_primed = true; pipe_set = cur_set;
+  return MIMRL_OK;
+}
+
+int mimrl_handle::run_stage1_pipe(bool next_valid) {
+  if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
+  if (bank_rows <= 0) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe: stage 1 needs the feature banks (epoch-0 rule)");
+  if (prefetch || comm) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe: not in stage-2 prefetch mode / with a communicator");
+  if (!pipe_primed || pipe_set != cur_set)
+    return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe: the bound batch has no forward pass yet (mimrl_stage1_pipe_prime, or the look-ahead pass of the last call belongs to the other input set)");
+  if (next_valid && !gsets[1 - cur_set].in[0]) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe: the other input set was never bound (mimrl_set_inputs)");
+  MX(ensure_images());
+  imgT_valid = false;                          // a critic update outside the combined step (as run(1, 0))
+  part0_done = false;
+  if (!grads_clean[1]) HIPX(hipMemsetAsync(bufs.crit_g, 0, sizeof(float) * layout.floats[MIMRL_GROUP_CRITIC], stream));
+  grads_clean[1] = true;
+  auto body = [&]() -> int {
+    if (!keep_events) ev_next = 0;
+    launch_begin_stage(stream, d_ints, d_ints + 2, bufs.scalars, 0, 32);
+    LAUNCH_CHECK();
+    bf16 = (prec & MIMRL_PREC_BF16_GEMM_FWD) != 0;
+    hipEvent_t e_begin = nullptr;
+    MX(next_event(&e_begin));
+    HIPX(hipEventRecord(e_begin, stream));
+    MX(fork(4, 4));                            // this stage's kNN sampler (banks only) on side 4: the CMI branch of the estimators joins it
+    MX(knn_launch(1, S(4)));
+    if (next_valid) {
+      HIPX(hipStreamWaitEvent(pre_stream, e_begin, 0));
+      StreamGuard g(this, pre_stream);
+      MX(pipe_forward_body(true));
+    }
+    MX(estimators_all(1, true, true));
+    launch_finalize_stage1(stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
+    LAUNCH_CHECK();
+    if (next_valid) {                          // rejoin before the stage ends (a captured graph must not leave a dangling branch)
+      hipEvent_t e;
+      MX(next_event(&e));
+      HIPX(hipEventRecord(e, pre_stream));
+      HIPX(hipStreamWaitEvent(stream, e, 0));
+    }
+    return enqueue_apply(1);
+  };
+  int r;
+  if (!cfg.use_graph || prof_on) r = body();
+  else {
+    hipGraphExec_t& ex = GS().pipe[next_valid ? 1 : 0];
+    int& tag = GS().pipe_tag[next_valid ? 1 : 0];
+    const int want = bank_rows * 2 + fwd_parity;          // bank size and the forward-set roles are baked into the kernel arguments
+    if (ex && tag != want) retire(ex);
+    if (!ex) {
+      hipGraph_t g = nullptr;
+      if (!cap_stream) HIPX(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+      HIPX(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+      stream = cap_stream;
+      const int rb = body();
+      stream = user_stream;
+      const hipError_t ce = hipStreamEndCapture(cap_stream, &g);
+      if (rb != 0) { if (g) (void)hipGraphDestroy(g); return rb; }
+      if (ce != hipSuccess) return set_error(MIMRL_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+      const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ie != hipSuccess) { ex = nullptr; return set_error(MIMRL_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie)); }
+      tag = want;
+    }
+    HIPX(hipGraphLaunch(ex, stream));
+    r = MIMRL_OK;
+  }
+  MX(r);
+  if (next_valid) { swap_fwd_set(); fwd_parity ^= 1; }   // the look-ahead pass's set is the primary one of the next call
+  pipe_primed = next_valid; pipe_set = 1 - cur_set;
+  return MIMRL_OK;
+}
+
 // Deferred-tail mode (data parallel): the stage-2 forward tail of the bound batch -- LN+ReLU+dropout, CubeMLP, head, with the
 // activations saved for the backward pass -- as its own launch on the caller's stream.  The caller starts the all-reduce of the
 // stage-1 (critic) gradients first; this work needs neither those gradients nor the critic update, so the collective hides under it.
@@ -412,6 +522,7 @@ static int graph_postprocess(hipGraph_t g) {
 int mimrl_handle::run_step() {
   Range rg("mimrl.two_stage_step (Solver.step)");
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
+  pipe_primed = false;
   static const bool no_step_graph = knob("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
   const bool combined = cfg.use_graph && !prof_on && prefetch && !defer_tail && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
   if (!combined) { MX(run(1, 0)); if (defer_tail) MX(run_fwd2_tail()); return run(2, 0); }

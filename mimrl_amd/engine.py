@@ -469,6 +469,50 @@ class HipEngine:
         self.text, self.audio, self.video, self.labels = t, a, v, y
         self._active = new
 
+    # ------------------------------------------------------------------ epoch-ordered critic pass with look-ahead forward (round 6)
+    def stage1_pass(self, batches, on_step=None):
+        """One pass of critic updates (reference: the inner loop of Solver.py:200-216) over ``batches`` = an iterable of
+        ``(text, audio, video, labels)`` DEVICE tensors of this engine's batch size.  The main model is frozen in such a pass, so
+        Model.forward of batch i + 1 runs beside the estimators / clip / Adam of batch i (`mimrl_stage1_pipe`): the next batch is copied
+        into the idle input set (device to device, on the engine's stream) in front of the step on the current one.  ``on_step(self)`` is
+        called behind every enqueued step (the caller accumulates ``self.scalars`` there).  Same losses, dropout masks and anchor draws as
+        ``stage1_step`` batch by batch."""
+        if not hasattr(self, "_sets"):
+            self._sets = [(self.text, self.audio, self.video, self.labels),
+                          tuple(torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels))]
+            self._active = 0
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return 0
+        def put(slot, b):
+            for dst, src in zip(self._sets[slot], b):
+                dst.copy_(torch.as_tensor(src).reshape(dst.shape), non_blocking=True)
+        def bind(slot):
+            t, a, v, y = self._sets[slot]
+            check(self.lib.mimrl_set_inputs(self.handle, slot, _ptr(t), _ptr(a), _ptr(v), _ptr(y)))
+            self.text, self.audio, self.video, self.labels = t, a, v, y
+            self._active = slot
+        self._coherent()
+        with torch.cuda.stream(self.stream):
+            bind(1 - self._active); bind(1 - self._active)           # (both sets known to the library; back on the active one)
+            put(self._active, cur)
+            check(self.lib.mimrl_stage1_pipe_prime(self.handle))
+            n = 0
+            while cur is not None:
+                nxt = next(it, None)
+                if nxt is not None:
+                    put(1 - self._active, nxt)
+                check(self.lib.mimrl_stage1_pipe(self.handle, 1 if nxt is not None else 0))
+                self._stepped()
+                n += 1
+                if on_step is not None:
+                    on_step(self)
+                if nxt is not None:
+                    bind(1 - self._active)
+                cur = nxt
+        return n
+
     def read_scalars(self) -> np.ndarray:
         """One device->host read-back (the reference does >= 10 ``.item()`` syncs per iteration)."""
         return self.scalars.detach().cpu().numpy()

@@ -77,6 +77,50 @@ def test_solver_train_evaluate_match_reference_solver(name, use_graph, monkeypat
         assert list(sol._tails) == [4], "the partial last batch (36 = 4*8 + 4) runs on a second handle of batch 4"
 
 
+@pytest.mark.parametrize("name,precision", [("tiny_sep", "fp32"), ("cfg1_cat", "bf16")])
+def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkeypatch):
+    """Round 6: in the reference's epoch schedule (Solver.py:200-216) the critic passes run over the whole loader with the
+    main model frozen, so `Solver.train` issues Model.forward of batch i + 1 beside the critic update on batch i (`mimrl_stage1_pipe`,
+    HipEngine.stage1_pass) when the batches are device-resident.  Same batches, same order, same dropout keys and device-drawn anchors: the
+    pass must give the stage-1 losses, the critic parameters and -- through the model pass that follows -- every returned value of the
+    sequential pass (MIMRL_NO_EPOCH_PIPE=1), up to the order of float atomics."""
+    c, opt, batch, banks = case(name)
+    B, T = c["B"], c["T"]
+    o = solver_opt(opt, host_anchors=False, no_graph=False, precision=precision, stage1_n=2)
+    o.dropout = [0.1, 0.1, 0.1, 0.1]
+    train = [as_datas(tuple(torch.as_tensor(x).cuda() for x in synth.synthetic_batch(B, T, seed=40 + i))) for i in range(5)]
+    train = [tuple(x.cuda() if torch.is_tensor(x) else x for x in d) for d in train]
+    res = {}
+    for tag in ("seq", "pipe"):
+        if tag == "seq":
+            monkeypatch.setenv("MIMRL_NO_EPOCH_PIPE", "1")
+        else:
+            monkeypatch.delenv("MIMRL_NO_EPOCH_PIPE", raising=False)
+        sol = Solver(o, (train, train[:1], train[:1], 768, 74, 35))
+        sol.model.load_state_dict(oracle_params(opt, c["seed"]))
+        called = {"n": 0}
+        orig = sol.engine.stage1_pass
+        def spy(*a, **k):
+            called["n"] += 1
+            return orig(*a, **k)
+        sol.engine.stage1_pass = spy
+        r = sol.train(1, sol.train_loader, *(torch.as_tensor(np.asarray(banks[k])) for k in "CFTAV"))
+        torch.cuda.synchronize()
+        assert called["n"] == (2 if tag == "pipe" else 0), (tag, called)
+        res[tag] = (r[0], r[1], np.asarray(r[2]), {n: v.double().cpu().numpy() for n, v in sol.model.state_dict().items()})
+        sol.engine.close()
+    a, b = res["pipe"], res["seq"]
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    assert_close(a[1], b[1], tol, tol, "mean stage-1 loss of the critic passes")
+    assert_close(a[0], b[0], tol, tol, "mean stage-2 loss of the model pass behind them")
+    assert_close(a[2], b[2], 10 * tol, 10 * tol, "MI means of the model pass")
+    lr = float(o.learning_rate)
+    for n, pa in a[3].items():     # (10 critic + 5 model Adam steps of ~lr each: a sign flip of a ~0 gradient moves an entry by 2 lr)
+        assert np.isfinite(pa).all() and np.abs(pa - b[3][n]).max() <= (2.5 * lr if precision == "fp32" else 8 * lr), n
+    drift = max(np.abs(pa - b[3][n]).mean() for n, pa in a[3].items())
+    assert drift <= (2e-6 if precision == "fp32" else 3e-4), drift
+
+
 @pytest.mark.parametrize("precision,use_graph", [("fp32", False), ("bf16", True)])
 def test_solver_step_equals_engine_step_and_oracle(precision, use_graph, monkeypatch):
     """Solver(opt, loaders).step(datas) x3 == HipEngine.step() x3 (bitwise: same library calls) == the oracle."""

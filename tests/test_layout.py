@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/mimrl.h but not exported"
     assert set(_lib.EXPORTS) == set(declared)
-    assert lib.mimrl_abi_version() == 5
+    assert lib.mimrl_abi_version() == 6
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
