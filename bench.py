@@ -249,6 +249,46 @@ def cpu_baseline(workload_name):
             "runs": probes + [best], "cfg1": dict(c1, workload="BASELINE configs[0]: B=32, T=50, separable InfoNCE, N=1284")}
 
 
+def epoch_schedule(args, B, T, nbatch=16, epochs=3):
+    from mimrl_amd.Solver import Solver
+    opt, N = workload(args.workload)
+    o = SimpleNamespace(**vars(opt))
+    o.task_name, o.seed, o.epochs_num, o.save_best_features, o.precision, o.no_graph, o.host_anchors = "bench", 0, 1, False, args.precision, args.no_graph, False
+    o.lr_decrease, o.lr_decrease_iter, o.lr_decrease_rate, o.task, o.stage1_n = "step", "1000", 0.1, "regression", 1
+    def datas(i):
+        t, a, v, y = (torch.from_numpy(x).cuda() for x in synth.synthetic_batch(B, T, seed=200 + i))
+        return (None, a, v, None, None, y.reshape(-1, 1), t, None, None, None, None)
+    train = [datas(i) for i in range(nbatch)]
+    banks = synth.synthetic_banks(N, seed=0)
+    out = {}
+    for tag, env in (("epoch_ms_per_pair", None), ("epoch_ms_per_pair_no_lookahead", "1")):
+        if env:
+            os.environ["MIMRL_NO_EPOCH_PIPE"] = env
+        else:
+            os.environ.pop("MIMRL_NO_EPOCH_PIPE", None)
+        try:
+            sol = Solver(o, (train, train[:1], train[:1], 768, 74, 35))
+            shapes = [(n, tuple(v.shape)) for n, v in sol.engine.params.items()]
+            sol.engine.load_params(synth.default_state(shapes, 0))
+            bk = tuple(torch.from_numpy(np.asarray(banks[k])) for k in "CFTAV")
+            r = sol.train(1, sol.train_loader, *bk)            # warm-up epoch (graph capture); its banks have nbatch * B rows
+            bk = tuple(x[:min(len(x), N)] for x in r[4:])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for ep in range(epochs):
+                r = sol.train(2 + ep, sol.train_loader, *bk)
+            torch.cuda.synchronize()
+            out[tag] = 1e3 * (time.perf_counter() - t0) / (epochs * nbatch)
+            sol.engine.close()
+        finally:
+            os.environ.pop("MIMRL_NO_EPOCH_PIPE", None)
+    out["epoch_pairs_per_sec"] = 1e3 / out["epoch_ms_per_pair"]
+    out["epoch_schedule_note"] = (f"Solver.train on {nbatch} device-resident batches x {epochs} epochs, stage1_n = 1: a critic pass over the loader (main model frozen: "
+                                  "the next batch's forward pass runs beside each critic update), then the model pass; per (stage-1 + stage-2) pair, "
+                                  "incl. the bank hand-over and the one read-back per epoch")
+    return out
+
+
 def extra_schedules(eng, args, B, T, rank):
     """ms/step of (a) strictly sequential stages and (b) a NEW pinned host batch every step through HipEngine.stage_batch /
     commit_batch (H2D into the idle one of two input sets on a copy stream under the previous step; the switch is host-only)."""
@@ -294,6 +334,13 @@ def extra_schedules(eng, args, B, T, rank):
         finally:
             os.environ.pop("MIMRL_DDP_SPLIT", None)
         eng.set_stage2_prefetch(True)
+    # Epoch schedule (the reference's OWN ordering, Solver.py:200-242: a full pass of critic updates over the loader with the main model
+    # frozen, then one model pass): pairs of (stage-1 update, stage-2 update) per second through Solver.train on fresh device-resident batches,
+    # stage1_n = 1 -- with the next batch's forward pass beside each critic update (round 6: mimrl_stage1_pipe) and with that switched off
+    try:
+        extra.update(epoch_schedule(args, B, T))
+    except Exception as e:      # noqa: BLE001 -- optional figure
+        extra["epoch_schedule_error"] = repr(e)[:200]
     host = [tuple(torch.from_numpy(x).pin_memory() for x in synth.synthetic_batch(B, T, seed=100 + i)) for i in range(4)]
     state = {"i": 0}
     eng.stage_batch(*host[0])

@@ -408,6 +408,7 @@ int mimrl_handle::run_stage1_pipe(bool next_valid) {
   if (!pipe_primed || pipe_set != cur_set)
     return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe: the bound batch has no forward pass yet (mimrl_stage1_pipe_prime, or the look-ahead pass of the last call belongs to the other input set)");
   if (next_valid && !gsets[1 - cur_set].in[0]) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe: the other input set was never bound (mimrl_set_inputs)");
+  if (!pre_stream) HIPX(hipStreamCreateWithFlags(&pre_stream, hipStreamNonBlocking));
   MX(ensure_images());
   imgT_valid = false;                          // a critic update outside the combined step (as run(1, 0))
   part0_done = false;

@@ -429,21 +429,26 @@ class HipEngine:
         return {"flops": out[0], "bytes": out[1], "ms": out[2], "launches": int(out[3])}
 
     # ------------------------------------------------------------------ overlapped batch upload (double-buffered inputs)
+    def _ensure_sets(self):
+        """The second input set + the upload machinery (copy stream, events), created on first use."""
+        if hasattr(self, "_sets"):
+            return
+        self._sets = [(self.text, self.audio, self.video, self.labels),
+                      tuple(torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels))]
+        self._active = 0
+        # high priority = its own hardware queue: on a normal-priority stream the copy's barrier packet shares one of the 4
+        # hardware queues with a branch of the step graph and the step starts BEHIND the upload (cfg2: 1.47 instead of 1.09 ms)
+        self._upload_legacy = os.environ.get("MIMRL_UPLOAD_LEGACY") is not None   # A/B knob: normal-priority stream + stream wait
+        self._copy_stream = torch.cuda.Stream(self.device, priority=0 if self._upload_legacy else -1)
+        self._staged_ev = torch.cuda.Event()
+        self._free_ev = [torch.cuda.Event(), torch.cuda.Event()]   # set q is no longer read by the device after this point
+        for ev in self._free_ev:
+            ev.record(self.stream)
+
     def stage_batch(self, text, audio, video, labels):
         """Start the host->device copy of the NEXT batch into the IDLE input set on a copy stream (it overlaps the step that
         is running on the active set).  Sources in pinned memory make the copy truly asynchronous."""
-        if not hasattr(self, "_sets"):
-            self._sets = [(self.text, self.audio, self.video, self.labels),
-                          tuple(torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels))]
-            self._active = 0
-            # high priority = its own hardware queue: on a normal-priority stream the copy's barrier packet shares one of the 4
-            # hardware queues with a branch of the step graph and the step starts BEHIND the upload (cfg2: 1.47 instead of 1.09 ms)
-            self._upload_legacy = os.environ.get("MIMRL_UPLOAD_LEGACY") is not None   # A/B knob: normal-priority stream + stream wait
-            self._copy_stream = torch.cuda.Stream(self.device, priority=0 if self._upload_legacy else -1)
-            self._staged_ev = torch.cuda.Event()
-            self._free_ev = [torch.cuda.Event(), torch.cuda.Event()]   # set q is no longer read by the device after this point
-            for ev in self._free_ev:
-                ev.record(self.stream)
+        self._ensure_sets()
         idle = 1 - self._active
         # steps that read the idle set have finished.  A HOST wait (the caller runs at most one step ahead of the device), not
         # hipStreamWaitEvent: a copy parked behind a not-yet-complete event of the compute stream cost the step 0.6 ms on this
@@ -477,10 +482,7 @@ class HipEngine:
         into the idle input set (device to device, on the engine's stream) in front of the step on the current one.  ``on_step(self)`` is
         called behind every enqueued step (the caller accumulates ``self.scalars`` there).  Same losses, dropout masks and anchor draws as
         ``stage1_step`` batch by batch."""
-        if not hasattr(self, "_sets"):
-            self._sets = [(self.text, self.audio, self.video, self.labels),
-                          tuple(torch.empty_like(t) for t in (self.text, self.audio, self.video, self.labels))]
-            self._active = 0
+        self._ensure_sets()
         it = iter(batches)
         cur = next(it, None)
         if cur is None:
@@ -511,6 +513,8 @@ class HipEngine:
                 if nxt is not None:
                     bind(1 - self._active)
                 cur = nxt
+            for ev in self._free_ev:                                   # (what was enqueued reads both sets: a later upload waits for it)
+                ev.record(self.stream)
         return n
 
     def read_scalars(self) -> np.ndarray:
