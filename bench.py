@@ -261,11 +261,11 @@ def epoch_schedule(args, B, T, nbatch=16, epochs=3):
     train = [datas(i) for i in range(nbatch)]
     banks = synth.synthetic_banks(N, seed=0)
     out = {}
-    for tag, env in (("epoch_ms_per_pair", None), ("epoch_ms_per_pair_no_lookahead", "1")):
+    for tag, env in (("epoch_ms_per_pair", None), ("epoch_ms_per_pair_lookahead", "1")):
         if env:
-            os.environ["MIMRL_NO_EPOCH_PIPE"] = env
+            os.environ["MIMRL_EPOCH_PIPE"] = env
         else:
-            os.environ.pop("MIMRL_NO_EPOCH_PIPE", None)
+            os.environ.pop("MIMRL_EPOCH_PIPE", None)
         try:
             sol = Solver(o, (train, train[:1], train[:1], 768, 74, 35))
             shapes = [(n, tuple(v.shape)) for n, v in sol.engine.params.items()]
@@ -281,11 +281,11 @@ def epoch_schedule(args, B, T, nbatch=16, epochs=3):
             out[tag] = 1e3 * (time.perf_counter() - t0) / (epochs * nbatch)
             sol.engine.close()
         finally:
-            os.environ.pop("MIMRL_NO_EPOCH_PIPE", None)
+            os.environ.pop("MIMRL_EPOCH_PIPE", None)
     out["epoch_pairs_per_sec"] = 1e3 / out["epoch_ms_per_pair"]
-    out["epoch_schedule_note"] = (f"Solver.train on {nbatch} device-resident batches x {epochs} epochs, stage1_n = 1: a critic pass over the loader (main model frozen: "
-                                  "the next batch's forward pass runs beside each critic update), then the model pass; per (stage-1 + stage-2) pair, "
-                                  "incl. the bank hand-over and the one read-back per epoch")
+    out["epoch_schedule_note"] = (f"Solver.train on {nbatch} device-resident batches x {epochs} epochs, stage1_n = 1: a critic pass over the loader (main model frozen), "
+                                  "then the model pass; per (stage-1 + stage-2) pair, incl. the bank hand-over and the one read-back per epoch.  _lookahead = "
+                                  "MIMRL_EPOCH_PIPE=1: the next batch's forward pass + kNN sampler beside each critic update (opt-in: it measured slower)")
     return out
 
 
@@ -336,7 +336,7 @@ def extra_schedules(eng, args, B, T, rank):
         eng.set_stage2_prefetch(True)
     # Epoch schedule (the reference's OWN ordering, Solver.py:200-242: a full pass of critic updates over the loader with the main model
     # frozen, then one model pass): pairs of (stage-1 update, stage-2 update) per second through Solver.train on fresh device-resident batches,
-    # stage1_n = 1 -- with the next batch's forward pass beside each critic update (round 6: mimrl_stage1_pipe) and with that switched off
+    # stage1_n = 1 -- the default (sequential passes) and with the next batch's forward pass beside each critic update (round 6: mimrl_stage1_pipe, opt-in)
     try:
         extra.update(epoch_schedule(args, B, T))
     except Exception as e:      # noqa: BLE001 -- optional figure

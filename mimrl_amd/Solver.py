@@ -212,9 +212,12 @@ class Solver:
         """One critic pass over ``self.train_loader`` with the NEXT batch's forward pass beside each update (HipEngine.stage1_pass): the main
         model is frozen in such a pass (Solver.py:204-216), so Model.forward(batch i + 1) does not depend on the critic update on batch i.
         Only when every batch is device-resident, full-size and the anchors are drawn on the device (no per-batch host work), single
-        process; otherwise False and the caller runs the sequential pass.  Same numbers as the sequential pass, batch by batch."""
+        process; otherwise False and the caller runs the sequential pass.  Same numbers as the sequential pass, batch by batch.
+        OPT-IN (MIMRL_EPOCH_PIPE=1): measured on cfg2 it LOSES to the sequential pass (1.40-1.56 vs 1.25 ms per stage-1 + stage-2 pair) --
+        the kNN sampler's merge kernel takes 132-151 us instead of 18 whenever it runs beside the estimators' or the forward pass's kernels
+        (DESIGN.md section 7), which eats the overlap."""
         e = self.engine
-        if self.world > 1 or not e.cfg.use_graph or not e.cfg.device_anchors or os.environ.get("MIMRL_NO_EPOCH_PIPE"):
+        if self.world > 1 or not e.cfg.use_graph or not e.cfg.device_anchors or os.environ.get("MIMRL_EPOCH_PIPE", "0") in ("", "0"):
             return False
         B = e.cfg.batch
         batches = []

@@ -261,6 +261,10 @@ struct mimrl_handle {
   bool fold_unpack_on = true;          // MIMRL_NO_FOLD_UNPACK=1: keep the separate scatter kernel (tuning knob)
   bool gx_f16 = false;                 // the hoisted GRU input projections gx[B,T,3H] are stored as fp16 (long sequences, bf16 mode: create)
   int *knn_idx = nullptr, *knn_idx2 = nullptr;   // neighbour indices; stage 2 has its own set (prefetch mode samples it early)
+  // which of the two anchor / neighbour-index sets a stage uses: its own -- except inside a pipelined critic pass (mimrl_stage1_pipe), where stage 1
+  // alternates between both (the sampler of the NEXT call runs beside this call's estimators; stage 2 is not running then)
+  int knn_flip = 0;
+  int knn_slot(int stage) const { return (stage - 1) ^ knn_flip; }
   char* knn_scr[2] = {nullptr, nullptr};         // candidate lists of the MFMA kNN (knn_mfma.hip), one per stage
   size_t knn_scr_bytes = 0;
   float *cmi_in = nullptr, *cc[3], *logits = nullptr, *dlogits = nullptr;
@@ -402,7 +406,8 @@ struct mimrl_handle {
     hipGraphExec_t graph[3][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [..][2], [..][3]: the two halves of a split stage-2 gradient pass
     int rows[3][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}};
     hipGraphExec_t tail = nullptr; int tail_rows = -1;
-    hipGraphExec_t pipe[2] = {nullptr, nullptr}; int pipe_tag[2] = {-1, -1};   // mimrl_stage1_pipe without / with the look-ahead forward pass
+    hipGraphExec_t pipe[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // mimrl_stage1_pipe [look-ahead off / on][forward-set parity * 2 + kNN-set parity]
+    int pipe_rows[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
     const void* in[4] = {nullptr, nullptr, nullptr, nullptr};
   } gsets[2];
   int cur_set = 0;
@@ -420,7 +425,7 @@ struct mimrl_handle {
       for (int s = 0; s <= 2; ++s)
         for (int k = 0; k < 4; ++k) retire(gsets[q].graph[s][k]);
       retire(gsets[q].tail);
-      retire(gsets[q].pipe[0]); retire(gsets[q].pipe[1]);
+      for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 4; ++b_) retire(gsets[q].pipe[a_][b_]);
     }
   }
   float* P(long off) const { return bufs.main_p + off; }

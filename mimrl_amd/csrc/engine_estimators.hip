@@ -159,8 +159,8 @@ int mimrl_handle::knn_launch(int stages, hipStream_t st) {
   ka.N = bank_rows; ka.m = m; ka.k = k; ka.ncall = 0; ad.n = 0;
   for (int stage = 1; stage <= 2; ++stage) {
     if (!((stages >> (stage - 1)) & 1)) continue;
-    int32_t* anc = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
-    int* idx = stage == 2 ? knn_idx2 : knn_idx;
+    int32_t* anc = bufs.anchors + (size_t)knn_slot(stage) * NE_CMI * m;
+    int* idx = knn_slot(stage) ? knn_idx2 : knn_idx;
     const unsigned ovr = bufs.knn_override ? knn_ovr_mask[stage - 1] : 0u;
     const int add = stages == 3 && stage == 2 ? 1 : rng_add;
     for (int e = 0; e < NE_CMI; ++e) {
@@ -177,7 +177,7 @@ int mimrl_handle::knn_launch(int stages, hipStream_t st) {
   for (int stage = 1; stage <= 2; ++stage) {
     if (!((stages >> (stage - 1)) & 1)) continue;
     const unsigned ovr = bufs.knn_override ? knn_ovr_mask[stage - 1] : 0u;
-    int* idx = stage == 2 ? knn_idx2 : knn_idx;
+    int* idx = knn_slot(stage) ? knn_idx2 : knn_idx;
     for (int e = 0; e < NE_CMI; ++e)   // caller-supplied neighbour rows (mimrl_set_knn_override_mask): copied in at every step
       if ((ovr >> e) & 1u)
         HIPX(hipMemcpyAsync(idx + (size_t)e * nprod(), bufs.knn_override + ((size_t)(stage - 1) * NE_CMI + e) * nprod(),
@@ -281,8 +281,8 @@ int mimrl_handle::cmi_forward(int stage, bool want_grad) {
   const float* cur[5] = {bufs.feats, bufs.feats + BD, bufs.feats + 2 * BD, bufs.feats + 3 * BD, bufs.labels};
   const float* bank[5] = {bufs.bank_f, bufs.bank_t, bufs.bank_a, bufs.bank_v, bufs.bank_c};
   CmiAssembleArgs ca_;
-  ca_.anchors = bufs.anchors + (size_t)(stage - 1) * NE_CMI * m;
-  ca_.idx_x = stage == 2 ? knn_idx2 : knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
+  ca_.anchors = bufs.anchors + (size_t)knn_slot(stage) * NE_CMI * m;
+  ca_.idx_x = knn_slot(stage) ? knn_idx2 : knn_idx; ca_.out = cmi_in; ca_.n = n; ca_.m = m; ca_.k = k; ca_.ncall = NE_CMI;
   for (int e = 0; e < NE_CMI; ++e)
     for (int o = 0; o < 3; ++o) {
       const int f = kCmiWire[e][o];

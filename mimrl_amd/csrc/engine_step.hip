@@ -288,7 +288,7 @@ int mimrl_handle::run(int stage, int kind) {
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
   if (stage != 1 && stage != 2) return set_error(MIMRL_ERR_ARG, "stage must be 1 or 2");
   MX(ensure_images());
-  pipe_primed = false;                                  // (this call's forward pass overwrites the primary forward set)
+  pipe_primed = false; knn_flip = 0;                    // (this call's forward pass overwrites the primary forward set)
   if (stage == 1 && kind != 1) imgT_valid = false;     // a critic update outside the combined step: its periodic image state is gone
   if (kind == 2) { grads_clean[stage] = true; return enqueue_apply(stage); }
   // kind 0 (fused step): the previous apply left the bucket zeroed, so no memset node; kind 1 (grads only, e.g. before
@@ -396,6 +396,9 @@ int mimrl_handle::run_stage1_pipe_prime() {
   if (prefetch || comm) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe_prime: not in stage-2 prefetch mode / with a communicator");
   MX(ensure_images());
   if (!keep_events) ev_next = 0;
+  if (knn_ovr_mask[0] != 0u) return set_error(MIMRL_ERR_STATE, "mimrl_stage1_pipe_prime: caller-supplied neighbour rows (exact tie order) need the sequential pass");
+  rng_add = 1;                                 // (anchor draws of the call that follows: the key its begin-of-stage will set)
+  { const int rk = knn_launch(1, stream); rng_add = 0; MX(rk); }
   MX(pipe_forward_body(false));
   pipe_primed = true; pipe_set = cur_set;
   return MIMRL_OK;
@@ -422,14 +425,23 @@ int mimrl_handle::run_stage1_pipe(bool next_valid) {
     hipEvent_t e_begin = nullptr;
     MX(next_event(&e_begin));
     HIPX(hipEventRecord(e_begin, stream));
-    MX(fork(4, 4));                            // this stage's kNN sampler (banks only) on side 4: the CMI branch of the estimators joins it
-    MX(knn_launch(1, S(4)));
+    // TWO branches behind the begin-of-stage node: (a) on pre_stream the NEXT call's kNN sampler (banks only; into the other anchor /
+    // neighbour-index set, with the key the next begin-of-stage will set) followed by the next batch's forward pass -- one sequential chain,
+    // captured first (graph nodes are dispatched in capture order); (b) this call's estimators, whose sampler the previous call (or the prime
+    // call) already ran.  As a third branch -- or at the head of (b) -- the sampler's merge kernel ran 134-151 us beside the forward pass's
+    // kernels instead of 18 and held the estimators back (gpurun_out/epoch_tl_pipe_stage1.txt of the first two cuts).
     if (next_valid) {
       HIPX(hipStreamWaitEvent(pre_stream, e_begin, 0));
       StreamGuard g(this, pre_stream);
+      knn_flip ^= 1; rng_add = 1;
+      const int rk = knn_launch(1, stream);
+      knn_flip ^= 1; rng_add = 0;
+      MX(rk);
       MX(pipe_forward_body(true));
     }
-    MX(estimators_all(1, true, true));
+    const unsigned keep_mask = side_mask;
+    side_mask &= ~(1u << 4);                   // (nothing on side 4 in this call: the CMI branch's chain(5, 4) then orders it behind the main stream)
+    { const int re = estimators_all(1, true, true); side_mask = keep_mask; MX(re); }
     launch_finalize_stage1(stream, bufs.scalars, mi_raw, cmi_raw, bce_raw, coef1());
     LAUNCH_CHECK();
     if (next_valid) {                          // rejoin before the stage ends (a captured graph must not leave a dangling branch)
@@ -443,9 +455,11 @@ int mimrl_handle::run_stage1_pipe(bool next_valid) {
   int r;
   if (!cfg.use_graph || prof_on) r = body();
   else {
-    hipGraphExec_t& ex = GS().pipe[next_valid ? 1 : 0];
-    int& tag = GS().pipe_tag[next_valid ? 1 : 0];
-    const int want = bank_rows * 2 + fwd_parity;          // bank size and the forward-set roles are baked into the kernel arguments
+    // (the forward-set roles are baked into the kernel arguments: one graph per parity -- a pass with an even number of batches flips the
+    //  relation between input set and forward set for the next pass; the bank size is baked in as well)
+    hipGraphExec_t& ex = GS().pipe[next_valid ? 1 : 0][fwd_parity * 2 + knn_flip];
+    int& tag = GS().pipe_rows[next_valid ? 1 : 0][fwd_parity * 2 + knn_flip];
+    const int want = bank_rows;
     if (ex && tag != want) retire(ex);
     if (!ex) {
       hipGraph_t g = nullptr;
@@ -466,7 +480,8 @@ int mimrl_handle::run_stage1_pipe(bool next_valid) {
     r = MIMRL_OK;
   }
   MX(r);
-  if (next_valid) { swap_fwd_set(); fwd_parity ^= 1; }   // the look-ahead pass's set is the primary one of the next call
+  if (next_valid) { swap_fwd_set(); fwd_parity ^= 1; knn_flip ^= 1; }   // the look-ahead pass's sets are the current ones of the next call
+  else knn_flip = 0;                           // end of the pass: stage 1 / stage 2 back on their own sets
   pipe_primed = next_valid; pipe_set = 1 - cur_set;
   return MIMRL_OK;
 }
@@ -523,7 +538,7 @@ static int graph_postprocess(hipGraph_t g) {
 int mimrl_handle::run_step() {
   Range rg("mimrl.two_stage_step (Solver.step)");
   if (!bound) return set_error(MIMRL_ERR_STATE, "mimrl_bind must be called before any step");
-  pipe_primed = false;
+  pipe_primed = false; knn_flip = 0;
   static const bool no_step_graph = knob("MIMRL_NO_STEP_GRAPH") != nullptr;   // tuning knob
   const bool combined = cfg.use_graph && !prof_on && prefetch && !defer_tail && bank_rows > 0 && grads_clean[1] && grads_clean[2] && !no_step_graph;
   if (!combined) { MX(run(1, 0)); if (defer_tail) MX(run_fwd2_tail()); return run(2, 0); }
