@@ -112,10 +112,10 @@ def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkey
         res[tag] = (r[0], r[1], np.asarray(r[2]), {n: v.double().cpu().numpy() for n, v in sol.model.state_dict().items()})
         sol.engine.close()
     a, b = res["pipe"], res["seq"]
-    tol = 1e-5 if precision == "fp32" else 2e-3
+    tol = 1e-5 if precision == "fp32" else 2e-2      # (bf16: 15 Adam steps at lr 4e-3 amplify the float-atomic order: the bf16 band of the step tests)
     assert_close(a[1], b[1], tol, tol, "mean stage-1 loss of the critic passes")
     assert_close(a[0], b[0], tol, tol, "mean stage-2 loss of the model pass behind them")
-    assert_close(a[2], b[2], 50 * tol, 50 * tol, "MI means of the model pass")     # (10 critic Adam steps apart by float-atomic order: measured 2e-4 in fp32)
+    assert_close(a[2], b[2], 50 * tol if precision == "fp32" else 5e-2, 50 * tol if precision == "fp32" else 5e-2, "MI means of the model pass")     # (10 critic Adam steps apart by float-atomic order: measured 2e-4 in fp32)
     lr = float(o.learning_rate)
     for n, pa in a[3].items():     # (10 critic + 5 model Adam steps of ~lr each: a sign flip of a ~0 gradient moves an entry by 2 lr)
         assert np.isfinite(pa).all() and np.abs(pa - b[3][n]).max() <= (2.5 * lr if precision == "fp32" else 8 * lr), n
