@@ -118,7 +118,7 @@ def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkey
     assert_close(a[2], b[2], 50 * tol if precision == "fp32" else 5e-2, 50 * tol if precision == "fp32" else 5e-2, "MI means of the model pass")     # (10 critic Adam steps apart by float-atomic order: measured 2e-4 in fp32)
     lr = float(o.learning_rate)
     for n, pa in a[3].items():     # (10 critic + 5 model Adam steps of ~lr each: a sign flip of a ~0 gradient moves an entry by 2 lr)
-        assert np.isfinite(pa).all() and np.abs(pa - b[3][n]).max() <= (2.5 * lr if precision == "fp32" else 8 * lr), n
+        assert np.isfinite(pa).all() and np.abs(pa - b[3][n]).max() <= (2.5 * lr if precision == "fp32" else 10.5 * lr), n    # (bf16: an entry may flip in each of the 5 model steps)
     drift = max(np.abs(pa - b[3][n]).mean() for n, pa in a[3].items())
     assert drift <= (0.05 if precision == "fp32" else 0.2) * lr, (drift, lr)    # (Adam's ~lr sign steps on near-zero gradients flip with the float-atomic order: measured 0.025 lr)
 
