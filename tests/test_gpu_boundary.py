@@ -77,7 +77,7 @@ def test_solver_train_evaluate_match_reference_solver(name, use_graph, monkeypat
         assert list(sol._tails) == [4], "the partial last batch (36 = 4*8 + 4) runs on a second handle of batch 4"
 
 
-@pytest.mark.parametrize("name,precision", [("tiny_sep", "fp32"), ("cfg1_cat", "bf16")])
+@pytest.mark.parametrize("name,precision", [("tiny_sep", "fp32"), ("cfg1_sep", "bf16"), ("cfg1_cat", "bf16")])
 def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkeypatch):
     """Round 6: in the reference's epoch schedule (Solver.py:200-216) the critic passes run over the whole loader with the
     main model frozen, so `Solver.train` CAN issue Model.forward of batch i + 1 beside the critic update on batch i (`mimrl_stage1_pipe`,
@@ -92,8 +92,8 @@ def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkey
     train = [as_datas(tuple(torch.as_tensor(x).cuda() for x in synth.synthetic_batch(B, T, seed=40 + i))) for i in range(5)]
     train = [tuple(x.cuda() if torch.is_tensor(x) else x for x in d) for d in train]
     res = {}
-    for tag in ("seq", "pipe"):
-        if tag == "seq":
+    for tag in ("seq", "seq2", "pipe"):
+        if tag != "pipe":
             monkeypatch.delenv("MIMRL_EPOCH_PIPE", raising=False)
         else:
             monkeypatch.setenv("MIMRL_EPOCH_PIPE", "1")
@@ -111,16 +111,20 @@ def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkey
         assert called["n"] == (2 if tag == "pipe" else 0), (tag, called)
         res[tag] = (r[0], r[1], np.asarray(r[2]), {n: v.double().cpu().numpy() for n, v in sol.model.state_dict().items()})
         sol.engine.close()
-    a, b = res["pipe"], res["seq"]
-    tol = 1e-5 if precision == "fp32" else 2e-2      # (bf16: 15 Adam steps at lr 4e-3 amplify the float-atomic order: the bf16 band of the step tests)
-    assert_close(a[1], b[1], tol, tol, "mean stage-1 loss of the critic passes")
-    assert_close(a[0], b[0], tol, tol, "mean stage-2 loss of the model pass behind them")
-    assert_close(a[2], b[2], 50 * tol if precision == "fp32" else 5e-2, 50 * tol if precision == "fp32" else 5e-2, "MI means of the model pass")     # (10 critic Adam steps apart by float-atomic order: measured 2e-4 in fp32)
+    a, b, b2 = res["pipe"], res["seq"], res["seq2"]
+    # the yardstick is the sequential pass AGAINST ITSELF (a second run): 10 critic + 5 model Adam steps at lr 4e-3 amplify the order of the
+    # float atomics (every entry whose gradient is ~0 moves by ~lr per step in a direction the noise picks) -- in bf16 mode two sequential
+    # runs already drift apart by ~1 lr per entry on average
+    def dist(x, y):
+        return (abs(x[1] - y[1]), abs(x[0] - y[0]), float(np.abs(x[2] - y[2]).max()),
+                max(float(np.abs(pa - y[3][n]).mean()) for n, pa in x[3].items()))
+    noise, got = dist(b, b2), dist(a, b)
     lr = float(o.learning_rate)
-    for n, pa in a[3].items():     # (10 critic + 5 model Adam steps of ~lr each: a sign flip of a ~0 gradient moves an entry by 2 lr)
-        assert np.isfinite(pa).all() and np.abs(pa - b[3][n]).max() <= (2.5 * lr if precision == "fp32" else 10.5 * lr), n    # (bf16: an entry may flip in each of the 5 model steps)
-    drift = max(np.abs(pa - b[3][n]).mean() for n, pa in a[3].items())
-    assert drift <= (0.05 if precision == "fp32" else 0.2) * lr, (drift, lr)    # (Adam's ~lr sign steps on near-zero gradients flip with the float-atomic order: measured 0.025 lr)
+    floor = (1e-4, 1e-4, 1e-3, 0.05 * lr) if precision == "fp32" else (2e-3, 2e-3, 5e-3, 0.3 * lr)
+    for what, g_, n_, f_ in zip(("mean stage-1 loss", "mean stage-2 loss", "MI means", "mean parameter drift"), got, noise, floor):
+        assert g_ <= max(3.0 * n_, f_), f"{what}: pipelined vs sequential {g_:.3e}, sequential vs sequential {n_:.3e}"
+    for n, pa in a[3].items():
+        assert np.isfinite(pa).all() and np.abs(pa - b[3][n]).max() <= 15 * 2 * lr, n
 
 
 @pytest.mark.parametrize("precision,use_graph", [("fp32", False), ("bf16", True)])
