@@ -259,6 +259,7 @@ def epoch_schedule(args, B, T, nbatch=16, epochs=3):
         t, a, v, y = (torch.from_numpy(x).cuda() for x in synth.synthetic_batch(B, T, seed=200 + i))
         return (None, a, v, None, None, y.reshape(-1, 1), t, None, None, None, None)
     train = [datas(i) for i in range(nbatch)]
+    N = min(N, nbatch * B)                                   # the banks of an epoch are its own samples' features: nbatch * B rows at most
     banks = synth.synthetic_banks(N, seed=0)
     out = {}
     for tag, env in (("epoch_ms_per_pair", None), ("epoch_ms_per_pair_lookahead", "1")):
