@@ -241,6 +241,12 @@ int mimrl_op_gru_forward(void* stream, const float* gx_f, const float* gx_r, con
 int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, const float* saved_f,
                           const float* saved_r, const int32_t* lens, const float* out, const float* dout, float* dg_f,
                           float* dg_r, float* hprev_f, float* hprev_r, int B, int T, int precision);
+/* (ABI v6) the layer-0 weight gradients of four (modality, direction) sequences in ONE pass over dg (gru_wgrad.hip; autograd of nn.GRU,
+ * Model.py:254-255): dw_ih[s] [384, kp] += dgx_s^T x_s, dw_hh[s] [384, 128] += dgh_s^T hp_s with dg[s] [rows, 512], x[s] [rows, kp], hp[s]
+ * [rows, 128] all STORED as bf16 (dgx / dgh as in mimrl_op_gru_backward); kp a multiple of 8, <= 96; x[s] of the two directions of a
+ * modality may be the same array.  The outputs accumulate (zero them first). */
+int mimrl_op_gru_wgrad(void* stream, const void* const* dg, const void* const* x, const void* const* hp, float* const* dw_ih,
+                       float* const* dw_hh, int64_t rows, int kp);
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
                       int bound);
 /* same + the estimators' loss terms (mi_loss of Model.py:115-148; differs from -mi only for `mine`); bit e of lossform:

@@ -248,4 +248,15 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 __device__ __forceinline__ _Float16 to_f16(float x) { return (_Float16)x; }
 __device__ __forceinline__ _Float16 to_f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
 
+// compute units of the current device (256 on MI355X); cached
+inline int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t pr;
+    int dev = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
 }  // namespace mimrl

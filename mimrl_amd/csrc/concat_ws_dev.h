@@ -93,15 +93,6 @@ struct UnitPos {
 };
 struct UnitRef { int e, base; };
 
-inline int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    hipDeviceProp_t pr;
-    int dev = 0;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-  }
-  return cus;
-}
 
 }  // namespace
 }  // namespace mimrl

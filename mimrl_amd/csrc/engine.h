@@ -32,6 +32,7 @@
 #include "estimator_ops.h"
 #include "gemm.h"
 #include "gru.h"
+#include "gru_wgrad.h"
 #include "lstm.h"
 #include "layout.h"
 #include "comm.h"

@@ -602,6 +602,18 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
   return gru_backward(reinterpret_cast<hipStream_t>(stream), a, (precision & 1) != 0);
 }
 
+int mimrl_op_gru_wgrad(void* stream, const void* const* dg, const void* const* x, const void* const* hp, float* const* dw_ih,
+                       float* const* dw_hh, int64_t rows, int kp) {
+  if (!dg || !x || !hp || !dw_ih || !dw_hh) return set_error(MIMRL_ERR_ARG, "mimrl_op_gru_wgrad: null argument");
+  GruWgradArgs a;
+  for (int s = 0; s < 4; ++s) {
+    if (!dg[s] || !x[s] || !hp[s] || !dw_ih[s] || !dw_hh[s]) return set_error(MIMRL_ERR_ARG, "mimrl_op_gru_wgrad: null array for sequence %d", s);
+    a.seq[s] = GruWgradSeq{static_cast<const __bf16*>(dg[s]), static_cast<const __bf16*>(x[s]), static_cast<const __bf16*>(hp[s]), dw_ih[s], dw_hh[s]};
+  }
+  a.rows = rows; a.kp = kp;
+  return gru_wgrad(reinterpret_cast<hipStream_t>(stream), a);
+}
+
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,
                       int bound) {
   return mi_bound_fwd_bwd(reinterpret_cast<hipStream_t>(stream), scores, dscores, mi, nullptr, gscale, E, B, bound, 0u);

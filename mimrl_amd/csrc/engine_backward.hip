@@ -567,6 +567,22 @@ int mimrl_handle::gru_layer_backward(int l) {
       // instead of four GEMMs in a row (the per-modality widths 74 / 35 ruled out both batching and 16-byte loads)
       const long s_dg = dg[0][0][1] - dg[0][0][0], o_dg = dg[0][1][0] - dg[0][0][0];
       const long s_hp = hprev[0][0][1] - hprev[0][0][0], o_hp = hprev[0][1][0] - hprev[0][0][0];
+      // round 6: ONE pass over dg for both products of all four sequences (gru_wgrad.hip) when every operand is stored as bf16;
+      // MIMRL_NO_GRU_WGRAD=1: the two batched split-K GEMMs below (each reads three of dg's four column blocks)
+      static const bool wgrad_on = knob("MIMRL_NO_GRU_WGRAD") == nullptr;   // tuning knob
+      // (long sequences only: at cfg2's 6400 rows the launch is 40 us against 31 for the pair, whose two launches overlap -- 0.801 vs 0.799 ms)
+      const bool one_pass = wgrad_on && lbf && xpack16 && BT_ >= 32768 && gru_wgrad_ok(BT_, KP());
+      if (one_pass) {
+        GruWgradArgs w;
+        const __bf16* xb = reinterpret_cast<const __bf16*>(xpack + BT_ * KP());   // the bf16 copy of the packed inputs, [modality][B*T, KP]
+        for (int m = 0; m < 2; ++m)
+          for (int d = 0; d < 2; ++d)
+            w.seq[m * 2 + d] = GruWgradSeq{reinterpret_cast<const __bf16*>(dg[0][m][d]), xb + (long)m * BT_ * KP(),
+                                           reinterpret_cast<const __bf16*>(hprev[0][m][d]), dwih_pack + (long)(m * 2 + d) * G * KP(),
+                                           dwhh_pack + (long)(m * 2 + d) * G * H};
+        w.rows = BT_; w.kp = KP();
+        MX(gru_wgrad(stream, w));
+      } else {
       { GemmDesc q = gemm_tn(dg[0][0][0], 4 * H, xpack, KP(), dwih_pack, KP(), G, KP(), (int)BT_);
         q.batch = 4; q.batch_in = 2; q.sa_b = s_dg; q.sa_bo = o_dg; q.sb_b = 0; q.sb_bo = BT_ * KP(); q.sc_b = (long)G * KP(); q.sc_bo = 2L * G * KP();
         if (lbf) { q.a_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; }
@@ -578,6 +594,7 @@ int mimrl_handle::gru_layer_backward(int l) {
         if (lbf) { q.a_bf16 = q.b_bf16 = 1; q.sa_b *= 2; q.sa_bo *= 2; q.sb_b *= 2; q.sb_bo *= 2; }
         q.atomic = 1; MX(G_on(S(l0_side), q)); }
       MX(join(l0_side, l0_side));
+      }
       L0Unpack up;
       for (int m = 0; m < 2; ++m) {
         up.d[m] = gru[m][0][0].din;

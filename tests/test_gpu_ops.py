@@ -629,3 +629,30 @@ def test_gemm_tall_weight_gradient_shape(lib, M, N, K, gap, shared_b, monkeypatc
     err = (out.double() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= 3e-6 * scale + 1e-4, f"tall TN {M}x{N}x{K}: max |err| {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("rows,kp", [(48, 80), (6400, 80), (20000 + 17, 80), (4096 + 5, 40), (1600, 96), (33, 8)])
+def test_gru_wgrad_one_pass_over_dg(lib, rows, kp):
+    """gru_wgrad.hip (round 6): both layer-0 weight-gradient products of all four (modality, direction) sequences in ONE launch that reads
+    dg once -- dW_ih[s] [384, kp] += dgx_s^T x_s (dgx = dg columns [0, 384)), dW_hh[s] [384, 128] += dgh_s^T h_prev_s (dgh = columns
+    [0, 256) u [384, 512)), Model.py:254-255's autograd; x shared by the two directions of a modality; every operand stored as bf16.
+    Row counts that are not a multiple of the 32-row k-tile or of the ring depth, fewer k-tiles than k-ranges, every packed width class
+    (kp = 8, 40, 80, 96).  Reference: float64 product of the same bf16 operands; outputs accumulate with float atomics over the k-split, and
+    on top of what the arrays held before."""
+    g = np.random.default_rng(rows + kp)
+    dg = torch.from_numpy(g.standard_normal((4, rows, 512)).astype(np.float32)).to(torch.bfloat16).cuda()
+    x = torch.from_numpy(g.standard_normal((2, rows, kp)).astype(np.float32) * 0.5).to(torch.bfloat16).cuda()
+    hp = torch.from_numpy(g.standard_normal((4, rows, 128)).astype(np.float32) * 0.3).to(torch.bfloat16).cuda()
+    dwih = torch.full((4, 384, kp), 0.25, device="cuda")
+    dwhh = torch.full((4, 384, 128), -0.5, device="cuda")
+    arr = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    _lib.check(lib.mimrl_op_gru_wgrad(stream(), arr([dg[s] for s in range(4)]), arr([x[s // 2] for s in range(4)]), arr([hp[s] for s in range(4)]),
+                                      arr([dwih[s] for s in range(4)]), arr([dwhh[s] for s in range(4)]), rows, kp))
+    torch.cuda.synchronize()
+    d = dg.double()
+    ref_ih = torch.einsum("skr,skn->srn", d[..., :384], x.double()[[0, 0, 1, 1]]) + 0.25
+    ref_hh = torch.einsum("skr,skn->srn", d[..., np.r_[0:256, 384:512]], hp.double()) - 0.5
+    for name, got, ref in (("dW_ih", dwih, ref_ih), ("dW_hh", dwhh, ref_hh)):
+        err = (got.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= 3e-6 * scale + 1e-4, f"{name} rows={rows} kp={kp}: max |err| {err} (scale {scale})"
