@@ -111,6 +111,7 @@ def load() -> C.CDLL:
                                   C.c_float, C.c_float]
     lib.mimrl_op_gru_forward.argtypes = [_FP] * 11 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_gru_backward.argtypes = [_FP] * 12 + [C.c_int, C.c_int, C.c_int]
+    lib.mimrl_op_concat_dw.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 3
     lib.mimrl_op_gru_wgrad.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.c_int64, C.c_int]
     lib.mimrl_op_mi_bound.argtypes = [_FP] * 5 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_mi_bound_ex.argtypes = [_FP] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint32]
@@ -159,7 +160,7 @@ EXPORTS = [
     "mimrl_bucket_floats", "mimrl_create", "mimrl_bind", "mimrl_set_bank_rows", "mimrl_set_inputs", "mimrl_stage1_step", "mimrl_stage2_step", "mimrl_two_stage_step",
     "mimrl_stage_grads", "mimrl_stage_grads_part", "mimrl_stage_apply", "mimrl_forward", "mimrl_estimate", "mimrl_profile_enable", "mimrl_profile_read", "mimrl_profile_read_gemm",
     "mimrl_workspace_bytes", "mimrl_params_changed", "mimrl_set_stage2_prefetch", "mimrl_stage2_forward_tail", "mimrl_set_grad_scale", "mimrl_destroy", "mimrl_op_gemm", "mimrl_op_gemm_ex", "mimrl_op_gemm16", "mimrl_op_gemm_wgrad_group",
-    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_gru_wgrad", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_mi_sep_infonce", "mimrl_op_knn",
+    "mimrl_op_gru_saved_floats", "mimrl_op_gru_forward", "mimrl_op_gru_backward", "mimrl_op_gru_wgrad", "mimrl_op_concat_dw", "mimrl_op_mi_bound", "mimrl_op_mi_bound_ex", "mimrl_op_mi_bound_baseline", "mimrl_op_mi_sep_infonce", "mimrl_op_knn",
     "mimrl_op_cmi_loss", "mimrl_op_sample_anchors", "mimrl_knn_r1_host", "mimrl_set_knn_override_mask", "mimrl_op_mlp_stack_forward", "mimrl_op_mlp_stack_backward", "mimrl_op_adam",
     "mimrl_probe_cube", "mimrl_probe_mi", "mimrl_probe_cmi", "mimrl_probe_knn", "mimrl_probe_encoders", "mimrl_set_kernel_stamps", "mimrl_comm_unique_id", "mimrl_set_comm", "mimrl_main_late_offset", "mimrl_set_comm_critic_bf16",
     "mimrl_stage1_pipe_prime", "mimrl_stage1_pipe",

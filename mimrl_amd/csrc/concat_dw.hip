@@ -1,0 +1,224 @@
+// Weight gradients of the concat critic's two hidden layers (stage 1), every operand row staged ONCE (round 6).
+//
+// Reference semantics: autograd of the three-layer critic of VMI.py:58-65 over the B x B pair rows -- per estimator e and hidden layer l
+//   dW_l[e] [256, 256] += dZ_l[e]^T A_{l-1}[e],   dZ_l, A_{l-1}: [B*B, 256]
+// with dZ_l as the fused backward kernel stored it (bf16) and A_{l-1} the bf16 activation copy of the forward kernel.
+//
+// Until now: one split-K GEMM launch per layer on 128 x 128 tiles -- 4 output tiles per estimator, so every dZ and A row went through two
+// workgroups' LDS (0.67 GB staged per layer for 0.34 GB of operands at cfg3), 189 + 115 us in a row on stage 1's chain between the backward
+// kernel and the critic update.  What bounds such a product is the rate at which a CU takes data in under load (~20-26 GB/s, gru_wgrad.hip),
+// i.e. the bytes staged.  Here a workgroup holds the WHOLE 256 x 256 output of one (layer, estimator) for its k-range: 64 accumulator tiles
+// over 8 waves (2 m-tiles x 4 n-tiles each = 128 registers), both operands through a [k][column] LDS image as loaded and
+// ds_read_b64_tr_b16 (both are k-major in memory), register ring of FPF k-tiles with counted waits, each load issued behind an MFMA.  Both
+// layers in ONE launch: workgroup = (layer, estimator, k-range), ~one per CU -- plus, optionally, the score head's weight gradient
+// dw3[e] = ds[e]^T a2[e] (a streaming weighted column sum over the fp16 a2) on the remaining ninth of the CUs, sized to stage the same bytes
+// per workgroup.  The result leaves through acc_add (float atomics; the deterministic build's table).  Algorithmic bytes per launch at cfg3 (5 estimators, B = 256): 4 x 168 MB = 0.67 GB.
+#include "concat_dw.h"
+
+#include <type_traits>
+
+namespace mimrl {
+
+namespace {
+
+constexpr int CH = 256;                // hidden width
+constexpr int KT = 32;                 // pair rows per k-tile
+constexpr int PI = CH + 32;            // image pitch (elements): 576 B = 64 mod 256 -> the four k-rows of a transposed read hit distinct bank quarters
+constexpr int NT = 512;                // 8 waves: 4 (pairs of m-tiles) x 2 (halves of the n-tiles)
+constexpr int FPF = 3;                 // k-tiles in flight per workgroup (register ring)
+constexpr int NL = 4;                  // 16-byte pieces per thread and k-tile: 2 of dZ, 2 of A (32 rows x 256 columns each)
+
+typedef __attribute__((address_space(3))) bf16x4 lds4;
+
+__device__ __forceinline__ void gld16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int N, int NEWER>
+__device__ __forceinline__ void ring_wait(f32x4* v) {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+#pragma unroll
+  for (int h = 0; h < N; ++h) asm volatile("" : "+v"(v[h]));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// MFMA operand fragment of the 32 columns starting at `col` of a [k][column] image, k-step s (gru_wgrad.hip: frag)
+__device__ __forceinline__ bf16x8 frag(const __bf16* img, int fo, int col, int s) {
+  const __bf16* a = img + s * 16 * PI + col + fo;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4*)(a));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4*)(a + 4 * PI));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__global__ __launch_bounds__(NT) void concat_dw_kernel(ConcatDwArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2 * KT * PI];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[2 * KT * PI];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+  // workgroup -> (layer, estimator, k-range)
+  const int per = a.E * a.nsplit;
+  if ((int)blockIdx.x >= a.nlayer * per) {   // the score head's rows: (estimator, row range); 8 columns per lane, 32 lanes per row, 16 row phases
+    const int b3 = (int)blockIdx.x - a.nlayer * per, e = b3 / a.n3, part_i = b3 - e * a.n3;
+    const long r0 = (long)part_i * a.rows3, r1 = min(a.rows, r0 + a.rows3);
+    const float* __restrict__ dse = a.ds + (long)e * a.rows;
+    const _Float16* __restrict__ ae = a.a2 + (long)e * a.rows * CH;
+    const int c8 = (tid & 31) * 8, ph = tid >> 5;
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = r0 + ph; r < r1; r += 128) {
+      f16x8 v[8]; float d[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long rr = min(r + 16 * q, r1 - 1);
+        v[q] = *reinterpret_cast<const f16x8*>(ae + rr * CH + c8);
+        d[q] = r + 16 * q < r1 ? dse[rr] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) sum[jj] += d[q] * (float)v[q][jj];
+    }
+    float* part = reinterpret_cast<float*>(sA);          // [16][256] floats = 16 KB of the 36 KB image
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) part[ph * CH + c8 + jj] = sum[jj];
+    __syncthreads();
+    if (tid < CH) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) t += part[p * CH + tid];
+      acc_add(a.dw3 + (long)e * a.dw_stride + tid, t);
+    }
+    return;
+  }
+  const int layer = (int)blockIdx.x / per, rem = (int)blockIdx.x - layer * per, e = rem / a.nsplit, split = rem - e * a.nsplit;
+  const long rows = a.rows;
+  const __bf16* __restrict__ dz = a.dz[layer] + (long)e * rows * CH;
+  const __bf16* __restrict__ act = a.act[layer] + (long)e * rows * CH;
+  float* __restrict__ out = a.dw[layer] + (long)e * a.dw_stride;
+  const int ktiles = (int)((rows + KT - 1) / KT);
+  const int kt0 = split * a.kt_per;
+  const int kt1 = kt0 + a.kt_per < ktiles ? kt0 + a.kt_per : ktiles;
+  if (kt0 >= kt1) return;
+  const int last = kt1 - 1;
+
+  // per-thread piece coordinates (loop-invariant): piece p = tid + 512 i of a 32 x 256 tile -> row p >> 5, 16-byte chunk p & 31
+  int gp[2], lp[2], rp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + NT * i, row = p >> 5, ch = p & 31;
+    rp[i] = row; gp[i] = row * CH + 8 * ch; lp[i] = row * PI + 8 * ch;
+  }
+  const int j = lane & 15;
+  const int fo = (8 * (lane >> 5) + (j >> 2)) * PI + 16 * ((lane >> 4) & 1) + 4 * (j & 3);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+  f32x4 rg[FPF][NL];
+  // load number `idx` of set jj: tile kt (clamped to the range's last tile; rows past the end re-read the last row)
+  auto request_one = [&](auto J, auto IDX, int kt) __attribute__((always_inline)) {
+    constexpr int jj = decltype(J)::value, i = decltype(IDX)::value, h = i & 1;
+    const long k0 = (long)(kt < last ? kt : last) * KT;
+    const long r = k0 + rp[h] < rows ? k0 : rows - 1 - rp[h];
+    gld16(rg[jj][i], (i < 2 ? dz : act) + r * CH + gp[h]);
+  };
+  // set jj holds tile kt: FPF - 1 newer sets may still be in flight behind it.  Tiles past the workgroup's range (the k-loop runs whole
+  // groups of FPF tiles: one straight-line loop body, tools/isa_inflight.py can follow it) and rows past the end contribute zero dZ rows.
+  auto publish = [&](auto J, int buf, int kt) __attribute__((always_inline)) {
+    constexpr int jj = decltype(J)::value;
+    const bool live = kt <= last;
+    const long k0 = (long)(live ? kt : last) * KT;
+    ring_wait<NL, (FPF - 1) * NL>(rg[jj]);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    __bf16* A = sA + buf * (KT * PI);
+    __bf16* Bm = sB + buf * (KT * PI);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(A + lp[i]) = live && k0 + rp[i] < rows ? rg[jj][i] : z;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Bm + lp[i]) = rg[jj][2 + i];
+  };
+  static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
+    static_for<0, NL>([&](auto IDX) __attribute__((always_inline)) { request_one(J, IDX, kt0 + decltype(J)::value); });
+  });
+  publish(std::integral_constant<int, 0>{}, 0, kt0);
+  __syncthreads();
+  int cur = 0;
+  const int kt1r = kt0 + (kt1 - kt0 + FPF - 1) / FPF * FPF;
+  for (int kb = kt0; kb < kt1r; kb += FPF) {
+    static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
+      constexpr int jj = decltype(J)::value;
+      const int kt = kb + jj;
+      const __bf16* A = sA + cur * (KT * PI);
+      const __bf16* Bm = sB + cur * (KT * PI);
+      static_for<0, KT / 16>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        bf16x8 af[2], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = frag(A, fo, 32 * (2 * wm + i), s);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bfr[n] = frag(Bm, fo, 32 * (4 * wn + n), s);
+        static_for<0, 8>([&](auto E) __attribute__((always_inline)) {
+          constexpr int q = decltype(E)::value, i = q >> 2, n = q & 3, c = s * 8 + q;
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[n], acc[i][n], 0, 0, 0);
+          if constexpr (c < NL) {   // the loads of tile kt + FPF, one behind each of the first NL products (gru_wgrad.hip)
+            __builtin_amdgcn_sched_barrier(0);
+            request_one(J, std::integral_constant<int, c>{}, kt + FPF);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      });
+      publish(std::integral_constant<int, (jj + 1) % FPF>{}, cur ^ 1, kt + 1);
+      __syncthreads();
+      cur ^= 1;
+    });
+  }
+  // drain the ring's last (duplicate) requests; the ties keep their registers reserved up to the wait (gru_wgrad.hip)
+  static_for<0, FPF>([&](auto J) __attribute__((always_inline)) { ring_wait<NL, 0>(rg[decltype(J)::value]); });
+
+  // epilogue: dW[m][n], m = dZ column (the layer's output unit), n = A column (its input unit)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float* o = out + (long)(32 * (2 * wm + i) + 4 * (lane >> 5)) * CH + 32 * (4 * wn + n) + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_add(o + (long)((r & 3) + 8 * (r >> 2)) * CH, acc[i][n][r]);
+    }
+}
+
+}  // namespace
+
+bool concat_dw_ok(int E, long rows, int hid) { return hid == CH && E >= 1 && rows >= 1 && rows < (1L << 31) / PI; }
+
+int concat_dw(hipStream_t s, const ConcatDwArgs& in) {
+  if (in.nlayer < 1 || in.nlayer > 2) return set_error(MIMRL_ERR_ARG, "concat_dw: one or two layers");
+  ConcatDwArgs a = in;
+  const int ktiles = (int)((a.rows + KT - 1) / KT);
+  // ~one workgroup per CU (one is resident: 512 threads, 72 KB of LDS), each staging about the same number of bytes: a row of a product
+  // is 2 x 512 bytes, a row of the score head's 512 -- of 4 * nlayer + 1 shares of the CUs the products take 4 * nlayer
+  const bool with3 = a.ds && a.a2 && a.dw3;
+  if ((a.ds || a.a2 || a.dw3) && !with3) return set_error(MIMRL_ERR_ARG, "concat_dw: ds, a2 and dw3 come as a set");
+  const int cus = device_cus();
+  const int cus_dw = with3 ? cus * 4 * a.nlayer / (4 * a.nlayer + 1) : cus;
+  int nsplit = cus_dw / (a.nlayer * a.E);
+  if (nsplit > ktiles) nsplit = ktiles;
+  if (nsplit < 1) nsplit = 1;
+  a.kt_per = (ktiles + nsplit - 1) / nsplit;
+  a.nsplit = (ktiles + a.kt_per - 1) / a.kt_per;
+  a.n3 = 0;
+  if (with3) {
+    int n3 = (cus - a.nlayer * a.E * a.nsplit) / a.E;
+    if (n3 < 1) n3 = 1;
+    a.rows3 = ((a.rows + n3 - 1) / n3 + 127) / 128 * 128;
+    a.n3 = (int)((a.rows + a.rows3 - 1) / a.rows3);
+  }
+  hipLaunchKernelGGL(concat_dw_kernel, dim3((unsigned)(a.nlayer * a.E * a.nsplit + a.E * a.n3)), dim3(NT), 0, s, a);
+  LAUNCH_CHECK();
+  return MIMRL_OK;
+}
+
+}  // namespace mimrl

@@ -17,8 +17,9 @@ struct ConcatFwdArgs {
   const float *b1, *b2, *w3, *b3;             // fp32 biases, score-head weight [256] and bias [1]; estimator e at + e*pstride
   long pstride;                               // parameter stride between estimators (elements, same for the image and the fp32 bucket)
   // what the backward pass gets (save): 0 nothing (evaluation), 1 fp32 activations a0, a1, a2 (the unfused GEMM-chain backward),
-  // 2 compact: bf16 values a0b, a1b (operands of the weight-gradient GEMMs, which round to bf16 anyway), fp32 a2 (the score head's
-  //   weight gradient sum ds * a2 cancels to ~1e-3 of its terms: bf16 values are not good enough; read by concat_dw3 only) + ReLU
+  // 2 compact: bf16 values a0b, a1b (operands of the weight-gradient products, which round to bf16 anyway), a2 as fp32 (weight-streaming
+  //   kernel) or fp16 (weights-stationary kernel: concat_fwd_a2_f16) -- the score head's weight gradient sum ds * a2 cancels to ~1e-3 of
+  //   its terms: bf16 values are not good enough; read by concat_dw3 only -- + ReLU
   //   bitmasks m0, m1, m2 (one 32-bit word per row and 32 columns; the fused backward, stage 1),
   // 3 bitmasks only (the fused backward of stage 2: no weight gradients, only the signs are needed)
   // (round 5: save >= 2 also writes m0, the sign of the pair-expanded layer 0 -- the backward recomputed it from P_i + Q_j with 64 loads
@@ -71,7 +72,9 @@ long concat_bwd_ws_scratch(int E, int B);
 int concat_bwd_ws(hipStream_t s, const ConcatBwdArgs& a);
 int concat_fwd_ws4(hipStream_t s, const ConcatFwdArgs& a);   // tools/hw/concat_ws4.hip (experiment, not in the library): one wave per SIMD
 // dw3[e] += ds[e]^T a2[e]  (compact saves: concat_bwd_fused leaves the score head's weight gradient to this streaming launch)
-int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride);
+int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride, bool a2_f16 = false);
+// does a saving (save == 2) forward pass of this batch size leave a2 as fp16 behind the float-typed pointer?
+bool concat_fwd_a2_f16(int B, int save);
 #ifdef MIMRL_PHASE_PROBE
 int concat_bwd_read_phases(long long* out);   // 16 slots, read-and-clear (concat_fused.hip)
 #endif

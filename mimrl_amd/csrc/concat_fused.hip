@@ -490,9 +490,44 @@ __global__ __launch_bounds__(256) void concat_dw3_kernel(const float* __restrict
   acc_add(dw3 + (long)e * pstride + c, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 }  // namespace
-int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride) {
+// a2 stored as fp16 (the weights-stationary forward kernel, concat_fwd_a2_f16): 8 columns = 16 bytes per lane, 32 lanes per row, 8 row phases;
+// 8 loads per thread in flight, 1024 rows per workgroup
+namespace {
+__global__ __launch_bounds__(256) void concat_dw3_h_kernel(const float* __restrict__ ds, const _Float16* __restrict__ a2, float* __restrict__ dw3,
+                                                           long rows, long pstride) {
+  __shared__ float part[8][CH];
+  const int e = blockIdx.y, c8 = (threadIdx.x & 31) * 8, ph = threadIdx.x >> 5;
+  const long r0 = (long)blockIdx.x * 1024, r1 = min(rows, r0 + 1024);
+  const float* __restrict__ dse = ds + (long)e * rows;
+  const _Float16* __restrict__ ae = a2 + (long)e * rows * CH;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long r = r0 + ph; r < r1; r += 64) {
+    f16x8 v[8]; float d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long rr = min(r + 8 * q, r1 - 1);
+      v[q] = *reinterpret_cast<const f16x8*>(ae + rr * CH + c8);
+      d[q] = r + 8 * q < r1 ? dse[rr] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum[j] += d[q] * (float)v[q][j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[ph][c8 + j] = sum[j];
+  __syncthreads();
+  const int c = threadIdx.x;
+  float t = 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) t += part[p][c];
+  acc_add(dw3 + (long)e * pstride + c, t);
+}
+}  // namespace
+int concat_dw3(hipStream_t s, const float* ds, const float* a2, float* dw3, int E, int B, long pstride, bool a2_f16) {
   const long rows = (long)B * B;
-  hipLaunchKernelGGL(concat_dw3_kernel, dim3((unsigned)((rows + 511) / 512), E), dim3(256), 0, s, ds, a2, dw3, rows, pstride);
+  if (a2_f16) hipLaunchKernelGGL(concat_dw3_h_kernel, dim3((unsigned)((rows + 1023) / 1024), E), dim3(256), 0, s, ds, reinterpret_cast<const _Float16*>(a2), dw3, rows, pstride);
+  else hipLaunchKernelGGL(concat_dw3_kernel, dim3((unsigned)((rows + 511) / 512), E), dim3(256), 0, s, ds, a2, dw3, rows, pstride);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }
@@ -558,6 +593,11 @@ int concat_bwd_fused(hipStream_t s, const ConcatBwdArgs& a) {
 }
 
 bool concat_fwd_fused_supported(int B, int hid) { return hid == CH && B >= 16 && ((long)B * B) % CR == 0; }
+
+// does a saving forward pass of this shape leave a2 as fp16 (the weights-stationary kernel, round 6) rather than fp32?  The score head's
+// weight gradient sum_rows ds * a2 cancels to ~1e-3 of its terms: bf16's 8 bits were not enough (round 4), fp16's 11 give ~2e-3 of the
+// gradient's scale at B = 256 (sqrt(N) 2^-11 against N 1e-3) -- and 168 MB less to write and to read per critic pass at cfg3
+bool concat_fwd_a2_f16(int B, int save) { return save == 2 && concat_fwd_ws_supported(B, CH, save) && !knob_on("MIMRL_CONCAT_STREAMED"); }
 
 int concat_fwd_fused(hipStream_t s, const ConcatFwdArgs& a) {
   if (!concat_fwd_fused_supported(a.B, CH)) return set_error(MIMRL_ERR_ARG, "concat_fwd_fused: batch %d unsupported", a.B);

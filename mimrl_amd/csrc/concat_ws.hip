@@ -38,7 +38,7 @@ __device__ long long g_ws_clk[2];   // shader-clock cycles / 100 MHz ticks of wo
 #define WPH(i) do { } while (0)
 #endif
 
-// SAVE: what the backward pass gets (ConcatFwdArgs::save): 0 nothing, 2 bf16 a0 / a1 + fp32 a2 + sign words (stage 1), 3 sign words only
+// SAVE: what the backward pass gets (ConcatFwdArgs::save): 0 nothing, 2 bf16 a0 / a1 + fp16 a2 + sign words (stage 1), 3 sign words only
 //
 // Iteration t of a run of U units (t = -2 .. U + 4); a barrier behind every ODD iteration (operand tiles live in rings of four units, every
 // producer is two iterations ahead of its consumer: exactly one barrier in between -- half the barriers of a one-unit step):
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512) void concat_fwd_ws_kernel(ConcatFwdArgs a, int
       }
     }
   };
-  // layer 2: ReLU -> sign word, fp32 a2 (stage 1: the score head's weight gradient reads it), score head partial dot product
+  // layer 2: ReLU -> sign word, fp16 a2 (stage 1: the score head's weight gradient reads it), score head partial dot product (on the fp32 values)
   auto epilogue2 = [&](const UnitRef& u, int slot) __attribute__((always_inline)) {
 #ifdef WS_X_NOEPI
     { float t = 0.f;
@@ -224,7 +224,11 @@ __global__ __launch_bounds__(512) void concat_fwd_ws_kernel(ConcatFwdArgs a, int
         v.x = relu1(acc[ct][4 * q]); v.y = relu1(acc[ct][4 * q + 1]); v.z = relu1(acc[ct][4 * q + 2]); v.w = relu1(acc[ct][4 * q + 3]);
         const float4 w3v = *reinterpret_cast<const float4*>(&sw3[f0]);
         hp += v.x * w3v.x + v.y * w3v.y + v.z * w3v.z + v.w * w3v.w;
-        if (SAVE == 2) { GLOBAL_AS float* o = uptr(a.a2 + (long)u.base * CH + ws * 64 + ct * 32 + 8 * q); f32x4v t_ = {v.x, v.y, v.z, v.w}; *(GLOBAL_AS f32x4v*)(o + row_f) = t_; }
+        if (SAVE == 2) {   // a2 leaves as fp16 (concat_fwd_a2_f16: same element indices behind the float-typed pointer)
+          GLOBAL_AS _Float16* o = (GLOBAL_AS _Float16*)uptr(reinterpret_cast<_Float16*>(a.a2) + (long)u.base * CH + ws * 64 + ct * 32 + 8 * q);
+          f16x4 t_; t_[0] = to_f16_sat(v.x); t_[1] = to_f16_sat(v.y); t_[2] = to_f16_sat(v.z); t_[3] = to_f16_sat(v.w);
+          *(GLOBAL_AS f16x4*)(o + row_f) = t_;
+        }
       }
     }
     hp = add_halves(hp);

@@ -33,6 +33,7 @@
 #include "gemm.h"
 #include "gru.h"
 #include "gru_wgrad.h"
+#include "concat_dw.h"
 #include "lstm.h"
 #include "layout.h"
 #include "comm.h"

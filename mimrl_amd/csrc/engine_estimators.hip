@@ -393,6 +393,19 @@ int mimrl_handle::mi_backward(int stage) {
     const bool side_wg = wgrad && multi_stream && wg_helper >= 0;
     if (wgrad) {   // dW2 = dZ2^T a1, dW1 = dZ1^T a0: K = B*B rows, split-K with atomics, beside pair_reduce_q on the helper stream
       if (side_wg) MX(fork(wg_helper, wg_helper));
+      bool dw3_done = false;
+      // round 6: both layers as ONE launch whose workgroups hold a whole 256 x 256 output (concat_dw.hip: every dZ / A row staged once);
+      // MIMRL_NO_CONCAT_DW=1: the two split-K GEMMs on 128 x 128 tiles
+      static const bool dw_on = knob("MIMRL_NO_CONCAT_DW") == nullptr;   // tuning knob
+      if (dw_on && concat_dw_ok(NE_MI, (long)B * B, HID)) {
+        ConcatDwArgs w;
+        w.dz[0] = dz2; w.act[0] = reinterpret_cast<const __bf16*>(ca[1]); w.dw[0] = CG(tower0 + tower_l[2][0]);
+        w.dz[1] = dz1; w.act[1] = reinterpret_cast<const __bf16*>(ca[0]); w.dw[1] = CG(tower0 + tower_l[1][0]);
+        w.nlayer = 2; w.E = NE_MI; w.rows = (long)B * B; w.dw_stride = tower_stride;
+        dw3_done = concat_fwd_a2_f16(B, 2);   // the score head's weight gradient rides on the same launch when a2 is the fp16 copy
+        if (dw3_done) { w.ds = dscores; w.a2 = reinterpret_cast<const _Float16*>(ca[2]); w.dw3 = CG(tower0 + tower_l[3][0]); }
+        MX(concat_dw(dw3_done ? stream : side_wg ? S(wg_helper) : stream, w));
+      } else
       for (int l = 2; l >= 1; --l) {
         GemmDesc g;
         g.A = reinterpret_cast<const float*>(l == 2 ? dz2 : dz1); g.a_bf16 = 1; g.sa_m = 1; g.sa_k = HID; g.sa_b = (long)B * B * HID;
@@ -403,7 +416,7 @@ int mimrl_handle::mi_backward(int stage) {
       }
       // the score head's weight gradient streams a2 on the main stream, under the products on the helper (one of the two products on the
       // main stream as well: no change, 5.87-5.90 vs 5.87-5.92 ms at cfg3)
-      MX(concat_dw3(stream, dscores, ca[2], CG(tower0 + tower_l[3][0]), NE_MI, B, tower_stride));
+      if (!dw3_done) MX(concat_dw3(stream, dscores, ca[2], CG(tower0 + tower_l[3][0]), NE_MI, B, tower_stride, concat_fwd_a2_f16(B, 2)));
     }
     if (!dq_in_kernel) MX(pair_reduce_q(stream, dca[2], dQ, NE_MI, B, HID));
     if (side_wg) MX(join(wg_helper, wg_helper));

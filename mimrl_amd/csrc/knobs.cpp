@@ -27,6 +27,7 @@ const KnobDef kKnobs[] = {
   {"MIMRL_GRU_WAVES", "gru.hip", "4", "8: one hidden unit per lane, two waves per SIMD, in the bf16 recurrence kernels (default 4)"},
   {"MIMRL_GX_F16", "engine_abi.hip", "", "1: hoisted GRU input projections stored as fp16 (measured slower at cfg3)"},
   {"MIMRL_L0_PACK", "engine_abi.hip", "", "0: no packed layer-0 operands (2 + 4 launches instead of 1 + 2)"},
+  {"MIMRL_NO_CONCAT_DW", "engine_estimators.hip", "", "1: the concat critic's hidden-layer weight gradients as two split-K GEMMs instead of the one-launch kernel (concat_dw.hip, round 6)"},
   {"MIMRL_NO_GRU_WGRAD", "engine_backward.hip", "", "1: the layer-0 GRU weight gradients as two batched split-K GEMMs instead of the one-pass kernel (gru_wgrad.hip, round 6)"},
   {"MIMRL_LAXIS_BWD_LONG", "engine_abi.hip", "", "0: the L-axis backward of a long-sequence CubeMLP block (L > 64) as colln_bwd + GEMM chain instead of the LONG instantiation of laxis_bwd_kernel"},
   {"MIMRL_LAXIS_LONG", "engine_abi.hip", "", "0: the L-axis MLP of a long-sequence CubeMLP block (L > 64) as the GEMM chain instead of the one-pass kernel of cube_long.hip"},

@@ -656,3 +656,35 @@ def test_gru_wgrad_one_pass_over_dg(lib, rows, kp):
         err = (got.double() - ref).abs().max().item()
         scale = ref.abs().max().item()
         assert err <= 3e-6 * scale + 1e-4, f"{name} rows={rows} kp={kp}: max |err| {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("E,rows,two,head", [(3, 4096, True, True), (2, 100, True, True), (5, 16384, True, True), (1, 33, False, False), (2, 65536, True, True),
+                                              (4, 1000, False, True)])
+def test_concat_dw_whole_output_per_workgroup(lib, E, rows, two, head):
+    """concat_dw.hip (round 6): the stage-1 weight gradients of the concat critic's hidden layers (VMI.py:58-65 under autograd),
+    dW_l[e] [256, 256] += dZ_l[e]^T A_{l-1}[e] over the B*B pair rows, both layers in one launch whose workgroups hold a whole 256 x 256
+    output, operands stored as bf16 -- and, on extra workgroups of the same launch, the score head's dw3[e] [256] += ds[e]^T a2[e] with a2
+    stored as fp16.  Row counts that are not a multiple of the 32-row k-tile, of the ring depth or of the score head's 128-row pass, fewer
+    k-tiles than k-ranges, one layer only, with and without the score head, estimator outputs a stride apart.  Reference: float64 product of
+    the same 16-bit operands; the outputs accumulate (float atomics over the k-split) on top of what they held."""
+    g = np.random.default_rng(E * 1000 + rows)
+    mk = lambda sc: torch.from_numpy(g.standard_normal((E, rows, 256)).astype(np.float32) * sc).to(torch.bfloat16).cuda()
+    dz2, a1, dz1, a0 = mk(0.1), mk(0.5), mk(0.1), mk(0.5)
+    ds = torch.from_numpy(g.standard_normal((E, rows)).astype(np.float32) * 0.01).cuda()
+    a2 = torch.from_numpy(np.maximum(g.standard_normal((E, rows, 256)), 0).astype(np.float32)).to(torch.float16).cuda()
+    stride = 256 * 256 + 1024
+    dw2 = torch.full((E, stride), 0.5, device="cuda"); dw1 = torch.full((E, stride), -0.25, device="cuda"); dw3 = torch.full((E, stride), 0.125, device="cuda")
+    _lib.check(lib.mimrl_op_concat_dw(stream(), P(dz2), P(a1), P(dw2), P(dz1) if two else None, P(a0) if two else None, P(dw1) if two else None,
+                                      E, rows, stride, P(ds) if head else None, P(a2) if head else None, P(dw3) if head else None))
+    torch.cuda.synchronize()
+    for name, got, dz, act, base, on in (("dW2", dw2, dz2, a1, 0.5, True), ("dW1", dw1, dz1, a0, -0.25, two)):
+        ref = torch.einsum("ekm,ekn->emn", dz.double(), act.double()) + base if on else torch.full((E, 256, 256), base, device="cuda", dtype=torch.float64)
+        out = got[:, :65536].reshape(E, 256, 256).double()
+        err = (out - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= 3e-6 * scale + 1e-4, f"{name} E={E} rows={rows}: max |err| {err} (scale {scale})"
+        assert torch.all(got[:, 65536:] == base), f"{name}: wrote past its 256 x 256 block"
+    ref3 = torch.einsum("ek,ekn->en", ds.double(), a2.double()) + 0.125 if head else torch.full((E, 256), 0.125, device="cuda", dtype=torch.float64)
+    err = (dw3[:, :256].double() - ref3).abs().max().item()
+    assert err <= 3e-6 * ref3.abs().max().item() + 1e-5 * math.sqrt(rows), f"dw3 E={E} rows={rows}: max |err| {err}"
+    assert torch.all(dw3[:, 256:] == 0.125), "dw3: wrote past its 256 floats"
