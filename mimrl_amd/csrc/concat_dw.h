@@ -16,7 +16,10 @@ struct ConcatDwArgs {
   // [E][rows] fp32 and a2 [E][rows, 256] stored as fp16 (concat_fwd_a2_f16) -- as its own launch beside this one the two competed for the
   // CUs' intake and the slower of them closed stage 1's chain
   const float* ds = nullptr; const _Float16* a2 = nullptr; float* dw3 = nullptr;
-  int nsplit = 0, kt_per = 0, n3 = 0; long rows3 = 0;   // filled by concat_dw(): k-ranges per (layer, estimator); dw3 workgroups per estimator, rows each
+  // optional: dz[0] is NOT read but regenerated (concat_dw.hip: GEN) from ds, the layer-2 sign words m2 [E][rows][8] (bit c of word g = sign of
+  // column 32 g + c) and the score head's weight w3 (estimator e at + e * dw_stride); needs ds
+  const uint32_t* m2 = nullptr; const float* w3 = nullptr;
+  int nsplit_l[2] = {0, 0}, kt_per_l[2] = {0, 0}, n3 = 0; long rows3 = 0;   // filled by concat_dw(): k-ranges per estimator of each layer, k-tiles each; dw3 workgroups per estimator, rows each
 };
 bool concat_dw_ok(int E, long rows, int hid);
 int concat_dw(hipStream_t s, const ConcatDwArgs& a);

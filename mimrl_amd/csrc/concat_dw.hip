@@ -31,11 +31,20 @@ constexpr int NL = 4;                  // 16-byte pieces per thread and k-tile: 
 typedef __attribute__((address_space(3))) bf16x4 lds4;
 
 __device__ __forceinline__ void gld16(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void gld4(uint32_t& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 template <int N, int NEWER>
 __device__ __forceinline__ void ring_wait(f32x4* v) {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
 #pragma unroll
   for (int h = 0; h < N; ++h) asm volatile("" : "+v"(v[h]));
+}
+template <int NEWER>
+__device__ __forceinline__ void gen_wait(uint32_t* g, f32x4* v) {   // the GEN set: four dwords + two pieces
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NEWER) : "memory");
+#pragma unroll
+  for (int h = 0; h < 4; ++h) asm volatile("" : "+v"(g[h]));
+  asm volatile("" : "+v"(v[0]));
+  asm volatile("" : "+v"(v[1]));
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -51,14 +60,158 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* img, int fo, int col, int s
   return r;
 }
 
+// GEN (layer 2 only): the dZ2 tile is not loaded but regenerated -- dZ2[r][c] = bf16(ds[r] * w3[c]) where bit c of the layer-2 sign words is
+// set, exactly what concat_bwd_ws_kernel computes for its own product (concat_ws_bwd.hip: gen_finish) and, until this round, also wrote out:
+// 168 MB less to write there and to read here per critic pass at cfg3.  Per piece (row, 8 columns): one sign word + one ds value.
+template <bool GEN>
+__device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e, int kt0, int kt1, __bf16* sA, __bf16* sB) {
+  constexpr int NLD = GEN ? 6 : NL;    // load instructions per thread and k-tile
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+  const long rows = a.rows;
+  const __bf16* __restrict__ dz = a.dz[layer] + (long)e * rows * CH;
+  const __bf16* __restrict__ act = a.act[layer] + (long)e * rows * CH;
+  float* __restrict__ out = a.dw[layer] + (long)e * a.dw_stride;
+  const int last = kt1 - 1;
+
+  // per-thread piece coordinates (loop-invariant): piece p = tid + 512 i of a 32 x 256 tile -> row p >> 5, 16-byte chunk p & 31
+  int gp[2], lp[2], rp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + NT * i, row = p >> 5, ch = p & 31;
+    rp[i] = row; gp[i] = row * CH + 8 * ch; lp[i] = row * PI + 8 * ch;
+  }
+  const int chn = tid & 31;            // this thread's 8-column chunk (the same for both of its pieces)
+  [[maybe_unused]] const uint32_t* __restrict__ m2e = nullptr;
+  [[maybe_unused]] const float* __restrict__ dse = nullptr;
+  [[maybe_unused]] float w3r[8];
+  if constexpr (GEN) {
+    m2e = a.m2 + (long)e * rows * 8 + (chn >> 2);
+    dse = a.ds + (long)e * rows;
+    const float* w3p = a.w3 + (long)e * a.dw_stride + 8 * chn;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w3r[c] = w3p[c];
+  }
+  const int j = lane & 15;
+  const int fo = (8 * (lane >> 5) + (j >> 2)) * PI + 16 * ((lane >> 4) & 1) + 4 * (j & 3);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+
+  f32x4 rg[FPF][NL];                    // [0, 1]: dZ pieces (not GEN), [2, 3]: A pieces
+  [[maybe_unused]] uint32_t gw[FPF][4]; // GEN: {sign word, ds} of the two rows
+  // load number `idx` of set jj: tile kt (clamped to the range's last tile; rows past the end re-read the last row)
+  auto request_one = [&](auto J, auto IDX, int kt) __attribute__((always_inline)) {
+    constexpr int jj = decltype(J)::value, i = decltype(IDX)::value;
+    const long k0 = (long)(kt < last ? kt : last) * KT;
+    if constexpr (GEN) {
+      if constexpr (i < 4) {
+        constexpr int h = i >> 1;
+        const long r = (k0 + rp[h] < rows ? k0 : rows - 1 - rp[h]) + rp[h];
+        if constexpr ((i & 1) == 0) gld4(gw[jj][i], m2e + r * 8); else gld4(gw[jj][i], dse + r);
+      } else {
+        constexpr int h = i - 4;
+        const long r = k0 + rp[h] < rows ? k0 : rows - 1 - rp[h];
+        gld16(rg[jj][2 + h], act + r * CH + gp[h]);
+      }
+    } else {
+      constexpr int h = i & 1;
+      const long r = k0 + rp[h] < rows ? k0 : rows - 1 - rp[h];
+      gld16(rg[jj][i], (i < 2 ? dz : act) + r * CH + gp[h]);
+    }
+  };
+  auto wait_set = [&](auto J, auto NEWER) __attribute__((always_inline)) {
+    constexpr int jj = decltype(J)::value;
+    if constexpr (GEN) gen_wait<decltype(NEWER)::value>(gw[jj], rg[jj] + 2);
+    else ring_wait<NL, decltype(NEWER)::value>(rg[jj]);
+  };
+  // set jj holds tile kt: FPF - 1 newer sets may still be in flight behind it.  Tiles past the workgroup's range (the k-loop runs whole
+  // groups of FPF tiles: one straight-line loop body, tools/isa_inflight.py can follow it) and rows past the end contribute zero dZ rows.
+  auto publish = [&](auto J, int buf, int kt) __attribute__((always_inline)) {
+    constexpr int jj = decltype(J)::value;
+    const bool live = kt <= last;
+    const long k0 = (long)(live ? kt : last) * KT;
+    wait_set(J, std::integral_constant<int, (FPF - 1) * NLD>{});
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    __bf16* A = sA + buf * (KT * PI);
+    __bf16* Bm = sB + buf * (KT * PI);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 piece;
+      if constexpr (GEN) {
+        const uint32_t bits = gw[jj][2 * i] >> (8 * (chn & 3));
+        const float d = __uint_as_float(gw[jj][2 * i + 1]);
+        bf16x8 v;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = to_bf16((bits >> c) & 1u ? d * w3r[c] : 0.f);
+        piece = __builtin_bit_cast(f32x4, v);
+      } else piece = rg[jj][i];
+      *reinterpret_cast<f32x4*>(A + lp[i]) = live && k0 + rp[i] < rows ? piece : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Bm + lp[i]) = rg[jj][2 + i];
+  };
+  static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
+    static_for<0, NLD>([&](auto IDX) __attribute__((always_inline)) { request_one(J, IDX, kt0 + decltype(J)::value); });
+  });
+  publish(std::integral_constant<int, 0>{}, 0, kt0);
+  __syncthreads();
+  int cur = 0;
+  const int kt1r = kt0 + (kt1 - kt0 + FPF - 1) / FPF * FPF;
+  for (int kb = kt0; kb < kt1r; kb += FPF) {
+    static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
+      constexpr int jj = decltype(J)::value;
+      const int kt = kb + jj;
+      const __bf16* A = sA + cur * (KT * PI);
+      const __bf16* Bm = sB + cur * (KT * PI);
+      static_for<0, KT / 16>([&](auto S) __attribute__((always_inline)) {
+        constexpr int s = decltype(S)::value;
+        bf16x8 af[2], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = frag(A, fo, 32 * (2 * wm + i), s);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bfr[n] = frag(Bm, fo, 32 * (4 * wn + n), s);
+        static_for<0, 8>([&](auto E) __attribute__((always_inline)) {
+          constexpr int q = decltype(E)::value, i = q >> 2, n = q & 3, c = s * 8 + q;
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[n], acc[i][n], 0, 0, 0);
+          if constexpr (c < NLD) {   // the loads of tile kt + FPF, one behind each of the first NLD products (gru_wgrad.hip)
+            __builtin_amdgcn_sched_barrier(0);
+            request_one(J, std::integral_constant<int, c>{}, kt + FPF);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      });
+      publish(std::integral_constant<int, (jj + 1) % FPF>{}, cur ^ 1, kt + 1);
+      __syncthreads();
+      cur ^= 1;
+    });
+  }
+  // drain the ring's last (duplicate) requests; the ties keep their registers reserved up to the wait (gru_wgrad.hip)
+  static_for<0, FPF>([&](auto J) __attribute__((always_inline)) { wait_set(J, std::integral_constant<int, 0>{}); });
+
+  // epilogue: dW[m][n], m = dZ column (the layer's output unit), n = A column (its input unit)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float* o = out + (long)(32 * (2 * wm + i) + 4 * (lane >> 5)) * CH + 32 * (4 * wn + n) + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_add(o + (long)((r & 3) + 8 * (r >> 2)) * CH, acc[i][n][r]);
+    }
+}
+
 __global__ __launch_bounds__(NT) void concat_dw_kernel(ConcatDwArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sA[2 * KT * PI];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2 * KT * PI];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-  // workgroup -> (layer, estimator, k-range)
-  const int per = a.E * a.nsplit;
-  if ((int)blockIdx.x >= a.nlayer * per) {   // the score head's rows: (estimator, row range); 8 columns per lane, 32 lanes per row, 16 row phases
-    const int b3 = (int)blockIdx.x - a.nlayer * per, e = b3 / a.n3, part_i = b3 - e * a.n3;
+  // workgroup -> (layer, estimator, k-range) | (score head: estimator, row range)
+  const int n0 = a.E * a.nsplit_l[0], n1 = a.nlayer > 1 ? a.E * a.nsplit_l[1] : 0;
+  if ((int)blockIdx.x >= n0 + n1) {   // the score head's rows: 8 columns per lane, 32 lanes per row, 16 row phases
+    const int b3 = (int)blockIdx.x - n0 - n1, e = b3 / a.n3, part_i = b3 - e * a.n3;
     const long r0 = (long)part_i * a.rows3, r1 = min(a.rows, r0 + a.rows3);
     const float* __restrict__ dse = a.ds + (long)e * a.rows;
     const _Float16* __restrict__ ae = a.a2 + (long)e * a.rows * CH;
@@ -89,105 +242,14 @@ __global__ __launch_bounds__(NT) void concat_dw_kernel(ConcatDwArgs a) {
     }
     return;
   }
-  const int layer = (int)blockIdx.x / per, rem = (int)blockIdx.x - layer * per, e = rem / a.nsplit, split = rem - e * a.nsplit;
-  const long rows = a.rows;
-  const __bf16* __restrict__ dz = a.dz[layer] + (long)e * rows * CH;
-  const __bf16* __restrict__ act = a.act[layer] + (long)e * rows * CH;
-  float* __restrict__ out = a.dw[layer] + (long)e * a.dw_stride;
-  const int ktiles = (int)((rows + KT - 1) / KT);
-  const int kt0 = split * a.kt_per;
-  const int kt1 = kt0 + a.kt_per < ktiles ? kt0 + a.kt_per : ktiles;
+  const int layer = (int)blockIdx.x >= n0 ? 1 : 0, rem = (int)blockIdx.x - (layer ? n0 : 0), nsp = a.nsplit_l[layer];
+  const int e = rem / nsp, split = rem - e * nsp;
+  const int ktiles = (int)((a.rows + KT - 1) / KT);
+  const int kt0 = split * a.kt_per_l[layer];
+  const int kt1 = kt0 + a.kt_per_l[layer] < ktiles ? kt0 + a.kt_per_l[layer] : ktiles;
   if (kt0 >= kt1) return;
-  const int last = kt1 - 1;
-
-  // per-thread piece coordinates (loop-invariant): piece p = tid + 512 i of a 32 x 256 tile -> row p >> 5, 16-byte chunk p & 31
-  int gp[2], lp[2], rp[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int p = tid + NT * i, row = p >> 5, ch = p & 31;
-    rp[i] = row; gp[i] = row * CH + 8 * ch; lp[i] = row * PI + 8 * ch;
-  }
-  const int j = lane & 15;
-  const int fo = (8 * (lane >> 5) + (j >> 2)) * PI + 16 * ((lane >> 4) & 1) + 4 * (j & 3);
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
-
-  f32x4 rg[FPF][NL];
-  // load number `idx` of set jj: tile kt (clamped to the range's last tile; rows past the end re-read the last row)
-  auto request_one = [&](auto J, auto IDX, int kt) __attribute__((always_inline)) {
-    constexpr int jj = decltype(J)::value, i = decltype(IDX)::value, h = i & 1;
-    const long k0 = (long)(kt < last ? kt : last) * KT;
-    const long r = k0 + rp[h] < rows ? k0 : rows - 1 - rp[h];
-    gld16(rg[jj][i], (i < 2 ? dz : act) + r * CH + gp[h]);
-  };
-  // set jj holds tile kt: FPF - 1 newer sets may still be in flight behind it.  Tiles past the workgroup's range (the k-loop runs whole
-  // groups of FPF tiles: one straight-line loop body, tools/isa_inflight.py can follow it) and rows past the end contribute zero dZ rows.
-  auto publish = [&](auto J, int buf, int kt) __attribute__((always_inline)) {
-    constexpr int jj = decltype(J)::value;
-    const bool live = kt <= last;
-    const long k0 = (long)(live ? kt : last) * KT;
-    ring_wait<NL, (FPF - 1) * NL>(rg[jj]);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    __bf16* A = sA + buf * (KT * PI);
-    __bf16* Bm = sB + buf * (KT * PI);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(A + lp[i]) = live && k0 + rp[i] < rows ? rg[jj][i] : z;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Bm + lp[i]) = rg[jj][2 + i];
-  };
-  static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
-    static_for<0, NL>([&](auto IDX) __attribute__((always_inline)) { request_one(J, IDX, kt0 + decltype(J)::value); });
-  });
-  publish(std::integral_constant<int, 0>{}, 0, kt0);
-  __syncthreads();
-  int cur = 0;
-  const int kt1r = kt0 + (kt1 - kt0 + FPF - 1) / FPF * FPF;
-  for (int kb = kt0; kb < kt1r; kb += FPF) {
-    static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
-      constexpr int jj = decltype(J)::value;
-      const int kt = kb + jj;
-      const __bf16* A = sA + cur * (KT * PI);
-      const __bf16* Bm = sB + cur * (KT * PI);
-      static_for<0, KT / 16>([&](auto S) __attribute__((always_inline)) {
-        constexpr int s = decltype(S)::value;
-        bf16x8 af[2], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = frag(A, fo, 32 * (2 * wm + i), s);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) bfr[n] = frag(Bm, fo, 32 * (4 * wn + n), s);
-        static_for<0, 8>([&](auto E) __attribute__((always_inline)) {
-          constexpr int q = decltype(E)::value, i = q >> 2, n = q & 3, c = s * 8 + q;
-          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[n], acc[i][n], 0, 0, 0);
-          if constexpr (c < NL) {   // the loads of tile kt + FPF, one behind each of the first NL products (gru_wgrad.hip)
-            __builtin_amdgcn_sched_barrier(0);
-            request_one(J, std::integral_constant<int, c>{}, kt + FPF);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        });
-      });
-      publish(std::integral_constant<int, (jj + 1) % FPF>{}, cur ^ 1, kt + 1);
-      __syncthreads();
-      cur ^= 1;
-    });
-  }
-  // drain the ring's last (duplicate) requests; the ties keep their registers reserved up to the wait (gru_wgrad.hip)
-  static_for<0, FPF>([&](auto J) __attribute__((always_inline)) { ring_wait<NL, 0>(rg[decltype(J)::value]); });
-
-  // epilogue: dW[m][n], m = dZ column (the layer's output unit), n = A column (its input unit)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      float* o = out + (long)(32 * (2 * wm + i) + 4 * (lane >> 5)) * CH + 32 * (4 * wn + n) + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_add(o + (long)((r & 3) + 8 * (r >> 2)) * CH, acc[i][n][r]);
-    }
+  if (layer == 0 && a.m2) products<true>(a, layer, e, kt0, kt1, sA, sB);
+  else products<false>(a, layer, e, kt0, kt1, sA, sB);
 }
 
 }  // namespace
@@ -198,25 +260,36 @@ int concat_dw(hipStream_t s, const ConcatDwArgs& in) {
   if (in.nlayer < 1 || in.nlayer > 2) return set_error(MIMRL_ERR_ARG, "concat_dw: one or two layers");
   ConcatDwArgs a = in;
   const int ktiles = (int)((a.rows + KT - 1) / KT);
-  // ~one workgroup per CU (one is resident: 512 threads, 72 KB of LDS), each staging about the same number of bytes: a row of a product
-  // is 2 x 512 bytes, a row of the score head's 512 -- of 4 * nlayer + 1 shares of the CUs the products take 4 * nlayer
+  // ~one workgroup per CU (one is resident: 512 threads, 72 KB of LDS), each busy for about the same time: per pair row a product stages
+  // 2 x 512 bytes (1 x 512 + 36 when its dZ is regenerated), the score head 512 -- the CUs are dealt in shares that follow
   const bool with3 = a.ds && a.a2 && a.dw3;
-  if ((a.ds || a.a2 || a.dw3) && !with3) return set_error(MIMRL_ERR_ARG, "concat_dw: ds, a2 and dw3 come as a set");
+  if ((a.a2 || a.dw3) && !with3) return set_error(MIMRL_ERR_ARG, "concat_dw: ds, a2 and dw3 come as a set");
+  const bool gen = a.m2 != nullptr;
+  if (gen && !(a.w3 && a.ds)) return set_error(MIMRL_ERR_ARG, "concat_dw: regenerating dZ2 needs m2, w3 and ds");
+  if (!gen && !a.dz[0]) return set_error(MIMRL_ERR_ARG, "concat_dw: null dZ");
   const int cus = device_cus();
-  const int cus_dw = with3 ? cus * 4 * a.nlayer / (4 * a.nlayer + 1) : cus;
-  int nsplit = cus_dw / (a.nlayer * a.E);
-  if (nsplit > ktiles) nsplit = ktiles;
-  if (nsplit < 1) nsplit = 1;
-  a.kt_per = (ktiles + nsplit - 1) / nsplit;
-  a.nsplit = (ktiles + a.kt_per - 1) / a.kt_per;
+  // (shares in tenths of a full product's: a k-tile whose dZ is regenerated still costs its MFMAs, LDS traffic and barrier -- 0.6 of a staged
+  //  one, measured, not the 0.5 its bytes say; the score head's rows 0.5)
+  const int share[2] = {gen ? 6 : 10, a.nlayer > 1 ? 10 : 0};
+  const int total = share[0] + share[1] + (with3 ? 5 : 0);
+  int used = 0;
+  for (int l = 0; l < a.nlayer; ++l) {
+    int nsplit = cus * share[l] / total / a.E;
+    if (nsplit > ktiles) nsplit = ktiles;
+    if (nsplit < 1) nsplit = 1;
+    a.kt_per_l[l] = (ktiles + nsplit - 1) / nsplit;
+    a.nsplit_l[l] = (ktiles + a.kt_per_l[l] - 1) / a.kt_per_l[l];
+    used += a.E * a.nsplit_l[l];
+  }
+  if (a.nlayer < 2) { a.nsplit_l[1] = 0; a.kt_per_l[1] = 0; }
   a.n3 = 0;
   if (with3) {
-    int n3 = (cus - a.nlayer * a.E * a.nsplit) / a.E;
+    int n3 = (cus - used) / a.E;
     if (n3 < 1) n3 = 1;
     a.rows3 = ((a.rows + n3 - 1) / n3 + 127) / 128 * 128;
     a.n3 = (int)((a.rows + a.rows3 - 1) / a.rows3);
   }
-  hipLaunchKernelGGL(concat_dw_kernel, dim3((unsigned)(a.nlayer * a.E * a.nsplit + a.E * a.n3)), dim3(NT), 0, s, a);
+  hipLaunchKernelGGL(concat_dw_kernel, dim3((unsigned)(used + a.E * a.n3)), dim3(NT), 0, s, a);
   LAUNCH_CHECK();
   return MIMRL_OK;
 }

@@ -55,6 +55,7 @@ struct ConcatBwdArgs {
   __bf16 *dz2, *dz1;                          // [E][B*B][256] bf16 or null (stage 2: no weight gradients)
   float *db1, *db2, *dw3, *db3;               // gradient slots (estimator e at + e*pstride) or null
   int E, B;
+  int no_dz2 = 0;                             // (weights-stationary kernel, stage 1) dZ2 is NOT written: concat_dw regenerates it from ds, w3 and m2
 };
 bool concat_bwd_fused_supported(int B, int hid);
 bool concat_bwd_dq_plan(int E, int B, int* per, int* nwg, int* slots);

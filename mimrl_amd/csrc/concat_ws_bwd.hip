@@ -46,7 +46,8 @@ __device__ __forceinline__ uint32_t pack2(float x, float y) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_));
 }
 
-template <bool WG>
+// DZ2 (stage 1): dZ2 is written out (false: its consumer regenerates it from ds, w3 and the layer-2 sign words -- concat_dw.hip)
+template <bool WG, bool DZ2 = WG>
 __global__ __launch_bounds__(512) void concat_bwd_ws_kernel(ConcatBwdArgs a, int total, int per, int slots, float* __restrict__ dp_part) {
   __shared__ __attribute__((aligned(16))) __bf16 g2[4][UR][AP];     // dZ2 tiles (operand of the W2 product), ring over units
   __shared__ __attribute__((aligned(16))) __bf16 g1[4][UR][AP];     // dZ1 tiles (operand of the W1 product)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512) void concat_bwd_ws_kernel(ConcatBwdArgs a, int
       u32x2 b; b[0] = pack2(vx, vy); b[1] = pack2(vz, vw);
       *reinterpret_cast<u32x2*>(&g2[buf][row][c4]) = b;
       if (WG) {
-        GLOBAL_AS __bf16* o = uptr(a.dz2 + ((long)u.base + row) * CH); *(GLOBAL_AS u32x2*)(o + c4) = b;
+        if constexpr (DZ2) { GLOBAL_AS __bf16* o = uptr(a.dz2 + ((long)u.base + row) * CH); *(GLOBAL_AS u32x2*)(o + c4) = b; }
         sdb.x += vx; sdb.y += vy; sdb.z += vz; sdb.w += vw;
         sds += d;                                        // (every lane holds d: lane 0's sum is the one flushed)
       }
@@ -359,7 +360,8 @@ int concat_bwd_ws(hipStream_t s, const ConcatBwdArgs& a) {
   int total, per, nwg, slots;
   bwd_ws_plan(a.E, a.B, &total, &per, &nwg, &slots);
   float* dp_part = a.dq_part + (long)a.E * (a.B / UR) * slots * UR * CH;
-  if (a.dz2) hipLaunchKernelGGL(concat_bwd_ws_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, s, a, total, per, slots, dp_part);
+  if (a.dz2 && a.no_dz2) hipLaunchKernelGGL((concat_bwd_ws_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, s, a, total, per, slots, dp_part);
+  else if (a.dz2) hipLaunchKernelGGL(concat_bwd_ws_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, s, a, total, per, slots, dp_part);
   else hipLaunchKernelGGL(concat_bwd_ws_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, s, a, total, per, slots, dp_part);
   LAUNCH_CHECK();
   const int nq = a.E * (a.B / UR) * 8, np = (a.E * a.B + 3) / 4;

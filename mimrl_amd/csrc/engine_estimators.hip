@@ -389,6 +389,11 @@ int mimrl_handle::mi_backward(int stage) {
     const long dq_need = concat_bwd_dq_scratch(NE_MI, B);
     const bool dq_in_kernel = dq_knob && dq_need > 0 && dq_need <= (long)NE_MI * B * B * HID;
     if (dq_in_kernel) { fa.dQ = dQ; fa.dq_part = dca[2]; }   // (the partials live in the dz0 buffer they replace)
+    // round 6b: the weights-stationary backward does not write dZ2 when the one-launch weight-gradient kernel will regenerate it
+    static const bool dw_on = knob("MIMRL_NO_CONCAT_DW") == nullptr;   // tuning knob
+    const bool use_dw = wgrad && dw_on && concat_dw_ok(NE_MI, (long)B * B, HID);
+    const bool dz2_regen = use_dw && dq_in_kernel && concat_bwd_ws_supported(B, HID) && !knob_on("MIMRL_CONCAT_STREAMED");
+    fa.no_dz2 = dz2_regen ? 1 : 0;
     MX(concat_bwd_fused(stream, fa));
     const bool side_wg = wgrad && multi_stream && wg_helper >= 0;
     if (wgrad) {   // dW2 = dZ2^T a1, dW1 = dZ1^T a0: K = B*B rows, split-K with atomics, beside pair_reduce_q on the helper stream
@@ -396,14 +401,14 @@ int mimrl_handle::mi_backward(int stage) {
       bool dw3_done = false;
       // round 6: both layers as ONE launch whose workgroups hold a whole 256 x 256 output (concat_dw.hip: every dZ / A row staged once);
       // MIMRL_NO_CONCAT_DW=1: the two split-K GEMMs on 128 x 128 tiles
-      static const bool dw_on = knob("MIMRL_NO_CONCAT_DW") == nullptr;   // tuning knob
-      if (dw_on && concat_dw_ok(NE_MI, (long)B * B, HID)) {
+      if (use_dw) {
         ConcatDwArgs w;
         w.dz[0] = dz2; w.act[0] = reinterpret_cast<const __bf16*>(ca[1]); w.dw[0] = CG(tower0 + tower_l[2][0]);
         w.dz[1] = dz1; w.act[1] = reinterpret_cast<const __bf16*>(ca[0]); w.dw[1] = CG(tower0 + tower_l[1][0]);
         w.nlayer = 2; w.E = NE_MI; w.rows = (long)B * B; w.dw_stride = tower_stride;
         dw3_done = concat_fwd_a2_f16(B, 2);   // the score head's weight gradient rides on the same launch when a2 is the fp16 copy
         if (dw3_done) { w.ds = dscores; w.a2 = reinterpret_cast<const _Float16*>(ca[2]); w.dw3 = CG(tower0 + tower_l[3][0]); }
+        if (dz2_regen) { w.ds = dscores; w.m2 = fa.m2; w.w3 = fa.w3; w.dz[0] = nullptr; }   // dZ2 was never written: regenerated from ds, w3, m2
         MX(concat_dw(dw3_done ? stream : side_wg ? S(wg_helper) : stream, w));
       } else
       for (int l = 2; l >= 1; --l) {

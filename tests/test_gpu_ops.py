@@ -658,15 +658,16 @@ def test_gru_wgrad_one_pass_over_dg(lib, rows, kp):
         assert err <= 3e-6 * scale + 1e-4, f"{name} rows={rows} kp={kp}: max |err| {err} (scale {scale})"
 
 
-@pytest.mark.parametrize("E,rows,two,head", [(3, 4096, True, True), (2, 100, True, True), (5, 16384, True, True), (1, 33, False, False), (2, 65536, True, True),
-                                              (4, 1000, False, True)])
-def test_concat_dw_whole_output_per_workgroup(lib, E, rows, two, head):
+@pytest.mark.parametrize("E,rows,two,head,gen", [(3, 4096, True, True, False), (2, 100, True, True, True), (5, 16384, True, True, True), (1, 33, False, False, False),
+                                                  (2, 65536, True, True, True), (4, 1000, False, True, False), (3, 2050, False, False, True)])
+def test_concat_dw_whole_output_per_workgroup(lib, E, rows, two, head, gen):
     """concat_dw.hip (round 6): the stage-1 weight gradients of the concat critic's hidden layers (VMI.py:58-65 under autograd),
     dW_l[e] [256, 256] += dZ_l[e]^T A_{l-1}[e] over the B*B pair rows, both layers in one launch whose workgroups hold a whole 256 x 256
-    output, operands stored as bf16 -- and, on extra workgroups of the same launch, the score head's dw3[e] [256] += ds[e]^T a2[e] with a2
-    stored as fp16.  Row counts that are not a multiple of the 32-row k-tile, of the ring depth or of the score head's 128-row pass, fewer
-    k-tiles than k-ranges, one layer only, with and without the score head, estimator outputs a stride apart.  Reference: float64 product of
-    the same 16-bit operands; the outputs accumulate (float atomics over the k-split) on top of what they held."""
+    output, operands stored as bf16 -- on extra workgroups of the same launch the score head's dw3[e] [256] += ds[e]^T a2[e] with a2
+    stored as fp16 -- and (gen) dZ2 regenerated inside the kernel from ds, the score head's weight and the layer-2 sign words instead of
+    read.  Row counts that are not a multiple of the 32-row k-tile, of the ring depth or of the score head's 128-row pass, fewer k-tiles
+    than k-ranges, one layer only, with and without the score head, estimator outputs a stride apart.  Reference: float64 product of the
+    same 16-bit operands; the outputs accumulate (float atomics over the k-split) on top of what they held."""
     g = np.random.default_rng(E * 1000 + rows)
     mk = lambda sc: torch.from_numpy(g.standard_normal((E, rows, 256)).astype(np.float32) * sc).to(torch.bfloat16).cuda()
     dz2, a1, dz1, a0 = mk(0.1), mk(0.5), mk(0.1), mk(0.5)
@@ -674,8 +675,19 @@ def test_concat_dw_whole_output_per_workgroup(lib, E, rows, two, head):
     a2 = torch.from_numpy(np.maximum(g.standard_normal((E, rows, 256)), 0).astype(np.float32)).to(torch.float16).cuda()
     stride = 256 * 256 + 1024
     dw2 = torch.full((E, stride), 0.5, device="cuda"); dw1 = torch.full((E, stride), -0.25, device="cuda"); dw3 = torch.full((E, stride), 0.125, device="cuda")
-    _lib.check(lib.mimrl_op_concat_dw(stream(), P(dz2), P(a1), P(dw2), P(dz1) if two else None, P(a0) if two else None, P(dw1) if two else None,
-                                      E, rows, stride, P(ds) if head else None, P(a2) if head else None, P(dw3) if head else None))
+    m2 = w3 = None
+    if gen:   # dZ2 = bf16(ds * w3) under the sign words of a2 (what concat_bwd_ws_kernel computes): the reference product uses exactly that
+        bits = (a2 > 0)
+        wts = (1 << torch.arange(32, device="cuda", dtype=torch.int64))
+        m2 = (bits.reshape(E, rows, 8, 32).to(torch.int64) * wts).sum(-1).to(torch.uint32 if hasattr(torch, "uint32") else torch.int64)
+        m2 = (bits.reshape(E, rows, 8, 32).to(torch.int64) * wts).sum(-1)
+        m2 = torch.where(m2 >= 2 ** 31, m2 - 2 ** 32, m2).to(torch.int32).contiguous()
+        w3 = torch.zeros(E, stride, device="cuda")
+        w3[:, :256] = torch.from_numpy(g.standard_normal((E, 256)).astype(np.float32)).cuda()
+        dz2 = ((ds[:, :, None] * w3[:, None, :256]) * bits).to(torch.bfloat16)
+    _lib.check(lib.mimrl_op_concat_dw(stream(), None if gen else P(dz2), P(a1), P(dw2), P(dz1) if two else None, P(a0) if two else None, P(dw1) if two else None,
+                                      E, rows, stride, P(ds) if (head or gen) else None, P(a2) if head else None, P(dw3) if head else None,
+                                      P(m2) if gen else None, P(w3) if gen else None))
     torch.cuda.synchronize()
     for name, got, dz, act, base, on in (("dW2", dw2, dz2, a1, 0.5, True), ("dW1", dw1, dz1, a0, -0.25, two)):
         ref = torch.einsum("ekm,ekn->emn", dz.double(), act.double()) + base if on else torch.full((E, 256, 256), base, device="cuda", dtype=torch.float64)
