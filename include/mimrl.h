@@ -250,9 +250,12 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
  * dw*[e] dw_stride floats apart; optional third product on the same launch (all three or none): the score head's
  * dw3[e] [256] += ds[e]^T a2[e], ds [E][rows] fp32, a2h [E][rows, 256] STORED as fp16.  With m2 ([E][rows][8] sign words of the
  * layer-2 activation: bit c of word g = column 32 g + c) and w3 (the score head's weight, estimator e at + e * dw_stride) dz2 is NOT read
- * (may be null) but regenerated as bf16(ds[r] * w3[c]) where the bit is set -- needs ds.  The outputs accumulate. */
+ * (may be null) but regenerated as bf16(ds[r] * w3[c]) where the bit is set -- needs ds.  With P, Q ([E][B][256] fp32: the separable first
+ * layer's two projections) and B (rows = B * B, B a multiple of 32) a0 is NOT read (may be null) but regenerated as bf16(relu(P[i] + Q[j]))
+ * for pair row i B + j.  The outputs accumulate. */
 int mimrl_op_concat_dw(void* stream, const void* dz2, const void* a1, float* dw2, const void* dz1, const void* a0, float* dw1, int E, int64_t rows,
-                       int64_t dw_stride, const float* ds, const void* a2h, float* dw3, const uint32_t* m2, const float* w3);
+                       int64_t dw_stride, const float* ds, const void* a2h, float* dw3, const uint32_t* m2, const float* w3, const float* P,
+                       const float* Q, int B);
 int mimrl_op_gru_wgrad(void* stream, const void* const* dg, const void* const* x, const void* const* hp, float* const* dw_ih,
                        float* const* dw_hh, int64_t rows, int kp);
 int mimrl_op_mi_bound(void* stream, const float* scores, float* dscores, float* mi, const float* gscale, int E, int B,

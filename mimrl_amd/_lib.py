@@ -111,7 +111,7 @@ def load() -> C.CDLL:
                                   C.c_float, C.c_float]
     lib.mimrl_op_gru_forward.argtypes = [_FP] * 11 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_gru_backward.argtypes = [_FP] * 12 + [C.c_int, C.c_int, C.c_int]
-    lib.mimrl_op_concat_dw.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 5
+    lib.mimrl_op_concat_dw.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int64, C.c_int64] + [C.c_void_p] * 7 + [C.c_int]
     lib.mimrl_op_gru_wgrad.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.c_int64, C.c_int]
     lib.mimrl_op_mi_bound.argtypes = [_FP] * 5 + [C.c_int, C.c_int, C.c_int]
     lib.mimrl_op_mi_bound_ex.argtypes = [_FP] * 6 + [C.c_int, C.c_int, C.c_int, C.c_uint32]

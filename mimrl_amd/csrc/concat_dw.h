@@ -19,6 +19,9 @@ struct ConcatDwArgs {
   // optional: dz[0] is NOT read but regenerated (concat_dw.hip: GEN) from ds, the layer-2 sign words m2 [E][rows][8] (bit c of word g = sign of
   // column 32 g + c) and the score head's weight w3 (estimator e at + e * dw_stride); needs ds
   const uint32_t* m2 = nullptr; const float* w3 = nullptr;
+  // optional: act[1] (a0) is NOT read but regenerated as bf16(relu(P[i] + Q[j])) for pair row i B + j from the separable first layer's two
+  // projections P, Q [E][B][256] fp32 (ConcatFwdArgs); rows must be B * B, B a multiple of 32
+  const float* P = nullptr; const float* Q = nullptr; int B = 0;
   int nsplit_l[2] = {0, 0}, kt_per_l[2] = {0, 0}, n3 = 0; long rows3 = 0;   // filled by concat_dw(): k-ranges per estimator of each layer, k-tiles each; dw3 workgroups per estimator, rows each
 };
 bool concat_dw_ok(int E, long rows, int hid);

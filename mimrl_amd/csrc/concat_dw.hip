@@ -63,13 +63,27 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* img, int fo, int col, int s
 // GEN (layer 2 only): the dZ2 tile is not loaded but regenerated -- dZ2[r][c] = bf16(ds[r] * w3[c]) where bit c of the layer-2 sign words is
 // set, exactly what concat_bwd_ws_kernel computes for its own product (concat_ws_bwd.hip: gen_finish) and, until this round, also wrote out:
 // 168 MB less to write there and to read here per critic pass at cfg3.  Per piece (row, 8 columns): one sign word + one ds value.
-template <bool GEN>
-__device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e, int kt0, int kt1, __bf16* sA, __bf16* sB) {
+// MODE 2 (layer 1 only): the A_0 tile is regenerated instead -- a0[i B + j][c] = bf16(relu(P[i][c] + Q[j][c])), the separable first layer exactly
+// as the forward kernel generates it (concat_ws.hip: gen_finish), which then does not save it (ConcatFwdArgs::save == 4).  As the rows are
+// ordered a k-tile is one i and 32 consecutive j: the workgroup walks its k-tiles j-BLOCK-major (tile t -> j block t / B, i = t % B), keeps
+// the block's 32 Q rows in LDS (reloaded when the block changes: at most once or twice per workgroup) and stages ONE P row per k-tile.
+template <int MODE>
+__device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e, int kt0, int kt1, __bf16* sA, __bf16* sB, float* sQ) {
+  constexpr bool GEN = MODE == 1, GA0 = MODE == 2;
   constexpr int NLD = GEN ? 6 : NL;    // load instructions per thread and k-tile
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
   const long rows = a.rows;
   const __bf16* __restrict__ dz = a.dz[layer] + (long)e * rows * CH;
-  const __bf16* __restrict__ act = a.act[layer] + (long)e * rows * CH;
+  const __bf16* __restrict__ act = GA0 ? nullptr : a.act[layer] + (long)e * rows * CH;
+  [[maybe_unused]] const float* __restrict__ Pe = GA0 ? a.P + (long)e * a.B * CH : nullptr;
+  [[maybe_unused]] const float* __restrict__ Qe = GA0 ? a.Q + (long)e * a.B * CH : nullptr;
+  [[maybe_unused]] const int Bn = a.B;
+  [[maybe_unused]] int cur_jb = -1;
+  // first pair row of k-tile t
+  auto row0 = [&](int t) __attribute__((always_inline)) -> long {
+    if constexpr (GA0) { const int jb = t / Bn, i = t - jb * Bn; return (long)i * Bn + (long)jb * KT; }
+    else return (long)t * KT;
+  };
   float* __restrict__ out = a.dw[layer] + (long)e * a.dw_stride;
   const int last = kt1 - 1;
 
@@ -107,8 +121,15 @@ __device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e
   // load number `idx` of set jj: tile kt (clamped to the range's last tile; rows past the end re-read the last row)
   auto request_one = [&](auto J, auto IDX, int kt) __attribute__((always_inline)) {
     constexpr int jj = decltype(J)::value, i = decltype(IDX)::value;
-    const long k0 = (long)(kt < last ? kt : last) * KT;
-    if constexpr (GEN) {
+    const int tc = kt < last ? kt : last;
+    const long k0 = row0(tc);
+    if constexpr (GA0) {
+      constexpr int h = i & 1;
+      if constexpr (i < 2) {
+        const long r = k0 + rp[h] < rows ? k0 : rows - 1 - rp[h];
+        gld16(rg[jj][i], dz + r * CH + gp[h]);
+      } else gld16(rg[jj][i], Pe + (long)(tc % Bn) * CH + 8 * chn + 4 * h);   // the k-tile's P row: this thread's 8 columns, two quads
+    } else if constexpr (GEN) {
       if constexpr (i < 4) {
         constexpr int h = i >> 1;
         const long r = (k0 + rp[h] < rows ? k0 : rows - 1 - rp[h]) + rp[h];
@@ -134,7 +155,21 @@ __device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e
   auto publish = [&](auto J, int buf, int kt) __attribute__((always_inline)) {
     constexpr int jj = decltype(J)::value;
     const bool live = kt <= last;
-    const long k0 = (long)(live ? kt : last) * KT;
+    const int tc = live ? kt : last;
+    const long k0 = row0(tc);
+    if constexpr (GA0) {   // the j block's Q rows -> LDS when the block changes (block-uniform; the loads are the compiler's own, waited for here)
+      const int jb = tc / Bn;
+      if (jb != cur_jb) {
+        cur_jb = jb;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int idx = tid + NT * k, row = idx >> 6, c4 = idx & 63;
+          *reinterpret_cast<float4*>(sQ + row * CH + 4 * c4) = *reinterpret_cast<const float4*>(Qe + ((long)jb * KT + row) * CH + 4 * c4);
+        }
+        __syncthreads();
+      }
+    }
     wait_set(J, std::integral_constant<int, (FPF - 1) * NLD>{});
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     __bf16* A = sA + buf * (KT * PI);
@@ -153,7 +188,18 @@ __device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e
       *reinterpret_cast<f32x4*>(A + lp[i]) = live && k0 + rp[i] < rows ? piece : z;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Bm + lp[i]) = rg[jj][2 + i];
+    for (int i = 0; i < 2; ++i) {
+      f32x4 piece;
+      if constexpr (GA0) {
+        const float4 q0 = *reinterpret_cast<const float4*>(sQ + rp[i] * CH + 8 * chn), q1 = *reinterpret_cast<const float4*>(sQ + rp[i] * CH + 8 * chn + 4);
+        const f32x4 p0 = rg[jj][2], p1 = rg[jj][3];
+        bf16x8 v;
+        v[0] = to_bf16(fmaxf(p0[0] + q0.x, 0.f)); v[1] = to_bf16(fmaxf(p0[1] + q0.y, 0.f)); v[2] = to_bf16(fmaxf(p0[2] + q0.z, 0.f)); v[3] = to_bf16(fmaxf(p0[3] + q0.w, 0.f));
+        v[4] = to_bf16(fmaxf(p1[0] + q1.x, 0.f)); v[5] = to_bf16(fmaxf(p1[1] + q1.y, 0.f)); v[6] = to_bf16(fmaxf(p1[2] + q1.z, 0.f)); v[7] = to_bf16(fmaxf(p1[3] + q1.w, 0.f));
+        piece = __builtin_bit_cast(f32x4, v);
+      } else piece = rg[jj][2 + i];
+      *reinterpret_cast<f32x4*>(Bm + lp[i]) = piece;
+    }
   };
   static_for<0, FPF>([&](auto J) __attribute__((always_inline)) {
     static_for<0, NLD>([&](auto IDX) __attribute__((always_inline)) { request_one(J, IDX, kt0 + decltype(J)::value); });
@@ -207,6 +253,7 @@ __device__ __forceinline__ void products(const ConcatDwArgs& a, int layer, int e
 __global__ __launch_bounds__(NT) void concat_dw_kernel(ConcatDwArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 sA[2 * KT * PI];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2 * KT * PI];
+  __shared__ __attribute__((aligned(16))) float sQ[KT * CH];   // the j block's Q rows (regenerated a0 only)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
   // workgroup -> (layer, estimator, k-range) | (score head: estimator, row range)
   const int n0 = a.E * a.nsplit_l[0], n1 = a.nlayer > 1 ? a.E * a.nsplit_l[1] : 0;
@@ -248,8 +295,9 @@ __global__ __launch_bounds__(NT) void concat_dw_kernel(ConcatDwArgs a) {
   const int kt0 = split * a.kt_per_l[layer];
   const int kt1 = kt0 + a.kt_per_l[layer] < ktiles ? kt0 + a.kt_per_l[layer] : ktiles;
   if (kt0 >= kt1) return;
-  if (layer == 0 && a.m2) products<true>(a, layer, e, kt0, kt1, sA, sB);
-  else products<false>(a, layer, e, kt0, kt1, sA, sB);
+  if (layer == 0 && a.m2) products<1>(a, layer, e, kt0, kt1, sA, sB, sQ);
+  else if (layer == 1 && a.P) products<2>(a, layer, e, kt0, kt1, sA, sB, sQ);
+  else products<0>(a, layer, e, kt0, kt1, sA, sB, sQ);
 }
 
 }  // namespace
@@ -270,7 +318,11 @@ int concat_dw(hipStream_t s, const ConcatDwArgs& in) {
   const int cus = device_cus();
   // (shares in tenths of a full product's: a k-tile whose dZ is regenerated still costs its MFMAs, LDS traffic and barrier -- 0.6 of a staged
   //  one, measured, not the 0.5 its bytes say; the score head's rows 0.5)
-  const int share[2] = {gen ? 6 : 10, a.nlayer > 1 ? 10 : 0};
+  const bool gen0 = a.P != nullptr;
+  if (gen0 && !(a.Q && a.nlayer == 2 && a.B >= KT && a.B % KT == 0 && (long)a.B * a.B == a.rows))
+    return set_error(MIMRL_ERR_ARG, "concat_dw: regenerating a0 needs P, Q, two layers and rows = B * B with B a multiple of 32");
+  if (!gen0 && a.nlayer > 1 && !a.act[1]) return set_error(MIMRL_ERR_ARG, "concat_dw: null a0");
+  const int share[2] = {gen ? 6 : 10, a.nlayer > 1 ? (gen0 ? 6 : 10) : 0};
   const int total = share[0] + share[1] + (with3 ? 5 : 0);
   int used = 0;
   for (int l = 0; l < a.nlayer; ++l) {

@@ -29,6 +29,7 @@ struct ConcatFwdArgs {
   __bf16 *a0b, *a1b;                          // [E][B*B][256] bf16 (save == 2)
   uint32_t *m0, *m1, *m2;                     // [E][B*B][8]        (save == 2, 3): bit c of word [row][g] = sign of column 32 g + c
   float* scores;                              // [E][B*B]   row p = i*B + j
+  int no_a0 = 0;                              // (weights-stationary kernel, save == 2) a0b is NOT written: concat_dw regenerates it from P and Q
   int E, B;
 };
 bool concat_fwd_fused_supported(int B, int hid);

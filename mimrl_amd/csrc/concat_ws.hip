@@ -46,7 +46,8 @@ __device__ long long g_ws_clk[2];   // shader-clock cycles / 100 MHz ticks of wo
 //   layer-2 wave:  epilogue of unit t - 3 (the accumulators of its last product) | layer 0 of unit t + 2 from the loads it requested in
 //                  iteration t - 1 | P / Q loads of unit t + 3 | product of unit t - 2
 //   all waves:     stage 1: act1 of unit t - 2 leaves as bf16;  wave 0: scores of unit t - 5
-template <int SAVE>
+// A0 (SAVE == 2): the bf16 copy of the generated layer 0 is written out (false: its consumer regenerates it from P and Q -- concat_dw.hip)
+template <int SAVE, bool A0 = true>
 __global__ __launch_bounds__(512) void concat_fwd_ws_kernel(ConcatFwdArgs a, int units_e, int total, int per) {
 #ifdef WS_PHASE
   const long long clk0 = (long long)clock64(), wall0 = (long long)wall_clock64();
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512) void concat_fwd_ws_kernel(ConcatFwdArgs a, int
       typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
       u32x2 b; b[0] = bq[q][0]; b[1] = bq[q][1];
       *reinterpret_cast<u32x2*>(&act0[buf][row][c4]) = b;
-      if (SAVE == 2) { GLOBAL_AS __bf16* o = uptr(a.a0b + ((long)u.base + row) * CH); *(GLOBAL_AS u32x2*)(o + c4) = b; }
+      if (SAVE == 2 && A0) { GLOBAL_AS __bf16* o = uptr(a.a0b + ((long)u.base + row) * CH); *(GLOBAL_AS u32x2*)(o + c4) = b; }
       if (SAVE >= 2) { GLOBAL_AS uint32_t* o = uptr(a.m0 + ((long)u.base + row) * 8); o[lane8] = nq[q]; }
     }
   };
@@ -369,6 +370,7 @@ int concat_fwd_ws(hipStream_t s, const ConcatFwdArgs& a) {
   const int nwg0 = std::min(device_cus(), total), per = (total + nwg0 - 1) / nwg0, nwg = (total + per - 1) / per;
   const dim3 grid((unsigned)nwg);
   if (a.save == 0) hipLaunchKernelGGL(concat_fwd_ws_kernel<0>, grid, dim3(512), 0, s, a, units_e, total, per);
+  else if (a.save == 2 && a.no_a0) hipLaunchKernelGGL((concat_fwd_ws_kernel<2, false>), grid, dim3(512), 0, s, a, units_e, total, per);
   else if (a.save == 2) hipLaunchKernelGGL(concat_fwd_ws_kernel<2>, grid, dim3(512), 0, s, a, units_e, total, per);
   else hipLaunchKernelGGL(concat_fwd_ws_kernel<3>, grid, dim3(512), 0, s, a, units_e, total, per);
   LAUNCH_CHECK();

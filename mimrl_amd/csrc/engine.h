@@ -206,6 +206,7 @@ struct mimrl_handle {
   int KP() const { return ((cfg.d_a > cfg.d_v ? cfg.d_a : cfg.d_v) + 15) & ~15; }
   bool dg_bf16 = false;                // BPTT outputs dg / h_prev stored as bf16 (GRU encoders, bf16 recurrence + bf16 backward GEMMs; MIMRL_DG_FP32=1: off)
   bool concat_compact = false;         // the last concat forward saved bitmasks (+ bf16 values) for the fused backward, not fp32 activations
+  bool a0_regen_live = false;         // stage 1's concat forward did not save a0 (round 6b): concat_dw regenerates it from P and Q
   bool fused_concat = true;            // concat critic forward as one launch (concat_fused.hip); MIMRL_NO_FUSED_CONCAT=1 at create time
   bool l0_packed = false;              // see mimrl_create
   bool l0_bwd_pack = false;            // small batches: only the INPUTS are packed (off the chain) and only the weight gradients use them

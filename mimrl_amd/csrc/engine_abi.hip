@@ -603,15 +603,16 @@ int mimrl_op_gru_backward(void* stream, const float* whh_f, const float* whh_r, 
 }
 
 int mimrl_op_concat_dw(void* stream, const void* dz2, const void* a1, float* dw2, const void* dz1, const void* a0, float* dw1, int E, int64_t rows,
-                       int64_t dw_stride, const float* ds, const void* a2h, float* dw3, const uint32_t* m2, const float* w3) {
+                       int64_t dw_stride, const float* ds, const void* a2h, float* dw3, const uint32_t* m2, const float* w3, const float* P,
+                       const float* Q, int B) {
   if ((!dz2 && !m2) || !a1 || !dw2) return set_error(MIMRL_ERR_ARG, "mimrl_op_concat_dw: null argument");
-  if ((dz1 != nullptr) != (a0 != nullptr) || (dz1 != nullptr) != (dw1 != nullptr)) return set_error(MIMRL_ERR_ARG, "mimrl_op_concat_dw: the second layer comes as a set");
+  if ((dz1 != nullptr) != (a0 != nullptr || P != nullptr) || (dz1 != nullptr) != (dw1 != nullptr)) return set_error(MIMRL_ERR_ARG, "mimrl_op_concat_dw: the second layer comes as a set");
   if (!concat_dw_ok(E, rows, 256)) return set_error(MIMRL_ERR_ARG, "mimrl_op_concat_dw: E >= 1, rows >= 1");
   ConcatDwArgs a;
   a.dz[0] = static_cast<const __bf16*>(dz2); a.act[0] = static_cast<const __bf16*>(a1); a.dw[0] = dw2;
   a.dz[1] = static_cast<const __bf16*>(dz1); a.act[1] = static_cast<const __bf16*>(a0); a.dw[1] = dw1;
   a.nlayer = dz1 ? 2 : 1; a.E = E; a.rows = rows; a.dw_stride = dw_stride;
-  a.ds = ds; a.a2 = static_cast<const _Float16*>(a2h); a.dw3 = dw3; a.m2 = m2; a.w3 = w3;
+  a.ds = ds; a.a2 = static_cast<const _Float16*>(a2h); a.dw3 = dw3; a.m2 = m2; a.w3 = w3; a.P = P; a.Q = Q; a.B = B;
   return concat_dw(reinterpret_cast<hipStream_t>(stream), a);
 }
 

@@ -261,9 +261,18 @@ int mimrl_handle::mi_forward(int stage, bool want_grad) {
       // sign bitmasks: m1 behind the bf16 a1, m0 and m2 behind the bf16 a0 (in stage 1 the fp32 a2 fills its own buffer)
       fa.m1 = reinterpret_cast<uint32_t*>(ca[1] + half);
       fa.m0 = reinterpret_cast<uint32_t*>(ca[0] + half); fa.m2 = fa.m0 + (size_t)NE_MI * B * B * 8;
+      // round 6b: stage 1 does not save a0 when the one-launch weight-gradient kernel will regenerate it from P and Q (the same conditions
+      // under which mi_backward routes there: concat_dw on, weights-stationary kernels with the in-kernel dQ reduction)
+      {
+        const long dq_need = concat_bwd_dq_scratch(NE_MI, B);
+        a0_regen_live = fa.save == 2 && knob("MIMRL_NO_CONCAT_DW") == nullptr && knob("MIMRL_NO_CONCAT_DQ") == nullptr &&
+                        concat_dw_ok(NE_MI, (long)B * B, HID) && concat_fwd_a2_f16(B, 2) && concat_bwd_ws_supported(B, HID) &&
+                        dq_need > 0 && dq_need <= (long)NE_MI * B * B * HID;
+        fa.no_a0 = a0_regen_live ? 1 : 0;
+      }
       MX(concat_fwd_fused(stream, fa));
     } else {
-      concat_compact = false;
+      concat_compact = false; a0_regen_live = false;
       MX(pair_expand_fwd(stream, cP, cQ, ca[0], NE_MI, B, HID));
       const int dims[4] = {HID, HID, HID, 1};
       MX(mlp_stack_forward(NE_MI, B * B, B * B, tower0, tower_stride, 3, &tower_l[1], dims, ca[0], &ca[1], scores));
@@ -394,6 +403,7 @@ int mimrl_handle::mi_backward(int stage) {
     const bool use_dw = wgrad && dw_on && concat_dw_ok(NE_MI, (long)B * B, HID);
     const bool dz2_regen = use_dw && dq_in_kernel && concat_bwd_ws_supported(B, HID) && !knob_on("MIMRL_CONCAT_STREAMED");
     fa.no_dz2 = dz2_regen ? 1 : 0;
+    if (wgrad && a0_regen_live && !dz2_regen) return set_error(MIMRL_ERR_STATE, "mi_backward: the forward pass did not save a0 but the one-launch weight-gradient kernel is off");
     MX(concat_bwd_fused(stream, fa));
     const bool side_wg = wgrad && multi_stream && wg_helper >= 0;
     if (wgrad) {   // dW2 = dZ2^T a1, dW1 = dZ1^T a0: K = B*B rows, split-K with atomics, beside pair_reduce_q on the helper stream
@@ -409,6 +419,7 @@ int mimrl_handle::mi_backward(int stage) {
         dw3_done = concat_fwd_a2_f16(B, 2);   // the score head's weight gradient rides on the same launch when a2 is the fp16 copy
         if (dw3_done) { w.ds = dscores; w.a2 = reinterpret_cast<const _Float16*>(ca[2]); w.dw3 = CG(tower0 + tower_l[3][0]); }
         if (dz2_regen) { w.ds = dscores; w.m2 = fa.m2; w.w3 = fa.w3; w.dz[0] = nullptr; }   // dZ2 was never written: regenerated from ds, w3, m2
+        if (a0_regen_live) { w.P = cP; w.Q = cQ; w.B = B; w.act[1] = nullptr; }             // a0 was never written: regenerated from P, Q
         MX(concat_dw(dw3_done ? stream : side_wg ? S(wg_helper) : stream, w));
       } else
       for (int l = 2; l >= 1; --l) {

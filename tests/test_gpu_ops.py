@@ -687,7 +687,7 @@ def test_concat_dw_whole_output_per_workgroup(lib, E, rows, two, head, gen):
         dz2 = ((ds[:, :, None] * w3[:, None, :256]) * bits).to(torch.bfloat16)
     _lib.check(lib.mimrl_op_concat_dw(stream(), None if gen else P(dz2), P(a1), P(dw2), P(dz1) if two else None, P(a0) if two else None, P(dw1) if two else None,
                                       E, rows, stride, P(ds) if (head or gen) else None, P(a2) if head else None, P(dw3) if head else None,
-                                      P(m2) if gen else None, P(w3) if gen else None))
+                                      P(m2) if gen else None, P(w3) if gen else None, None, None, 0))
     torch.cuda.synchronize()
     for name, got, dz, act, base, on in (("dW2", dw2, dz2, a1, 0.5, True), ("dW1", dw1, dz1, a0, -0.25, two)):
         ref = torch.einsum("ekm,ekn->emn", dz.double(), act.double()) + base if on else torch.full((E, 256, 256), base, device="cuda", dtype=torch.float64)
@@ -700,3 +700,38 @@ def test_concat_dw_whole_output_per_workgroup(lib, E, rows, two, head, gen):
     err = (dw3[:, :256].double() - ref3).abs().max().item()
     assert err <= 3e-6 * ref3.abs().max().item() + 1e-5 * math.sqrt(rows), f"dw3 E={E} rows={rows}: max |err| {err}"
     assert torch.all(dw3[:, 256:] == 0.125), "dw3: wrote past its 256 floats"
+
+
+@pytest.mark.parametrize("E,B", [(2, 32), (3, 96), (5, 128), (2, 256)])
+def test_concat_dw_regenerates_the_separable_first_layer(lib, E, B):
+    """concat_dw.hip, a0 regenerated (round 6b): dW1[e] += dZ1[e]^T a0[e] with a0[i B + j] = bf16(relu(P[i] + Q[j])) generated inside the kernel
+    from the separable first layer's projections (VMI.py:59-65: the first Linear of f([x_i | y_j]) splits into W0x x_i + (W0y y_j + b0)) --
+    the workgroups walk their k-tiles j-block-major with the block's Q rows in LDS; together with the regenerated dZ2 and the score head in
+    the same launch (the engine's configuration).  Batch sizes with one, three, four and eight j blocks; reference: float64 product of the
+    bf16 a0 the forward kernel would have saved."""
+    g = np.random.default_rng(E * 100 + B)
+    rows = B * B
+    mk = lambda sc: torch.from_numpy(g.standard_normal((E, rows, 256)).astype(np.float32) * sc).to(torch.bfloat16).cuda()
+    a1, dz1 = mk(0.5), mk(0.1)
+    Pm = torch.from_numpy(g.standard_normal((E, B, 256)).astype(np.float32)).cuda()
+    Qm = torch.from_numpy(g.standard_normal((E, B, 256)).astype(np.float32)).cuda()
+    a0 = torch.relu(Pm[:, :, None, :] + Qm[:, None, :, :]).to(torch.bfloat16).reshape(E, rows, 256)
+    ds = torch.from_numpy(g.standard_normal((E, rows)).astype(np.float32) * 0.01).cuda()
+    a2 = torch.from_numpy(np.maximum(g.standard_normal((E, rows, 256)), 0).astype(np.float32)).to(torch.float16).cuda()
+    bits = a2 > 0
+    wts = 1 << torch.arange(32, device="cuda", dtype=torch.int64)
+    m2 = (bits.reshape(E, rows, 8, 32).to(torch.int64) * wts).sum(-1)
+    m2 = torch.where(m2 >= 2 ** 31, m2 - 2 ** 32, m2).to(torch.int32).contiguous()
+    stride = 256 * 256
+    w3 = torch.zeros(E, stride, device="cuda"); w3[:, :256] = torch.from_numpy(g.standard_normal((E, 256)).astype(np.float32)).cuda()
+    dz2 = ((ds[:, :, None] * w3[:, None, :256]) * bits).to(torch.bfloat16)
+    dw2 = torch.zeros(E, stride, device="cuda"); dw1 = torch.zeros(E, stride, device="cuda"); dw3 = torch.zeros(E, stride, device="cuda")
+    _lib.check(lib.mimrl_op_concat_dw(stream(), None, P(a1), P(dw2), P(dz1), None, P(dw1), E, rows, stride, P(ds), P(a2), P(dw3), P(m2), P(w3), P(Pm), P(Qm), B))
+    torch.cuda.synchronize()
+    for name, got, dz, act in (("dW2", dw2, dz2, a1), ("dW1", dw1, dz1, a0)):
+        ref = torch.einsum("ekm,ekn->emn", dz.double(), act.double())
+        err = (got.reshape(E, 256, 256).double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= 3e-6 * scale + 1e-4, f"{name} E={E} B={B}: max |err| {err} (scale {scale})"
+    ref3 = torch.einsum("ek,ekn->en", ds.double(), a2.double())
+    assert (dw3[:, :256].double() - ref3).abs().max().item() <= 3e-6 * ref3.abs().max().item() + 1e-5 * B

@@ -19,16 +19,21 @@ a2 = torch.relu(torch.randn(E, rows, 256, device="cuda", generator=g)).to(torch.
 S = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 def one():
-    _lib.check(lib.mimrl_op_concat_dw(S, P(dz2), P(a1), P(dw2), P(dz1), P(a0), P(dw1), E, rows, 65536, None, None, None, None, None))
+    _lib.check(lib.mimrl_op_concat_dw(S, P(dz2), P(a1), P(dw2), P(dz1), P(a0), P(dw1), E, rows, 65536, None, None, None, None, None, None, None, 0))
 
 def one3():
-    _lib.check(lib.mimrl_op_concat_dw(S, P(dz2), P(a1), P(dw2), P(dz1), P(a0), P(dw1), E, rows, 65536, P(ds), P(a2), P(dw3), None, None))
+    _lib.check(lib.mimrl_op_concat_dw(S, P(dz2), P(a1), P(dw2), P(dz1), P(a0), P(dw1), E, rows, 65536, P(ds), P(a2), P(dw3), None, None, None, None, 0))
 
 m2 = torch.randint(-2 ** 31, 2 ** 31 - 1, (E, rows, 8), device="cuda", dtype=torch.int32, generator=g)
 w3 = torch.randn(E, 65536, device="cuda", generator=g)
 
 def one3g():
-    _lib.check(lib.mimrl_op_concat_dw(S, None, P(a1), P(dw2), P(dz1), P(a0), P(dw1), E, rows, 65536, P(ds), P(a2), P(dw3), P(m2), P(w3)))
+    _lib.check(lib.mimrl_op_concat_dw(S, None, P(a1), P(dw2), P(dz1), P(a0), P(dw1), E, rows, 65536, P(ds), P(a2), P(dw3), P(m2), P(w3), None, None, 0))
+
+Pm = torch.randn(E, B, 256, device="cuda", generator=g); Qm = torch.randn(E, B, 256, device="cuda", generator=g)
+
+def one3ga():
+    _lib.check(lib.mimrl_op_concat_dw(S, None, P(a1), P(dw2), P(dz1), None, P(dw1), E, rows, 65536, P(ds), P(a2), P(dw3), P(m2), P(w3), P(Pm), P(Qm), B))
 
 def gemm(A, Bm, Cm):
     K = rows
@@ -52,6 +57,6 @@ one(); torch.cuda.synchronize(); r = (dw2.clone(), dw1.clone()); dw2.zero_(); dw
 pair(); torch.cuda.synchronize()
 print("max |one launch - GEMM pair|: dW2 %.3e (scale %.3e)  dW1 %.3e (scale %.3e)" % ((r[0] - dw2).abs().max().item(), dw2.abs().max().item(), (r[1] - dw1).abs().max().item(), dw1.abs().max().item()))
 by = 4 * E * rows * 256 * 2
-for name, fn in (("one launch (concat_dw)", one), ("two split-K GEMMs", pair), ("one launch (concat_dw)", one), ("one launch + score head", one3), ("  ... + dZ2 regenerated", one3g)):
+for name, fn in (("one launch (concat_dw)", one), ("two split-K GEMMs", pair), ("one launch (concat_dw)", one), ("one launch + score head", one3), ("  ... + dZ2 regenerated", one3g), ("  ... + a0 regenerated", one3ga)):
     us = timed(fn)
     print("%-24s %8.1f us   %.2f TB/s of the %.0f MB of operands" % (name, us, by / us / 1e6, by / 1e6))
