@@ -420,7 +420,7 @@ int mimrl_handle::mi_backward(int stage) {
         if (dw3_done) { w.ds = dscores; w.a2 = reinterpret_cast<const _Float16*>(ca[2]); w.dw3 = CG(tower0 + tower_l[3][0]); }
         if (dz2_regen) { w.ds = dscores; w.m2 = fa.m2; w.w3 = fa.w3; w.dz[0] = nullptr; }   // dZ2 was never written: regenerated from ds, w3, m2
         if (a0_regen_live) { w.P = cP; w.Q = cQ; w.B = B; w.act[1] = nullptr; }             // a0 was never written: regenerated from P, Q
-        MX(concat_dw(dw3_done ? stream : side_wg ? S(wg_helper) : stream, w));
+        MX(concat_dw(side_wg ? S(wg_helper) : stream, w));   // (beside the layer-0 weight gradients and bias sums below, which need dP / dQ only)
       } else
       for (int l = 2; l >= 1; --l) {
         GemmDesc g;
