@@ -335,13 +335,6 @@ def extra_schedules(eng, args, B, T, rank):
         finally:
             os.environ.pop("MIMRL_DDP_SPLIT", None)
         eng.set_stage2_prefetch(True)
-    # Epoch schedule (the reference's OWN ordering, Solver.py:200-242: a full pass of critic updates over the loader with the main model
-    # frozen, then one model pass): pairs of (stage-1 update, stage-2 update) per second through Solver.train on fresh device-resident batches,
-    # stage1_n = 1 -- the default (sequential passes) and with the next batch's forward pass beside each critic update (round 6: mimrl_stage1_pipe, opt-in)
-    try:
-        extra.update(epoch_schedule(args, B, T))
-    except Exception as e:      # noqa: BLE001 -- optional figure
-        extra["epoch_schedule_error"] = repr(e)[:200]
     host = [tuple(torch.from_numpy(x).pin_memory() for x in synth.synthetic_batch(B, T, seed=100 + i)) for i in range(4)]
     state = {"i": 0}
     eng.stage_batch(*host[0])
@@ -358,6 +351,15 @@ def extra_schedules(eng, args, B, T, rank):
                                  "the host waits for the idle set (one step of run-ahead).  tools/fresh_variants.py: on a normal-priority "
                                  "stream the step queued behind the upload (1.47-1.63 ms)")
     torch.cuda.synchronize()
+    # (LAST in this process: it creates and closes two more engines -- the copy stream above must get its hardware queue first; measured
+    #  in front of it the fresh-batch figure read 1.08-1.10 instead of 0.88 ms)
+    # Epoch schedule (the reference's OWN ordering, Solver.py:200-242: a full pass of critic updates over the loader with the main model
+    # frozen, then one model pass): pairs of (stage-1 update, stage-2 update) per second through Solver.train on fresh device-resident batches,
+    # stage1_n = 1 -- the default (sequential passes) and with the next batch's forward pass beside each critic update (round 6: mimrl_stage1_pipe, opt-in)
+    try:
+        extra.update(epoch_schedule(args, B, T))
+    except Exception as e:      # noqa: BLE001 -- optional figure
+        extra["epoch_schedule_error"] = repr(e)[:200]
     return extra
 
 
